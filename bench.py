@@ -1,0 +1,175 @@
+"""Headline benchmark: SDE steps/sec (batch x timesteps / sec) of the fixed-step hot path.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One bench "step" = one full solve of the workload: BASELINE.json configs[1], diagonal-noise Ito
+Euler-Maruyama, batch 65536 x state 64, 1000 fixed solver steps (dyadic dt = 2^-10 so the count is exact
+in float32), geometric Brownian motion f = mu*y, g = sigma*y as user torch code, Brownian increments
+generated in registers by the fused step kernel. Inputs are resident in HBM before the timed region.
+N > 1: every rank solves its own 65536 rows (weak scaling; RNG rows are global, so results are the rows an
+unsharded run would produce) and the final states are all-gathered once per solve over RCCL.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: tsde_step_diag; algorithmic bytes per launch
+= 16*d bytes per trajectory-step x batch = 4 streams x B*d*4 B, over the kernel's average duration measured
+with HIP events inside the library) and `cpu_baseline` (the oracle's port of the reference's CPU algorithm,
+timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (problem, method, levy, B, d, solver steps, dt, algorithmic bytes per trajectory-step, kernel id)
+    "c2_euler_diag_b65536_d64_s1000": dict(problem="gbm_ito", method="euler", levy="none", B=65536, d=64,
+                                           nsteps=1000, dt=2.0 ** -10, bytes_per_traj_step=16 * 64, kid=1,
+                                           launches_per_step=1),
+}
+
+
+def _cpu_baseline(cfg, budget_s=20.0):
+    """The oracle's restatement of the reference CPU path (tree-based BrownianInterval + Euler loop), timed on
+    this host with all cores on a bounded number of solver steps of the same workload."""
+    try:
+        from oracle import brownian_ref, solvers_ref
+    except Exception as e:  # oracle piece missing: report, don't fake
+        return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"unavailable: {e}"}
+    from tests import problems
+    torch.set_num_threads(os.cpu_count() or 1)
+    B, d, dt = cfg["B"], cfg["d"], cfg["dt"]
+    sde = problems.make(cfg["problem"], d=d)
+    y0 = torch.full((B, d), 0.1)
+    t1 = cfg["nsteps"] * dt
+    bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, d), dtype=torch.float32, entropy=20240601,
+                                          dt=dt, levy_area_approximation=cfg["levy"])
+    n = 0
+    y = y0
+    t = torch.tensor(0.0)
+    step = solvers_ref.STEPS[cfg["method"]]
+    start = time.perf_counter()
+    with torch.no_grad():
+        while n < cfg["nsteps"]:
+            t_next = t + dt
+            y = step(sde, bm, t, t_next, y)
+            t = t_next
+            n += 1
+            if n >= 8 and time.perf_counter() - start > budget_s:
+                break
+    el = time.perf_counter() - start
+    return {"value": B * n / el, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}), "
+                      f"{el:.1f} s, torch CPU ops with {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2_euler_diag_b65536_d64_s1000")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import torchsde_amd
+    from torchsde_amd import kernels as K
+    from tests import problems
+
+    cfg = WORKLOADS[args.workload]
+    B, d, nsteps, dt = cfg["B"], cfg["d"], cfg["nsteps"], cfg["dt"]
+    sde = problems.make(cfg["problem"], d=d).to(dev)
+    y0 = torch.full((B, d), 0.1, device=dev)
+    ts = torch.tensor([0.0, nsteps * dt], device=dev)
+    gathered = torch.empty((world * B, d), device=dev) if world > 1 else None
+
+    def one_solve(i):
+        bm = torchsde_amd.BrownianInterval(t0=0.0, t1=nsteps * dt, size=(B, d), dtype=torch.float32, device=dev,
+                                           entropy=20240601 + i, dt=dt, levy_area_approximation=cfg["levy"],
+                                           row_offset=rank * B)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, ys[-1])
+            return gathered
+        return ys[-1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            one_solve(i)
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(args.steps):
+            out = one_solve(1000 + i)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+
+        # roofline of the dominant kernel: every launch of the step kernel in one more solve is bracketed by
+        # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
+        K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
+        one_solve(5000)
+        torch.cuda.synchronize()
+        k_ms, k_launches = K.prof_end()
+    assert torch.isfinite(out).all()
+
+    value = world * B * nsteps * args.steps / elapsed
+    roofline = None
+    if k_launches > 0:
+        avg_s = k_ms * 1e-3 / k_launches
+        bytes_per_launch = cfg["bytes_per_traj_step"] * B / cfg["launches_per_step"]
+        achieved = bytes_per_launch / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
+                    "launches_timed": k_launches}
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = _cpu_baseline(cfg)
+        line = {
+            "metric": "SDE steps/sec (batch x timesteps / sec)", "value": value, "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "sde": "GBM diagonal Ito (f=mu*y, g=sigma*y as torch ops)",
+                       "method": cfg["method"], "batch_per_gpu": B, "global_batch": world * B, "state": d,
+                       "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
+                       "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

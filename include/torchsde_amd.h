@@ -1,0 +1,159 @@
+/*
+ * torchsde_amd -- C ABI of the MI355X (gfx950) time-stepping hot path.
+ *
+ * The reference (google-research/torchsde v0.2.6) is pure Python: it has no FFI. The seams this
+ * library sits behind are therefore the Python protocols of the reference, and every entry point
+ * below names the reference code it replaces (paths relative to /root/reference/torchsde):
+ *
+ *   tsde_brownian_*      _brownian/brownian_interval.py:589-687  BrownianInterval.__call__
+ *                        (+ :188-241 bridge split, :643-676 merge / H->U, :30-32 _randn)
+ *   tsde_step_diag       _core/methods/euler.py:29-37, midpoint.py:29-45 (+ base_sde.py:98-99 prod_diagonal)
+ *   tsde_step_prod       the same steps when the SDE supplies g_prod / f_and_g_prod (base_sde.py:115-117)
+ *   tsde_step_general    euler.py / midpoint.py with base_sde.py:101-102 -> misc.py:62-63 batch_mvp (bmm)
+ *   tsde_milstein_*      _core/methods/milstein.py:52-94 (+ base_sde.py:142-158)
+ *   tsde_srk_diag_stage  _core/methods/srk.py:57-88 + tableaus/srid2.py
+ *   tsde_srk_additive_*  _core/methods/srk.py:90-111 + tableaus/sra1.py
+ *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
+ *   tsde_linear_interp   _core/interp.py:15-18
+ *
+ * Conventions
+ *   - all tensors are contiguous row-major device buffers; `dtype` is TSDE_F32 or TSDE_F64;
+ *   - every launch goes to `stream` (a hipStream_t; NULL = the null stream), never synchronises,
+ *     never allocates; the return value is a hipError_t (0 = success) -- tsde_last_error() has text;
+ *   - scalars that the reference computes as 0-d tensors in ts.dtype (dt, sqrt(dt) ...) are passed as
+ *     doubles holding the already-rounded value and are cast to `dtype` inside the kernel;
+ *   - arithmetic follows the reference's operation order with one rounding per operation (no FMA
+ *     contraction), so that with identical increments the results are bit-identical to the
+ *     reference's CPU tensors wherever the reference itself is a chain of elementwise ops.
+ */
+#ifndef TORCHSDE_AMD_H
+#define TORCHSDE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSDE_ABI_VERSION 1
+#define TSDE_F32 0
+#define TSDE_F64 1
+
+/* Where a step kernel gets the Brownian increment of its time cell from.
+ *   dW == NULL : generate W (and U) in registers from the counter RNG: key = entropy,
+ *                element index = elem0 + local index, cell index `cell`, cell width `h`.
+ *   dW != NULL : read materialised increments (a foreign BaseBrownian, or a replay).
+ * `bcast_d` > 0: the external tensors hold one value per batch row (scalar noise, m = 1). */
+typedef struct tsde_noise {
+  const void* dW;
+  const void* dU;
+  uint64_t entropy;
+  uint64_t elem0;
+  uint32_t cell;
+  uint32_t reserved;
+  double h;
+  int64_t bcast_d;
+} tsde_noise_t;
+
+/* One segment of the adjoint's augmented state (y, a_y, or one parameter's a_theta). */
+typedef struct tsde_seg {
+  void* out;        /* may alias `s` */
+  const void* s;    /* current state segment */
+  const void* F;    /* drift term or NULL */
+  const void* G;    /* diffusion-product term or NULL */
+  const void* D;    /* Milstein gdg term or NULL */
+  int64_t n;
+  double sF, sG, sD; /* +1 / -1: the reference negates f and g_prod for the y segment */
+} tsde_seg_t;
+
+int tsde_abi_version(void);
+const char* tsde_last_error(void);
+
+/* Host-side (no GPU): the Philox-4x32-10 block function the kernels use; for known-answer tests. */
+void tsde_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* Host-side: the 128-bit counter the kernels build for (quad, cell, node, stream). */
+void tsde_noise_counter(uint64_t quad, uint32_t cell, uint64_t node, uint32_t stream, uint32_t out[4]);
+
+/* ---- Brownian source ------------------------------------------------------------------------ */
+
+/* Raw standard normals of one tree node: out[i] = N(entropy; elem0+i, cell, node, stream). */
+int tsde_brownian_normals(void* out, int64_t n, uint64_t entropy, uint64_t elem0, uint32_t cell, uint64_t node,
+                          uint32_t stream_id, int dtype, void* stream);
+
+/* Increment over [a,b] of the Brownian path defined by (entropy, cell edges).
+ *   edges : DEVICE pointer to the n_cells+1 cell edges (double); edges[ca] <= a < edges[ca+1],
+ *           edges[cb] < b <= edges[cb+1].
+ *   W (required), U and H (optional, need have_h): outputs of n elements each.
+ *   rootW / rootH : optional user-pinned (W,H) of a single top-level cell (`W=`, `H=` arguments of
+ *           BrownianInterval, brownian_interval.py:407-408); needs ca == cb == 0.
+ *   max_depth / snap : in-cell dyadic descent limit and leaf rule (0 = exact split, 1 = snap). */
+int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0,
+                        const double* edges, int64_t ca, int64_t cb, double a, double b, const void* rootW,
+                        const void* rootH, int have_h, int max_depth, int snap, int dtype, void* stream);
+
+/* W (and U, optional) of ONE whole cell written to memory: the aligned fast path of a query, for
+ * callers that must hand the increment to user torch code (g_prod, adjoint VJPs). `noise->dW` must be NULL. */
+int tsde_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* noise, int dtype, void* stream);
+
+/* ---- solver steps --------------------------------------------------------------------------- */
+
+/* y1 = (y0 + cf*f) + cg*(g*dW)          diagonal noise, g:(B,d), n = B*d.
+ * Euler: cf=dt, cg=1.  Midpoint stage 1: cf=dt/2, cg=0.5.  Midpoint stage 2: cf=dt, cg=1 on (f',g'). */
+int tsde_step_diag(void* y1, const void* y0, const void* f, const void* g, int64_t n, double cf, double cg,
+                   const tsde_noise_t* noise, int dtype, void* stream);
+
+/* y1 = (y0 + cf*f) + cg*gp              the SDE supplied the diffusion-vector product itself. */
+int tsde_step_prod(void* y1, const void* y0, const void* f, const void* gp, int64_t n, double cf, double cg,
+                   int dtype, void* stream);
+
+/* y1 = (y0 + cf*f) + cg*(g . dW)        g:(B,d,m), dW:(B,m); general / additive / scalar noise. */
+int tsde_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
+                      double cf, double cg, const tsde_noise_t* noise, int dtype, void* stream);
+
+/* Milstein helper: v_out = scale * (W^2 - dt) (ito != 0) or scale * W^2; W_out optional. */
+int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
+                    const tsde_noise_t* noise, int dtype, void* stream);
+/* y1 = ((y0 + f*dt) + g*W) + gdg        derivative form, diagonal noise. */
+int tsde_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n,
+                       double dt, const tsde_noise_t* noise, int dtype, void* stream);
+/* y' = (y0 + dt*f) + g*sqrt_dt (ito) or y0 + g*sqrt_dt (stratonovich)   derivative-free stage. */
+int tsde_milstein_gf_prime(void* yp, const void* y0, const void* f, const void* g, int64_t n, double dt,
+                           double sqrt_dt, int ito, int dtype, void* stream);
+/* y1 = ((y0 + f*dt) + g*W) + ((g'-g)*v)/(2*sqrt_dt), v = W^2 - dt (ito) or W^2. */
+int tsde_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gprime, int64_t n,
+                          double dt, double sqrt_dt, int ito, const tsde_noise_t* noise, int dtype, void* stream);
+
+/* SRID2 stage kernels (diagonal noise). fs/gs: arrays of 4 device pointers (unused entries NULL).
+ *   stage 1: out0=H0_1, out1=H1_1   from y0,f0,g0
+ *   stage 2: out0=H0_2, out1=H1_2   from y0,f0,g0,f1,g1
+ *   stage 3: out1=H1_3              from y0,g0,g1,f2,g2
+ *   stage 4: out0=y1                from y0,f0..f2,g0..g3 */
+int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
+                        const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
+                        const tsde_noise_t* noise, int dtype, void* stream);
+
+/* ---- adjoint, output ------------------------------------------------------------------------ */
+
+/* For each segment: out = ((s + sF*(F*cF)) + sG*(cG*G)) + sD*D   (absent terms skipped). */
+int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int dtype, void* stream);
+
+/* out = w0*ya + w1*yb */
+int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, int dtype,
+                       void* stream);
+
+/* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
+#define TSDE_KID_STEP_DIAG 1
+#define TSDE_KID_STEP_GENERAL 2
+#define TSDE_KID_MILSTEIN_DIAG 3
+#define TSDE_KID_SRK_STAGE 4
+#define TSDE_KID_AUG_UPDATE 5
+#define TSDE_KID_BROWNIAN_QUERY 6
+/* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
+int tsde_prof_begin(int kid, int capacity);
+/* Synchronise the events, return the summed kernel time and launch count, stop profiling. */
+int tsde_prof_end(double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCHSDE_AMD_H */

@@ -1,0 +1,191 @@
+"""ORACLE (test infrastructure only): torch-CPU restatement of the reference's solver steps and loop.
+
+Each function follows the cited lines of /root/reference/torchsde and uses plain elementwise torch CPU ops
+(one IEEE rounding per op, in the tensor dtype), i.e. the arithmetic the reference itself performs.
+Pinned by tests/golden/solver_*.npz, which hold outputs of the real reference under replayed increments
+(tests/golden/make_golden.py, checked in tests/test_oracle_solvers.py).
+
+`bm` is any callable ``bm(t0, t1, return_U=False)`` returning W or (W, U) as CPU tensors; `sde` is a plain
+object with ``noise_type``, ``sde_type`` and ``f``/``g`` (optionally ``g_prod`` / ``f_and_g`` /
+``f_and_g_prod``), resolved with the reference's priority (base_sde.py:51-73).
+"""
+import torch
+
+# tableaus/srid2.py:19-54
+SRID2 = dict(
+    STAGES=4,
+    C0=(0, 1, 1 / 2, 0), C1=(0, 1 / 4, 1, 1 / 4),
+    A0=((), (1,), (1 / 4, 1 / 4), (0, 0, 0)),
+    A1=((), (1 / 4,), (1, 0), (0, 0, 1 / 4)),
+    B0=((), (0,), (1, 1 / 2), (0, 0, 0)),
+    B1=((), (-1 / 2,), (1, 0), (2, -1, 1 / 2)),
+    alpha=(1 / 6, 1 / 6, 2 / 3, 0),
+    beta1=(-1, 4 / 3, 2 / 3, 0), beta2=(1, -4 / 3, 1 / 3, 0), beta3=(2, -4 / 3, -2 / 3, 0),
+    beta4=(-2, 5 / 3, -2 / 3, 1),
+)
+# tableaus/sra1.py:19-36
+SRA1 = dict(STAGES=2, C0=(0, 3 / 4), C1=(1, 0), A0=((), (3 / 4,)), B0=((), (3 / 2,)), alpha=(1 / 3, 2 / 3),
+            beta1=(1, 0), beta2=(-1, 1))
+
+
+# ---- SDE method resolution (base_sde.py:42-158) ----------------------------------------------------------
+def prod(sde, g, v):
+    """base_sde.py:98-102 + misc.py:62-63."""
+    if sde.noise_type == "diagonal":
+        return g * v
+    return torch.bmm(g, v.unsqueeze(-1)).squeeze(dim=-1)
+
+
+def g_prod(sde, t, y, v):
+    if hasattr(sde, "g_prod"):
+        return sde.g_prod(t, y, v)
+    return prod(sde, sde.g(t, y), v)
+
+
+def f_and_g(sde, t, y):
+    if hasattr(sde, "f_and_g"):
+        return sde.f_and_g(t, y)
+    return sde.f(t, y), sde.g(t, y)
+
+
+def f_and_g_prod(sde, t, y, v):
+    """base_sde.py:51-56, 115-120."""
+    if hasattr(sde, "f_and_g_prod"):
+        return sde.f_and_g_prod(t, y, v)
+    if hasattr(sde, "f") and hasattr(sde, "g_prod"):
+        return sde.f(t, y), sde.g_prod(t, y, v)
+    f, g = f_and_g(sde, t, y)
+    return f, prod(sde, g, v)
+
+
+def g_prod_and_gdg_prod(sde, t, y, v1, v2):
+    """base_sde.py:127-158."""
+    if sde.noise_type == "additive":
+        return g_prod(sde, t, y, v1), 0.
+    with torch.enable_grad():
+        y = y if y.requires_grad else y.detach().requires_grad_(True)
+        g = sde.g(t, y)
+        weight = g * v2 if sde.noise_type == "diagonal" else g * v2.unsqueeze(-2)
+        gdg, = torch.autograd.grad(g, y, grad_outputs=weight, retain_graph=True, allow_unused=True)
+        if gdg is None:
+            gdg = torch.zeros_like(y)
+    return prod(sde, g.detach(), v1), gdg
+
+
+# ---- one step of each method ------------------------------------------------------------------------------
+def euler_step(sde, bm, t0, t1, y0, options=None):
+    """methods/euler.py:29-37."""
+    dt = t1 - t0
+    I_k = bm(t0, t1)
+    f, gp = f_and_g_prod(sde, t0, y0, I_k)
+    return y0 + f * dt + gp
+
+
+def midpoint_step(sde, bm, t0, t1, y0, options=None):
+    """methods/midpoint.py:29-45."""
+    dt = t1 - t0
+    I_k = bm(t0, t1)
+    f, gp = f_and_g_prod(sde, t0, y0, I_k)
+    half_dt = 0.5 * dt
+    t_prime = t0 + half_dt
+    y_prime = y0 + half_dt * f + 0.5 * gp
+    f_prime, gp_prime = f_and_g_prod(sde, t_prime, y_prime, I_k)
+    return y0 + dt * f_prime + gp_prime
+
+
+def milstein_step(sde, bm, t0, t1, y0, options=None):
+    """methods/milstein.py:52-94."""
+    options = options or {}
+    ito = sde.sde_type == "ito"
+    grad_free = options.get("grad_free", False) and sde.noise_type != "additive"
+    dt = t1 - t0
+    I_k = bm(t0, t1)
+    v = I_k ** 2 - dt if ito else I_k ** 2
+    if grad_free:
+        f, g = f_and_g(sde, t0, y0)
+        g_ = g.squeeze(2) if g.dim() == 3 else g
+        sqrt_dt = dt.sqrt()
+        y0_prime = y0 + (dt * f if ito else 0.) + g_ * sqrt_dt
+        g_prime = sde.g(t0, y0_prime)
+        gp = prod(sde, g, I_k)
+        gdg = prod(sde, g_prime - g, v) / (2 * sqrt_dt)
+    else:
+        f = sde.f(t0, y0)
+        gp, gdg = g_prod_and_gdg_prod(sde, t0, y0, I_k, 0.5 * v)
+    return y0 + f * dt + gp + gdg
+
+
+def srk_step(sde, bm, t0, t1, y0, options=None):
+    """methods/srk.py:57-111 (the reference's loops, including its repeated f/g evaluations)."""
+    dt = t1 - t0
+    rdt = 1 / dt
+    I_k, I_k0 = bm(t0, t1, return_U=True)
+    if sde.noise_type == "additive":
+        tb = SRA1
+        y1 = y0
+        H0 = []
+        for i in range(tb["STAGES"]):
+            H0i = y0
+            for j in range(i):
+                f = sde.f(t0 + tb["C0"][j] * dt, H0[j])
+                gw = tb["B0"][i][j] * I_k0 * rdt
+                H0i = H0i + tb["A0"][i][j] * f * dt + g_prod(sde, t0 + tb["C1"][j] * dt, y0, gw)
+            H0.append(H0i)
+            f = sde.f(t0 + tb["C0"][i] * dt, H0i)
+            gw = tb["beta1"][i] * I_k + tb["beta2"][i] * I_k0 * rdt
+            y1 = y1 + tb["alpha"][i] * f * dt + g_prod(sde, t0 + tb["C1"][i] * dt, y0, gw)
+        return y1
+    tb = SRID2
+    sqrt_dt = dt.sqrt()
+    I_kk = (I_k ** 2 - dt) * (1 / 2)
+    I_kkk = (I_k ** 3 - 3 * dt * I_k) * (1 / 6)
+    y1 = y0
+    H0, H1 = [], []
+    for s in range(tb["STAGES"]):
+        H0s, H1s = y0, y0
+        for j in range(s):
+            f = sde.f(t0 + tb["C0"][j] * dt, H0[j])
+            g = sde.g(t0 + tb["C1"][j] * dt, H1[j])
+            g = g.squeeze(2) if g.dim() == 3 else g
+            H0s = H0s + tb["A0"][s][j] * f * dt + tb["B0"][s][j] * g * I_k0 * rdt
+            H1s = H1s + tb["A1"][s][j] * f * dt + tb["B1"][s][j] * g * sqrt_dt
+        H0.append(H0s)
+        H1.append(H1s)
+        f = sde.f(t0 + tb["C0"][s] * dt, H0s)
+        gw = (tb["beta1"][s] * I_k + tb["beta2"][s] * I_kk / sqrt_dt + tb["beta3"][s] * I_k0 * rdt +
+              tb["beta4"][s] * I_kkk * rdt)
+        y1 = y1 + tb["alpha"][s] * f * dt + g_prod(sde, t0 + tb["C1"][s] * dt, H1s, gw)
+    return y1
+
+
+STEPS = {"euler": euler_step, "midpoint": midpoint_step, "milstein": milstein_step, "srk": srk_step}
+
+
+# ---- the stepping loop ------------------------------------------------------------------------------------
+def integrate(sde, bm, y0, ts, dt, method, options=None, record=None):
+    """base_solver.py:92-116,143-149 (fixed step) + interp.py:15-18. `ts` is a CPU tensor."""
+    step = STEPS[method]
+    prev_t = curr_t = ts[0]
+    prev_y = curr_y = y0
+    ys = [y0]
+    for out_t in ts[1:]:
+        while curr_t < out_t:
+            next_t = min(curr_t + dt, ts[-1])
+            if record is not None:
+                record.append((float(curr_t), float(next_t)))
+            prev_t, prev_y = curr_t, curr_y
+            curr_y = step(sde, bm, curr_t, next_t, curr_y, options)
+            curr_t = next_t
+        ys.append((curr_t - out_t) / (curr_t - prev_t) * prev_y + (out_t - prev_t) / (curr_t - prev_t) * curr_y)
+    return torch.stack(ys, dim=0)
+
+
+class ReplayBrownian:
+    """Serves pre-computed increments keyed by the exact (t0, t1) floats of each query."""
+
+    def __init__(self, table):
+        self.table = table   # {(ta, tb): (W, U or None)}
+
+    def __call__(self, ta, tb, return_U=False):
+        W, U = self.table[(float(ta), float(tb))]
+        return (W, U) if return_U else W

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (MI355X); run with `-m gpu` on the GPU box")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """Make sure the HIP library (cross-compiled, no GPU needed) and the oracle's C twin exist."""
+    from torchsde_amd import _native
+    if not _native.is_built():
+        import __graft_entry__
+        __graft_entry__.build()
+    from oracle import build as oracle_build
+    oracle_build.build()
+    yield

@@ -1,0 +1,243 @@
+"""Generates the golden fixtures in this directory by running the REAL reference (read-only checkout at
+/root/reference, CPU) -- run in the dev container only:
+
+    python tests/golden/make_golden.py
+
+The GPU box has no /root/reference; tests read the committed .npz files. Fixtures:
+  timegrid.npz        the (t0, t1) pairs the reference's stepping loop queries for several (ts, dt, dtype)
+  solver_<case>.npz   reference `sdeint` outputs under replayed Brownian increments (increments stored)
+  adjoint_<case>.npz  reference `sdeint_adjoint` outputs + gradients under replayed increments
+  bridge.npz          (parent, normals, children) tuples recorded inside the reference's bridge code and
+                      multi-interval merge results
+  brownian_seq.npz    reference BrownianInterval outputs for fixed entropy and query sequences
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, "_ref_shim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import torchsde  # noqa: E402  (the reference)
+from torchsde._brownian import brownian_interval as ref_bi  # noqa: E402
+
+from tests import problems  # noqa: E402
+
+DT = {"f32": torch.float32, "f64": torch.float64}
+
+
+class ReplayBM(torchsde.BaseBrownian):
+    """Draws an increment the first time an interval is queried and replays it afterwards."""
+
+    def __init__(self, shape, dtype, seed, levy="none"):
+        super().__init__()
+        self._shape, self._dtype, self._levy = tuple(shape), dtype, levy
+        self.rng = np.random.default_rng(seed)
+        self.table, self.order = {}, []
+
+    def __call__(self, ta, tb=None, return_U=False, return_A=False):
+        key = (float(ta), float(tb))
+        if key not in self.table:
+            h = key[1] - key[0]
+            W = torch.tensor(self.rng.standard_normal(self._shape) * np.sqrt(h), dtype=self._dtype)
+            H = torch.tensor(self.rng.standard_normal(self._shape) * np.sqrt(h / 12), dtype=self._dtype)
+            U = h * (.5 * W + H)
+            self.table[key] = (W, U)
+            self.order.append(key)
+        W, U = self.table[key]
+        return (W, U) if return_U else W
+
+    def __repr__(self):
+        return "ReplayBM"
+
+    dtype = property(lambda self: self._dtype)
+    device = property(lambda self: torch.device("cpu"))
+    shape = property(lambda self: self._shape)
+    levy_area_approximation = property(lambda self: self._levy)
+
+    def dump(self):
+        keys = np.array(self.order, dtype=np.float64).reshape(-1, 2)
+        W = np.stack([self.table[k][0].numpy() for k in self.order])
+        U = np.stack([self.table[k][1].numpy() for k in self.order])
+        return keys, W, U
+
+
+def param_checksum(sde):
+    return float(sum(p.detach().double().abs().sum() for p in sde.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------- timegrid
+def gen_timegrid():
+    class Rec(ReplayBM):
+        pass
+    out = {}
+    cases = {
+        "f32_1e-3": (torch.tensor([0., 1.], dtype=torch.float32), 1e-3),
+        "f32_dyadic": (torch.tensor([0., 1000 * 2.0 ** -10], dtype=torch.float32), 2.0 ** -10),
+        "f32_multi": (torch.tensor([0., 0.25, 0.5, 0.77], dtype=torch.float32), 0.1),
+        "f64_multi": (torch.tensor([0., 0.25, 0.5, 0.77], dtype=torch.float64), 0.1),
+        "f32_linspace20": (torch.linspace(0, 1, 20, dtype=torch.float32), 1e-3),
+        "f64_1e-2": (torch.tensor([0.3, 1.7], dtype=torch.float64), 1e-2),
+        "f32_coarse": (torch.tensor([0., 0.05, 0.1, 0.15, 1.0], dtype=torch.float32), 0.4),
+    }
+    for name, (ts, dt) in cases.items():
+        sde = problems.make("gbm_ito", dtype=ts.dtype)
+        bm = Rec((2, 4), ts.dtype, seed=0)
+        y0 = torch.full((2, 4), 0.1, dtype=ts.dtype)
+        with torch.no_grad():
+            torchsde.sdeint(sde, y0, ts, bm=bm, method="euler", dt=dt)
+        keys, _, _ = bm.dump()
+        out[name + "__ts"] = ts.numpy()
+        out[name + "__dt"] = np.float64(dt)
+        out[name + "__queries"] = keys
+    np.savez(os.path.join(HERE, "timegrid.npz"), **out)
+    print("timegrid.npz:", {k: v.shape for k, v in out.items() if k.endswith("queries")})
+
+
+# --------------------------------------------------------------------------------------------------- solver
+SOLVER_CASES = [
+    # name, problem, method, options, levy, (B, d, m), ts, dt
+    ("euler_gbm", "gbm_ito", "euler", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("euler_gbm_odd", "gbm_ito", "euler", None, "none", (5, 3, 3), [0., 0.5], 2.0 ** -4),
+    ("euler_scalar", "scalar_ito", "euler", None, "none", (5, 4, 1), [0., 0.3, 0.6], 0.05),
+    ("euler_additive", "additive_ito", "euler", None, "none", (5, 4, 3), [0., 0.5], 0.05),
+    ("euler_general", "general_ito", "euler", None, "none", (6, 4, 4), [0., 0.5], 0.05),
+    ("euler_general_odd", "general_odd_ito", "euler", None, "none", (6, 3, 5), [0., 0.5], 0.05),
+    ("euler_readme", "readme", "euler", None, "none", (32, 3, 2), list(np.linspace(0, 1, 20)), 1e-3),
+    ("milstein_gbm_ito", "gbm_ito", "milstein", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("milstein_gbm_strat", "gbm_strat", "milstein", None, "none", (5, 4, 4), [0., 0.5], 0.05),
+    ("milstein_gf_gbm_ito", "gbm_ito", "milstein", {"grad_free": True}, "none", (5, 4, 4), [0., 0.5], 0.05),
+    ("milstein_gf_gbm_strat", "gbm_strat", "milstein", {"grad_free": True}, "none", (5, 4, 4), [0., 0.5], 0.05),
+    ("milstein_scalar", "scalar_ito", "milstein", None, "none", (5, 4, 1), [0., 0.5], 0.05),
+    ("milstein_gf_scalar", "scalar_ito", "milstein", {"grad_free": True}, "none", (5, 4, 1), [0., 0.5], 0.05),
+    ("milstein_additive", "additive_ito", "milstein", None, "none", (5, 4, 3), [0., 0.5], 0.05),
+    ("milstein_mlpdiag", "mlpdiag_ito", "milstein", None, "none", (5, 4, 4), [0., 0.5], 0.05),
+    ("srk_gbm", "gbm_ito", "srk", None, "space-time", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("srk_scalar", "scalar_ito", "srk", None, "space-time", (5, 4, 1), [0., 0.5], 0.05),
+    ("srk_additive", "additive_ito", "srk", None, "space-time", (5, 4, 3), [0., 0.5], 0.05),
+    ("srk_mlpdiag", "mlpdiag_ito", "srk", None, "space-time", (5, 4, 4), [0., 0.5], 0.05),
+    ("midpoint_gbm", "gbm_strat", "midpoint", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("midpoint_scalar", "scalar_strat", "midpoint", None, "none", (5, 4, 1), [0., 0.5], 0.05),
+    ("midpoint_additive", "additive_strat", "midpoint", None, "none", (5, 4, 3), [0., 0.5], 0.05),
+    ("midpoint_general", "general_strat", "midpoint", None, "none", (6, 4, 4), [0., 0.5], 0.05),
+]
+
+
+def gen_solver():
+    for name, prob, method, options, levy, (B, d, m), ts, dt in SOLVER_CASES:
+        out = {"problem": prob, "method": method, "levy": levy, "dt": np.float64(dt),
+               "grad_free": bool(options and options.get("grad_free")), "shape": np.array([B, d, m])}
+        for tag, dtype in DT.items():
+            sde = problems.make(prob, dtype=dtype, d=d, m=m)
+            y0 = torch.full((B, d), 0.1, dtype=dtype)
+            tst = torch.tensor(ts, dtype=dtype)
+            bm = ReplayBM((B, m), dtype, seed=hash(name) % 2 ** 31 if False else sum(map(ord, name)), levy=levy)
+            with torch.no_grad():
+                ys = torchsde.sdeint(sde, y0, tst, bm=bm, method=method, dt=dt,
+                                     options=None if options is None else dict(options))
+            keys, W, U = bm.dump()
+            out[f"{tag}__ts"] = tst.numpy()
+            out[f"{tag}__queries"] = keys
+            out[f"{tag}__W"] = W
+            out[f"{tag}__U"] = U
+            out[f"{tag}__ys"] = ys.numpy()
+            out[f"{tag}__param_checksum"] = np.float64(param_checksum(sde))
+        np.savez_compressed(os.path.join(HERE, f"solver_{name}.npz"), **out)
+        print(f"solver_{name}.npz  steps={len(keys)}  ys[-1,0,:2]={out['f32__ys'][-1, 0, :2]}")
+
+
+# --------------------------------------------------------------------------------------------------- bridge
+def gen_bridge():
+    """Record what the reference's bridge code does with known normals, and multi-interval merges."""
+    recs = []
+    orig_randn = ref_bi._randn
+    log = {}
+
+    def spy_randn(size, dtype, device, seed):
+        x = orig_randn(size, dtype, device, seed)
+        log[int(seed)] = x
+        return x
+
+    ref_bi._randn = spy_randn
+    try:
+        out = {}
+        for levy in ("none", "space-time"):
+            for tag, dtype in DT.items():
+                bm = torchsde.BrownianInterval(t0=0., t1=1., size=(6,), dtype=dtype, entropy=1234,
+                                               levy_area_approximation=levy)
+                W0, H0 = bm._w_h
+                # one split at x: children are (0,x) and (x,1)
+                x = 0.3
+                res_l = bm(0., x, return_U=(levy != "none"))
+                res_r = bm(x, 1., return_U=(levy != "none"))
+                Wl, Ul = res_l if levy != "none" else (res_l, None)
+                Wr, Ur = res_r if levy != "none" else (res_r, None)
+                X1 = log[int(bm._W_seed)]
+                X2 = log.get(int(bm._H_seed))
+                pre = f"{levy}__{tag}__"
+                out[pre + "x"] = np.float64(x)
+                out[pre + "W"] = W0.numpy()
+                out[pre + "H"] = (H0 if H0 is not None else torch.zeros_like(W0)).numpy()
+                out[pre + "X1"] = X1.numpy()
+                out[pre + "X2"] = (X2 if X2 is not None else torch.zeros_like(X1)).numpy()
+                out[pre + "Wl"] = Wl.numpy()
+                out[pre + "Wr"] = Wr.numpy()
+                if levy != "none":
+                    out[pre + "Ul"] = Ul.numpy()
+                    out[pre + "Ur"] = Ur.numpy()
+                    # merged query across the split: pieces (0.3->0.55 after another split) etc.
+                    W_a, U_a = bm(0.1, 0.3, return_U=True)
+                    W_b, U_b = bm(0.3, 0.8, return_U=True)
+                    W_ab, U_ab = bm(0.1, 0.8, return_U=True)
+                    out[pre + "merge_ta_u_t"] = np.array([0.1, 0.3, 0.8])
+                    for k, v in (("W_a", W_a), ("U_a", U_a), ("W_b", W_b), ("U_b", U_b), ("W_ab", W_ab),
+                                 ("U_ab", U_ab)):
+                        out[pre + k] = v.numpy()
+    finally:
+        ref_bi._randn = orig_randn
+    np.savez(os.path.join(HERE, "bridge.npz"), **out)
+    print("bridge.npz:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------------------------- brownian seq
+def gen_brownian_seq():
+    out = {}
+    rng = np.random.default_rng(7)
+    seqs = {
+        "seq_steps": [(k * 0.01, (k + 1) * 0.01) for k in range(100)] + [(1 - (k + 1) * 0.01, 1 - k * 0.01)
+                                                                           for k in range(100)],
+        "seq_random": [tuple(sorted(rng.uniform(0, 1, 2))) for _ in range(150)],
+    }
+    for sname, seq in seqs.items():
+        for levy in ("none", "space-time"):
+            for hint in (None, 0.01):
+                bm = torchsde.BrownianInterval(t0=0., t1=1., size=(3, 2), dtype=torch.float64, entropy=4321,
+                                               levy_area_approximation=levy, dt=hint)
+                Ws, Us = [], []
+                for (a, b) in seq:
+                    if levy == "none":
+                        Ws.append(bm(a, b).numpy())
+                    else:
+                        W, U = bm(a, b, return_U=True)
+                        Ws.append(W.numpy())
+                        Us.append(U.numpy())
+                pre = f"{sname}__{levy}__{'hint' if hint else 'nohint'}__"
+                out[pre + "queries"] = np.array(seq, dtype=np.float64)
+                out[pre + "W"] = np.stack(Ws)
+                if Us:
+                    out[pre + "U"] = np.stack(Us)
+    np.savez_compressed(os.path.join(HERE, "brownian_seq.npz"), **out)
+    print("brownian_seq.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["timegrid", "solver", "bridge", "brownian_seq"]
+    torch.manual_seed(0)
+    for w in which:
+        globals()["gen_" + w]()

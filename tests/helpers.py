@@ -1,0 +1,91 @@
+"""Shared test helpers: golden fixture loading and replay Brownian motions."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TORCH_DT = {"f32": torch.float32, "f64": torch.float64}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def solver_cases():
+    return sorted(f[len("solver_"):-4] for f in os.listdir(GOLDEN) if f.startswith("solver_") and f.endswith(".npz"))
+
+
+def adjoint_cases():
+    return sorted(f[len("adjoint_"):-4] for f in os.listdir(GOLDEN) if f.startswith("adjoint_") and f.endswith(".npz"))
+
+
+class Case:
+    """One golden solver case in one precision."""
+
+    def __init__(self, name, tag, prefix="solver_"):
+        z = load(f"{prefix}{name}.npz")
+        self.z = z
+        self.name, self.tag, self.dtype = name, tag, TORCH_DT[tag]
+        self.problem, self.method, self.levy = str(z["problem"]), str(z["method"]), str(z["levy"])
+        self.dt = float(z["dt"])
+        self.options = {"grad_free": True} if bool(z["grad_free"]) else None
+        self.B, self.d, self.m = (int(v) for v in z["shape"])
+        self.ts = torch.tensor(z[f"{tag}__ts"], dtype=self.dtype)
+        self.queries = z[f"{tag}__queries"]
+        self.W = z[f"{tag}__W"]
+        self.U = z[f"{tag}__U"]
+        self.ys = torch.tensor(z[f"{tag}__ys"], dtype=self.dtype)
+        self.param_checksum = float(z[f"{tag}__param_checksum"])
+
+    def sde(self, device="cpu"):
+        from tests import problems
+        sde = problems.make(self.problem, dtype=self.dtype, d=self.d, m=self.m)
+        got = float(sum(p.detach().double().abs().sum() for p in sde.parameters()))
+        assert abs(got - self.param_checksum) <= 1e-9 * max(1.0, abs(got)), "test problem parameters drifted"
+        return sde.to(device)
+
+    def y0(self, device="cpu"):
+        return torch.full((self.B, self.d), 0.1, dtype=self.dtype, device=device)
+
+    def table(self, device="cpu"):
+        return {(float(a), float(b)): (torch.tensor(self.W[i], dtype=self.dtype, device=device),
+                                       torch.tensor(self.U[i], dtype=self.dtype, device=device))
+                for i, (a, b) in enumerate(self.queries)}
+
+
+def make_replay_bm(table, shape, dtype, device, levy):
+    """A foreign BaseBrownian (seam S3) that replays stored increments."""
+    from torchsde_amd import BaseBrownian
+
+    class Replay(BaseBrownian):
+        def __call__(self, ta, tb=None, return_U=False, return_A=False):
+            W, U = table[(float(ta), float(tb))]
+            return (W, U) if return_U else W
+
+        def __repr__(self):
+            return "Replay"
+
+        dtype_ = dtype
+
+        @property
+        def dtype(self):
+            return dtype
+
+        @property
+        def device(self):
+            return torch.device(device)
+
+        @property
+        def shape(self):
+            return tuple(shape)
+
+        @property
+        def levy_area_approximation(self):
+            return levy
+
+    return Replay()
+
+
+def has_gpu():
+    return torch.cuda.is_available()

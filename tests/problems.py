@@ -1,0 +1,188 @@
+"""Test SDEs (one per noise type), defined without importing either torchsde or torchsde_amd so that the
+same objects can be handed to the reference (golden generation), to the oracle and to the HIP path.
+
+They cover the families the reference's own tests use (reference tests/problems.py): geometric Brownian
+motion for diagonal noise (closed-form solution available), a trigonometric scalar-noise SDE, a
+time-dependent additive-noise SDE, small MLPs for general/diagonal noise, and the README quick example.
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def _sigmoid_randn(gen, *shape):
+    return torch.sigmoid(torch.randn(*shape, generator=gen, dtype=torch.float64))
+
+
+class GBMDiag(nn.Module):
+    """dy = mu*y dt + sigma*y dW (Ito) / with the -sigma^2 y/2 correction (Stratonovich); non-exploding."""
+    noise_type = "diagonal"
+
+    def __init__(self, d, sde_type="ito", seed=0, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        sigma = _sigmoid_randn(gen, d)
+        mu = -sigma ** 2 - _sigmoid_randn(gen, d)
+        self.mu = nn.Parameter(mu.to(dtype))
+        self.sigma = nn.Parameter(sigma.to(dtype))
+        self.sde_type = sde_type
+
+    def f(self, t, y):
+        if self.sde_type == "ito":
+            return self.mu * y
+        return self.mu * y - .5 * (self.sigma ** 2) * y
+
+    def g(self, t, y):
+        return self.sigma * y
+
+    def exact(self, y0, t, W_t):
+        """Closed form y0 * exp((mu - sigma^2/2) t + sigma W_t) on the same Brownian path."""
+        return y0 * torch.exp((self.mu - 0.5 * self.sigma ** 2) * t + self.sigma * W_t)
+
+
+class ScalarTrig(nn.Module):
+    """Scalar noise: dy = -p^2 sin(y) cos^3(y) dt + p cos^2(y) dW (Ito form)."""
+    noise_type = "scalar"
+
+    def __init__(self, d, sde_type="ito", seed=1, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.p = nn.Parameter(_sigmoid_randn(gen, d).to(dtype))
+        self.sde_type = sde_type
+
+    def f(self, t, y):
+        if self.sde_type == "ito":
+            return -self.p ** 2. * torch.sin(y) * torch.cos(y) ** 3.
+        return torch.zeros_like(y)
+
+    def g(self, t, y):
+        return (self.p * torch.cos(y) ** 2).unsqueeze(dim=-1)
+
+
+class AdditiveDecay(nn.Module):
+    """Additive noise with time-dependent diffusion: g does not depend on y."""
+    noise_type = "additive"
+
+    def __init__(self, d, m, sde_type="ito", seed=2, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.a = nn.Parameter(_sigmoid_randn(gen, d).to(dtype))
+        self.b = nn.Parameter(_sigmoid_randn(gen, d).to(dtype))
+        self.m = m
+        self.sde_type = sde_type
+
+    def f(self, t, y):
+        return self.b / torch.sqrt(1. + t) - y / (2. + 2. * t)
+
+    def g(self, t, y):
+        fill = self.a * self.b / torch.sqrt(1. + t)
+        return fill.unsqueeze(0).unsqueeze(-1).repeat(y.size(0), 1, self.m)
+
+
+def _mlp(gen, sizes, dtype, final=None):
+    layers = []
+    for i, (a, b) in enumerate(zip(sizes[:-1], sizes[1:])):
+        lin = nn.Linear(a, b)
+        with torch.no_grad():
+            lin.weight.copy_((torch.randn(b, a, generator=gen, dtype=torch.float64) / math.sqrt(a)).to(dtype))
+            lin.bias.copy_((0.1 * torch.randn(b, generator=gen, dtype=torch.float64)).to(dtype))
+        layers.append(lin.to(dtype))
+        if i < len(sizes) - 2:
+            layers.append(nn.Softplus())
+    if final is not None:
+        layers.append(final)
+    return nn.Sequential(*layers)
+
+
+class MLPGeneral(nn.Module):
+    """General noise: drift and diffusion are small time-dependent MLPs; g has shape (B, d, m)."""
+    noise_type = "general"
+
+    def __init__(self, d, m, sde_type="ito", seed=3, hidden=8, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.d, self.m, self.sde_type = d, m, sde_type
+        self.f_net = _mlp(gen, (d + 1, hidden, d), dtype)
+        self.g_net = _mlp(gen, (d + 1, hidden, d * m), dtype, final=nn.Sigmoid())
+
+    def _ty(self, t, y):
+        return torch.cat([t.expand(y.size(0), 1).to(y.dtype), y], dim=1)
+
+    def f(self, t, y):
+        return self.f_net(self._ty(t, y))
+
+    def g(self, t, y):
+        return self.g_net(self._ty(t, y)).reshape(y.size(0), self.d, self.m)
+
+
+class MLPDiag(nn.Module):
+    """Diagonal noise with an elementwise diffusion g_i(y_i) (a valid diagonal SDE for Milstein/adjoint)."""
+    noise_type = "diagonal"
+
+    def __init__(self, d, sde_type="ito", seed=4, hidden=8, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.sde_type = sde_type
+        self.f_net = _mlp(gen, (d + 1, hidden, d), dtype)
+        self.w = nn.Parameter(torch.randn(d, generator=gen, dtype=torch.float64).to(dtype))
+        self.b = nn.Parameter((0.1 * torch.randn(d, generator=gen, dtype=torch.float64)).to(dtype))
+
+    def f(self, t, y):
+        return self.f_net(torch.cat([t.expand(y.size(0), 1).to(y.dtype), y], dim=1))
+
+    def g(self, t, y):
+        return 0.1 * torch.sigmoid(self.w * y + self.b)
+
+
+class ReadmeSDE(nn.Module):
+    """The README quick example: general Ito noise, linear drift, linear diffusion reshaped to (B, d, m)."""
+    noise_type = "general"
+    sde_type = "ito"
+
+    def __init__(self, d=3, m=2, seed=5, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.d, self.m = d, m
+        self.mu = _mlp(gen, (d, d), dtype)
+        self.sigma = _mlp(gen, (d, d * m), dtype)
+
+    def f(self, t, y):
+        return self.mu(y)
+
+    def g(self, t, y):
+        return self.sigma(y).view(y.size(0), self.d, self.m)
+
+
+# ---- the same diagonal SDE exposed through the other provider combinations (base_sde.py:51-73) -----------
+class GBMViaFAndG(GBMDiag):
+    def f_and_g(self, t, y):
+        return GBMDiag.f(self, t, y), GBMDiag.g(self, t, y)
+
+
+class GBMViaGProd(GBMDiag):
+    def g_prod(self, t, y, v):
+        return GBMDiag.g(self, t, y) * v
+
+
+class GBMViaFAndGProd(GBMDiag):
+    def f_and_g_prod(self, t, y, v):
+        return GBMDiag.f(self, t, y), GBMDiag.g(self, t, y) * v
+
+
+def make(name, dtype=torch.float32, **kw):
+    table = {
+        "gbm_ito": lambda: GBMDiag(kw.get("d", 4), "ito", dtype=dtype),
+        "gbm_strat": lambda: GBMDiag(kw.get("d", 4), "stratonovich", dtype=dtype),
+        "scalar_ito": lambda: ScalarTrig(kw.get("d", 4), "ito", dtype=dtype),
+        "scalar_strat": lambda: ScalarTrig(kw.get("d", 4), "stratonovich", dtype=dtype),
+        "additive_ito": lambda: AdditiveDecay(kw.get("d", 4), kw.get("m", 3), "ito", dtype=dtype),
+        "additive_strat": lambda: AdditiveDecay(kw.get("d", 4), kw.get("m", 3), "stratonovich", dtype=dtype),
+        "general_ito": lambda: MLPGeneral(kw.get("d", 4), kw.get("m", 4), "ito", dtype=dtype),
+        "general_strat": lambda: MLPGeneral(kw.get("d", 4), kw.get("m", 4), "stratonovich", dtype=dtype),
+        "general_odd_ito": lambda: MLPGeneral(kw.get("d", 3), kw.get("m", 5), "ito", dtype=dtype),
+        "mlpdiag_ito": lambda: MLPDiag(kw.get("d", 4), "ito", dtype=dtype),
+        "mlpdiag_strat": lambda: MLPDiag(kw.get("d", 4), "stratonovich", dtype=dtype),
+        "readme": lambda: ReadmeSDE(dtype=dtype),
+    }
+    return table[name]()

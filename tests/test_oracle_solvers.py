@@ -1,0 +1,23 @@
+"""The oracle's restatement of the reference's solver steps reproduces the REAL reference's outputs
+(golden fixtures produced by tests/golden/make_golden.py from /root/reference) under replayed increments."""
+import pytest
+import torch
+
+from oracle import solvers_ref
+from tests import helpers
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("name", helpers.solver_cases())
+def test_oracle_matches_reference(name, tag):
+    case = helpers.Case(name, tag)
+    sde = case.sde()
+    bm = solvers_ref.ReplayBrownian(case.table())
+    with torch.no_grad():
+        ys = solvers_ref.integrate(sde, bm, case.y0(), case.ts, case.dt, case.method, case.options)
+    assert ys.shape == case.ys.shape
+    if case.problem.startswith(("general", "readme", "mlpdiag")) or "additive" in case.problem or "scalar" in case.problem:
+        # bmm / Linear layers: same library, same machine -> still expected equal; allow 2 ulp-scale slack
+        torch.testing.assert_close(ys, case.ys, rtol=2e-6 if tag == "f32" else 1e-13, atol=1e-7 if tag == "f32" else 1e-15)
+    else:
+        assert torch.equal(ys, case.ys), f"max diff {(ys - case.ys).abs().max().item():.3e}"

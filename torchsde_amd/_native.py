@@ -1,0 +1,145 @@
+"""ctypes binding of ``csrc/libtorchsde_amd.so`` -- the C ABI declared in ``include/torchsde_amd.h``.
+
+This is the only way the Python host code reaches the HIP kernels. There is no CPU fallback: if the
+shared library is missing, or a tensor is not on a ROCm device, the call fails loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtorchsde_amd.so")
+
+F32, F64 = 0, 1
+KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDATE, KID_BROWNIAN_QUERY = 1, 2, 3, 4, 5, 6
+
+_c_i64 = ctypes.c_int64
+_c_u64 = ctypes.c_uint64
+_c_u32 = ctypes.c_uint32
+_c_dbl = ctypes.c_double
+_c_ptr = ctypes.c_void_p
+_c_int = ctypes.c_int
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class Noise(ctypes.Structure):
+    """``tsde_noise_t``."""
+    _fields_ = [("dW", _c_ptr), ("dU", _c_ptr), ("entropy", _c_u64), ("elem0", _c_u64), ("cell", _c_u32),
+                ("reserved", _c_u32), ("h", _c_dbl), ("bcast_d", _c_i64)]
+
+
+class Seg(ctypes.Structure):
+    """``tsde_seg_t``."""
+    _fields_ = [("out", _c_ptr), ("s", _c_ptr), ("F", _c_ptr), ("G", _c_ptr), ("D", _c_ptr), ("n", _c_i64),
+                ("sF", _c_dbl), ("sG", _c_dbl), ("sD", _c_dbl)]
+
+
+_PTR4 = _c_ptr * 4
+
+# name -> (restype, argtypes); mirrors include/torchsde_amd.h one to one.
+SIGNATURES = {
+    "tsde_abi_version": (_c_int, []),
+    "tsde_last_error": (ctypes.c_char_p, []),
+    "tsde_philox4x32_10": (None, [ctypes.POINTER(_c_u32), ctypes.POINTER(_c_u32), ctypes.POINTER(_c_u32)]),
+    "tsde_noise_counter": (None, [_c_u64, _c_u32, _c_u64, _c_u32, ctypes.POINTER(_c_u32)]),
+    "tsde_brownian_normals": (_c_int, [_c_ptr, _c_i64, _c_u64, _c_u64, _c_u32, _c_u64, _c_u32, _c_int, _c_ptr]),
+    "tsde_brownian_query": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_u64, _c_u64, _c_ptr, _c_i64, _c_i64, _c_dbl,
+                                     _c_dbl, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr]),
+    "tsde_cell_increment": (_c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_step_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int,
+                                _c_ptr]),
+    "tsde_step_prod": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
+    "tsde_step_general": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl,
+                                   ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_milstein_v": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_dbl, ctypes.POINTER(Noise), _c_int,
+                                 _c_ptr]),
+    "tsde_milstein_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, ctypes.POINTER(Noise),
+                                    _c_int, _c_ptr]),
+    "tsde_milstein_gf_prime": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_int,
+                                        _c_ptr]),
+    "tsde_milstein_gf_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int,
+                                       ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_srk_diag_stage": (_c_int, [_c_int, _c_ptr, _c_ptr, _c_ptr, _PTR4, _PTR4, _c_i64, _c_dbl, _c_dbl, _c_dbl,
+                                     ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_aug_update": (_c_int, [ctypes.POINTER(Seg), _c_int, _c_dbl, _c_dbl, _c_int, _c_ptr]),
+    "tsde_linear_interp": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
+    "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
+    "tsde_prof_end": (_c_int, [ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and type every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"torchsde_amd: HIP extension not built ({LIB_PATH} is missing). Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C torchsde_amd/csrc`. "
+            f"There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise NativeLibraryError(f"torchsde_amd: cannot load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"torchsde_amd: {LIB_PATH} does not export `{name}`; rebuild it.") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.tsde_abi_version() != 1:
+        raise NativeLibraryError("torchsde_amd: ABI version mismatch between the Python host code and the .so")
+    _lib = lib
+    return lib
+
+
+def is_built():
+    return os.path.exists(LIB_PATH)
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.float64:
+        return F64
+    raise ValueError(f"torchsde_amd supports float32 and float64 state, got {dtype}.")
+
+
+def require_device(*tensors):
+    """The product path runs on the GPU only."""
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise NativeLibraryError(
+                "torchsde_amd: tensors must live on a ROCm device (got device "
+                f"'{t.device}'). This package is the MI355X hot path of torchsde and has no CPU fallback.")
+
+
+def stream_ptr(device=None):
+    """The HIP stream torch is currently issuing work on (so launches order with the user's f/g ops
+    and are captured by an enclosing HIP graph)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def check(code, what):
+    if code != 0:
+        lib = load()
+        msg = lib.tsde_last_error().decode("utf-8", "replace")
+        raise NativeLibraryError(f"torchsde_amd: {what} failed with hipError {code}: {msg}")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def contiguous(t):
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,136 @@
+// Standalone Brownian-increment kernels behind BrownianInterval.__call__
+// (replaces torchsde/_brownian/brownian_interval.py:589-687 and the tree/LRU/seed machinery under it).
+#include "tsde_common.h"
+#include "tsde_launch.h"
+
+namespace tsde {
+
+// ---- raw normals (test / diagnostics) -----------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kBlock) normals_kernel(T* __restrict__ out, int64_t n, NoiseKey key, uint32_t cell,
+                                                         uint64_t node, uint32_t stream_id) {
+  const uint64_t q0 = key.elem0 >> 2;
+  const uint64_t q1 = (key.elem0 + (uint64_t)n + 3) >> 2;
+  const int64_t nq = (int64_t)(q1 - q0);
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kBlock) {
+    const uint64_t quad = q0 + (uint64_t)t;
+    T v[4];
+    normal4<T>(key, quad, cell, node, stream_id, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = (int64_t)(quad * 4 + j) - (int64_t)key.elem0;
+      if (i >= 0 && i < n) out[i] = v[j];
+    }
+  }
+}
+
+// ---- general interval query ----------------------------------------------------------------------
+template <typename T, bool HAVE_H>
+__global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __restrict__ U, T* __restrict__ H,
+                                                       int64_t n, NoiseKey key, QueryArgs qa, int vec) {
+  const uint64_t q0 = key.elem0 >> 2;
+  const uint64_t q1 = (key.elem0 + (uint64_t)n + 3) >> 2;
+  const int64_t nq = (int64_t)(q1 - q0);
+  const double hq = qa.b - qa.a;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kBlock) {
+    const uint64_t quad = q0 + (uint64_t)t;
+    PieceAcc<T, HAVE_H> acc;
+    acc.clear();
+    WH4<T> root;
+    {
+      const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
+      cell_root<T, HAVE_H>(key, quad, (uint32_t)qa.ca, e - s, root);
+      if (qa.rootW != nullptr) {
+        // Pinned top-level interval: the user supplied W (and maybe H) of the single cell
+        // (brownian_interval.py:553-561, arguments `W=` / `H=`).
+        const T* rw = (const T*)qa.rootW;
+        const T* rh = (const T*)qa.rootH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t i = (int64_t)(quad * 4 + j) - (int64_t)key.elem0;
+          if (i >= 0 && i < n) {
+            root.W[j] = rw[i];
+            if (HAVE_H && rh) root.H[j] = rh[i];
+          }
+        }
+      }
+    }
+    if (qa.ca == qa.cb) {
+      const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
+      cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, qa.b, root, qa.cfg, acc);
+    } else {
+      {
+        const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
+        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, e, root, qa.cfg, acc);
+      }
+      for (int64_t c = qa.ca + 1; c < qa.cb; ++c) {
+        const double h = qa.edges[c + 1] - qa.edges[c];
+        WH4<T> P;
+        cell_root<T, HAVE_H>(key, quad, (uint32_t)c, h, P);
+        acc.push_right(P, h);
+      }
+      {
+        const double s = qa.edges[qa.cb], e = qa.edges[qa.cb + 1];
+        WH4<T> P;
+        cell_root<T, HAVE_H>(key, quad, (uint32_t)qa.cb, e - s, P);
+        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.cb, s, e, s, qa.b, P, qa.cfg, acc);
+      }
+    }
+    Pack<T, 4> w, u, hh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w.v[j] = acc.v.W[j];
+      hh.v[j] = acc.v.H[j];
+      u.v[j] = (T)hq * ((T)0.5 * acc.v.W[j] + acc.v.H[j]);  // _H_to_U, brownian_interval.py:102-103
+    }
+    const int64_t i0 = (int64_t)(quad * 4) - (int64_t)key.elem0;
+    if (vec) {
+      store<T, 4>(W, i0, w);
+      if (HAVE_H && U) store<T, 4>(U, i0, u);
+      if (HAVE_H && H) store<T, 4>(H, i0, hh);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + j;
+        if (i >= 0 && i < n) {
+          W[i] = w.v[j];
+          if (HAVE_H && U) U[i] = u.v[j];
+          if (HAVE_H && H) H[i] = hh.v[j];
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_normals(void* out, int64_t n, NoiseKey key, uint32_t cell, uint64_t node, uint32_t stream_id,
+                          hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(normals_kernel<T>, dim3(grid_for((n + 3) / 4 + 1)), dim3(kBlock), 0, s, (T*)out, n, key, cell,
+                     node, stream_id);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_query(void* W, void* U, void* H, int64_t n, NoiseKey key, const QueryArgs& qa, bool have_h,
+                        hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const bool vec = (key.elem0 % 4 == 0) && (n % 4 == 0) && aligned16(W) && (!U || aligned16(U)) &&
+                   (!H || aligned16(H));
+  const dim3 grid(grid_for((n + 3) / 4 + 1));
+  if (have_h) {
+    hipLaunchKernelGGL((query_kernel<T, true>), grid, dim3(kBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa,
+                       vec ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL((query_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key,
+                       qa, vec ? 1 : 0);
+  }
+  return hipGetLastError();
+}
+
+template hipError_t launch_normals<float>(void*, int64_t, NoiseKey, uint32_t, uint64_t, uint32_t, hipStream_t);
+template hipError_t launch_normals<double>(void*, int64_t, NoiseKey, uint32_t, uint64_t, uint32_t, hipStream_t);
+template hipError_t launch_query<float>(void*, void*, void*, int64_t, NoiseKey, const QueryArgs&, bool, hipStream_t);
+template hipError_t launch_query<double>(void*, void*, void*, int64_t, NoiseKey, const QueryArgs&, bool, hipStream_t);
+
+}  // namespace tsde

@@ -1,0 +1,266 @@
+// extern "C" surface of libtorchsde_amd.so (declared in include/torchsde_amd.h).
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "tsde_common.h"
+#include "tsde_launch.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(hipError_t e, const char* where) {
+  if (e != hipSuccess) snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return (int)e;
+}
+
+int bad_arg(const char* where, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, what);
+  return (int)hipErrorInvalidValue;
+}
+
+tsde::NoiseKey make_key(uint64_t entropy, uint64_t elem0) {
+  tsde::NoiseKey k;
+  k.k0 = (uint32_t)entropy;
+  k.k1 = (uint32_t)(entropy >> 32);
+  k.elem0 = elem0;
+  return k;
+}
+
+// ---- optional per-launch HIP-event timing of one kernel family -------------------------------------
+struct Prof {
+  int kid = 0;
+  int cap = 0;
+  int used = 0;
+  std::vector<hipEvent_t> ev;  // 2 per launch
+} g_prof;
+
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  int slot;
+  ProfScope(int kid, hipStream_t stream) : on(false), s(stream), slot(0) {
+    if (g_prof.kid == kid && g_prof.used < g_prof.cap) {
+      on = true;
+      slot = g_prof.used++;
+      (void)hipEventRecord(g_prof.ev[2 * slot], s);
+    }
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+  }
+};
+
+#define TSDE_DISPATCH(dtype, where, expr_f32, expr_f64)         \
+  do {                                                          \
+    if ((dtype) == TSDE_F32) return fail((expr_f32), where);    \
+    if ((dtype) == TSDE_F64) return fail((expr_f64), where);    \
+    return bad_arg(where, "dtype must be TSDE_F32 or TSDE_F64"); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int tsde_abi_version(void) { return TSDE_ABI_VERSION; }
+
+const char* tsde_last_error(void) { return g_err; }
+
+void tsde_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  const tsde::u32x4 r = tsde::philox4x32_10({ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
+  out[0] = r.x;
+  out[1] = r.y;
+  out[2] = r.z;
+  out[3] = r.w;
+}
+
+void tsde_noise_counter(uint64_t quad, uint32_t cell, uint64_t node, uint32_t stream, uint32_t out[4]) {
+  const tsde::u32x4 c = tsde::noise_counter(quad, cell, node, stream);
+  out[0] = c.x;
+  out[1] = c.y;
+  out[2] = c.z;
+  out[3] = c.w;
+}
+
+int tsde_brownian_normals(void* out, int64_t n, uint64_t entropy, uint64_t elem0, uint32_t cell, uint64_t node,
+                          uint32_t stream_id, int dtype, void* stream) {
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  TSDE_DISPATCH(dtype, "tsde_brownian_normals", tsde::launch_normals<float>(out, n, key, cell, node, stream_id, s),
+                tsde::launch_normals<double>(out, n, key, cell, node, stream_id, s));
+}
+
+int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,
+                        int64_t ca, int64_t cb, double a, double b, const void* rootW, const void* rootH, int have_h,
+                        int max_depth, int snap, int dtype, void* stream) {
+  if (!W || !edges) return bad_arg("tsde_brownian_query", "W and edges are required");
+  if (ca < 0 || cb < ca || !(a < b)) return bad_arg("tsde_brownian_query", "need 0 <= ca <= cb and a < b");
+  if ((U || H) && !have_h) return bad_arg("tsde_brownian_query", "U/H requested without have_h");
+  if (max_depth < 0 || max_depth > 40) return bad_arg("tsde_brownian_query", "max_depth must be in [0, 40]");
+  if (rootW && (ca != 0 || cb != 0)) return bad_arg("tsde_brownian_query", "a pinned root needs a single cell");
+  if (rootH && !rootW) return bad_arg("tsde_brownian_query", "rootH without rootW");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  tsde::QueryArgs qa;
+  qa.edges = edges;
+  qa.ca = ca;
+  qa.cb = cb;
+  qa.a = a;
+  qa.b = b;
+  qa.rootW = rootW;
+  qa.rootH = rootH;
+  qa.cfg.max_depth = max_depth;
+  qa.cfg.snap = snap;
+  ProfScope p(TSDE_KID_BROWNIAN_QUERY, s);
+  TSDE_DISPATCH(dtype, "tsde_brownian_query", tsde::launch_query<float>(W, U, H, n, key, qa, have_h != 0, s),
+                tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
+}
+
+int tsde_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!W_out || !noise) return bad_arg("tsde_cell_increment", "null argument");
+  if (noise->dW) return bad_arg("tsde_cell_increment", "noise must describe a generated cell (dW == NULL)");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_cell_increment", tsde::launch_cell_increment<float>(W_out, U_out, n, noise, s),
+                tsde::launch_cell_increment<double>(W_out, U_out, n, noise, s));
+}
+
+int tsde_step_diag(void* y1, const void* y0, const void* f, const void* g, int64_t n, double cf, double cg,
+                   const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y1 || !y0 || !f || !g || !noise) return bad_arg("tsde_step_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_STEP_DIAG, s);
+  TSDE_DISPATCH(dtype, "tsde_step_diag", tsde::launch_step_diag<float>(y1, y0, f, g, n, cf, cg, noise, s),
+                tsde::launch_step_diag<double>(y1, y0, f, g, n, cf, cg, noise, s));
+}
+
+int tsde_step_prod(void* y1, const void* y0, const void* f, const void* gp, int64_t n, double cf, double cg, int dtype,
+                   void* stream) {
+  if (!y1 || !y0 || !f || !gp) return bad_arg("tsde_step_prod", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_step_prod", tsde::launch_step_prod<float>(y1, y0, f, gp, n, cf, cg, s),
+                tsde::launch_step_prod<double>(y1, y0, f, gp, n, cf, cg, s));
+}
+
+int tsde_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
+                      double cf, double cg, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y1 || !y0 || !f || !g || !noise) return bad_arg("tsde_step_general", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_STEP_GENERAL, s);
+  TSDE_DISPATCH(dtype, "tsde_step_general", tsde::launch_step_general<float>(y1, y0, f, g, B, d, m, cf, cg, noise, s),
+                tsde::launch_step_general<double>(y1, y0, f, g, B, d, m, cf, cg, noise, s));
+}
+
+int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale, const tsde_noise_t* noise,
+                    int dtype, void* stream) {
+  if (!v_out || !noise) return bad_arg("tsde_milstein_v", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_milstein_v", tsde::launch_milstein_v<float>(v_out, W_out, n, dt, ito, scale, noise, s),
+                tsde::launch_milstein_v<double>(v_out, W_out, n, dt, ito, scale, noise, s));
+}
+
+int tsde_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n, double dt,
+                       const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y1 || !y0 || !f || !g || !gdg || !noise) return bad_arg("tsde_milstein_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_MILSTEIN_DIAG, s);
+  TSDE_DISPATCH(dtype, "tsde_milstein_diag", tsde::launch_milstein_diag<float>(y1, y0, f, g, gdg, n, dt, noise, s),
+                tsde::launch_milstein_diag<double>(y1, y0, f, g, gdg, n, dt, noise, s));
+}
+
+int tsde_milstein_gf_prime(void* yp, const void* y0, const void* f, const void* g, int64_t n, double dt,
+                           double sqrt_dt, int ito, int dtype, void* stream) {
+  if (!yp || !y0 || !f || !g) return bad_arg("tsde_milstein_gf_prime", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_milstein_gf_prime",
+                tsde::launch_milstein_gf_prime<float>(yp, y0, f, g, n, dt, sqrt_dt, ito, s),
+                tsde::launch_milstein_gf_prime<double>(yp, y0, f, g, n, dt, sqrt_dt, ito, s));
+}
+
+int tsde_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gprime, int64_t n,
+                          double dt, double sqrt_dt, int ito, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y1 || !y0 || !f || !g || !gprime || !noise) return bad_arg("tsde_milstein_gf_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_MILSTEIN_DIAG, s);
+  TSDE_DISPATCH(dtype, "tsde_milstein_gf_diag",
+                tsde::launch_milstein_gf_diag<float>(y1, y0, f, g, gprime, n, dt, sqrt_dt, ito, noise, s),
+                tsde::launch_milstein_gf_diag<double>(y1, y0, f, g, gprime, n, dt, sqrt_dt, ito, noise, s));
+}
+
+int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
+                        const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
+                        const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y0 || !fs || !gs || !noise) return bad_arg("tsde_srk_diag_stage", "null argument");
+  if (stage < 1 || stage > 4) return bad_arg("tsde_srk_diag_stage", "stage must be 1..4");
+  for (int j = 0; j < stage && j < 4; ++j) {
+    const bool need_g = (stage < 4) ? (j < stage) : true;
+    if (need_g && !gs[j]) return bad_arg("tsde_srk_diag_stage", "missing g pointer");
+  }
+  if (stage == 4 && (!fs[0] || !fs[1] || !fs[2] || !gs[3] || !out0))
+    return bad_arg("tsde_srk_diag_stage", "stage 4 needs f0..f2, g0..g3, out0");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_SRK_STAGE, s);
+  TSDE_DISPATCH(dtype, "tsde_srk_diag_stage",
+                tsde::launch_srk_stage<float>(stage, out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, noise, s),
+                tsde::launch_srk_stage<double>(stage, out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, noise, s));
+}
+
+int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int dtype, void* stream) {
+  if (!segs || nseg < 0) return bad_arg("tsde_aug_update", "bad segment list");
+  if (dtype != TSDE_F32 && dtype != TSDE_F64) return bad_arg("tsde_aug_update", "dtype");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_AUG_UPDATE, s);
+  for (int i = 0; i < nseg; ++i) {
+    if (segs[i].n == 0) continue;
+    if (!segs[i].out || !segs[i].s) return bad_arg("tsde_aug_update", "segment without state");
+    const hipError_t e = (dtype == TSDE_F32) ? tsde::launch_aug_seg<float>(segs[i], cF, cG, s)
+                                             : tsde::launch_aug_seg<double>(segs[i], cF, cG, s);
+    if (e != hipSuccess) return fail(e, "tsde_aug_update");
+  }
+  return 0;
+}
+
+int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, int dtype,
+                       void* stream) {
+  if (!out || !ya || !yb) return bad_arg("tsde_linear_interp", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_linear_interp", tsde::launch_interp<float>(out, ya, yb, n, w0, w1, s),
+                tsde::launch_interp<double>(out, ya, yb, n, w0, w1, s));
+}
+
+int tsde_prof_begin(int kid, int capacity) {
+  if (capacity <= 0) return bad_arg("tsde_prof_begin", "capacity must be positive");
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.ev.resize(2 * (size_t)capacity);
+  for (auto& e : g_prof.ev) {
+    const hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return fail(r, "tsde_prof_begin");
+  }
+  g_prof.kid = kid;
+  g_prof.cap = capacity;
+  g_prof.used = 0;
+  return 0;
+}
+
+int tsde_prof_end(double* total_ms, int64_t* launches) {
+  double sum = 0.0;
+  hipError_t r = hipSuccess;
+  for (int i = 0; i < g_prof.used && r == hipSuccess; ++i) {
+    r = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+    float ms = 0.f;
+    if (r == hipSuccess) r = hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    sum += ms;
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = g_prof.used;
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.kid = 0;
+  g_prof.cap = 0;
+  g_prof.used = 0;
+  return fail(r, "tsde_prof_end");
+}
+
+}  // extern "C"

@@ -1,0 +1,594 @@
+// Fused per-step solver updates for gfx950: one kernel per solver stage over the flat (batch, state) axis,
+// 16 B per lane, Brownian increment generated in registers (tsde_common.h: cell_noise).
+//
+// Reference arithmetic being reproduced (operation order kept, one rounding per op):
+//   Euler      torchsde/_core/methods/euler.py:31-36        y1 = y0 + f*dt + g_prod
+//   Midpoint   torchsde/_core/methods/midpoint.py:31-43
+//   Milstein   torchsde/_core/methods/milstein.py:52-94
+//   SRK/SRID2  torchsde/_core/methods/srk.py:57-88, tableaus/srid2.py:19-54
+//   prod       torchsde/_core/base_sde.py:98-102 (diagonal: g*v; otherwise bmm(g, v))
+#include "tsde_common.h"
+#include "tsde_launch.h"
+
+namespace tsde {
+
+// ---- y1 = (y0 + cf*f) + cg*(g*dW) ------------------------------------------------------------------
+template <typename T>
+struct StepDiagOp {
+  T* y1;
+  const T *y0, *f, *g;
+  T cf, cg;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(g, i);
+    Pack<T, W> w, u, o;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + b.v[j] * cf) + cg * (c.v[j] * w.v[j]);
+    store<T, W>(y1, i, o);
+  }
+};
+
+// ---- y1 = (y0 + cf*f) + cg*gp ----------------------------------------------------------------------
+template <typename T>
+struct StepProdOp {
+  T* y1;
+  const T *y0, *f, *gp;
+  T cf, cg;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(gp, i);
+    Pack<T, W> o;
+#pragma unroll
+    for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + b.v[j] * cf) + cg * c.v[j];
+    store<T, W>(y1, i, o);
+  }
+};
+
+// ---- materialise the increment of one cell (for user code that needs dW as a tensor) ---------------
+template <typename T>
+struct CellIncrementOp {
+  T *W_out, *U_out;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    Pack<T, W> w, u;
+    if (U_out) {
+      cell_noise<T, W, true>(nz, i, w, u);
+      store<T, W>(U_out, i, u);
+    } else {
+      cell_noise<T, W, false>(nz, i, w, u);
+    }
+    store<T, W>(W_out, i, w);
+  }
+};
+
+// ---- Milstein ------------------------------------------------------------------------------------
+template <typename T>
+struct MilsteinVOp {
+  T *v_out, *W_out;
+  T dt, scale;
+  int ito;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    Pack<T, W> w, u, o;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const T sq = w.v[j] * w.v[j];
+      o.v[j] = scale * (ito ? (sq - dt) : sq);
+    }
+    store<T, W>(v_out, i, o);
+    if (W_out) store<T, W>(W_out, i, w);
+  }
+};
+
+template <typename T>
+struct MilsteinDiagOp {
+  T* y1;
+  const T *y0, *f, *g, *gdg;
+  T dt;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(g, i), d = load<T, W>(gdg, i);
+    Pack<T, W> w, u, o;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) o.v[j] = ((a.v[j] + b.v[j] * dt) + c.v[j] * w.v[j]) + d.v[j];
+    store<T, W>(y1, i, o);
+  }
+};
+
+template <typename T>
+struct MilsteinGfPrimeOp {
+  T* yp;
+  const T *y0, *f, *g;
+  T dt, sqrt_dt;
+  int ito;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(y0, i), c = load<T, W>(g, i);
+    Pack<T, W> o;
+    if (ito) {
+      const Pack<T, W> b = load<T, W>(f, i);
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + dt * b.v[j]) + c.v[j] * sqrt_dt;
+    } else {
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + (T)0) + c.v[j] * sqrt_dt;
+    }
+    store<T, W>(yp, i, o);
+  }
+};
+
+template <typename T>
+struct MilsteinGfDiagOp {
+  T* y1;
+  const T *y0, *f, *g, *gp;
+  T dt, two_sqrt_dt;
+  int ito;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(g, i), d = load<T, W>(gp, i);
+    Pack<T, W> w, u, o;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const T sq = w.v[j] * w.v[j];
+      const T v = ito ? (sq - dt) : sq;
+      const T gdg = ((d.v[j] - c.v[j]) * v) / two_sqrt_dt;
+      o.v[j] = ((a.v[j] + b.v[j] * dt) + c.v[j] * w.v[j]) + gdg;
+    }
+    store<T, W>(y1, i, o);
+  }
+};
+
+// ---- SRK (SRID2, diagonal noise) -----------------------------------------------------------------
+// Tableau (srid2.py:21-54); entries are cast to T at use, exactly like `python_float * tensor`.
+struct Srid2 {
+  static TSDE_HD constexpr double A0(int s, int j) {
+    constexpr double t[4][3] = {{0, 0, 0}, {1, 0, 0}, {0.25, 0.25, 0}, {0, 0, 0}};
+    return t[s][j];
+  }
+  static TSDE_HD constexpr double A1(int s, int j) {
+    constexpr double t[4][3] = {{0, 0, 0}, {0.25, 0, 0}, {1, 0, 0}, {0, 0, 0.25}};
+    return t[s][j];
+  }
+  static TSDE_HD constexpr double B0(int s, int j) {
+    constexpr double t[4][3] = {{0, 0, 0}, {0, 0, 0}, {1, 0.5, 0}, {0, 0, 0}};
+    return t[s][j];
+  }
+  static TSDE_HD constexpr double B1(int s, int j) {
+    constexpr double t[4][3] = {{0, 0, 0}, {-0.5, 0, 0}, {1, 0, 0}, {2, -1, 0.5}};
+    return t[s][j];
+  }
+  static TSDE_HD constexpr double alpha(int s) {
+    constexpr double t[4] = {1.0 / 6, 1.0 / 6, 2.0 / 3, 0};
+    return t[s];
+  }
+  static TSDE_HD constexpr double beta1(int s) {
+    constexpr double t[4] = {-1, 4.0 / 3, 2.0 / 3, 0};
+    return t[s];
+  }
+  static TSDE_HD constexpr double beta2(int s) {
+    constexpr double t[4] = {1, -4.0 / 3, 1.0 / 3, 0};
+    return t[s];
+  }
+  static TSDE_HD constexpr double beta3(int s) {
+    constexpr double t[4] = {2, -4.0 / 3, -2.0 / 3, 0};
+    return t[s];
+  }
+  static TSDE_HD constexpr double beta4(int s) {
+    constexpr double t[4] = {-2, 5.0 / 3, -2.0 / 3, 1};
+    return t[s];
+  }
+};
+
+template <typename T, int STAGE>
+struct SrkDiagOp {
+  T *out0, *out1;
+  const T* y0;
+  const T* fs[4];
+  const T* gs[4];
+  T dt, rdt, sqrt_dt;
+  CellNoise<T> nz;
+
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> y = load<T, W>(y0, i);
+    Pack<T, W> w, u;
+    cell_noise<T, W, true>(nz, i, w, u);
+    if constexpr (STAGE < 4) {
+      // Stage states H0_s, H1_s for s = STAGE (srk.py:69-77). f-terms whose A-coefficient is zero
+      // for every j are not loaded (they only add +0.0).
+      constexpr int s = STAGE;
+      Pack<T, W> fj[3], gj[3];
+#pragma unroll
+      for (int j = 0; j < s; ++j) {
+        const bool need_f = (Srid2::A0(s, j) != 0.0) || (Srid2::A1(s, j) != 0.0);
+        if (need_f) fj[j] = load<T, W>(fs[j], i);
+        gj[j] = load<T, W>(gs[j], i);
+      }
+      Pack<T, W> h0 = y, h1 = y;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+#pragma unroll
+        for (int j = 0; j < s; ++j) {
+          const bool need_f = (Srid2::A0(s, j) != 0.0) || (Srid2::A1(s, j) != 0.0);
+          const T f = need_f ? fj[j].v[k] : (T)0;
+          const T g = gj[j].v[k];
+          h0.v[k] = (h0.v[k] + ((T)Srid2::A0(s, j) * f) * dt) + (((T)Srid2::B0(s, j) * g) * u.v[k]) * rdt;
+          h1.v[k] = (h1.v[k] + ((T)Srid2::A1(s, j) * f) * dt) + ((T)Srid2::B1(s, j) * g) * sqrt_dt;
+        }
+      }
+      if (out0) store<T, W>(out0, i, h0);
+      if (out1) store<T, W>(out1, i, h1);
+    } else {
+      // y1 = y0 + sum_s [alpha_s f_s dt + g_s * g_weight_s]   (srk.py:79-87); alpha_3 = 0 so f_3 is skipped.
+      Pack<T, W> acc = y;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const Pack<T, W> g = load<T, W>(gs[s], i);
+        Pack<T, W> f;
+        if (s < 3) f = load<T, W>(fs[s], i);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          const T Ik = w.v[k];
+          const T Ikk = (Ik * Ik - dt) * (T)0.5;
+          const T Ikkk = ((Ik * Ik) * Ik - ((T)3 * dt) * Ik) * (T)(1.0 / 6);
+          const T gw = ((((T)Srid2::beta1(s) * Ik) + ((T)Srid2::beta2(s) * Ikk) / sqrt_dt) +
+                        ((T)Srid2::beta3(s) * u.v[k]) * rdt) +
+                       ((T)Srid2::beta4(s) * Ikkk) * rdt;
+          const T drift = (s < 3) ? ((T)Srid2::alpha(s) * f.v[k]) * dt : (T)0;
+          acc.v[k] = (acc.v[k] + drift) + g.v[k] * gw;
+        }
+      }
+      store<T, W>(out0, i, acc);
+    }
+  }
+};
+
+// ---- adjoint augmented-state update ----------------------------------------------------------------
+template <typename T>
+struct AugSegOp {
+  T* out;
+  const T *s, *F, *G, *D;
+  T cF, cG, sF, sG, sD;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    Pack<T, W> o = load<T, W>(s, i);
+    if (F) {
+      const Pack<T, W> x = load<T, W>(F, i);
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = o.v[j] + sF * (x.v[j] * cF);
+    }
+    if (G) {
+      const Pack<T, W> x = load<T, W>(G, i);
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = o.v[j] + sG * (cG * x.v[j]);
+    }
+    if (D) {
+      const Pack<T, W> x = load<T, W>(D, i);
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = o.v[j] + sD * x.v[j];
+    }
+    store<T, W>(out, i, o);
+  }
+};
+
+template <typename T>
+struct InterpOp {
+  T* out;
+  const T *ya, *yb;
+  T w0, w1;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(ya, i), b = load<T, W>(yb, i);
+    Pack<T, W> o;
+#pragma unroll
+    for (int j = 0; j < W; ++j) o.v[j] = w0 * a.v[j] + w1 * b.v[j];
+    store<T, W>(out, i, o);
+  }
+};
+
+// ---- general-noise contraction: y1 = (y0 + cf*f) + cg * sum_j g[b,i,j] dW[b,j] ---------------------
+// HBM-bound on g (d*m*4 B per row vs 12*d for y0,f,y1): g is streamed with perfectly coalesced 16-B
+// loads, the row's increment vector is generated once per block into LDS (one Philox call per 4
+// channels) and the m-long dot products are reduced across the m/4 neighbouring lanes with DPP shuffles.
+constexpr int kGenMaxNoise = 2048;  // LDS floats/doubles of staged increments per block
+
+template <typename T>
+struct GeneralArgs {
+  T* y1;
+  const T *y0, *f, *g;
+  int64_t B, d, m;
+  T cf, cg;
+  CellNoise<T> nz;
+  int rows_per_tile;
+};
+
+template <typename T>
+TSDE_D void stage_noise(const CellNoise<T>& nz, T* lds, int64_t row0, int rows, int64_t m, int64_t B) {
+  // lds[r*m + j] = dW[row0 + r, j]
+  const int64_t cnt = (int64_t)rows * m;
+  const int64_t base = row0 * m;
+  if (nz.dW != nullptr) {
+    for (int64_t t = threadIdx.x; t < cnt; t += kBlock) lds[t] = (base + t < B * m) ? nz.dW[base + t] : (T)0;
+  } else {
+    const T sw = (T)sqrt(nz.h);
+    const uint64_t e0 = nz.key.elem0 + (uint64_t)base;
+    const uint64_t q0 = e0 >> 2, q1 = (e0 + (uint64_t)cnt + 3) >> 2;
+    for (uint64_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
+      T n[4];
+      normal4<T>(nz.key, q, nz.cell, 0, kStreamW, n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t t = (int64_t)(q * 4 + j) - (int64_t)e0;
+        if (t >= 0 && t < cnt) lds[t] = n[j] * sw;
+      }
+    }
+  }
+}
+
+// Fast path: m % 4 == 0, G = m/4 a power of two <= 64, everything 16-B aligned.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<T> a) {
+  __shared__ __attribute__((aligned(16))) T lds[kGenMaxNoise];
+  const int G = (int)(a.m >> 2);
+  const int64_t vec_per_row = a.d * G;  // float4 groups of g per batch row
+  const int64_t n_tiles = (a.B + a.rows_per_tile - 1) / a.rows_per_tile;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * a.rows_per_tile;
+    const int rows = (int)((a.B - row0 < a.rows_per_tile) ? (a.B - row0) : a.rows_per_tile);
+    __syncthreads();
+    stage_noise<T>(a.nz, lds, row0, rows, a.m, a.B);
+    __syncthreads();
+    const int64_t nv = (int64_t)rows * vec_per_row;
+    const int64_t nv_pad = (nv + kBlock - 1) / kBlock * kBlock;  // keep whole waves in the shuffles
+    for (int64_t v = threadIdx.x; v < nv_pad; v += kBlock) {
+      T part = (T)0;
+      const bool live = v < nv;
+      int64_t out_idx = 0;
+      if (live) {
+        const int64_t r = v / vec_per_row;
+        const int64_t rem = v - r * vec_per_row;
+        const int lp = (int)(rem & (G - 1));
+        const Pack<T, 4> gq = load<T, 4>(a.g, (row0 * vec_per_row + v) * 4);
+        const Pack<T, 4> wq = load<T, 4>(lds, r * a.m + (int64_t)lp * 4);
+        part = ((gq.v[0] * wq.v[0] + gq.v[1] * wq.v[1]) + gq.v[2] * wq.v[2]) + gq.v[3] * wq.v[3];
+        out_idx = (row0 + r) * a.d + (rem >> __builtin_ctz(G));
+      }
+      for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
+      if (live && (v & (G - 1)) == 0) {
+        a.y1[out_idx] = (a.y0[out_idx] + a.cf * a.f[out_idx]) + a.cg * part;
+      }
+    }
+  }
+}
+
+// Generic path: any d, m (m*rows_per_tile <= kGenMaxNoise): one thread per output, scalar loads of g.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralArgs<T> a) {
+  __shared__ T lds[kGenMaxNoise];
+  const int64_t n_tiles = (a.B + a.rows_per_tile - 1) / a.rows_per_tile;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * a.rows_per_tile;
+    const int rows = (int)((a.B - row0 < a.rows_per_tile) ? (a.B - row0) : a.rows_per_tile);
+    __syncthreads();
+    stage_noise<T>(a.nz, lds, row0, rows, a.m, a.B);
+    __syncthreads();
+    const int64_t nout = (int64_t)rows * a.d;
+    for (int64_t o = threadIdx.x; o < nout; o += kBlock) {
+      const int64_t r = o / a.d;
+      const int64_t idx = row0 * a.d + o;
+      const T* grow = a.g + idx * a.m;
+      const T* wrow = lds + r * a.m;
+      T acc = (T)0;
+      for (int64_t j = 0; j < a.m; ++j) acc += grow[j] * wrow[j];
+      a.y1[idx] = (a.y0[idx] + a.cf * a.f[idx]) + a.cg * acc;
+    }
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+template <typename T>
+static CellNoise<T> make_noise(const tsde_noise_t* nz) {
+  CellNoise<T> c;
+  c.dW = (const T*)nz->dW;
+  c.dU = (const T*)nz->dU;
+  c.key.k0 = (uint32_t)nz->entropy;
+  c.key.k1 = (uint32_t)(nz->entropy >> 32);
+  c.key.elem0 = nz->elem0;
+  c.cell = nz->cell;
+  c.h = nz->h;
+  c.bcast_d = nz->bcast_d;
+  return c;
+}
+
+static bool noise_vec_ok(const tsde_noise_t* nz, bool need_u) {
+  if (nz->dW == nullptr) return (nz->elem0 % 4) == 0;
+  if (nz->bcast_d > 0) return (nz->bcast_d % 4) == 0;  // 4 consecutive elements share a row only if d % 4 == 0
+  return aligned16(nz->dW) && (!need_u || aligned16(nz->dU));
+}
+
+template <typename T>
+hipError_t launch_step_diag(void* y1, const void* y0, const void* f, const void* g, int64_t n, double cf, double cg,
+                            const tsde_noise_t* nz, hipStream_t s) {
+  StepDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (T)cf, (T)cg, make_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) &&
+                   noise_vec_ok(nz, false);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* nz, hipStream_t s) {
+  CellIncrementOp<T> op{(T*)W_out, (T*)U_out, make_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(W_out) && (!U_out || aligned16(U_out)) && (nz->elem0 % 4 == 0);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_step_prod(void* y1, const void* y0, const void* f, const void* gp, int64_t n, double cf, double cg,
+                            hipStream_t s) {
+  StepProdOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)gp, (T)cf, (T)cg};
+  const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(gp);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
+                             const tsde_noise_t* nz, hipStream_t s) {
+  MilsteinVOp<T> op{(T*)v_out, (T*)W_out, (T)dt, (T)scale, ito, make_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(v_out) && (!W_out || aligned16(W_out)) && noise_vec_ok(nz, false);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n,
+                                double dt, const tsde_noise_t* nz, hipStream_t s) {
+  MilsteinDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gdg, (T)dt, make_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) && aligned16(gdg) &&
+                   noise_vec_ok(nz, false);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_milstein_gf_prime(void* yp, const void* y0, const void* f, const void* g, int64_t n, double dt,
+                                    double sqrt_dt, int ito, hipStream_t s) {
+  MilsteinGfPrimeOp<T> op{(T*)yp, (const T*)y0, (const T*)f, (const T*)g, (T)dt, (T)sqrt_dt, ito};
+  const bool vec = (n % 4 == 0) && aligned16(yp) && aligned16(y0) && aligned16(f) && aligned16(g);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gp, int64_t n,
+                                   double dt, double sqrt_dt, int ito, const tsde_noise_t* nz, hipStream_t s) {
+  // `2 * sqrt_dt` is a 0-d tensor product in the reference (milstein.py:67): rounded in T.
+  const T two_sqrt = (T)2 * (T)sqrt_dt;
+  MilsteinGfDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gp, (T)dt, two_sqrt, ito,
+                         make_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) && aligned16(gp) &&
+                   noise_vec_ok(nz, false);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T, int STAGE>
+static hipError_t launch_srk_stage_t(void* out0, void* out1, const void* y0, const void* const fs[4],
+                                     const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
+                                     const tsde_noise_t* nz, hipStream_t s) {
+  SrkDiagOp<T, STAGE> op;
+  op.out0 = (T*)out0;
+  op.out1 = (T*)out1;
+  op.y0 = (const T*)y0;
+  bool vec = (n % 4 == 0) && aligned16(y0) && (!out0 || aligned16(out0)) && (!out1 || aligned16(out1)) &&
+             noise_vec_ok(nz, true);
+  for (int j = 0; j < 4; ++j) {
+    op.fs[j] = (const T*)fs[j];
+    op.gs[j] = (const T*)gs[j];
+    vec = vec && (!fs[j] || aligned16(fs[j])) && (!gs[j] || aligned16(gs[j]));
+  }
+  op.dt = (T)dt;
+  op.rdt = (T)rdt;
+  op.sqrt_dt = (T)sqrt_dt;
+  op.nz = make_noise<T>(nz);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_srk_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
+                            const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
+                            const tsde_noise_t* nz, hipStream_t s) {
+  switch (stage) {
+    case 1: return launch_srk_stage_t<T, 1>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
+    case 2: return launch_srk_stage_t<T, 2>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
+    case 3: return launch_srk_stage_t<T, 3>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
+    case 4: return launch_srk_stage_t<T, 4>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <typename T>
+hipError_t launch_aug_seg(const tsde_seg_t& sg, double cF, double cG, hipStream_t s) {
+  AugSegOp<T> op{(T*)sg.out, (const T*)sg.s, (const T*)sg.F, (const T*)sg.G, (const T*)sg.D,
+                 (T)cF,      (T)cG,          (T)sg.sF,       (T)sg.sG,       (T)sg.sD};
+  const bool vec = (sg.n % 4 == 0) && aligned16(sg.out) && aligned16(sg.s) && (!sg.F || aligned16(sg.F)) &&
+                   (!sg.G || aligned16(sg.G)) && (!sg.D || aligned16(sg.D));
+  return launch_elementwise(op, sg.n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s) {
+  InterpOp<T> op{(T*)out, (const T*)ya, (const T*)yb, (T)w0, (T)w1};
+  const bool vec = (n % 4 == 0) && aligned16(out) && aligned16(ya) && aligned16(yb);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
+                               double cf, double cg, const tsde_noise_t* nz, hipStream_t s) {
+  if (B <= 0 || d <= 0) return hipSuccess;
+  if (m <= 0 || m > kGenMaxNoise) return hipErrorInvalidValue;
+  GeneralArgs<T> a;
+  a.y1 = (T*)y1;
+  a.y0 = (const T*)y0;
+  a.f = (const T*)f;
+  a.g = (const T*)g;
+  a.B = B;
+  a.d = d;
+  a.m = m;
+  a.cf = (T)cf;
+  a.cg = (T)cg;
+  a.nz = make_noise<T>(nz);
+  const int64_t G = m / 4;
+  const bool pow2 = (m % 4 == 0) && G >= 1 && G <= 64 && ((G & (G - 1)) == 0);
+  const bool fast = pow2 && aligned16(g);
+  // Rows per tile: enough float4 groups to keep 256 lanes busy for a few iterations, bounded by LDS.
+  int64_t rows = kGenMaxNoise / m;
+  if (fast) {
+    const int64_t want = (4 * kBlock + d * G - 1) / (d * G);  // ~4 vector loads per lane per tile
+    if (rows > want) rows = want;
+  } else {
+    const int64_t want = (2 * kBlock + d - 1) / d;
+    if (rows > want) rows = want;
+  }
+  if (rows < 1) rows = 1;
+  a.rows_per_tile = (int)rows;
+  const int64_t n_tiles = (B + rows - 1) / rows;
+  const int grid = (int)(n_tiles < kMaxGrid ? n_tiles : kMaxGrid);
+  if (fast) {
+    hipLaunchKernelGGL(general_fast_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(general_generic_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+#define TSDE_INSTANTIATE(T)                                                                                          \
+  template hipError_t launch_cell_increment<T>(void*, void*, int64_t, const tsde_noise_t*, hipStream_t);             \
+  template hipError_t launch_step_diag<T>(void*, const void*, const void*, const void*, int64_t, double, double,     \
+                                          const tsde_noise_t*, hipStream_t);                                         \
+  template hipError_t launch_step_prod<T>(void*, const void*, const void*, const void*, int64_t, double, double,     \
+                                          hipStream_t);                                                              \
+  template hipError_t launch_step_general<T>(void*, const void*, const void*, const void*, int64_t, int64_t, int64_t, \
+                                             double, double, const tsde_noise_t*, hipStream_t);                      \
+  template hipError_t launch_milstein_v<T>(void*, void*, int64_t, double, int, double, const tsde_noise_t*,          \
+                                           hipStream_t);                                                             \
+  template hipError_t launch_milstein_diag<T>(void*, const void*, const void*, const void*, const void*, int64_t,    \
+                                              double, const tsde_noise_t*, hipStream_t);                             \
+  template hipError_t launch_milstein_gf_prime<T>(void*, const void*, const void*, const void*, int64_t, double,     \
+                                                  double, int, hipStream_t);                                         \
+  template hipError_t launch_milstein_gf_diag<T>(void*, const void*, const void*, const void*, const void*, int64_t, \
+                                                 double, double, int, const tsde_noise_t*, hipStream_t);             \
+  template hipError_t launch_srk_stage<T>(int, void*, void*, const void*, const void* const[4], const void* const[4], \
+                                          int64_t, double, double, double, const tsde_noise_t*, hipStream_t);        \
+  template hipError_t launch_aug_seg<T>(const tsde_seg_t&, double, double, hipStream_t);                             \
+  template hipError_t launch_interp<T>(void*, const void*, const void*, int64_t, double, double, hipStream_t);
+
+TSDE_INSTANTIATE(float)
+TSDE_INSTANTIATE(double)
+
+}  // namespace tsde

@@ -1,0 +1,136 @@
+// Shared launch plumbing for the gfx950 kernels: 16-byte packs, grid sizing, noise sources.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsde_bridge.h"
+#include "tsde_rng.h"
+
+namespace tsde {
+
+constexpr int kBlock = 256;         // 4 waves of 64 lanes
+constexpr int kMaxGrid = 256 * 8;   // 256 CUs x 8 resident blocks; the rest is grid-stride
+
+// W contiguous elements of T. W=4 is the vector path: 16 B (fp32) or 2x16 B (fp64) per lane.
+template <typename T, int W>
+struct Pack {
+  T v[W];
+};
+
+template <typename T, int W>
+TSDE_D Pack<T, W> load(const T* __restrict__ p, int64_t i) {
+  Pack<T, W> r;
+  if constexpr (W == 4 && sizeof(T) == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p + i);
+    r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+  } else if constexpr (W == 4 && sizeof(T) == 8) {
+    const double2 q0 = *reinterpret_cast<const double2*>(p + i);
+    const double2 q1 = *reinterpret_cast<const double2*>(p + i + 2);
+    r.v[0] = q0.x; r.v[1] = q0.y; r.v[2] = q1.x; r.v[3] = q1.y;
+  } else {
+#pragma unroll
+    for (int j = 0; j < W; ++j) r.v[j] = p[i + j];
+  }
+  return r;
+}
+
+template <typename T, int W>
+TSDE_D void store(T* __restrict__ p, int64_t i, const Pack<T, W>& r) {
+  if constexpr (W == 4 && sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else if constexpr (W == 4 && sizeof(T) == 8) {
+    *reinterpret_cast<double2*>(p + i) = make_double2(r.v[0], r.v[1]);
+    *reinterpret_cast<double2*>(p + i + 2) = make_double2(r.v[2], r.v[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < W; ++j) p[i + j] = r.v[j];
+  }
+}
+
+// The Brownian increment of ONE grid cell, as the step kernels consume it.
+//   dW  == nullptr : generate in registers from (key, cell, h)              [fused, 0 bytes of HBM]
+//   dW  != nullptr : read a materialised increment (foreign bm / replay).   [+4 B per element]
+// `bcast_d` > 0 reads the external tensor with one value per row of d state channels (scalar noise).
+template <typename T>
+struct CellNoise {
+  const T* dW;
+  const T* dU;
+  NoiseKey key;
+  uint32_t cell;
+  double h;
+  int64_t bcast_d;
+};
+
+// W and (optionally) U = h (W/2 + H) for W consecutive elements starting at local index i.
+template <typename T, int W, bool NEED_U>
+TSDE_D void cell_noise(const CellNoise<T>& nz, int64_t i, Pack<T, W>& w, Pack<T, W>& u) {
+  if (nz.dW != nullptr) {
+    if (nz.bcast_d > 0) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const int64_t r = (i + j) / nz.bcast_d;
+        w.v[j] = nz.dW[r];
+        if (NEED_U) u.v[j] = nz.dU[r];
+      }
+    } else {
+      w = load<T, W>(nz.dW, i);
+      if (NEED_U) u = load<T, W>(nz.dU, i);
+    }
+    return;
+  }
+  const T sw = (T)sqrt(nz.h);
+  const T sh = (T)sqrt(nz.h / 12.0);
+  const T th = (T)nz.h;
+  const uint64_t e = nz.key.elem0 + (uint64_t)i;
+  if constexpr (W == 4) {
+    T n[4];
+    normal4<T>(nz.key, e >> 2, nz.cell, 0, kStreamW, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w.v[j] = n[j] * sw;
+    if (NEED_U) {
+      normal4<T>(nz.key, e >> 2, nz.cell, 0, kStreamH, n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u.v[j] = th * ((T)0.5 * w.v[j] + n[j] * sh);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      w.v[j] = normal1<T>(nz.key, e + j, nz.cell, 0, kStreamW) * sw;
+      if (NEED_U) u.v[j] = th * ((T)0.5 * w.v[j] + normal1<T>(nz.key, e + j, nz.cell, 0, kStreamH) * sh);
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int grid_for(int64_t work_items) {
+  int64_t g = (work_items + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+
+// Elementwise driver. `Op` provides  template<int W> __device__ void run(int64_t i) const  acting on
+// elements [i, i+W). The vector path (W=4) is taken when `vec` is set by the launcher (all pointers
+// 16-byte aligned, n % 4 == 0 and the global noise offset % 4 == 0).
+template <typename Op>
+__global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const int64_t n, const int vec) {
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (vec) {
+    const int64_t nq = n >> 2;
+    for (int64_t q = tid; q < nq; q += stride) op.template run<4>(q << 2);
+  } else {
+    for (int64_t i = tid; i < n; i += stride) op.template run<1>(i);
+  }
+}
+
+template <typename Op>
+inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const int64_t items = vec ? (n >> 2) : n;
+  hipLaunchKernelGGL(elementwise_kernel<Op>, dim3(grid_for(items)), dim3(kBlock), 0, stream, op, n, vec ? 1 : 0);
+  return hipGetLastError();
+}
+
+}  // namespace tsde

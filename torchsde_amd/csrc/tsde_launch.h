@@ -1,0 +1,58 @@
+// Typed launchers behind the C ABI (capi.hip dispatches on dtype).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/torchsde_amd.h"
+#include "tsde_bridge.h"
+#include "tsde_rng.h"
+
+namespace tsde {
+
+struct QueryArgs {
+  const double* edges;  // device pointer, n_cells + 1 doubles
+  int64_t ca, cb;
+  double a, b;
+  const void* rootW;    // optional pinned (W,H) of the single top-level cell
+  const void* rootH;
+  WalkCfg cfg;
+};
+
+template <typename T>
+hipError_t launch_normals(void* out, int64_t n, NoiseKey key, uint32_t cell, uint64_t node, uint32_t stream_id,
+                          hipStream_t s);
+template <typename T>
+hipError_t launch_query(void* W, void* U, void* H, int64_t n, NoiseKey key, const QueryArgs& qa, bool have_h,
+                        hipStream_t s);
+template <typename T>
+hipError_t launch_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_step_diag(void* y1, const void* y0, const void* f, const void* g, int64_t n, double cf, double cg,
+                            const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_step_prod(void* y1, const void* y0, const void* f, const void* gp, int64_t n, double cf, double cg,
+                            hipStream_t s);
+template <typename T>
+hipError_t launch_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
+                               double cf, double cg, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
+                             const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n,
+                                double dt, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_milstein_gf_prime(void* yp, const void* y0, const void* f, const void* g, int64_t n, double dt,
+                                    double sqrt_dt, int ito, hipStream_t s);
+template <typename T>
+hipError_t launch_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gp, int64_t n,
+                                   double dt, double sqrt_dt, int ito, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_srk_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
+                            const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
+                            const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_aug_seg(const tsde_seg_t& sg, double cF, double cG, hipStream_t s);
+template <typename T>
+hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s);
+
+}  // namespace tsde

@@ -1,0 +1,364 @@
+"""Tensor-level wrappers of the C ABI: argument checking, ctypes marshalling, and autograd support.
+
+Every update of the solver state goes through a function here, which launches a HIP kernel from
+``libtorchsde_amd.so`` on torch's current stream. When gradients are requested *through the solver*
+(``sdeint`` with tensors that require grad), the forward is still the fused kernel; the backward is
+expressed with differentiable torch ops on the re-materialised increment (the step maps are linear in
+``y0, f, g``), so higher-order derivatives work too.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import Noise, Seg
+
+
+class NoiseSpec:
+    """The Brownian increment of one step: either a generated grid cell or materialised tensors."""
+
+    __slots__ = ("W", "U", "entropy", "elem0", "cell", "h", "bcast_d", "shape", "dtype", "device", "_struct")
+
+    def __init__(self, shape, dtype, device, W=None, U=None, entropy=0, elem0=0, cell=0, h=0.0, bcast_d=0):
+        self.shape, self.dtype, self.device = tuple(shape), dtype, device
+        self.W = None if W is None else _native.contiguous(W)
+        self.U = None if U is None else _native.contiguous(U)
+        self.entropy, self.elem0, self.cell, self.h, self.bcast_d = entropy, elem0, cell, h, bcast_d
+        self._struct = None
+
+    @classmethod
+    def generated(cls, bm, cell, h):
+        return cls(bm.shape, bm.dtype, bm.device, entropy=bm._key, elem0=bm._elem0, cell=int(cell), h=float(h))
+
+    @classmethod
+    def external(cls, W, U=None, bcast_d=0):
+        return cls(W.shape, W.dtype, W.device, W=W, U=U, bcast_d=bcast_d)
+
+    @property
+    def is_generated(self):
+        return self.W is None
+
+    def struct(self):
+        if self._struct is None:
+            s = Noise()
+            s.dW = None if self.W is None else self.W.data_ptr()
+            s.dU = None if self.U is None else self.U.data_ptr()
+            s.entropy, s.elem0, s.cell, s.reserved = self.entropy, self.elem0, self.cell, 0
+            s.h, s.bcast_d = self.h, self.bcast_d
+            self._struct = s
+        return ctypes.byref(self._struct)
+
+    def materialise(self, need_U=False):
+        """(W, U) as tensors of the noise shape (launches ``tsde_cell_increment`` for a generated cell)."""
+        if self.W is not None:
+            return self.W, self.U
+        W = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        U = torch.empty(self.shape, dtype=self.dtype, device=self.device) if need_U else None
+        _native.require_device(W)
+        lib = _native.load()
+        code = lib.tsde_cell_increment(_native.ptr(W), _native.ptr(U), W.numel(), self.struct(),
+                                       _native.dtype_code(self.dtype), _native.stream_ptr(self.device))
+        _native.check(code, "tsde_cell_increment")
+        return W, U
+
+
+def _prep(ref, *tensors):
+    """Contiguous, same dtype/device as `ref`; detached (kernels are autograd-opaque)."""
+    out = []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        t = t.detach()
+        if t.dtype != ref.dtype:
+            t = t.to(ref.dtype)
+        if t.shape != ref.shape:
+            t = t.expand(ref.shape)
+        out.append(_native.contiguous(t))
+    return out
+
+
+def _launch_env(ref):
+    _native.require_device(ref)
+    return _native.load(), _native.dtype_code(ref.dtype), _native.stream_ptr(ref.device)
+
+
+def _new_like(ref, out):
+    return torch.empty_like(ref, memory_format=torch.contiguous_format) if out is None else out
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+# ---- raw launches --------------------------------------------------------------------------------------
+def _raw_step_diag(y0, f, g, cf, cg, noise, out):
+    y0 = _native.contiguous(y0.detach())
+    f, g = _prep(y0, f, g)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_step_diag(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g), y0.numel(),
+                              float(cf), float(cg), noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_step_diag")
+    return out
+
+
+def _raw_step_prod(y0, f, gp, cf, cg, out):
+    y0 = _native.contiguous(y0.detach())
+    f, gp = _prep(y0, f, gp)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_step_prod(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(gp), y0.numel(),
+                              float(cf), float(cg), dt_code, stream)
+    _native.check(code, "tsde_step_prod")
+    return out
+
+
+def _raw_step_general(y0, f, g, cf, cg, noise, out):
+    y0 = _native.contiguous(y0.detach())
+    f, = _prep(y0, f)
+    g = g.detach()
+    if g.dtype != y0.dtype:
+        g = g.to(y0.dtype)
+    B, d = y0.shape
+    m = g.shape[-1]
+    if g.shape != (B, d, m):
+        g = g.expand(B, d, m)
+    g = _native.contiguous(g)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_step_general(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g), B, d, m,
+                                 float(cf), float(cg), noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_step_general")
+    return out
+
+
+# ---- differentiable wrappers -----------------------------------------------------------------------------
+class _StepDiagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, f, g, cf, cg, noise):
+        ctx.cf, ctx.cg, ctx.noise = cf, cg, noise
+        return _raw_step_diag(y0, f, g, cf, cg, noise, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, _ = ctx.noise.materialise()
+        if ctx.noise.bcast_d:
+            W = W.reshape(-1, 1)
+        return gy, gy * ctx.cf, gy * W * ctx.cg, None, None, None
+
+
+class _StepProdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, f, gp, cf, cg):
+        ctx.cf, ctx.cg = cf, cg
+        return _raw_step_prod(y0, f, gp, cf, cg, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, gy * ctx.cf, gy * ctx.cg, None, None
+
+
+class _StepGeneralFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, f, g, cf, cg, noise):
+        ctx.cf, ctx.cg, ctx.noise = cf, cg, noise
+        return _raw_step_general(y0, f, g, cf, cg, noise, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, _ = ctx.noise.materialise()
+        return gy, gy * ctx.cf, (gy.unsqueeze(-1) * W.unsqueeze(-2)) * ctx.cg, None, None, None
+
+
+def step_diag(y0, f, g, cf, cg, noise, out=None):
+    """y1 = (y0 + cf*f) + cg*(g*dW), diagonal noise."""
+    if _needs_grad(y0, f, g):
+        return _StepDiagFn.apply(y0, f.expand_as(y0), g.expand_as(y0), cf, cg, noise)
+    return _raw_step_diag(y0, f, g, cf, cg, noise, out)
+
+
+def step_prod(y0, f, gp, cf, cg, out=None):
+    """y1 = (y0 + cf*f) + cg*gp."""
+    if _needs_grad(y0, f, gp):
+        return _StepProdFn.apply(y0, f.expand_as(y0), gp.expand_as(y0), cf, cg)
+    return _raw_step_prod(y0, f, gp, cf, cg, out)
+
+
+def step_general(y0, f, g, cf, cg, noise, out=None):
+    """y1 = (y0 + cf*f) + cg*(g . dW), g:(B,d,m)."""
+    if _needs_grad(y0, f, g):
+        B, d = y0.shape
+        return _StepGeneralFn.apply(y0, f.expand_as(y0), g.expand(B, d, g.shape[-1]), cf, cg, noise)
+    return _raw_step_general(y0, f, g, cf, cg, noise, out)
+
+
+# ---- Milstein --------------------------------------------------------------------------------------------
+def milstein_v(noise, dt, ito, scale, like, want_W=False):
+    """scale*(W^2 - dt) (Ito) or scale*W^2 as a tensor shaped like the noise (+ W itself if asked)."""
+    v = torch.empty(noise.shape, dtype=like.dtype, device=like.device)
+    Wt = torch.empty(noise.shape, dtype=like.dtype, device=like.device) if want_W else None
+    lib, dt_code, stream = _launch_env(v)
+    code = lib.tsde_milstein_v(_native.ptr(v), _native.ptr(Wt), v.numel(), float(dt), 1 if ito else 0, float(scale),
+                               noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_milstein_v")
+    return v, Wt
+
+
+class _MilsteinDiagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, f, g, gdg, dt, noise):
+        ctx.dt, ctx.noise = dt, noise
+        return _raw_milstein_diag(y0, f, g, gdg, dt, noise, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, _ = ctx.noise.materialise()
+        if ctx.noise.bcast_d:
+            W = W.reshape(-1, 1)
+        return gy, gy * ctx.dt, gy * W, gy, None, None
+
+
+def _raw_milstein_diag(y0, f, g, gdg, dt, noise, out):
+    y0 = _native.contiguous(y0.detach())
+    f, g, gdg = _prep(y0, f, g, gdg)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_milstein_diag(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g),
+                                  _native.ptr(gdg), y0.numel(), float(dt), noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_milstein_diag")
+    return out
+
+
+def milstein_diag(y0, f, g, gdg, dt, noise, out=None):
+    """y1 = ((y0 + f*dt) + g*W) + gdg."""
+    if _needs_grad(y0, f, g, gdg):
+        return _MilsteinDiagFn.apply(y0, f.expand_as(y0), g.expand_as(y0), gdg.expand_as(y0), dt, noise)
+    return _raw_milstein_diag(y0, f, g, gdg, dt, noise, out)
+
+
+def milstein_gf_prime(y0, f, g, dt, sqrt_dt, ito, out=None):
+    """y' = (y0 + dt*f) + g*sqrt_dt (Ito) or y0 + g*sqrt_dt (Stratonovich)."""
+    if _needs_grad(y0, f, g):
+        return (y0 + dt * f + g * sqrt_dt) if ito else (y0 + g * sqrt_dt)
+    y0 = _native.contiguous(y0.detach())
+    f, g = _prep(y0, f, g)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_milstein_gf_prime(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g), y0.numel(),
+                                      float(dt), float(sqrt_dt), 1 if ito else 0, dt_code, stream)
+    _native.check(code, "tsde_milstein_gf_prime")
+    return out
+
+
+class _MilsteinGfDiagFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, f, g, gprime, dt, sqrt_dt, ito, noise):
+        ctx.dt, ctx.sqrt_dt, ctx.ito, ctx.noise = dt, sqrt_dt, ito, noise
+        return _raw_milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, _ = ctx.noise.materialise()
+        if ctx.noise.bcast_d:
+            W = W.reshape(-1, 1)
+        v = W * W - ctx.dt if ctx.ito else W * W
+        q = v / (2 * ctx.sqrt_dt)
+        return gy, gy * ctx.dt, gy * (W - q), gy * q, None, None, None, None
+
+
+def _raw_milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out):
+    y0 = _native.contiguous(y0.detach())
+    f, g, gprime = _prep(y0, f, g, gprime)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_milstein_gf_diag(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g),
+                                     _native.ptr(gprime), y0.numel(), float(dt), float(sqrt_dt), 1 if ito else 0,
+                                     noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_milstein_gf_diag")
+    return out
+
+
+def milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out=None):
+    """y1 = ((y0 + f*dt) + g*W) + ((g'-g)*v)/(2*sqrt_dt)."""
+    if _needs_grad(y0, f, g, gprime):
+        return _MilsteinGfDiagFn.apply(y0, f.expand_as(y0), g.expand_as(y0), gprime.expand_as(y0), dt, sqrt_dt, ito,
+                                       noise)
+    return _raw_milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out)
+
+
+# ---- SRK ---------------------------------------------------------------------------------------------------
+def srk_diag_stage(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0=True, want1=True, out0=None):
+    """One SRID2 stage kernel; returns (out0, out1) (None where not requested)."""
+    if _needs_grad(y0, *fs, *gs):
+        raise NotImplementedError("torchsde_amd: back-propagating through the SRK solver is not supported; use "
+                                  "`method='milstein'`/'euler' or `sdeint_adjoint`.")
+    y0 = _native.contiguous(y0.detach())
+    fs = _prep(y0, *fs) + [None] * (4 - len(fs))
+    gs = _prep(y0, *gs) + [None] * (4 - len(gs))
+    if out0 is None:
+        out0 = torch.empty_like(y0) if want0 else None
+    out1 = torch.empty_like(y0) if want1 else None
+    lib, dt_code, stream = _launch_env(y0)
+    f_arr = _native._PTR4(*[None if t is None else t.data_ptr() for t in fs])
+    g_arr = _native._PTR4(*[None if t is None else t.data_ptr() for t in gs])
+    code = lib.tsde_srk_diag_stage(stage, _native.ptr(out0), _native.ptr(out1), _native.ptr(y0), f_arr, g_arr,
+                                   y0.numel(), float(dt), float(rdt), float(sqrt_dt), noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_srk_diag_stage")
+    return out0, out1
+
+
+# ---- adjoint / output --------------------------------------------------------------------------------------
+def aug_update(segments, cF, cG, dtype, device):
+    """segments: list of dicts(out, s, F, G, D, sF, sG, sD); one fused update per segment."""
+    lib = _native.load()
+    arr = (Seg * len(segments))()
+    keep = []
+    for i, sg in enumerate(segments):
+        s = sg["s"]
+        _native.require_device(s)
+        terms = []
+        for name in ("F", "G", "D"):
+            t = sg.get(name)
+            if t is not None:
+                t = t.detach()
+                if t.dtype != s.dtype:
+                    t = t.to(s.dtype)
+                t = _native.contiguous(t.reshape(s.shape) if t.numel() == s.numel() else t.expand(s.shape))
+            terms.append(t)
+        keep.append(terms)
+        arr[i].out = sg["out"].data_ptr()
+        arr[i].s = s.data_ptr()
+        arr[i].F = None if terms[0] is None else terms[0].data_ptr()
+        arr[i].G = None if terms[1] is None else terms[1].data_ptr()
+        arr[i].D = None if terms[2] is None else terms[2].data_ptr()
+        arr[i].n = s.numel()
+        arr[i].sF, arr[i].sG, arr[i].sD = sg.get("sF", 1.0), sg.get("sG", 1.0), sg.get("sD", 1.0)
+    code = lib.tsde_aug_update(arr, len(segments), float(cF), float(cG), _native.dtype_code(dtype),
+                               _native.stream_ptr(device))
+    _native.check(code, "tsde_aug_update")
+
+
+def linear_interp(ya, yb, w0, w1, out=None):
+    """out = w0*ya + w1*yb (interp.py:17)."""
+    if _needs_grad(ya, yb):
+        return w0 * ya + w1 * yb
+    ya = _native.contiguous(ya.detach())
+    yb, = _prep(ya, yb)
+    out = _new_like(ya, out)
+    lib, dt_code, stream = _launch_env(ya)
+    code = lib.tsde_linear_interp(_native.ptr(out), _native.ptr(ya), _native.ptr(yb), ya.numel(), float(w0),
+                                  float(w1), dt_code, stream)
+    _native.check(code, "tsde_linear_interp")
+    return out
+
+
+# ---- in-library event timing (bench.py's roofline) ----------------------------------------------------------
+def prof_begin(kid, capacity):
+    _native.check(_native.load().tsde_prof_begin(kid, capacity), "tsde_prof_begin")
+
+
+def prof_end():
+    ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+    _native.check(_native.load().tsde_prof_end(ctypes.byref(ms), ctypes.byref(n)), "tsde_prof_end")
+    return ms.value, n.value

@@ -1,0 +1,402 @@
+"""Fixed-step SDE solvers whose state updates are HIP kernels.
+
+Solver protocol as in the reference (torchsde/_core/base_solver.py:29-149): class attributes
+``strong_order, weak_order, sde_type, noise_types, levy_area_approximations``; constructor
+``(sde, bm, dt, adaptive, rtol, atol, dt_min, options)`` with the same compatibility errors (:49-58);
+``init_extra_solver_state``; ``step(t0, t1, y0, extra0) -> (y1, extra1)``; ``integrate(y0, ts, extra0)``.
+
+``integrate`` is a different program from the reference's loop (:114-149): the time grid, per-step ``dt``,
+stage times and interpolation weights are computed once on the host (timegrid.py); each step is the user's
+``f``/``g`` torch ops plus ONE fused kernel per solver stage that reads ``y, f, g``, generates the Brownian
+increment of the step's grid cell in registers and writes the new state straight into its destination
+(the next ``ys[i]`` slot when the step lands on an output time). No host sync, no per-step allocation of
+increments, no ``torch.stack`` copy.
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import timegrid
+from .brownian import BaseBrownian, BrownianInterval
+from .kernels import NoiseSpec
+from .settings import LEVY_AREA_APPROXIMATIONS, METHOD_OPTIONS, METHODS, NOISE_TYPES, SDE_TYPES
+
+
+class _Step:
+    """Everything one solver step needs besides the state."""
+    __slots__ = ("times", "dt", "noise", "h64")
+
+    def __init__(self, times, dt, noise, h64):
+        self.times = times   # tuple of 0-d device tensors: stage times (times[0] = t0)
+        self.dt = dt         # numpy scalar in ts.dtype: t1 - t0
+        self.noise = noise   # NoiseSpec
+        self.h64 = h64       # float(t1) - float(t0) in double (what the Brownian motion sees)
+
+
+class BaseSDESolver:
+    strong_order = None
+    weak_order = None
+    sde_type = None
+    noise_types = ()
+    levy_area_approximations = ()
+    needs_U = False
+    # host-side stage-time offsets as multiples of dt (times[j] = t0 + stage_fracs[j]*dt), t0 first
+    stage_fracs = (0,)
+
+    def __init__(self, sde, bm, dt, adaptive, rtol, atol, dt_min, options, **kwargs):
+        super().__init__(**kwargs)
+        for attr in ("strong_order", "weak_order", "sde_type"):
+            if getattr(self, attr) is None:
+                raise NotImplementedError(f"{type(self).__name__} must define `{attr}`.")
+        if sde.sde_type != self.sde_type:
+            raise ValueError(f"SDE is of type {sde.sde_type} but solver is for type {self.sde_type}")
+        if sde.noise_type not in self.noise_types:
+            raise ValueError(f"SDE has noise type {sde.noise_type} but solver only supports noise types "
+                             f"{self.noise_types}")
+        if bm.levy_area_approximation not in self.levy_area_approximations:
+            raise ValueError(f"SDE solver requires one of {self.levy_area_approximations} set as the "
+                             f"`levy_area_approximation` on the Brownian motion.")
+        if sde.noise_type == NOISE_TYPES.scalar and torch.Size(bm.shape[1:]).numel() != 1:
+            raise ValueError("The Brownian motion for scalar SDEs must of dimension 1.")
+        self.sde = sde
+        self.bm = bm
+        self.dt = dt
+        self.adaptive = adaptive
+        self.rtol = rtol
+        self.atol = atol
+        self.dt_min = dt_min
+        self.options = options
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} of strong order: {self.strong_order}, and weak order: {self.weak_order}"
+
+    def init_extra_solver_state(self, t0, y0):
+        return ()
+
+    # ---- what subclasses implement ---------------------------------------------------------------
+    def _advance(self, y0, st, out):
+        """One step from y0 using the prepared `_Step`; writes into `out` if given. Returns y1."""
+        raise NotImplementedError
+
+    # ---- noise plumbing ---------------------------------------------------------------------------
+    def _native_bm(self):
+        bm = self.bm
+        return bm if isinstance(bm, BrownianInterval) else None
+
+    def _noise_for(self, ta, tb, t0_tensor, t1_tensor, cell=None):
+        """NoiseSpec of [ta, tb]: generated cell, native query, or a call into a foreign Brownian object."""
+        bm = self._native_bm()
+        if bm is not None:
+            if cell is not None:
+                return NoiseSpec.generated(bm, cell, bm.cell_width(cell))
+            W, U = bm.increment(ta, tb, want_U=self.needs_U)
+            return NoiseSpec.external(W, U)
+        if self.needs_U:
+            W, U = self.bm(t0_tensor, t1_tensor, return_U=True)
+            return NoiseSpec.external(W, U)
+        return NoiseSpec.external(self.bm(t0_tensor, t1_tensor))
+
+    # ---- public single-step API (the reference's solver seam) --------------------------------------
+    def step(self, t0, t1, y0, extra0):
+        del extra0
+        np_dtype = timegrid._NP.get(y0.dtype if not torch.is_tensor(t0) else t0.dtype, np.float64)
+        ta, tb = float(t0), float(t1)
+        t0n, t1n = np_dtype(ta), np_dtype(tb)
+        dt = np_dtype(t1n - t0n)
+        dev = y0.device
+        t0_t = t0 if torch.is_tensor(t0) else torch.tensor(ta, dtype=y0.dtype, device=dev)
+        t1_t = t1 if torch.is_tensor(t1) else torch.tensor(tb, dtype=y0.dtype, device=dev)
+        cell = None
+        bm = self._native_bm()
+        if bm is not None and bm.frozen:
+            cells = bm.match_grid(np.array([ta, tb]))
+            cell = None if cells is None else int(cells[0])
+        times = tuple(t0_t if frac == 0 else torch.tensor(t0n + np_dtype(frac) * dt, dtype=t0_t.dtype, device=dev)
+                      for frac in self.stage_fracs)
+        st = _Step(times, dt, self._noise_for(ta, tb, t0_t, t1_t, cell), tb - ta)
+        return self._advance(y0, st, None), ()
+
+    # ---- the fixed-step driver -------------------------------------------------------------------------
+    def integrate(self, y0, ts, extra0):
+        if self.adaptive:
+            raise NotImplementedError(
+                "torchsde_amd: adaptive step-size control is outside the MI355X hot path built so far "
+                "(SURVEY.md section 8(f), rank 2). Use `adaptive=False`.")
+        device = y0.device
+        grid = timegrid.build(timegrid.ts_to_host(ts), self.dt)
+        n_steps = grid.n_steps
+        np_dtype = grid.t.dtype.type
+        t64 = grid.t_f64()
+
+        # Stage times for every step in one upload: times[k][j] = t_k + frac_j * dt_k, rounded like the
+        # reference's 0-d tensor arithmetic (`t0 + C * dt`).
+        fracs = self.stage_fracs
+        stage = np.empty((max(n_steps, 1), len(fracs)), dtype=grid.t.dtype)
+        for j, frac in enumerate(fracs):
+            if frac == 0:
+                stage[:n_steps, j] = grid.t[:-1]
+            else:
+                stage[:n_steps, j] = grid.t[:-1] + np_dtype(frac) * grid.dt
+        stage_dev = torch.from_numpy(stage).to(device=device)
+        if stage_dev.dtype != ts.dtype:
+            stage_dev = stage_dev.to(ts.dtype)
+        stage_rows = [row.unbind(0) for row in stage_dev.unbind(0)] if n_steps > 0 else []
+        t_dev = None  # step boundaries as tensors, only needed for foreign Brownian objects
+
+        bm = self._native_bm()
+        cells = None
+        if bm is not None and n_steps > 0:
+            bm.adopt_grid(t64)
+            cells = bm.match_grid(t64)
+        elif n_steps > 0:
+            t_dev = torch.from_numpy(grid.t).to(device=device).unbind(0)
+
+        # Output bookkeeping: which step completes which ys[i]; exact hits are written in place.
+        T = len(grid.outputs) + 1
+        done_at = {}
+        for j, (kp, kc, w0, w1) in enumerate(grid.outputs):
+            done_at.setdefault(kc, []).append((j + 1, kp, w0, w1))
+        y0c = y0 if y0.is_contiguous() else y0.contiguous()
+        track = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
+        ys_buf = None if track else torch.empty((T,) + tuple(y0.shape), dtype=y0.dtype, device=device)
+        ys_list = [y0c] + [None] * (T - 1)
+        if ys_buf is not None:
+            ys_buf[0].copy_(y0c.detach())
+            scratch = (torch.empty_like(ys_buf[0]), torch.empty_like(ys_buf[0]))
+        in_place = ys_buf is not None
+
+        cur = y0c
+        for k in range(n_steps):
+            slot = None
+            if in_place:
+                slot = scratch[k & 1]
+                for (i, kp, w0, w1) in done_at.get(k + 1, ()):
+                    if w1 == 1.0 and w0 == 0.0:
+                        slot = ys_buf[i]
+            noise = self._noise_for(t64[k], t64[k + 1], None if t_dev is None else t_dev[k],
+                                    None if t_dev is None else t_dev[k + 1],
+                                    None if cells is None else int(cells[k]))
+            st = _Step(stage_rows[k], grid.dt[k], noise, t64[k + 1] - t64[k])
+            nxt = self._advance(cur, st, slot)
+            if in_place and (nxt.requires_grad or (slot is not None and nxt.data_ptr() != slot.data_ptr())):
+                # A tensor that requires grad appeared mid-solve (e.g. a non-Parameter leaf inside the SDE):
+                # the autograd wrappers allocate their own outputs, so assemble `ys` with torch.stack instead.
+                in_place = False
+            for (i, kp, w0, w1) in done_at.get(k + 1, ()):
+                if w1 == 1.0 and w0 == 0.0:
+                    ys_list[i] = nxt
+                else:
+                    dst = ys_buf[i] if in_place else None
+                    ys_list[i] = K.linear_interp(cur, nxt, w0, w1, out=dst)
+            cur = nxt
+        for i in range(1, T):
+            if ys_list[i] is None:   # output times that need no step (cannot happen for increasing ts)
+                ys_list[i] = cur
+        if in_place:
+            return ys_buf, ()
+        return torch.stack(ys_list, dim=0), ()
+
+    def _params(self):
+        try:
+            return list(self.sde.parameters())
+        except AttributeError:
+            return []
+
+    # ---- helpers shared by the concrete methods ------------------------------------------------------------
+    def _diag(self):
+        return self.sde.noise_type == NOISE_TYPES.diagonal
+
+    def _drift_diffusion_update(self, t, y, cf, cg, noise, out):
+        """y + cf*f(t,y) + cg*g(t,y).dW with the product fused unless the user computes it."""
+        sde = self.sde
+        if sde.user_product:
+            W, _ = noise.materialise()
+            f, gp = sde.f_and_g_prod(t, y, W)
+            return K.step_prod(y, f, gp, cf, cg, out=out)
+        f, g = sde.f_and_g(t, y)
+        if self._diag():
+            return K.step_diag(y, f, g, cf, cg, noise, out=out)
+        return K.step_general(y, f, g, cf, cg, noise, out=out)
+
+
+class Euler(BaseSDESolver):
+    """Euler-Maruyama (reference: methods/euler.py:19-37)."""
+    weak_order = 1.0
+    sde_type = SDE_TYPES.ito
+    noise_types = NOISE_TYPES.all()
+    levy_area_approximations = LEVY_AREA_APPROXIMATIONS.all()
+
+    def __init__(self, sde, **kwargs):
+        self.strong_order = 1.0 if sde.noise_type == NOISE_TYPES.additive else 0.5
+        super().__init__(sde=sde, **kwargs)
+
+    def _advance(self, y0, st, out):
+        return self._drift_diffusion_update(st.times[0], y0, st.dt, 1.0, st.noise, out)
+
+
+class Midpoint(BaseSDESolver):
+    """Stratonovich midpoint (reference: methods/midpoint.py:19-45)."""
+    weak_order = 1.0
+    sde_type = SDE_TYPES.stratonovich
+    noise_types = NOISE_TYPES.all()
+    levy_area_approximations = LEVY_AREA_APPROXIMATIONS.all()
+    stage_fracs = (0, 0.5)
+
+    def __init__(self, sde, **kwargs):
+        self.strong_order = 0.5 if sde.noise_type == NOISE_TYPES.general else 1.0
+        super().__init__(sde=sde, **kwargs)
+
+    def _advance(self, y0, st, out):
+        dt = st.dt
+        half_dt = type(dt)(0.5) * dt
+        if self.sde.user_product:
+            W, _ = st.noise.materialise()
+            f, gp = self.sde.f_and_g_prod(st.times[0], y0, W)
+            y_prime = K.step_prod(y0, f, gp, half_dt, 0.5)
+            f2, gp2 = self.sde.f_and_g_prod(st.times[1], y_prime, W)
+            return K.step_prod(y0, f2, gp2, dt, 1.0, out=out)
+        diag = self._diag()
+        f, g = self.sde.f_and_g(st.times[0], y0)
+        upd = K.step_diag if diag else K.step_general
+        y_prime = upd(y0, f, g, half_dt, 0.5, st.noise)
+        f2, g2 = self.sde.f_and_g(st.times[1], y_prime)
+        return upd(y0, f2, g2, dt, 1.0, st.noise, out=out)
+
+
+class _Milstein(BaseSDESolver):
+    """Milstein, derivative-using or derivative-free (reference: methods/milstein.py:21-94)."""
+    strong_order = 1.0
+    weak_order = 1.0
+    noise_types = (NOISE_TYPES.additive, NOISE_TYPES.diagonal, NOISE_TYPES.scalar)
+    levy_area_approximations = LEVY_AREA_APPROXIMATIONS.all()
+    ito = True
+
+    def __init__(self, sde, options, **kwargs):
+        from . import adjoint  # circular: the adjoint module builds solvers
+        if METHOD_OPTIONS.grad_free not in options:
+            options[METHOD_OPTIONS.grad_free] = False
+        if options[METHOD_OPTIONS.grad_free] and sde.noise_type == NOISE_TYPES.additive:
+            options[METHOD_OPTIONS.grad_free] = False   # dg = 0: the derivative form already handles it
+        if options[METHOD_OPTIONS.grad_free] and isinstance(sde, adjoint.AdjointSDE):
+            raise ValueError(f"Derivative-free Milstein cannot be used for adjoint SDEs, because it requires "
+                             f"direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
+                             f"diffusion-vector product. Use derivative-using Milstein instead: "
+                             f"`adjoint_options=dict({METHOD_OPTIONS.grad_free}=False)`")
+        super().__init__(sde=sde, options=options, **kwargs)
+
+    def _row_noise(self, noise, d):
+        """Scalar noise: one increment per batch row, broadcast over the d state channels."""
+        W, U = noise.materialise()
+        return NoiseSpec.external(W.reshape(-1), None if U is None else U.reshape(-1), bcast_d=d)
+
+    def _advance(self, y0, st, out):
+        sde, dt, noise = self.sde, st.dt, st.noise
+        t0 = st.times[0]
+        kind = sde.noise_type
+        if kind == NOISE_TYPES.additive:
+            # gdg = 0 (base_sde.py:157-158): y1 = y0 + f*dt + g_prod + 0.
+            if sde.user_g_prod:
+                W, _ = noise.materialise()
+                return K.step_prod(y0, sde.f(t0, y0), sde.g_prod(t0, y0, W), dt, 1.0, out=out)
+            return K.step_general(y0, sde.f(t0, y0), sde.g(t0, y0), dt, 1.0, noise, out=out)
+        scalar = kind == NOISE_TYPES.scalar
+        if scalar:
+            noise = self._row_noise(noise, y0.shape[1])
+        if self.options[METHOD_OPTIONS.grad_free]:
+            sqrt_dt = np.sqrt(dt)
+            f, g = sde.f_and_g(t0, y0)
+            g_ = g.squeeze(2) if g.dim() == 3 else g
+            y_prime = K.milstein_gf_prime(y0, f, g_, dt, sqrt_dt, self.ito)
+            g_prime = sde.g(t0, y_prime)
+            g_prime = g_prime.squeeze(2) if g_prime.dim() == 3 else g_prime
+            return K.milstein_gf_diag(y0, f, g_, g_prime, dt, sqrt_dt, self.ito, noise, out=out)
+        # derivative form: the VJP (dg/dy)^T (g * v/2) stays in autograd, everything else is fused
+        v2, _ = K.milstein_v(noise if not scalar else NoiseSpec.external(noise.W), dt, self.ito, 0.5, like=y0)
+        if scalar:
+            v2 = v2.reshape(-1, 1)
+        f = sde.f(t0, y0)
+        g, gdg = sde._g_and_gdg(t0, y0, v2, scalar_like=scalar)
+        g_ = g.squeeze(2) if g.dim() == 3 else g
+        return K.milstein_diag(y0, f, g_, gdg, dt, noise, out=out)
+
+
+class MilsteinIto(_Milstein):
+    sde_type = SDE_TYPES.ito
+    ito = True
+
+
+class MilsteinStratonovich(_Milstein):
+    sde_type = SDE_TYPES.stratonovich
+    ito = False
+
+
+class SRK(BaseSDESolver):
+    """Roessler's strong-order-1.5 SRI (diagonal/scalar, tableau SRID2) scheme (reference: methods/srk.py:30-88).
+
+    The reference re-evaluates f and g of every earlier stage inside its double loop (10 f + 6 g + 4 g_prod
+    per step); identical values are obtained here with 3 f and 4 g evaluations and four stage kernels.
+    """
+    strong_order = 1.5
+    weak_order = 1.5
+    sde_type = SDE_TYPES.ito
+    noise_types = (NOISE_TYPES.additive, NOISE_TYPES.diagonal, NOISE_TYPES.scalar)
+    levy_area_approximations = (LEVY_AREA_APPROXIMATIONS.space_time, LEVY_AREA_APPROXIMATIONS.davie,
+                                LEVY_AREA_APPROXIMATIONS.foster)
+    needs_U = True
+    stage_fracs = (0, 0.25, 0.5, 1)   # t0, +dt/4, +dt/2, +dt
+
+    def __init__(self, sde, **kwargs):
+        from . import adjoint
+        if isinstance(sde, adjoint.AdjointSDE):
+            raise ValueError("Stochastic Runge–Kutta methods cannot be used for adjoint SDEs, because it requires "
+                             "direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
+                             "diffusion-vector product. Use a different method instead.")
+        super().__init__(sde=sde, **kwargs)
+
+    def _advance(self, y0, st, out):
+        if self.sde.noise_type == NOISE_TYPES.additive:
+            return self._advance_additive(y0, st, out)
+        sde, dt, noise = self.sde, st.dt, st.noise
+        t_0, t_q, t_h, t_1 = st.times
+        one = type(dt)(1)
+        rdt = one / dt
+        sqrt_dt = np.sqrt(dt)
+        if sde.noise_type == NOISE_TYPES.scalar:
+            W, U = noise.materialise(need_U=True)
+            noise = NoiseSpec.external(W.reshape(-1), U.reshape(-1), bcast_d=y0.shape[1])
+
+        def g_of(t, y):
+            g = sde.g(t, y)
+            return g.squeeze(2) if g.dim() == 3 else g
+
+        # C0 = (0, 1, 1/2, 0) for f, C1 = (0, 1/4, 1, 1/4) for g   (srid2.py:21-22)
+        f0, g0 = sde.f(t_0, y0), g_of(t_0, y0)
+        H0_1, H1_1 = K.srk_diag_stage(1, y0, [f0], [g0], dt, rdt, sqrt_dt, noise)
+        f1, g1 = sde.f(t_1, H0_1), g_of(t_q, H1_1)
+        H0_2, H1_2 = K.srk_diag_stage(2, y0, [f0, f1], [g0, g1], dt, rdt, sqrt_dt, noise)
+        f2, g2 = sde.f(t_h, H0_2), g_of(t_1, H1_2)
+        _, H1_3 = K.srk_diag_stage(3, y0, [f0, f1, f2], [g0, g1, g2], dt, rdt, sqrt_dt, noise, want0=False)
+        g3 = g_of(t_q, H1_3)
+        y1, _ = K.srk_diag_stage(4, y0, [f0, f1, f2], [g0, g1, g2, g3], dt, rdt, sqrt_dt, noise, want1=False,
+                                 out0=out)
+        return y1
+
+    def _advance_additive(self, y0, st, out):
+        raise NotImplementedError("torchsde_amd: SRK for additive noise (SRA1) is not built yet.")
+
+
+def select(method, sde_type):
+    """method name -> solver class (reference: methods/__init__.py:26-48)."""
+    if method == METHODS.euler:
+        return Euler
+    if method == METHODS.milstein:
+        return MilsteinIto if sde_type == SDE_TYPES.ito else MilsteinStratonovich
+    if method == METHODS.srk:
+        return SRK
+    if method == METHODS.midpoint:
+        return Midpoint
+    if method in METHODS:
+        raise NotImplementedError(
+            f"torchsde_amd: method '{method}' is outside the MI355X hot path built so far (euler, milstein, srk, "
+            f"midpoint -- SURVEY.md section 8); see section 8(f) for what comes next.")
+    raise ValueError(f"Method '{method}' does not match any known method.")

@@ -1,0 +1,83 @@
+"""Host-side time grid of a fixed-step solve.
+
+The reference advances time inside its stepping loop with 0-d tensors in ``ts.dtype``:
+``next_t = min(curr_t + step_size, ts[-1])`` (torchsde/_core/base_solver.py:114-116), never clipping to the
+intermediate output times and linearly interpolating back to them (:147, interp.py:15-18). Each of those
+tensor operations costs a device->host sync on a GPU. Here the whole grid -- step boundaries, per-step
+``dt``, stage times and interpolation weights -- is computed once on the host with numpy scalars of the
+same dtype (identical IEEE arithmetic, e.g. float32 ``dt=1e-3`` over [0,1] gives 1001 steps exactly like
+the reference) and uploaded in one copy.
+"""
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+_NP = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16}
+
+
+@dataclass
+class TimeGrid:
+    t: np.ndarray                      # (N+1,) step boundaries, in ts.dtype
+    dt: np.ndarray                     # (N,)   t[k+1] - t[k] rounded in ts.dtype (what `f * dt` uses)
+    outputs: List[Tuple[int, int, float, float]] = field(default_factory=list)
+    # outputs[j] = (k_prev, k_curr, w0, w1): ys[j+1] = w0 * y[k_prev] + w1 * y[k_curr]
+
+    @property
+    def n_steps(self):
+        return self.dt.shape[0]
+
+    def t_f64(self):
+        return self.t.astype(np.float64)
+
+
+def _step_value(dt, np_dtype):
+    """`curr_t + dt` with a Python-number dt: torch rounds the scalar to the tensor dtype first."""
+    return np_dtype(dt)
+
+
+def build(ts_host: np.ndarray, dt) -> TimeGrid:
+    """ts_host: 1-D numpy array in the dtype of `ts`; dt: Python number (or 0-d tensor of the same dtype)."""
+    np_dtype = ts_host.dtype.type
+    if torch.is_tensor(dt):
+        if dt.numel() != 1:
+            raise ValueError("`dt` must be a scalar.")
+        if _NP.get(dt.dtype) is not np_dtype:
+            # A 0-d tensor dt of another dtype would promote `curr_t + dt`; not worth emulating.
+            raise ValueError("A tensor-valued `dt` must have the dtype of `ts`.")
+        step = np_dtype(dt.item())
+    else:
+        step = _step_value(dt, np_dtype)
+    if not step > 0:
+        raise ValueError("`dt` must be positive.")
+    t_end = ts_host[-1]
+    times = [ts_host[0]]
+    outputs = []
+    prev_k = curr_k = 0
+    curr_t = ts_host[0]
+    for out_t in ts_host[1:]:
+        while curr_t < out_t:
+            nxt = curr_t + step          # rounded once in np_dtype
+            next_t = nxt if nxt <= t_end else t_end
+            times.append(next_t)
+            prev_k, curr_k = curr_k, curr_k + 1
+            curr_t = next_t
+        t0, t1 = times[prev_k], times[curr_k]
+        if t1 == t0:   # out_t == ts[0] cannot happen for strictly increasing ts; guard anyway
+            w0, w1 = np_dtype(0), np_dtype(1)
+        else:
+            # (t1 - t) / (t1 - t0) and (t - t0) / (t1 - t0), each op rounded in ts.dtype (interp.py:17)
+            w0 = (t1 - out_t) / (t1 - t0)
+            w1 = (out_t - t0) / (t1 - t0)
+        outputs.append((prev_k, curr_k, float(w0), float(w1)))
+    t = np.asarray(times, dtype=ts_host.dtype)
+    step_dt = (t[1:] - t[:-1]).astype(ts_host.dtype)
+    return TimeGrid(t=t, dt=step_dt, outputs=outputs)
+
+
+def ts_to_host(ts: torch.Tensor) -> np.ndarray:
+    """One device->host copy of the output times (the only sync of a fixed-step solve)."""
+    if ts.dtype not in _NP:
+        raise ValueError(f"Unsupported dtype for `ts`: {ts.dtype}")
+    return ts.detach().cpu().numpy()
