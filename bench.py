@@ -45,30 +45,43 @@ def _cpu_baseline(cfg, budget_s=20.0):
         return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": f"unavailable: {e}"}
     from tests import problems
-    torch.set_num_threads(os.cpu_count() or 1)
     B, d, dt = cfg["B"], cfg["d"], cfg["dt"]
     sde = problems.make(cfg["problem"], d=d)
     y0 = torch.full((B, d), 0.1)
     t1 = cfg["nsteps"] * dt
-    bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, d), dtype=torch.float32, entropy=20240601,
-                                          dt=dt, levy_area_approximation=cfg["levy"])
-    n = 0
-    y = y0
-    t = torch.tensor(0.0)
     step = solvers_ref.STEPS[cfg["method"]]
-    start = time.perf_counter()
-    with torch.no_grad():
-        while n < cfg["nsteps"]:
-            t_next = t + dt
-            y = step(sde, bm, t, t_next, y)
-            t = t_next
-            n += 1
-            if n >= 8 and time.perf_counter() - start > budget_s:
-                break
-    el = time.perf_counter() - start
-    return {"value": B * n / el, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}), "
-                      f"{el:.1f} s, torch CPU ops with {torch.get_num_threads()} threads"}
+
+    def run(threads, budget, min_steps):
+        torch.set_num_threads(threads)
+        bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, d), dtype=torch.float32, entropy=20240601,
+                                              dt=dt, levy_area_approximation=cfg["levy"])
+        n, y, t = 0, y0, torch.tensor(0.0)
+        start = time.perf_counter()
+        with torch.no_grad():
+            while n < cfg["nsteps"]:
+                t_next = t + dt
+                y = step(sde, bm, t, t_next, y)
+                t = t_next
+                n += 1
+                if n >= min_steps and time.perf_counter() - start > budget:
+                    break
+        return n, time.perf_counter() - start
+
+    # torch CPU elementwise ops on 4M-element tensors do not scale to hundreds of threads; give the
+    # baseline its best thread count (probed on a few steps each) and report the count used.
+    ncpu = os.cpu_count() or 1
+    candidates = sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)})
+    best, best_rate = candidates[0], 0.0
+    for c in candidates:
+        n, el = run(c, 1.5, 2)
+        if n / el > best_rate:
+            best, best_rate = c, n / el
+    n, el = run(best, budget_s, 8)
+    return {"value": B * n / el, "unit": "trajectory-steps/s", "cores": best, "kind": "port",
+            "host_cpus": ncpu,
+            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}) in {el:.1f} s; "
+                      f"oracle port of the reference CPU algorithm (tree BrownianInterval + Euler loop, torch CPU "
+                      f"ops), best of thread counts {candidates} -> {best} threads"}
 
 
 def main():

@@ -152,6 +152,50 @@ def gen_solver():
         print(f"solver_{name}.npz  steps={len(keys)}  ys[-1,0,:2]={out['f32__ys'][-1, 0, :2]}")
 
 
+# -------------------------------------------------------------------------------------------------- adjoint
+ADJOINT_CASES = [
+    # name, problem, method, adjoint_method, levy, (B, d, m), ts, dt
+    ("gbm_ito_euler_euler", "gbm_ito", "euler", "euler", "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("gbm_ito_default", "gbm_ito", "euler", None, "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("gbm_ito_srk_fwd", "gbm_ito", "srk", "milstein", "space-time", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("gbm_strat_midpoint", "gbm_strat", "midpoint", None, "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("mlpdiag_ito_milstein", "mlpdiag_ito", "milstein", None, "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("mlpdiag_strat_midpoint", "mlpdiag_strat", "midpoint", None, "none", (5, 4, 4), [0., 1.0], 2.0 ** -4),
+    ("general_ito_euler", "general_ito", "euler", None, "none", (6, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("general_strat_midpoint", "general_strat", "midpoint", None, "none", (6, 4, 4), [0., 1.0], 2.0 ** -4),
+    ("scalar_ito_euler", "scalar_ito", "euler", None, "none", (5, 4, 1), [0., 1.0], 2.0 ** -4),
+    ("additive_ito_euler", "additive_ito", "euler", None, "none", (5, 4, 3), [0., 1.0], 2.0 ** -4),
+    ("gbm_ito_nondyadic", "gbm_ito", "euler", "euler", "none", (5, 4, 4), [0., 0.35, 0.9], 0.1),
+]
+
+
+def gen_adjoint():
+    for name, prob, method, adjoint_method, levy, (B, d, m), ts, dt in ADJOINT_CASES:
+        out = {"problem": prob, "method": method, "adjoint_method": adjoint_method or "", "levy": levy,
+               "dt": np.float64(dt), "grad_free": False, "shape": np.array([B, d, m])}
+        for tag, dtype in DT.items():
+            sde = problems.make(prob, dtype=dtype, d=d, m=m)
+            y0 = torch.full((B, d), 0.1, dtype=dtype, requires_grad=True)
+            tst = torch.tensor(ts, dtype=dtype)
+            bm = ReplayBM((B, m), dtype, seed=sum(map(ord, name)), levy=levy)
+            ys = torchsde.sdeint_adjoint(sde, y0, tst, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt)
+            wt = torch.tensor(np.random.default_rng(5).standard_normal(tuple(ys.shape)), dtype=dtype)
+            (ys * wt).sum().backward()
+            keys, W, U = bm.dump()
+            out[f"{tag}__ts"] = tst.numpy()
+            out[f"{tag}__queries"] = keys
+            out[f"{tag}__W"] = W
+            out[f"{tag}__U"] = U
+            out[f"{tag}__ys"] = ys.detach().numpy()
+            out[f"{tag}__loss_weights"] = wt.numpy()
+            out[f"{tag}__grad_y0"] = y0.grad.numpy()
+            for j, p in enumerate(sde.parameters()):
+                out[f"{tag}__grad_p{j}"] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy()
+            out[f"{tag}__param_checksum"] = np.float64(param_checksum(sde))
+        np.savez_compressed(os.path.join(HERE, f"adjoint_{name}.npz"), **out)
+        print(f"adjoint_{name}.npz  queries={len(keys)}  |grad_y0|={np.abs(out['f32__grad_y0']).sum():.4f}")
+
+
 # --------------------------------------------------------------------------------------------------- bridge
 def gen_bridge():
     """Record what the reference's bridge code does with known normals, and multi-interval merges."""
@@ -237,7 +281,7 @@ def gen_brownian_seq():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["timegrid", "solver", "bridge", "brownian_seq"]
+    which = sys.argv[1:] or ["timegrid", "solver", "adjoint", "bridge", "brownian_seq"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

@@ -57,6 +57,7 @@ class Case:
 def make_replay_bm(table, shape, dtype, device, levy):
     """A foreign BaseBrownian (seam S3) that replays stored increments."""
     from torchsde_amd import BaseBrownian
+    _dtype, _device, _shape, _levy = dtype, device, shape, levy
 
     class Replay(BaseBrownian):
         def __call__(self, ta, tb=None, return_U=False, return_A=False):
@@ -66,23 +67,21 @@ def make_replay_bm(table, shape, dtype, device, levy):
         def __repr__(self):
             return "Replay"
 
-        dtype_ = dtype
-
         @property
         def dtype(self):
-            return dtype
+            return _dtype
 
         @property
         def device(self):
-            return torch.device(device)
+            return torch.device(_device)
 
         @property
         def shape(self):
-            return tuple(shape)
+            return tuple(_shape)
 
         @property
         def levy_area_approximation(self):
-            return levy
+            return _levy
 
     return Replay()
 

@@ -1,0 +1,102 @@
+"""GPU parity of ``sdeint_adjoint`` (run with ``-m gpu``): gradients vs the REAL reference under replayed
+increments (golden fixtures), native vs materialised increments, and adjoint vs backprop-through-the-solver."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers, problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("name", helpers.adjoint_cases())
+def test_adjoint_matches_reference_golden(name, tag):
+    import torchsde_amd
+    case = helpers.Case(name, tag, prefix="adjoint_")
+    z = case.z
+    adjoint_method = str(z["adjoint_method"]) or None
+    sde = case.sde(DEV)
+    y0 = case.y0(DEV).requires_grad_(True)
+    bm = helpers.make_replay_bm(case.table(DEV), (case.B, case.m), case.dtype, DEV, case.levy)
+    ys = torchsde_amd.sdeint_adjoint(sde, y0, case.ts.to(DEV), bm=bm, method=case.method,
+                                     adjoint_method=adjoint_method, dt=case.dt)
+    wt = torch.tensor(z[f"{tag}__loss_weights"], dtype=case.dtype, device=DEV)
+    (ys * wt).sum().backward()
+    rtol, atol = (3e-4, 3e-5) if tag == "f32" else (1e-9, 1e-11)
+    torch.testing.assert_close(ys.detach().cpu(), case.ys, rtol=rtol, atol=atol)
+    torch.testing.assert_close(y0.grad.cpu(), torch.tensor(z[f"{tag}__grad_y0"], dtype=case.dtype), rtol=rtol,
+                               atol=atol)
+    for j, p in enumerate(sde.parameters()):
+        ref = torch.tensor(z[f"{tag}__grad_p{j}"], dtype=case.dtype)
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
+        # parameter gradients are sums over the batch and the steps: scale the absolute tolerance
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol * 10)
+
+
+@pytest.mark.parametrize("prob,method,adjoint_method", [
+    ("gbm_ito", "euler", "euler"), ("gbm_ito", "milstein", "milstein"), ("gbm_strat", "midpoint", "midpoint"),
+    ("general_ito", "euler", "euler"), ("mlpdiag_ito", "srk", "milstein"),
+])
+def test_adjoint_native_equals_materialised(prob, method, adjoint_method):
+    """Backward sweep on the counter-RNG path: generated cells == the same increments served as tensors."""
+    import torchsde_amd
+    B, d, m, steps, dt = 32, 4, 4, 16, 2.0 ** -5
+    levy = "space-time" if method == "srk" else "none"
+    kw = dict(t0=0.0, t1=steps * dt, size=(B, m), dtype=torch.float64, device=DEV, entropy=99,
+              levy_area_approximation=levy, dt=dt)
+    ts = torch.tensor([0.0, 6 * dt, steps * dt], dtype=torch.float64, device=DEV)
+
+    def run(make_bm):
+        sde = problems.make(prob, dtype=torch.float64, d=d, m=m).to(DEV)
+        y0 = torch.full((B, d), 0.1, dtype=torch.float64, device=DEV, requires_grad=True)
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=make_bm(), method=method, adjoint_method=adjoint_method,
+                                         dt=dt)
+        (ys ** 2).sum().backward()
+        return ys.detach(), y0.grad, [p.grad for p in sde.parameters()]
+
+    def foreign():
+        inner = torchsde_amd.BrownianInterval(**kw)
+
+        class Foreign(torchsde_amd.BaseBrownian):
+            def __call__(self, ta, tb=None, return_U=False, return_A=False):
+                return inner(ta, tb, return_U=return_U)
+
+            def __repr__(self):
+                return "Foreign"
+            dtype = property(lambda s: inner.dtype)
+            device = property(lambda s: inner.device)
+            shape = property(lambda s: inner.shape)
+            levy_area_approximation = property(lambda s: inner.levy_area_approximation)
+        return Foreign()
+
+    a = run(lambda: torchsde_amd.BrownianInterval(**kw))
+    b = run(foreign)
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[1], b[1])
+    for ga, gb in zip(a[2], b[2]):
+        assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("prob,method", [("gbm_strat", "midpoint"), ("gbm_ito", "euler"), ("mlpdiag_ito", "milstein")])
+def test_adjoint_close_to_backprop_through_solver(prob, method):
+    """reference tests/test_adjoint.py:100-154 (`test_against_sdeint`): same outputs, gradients agree loosely."""
+    import torchsde_amd
+    B, d, steps, dt = 64, 4, 256, 2.0 ** -8
+    kw = dict(t0=0.0, t1=1.0, size=(B, d), dtype=torch.float64, device=DEV, entropy=5, dt=dt)
+    ts = torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64, device=DEV)
+
+    def run(fn):
+        sde = problems.make(prob, dtype=torch.float64, d=d).to(DEV)
+        y0 = torch.full((B, d), 0.1, dtype=torch.float64, device=DEV, requires_grad=True)
+        ys = fn(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method=method, dt=dt)
+        ys.sum().backward()
+        return ys.detach(), y0.grad, [p.grad for p in sde.parameters()]
+
+    ys_a, gy_a, gp_a = run(torchsde_amd.sdeint_adjoint)
+    ys_b, gy_b, gp_b = run(torchsde_amd.sdeint)
+    assert torch.equal(ys_a, ys_b)
+    torch.testing.assert_close(gy_a, gy_b, rtol=2e-2, atol=2e-2)
+    for p, q in zip(gp_a, gp_b):
+        torch.testing.assert_close(p, q, rtol=2e-2, atol=2e-2 * max(1.0, q.abs().max().item()))

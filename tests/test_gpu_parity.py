@@ -90,7 +90,9 @@ def test_query_matches_oracle(levy, grid, dtype):
     np_dt = np.float32 if dtype == torch.float32 else np.float64
     tol = 3e-5 if dtype == torch.float32 else 1e-11
     rng = np.random.default_rng(0)
-    queries = [(0.0, 1.0), (edges[1], edges[2]), (edges[0], edges[-2]), (0.05, 0.07), (0.3, 0.99)]
+    queries = [(0.0, 1.0), (edges[-2], edges[-1]), (edges[0], edges[1]), (0.05, 0.07), (0.3, 0.99)]
+    if len(edges) > 3:
+        queries += [(edges[1], edges[2]), (edges[0], edges[-2]), (edges[1], edges[-1])]
     queries += [tuple(sorted(rng.uniform(0, 1, 2))) for _ in range(12)]
     for a, b in queries:
         W, U = bm.increment(a, b, want_U=have_h)

@@ -1,0 +1,40 @@
+"""Condenses rocprofv3 CSV output (kernel stats + FETCH_SIZE / WRITE_SIZE counter passes) into a short text
+summary that is committed under profiles/."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats = find("trace", "*kernel_stats.csv")
+if stats:
+    print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1): per-kernel totals ==")
+    with open(stats) as f:
+        rows = list(csv.DictReader(f))
+    for r in rows[:12]:
+        print(f"{r.get('Name','')[:110]:110s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
+              f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
+for label, sub, col in (("FETCH_SIZE", "pmc_fetch", "FETCH_SIZE"), ("WRITE_SIZE", "pmc_write", "WRITE_SIZE")):
+    path = find(sub, "*counter_collection.csv")
+    if not path:
+        print(f"== {label}: no counter file ==")
+        continue
+    agg = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != col:
+                continue
+            k = r.get("Kernel_Name", "")
+            agg[k][0] += 1
+            agg[k][1] += float(r.get("Counter_Value", 0))
+    print(f"== {label} per launch (raw counter units as reported by rocprofv3; KiB on this stack) ==")
+    for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+        print(f"{k[:110]:110s} launches={n} mean={tot / max(n, 1):.1f}")

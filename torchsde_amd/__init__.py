@@ -1,6 +1,7 @@
 """torchsde_amd -- the MI355X-native time-stepping hot path of torchsde, behind torchsde's own API."""
 from .brownian import (BaseBrownian, BrownianInterval, BrownianPath, BrownianTree, ReverseBrownian,
                        brownian_interval_like)
+from .adjoint import sdeint_adjoint
 from .integrate import sdeint
 from .sde import BaseSDE, SDEIto, SDEStratonovich
 

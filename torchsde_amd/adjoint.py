@@ -1,6 +1,333 @@
-"""Stochastic adjoint (placeholder module: filled in below)."""
-from .sde import BaseSDE
+"""``sdeint_adjoint``: O(1)-memory gradients via the stochastic adjoint, with a fused augmented-state update.
+
+Same signature, defaults, warnings and errors as the reference's ``sdeint_adjoint``
+(torchsde/_core/adjoint.py:130-296). The mathematics of the backward pass is the reference's
+(adjoint.py:64-127 + adjoint_sde.py:23-377): integrate, backwards in time and on the SAME Brownian path, the
+augmented state (y, a_y, a_theta) whose drift is (-f~, a^T df~/dy, a^T df~/dtheta) and whose
+diffusion-vector product is (-g.v, a^T d(g.v)/dy, a^T d(g.v)/dtheta); for Ito SDEs f~ carries the
+double-Stratonovich correction (adjoint_sde.py:130-216); at every output time reset y to the stored forward
+value and add the incoming gradient to a_y (adjoint.py:114-116).
+
+What differs is the program: the reference flattens the augmented state into one (1, 2Bd+P) tensor and
+re-packs it (cat/split) around every VJP and every output time, and pushes it through the generic solver
+(~10 elementwise kernels per step); here the three segments stay unpacked in persistent buffers, the VJPs are
+taken directly on (y, theta) with ``torch.autograd.grad`` (user code stays user code), and ONE kernel launch
+(``tsde_aug_update``) applies the solver update to y, a_y and every parameter segment. The Brownian increments
+of the backward sweep are re-materialised from the counter RNG (no tree, no cache to thrash).
+"""
+import warnings
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import contract
+from . import kernels as K
+from . import solvers
+from . import timegrid
+from .brownian import BaseBrownian, BrownianInterval, ReverseBrownian
+from .kernels import NoiseSpec
+from .sde import BaseSDE, ForwardSDE, jvp, vjp
+from .settings import METHOD_OPTIONS, METHODS, NOISE_TYPES, SDE_TYPES
+
+_ADJOINT_NOISE = {NOISE_TYPES.general: NOISE_TYPES.general, NOISE_TYPES.additive: NOISE_TYPES.general,
+                  NOISE_TYPES.scalar: NOISE_TYPES.scalar, NOISE_TYPES.diagonal: NOISE_TYPES.diagonal}
 
 
 class AdjointSDE(BaseSDE):
-    pass
+    """The augmented backward SDE of ``forward_sde`` on the unpacked state (y, a_y, a_theta...).
+
+    Methods take the *forward* time ``t`` (= minus the backward solver's time, adjoint_sde.py:240,298) and
+    return lists ``[part_y, part_a, *parts_theta]`` holding f~, g.v (un-negated; the update kernel applies the
+    reference's minus sign to the y segment) and the VJPs.
+    """
+
+    def __init__(self, forward_sde, params, shapes=None):
+        super().__init__(sde_type=forward_sde.sde_type, noise_type=_ADJOINT_NOISE[forward_sde.noise_type])
+        self.forward_sde = forward_sde
+        self.params = list(params)
+        self._shapes = shapes
+        ito = forward_sde.sde_type == SDE_TYPES.ito
+        kind = forward_sde.noise_type
+        if not ito or kind == NOISE_TYPES.additive:
+            self._correction = None
+        elif kind == NOISE_TYPES.diagonal:
+            self._correction = "diagonal"
+        else:
+            self._correction = "columns"
+
+    # -- pieces ---------------------------------------------------------------------------------------
+    def _inputs(self, y):
+        return [y] + self.params
+
+    def _drift_parts(self, f, g, y, a):
+        """(f~, vjp_y, vjp_theta...) -- adjoint_sde.py:111-216."""
+        if self._correction is None:
+            grads = vjp(f, self._inputs(y), grad_outputs=a, allow_unused=True, retain_graph=True)
+            return [f.detach()] + grads
+        if self._correction == "diagonal":
+            g_dg, = vjp(g, y, grad_outputs=g, allow_unused=True, create_graph=True)
+            f = f - g_dg                                   # double Stratonovich correction
+            grads = vjp(f, self._inputs(y), grad_outputs=a, allow_unused=True, retain_graph=True)
+            a_dg, = vjp(g, y, grad_outputs=a, allow_unused=True, retain_graph=True)
+            extra = vjp(g, self._inputs(y), grad_outputs=a_dg, allow_unused=True, retain_graph=True)
+            return [f.detach()] + [p + q for p, q in zip(grads, extra)]
+        columns = [c.squeeze(dim=-1) for c in g.split(1, dim=-1)]
+        dg_g = sum(jvp(c, y, grad_inputs=c, allow_unused=True, create_graph=True)[0] for c in columns)
+        f = f - dg_g
+        grads = vjp(f, self._inputs(y), grad_outputs=a, allow_unused=True, retain_graph=True)
+        for c in columns:
+            a_dg, = vjp(c, y, grad_outputs=a, allow_unused=True, retain_graph=True)
+            extra = vjp(c, self._inputs(y), grad_outputs=a_dg, allow_unused=True, retain_graph=True)
+            grads = [p + q for p, q in zip(grads, extra)]
+        return [f.detach()] + grads
+
+    def _diffusion_parts(self, g_prod, y, a):
+        """(g.v, vjp_y, vjp_theta...) -- adjoint_sde.py:218-230."""
+        grads = vjp(g_prod, self._inputs(y), grad_outputs=a, allow_unused=True, retain_graph=True)
+        return [g_prod.detach()] + grads
+
+    @staticmethod
+    def _leaf(y):
+        return y.detach().requires_grad_(True)
+
+    # -- what the backward solvers call ------------------------------------------------------------------
+    def f_and_g_prod(self, t, y, a, v):
+        """Drift and diffusion-product parts at forward time t (adjoint_sde.py:296-323)."""
+        fwd = self.forward_sde
+        y = self._leaf(y)
+        with torch.enable_grad():
+            if self._correction is None:
+                f, g_prod = fwd.f_and_g_prod(t, y, v)
+                g = None
+            else:
+                f, g = fwd.f_and_g(t, y)
+                g_prod = fwd.prod(g, v)
+            return self._drift_parts(f, g, y, a), self._diffusion_parts(g_prod, y, a)
+
+    def f(self, t, y, a):
+        """Drift parts only (adjoint_sde.py:236-252)."""
+        fwd = self.forward_sde
+        y = self._leaf(y)
+        with torch.enable_grad():
+            if self._correction is None:
+                return self._drift_parts(fwd.f(t, y), None, y, a)
+            f, g = fwd.f_and_g(t, y)
+            return self._drift_parts(f, g, y, a)
+
+    def g_prod_and_gdg_prod(self, t, y, a, v1, v2):
+        """Milstein pieces of the adjoint of a diagonal-noise SDE (adjoint_sde.py:332-377)."""
+        if self.forward_sde.noise_type != NOISE_TYPES.diagonal:
+            raise NotImplementedError
+        fwd = self.forward_sde
+        y = self._leaf(y)
+        inputs = self._inputs(y)
+        with torch.enable_grad():
+            g = fwd.g(t, y)
+            g_prod = fwd.prod(g, v1)
+            vg_dg, = vjp(g, y, grad_outputs=v2 * g, allow_unused=True, retain_graph=True)
+            dgdy, = vjp(g.sum(), y, allow_unused=True, retain_graph=True)
+            prod_partials = vjp(g, inputs, grad_outputs=a * v2 * dgdy, allow_unused=True, retain_graph=True)
+            avg_dg, = vjp(g, y, grad_outputs=(a * v2 * g).detach(), allow_unused=True, create_graph=True)
+            mixed_partials = vjp(avg_dg.sum(), inputs, allow_unused=True, retain_graph=True)
+            gdg_parts = [vg_dg] + [p - q for p, q in zip(prod_partials, mixed_partials)]
+            return self._diffusion_parts(g_prod, y, a), gdg_parts
+
+    # the reference never evaluates these for an adjoint SDE (adjoint_sde.py:254-281)
+    def g(self, t, y):
+        raise RuntimeError("Adjoint `g` not defined. Please report a bug to torchsde.")
+
+    def f_and_g(self, t, y):
+        raise RuntimeError("Adjoint `f_and_g` not defined. Please report a bug to torchsde.")
+
+    def prod(self, g, v):
+        raise RuntimeError("Adjoint `prod` not defined. Please report a bug to torchsde.")
+
+
+class _AugState:
+    """The augmented state as separate persistent buffers: [y, a_y, a_theta_0, ...]."""
+
+    def __init__(self, tensors):
+        self.t = list(tensors)
+
+    @classmethod
+    def like(cls, other):
+        return cls([torch.empty_like(x) for x in other.t])
+
+
+def _update(dst, src, F, G, D, cF, cG):
+    """dst = src + F*cF + cG*G (+ D), with the reference's sign on the y segment; ONE kernel launch."""
+    segs = []
+    for i, s in enumerate(src.t):
+        sign = -1.0 if i == 0 else 1.0
+        segs.append(dict(out=dst.t[i], s=s, F=None if F is None else F[i], G=None if G is None else G[i],
+                         D=None if D is None else D[i], sF=sign, sG=sign, sD=1.0))
+    K.aug_update(segs, cF, cG, src.t[0].dtype, src.t[0].device)
+
+
+def _check_adjoint_method(adjoint_sde, adjoint_method, adjoint_options, bm):
+    """The compatibility errors the reference raises when it builds the backward solver (adjoint.py:83-93)."""
+    cls = solvers.select(adjoint_method, adjoint_sde.sde_type)
+    if cls is solvers.SRK:
+        raise ValueError("Stochastic Runge–Kutta methods cannot be used for adjoint SDEs, because it requires "
+                         "direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
+                         "diffusion-vector product. Use a different method instead.")
+    if issubclass(cls, solvers._Milstein) and adjoint_options.get(METHOD_OPTIONS.grad_free, False):
+        raise ValueError(f"Derivative-free Milstein cannot be used for adjoint SDEs, because it requires "
+                         f"direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
+                         f"diffusion-vector product. Use derivative-using Milstein instead: "
+                         f"`adjoint_options=dict({METHOD_OPTIONS.grad_free}=False)`")
+    if adjoint_sde.sde_type != cls.sde_type:
+        raise ValueError(f"SDE is of type {adjoint_sde.sde_type} but solver is for type {cls.sde_type}")
+    if adjoint_sde.noise_type not in cls.noise_types:
+        raise ValueError(f"SDE has noise type {adjoint_sde.noise_type} but solver only supports noise types "
+                         f"{cls.noise_types}")
+    if bm.levy_area_approximation not in cls.levy_area_approximations:
+        raise ValueError(f"SDE solver requires one of {cls.levy_area_approximations} set as the "
+                         f"`levy_area_approximation` on the Brownian motion.")
+    return cls
+
+
+class _SdeintAdjointMethod(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol,
+                dt_min, adjoint_options, len_extras, y0, *extras_and_adjoint_params):
+        ctx.sde, ctx.dt, ctx.bm = sde, dt, bm
+        ctx.adjoint_method, ctx.adjoint_options = adjoint_method, adjoint_options
+        ctx.len_extras = len_extras
+        extra_solver_state = extras_and_adjoint_params[:len_extras]
+        adjoint_params = extras_and_adjoint_params[len_extras:]
+        # detached on purpose: the backward pass differentiates f, g at leaf copies of y (adjoint.py:48-51)
+        y0 = y0.detach()
+        extra_solver_state = tuple(x.detach() for x in extra_solver_state)
+        ys, extra_solver_state = solver.integrate(y0, ts, extra_solver_state)
+        ctx.save_for_backward(ys, ts, *adjoint_params)
+        return (ys, *extra_solver_state)
+
+    @staticmethod
+    def backward(ctx, grad_ys, *grad_extra_solver_state):
+        if torch.is_grad_enabled():
+            raise NotImplementedError("torchsde_amd: double backward through sdeint_adjoint is not supported.")
+        ys, ts, *adjoint_params = ctx.saved_tensors
+        sde, bm, dt = ctx.sde, ctx.bm, ctx.dt
+        adjoint_sde = AdjointSDE(sde, adjoint_params)
+        method_cls = _check_adjoint_method(adjoint_sde, ctx.adjoint_method, ctx.adjoint_options, bm)
+        kind = ("euler" if method_cls is solvers.Euler else "midpoint" if method_cls is solvers.Midpoint
+                else "milstein")
+        ito = sde.sde_type == SDE_TYPES.ito
+        device, dtype = ys.device, ys.dtype
+        native = bm if isinstance(bm, BrownianInterval) else None
+        reverse_bm = None if native is not None else ReverseBrownian(bm)
+
+        ts_host = timegrid.ts_to_host(ts)
+        T = ys.size(0)
+        state = _AugState([ys[-1].clone(), grad_ys[-1].contiguous().clone()] +
+                          [torch.zeros_like(p) for p in adjoint_params])
+        other = _AugState.like(state)
+        mid = _AugState.like(state) if kind == "midpoint" else None
+
+        for i in range(T - 1, 0, -1):
+            grid = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)
+            n = grid.n_steps
+            np_dtype = grid.t.dtype.type
+            tau64 = grid.t_f64()
+            # forward-time stage tensors: -(tau0), and for midpoint -(tau0 + dt/2)   (adjoint_sde.py passes -t)
+            stage = np.empty((max(n, 1), 2), dtype=grid.t.dtype)
+            stage[:n, 0] = -grid.t[:-1]
+            stage[:n, 1] = -(grid.t[:-1] + np_dtype(0.5) * grid.dt)
+            stage_dev = torch.from_numpy(stage).to(device)
+            stage_rows = [r.unbind(0) for r in stage_dev.unbind(0)]
+            tau_dev = None
+            cells = None
+            if native is not None:
+                cells = native.match_grid(-tau64[::-1]) if native.frozen else None
+            else:
+                tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
+
+            for k in range(n):
+                step_dt = grid.dt[k]
+                if native is not None:
+                    if cells is not None:
+                        c = int(cells[n - 1 - k])
+                        noise = NoiseSpec.generated(native, c, native.cell_width(c))
+                        v, _ = noise.materialise()
+                    else:
+                        v, _ = native.increment(-tau64[k + 1], -tau64[k])
+                else:
+                    v = reverse_bm(tau_dev[k], tau_dev[k + 1])
+                y, a = state.t[0], state.t[1]
+                t_fwd = stage_rows[k][0]
+                if kind == "euler":
+                    F, G = adjoint_sde.f_and_g_prod(t_fwd, y, a, v)
+                    _update(other, state, F, G, None, step_dt, 1.0)
+                elif kind == "midpoint":
+                    half_dt = np_dtype(0.5) * step_dt
+                    F, G = adjoint_sde.f_and_g_prod(t_fwd, y, a, v)
+                    _update(mid, state, F, G, None, half_dt, 0.5)
+                    F2, G2 = adjoint_sde.f_and_g_prod(stage_rows[k][1], mid.t[0], mid.t[1], v)
+                    _update(other, state, F2, G2, None, step_dt, 1.0)
+                else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
+                    v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
+                    F = adjoint_sde.f(t_fwd, y, a)
+                    G, D = adjoint_sde.g_prod_and_gdg_prod(t_fwd, y, a, v, v2)
+                    _update(other, state, F, G, D, step_dt, 1.0)
+                state, other = other, state
+            # adjoint.py:114-116
+            state.t[0].copy_(ys[i - 1])
+            state.t[1].add_(grad_ys[i - 1])
+
+        out = [state.t[1]] + ([None] * ctx.len_extras) + state.t[2:]
+        return (None,) * 13 + tuple(out)
+
+
+def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e-3, adaptive=False,
+                   adjoint_adaptive=False, rtol=1e-5, adjoint_rtol=1e-5, atol=1e-4, adjoint_atol=1e-4, dt_min=1e-5,
+                   options=None, adjoint_options=None, adjoint_params=None, names=None, logqp=False, extra=False,
+                   extra_solver_state=None, **unused_kwargs):
+    """Numerically integrate an SDE with stochastic-adjoint gradients (see ``torchsde.sdeint_adjoint``)."""
+    contract.handle_unused_kwargs(unused_kwargs, msg="`sdeint_adjoint`")
+    del unused_kwargs
+
+    if adjoint_params is None and not isinstance(sde, nn.Module):
+        raise ValueError("`sde` must be an instance of nn.Module to specify the adjoint parameters; alternatively they "
+                         "can be specified explicitly via the `adjoint_params` argument. If there are no parameters "
+                         "then it is allowable to set `adjoint_params=()`.")
+
+    sde, y0, ts, bm, method, options = contract.check_contract(sde, y0, ts, bm, method, adaptive, options, names,
+                                                               logqp)
+    contract.assert_no_grad(["ts", "dt", "rtol", "adjoint_rtol", "atol", "adjoint_atol", "dt_min"],
+                            [ts, dt, rtol, adjoint_rtol, atol, adjoint_atol, dt_min])
+    adjoint_params = tuple(sde.parameters()) if adjoint_params is None else tuple(adjoint_params)
+    adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
+    adjoint_method = _select_default_adjoint_method(sde, method, adjoint_method)
+    adjoint_options = {} if adjoint_options is None else adjoint_options.copy()
+    if adjoint_adaptive:
+        raise NotImplementedError("torchsde_amd: adaptive stepping of the adjoint is not part of the hot path built "
+                                  "so far; use `adjoint_adaptive=False`.")
+    if method == METHODS.reversible_heun and adjoint_method != METHODS.adjoint_reversible_heun:
+        warnings.warn(f"method={repr(method)}, but adjoint_method!={repr(METHODS.adjoint_reversible_heun)}.")
+
+    solver_cls = solvers.select(method=method, sde_type=sde.sde_type)
+    solver = solver_cls(sde=sde, bm=bm, dt=dt, adaptive=adaptive, rtol=rtol, atol=atol, dt_min=dt_min,
+                        options=options)
+    # fail early (at call time, like the reference would at backward time) on unusable adjoint methods
+    _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
+    if extra_solver_state is None:
+        extra_solver_state = solver.init_extra_solver_state(ts[0], y0)
+
+    ys, *extra_solver_state = _SdeintAdjointMethod.apply(
+        sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,
+        adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
+    return contract.parse_return(y0, ys, tuple(extra_solver_state), extra, logqp)
+
+
+def _select_default_adjoint_method(sde, method, adjoint_method):
+    """adjoint.py:281-296."""
+    if adjoint_method is not None:
+        return adjoint_method
+    if method == METHODS.reversible_heun:
+        return METHODS.adjoint_reversible_heun
+    if sde.sde_type == SDE_TYPES.stratonovich:
+        return METHODS.midpoint
+    return METHODS.milstein if sde.noise_type == NOISE_TYPES.diagonal else METHODS.euler

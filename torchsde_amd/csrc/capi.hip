@@ -210,15 +210,12 @@ int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int 
   if (!segs || nseg < 0) return bad_arg("tsde_aug_update", "bad segment list");
   if (dtype != TSDE_F32 && dtype != TSDE_F64) return bad_arg("tsde_aug_update", "dtype");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_AUG_UPDATE, s);
   for (int i = 0; i < nseg; ++i) {
-    if (segs[i].n == 0) continue;
-    if (!segs[i].out || !segs[i].s) return bad_arg("tsde_aug_update", "segment without state");
-    const hipError_t e = (dtype == TSDE_F32) ? tsde::launch_aug_seg<float>(segs[i], cF, cG, s)
-                                             : tsde::launch_aug_seg<double>(segs[i], cF, cG, s);
-    if (e != hipSuccess) return fail(e, "tsde_aug_update");
+    if (segs[i].n > 0 && (!segs[i].out || !segs[i].s)) return bad_arg("tsde_aug_update", "segment without state");
   }
-  return 0;
+  ProfScope p(TSDE_KID_AUG_UPDATE, s);
+  if (dtype == TSDE_F32) return fail(tsde::launch_aug_segments<float>(segs, nseg, cF, cG, s), "tsde_aug_update");
+  return fail(tsde::launch_aug_segments<double>(segs, nseg, cF, cG, s), "tsde_aug_update");
 }
 
 int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, int dtype,

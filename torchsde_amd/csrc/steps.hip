@@ -280,6 +280,37 @@ struct AugSegOp {
   }
 };
 
+// All segments of the augmented state (y, a_y, one a_theta per parameter tensor) in ONE launch:
+// a block walks 4096-element chunks; the chunk -> segment map is a small table in kernel arguments.
+constexpr int kAugMaxSeg = 24;
+constexpr int kAugChunk = 4096;
+
+template <typename T>
+struct AugTable {
+  AugSegOp<T> seg[kAugMaxSeg];
+  int64_t n[kAugMaxSeg];
+  int32_t chunk_begin[kAugMaxSeg + 1];
+  int32_t vec[kAugMaxSeg];
+  int32_t nseg;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) aug_multi_kernel(const AugTable<T> tb) {
+  const int total = tb.chunk_begin[tb.nseg];
+  for (int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+    int sidx = 0;
+    while (sidx + 1 < tb.nseg && chunk >= tb.chunk_begin[sidx + 1]) ++sidx;
+    const AugSegOp<T>& op = tb.seg[sidx];
+    const int64_t base = (int64_t)(chunk - tb.chunk_begin[sidx]) * kAugChunk;
+    const int64_t end = (base + kAugChunk < tb.n[sidx]) ? base + kAugChunk : tb.n[sidx];
+    if (tb.vec[sidx]) {
+      for (int64_t i = base + (int64_t)threadIdx.x * 4; i < end; i += kBlock * 4) op.template run<4>(i);
+    } else {
+      for (int64_t i = base + threadIdx.x; i < end; i += kBlock) op.template run<1>(i);
+    }
+  }
+}
+
 template <typename T>
 struct InterpOp {
   T* out;
@@ -512,12 +543,34 @@ hipError_t launch_srk_stage(int stage, void* out0, void* out1, const void* y0, c
 }
 
 template <typename T>
-hipError_t launch_aug_seg(const tsde_seg_t& sg, double cF, double cG, hipStream_t s) {
-  AugSegOp<T> op{(T*)sg.out, (const T*)sg.s, (const T*)sg.F, (const T*)sg.G, (const T*)sg.D,
-                 (T)cF,      (T)cG,          (T)sg.sF,       (T)sg.sG,       (T)sg.sD};
-  const bool vec = (sg.n % 4 == 0) && aligned16(sg.out) && aligned16(sg.s) && (!sg.F || aligned16(sg.F)) &&
-                   (!sg.G || aligned16(sg.G)) && (!sg.D || aligned16(sg.D));
-  return launch_elementwise(op, sg.n, vec, s);
+hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, double cG, hipStream_t s) {
+  int done = 0;
+  while (done < nseg) {
+    AugTable<T> tb;
+    tb.nseg = 0;
+    tb.chunk_begin[0] = 0;
+    while (done < nseg && tb.nseg < kAugMaxSeg) {
+      const tsde_seg_t& sg = segs[done++];
+      if (sg.n <= 0) continue;
+      const int k = tb.nseg++;
+      tb.seg[k] = AugSegOp<T>{(T*)sg.out, (const T*)sg.s, (const T*)sg.F, (const T*)sg.G, (const T*)sg.D,
+                              (T)cF,      (T)cG,          (T)sg.sF,       (T)sg.sG,       (T)sg.sD};
+      tb.n[k] = sg.n;
+      // chunks start at multiples of 4096 elements, so pointer alignment decides the vector path
+      tb.vec[k] = ((sg.n % 4 == 0) && aligned16(sg.out) && aligned16(sg.s) && (!sg.F || aligned16(sg.F)) &&
+                   (!sg.G || aligned16(sg.G)) && (!sg.D || aligned16(sg.D)))
+                      ? 1
+                      : 0;
+      tb.chunk_begin[k + 1] = tb.chunk_begin[k] + (int32_t)((sg.n + kAugChunk - 1) / kAugChunk);
+    }
+    if (tb.nseg == 0) break;
+    const int total = tb.chunk_begin[tb.nseg];
+    const int grid = total < kMaxGrid ? total : kMaxGrid;
+    hipLaunchKernelGGL(aug_multi_kernel<T>, dim3(grid), dim3(kBlock), 0, s, tb);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <typename T>
@@ -585,7 +638,7 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
                                                  double, double, int, const tsde_noise_t*, hipStream_t);             \
   template hipError_t launch_srk_stage<T>(int, void*, void*, const void*, const void* const[4], const void* const[4], \
                                           int64_t, double, double, double, const tsde_noise_t*, hipStream_t);        \
-  template hipError_t launch_aug_seg<T>(const tsde_seg_t&, double, double, hipStream_t);                             \
+  template hipError_t launch_aug_segments<T>(const tsde_seg_t*, int, double, double, hipStream_t);                   \
   template hipError_t launch_interp<T>(void*, const void*, const void*, int64_t, double, double, hipStream_t);
 
 TSDE_INSTANTIATE(float)

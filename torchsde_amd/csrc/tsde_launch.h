@@ -51,7 +51,7 @@ hipError_t launch_srk_stage(int stage, void* out0, void* out1, const void* y0, c
                             const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
                             const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
-hipError_t launch_aug_seg(const tsde_seg_t& sg, double cF, double cG, hipStream_t s);
+hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, double cG, hipStream_t s);
 template <typename T>
 hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s);
 
