@@ -1,0 +1,201 @@
+"""The reference's own BrownianInterval property tests (reference tests/test_brownian_interval.py:69-334),
+re-pointed at the counter-RNG generator on the GPU, plus strong-order convergence on its sample paths."""
+import math
+
+import numpy as np
+import numpy.random as npr
+import pytest
+import torch
+from scipy.stats import kstest, linregress
+
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D = 3
+SMALL_BATCH, LARGE_BATCH = 16, 131072
+REPS, MEDIUM_REPS, LARGE_REPS = 2, 25, 500
+ALPHA = 0.00001
+F64 = torch.float64
+
+
+def _U_to_H(W, U, h):
+    return U / h - .5 * W
+
+
+def _levy_returns():
+    yield "none", False
+    yield "space-time", False
+    yield "space-time", True
+
+
+@pytest.mark.parametrize("levy,return_U", _levy_returns())
+def test_shape(levy, return_U):
+    import torchsde_amd
+    for shape in ((SMALL_BATCH, D), (SMALL_BATCH,), ()):
+        bm = torchsde_amd.BrownianInterval(t0=0., t1=1., size=shape, dtype=F64, device=DEV,
+                                           levy_area_approximation=levy)
+        ta, tb = sorted(npr.uniform(0, 1, 2))
+        with pytest.warns(UserWarning):
+            s1 = bm(ta, return_U=return_U)
+        s3 = bm(ta, tb, return_U=return_U)
+        for s in (s1, s3):
+            for x in (s if return_U else (s,)):
+                assert x.shape == shape and x.device.type == "cuda"
+
+
+@pytest.mark.parametrize("levy,return_U", _levy_returns())
+def test_determinism_large(levy, return_U):
+    """Re-querying 500 random intervals gives identical tensors (there is no cache to fall out of)."""
+    import torchsde_amd
+    bm = torchsde_amd.BrownianInterval(t0=0., t1=1., size=(SMALL_BATCH, D), dtype=F64, device=DEV,
+                                       levy_area_approximation=levy)
+    cache = {}
+    for _ in range(LARGE_REPS):
+        ta, tb = sorted(npr.uniform(0, 1, 2))
+        val = bm(ta, tb, return_U=return_U)
+        cache[ta, tb] = tuple(v.clone() for v in (val if return_U else (val,)))
+    for (ta, tb), vals in cache.items():
+        again = bm(ta, tb, return_U=return_U)
+        for v1, v2 in zip(vals, again if return_U else (again,)):
+            assert torch.equal(v1, v2)
+
+
+@pytest.mark.parametrize("levy", ["none", "space-time"])
+def test_normality_simple(levy):
+    """W(t0,t) | W(t0,t1) is the Brownian bridge; H(t0,t) ~ N(0, (t-t0)/12)  (reference :164-195)."""
+    import torchsde_amd
+    t0, t1 = 0.0, 1.0
+    for _ in range(REPS):
+        base_W = torch.tensor(npr.randn(), device=DEV, dtype=F64).repeat(LARGE_BATCH)
+        bm = torchsde_amd.BrownianInterval(t0=t0, t1=t1, W=base_W, levy_area_approximation=levy)
+        t_ = npr.uniform(low=t0, high=t1)
+        W = bm(t0, t_)
+        mean_W = base_W * (t_ - t0) / (t1 - t0)
+        std_W = math.sqrt((t1 - t_) * (t_ - t0) / (t1 - t0))
+        _, pval = kstest(((W - mean_W) / std_W).cpu().numpy(), "norm")
+        assert pval >= ALPHA
+        if levy != "none":
+            W, U = bm(t0, t_, return_U=True)
+            H = _U_to_H(W, U, t_ - t0)
+            _, pval = kstest((H / math.sqrt((t_ - t0) / 12)).cpu().numpy(), "norm")
+            assert pval >= ALPHA
+
+
+@pytest.mark.parametrize("levy", ["none", "space-time"])
+def test_normality_conditional(levy):
+    """Conditional bridge law of (W1, W2, H1, H2) given (W, H) on random nested intervals (reference :198-258)."""
+    import torchsde_amd
+    for _ in range(REPS):
+        bm = torchsde_amd.BrownianInterval(t0=0., t1=1., size=(LARGE_BATCH,), dtype=F64, device=DEV,
+                                           levy_area_approximation=levy)
+        for _ in range(MEDIUM_REPS):
+            ta, t_, tb = sorted(npr.uniform(low=0., high=1., size=(3,)))
+            W, W1, W2 = bm(ta, tb), bm(ta, t_), bm(t_, tb)
+            std = math.sqrt((tb - t_) * (t_ - ta) / (tb - ta))
+            for Wp, frac in ((W1, (t_ - ta) / (tb - ta)), (W2, (tb - t_) / (tb - ta))):
+                _, pval = kstest(((Wp - W * frac) / std).cpu().numpy(), "norm")
+                assert pval >= ALPHA
+            if levy != "none":
+                W, U = bm(ta, tb, return_U=True)
+                W1, U1 = bm(ta, t_, return_U=True)
+                W2, U2 = bm(t_, tb, return_U=True)
+                h, h1, h2 = tb - ta, t_ - ta, tb - t_
+                denom = math.sqrt(h1 ** 3 + h2 ** 3)
+                a = h1 ** 3.5 * h2 ** 0.5 / (2 * h * denom)
+                b = h1 ** 0.5 * h2 ** 3.5 / (2 * h * denom)
+                c = math.sqrt(3) * h1 ** 1.5 * h2 ** 1.5 / (6 * denom)
+                H, H1, H2 = _U_to_H(W, U, h), _U_to_H(W1, U1, h1), _U_to_H(W2, U2, h2)
+                for Hp, hp, coef in ((H1, h1, a), (H2, h2, b)):
+                    resc = (Hp - H * (hp / h) ** 2) / (math.sqrt(coef ** 2 + c ** 2) / hp)
+                    # H_child also depends linearly on the parent's W; only the conditional law given (W, H) is normal
+                    # with this std when W's contribution is removed -- the reference tests exactly this statistic.
+                    _, pval = kstest(resc.cpu().numpy(), "norm")
+                    assert pval >= ALPHA
+
+
+@pytest.mark.parametrize("levy", ["none", "space-time"])
+def test_consistency(levy):
+    """W1 + W2 = W and U1 + U2 + (tb - t) W1 = U to 1e-6 (reference :261-288)."""
+    import torchsde_amd
+    for _ in range(REPS):
+        bm = torchsde_amd.BrownianInterval(t0=0., t1=1., size=(LARGE_BATCH,), dtype=F64, device=DEV,
+                                           levy_area_approximation=levy)
+        for _ in range(MEDIUM_REPS):
+            ta, t_, tb = sorted(npr.uniform(low=0., high=1., size=(3,)))
+            if levy == "none":
+                W, W1, W2 = bm(ta, tb), bm(ta, t_), bm(t_, tb)
+            else:
+                W, U = bm(ta, tb, return_U=True)
+                W1, U1 = bm(ta, t_, return_U=True)
+                W2, U2 = bm(t_, tb, return_U=True)
+                torch.testing.assert_close(U1 + U2 + (tb - t_) * W1, U, rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(W1 + W2, W, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("random_order", [False, True])
+@pytest.mark.parametrize("levy,return_U", _levy_returns())
+def test_entropy_determinism(random_order, levy, return_U):
+    """Same entropy => same values; with halfway_tree also under a permuted query order (reference :291-334).
+    (The new generator is order-independent in both modes.)"""
+    import torchsde_amd
+    points1, points2 = torch.rand(300), torch.rand(300)
+    tol = 1e-6 if random_order else 0.
+
+    def make():
+        return torchsde_amd.BrownianInterval(t0=0., t1=1., size=(), dtype=F64, device=DEV, entropy=56789, tol=tol,
+                                             levy_area_approximation=levy, halfway_tree=random_order)
+    bm = make()
+    outs = [bm(*sorted([float(p1), float(p2)]), return_U=return_U) for p1, p2 in zip(points1, points2)]
+    bm = make()
+    perm = torch.randperm(300)
+    for i in perm.tolist():
+        again = bm(*sorted([float(points1[i]), float(points2[i])]), return_U=return_U)
+        for a, b in zip(outs[i] if return_U else (outs[i],), again if return_U else (again,)):
+            assert torch.equal(a, b)
+
+
+def test_fp32_increment_moments_by_cell():
+    """Independent cells: mean 0, variance h, no correlation between neighbouring cells or neighbouring rows."""
+    import torchsde_amd
+    B, m, dt = 1 << 16, 8, 2.0 ** -6
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), dtype=torch.float32, device=DEV, entropy=1, dt=dt)
+    W = torch.stack([bm(k * dt, (k + 1) * dt) for k in range(8)]).double()
+    n = B * m
+    assert W.mean().abs().item() < 5 * math.sqrt(dt / (8 * n))
+    assert abs(W.var().item() / dt - 1) < 5 * math.sqrt(2 / (8 * n))
+    flat = W.reshape(8, -1)
+    corr_cells = torch.corrcoef(flat)[0, 1:].abs().max().item()
+    corr_rows = torch.corrcoef(torch.stack([W[0, :-1].reshape(-1), W[0, 1:].reshape(-1)]))[0, 1].abs().item()
+    assert corr_cells < 5 / math.sqrt(n) and corr_rows < 5 / math.sqrt(n)
+
+
+# ---- strong order on the generator's own sample paths ------------------------------------------------------------
+REFERENCE_SLOPES = {   # reference on GBM vs its closed form, same procedure
+    ("ito", "euler"): 0.591, ("ito", "milstein"): 1.018, ("ito", "srk"): 1.522, ("stratonovich", "midpoint"): 1.084,
+}
+
+
+@pytest.mark.parametrize("sde_type,method", list(REFERENCE_SLOPES))
+def test_strong_order_slopes(sde_type, method):
+    """GBM against y0*exp((mu - sigma^2/2)t + sigma W_t) on the SAME path: slope of 0.5*log(mse) vs log(dt),
+    dt = 2^-3..2^-8, must land within 0.1 of the reference's slope. SRK's 1.5 collapses if U has the wrong law."""
+    import torchsde_amd
+    B, d, t1 = 8192, 4, 1.0
+    sde = problems.GBMDiag(d, sde_type, dtype=F64).to(DEV)
+    y0 = torch.full((B, d), 0.1, dtype=F64, device=DEV)
+    ts = torch.tensor([0.0, t1], dtype=F64, device=DEV)
+    levy = "space-time" if method == "srk" else "none"
+    bm = torchsde_amd.BrownianInterval(0.0, t1, size=(B, d), dtype=F64, device=DEV, entropy=271828, dt=2.0 ** -8,
+                                       levy_area_approximation=levy)
+    exact = sde.exact(y0, t1, bm(0.0, t1))
+    log_dt, log_rmse = [], []
+    with torch.no_grad():
+        for k in range(3, 9):
+            dt = 2.0 ** -k
+            ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt)
+            mse = ((ys[-1] - exact) ** 2).sum(dim=1).mean().item()
+            log_dt.append(math.log(dt))
+            log_rmse.append(0.5 * math.log(mse))
+    slope = linregress(log_dt, log_rmse).slope
+    assert abs(slope - REFERENCE_SLOPES[(sde_type, method)]) < 0.1, slope

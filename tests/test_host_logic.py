@@ -1,0 +1,213 @@
+"""CPU tests of everything that is not a kernel: the C ABI surface, the contract checks, the time grid, the
+Brownian cell bookkeeping and the loud-failure rules. (No GPU compute is attempted.)"""
+import ctypes
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import torchsde_amd
+from tests import helpers, problems
+from torchsde_amd import _native, contract, solvers, timegrid
+from torchsde_amd.brownian import BrownianInterval, uniform_edges
+from torchsde_amd.sde import ForwardSDE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------------
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "torchsde_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsde_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = _header_symbols()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/torchsde_amd.h but not exported"
+
+
+def test_python_binding_covers_header():
+    assert sorted(_native.SIGNATURES) == _header_symbols()
+    assert _native.load().tsde_abi_version() == 1
+
+
+def test_noise_struct_layout_matches_header():
+    assert ctypes.sizeof(_native.Noise) == 56
+    assert _native.Noise.h.offset == 40 and _native.Noise.bcast_d.offset == 48
+    assert ctypes.sizeof(_native.Seg) == 72
+
+
+def test_cpu_tensors_fail_loudly():
+    sde = problems.make("gbm_ito", d=4)
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        torchsde_amd.sdeint(sde, torch.full((3, 4), 0.1), torch.tensor([0.0, 0.1]), method="euler", dt=0.05)
+    bm = BrownianInterval(0.0, 1.0, size=(3, 4))
+    with pytest.raises(_native.NativeLibraryError):
+        bm(0.0, 0.5)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libtorchsde_amd.so")
+    with pytest.raises(_native.NativeLibraryError, match="not built"):
+        _native.load()
+
+
+# ---- time grid --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["f32_1e-3", "f32_dyadic", "f32_multi", "f64_multi", "f32_linspace20", "f64_1e-2",
+                                  "f32_coarse"])
+def test_time_grid_matches_reference_queries(name):
+    """The host-side grid equals, query for query, what the reference's stepping loop asks its Brownian motion."""
+    z = helpers.load("timegrid.npz")
+    grid = timegrid.build(z[name + "__ts"], float(z[name + "__dt"]))
+    t = grid.t_f64()
+    assert np.array_equal(np.stack([t[:-1], t[1:]], axis=1), z[name + "__queries"])
+
+
+def test_time_grid_fp32_remainder_and_interpolation():
+    grid = timegrid.build(np.array([0.0, 1.0], dtype=np.float32), 1e-3)
+    assert grid.n_steps == 1001                       # 1000 steps + a 9.3e-6 remainder
+    assert grid.outputs[-1][1] == 1001 and grid.outputs[-1][2:] == (0.0, 1.0)
+    grid = timegrid.build(np.array([0.0, 0.25, 0.5], dtype=np.float64), 0.1)
+    assert grid.n_steps == 5                          # no clipping at 0.25: interpolated from the (0.2, 0.3) step
+    kp, kc, w0, w1 = grid.outputs[0]
+    assert (kp, kc) == (2, 3) and abs(w0 - 0.5) < 1e-12 and abs(w1 - 0.5) < 1e-12
+
+
+# ---- contract ------------------------------------------------------------------------------------------------
+class _NoNoiseType:
+    sde_type = "ito"
+
+    def f(self, t, y):
+        return y
+
+    def g(self, t, y):
+        return y
+
+
+def test_contract_errors():
+    y0 = torch.zeros(3, 4)
+    ts = torch.tensor([0.0, 1.0])
+    sde = problems.make("gbm_ito", d=4)
+    with pytest.raises(ValueError, match="noise_type"):
+        contract.check_contract(_NoNoiseType(), y0, ts, None, None, False, None, None, False)
+    with pytest.raises(ValueError, match="2-dimensional"):
+        contract.check_contract(sde, torch.zeros(4), ts, None, None, False, None, None, False)
+    with pytest.raises(ValueError, match="strictly increasing"):
+        contract.check_contract(sde, y0, torch.tensor([0.0, 0.0]), None, None, False, None, None, False)
+    with pytest.raises(ValueError, match="Expected method"):
+        contract.check_contract(sde, y0, ts, None, "rk4", False, None, None, False)
+    with pytest.raises(ValueError, match="Batch sizes not consistent"):
+        bm = BrownianInterval(0.0, 1.0, size=(5, 4))
+        contract.check_contract(sde, y0, ts, bm, None, False, None, None, False)
+    with pytest.raises(ValueError, match="list/tuple of floats"):
+        contract.check_contract(sde, y0, "0,1", None, None, False, None, None, False)
+    scalar_bad = problems.ScalarTrig(4)
+    scalar_bad.g = lambda t, y: torch.ones(y.size(0), 4, 2)
+    with pytest.raises(ValueError, match="Scalar noise must have only one channel"):
+        contract.check_contract(scalar_bad, y0, ts, None, None, False, None, None, False)
+
+
+def test_contract_defaults():
+    y0 = torch.zeros(3, 4)
+    ts = [0.0, 1.0]
+    for prob, method, levy in [("gbm_ito", "srk", "space-time"), ("general_ito", "euler", "none"),
+                               ("gbm_strat", "midpoint", "none"), ("additive_ito", "srk", "space-time")]:
+        sde, y, t, bm, m, opts = contract.check_contract(problems.make(prob), y0, ts, None, None, False, None, None,
+                                                         False)
+        assert isinstance(sde, ForwardSDE) and m == method and bm.levy_area_approximation == levy
+        assert torch.is_tensor(t) and t.dtype == y0.dtype and opts == {}
+        assert bm.shape == (3, 4 if prob != "additive_ito" else 3) and not bm.frozen
+
+
+def test_forward_sde_dispatch_flags():
+    assert not ForwardSDE(problems.GBMDiag(4)).user_product
+    assert not ForwardSDE(problems.GBMViaFAndG(4)).user_product
+    assert ForwardSDE(problems.GBMViaGProd(4)).user_product
+    assert ForwardSDE(problems.GBMViaFAndGProd(4)).user_product
+
+
+def test_solver_compatibility_errors():
+    bm = BrownianInterval(0.0, 1.0, size=(3, 4))
+    kw = dict(bm=bm, dt=0.1, adaptive=False, rtol=1e-5, atol=1e-4, dt_min=1e-5)
+    with pytest.raises(ValueError, match="only supports noise types"):
+        solvers.MilsteinIto(sde=ForwardSDE(problems.make("general_ito")), options={}, **kw)
+    with pytest.raises(ValueError, match="levy_area_approximation"):
+        solvers.SRK(sde=ForwardSDE(problems.make("gbm_ito")), options={}, **kw)
+    with pytest.raises(ValueError, match="solver is for type"):
+        solvers.Euler(sde=ForwardSDE(problems.make("gbm_strat")), options={}, **kw)
+    with pytest.raises(ValueError, match="does not match any known method"):
+        solvers.select("rk4", "ito")
+    with pytest.raises(NotImplementedError):
+        solvers.select("reversible_heun", "stratonovich")
+
+
+def test_unknown_kwargs_warn():
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        contract.handle_unused_kwargs({"foo": 1}, msg="`sdeint`")
+    assert any("Unexpected arguments" in str(x.message) for x in w)
+
+
+# ---- Brownian bookkeeping (host side only) -------------------------------------------------------------------------
+def test_brownian_constructor_validation():
+    with pytest.raises(ValueError, match="less than terminal"):
+        BrownianInterval(1.0, 0.0, size=(2,))
+    with pytest.raises(ValueError, match="`tol` should be positive"):
+        BrownianInterval(0.0, 1.0, size=(2,), halfway_tree=True)
+    with pytest.raises(ValueError, match="non-negative"):
+        BrownianInterval(0.0, 1.0, size=(2,), tol=-1.0)
+    with pytest.raises(ValueError, match="levy_area_approximation"):
+        BrownianInterval(0.0, 1.0, size=(2,), levy_area_approximation="bogus")
+    with pytest.raises(ValueError, match="Must either specify `size`"):
+        BrownianInterval(0.0, 1.0)
+    with pytest.raises(ValueError, match="Multiple sizes"):
+        BrownianInterval(0.0, 1.0, size=(3,), W=torch.zeros(4))
+    bm = BrownianInterval(0.0, 1.0, size=(2, 3), entropy=7, levy_area_approximation="space-time")
+    assert bm.shape == (2, 3) and bm.size() == (2, 3) and bm.entropy == 7 and bm.dtype == torch.get_default_dtype()
+    with pytest.raises(RuntimeError, match="must respect ta <= tb"):
+        bm(0.7, 0.2)
+
+
+def test_cell_bookkeeping():
+    e = uniform_edges(0.0, 1.0, 0.25)
+    assert np.array_equal(e, [0, 0.25, 0.5, 0.75, 1.0])
+    e = uniform_edges(0.0, 1.0, 0.3)
+    assert np.allclose(e, [0, 0.3, 0.6, 0.9, 1.0]) and e[-1] == 1.0
+    bm = BrownianInterval(0.0, 1.0, size=(2, 2), dt=0.25)
+    assert bm.frozen and list(bm.match_grid(np.array([0.25, 0.5, 0.75]))) == [1, 2]
+    assert bm.match_grid(np.array([0.25, 0.75])) is None          # two cells in one step: general query
+    assert bm.match_grid(np.array([0.1, 0.25])) is None
+    assert bm.locate(0.3, 0.8) == (1, 3) and bm.locate(0.25, 0.5) == (1, 1) and bm.locate(0.0, 1.0) == (0, 3)
+    lazy = BrownianInterval(0.0, 1.0, size=(2, 2))
+    grid = np.array([0.0, 0.1, 0.2, 0.35])
+    assert lazy.adopt_grid(grid) and np.array_equal(lazy._edges, [0.0, 0.1, 0.2, 0.35, 1.0])
+    assert not lazy.adopt_grid(np.array([0.0, 0.5, 1.0]))          # already frozen: path is fixed
+    assert list(lazy.match_grid(grid)) == [0, 1, 2]
+    sharded = BrownianInterval(0.0, 1.0, size=(8, 3), row_offset=16)
+    assert sharded._elem0 == 48
+
+
+def test_adjoint_argument_errors():
+    class Plain:
+        noise_type, sde_type = "diagonal", "ito"
+
+        def f(self, t, y):
+            return y
+
+        def g(self, t, y):
+            return y
+    with pytest.raises(ValueError, match="nn.Module"):
+        torchsde_amd.sdeint_adjoint(Plain(), torch.zeros(2, 2), [0.0, 1.0])
+    sde = problems.make("general_ito")
+    with pytest.raises(ValueError, match="only supports noise types"):
+        torchsde_amd.sdeint_adjoint(sde, torch.zeros(2, 4), [0.0, 1.0], adjoint_method="milstein")
+    with pytest.raises(ValueError, match="Runge"):
+        torchsde_amd.sdeint_adjoint(problems.make("gbm_ito"), torch.zeros(2, 4), [0.0, 1.0], adjoint_method="srk")
