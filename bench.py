@@ -29,11 +29,61 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (problem, method, levy, B, d, solver steps, dt, algorithmic bytes per trajectory-step, kernel id)
-    "c2_euler_diag_b65536_d64_s1000": dict(problem="gbm_ito", method="euler", levy="none", B=65536, d=64,
-                                           nsteps=1000, dt=2.0 ** -10, bytes_per_traj_step=16 * 64, kid=1,
-                                           launches_per_step=1),
+    # BASELINE.json configs[1] -- the headline (default) workload
+    "c2_euler_diag_b65536_d64_s1000": dict(
+        problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
+    # the other BASELINE configs at their single-GPU size (parity-test cases; measured for DESIGN.md, not the headline)
+    "c2_milstein_diag": dict(
+        problem="gbm_ito", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=20 * 64, kid=3, launches_per_step=1,
+        kernel="tsde_milstein_diag<float>"),
+    "c2_srk_diag": dict(
+        problem="gbm_ito", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=108 * 64, kid=4, launches_per_step=4,
+        kernel="tsde_srk_diag_stage<float> (4 stage kernels)"),
+    "c3_euler_general_b16384_d32_m16": dict(
+        problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1,
+        kernel="tsde_step_general<float> (general_fast_kernel)"),
+    "c4_midpoint_diag_b32768_d64": dict(
+        problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
+        kernel="tsde_step_diag<float> (two stages per step)"),
+    "c5_adjoint_latent_b32768_d128_s500": dict(
+        problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
+        kernel="tsde_aug_update<float> (aug_multi_kernel, backward sweep)"),
 }
+
+
+def _make_problem(name, d, m, dev):
+    from torch import nn
+    from tests import problems
+    if name == "general_big":      # NeuralGeneral-style: hidden 64
+        return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
+    if name == "latent_diag":      # latent-SDE-style diagonal SDE
+        class Latent(nn.Module):
+            noise_type, sde_type = "diagonal", "ito"
+
+            def __init__(self):
+                super().__init__()
+                gen = torch.Generator().manual_seed(0)
+                self.net = nn.Sequential(nn.Linear(d, d), nn.Softplus(), nn.Linear(d, d))
+                with torch.no_grad():
+                    for p in self.net.parameters():
+                        p.copy_(torch.randn(p.shape, generator=gen) / (d ** 0.5))
+                self.w = nn.Parameter(torch.randn(d, generator=gen))
+                self.b = nn.Parameter(0.1 * torch.randn(d, generator=gen))
+
+            def f(self, t, y):
+                return self.net(y)
+
+            def g(self, t, y):
+                return 0.1 * torch.sigmoid(self.w * y + self.b)
+        return Latent().to(dev)
+    return problems.make(name, d=d, m=m).to(dev)
 
 
 def _cpu_baseline(cfg, budget_s=20.0):
@@ -44,16 +94,18 @@ def _cpu_baseline(cfg, budget_s=20.0):
     except Exception as e:  # oracle piece missing: report, don't fake
         return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": f"unavailable: {e}"}
-    from tests import problems
+    if cfg.get("adjoint"):
+        return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "not timed for the adjoint workload"}
     B, d, dt = cfg["B"], cfg["d"], cfg["dt"]
-    sde = problems.make(cfg["problem"], d=d)
+    sde = _make_problem(cfg["problem"], d, cfg["m"], "cpu")
     y0 = torch.full((B, d), 0.1)
     t1 = cfg["nsteps"] * dt
     step = solvers_ref.STEPS[cfg["method"]]
 
     def run(threads, budget, min_steps):
         torch.set_num_threads(threads)
-        bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, d), dtype=torch.float32, entropy=20240601,
+        bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, cfg["m"]), dtype=torch.float32, entropy=20240601,
                                               dt=dt, levy_area_approximation=cfg["levy"])
         n, y, t = 0, y0, torch.tensor(0.0)
         start = time.perf_counter()
@@ -108,19 +160,28 @@ def main():
 
     import torchsde_amd
     from torchsde_amd import kernels as K
-    from tests import problems
 
     cfg = WORKLOADS[args.workload]
-    B, d, nsteps, dt = cfg["B"], cfg["d"], cfg["nsteps"], cfg["dt"]
-    sde = problems.make(cfg["problem"], d=d).to(dev)
-    y0 = torch.full((B, d), 0.1, device=dev)
+    B, d, m, nsteps, dt = cfg["B"], cfg["d"], cfg["m"], cfg["nsteps"], cfg["dt"]
+    adjoint = cfg.get("adjoint", False)
+    sde = _make_problem(cfg["problem"], d, m, dev)
+    y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
     ts = torch.tensor([0.0, nsteps * dt], device=dev)
     gathered = torch.empty((world * B, d), device=dev) if world > 1 else None
 
     def one_solve(i):
-        bm = torchsde_amd.BrownianInterval(t0=0.0, t1=nsteps * dt, size=(B, d), dtype=torch.float32, device=dev,
+        bm = torchsde_amd.BrownianInterval(t0=0.0, t1=nsteps * dt, size=(B, m), dtype=torch.float32, device=dev,
                                            entropy=20240601 + i, dt=dt, levy_area_approximation=cfg["levy"],
                                            row_offset=rank * B)
+        if adjoint:
+            with torch.enable_grad():
+                ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=cfg["method"],
+                                                 adjoint_method=cfg["adjoint_method"], dt=dt)
+                ys[-1].sum().backward()
+            if world > 1:
+                from torchsde_amd import sharding
+                sharding.all_reduce_gradients(list(sde.parameters()))
+            return y0.grad
         ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt)
         if world > 1:
             dist.all_gather_into_tensor(gathered, ys[-1])
@@ -160,7 +221,7 @@ def main():
         avg_s = k_ms * 1e-3 / k_launches
         bytes_per_launch = cfg["bytes_per_traj_step"] * B / cfg["launches_per_step"]
         achieved = bytes_per_launch / avg_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)",
+        roofline = {"bound": "hbm", "kernel": cfg["kernel"],
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
                     "launches_timed": k_launches}
@@ -173,8 +234,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "sde": "GBM diagonal Ito (f=mu*y, g=sigma*y as torch ops)",
-                       "method": cfg["method"], "batch_per_gpu": B, "global_batch": world * B, "state": d,
+            "config": {"workload": args.workload, "sde": cfg["problem"] + " (f, g are user torch ops)",
+                       "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else ""),
+                       "batch_per_gpu": B, "global_batch": world * B, "state": d, "brownian_channels": m,
                        "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
                        "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -12,7 +12,7 @@
  *   tsde_step_general    euler.py / midpoint.py with base_sde.py:101-102 -> misc.py:62-63 batch_mvp (bmm)
  *   tsde_milstein_*      _core/methods/milstein.py:52-94 (+ base_sde.py:142-158)
  *   tsde_srk_diag_stage  _core/methods/srk.py:57-88 + tableaus/srid2.py
- *   tsde_srk_additive_*  _core/methods/srk.py:90-111 + tableaus/sra1.py
+ *   tsde_step_general_w  _core/methods/srk.py:90-111 + tableaus/sra1.py (SRK for additive noise)
  *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
  *   tsde_linear_interp   _core/interp.py:15-18
  *
@@ -109,6 +109,13 @@ int tsde_step_prod(void* y1, const void* y0, const void* f, const void* gp, int6
 /* y1 = (y0 + cf*f) + cg*(g . dW)        g:(B,d,m), dW:(B,m); general / additive / scalar noise. */
 int tsde_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
                       double cf, double cg, const tsde_noise_t* noise, int dtype, void* stream);
+
+/* y1 = (y0 + (ca*f)*cf) + cg*(g . w)    the same contraction against a weight vector built from (W, U):
+ *   weight_mode 0: w = W;  1: w = (cu*U)*rdt;  2: w = (cw*W) + (cu*U)*rdt.
+ * This is every stage of SRK for additive noise (SRA1): srk.py:90-111 with tableaus/sra1.py. */
+int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
+                        double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
+                        const tsde_noise_t* noise, int dtype, void* stream);
 
 /* Milstein helper: v_out = scale * (W^2 - dt) (ito != 0) or scale * W^2; W_out optional. */
 int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,

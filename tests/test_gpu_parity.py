@@ -10,7 +10,7 @@ from tests import helpers, problems
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-NATIVE_UNSUPPORTED = {"srk_additive"}
+NATIVE_UNSUPPORTED = set()
 
 
 def _exact_expected(case):
@@ -140,6 +140,8 @@ FUSED_CASES = [
     ("scalar_ito", "milstein", None, "none", (48, 4, 1)),
     ("scalar_ito", "srk", None, "space-time", (48, 4, 1)),
     ("additive_ito", "euler", None, "none", (48, 4, 3)),
+    ("additive_ito", "srk", None, "space-time", (48, 4, 3)),
+    ("additive_ito", "milstein", None, "none", (48, 4, 4)),
 ]
 
 
@@ -177,8 +179,6 @@ def test_fused_equals_materialised_and_oracle(prob, method, options, levy, shape
     assert torch.equal(ys_fused, ys_mat), (ys_fused - ys_mat).abs().max().item()
 
     # oracle: reference arithmetic on CPU + C twin of the generator
-    if method == "srk" and prob.startswith("additive"):
-        return
     np_dt = np.float32 if dtype == torch.float32 else np.float64
     edges = np.arange(steps + 1) * dt
 

@@ -55,6 +55,8 @@ SIGNATURES = {
     "tsde_step_prod": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_step_general": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl,
                                    ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_step_general_w": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _c_dbl,
+                                     _c_int, _c_dbl, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_milstein_v": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_dbl, ctypes.POINTER(Noise), _c_int,
                                  _c_ptr]),
     "tsde_milstein_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, ctypes.POINTER(Noise),

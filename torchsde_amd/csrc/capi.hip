@@ -145,11 +145,21 @@ int tsde_step_prod(void* y1, const void* y0, const void* f, const void* gp, int6
 
 int tsde_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
                       double cf, double cg, const tsde_noise_t* noise, int dtype, void* stream) {
+  return tsde_step_general_w(y1, y0, f, g, B, d, m, 1.0, cf, cg, 0, 0.0, 0.0, 0.0, noise, dtype, stream);
+}
+
+int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
+                        double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
+                        const tsde_noise_t* noise, int dtype, void* stream) {
   if (!y1 || !y0 || !f || !g || !noise) return bad_arg("tsde_step_general", "null argument");
+  if (weight_mode < 0 || weight_mode > 2) return bad_arg("tsde_step_general", "weight_mode must be 0, 1 or 2");
+  if (weight_mode != 0 && noise->dW && !noise->dU) return bad_arg("tsde_step_general", "weights need dU");
   const hipStream_t s = (hipStream_t)stream;
   ProfScope p(TSDE_KID_STEP_GENERAL, s);
-  TSDE_DISPATCH(dtype, "tsde_step_general", tsde::launch_step_general<float>(y1, y0, f, g, B, d, m, cf, cg, noise, s),
-                tsde::launch_step_general<double>(y1, y0, f, g, B, d, m, cf, cg, noise, s));
+  TSDE_DISPATCH(dtype, "tsde_step_general",
+                tsde::launch_step_general<float>(y1, y0, f, g, B, d, m, ca, cf, cg, weight_mode, cw, cu, rdt, noise, s),
+                tsde::launch_step_general<double>(y1, y0, f, g, B, d, m, ca, cf, cg, weight_mode, cw, cu, rdt, noise,
+                                                  s));
 }
 
 int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale, const tsde_noise_t* noise,

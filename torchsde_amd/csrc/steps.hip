@@ -337,29 +337,52 @@ struct GeneralArgs {
   T* y1;
   const T *y0, *f, *g;
   int64_t B, d, m;
-  T cf, cg;
+  T ca, cf, cg;        // drift term is (ca*f)*cf: the reference's `alpha * f * dt` rounding order
+  // weight vector the diffusion row is contracted with (SRA1, srk.py:96-109):
+  //   mode 0: W      mode 1: (cu*U)*rdt      mode 2: (cw*W) + (cu*U)*rdt
+  int weight_mode;
+  T cw, cu, rdt;
   CellNoise<T> nz;
   int rows_per_tile;
 };
 
 template <typename T>
-TSDE_D void stage_noise(const CellNoise<T>& nz, T* lds, int64_t row0, int rows, int64_t m, int64_t B) {
-  // lds[r*m + j] = dW[row0 + r, j]
+TSDE_D T row_weight(const GeneralArgs<T>& a, T W, T U) {
+  if (a.weight_mode == 0) return W;
+  if (a.weight_mode == 1) return (a.cu * U) * a.rdt;
+  return (a.cw * W) + (a.cu * U) * a.rdt;
+}
+
+template <typename T>
+TSDE_D void stage_noise(const GeneralArgs<T>& a, T* lds, int64_t row0, int rows) {
+  // lds[r*m + j] = weight(dW[row0 + r, j], dU[row0 + r, j])
+  const CellNoise<T>& nz = a.nz;
+  const int64_t m = a.m;
   const int64_t cnt = (int64_t)rows * m;
   const int64_t base = row0 * m;
+  const bool need_u = a.weight_mode != 0;
   if (nz.dW != nullptr) {
-    for (int64_t t = threadIdx.x; t < cnt; t += kBlock) lds[t] = (base + t < B * m) ? nz.dW[base + t] : (T)0;
+    for (int64_t t = threadIdx.x; t < cnt; t += kBlock) {
+      const T W = nz.dW[base + t];
+      const T U = need_u ? nz.dU[base + t] : (T)0;
+      lds[t] = row_weight<T>(a, W, U);
+    }
   } else {
-    const T sw = (T)sqrt(nz.h);
+    const T sw = (T)sqrt(nz.h), sh = (T)sqrt(nz.h / 12.0), th = (T)nz.h;
     const uint64_t e0 = nz.key.elem0 + (uint64_t)base;
     const uint64_t q0 = e0 >> 2, q1 = (e0 + (uint64_t)cnt + 3) >> 2;
     for (uint64_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
-      T n[4];
+      T n[4], hn[4] = {(T)0, (T)0, (T)0, (T)0};
       normal4<T>(nz.key, q, nz.cell, 0, kStreamW, n);
+      if (need_u) normal4<T>(nz.key, q, nz.cell, 0, kStreamH, hn);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t t = (int64_t)(q * 4 + j) - (int64_t)e0;
-        if (t >= 0 && t < cnt) lds[t] = n[j] * sw;
+        if (t >= 0 && t < cnt) {
+          const T W = n[j] * sw;
+          const T U = th * ((T)0.5 * W + hn[j] * sh);
+          lds[t] = row_weight<T>(a, W, U);
+        }
       }
     }
   }
@@ -376,7 +399,7 @@ __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<
     const int64_t row0 = tile * a.rows_per_tile;
     const int rows = (int)((a.B - row0 < a.rows_per_tile) ? (a.B - row0) : a.rows_per_tile);
     __syncthreads();
-    stage_noise<T>(a.nz, lds, row0, rows, a.m, a.B);
+    stage_noise<T>(a, lds, row0, rows);
     __syncthreads();
     const int64_t nv = (int64_t)rows * vec_per_row;
     const int64_t nv_pad = (nv + kBlock - 1) / kBlock * kBlock;  // keep whole waves in the shuffles
@@ -395,7 +418,7 @@ __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<
       }
       for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
       if (live && (v & (G - 1)) == 0) {
-        a.y1[out_idx] = (a.y0[out_idx] + a.cf * a.f[out_idx]) + a.cg * part;
+        a.y1[out_idx] = (a.y0[out_idx] + (a.ca * a.f[out_idx]) * a.cf) + a.cg * part;
       }
     }
   }
@@ -410,7 +433,7 @@ __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralAr
     const int64_t row0 = tile * a.rows_per_tile;
     const int rows = (int)((a.B - row0 < a.rows_per_tile) ? (a.B - row0) : a.rows_per_tile);
     __syncthreads();
-    stage_noise<T>(a.nz, lds, row0, rows, a.m, a.B);
+    stage_noise<T>(a, lds, row0, rows);
     __syncthreads();
     const int64_t nout = (int64_t)rows * a.d;
     for (int64_t o = threadIdx.x; o < nout; o += kBlock) {
@@ -420,7 +443,7 @@ __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralAr
       const T* wrow = lds + r * a.m;
       T acc = (T)0;
       for (int64_t j = 0; j < a.m; ++j) acc += grow[j] * wrow[j];
-      a.y1[idx] = (a.y0[idx] + a.cf * a.f[idx]) + a.cg * acc;
+      a.y1[idx] = (a.y0[idx] + (a.ca * a.f[idx]) * a.cf) + a.cg * acc;
     }
   }
 }
@@ -582,7 +605,8 @@ hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, d
 
 template <typename T>
 hipError_t launch_step_general(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
-                               double cf, double cg, const tsde_noise_t* nz, hipStream_t s) {
+                               double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
+                               const tsde_noise_t* nz, hipStream_t s) {
   if (B <= 0 || d <= 0) return hipSuccess;
   if (m <= 0 || m > kGenMaxNoise) return hipErrorInvalidValue;
   GeneralArgs<T> a;
@@ -593,8 +617,13 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   a.B = B;
   a.d = d;
   a.m = m;
+  a.ca = (T)ca;
   a.cf = (T)cf;
   a.cg = (T)cg;
+  a.weight_mode = weight_mode;
+  a.cw = (T)cw;
+  a.cu = (T)cu;
+  a.rdt = (T)rdt;
   a.nz = make_noise<T>(nz);
   const int64_t G = m / 4;
   const bool pow2 = (m % 4 == 0) && G >= 1 && G <= 64 && ((G & (G - 1)) == 0);
@@ -627,7 +656,8 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   template hipError_t launch_step_prod<T>(void*, const void*, const void*, const void*, int64_t, double, double,     \
                                           hipStream_t);                                                              \
   template hipError_t launch_step_general<T>(void*, const void*, const void*, const void*, int64_t, int64_t, int64_t, \
-                                             double, double, const tsde_noise_t*, hipStream_t);                      \
+                                             double, double, double, int, double, double, double,                    \
+                                             const tsde_noise_t*, hipStream_t);                                      \
   template hipError_t launch_milstein_v<T>(void*, void*, int64_t, double, int, double, const tsde_noise_t*,          \
                                            hipStream_t);                                                             \
   template hipError_t launch_milstein_diag<T>(void*, const void*, const void*, const void*, const void*, int64_t,    \

@@ -193,6 +193,30 @@ def step_general(y0, f, g, cf, cg, noise, out=None):
     return _raw_step_general(y0, f, g, cf, cg, noise, out)
 
 
+def step_general_weighted(y0, f, g, ca, cf, cg, weight_mode, cw, cu, rdt, noise, out=None):
+    """y1 = (y0 + (ca*f)*cf) + cg*(g . w), w built from (W, U): the stages of SRK for additive noise (SRA1)."""
+    if _needs_grad(y0, f, g):
+        raise NotImplementedError("torchsde_amd: back-propagating through the SRK solver is not supported; use "
+                                  "`method='milstein'`/'euler' or `sdeint_adjoint`.")
+    y0 = _native.contiguous(y0.detach())
+    f, = _prep(y0, f)
+    g = g.detach()
+    if g.dtype != y0.dtype:
+        g = g.to(y0.dtype)
+    B, d = y0.shape
+    m = g.shape[-1]
+    if g.shape != (B, d, m):
+        g = g.expand(B, d, m)
+    g = _native.contiguous(g)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_step_general_w(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g), B, d, m,
+                                   float(ca), float(cf), float(cg), int(weight_mode), float(cw), float(cu),
+                                   float(rdt), noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_step_general_w")
+    return out
+
+
 # ---- Milstein --------------------------------------------------------------------------------------------
 def milstein_v(noise, dt, ito, scale, like, want_W=False):
     """scale*(W^2 - dt) (Ito) or scale*W^2 as a tensor shaped like the noise (+ W itself if asked)."""

@@ -343,7 +343,7 @@ class SRK(BaseSDESolver):
     levy_area_approximations = (LEVY_AREA_APPROXIMATIONS.space_time, LEVY_AREA_APPROXIMATIONS.davie,
                                 LEVY_AREA_APPROXIMATIONS.foster)
     needs_U = True
-    stage_fracs = (0, 0.25, 0.5, 1)   # t0, +dt/4, +dt/2, +dt
+    stage_fracs = (0, 0.25, 0.5, 0.75, 1)   # t0, +dt/4, +dt/2, +3dt/4 (SRA1), +dt
 
     def __init__(self, sde, **kwargs):
         from . import adjoint
@@ -357,7 +357,7 @@ class SRK(BaseSDESolver):
         if self.sde.noise_type == NOISE_TYPES.additive:
             return self._advance_additive(y0, st, out)
         sde, dt, noise = self.sde, st.dt, st.noise
-        t_0, t_q, t_h, t_1 = st.times
+        t_0, t_q, t_h, _t_3q, t_1 = st.times
         one = type(dt)(1)
         rdt = one / dt
         sqrt_dt = np.sqrt(dt)
@@ -382,7 +382,19 @@ class SRK(BaseSDESolver):
         return y1
 
     def _advance_additive(self, y0, st, out):
-        raise NotImplementedError("torchsde_amd: SRK for additive noise (SRA1) is not built yet.")
+        """SRA1 (srk.py:90-111, tableaus/sra1.py): three weighted contractions g(t, y0) . w(W, U).
+        C0 = (0, 3/4), C1 = (1, 0), A0[1][0] = 3/4, B0[1][0] = 3/2, alpha = (1/3, 2/3), beta1 = (1, 0),
+        beta2 = (-1, 1). The diffusion always comes from `g` (a user `g_prod` computes the same product)."""
+        sde, dt, noise = self.sde, st.dt, st.noise
+        t_0, _t_q, _t_h, t_3q, t_1 = st.times
+        rdt = type(dt)(1) / dt
+        f0 = sde.f(t_0, y0)
+        g_a = sde.g(t_1, y0)     # t0 + C1[0]*dt
+        H0_1 = K.step_general_weighted(y0, f0, g_a, 3 / 4, dt, 1.0, 1, 0.0, 3 / 2, rdt, noise)
+        acc = K.step_general_weighted(y0, f0, g_a, 1 / 3, dt, 1.0, 2, 1.0, -1.0, rdt, noise)
+        f1 = sde.f(t_3q, H0_1)
+        g_b = sde.g(t_0, y0)     # t0 + C1[1]*dt
+        return K.step_general_weighted(acc, f1, g_b, 2 / 3, dt, 1.0, 2, 0.0, 1.0, rdt, noise, out=out)
 
 
 def select(method, sde_type):
