@@ -53,6 +53,8 @@ typedef struct tsde_noise {
   uint32_t reserved;
   double h;
   int64_t bcast_d;
+  const uint64_t* entropy_dev; /* optional DEVICE word overriding `entropy` at run time: lets a captured
+                                  HIP graph of a whole solve be replayed with a new Brownian seed */
 } tsde_noise_t;
 
 /* One segment of the adjoint's augmented state (y, a_y, or one parameter's a_theta). */
@@ -86,10 +88,12 @@ int tsde_brownian_normals(void* out, int64_t n, uint64_t entropy, uint64_t elem0
  *   W (required), U and H (optional, need have_h): outputs of n elements each.
  *   rootW / rootH : optional user-pinned (W,H) of a single top-level cell (`W=`, `H=` arguments of
  *           BrownianInterval, brownian_interval.py:407-408); needs ca == cb == 0.
- *   max_depth / snap : in-cell dyadic descent limit and leaf rule (0 = exact split, 1 = snap). */
+ *   max_depth / snap : in-cell dyadic descent limit and leaf rule (0 = exact split, 1 = snap).
+ *   entropy_dev : optional device word overriding `entropy` (see tsde_noise_t). */
 int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0,
                         const double* edges, int64_t ca, int64_t cb, double a, double b, const void* rootW,
-                        const void* rootH, int have_h, int max_depth, int snap, int dtype, void* stream);
+                        const void* rootH, int have_h, int max_depth, int snap, const uint64_t* entropy_dev,
+                        int dtype, void* stream);
 
 /* W (and U, optional) of ONE whole cell written to memory: the aligned fast path of a query, for
  * callers that must hand the increment to user torch code (g_prod, adjoint VJPs). `noise->dW` must be NULL. */

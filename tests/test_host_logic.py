@@ -39,7 +39,7 @@ def test_python_binding_covers_header():
 
 
 def test_noise_struct_layout_matches_header():
-    assert ctypes.sizeof(_native.Noise) == 56
+    assert ctypes.sizeof(_native.Noise) == 64 and _native.Noise.entropy_dev.offset == 56
     assert _native.Noise.h.offset == 40 and _native.Noise.bcast_d.offset == 48
     assert ctypes.sizeof(_native.Seg) == 72
 

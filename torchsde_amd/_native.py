@@ -29,7 +29,7 @@ class NativeLibraryError(RuntimeError):
 class Noise(ctypes.Structure):
     """``tsde_noise_t``."""
     _fields_ = [("dW", _c_ptr), ("dU", _c_ptr), ("entropy", _c_u64), ("elem0", _c_u64), ("cell", _c_u32),
-                ("reserved", _c_u32), ("h", _c_dbl), ("bcast_d", _c_i64)]
+                ("reserved", _c_u32), ("h", _c_dbl), ("bcast_d", _c_i64), ("entropy_dev", _c_ptr)]
 
 
 class Seg(ctypes.Structure):
@@ -48,7 +48,7 @@ SIGNATURES = {
     "tsde_noise_counter": (None, [_c_u64, _c_u32, _c_u64, _c_u32, ctypes.POINTER(_c_u32)]),
     "tsde_brownian_normals": (_c_int, [_c_ptr, _c_i64, _c_u64, _c_u64, _c_u32, _c_u64, _c_u32, _c_int, _c_ptr]),
     "tsde_brownian_query": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_u64, _c_u64, _c_ptr, _c_i64, _c_i64, _c_dbl,
-                                     _c_dbl, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr]),
+                                     _c_dbl, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_int, _c_ptr]),
     "tsde_cell_increment": (_c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_step_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int,
                                 _c_ptr]),

@@ -165,6 +165,7 @@ class BrownianInterval(BaseBrownian):
             self._round = lambda x: x
 
         # ---- the cell structure ("grid") -----------------------------------------------------------
+        self._entropy_dev = None  # set by graph capture: device word that overrides the seed at replay
         self._edges = None       # np.float64 (n_cells + 1,)
         self._edges_dev = None   # the same on the device, for the query kernel
         self._max_depth, self._snap = _EXACT_DEPTH, 0
@@ -291,7 +292,8 @@ class BrownianInterval(BaseBrownian):
         code = lib.tsde_brownian_query(
             _native.ptr(out_W), _native.ptr(out_U if want_U else None), None, self._numel, self._key, self._elem0,
             _native.ptr(edges), ca, cb, ta, tb, _native.ptr(self._rootW), _native.ptr(self._rootH),
-            1 if self._have_H else 0, self._max_depth, self._snap, _native.dtype_code(self._dtype),
+            1 if self._have_H else 0, self._max_depth, self._snap,
+            None if self._entropy_dev is None else self._entropy_dev.data_ptr(), _native.dtype_code(self._dtype),
             _native.stream_ptr(self._device))
         _native.check(code, "tsde_brownian_query")
         return out_W, (out_U if want_U else None)

@@ -28,6 +28,11 @@ __global__ void __launch_bounds__(kBlock) normals_kernel(T* __restrict__ out, in
 template <typename T, bool HAVE_H>
 __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __restrict__ U, T* __restrict__ H,
                                                        int64_t n, NoiseKey key, QueryArgs qa, int vec) {
+  if (qa.key_dev != nullptr) {
+    const uint64_t e = *qa.key_dev;
+    key.k0 = (uint32_t)e;
+    key.k1 = (uint32_t)(e >> 32);
+  }
   const uint64_t q0 = key.elem0 >> 2;
   const uint64_t q1 = (key.elem0 + (uint64_t)n + 3) >> 2;
   const int64_t nq = (int64_t)(q1 - q0);

@@ -94,7 +94,7 @@ int tsde_brownian_normals(void* out, int64_t n, uint64_t entropy, uint64_t elem0
 
 int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,
                         int64_t ca, int64_t cb, double a, double b, const void* rootW, const void* rootH, int have_h,
-                        int max_depth, int snap, int dtype, void* stream) {
+                        int max_depth, int snap, const uint64_t* entropy_dev, int dtype, void* stream) {
   if (!W || !edges) return bad_arg("tsde_brownian_query", "W and edges are required");
   if (ca < 0 || cb < ca || !(a < b)) return bad_arg("tsde_brownian_query", "need 0 <= ca <= cb and a < b");
   if ((U || H) && !have_h) return bad_arg("tsde_brownian_query", "U/H requested without have_h");
@@ -111,6 +111,7 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
   qa.b = b;
   qa.rootW = rootW;
   qa.rootH = rootH;
+  qa.key_dev = entropy_dev;
   qa.cfg.max_depth = max_depth;
   qa.cfg.snap = snap;
   ProfScope p(TSDE_KID_BROWNIAN_QUERY, s);

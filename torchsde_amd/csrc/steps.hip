@@ -369,12 +369,13 @@ TSDE_D void stage_noise(const GeneralArgs<T>& a, T* lds, int64_t row0, int rows)
     }
   } else {
     const T sw = (T)sqrt(nz.h), sh = (T)sqrt(nz.h / 12.0), th = (T)nz.h;
-    const uint64_t e0 = nz.key.elem0 + (uint64_t)base;
+    const NoiseKey key = live_key(nz);
+    const uint64_t e0 = key.elem0 + (uint64_t)base;
     const uint64_t q0 = e0 >> 2, q1 = (e0 + (uint64_t)cnt + 3) >> 2;
     for (uint64_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
       T n[4], hn[4] = {(T)0, (T)0, (T)0, (T)0};
-      normal4<T>(nz.key, q, nz.cell, 0, kStreamW, n);
-      if (need_u) normal4<T>(nz.key, q, nz.cell, 0, kStreamH, hn);
+      normal4<T>(key, q, nz.cell, 0, kStreamW, n);
+      if (need_u) normal4<T>(key, q, nz.cell, 0, kStreamH, hn);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t t = (int64_t)(q * 4 + j) - (int64_t)e0;
@@ -388,37 +389,87 @@ TSDE_D void stage_noise(const GeneralArgs<T>& a, T* lds, int64_t row0, int rows)
   }
 }
 
-// Fast path: m % 4 == 0, G = m/4 a power of two <= 64, everything 16-B aligned.
+// Fast path: m % 4 == 0, G = m/4 a power of two <= 64, everything 16-B aligned. No LDS, no barriers:
+// a wave streams a contiguous span of g with 16-B loads (U independent loads in flight per lane); lane L
+// always sits on channel quad L % G of its row, so it regenerates its 4 increments only when the row changes
+// (one Philox call per row per lane), multiplies, and the m-long dot product is finished by an xor-shuffle
+// reduction over the G neighbouring lanes.
+template <typename T>
+TSDE_D void lane_weights(const GeneralArgs<T>& a, int64_t row, int lp, T (&wq)[4]) {
+  const CellNoise<T>& nz = a.nz;
+  const bool need_u = a.weight_mode != 0;
+  const int64_t off = row * a.m + (int64_t)lp * 4;
+  T W[4], Uv[4] = {(T)0, (T)0, (T)0, (T)0};
+  if (nz.dW != nullptr) {
+    const Pack<T, 4> w = load<T, 4>(nz.dW, off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[j] = w.v[j];
+    if (need_u) {
+      const Pack<T, 4> u = load<T, 4>(nz.dU, off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Uv[j] = u.v[j];
+    }
+  } else {
+    const T sw = (T)sqrt(nz.h), sh = (T)sqrt(nz.h / 12.0), th = (T)nz.h;
+    const NoiseKey key = live_key(nz);
+    const uint64_t quad = (key.elem0 + (uint64_t)off) >> 2;
+    T n[4];
+    normal4<T>(key, quad, nz.cell, 0, kStreamW, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[j] = n[j] * sw;
+    if (need_u) {
+      normal4<T>(key, quad, nz.cell, 0, kStreamH, n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Uv[j] = th * ((T)0.5 * W[j] + n[j] * sh);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wq[j] = row_weight<T>(a, W[j], Uv[j]);
+}
+
+constexpr int kGenUnroll = 4;
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<T> a) {
-  __shared__ __attribute__((aligned(16))) T lds[kGenMaxNoise];
   const int G = (int)(a.m >> 2);
-  const int64_t vec_per_row = a.d * G;  // float4 groups of g per batch row
-  const int64_t n_tiles = (a.B + a.rows_per_tile - 1) / a.rows_per_tile;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * a.rows_per_tile;
-    const int rows = (int)((a.B - row0 < a.rows_per_tile) ? (a.B - row0) : a.rows_per_tile);
-    __syncthreads();
-    stage_noise<T>(a, lds, row0, rows);
-    __syncthreads();
-    const int64_t nv = (int64_t)rows * vec_per_row;
-    const int64_t nv_pad = (nv + kBlock - 1) / kBlock * kBlock;  // keep whole waves in the shuffles
-    for (int64_t v = threadIdx.x; v < nv_pad; v += kBlock) {
+  const int logG = __builtin_ctz(G);
+  const int64_t row4 = a.d * G;            // 16-B groups of g per batch row
+  const int64_t total = a.B * row4;
+  const int lane = threadIdx.x & 63;
+  const int lp = lane & (G - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  constexpr int64_t kSpan = 64 * kGenUnroll;
+  int64_t cached_row = -1;
+  T wq[4] = {(T)0, (T)0, (T)0, (T)0};
+  for (int64_t s0 = wave * kSpan; s0 < total; s0 += n_waves * kSpan) {
+    Pack<T, 4> gq[kGenUnroll];
+    int64_t row[kGenUnroll], rem[kGenUnroll];
+#pragma unroll
+    for (int u = 0; u < kGenUnroll; ++u) {
+      const int64_t v = s0 + u * 64 + lane;
+      row[u] = -1;
+      if (v < total) {
+        gq[u] = load<T, 4>(a.g, v * 4);
+        row[u] = v / row4;
+        rem[u] = v - row[u] * row4;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kGenUnroll; ++u) {
       T part = (T)0;
-      const bool live = v < nv;
-      int64_t out_idx = 0;
+      const bool live = row[u] >= 0;
       if (live) {
-        const int64_t r = v / vec_per_row;
-        const int64_t rem = v - r * vec_per_row;
-        const int lp = (int)(rem & (G - 1));
-        const Pack<T, 4> gq = load<T, 4>(a.g, (row0 * vec_per_row + v) * 4);
-        const Pack<T, 4> wq = load<T, 4>(lds, r * a.m + (int64_t)lp * 4);
-        part = ((gq.v[0] * wq.v[0] + gq.v[1] * wq.v[1]) + gq.v[2] * wq.v[2]) + gq.v[3] * wq.v[3];
-        out_idx = (row0 + r) * a.d + (rem >> __builtin_ctz(G));
+        if (row[u] != cached_row) {
+          lane_weights<T>(a, row[u], lp, wq);
+          cached_row = row[u];
+        }
+        part = ((gq[u].v[0] * wq[0] + gq[u].v[1] * wq[1]) + gq[u].v[2] * wq[2]) + gq[u].v[3] * wq[3];
       }
       for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
-      if (live && (v & (G - 1)) == 0) {
-        a.y1[out_idx] = (a.y0[out_idx] + (a.ca * a.f[out_idx]) * a.cf) + a.cg * part;
+      if (live && lp == 0) {
+        const int64_t o = row[u] * a.d + (rem[u] >> logG);
+        a.y1[o] = (a.y0[o] + (a.ca * a.f[o]) * a.cf) + a.cg * part;
       }
     }
   }
@@ -460,6 +511,7 @@ static CellNoise<T> make_noise(const tsde_noise_t* nz) {
   c.cell = nz->cell;
   c.h = nz->h;
   c.bcast_d = nz->bcast_d;
+  c.key_dev = nz->entropy_dev;
   return c;
 }
 
@@ -627,25 +679,27 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   a.nz = make_noise<T>(nz);
   const int64_t G = m / 4;
   const bool pow2 = (m % 4 == 0) && G >= 1 && G <= 64 && ((G & (G - 1)) == 0);
-  const bool fast = pow2 && aligned16(g);
-  // Rows per tile: enough float4 groups to keep 256 lanes busy for a few iterations, bounded by LDS.
-  int64_t rows = kGenMaxNoise / m;
+  // the fast path loads increments (external) or forms Philox quads at row*m + 4*lane: needs 16-B alignment there
+  const bool noise_ok = nz->dW ? (aligned16(nz->dW) && (!nz->dU || aligned16(nz->dU))) : (nz->elem0 % 4 == 0);
+  const bool fast = pow2 && aligned16(g) && noise_ok;
   if (fast) {
-    const int64_t want = (4 * kBlock + d * G - 1) / (d * G);  // ~4 vector loads per lane per tile
-    if (rows > want) rows = want;
-  } else {
-    const int64_t want = (2 * kBlock + d - 1) / d;
-    if (rows > want) rows = want;
+    const int64_t total4 = B * d * G;
+    const int64_t spans = (total4 + 64 * kGenUnroll - 1) / (64 * kGenUnroll);   // one wave per span
+    int64_t blocks = (spans + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    a.rows_per_tile = 0;
+    hipLaunchKernelGGL(general_fast_kernel<T>, dim3((int)blocks), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
   }
+  // generic path: rows per tile bounded by the LDS staging buffer
+  int64_t rows = kGenMaxNoise / m;
+  const int64_t want = (2 * kBlock + d - 1) / d;
+  if (rows > want) rows = want;
   if (rows < 1) rows = 1;
   a.rows_per_tile = (int)rows;
   const int64_t n_tiles = (B + rows - 1) / rows;
   const int grid = (int)(n_tiles < kMaxGrid ? n_tiles : kMaxGrid);
-  if (fast) {
-    hipLaunchKernelGGL(general_fast_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(general_generic_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
-  }
+  hipLaunchKernelGGL(general_generic_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

@@ -59,7 +59,20 @@ struct CellNoise {
   uint32_t cell;
   double h;
   int64_t bcast_d;
+  const uint64_t* key_dev;   // optional run-time entropy (HIP-graph replay with a new seed)
 };
+
+// The key a kernel actually draws with: the baked one, or the device word if present (wave-uniform load).
+template <typename T>
+TSDE_D NoiseKey live_key(const CellNoise<T>& nz) {
+  NoiseKey k = nz.key;
+  if (nz.key_dev != nullptr) {
+    const uint64_t e = *nz.key_dev;
+    k.k0 = (uint32_t)e;
+    k.k1 = (uint32_t)(e >> 32);
+  }
+  return k;
+}
 
 // W and (optionally) U = h (W/2 + H) for W consecutive elements starting at local index i.
 template <typename T, int W, bool NEED_U>
@@ -81,22 +94,23 @@ TSDE_D void cell_noise(const CellNoise<T>& nz, int64_t i, Pack<T, W>& w, Pack<T,
   const T sw = (T)sqrt(nz.h);
   const T sh = (T)sqrt(nz.h / 12.0);
   const T th = (T)nz.h;
-  const uint64_t e = nz.key.elem0 + (uint64_t)i;
+  const NoiseKey key = live_key(nz);
+  const uint64_t e = key.elem0 + (uint64_t)i;
   if constexpr (W == 4) {
     T n[4];
-    normal4<T>(nz.key, e >> 2, nz.cell, 0, kStreamW, n);
+    normal4<T>(key, e >> 2, nz.cell, 0, kStreamW, n);
 #pragma unroll
     for (int j = 0; j < 4; ++j) w.v[j] = n[j] * sw;
     if (NEED_U) {
-      normal4<T>(nz.key, e >> 2, nz.cell, 0, kStreamH, n);
+      normal4<T>(key, e >> 2, nz.cell, 0, kStreamH, n);
 #pragma unroll
       for (int j = 0; j < 4; ++j) u.v[j] = th * ((T)0.5 * w.v[j] + n[j] * sh);
     }
   } else {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      w.v[j] = normal1<T>(nz.key, e + j, nz.cell, 0, kStreamW) * sw;
-      if (NEED_U) u.v[j] = th * ((T)0.5 * w.v[j] + normal1<T>(nz.key, e + j, nz.cell, 0, kStreamH) * sh);
+      w.v[j] = normal1<T>(key, e + j, nz.cell, 0, kStreamW) * sw;
+      if (NEED_U) u.v[j] = th * ((T)0.5 * w.v[j] + normal1<T>(key, e + j, nz.cell, 0, kStreamH) * sh);
     }
   }
 }
@@ -113,19 +127,17 @@ inline int grid_for(int64_t work_items) {
 // Elementwise driver. `Op` provides  template<int W> __device__ void run(int64_t i) const  acting on
 // elements [i, i+W). The vector path (W=4) is taken when `vec` is set by the launcher (all pointers
 // 16-byte aligned, n % 4 == 0 and the global noise offset % 4 == 0).
-// Vector path tiling: a block owns kQuadsPerThread * 256 CONSECUTIVE 16-byte groups (8 KiB of each stream per
-// block visit). Measured in situ on MI355X (tools/microbench_seq.hip, C2 shapes, between producer kernels):
-// 2 -> 12.0 us per step kernel, 1 -> 13.4 us, 4 or 8 -> 13.3-13.7 us.
-constexpr int kQuadsPerThread = 2;
-
-template <typename Op>
+// Vector path tiling: a block owns QPT * 256 CONSECUTIVE 16-byte groups. Measured in situ on MI355X
+// (tools/microbench_seq.hip, C2 shapes, between producer kernels): QPT=2 -> 12.0 us per step kernel,
+// 1 -> 13.4 us, 4 or 8 -> 13.3-13.7 us. Small problems keep QPT=1 so that every CU still gets >= 8 blocks.
+template <typename Op, int QPT>
 __global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const int64_t n, const int vec) {
   if (vec) {
     const int64_t nq = n >> 2;
-    constexpr int64_t kChunk = (int64_t)kBlock * kQuadsPerThread;
+    constexpr int64_t kChunk = (int64_t)kBlock * QPT;
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < nq; base += (int64_t)gridDim.x * kChunk) {
 #pragma unroll
-      for (int u = 0; u < kQuadsPerThread; ++u) {
+      for (int u = 0; u < QPT; ++u) {
         const int64_t q = base + (int64_t)u * kBlock + threadIdx.x;
         if (q < nq) op.template run<4>(q << 2);
       }
@@ -140,8 +152,13 @@ __global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const 
 template <typename Op>
 inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  const int64_t items = vec ? ((n >> 2) + kQuadsPerThread - 1) / kQuadsPerThread : n;
-  hipLaunchKernelGGL(elementwise_kernel<Op>, dim3(grid_for(items)), dim3(kBlock), 0, stream, op, n, vec ? 1 : 0);
+  const int64_t nq = n >> 2;
+  if (vec && nq >= (int64_t)2 * kBlock * kMaxGrid) {
+    hipLaunchKernelGGL((elementwise_kernel<Op, 2>), dim3(grid_for((nq + 1) / 2)), dim3(kBlock), 0, stream, op, n, 1);
+  } else {
+    hipLaunchKernelGGL((elementwise_kernel<Op, 1>), dim3(grid_for(vec ? nq : n)), dim3(kBlock), 0, stream, op, n,
+                       vec ? 1 : 0);
+  }
   return hipGetLastError();
 }
 

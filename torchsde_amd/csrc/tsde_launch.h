@@ -14,6 +14,7 @@ struct QueryArgs {
   double a, b;
   const void* rootW;    // optional pinned (W,H) of the single top-level cell
   const void* rootH;
+  const uint64_t* key_dev;  // optional run-time entropy
   WalkCfg cfg;
 };
 

@@ -1,0 +1,94 @@
+"""HIP-graph capture of a whole fixed-step solve (opt-in: ``options={"hip_graph": True}``).
+
+A solve is thousands of short kernels (the user's ``f``/``g`` torch ops plus one fused step kernel per stage).
+For small and medium batches the GPU finishes each of them faster than Python can issue the next one; the
+reference is in the same regime and additionally syncs three times per step. Here the launch-only part of a
+solve (``BaseSDESolver._run``) is captured ONCE into a HIP graph -- through torch's capture stream, which also
+records the ``libtorchsde_amd.so`` launches because they are issued on torch's current stream -- and replayed
+for every later solve with the same SDE object, shapes, method, time grid and Brownian structure.
+
+What changes between solves is the initial state (copied into the graph's static input buffer) and the Brownian
+seed: the kernels read the entropy from one device word (``tsde_noise_t.entropy_dev``) that is rewritten before
+each replay, so a new ``BrownianInterval`` (new entropy) reuses the captured graph.
+
+Constraints (checked, with a loud fallback to the eager path otherwise): forward solve without autograd
+tracking; a native ``BrownianInterval``; the user's ``f``/``g`` must be capture-safe torch code (static shapes,
+no host sync, no Python-side state that changes between solves).
+"""
+import warnings
+
+import torch
+
+from .brownian import BrownianInterval
+
+_CACHE_ATTR = "_tsde_hip_graphs"
+
+
+class _CapturedSolve:
+    def __init__(self, solver, y0, ts):
+        bm = solver.bm
+        device = y0.device
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.y_in = torch.empty_like(y0, memory_format=torch.contiguous_format)
+        self.y_in.copy_(y0)
+        self._set_seed(bm)
+        bm._entropy_dev = self.seed_dev
+        try:
+            self.plan = solver._plan(self.y_in, ts)
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
+                solver._run(self.plan, self.y_in)
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.ys = solver._run(self.plan, self.y_in)
+        finally:
+            bm._entropy_dev = None
+        self.graph.replay()     # capture only records: run once so that `ys` holds this solve's result
+
+    def _set_seed(self, bm):
+        key = bm._key
+        self.seed_dev.fill_(key - (1 << 64) if key >= (1 << 63) else key)   # two's complement into int64
+
+    def replay(self, bm, y0):
+        self.y_in.copy_(y0)
+        self._set_seed(bm)
+        self.graph.replay()
+        return self.ys.clone()
+
+
+def _signature(solver, y0, ts_host):
+    bm = solver.bm
+    return (type(solver).__name__, tuple(y0.shape), y0.dtype, str(y0.device), tuple(ts_host.tolist()),
+            float(solver.dt), tuple(bm.shape), bm.levy_area_approximation, bm.row_offset,
+            None if bm._edges is None else bm._edges.tobytes(), bm._max_depth, bm._snap,
+            tuple(sorted((k, v) for k, v in solver.options.items() if isinstance(v, (bool, int, float, str)))))
+
+
+def replay_or_capture(solver, y0, ts):
+    """Run the solve through a cached HIP graph (capturing it on first use); returns ys."""
+    bm = solver.bm
+    if not isinstance(bm, BrownianInterval) or bm._rootW is not None or bm._rootH is not None:
+        warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
+        return solver._run(solver._plan(y0, ts), y0)
+    from . import timegrid
+    ts_host = timegrid.ts_to_host(ts)
+    base = solver.sde
+    while hasattr(base, "_base_sde"):    # ForwardSDE / RenameMethodsSDE / SDELogqp wrappers are rebuilt per call
+        base = base._base_sde
+    cache = getattr(base, _CACHE_ATTR, None)
+    if cache is None:
+        cache = {}
+        setattr(base, _CACHE_ATTR, cache)
+    # the grid the Brownian motion will have after adoption is part of the signature
+    probe_plan_needed = not bm.frozen
+    if probe_plan_needed:
+        bm.adopt_grid(timegrid.build(ts_host, solver.dt).t_f64())
+    sig = _signature(solver, y0, ts_host)
+    captured = cache.get(sig)
+    if captured is None:
+        captured = _CapturedSolve(solver, y0, ts)
+        cache[sig] = captured
+        return captured.ys.clone()
+    return captured.replay(bm, y0)

@@ -17,18 +17,22 @@ from ._native import Noise, Seg
 class NoiseSpec:
     """The Brownian increment of one step: either a generated grid cell or materialised tensors."""
 
-    __slots__ = ("W", "U", "entropy", "elem0", "cell", "h", "bcast_d", "shape", "dtype", "device", "_struct")
+    __slots__ = ("W", "U", "entropy", "elem0", "cell", "h", "bcast_d", "shape", "dtype", "device", "entropy_dev",
+                 "_struct")
 
-    def __init__(self, shape, dtype, device, W=None, U=None, entropy=0, elem0=0, cell=0, h=0.0, bcast_d=0):
+    def __init__(self, shape, dtype, device, W=None, U=None, entropy=0, elem0=0, cell=0, h=0.0, bcast_d=0,
+                 entropy_dev=None):
         self.shape, self.dtype, self.device = tuple(shape), dtype, device
         self.W = None if W is None else _native.contiguous(W)
         self.U = None if U is None else _native.contiguous(U)
         self.entropy, self.elem0, self.cell, self.h, self.bcast_d = entropy, elem0, cell, h, bcast_d
+        self.entropy_dev = entropy_dev   # int64 device tensor holding the run-time seed (HIP-graph replay)
         self._struct = None
 
     @classmethod
     def generated(cls, bm, cell, h):
-        return cls(bm.shape, bm.dtype, bm.device, entropy=bm._key, elem0=bm._elem0, cell=int(cell), h=float(h))
+        return cls(bm.shape, bm.dtype, bm.device, entropy=bm._key, elem0=bm._elem0, cell=int(cell), h=float(h),
+                   entropy_dev=bm._entropy_dev)
 
     @classmethod
     def external(cls, W, U=None, bcast_d=0):
@@ -45,6 +49,7 @@ class NoiseSpec:
             s.dU = None if self.U is None else self.U.data_ptr()
             s.entropy, s.elem0, s.cell, s.reserved = self.entropy, self.elem0, self.cell, 0
             s.h, s.bcast_d = self.h, self.bcast_d
+            s.entropy_dev = None if self.entropy_dev is None else self.entropy_dev.data_ptr()
             self._struct = s
         return ctypes.byref(self._struct)
 
@@ -63,24 +68,33 @@ class NoiseSpec:
 
 
 def _prep(ref, *tensors):
-    """Contiguous, same dtype/device as `ref`; detached (kernels are autograd-opaque)."""
+    """Contiguous, same dtype/shape as `ref`. (Kernels only see data pointers, so no detach is needed.)"""
     out = []
     for t in tensors:
         if t is None:
             out.append(None)
             continue
-        t = t.detach()
         if t.dtype != ref.dtype:
             t = t.to(ref.dtype)
         if t.shape != ref.shape:
             t = t.expand(ref.shape)
-        out.append(_native.contiguous(t))
+        out.append(t if t.is_contiguous() else t.contiguous())
     return out
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _launch_env(ref):
-    _native.require_device(ref)
-    return _native.load(), _native.dtype_code(ref.dtype), _native.stream_ptr(ref.device)
+    """(library, dtype code, current HIP stream of ref's device) -- the per-launch constants, cheaply."""
+    dev = ref.device
+    if dev.type != "cuda":
+        _native.require_device(ref)
+    if _raw_stream is not None:
+        stream = _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+    else:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    return _native.load(), (_native.F32 if ref.dtype == torch.float32 else _native.dtype_code(ref.dtype)), stream
 
 
 def _new_like(ref, out):
@@ -93,43 +107,49 @@ def _needs_grad(*tensors):
 
 # ---- raw launches --------------------------------------------------------------------------------------
 def _raw_step_diag(y0, f, g, cf, cg, noise, out):
-    y0 = _native.contiguous(y0.detach())
+    if not y0.is_contiguous():
+        y0 = y0.contiguous()
     f, g = _prep(y0, f, g)
     out = _new_like(y0, out)
     lib, dt_code, stream = _launch_env(y0)
-    code = lib.tsde_step_diag(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g), y0.numel(),
-                              float(cf), float(cg), noise.struct(), dt_code, stream)
-    _native.check(code, "tsde_step_diag")
+    code = lib.tsde_step_diag(out.data_ptr(), y0.data_ptr(), f.data_ptr(), g.data_ptr(), y0.numel(),
+                              cf, cg, noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_step_diag")
     return out
 
 
 def _raw_step_prod(y0, f, gp, cf, cg, out):
-    y0 = _native.contiguous(y0.detach())
+    if not y0.is_contiguous():
+        y0 = y0.contiguous()
     f, gp = _prep(y0, f, gp)
     out = _new_like(y0, out)
     lib, dt_code, stream = _launch_env(y0)
-    code = lib.tsde_step_prod(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(gp), y0.numel(),
-                              float(cf), float(cg), dt_code, stream)
-    _native.check(code, "tsde_step_prod")
+    code = lib.tsde_step_prod(out.data_ptr(), y0.data_ptr(), f.data_ptr(), gp.data_ptr(), y0.numel(),
+                              cf, cg, dt_code, stream)
+    if code:
+        _native.check(code, "tsde_step_prod")
     return out
 
 
 def _raw_step_general(y0, f, g, cf, cg, noise, out):
-    y0 = _native.contiguous(y0.detach())
+    if not y0.is_contiguous():
+        y0 = y0.contiguous()
     f, = _prep(y0, f)
-    g = g.detach()
     if g.dtype != y0.dtype:
         g = g.to(y0.dtype)
     B, d = y0.shape
     m = g.shape[-1]
     if g.shape != (B, d, m):
         g = g.expand(B, d, m)
-    g = _native.contiguous(g)
+    if not g.is_contiguous():
+        g = g.contiguous()
     out = _new_like(y0, out)
     lib, dt_code, stream = _launch_env(y0)
-    code = lib.tsde_step_general(_native.ptr(out), _native.ptr(y0), _native.ptr(f), _native.ptr(g), B, d, m,
-                                 float(cf), float(cg), noise.struct(), dt_code, stream)
-    _native.check(code, "tsde_step_general")
+    code = lib.tsde_step_general(out.data_ptr(), y0.data_ptr(), f.data_ptr(), g.data_ptr(), B, d, m,
+                                 cf, cg, noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_step_general")
     return out
 
 
@@ -198,9 +218,8 @@ def step_general_weighted(y0, f, g, ca, cf, cg, weight_mode, cw, cu, rdt, noise,
     if _needs_grad(y0, f, g):
         raise NotImplementedError("torchsde_amd: back-propagating through the SRK solver is not supported; use "
                                   "`method='milstein'`/'euler' or `sdeint_adjoint`.")
-    y0 = _native.contiguous(y0.detach())
+    y0 = _native.contiguous(y0)
     f, = _prep(y0, f)
-    g = g.detach()
     if g.dtype != y0.dtype:
         g = g.to(y0.dtype)
     B, d = y0.shape
@@ -244,7 +263,7 @@ class _MilsteinDiagFn(torch.autograd.Function):
 
 
 def _raw_milstein_diag(y0, f, g, gdg, dt, noise, out):
-    y0 = _native.contiguous(y0.detach())
+    y0 = _native.contiguous(y0)
     f, g, gdg = _prep(y0, f, g, gdg)
     out = _new_like(y0, out)
     lib, dt_code, stream = _launch_env(y0)
@@ -265,7 +284,7 @@ def milstein_gf_prime(y0, f, g, dt, sqrt_dt, ito, out=None):
     """y' = (y0 + dt*f) + g*sqrt_dt (Ito) or y0 + g*sqrt_dt (Stratonovich)."""
     if _needs_grad(y0, f, g):
         return (y0 + dt * f + g * sqrt_dt) if ito else (y0 + g * sqrt_dt)
-    y0 = _native.contiguous(y0.detach())
+    y0 = _native.contiguous(y0)
     f, g = _prep(y0, f, g)
     out = _new_like(y0, out)
     lib, dt_code, stream = _launch_env(y0)
@@ -292,7 +311,7 @@ class _MilsteinGfDiagFn(torch.autograd.Function):
 
 
 def _raw_milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out):
-    y0 = _native.contiguous(y0.detach())
+    y0 = _native.contiguous(y0)
     f, g, gprime = _prep(y0, f, g, gprime)
     out = _new_like(y0, out)
     lib, dt_code, stream = _launch_env(y0)
@@ -317,7 +336,7 @@ def srk_diag_stage(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0=True, want1
     if _needs_grad(y0, *fs, *gs):
         raise NotImplementedError("torchsde_amd: back-propagating through the SRK solver is not supported; use "
                                   "`method='milstein'`/'euler' or `sdeint_adjoint`.")
-    y0 = _native.contiguous(y0.detach())
+    y0 = _native.contiguous(y0)
     fs = _prep(y0, *fs) + [None] * (4 - len(fs))
     gs = _prep(y0, *gs) + [None] * (4 - len(gs))
     if out0 is None:
@@ -367,7 +386,7 @@ def linear_interp(ya, yb, w0, w1, out=None):
     """out = w0*ya + w1*yb (interp.py:17)."""
     if _needs_grad(ya, yb):
         return w0 * ya + w1 * yb
-    ya = _native.contiguous(ya.detach())
+    ya = _native.contiguous(ya)
     yb, = _prep(ya, yb)
     out = _new_like(ya, out)
     lib, dt_code, stream = _launch_env(ya)

@@ -122,14 +122,23 @@ class BaseSDESolver:
             raise NotImplementedError(
                 "torchsde_amd: adaptive step-size control is outside the MI355X hot path built so far "
                 "(SURVEY.md section 8(f), rank 2). Use `adaptive=False`.")
+        if self.options.get("hip_graph", False) and not self._tracks_grad(y0):
+            from . import graph
+            return graph.replay_or_capture(self, y0, ts), ()
+        return self._run(self._plan(y0, ts), y0), ()
+
+    def _tracks_grad(self, y0):
+        return torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
+
+    def _plan(self, y0, ts):
+        """Host-side preparation of a solve: time grid, stage times (one upload), Brownian cell map, output map.
+        Everything that synchronises or copies from the host happens here, none of it in `_run`."""
         device = y0.device
         grid = timegrid.build(timegrid.ts_to_host(ts), self.dt)
         n_steps = grid.n_steps
         np_dtype = grid.t.dtype.type
         t64 = grid.t_f64()
-
-        # Stage times for every step in one upload: times[k][j] = t_k + frac_j * dt_k, rounded like the
-        # reference's 0-d tensor arithmetic (`t0 + C * dt`).
+        # times[k][j] = t_k + frac_j * dt_k, rounded like the reference's 0-d tensor arithmetic (`t0 + C * dt`)
         fracs = self.stage_fracs
         stage = np.empty((max(n_steps, 1), len(fracs)), dtype=grid.t.dtype)
         for j, frac in enumerate(fracs):
@@ -141,23 +150,29 @@ class BaseSDESolver:
         if stage_dev.dtype != ts.dtype:
             stage_dev = stage_dev.to(ts.dtype)
         stage_rows = [row.unbind(0) for row in stage_dev.unbind(0)] if n_steps > 0 else []
-        t_dev = None  # step boundaries as tensors, only needed for foreign Brownian objects
-
+        t_dev = None   # step boundaries as tensors, only needed for foreign Brownian objects
         bm = self._native_bm()
         cells = None
         if bm is not None and n_steps > 0:
             bm.adopt_grid(t64)
             cells = bm.match_grid(t64)
+            if cells is None:
+                bm._device_edges()   # upload the cell edges now: `_run` must not copy from the host
         elif n_steps > 0:
             t_dev = torch.from_numpy(grid.t).to(device=device).unbind(0)
-
-        # Output bookkeeping: which step completes which ys[i]; exact hits are written in place.
-        T = len(grid.outputs) + 1
-        done_at = {}
+        done_at = {}   # step index -> outputs it completes; exact hits are written in place
         for j, (kp, kc, w0, w1) in enumerate(grid.outputs):
             done_at.setdefault(kc, []).append((j + 1, kp, w0, w1))
+        return dict(grid=grid, t64=t64, stage_rows=stage_rows, t_dev=t_dev, cells=cells, done_at=done_at,
+                    T=len(grid.outputs) + 1)
+
+    def _run(self, plan, y0):
+        """Launch-only part of a solve (no host sync, no host->device copy): capturable in a HIP graph."""
+        grid, t64, stage_rows, t_dev, cells, done_at, T = (plan[k] for k in ("grid", "t64", "stage_rows", "t_dev",
+                                                                              "cells", "done_at", "T"))
+        device = y0.device
         y0c = y0 if y0.is_contiguous() else y0.contiguous()
-        track = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
+        track = self._tracks_grad(y0)
         ys_buf = None if track else torch.empty((T,) + tuple(y0.shape), dtype=y0.dtype, device=device)
         ys_list = [y0c] + [None] * (T - 1)
         if ys_buf is not None:
@@ -166,7 +181,7 @@ class BaseSDESolver:
         in_place = ys_buf is not None
 
         cur = y0c
-        for k in range(n_steps):
+        for k in range(grid.n_steps):
             slot = None
             if in_place:
                 slot = scratch[k & 1]
@@ -193,8 +208,8 @@ class BaseSDESolver:
             if ys_list[i] is None:   # output times that need no step (cannot happen for increasing ts)
                 ys_list[i] = cur
         if in_place:
-            return ys_buf, ()
-        return torch.stack(ys_list, dim=0), ()
+            return ys_buf
+        return torch.stack(ys_list, dim=0)
 
     def _params(self):
         try:
