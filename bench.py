@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_euler_diag_b65536_d64_s1000")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,12 +165,16 @@ def main():
     cfg = WORKLOADS[args.workload]
     B, d, m, nsteps, dt = cfg["B"], cfg["d"], cfg["m"], cfg["nsteps"], cfg["dt"]
     adjoint = cfg.get("adjoint", False)
+    # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
+    # the derivative form of Milstein and the adjoint run autograd inside the loop and stay eager.
+    use_graph = (not args.eager) and (not adjoint) and cfg["method"] != "milstein"
     sde = _make_problem(cfg["problem"], d, m, dev)
     y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
     ts = torch.tensor([0.0, nsteps * dt], device=dev)
     gathered = torch.empty((world * B, d), device=dev) if world > 1 else None
 
-    def one_solve(i):
+    def one_solve(i, graph=None):
+        graph = use_graph if graph is None else graph
         bm = torchsde_amd.BrownianInterval(t0=0.0, t1=nsteps * dt, size=(B, m), dtype=torch.float32, device=dev,
                                            entropy=20240601 + i, dt=dt, levy_area_approximation=cfg["levy"],
                                            row_offset=rank * B)
@@ -182,7 +187,8 @@ def main():
                 from torchsde_amd import sharding
                 sharding.all_reduce_gradients(list(sde.parameters()))
             return y0.grad
-        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt,
+                                 options={"hip_graph": True} if graph else None)
         if world > 1:
             dist.all_gather_into_tensor(gathered, ys[-1])
             return gathered
@@ -209,8 +215,9 @@ def main():
 
         # roofline of the dominant kernel: every launch of the step kernel in one more solve is bracketed by
         # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
+        # (issued eagerly: event records are host-side calls and are not part of a replayed graph)
         K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
-        one_solve(5000)
+        one_solve(5000, graph=False)
         torch.cuda.synchronize()
         k_ms, k_launches = K.prof_end()
     assert torch.isfinite(out).all()
@@ -238,6 +245,7 @@ def main():
                        "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "state": d, "brownian_channels": m,
                        "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
+                       "launch": "HIP graph replay of the whole solve" if use_graph else "eager launches",
                        "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

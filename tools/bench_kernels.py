@@ -1,0 +1,62 @@
+"""Kernel-level timings through the C ABI (back-to-back launches on random data, torch events).
+In-situ numbers (between the user's f/g kernels) are ~15-25 % lower: see tools/microbench_seq.hip and bench.py."""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from torchsde_amd import kernels as K  # noqa: E402
+from torchsde_amd.kernels import NoiseSpec  # noqa: E402
+
+
+def timeit(fn, iters=200):
+    for _ in range(10):
+        fn(0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def gen_noise(shape, cell, dt, dev):
+    return NoiseSpec(shape, torch.float32, torch.device(dev), entropy=12345, elem0=0, cell=cell, h=dt)
+
+
+def main():
+    dev = "cuda"
+    dt = 2.0 ** -10
+    rows = []
+    for (B, d) in [(65536, 64), (32768, 64), (32768, 128), (16384, 32)]:
+        y = [torch.rand(B, d, device=dev) for _ in range(2)]
+        f, g = torch.randn(B, d, device=dev), torch.rand(B, d, device=dev)
+        us = timeit(lambda i: K._raw_step_diag(y[i & 1], f, g, dt, 1.0, gen_noise((B, d), i, dt, dev), y[(i + 1) & 1]))
+        rows.append((f"step_diag B={B} d={d}", us, 16 * B * d))
+        gdg = torch.randn(B, d, device=dev)
+        us = timeit(lambda i: K._raw_milstein_diag(y[i & 1], f, g, gdg, dt, gen_noise((B, d), i, dt, dev), y[(i + 1) & 1]))
+        rows.append((f"milstein_diag B={B} d={d}", us, 20 * B * d))
+    for (B, d, m) in [(16384, 32, 16), (16384, 64, 16), (65536, 16, 16), (16384, 32, 64)]:
+        y = [torch.rand(B, d, device=dev) for _ in range(2)]
+        f, g = torch.randn(B, d, device=dev), torch.rand(B, d, m, device=dev)
+        us = timeit(lambda i: K._raw_step_general(y[i & 1], f, g, dt, 1.0, gen_noise((B, m), i, dt, dev), y[(i + 1) & 1]))
+        rows.append((f"step_general B={B} d={d} m={m}", us, 4 * B * (d * m + 3 * d)))
+    B, d = 32768, 128
+    s = [torch.rand(B, d, device=dev) for _ in range(4)]
+    F = [torch.randn(B, d, device=dev) for _ in range(4)]
+    P = [torch.randn(128, 128, device=dev) for _ in range(4)] + [torch.randn(128, device=dev) for _ in range(4)]
+
+    def aug(i):
+        segs = [dict(out=s[2], s=s[0], F=F[0], G=F[1], sF=-1.0, sG=-1.0), dict(out=s[3], s=s[1], F=F[2], G=F[3])]
+        segs += [dict(out=p, s=p, F=p, G=p) for p in P]
+        K.aug_update(segs, dt, 1.0, torch.float32, torch.device(dev))
+    us = timeit(aug)
+    rows.append((f"aug_update B={B} d={d} (+8 param segments)", us, 32 * B * d))
+    for name, us, nbytes in rows:
+        print(f"{name:48s} {us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / us / 1e3 / 80:.1f} % of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,39 @@ class AdjointSDE(BaseSDE):
                 g_prod = fwd.prod(g, v)
             return self._drift_parts(f, g, y, a), self._diffusion_parts(g_prod, y, a)
 
+    def fused_terms(self, t, y, a, v, cF, cG):
+        """(f~, g.v, cF * vjp(f~) + cG * vjp(g.v)) for the Euler / midpoint backward updates.
+
+        Same quantities as `f_and_g_prod`, but the cotangent-weighted sum over the adjoint segments is taken
+        in ONE reverse sweep: ``autograd.grad([f~, g.v, g], [y, theta], [cF*a, cG*a, cF*a_dg])`` instead of one
+        sweep per term (3 sweeps instead of the reference's 5 for Ito-diagonal, 1 instead of 2 otherwise).
+        """
+        fwd = self.forward_sde
+        y = self._leaf(y)
+        inputs = self._inputs(y)
+        with torch.enable_grad():
+            if self._correction is None:
+                f, g_prod = fwd.f_and_g_prod(t, y, v)
+                outs, cots = [f, g_prod], [a * cF, a * cG]
+            elif self._correction == "diagonal":
+                f, g = fwd.f_and_g(t, y)
+                g_prod = fwd.prod(g, v)
+                g_dg, = vjp(g, y, grad_outputs=g, allow_unused=True, create_graph=True)
+                f = f - g_dg
+                a_dg, = vjp(g, y, grad_outputs=a, allow_unused=True, retain_graph=True)
+                outs, cots = [f, g_prod, g], [a * cF, a * cG, a_dg * cF]
+            else:
+                parts_f, parts_g = self.f_and_g_prod(t, y, a, v)
+                return parts_f[0], parts_g[0], [p * cF + q * cG for p, q in zip(parts_f[1:], parts_g[1:])]
+            live = [(o, c) for o, c in zip(outs, cots) if o.requires_grad]
+            if live:
+                grads = torch.autograd.grad([o for o, _ in live], inputs, grad_outputs=[c for _, c in live],
+                                            allow_unused=True)
+            else:
+                grads = [None] * len(inputs)
+            grads = [torch.zeros_like(x) if gr is None else gr for gr, x in zip(grads, inputs)]
+            return f.detach(), g_prod.detach(), grads
+
     def f(self, t, y, a):
         """Drift parts only (adjoint_sde.py:236-252)."""
         fwd = self.forward_sde
@@ -155,14 +188,48 @@ class _AugState:
         return cls([torch.empty_like(x) for x in other.t])
 
 
+_SEG_CACHE = {}
+
+
 def _update(dst, src, F, G, D, cF, cG):
-    """dst = src + F*cF + cG*G (+ D), with the reference's sign on the y segment; ONE kernel launch."""
-    segs = []
+    """dst = src + F*cF + cG*G (+ D), with the reference's sign on the y segment; ONE kernel launch.
+
+    The (dst, src) buffer sets are persistent, so their descriptor array is built once and only the term
+    pointers are refreshed per step (this runs ~1000 times per backward pass)."""
+    from . import _native
+    key = (id(dst), id(src))
+    entry = _SEG_CACHE.get(key)
+    if entry is None or entry[1] is not dst or entry[2] is not src:
+        arr = (_native.Seg * len(src.t))()
+        for i, s in enumerate(src.t):
+            arr[i].out, arr[i].s, arr[i].n = dst.t[i].data_ptr(), s.data_ptr(), s.numel()
+            sign = -1.0 if i == 0 else 1.0
+            arr[i].sF, arr[i].sG, arr[i].sD = sign, sign, 1.0
+        if len(_SEG_CACHE) > 64:
+            _SEG_CACHE.clear()
+        entry = (arr, dst, src)
+        _SEG_CACHE[key] = entry
+    arr = entry[0]
+    keep = []
     for i, s in enumerate(src.t):
-        sign = -1.0 if i == 0 else 1.0
-        segs.append(dict(out=dst.t[i], s=s, F=None if F is None else F[i], G=None if G is None else G[i],
-                         D=None if D is None else D[i], sF=sign, sG=sign, sD=1.0))
-    K.aug_update(segs, cF, cG, src.t[0].dtype, src.t[0].device)
+        for name, terms in (("F", F), ("G", G), ("D", D)):
+            t = None if terms is None else terms[i]
+            if t is None:
+                setattr(arr[i], name, None)
+                continue
+            if t.dtype != s.dtype:
+                t = t.to(s.dtype)
+            if t.shape != s.shape:
+                t = t.reshape(s.shape) if t.numel() == s.numel() else t.expand(s.shape)
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            setattr(arr[i], name, t.data_ptr())
+    lib, dt_code, stream = K._launch_env(src.t[0])
+    code = lib.tsde_aug_update(arr, len(src.t), float(cF), float(cG), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_aug_update")
+    return keep
 
 
 def _check_adjoint_method(adjoint_sde, adjoint_method, adjoint_options, bm):
@@ -226,6 +293,7 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                           [torch.zeros_like(p) for p in adjoint_params])
         other = _AugState.like(state)
         mid = _AugState.like(state) if kind == "midpoint" else None
+        none_tail = [None] * (len(state.t) - 1)
 
         for i in range(T - 1, 0, -1):
             grid = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)
@@ -259,14 +327,15 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                 y, a = state.t[0], state.t[1]
                 t_fwd = stage_rows[k][0]
                 if kind == "euler":
-                    F, G = adjoint_sde.f_and_g_prod(t_fwd, y, a, v)
-                    _update(other, state, F, G, None, step_dt, 1.0)
+                    # y' = y - f~ dt - g.v ;  (a, theta)' += dt*vjp(f~) + vjp(g.v)  (one reverse sweep, one launch)
+                    ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(step_dt), 1.0)
+                    _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
                 elif kind == "midpoint":
                     half_dt = np_dtype(0.5) * step_dt
-                    F, G = adjoint_sde.f_and_g_prod(t_fwd, y, a, v)
-                    _update(mid, state, F, G, None, half_dt, 0.5)
-                    F2, G2 = adjoint_sde.f_and_g_prod(stage_rows[k][1], mid.t[0], mid.t[1], v)
-                    _update(other, state, F2, G2, None, step_dt, 1.0)
+                    ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(half_dt), 0.5)
+                    _update(mid, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, half_dt, 0.5)
+                    ft, gp, tot = adjoint_sde.fused_terms(stage_rows[k][1], mid.t[0], mid.t[1], v, float(step_dt), 1.0)
+                    _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
                 else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
                     v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
                     F = adjoint_sde.f(t_fwd, y, a)
@@ -277,6 +346,7 @@ class _SdeintAdjointMethod(torch.autograd.Function):
             state.t[0].copy_(ys[i - 1])
             state.t[1].add_(grad_ys[i - 1])
 
+        _SEG_CACHE.clear()   # drop the references to this pass's buffers
         out = [state.t[1]] + ([None] * ctx.len_extras) + state.t[2:]
         return (None,) * 13 + tuple(out)
 

@@ -475,6 +475,45 @@ __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<
   }
 }
 
+// Row-per-wave variant for rows that are a whole number (NC = 1, 2 or 4) of 64-lane, 16-B vector loads
+// (C3: d*m/4 = 128 -> NC = 2): no index division, all of a row's loads (g, and y0/f for the output lanes) are
+// issued before the Philox call so that the RNG hides under the memory latency.
+template <typename T, int NC>
+__global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<T> a) {
+  const int G = (int)(a.m >> 2);
+  const int logG = __builtin_ctz(G);
+  const int lane = threadIdx.x & 63;
+  const int lp = lane & (G - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  const int outs_per_chunk = 64 >> logG;        // outputs (b, i) finished by one 64-lane load
+  for (int64_t row = wave; row < a.B; row += n_waves) {
+    const T* grow = a.g + row * (int64_t)(NC * 64 * 4);
+    Pack<T, 4> gq[NC];
+    T y0v[NC], fv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      gq[c] = load<T, 4>(grow, (int64_t)(c * 64 + lane) * 4);
+      const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
+      if (lp == 0) {
+        y0v[c] = a.y0[o];
+        fv[c] = a.f[o];
+      }
+    }
+    T wq[4];
+    lane_weights<T>(a, row, lp, wq);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      T part = ((gq[c].v[0] * wq[0] + gq[c].v[1] * wq[1]) + gq[c].v[2] * wq[2]) + gq[c].v[3] * wq[3];
+      for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
+      if (lp == 0) {
+        const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
+        a.y1[o] = (y0v[c] + (a.ca * fv[c]) * a.cf) + a.cg * part;
+      }
+    }
+  }
+}
+
 // Generic path: any d, m (m*rows_per_tile <= kGenMaxNoise): one thread per output, scalar loads of g.
 template <typename T>
 __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralArgs<T> a) {
@@ -682,6 +721,16 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   // the fast path loads increments (external) or forms Philox quads at row*m + 4*lane: needs 16-B alignment there
   const bool noise_ok = nz->dW ? (aligned16(nz->dW) && (!nz->dU || aligned16(nz->dU))) : (nz->elem0 % 4 == 0);
   const bool fast = pow2 && aligned16(g) && noise_ok;
+  if (fast && (d * G) % 64 == 0 && ((d * G) / 64 == 1 || (d * G) / 64 == 2 || (d * G) / 64 == 4)) {
+    const int nc = (int)((d * G) / 64);
+    int64_t blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);   // one wave per row
+    if (blocks > kMaxGrid) blocks = kMaxGrid;
+    a.rows_per_tile = 0;
+    if (nc == 1) hipLaunchKernelGGL((general_rows_kernel<T, 1>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    else if (nc == 2) hipLaunchKernelGGL((general_rows_kernel<T, 2>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((general_rows_kernel<T, 4>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+  }
   if (fast) {
     const int64_t total4 = B * d * G;
     const int64_t spans = (total4 + 64 * kGenUnroll - 1) / (64 * kGenUnroll);   // one wave per span
