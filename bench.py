@@ -216,6 +216,7 @@ def main():
         # roofline of the dominant kernel: every launch of the step kernel in one more solve is bracketed by
         # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
         # (issued eagerly: event records are host-side calls and are not part of a replayed graph)
+        null_ms = K.prof_null_bracket(200, dev)
         K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
         one_solve(5000, graph=False)
         torch.cuda.synchronize()
@@ -225,12 +226,28 @@ def main():
     value = world * B * nsteps * args.steps / elapsed
     roofline = None
     if k_launches > 0:
-        avg_s = k_ms * 1e-3 / k_launches
+        # each bracket = kernel + the fixed cost of the two event records; the latter is measured (empty brackets
+        # on the same stream) and removed. rocprofv3's kernel trace of this command is the cross-check (profiles/).
+        raw_s = k_ms * 1e-3 / k_launches
+        avg_s = max(raw_s - null_ms * 1e-3, 1e-9)
         bytes_per_launch = cfg["bytes_per_traj_step"] * B / cfg["launches_per_step"]
         achieved = bytes_per_launch / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath) and args.workload == "c2_euler_diag_b65536_d64_s1000":
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools_profile.sh), corrected as
+            # guides/MI355X_MICROARCH.md prescribes; collected offline because counters need their own passes.
+            try:
+                with open(tpath) as fh:
+                    for kname, rec in json.load(fh).items():
+                        if "StepDiagOp<float>" in kname:
+                            traffic = rec["traffic_bytes_per_launch"]
+            except Exception:
+                traffic = None
         roofline = {"bound": "hbm", "kernel": cfg["kernel"],
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
+                    "traffic": traffic, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "avg_bracket_us_raw": raw_s * 1e6,
+                    "event_bracket_overhead_us": null_ms * 1e3,
                     "launches_timed": k_launches}
     if rank == 0:
         cpu = None

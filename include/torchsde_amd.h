@@ -161,6 +161,9 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
 #define TSDE_KID_BROWNIAN_QUERY 6
 /* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
 int tsde_prof_begin(int kid, int capacity);
+/* Mean duration of `n` empty (record, record) event brackets on `stream`: the fixed cost event timing adds
+ * to each bracketed kernel (bench.py reports durations with and without it). Synchronises. */
+int tsde_prof_null_bracket(int n, double* mean_ms, void* stream);
 /* Synchronise the events, return the summed kernel time and launch count, stop profiling. */
 int tsde_prof_end(double* total_ms, int64_t* launches);
 

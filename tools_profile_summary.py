@@ -22,6 +22,7 @@ if stats:
     for r in rows[:12]:
         print(f"{r.get('Name','')[:110]:110s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
               f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
+traffic = {}
 for label, sub, col in (("FETCH_SIZE", "pmc_fetch", "FETCH_SIZE"), ("WRITE_SIZE", "pmc_write", "WRITE_SIZE")):
     path = find(sub, "*counter_collection.csv")
     if not path:
@@ -38,3 +39,19 @@ for label, sub, col in (("FETCH_SIZE", "pmc_fetch", "FETCH_SIZE"), ("WRITE_SIZE"
     print(f"== {label} per launch (raw counter units as reported by rocprofv3; KiB on this stack) ==")
     for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
         print(f"{k[:110]:110s} launches={n} mean={tot / max(n, 1):.1f}")
+        if "tsde::" in k:
+            traffic.setdefault(k, {})[label] = tot / max(n, 1)
+
+# HBM traffic per launch of our kernels: FETCH_SIZE is reported in KiB and counts 64 B per 128-B request for wide
+# coalesced reads on gfx950 (guides/MI355X_MICROARCH.md section HBM) -> x2; WRITE_SIZE in KiB as reported.
+import json
+out_json = {}
+for k, v in traffic.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out_json[k] = {"fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
+                       "traffic_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
+                       "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), units KiB"}
+with open(os.path.join(out, "traffic.json"), "w") as f:
+    json.dump(out_json, f, indent=1)
+print("== traffic.json ==")
+print(json.dumps(out_json, indent=1))

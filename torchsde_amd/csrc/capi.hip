@@ -252,6 +252,32 @@ int tsde_prof_begin(int kid, int capacity) {
   return 0;
 }
 
+int tsde_prof_null_bracket(int n, double* mean_ms, void* stream) {
+  // Cost of an empty (record, record) bracket on `stream`: what event timing adds to every kernel it brackets.
+  if (n <= 0 || !mean_ms) return bad_arg("tsde_prof_null_bracket", "bad arguments");
+  const hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  hipError_t r = hipSuccess;
+  for (auto& e : ev) {
+    r = hipEventCreate(&e);
+    if (r != hipSuccess) return fail(r, "tsde_prof_null_bracket");
+  }
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventRecord(ev[2 * i], s);
+    (void)hipEventRecord(ev[2 * i + 1], s);
+  }
+  double sum = 0.0;
+  for (int i = 0; i < n && r == hipSuccess; ++i) {
+    r = hipEventSynchronize(ev[2 * i + 1]);
+    float ms = 0.f;
+    if (r == hipSuccess) r = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+    sum += ms;
+  }
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  *mean_ms = sum / n;
+  return fail(r, "tsde_prof_null_bracket");
+}
+
 int tsde_prof_end(double* total_ms, int64_t* launches) {
   double sum = 0.0;
   hipError_t r = hipSuccess;

@@ -401,6 +401,14 @@ def prof_begin(kid, capacity):
     _native.check(_native.load().tsde_prof_begin(kid, capacity), "tsde_prof_begin")
 
 
+def prof_null_bracket(n=200, device=None):
+    """Mean cost (ms) of an empty event bracket on the current stream."""
+    ms = ctypes.c_double(0.0)
+    _native.check(_native.load().tsde_prof_null_bracket(n, ctypes.byref(ms), _native.stream_ptr(device)),
+                  "tsde_prof_null_bracket")
+    return ms.value
+
+
 def prof_end():
     ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
     _native.check(_native.load().tsde_prof_end(ctypes.byref(ms), ctypes.byref(n)), "tsde_prof_end")
