@@ -161,9 +161,13 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
 #define TSDE_KID_BROWNIAN_QUERY 6
 /* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
 int tsde_prof_begin(int kid, int capacity);
-/* Mean duration of `n` empty (record, record) event brackets on `stream`: the fixed cost event timing adds
- * to each bracketed kernel (bench.py reports durations with and without it). Synchronises. */
-int tsde_prof_null_bracket(int n, double* mean_ms, void* stream);
+/* Occupies `stream` with a single-thread kernel for about `microseconds` (<= 2 s). bench.py queues one before
+ * its event-timed pass so that the host can enqueue the whole solve first and no bracket contains queue-empty
+ * time. */
+int tsde_delay_us(double microseconds, void* stream);
+/* What an event bracket adds to the kernel inside it, measured by bracketing `n` single-thread kernels that spin
+ * for `spin_us` and report their own duration from the constant-rate wall clock. Synchronises `stream`. */
+int tsde_prof_bracket_overhead(int n, double spin_us, double* overhead_ms, void* stream);
 /* Synchronise the events, return the summed kernel time and launch count, stop profiling. */
 int tsde_prof_end(double* total_ms, int64_t* launches);
 

@@ -222,3 +222,55 @@ def test_nondyadic_fp32_grid_default_bm():
     assert ys.shape == (3, 16, 8)
     assert torch.isfinite(ys).all()
     assert torch.equal(ys[0], y0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 4. Provider dispatch: the same SDE exposed through f/g, f_and_g, g_prod, f_and_g_prod gives bit-identical
+#    results under the same entropy (reference tests/test_sdeint.py:79-98 `test_specialised_functions`).
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich")])
+def test_specialised_functions_bit_identical(method, sde_type):
+    import torchsde_amd
+    B, d, steps, dt = 32, 8, 8, 2.0 ** -4
+    ts = torch.tensor([0.0, steps * dt], device=DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    outs = []
+    for cls in (problems.GBMDiag, problems.GBMViaFAndG, problems.GBMViaGProd, problems.GBMViaFAndGProd):
+        sde = cls(d, sde_type).to(DEV)
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), device=DEV, dtype=torch.float32, entropy=8)
+        with torch.no_grad():
+            outs.append(torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt))
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
+def test_logqp_and_names():
+    """logqp=True appends the KL column and returns log-ratio increments; names= renames drift/diffusion
+    (reference sdeint.py:142-144,284-295; base_sde.py:212-306)."""
+    import torchsde_amd
+
+    class Latent(torch.nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.theta = torch.nn.Parameter(torch.tensor(0.5))
+
+        def drift(self, t, y):
+            return -self.theta * y
+
+        def diffusion(self, t, y):
+            return 0.3 + 0.0 * y
+
+        def h(self, t, y):
+            return -y
+
+    sde = Latent().to(DEV)
+    y0 = torch.full((16, 4), 0.2, device=DEV)
+    ts = torch.tensor([0.0, 0.25, 0.5], device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(16, 5), device=DEV, dtype=torch.float32, entropy=4)
+    with torch.no_grad():
+        ys, logqp = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=2.0 ** -5, logqp=True,
+                                        names={"drift": "drift", "diffusion": "diffusion"})
+    assert ys.shape == (3, 16, 4) and logqp.shape == (2, 16)
+    # u = (f - h)/g = (1 - theta) y / 0.3 ; the KL integrand is 0.5 |u|^2 >= 0
+    assert (logqp >= 0).all() and torch.isfinite(ys).all()

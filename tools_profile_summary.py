@@ -14,11 +14,17 @@ def find(sub, pattern):
     return hits[0] if hits else None
 
 
+kernel_avg_us = {}
 stats = find("trace", "*kernel_stats.csv")
 if stats:
     print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1): per-kernel totals ==")
     with open(stats) as f:
         rows = list(csv.DictReader(f))
+    for r in rows:
+        try:
+            kernel_avg_us[r.get("Name", "")] = float(r.get("AverageNs")) / 1e3
+        except (TypeError, ValueError):
+            pass
     for r in rows[:12]:
         print(f"{r.get('Name','')[:110]:110s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
               f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
@@ -50,6 +56,7 @@ for k, v in traffic.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out_json[k] = {"fetch_kib_raw": v["FETCH_SIZE"], "write_kib_raw": v["WRITE_SIZE"],
                        "traffic_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
+                       "kernel_avg_us": kernel_avg_us.get(k),
                        "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), units KiB"}
 with open(os.path.join(out, "traffic.json"), "w") as f:
     json.dump(out_json, f, indent=1)

@@ -70,7 +70,8 @@ SIGNATURES = {
     "tsde_aug_update": (_c_int, [ctypes.POINTER(Seg), _c_int, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_linear_interp": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
-    "tsde_prof_null_bracket": (_c_int, [_c_int, ctypes.POINTER(_c_dbl), _c_ptr]),
+    "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
+    "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),
     "tsde_prof_end": (_c_int, [ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
 }
 

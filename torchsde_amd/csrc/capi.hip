@@ -252,30 +252,64 @@ int tsde_prof_begin(int kid, int capacity) {
   return 0;
 }
 
-int tsde_prof_null_bracket(int n, double* mean_ms, void* stream) {
-  // Cost of an empty (record, record) bracket on `stream`: what event timing adds to every kernel it brackets.
-  if (n <= 0 || !mean_ms) return bad_arg("tsde_prof_null_bracket", "bad arguments");
+namespace {
+__global__ void delay_kernel(long long ticks) {
+  const long long start = wall_clock64();   // constant 100 MHz counter
+  while (wall_clock64() - start < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+
+int tsde_delay_us(double microseconds, void* stream) {
+  if (!(microseconds >= 0.0) || microseconds > 2.0e6) return bad_arg("tsde_delay_us", "delay must be in [0, 2 s]");
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long)(microseconds * 100.0));
+  return fail(hipGetLastError(), "tsde_delay_us");
+}
+
+namespace {
+__global__ void timed_spin_kernel(long long ticks, long long* measured) {
+  const long long start = wall_clock64();
+  long long now = start;
+  while (now - start < ticks) now = wall_clock64();
+  *measured = now - start;
+}
+}  // namespace
+
+int tsde_prof_bracket_overhead(int n, double spin_us, double* overhead_ms, void* stream) {
+  // What an event bracket adds to the kernel inside it: bracket a single-thread kernel that spins for `spin_us`
+  // and reports its own duration from the constant-rate wall clock; overhead = mean(bracket - self-measured).
+  if (n <= 0 || !overhead_ms || !(spin_us > 0.0)) return bad_arg("tsde_prof_bracket_overhead", "bad arguments");
   const hipStream_t s = (hipStream_t)stream;
+  int dev = 0, khz = 0;
+  hipError_t r = hipGetDevice(&dev);
+  if (r == hipSuccess) r = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+  if (r != hipSuccess || khz <= 0) return fail(r == hipSuccess ? hipErrorUnknown : r, "tsde_prof_bracket_overhead");
+  const double ticks_per_us = khz * 1e-3;
+  long long* measured = nullptr;
+  r = hipMalloc(&measured, sizeof(long long) * (size_t)n);
+  if (r != hipSuccess) return fail(r, "tsde_prof_bracket_overhead");
   std::vector<hipEvent_t> ev(2 * (size_t)n);
-  hipError_t r = hipSuccess;
   for (auto& e : ev) {
     r = hipEventCreate(&e);
-    if (r != hipSuccess) return fail(r, "tsde_prof_null_bracket");
+    if (r != hipSuccess) return fail(r, "tsde_prof_bracket_overhead");
   }
   for (int i = 0; i < n; ++i) {
     (void)hipEventRecord(ev[2 * i], s);
+    hipLaunchKernelGGL(timed_spin_kernel, dim3(1), dim3(1), 0, s, (long long)(spin_us * ticks_per_us), measured + i);
     (void)hipEventRecord(ev[2 * i + 1], s);
   }
+  std::vector<long long> host(n);
+  r = hipStreamSynchronize(s);
+  if (r == hipSuccess) r = hipMemcpy(host.data(), measured, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost);
   double sum = 0.0;
   for (int i = 0; i < n && r == hipSuccess; ++i) {
-    r = hipEventSynchronize(ev[2 * i + 1]);
     float ms = 0.f;
-    if (r == hipSuccess) r = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
-    sum += ms;
+    r = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+    sum += (double)ms - (double)host[i] / ticks_per_us * 1e-3;
   }
   for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-  *mean_ms = sum / n;
-  return fail(r, "tsde_prof_null_bracket");
+  (void)hipFree(measured);
+  *overhead_ms = sum / n;
+  return fail(r, "tsde_prof_bracket_overhead");
 }
 
 int tsde_prof_end(double* total_ms, int64_t* launches) {

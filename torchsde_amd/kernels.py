@@ -401,11 +401,17 @@ def prof_begin(kid, capacity):
     _native.check(_native.load().tsde_prof_begin(kid, capacity), "tsde_prof_begin")
 
 
-def prof_null_bracket(n=200, device=None):
-    """Mean cost (ms) of an empty event bracket on the current stream."""
+def gpu_delay(microseconds, device=None):
+    """Keep the current stream busy for ~`microseconds` (lets the host run ahead of the GPU)."""
+    _native.check(_native.load().tsde_delay_us(float(microseconds), _native.stream_ptr(device)), "tsde_delay_us")
+
+
+def prof_bracket_overhead(n=100, spin_us=12.0, device=None):
+    """Mean cost (ms) an event bracket adds to the kernel it brackets (calibrated with self-timed spin kernels)."""
     ms = ctypes.c_double(0.0)
-    _native.check(_native.load().tsde_prof_null_bracket(n, ctypes.byref(ms), _native.stream_ptr(device)),
-                  "tsde_prof_null_bracket")
+    _native.check(_native.load().tsde_prof_bracket_overhead(n, float(spin_us), ctypes.byref(ms),
+                                                            _native.stream_ptr(device)),
+                  "tsde_prof_bracket_overhead")
     return ms.value
 
 
