@@ -162,20 +162,63 @@ STEPS = {"euler": euler_step, "midpoint": midpoint_step, "milstein": milstein_st
 
 
 # ---- the stepping loop ------------------------------------------------------------------------------------
-def integrate(sde, bm, y0, ts, dt, method, options=None, record=None):
-    """base_solver.py:92-116,143-149 (fixed step) + interp.py:15-18. `ts` is a CPU tensor."""
+def _update_step_size(error_estimate, prev_step_size, safety=0.9, facmin=0.2, facmax=1.4, prev_error_ratio=None):
+    """adaptive_stepping.py:21-39."""
+    if error_estimate > 1:
+        pfactor, ifactor = 0, 1 / 1.5
+    else:
+        pfactor, ifactor = 0.13, 1 / 4.5
+    error_ratio = safety / error_estimate
+    if prev_error_ratio is None:
+        prev_error_ratio = error_ratio
+    factor = error_ratio ** ifactor * (error_ratio / prev_error_ratio) ** pfactor
+    if error_estimate <= 1:
+        prev_error_ratio = error_ratio
+        facmin = 1.0
+    factor = min(facmax, max(facmin, factor))
+    return prev_step_size * factor, prev_error_ratio
+
+
+def _compute_error(y11, y12, rtol, atol, eps=1e-7):
+    """adaptive_stepping.py:42-76."""
+    tol = (rtol * torch.max(torch.abs(y11), torch.abs(y12)) + atol).clamp_min(eps)
+    x = (y11 - y12) / tol
+    return torch.sqrt((x ** 2.).sum() / x.numel()).clamp_min(eps).item()
+
+
+def integrate(sde, bm, y0, ts, dt, method, options=None, record=None, adaptive=False, rtol=1e-5, atol=1e-4,
+              dt_min=1e-5):
+    """base_solver.py:92-149 (fixed-step and step-doubling adaptive branches) + interp.py:15-18.
+    `ts` is a CPU tensor."""
     step = STEPS[method]
+    step_size = dt
     prev_t = curr_t = ts[0]
     prev_y = curr_y = y0
     ys = [y0]
+    prev_error_ratio = None
     for out_t in ts[1:]:
         while curr_t < out_t:
-            next_t = min(curr_t + dt, ts[-1])
+            next_t = min(curr_t + step_size, ts[-1])
             if record is not None:
                 record.append((float(curr_t), float(next_t)))
-            prev_t, prev_y = curr_t, curr_y
-            curr_y = step(sde, bm, curr_t, next_t, curr_y, options)
-            curr_t = next_t
+            if adaptive:
+                next_y_full = step(sde, bm, curr_t, next_t, curr_y, options)
+                midpoint_t = 0.5 * (curr_t + next_t)
+                midpoint_y = step(sde, bm, curr_t, midpoint_t, curr_y, options)
+                next_y = step(sde, bm, midpoint_t, next_t, midpoint_y, options)
+                error_estimate = _compute_error(next_y_full, next_y, rtol, atol)
+                step_size, prev_error_ratio = _update_step_size(error_estimate, step_size,
+                                                                prev_error_ratio=prev_error_ratio)
+                if step_size < dt_min:
+                    step_size = dt_min
+                    prev_error_ratio = None
+                if error_estimate <= 1 or step_size <= dt_min:
+                    prev_t, prev_y = curr_t, curr_y
+                    curr_t, curr_y = next_t, next_y
+            else:
+                prev_t, prev_y = curr_t, curr_y
+                curr_y = step(sde, bm, curr_t, next_t, curr_y, options)
+                curr_t = next_t
         ys.append((curr_t - out_t) / (curr_t - prev_t) * prev_y + (out_t - prev_t) / (curr_t - prev_t) * curr_y)
     return torch.stack(ys, dim=0)
 

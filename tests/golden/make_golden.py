@@ -152,6 +152,69 @@ def gen_solver():
         print(f"solver_{name}.npz  steps={len(keys)}  ys[-1,0,:2]={out['f32__ys'][-1, 0, :2]}")
 
 
+# ------------------------------------------------------------------------------------------------- adaptive
+class RecordingBM(torchsde.BaseBrownian):
+    """Wraps the reference's own BrownianInterval (a consistent path) and records every query it answers."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner, self.table, self.order = inner, {}, []
+
+    def __call__(self, ta, tb=None, return_U=False, return_A=False):
+        key = (float(ta), float(tb))
+        if key not in self.table:
+            if self.inner.levy_area_approximation != "none":
+                W, U = self.inner(ta, tb, return_U=True)
+            else:
+                W, U = self.inner(ta, tb), None
+            self.table[key] = (W, torch.zeros_like(W) if U is None else U)
+            self.order.append(key)
+        W, U = self.table[key]
+        return (W, U) if return_U else W
+
+    def __repr__(self):
+        return "RecordingBM"
+
+    dtype = property(lambda self: self.inner.dtype)
+    device = property(lambda self: self.inner.device)
+    shape = property(lambda self: self.inner.shape)
+    levy_area_approximation = property(lambda self: self.inner.levy_area_approximation)
+
+    dump = ReplayBM.dump
+
+
+ADAPTIVE_CASES = [
+    ("adaptive_milstein_gbm", "gbm_ito", "milstein", "none", (5, 4, 4), [0., 0.5, 1.0], 0.05, 1e-3, 1e-3),
+    ("adaptive_srk_gbm", "gbm_ito", "srk", "space-time", (5, 4, 4), [0., 1.0], 0.1, 1e-4, 1e-4),
+    ("adaptive_midpoint_gbm", "gbm_strat", "midpoint", "none", (5, 4, 4), [0., 0.4, 1.0], 0.1, 1e-3, 1e-3),
+    ("adaptive_euler_additive", "additive_ito", "euler", "none", (5, 4, 3), [0., 1.0], 0.1, 1e-3, 1e-3),
+]
+
+
+def gen_adaptive():
+    for name, prob, method, levy, (B, d, m), ts, dt, rtol, atol in ADAPTIVE_CASES:
+        out = {"problem": prob, "method": method, "levy": levy, "dt": np.float64(dt), "grad_free": False,
+               "shape": np.array([B, d, m]), "rtol": np.float64(rtol), "atol": np.float64(atol)}
+        for tag, dtype in DT.items():
+            sde = problems.make(prob, dtype=dtype, d=d, m=m)
+            y0 = torch.full((B, d), 0.1, dtype=dtype)
+            tst = torch.tensor(ts, dtype=dtype)
+            inner = torchsde.BrownianInterval(t0=ts[0], t1=ts[-1], size=(B, m), dtype=dtype, entropy=99,
+                                              levy_area_approximation=levy)
+            bm = RecordingBM(inner)
+            with torch.no_grad():
+                ys = torchsde.sdeint(sde, y0, tst, bm=bm, method=method, dt=dt, adaptive=True, rtol=rtol, atol=atol)
+            keys, W, U = bm.dump()
+            out[f"{tag}__ts"] = tst.numpy()
+            out[f"{tag}__queries"] = keys
+            out[f"{tag}__W"] = W
+            out[f"{tag}__U"] = U
+            out[f"{tag}__ys"] = ys.numpy()
+            out[f"{tag}__param_checksum"] = np.float64(param_checksum(sde))
+        np.savez_compressed(os.path.join(HERE, f"adaptive_{name[len('adaptive_'):]}.npz"), **out)
+        print(f"adaptive_{name[len('adaptive_'):]}.npz  distinct queries={len(keys)}")
+
+
 # -------------------------------------------------------------------------------------------------- adjoint
 ADJOINT_CASES = [
     # name, problem, method, adjoint_method, levy, (B, d, m), ts, dt
@@ -281,7 +344,7 @@ def gen_brownian_seq():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["timegrid", "solver", "adjoint", "bridge", "brownian_seq"]
+    which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

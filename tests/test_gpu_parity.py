@@ -274,3 +274,34 @@ def test_logqp_and_names():
     assert ys.shape == (3, 16, 4) and logqp.shape == (2, 16)
     # u = (f - h)/g = (1 - theta) y / 0.3 ; the KL integrand is 0.5 |u|^2 >= 0
     assert (logqp >= 0).all() and torch.isfinite(ys).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 5. Adaptive stepping (step doubling on the virtual bridge tree) vs the oracle's restatement of the reference's
+#    adaptive loop driven by the C twin of the generator.
+@pytest.mark.parametrize("prob,method,levy", [("gbm_ito", "milstein", "none"), ("gbm_ito", "srk", "space-time"),
+                                              ("gbm_strat", "midpoint", "none")])
+def test_adaptive_matches_oracle(prob, method, levy):
+    import torchsde_amd
+    B, d = 16, 4
+    dtype = torch.float64
+    ts = torch.tensor([0.0, 0.4, 1.0], dtype=dtype, device=DEV)
+    sde = problems.make(prob, dtype=dtype, d=d).to(DEV)
+    y0 = torch.full((B, d), 0.1, dtype=dtype, device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, d), dtype=dtype, device=DEV, entropy=2718,
+                                       levy_area_approximation=levy)
+    with torch.no_grad():
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.1, adaptive=True, rtol=1e-3, atol=1e-3)
+
+    def bm_cpu(ta, tb, return_U=False):
+        W, U, _ = counter.query(B * d, 2718, [0.0, 1.0], float(ta), float(tb), dtype=np.float64,
+                                have_h=(levy != "none"))
+        W = torch.from_numpy(W).reshape(B, d)
+        return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+    queries = []
+    with torch.no_grad():
+        ref = solvers_ref.integrate(sde.cpu(), bm_cpu, y0.cpu(), ts.cpu(), 0.1, method, record=queries, adaptive=True,
+                                    rtol=1e-3, atol=1e-3)
+    assert len(queries) > 10      # the controller actually adapted
+    torch.testing.assert_close(ys.cpu(), ref, rtol=1e-7, atol=1e-9)

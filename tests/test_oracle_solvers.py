@@ -21,3 +21,21 @@ def test_oracle_matches_reference(name, tag):
         torch.testing.assert_close(ys, case.ys, rtol=2e-6 if tag == "f32" else 1e-13, atol=1e-7 if tag == "f32" else 1e-15)
     else:
         assert torch.equal(ys, case.ys), f"max diff {(ys - case.ys).abs().max().item():.3e}"
+
+
+def _adaptive_cases():
+    import os
+    return sorted(f[len("adaptive_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("adaptive_"))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("name", _adaptive_cases())
+def test_oracle_adaptive_matches_reference(name, tag):
+    """Step-doubling adaptive stepping: same accepted steps and same outputs as the real reference when fed the
+    increments the reference's own BrownianInterval produced (recorded per queried interval)."""
+    case = helpers.Case(name, tag, prefix="adaptive_")
+    bm = solvers_ref.ReplayBrownian(case.table())
+    with torch.no_grad():
+        ys = solvers_ref.integrate(case.sde(), bm, case.y0(), case.ts, case.dt, case.method, adaptive=True,
+                                   rtol=float(case.z["rtol"]), atol=float(case.z["atol"]))
+    torch.testing.assert_close(ys, case.ys, rtol=0, atol=0)

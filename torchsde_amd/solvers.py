@@ -33,6 +33,35 @@ class _Step:
         self.h64 = h64       # float(t1) - float(t0) in double (what the Brownian motion sees)
 
 
+def _error_estimate(y_full, y_half, rtol, atol, eps=1e-7):
+    """Scaled RMS difference between one full step and two half steps (adaptive_stepping.py:42-76)."""
+    tol = (rtol * torch.max(y_full.abs(), y_half.abs()) + atol).clamp_min(eps)
+    ratio = (y_full - y_half) / tol
+    err = torch.sqrt((ratio ** 2.).sum() / ratio.numel()).clamp_min(eps)
+    value = err.item()   # the one host sync of an adaptive step
+    if value != value:
+        raise AssertionError("Found nans in the error estimate. Try increasing the tolerance or regularizing the "
+                             "dynamics.")
+    return value
+
+
+def _update_step_size(error_estimate, prev_step_size, prev_error_ratio, safety=0.9, facmin=0.2, facmax=1.4):
+    """PI controller proposing the next step size (adaptive_stepping.py:21-39)."""
+    if error_estimate > 1:
+        pfactor, ifactor = 0, 1 / 1.5
+    else:
+        pfactor, ifactor = 0.13, 1 / 4.5
+    error_ratio = safety / error_estimate
+    if prev_error_ratio is None:
+        prev_error_ratio = error_ratio
+    factor = error_ratio ** ifactor * (error_ratio / prev_error_ratio) ** pfactor
+    if error_estimate <= 1:
+        prev_error_ratio = error_ratio
+        facmin = 1.0
+    factor = min(facmax, max(facmin, factor))
+    return prev_step_size * factor, prev_error_ratio
+
+
 class BaseSDESolver:
     strong_order = None
     weak_order = None
@@ -119,13 +148,49 @@ class BaseSDESolver:
     # ---- the fixed-step driver -------------------------------------------------------------------------
     def integrate(self, y0, ts, extra0):
         if self.adaptive:
-            raise NotImplementedError(
-                "torchsde_amd: adaptive step-size control is outside the MI355X hot path built so far "
-                "(SURVEY.md section 8(f), rank 2). Use `adaptive=False`.")
+            return self._integrate_adaptive(y0, ts, extra0)
         if self.options.get("hip_graph", False) and not self._tracks_grad(y0):
             from . import graph
             return graph.replay_or_capture(self, y0, ts), ()
         return self._run(self._plan(y0, ts), y0), ()
+
+    def _integrate_adaptive(self, y0, ts, extra0):
+        """Step-doubling adaptive stepping (reference: base_solver.py:114-149 adaptive branch +
+        adaptive_stepping.py:21-76): one full step vs two half steps on the SAME Brownian path (the virtual bridge
+        tree serves the half-interval queries), PI step-size controller, accept when the scaled RMS error <= 1.
+        The accept/reject decision is data dependent, so this path synchronises once per attempted step; the
+        state updates themselves are the same HIP kernels as the fixed-step path."""
+        import warnings
+        np_dtype = timegrid._NP[ts.dtype]
+        ts_host = timegrid.ts_to_host(ts)
+        t_end = ts_host[-1]
+        step_size = self.dt if not torch.is_tensor(self.dt) else float(self.dt)
+        prev_t = curr_t = ts_host[0]
+        prev_y = curr_y = y0
+        ys = [y0]
+        prev_error_ratio = None
+        for out_t in ts_host[1:]:
+            while curr_t < out_t:
+                nxt = curr_t + np_dtype(step_size)
+                next_t = nxt if nxt <= t_end else t_end
+                midpoint_t = np_dtype(0.5) * (curr_t + next_t)
+                y_full, _ = self.step(curr_t, next_t, curr_y, ())
+                y_mid, _ = self.step(curr_t, midpoint_t, curr_y, ())
+                y_next, _ = self.step(midpoint_t, next_t, y_mid, ())
+                with torch.no_grad():
+                    error_estimate = _error_estimate(y_full, y_next, self.rtol, self.atol)
+                    step_size, prev_error_ratio = _update_step_size(error_estimate, step_size, prev_error_ratio)
+                if step_size < self.dt_min:
+                    warnings.warn("Hitting minimum allowed step size in adaptive time-stepping.")
+                    step_size = self.dt_min
+                    prev_error_ratio = None
+                if error_estimate <= 1 or step_size <= self.dt_min:
+                    prev_t, prev_y = curr_t, curr_y
+                    curr_t, curr_y = next_t, y_next
+            w0 = (curr_t - out_t) / (curr_t - prev_t)
+            w1 = (out_t - prev_t) / (curr_t - prev_t)
+            ys.append(K.linear_interp(prev_y, curr_y, float(w0), float(w1)))
+        return torch.stack(ys, dim=0), ()
 
     def _tracks_grad(self, y0):
         return torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
