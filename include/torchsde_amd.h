@@ -13,6 +13,7 @@
  *   tsde_milstein_*      _core/methods/milstein.py:52-94 (+ base_sde.py:142-158)
  *   tsde_srk_diag_stage  _core/methods/srk.py:57-88 + tableaus/srid2.py
  *   tsde_step_general_w  _core/methods/srk.py:90-111 + tableaus/sra1.py (SRK for additive noise)
+ *   tsde_rheun_*         _core/methods/reversible_heun.py:48-144 (reversible Heun and its adjoint)
  *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
  *   tsde_linear_interp   _core/interp.py:15-18
  *
@@ -143,6 +144,25 @@ int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const
                         const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
                         const tsde_noise_t* noise, int dtype, void* stream);
 
+/* ---- reversible Heun (Stratonovich) and its exact-gradient adjoint: _core/methods/reversible_heun.py ---- */
+
+/* z1 = ((2*y0 - z0) + sign*(f0*dt)) + sign*(g0*dW)    :69 forward (sign=+1), :109 reconstruction (sign=-1) */
+int tsde_rheun_z_diag(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
+                      double sign, const tsde_noise_t* noise, int dtype, void* stream);
+/* y1 = (y0 + sign*((f0+f1)*half_dt)) + sign*((g0+g1)*(0.5*dW))    :71 forward, :130-131 reconstruction */
+int tsde_rheun_y_diag(void* y1, const void* y0, const void* f0, const void* f1, const void* g0, const void* g1,
+                      int64_t n, double half_dt, double sign, const tsde_noise_t* noise, int dtype, void* stream);
+/* out = a*x + b*y   (2*y0 - z0, f0 + f1, g0 + g1 for the general-noise variants, which then use tsde_step_general_w) */
+int tsde_lincomb2(void* out, const void* x, const void* y, int64_t n, double a, double b, int dtype, void* stream);
+/* adjoint step, diagonal noise, before the VJP (:106-117):  af0' = af0 + ay*half_dt ; ag0' = ag0 + ay*(0.5*dW) */
+int tsde_rheun_adj_a_diag(void* af0_out, void* ag0_out, const void* ay, const void* af0, const void* ag0, int64_t n,
+                          double half_dt, const tsde_noise_t* noise, int dtype, void* stream);
+/* adjoint step, diagonal noise, after the VJP (:127,134-137):  az0' = az0 + vjp_z ; ay1 = ay + 2*az0' ; az1 = -az0' ;
+ * af1 = ay*half_dt + az0'*dt ; ag1 = ay*(0.5*dW) + az0'*dW */
+int tsde_rheun_adj_b_diag(void* ay1, void* az1, void* af1, void* ag1, const void* ay, const void* az0,
+                          const void* vjp_z, int64_t n, double dt, double half_dt, const tsde_noise_t* noise, int dtype,
+                          void* stream);
+
 /* ---- adjoint, output ------------------------------------------------------------------------ */
 
 /* For each segment: out = ((s + sF*(F*cF)) + sG*(cG*G)) + sD*D   (absent terms skipped). */
@@ -159,6 +179,7 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
 #define TSDE_KID_SRK_STAGE 4
 #define TSDE_KID_AUG_UPDATE 5
 #define TSDE_KID_BROWNIAN_QUERY 6
+#define TSDE_KID_RHEUN 7
 /* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
 int tsde_prof_begin(int kid, int capacity);
 /* Occupies `stream` with a single-thread kernel for about `microseconds` (<= 2 s). bench.py queues one before

@@ -232,3 +232,31 @@ class ReplayBrownian:
     def __call__(self, ta, tb, return_U=False):
         W, U = self.table[(float(ta), float(tb))]
         return (W, U) if return_U else W
+
+
+# ---- reversible Heun (carries extra state) ------------------------------------------------------------------
+def reversible_heun_step(sde, bm, t0, t1, y0, extra0):
+    """methods/reversible_heun.py:61-73."""
+    f0, g0, z0 = extra0
+    dt = t1 - t0
+    dW = bm(t0, t1)
+    z1 = 2 * y0 - z0 + f0 * dt + prod(sde, g0, dW)
+    f1, g1 = f_and_g(sde, t1, z1)
+    y1 = y0 + (f0 + f1) * (0.5 * dt) + prod(sde, g0 + g1, 0.5 * dW)
+    return y1, (f1, g1, z1)
+
+
+def integrate_reversible_heun(sde, bm, y0, ts, dt):
+    """base_solver.py:92-116,143-149 with the solver's extra state threaded through (reversible_heun.py:58-59)."""
+    extra = tuple(f_and_g(sde, ts[0], y0)) + (y0,)
+    prev_t = curr_t = ts[0]
+    prev_y = curr_y = y0
+    ys = [y0]
+    for out_t in ts[1:]:
+        while curr_t < out_t:
+            next_t = min(curr_t + dt, ts[-1])
+            prev_t, prev_y = curr_t, curr_y
+            curr_y, extra = reversible_heun_step(sde, bm, curr_t, next_t, curr_y, extra)
+            curr_t = next_t
+        ys.append((curr_t - out_t) / (curr_t - prev_t) * prev_y + (out_t - prev_t) / (curr_t - prev_t) * curr_y)
+    return torch.stack(ys, dim=0), extra

@@ -126,6 +126,10 @@ SOLVER_CASES = [
     ("midpoint_scalar", "scalar_strat", "midpoint", None, "none", (5, 4, 1), [0., 0.5], 0.05),
     ("midpoint_additive", "additive_strat", "midpoint", None, "none", (5, 4, 3), [0., 0.5], 0.05),
     ("midpoint_general", "general_strat", "midpoint", None, "none", (6, 4, 4), [0., 0.5], 0.05),
+    ("rheun_gbm", "gbm_strat", "reversible_heun", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("rheun_scalar", "scalar_strat", "reversible_heun", None, "none", (5, 4, 1), [0., 0.5], 0.05),
+    ("rheun_additive", "additive_strat", "reversible_heun", None, "none", (5, 4, 3), [0., 0.5], 0.05),
+    ("rheun_general", "general_strat", "reversible_heun", None, "none", (6, 4, 4), [0., 0.5], 0.05),
 ]
 
 
@@ -229,6 +233,10 @@ ADJOINT_CASES = [
     ("scalar_ito_euler", "scalar_ito", "euler", None, "none", (5, 4, 1), [0., 1.0], 2.0 ** -4),
     ("additive_ito_euler", "additive_ito", "euler", None, "none", (5, 4, 3), [0., 1.0], 2.0 ** -4),
     ("gbm_ito_nondyadic", "gbm_ito", "euler", "euler", "none", (5, 4, 4), [0., 0.35, 0.9], 0.1),
+    ("gbm_strat_rheun", "gbm_strat", "reversible_heun", None, "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("mlpdiag_strat_rheun", "mlpdiag_strat", "reversible_heun", None, "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("general_strat_rheun", "general_strat", "reversible_heun", None, "none", (6, 4, 4), [0., 1.0], 2.0 ** -4),
+    ("scalar_strat_rheun", "scalar_strat", "reversible_heun", None, "none", (5, 4, 1), [0., 1.0], 2.0 ** -4),
 ]
 
 

@@ -103,3 +103,33 @@ def test_adjoint_close_to_backprop_through_solver(prob, method):
     for p, q in zip(gp_a, gp_b):
         scale = max(1.0, q.abs().max().item())
         assert ((p - q).abs().max() / scale).item() < 5e-2
+
+
+@pytest.mark.parametrize("prob,shape", [("gbm_strat", (32, 8, 8)), ("general_strat", (32, 4, 4))])
+def test_reversible_heun_is_reversible(prob, shape):
+    """Solving forwards and then backwards in time with the carried (f, g, z) state reproduces the trajectory
+    (reference tests/test_sdeint.py:219-252 `test_reversibility`, tolerance 1e-6)."""
+    import torchsde_amd
+    B, d, m = shape
+    dtype = torch.float64
+    steps, dt = 16, 2.0 ** -5
+    ts = torch.linspace(0, steps * dt, 5, dtype=dtype, device=DEV)
+    sde = problems.make(prob, dtype=dtype, d=d, m=m).to(DEV)
+    y0 = torch.full((B, d), 0.1, dtype=dtype, device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, m), dtype=dtype, device=DEV, entropy=13, dt=dt)
+    with torch.no_grad():
+        ys, (f, g, z) = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="reversible_heun", dt=dt, extra=True)
+
+        class NegatedTime(torch.nn.Module):       # the same SDE run backwards: t -> -t, drift and diffusion negated
+            noise_type, sde_type = sde.noise_type, sde.sde_type
+
+            def f(self, t, y):
+                return -sde.f(-t, y)
+
+            def g(self, t, y):
+                return -sde.g(-t, y)
+
+        rev_bm = torchsde_amd.ReverseBrownian(bm)
+        back = torchsde_amd.sdeint(NegatedTime(), ys[-1], -ts.flip(0), bm=rev_bm, method="reversible_heun", dt=dt,
+                                   extra_solver_state=(-f, -g, z))
+    torch.testing.assert_close(back.flip(0), ys, rtol=1e-6, atol=1e-6)

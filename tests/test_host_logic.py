@@ -146,7 +146,8 @@ def test_solver_compatibility_errors():
     with pytest.raises(ValueError, match="does not match any known method"):
         solvers.select("rk4", "ito")
     with pytest.raises(NotImplementedError):
-        solvers.select("reversible_heun", "stratonovich")
+        solvers.select("heun", "stratonovich")
+    assert solvers.select("reversible_heun", "stratonovich") is solvers.ReversibleHeun
 
 
 def test_unknown_kwargs_warn():

@@ -67,6 +67,15 @@ SIGNATURES = {
                                        ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_srk_diag_stage": (_c_int, [_c_int, _c_ptr, _c_ptr, _c_ptr, _PTR4, _PTR4, _c_i64, _c_dbl, _c_dbl, _c_dbl,
                                      ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_rheun_z_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl,
+                                   ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_rheun_y_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl,
+                                   ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_lincomb2": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
+    "tsde_rheun_adj_a_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl,
+                                       ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_rheun_adj_b_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl,
+                                       ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_aug_update": (_c_int, [ctypes.POINTER(Seg), _c_int, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_linear_interp": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),

@@ -234,6 +234,10 @@ def _update(dst, src, F, G, D, cF, cG):
 
 def _check_adjoint_method(adjoint_sde, adjoint_method, adjoint_options, bm):
     """The compatibility errors the reference raises when it builds the backward solver (adjoint.py:83-93)."""
+    if adjoint_method == METHODS.adjoint_reversible_heun:
+        if adjoint_sde.sde_type != SDE_TYPES.stratonovich:
+            raise ValueError(f"SDE is of type {adjoint_sde.sde_type} but solver is for type {SDE_TYPES.stratonovich}")
+        return _ReversibleHeunBackward
     cls = solvers.select(adjoint_method, adjoint_sde.sde_type)
     if cls is solvers.SRK:
         raise ValueError("Stochastic Runge–Kutta methods cannot be used for adjoint SDEs, because it requires "
@@ -255,6 +259,93 @@ def _check_adjoint_method(adjoint_sde, adjoint_method, adjoint_options, bm):
     return cls
 
 
+class _ReversibleHeunBackward:
+    """Marker returned by `_check_adjoint_method` for METHODS.adjoint_reversible_heun."""
+
+
+def _reversible_heun_backward(ctx, ys, ts, forward_extras, adjoint_params, grad_ys, grad_extras):
+    """Exact-gradient backward pass of reversible Heun (reference: methods/reversible_heun.py:98-144 driven by
+    adjoint.py:64-127): reconstruct (y, f, g, z) algebraically step by step while propagating
+    (a_y, a_f, a_g, a_z, a_theta); one VJP through f_and_g per step. Diagonal noise runs entirely on fused HIP
+    kernels (tsde_rheun_*); other noise types use the contraction kernel for the state and torch ops for the
+    (B, d, m) outer products of the adjoint."""
+    sde, bm, dt = ctx.sde, ctx.bm, ctx.dt
+    _check_adjoint_method(AdjointSDE(sde, adjoint_params), ctx.adjoint_method, ctx.adjoint_options, bm)
+    diag = sde.noise_type == NOISE_TYPES.diagonal
+    device = ys.device
+    native = bm if isinstance(bm, BrownianInterval) else None
+    reverse_bm = None if native is not None else ReverseBrownian(bm)
+    params = list(adjoint_params)
+    ts_host = timegrid.ts_to_host(ts)
+    T = ys.size(0)
+    y = ys[-1]
+    f, g, z = forward_extras
+    a_y = grad_ys[-1].contiguous().clone()
+    a_f, a_g, a_z = [torch.zeros_like(x) if gr is None else gr.contiguous().clone()
+                     for gr, x in zip(grad_extras, forward_extras)]
+    a_theta = [torch.zeros_like(p) for p in params]
+
+    for i in range(T - 1, 0, -1):
+        grid = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)
+        n = grid.n_steps
+        np_dtype = grid.t.dtype.type
+        tau64 = grid.t_f64()
+        fwd_times = torch.from_numpy((-grid.t).astype(grid.t.dtype)).to(device).unbind(0)   # forward time = -tau
+        tau_dev = None
+        cells = None
+        if native is not None:
+            cells = native.match_grid(-tau64[::-1]) if native.frozen else None
+        else:
+            tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
+        for k in range(n):
+            step_dt = grid.dt[k]
+            half_dt = np_dtype(0.5) * step_dt
+            if native is not None:
+                if cells is not None:
+                    c = int(cells[n - 1 - k])
+                    noise = NoiseSpec.generated(native, c, native.cell_width(c))
+                else:
+                    W, _ = native.increment(-tau64[k + 1], -tau64[k])
+                    noise = NoiseSpec.external(W)
+            else:
+                noise = NoiseSpec.external(reverse_bm(tau_dev[k], tau_dev[k + 1]))
+            if diag:
+                a_f0, a_g0 = K.rheun_adj_a(a_y, a_f, a_g, half_dt, noise)
+                z1 = K.rheun_z(y, z, f, g, step_dt, -1.0, noise)
+            else:
+                dW, _ = noise.materialise()
+                half_dW = 0.5 * dW
+                a_y_half_dW = a_y.unsqueeze(-1) * half_dW.unsqueeze(-2)
+                a_f0 = a_f + a_y * half_dt
+                a_g0 = a_g + a_y_half_dW
+                z1 = K.step_general_weighted(K.lincomb2(y, z, 2.0, -1.0), f, g, -1.0, step_dt, -1.0, 0, 0.0, 0.0, 0.0,
+                                             noise)
+            z_leaf = z.detach().requires_grad_(True)
+            with torch.enable_grad():
+                re_f, re_g = sde.f_and_g(fwd_times[k], z_leaf)
+                vjp_z, *vjp_theta = vjp((re_f, re_g), [z_leaf] + params, grad_outputs=[a_f0, a_g0],
+                                        allow_unused=True)
+            for acc, v in zip(a_theta, vjp_theta):
+                acc.add_(v)
+            f1, g1 = sde.f_and_g(fwd_times[k + 1], z1)
+            if diag:
+                y1 = K.rheun_y(y, f, f1, g, g1, half_dt, -1.0, noise)
+                a_y, a_z, a_f, a_g = K.rheun_adj_b(a_y, a_z, vjp_z, step_dt, half_dt, noise)
+            else:
+                y1 = K.step_general_weighted(y, K.lincomb2(f, f1, 1.0, 1.0), K.lincomb2(g, g1, 1.0, 1.0), -1.0,
+                                             half_dt, -0.5, 0, 0.0, 0.0, 0.0, noise)
+                zz = a_z + vjp_z
+                a_f = a_y * half_dt + zz * step_dt
+                a_g = a_y_half_dW + zz.unsqueeze(-1) * dW.unsqueeze(-2)
+                a_y = a_y + 2 * zz
+                a_z = -zz
+            y, f, g, z = y1, f1, g1, z1
+        # adjoint.py:114-116
+        y = ys[i - 1]
+        a_y = a_y + grad_ys[i - 1]
+    return (None,) * 13 + (a_y, a_f, a_g, a_z) + tuple(a_theta)
+
+
 class _SdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
@@ -269,14 +360,23 @@ class _SdeintAdjointMethod(torch.autograd.Function):
         y0 = y0.detach()
         extra_solver_state = tuple(x.detach() for x in extra_solver_state)
         ys, extra_solver_state = solver.integrate(y0, ts, extra_solver_state)
-        ctx.save_for_backward(ys, ts, *adjoint_params)
+        # only the reversible pair reuses the solver's final (f, g, z) in the backward pass (adjoint.py:54-60)
+        ctx.saved_extras_for_backward = (method == METHODS.reversible_heun and
+                                         adjoint_method == METHODS.adjoint_reversible_heun)
+        extras_for_backward = tuple(extra_solver_state) if ctx.saved_extras_for_backward else ()
+        ctx.save_for_backward(ys, ts, *extras_for_backward, *adjoint_params)
         return (ys, *extra_solver_state)
 
     @staticmethod
     def backward(ctx, grad_ys, *grad_extra_solver_state):
         if torch.is_grad_enabled():
             raise NotImplementedError("torchsde_amd: double backward through sdeint_adjoint is not supported.")
-        ys, ts, *adjoint_params = ctx.saved_tensors
+        ys, ts, *rest = ctx.saved_tensors
+        if ctx.saved_extras_for_backward:
+            forward_extras, adjoint_params = rest[:ctx.len_extras], rest[ctx.len_extras:]
+            return _reversible_heun_backward(ctx, ys, ts, forward_extras, adjoint_params, grad_ys,
+                                             grad_extra_solver_state)
+        adjoint_params = rest
         sde, bm, dt = ctx.sde, ctx.bm, ctx.dt
         adjoint_sde = AdjointSDE(sde, adjoint_params)
         method_cls = _check_adjoint_method(adjoint_sde, ctx.adjoint_method, ctx.adjoint_options, bm)
@@ -375,8 +475,16 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e
     if adjoint_adaptive:
         raise NotImplementedError("torchsde_amd: adaptive stepping of the adjoint is not part of the hot path built "
                                   "so far; use `adjoint_adaptive=False`.")
-    if method == METHODS.reversible_heun and adjoint_method != METHODS.adjoint_reversible_heun:
-        warnings.warn(f"method={repr(method)}, but adjoint_method!={repr(METHODS.adjoint_reversible_heun)}.")
+    if method == METHODS.reversible_heun:   # adjoint.py:243-257
+        if adjoint_method != METHODS.adjoint_reversible_heun:
+            warnings.warn(f"method={repr(method)}, but adjoint_method!={repr(METHODS.adjoint_reversible_heun)}.")
+        num_steps = (ts - ts[0]) / dt
+        if not torch.allclose(num_steps, num_steps.round()):
+            warnings.warn(f"The spacing between time points `ts` is not an integer multiple of the time step `dt`. "
+                          f"This means that the backward pass (which is forced to step to each of `ts` to get "
+                          f"dL/dy(t) for t in ts) will not perfectly mimick the forward pass (which does not step "
+                          f"to each `ts`, and instead interpolates to them). This means that "
+                          f"method={repr(method)} may not be perfectly accurate.")
 
     solver_cls = solvers.select(method=method, sde_type=sde.sde_type)
     solver = solver_cls(sde=sde, bm=bm, dt=dt, adaptive=adaptive, rtol=rtol, atol=atol, dt_min=dt_min,

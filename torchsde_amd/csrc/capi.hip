@@ -217,6 +217,52 @@ int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const
                 tsde::launch_srk_stage<double>(stage, out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, noise, s));
 }
 
+int tsde_rheun_z_diag(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
+                      double sign, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!z1 || !y0 || !z0 || !f0 || !g0 || !noise) return bad_arg("tsde_rheun_z_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_RHEUN, s);
+  TSDE_DISPATCH(dtype, "tsde_rheun_z_diag", tsde::launch_rheun_z<float>(z1, y0, z0, f0, g0, n, dt, sign, noise, s),
+                tsde::launch_rheun_z<double>(z1, y0, z0, f0, g0, n, dt, sign, noise, s));
+}
+
+int tsde_rheun_y_diag(void* y1, const void* y0, const void* f0, const void* f1, const void* g0, const void* g1,
+                      int64_t n, double half_dt, double sign, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y1 || !y0 || !f0 || !f1 || !g0 || !g1 || !noise) return bad_arg("tsde_rheun_y_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_RHEUN, s);
+  TSDE_DISPATCH(dtype, "tsde_rheun_y_diag",
+                tsde::launch_rheun_y<float>(y1, y0, f0, f1, g0, g1, n, half_dt, sign, noise, s),
+                tsde::launch_rheun_y<double>(y1, y0, f0, f1, g0, g1, n, half_dt, sign, noise, s));
+}
+
+int tsde_lincomb2(void* out, const void* x, const void* y, int64_t n, double a, double b, int dtype, void* stream) {
+  if (!out || !x || !y) return bad_arg("tsde_lincomb2", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_lincomb2", tsde::launch_lincomb2<float>(out, x, y, n, a, b, s),
+                tsde::launch_lincomb2<double>(out, x, y, n, a, b, s));
+}
+
+int tsde_rheun_adj_a_diag(void* af0_out, void* ag0_out, const void* ay, const void* af0, const void* ag0, int64_t n,
+                          double half_dt, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!af0_out || !ag0_out || !ay || !af0 || !ag0 || !noise) return bad_arg("tsde_rheun_adj_a_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_rheun_adj_a_diag",
+                tsde::launch_rheun_adj_a<float>(af0_out, ag0_out, ay, af0, ag0, n, half_dt, noise, s),
+                tsde::launch_rheun_adj_a<double>(af0_out, ag0_out, ay, af0, ag0, n, half_dt, noise, s));
+}
+
+int tsde_rheun_adj_b_diag(void* ay1, void* az1, void* af1, void* ag1, const void* ay, const void* az0,
+                          const void* vjp_z, int64_t n, double dt, double half_dt, const tsde_noise_t* noise, int dtype,
+                          void* stream) {
+  if (!ay1 || !az1 || !af1 || !ag1 || !ay || !az0 || !vjp_z || !noise)
+    return bad_arg("tsde_rheun_adj_b_diag", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_rheun_adj_b_diag",
+                tsde::launch_rheun_adj_b<float>(ay1, az1, af1, ag1, ay, az0, vjp_z, n, dt, half_dt, noise, s),
+                tsde::launch_rheun_adj_b<double>(ay1, az1, af1, ag1, ay, az0, vjp_z, n, dt, half_dt, noise, s));
+}
+
 int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int dtype, void* stream) {
   if (!segs || nseg < 0) return bad_arg("tsde_aug_update", "bad segment list");
   if (dtype != TSDE_F32 && dtype != TSDE_F64) return bad_arg("tsde_aug_update", "dtype");

@@ -1,0 +1,197 @@
+// Reversible Heun (Stratonovich, arXiv:2105.13493) and its exact-gradient adjoint: fused elementwise kernels.
+// Reference: torchsde/_core/methods/reversible_heun.py:48-73 (forward step), :98-144 (adjoint step).
+// Same conventions as steps.hip: reference operation order, one rounding per op, increment generated in
+// registers from the step's grid cell (or read from memory for foreign Brownian objects).
+#include "tsde_common.h"
+#include "tsde_launch.h"
+
+namespace tsde {
+
+template <typename T>
+static CellNoise<T> rh_noise(const tsde_noise_t* nz) {
+  CellNoise<T> c;
+  c.dW = (const T*)nz->dW;
+  c.dU = (const T*)nz->dU;
+  c.key.k0 = (uint32_t)nz->entropy;
+  c.key.k1 = (uint32_t)(nz->entropy >> 32);
+  c.key.elem0 = nz->elem0;
+  c.cell = nz->cell;
+  c.h = nz->h;
+  c.bcast_d = nz->bcast_d;
+  c.key_dev = nz->entropy_dev;
+  return c;
+}
+
+static bool rh_noise_vec(const tsde_noise_t* nz) {
+  if (nz->dW == nullptr) return (nz->elem0 % 4) == 0;
+  if (nz->bcast_d > 0) return (nz->bcast_d % 4) == 0;
+  return aligned16(nz->dW);
+}
+
+// z1 = ((2*y0 - z0) + s*(f0*dt)) + s*(g0*dW)      reversible_heun.py:69 (s=+1), :109 (s=-1)
+template <typename T>
+struct RheunZOp {
+  T* z1;
+  const T *y0, *z0, *f0, *g0;
+  T dt, sgn;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> y = load<T, W>(y0, i), z = load<T, W>(z0, i), f = load<T, W>(f0, i), g = load<T, W>(g0, i);
+    Pack<T, W> w, u, o;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) o.v[j] = ((((T)2 * y.v[j]) - z.v[j]) + sgn * (f.v[j] * dt)) + sgn * (g.v[j] * w.v[j]);
+    store<T, W>(z1, i, o);
+  }
+};
+
+// y1 = (y0 + s*((f0+f1)*half_dt)) + s*((g0+g1)*(0.5*dW))     reversible_heun.py:71 (s=+1), :130-131 (s=-1)
+template <typename T>
+struct RheunYOp {
+  T* y1;
+  const T *y0, *f0, *f1, *g0, *g1;
+  T half_dt, sgn;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> y = load<T, W>(y0, i), a = load<T, W>(f0, i), b = load<T, W>(f1, i), c = load<T, W>(g0, i),
+                     d = load<T, W>(g1, i);
+    Pack<T, W> w, u, o;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const T drift = (a.v[j] + b.v[j]) * half_dt;
+      const T diff = (c.v[j] + d.v[j]) * ((T)0.5 * w.v[j]);
+      o.v[j] = (y.v[j] + sgn * drift) + sgn * diff;
+    }
+    store<T, W>(y1, i, o);
+  }
+};
+
+// out = a*x + b*y
+template <typename T>
+struct Lincomb2Op {
+  T* out;
+  const T *x, *y;
+  T a, b;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> p = load<T, W>(x, i), q = load<T, W>(y, i);
+    Pack<T, W> o;
+#pragma unroll
+    for (int j = 0; j < W; ++j) o.v[j] = a * p.v[j] + b * q.v[j];
+    store<T, W>(out, i, o);
+  }
+};
+
+// adjoint stage A (diagonal noise): af0' = af0 + ay*half_dt ; ag0' = ag0 + ay*(0.5*dW)     :106-117
+template <typename T>
+struct RheunAdjAOp {
+  T *af0_out, *ag0_out;
+  const T *ay, *af0, *ag0;
+  T half_dt;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(ay, i), f = load<T, W>(af0, i), g = load<T, W>(ag0, i);
+    Pack<T, W> w, u, of, og;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      of.v[j] = f.v[j] + a.v[j] * half_dt;
+      og.v[j] = g.v[j] + a.v[j] * ((T)0.5 * w.v[j]);
+    }
+    store<T, W>(af0_out, i, of);
+    store<T, W>(ag0_out, i, og);
+  }
+};
+
+// adjoint stage B (diagonal noise), after the VJP through f_and_g(z0):                       :127,134-137
+//   az0' = az0 + vjp_z ; ay1 = ay + 2*az0' ; az1 = -az0' ; af1 = ay*half_dt + az0'*dt ; ag1 = ay*(0.5*dW) + az0'*dW
+template <typename T>
+struct RheunAdjBOp {
+  T *ay1, *az1, *af1, *ag1;
+  const T *ay, *az0, *vjp_z;
+  T dt, half_dt;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> a = load<T, W>(ay, i), z = load<T, W>(az0, i), v = load<T, W>(vjp_z, i);
+    Pack<T, W> w, u, oy, oz, of, og;
+    cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const T zz = z.v[j] + v.v[j];
+      oy.v[j] = a.v[j] + (T)2 * zz;
+      oz.v[j] = -zz;
+      of.v[j] = a.v[j] * half_dt + zz * dt;
+      og.v[j] = a.v[j] * ((T)0.5 * w.v[j]) + zz * w.v[j];
+    }
+    store<T, W>(ay1, i, oy);
+    store<T, W>(az1, i, oz);
+    store<T, W>(af1, i, of);
+    store<T, W>(ag1, i, og);
+  }
+};
+
+template <typename T>
+hipError_t launch_rheun_z(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
+                          double sgn, const tsde_noise_t* nz, hipStream_t s) {
+  RheunZOp<T> op{(T*)z1, (const T*)y0, (const T*)z0, (const T*)f0, (const T*)g0, (T)dt, (T)sgn, rh_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(z1) && aligned16(y0) && aligned16(z0) && aligned16(f0) && aligned16(g0) &&
+                   rh_noise_vec(nz);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_rheun_y(void* y1, const void* y0, const void* f0, const void* f1, const void* g0, const void* g1,
+                          int64_t n, double half_dt, double sgn, const tsde_noise_t* nz, hipStream_t s) {
+  RheunYOp<T> op{(T*)y1,      (const T*)y0, (const T*)f0, (const T*)f1,   (const T*)g0,
+                 (const T*)g1, (T)half_dt,   (T)sgn,       rh_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f0) && aligned16(f1) && aligned16(g0) &&
+                   aligned16(g1) && rh_noise_vec(nz);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_lincomb2(void* out, const void* x, const void* y, int64_t n, double a, double b, hipStream_t s) {
+  Lincomb2Op<T> op{(T*)out, (const T*)x, (const T*)y, (T)a, (T)b};
+  const bool vec = (n % 4 == 0) && aligned16(out) && aligned16(x) && aligned16(y);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_rheun_adj_a(void* af0_out, void* ag0_out, const void* ay, const void* af0, const void* ag0, int64_t n,
+                              double half_dt, const tsde_noise_t* nz, hipStream_t s) {
+  RheunAdjAOp<T> op{(T*)af0_out, (T*)ag0_out, (const T*)ay, (const T*)af0, (const T*)ag0, (T)half_dt, rh_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(af0_out) && aligned16(ag0_out) && aligned16(ay) && aligned16(af0) &&
+                   aligned16(ag0) && rh_noise_vec(nz);
+  return launch_elementwise(op, n, vec, s);
+}
+
+template <typename T>
+hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const void* ay, const void* az0,
+                              const void* vjp_z, int64_t n, double dt, double half_dt, const tsde_noise_t* nz,
+                              hipStream_t s) {
+  RheunAdjBOp<T> op{(T*)ay1, (T*)az1, (T*)af1, (T*)ag1, (const T*)ay, (const T*)az0, (const T*)vjp_z,
+                    (T)dt,   (T)half_dt, rh_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(ay1) && aligned16(az1) && aligned16(af1) && aligned16(ag1) &&
+                   aligned16(ay) && aligned16(az0) && aligned16(vjp_z) && rh_noise_vec(nz);
+  return launch_elementwise(op, n, vec, s);
+}
+
+#define TSDE_RH_INSTANTIATE(T)                                                                                       \
+  template hipError_t launch_rheun_z<T>(void*, const void*, const void*, const void*, const void*, int64_t, double,  \
+                                        double, const tsde_noise_t*, hipStream_t);                                   \
+  template hipError_t launch_rheun_y<T>(void*, const void*, const void*, const void*, const void*, const void*,      \
+                                        int64_t, double, double, const tsde_noise_t*, hipStream_t);                  \
+  template hipError_t launch_lincomb2<T>(void*, const void*, const void*, int64_t, double, double, hipStream_t);     \
+  template hipError_t launch_rheun_adj_a<T>(void*, void*, const void*, const void*, const void*, int64_t, double,    \
+                                            const tsde_noise_t*, hipStream_t);                                       \
+  template hipError_t launch_rheun_adj_b<T>(void*, void*, void*, void*, const void*, const void*, const void*,       \
+                                            int64_t, double, double, const tsde_noise_t*, hipStream_t);
+TSDE_RH_INSTANTIATE(float)
+TSDE_RH_INSTANTIATE(double)
+
+}  // namespace tsde

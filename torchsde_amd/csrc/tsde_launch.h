@@ -58,3 +58,22 @@ template <typename T>
 hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s);
 
 }  // namespace tsde
+
+namespace tsde {
+// rheun.hip
+template <typename T>
+hipError_t launch_rheun_z(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
+                          double sgn, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_rheun_y(void* y1, const void* y0, const void* f0, const void* f1, const void* g0, const void* g1,
+                          int64_t n, double half_dt, double sgn, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_lincomb2(void* out, const void* x, const void* y, int64_t n, double a, double b, hipStream_t s);
+template <typename T>
+hipError_t launch_rheun_adj_a(void* af0_out, void* ag0_out, const void* ay, const void* af0, const void* ag0, int64_t n,
+                              double half_dt, const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
+hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const void* ay, const void* az0,
+                              const void* vjp_z, int64_t n, double dt, double half_dt, const tsde_noise_t* nz,
+                              hipStream_t s);
+}  // namespace tsde

@@ -216,8 +216,9 @@ def step_general(y0, f, g, cf, cg, noise, out=None):
 def step_general_weighted(y0, f, g, ca, cf, cg, weight_mode, cw, cu, rdt, noise, out=None):
     """y1 = (y0 + (ca*f)*cf) + cg*(g . w), w built from (W, U): the stages of SRK for additive noise (SRA1)."""
     if _needs_grad(y0, f, g):
-        raise NotImplementedError("torchsde_amd: back-propagating through the SRK solver is not supported; use "
-                                  "`method='milstein'`/'euler' or `sdeint_adjoint`.")
+        W, U = noise.materialise(need_U=weight_mode != 0)
+        w = W if weight_mode == 0 else ((cu * U) * rdt if weight_mode == 1 else (cw * W) + (cu * U) * rdt)
+        return (y0 + (ca * f) * cf) + cg * torch.bmm(g, w.unsqueeze(-1)).squeeze(-1)
     y0 = _native.contiguous(y0)
     f, = _prep(y0, f)
     if g.dtype != y0.dtype:
@@ -419,3 +420,80 @@ def prof_end():
     ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
     _native.check(_native.load().tsde_prof_end(ctypes.byref(ms), ctypes.byref(n)), "tsde_prof_end")
     return ms.value, n.value
+
+
+# ---- reversible Heun --------------------------------------------------------------------------------------
+def _noise_W(noise):
+    W, _ = noise.materialise()
+    return W.reshape(-1, 1) if noise.bcast_d else W
+
+
+def rheun_z(y0, z0, f0, g0, dt, sign, noise, out=None):
+    """z1 = ((2*y0 - z0) + sign*(f0*dt)) + sign*(g0*dW), diagonal noise (reversible_heun.py:69 / :109)."""
+    if _needs_grad(y0, z0, f0, g0):
+        return 2 * y0 - z0 + sign * (f0 * dt) + sign * (g0 * _noise_W(noise))
+    y0 = _native.contiguous(y0)
+    z0, f0, g0 = _prep(y0, z0, f0, g0)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_rheun_z_diag(out.data_ptr(), y0.data_ptr(), z0.data_ptr(), f0.data_ptr(), g0.data_ptr(),
+                                 y0.numel(), dt, sign, noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_rheun_z_diag")
+    return out
+
+
+def rheun_y(y0, f0, f1, g0, g1, half_dt, sign, noise, out=None):
+    """y1 = (y0 + sign*((f0+f1)*half_dt)) + sign*((g0+g1)*(0.5*dW)), diagonal noise (:71 / :130-131)."""
+    if _needs_grad(y0, f0, f1, g0, g1):
+        return y0 + sign * ((f0 + f1) * half_dt) + sign * ((g0 + g1) * (0.5 * _noise_W(noise)))
+    y0 = _native.contiguous(y0)
+    f0, f1, g0, g1 = _prep(y0, f0, f1, g0, g1)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_rheun_y_diag(out.data_ptr(), y0.data_ptr(), f0.data_ptr(), f1.data_ptr(), g0.data_ptr(),
+                                 g1.data_ptr(), y0.numel(), half_dt, sign, noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_rheun_y_diag")
+    return out
+
+
+def lincomb2(x, y, a, b, out=None):
+    """out = a*x + b*y."""
+    if _needs_grad(x, y):
+        return a * x + b * y
+    x = _native.contiguous(x)
+    y, = _prep(x, y)
+    out = _new_like(x, out)
+    lib, dt_code, stream = _launch_env(x)
+    code = lib.tsde_lincomb2(out.data_ptr(), x.data_ptr(), y.data_ptr(), x.numel(), a, b, dt_code, stream)
+    if code:
+        _native.check(code, "tsde_lincomb2")
+    return out
+
+
+def rheun_adj_a(ay, af0, ag0, half_dt, noise):
+    """(af0 + ay*half_dt, ag0 + ay*(0.5*dW)), diagonal noise (reversible_heun.py:106-117)."""
+    ay = _native.contiguous(ay)
+    af0, ag0 = _prep(ay, af0, ag0)
+    of, og = torch.empty_like(ay), torch.empty_like(ay)
+    lib, dt_code, stream = _launch_env(ay)
+    code = lib.tsde_rheun_adj_a_diag(of.data_ptr(), og.data_ptr(), ay.data_ptr(), af0.data_ptr(), ag0.data_ptr(),
+                                     ay.numel(), half_dt, noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_rheun_adj_a_diag")
+    return of, og
+
+
+def rheun_adj_b(ay, az0, vjp_z, dt, half_dt, noise):
+    """(ay1, az1, af1, ag1) after the VJP, diagonal noise (reversible_heun.py:127,134-137)."""
+    ay = _native.contiguous(ay)
+    az0, vjp_z = _prep(ay, az0, vjp_z)
+    outs = [torch.empty_like(ay) for _ in range(4)]
+    lib, dt_code, stream = _launch_env(ay)
+    code = lib.tsde_rheun_adj_b_diag(outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(),
+                                     ay.data_ptr(), az0.data_ptr(), vjp_z.data_ptr(), ay.numel(), dt, half_dt,
+                                     noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_rheun_adj_b_diag")
+    return outs

@@ -69,6 +69,7 @@ class BaseSDESolver:
     noise_types = ()
     levy_area_approximations = ()
     needs_U = False
+    stateful = False   # True for solvers that carry extra state between steps (reversible Heun: f, g, z)
     # host-side stage-time offsets as multiples of dt (times[j] = t0 + stage_fracs[j]*dt), t0 first
     stage_fracs = (0,)
 
@@ -127,7 +128,7 @@ class BaseSDESolver:
 
     # ---- public single-step API (the reference's solver seam) --------------------------------------
     def step(self, t0, t1, y0, extra0):
-        del extra0
+        self._extra = tuple(extra0) if extra0 is not None else ()
         np_dtype = timegrid._NP.get(y0.dtype if not torch.is_tensor(t0) else t0.dtype, np.float64)
         ta, tb = float(t0), float(t1)
         t0n, t1n = np_dtype(ta), np_dtype(tb)
@@ -141,18 +142,21 @@ class BaseSDESolver:
             cells = bm.match_grid(np.array([ta, tb]))
             cell = None if cells is None else int(cells[0])
         times = tuple(t0_t if frac == 0 else torch.tensor(t0n + np_dtype(frac) * dt, dtype=t0_t.dtype, device=dev)
-                      for frac in self.stage_fracs)
+                      for frac in self.stage_fracs) + (t1_t,)
         st = _Step(times, dt, self._noise_for(ta, tb, t0_t, t1_t, cell), tb - ta)
-        return self._advance(y0, st, None), ()
+        y1 = self._advance(y0, st, None)
+        return y1, self._extra
 
     # ---- the fixed-step driver -------------------------------------------------------------------------
     def integrate(self, y0, ts, extra0):
         if self.adaptive:
             return self._integrate_adaptive(y0, ts, extra0)
-        if self.options.get("hip_graph", False) and not self._tracks_grad(y0):
+        self._extra = tuple(extra0) if extra0 is not None else ()
+        if self.options.get("hip_graph", False) and not self._tracks_grad(y0) and not self.stateful:
             from . import graph
             return graph.replay_or_capture(self, y0, ts), ()
-        return self._run(self._plan(y0, ts), y0), ()
+        ys = self._run(self._plan(y0, ts), y0)
+        return ys, self._extra
 
     def _integrate_adaptive(self, y0, ts, extra0):
         """Step-doubling adaptive stepping (reference: base_solver.py:114-149 adaptive branch +
@@ -167,6 +171,7 @@ class BaseSDESolver:
         step_size = self.dt if not torch.is_tensor(self.dt) else float(self.dt)
         prev_t = curr_t = ts_host[0]
         prev_y = curr_y = y0
+        curr_extra = tuple(extra0) if extra0 is not None else ()
         ys = [y0]
         prev_error_ratio = None
         for out_t in ts_host[1:]:
@@ -174,9 +179,9 @@ class BaseSDESolver:
                 nxt = curr_t + np_dtype(step_size)
                 next_t = nxt if nxt <= t_end else t_end
                 midpoint_t = np_dtype(0.5) * (curr_t + next_t)
-                y_full, _ = self.step(curr_t, next_t, curr_y, ())
-                y_mid, _ = self.step(curr_t, midpoint_t, curr_y, ())
-                y_next, _ = self.step(midpoint_t, next_t, y_mid, ())
+                y_full, _ = self.step(curr_t, next_t, curr_y, curr_extra)
+                y_mid, mid_extra = self.step(curr_t, midpoint_t, curr_y, curr_extra)
+                y_next, next_extra = self.step(midpoint_t, next_t, y_mid, mid_extra)
                 with torch.no_grad():
                     error_estimate = _error_estimate(y_full, y_next, self.rtol, self.atol)
                     step_size, prev_error_ratio = _update_step_size(error_estimate, step_size, prev_error_ratio)
@@ -186,11 +191,11 @@ class BaseSDESolver:
                     prev_error_ratio = None
                 if error_estimate <= 1 or step_size <= self.dt_min:
                     prev_t, prev_y = curr_t, curr_y
-                    curr_t, curr_y = next_t, y_next
+                    curr_t, curr_y, curr_extra = next_t, y_next, next_extra
             w0 = (curr_t - out_t) / (curr_t - prev_t)
             w1 = (out_t - prev_t) / (curr_t - prev_t)
             ys.append(K.linear_interp(prev_y, curr_y, float(w0), float(w1)))
-        return torch.stack(ys, dim=0), ()
+        return torch.stack(ys, dim=0), curr_extra
 
     def _tracks_grad(self, y0):
         return torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
@@ -205,7 +210,8 @@ class BaseSDESolver:
         t64 = grid.t_f64()
         # times[k][j] = t_k + frac_j * dt_k, rounded like the reference's 0-d tensor arithmetic (`t0 + C * dt`)
         fracs = self.stage_fracs
-        stage = np.empty((max(n_steps, 1), len(fracs)), dtype=grid.t.dtype)
+        stage = np.empty((max(n_steps, 1), len(fracs) + 1), dtype=grid.t.dtype)
+        stage[:n_steps, -1] = grid.t[1:]     # the exact step end t1 (not t0 + dt), last entry of `_Step.times`
         for j, frac in enumerate(fracs):
             if frac == 0:
                 stage[:n_steps, j] = grid.t[:-1]
@@ -343,6 +349,40 @@ class Midpoint(BaseSDESolver):
         return upd(y0, f2, g2, dt, 1.0, st.noise, out=out)
 
 
+class ReversibleHeun(BaseSDESolver):
+    """Reversible Heun (reference: methods/reversible_heun.py:33-73): carries (f, g, z) between steps."""
+    weak_order = 1.0
+    sde_type = SDE_TYPES.stratonovich
+    noise_types = NOISE_TYPES.all()
+    levy_area_approximations = LEVY_AREA_APPROXIMATIONS.all()
+    stateful = True
+
+    def __init__(self, sde, **kwargs):
+        self.strong_order = 1.0 if sde.noise_type == NOISE_TYPES.additive else 0.5
+        super().__init__(sde=sde, **kwargs)
+
+    def init_extra_solver_state(self, t0, y0):
+        return tuple(self.sde.f_and_g(t0, y0)) + (y0,)
+
+    def _advance(self, y0, st, out):
+        f0, g0, z0 = self._extra
+        sde, dt, noise = self.sde, st.dt, st.noise
+        half_dt = type(dt)(0.5) * dt
+        t1 = st.times[-1]
+        if self._diag():
+            z1 = K.rheun_z(y0, z0, f0, g0, dt, 1.0, noise)
+            f1, g1 = sde.f_and_g(t1, z1)
+            y1 = K.rheun_y(y0, f0, f1, g0, g1, half_dt, 1.0, noise, out=out)
+        else:
+            base = K.lincomb2(y0, z0, 2.0, -1.0)
+            z1 = K.step_general_weighted(base, f0, g0, 1.0, dt, 1.0, 0, 0.0, 0.0, 0.0, noise)
+            f1, g1 = sde.f_and_g(t1, z1)
+            y1 = K.step_general_weighted(y0, K.lincomb2(f0, f1, 1.0, 1.0), K.lincomb2(g0, g1, 1.0, 1.0), 1.0, half_dt,
+                                         0.5, 0, 0.0, 0.0, 0.0, noise, out=out)
+        self._extra = (f1, g1, z1)
+        return y1
+
+
 class _Milstein(BaseSDESolver):
     """Milstein, derivative-using or derivative-free (reference: methods/milstein.py:21-94)."""
     strong_order = 1.0
@@ -437,7 +477,7 @@ class SRK(BaseSDESolver):
         if self.sde.noise_type == NOISE_TYPES.additive:
             return self._advance_additive(y0, st, out)
         sde, dt, noise = self.sde, st.dt, st.noise
-        t_0, t_q, t_h, _t_3q, t_1 = st.times
+        t_0, t_q, t_h, _t_3q, t_1, _t_end = st.times
         one = type(dt)(1)
         rdt = one / dt
         sqrt_dt = np.sqrt(dt)
@@ -466,7 +506,7 @@ class SRK(BaseSDESolver):
         C0 = (0, 3/4), C1 = (1, 0), A0[1][0] = 3/4, B0[1][0] = 3/2, alpha = (1/3, 2/3), beta1 = (1, 0),
         beta2 = (-1, 1). The diffusion always comes from `g` (a user `g_prod` computes the same product)."""
         sde, dt, noise = self.sde, st.dt, st.noise
-        t_0, _t_q, _t_h, t_3q, t_1 = st.times
+        t_0, _t_q, _t_h, t_3q, t_1, _t_end = st.times
         rdt = type(dt)(1) / dt
         f0 = sde.f(t_0, y0)
         g_a = sde.g(t_1, y0)     # t0 + C1[0]*dt
@@ -487,6 +527,10 @@ def select(method, sde_type):
         return SRK
     if method == METHODS.midpoint:
         return Midpoint
+    if method == METHODS.reversible_heun:
+        return ReversibleHeun
+    if method == METHODS.adjoint_reversible_heun:
+        raise ValueError(f"{METHODS.adjoint_reversible_heun} can only be used for adjoint_method.")
     if method in METHODS:
         raise NotImplementedError(
             f"torchsde_amd: method '{method}' is outside the MI355X hot path built so far (euler, milstein, srk, "
