@@ -144,6 +144,18 @@ int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const
                         const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
                         const tsde_noise_t* noise, int dtype, void* stream);
 
+/* Final stage of the Stratonovich predictor-corrector schemes, diagonal noise (or products when `prod`):
+ *   mode 0, Heun       (_core/methods/heun.py:35-48):        y1 = y0 + (((dt*(f + fp)) + g*dW) + gp*dW) * 0.5
+ *   mode 1, Euler-Heun (_core/methods/euler_heun.py:29-42):  y1 = (y0 + dt*f) + ((g*dW + gp*dW) * 0.5)
+ * prod != 0: g / gp already are diffusion-vector products (user g_prod, or results of a contraction). */
+int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp, int64_t n,
+                    double dt, int mode, int prod, const tsde_noise_t* noise, int dtype, void* stream);
+
+/* Davie (foster=0) / Foster (foster=1) approximation of the Levy area of one interval of width h from its
+ * (W, H): A:(B,m,m) (_brownian/brownian_interval.py:78-99); antisymmetric noise keyed on (entropy, cell, node). */
+int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster, uint64_t entropy,
+                   uint64_t elem0, uint32_t cell, uint64_t node, const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* ---- reversible Heun (Stratonovich) and its exact-gradient adjoint: _core/methods/reversible_heun.py ---- */
 
 /* z1 = ((2*y0 - z0) + sign*(f0*dt)) + sign*(g0*dW)    :69 forward (sign=+1), :109 reconstruction (sign=-1) */

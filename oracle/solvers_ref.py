@@ -158,7 +158,60 @@ def srk_step(sde, bm, t0, t1, y0, options=None):
     return y1
 
 
-STEPS = {"euler": euler_step, "midpoint": midpoint_step, "milstein": milstein_step, "srk": srk_step}
+def heun_step(sde, bm, t0, t1, y0, options=None):
+    """methods/heun.py:35-48."""
+    dt = t1 - t0
+    I_k = bm(t0, t1)
+    f, gp = f_and_g_prod(sde, t0, y0, I_k)
+    y0_prime = y0 + dt * f + gp
+    f_prime, gp_prime = f_and_g_prod(sde, t1, y0_prime, I_k)
+    return y0 + (dt * (f + f_prime) + gp + gp_prime) * 0.5
+
+
+def euler_heun_step(sde, bm, t0, t1, y0, options=None):
+    """methods/euler_heun.py:29-42."""
+    dt = t1 - t0
+    I_k = bm(t0, t1)
+    f, gp = f_and_g_prod(sde, t0, y0, I_k)
+    y_prime = y0 + gp
+    gp_prime = g_prod(sde, t1, y_prime, I_k)
+    return y0 + dt * f + (gp + gp_prime) * 0.5
+
+
+def dg_ga_jvp_column_sum(sde, t, y, a):
+    """base_sde.py:164-183: sum_{j,k,l} d g_{i,l} / d y_j  g_{j,k} A_{k,l} (zero unless the noise is general)."""
+    if sde.noise_type != "general":
+        return 0.
+    with torch.enable_grad():
+        y = y.detach().requires_grad_(True)
+        g = sde.g(t, y)
+        ga = torch.bmm(g, a)
+        total = 0.
+        for col in range(g.size(-1)):
+            out = g[..., col]
+            dummy = torch.zeros_like(out, requires_grad=True)
+            back, = torch.autograd.grad(out, y, grad_outputs=dummy, create_graph=True, allow_unused=True)
+            if back is None:
+                continue
+            jv, = torch.autograd.grad(back, dummy, grad_outputs=ga[..., col], retain_graph=True, allow_unused=True)
+            total = total + (0. if jv is None else jv)
+    return total.detach() if torch.is_tensor(total) else total
+
+
+def log_ode_step(sde, bm, t0, t1, y0, options=None):
+    """methods/log_ode.py:39-56."""
+    dt = t1 - t0
+    I_k, A = bm(t0, t1, return_A=True)
+    f, gp = f_and_g_prod(sde, t0, y0, I_k)
+    half_dt = 0.5 * dt
+    t_prime = t0 + half_dt
+    y_prime = y0 + half_dt * f + .5 * gp
+    f_prime, gp_prime = f_and_g_prod(sde, t_prime, y_prime, I_k)
+    return y0 + dt * f_prime + gp_prime + dg_ga_jvp_column_sum(sde, t_prime, y_prime, A)
+
+
+STEPS = {"euler": euler_step, "midpoint": midpoint_step, "milstein": milstein_step, "srk": srk_step,
+         "heun": heun_step, "euler_heun": euler_heun_step, "log_ode": log_ode_step}
 
 
 # ---- the stepping loop ------------------------------------------------------------------------------------
@@ -229,9 +282,12 @@ class ReplayBrownian:
     def __init__(self, table):
         self.table = table   # {(ta, tb): (W, U or None)}
 
-    def __call__(self, ta, tb, return_U=False):
-        W, U = self.table[(float(ta), float(tb))]
-        return (W, U) if return_U else W
+    def __call__(self, ta, tb, return_U=False, return_A=False):
+        entry = self.table[(float(ta), float(tb))]
+        W, U, A = entry if len(entry) == 3 else (entry[0], entry[1], None)
+        if return_U:
+            return (W, U, A) if return_A else (W, U)
+        return (W, A) if return_A else W
 
 
 # ---- reversible Heun (carries extra state) ------------------------------------------------------------------

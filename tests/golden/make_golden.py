@@ -48,10 +48,16 @@ class ReplayBM(torchsde.BaseBrownian):
             W = torch.tensor(self.rng.standard_normal(self._shape) * np.sqrt(h), dtype=self._dtype)
             H = torch.tensor(self.rng.standard_normal(self._shape) * np.sqrt(h / 12), dtype=self._dtype)
             U = h * (.5 * W + H)
-            self.table[key] = (W, U)
+            A = None
+            if self._levy in ("davie", "foster"):
+                N = torch.tensor(self.rng.standard_normal(self._shape + self._shape[-1:]) * h, dtype=self._dtype)
+                A = 0.5 * (N - N.transpose(-1, -2))
+            self.table[key] = (W, U, A)
             self.order.append(key)
-        W, U = self.table[key]
-        return (W, U) if return_U else W
+        W, U, A = self.table[key]
+        if return_U:
+            return (W, U, A) if return_A else (W, U)
+        return (W, A) if return_A else W
 
     def __repr__(self):
         return "ReplayBM"
@@ -65,6 +71,9 @@ class ReplayBM(torchsde.BaseBrownian):
         keys = np.array(self.order, dtype=np.float64).reshape(-1, 2)
         W = np.stack([self.table[k][0].numpy() for k in self.order])
         U = np.stack([self.table[k][1].numpy() for k in self.order])
+        self.A_dump = None
+        if len(self.table[self.order[0]]) > 2 and self.table[self.order[0]][2] is not None:
+            self.A_dump = np.stack([self.table[k][2].numpy() for k in self.order])
         return keys, W, U
 
 
@@ -126,6 +135,14 @@ SOLVER_CASES = [
     ("midpoint_scalar", "scalar_strat", "midpoint", None, "none", (5, 4, 1), [0., 0.5], 0.05),
     ("midpoint_additive", "additive_strat", "midpoint", None, "none", (5, 4, 3), [0., 0.5], 0.05),
     ("midpoint_general", "general_strat", "midpoint", None, "none", (6, 4, 4), [0., 0.5], 0.05),
+    ("heun_gbm", "gbm_strat", "heun", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("heun_general", "general_strat", "heun", None, "none", (6, 4, 4), [0., 0.5], 0.05),
+    ("heun_scalar", "scalar_strat", "heun", None, "none", (5, 4, 1), [0., 0.5], 0.05),
+    ("euler_heun_gbm", "gbm_strat", "euler_heun", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
+    ("euler_heun_general", "general_strat", "euler_heun", None, "none", (6, 4, 4), [0., 0.5], 0.05),
+    ("euler_heun_additive", "additive_strat", "euler_heun", None, "none", (5, 4, 3), [0., 0.5], 0.05),
+    ("log_ode_gbm", "gbm_strat", "log_ode", None, "foster", (5, 4, 4), [0., 0.5], 0.05),
+    ("log_ode_general", "general_strat", "log_ode", None, "davie", (6, 4, 4), [0., 0.5], 0.05),
     ("rheun_gbm", "gbm_strat", "reversible_heun", None, "none", (5, 4, 4), [0., 0.25, 0.5, 0.77], 0.1),
     ("rheun_scalar", "scalar_strat", "reversible_heun", None, "none", (5, 4, 1), [0., 0.5], 0.05),
     ("rheun_additive", "additive_strat", "reversible_heun", None, "none", (5, 4, 3), [0., 0.5], 0.05),
@@ -150,6 +167,8 @@ def gen_solver():
             out[f"{tag}__queries"] = keys
             out[f"{tag}__W"] = W
             out[f"{tag}__U"] = U
+            if getattr(bm, "A_dump", None) is not None:
+                out[f"{tag}__A"] = bm.A_dump
             out[f"{tag}__ys"] = ys.numpy()
             out[f"{tag}__param_checksum"] = np.float64(param_checksum(sde))
         np.savez_compressed(os.path.join(HERE, f"solver_{name}.npz"), **out)

@@ -35,6 +35,7 @@ class Case:
         self.queries = z[f"{tag}__queries"]
         self.W = z[f"{tag}__W"]
         self.U = z[f"{tag}__U"]
+        self.A = z[f"{tag}__A"] if f"{tag}__A" in z.files else None
         self.ys = torch.tensor(z[f"{tag}__ys"], dtype=self.dtype)
         self.param_checksum = float(z[f"{tag}__param_checksum"])
 
@@ -50,7 +51,9 @@ class Case:
 
     def table(self, device="cpu"):
         return {(float(a), float(b)): (torch.tensor(self.W[i], dtype=self.dtype, device=device),
-                                       torch.tensor(self.U[i], dtype=self.dtype, device=device))
+                                       torch.tensor(self.U[i], dtype=self.dtype, device=device),
+                                       None if self.A is None else torch.tensor(self.A[i], dtype=self.dtype,
+                                                                                device=device))
                 for i, (a, b) in enumerate(self.queries)}
 
 
@@ -61,8 +64,10 @@ def make_replay_bm(table, shape, dtype, device, levy):
 
     class Replay(BaseBrownian):
         def __call__(self, ta, tb=None, return_U=False, return_A=False):
-            W, U = table[(float(ta), float(tb))]
-            return (W, U) if return_U else W
+            W, U, A = table[(float(ta), float(tb))]
+            if return_U:
+                return (W, U, A) if return_A else (W, U)
+            return (W, A) if return_A else W
 
         def __repr__(self):
             return "Replay"

@@ -199,3 +199,31 @@ def test_strong_order_slopes(sde_type, method):
             log_rmse.append(0.5 * math.log(mse))
     slope = linregress(log_dt, log_rmse).slope
     assert abs(slope - REFERENCE_SLOPES[(sde_type, method)]) < 0.1, slope
+
+
+@pytest.mark.parametrize("levy", ["davie", "foster"])
+def test_levy_area(levy):
+    """return_A: shape (B, m, m), exactly antisymmetric, reproducible, zero for one-channel shapes, and with the
+    moments implied by the reference's formula A = H (x) W - W (x) H + std (N - N^T)  (brownian_interval.py:78-99)."""
+    import torchsde_amd
+    B, m, h = 1 << 15, 3, 0.25
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), dtype=F64, device=DEV, entropy=77,
+                                       levy_area_approximation=levy)
+    W, U, A = bm(0.5, 0.5 + h, return_U=True, return_A=True)
+    W2, A2 = bm(0.5, 0.5 + h, return_A=True)
+    assert A.shape == (B, m, m) and torch.equal(A, A2) and torch.equal(W, W2)
+    assert torch.equal(A, -A.transpose(-1, -2))
+    H = _U_to_H(W, U, h)
+    det = H.unsqueeze(-1) * W.unsqueeze(-2) - W.unsqueeze(-1) * H.unsqueeze(-2)
+    resid = (A - det)[:, 0, 1]
+    if levy == "davie":
+        expected_var = 2 * h * h / 12
+    else:
+        tenth = 0.1 * h
+        expected_var = (2 * tenth * (tenth + H[:, 0] ** 2 + H[:, 1] ** 2)).mean().item()
+    assert abs(resid.mean().item()) < 5 * math.sqrt(expected_var / B)
+    assert abs(resid.var().item() / expected_var - 1) < 0.05
+    one_channel = torchsde_amd.BrownianInterval(0.0, 1.0, size=(16,), dtype=F64, device=DEV, entropy=1,
+                                                levy_area_approximation=levy)
+    w, a = one_channel(0.1, 0.4, return_A=True)
+    assert a.shape == (16,) and (a == 0).all()

@@ -145,8 +145,7 @@ def test_solver_compatibility_errors():
         solvers.Euler(sde=ForwardSDE(problems.make("gbm_strat")), options={}, **kw)
     with pytest.raises(ValueError, match="does not match any known method"):
         solvers.select("rk4", "ito")
-    with pytest.raises(NotImplementedError):
-        solvers.select("heun", "stratonovich")
+    assert solvers.select("heun", "stratonovich") is solvers.Heun
     assert solvers.select("reversible_heun", "stratonovich") is solvers.ReversibleHeun
 
 

@@ -261,19 +261,40 @@ class BrownianInterval(BaseBrownian):
             tb = self._t1
         if ta > tb:
             raise RuntimeError(f"Query times ta={ta:.3f} and tb={tb:.3f} must respect ta <= tb.")
-        W, U = self.increment(ta, tb, want_U=self._have_H)
         A = None
-        if return_A:
-            if self._have_A:
-                raise NotImplementedError(
-                    "torchsde_amd: the Davie/Foster Levy-area tensor A is not built yet (SURVEY.md section 8(f), "
-                    "rank 3); W and U are available.")
+        if return_A and self._have_A:
+            W, U, A = self.increment_with_levy_area(ta, tb)
+        else:
+            W, U = self.increment(ta, tb, want_U=self._have_H)
         if return_U:
             return (W, U, A) if return_A else (W, U)
         return (W, A) if return_A else W
 
-    def increment(self, ta, tb, want_U=False, out_W=None, out_U=None):
-        """W (and U) over [ta, tb] for host floats ta <= tb inside [t0, t1]; one kernel launch."""
+    def increment_with_levy_area(self, ta, tb):
+        """(W, U, A) with A the Davie / Foster approximation of the Levy area of [ta, tb] built from the exact
+        (W, H) of that interval (brownian_interval.py:78-99). Like the reference's, A is an approximation and is
+        not additive over sub-intervals; its antisymmetric noise is keyed on the interval so re-queries agree."""
+        import struct
+        from . import kernels as K
+        ta_r, tb_r = self._round(ta), self._round(tb)
+        out_H = torch.empty(self._size, dtype=self._dtype, device=self._device)
+        W, U = self.increment(ta, tb, want_U=True, out_H=out_H)
+        if len(self._size) in (0, 1):   # one Brownian channel per batch element: no Levy area (:81-84)
+            return W, U, torch.zeros_like(W)
+        if not (ta_r < tb_r):
+            return W, U, torch.zeros(self._size + self._size[-1:], dtype=self._dtype, device=self._device)
+        ca, _ = self.locate(ta_r, tb_r)
+        bits_a, bits_b = (struct.unpack("<Q", struct.pack("<d", x))[0] for x in (ta_r, tb_r))
+        mix = (bits_a * 0x9E3779B97F4A7C15 + ((bits_b << 31) | (bits_b >> 33)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+        node = (mix ^ (mix >> 29)) & ((1 << 42) - 1)
+        m = self._size[-1]
+        A = K.levy_area(W.reshape(-1, m), out_H.reshape(-1, m), tb_r - ta_r,
+                        self._levy == LEVY_AREA_APPROXIMATIONS.foster, self._key, self._elem0, ca, node,
+                        self._entropy_dev)
+        return W, U, A.reshape(self._size + (m,))
+
+    def increment(self, ta, tb, want_U=False, out_W=None, out_U=None, out_H=None):
+        """W (and U, H) over [ta, tb] for host floats ta <= tb inside [t0, t1]; one kernel launch."""
         ta, tb = self._round(ta), self._round(tb)
         want_U = want_U and self._have_H
         if out_W is None:
@@ -284,13 +305,16 @@ class BrownianInterval(BaseBrownian):
             out_W.zero_()
             if want_U:
                 out_U.zero_()
+            if out_H is not None:
+                out_H.zero_()
             return out_W, (out_U if want_U else None)
         _native.require_device(out_W)
         lib = _native.load()
         ca, cb = self.locate(ta, tb)
         edges = self._device_edges()
         code = lib.tsde_brownian_query(
-            _native.ptr(out_W), _native.ptr(out_U if want_U else None), None, self._numel, self._key, self._elem0,
+            _native.ptr(out_W), _native.ptr(out_U if want_U else None),
+            _native.ptr(out_H if self._have_H else None), self._numel, self._key, self._elem0,
             _native.ptr(edges), ca, cb, ta, tb, _native.ptr(self._rootW), _native.ptr(self._rootH),
             1 if self._have_H else 0, self._max_depth, self._snap,
             None if self._entropy_dev is None else self._entropy_dev.data_ptr(), _native.dtype_code(self._dtype),

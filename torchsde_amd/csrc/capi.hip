@@ -217,6 +217,27 @@ int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const
                 tsde::launch_srk_stage<double>(stage, out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, noise, s));
 }
 
+int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp, int64_t n,
+                    double dt, int mode, int prod, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!y1 || !y0 || !f || !g || !gp) return bad_arg("tsde_heun_final", "null argument");
+  if (mode != 0 && mode != 1) return bad_arg("tsde_heun_final", "mode must be 0 (heun) or 1 (euler_heun)");
+  if (mode == 0 && !fp) return bad_arg("tsde_heun_final", "heun needs the second drift evaluation");
+  if (!prod && !noise) return bad_arg("tsde_heun_final", "noise required unless prod");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_heun_final", tsde::launch_heun_final<float>(y1, y0, f, fp, g, gp, n, dt, mode, prod, noise, s),
+                tsde::launch_heun_final<double>(y1, y0, f, fp, g, gp, n, dt, mode, prod, noise, s));
+}
+
+int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster, uint64_t entropy,
+                   uint64_t elem0, uint32_t cell, uint64_t node, const uint64_t* entropy_dev, int dtype, void* stream) {
+  if (!A || !W || !H) return bad_arg("tsde_levy_area", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  TSDE_DISPATCH(dtype, "tsde_levy_area",
+                tsde::launch_levy_area<float>(A, W, H, B, m, h, foster, key, entropy_dev, cell, node, s),
+                tsde::launch_levy_area<double>(A, W, H, B, m, h, foster, key, entropy_dev, cell, node, s));
+}
+
 int tsde_rheun_z_diag(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
                       double sign, const tsde_noise_t* noise, int dtype, void* stream) {
   if (!z1 || !y0 || !z0 || !f0 || !g0 || !noise) return bad_arg("tsde_rheun_z_diag", "null argument");

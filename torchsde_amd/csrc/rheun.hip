@@ -135,6 +135,97 @@ struct RheunAdjBOp {
   }
 };
 
+// ---- Heun / Euler-Heun final stage (Stratonovich predictor-corrector) ------------------------------------------
+//   mode 0, Heun        (heun.py:35-48):        y1 = y0 + (((dt*(f + fp)) + g*dW) + gp*dW) * 0.5
+//   mode 1, Euler-Heun  (euler_heun.py:29-42):  y1 = (y0 + dt*f) + ((g*dW + gp*dW) * 0.5)
+// PROD = true: g / gp already hold the diffusion-vector products (user-supplied g_prod, or a contraction).
+template <typename T, bool PROD>
+struct HeunFinalOp {
+  T* y1;
+  const T *y0, *f, *fp, *g, *gp;
+  T dt;
+  int mode;
+  CellNoise<T> nz;
+  template <int W>
+  TSDE_D void run(int64_t i) const {
+    const Pack<T, W> y = load<T, W>(y0, i), a = load<T, W>(f, i), c = load<T, W>(g, i), d = load<T, W>(gp, i);
+    Pack<T, W> b, w, u, o;
+    if (mode == 0) b = load<T, W>(fp, i);
+    if (!PROD) cell_noise<T, W, false>(nz, i, w, u);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const T p0 = PROD ? c.v[j] : c.v[j] * w.v[j];
+      const T p1 = PROD ? d.v[j] : d.v[j] * w.v[j];
+      if (mode == 0) {
+        o.v[j] = y.v[j] + (((dt * (a.v[j] + b.v[j])) + p0) + p1) * (T)0.5;
+      } else {
+        o.v[j] = (y.v[j] + dt * a.v[j]) + ((p0 + p1) * (T)0.5);
+      }
+    }
+    store<T, W>(y1, i, o);
+  }
+};
+
+template <typename T>
+hipError_t launch_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp,
+                             int64_t n, double dt, int mode, int prod, const tsde_noise_t* nz, hipStream_t s) {
+  bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && (!fp || aligned16(fp)) && aligned16(g) &&
+             aligned16(gp);
+  if (prod) {
+    HeunFinalOp<T, true> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, (T)dt, mode,
+                            CellNoise<T>{}};
+    return launch_elementwise(op, n, vec, s);
+  }
+  HeunFinalOp<T, false> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, (T)dt, mode,
+                           rh_noise<T>(nz)};
+  vec = vec && rh_noise_vec(nz);
+  return launch_elementwise(op, n, vec, s);
+}
+
+// ---- Davie / Foster approximation of the Levy area of one interval (brownian_interval.py:78-99) ------------------
+//   A[b,i,j] = H_i W_j - W_i H_j + std_ij (N_ij - N_ji),  std = sqrt(h^2/12) (Davie) or
+//   sqrt(0.1h (0.1h + H_i^2 + H_j^2)) (Foster);  N: independent normals of stream A keyed on (cell, node).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) levy_area_kernel(T* __restrict__ A, const T* __restrict__ W,
+                                                           const T* __restrict__ H, int64_t B, int64_t m, double h,
+                                                           int foster, NoiseKey key, const uint64_t* key_dev,
+                                                           uint32_t cell, uint64_t node) {
+  if (key_dev != nullptr) {
+    const uint64_t e = *key_dev;
+    key.k0 = (uint32_t)e;
+    key.k1 = (uint32_t)(e >> 32);
+  }
+  const int64_t total = B * m * m;
+  const T tenth_h = (T)(0.1 * h);
+  const T davie_std = (T)sqrt(h * h / 12.0);
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t b = t / (m * m);
+    const int64_t r = t - b * m * m;
+    const int64_t i = r / m, j = r - i * m;
+    const T Wi = W[b * m + i], Wj = W[b * m + j], Hi = H[b * m + i], Hj = H[b * m + j];
+    T a = Hi * Wj - Wi * Hj;
+    if (i != j) {
+      const uint64_t eij = key.elem0 * (uint64_t)m + (uint64_t)t;
+      const uint64_t eji = key.elem0 * (uint64_t)m + (uint64_t)(b * m * m + j * m + i);
+      const T nij = normal1<T>(key, eij, cell, node, kStreamA);
+      const T nji = normal1<T>(key, eji, cell, node, kStreamA);
+      const T sd = foster ? (T)sqrt((double)(tenth_h * (tenth_h + Hi * Hi + Hj * Hj))) : davie_std;
+      a += sd * (nij - nji);
+    }
+    A[t] = a;
+  }
+}
+
+template <typename T>
+hipError_t launch_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
+                            NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s) {
+  const int64_t total = B * m * m;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(levy_area_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (T*)A, (const T*)W, (const T*)H, B,
+                     m, h, foster, key, key_dev, cell, node);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_rheun_z(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
                           double sgn, const tsde_noise_t* nz, hipStream_t s) {
@@ -182,6 +273,10 @@ hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const 
 }
 
 #define TSDE_RH_INSTANTIATE(T)                                                                                       \
+  template hipError_t launch_heun_final<T>(void*, const void*, const void*, const void*, const void*, const void*,   \
+                                           int64_t, double, int, int, const tsde_noise_t*, hipStream_t);             \
+  template hipError_t launch_levy_area<T>(void*, const void*, const void*, int64_t, int64_t, double, int, NoiseKey,  \
+                                          const uint64_t*, uint32_t, uint64_t, hipStream_t);                         \
   template hipError_t launch_rheun_z<T>(void*, const void*, const void*, const void*, const void*, int64_t, double,  \
                                         double, const tsde_noise_t*, hipStream_t);                                   \
   template hipError_t launch_rheun_y<T>(void*, const void*, const void*, const void*, const void*, const void*,      \

@@ -497,3 +497,39 @@ def rheun_adj_b(ay, az0, vjp_z, dt, half_dt, noise):
     if code:
         _native.check(code, "tsde_rheun_adj_b_diag")
     return outs
+
+
+# ---- Heun / Euler-Heun / log-ODE helpers ------------------------------------------------------------------------
+def heun_final(y0, f, fp, g, gp, dt, mode, noise, prod=False, out=None):
+    """mode 0 (Heun): y0 + (((dt*(f+fp)) + g.dW) + gp.dW)*0.5 ; mode 1 (Euler-Heun): (y0 + dt*f) + ((g.dW + gp.dW)*0.5).
+    Diagonal noise, or already-formed products when `prod`."""
+    if _needs_grad(y0, f, fp, g, gp):
+        p0, p1 = (g, gp) if prod else (g * _noise_W(noise), gp * _noise_W(noise))
+        if mode == 0:
+            return y0 + (dt * (f + fp) + p0 + p1) * 0.5
+        return y0 + dt * f + (p0 + p1) * 0.5
+    y0 = _native.contiguous(y0)
+    f, fp, g, gp = _prep(y0, f, fp, g, gp)
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_heun_final(out.data_ptr(), y0.data_ptr(), f.data_ptr(), None if fp is None else fp.data_ptr(),
+                               g.data_ptr(), gp.data_ptr(), y0.numel(), dt, mode, 1 if prod else 0,
+                               None if prod else noise.struct(), dt_code, stream)
+    if code:
+        _native.check(code, "tsde_heun_final")
+    return out
+
+
+def levy_area(W, H, h, foster, entropy, elem0, cell, node, entropy_dev=None):
+    """Davie/Foster Levy-area approximation A:(B,m,m) of one interval from its (W, H):(B,m)."""
+    W = _native.contiguous(W)
+    H, = _prep(W, H)
+    B, m = W.shape
+    A = torch.empty((B, m, m), dtype=W.dtype, device=W.device)
+    lib, dt_code, stream = _launch_env(W)
+    code = lib.tsde_levy_area(A.data_ptr(), W.data_ptr(), H.data_ptr(), B, m, float(h), 1 if foster else 0, entropy,
+                              elem0, cell, node, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code,
+                              stream)
+    if code:
+        _native.check(code, "tsde_levy_area")
+    return A

@@ -517,6 +517,117 @@ class SRK(BaseSDESolver):
         return K.step_general_weighted(acc, f1, g_b, 2 / 3, dt, 1.0, 2, 0.0, 1.0, rdt, noise, out=out)
 
 
+class _TwoStageStratonovich(BaseSDESolver):
+    """Shared body of Heun (heun.py:24-48) and Euler-Heun (euler_heun.py:19-42): a predictor with the step kernel,
+    then the fused corrector `tsde_heun_final`."""
+    weak_order = 1.0
+    sde_type = SDE_TYPES.stratonovich
+    noise_types = NOISE_TYPES.all()
+    levy_area_approximations = LEVY_AREA_APPROXIMATIONS.all()
+    mode = 0   # 0 = Heun, 1 = Euler-Heun
+
+    def __init__(self, sde, **kwargs):
+        self.strong_order = 0.5 if sde.noise_type == NOISE_TYPES.general else 1.0
+        super().__init__(sde=sde, **kwargs)
+
+    def _advance(self, y0, st, out):
+        sde, dt, noise = self.sde, st.dt, st.noise
+        t0, t1 = st.times[0], st.times[-1]
+        heun = self.mode == 0
+        cf = dt if heun else type(dt)(0)     # predictor: y0 + dt*f + g.dW (Heun) or y0 + g.dW (Euler-Heun)
+        if sde.user_product or not self._diag():
+            # products are formed by the user / the contraction kernel; the corrector combines them elementwise
+            if sde.user_product:
+                W, _ = noise.materialise()
+                f, gp = sde.f_and_g_prod(t0, y0, W)
+                y_prime = K.step_prod(y0, f, gp, cf, 1.0)
+                if heun:
+                    f_prime, gp_prime = sde.f_and_g_prod(t1, y_prime, W)
+                else:
+                    f_prime, gp_prime = None, sde.g_prod(t1, y_prime, W)
+            else:
+                f, g = sde.f_and_g(t0, y0)
+                zero = torch.zeros_like(y0)
+                gp = K.step_general(zero, zero, g, 0.0, 1.0, noise)
+                y_prime = K.step_prod(y0, f, gp, cf, 1.0)
+                if heun:
+                    f_prime, g_prime = sde.f_and_g(t1, y_prime)
+                else:
+                    f_prime, g_prime = None, sde.g(t1, y_prime)
+                gp_prime = K.step_general(zero, zero, g_prime, 0.0, 1.0, noise)
+            return K.heun_final(y0, f, f_prime, gp, gp_prime, dt, self.mode, None, prod=True, out=out)
+        f, g = sde.f_and_g(t0, y0)
+        y_prime = K.step_diag(y0, f, g, cf, 1.0, noise)
+        if heun:
+            f_prime, g_prime = sde.f_and_g(t1, y_prime)
+        else:
+            f_prime, g_prime = None, sde.g(t1, y_prime)
+        return K.heun_final(y0, f, f_prime, g, g_prime, dt, self.mode, noise, out=out)
+
+
+class Heun(_TwoStageStratonovich):
+    mode = 0
+
+
+class EulerHeun(_TwoStageStratonovich):
+    mode = 1
+
+
+class LogODEMidpoint(BaseSDESolver):
+    """Log-ODE / midpoint scheme with Levy area (reference: methods/log_ode.py:25-56)."""
+    weak_order = 1.0
+    sde_type = SDE_TYPES.stratonovich
+    noise_types = NOISE_TYPES.all()
+    levy_area_approximations = (LEVY_AREA_APPROXIMATIONS.davie, LEVY_AREA_APPROXIMATIONS.foster)
+    stage_fracs = (0, 0.5)
+
+    def __init__(self, sde, **kwargs):
+        from . import adjoint
+        if isinstance(sde, adjoint.AdjointSDE):
+            raise ValueError("Log-ODE schemes cannot be used for adjoint SDEs, because they require "
+                             "direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
+                             "diffusion-vector product. Use a different method instead.")
+        self.strong_order = 0.5 if sde.noise_type == NOISE_TYPES.general else 1.0
+        super().__init__(sde=sde, **kwargs)
+
+    def _noise_for(self, ta, tb, t0_tensor, t1_tensor, cell=None):
+        # the Levy area is a (B, m, m) tensor for user autograd code: this method always materialises (W, A)
+        bm = self._native_bm()
+        if bm is not None:
+            W, _, A = bm.increment_with_levy_area(ta, tb)
+        else:
+            W, A = self.bm(t0_tensor, t1_tensor, return_A=True)
+        spec = NoiseSpec.external(W)
+        self._levy_area = A
+        return spec
+
+    def _advance(self, y0, st, out):
+        sde, dt, noise = self.sde, st.dt, st.noise
+        A = self._levy_area
+        half_dt = type(dt)(0.5) * dt
+        t0, t_prime = st.times[0], st.times[1]
+        y_prime = self._drift_diffusion_update(t0, y0, half_dt, 0.5, noise, None)
+        dg_ga = sde.dg_ga_jvp_column_sum(t_prime, y_prime, A)
+        if not torch.is_tensor(dg_ga):   # 0. for non-general noise (base_sde.py:73-77, :208-209)
+            dg_ga = None
+        return self._final(y0, y_prime, t_prime, dt, noise, dg_ga, out)
+
+    def _final(self, y0, y_prime, t_prime, dt, noise, dg_ga, out):
+        """y1 = ((y0 + dt*f') + g'.dW) + dg_ga', f' and g' evaluated at (t', y')."""
+        sde = self.sde
+        if sde.user_product:
+            W, _ = noise.materialise()
+            f_p, gp_p = sde.f_and_g_prod(t_prime, y_prime, W)
+            y1 = K.step_prod(y0, f_p, gp_p, dt, 1.0, out=out if dg_ga is None else None)
+        else:
+            f_p, g_p = sde.f_and_g(t_prime, y_prime)
+            upd = K.step_diag if self._diag() else K.step_general
+            y1 = upd(y0, f_p, g_p, dt, 1.0, noise, out=out if dg_ga is None else None)
+        if dg_ga is None:
+            return y1
+        return K.lincomb2(y1, dg_ga, 1.0, 1.0, out=out)
+
+
 def select(method, sde_type):
     """method name -> solver class (reference: methods/__init__.py:26-48)."""
     if method == METHODS.euler:
@@ -529,6 +640,12 @@ def select(method, sde_type):
         return Midpoint
     if method == METHODS.reversible_heun:
         return ReversibleHeun
+    if method == METHODS.heun:
+        return Heun
+    if method == METHODS.euler_heun:
+        return EulerHeun
+    if method == METHODS.log_ode_midpoint:
+        return LogODEMidpoint
     if method == METHODS.adjoint_reversible_heun:
         raise ValueError(f"{METHODS.adjoint_reversible_heun} can only be used for adjoint_method.")
     if method in METHODS:
