@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(kBlock) levy_area_kernel(T* __restrict__ A, co
       const uint64_t eji = key.elem0 * (uint64_t)m + (uint64_t)(b * m * m + j * m + i);
       const T nij = normal1<T>(key, eij, cell, node, kStreamA);
       const T nji = normal1<T>(key, eji, cell, node, kStreamA);
-      const T sd = foster ? (T)sqrt((double)(tenth_h * (tenth_h + Hi * Hi + Hj * Hj))) : davie_std;
+      // Hi^2 + Hj^2 first: commutative, so A stays exactly antisymmetric
+      const T sd = foster ? (T)sqrt((double)(tenth_h * (tenth_h + (Hi * Hi + Hj * Hj)))) : davie_std;
       a += sd * (nij - nji);
     }
     A[t] = a;
