@@ -62,5 +62,6 @@ class METHOD_OPTIONS(metaclass=_StrEnumMeta):  # noqa: N801
     grad_free = "grad_free"
 
 
-# Methods whose per-step update is a hand-written HIP kernel in this package.
-NATIVE_METHODS = (METHODS.euler, METHODS.milstein, METHODS.srk, METHODS.midpoint)
+# Methods whose per-step update is a hand-written HIP kernel in this package (SURVEY.md section 8 a + f).
+NATIVE_METHODS = (METHODS.euler, METHODS.milstein, METHODS.srk, METHODS.midpoint, METHODS.heun, METHODS.euler_heun,
+                  METHODS.log_ode_midpoint, METHODS.reversible_heun, METHODS.adjoint_reversible_heun)
