@@ -62,14 +62,16 @@ def g_prod_and_gdg_prod(sde, t, y, v1, v2):
     """base_sde.py:127-158."""
     if sde.noise_type == "additive":
         return g_prod(sde, t, y, v1), 0.
+    requires_grad = torch.is_grad_enabled()
     with torch.enable_grad():
         y = y if y.requires_grad else y.detach().requires_grad_(True)
         g = sde.g(t, y)
         weight = g * v2 if sde.noise_type == "diagonal" else g * v2.unsqueeze(-2)
-        gdg, = torch.autograd.grad(g, y, grad_outputs=weight, retain_graph=True, allow_unused=True)
+        gdg, = torch.autograd.grad(g, y, grad_outputs=weight, retain_graph=True, create_graph=requires_grad,
+                                   allow_unused=True)
         if gdg is None:
             gdg = torch.zeros_like(y)
-    return prod(sde, g.detach(), v1), gdg
+    return prod(sde, g, v1), gdg
 
 
 # ---- one step of each method ------------------------------------------------------------------------------
