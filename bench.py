@@ -47,6 +47,12 @@ WORKLOADS = {
         problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1,
         kernel="tsde_step_general<float> (general_fast_kernel)"),
+    # BASELINE configs[2] as literally worded: Milstein for GENERAL noise does not exist in the reference (it raises
+    # ValueError, milstein.py:25); this is the opt-in extension pinned by reduction tests (tests/test_gpu_milstein_general.py)
+    "c3_milstein_general_b16384_d32_m16": dict(
+        problem="general_big", method="milstein", levy="foster", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1, options={"general_noise": True},
+        kernel="tsde_step_general<float> (+ tsde_levy_area, tsde_iterated_integrals, 16 user JVPs per step)"),
     "c4_midpoint_diag_b32768_d64": dict(
         problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
@@ -171,6 +177,7 @@ def main():
     # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
     # the derivative form of Milstein and the adjoint run autograd inside the loop and stay eager.
     use_graph = (not args.eager) and (not adjoint) and cfg["method"] != "milstein"
+    extra_options = dict(cfg.get("options") or {})
     sde = _make_problem(cfg["problem"], d, m, dev)
     y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
     ts = torch.tensor([0.0, nsteps * dt], device=dev)
@@ -191,7 +198,7 @@ def main():
                 sharding.all_reduce_gradients(list(sde.parameters()))
             return y0.grad
         ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt,
-                                 options={"hip_graph": True} if graph else None)
+                                 options=dict(extra_options, hip_graph=True) if graph else (extra_options or None))
         if use_dist:
             dist.all_gather_into_tensor(gathered, ys[-1])
             return gathered

@@ -151,6 +151,13 @@ int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const
 int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp, int64_t n,
                     double dt, int mode, int prod, const tsde_noise_t* noise, int dtype, void* stream);
 
+/* Iterated integrals for the general-noise Milstein EXTENSION (the reference's Milstein rejects general noise,
+ * milstein.py:25; SURVEY.md section 8 note N1): I[b,k,l] = 0.5*(W_k W_l - [k==l]*dt) + A[b,k,l] (ito != 0) or
+ * 0.5*W_k W_l + A (Stratonovich); A may be NULL (commutative noise). The derivative term is then
+ * ForwardSDE.dg_ga_jvp_column_sum(t, y, I) (base_sde.py:164-183). */
+int tsde_iterated_integrals(void* I, const void* W, const void* A, int64_t B, int64_t m, double dt, int ito, int dtype,
+                            void* stream);
+
 /* Davie (foster=0) / Foster (foster=1) approximation of the Levy area of one interval of width h from its
  * (W, H): A:(B,m,m) (_brownian/brownian_interval.py:78-99); antisymmetric noise keyed on (entropy, cell, node). */
 int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster, uint64_t entropy,

@@ -69,6 +69,7 @@ SIGNATURES = {
                                      ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_heun_final": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_int,
                                  ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_iterated_integrals": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_dbl, _c_int, _c_int, _c_ptr]),
     "tsde_levy_area": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_dbl, _c_int, _c_u64, _c_u64, _c_u32, _c_u64,
                                 _c_ptr, _c_int, _c_ptr]),
     "tsde_rheun_z_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl,

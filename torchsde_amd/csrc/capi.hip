@@ -228,6 +228,14 @@ int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, con
                 tsde::launch_heun_final<double>(y1, y0, f, fp, g, gp, n, dt, mode, prod, noise, s));
 }
 
+int tsde_iterated_integrals(void* I, const void* W, const void* A, int64_t B, int64_t m, double dt, int ito, int dtype,
+                            void* stream) {
+  if (!I || !W) return bad_arg("tsde_iterated_integrals", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_iterated_integrals", tsde::launch_iterated_integrals<float>(I, W, A, B, m, dt, ito, s),
+                tsde::launch_iterated_integrals<double>(I, W, A, B, m, dt, ito, s));
+}
+
 int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster, uint64_t entropy,
                    uint64_t elem0, uint32_t cell, uint64_t node, const uint64_t* entropy_dev, int dtype, void* stream) {
   if (!A || !W || !H) return bad_arg("tsde_levy_area", "null argument");

@@ -217,6 +217,35 @@ __global__ void __launch_bounds__(kBlock) levy_area_kernel(T* __restrict__ A, co
   }
 }
 
+// ---- iterated integrals for general-noise Milstein (extension, SURVEY.md section 8 note N1) ----------------------
+//   I[b,k,l] = 0.5*(W_k W_l - [k==l] dt) + A[b,k,l]   (Ito; Stratonovich drops the dt term; A may be absent)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) iterated_integrals_kernel(T* __restrict__ I, const T* __restrict__ W,
+                                                                    const T* __restrict__ A, int64_t B, int64_t m,
+                                                                    T dt, int ito) {
+  const int64_t total = B * m * m;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t b = t / (m * m);
+    const int64_t r = t - b * m * m;
+    const int64_t k = r / m, l = r - k * m;
+    T v = W[b * m + k] * W[b * m + l];
+    if (ito && k == l) v = v - dt;
+    v = (T)0.5 * v;
+    if (A != nullptr) v = v + A[t];
+    I[t] = v;
+  }
+}
+
+template <typename T>
+hipError_t launch_iterated_integrals(void* I, const void* W, const void* A, int64_t B, int64_t m, double dt, int ito,
+                                     hipStream_t s) {
+  const int64_t total = B * m * m;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(iterated_integrals_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (T*)I, (const T*)W,
+                     (const T*)A, B, m, (T)dt, ito);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
                             NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s) {
@@ -276,6 +305,8 @@ hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const 
 #define TSDE_RH_INSTANTIATE(T)                                                                                       \
   template hipError_t launch_heun_final<T>(void*, const void*, const void*, const void*, const void*, const void*,   \
                                            int64_t, double, int, int, const tsde_noise_t*, hipStream_t);             \
+  template hipError_t launch_iterated_integrals<T>(void*, const void*, const void*, int64_t, int64_t, double, int,   \
+                                                   hipStream_t);                                                     \
   template hipError_t launch_levy_area<T>(void*, const void*, const void*, int64_t, int64_t, double, int, NoiseKey,  \
                                           const uint64_t*, uint32_t, uint64_t, hipStream_t);                         \
   template hipError_t launch_rheun_z<T>(void*, const void*, const void*, const void*, const void*, int64_t, double,  \

@@ -65,6 +65,9 @@ template <typename T>
 hipError_t launch_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp,
                              int64_t n, double dt, int mode, int prod, const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
+hipError_t launch_iterated_integrals(void* I, const void* W, const void* A, int64_t B, int64_t m, double dt, int ito,
+                                     hipStream_t s);
+template <typename T>
 hipError_t launch_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
                             NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s);
 template <typename T>

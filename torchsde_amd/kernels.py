@@ -533,3 +533,18 @@ def levy_area(W, H, h, foster, entropy, elem0, cell, node, entropy_dev=None):
     if code:
         _native.check(code, "tsde_levy_area")
     return A
+
+
+def iterated_integrals(W, A, dt, ito):
+    """I[b,k,l] = 0.5*(W_k W_l - [k==l] dt) + A[b,k,l] (Ito) / 0.5*W_k W_l + A (Stratonovich); A may be None."""
+    W = _native.contiguous(W)
+    B, m = W.shape
+    if A is not None:
+        A = _native.contiguous(A.to(W.dtype))
+    out = torch.empty((B, m, m), dtype=W.dtype, device=W.device)
+    lib, dt_code, stream = _launch_env(W)
+    code = lib.tsde_iterated_integrals(out.data_ptr(), W.data_ptr(), None if A is None else A.data_ptr(), B, m,
+                                       float(dt), 1 if ito else 0, dt_code, stream)
+    if code:
+        _native.check(code, "tsde_iterated_integrals")
+    return out

@@ -24,9 +24,10 @@ from .settings import LEVY_AREA_APPROXIMATIONS, METHOD_OPTIONS, METHODS, NOISE_T
 
 class _Step:
     """Everything one solver step needs besides the state."""
-    __slots__ = ("times", "dt", "noise", "h64")
+    __slots__ = ("times", "dt", "noise", "h64", "t0_64")
 
-    def __init__(self, times, dt, noise, h64):
+    def __init__(self, times, dt, noise, h64, t0_64=None):
+        self.t0_64 = t0_64   # float(t0) on the host
         self.times = times   # tuple of 0-d device tensors: stage times (times[0] = t0)
         self.dt = dt         # numpy scalar in ts.dtype: t1 - t0
         self.noise = noise   # NoiseSpec
@@ -143,7 +144,7 @@ class BaseSDESolver:
             cell = None if cells is None else int(cells[0])
         times = tuple(t0_t if frac == 0 else torch.tensor(t0n + np_dtype(frac) * dt, dtype=t0_t.dtype, device=dev)
                       for frac in self.stage_fracs) + (t1_t,)
-        st = _Step(times, dt, self._noise_for(ta, tb, t0_t, t1_t, cell), tb - ta)
+        st = _Step(times, dt, self._noise_for(ta, tb, t0_t, t1_t, cell), tb - ta, ta)
         y1 = self._advance(y0, st, None)
         return y1, self._extra
 
@@ -262,7 +263,7 @@ class BaseSDESolver:
             noise = self._noise_for(t64[k], t64[k + 1], None if t_dev is None else t_dev[k],
                                     None if t_dev is None else t_dev[k + 1],
                                     None if cells is None else int(cells[k]))
-            st = _Step(stage_rows[k], grid.dt[k], noise, t64[k + 1] - t64[k])
+            st = _Step(stage_rows[k], grid.dt[k], noise, t64[k + 1] - t64[k], t64[k])
             nxt = self._advance(cur, st, slot)
             if in_place and (nxt.requires_grad or (slot is not None and nxt.data_ptr() != slot.data_ptr())):
                 # A tensor that requires grad appeared mid-solve (e.g. a non-Parameter leaf inside the SDE):
@@ -402,6 +403,10 @@ class _Milstein(BaseSDESolver):
                              f"direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
                              f"diffusion-vector product. Use derivative-using Milstein instead: "
                              f"`adjoint_options=dict({METHOD_OPTIONS.grad_free}=False)`")
+        if sde.noise_type == NOISE_TYPES.general and options.get("general_noise", False):
+            # Opt-in EXTENSION (the reference rejects this combination, milstein.py:25): Milstein for general
+            # noise with the iterated integrals I_kl = (W_k W_l - delta_kl dt)/2 + A_kl.
+            self.noise_types = tuple(NOISE_TYPES.all())
         super().__init__(sde=sde, options=options, **kwargs)
 
     def _row_noise(self, noise, d):
@@ -409,10 +414,28 @@ class _Milstein(BaseSDESolver):
         W, U = noise.materialise()
         return NoiseSpec.external(W.reshape(-1), None if U is None else U.reshape(-1), bcast_d=d)
 
+    def _advance_general(self, y0, st, out):
+        """y1 = y0 + f dt + g.dW + sum_{j,k,l} dg_{i,l}/dy_j g_{j,k} I_{k,l}  (extension; see __init__)."""
+        sde, dt = self.sde, st.dt
+        t0 = st.times[0]
+        bm = self._native_bm()
+        A = None
+        if bm is not None and bm._have_A:
+            W, _, A = bm.increment_with_levy_area(st.t0_64, st.t0_64 + st.h64)
+        else:
+            W, _ = st.noise.materialise()
+        integrals = K.iterated_integrals(W, A, dt, self.ito)
+        f, g = sde.f_and_g(t0, y0)
+        correction = sde.dg_ga_jvp_column_sum(t0, y0, integrals)
+        y1 = K.step_general(y0, f, g, dt, 1.0, NoiseSpec.external(W))
+        return K.lincomb2(y1, correction, 1.0, 1.0, out=out)
+
     def _advance(self, y0, st, out):
         sde, dt, noise = self.sde, st.dt, st.noise
         t0 = st.times[0]
         kind = sde.noise_type
+        if kind == NOISE_TYPES.general:
+            return self._advance_general(y0, st, out)
         if kind == NOISE_TYPES.additive:
             # gdg = 0 (base_sde.py:157-158): y1 = y0 + f*dt + g_prod + 0.
             if sde.user_g_prod:
