@@ -229,7 +229,7 @@ def main():
         over_ms = K.prof_bracket_overhead(100, 12.0, dev)
         K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
         # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
-        K.gpu_delay(min(2.0e6, 60.0 * nsteps * (3 + cfg["launches_per_step"])), dev)
+        K.gpu_delay(min(2.0e6, 40.0 * nsteps * (2 + cfg["launches_per_step"])), dev)
         one_solve(5000, graph=False)
         torch.cuda.synchronize()
         k_ms, k_launches = K.prof_end()
