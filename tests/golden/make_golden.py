@@ -158,7 +158,7 @@ def gen_solver():
             sde = problems.make(prob, dtype=dtype, d=d, m=m)
             y0 = torch.full((B, d), 0.1, dtype=dtype)
             tst = torch.tensor(ts, dtype=dtype)
-            bm = ReplayBM((B, m), dtype, seed=hash(name) % 2 ** 31 if False else sum(map(ord, name)), levy=levy)
+            bm = ReplayBM((B, m), dtype, seed=sum(map(ord, name)), levy=levy)
             with torch.no_grad():
                 ys = torchsde.sdeint(sde, y0, tst, bm=bm, method=method, dt=dt,
                                      options=None if options is None else dict(options))

@@ -2,6 +2,7 @@
 // Prints average kernel time and algorithmic GB/s (4 streams x n x 4 B) per variant.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "../torchsde_amd/csrc/tsde_common.h"
 using namespace tsde;
@@ -72,7 +73,18 @@ int main() {
   Bufs b;
   for (int i = 0; i < 2; ++i) CK(hipMalloc(&b.y[i], n * 4));
   CK(hipMalloc(&b.f, n * 4)); CK(hipMalloc(&b.g, n * 4));
-  CK(hipMemset(b.y[0], 0, n * 4)); CK(hipMemset(b.y[1], 0, n * 4)); CK(hipMemset(b.f, 0, n * 4)); CK(hipMemset(b.g, 0, n * 4));
+  const bool random_data = (getenv("TSDE_RANDOM") != nullptr);
+  if (random_data) {
+    std::vector<float> h(n);
+    for (int k = 0; k < 4; ++k) {
+      for (int64_t i = 0; i < n; ++i) h[i] = (k == 2 ? -0.5f : 0.05f) + 0.3f * (float)rand() / RAND_MAX;
+      CK(hipMemcpy(k == 0 ? b.y[0] : k == 1 ? b.y[1] : k == 2 ? b.f : b.g, h.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    printf("random (live-like) data\n");
+  } else {
+    CK(hipMemset(b.y[0], 0, n * 4)); CK(hipMemset(b.y[1], 0, n * 4)); CK(hipMemset(b.f, 0, n * 4)); CK(hipMemset(b.g, 0, n * 4));
+    printf("zero-filled data\n");
+  }
   const int64_t nq = n / 4;
   const int full = (int)((nq + 255) / 256);
   const int it = 300;
