@@ -121,15 +121,23 @@ class BaseSDESolver:
             if cell is not None:
                 return NoiseSpec.generated(bm, cell, bm.cell_width(cell))
             W, U = bm.increment(ta, tb, want_U=self.needs_U)
-            return NoiseSpec.external(W, U)
+            return NoiseSpec.external(self._as_state_dtype(W), self._as_state_dtype(U))
         if self.needs_U:
             W, U = self.bm(t0_tensor, t1_tensor, return_U=True)
-            return NoiseSpec.external(W, U)
-        return NoiseSpec.external(self.bm(t0_tensor, t1_tensor))
+            return NoiseSpec.external(self._as_state_dtype(W), self._as_state_dtype(U))
+        return NoiseSpec.external(self._as_state_dtype(self.bm(t0_tensor, t1_tensor)))
+
+    def _as_state_dtype(self, x):
+        """Materialised increments are read by the kernels in the state's dtype."""
+        dtype = getattr(self, "_state_dtype", None)
+        if x is None or dtype is None or x.dtype == dtype:
+            return x
+        return x.to(dtype)
 
     # ---- public single-step API (the reference's solver seam) --------------------------------------
     def step(self, t0, t1, y0, extra0):
         self._extra = tuple(extra0) if extra0 is not None else ()
+        self._state_dtype = y0.dtype
         np_dtype = timegrid._NP.get(y0.dtype if not torch.is_tensor(t0) else t0.dtype, np.float64)
         ta, tb = float(t0), float(t1)
         t0n, t1n = np_dtype(ta), np_dtype(tb)
@@ -153,6 +161,7 @@ class BaseSDESolver:
         if self.adaptive:
             return self._integrate_adaptive(y0, ts, extra0)
         self._extra = tuple(extra0) if extra0 is not None else ()
+        self._state_dtype = y0.dtype
         if self.options.get("hip_graph", False) and not self._tracks_grad(y0) and not self.stateful:
             from . import graph
             return graph.replay_or_capture(self, y0, ts), ()
