@@ -133,3 +133,49 @@ def test_reversible_heun_is_reversible(prob, shape):
         back = torchsde_amd.sdeint(NegatedTime(), ys[-1], -ts.flip(0), bm=rev_bm, method="reversible_heun", dt=dt,
                                    extra_solver_state=(-f, -g, z))
     torch.testing.assert_close(back.flip(0), ys, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("prob,method,adjoint_method,shape", [
+    ("gbm_ito", "euler", "euler", (128, 8, 8)),
+    ("gbm_ito", "srk", None, (128, 8, 8)),
+    ("mlpdiag_ito", "milstein", None, (96, 8, 8)),
+    ("gbm_strat", "midpoint", None, (128, 8, 8)),
+    ("general_ito", "euler", None, (64, 4, 4)),
+    ("general_strat", "midpoint", None, (64, 4, 4)),
+    ("additive_ito", "euler", None, (64, 4, 3)),
+    ("scalar_ito", "euler", None, (64, 4, 1)),
+])
+def test_adjoint_matches_oracle_on_counter_rng_path(prob, method, adjoint_method, shape):
+    """sdeint_adjoint on the generator's own path (fused forward, re-materialised reverse sweep) vs the oracle's
+    restatement of the reference's adjoint (pinned to the real reference in tests/test_oracle_adjoint.py) driven
+    by the C twin of the generator; float64, at shapes beyond the golden fixtures."""
+    import torchsde_amd
+    from oracle import adjoint_ref, counter
+    B, d, m = shape
+    dtype = torch.float64
+    steps, dt = 16, 2.0 ** -5
+    levy = "space-time" if method == "srk" else "none"
+    ts_list = [0.0, 6 * dt, steps * dt]
+    edges = np.arange(steps + 1) * dt
+    sde = problems.make(prob, dtype=dtype, d=d, m=m)
+    wt = torch.linspace(-1, 1, 3 * B * d, dtype=dtype).reshape(3, B, d)
+
+    def bm_cpu(ta, tb, return_U=False):
+        W, U, _ = counter.query(B * m, 404, edges, float(ta), float(tb), dtype=np.float64, have_h=(levy != "none"))
+        W = torch.from_numpy(W).reshape(B, m)
+        return (W, torch.from_numpy(U).reshape(B, m)) if return_U else W
+
+    ys_ref, gy_ref, gp_ref = adjoint_ref.adjoint_gradients(sde, torch.full((B, d), 0.1, dtype=dtype),
+                                                           torch.tensor(ts_list, dtype=dtype), bm_cpu, dt, method,
+                                                           adjoint_method, wt)
+    sde_g = problems.make(prob, dtype=dtype, d=d, m=m).to(DEV)
+    y0 = torch.full((B, d), 0.1, dtype=dtype, device=DEV, requires_grad=True)
+    bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, m), dtype=dtype, device=DEV, entropy=404, dt=dt,
+                                       levy_area_approximation=levy)
+    ys = torchsde_amd.sdeint_adjoint(sde_g, y0, torch.tensor(ts_list, dtype=dtype, device=DEV), bm=bm, method=method,
+                                     adjoint_method=adjoint_method, dt=dt)
+    (ys * wt.to(DEV)).sum().backward()
+    torch.testing.assert_close(ys.detach().cpu(), ys_ref, rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(y0.grad.cpu(), gy_ref, rtol=1e-8, atol=1e-10)
+    for p, ref in zip(sde_g.parameters(), gp_ref):
+        torch.testing.assert_close(p.grad.cpu(), ref, rtol=1e-8, atol=1e-9)

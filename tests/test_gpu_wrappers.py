@@ -1,0 +1,98 @@
+"""Legacy Brownian wrappers and adjoint parameter handling on the GPU (reference tests/test_brownian_path.py,
+test_brownian_tree.py, test_sdeint.py:160-179, test_adjoint.py:157-177)."""
+import math
+
+import pytest
+import torch
+from scipy.stats import kstest
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F64 = torch.float64
+
+
+@pytest.mark.parametrize("kind", ["path", "tree"])
+def test_brownian_path_and_tree(kind):
+    import torchsde_amd
+    B = 65536
+    w0 = torch.zeros(B, dtype=F64, device=DEV)
+    if kind == "path":
+        bm = torchsde_amd.BrownianPath(t0=0.0, w0=w0)
+    else:
+        bm = torchsde_amd.BrownianTree(t0=0.0, w0=w0, t1=1.0, entropy=5, tol=1e-6)
+    with pytest.warns(UserWarning):
+        w_a = bm(0.3)
+    with pytest.warns(UserWarning):
+        w_a2 = bm(0.3)
+    assert w_a.shape == (B,) and torch.equal(w_a, w_a2)          # shape + repeat determinism
+    inc = bm(0.3, 0.7)
+    with pytest.warns(UserWarning):
+        w_b = bm(0.7)
+    torch.testing.assert_close(w_a + inc, w_b, rtol=1e-6, atol=1e-6)
+    _, pval = kstest((inc / math.sqrt(0.4)).cpu().numpy(), "norm")
+    assert pval > 1e-5
+    if kind == "tree":    # pinned terminal value
+        w1 = torch.ones(B, dtype=F64, device=DEV)
+        pinned = torchsde_amd.BrownianTree(t0=0.0, w0=w0, t1=1.0, w1=w1, entropy=6, tol=1e-6)
+        with pytest.warns(UserWarning):
+            assert torch.allclose(pinned(1.0), w1)
+
+
+def test_brownian_interval_like():
+    import torchsde_amd
+    y = torch.zeros(8, 3, dtype=F64, device=DEV)
+    bm = torchsde_amd.brownian_interval_like(y, t0=0.0, t1=2.0, entropy=1)
+    assert bm.shape == (8, 3) and bm.dtype == F64 and bm.device.type == "cuda"
+    assert bm(0.5, 1.5).shape == (8, 3)
+
+
+class _WithUnused(nn.Module):
+    noise_type, sde_type = "diagonal", "stratonovich"
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Parameter(torch.tensor(-0.5, dtype=F64))
+        self.frozen = nn.Parameter(torch.tensor(0.3, dtype=F64), requires_grad=False)
+        self.unused = nn.Parameter(torch.tensor(1.0, dtype=F64))
+
+    def f(self, t, y):
+        return self.a * y
+
+    def g(self, t, y):
+        return self.frozen * torch.ones_like(y)
+
+
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_params_with_without_grad_and_unused(adjoint):
+    import torchsde_amd
+    sde = _WithUnused().to(DEV)
+    y0 = torch.full((16, 4), 0.1, dtype=F64, device=DEV, requires_grad=True)
+    ts = torch.tensor([0.0, 0.5], dtype=F64, device=DEV)
+    fn = torchsde_amd.sdeint_adjoint if adjoint else torchsde_amd.sdeint
+    ys = fn(sde, y0, ts, method="midpoint", dt=2.0 ** -4)
+    ys.sum().backward()
+    assert y0.grad is not None and sde.a.grad is not None and torch.isfinite(sde.a.grad)
+    assert sde.frozen.grad is None and sde.frozen.requires_grad is False
+    assert sde.unused.grad is None or float(sde.unused.grad) == 0.0
+    assert sde.a.requires_grad and y0.requires_grad           # flags untouched (test_adjoint.py:157-177)
+
+
+def test_explicit_adjoint_params_and_no_module():
+    import torchsde_amd
+    theta = torch.tensor(-0.4, dtype=F64, device=DEV, requires_grad=True)
+
+    class Plain:
+        noise_type, sde_type = "diagonal", "ito"
+
+        def f(self, t, y):
+            return theta * y
+
+        def g(self, t, y):
+            return 0.2 * y
+
+    y0 = torch.full((8, 4), 0.1, dtype=F64, device=DEV)
+    ts = torch.tensor([0.0, 0.25], dtype=F64, device=DEV)
+    ys = torchsde_amd.sdeint_adjoint(Plain(), y0, ts, method="euler", dt=2.0 ** -5, adjoint_params=(theta,))
+    ys[-1].sum().backward()
+    assert theta.grad is not None and torch.isfinite(theta.grad)
