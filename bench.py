@@ -226,7 +226,6 @@ def main():
         # roofline of the dominant kernel: every launch of the step kernel in one more solve is bracketed by
         # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
         # (issued eagerly: event records are host-side calls and are not part of a replayed graph)
-        over_ms = K.prof_bracket_overhead(100, 12.0, dev)
         K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
         # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
         K.gpu_delay(min(2.0e6, 40.0 * nsteps * (2 + cfg["launches_per_step"])), dev)
@@ -287,7 +286,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": cfg["kernel"],
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "traffic": traffic, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "bracket_us_in_situ": raw_s * 1e6,
-                    "event_bracket_overhead_us": over_ms * 1e3, "kernel_us_rocprofv3": rocprof_us,
+                    "kernel_us_rocprofv3": rocprof_us,
                     "timing": ("HIP events around 200 back-to-back launches on live data (avg_launch_us); bracket_us_in_situ = "
                                "HIP events bracketing each of the launches of one eagerly issued solve, an upper bound "
                                "that includes marker-packet latency") if b2b_us is not None else
