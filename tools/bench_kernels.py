@@ -30,7 +30,8 @@ def main():
     dev = "cuda"
     dt = 2.0 ** -10
     rows = []
-    for (B, d) in [(65536, 64), (32768, 64), (32768, 128), (16384, 32)]:
+    # the last two exceed the 256 MiB Infinity Cache (4 x 64 MiB and 4 x 256 MiB live streams): true HBM traffic
+    for (B, d) in [(65536, 64), (32768, 64), (32768, 128), (16384, 32), (262144, 64), (1048576, 64)]:
         y = [torch.rand(B, d, device=dev) for _ in range(2)]
         f, g = torch.randn(B, d, device=dev), torch.rand(B, d, device=dev)
         us = timeit(lambda i: K._raw_step_diag(y[i & 1], f, g, dt, 1.0, gen_noise((B, d), i, dt, dev), y[(i + 1) & 1]))

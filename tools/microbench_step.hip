@@ -69,7 +69,7 @@ int run(const char* name, int grid, const Bufs& b, int64_t n, int iters) {
 }
 
 int main() {
-  const int64_t n = 65536LL * 64;
+  const int64_t n = (getenv("TSDE_ROWS") ? atoll(getenv("TSDE_ROWS")) : 65536LL) * 64;
   Bufs b;
   for (int i = 0; i < 2; ++i) CK(hipMalloc(&b.y[i], n * 4));
   CK(hipMalloc(&b.f, n * 4)); CK(hipMalloc(&b.g, n * 4));
@@ -87,7 +87,7 @@ int main() {
   }
   const int64_t nq = n / 4;
   const int full = (int)((nq + 255) / 256);
-  const int it = 300;
+  const int it = n > (1LL << 26) ? 40 : 300;
   for (int rep = 0; rep < 2; ++rep) {
     run<false, 1, false>("copy-like (no RNG) u1", 2048, b, n, it);
     run<false, 1, false>("copy-like (no RNG) u1", full, b, n, it);

@@ -35,14 +35,14 @@ struct RheunZOp {
   const T *y0, *z0, *f0, *g0;
   T dt, sgn;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> y = load<T, W>(y0, i), z = load<T, W>(z0, i), f = load<T, W>(f0, i), g = load<T, W>(g0, i);
+    const Pack<T, W> y = load<T, W, NT>(y0, i), z = load<T, W, NT>(z0, i), f = load<T, W, NT>(f0, i), g = load<T, W, NT>(g0, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = ((((T)2 * y.v[j]) - z.v[j]) + sgn * (f.v[j] * dt)) + sgn * (g.v[j] * w.v[j]);
-    store<T, W>(z1, i, o);
+    store<T, W, NT>(z1, i, o);
   }
 };
 
@@ -53,10 +53,10 @@ struct RheunYOp {
   const T *y0, *f0, *f1, *g0, *g1;
   T half_dt, sgn;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> y = load<T, W>(y0, i), a = load<T, W>(f0, i), b = load<T, W>(f1, i), c = load<T, W>(g0, i),
-                     d = load<T, W>(g1, i);
+    const Pack<T, W> y = load<T, W, NT>(y0, i), a = load<T, W, NT>(f0, i), b = load<T, W, NT>(f1, i), c = load<T, W, NT>(g0, i),
+                     d = load<T, W, NT>(g1, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
@@ -65,7 +65,7 @@ struct RheunYOp {
       const T diff = (c.v[j] + d.v[j]) * ((T)0.5 * w.v[j]);
       o.v[j] = (y.v[j] + sgn * drift) + sgn * diff;
     }
-    store<T, W>(y1, i, o);
+    store<T, W, NT>(y1, i, o);
   }
 };
 
@@ -75,13 +75,13 @@ struct Lincomb2Op {
   T* out;
   const T *x, *y;
   T a, b;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> p = load<T, W>(x, i), q = load<T, W>(y, i);
+    const Pack<T, W> p = load<T, W, NT>(x, i), q = load<T, W, NT>(y, i);
     Pack<T, W> o;
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = a * p.v[j] + b * q.v[j];
-    store<T, W>(out, i, o);
+    store<T, W, NT>(out, i, o);
   }
 };
 
@@ -92,9 +92,9 @@ struct RheunAdjAOp {
   const T *ay, *af0, *ag0;
   T half_dt;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(ay, i), f = load<T, W>(af0, i), g = load<T, W>(ag0, i);
+    const Pack<T, W> a = load<T, W, NT>(ay, i), f = load<T, W, NT>(af0, i), g = load<T, W, NT>(ag0, i);
     Pack<T, W> w, u, of, og;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
@@ -102,8 +102,8 @@ struct RheunAdjAOp {
       of.v[j] = f.v[j] + a.v[j] * half_dt;
       og.v[j] = g.v[j] + a.v[j] * ((T)0.5 * w.v[j]);
     }
-    store<T, W>(af0_out, i, of);
-    store<T, W>(ag0_out, i, og);
+    store<T, W, NT>(af0_out, i, of);
+    store<T, W, NT>(ag0_out, i, og);
   }
 };
 
@@ -115,9 +115,9 @@ struct RheunAdjBOp {
   const T *ay, *az0, *vjp_z;
   T dt, half_dt;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(ay, i), z = load<T, W>(az0, i), v = load<T, W>(vjp_z, i);
+    const Pack<T, W> a = load<T, W, NT>(ay, i), z = load<T, W, NT>(az0, i), v = load<T, W, NT>(vjp_z, i);
     Pack<T, W> w, u, oy, oz, of, og;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
@@ -128,10 +128,10 @@ struct RheunAdjBOp {
       of.v[j] = a.v[j] * half_dt + zz * dt;
       og.v[j] = a.v[j] * ((T)0.5 * w.v[j]) + zz * w.v[j];
     }
-    store<T, W>(ay1, i, oy);
-    store<T, W>(az1, i, oz);
-    store<T, W>(af1, i, of);
-    store<T, W>(ag1, i, og);
+    store<T, W, NT>(ay1, i, oy);
+    store<T, W, NT>(az1, i, oz);
+    store<T, W, NT>(af1, i, of);
+    store<T, W, NT>(ag1, i, og);
   }
 };
 
@@ -146,11 +146,11 @@ struct HeunFinalOp {
   T dt;
   int mode;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> y = load<T, W>(y0, i), a = load<T, W>(f, i), c = load<T, W>(g, i), d = load<T, W>(gp, i);
+    const Pack<T, W> y = load<T, W, NT>(y0, i), a = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i), d = load<T, W, NT>(gp, i);
     Pack<T, W> b, w, u, o;
-    if (mode == 0) b = load<T, W>(fp, i);
+    if (mode == 0) b = load<T, W, NT>(fp, i);
     if (!PROD) cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -162,7 +162,7 @@ struct HeunFinalOp {
         o.v[j] = (y.v[j] + dt * a.v[j]) + ((p0 + p1) * (T)0.5);
       }
     }
-    store<T, W>(y1, i, o);
+    store<T, W, NT>(y1, i, o);
   }
 };
 
@@ -174,12 +174,12 @@ hipError_t launch_heun_final(void* y1, const void* y0, const void* f, const void
   if (prod) {
     HeunFinalOp<T, true> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, (T)dt, mode,
                             CellNoise<T>{}};
-    return launch_elementwise(op, n, vec, s);
+    return launch_elementwise(op, n, vec, s, sizeof(T));
   }
   HeunFinalOp<T, false> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, (T)dt, mode,
                            rh_noise<T>(nz)};
   vec = vec && rh_noise_vec(nz);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 // ---- Davie / Foster approximation of the Levy area of one interval (brownian_interval.py:78-99) ------------------
@@ -262,7 +262,7 @@ hipError_t launch_rheun_z(void* z1, const void* y0, const void* z0, const void* 
   RheunZOp<T> op{(T*)z1, (const T*)y0, (const T*)z0, (const T*)f0, (const T*)g0, (T)dt, (T)sgn, rh_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(z1) && aligned16(y0) && aligned16(z0) && aligned16(f0) && aligned16(g0) &&
                    rh_noise_vec(nz);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -272,14 +272,14 @@ hipError_t launch_rheun_y(void* y1, const void* y0, const void* f0, const void* 
                  (const T*)g1, (T)half_dt,   (T)sgn,       rh_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f0) && aligned16(f1) && aligned16(g0) &&
                    aligned16(g1) && rh_noise_vec(nz);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
 hipError_t launch_lincomb2(void* out, const void* x, const void* y, int64_t n, double a, double b, hipStream_t s) {
   Lincomb2Op<T> op{(T*)out, (const T*)x, (const T*)y, (T)a, (T)b};
   const bool vec = (n % 4 == 0) && aligned16(out) && aligned16(x) && aligned16(y);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -288,7 +288,7 @@ hipError_t launch_rheun_adj_a(void* af0_out, void* ag0_out, const void* ay, cons
   RheunAdjAOp<T> op{(T*)af0_out, (T*)ag0_out, (const T*)ay, (const T*)af0, (const T*)ag0, (T)half_dt, rh_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(af0_out) && aligned16(ag0_out) && aligned16(ay) && aligned16(af0) &&
                    aligned16(ag0) && rh_noise_vec(nz);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -299,7 +299,7 @@ hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const 
                     (T)dt,   (T)half_dt, rh_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(ay1) && aligned16(az1) && aligned16(af1) && aligned16(ag1) &&
                    aligned16(ay) && aligned16(az0) && aligned16(vjp_z) && rh_noise_vec(nz);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 #define TSDE_RH_INSTANTIATE(T)                                                                                       \

@@ -19,14 +19,14 @@ struct StepDiagOp {
   const T *y0, *f, *g;
   T cf, cg;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(g, i);
+    const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + b.v[j] * cf) + cg * (c.v[j] * w.v[j]);
-    store<T, W>(y1, i, o);
+    store<T, W, NT>(y1, i, o);
   }
 };
 
@@ -36,13 +36,13 @@ struct StepProdOp {
   T* y1;
   const T *y0, *f, *gp;
   T cf, cg;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(gp, i);
+    const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(gp, i);
     Pack<T, W> o;
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + b.v[j] * cf) + cg * c.v[j];
-    store<T, W>(y1, i, o);
+    store<T, W, NT>(y1, i, o);
   }
 };
 
@@ -51,16 +51,16 @@ template <typename T>
 struct CellIncrementOp {
   T *W_out, *U_out;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
     Pack<T, W> w, u;
     if (U_out) {
       cell_noise<T, W, true>(nz, i, w, u);
-      store<T, W>(U_out, i, u);
+      store<T, W, NT>(U_out, i, u);
     } else {
       cell_noise<T, W, false>(nz, i, w, u);
     }
-    store<T, W>(W_out, i, w);
+    store<T, W, NT>(W_out, i, w);
   }
 };
 
@@ -71,7 +71,7 @@ struct MilsteinVOp {
   T dt, scale;
   int ito;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
@@ -80,8 +80,8 @@ struct MilsteinVOp {
       const T sq = w.v[j] * w.v[j];
       o.v[j] = scale * (ito ? (sq - dt) : sq);
     }
-    store<T, W>(v_out, i, o);
-    if (W_out) store<T, W>(W_out, i, w);
+    store<T, W, NT>(v_out, i, o);
+    if (W_out) store<T, W, NT>(W_out, i, w);
   }
 };
 
@@ -91,14 +91,14 @@ struct MilsteinDiagOp {
   const T *y0, *f, *g, *gdg;
   T dt;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(g, i), d = load<T, W>(gdg, i);
+    const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i), d = load<T, W, NT>(gdg, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = ((a.v[j] + b.v[j] * dt) + c.v[j] * w.v[j]) + d.v[j];
-    store<T, W>(y1, i, o);
+    store<T, W, NT>(y1, i, o);
   }
 };
 
@@ -108,19 +108,19 @@ struct MilsteinGfPrimeOp {
   const T *y0, *f, *g;
   T dt, sqrt_dt;
   int ito;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(y0, i), c = load<T, W>(g, i);
+    const Pack<T, W> a = load<T, W, NT>(y0, i), c = load<T, W, NT>(g, i);
     Pack<T, W> o;
     if (ito) {
-      const Pack<T, W> b = load<T, W>(f, i);
+      const Pack<T, W> b = load<T, W, NT>(f, i);
 #pragma unroll
       for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + dt * b.v[j]) + c.v[j] * sqrt_dt;
     } else {
 #pragma unroll
       for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + (T)0) + c.v[j] * sqrt_dt;
     }
-    store<T, W>(yp, i, o);
+    store<T, W, NT>(yp, i, o);
   }
 };
 
@@ -131,9 +131,9 @@ struct MilsteinGfDiagOp {
   T dt, two_sqrt_dt;
   int ito;
   CellNoise<T> nz;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(y0, i), b = load<T, W>(f, i), c = load<T, W>(g, i), d = load<T, W>(gp, i);
+    const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i), d = load<T, W, NT>(gp, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
@@ -143,7 +143,7 @@ struct MilsteinGfDiagOp {
       const T gdg = ((d.v[j] - c.v[j]) * v) / two_sqrt_dt;
       o.v[j] = ((a.v[j] + b.v[j] * dt) + c.v[j] * w.v[j]) + gdg;
     }
-    store<T, W>(y1, i, o);
+    store<T, W, NT>(y1, i, o);
   }
 };
 
@@ -197,9 +197,9 @@ struct SrkDiagOp {
   T dt, rdt, sqrt_dt;
   CellNoise<T> nz;
 
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> y = load<T, W>(y0, i);
+    const Pack<T, W> y = load<T, W, NT>(y0, i);
     Pack<T, W> w, u;
     cell_noise<T, W, true>(nz, i, w, u);
     if constexpr (STAGE < 4) {
@@ -210,8 +210,8 @@ struct SrkDiagOp {
 #pragma unroll
       for (int j = 0; j < s; ++j) {
         const bool need_f = (Srid2::A0(s, j) != 0.0) || (Srid2::A1(s, j) != 0.0);
-        if (need_f) fj[j] = load<T, W>(fs[j], i);
-        gj[j] = load<T, W>(gs[j], i);
+        if (need_f) fj[j] = load<T, W, NT>(fs[j], i);
+        gj[j] = load<T, W, NT>(gs[j], i);
       }
       Pack<T, W> h0 = y, h1 = y;
 #pragma unroll
@@ -225,16 +225,16 @@ struct SrkDiagOp {
           h1.v[k] = (h1.v[k] + ((T)Srid2::A1(s, j) * f) * dt) + ((T)Srid2::B1(s, j) * g) * sqrt_dt;
         }
       }
-      if (out0) store<T, W>(out0, i, h0);
-      if (out1) store<T, W>(out1, i, h1);
+      if (out0) store<T, W, NT>(out0, i, h0);
+      if (out1) store<T, W, NT>(out1, i, h1);
     } else {
       // y1 = y0 + sum_s [alpha_s f_s dt + g_s * g_weight_s]   (srk.py:79-87); alpha_3 = 0 so f_3 is skipped.
       Pack<T, W> acc = y;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const Pack<T, W> g = load<T, W>(gs[s], i);
+        const Pack<T, W> g = load<T, W, NT>(gs[s], i);
         Pack<T, W> f;
-        if (s < 3) f = load<T, W>(fs[s], i);
+        if (s < 3) f = load<T, W, NT>(fs[s], i);
 #pragma unroll
         for (int k = 0; k < W; ++k) {
           const T Ik = w.v[k];
@@ -247,7 +247,7 @@ struct SrkDiagOp {
           acc.v[k] = (acc.v[k] + drift) + g.v[k] * gw;
         }
       }
-      store<T, W>(out0, i, acc);
+      store<T, W, NT>(out0, i, acc);
     }
   }
 };
@@ -258,25 +258,25 @@ struct AugSegOp {
   T* out;
   const T *s, *F, *G, *D;
   T cF, cG, sF, sG, sD;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    Pack<T, W> o = load<T, W>(s, i);
+    Pack<T, W> o = load<T, W, NT>(s, i);
     if (F) {
-      const Pack<T, W> x = load<T, W>(F, i);
+      const Pack<T, W> x = load<T, W, NT>(F, i);
 #pragma unroll
       for (int j = 0; j < W; ++j) o.v[j] = o.v[j] + sF * (x.v[j] * cF);
     }
     if (G) {
-      const Pack<T, W> x = load<T, W>(G, i);
+      const Pack<T, W> x = load<T, W, NT>(G, i);
 #pragma unroll
       for (int j = 0; j < W; ++j) o.v[j] = o.v[j] + sG * (cG * x.v[j]);
     }
     if (D) {
-      const Pack<T, W> x = load<T, W>(D, i);
+      const Pack<T, W> x = load<T, W, NT>(D, i);
 #pragma unroll
       for (int j = 0; j < W; ++j) o.v[j] = o.v[j] + sD * x.v[j];
     }
-    store<T, W>(out, i, o);
+    store<T, W, NT>(out, i, o);
   }
 };
 
@@ -316,13 +316,13 @@ struct InterpOp {
   T* out;
   const T *ya, *yb;
   T w0, w1;
-  template <int W>
+  template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
-    const Pack<T, W> a = load<T, W>(ya, i), b = load<T, W>(yb, i);
+    const Pack<T, W> a = load<T, W, NT>(ya, i), b = load<T, W, NT>(yb, i);
     Pack<T, W> o;
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = w0 * a.v[j] + w1 * b.v[j];
-    store<T, W>(out, i, o);
+    store<T, W, NT>(out, i, o);
   }
 };
 
@@ -566,14 +566,14 @@ hipError_t launch_step_diag(void* y1, const void* y0, const void* f, const void*
   StepDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (T)cf, (T)cg, make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) &&
                    noise_vec_ok(nz, false);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
 hipError_t launch_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* nz, hipStream_t s) {
   CellIncrementOp<T> op{(T*)W_out, (T*)U_out, make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(W_out) && (!U_out || aligned16(U_out)) && (nz->elem0 % 4 == 0);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -581,7 +581,7 @@ hipError_t launch_step_prod(void* y1, const void* y0, const void* f, const void*
                             hipStream_t s) {
   StepProdOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)gp, (T)cf, (T)cg};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(gp);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -589,7 +589,7 @@ hipError_t launch_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int
                              const tsde_noise_t* nz, hipStream_t s) {
   MilsteinVOp<T> op{(T*)v_out, (T*)W_out, (T)dt, (T)scale, ito, make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(v_out) && (!W_out || aligned16(W_out)) && noise_vec_ok(nz, false);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -598,7 +598,7 @@ hipError_t launch_milstein_diag(void* y1, const void* y0, const void* f, const v
   MilsteinDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gdg, (T)dt, make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) && aligned16(gdg) &&
                    noise_vec_ok(nz, false);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -606,7 +606,7 @@ hipError_t launch_milstein_gf_prime(void* yp, const void* y0, const void* f, con
                                     double sqrt_dt, int ito, hipStream_t s) {
   MilsteinGfPrimeOp<T> op{(T*)yp, (const T*)y0, (const T*)f, (const T*)g, (T)dt, (T)sqrt_dt, ito};
   const bool vec = (n % 4 == 0) && aligned16(yp) && aligned16(y0) && aligned16(f) && aligned16(g);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -618,7 +618,7 @@ hipError_t launch_milstein_gf_diag(void* y1, const void* y0, const void* f, cons
                          make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) && aligned16(gp) &&
                    noise_vec_ok(nz, false);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T, int STAGE>
@@ -640,7 +640,7 @@ static hipError_t launch_srk_stage_t(void* out0, void* out1, const void* y0, con
   op.rdt = (T)rdt;
   op.sqrt_dt = (T)sqrt_dt;
   op.nz = make_noise<T>(nz);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -691,7 +691,7 @@ template <typename T>
 hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s) {
   InterpOp<T> op{(T*)out, (const T*)ya, (const T*)yb, (T)w0, (T)w1};
   const bool vec = (n % 4 == 0) && aligned16(out) && aligned16(ya) && aligned16(yb);
-  return launch_elementwise(op, n, vec, s);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tsde_bridge.h"
 #include "tsde_rng.h"
@@ -17,15 +18,22 @@ struct Pack {
   T v[W];
 };
 
-template <typename T, int W>
+typedef float tsde_f4 __attribute__((ext_vector_type(4)));
+typedef double tsde_d2 __attribute__((ext_vector_type(2)));
+
+// NT = nontemporal (streaming) access: used when the kernel's streams exceed the 256 MiB Infinity Cache, where it
+// is worth +30 % (tools/microbench_seq.hip at 1M rows: 216 -> 166 us); inside the cache it costs 5-8 %.
+template <typename T, int W, bool NT = false>
 TSDE_D Pack<T, W> load(const T* __restrict__ p, int64_t i) {
   Pack<T, W> r;
   if constexpr (W == 4 && sizeof(T) == 4) {
-    const float4 q = *reinterpret_cast<const float4*>(p + i);
+    const tsde_f4* q4 = reinterpret_cast<const tsde_f4*>(p + i);
+    const tsde_f4 q = NT ? __builtin_nontemporal_load(q4) : *q4;
     r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
   } else if constexpr (W == 4 && sizeof(T) == 8) {
-    const double2 q0 = *reinterpret_cast<const double2*>(p + i);
-    const double2 q1 = *reinterpret_cast<const double2*>(p + i + 2);
+    const tsde_d2* q2 = reinterpret_cast<const tsde_d2*>(p + i);
+    const tsde_d2 q0 = NT ? __builtin_nontemporal_load(q2) : q2[0];
+    const tsde_d2 q1 = NT ? __builtin_nontemporal_load(q2 + 1) : q2[1];
     r.v[0] = q0.x; r.v[1] = q0.y; r.v[2] = q1.x; r.v[3] = q1.y;
   } else {
 #pragma unroll
@@ -34,13 +42,21 @@ TSDE_D Pack<T, W> load(const T* __restrict__ p, int64_t i) {
   return r;
 }
 
-template <typename T, int W>
+template <typename T, int W, bool NT = false>
 TSDE_D void store(T* __restrict__ p, int64_t i, const Pack<T, W>& r) {
   if constexpr (W == 4 && sizeof(T) == 4) {
-    *reinterpret_cast<float4*>(p + i) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    const tsde_f4 q = {r.v[0], r.v[1], r.v[2], r.v[3]};
+    if (NT) __builtin_nontemporal_store(q, reinterpret_cast<tsde_f4*>(p + i));
+    else *reinterpret_cast<tsde_f4*>(p + i) = q;
   } else if constexpr (W == 4 && sizeof(T) == 8) {
-    *reinterpret_cast<double2*>(p + i) = make_double2(r.v[0], r.v[1]);
-    *reinterpret_cast<double2*>(p + i + 2) = make_double2(r.v[2], r.v[3]);
+    const tsde_d2 q0 = {r.v[0], r.v[1]}, q1 = {r.v[2], r.v[3]};
+    if (NT) {
+      __builtin_nontemporal_store(q0, reinterpret_cast<tsde_d2*>(p + i));
+      __builtin_nontemporal_store(q1, reinterpret_cast<tsde_d2*>(p + i) + 1);
+    } else {
+      reinterpret_cast<tsde_d2*>(p + i)[0] = q0;
+      reinterpret_cast<tsde_d2*>(p + i)[1] = q1;
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < W; ++j) p[i + j] = r.v[j];
@@ -130,7 +146,7 @@ inline int grid_for(int64_t work_items) {
 // Vector path tiling: a block owns QPT * 256 CONSECUTIVE 16-byte groups. Measured in situ on MI355X
 // (tools/microbench_seq.hip, C2 shapes, between producer kernels): QPT=2 -> 12.0 us per step kernel,
 // 1 -> 13.4 us, 4 or 8 -> 13.3-13.7 us. Small problems keep QPT=1 so that every CU still gets >= 8 blocks.
-template <typename Op, int QPT>
+template <typename Op, int QPT, bool NT>
 __global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const int64_t n, const int vec) {
   if (vec) {
     const int64_t nq = n >> 2;
@@ -139,25 +155,40 @@ __global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const 
 #pragma unroll
       for (int u = 0; u < QPT; ++u) {
         const int64_t q = base + (int64_t)u * kBlock + threadIdx.x;
-        if (q < nq) op.template run<4>(q << 2);
+        if (q < nq) op.template run<4, NT>(q << 2);
       }
     }
   } else {
     const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = tid; i < n; i += stride) op.template run<1>(i);
+    for (int64_t i = tid; i < n; i += stride) op.template run<1, false>(i);
   }
 }
 
+// Per-stream size above which the streaming (nontemporal, uncapped-grid) variant is used: 96 MiB per stream, i.e.
+// a 4-stream kernel whose live data no longer fits the 256 MiB Infinity Cache. TSDE_FORCE_NT=1 forces it (tests).
+inline bool use_streaming_variant(int64_t n, size_t elem_size) {
+  static const int forced = [] {
+    const char* e = getenv("TSDE_FORCE_NT");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return forced || (uint64_t)n * elem_size >= (96ull << 20);
+}
+
 template <typename Op>
-inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStream_t stream) {
+inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStream_t stream, size_t elem_size = 4) {
   if (n <= 0) return hipSuccess;
   const int64_t nq = n >> 2;
-  if (vec && nq >= (int64_t)2 * kBlock * kMaxGrid) {
-    hipLaunchKernelGGL((elementwise_kernel<Op, 2>), dim3(grid_for((nq + 1) / 2)), dim3(kBlock), 0, stream, op, n, 1);
+  if (vec && use_streaming_variant(n, elem_size)) {
+    int64_t blocks = (nq + kBlock - 1) / kBlock;                 // one 16-B group per thread, no grid cap
+    if (blocks > (1 << 30)) blocks = 1 << 30;
+    hipLaunchKernelGGL((elementwise_kernel<Op, 1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, op, n, 1);
+  } else if (vec && nq >= (int64_t)2 * kBlock * kMaxGrid) {
+    hipLaunchKernelGGL((elementwise_kernel<Op, 2, false>), dim3(grid_for((nq + 1) / 2)), dim3(kBlock), 0, stream, op,
+                       n, 1);
   } else {
-    hipLaunchKernelGGL((elementwise_kernel<Op, 1>), dim3(grid_for(vec ? nq : n)), dim3(kBlock), 0, stream, op, n,
-                       vec ? 1 : 0);
+    hipLaunchKernelGGL((elementwise_kernel<Op, 1, false>), dim3(grid_for(vec ? nq : n)), dim3(kBlock), 0, stream, op,
+                       n, vec ? 1 : 0);
   }
   return hipGetLastError();
 }
