@@ -16,6 +16,8 @@
  *   tsde_rheun_*         _core/methods/reversible_heun.py:48-144 (reversible Heun and its adjoint)
  *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
  *   tsde_linear_interp   _core/interp.py:15-18
+ *   tsde_trajectory_*    _core/base_solver.py:114-134 (the whole stepping loop of `integrate`) for SDEs whose
+ *                        drift and diffusion are given in closed form instead of as Python callables
  *
  * Conventions
  *   - all tensors are contiguous row-major device buffers; `dtype` is TSDE_F32 or TSDE_F64;
@@ -68,6 +70,21 @@ typedef struct tsde_seg {
   int64_t n;
   double sF, sG, sD; /* +1 / -1: the reference negates f and g_prod for the y segment */
 } tsde_seg_t;
+
+/* The step schedule of one whole solve, for the trajectory kernels (all DEVICE pointers).
+ * Row k of `step_rows` holds, already rounded to `dtype` exactly as the per-step entry points round their
+ * double arguments:  dt_k, dt_k/2, 1/dt_k, sqrt(dt_k), sqrt(h_k), sqrt(h_k/12), h_k, 0   (h_k = width of
+ * Brownian cell `cells[k]`; step k must cover exactly that cell). Output j (the j-th requested time after
+ * t0) is written once `out_step[j]` steps are complete, as w0*y_prev + w1*y_curr with the weights of row j
+ * of `out_w` ((0,1) = the step lands on the output time). `out_step` is ascending. */
+typedef struct tsde_traj {
+  const void* step_rows;   /* [n_steps][8], dtype */
+  const uint32_t* cells;   /* [n_steps] */
+  const int32_t* out_step; /* [n_out] */
+  const void* out_w;       /* [n_out][2], dtype */
+  int32_t n_steps;
+  int32_t n_out;
+} tsde_traj_t;
 
 int tsde_abi_version(void);
 const char* tsde_last_error(void);
@@ -191,6 +208,25 @@ int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int 
 int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, int dtype,
                        void* stream);
 
+/* ---- whole-trajectory kernels (closed-form SDEs) ---------------------------------------------- */
+#define TSDE_TRAJ_EULER 0
+#define TSDE_TRAJ_MILSTEIN_ITO 1
+#define TSDE_TRAJ_MILSTEIN_STRAT 2
+#define TSDE_TRAJ_MIDPOINT 3
+#define TSDE_TRAJ_SRK 4
+
+/* All `traj->n_steps` fixed steps of a diagonal-noise SDE with per-channel affine drift and diffusion
+ *   f(t, y) = drift_rate * y + drift_shift,   g(t, y) = diff_rate * y + diff_shift      (each of length d)
+ * in ONE launch: y0 (rows, d) is read once, the state stays in registers, every step's increment is the
+ * generated cell (entropy, elem0 + i, cells[k]) of the counter RNG, and only the requested outputs
+ * ys (n_out, rows, d) are written. `method` is one of TSDE_TRAJ_*. Results are bit-identical to driving
+ * tsde_step_diag / tsde_milstein_diag / tsde_srk_diag_stage step by step with f, g evaluated as
+ * (rate * y) + shift. */
+int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
+                                const void* drift_shift, const void* diff_rate, const void* diff_shift, int method,
+                                const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
 #define TSDE_KID_STEP_DIAG 1
 #define TSDE_KID_STEP_GENERAL 2
@@ -199,6 +235,7 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
 #define TSDE_KID_AUG_UPDATE 5
 #define TSDE_KID_BROWNIAN_QUERY 6
 #define TSDE_KID_RHEUN 7
+#define TSDE_KID_TRAJECTORY 8
 /* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
 int tsde_prof_begin(int kid, int capacity);
 /* Occupies `stream` with a single-thread kernel for about `microseconds` (<= 2 s). bench.py queues one before

@@ -1,0 +1,153 @@
+"""GPU parity of the whole-trajectory kernel (``tsde_trajectory_affine_diag``; run with ``-m gpu``): bit-identical
+to the stepwise path (same SDE evaluated by torch ops between the per-step kernels), equal to the oracle's
+restatement of the reference's solvers on the C twin of the generator, sharding-invariant, and transparent
+(falls back to the stepwise path whenever gradients or foreign Brownian motions are involved)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+METHODS = [("euler", "ito"), ("milstein", "ito"), ("milstein", "stratonovich"), ("midpoint", "stratonovich"),
+           ("srk", "ito")]
+
+
+def _sde(d, dtype, sde_type, device=DEV, scalar_coefficients=False):
+    import torchsde_amd
+    if scalar_coefficients:
+        coefs = (0.3, -0.1, 0.4, 0.05)
+    else:
+        gen = torch.Generator().manual_seed(7)
+        coefs = tuple(torch.rand(d, generator=gen, dtype=torch.float64) * s + o
+                      for s, o in ((0.6, -0.3), (0.4, -0.2), (0.5, 0.1), (0.2, -0.1)))
+    return torchsde_amd.AffineDiagonalSDE(*coefs, sde_type=sde_type, dtype=dtype, device=device)
+
+
+def _solve(sde, y0, ts, method, dt, entropy, trajectory, row_offset=0, **kw):
+    import torchsde_amd
+    levy = "space-time" if method == "srk" else "none"
+    bm = torchsde_amd.BrownianInterval(float(ts[0]), float(ts[-1]), size=tuple(y0.shape), dtype=y0.dtype, device=DEV,
+                                       entropy=entropy, levy_area_approximation=levy, row_offset=row_offset)
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt,
+                                   options={"trajectory_kernel": trajectory}, **kw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(8192, 64), (33, 5), (16, 8)])       # 16-byte-group path, scalar paths
+@pytest.mark.parametrize("method,sde_type", METHODS)
+def test_trajectory_kernel_is_bit_identical_to_stepwise_path(method, sde_type, shape, dtype):
+    B, d = shape
+    sde = _sde(d, dtype, sde_type)
+    y0 = torch.linspace(0.5, 1.5, B * d, dtype=dtype, device=DEV).reshape(B, d)
+    # output times on and off the step grid (off-grid ones are interpolated inside a step), ragged last step
+    ts = torch.tensor([0.0, 0.1, 0.25, 0.26, 0.7, 1.03], dtype=dtype, device=DEV)
+    a = _solve(sde, y0, ts, method, 0.05, 11, trajectory=True)
+    b = _solve(sde, y0, ts, method, 0.05, 11, trajectory=False)
+    assert a.shape == (6, B, d) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("method,sde_type", METHODS)
+def test_trajectory_kernel_matches_oracle(method, sde_type):
+    """The oracle's restatement of the reference's step functions (pinned to the real reference by the golden
+    fixtures) driven by the C twin of the counter generator; float64."""
+    from oracle import counter, solvers_ref
+    B, d, dt, steps = 24, 8, 2.0 ** -5, 20
+    dtype = torch.float64
+    levy = method == "srk"
+    ts_list = [0.0, 5 * dt, 7.5 * dt, steps * dt]
+    edges = np.arange(steps + 1) * dt
+
+    def bm_cpu(ta, tb, return_U=False, return_A=False):
+        W, U, _ = counter.query(B * d, 2024, edges, float(ta), float(tb), dtype=np.float64, have_h=levy)
+        W = torch.from_numpy(W).reshape(B, d)
+        return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+    sde_cpu = _sde(d, dtype, sde_type, device="cpu")
+    y0 = torch.linspace(0.5, 1.5, B * d, dtype=dtype).reshape(B, d)
+    with torch.no_grad():
+        ref = solvers_ref.integrate(sde_cpu, bm_cpu, y0, torch.tensor(ts_list, dtype=dtype), dt, method)
+    got = _solve(_sde(d, dtype, sde_type), y0.to(DEV), torch.tensor(ts_list, dtype=dtype, device=DEV), method, dt,
+                 2024, trajectory=True)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-12, atol=1e-13)
+
+
+def test_trajectory_kernel_is_sharding_invariant():
+    """Rows [r0, r1) solved with `row_offset=r0` equal the same rows of the full solve (counter RNG addressing)."""
+    B, d = 8192, 64
+    sde = _sde(d, torch.float32, "ito")
+    y0 = torch.linspace(0.5, 1.5, B * d, device=DEV).reshape(B, d)
+    ts = torch.tensor([0.0, 0.5, 1.0], device=DEV)
+    full = _solve(sde, y0, ts, "euler", 0.05, 5, trajectory=True)
+    lo = _solve(sde, y0[:4096], ts, "euler", 0.05, 5, trajectory=True)
+    hi = _solve(sde, y0[4096:], ts, "euler", 0.05, 5, trajectory=True, row_offset=4096)
+    odd = _solve(sde, y0[4097:4100], ts, "euler", 0.05, 5, trajectory=True, row_offset=4097)
+    assert torch.equal(full[:, :4096], lo) and torch.equal(full[:, 4096:], hi)
+    assert torch.equal(full[:, 4097:4100], odd)
+
+
+def test_scalar_coefficients_and_fp32_time_grid():
+    """Scalar (0-d) coefficients broadcast over the channels; float32 dt=1e-3 over [0,1] takes 1001 steps like
+    the reference's loop, and the trajectory kernel follows the same grid."""
+    B, d = 64, 16
+    sde = _sde(d, torch.float32, "ito", scalar_coefficients=True)
+    y0 = torch.full((B, d), 1.0, device=DEV)
+    ts = torch.tensor([0.0, 1.0], device=DEV)
+    a = _solve(sde, y0, ts, "euler", 1e-3, 3, trajectory=True)
+    b = _solve(sde, y0, ts, "euler", 1e-3, 3, trajectory=False)
+    assert torch.equal(a, b)
+
+
+def test_geometric_brownian_motion_moments():
+    """E[y_T] = y0 exp(mu T) and Var[log y_T] = sigma^2 T for GBM: the kernel's increments have the right law."""
+    import torchsde_amd
+    B, d, mu, sigma = 65536, 8, 0.3, 0.4
+    sde = torchsde_amd.AffineDiagonalSDE(mu, 0.0, sigma, 0.0, dtype=torch.float32, device=DEV)
+    y0 = torch.ones(B, d, device=DEV)
+    ys = _solve(sde, y0, torch.tensor([0.0, 1.0], device=DEV), "milstein", 2.0 ** -7, 99, trajectory=True)
+    mean = ys[-1].double().mean().item()
+    var_log = ys[-1].double().log().var().item()
+    n = B * d
+    assert abs(mean - np.exp(mu)) < 5 * np.exp(mu) * np.sqrt((np.exp(sigma ** 2) - 1) / n) + 2e-3
+    assert abs(var_log - sigma ** 2) < 0.02 * sigma ** 2
+
+
+def test_falls_back_to_stepwise_path_when_it_must():
+    """Gradients through the solver, a foreign Brownian motion or `names=` remapping use the stepwise path and
+    still work; the adjoint works on the closed-form SDE like on any other module."""
+    import torchsde_amd
+    B, d = 32, 8
+    dtype = torch.float64
+    sde = _sde(d, dtype, "ito")
+    y0 = torch.full((B, d), 0.7, dtype=dtype, device=DEV, requires_grad=True)
+    ts = torch.tensor([0.0, 0.5], dtype=dtype, device=DEV)
+    kw = dict(t0=0.0, t1=0.5, size=(B, d), dtype=dtype, device=DEV, entropy=8)
+    ys = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="euler", dt=0.05)
+    ys[-1].sum().backward()
+    assert y0.grad is not None and sde.drift_rate.grad is not None
+    with torch.no_grad():
+        fast = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="euler", dt=0.05)
+    assert torch.equal(fast, ys.detach())
+    reverse = torchsde_amd.ReverseBrownian(torchsde_amd.BrownianInterval(**{**kw, "t0": -0.5, "t1": 0.0}))
+    with torch.no_grad():
+        out = torchsde_amd.sdeint(sde, y0, ts, bm=reverse, method="euler", dt=0.05)
+    assert out.shape == (2, B, d) and torch.isfinite(out).all()
+    ys_adj = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="euler", dt=0.05)
+    assert torch.equal(ys_adj.detach(), fast)
+
+
+def test_c_abi_rejects_bad_schedules():
+    from torchsde_amd import _native
+    lib = _native.load()
+    y = torch.zeros(4, 4, device=DEV)
+    c = torch.zeros(4, device=DEV)
+    traj = _native.Traj()
+    traj.n_steps, traj.n_out = 3, 1          # lengths without tables
+    code = lib.tsde_trajectory_affine_diag(y.data_ptr(), y.data_ptr(), 4, 4, c.data_ptr(), c.data_ptr(), c.data_ptr(),
+                                           c.data_ptr(), 0, traj, 1, 0, None, 0, None)
+    assert code != 0 and b"schedule" in lib.tsde_last_error()
+    code = lib.tsde_trajectory_affine_diag(y.data_ptr(), y.data_ptr(), 4, 4, c.data_ptr(), c.data_ptr(), c.data_ptr(),
+                                           c.data_ptr(), 9, traj, 1, 0, None, 0, None)
+    assert code != 0 and b"method" in lib.tsde_last_error()

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtorchsde_amd.so")
 
 F32, F64 = 0, 1
 KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDATE, KID_BROWNIAN_QUERY = 1, 2, 3, 4, 5, 6
+KID_RHEUN, KID_TRAJECTORY = 7, 8
+TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 
 _c_i64 = ctypes.c_int64
 _c_u64 = ctypes.c_uint64
@@ -36,6 +38,12 @@ class Seg(ctypes.Structure):
     """``tsde_seg_t``."""
     _fields_ = [("out", _c_ptr), ("s", _c_ptr), ("F", _c_ptr), ("G", _c_ptr), ("D", _c_ptr), ("n", _c_i64),
                 ("sF", _c_dbl), ("sG", _c_dbl), ("sD", _c_dbl)]
+
+
+class Traj(ctypes.Structure):
+    """``tsde_traj_t``."""
+    _fields_ = [("step_rows", _c_ptr), ("cells", _c_ptr), ("out_step", _c_ptr), ("out_w", _c_ptr),
+                ("n_steps", ctypes.c_int32), ("n_out", ctypes.c_int32)]
 
 
 _PTR4 = _c_ptr * 4
@@ -83,6 +91,8 @@ SIGNATURES = {
                                        ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_aug_update": (_c_int, [ctypes.POINTER(Seg), _c_int, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_linear_interp": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
+    "tsde_trajectory_affine_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
+                                             ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),

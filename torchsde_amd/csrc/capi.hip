@@ -312,6 +312,27 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
                 tsde::launch_interp<double>(out, ya, yb, n, w0, w1, s));
 }
 
+int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
+                                const void* drift_shift, const void* diff_rate, const void* diff_shift, int method,
+                                const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_trajectory_affine_diag";
+  if (!ys || !y0 || !drift_rate || !drift_shift || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
+  if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
+  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
+  if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  TSDE_DISPATCH(dtype, where,
+                tsde::launch_trajectory_affine_diag<float>(ys, y0, rows, d, drift_rate, drift_shift, diff_rate,
+                                                           diff_shift, method, traj, key, entropy_dev, s),
+                tsde::launch_trajectory_affine_diag<double>(ys, y0, rows, d, drift_rate, drift_shift, diff_rate,
+                                                            diff_shift, method, traj, key, entropy_dev, s));
+}
+
 int tsde_prof_begin(int kid, int capacity) {
   if (capacity <= 0) return bad_arg("tsde_prof_begin", "capacity must be positive");
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);

@@ -9,6 +9,7 @@
 //   prod       torchsde/_core/base_sde.py:98-102 (diagonal: g*v; otherwise bmm(g, v))
 #include "tsde_common.h"
 #include "tsde_launch.h"
+#include "tsde_schemes.h"
 
 namespace tsde {
 
@@ -25,7 +26,7 @@ struct StepDiagOp {
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
-    for (int j = 0; j < W; ++j) o.v[j] = (a.v[j] + b.v[j] * cf) + cg * (c.v[j] * w.v[j]);
+    for (int j = 0; j < W; ++j) o.v[j] = drift_diffusion_update<T>(a.v[j], b.v[j], c.v[j], w.v[j], cf, cg);
     store<T, W, NT>(y1, i, o);
   }
 };
@@ -76,10 +77,7 @@ struct MilsteinVOp {
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const T sq = w.v[j] * w.v[j];
-      o.v[j] = scale * (ito ? (sq - dt) : sq);
-    }
+    for (int j = 0; j < W; ++j) o.v[j] = milstein_v<T>(w.v[j], dt, scale, ito);
     store<T, W, NT>(v_out, i, o);
     if (W_out) store<T, W, NT>(W_out, i, w);
   }
@@ -97,7 +95,7 @@ struct MilsteinDiagOp {
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
-    for (int j = 0; j < W; ++j) o.v[j] = ((a.v[j] + b.v[j] * dt) + c.v[j] * w.v[j]) + d.v[j];
+    for (int j = 0; j < W; ++j) o.v[j] = milstein_update<T>(a.v[j], b.v[j], c.v[j], d.v[j], w.v[j], dt);
     store<T, W, NT>(y1, i, o);
   }
 };
@@ -147,47 +145,7 @@ struct MilsteinGfDiagOp {
   }
 };
 
-// ---- SRK (SRID2, diagonal noise) -----------------------------------------------------------------
-// Tableau (srid2.py:21-54); entries are cast to T at use, exactly like `python_float * tensor`.
-struct Srid2 {
-  static TSDE_HD constexpr double A0(int s, int j) {
-    constexpr double t[4][3] = {{0, 0, 0}, {1, 0, 0}, {0.25, 0.25, 0}, {0, 0, 0}};
-    return t[s][j];
-  }
-  static TSDE_HD constexpr double A1(int s, int j) {
-    constexpr double t[4][3] = {{0, 0, 0}, {0.25, 0, 0}, {1, 0, 0}, {0, 0, 0.25}};
-    return t[s][j];
-  }
-  static TSDE_HD constexpr double B0(int s, int j) {
-    constexpr double t[4][3] = {{0, 0, 0}, {0, 0, 0}, {1, 0.5, 0}, {0, 0, 0}};
-    return t[s][j];
-  }
-  static TSDE_HD constexpr double B1(int s, int j) {
-    constexpr double t[4][3] = {{0, 0, 0}, {-0.5, 0, 0}, {1, 0, 0}, {2, -1, 0.5}};
-    return t[s][j];
-  }
-  static TSDE_HD constexpr double alpha(int s) {
-    constexpr double t[4] = {1.0 / 6, 1.0 / 6, 2.0 / 3, 0};
-    return t[s];
-  }
-  static TSDE_HD constexpr double beta1(int s) {
-    constexpr double t[4] = {-1, 4.0 / 3, 2.0 / 3, 0};
-    return t[s];
-  }
-  static TSDE_HD constexpr double beta2(int s) {
-    constexpr double t[4] = {1, -4.0 / 3, 1.0 / 3, 0};
-    return t[s];
-  }
-  static TSDE_HD constexpr double beta3(int s) {
-    constexpr double t[4] = {2, -4.0 / 3, -2.0 / 3, 0};
-    return t[s];
-  }
-  static TSDE_HD constexpr double beta4(int s) {
-    constexpr double t[4] = {-2, 5.0 / 3, -2.0 / 3, 1};
-    return t[s];
-  }
-};
-
+// ---- SRK (SRID2, diagonal noise): tableau and per-element arithmetic live in tsde_schemes.h -----------
 template <typename T, int STAGE>
 struct SrkDiagOp {
   T *out0, *out1;
@@ -203,54 +161,46 @@ struct SrkDiagOp {
     Pack<T, W> w, u;
     cell_noise<T, W, true>(nz, i, w, u);
     if constexpr (STAGE < 4) {
-      // Stage states H0_s, H1_s for s = STAGE (srk.py:69-77). f-terms whose A-coefficient is zero
-      // for every j are not loaded (they only add +0.0).
+      // Stage states H0_s, H1_s for s = STAGE. f-terms whose A-coefficient is zero for every j are not
+      // loaded (they only add +0.0).
       constexpr int s = STAGE;
       Pack<T, W> fj[3], gj[3];
 #pragma unroll
       for (int j = 0; j < s; ++j) {
-        const bool need_f = (Srid2::A0(s, j) != 0.0) || (Srid2::A1(s, j) != 0.0);
-        if (need_f) fj[j] = load<T, W, NT>(fs[j], i);
+        if (Srid2::need_f(s, j)) fj[j] = load<T, W, NT>(fs[j], i);
         gj[j] = load<T, W, NT>(gs[j], i);
       }
-      Pack<T, W> h0 = y, h1 = y;
+      Pack<T, W> h0, h1;
 #pragma unroll
       for (int k = 0; k < W; ++k) {
+        T f[3], g[3];
 #pragma unroll
         for (int j = 0; j < s; ++j) {
-          const bool need_f = (Srid2::A0(s, j) != 0.0) || (Srid2::A1(s, j) != 0.0);
-          const T f = need_f ? fj[j].v[k] : (T)0;
-          const T g = gj[j].v[k];
-          h0.v[k] = (h0.v[k] + ((T)Srid2::A0(s, j) * f) * dt) + (((T)Srid2::B0(s, j) * g) * u.v[k]) * rdt;
-          h1.v[k] = (h1.v[k] + ((T)Srid2::A1(s, j) * f) * dt) + ((T)Srid2::B1(s, j) * g) * sqrt_dt;
+          f[j] = Srid2::need_f(s, j) ? fj[j].v[k] : (T)0;
+          g[j] = gj[j].v[k];
         }
+        srid2_stage_states<T, s>(y.v[k], f, g, u.v[k], dt, rdt, sqrt_dt, h0.v[k], h1.v[k]);
       }
       if (out0) store<T, W, NT>(out0, i, h0);
       if (out1) store<T, W, NT>(out1, i, h1);
     } else {
-      // y1 = y0 + sum_s [alpha_s f_s dt + g_s * g_weight_s]   (srk.py:79-87); alpha_3 = 0 so f_3 is skipped.
-      Pack<T, W> acc = y;
+      Pack<T, W> fj[3], gj[4], acc;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const Pack<T, W> g = load<T, W, NT>(gs[s], i);
-        Pack<T, W> f;
-        if (s < 3) f = load<T, W, NT>(fs[s], i);
+        gj[s] = load<T, W, NT>(gs[s], i);
+        if (s < 3) fj[s] = load<T, W, NT>(fs[s], i);
+      }
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-          const T Ik = w.v[k];
-          const T Ikk = (Ik * Ik - dt) * (T)0.5;
-          const T Ikkk = ((Ik * Ik) * Ik - ((T)3 * dt) * Ik) * (T)(1.0 / 6);
-          const T gw = ((((T)Srid2::beta1(s) * Ik) + ((T)Srid2::beta2(s) * Ikk) / sqrt_dt) +
-                        ((T)Srid2::beta3(s) * u.v[k]) * rdt) +
-                       ((T)Srid2::beta4(s) * Ikkk) * rdt;
-          const T drift = (s < 3) ? ((T)Srid2::alpha(s) * f.v[k]) * dt : (T)0;
-          acc.v[k] = (acc.v[k] + drift) + g.v[k] * gw;
-        }
+      for (int k = 0; k < W; ++k) {
+        const T f[3] = {fj[0].v[k], fj[1].v[k], fj[2].v[k]};
+        const T g[4] = {gj[0].v[k], gj[1].v[k], gj[2].v[k], gj[3].v[k]};
+        acc.v[k] = srid2_final<T>(y.v[k], f, g, w.v[k], u.v[k], dt, rdt, sqrt_dt);
       }
       store<T, W, NT>(out0, i, acc);
     }
   }
 };
+
 
 // ---- adjoint augmented-state update ----------------------------------------------------------------
 template <typename T>

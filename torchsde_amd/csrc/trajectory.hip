@@ -1,0 +1,197 @@
+// Whole-trajectory kernel for closed-form diagonal SDEs on gfx950.
+//
+// When drift and diffusion are known in closed form (affine here: f = a*y + b, g = c*y + e, per state channel),
+// nothing in the reference's stepping loop (torchsde/_core/base_solver.py:114-134) has to leave the chip between
+// steps: every (batch row, channel) element is an independent scalar recursion. One lane owns 4 consecutive
+// elements, keeps them in registers for ALL steps of the solve, draws each step's Brownian increment from the
+// counter RNG (the same (entropy, element, cell) field the per-step kernels use) and only touches HBM to read
+// y0 and to write the requested output times. HBM traffic drops from 4 streams per step to ~0, and the bound
+// becomes the Philox/Box-Muller ALU work.
+//
+// The arithmetic is the per-step kernels' arithmetic (tsde_schemes.h), so the results are bit-identical to the
+// stepwise path with the same SDE evaluated by torch ops:
+//   Euler      _core/methods/euler.py:31-36         Midpoint  _core/methods/midpoint.py:31-43
+//   Milstein   _core/methods/milstein.py:52-74      SRK       _core/methods/srk.py:57-88 (SRID2)
+//   outputs    _core/base_solver.py:131-134 + _core/interp.py:19-26 (linear interpolation inside a step)
+#include "tsde_common.h"
+#include "tsde_launch.h"
+#include "tsde_schemes.h"
+
+namespace tsde {
+
+template <typename T>
+struct TrajArgs {
+  T* ys;                    // (n_out, n) outputs after t0
+  const T* y0;              // (n)
+  const T *a, *b, *c, *e;   // (d) per-channel coefficients
+  const T* rows;            // (n_steps, 8): dt, dt/2, 1/dt, sqrt(dt), sqrt(h), sqrt(h/12), h, 0
+  const uint32_t* cells;    // (n_steps)
+  const int32_t* out_step;  // (n_out) ascending: output j is due once `out_step[j]` steps are complete
+  const T* out_w;           // (n_out, 2) weights on (previous state, current state)
+  int64_t n, d;
+  int32_t n_steps, n_out;
+  NoiseKey key;
+  const uint64_t* key_dev;
+};
+
+enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStrat = TSDE_TRAJ_MILSTEIN_STRAT,
+             kMidpoint = TSDE_TRAJ_MIDPOINT, kSrk = TSDE_TRAJ_SRK };
+
+// One step of one element. `w` = W, `u` = U (SRK only).
+template <typename T, int METHOD>
+TSDE_D T affine_step(const T y, const T a, const T b, const T c, const T e, const T w, const T u, const T dt,
+                     const T half_dt, const T rdt, const T sqrt_dt) {
+  auto F = [&](T x) { return a * x + b; };
+  auto G = [&](T x) { return c * x + e; };
+  if constexpr (METHOD == kEuler) {
+    return drift_diffusion_update<T>(y, F(y), G(y), w, dt, (T)1);
+  } else if constexpr (METHOD == kMilIto || METHOD == kMilStrat) {
+    const T v2 = milstein_v<T>(w, dt, (T)0.5, METHOD == kMilIto);
+    const T g = G(y);
+    const T gdg = (g * v2) * c;        // vjp of y -> c*y + e with cotangent g*v2 (base_sde.py:147-152)
+    return milstein_update<T>(y, F(y), g, gdg, w, dt);
+  } else if constexpr (METHOD == kMidpoint) {
+    const T yp = drift_diffusion_update<T>(y, F(y), G(y), w, half_dt, (T)0.5);
+    return drift_diffusion_update<T>(y, F(yp), G(yp), w, dt, (T)1);
+  } else {
+    T f[3], g[4], h0, h1;
+    T fz[3] = {(T)0, (T)0, (T)0};
+    f[0] = F(y);
+    g[0] = G(y);
+    fz[0] = Srid2::need_f(1, 0) ? f[0] : (T)0;
+    srid2_stage_states<T, 1>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
+    f[1] = F(h0);
+    g[1] = G(h1);
+    fz[0] = Srid2::need_f(2, 0) ? f[0] : (T)0;
+    fz[1] = Srid2::need_f(2, 1) ? f[1] : (T)0;
+    srid2_stage_states<T, 2>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
+    f[2] = F(h0);
+    g[2] = G(h1);
+    fz[0] = Srid2::need_f(3, 0) ? f[0] : (T)0;
+    fz[1] = Srid2::need_f(3, 1) ? f[1] : (T)0;
+    fz[2] = Srid2::need_f(3, 2) ? f[2] : (T)0;
+    srid2_stage_states<T, 3>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
+    g[3] = G(h1);
+    return srid2_final<T>(y, f, g, w, u, dt, rdt, sqrt_dt);
+  }
+}
+
+// W = 4: a lane owns one 16-byte group (needs d % 4 == 0 so the group stays inside one row).
+// W = 1: a lane owns one element (any d; also used for small problems, where it exposes 4x the lanes).
+template <typename T, int METHOD, int W>
+__global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p) {
+  constexpr bool kNeedU = METHOD == kSrk;
+  const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = lane * W;
+  if (i >= p.n) return;
+  const int64_t col = i % p.d;
+  const Pack<T, W> a = load<T, W>(p.a, col), b = load<T, W>(p.b, col), c = load<T, W>(p.c, col),
+                   e = load<T, W>(p.e, col);
+  Pack<T, W> y = load<T, W>(p.y0, i);
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+  const uint64_t elem = key.elem0 + (uint64_t)i;
+  int j = 0;
+  for (int k = 0; k < p.n_steps; ++k) {
+    const T* row = p.rows + (int64_t)k * 8;   // wave-uniform: scalar loads
+    const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
+    const uint32_t cell = p.cells[k];
+    Pack<T, W> w, u;
+    if constexpr (W == 4) {
+      T z[4];
+      normal4<T>(key, elem >> 2, cell, 0, kStreamW, z);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w.v[q] = z[q] * sw;
+      if constexpr (kNeedU) {
+        normal4<T>(key, elem >> 2, cell, 0, kStreamH, z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.v[q] = th * ((T)0.5 * w.v[q] + z[q] * sh);
+      }
+    } else {
+      w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
+      if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+    }
+    Pack<T, W> y1;
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      y1.v[q] = affine_step<T, METHOD>(y.v[q], a.v[q], b.v[q], c.v[q], e.v[q], w.v[q], kNeedU ? u.v[q] : (T)0, dt,
+                                       half_dt, rdt, sqrt_dt);
+    }
+    while (j < p.n_out && p.out_step[j] == k + 1) {
+      const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+      Pack<T, W> o = y1;
+      if (!(w0 == (T)0 && w1 == (T)1)) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) o.v[q] = w0 * y.v[q] + w1 * y1.v[q];
+      }
+      store<T, W>(p.ys + (int64_t)j * p.n, i, o);
+      ++j;
+    }
+    y = y1;
+  }
+}
+
+template <typename T, int METHOD>
+static hipError_t launch_traj_m(const TrajArgs<T>& p, bool vec, hipStream_t s) {
+  if (vec) {
+    const int64_t lanes = p.n >> 2;
+    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 4>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 1>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, s, p);
+  }
+  return hipGetLastError();
+}
+
+// Below this many 16-byte groups the one-element-per-lane form is used even when the vector form is legal:
+// the kernel is ALU/latency bound per lane, so a half-empty chip finishes sooner with 4x the lanes.
+constexpr int64_t kTrajVecMinGroups = 256 * 8 * 64;
+
+template <typename T>
+hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* a,
+                                         const void* b, const void* c, const void* e, int method,
+                                         const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
+  TrajArgs<T> p;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  p.a = (const T*)a;
+  p.b = (const T*)b;
+  p.c = (const T*)c;
+  p.e = (const T*)e;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
+  const bool can_vec = (d % 4 == 0) && (key.elem0 % 4 == 0) && aligned16(ys) && aligned16(y0) && aligned16(a) &&
+                       aligned16(b) && aligned16(c) && aligned16(e) && ((p.n * sizeof(T)) % 16 == 0);
+  const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
+  switch (method) {
+    case kEuler: return launch_traj_m<T, kEuler>(p, vec, s);
+    case kMilIto: return launch_traj_m<T, kMilIto>(p, vec, s);
+    case kMilStrat: return launch_traj_m<T, kMilStrat>(p, vec, s);
+    case kMidpoint: return launch_traj_m<T, kMidpoint>(p, vec, s);
+    case kSrk: return launch_traj_m<T, kSrk>(p, vec, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t launch_trajectory_affine_diag<float>(void*, const void*, int64_t, int64_t, const void*,
+                                                         const void*, const void*, const void*, int,
+                                                         const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
+template hipError_t launch_trajectory_affine_diag<double>(void*, const void*, int64_t, int64_t, const void*,
+                                                          const void*, const void*, const void*, int,
+                                                          const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
+
+}  // namespace tsde

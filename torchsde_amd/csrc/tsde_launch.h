@@ -85,4 +85,9 @@ template <typename T>
 hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const void* ay, const void* az0,
                               const void* vjp_z, int64_t n, double dt, double half_dt, const tsde_noise_t* nz,
                               hipStream_t s);
+// trajectory.hip
+template <typename T>
+hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* a,
+                                         const void* b, const void* c, const void* e, int method,
+                                         const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 }  // namespace tsde

@@ -8,6 +8,7 @@ expressed with differentiable torch ops on the re-materialised increment (the st
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _native
@@ -395,6 +396,51 @@ def linear_interp(ya, yb, w0, w1, out=None):
                                   float(w1), dt_code, stream)
     _native.check(code, "tsde_linear_interp")
     return out
+
+
+class TrajectorySchedule:
+    """Device-resident ``tsde_traj_t`` of one solve: step rows, Brownian cells and the output map."""
+
+    def __init__(self, step_rows, cells, out_step, out_w, device, dtype):
+        np_dtype = np.float32 if dtype == torch.float32 else np.float64
+        rows = np.ascontiguousarray(step_rows, dtype=np_dtype)
+        assert rows.ndim == 2 and rows.shape[1] == 8
+        self.n_steps, self.n_out = rows.shape[0], len(out_step)
+        self.dtype = dtype
+        self.rows = torch.from_numpy(rows).to(device)
+        self.cells = torch.from_numpy(np.ascontiguousarray(cells, dtype=np.uint32).view(np.int32)).to(device)
+        self.out_step = torch.from_numpy(np.ascontiguousarray(out_step, dtype=np.int32)).to(device)
+        self.out_w = torch.from_numpy(np.ascontiguousarray(out_w, dtype=np_dtype).reshape(-1, 2)).to(device)
+        s = _native.Traj()
+        s.step_rows, s.cells = self.rows.data_ptr(), self.cells.data_ptr()
+        s.out_step, s.out_w = self.out_step.data_ptr(), self.out_w.data_ptr()
+        s.n_steps, s.n_out = self.n_steps, self.n_out
+        self._struct = s
+
+    def struct(self):
+        return ctypes.byref(self._struct)
+
+
+def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm):
+    """All steps of an affine diagonal SDE in one launch (``tsde_trajectory_affine_diag``); writes ys[j] for the
+    schedule's outputs. `bm` is the native BrownianInterval whose generated cells drive the steps."""
+    _native.require_device(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift)
+    rows, d = y0.shape
+    for c in (drift_rate, drift_shift, diff_rate, diff_shift):
+        if c.dtype != y0.dtype or c.numel() != d or not c.is_contiguous():
+            raise ValueError("coefficients must be contiguous (d,) tensors in the state dtype")
+    if schedule.dtype != y0.dtype or ys.dtype != y0.dtype:
+        raise ValueError("schedule / output dtype must equal the state dtype")
+    if not (ys.is_contiguous() and y0.is_contiguous()) or ys.shape != (schedule.n_out, rows, d):
+        raise ValueError("ys must be a contiguous (n_out, rows, d) tensor and y0 contiguous")
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    code = lib.tsde_trajectory_affine_diag(
+        ys.data_ptr(), y0.data_ptr(), rows, d, drift_rate.data_ptr(), drift_shift.data_ptr(), diff_rate.data_ptr(),
+        diff_shift.data_ptr(), int(method), schedule.struct(), bm._key, bm._elem0,
+        None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    _native.check(code, "tsde_trajectory_affine_diag")
+    return ys
 
 
 # ---- in-library event timing (bench.py's roofline) ----------------------------------------------------------

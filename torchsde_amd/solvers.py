@@ -15,6 +15,7 @@ increments, no ``torch.stack`` copy.
 import numpy as np
 import torch
 
+from . import _native
 from . import kernels as K
 from . import timegrid
 from .brownian import BaseBrownian, BrownianInterval
@@ -162,6 +163,11 @@ class BaseSDESolver:
             return self._integrate_adaptive(y0, ts, extra0)
         self._extra = tuple(extra0) if extra0 is not None else ()
         self._state_dtype = y0.dtype
+        coefficients = self._closed_form_coefficients(y0)
+        if coefficients is not None:
+            ys = self._integrate_trajectory(coefficients, y0, ts)
+            if ys is not None:
+                return ys, self._extra
         if self.options.get("hip_graph", False) and not self._tracks_grad(y0) and not self.stateful:
             from . import graph
             return graph.replay_or_capture(self, y0, ts), ()
@@ -209,6 +215,63 @@ class BaseSDESolver:
 
     def _tracks_grad(self, y0):
         return torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
+
+    # ---- whole-trajectory kernel (closed-form SDEs) ----------------------------------------------------------
+    def _trajectory_code(self):
+        """TSDE_TRAJ_* code of this scheme's in-register form, or None if it has none."""
+        return None
+
+    def _closed_form_coefficients(self, y0):
+        """Coefficient tensors if the whole solve can run as ONE launch of the trajectory kernel: a closed-form
+        SDE handed to `sdeint` as is (closed_form.py), forward only, this package's BrownianInterval generating
+        the increments. `options={"trajectory_kernel": False}` keeps the stepwise path."""
+        from .sde import ForwardSDE
+        if not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful:
+            return None
+        base = getattr(self.sde, "_base_sde", None)
+        if type(self.sde) is not ForwardSDE or not hasattr(base, "closed_form"):
+            return None
+        bm = self._native_bm()
+        if (self._trajectory_code() is None or bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape)
+                or y0.dtype not in (torch.float32, torch.float64) or self._tracks_grad(y0)):
+            return None
+        spec = base.closed_form(y0.shape[1], y0.dtype, y0.device)
+        if spec is None or spec[0] != "affine_diagonal":
+            return None
+        return spec[1:]
+
+    def _integrate_trajectory(self, coefficients, y0, ts):
+        """All steps in one kernel launch; None if the Brownian motion's cells do not line up with the steps."""
+        bm = self.bm
+        grid = timegrid.build(timegrid.ts_to_host(ts), self.dt)
+        if grid.n_steps == 0:
+            return None
+        t64 = grid.t_f64()
+        bm.adopt_grid(t64)
+        cells = bm.match_grid(t64)
+        if cells is None:
+            return None
+        cells = np.asarray(cells, dtype=np.int64)
+        np_dtype = grid.t.dtype.type
+        dt = grid.dt
+        h = bm._edges[cells + 1] - bm._edges[cells]
+        rows = np.zeros((grid.n_steps, 8), dtype=np.float64)
+        # each entry is rounded in ts.dtype like the stepwise path's scalars, then (below) cast to the state dtype
+        rows[:, 0] = dt
+        rows[:, 1] = np_dtype(0.5) * dt
+        rows[:, 2] = np_dtype(1) / dt
+        rows[:, 3] = np.sqrt(dt)
+        rows[:, 4] = np.sqrt(h)
+        rows[:, 5] = np.sqrt(h / 12.0)
+        rows[:, 6] = h
+        out_step = [kc for (_, kc, _, _) in grid.outputs]
+        out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
+        schedule = K.TrajectorySchedule(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+        ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+        ys[0].copy_(y0c)
+        K.trajectory_affine_diag(ys[1:], y0c, *coefficients, self._trajectory_code(), schedule, bm)
+        return ys
 
     def _plan(self, y0, ts):
         """Host-side preparation of a solve: time grid, stage times (one upload), Brownian cell map, output map.
@@ -326,6 +389,9 @@ class Euler(BaseSDESolver):
         self.strong_order = 1.0 if sde.noise_type == NOISE_TYPES.additive else 0.5
         super().__init__(sde=sde, **kwargs)
 
+    def _trajectory_code(self):
+        return _native.TRAJ_EULER if self._diag() else None
+
     def _advance(self, y0, st, out):
         return self._drift_diffusion_update(st.times[0], y0, st.dt, 1.0, st.noise, out)
 
@@ -341,6 +407,9 @@ class Midpoint(BaseSDESolver):
     def __init__(self, sde, **kwargs):
         self.strong_order = 0.5 if sde.noise_type == NOISE_TYPES.general else 1.0
         super().__init__(sde=sde, **kwargs)
+
+    def _trajectory_code(self):
+        return _native.TRAJ_MIDPOINT if self._diag() else None
 
     def _advance(self, y0, st, out):
         dt = st.dt
@@ -417,6 +486,11 @@ class _Milstein(BaseSDESolver):
             # noise with the iterated integrals I_kl = (W_k W_l - delta_kl dt)/2 + A_kl.
             self.noise_types = tuple(NOISE_TYPES.all())
         super().__init__(sde=sde, options=options, **kwargs)
+
+    def _trajectory_code(self):
+        if not self._diag() or self.options[METHOD_OPTIONS.grad_free]:
+            return None
+        return _native.TRAJ_MILSTEIN_ITO if self.ito else _native.TRAJ_MILSTEIN_STRAT
 
     def _row_noise(self, noise, d):
         """Scalar noise: one increment per batch row, broadcast over the d state channels."""
@@ -504,6 +578,9 @@ class SRK(BaseSDESolver):
                              "direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
                              "diffusion-vector product. Use a different method instead.")
         super().__init__(sde=sde, **kwargs)
+
+    def _trajectory_code(self):
+        return _native.TRAJ_SRK if self._diag() else None
 
     def _advance(self, y0, st, out):
         if self.sde.noise_type == NOISE_TYPES.additive:
