@@ -57,6 +57,22 @@ WORKLOADS = {
         problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
         kernel="tsde_step_diag<float> (two stages per step)"),
+    # The headline dynamics (same mu, sigma, seed addressing: bit-identical final states) handed over as a closed-form
+    # SDE (torchsde_amd.AffineDiagonalSDE): the whole solve is ONE launch of the trajectory kernel, state in
+    # registers. VALU-bound (Philox + Box-Muller), so the HBM roofline fraction is ~0 by design.
+    "c2_euler_closed_form_b65536_d64_s1000": dict(
+        problem="gbm_closed_form", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, euler> (trajectory_kernel)"),
+    "c2_milstein_closed_form": dict(
+        problem="gbm_closed_form", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, milstein> (trajectory_kernel)"),
+    "c2_srk_closed_form": dict(
+        problem="gbm_closed_form", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, srk> (trajectory_kernel)"),
+    "c4_midpoint_closed_form_b32768_d64": dict(
+        problem="gbm_closed_form_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000,
+        dt=2.0 ** -10, kid=8, trajectory=True,
+        kernel="tsde_trajectory_affine_diag<float, midpoint> (trajectory_kernel)"),
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
@@ -89,6 +105,14 @@ def _make_problem(name, d, m, dev):
             def g(self, t, y):
                 return 0.1 * torch.sigmoid(self.w * y + self.b)
         return Latent().to(dev)
+    if name.startswith("gbm_closed_form"):
+        import torchsde_amd
+        strat = name.endswith("_strat")
+        gbm = problems.make("gbm_strat" if strat else "gbm_ito", d=d, m=m)
+        mu, sigma = gbm.mu.detach(), gbm.sigma.detach()
+        rate = mu - 0.5 * sigma ** 2 if strat else mu
+        return torchsde_amd.AffineDiagonalSDE(rate, 0.0, sigma, 0.0, sde_type="stratonovich" if strat else "ito",
+                                              dtype=torch.float32).to(dev)
     return problems.make(name, d=d, m=m).to(dev)
 
 
@@ -176,7 +200,8 @@ def main():
     adjoint = cfg.get("adjoint", False)
     # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
     # the derivative form of Milstein and the adjoint run autograd inside the loop and stay eager.
-    use_graph = (not args.eager) and (not adjoint) and cfg["method"] != "milstein"
+    trajectory = cfg.get("trajectory", False)
+    use_graph = (not args.eager) and (not adjoint) and cfg["method"] != "milstein" and not trajectory
     extra_options = dict(cfg.get("options") or {})
     sde = _make_problem(cfg["problem"], d, m, dev)
     y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
@@ -226,10 +251,15 @@ def main():
         # roofline of the dominant kernel: every launch of the step kernel in one more solve is bracketed by
         # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
         # (issued eagerly: event records are host-side calls and are not part of a replayed graph)
-        K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
-        # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
-        K.gpu_delay(min(2.0e6, 40.0 * nsteps * (2 + cfg["launches_per_step"])), dev)
-        one_solve(5000, graph=False)
+        if trajectory:
+            K.prof_begin(cfg["kid"], 16)
+            for i in range(8):
+                one_solve(5000 + i, graph=False)
+        else:
+            K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
+            # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
+            K.gpu_delay(min(2.0e6, 40.0 * nsteps * (2 + cfg["launches_per_step"])), dev)
+            one_solve(5000, graph=False)
         torch.cuda.synchronize()
         k_ms, k_launches = K.prof_end()
 
@@ -256,7 +286,21 @@ def main():
 
     value = world * B * nsteps * args.steps / elapsed
     roofline = None
-    if k_launches > 0:
+    if k_launches > 0 and trajectory:
+        # One launch per solve: it reads y0 and writes the requested outputs, nothing else touches HBM. The kernel is
+        # bound by the VALU work of the counter RNG (Philox-4x32-10 + Box-Muller per element-step), so its HBM
+        # roofline fraction is ~0 by design; `valu_*` restate the same launch against the vector-ALU issue peak.
+        avg_s = k_ms * 1e-3 / k_launches
+        bytes_per_launch = 2 * B * d * 4
+        achieved = bytes_per_launch / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                    "avg_launch_us": avg_s * 1e6, "launches_timed": k_launches,
+                    "element_steps_per_s": B * d * nsteps / avg_s,
+                    "note": "VALU-bound by design (state in registers, increments from the counter RNG); see DESIGN.md "
+                            "for the VALU utilisation measured with rocprofv3 PMC counters",
+                    "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
+    elif k_launches > 0:
         # Each bracket is (event record, kernel, event record) on the launch stream of an eagerly issued solve that
         # was fully enqueued behind a delay kernel (the queue never runs dry). A bracket = kernel + the marker
         # packets' latency, i.e. an UPPER bound on the kernel time, and `achieved` is therefore a LOWER bound.
@@ -301,11 +345,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "sde": cfg["problem"] + " (f, g are user torch ops)",
+            "config": {"workload": args.workload, "sde": cfg["problem"] + (" (closed-form coefficients; f, g evaluated in the kernel)" if trajectory
+                                                          else " (f, g are user torch ops)"),
                        "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "state": d, "brownian_channels": m,
                        "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
-                       "launch": "HIP graph replay of the whole solve" if use_graph else "eager launches",
+                       "launch": ("one trajectory-kernel launch per solve" if trajectory else
+                                  "HIP graph replay of the whole solve" if use_graph else "eager launches"),
                        "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

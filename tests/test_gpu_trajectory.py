@@ -100,6 +100,22 @@ def test_scalar_coefficients_and_fp32_time_grid():
     assert torch.equal(a, b)
 
 
+def test_closed_form_gbm_equals_user_module_gbm():
+    """The headline benchmark's SDE (tests/problems.py GBMDiag: f = mu*y, g = sigma*y as user torch code, stepwise
+    path) and the same coefficients handed over in closed form (one trajectory launch) give the same bits."""
+    import torchsde_amd
+    from tests import problems
+    B, d = 8192, 64
+    gbm = problems.make("gbm_ito", d=d).to(DEV)
+    closed = torchsde_amd.AffineDiagonalSDE(gbm.mu.detach(), 0.0, gbm.sigma.detach(), 0.0, dtype=torch.float32).to(DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, 0.125], device=DEV)
+    for method in ("euler", "milstein"):
+        a = _solve(closed, y0, ts, method, 2.0 ** -10, 77, trajectory=True)
+        b = _solve(gbm, y0, ts, method, 2.0 ** -10, 77, trajectory=True)     # a plain module: always stepwise
+        assert torch.equal(a, b), method
+
+
 def test_geometric_brownian_motion_moments():
     """E[y_T] = y0 exp(mu T) and Var[log y_T] = sigma^2 T for GBM: the kernel's increments have the right law."""
     import torchsde_amd

@@ -24,6 +24,14 @@ struct u32x4 {
   uint32_t x, y, z, w;
 };
 
+// a ^ b ^ c in one instruction on the device (gfx950 v_bitop3_b32, truth table 0x96); hipcc does not fuse the
+// two xors of a Philox round on its own, and they are a third of the round's VALU work.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TSDE_XOR3(a, b, c) ((uint32_t)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96))
+#else
+#define TSDE_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
+
 // Philox-4x32-10 (Salmon et al., SC'11). One call = 4 x 32 random bits.
 TSDE_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
   constexpr uint32_t kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u;
@@ -32,8 +40,8 @@ TSDE_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)kM0 * c.x;
     const uint64_t p1 = (uint64_t)kM1 * c.z;
-    const u32x4 n = {(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1,
-                     (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
+    const u32x4 n = {TSDE_XOR3((uint32_t)(p1 >> 32), c.y, k0), (uint32_t)p1,
+                     TSDE_XOR3((uint32_t)(p0 >> 32), c.w, k1), (uint32_t)p0};
     c = n;
     k0 += kW0;
     k1 += kW1;
