@@ -199,9 +199,11 @@ def main():
     B, d, m, nsteps, dt = cfg["B"], cfg["d"], cfg["m"], cfg["nsteps"], cfg["dt"]
     adjoint = cfg.get("adjoint", False)
     # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
-    # the derivative form of Milstein and the adjoint run autograd inside the loop and stay eager.
+    # the derivative form of Milstein runs its diffusion VJP through autograd INSIDE the captured region (fine: same
+    # kernels every step). The adjoint (backward pass outside the solver) and the general-noise Milstein extension
+    # (16 JVPs per step) stay eager.
     trajectory = cfg.get("trajectory", False)
-    use_graph = (not args.eager) and (not adjoint) and cfg["method"] != "milstein" and not trajectory
+    use_graph = (not args.eager) and (not adjoint) and not cfg.get("options") and not trajectory
     extra_options = dict(cfg.get("options") or {})
     sde = _make_problem(cfg["problem"], d, m, dev)
     y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
