@@ -37,6 +37,15 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
   const uint64_t q1 = (key.elem0 + (uint64_t)n + 3) >> 2;
   const int64_t nq = (int64_t)(q1 - q0);
   const double hq = qa.b - qa.a;
+  // Bridge-split coefficients of every tree level on the way to a (in cell ca) and to b (in cell cb): computed
+  // once per block by threads 0..max_depth, shared through LDS (tsde_bridge.h: DescentTable).
+  __shared__ T rows_a[kMaxLevels * DescentTable<T, HAVE_H>::N];
+  __shared__ T rows_b[kMaxLevels * DescentTable<T, HAVE_H>::N];
+  const DescentTable<T, HAVE_H> ta{rows_a}, tb{rows_b};
+  // (an end point that sits on a cell edge needs no split, so its table is neither built nor read)
+  if (qa.a != qa.edges[qa.ca]) ta.template build<false>(qa.edges[qa.ca], qa.edges[qa.ca + 1], qa.a, qa.cfg);
+  if (qa.b != qa.edges[qa.cb + 1]) tb.template build<true>(qa.edges[qa.cb], qa.edges[qa.cb + 1], qa.b, qa.cfg);
+  __syncthreads();
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kBlock) {
     const uint64_t quad = q0 + (uint64_t)t;
     PieceAcc<T, HAVE_H> acc;
@@ -62,11 +71,11 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
     }
     if (qa.ca == qa.cb) {
       const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
-      cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, qa.b, root, qa.cfg, acc);
+      cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, qa.b, root, qa.cfg, ta, tb, acc);
     } else {
       {
         const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
-        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, e, root, qa.cfg, acc);
+        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, e, root, qa.cfg, ta, tb, acc);
       }
       for (int64_t c = qa.ca + 1; c < qa.cb; ++c) {
         const double h = qa.edges[c + 1] - qa.edges[c];
@@ -78,7 +87,7 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
         const double s = qa.edges[qa.cb], e = qa.edges[qa.cb + 1];
         WH4<T> P;
         cell_root<T, HAVE_H>(key, quad, (uint32_t)qa.cb, e - s, P);
-        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.cb, s, e, s, qa.b, P, qa.cfg, acc);
+        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.cb, s, e, s, qa.b, P, qa.cfg, ta, tb, acc);
       }
     }
     Pack<T, 4> w, u, hh;

@@ -41,30 +41,55 @@ TSDE_D void cell_root(const NoiseKey& key, uint64_t quad, uint32_t cell, double 
   }
 }
 
-// Split parent P over [lo,hi] at x into L=[lo,x], R=[x,hi] using the parent's node normals.
+// Coefficients of one bridge split of [lo,hi] at x. They depend on the three times only, so a wave computes them
+// once per tree level (lane k <-> level k, `DescentTable` below) instead of once per lane per level: the double-
+// precision divide and square roots were ~45 % of a misaligned query's instructions.
 template <typename T, bool HAVE_H>
-TSDE_D void bridge_split(const NoiseKey& key, uint64_t quad, uint32_t cell, uint64_t node, double lo, double x,
-                         double hi, const WH4<T>& P, WH4<T>& L, WH4<T>& R) {
+struct SplitCoef {
+  // without H: tl, th, sd.  with H: fcl, scl, third, fl2, ta, cr, fcr, scr, fr2, tb, cl.
+  T c[HAVE_H ? 11 : 3];
+};
+
+template <typename T, bool HAVE_H>
+TSDE_D SplitCoef<T, HAVE_H> split_coef(double lo, double x, double hi) {
+  SplitCoef<T, HAVE_H> k;
   const double hrec = 1.0 / (hi - lo);
   const double l = x - lo;
   const double r = hi - x;
-  T X1[4];
-  normal4<T>(key, quad, cell, node, kStreamW, X1);
-  if (HAVE_H) {
-    T X2[4];
-    normal4<T>(key, quad, cell, node, kStreamH, X2);
+  if constexpr (HAVE_H) {
     const double l2 = l * l, r2 = r * r;
     const double l3 = l * l2, r3 = r * r2;
     const double v = 0.5 * sqrt(l * r / (l3 + r3));
     const double a = v * l2 * hrec;
     const double b = v * r2 * hrec;
     const double c = v * 0.57735026918962584;  // 1/sqrt(3)
-    const T third = (T)(2.0 * (a * l + b * r) * hrec);
     const double fl = l * hrec, fr = r * hrec;
-    const T fcl = (T)fl, fcr = (T)fr;
-    const T scl = (T)(6.0 * fl * r * hrec), scr = (T)(6.0 * fr * l * hrec);
-    const T fl2 = (T)(fl * fl), fr2 = (T)(fr * fr);
-    const T ta = (T)a, tb = (T)b, cr = (T)(c * r), cl = (T)(c * l);
+    k.c[0] = (T)fl;
+    k.c[1] = (T)(6.0 * fl * r * hrec);
+    k.c[2] = (T)(2.0 * (a * l + b * r) * hrec);
+    k.c[3] = (T)(fl * fl);
+    k.c[4] = (T)a;
+    k.c[5] = (T)(c * r);
+    k.c[6] = (T)fr;
+    k.c[7] = (T)(6.0 * fr * l * hrec);
+    k.c[8] = (T)(fr * fr);
+    k.c[9] = (T)b;
+    k.c[10] = (T)(c * l);
+  } else {
+    k.c[0] = (T)l;
+    k.c[1] = (T)hrec;
+    k.c[2] = (T)sqrt(l * r * hrec);
+  }
+  return k;
+}
+
+// L, R from the parent P and the node normals X1 (W stream), X2 (H stream).
+template <typename T, bool HAVE_H>
+TSDE_D void split_apply(const SplitCoef<T, HAVE_H>& k, const T (&X1)[4], const T (&X2)[4], const WH4<T>& P, WH4<T>& L,
+                        WH4<T>& R) {
+  if constexpr (HAVE_H) {
+    const T fcl = k.c[0], scl = k.c[1], third = k.c[2], fl2 = k.c[3], ta = k.c[4], cr = k.c[5];
+    const T fcr = k.c[6], scr = k.c[7], fr2 = k.c[8], tb = k.c[9], cl = k.c[10];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const T W = P.W[j], H = P.H[j];
@@ -74,7 +99,7 @@ TSDE_D void bridge_split(const NoiseKey& key, uint64_t quad, uint32_t cell, uint
       R.H[j] = (fr2 * H - tb * X1[j]) - cl * X2[j];
     }
   } else {
-    const T tl = (T)l, th = (T)hrec, sd = (T)sqrt(l * r * hrec);
+    const T tl = k.c[0], th = k.c[1], sd = k.c[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const T W = P.W[j];
@@ -85,6 +110,16 @@ TSDE_D void bridge_split(const NoiseKey& key, uint64_t quad, uint32_t cell, uint
       R.H[j] = (T)0;
     }
   }
+}
+
+// Split parent P over [lo,hi] at x into L=[lo,x], R=[x,hi] using the parent's node normals.
+template <typename T, bool HAVE_H>
+TSDE_D void bridge_split(const NoiseKey& key, uint64_t quad, uint32_t cell, uint64_t node, const SplitCoef<T, HAVE_H>& k,
+                         const WH4<T>& P, WH4<T>& L, WH4<T>& R) {
+  T X1[4], X2[4] = {(T)0, (T)0, (T)0, (T)0};
+  normal4<T>(key, quad, cell, node, kStreamW, X1);
+  if constexpr (HAVE_H) normal4<T>(key, quad, cell, node, kStreamH, X2);
+  split_apply<T, HAVE_H>(k, X1, X2, P, L, R);
 }
 
 // Concatenate A over an interval of length ha with B over the adjacent interval of length hb
@@ -141,27 +176,70 @@ struct WalkCfg {
   int snap;       // leaf rule: 0 = split the leaf exactly at the query point, 1 = snap to the nearer edge
 };
 
+// Where the in-cell walk bisects at `depth`: the dyadic midpoint, or (leaf rule, exact mode) the query point itself.
+TSDE_D double split_point(int depth, double lo, double hi, double p, const WalkCfg& cfg) {
+  return (depth >= cfg.max_depth) ? p : 0.5 * (lo + hi);
+}
+
+// Split coefficients along the descent from the cell [s,e] toward the point p, one tree level per table row.
+// The descent is a pure function of (s, e, p, cfg) -- the same for every element -- so instead of every lane
+// redoing the double-precision divide/sqrt at every level, 64 threads of the block each replay the cheap
+// bookkeeping down to their own level and compute that level's coefficients ONCE into LDS; after a barrier the
+// walk fetches row `depth` (a wave-uniform, conflict-free broadcast read). Needs max_depth + 1 <= kMaxLevels
+// (the C ABI caps max_depth at 40).
+//   TOWARD_B = false: the left end a of a query  (go left iff a < x,  as walk_suffix / cell_range do)
+//   TOWARD_B = true : the right end b of a query (go right iff b > x, as walk_prefix / cell_range do)
+constexpr int kMaxLevels = 64;
+
+template <typename T, bool HAVE_H>
+struct DescentTable {
+  static constexpr int N = HAVE_H ? 11 : 3;
+  T* rows;   // LDS, kMaxLevels x N
+
+  // Called by ALL threads of the block (the caller places the barrier after the last build).
+  template <bool TOWARD_B>
+  TSDE_D void build(double s, double e, double p, const WalkCfg& cfg) const {
+    const int level = (int)threadIdx.x;
+    if (level >= kMaxLevels || level > cfg.max_depth) return;
+    double lo = s, hi = e;
+    for (int d = 0; d < level; ++d) {
+      if (TOWARD_B ? (p == hi) : (p == lo)) return;   // the walk stops here: deeper rows are never read
+      const double x = split_point(d, lo, hi, p, cfg);
+      const bool left = TOWARD_B ? !(p > x) : (p < x);
+      if (left) hi = x; else lo = x;
+    }
+    if (TOWARD_B ? (p == hi) : (p == lo)) return;
+    const SplitCoef<T, HAVE_H> k = split_coef<T, HAVE_H>(lo, split_point(level, lo, hi, p, cfg), hi);
+#pragma unroll
+    for (int i = 0; i < N; ++i) rows[level * N + i] = k.c[i];
+  }
+
+  // Coefficients of level `depth` (wave-uniform index).
+  TSDE_D SplitCoef<T, HAVE_H> at(int depth) const {
+    SplitCoef<T, HAVE_H> k;
+#pragma unroll
+    for (int i = 0; i < N; ++i) k.c[i] = rows[depth * N + i];
+    return k;
+  }
+};
+
 // (W,H) of [a, hi] inside node `node`=[lo,hi] whose value is P. Pieces are prepended to acc.
 template <typename T, bool HAVE_H>
 TSDE_D void walk_suffix(const NoiseKey& key, uint64_t quad, uint32_t cell, uint64_t node, int depth, double lo,
-                        double hi, double a, WH4<T> P, const WalkCfg& cfg, PieceAcc<T, HAVE_H>& acc) {
+                        double hi, double a, WH4<T> P, const WalkCfg& cfg, const DescentTable<T, HAVE_H>& ta,
+                        PieceAcc<T, HAVE_H>& acc) {
   for (;;) {
     if (a == lo) {
       acc.push_left(P, hi - lo);
       return;
     }
-    double x;
-    if (depth >= cfg.max_depth) {
-      if (cfg.snap) {
-        if ((a - lo) < (hi - a)) acc.push_left(P, hi - lo);
-        return;
-      }
-      x = a;
-    } else {
-      x = 0.5 * (lo + hi);
+    if (depth >= cfg.max_depth && cfg.snap) {
+      if ((a - lo) < (hi - a)) acc.push_left(P, hi - lo);
+      return;
     }
+    const double x = split_point(depth, lo, hi, a, cfg);
     WH4<T> L, R;
-    bridge_split<T, HAVE_H>(key, quad, cell, node, lo, x, hi, P, L, R);
+    bridge_split<T, HAVE_H>(key, quad, cell, node, ta.at(depth), P, L, R);
     ++depth;
     if (a < x) {
       acc.push_left(R, hi - x);
@@ -179,24 +257,20 @@ TSDE_D void walk_suffix(const NoiseKey& key, uint64_t quad, uint32_t cell, uint6
 // (W,H) of [lo, b] inside node=[lo,hi]. Pieces are appended to acc.
 template <typename T, bool HAVE_H>
 TSDE_D void walk_prefix(const NoiseKey& key, uint64_t quad, uint32_t cell, uint64_t node, int depth, double lo,
-                        double hi, double b, WH4<T> P, const WalkCfg& cfg, PieceAcc<T, HAVE_H>& acc) {
+                        double hi, double b, WH4<T> P, const WalkCfg& cfg, const DescentTable<T, HAVE_H>& tb,
+                        PieceAcc<T, HAVE_H>& acc) {
   for (;;) {
     if (b == hi) {
       acc.push_right(P, hi - lo);
       return;
     }
-    double x;
-    if (depth >= cfg.max_depth) {
-      if (cfg.snap) {
-        if ((hi - b) <= (b - lo)) acc.push_right(P, hi - lo);
-        return;
-      }
-      x = b;
-    } else {
-      x = 0.5 * (lo + hi);
+    if (depth >= cfg.max_depth && cfg.snap) {
+      if ((hi - b) <= (b - lo)) acc.push_right(P, hi - lo);
+      return;
     }
+    const double x = split_point(depth, lo, hi, b, cfg);
     WH4<T> L, R;
-    bridge_split<T, HAVE_H>(key, quad, cell, node, lo, x, hi, P, L, R);
+    bridge_split<T, HAVE_H>(key, quad, cell, node, tb.at(depth), P, L, R);
     ++depth;
     if (b > x) {
       acc.push_right(L, x - lo);
@@ -212,9 +286,11 @@ TSDE_D void walk_prefix(const NoiseKey& key, uint64_t quad, uint32_t cell, uint6
 }
 
 // (W,H) of [a,b] inside the cell [s,e]  (s <= a < b <= e) whose root value is P. Appends to acc (time-ordered).
+// `ta` / `tb`: descent tables of this cell toward a / toward b (a table whose end point is a cell edge is never read).
 template <typename T, bool HAVE_H>
 TSDE_D void cell_range(const NoiseKey& key, uint64_t quad, uint32_t cell, double s, double e, double a, double b,
-                       WH4<T> P, const WalkCfg& cfg, PieceAcc<T, HAVE_H>& acc) {
+                       WH4<T> P, const WalkCfg& cfg, const DescentTable<T, HAVE_H>& ta,
+                       const DescentTable<T, HAVE_H>& tb, PieceAcc<T, HAVE_H>& acc) {
   uint64_t node = 1;
   int depth = 0;
   double lo = s, hi = e;
@@ -223,20 +299,18 @@ TSDE_D void cell_range(const NoiseKey& key, uint64_t quad, uint32_t cell, double
       acc.push_right(P, hi - lo);
       return;
     }
-    double x;
-    if (depth >= cfg.max_depth) {
-      if (cfg.snap) {
-        const bool a_lo = (a - lo) < (hi - a);
-        const bool b_hi = (hi - b) <= (b - lo);
-        if (a_lo && b_hi) acc.push_right(P, hi - lo);
-        return;
-      }
-      x = (a > lo) ? a : b;
-    } else {
-      x = 0.5 * (lo + hi);
+    if (depth >= cfg.max_depth && cfg.snap) {
+      const bool a_lo = (a - lo) < (hi - a);
+      const bool b_hi = (hi - b) <= (b - lo);
+      if (a_lo && b_hi) acc.push_right(P, hi - lo);
+      return;
     }
+    // Above the fork both descents visit this node; below max_depth they also split it at the same point.
+    // At the leaf rule the split point is a if a is interior, else b.
+    const bool use_a = a > lo;
+    const double x = split_point(depth, lo, hi, use_a ? a : b, cfg);
     WH4<T> L, R;
-    bridge_split<T, HAVE_H>(key, quad, cell, node, lo, x, hi, P, L, R);
+    bridge_split<T, HAVE_H>(key, quad, cell, node, use_a ? ta.at(depth) : tb.at(depth), P, L, R);
     ++depth;
     if (b <= x) {
       P = L;
@@ -249,9 +323,9 @@ TSDE_D void cell_range(const NoiseKey& key, uint64_t quad, uint32_t cell, double
     } else {
       PieceAcc<T, HAVE_H> left;
       left.clear();
-      walk_suffix<T, HAVE_H>(key, quad, cell, 2 * node, depth, lo, x, a, L, cfg, left);
+      walk_suffix<T, HAVE_H>(key, quad, cell, 2 * node, depth, lo, x, a, L, cfg, ta, left);
       if (left.len != 0.0) acc.push_right(left.v, left.len);
-      walk_prefix<T, HAVE_H>(key, quad, cell, 2 * node + 1, depth, x, hi, b, R, cfg, acc);
+      walk_prefix<T, HAVE_H>(key, quad, cell, 2 * node + 1, depth, x, hi, b, R, cfg, tb, acc);
       return;
     }
   }
