@@ -227,3 +227,19 @@ def test_levy_area(levy):
                                                 levy_area_approximation=levy)
     w, a = one_channel(0.1, 0.4, return_A=True)
     assert a.shape == (16,) and (a == 0).all()
+
+
+def test_query_kernel_regression_fixture():
+    """264 queries (fp32/fp64, with/without H, single cell / dt grid / halfway tree, aligned and misaligned) must
+    reproduce, bit for bit, the outputs recorded on an MI355X before the kernel's coefficient computation was
+    moved into a per-block table (tests/golden/query_kernel_r1.pt, written by tools/query_regress.py dump)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import query_regress
+    ref = torch.load(os.path.join(root, "tests", "golden", "query_kernel_r1.pt"))
+    got = query_regress.run()
+    assert len(ref) == 264 and set(ref) == set(got)
+    bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+    assert not bad, bad[:5]
