@@ -16,6 +16,7 @@
  *   tsde_rheun_*         _core/methods/reversible_heun.py:48-144 (reversible Heun and its adjoint)
  *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
  *   tsde_linear_interp   _core/interp.py:15-18
+ *   tsde_error_norm      _core/adaptive_stepping.py:42-76 (error estimate of step doubling, base_solver.py:125-128)
  *   tsde_trajectory_*    _core/base_solver.py:114-134 (the whole stepping loop of `integrate`) for SDEs whose
  *                        drift and diffusion are given in closed form instead of as Python callables
  *
@@ -207,6 +208,15 @@ int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int 
 /* out = w0*ya + w1*yb */
 int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, int dtype,
                        void* stream);
+
+/* Error norm of adaptive step doubling (adaptive_stepping.py:42-76 `compute_error`, one fused reduction):
+ *   out[0] = max(eps, sqrt( sum_i ((yf_i - yh_i) / max(eps, rtol*max(|yf_i|,|yh_i|) + atol))^2 / n ))   as a DOUBLE.
+ * `workspace`: device scratch of >= TSDE_ERROR_NORM_WORKSPACE doubles. The summation tree is fixed (no atomics):
+ * the value, and with it every accept/reject decision of an adaptive solve, is reproducible. Terms are
+ * evaluated in `dtype`, accumulated in double. */
+#define TSDE_ERROR_NORM_WORKSPACE 1024
+int tsde_error_norm(double* out, double* workspace, const void* y_full, const void* y_half, int64_t n, double rtol,
+                    double atol, double eps, int dtype, void* stream);
 
 /* ---- whole-trajectory kernels (closed-form SDEs) ---------------------------------------------- */
 #define TSDE_TRAJ_EULER 0

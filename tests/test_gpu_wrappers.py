@@ -96,3 +96,24 @@ def test_explicit_adjoint_params_and_no_module():
     ys = torchsde_amd.sdeint_adjoint(Plain(), y0, ts, method="euler", dt=2.0 ** -5, adjoint_params=(theta,))
     ys[-1].sum().backward()
     assert theta.grad is not None and torch.isfinite(theta.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 7, 4096, 65536 * 64 + 3])
+def test_error_norm_matches_reference_formula(n, dtype):
+    """tsde_error_norm vs adaptive_stepping.py:42-76 evaluated with torch ops (sum order differs: tolerance)."""
+    from torchsde_amd import kernels as K
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    a = torch.randn(n, generator=gen, device=DEV, dtype=dtype)
+    b = a + 1e-3 * torch.randn(n, generator=gen, device=DEV, dtype=dtype)
+    rtol, atol, eps = 1e-3, 1e-4, 1e-7
+    tol = (rtol * torch.max(a.abs(), b.abs()) + atol).clamp_min(eps)
+    ref = torch.sqrt((((a - b) / tol) ** 2.).double().sum() / n).clamp_min(eps).item()
+    got = K.error_norm(a, b, rtol, atol, eps)
+    assert got.dtype == torch.float64 and got.dim() == 0
+    assert abs(got.item() - ref) <= (1e-5 if dtype == torch.float32 else 1e-12) * ref
+    assert K.error_norm(a, b, rtol, atol, eps).item() == got.item()          # fixed summation tree: reproducible
+    assert K.error_norm(a, a, rtol, atol, eps).item() == pytest.approx(eps)  # clamped from below
+    if n > 1:
+        b[n // 2] = float("nan")
+        assert math.isnan(K.error_norm(a, b, rtol, atol, eps).item())

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtorchsde_amd.so")
 F32, F64 = 0, 1
 KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDATE, KID_BROWNIAN_QUERY = 1, 2, 3, 4, 5, 6
 KID_RHEUN, KID_TRAJECTORY = 7, 8
+ERROR_NORM_WORKSPACE = 1024
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 
 _c_i64 = ctypes.c_int64
@@ -91,6 +92,7 @@ SIGNATURES = {
                                        ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_aug_update": (_c_int, [ctypes.POINTER(Seg), _c_int, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_linear_interp": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_ptr]),
+    "tsde_error_norm": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_trajectory_affine_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
                                              ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),

@@ -312,6 +312,16 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
                 tsde::launch_interp<double>(out, ya, yb, n, w0, w1, s));
 }
 
+int tsde_error_norm(double* out, double* workspace, const void* y_full, const void* y_half, int64_t n, double rtol,
+                    double atol, double eps, int dtype, void* stream) {
+  if (!out || !workspace || !y_full || !y_half) return bad_arg("tsde_error_norm", "null argument");
+  if (n <= 0) return bad_arg("tsde_error_norm", "n must be positive");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_error_norm",
+                tsde::launch_error_norm<float>(out, workspace, y_full, y_half, n, rtol, atol, eps, s),
+                tsde::launch_error_norm<double>(out, workspace, y_full, y_half, n, rtol, atol, eps, s));
+}
+
 int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
                                 const void* drift_shift, const void* diff_rate, const void* diff_shift, int method,
                                 const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,

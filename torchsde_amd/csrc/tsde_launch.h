@@ -85,6 +85,10 @@ template <typename T>
 hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const void* ay, const void* az0,
                               const void* vjp_z, int64_t n, double dt, double half_dt, const tsde_noise_t* nz,
                               hipStream_t s);
+// reduce.hip
+template <typename T>
+hipError_t launch_error_norm(double* out, double* workspace, const void* yf, const void* yh, int64_t n, double rtol,
+                             double atol, double eps, hipStream_t s);
 // trajectory.hip
 template <typename T>
 hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* a,

@@ -398,6 +398,27 @@ def linear_interp(ya, yb, w0, w1, out=None):
     return out
 
 
+_ERROR_NORM_SCRATCH = {}
+
+
+def error_norm(y_full, y_half, rtol, atol, eps=1e-7):
+    """Scaled RMS difference of a full step and two half steps (adaptive_stepping.py:42-76) as a 0-d float64
+    device tensor: one fused, deterministic reduction (``tsde_error_norm``). The caller reads it with ``.item()``."""
+    y_full = _native.contiguous(y_full.detach())
+    y_half, = _prep(y_full, y_half.detach())
+    lib, dt_code, stream = _launch_env(y_full)
+    dev = y_full.device
+    buf = _ERROR_NORM_SCRATCH.get((dev, stream))   # one scratch per stream: launches on a stream are ordered
+    if buf is None:
+        buf = torch.empty(_native.ERROR_NORM_WORKSPACE + 1, dtype=torch.float64, device=dev)
+        _ERROR_NORM_SCRATCH[(dev, stream)] = buf
+    out = buf[_native.ERROR_NORM_WORKSPACE:]
+    code = lib.tsde_error_norm(out.data_ptr(), buf.data_ptr(), y_full.data_ptr(), y_half.data_ptr(), y_full.numel(),
+                               float(rtol), float(atol), float(eps), dt_code, stream)
+    _native.check(code, "tsde_error_norm")
+    return out[0]
+
+
 class TrajectorySchedule:
     """Device-resident ``tsde_traj_t`` of one solve: step rows, Brownian cells and the output map."""
 

@@ -37,10 +37,7 @@ class _Step:
 
 def _error_estimate(y_full, y_half, rtol, atol, eps=1e-7):
     """Scaled RMS difference between one full step and two half steps (adaptive_stepping.py:42-76)."""
-    tol = (rtol * torch.max(y_full.abs(), y_half.abs()) + atol).clamp_min(eps)
-    ratio = (y_full - y_half) / tol
-    err = torch.sqrt((ratio ** 2.).sum() / ratio.numel()).clamp_min(eps)
-    value = err.item()   # the one host sync of an adaptive step
+    value = K.error_norm(y_full, y_half, rtol, atol, eps).item()   # the one host sync of an adaptive step
     if value != value:
         raise AssertionError("Found nans in the error estimate. Try increasing the tolerance or regularizing the "
                              "dynamics.")
