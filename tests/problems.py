@@ -186,3 +186,44 @@ def make(name, dtype=torch.float32, **kw):
         "readme": lambda: ReadmeSDE(dtype=dtype),
     }
     return table[name]()
+
+
+class PartialDependence(nn.Module):
+    """Diagonal Ito SDEs whose drift/diffusion ignore part of their inputs, with a mix of trainable, frozen and unused
+    parameters (the situations of the reference's BasicSDE1-4, tests/problems.py:258-328):
+
+      kind "state"     f, g depend on t, y, a trainable and a frozen parameter
+      kind "params"    f, g depend on the parameters only (not on y or t)
+      kind "frozen"    like "params", but every parameter that is used is frozen
+      kind "constant"  f, g are constants
+    An auxiliary drift `h` exists for `names={"drift": "h"}`.
+    """
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, d=10, kind="state", seed=11, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        used_trainable = kind != "frozen"
+        self.kind = kind
+        self.scale = nn.Parameter(torch.randn(1, d, generator=gen).to(dtype), requires_grad=used_trainable)
+        self.frozen = nn.Parameter(torch.randn(1, d, generator=gen).to(dtype), requires_grad=False)
+        self.spare_frozen = nn.Parameter(torch.randn(1, d, generator=gen).to(dtype), requires_grad=False)
+        self.spare_trainable = nn.Parameter(torch.randn(1, d, generator=gen).to(dtype), requires_grad=True)
+
+    def f(self, t, y):
+        if self.kind == "state":
+            return 0.2 * self.scale * torch.sin(y) + 0.1 * torch.cos(y * y) + torch.cos(t) + 0.1 * self.frozen * y
+        if self.kind == "constant":
+            return torch.full_like(y, 0.1)
+        return 0.2 * self.scale + 0.1 * self.frozen + torch.zeros_like(y)
+
+    def g(self, t, y):
+        if self.kind == "state":
+            return (torch.sigmoid(0.3 * self.scale * torch.cos(y) + torch.sin(t)) + torch.sigmoid(self.frozen * y)
+                    + 0.1)
+        if self.kind == "constant":
+            return torch.full_like(y, 0.6)
+        return torch.sigmoid(0.3 * self.scale) + torch.sigmoid(self.frozen) + torch.zeros_like(y) + 0.1
+
+    def h(self, t, y):
+        return torch.sigmoid(y)

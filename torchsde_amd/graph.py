@@ -41,7 +41,9 @@ class _CapturedSolve:
                 solver._run(self.plan, self.y_in)
             torch.cuda.current_stream(device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: API calls from other threads (e.g. the RCCL watchdog of a multi-GPU run) must not
+            # invalidate this capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.ys = solver._run(self.plan, self.y_in)
         finally:
             bm._entropy_dev = None
