@@ -1,0 +1,73 @@
+"""Host-side cost per solver step in the TRAINING regime (small batch, gradients on): backprop through the solver and
+sdeint_adjoint, on a latent-SDE-sized diagonal problem. Prints time per step and a cProfile of one iteration."""
+import cProfile
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import torchsde_amd  # noqa: E402
+from tests import problems  # noqa: E402
+
+dev = "cuda"
+B, d, n, dt = 1024, 8, 200, 2.0 ** -8
+ts = torch.tensor([0.0, n * dt], device=dev)
+
+
+def iteration(fn, method, sde_type, **kw):
+    sde = problems.make("mlpdiag_" + ("ito" if sde_type == "ito" else "strat"), d=d).to(dev)
+    y0 = torch.full((B, d), 0.1, device=dev, requires_grad=True)
+    levy = "space-time" if method == "srk" else "none"
+
+    def go(i):
+        bm = torchsde_amd.BrownianInterval(0.0, n * dt, size=(B, d), device=dev, dtype=torch.float32, entropy=i, dt=dt,
+                                           levy_area_approximation=levy)
+        ys = fn(sde, y0, ts, bm=bm, method=method, dt=dt, **kw)
+        ys[-1].sum().backward()
+    return go
+
+
+cases = [("backprop euler", torchsde_amd.sdeint, "euler", "ito", {}),
+         ("backprop midpoint", torchsde_amd.sdeint, "midpoint", "stratonovich", {}),
+         ("backprop reversible_heun", torchsde_amd.sdeint, "reversible_heun", "stratonovich", {}),
+         ("adjoint euler/euler", torchsde_amd.sdeint_adjoint, "euler", "ito", {"adjoint_method": "euler"}),
+         ("adjoint midpoint", torchsde_amd.sdeint_adjoint, "midpoint", "stratonovich", {}),
+         ("adjoint reversible_heun", torchsde_amd.sdeint_adjoint, "reversible_heun", "stratonovich",
+          {"adjoint_method": "adjoint_reversible_heun"})]
+for name, fn, method, sde_type, kw in cases:
+    go = iteration(fn, method, sde_type, **kw)
+    go(0)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(3):
+        go(1 + i)
+    torch.cuda.synchronize()
+    print(f"{name:28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 3 / n * 1e6:7.1f} us")
+
+which = sys.argv[1] if len(sys.argv) > 1 else "adjoint midpoint"
+for name, fn, method, sde_type, kw in cases:
+    if name == which:
+        go = iteration(fn, method, sde_type, **kw)
+        go(0)
+        pr = cProfile.Profile()
+        pr.enable()
+        go(1)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+
+# the same adjoint cases with forward solve and backward sweep replayed as HIP graphs
+for name, fn, method, sde_type, kw in cases:
+    if fn is not torchsde_amd.sdeint_adjoint or method == "reversible_heun":
+        continue
+    go = iteration(fn, method, sde_type, options={"hip_graph": True}, adjoint_options={"hip_graph": True}, **kw)
+    go(0)
+    go(1)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(5):
+        go(2 + i)
+    torch.cuda.synchronize()
+    print(f"{name + ' [graphs]':28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")

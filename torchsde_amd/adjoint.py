@@ -365,6 +365,7 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                                          adjoint_method == METHODS.adjoint_reversible_heun)
         extras_for_backward = tuple(extra_solver_state) if ctx.saved_extras_for_backward else ()
         ctx.save_for_backward(ys, ts, *extras_for_backward, *adjoint_params)
+        ctx.captured_backward = None   # set by `sdeint_adjoint` when adjoint_options={"hip_graph": True}
         return (ys, *extra_solver_state)
 
     @staticmethod
@@ -377,78 +378,146 @@ class _SdeintAdjointMethod(torch.autograd.Function):
             return _reversible_heun_backward(ctx, ys, ts, forward_extras, adjoint_params, grad_ys,
                                              grad_extra_solver_state)
         adjoint_params = rest
-        sde, bm, dt = ctx.sde, ctx.bm, ctx.dt
-        adjoint_sde = AdjointSDE(sde, adjoint_params)
-        method_cls = _check_adjoint_method(adjoint_sde, ctx.adjoint_method, ctx.adjoint_options, bm)
-        kind = ("euler" if method_cls is solvers.Euler else "midpoint" if method_cls is solvers.Midpoint
-                else "milstein")
-        ito = sde.sde_type == SDE_TYPES.ito
-        device, dtype = ys.device, ys.dtype
-        native = bm if isinstance(bm, BrownianInterval) else None
-        reverse_bm = None if native is not None else ReverseBrownian(bm)
+        captured = ctx.captured_backward
+        if captured is not None:
+            a_y, a_theta = captured.replay(ctx.bm, ys, grad_ys)
+        else:
+            kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
+            run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
+            a_y, a_theta = run(ys, grad_ys)
+        return (None,) * 13 + tuple([a_y] + ([None] * ctx.len_extras) + list(a_theta))
 
-        ts_host = timegrid.ts_to_host(ts)
-        T = ys.size(0)
-        state = _AugState([ys[-1].clone(), grad_ys[-1].contiguous().clone()] +
-                          [torch.zeros_like(p) for p in adjoint_params])
-        other = _AugState.like(state)
-        mid = _AugState.like(state) if kind == "midpoint" else None
-        none_tail = [None] * (len(state.t) - 1)
 
-        for i in range(T - 1, 0, -1):
-            grid = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)
-            n = grid.n_steps
-            np_dtype = grid.t.dtype.type
-            tau64 = grid.t_f64()
-            # forward-time stage tensors: -(tau0), and for midpoint -(tau0 + dt/2)   (adjoint_sde.py passes -t)
-            stage = np.empty((max(n, 1), 2), dtype=grid.t.dtype)
-            stage[:n, 0] = -grid.t[:-1]
-            stage[:n, 1] = -(grid.t[:-1] + np_dtype(0.5) * grid.dt)
-            stage_dev = torch.from_numpy(stage).to(device)
-            stage_rows = [r.unbind(0) for r in stage_dev.unbind(0)]
-            tau_dev = None
-            cells = None
+def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys):
+    """HIP graph of the backward sweep (cached per structure on the SDE object), or None -> eager backward.
+
+    The VJPs of the sweep are taken w.r.t. the parameters. The real parameters already carry AccumulateGrad nodes
+    created on the default stream by the forward call (the autograd graph of `ys` keeps them alive), and autograd
+    would synchronise the capture stream with that stream -- which invalidates the capture. So, while the sweep is
+    recorded, the module runs on leaf ALIASES of its parameters (same storage, fresh autograd identity): the
+    recorded kernels read the real parameter memory, so optimiser steps are seen by every replay."""
+    from torch.nn.utils.stateless import _reparametrize_module
+    from . import graph
+    if not isinstance(sde, nn.Module):
+        return None
+    ts_host = timegrid.ts_to_host(ts)
+    kind = _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params)
+    signature = ("adjoint-backward", kind, sde.sde_type, sde.noise_type, tuple(ys.shape), ys.dtype, str(ys.device),
+                 tuple(ts_host.tolist()), float(dt), tuple((p.data_ptr(), tuple(p.shape)) for p in adjoint_params))
+
+    def capture():
+        alias_of = {id(p): p.detach().requires_grad_(True) for p in adjoint_params}
+        swapped = {name: alias_of[id(p)] for name, p in sde.named_parameters(remove_duplicate=False)
+                   if id(p) in alias_of}
+        if len({id(a) for a in swapped.values()}) != len(alias_of):
+            warnings.warn("adjoint_options['hip_graph'] needs every adjoint parameter to be a parameter of the SDE "
+                          "module; running the backward pass eagerly.")
+            return None
+        run = _backward_runner(sde, bm, dt, kind, [alias_of[id(p)] for p in adjoint_params], ts_host, ys.device)
+        with torch.no_grad(), _reparametrize_module(sde, swapped):
+            return graph._CapturedBackward(run, bm, ys, torch.zeros_like(ys))
+
+    return graph.cached_backward(sde, bm, signature, capture)
+
+
+def _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params):
+    method_cls = _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
+    return "euler" if method_cls is solvers.Euler else "midpoint" if method_cls is solvers.Midpoint else "milstein"
+
+
+def _backward_runner(sde, bm, dt, kind, adjoint_params, ts_host, device):
+    """`run(ys, grad_ys) -> (a_y0, [a_theta...])`: the launch-only backward sweep over a plan prepared here."""
+    adjoint_sde = AdjointSDE(sde, adjoint_params)
+    plan = _plan_backward(ts_host, dt, bm if isinstance(bm, BrownianInterval) else None, device)
+
+    def run(ys_, grad_ys_):
+        return _run_backward(adjoint_sde, kind, bm, plan, ys_, grad_ys_)
+
+    return run
+
+
+def _plan_backward(ts_host, dt, native, device):
+    """Host-side preparation of the backward sweep (everything that copies from the host): per output interval the
+    reversed time grid, its stage times on the device, and the Brownian cell of every step when the reversed steps
+    line up with the generator's cells."""
+    intervals = []
+    misaligned = False
+    for i in range(len(ts_host) - 1, 0, -1):
+        grid = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)
+        n = grid.n_steps
+        np_dtype = grid.t.dtype.type
+        tau64 = grid.t_f64()
+        # forward-time stage tensors: -(tau0), and for midpoint -(tau0 + dt/2)   (adjoint_sde.py passes -t)
+        stage = np.empty((max(n, 1), 2), dtype=grid.t.dtype)
+        stage[:n, 0] = -grid.t[:-1]
+        stage[:n, 1] = -(grid.t[:-1] + np_dtype(0.5) * grid.dt)
+        stage_dev = torch.from_numpy(stage).to(device)
+        stage_rows = [r.unbind(0) for r in stage_dev.unbind(0)]
+        tau_dev = None
+        cells = None
+        if native is not None:
+            cells = native.match_grid(-tau64[::-1]) if native.frozen else None
+            misaligned = misaligned or cells is None
+        else:
+            tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
+        intervals.append((i, grid, tau64, stage_rows, cells, tau_dev))
+    if misaligned:
+        native.locate(float(ts_host[0]), float(ts_host[-1]))   # freezes a generator that never saw a grid
+        native._device_edges()    # upload the cell edges now: the sweep itself must not copy from the host
+    return intervals
+
+
+def _run_backward(adjoint_sde, kind, bm, plan, ys, grad_ys):
+    """Launch-only part of the backward sweep (capturable in a HIP graph): returns (a_y0, [a_theta...])."""
+    sde = adjoint_sde.forward_sde
+    adjoint_params = adjoint_sde.params
+    ito = sde.sde_type == SDE_TYPES.ito
+    native = bm if isinstance(bm, BrownianInterval) else None
+    reverse_bm = None if native is not None else ReverseBrownian(bm)
+    state = _AugState([ys[-1].clone(), grad_ys[-1].contiguous().clone()] +
+                      [torch.zeros_like(p) for p in adjoint_params])
+    other = _AugState.like(state)
+    mid = _AugState.like(state) if kind == "midpoint" else None
+    none_tail = [None] * (len(state.t) - 1)
+
+    for (i, grid, tau64, stage_rows, cells, tau_dev) in plan:
+        n = grid.n_steps
+        np_dtype = grid.t.dtype.type
+        for k in range(n):
+            step_dt = grid.dt[k]
             if native is not None:
-                cells = native.match_grid(-tau64[::-1]) if native.frozen else None
-            else:
-                tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
-
-            for k in range(n):
-                step_dt = grid.dt[k]
-                if native is not None:
-                    if cells is not None:
-                        c = int(cells[n - 1 - k])
-                        noise = NoiseSpec.generated(native, c, native.cell_width(c))
-                        v, _ = noise.materialise()
-                    else:
-                        v, _ = native.increment(-tau64[k + 1], -tau64[k])
+                if cells is not None:
+                    c = int(cells[n - 1 - k])
+                    noise = NoiseSpec.generated(native, c, native.cell_width(c))
+                    v, _ = noise.materialise()
                 else:
-                    v = reverse_bm(tau_dev[k], tau_dev[k + 1])
-                y, a = state.t[0], state.t[1]
-                t_fwd = stage_rows[k][0]
-                if kind == "euler":
-                    # y' = y - f~ dt - g.v ;  (a, theta)' += dt*vjp(f~) + vjp(g.v)  (one reverse sweep, one launch)
-                    ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(step_dt), 1.0)
-                    _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
-                elif kind == "midpoint":
-                    half_dt = np_dtype(0.5) * step_dt
-                    ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(half_dt), 0.5)
-                    _update(mid, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, half_dt, 0.5)
-                    ft, gp, tot = adjoint_sde.fused_terms(stage_rows[k][1], mid.t[0], mid.t[1], v, float(step_dt), 1.0)
-                    _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
-                else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
-                    v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
-                    F = adjoint_sde.f(t_fwd, y, a)
-                    G, D = adjoint_sde.g_prod_and_gdg_prod(t_fwd, y, a, v, v2)
-                    _update(other, state, F, G, D, step_dt, 1.0)
-                state, other = other, state
-            # adjoint.py:114-116
-            state.t[0].copy_(ys[i - 1])
-            state.t[1].add_(grad_ys[i - 1])
+                    v, _ = native.increment(-tau64[k + 1], -tau64[k])
+            else:
+                v = reverse_bm(tau_dev[k], tau_dev[k + 1])
+            y, a = state.t[0], state.t[1]
+            t_fwd = stage_rows[k][0]
+            if kind == "euler":
+                # y' = y - f~ dt - g.v ;  (a, theta)' += dt*vjp(f~) + vjp(g.v)  (one reverse sweep, one launch)
+                ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(step_dt), 1.0)
+                _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
+            elif kind == "midpoint":
+                half_dt = np_dtype(0.5) * step_dt
+                ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(half_dt), 0.5)
+                _update(mid, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, half_dt, 0.5)
+                ft, gp, tot = adjoint_sde.fused_terms(stage_rows[k][1], mid.t[0], mid.t[1], v, float(step_dt), 1.0)
+                _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
+            else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
+                v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
+                F = adjoint_sde.f(t_fwd, y, a)
+                G, D = adjoint_sde.g_prod_and_gdg_prod(t_fwd, y, a, v, v2)
+                _update(other, state, F, G, D, step_dt, 1.0)
+            state, other = other, state
+        # adjoint.py:114-116
+        state.t[0].copy_(ys[i - 1])
+        state.t[1].add_(grad_ys[i - 1])
 
-        _SEG_CACHE.clear()   # drop the references to this pass's buffers
-        out = [state.t[1]] + ([None] * ctx.len_extras) + state.t[2:]
-        return (None,) * 13 + tuple(out)
+    _SEG_CACHE.clear()   # drop the references to this pass's buffers
+    return state.t[1], state.t[2:]
 
 
 def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e-3, adaptive=False,
@@ -497,6 +566,13 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e
     ys, *extra_solver_state = _SdeintAdjointMethod.apply(
         sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
+    if (adjoint_options.get("hip_graph", False) and ys.grad_fn is not None and isinstance(bm, BrownianInterval)
+            and not (method == METHODS.reversible_heun and adjoint_method == METHODS.adjoint_reversible_heun)):
+        # The backward sweep replays ONE HIP graph, captured HERE (on the caller's thread, outside the autograd
+        # Function) with zero cotangents; `backward` only copies ys / grad_ys into the graph's static inputs and
+        # replays. `ys.grad_fn` is the Function's ctx.
+        ys.grad_fn.captured_backward = _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params,
+                                                         ts, ys.detach())
     return contract.parse_return(y0, ys, tuple(extra_solver_state), extra, logqp)
 
 

@@ -33,6 +33,9 @@ class _CapturedSolve:
         self.y_in.copy_(y0)
         self._set_seed(bm)
         bm._entropy_dev = self.seed_dev
+        # the captured kernels hold raw pointers into this solver's Brownian motion (device copy of the cell edges)
+        # and into the plan's stage-time tensors: keep both alive for as long as the graph
+        self._keepalive = solver
         try:
             self.plan = solver._plan(self.y_in, ts)
             side = torch.cuda.Stream(device=device)
@@ -94,3 +97,73 @@ def replay_or_capture(solver, y0, ts):
         cache[sig] = captured
         return captured.ys.clone()
     return captured.replay(bm, y0)
+
+
+class _CapturedBackward:
+    """The launch-only backward sweep of ``sdeint_adjoint`` (``adjoint._run_backward``: re-materialised increments,
+    the user's f/g and their VJPs through autograd, ``tsde_aug_update``) as ONE HIP graph. Static inputs: the stored
+    forward states ``ys`` and the incoming gradients ``grad_ys`` (copied in before each replay), the Brownian seed
+    (device word) and the parameters themselves (read in place: an optimiser step is seen by the next replay)."""
+
+    def __init__(self, run, bm, ys, grad_ys):
+        device = ys.device
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.ys_in = torch.empty_like(ys, memory_format=torch.contiguous_format)
+        self.gy_in = torch.empty_like(grad_ys, memory_format=torch.contiguous_format)
+        self._load(bm, ys, grad_ys)
+        bm._entropy_dev = self.seed_dev
+        # `run` owns the plan (stage-time tensors) and the Brownian motion (device copy of the cell edges) that the
+        # captured kernels point into: keep it alive for as long as the graph
+        self._keepalive = run
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
+                run(self.ys_in, self.gy_in)
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                a_y, a_theta = run(self.ys_in, self.gy_in)
+            self.out = [a_y] + list(a_theta)
+        finally:
+            bm._entropy_dev = None
+        self.graph.replay()
+
+    def _load(self, bm, ys, grad_ys):
+        self.ys_in.copy_(ys)
+        self.gy_in.copy_(grad_ys)
+        key = bm._key
+        self.seed_dev.fill_(key - (1 << 64) if key >= (1 << 63) else key)
+
+    def result(self):
+        out = [o.clone() for o in self.out]
+        return out[0], out[1:]
+
+    def replay(self, bm, ys, grad_ys):
+        self._load(bm, ys, grad_ys)
+        self.graph.replay()
+        return self.result()
+
+
+def cached_backward(sde, bm, signature, capture):
+    """The cached HIP graph of the adjoint's backward sweep for this structure; `capture()` builds it on a miss
+    (and may return None: then nothing is cached and the backward pass runs eagerly).
+    `signature` identifies the sweep's structure; the Brownian structure is appended here."""
+    if bm._rootW is not None or bm._rootH is not None:
+        warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
+        return None
+    base = sde
+    while hasattr(base, "_base_sde"):
+        base = base._base_sde
+    cache = getattr(base, _CACHE_ATTR, None)
+    if cache is None:
+        cache = {}
+        setattr(base, _CACHE_ATTR, cache)
+    sig = signature + (tuple(bm.shape), bm.levy_area_approximation, bm.row_offset,
+                       None if bm._edges is None else bm._edges.tobytes(), bm._max_depth, bm._snap)
+    captured = cache.get(sig)
+    if captured is None:
+        captured = capture()
+        if captured is not None:
+            cache[sig] = captured
+    return captured
