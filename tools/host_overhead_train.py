@@ -60,7 +60,7 @@ for name, fn, method, sde_type, kw in cases:
 
 # the same adjoint cases with forward solve and backward sweep replayed as HIP graphs
 for name, fn, method, sde_type, kw in cases:
-    if fn is not torchsde_amd.sdeint_adjoint or method == "reversible_heun":
+    if fn is not torchsde_amd.sdeint_adjoint:
         continue
     go = iteration(fn, method, sde_type, options={"hip_graph": True}, adjoint_options={"hip_graph": True}, **kw)
     go(0)

@@ -263,40 +263,47 @@ class _ReversibleHeunBackward:
     """Marker returned by `_check_adjoint_method` for METHODS.adjoint_reversible_heun."""
 
 
-def _reversible_heun_backward(ctx, ys, ts, forward_extras, adjoint_params, grad_ys, grad_extras):
-    """Exact-gradient backward pass of reversible Heun (reference: methods/reversible_heun.py:98-144 driven by
-    adjoint.py:64-127): reconstruct (y, f, g, z) algebraically step by step while propagating
-    (a_y, a_f, a_g, a_z, a_theta); one VJP through f_and_g per step. Diagonal noise runs entirely on fused HIP
-    kernels (tsde_rheun_*); other noise types use the contraction kernel for the state and torch ops for the
-    (B, d, m) outer products of the adjoint."""
-    sde, bm, dt = ctx.sde, ctx.bm, ctx.dt
-    _check_adjoint_method(AdjointSDE(sde, adjoint_params), ctx.adjoint_method, ctx.adjoint_options, bm)
-    diag = sde.noise_type == NOISE_TYPES.diagonal
-    device = ys.device
-    native = bm if isinstance(bm, BrownianInterval) else None
-    reverse_bm = None if native is not None else ReverseBrownian(bm)
-    params = list(adjoint_params)
-    ts_host = timegrid.ts_to_host(ts)
-    T = ys.size(0)
-    y = ys[-1]
-    f, g, z = forward_extras
-    a_y = grad_ys[-1].contiguous().clone()
-    a_f, a_g, a_z = [torch.zeros_like(x) if gr is None else gr.contiguous().clone()
-                     for gr, x in zip(grad_extras, forward_extras)]
-    a_theta = [torch.zeros_like(p) for p in params]
-
-    for i in range(T - 1, 0, -1):
+def _plan_reversible_heun_backward(ts_host, dt, native, device):
+    """Host-side preparation of the reversible-Heun backward sweep: per output interval the reversed grid, the
+    forward times of its step boundaries on the device, and the Brownian cell of every step if they line up."""
+    intervals = []
+    misaligned = False
+    for i in range(len(ts_host) - 1, 0, -1):
         grid = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)
-        n = grid.n_steps
-        np_dtype = grid.t.dtype.type
         tau64 = grid.t_f64()
         fwd_times = torch.from_numpy((-grid.t).astype(grid.t.dtype)).to(device).unbind(0)   # forward time = -tau
         tau_dev = None
         cells = None
         if native is not None:
             cells = native.match_grid(-tau64[::-1]) if native.frozen else None
+            misaligned = misaligned or cells is None
         else:
             tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
+        intervals.append((i, grid, tau64, fwd_times, cells, tau_dev))
+    if misaligned:
+        native.locate(float(ts_host[0]), float(ts_host[-1]))
+        native._device_edges()
+    return intervals
+
+
+def _run_reversible_heun_backward(sde, bm, params, plan, ys, grad_ys, f, g, z, a_f, a_g, a_z):
+    """Exact-gradient backward pass of reversible Heun (reference: methods/reversible_heun.py:98-144 driven by
+    adjoint.py:64-127), launch-only part: reconstruct (y, f, g, z) algebraically step by step while propagating
+    (a_y, a_f, a_g, a_z, a_theta); one VJP through f_and_g per step. Diagonal noise runs entirely on fused HIP
+    kernels (tsde_rheun_*); other noise types use the contraction kernel for the state and torch ops for the
+    (B, d, m) outer products of the adjoint. Returns [a_y, a_f, a_g, a_z, *a_theta]."""
+    diag = sde.noise_type == NOISE_TYPES.diagonal
+    native = bm if isinstance(bm, BrownianInterval) else None
+    reverse_bm = None if native is not None else ReverseBrownian(bm)
+    params = list(params)
+    y = ys[-1]
+    a_y = grad_ys[-1].contiguous().clone()
+    a_f, a_g, a_z = a_f.contiguous().clone(), a_g.contiguous().clone(), a_z.contiguous().clone()
+    a_theta = [torch.zeros_like(p) for p in params]
+
+    for (i, grid, tau64, fwd_times, cells, tau_dev) in plan:
+        n = grid.n_steps
+        np_dtype = grid.t.dtype.type
         for k in range(n):
             step_dt = grid.dt[k]
             half_dt = np_dtype(0.5) * step_dt
@@ -343,7 +350,7 @@ def _reversible_heun_backward(ctx, ys, ts, forward_extras, adjoint_params, grad_
         # adjoint.py:114-116
         y = ys[i - 1]
         a_y = a_y + grad_ys[i - 1]
-    return (None,) * 13 + (a_y, a_f, a_g, a_z) + tuple(a_theta)
+    return [a_y, a_f, a_g, a_z] + a_theta
 
 
 class _SdeintAdjointMethod(torch.autograd.Function):
@@ -373,22 +380,25 @@ class _SdeintAdjointMethod(torch.autograd.Function):
         if torch.is_grad_enabled():
             raise NotImplementedError("torchsde_amd: double backward through sdeint_adjoint is not supported.")
         ys, ts, *rest = ctx.saved_tensors
-        if ctx.saved_extras_for_backward:
-            forward_extras, adjoint_params = rest[:ctx.len_extras], rest[ctx.len_extras:]
-            return _reversible_heun_backward(ctx, ys, ts, forward_extras, adjoint_params, grad_ys,
-                                             grad_extra_solver_state)
-        adjoint_params = rest
+        reversible = ctx.saved_extras_for_backward
+        forward_extras = rest[:ctx.len_extras] if reversible else []
+        adjoint_params = rest[ctx.len_extras:] if reversible else rest
+        grad_extras = [torch.zeros_like(x) if gr is None else gr
+                       for gr, x in zip(grad_extra_solver_state, forward_extras)]
+        inputs = [ys, grad_ys] + list(forward_extras) + grad_extras
         captured = ctx.captured_backward
         if captured is not None:
-            a_y, a_theta = captured.replay(ctx.bm, ys, grad_ys)
+            out = captured.replay(ctx.bm, inputs)
         else:
             kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
             run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
-            a_y, a_theta = run(ys, grad_ys)
-        return (None,) * 13 + tuple([a_y] + ([None] * ctx.len_extras) + list(a_theta))
+            out = run(*inputs)
+        if reversible:      # a_y, (a_f, a_g, a_z), a_theta...
+            return (None,) * 13 + tuple(out)
+        return (None,) * 13 + tuple([out[0]] + ([None] * ctx.len_extras) + list(out[1:]))
 
 
-def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys):
+def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys, forward_extras):
     """HIP graph of the backward sweep (cached per structure on the SDE object), or None -> eager backward.
 
     The VJPs of the sweep are taken w.r.t. the parameters. The real parameters already carry AccumulateGrad nodes
@@ -414,25 +424,38 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
                           "module; running the backward pass eagerly.")
             return None
         run = _backward_runner(sde, bm, dt, kind, [alias_of[id(p)] for p in adjoint_params], ts_host, ys.device)
+        # zero cotangents: the capture only records; `backward` copies the real ones in before each replay
+        inputs = [ys, torch.zeros_like(ys)] + list(forward_extras) + [torch.zeros_like(x) for x in forward_extras]
         with torch.no_grad(), _reparametrize_module(sde, swapped):
-            return graph._CapturedBackward(run, bm, ys, torch.zeros_like(ys))
+            return graph._CapturedBackward(run, bm, inputs)
 
     return graph.cached_backward(sde, bm, signature, capture)
 
 
 def _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params):
     method_cls = _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
+    if method_cls is _ReversibleHeunBackward:
+        return "reversible_heun"
     return "euler" if method_cls is solvers.Euler else "midpoint" if method_cls is solvers.Midpoint else "milstein"
 
 
 def _backward_runner(sde, bm, dt, kind, adjoint_params, ts_host, device):
-    """`run(ys, grad_ys) -> (a_y0, [a_theta...])`: the launch-only backward sweep over a plan prepared here."""
+    """`run(ys, grad_ys, *extras) -> [a_y0, ..., *a_theta]`: the launch-only backward sweep over a plan prepared here.
+    For the reversible-Heun pair the extras are (f, g, z, a_f, a_g, a_z) and the result carries (a_f, a_g, a_z)
+    after a_y."""
+    native = bm if isinstance(bm, BrownianInterval) else None
+    if kind == "reversible_heun":
+        plan = _plan_reversible_heun_backward(ts_host, dt, native, device)
+
+        def run(ys_, grad_ys_, f, g, z, a_f, a_g, a_z):
+            return _run_reversible_heun_backward(sde, bm, adjoint_params, plan, ys_, grad_ys_, f, g, z, a_f, a_g, a_z)
+        return run
     adjoint_sde = AdjointSDE(sde, adjoint_params)
-    plan = _plan_backward(ts_host, dt, bm if isinstance(bm, BrownianInterval) else None, device)
+    plan = _plan_backward(ts_host, dt, native, device)
 
     def run(ys_, grad_ys_):
-        return _run_backward(adjoint_sde, kind, bm, plan, ys_, grad_ys_)
-
+        a_y, a_theta = _run_backward(adjoint_sde, kind, bm, plan, ys_, grad_ys_)
+        return [a_y] + list(a_theta)
     return run
 
 
@@ -566,13 +589,14 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e
     ys, *extra_solver_state = _SdeintAdjointMethod.apply(
         sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
-    if (adjoint_options.get("hip_graph", False) and ys.grad_fn is not None and isinstance(bm, BrownianInterval)
-            and not (method == METHODS.reversible_heun and adjoint_method == METHODS.adjoint_reversible_heun)):
+    if adjoint_options.get("hip_graph", False) and ys.grad_fn is not None and isinstance(bm, BrownianInterval):
         # The backward sweep replays ONE HIP graph, captured HERE (on the caller's thread, outside the autograd
         # Function) with zero cotangents; `backward` only copies ys / grad_ys into the graph's static inputs and
         # replays. `ys.grad_fn` is the Function's ctx.
-        ys.grad_fn.captured_backward = _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params,
-                                                         ts, ys.detach())
+        reversible = method == METHODS.reversible_heun and adjoint_method == METHODS.adjoint_reversible_heun
+        ys.grad_fn.captured_backward = _capture_backward(
+            sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys.detach(),
+            [x.detach() for x in extra_solver_state] if reversible else [])
     return contract.parse_return(y0, ys, tuple(extra_solver_state), extra, logqp)
 
 

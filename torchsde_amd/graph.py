@@ -25,12 +25,14 @@ _CACHE_ATTR = "_tsde_hip_graphs"
 
 
 class _CapturedSolve:
-    def __init__(self, solver, y0, ts):
+    def __init__(self, solver, y0, ts, extra0=()):
         bm = solver.bm
         device = y0.device
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
         self.y_in = torch.empty_like(y0, memory_format=torch.contiguous_format)
         self.y_in.copy_(y0)
+        # solvers that carry state between steps (reversible Heun: f, g, z) get it as further static inputs
+        self.extra_in = [torch.empty_like(e, memory_format=torch.contiguous_format).copy_(e) for e in extra0]
         self._set_seed(bm)
         bm._entropy_dev = self.seed_dev
         # the captured kernels hold raw pointers into this solver's Brownian motion (device copy of the cell edges)
@@ -41,13 +43,16 @@ class _CapturedSolve:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
+                solver._extra = tuple(self.extra_in)
                 solver._run(self.plan, self.y_in)
             torch.cuda.current_stream(device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls from other threads (e.g. the RCCL watchdog of a multi-GPU run) must not
             # invalidate this capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                solver._extra = tuple(self.extra_in)
                 self.ys = solver._run(self.plan, self.y_in)
+                self.extra_out = tuple(solver._extra)
         finally:
             bm._entropy_dev = None
         self.graph.replay()     # capture only records: run once so that `ys` holds this solve's result
@@ -56,11 +61,16 @@ class _CapturedSolve:
         key = bm._key
         self.seed_dev.fill_(key - (1 << 64) if key >= (1 << 63) else key)   # two's complement into int64
 
-    def replay(self, bm, y0):
+    def result(self):
+        return self.ys.clone(), tuple(e.clone() for e in self.extra_out)
+
+    def replay(self, bm, y0, extra0=()):
         self.y_in.copy_(y0)
+        for dst, src in zip(self.extra_in, extra0):
+            dst.copy_(src)
         self._set_seed(bm)
         self.graph.replay()
-        return self.ys.clone()
+        return self.result()
 
 
 def _signature(solver, y0, ts_host):
@@ -71,12 +81,13 @@ def _signature(solver, y0, ts_host):
             tuple(sorted((k, v) for k, v in solver.options.items() if isinstance(v, (bool, int, float, str)))))
 
 
-def replay_or_capture(solver, y0, ts):
-    """Run the solve through a cached HIP graph (capturing it on first use); returns ys."""
+def replay_or_capture(solver, y0, ts, extra0=()):
+    """Run the solve through a cached HIP graph (capturing it on first use); returns (ys, extra solver state)."""
     bm = solver.bm
     if not isinstance(bm, BrownianInterval) or bm._rootW is not None or bm._rootH is not None:
         warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
-        return solver._run(solver._plan(y0, ts), y0)
+        solver._extra = tuple(extra0)
+        return solver._run(solver._plan(y0, ts), y0), solver._extra
     from . import timegrid
     ts_host = timegrid.ts_to_host(ts)
     base = solver.sde
@@ -93,24 +104,24 @@ def replay_or_capture(solver, y0, ts):
     sig = _signature(solver, y0, ts_host)
     captured = cache.get(sig)
     if captured is None:
-        captured = _CapturedSolve(solver, y0, ts)
+        captured = _CapturedSolve(solver, y0, ts, extra0)
         cache[sig] = captured
-        return captured.ys.clone()
-    return captured.replay(bm, y0)
+        return captured.result()
+    return captured.replay(bm, y0, extra0)
 
 
 class _CapturedBackward:
     """The launch-only backward sweep of ``sdeint_adjoint`` (``adjoint._run_backward``: re-materialised increments,
     the user's f/g and their VJPs through autograd, ``tsde_aug_update``) as ONE HIP graph. Static inputs: the stored
-    forward states ``ys`` and the incoming gradients ``grad_ys`` (copied in before each replay), the Brownian seed
+    forward states ``ys`` and the incoming gradients ``grad_ys`` -- plus, for the reversible-Heun pair, the solver's
+    final (f, g, z) and their cotangents -- (copied in before each replay), the Brownian seed
     (device word) and the parameters themselves (read in place: an optimiser step is seen by the next replay)."""
 
-    def __init__(self, run, bm, ys, grad_ys):
-        device = ys.device
+    def __init__(self, run, bm, inputs):
+        device = inputs[0].device
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
-        self.ys_in = torch.empty_like(ys, memory_format=torch.contiguous_format)
-        self.gy_in = torch.empty_like(grad_ys, memory_format=torch.contiguous_format)
-        self._load(bm, ys, grad_ys)
+        self.static = [torch.empty_like(x, memory_format=torch.contiguous_format) for x in inputs]
+        self._load(bm, inputs)
         bm._entropy_dev = self.seed_dev
         # `run` owns the plan (stage-time tensors) and the Brownian motion (device copy of the cell edges) that the
         # captured kernels point into: keep it alive for as long as the graph
@@ -119,30 +130,24 @@ class _CapturedBackward:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
-                run(self.ys_in, self.gy_in)
+                run(*self.static)
             torch.cuda.current_stream(device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                a_y, a_theta = run(self.ys_in, self.gy_in)
-            self.out = [a_y] + list(a_theta)
+                self.out = list(run(*self.static))
         finally:
             bm._entropy_dev = None
-        self.graph.replay()
 
-    def _load(self, bm, ys, grad_ys):
-        self.ys_in.copy_(ys)
-        self.gy_in.copy_(grad_ys)
+    def _load(self, bm, inputs):
+        for dst, src in zip(self.static, inputs):
+            dst.copy_(src)
         key = bm._key
         self.seed_dev.fill_(key - (1 << 64) if key >= (1 << 63) else key)
 
-    def result(self):
-        out = [o.clone() for o in self.out]
-        return out[0], out[1:]
-
-    def replay(self, bm, ys, grad_ys):
-        self._load(bm, ys, grad_ys)
+    def replay(self, bm, inputs):
+        self._load(bm, inputs)
         self.graph.replay()
-        return self.result()
+        return [o.clone() for o in self.out]
 
 
 def cached_backward(sde, bm, signature, capture):

@@ -165,9 +165,9 @@ class BaseSDESolver:
             ys = self._integrate_trajectory(coefficients, y0, ts)
             if ys is not None:
                 return ys, self._extra
-        if self.options.get("hip_graph", False) and not self._tracks_grad(y0) and not self.stateful:
+        if self.options.get("hip_graph", False) and not self._tracks_grad(y0):
             from . import graph
-            return graph.replay_or_capture(self, y0, ts), ()
+            return graph.replay_or_capture(self, y0, ts, self._extra)
         ys = self._run(self._plan(y0, ts), y0)
         return ys, self._extra
 
