@@ -24,6 +24,17 @@ from .brownian import BrownianInterval
 _CACHE_ATTR = "_tsde_hip_graphs"
 
 
+_MAX_GRAPHS_PER_SDE = 16
+
+
+def _remember(cache, sig, captured):
+    """Each captured graph pins its memory pool; a caller that keeps changing the structure (e.g. random `ts`) must
+    not grow the cache without bound: the oldest entry goes first."""
+    while len(cache) >= _MAX_GRAPHS_PER_SDE:
+        cache.pop(next(iter(cache)))
+    cache[sig] = captured
+
+
 class _CapturedSolve:
     def __init__(self, solver, y0, ts, extra0=()):
         bm = solver.bm
@@ -105,7 +116,7 @@ def replay_or_capture(solver, y0, ts, extra0=()):
     captured = cache.get(sig)
     if captured is None:
         captured = _CapturedSolve(solver, y0, ts, extra0)
-        cache[sig] = captured
+        _remember(cache, sig, captured)
         return captured.result()
     return captured.replay(bm, y0, extra0)
 
@@ -170,5 +181,5 @@ def cached_backward(sde, bm, signature, capture):
     if captured is None:
         captured = capture()
         if captured is not None:
-            cache[sig] = captured
+            _remember(cache, sig, captured)
     return captured
