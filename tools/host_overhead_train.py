@@ -71,3 +71,17 @@ for name, fn, method, sde_type, kw in cases:
         go(2 + i)
     torch.cuda.synchronize()
     print(f"{name + ' [graphs]':28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
+
+# back-propagation through the solver with the forward solve and its backward recorded as two HIP graphs
+for name, fn, method, sde_type, kw in cases:
+    if fn is not torchsde_amd.sdeint:
+        continue
+    go = iteration(fn, method, sde_type, options={"hip_graph": True}, **kw)
+    go(0)
+    go(1)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(5):
+        go(2 + i)
+    torch.cuda.synchronize()
+    print(f"{name + ' [graphs]':28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")

@@ -427,7 +427,7 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
         # zero cotangents: the capture only records; `backward` copies the real ones in before each replay
         inputs = [ys, torch.zeros_like(ys)] + list(forward_extras) + [torch.zeros_like(x) for x in forward_extras]
         with torch.no_grad(), _reparametrize_module(sde, swapped):
-            return graph._CapturedBackward(run, bm, inputs)
+            return graph._CapturedBackward(run, bm, inputs, keepalive=(run.plan,))
 
     return graph.cached_backward(sde, bm, signature, capture)
 
@@ -449,6 +449,7 @@ def _backward_runner(sde, bm, dt, kind, adjoint_params, ts_host, device):
 
         def run(ys_, grad_ys_, f, g, z, a_f, a_g, a_z):
             return _run_reversible_heun_backward(sde, bm, adjoint_params, plan, ys_, grad_ys_, f, g, z, a_f, a_g, a_z)
+        run.plan = plan
         return run
     adjoint_sde = AdjointSDE(sde, adjoint_params)
     plan = _plan_backward(ts_host, dt, native, device)
@@ -456,6 +457,7 @@ def _backward_runner(sde, bm, dt, kind, adjoint_params, ts_host, device):
     def run(ys_, grad_ys_):
         a_y, a_theta = _run_backward(adjoint_sde, kind, bm, plan, ys_, grad_ys_)
         return [a_y] + list(a_theta)
+    run.plan = plan
     return run
 
 

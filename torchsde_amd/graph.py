@@ -15,6 +15,8 @@ Constraints (checked, with a loud fallback to the eager path otherwise): forward
 tracking; a native ``BrownianInterval``; the user's ``f``/``g`` must be capture-safe torch code (static shapes,
 no host sync, no Python-side state that changes between solves).
 """
+import contextlib
+import gc
 import warnings
 
 import torch
@@ -25,6 +27,20 @@ _CACHE_ATTR = "_tsde_hip_graphs"
 
 
 _MAX_GRAPHS_PER_SDE = 16
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a capture is open: a collected object whose destructor touches the HIP
+    runtime (another CUDAGraph, an event, a cached block) aborts the process when it runs mid-capture."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _remember(cache, sig, captured):
@@ -46,9 +62,10 @@ class _CapturedSolve:
         self.extra_in = [torch.empty_like(e, memory_format=torch.contiguous_format).copy_(e) for e in extra0]
         self._set_seed(bm)
         bm._entropy_dev = self.seed_dev
-        # the captured kernels hold raw pointers into this solver's Brownian motion (device copy of the cell edges)
-        # and into the plan's stage-time tensors: keep both alive for as long as the graph
-        self._keepalive = solver
+        # the captured kernels hold raw pointers into this Brownian motion (device copy of the cell edges) and into
+        # the plan's stage-time tensors: keep both alive for as long as the graph. (Not the solver: it references the
+        # SDE object that owns this cache, and a reference cycle would leave the graph's destruction to the GC.)
+        self._keepalive = bm
         try:
             self.plan = solver._plan(self.y_in, ts)
             side = torch.cuda.Stream(device=device)
@@ -60,7 +77,7 @@ class _CapturedSolve:
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls from other threads (e.g. the RCCL watchdog of a multi-GPU run) must not
             # invalidate this capture
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 solver._extra = tuple(self.extra_in)
                 self.ys = solver._run(self.plan, self.y_in)
                 self.extra_out = tuple(solver._extra)
@@ -128,15 +145,16 @@ class _CapturedBackward:
     final (f, g, z) and their cotangents -- (copied in before each replay), the Brownian seed
     (device word) and the parameters themselves (read in place: an optimiser step is seen by the next replay)."""
 
-    def __init__(self, run, bm, inputs):
+    def __init__(self, run, bm, inputs, keepalive=()):
         device = inputs[0].device
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
         self.static = [torch.empty_like(x, memory_format=torch.contiguous_format) for x in inputs]
         self._load(bm, inputs)
         bm._entropy_dev = self.seed_dev
-        # `run` owns the plan (stage-time tensors) and the Brownian motion (device copy of the cell edges) that the
-        # captured kernels point into: keep it alive for as long as the graph
-        self._keepalive = run
+        # the captured kernels point into the plan (stage-time tensors) and into the Brownian motion (device copy of
+        # the cell edges): keep those alive for as long as the graph (but not `run`, which references the SDE object
+        # that owns this cache)
+        self._keepalive = (bm,) + tuple(keepalive)
         try:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
@@ -144,7 +162,7 @@ class _CapturedBackward:
                 run(*self.static)
             torch.cuda.current_stream(device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = list(run(*self.static))
         finally:
             bm._entropy_dev = None
@@ -183,3 +201,157 @@ def cached_backward(sde, bm, signature, capture):
         if captured is not None:
             _remember(cache, sig, captured)
     return captured
+
+
+# ---- back-propagation THROUGH the solver (sdeint with autograd) as two HIP graphs -------------------------------
+class _CapturedTrainingSolve:
+    """Forward solve recorded WITH its autograd graph, and the back-propagation through it, as two HIP graphs that
+    share a memory pool (the scheme of ``torch.cuda.make_graphed_callables``, with the host-side planning kept
+    outside and the Brownian seed in a device word).
+
+    Static inputs: y0, the solver's initial extra state, the Brownian seed; the parameters are read in place (the
+    module runs on leaf aliases of them while recording, see ``adjoint._capture_backward``). One forward replay
+    must be followed by at most one backward replay before the next forward (the activations live in the pool)."""
+
+    def __init__(self, solver, y0, ts, extra0, params):
+        from torch.nn.utils.stateless import _reparametrize_module
+        bm = solver.bm
+        device = y0.device
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.y_in = torch.empty_like(y0, memory_format=torch.contiguous_format).requires_grad_(y0.requires_grad)
+        self.extra_in = [torch.empty_like(e, memory_format=torch.contiguous_format).requires_grad_(e.requires_grad)
+                         for e in extra0]
+        self._load(bm, y0, extra0)
+        alias_of = {id(p): p.detach().requires_grad_(True) for p in params}
+        swapped = {name: alias_of[id(p)] for name, p in solver.sde.named_parameters(remove_duplicate=False)
+                   if id(p) in alias_of}
+        self.n_params = len(params)
+        leaves = [x for x in [self.y_in] + self.extra_in if x.requires_grad] + [alias_of[id(p)] for p in params]
+        self.leaf_is_input = [x.requires_grad for x in [self.y_in] + self.extra_in]
+        self._keepalive = bm
+        bm._entropy_dev = self.seed_dev
+
+        def forward():
+            solver._extra = tuple(self.extra_in)
+            ys = solver._run(self.plan, self.y_in)
+            return [ys] + list(solver._extra)
+
+        def backward(outs, cotangents):
+            live = [(o, c) for o, c in zip(outs, cotangents) if o.requires_grad]
+            grads = torch.autograd.grad([o for o, _ in live], leaves, grad_outputs=[c for _, c in live],
+                                        allow_unused=True)
+            return [torch.zeros_like(x) if g is None else g for g, x in zip(grads, leaves)]
+
+        try:
+            with torch.enable_grad(), _reparametrize_module(solver.sde, swapped):
+                self.plan = solver._plan(self.y_in, ts)
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):       # warm-up outside capture (lazy inits, allocator)
+                    outs = forward()
+                    if _has_foreign_leaves(outs, leaves):
+                        raise _NotCapturable("the solve depends on trainable tensors that are neither y0 nor "
+                                             "parameters of the SDE module")
+                    backward(outs, [torch.zeros_like(o) for o in outs])
+                    del outs
+                torch.cuda.current_stream(device).wait_stream(side)
+                self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with _no_gc(), torch.cuda.graph(self.fwd_graph, capture_error_mode="thread_local"):
+                    self.outs = forward()
+                self.cotangents = [torch.zeros_like(o) for o in self.outs]
+                with _no_gc(), torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(),
+                                                capture_error_mode="thread_local"):
+                    self.grads = backward(self.outs, self.cotangents)
+        finally:
+            bm._entropy_dev = None
+
+    def _load(self, bm, y0, extra0):
+        with torch.no_grad():
+            self.y_in.copy_(y0)
+            for dst, src in zip(self.extra_in, extra0):
+                dst.copy_(src)
+        key = bm._key
+        self.seed_dev.fill_(key - (1 << 64) if key >= (1 << 63) else key)
+
+
+class _NotCapturable(Exception):
+    pass
+
+
+def _has_foreign_leaves(outs, leaves):
+    """True if the autograd graph of `outs` reaches a trainable leaf outside `leaves`: replaying a recorded backward
+    pass would silently drop its gradient, so such solves are not recorded."""
+    known = {id(x) for x in leaves}
+    seen = set()
+    stack = [o.grad_fn for o in outs if o.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)
+        if var is not None and id(var) not in known:
+            return True
+        stack.extend(f for f, _ in fn.next_functions if f is not None)
+    return False
+
+
+class _GraphedSolve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, captured, bm, n_extra, y0, *extras_and_params):
+        captured._load(bm, y0, extras_and_params[:n_extra])
+        captured.fwd_graph.replay()
+        ctx.captured, ctx.n_extra = captured, n_extra
+        return tuple(o.detach().clone() for o in captured.outs)
+
+    @staticmethod
+    def backward(ctx, *cotangents):
+        captured = ctx.captured
+        for dst, src in zip(captured.cotangents, cotangents):
+            if src is None:
+                dst.zero_()
+            else:
+                dst.copy_(src)
+        captured.bwd_graph.replay()
+        grads = [g.clone() for g in captured.grads]
+        out, k = [], 0
+        for is_leaf in captured.leaf_is_input:       # y0, then the extras
+            out.append(grads[k] if is_leaf else None)
+            k += 1 if is_leaf else 0
+        return (None, None, None) + tuple(out) + tuple(grads[k:])
+
+
+def replay_or_capture_training(solver, y0, ts, extra0, params):
+    """`sdeint` with autograd through the solver, as a forward graph and a backward graph; returns (ys, extras) that
+    carry a grad_fn. Falls back (returns None) when the Brownian motion cannot be re-seeded through a device word."""
+    bm = solver.bm
+    if not isinstance(bm, BrownianInterval) or bm._rootW is not None or bm._rootH is not None:
+        warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
+        return None
+    from . import timegrid
+    ts_host = timegrid.ts_to_host(ts)
+    params = [p for p in params if p.requires_grad]
+    named = {id(p) for _, p in solver.sde.named_parameters(remove_duplicate=False)}
+    if any(id(p) not in named for p in params):
+        return None
+    base = solver.sde
+    while hasattr(base, "_base_sde"):
+        base = base._base_sde
+    cache = getattr(base, _CACHE_ATTR, None)
+    if cache is None:
+        cache = {}
+        setattr(base, _CACHE_ATTR, cache)
+    if not bm.frozen:
+        bm.adopt_grid(timegrid.build(ts_host, solver.dt).t_f64())
+    sig = ("training",) + _signature(solver, y0, ts_host) + (
+        y0.requires_grad, tuple(e.requires_grad for e in extra0), tuple((p.data_ptr(), tuple(p.shape)) for p in params))
+    captured = cache.get(sig)
+    if captured is None:
+        try:
+            captured = _CapturedTrainingSolve(solver, y0, ts, extra0, params)
+        except _NotCapturable as e:
+            warnings.warn(f"hip_graph=True: {e}; running eagerly.")
+            return None
+        _remember(cache, sig, captured)
+    outs = _GraphedSolve.apply(captured, bm, len(extra0), y0, *extra0, *params)
+    return outs[0], tuple(outs[1:])

@@ -165,9 +165,13 @@ class BaseSDESolver:
             ys = self._integrate_trajectory(coefficients, y0, ts)
             if ys is not None:
                 return ys, self._extra
-        if self.options.get("hip_graph", False) and not self._tracks_grad(y0):
+        if self.options.get("hip_graph", False):
             from . import graph
-            return graph.replay_or_capture(self, y0, ts, self._extra)
+            if not self._tracks_grad(y0):
+                return graph.replay_or_capture(self, y0, ts, self._extra)
+            graphed = graph.replay_or_capture_training(self, y0, ts, self._extra, self._params())
+            if graphed is not None:
+                return graphed
         ys = self._run(self._plan(y0, ts), y0)
         return ys, self._extra
 
