@@ -200,10 +200,10 @@ def main():
     adjoint = cfg.get("adjoint", False)
     # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
     # the derivative form of Milstein runs its diffusion VJP through autograd INSIDE the captured region (fine: same
-    # kernels every step). The adjoint (backward pass outside the solver) and the general-noise Milstein extension
-    # (16 JVPs per step) stay eager.
+    # kernels every step); the adjoint replays one graph for the forward solve and one for the backward sweep.
+    # The general-noise Milstein extension (16 JVPs per step) stays eager.
     trajectory = cfg.get("trajectory", False)
-    use_graph = (not args.eager) and (not adjoint) and not cfg.get("options") and not trajectory
+    use_graph = (not args.eager) and not cfg.get("options") and not trajectory
     extra_options = dict(cfg.get("options") or {})
     sde = _make_problem(cfg["problem"], d, m, dev)
     y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
@@ -217,8 +217,11 @@ def main():
                                            row_offset=rank * B)
         if adjoint:
             with torch.enable_grad():
+                gopt = {"hip_graph": True} if graph else {}
                 ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=cfg["method"],
-                                                 adjoint_method=cfg["adjoint_method"], dt=dt)
+                                                 adjoint_method=cfg["adjoint_method"], dt=dt, options=dict(gopt),
+                                                 adjoint_options=dict(gopt))
+                y0.grad = None
                 ys[-1].sum().backward()
             if use_dist:
                 from torchsde_amd import sharding
@@ -353,7 +356,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "state": d, "brownian_channels": m,
                        "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
                        "launch": ("one trajectory-kernel launch per solve" if trajectory else
-                                  "HIP graph replay of the whole solve" if use_graph else "eager launches"),
+                                  "HIP graph replay of the whole solve" + (" and of the backward sweep" if adjoint else "")
+                                  if use_graph else "eager launches"),
                        "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
