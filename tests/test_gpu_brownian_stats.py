@@ -2,7 +2,6 @@
 re-pointed at the counter-RNG generator on the GPU, plus strong-order convergence on its sample paths."""
 import math
 
-import numpy as np
 import numpy.random as npr
 import pytest
 import torch

@@ -2,7 +2,6 @@
 every (noise type x sde type x method x Levy approximation x adaptive) combination either runs and returns
 (T, batch, d) or raises ValueError exactly when the reference's rules say so (failure rules :124-136,
 compatibility table SURVEY.md appendix A.4)."""
-import itertools
 
 import pytest
 import torch

@@ -25,9 +25,9 @@ from . import contract
 from . import kernels as K
 from . import solvers
 from . import timegrid
-from .brownian import BaseBrownian, BrownianInterval, ReverseBrownian
+from .brownian import BrownianInterval, ReverseBrownian
 from .kernels import NoiseSpec
-from .sde import BaseSDE, ForwardSDE, jvp, vjp
+from .sde import BaseSDE, jvp, vjp
 from .settings import METHOD_OPTIONS, METHODS, NOISE_TYPES, SDE_TYPES
 
 _ADJOINT_NOISE = {NOISE_TYPES.general: NOISE_TYPES.general, NOISE_TYPES.additive: NOISE_TYPES.general,

@@ -18,7 +18,7 @@ import torch
 from . import _native
 from . import kernels as K
 from . import timegrid
-from .brownian import BaseBrownian, BrownianInterval
+from .brownian import BrownianInterval
 from .kernels import NoiseSpec
 from .settings import LEVY_AREA_APPROXIMATIONS, METHOD_OPTIONS, METHODS, NOISE_TYPES, SDE_TYPES
 
