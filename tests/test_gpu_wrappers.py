@@ -117,3 +117,37 @@ def test_error_norm_matches_reference_formula(n, dtype):
     if n > 1:
         b[n // 2] = float("nan")
         assert math.isnan(K.error_norm(a, b, rtol, atol, eps).item())
+
+
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich"), ("heun", "stratonovich")])
+def test_batch_broadcast_diffusion_uses_one_gemm(method, sde_type):
+    """Additive noise whose g is the same (d, m) matrix for every row, returned as an expanded view: the product
+    g.dW is taken as one GEMM; the result matches the materialised-g path to GEMM rounding."""
+    import torchsde_amd
+    B, d, m = 4096, 16, 8
+    gen = torch.Generator().manual_seed(0)
+    sigma = (0.3 * torch.rand(d, m, generator=gen)).to(DEV)
+
+    class Shared(nn.Module):
+        noise_type = "additive"
+
+        def __init__(self, expand):
+            super().__init__()
+            self.sde_type, self.expand = sde_type, expand
+
+        def f(self, t, y):
+            return -0.5 * y
+
+        def g(self, t, y):
+            if self.expand:
+                return sigma.unsqueeze(0).expand(y.size(0), d, m)          # stride-0 batch dimension
+            return sigma.unsqueeze(0).repeat(y.size(0), 1, 1)              # materialised copies
+
+    y0 = torch.full((B, d), 0.2, device=DEV)
+    ts = torch.tensor([0.0, 0.25, 0.5], device=DEV)
+    outs = []
+    for expand in (True, False):
+        bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, m), device=DEV, dtype=torch.float32, entropy=9)
+        with torch.no_grad():
+            outs.append(torchsde_amd.sdeint(Shared(expand), y0, ts, bm=bm, method=method, dt=2.0 ** -5))
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)

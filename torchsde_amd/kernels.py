@@ -133,6 +133,14 @@ def _raw_step_prod(y0, f, gp, cf, cg, out):
     return out
 
 
+def _shared_diffusion(g, B):
+    """The (d, m) matrix behind a diffusion that is the SAME for every batch row (additive noise returned as
+    ``sigma.expand(B, d, m)`` or with a leading 1), else None."""
+    if g.dim() == 3 and B > 1 and (g.shape[0] == 1 or (g.shape[0] == B and g.stride(0) == 0)):
+        return g[0]
+    return None
+
+
 def _raw_step_general(y0, f, g, cf, cg, noise, out):
     if not y0.is_contiguous():
         y0 = y0.contiguous()
@@ -141,6 +149,13 @@ def _raw_step_general(y0, f, g, cf, cg, noise, out):
         g = g.to(y0.dtype)
     B, d = y0.shape
     m = g.shape[-1]
+    shared = _shared_diffusion(g, B)
+    if shared is not None:
+        # Batch-broadcast diffusion: g . dW is ONE dense (B, m) x (m, d) GEMM -- the only matrix-core-shaped
+        # product on this path -- instead of B copies of g streamed through the contraction
+        # kernel (B*d*m*4 bytes written by the expand and read back). Library GEMM + the fused update.
+        W, _ = noise.materialise()
+        return _raw_step_prod(y0, f, torch.matmul(W.to(y0.dtype), shared.t()), cf, cg, out)
     if g.shape != (B, d, m):
         g = g.expand(B, d, m)
     if not g.is_contiguous():
