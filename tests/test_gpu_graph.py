@@ -174,3 +174,20 @@ def test_backprop_graph_refuses_foreign_trainable_tensors():
     assert any("running eagerly" in str(x.message) for x in w)
     ys.sum().backward()
     assert outside.grad is not None and outside.grad.abs().sum() > 0
+
+
+def test_backprop_graph_detects_overwritten_activations():
+    import torchsde_amd
+    B, d = 32, 4
+    sde = problems.make("mlpdiag_ito", d=d).to(DEV)
+    ts = torch.tensor([0.0, 0.25], device=DEV)
+
+    def solve(entropy):
+        y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 0.25, size=(B, d), device=DEV, dtype=torch.float32, entropy=entropy)
+        return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=2.0 ** -5, options={"hip_graph": True})
+
+    first, second = solve(1), solve(2)
+    second.sum().backward()                       # the most recent solve can be differentiated
+    with pytest.raises(RuntimeError, match="overwritten by a later solve"):
+        first.sum().backward()

@@ -301,12 +301,17 @@ class _GraphedSolve(torch.autograd.Function):
     def forward(ctx, captured, bm, n_extra, y0, *extras_and_params):
         captured._load(bm, y0, extras_and_params[:n_extra])
         captured.fwd_graph.replay()
-        ctx.captured, ctx.n_extra = captured, n_extra
+        captured.generation = getattr(captured, "generation", 0) + 1
+        ctx.captured, ctx.n_extra, ctx.generation = captured, n_extra, captured.generation
         return tuple(o.detach().clone() for o in captured.outs)
 
     @staticmethod
     def backward(ctx, *cotangents):
         captured = ctx.captured
+        if captured.generation != ctx.generation:
+            raise RuntimeError("torchsde_amd: with options={'hip_graph': True} the activations of a solve live in the "
+                               "graph's memory pool and were overwritten by a later solve of the same structure; call "
+                               "backward() before solving again, or drop the option for this call.")
         for dst, src in zip(captured.cotangents, cotangents):
             if src is None:
                 dst.zero_()
