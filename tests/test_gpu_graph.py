@@ -191,3 +191,57 @@ def test_backprop_graph_detects_overwritten_activations():
     second.sum().backward()                       # the most recent solve can be differentiated
     with pytest.raises(RuntimeError, match="overwritten by a later solve"):
         first.sum().backward()
+
+
+def test_latent_sde_training_step_with_graphs():
+    """The latent-SDE training pattern of the reference's examples (`sdeint(..., logqp=True)`, loss = reconstruction
+    + KL, back-propagation through the solver): with hip_graph the (ys, logqp) pair and every gradient match the
+    eager run, over several optimiser steps."""
+    import torchsde_amd
+
+    class Latent(torch.nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            gen = torch.Generator().manual_seed(0)
+            self.post = torch.nn.Linear(4, 4)
+            self.prior = torch.nn.Linear(4, 4)
+            with torch.no_grad():
+                for p in self.parameters():
+                    p.copy_(0.3 * torch.randn(p.shape, generator=gen))
+
+        def f(self, t, y):       # posterior drift
+            return torch.tanh(self.post(y))
+
+        def h(self, t, y):       # prior drift
+            return torch.tanh(self.prior(y))
+
+        def g(self, t, y):
+            return torch.full_like(y, 0.5)
+
+    B = 64
+    ts = torch.tensor([0.0, 0.25, 0.5], device=DEV)
+
+    def train(graph, steps=3):
+        torch.manual_seed(0)
+        sde = Latent().to(DEV)
+        opt = torch.optim.SGD(sde.parameters(), lr=0.1)
+        losses = []
+        for it in range(steps):
+            y0 = torch.full((B, 4), 0.2, device=DEV)
+            bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, 5), device=DEV, dtype=torch.float32, entropy=it)
+            ys, logqp = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=2.0 ** -5, logqp=True,
+                                            options={"hip_graph": True} if graph else None)
+            loss = (ys[-1] ** 2).mean() + logqp.sum(0).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses, [p.detach().clone() for p in sde.parameters()]
+
+    loss_g, params_g = train(True)
+    loss_e, params_e = train(False)
+    assert loss_g == pytest.approx(loss_e, rel=1e-5)
+    for a, b in zip(params_g, params_e):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
