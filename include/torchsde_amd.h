@@ -237,6 +237,18 @@ int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t 
                                 const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                                 const uint64_t* entropy_dev, int dtype, void* stream);
 
+/* The same solve with path-wise sensitivities: next to every output element its derivatives with respect to its
+ * own initial value and its channel's four coefficients are written to
+ *   sens (n_out, TSDE_TRAJ_SENS, rows, d)   planes in the order  d/dy0, d/d drift_rate, d/d drift_shift,
+ *                                           d/d diff_rate, d/d diff_shift
+ * (forward-mode derivatives carried through exactly the operations of the solve: what back-propagation through
+ * torchsde.sdeint computes for this SDE). `ys` is bit-identical to tsde_trajectory_affine_diag. */
+#define TSDE_TRAJ_SENS 5
+int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64_t rows, int64_t d,
+                                     const void* drift_rate, const void* drift_shift, const void* diff_rate,
+                                     const void* diff_shift, int method, const tsde_traj_t* traj, uint64_t entropy,
+                                     uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
 #define TSDE_KID_STEP_DIAG 1
 #define TSDE_KID_STEP_GENERAL 2

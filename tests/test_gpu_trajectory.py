@@ -167,3 +167,75 @@ def test_c_abi_rejects_bad_schedules():
     code = lib.tsde_trajectory_affine_diag(y.data_ptr(), y.data_ptr(), 4, 4, c.data_ptr(), c.data_ptr(), c.data_ptr(),
                                            c.data_ptr(), 9, traj, 1, 0, None, 0, None)
     assert code != 0 and b"method" in lib.tsde_last_error()
+
+
+@pytest.mark.parametrize("shape", [(8192, 64), (24, 8), (7, 3)])
+@pytest.mark.parametrize("method,sde_type", METHODS)
+def test_trajectory_kernel_gradients_match_backprop_through_the_oracle(method, sde_type, shape):
+    """Autograd through the closed-form solve (one launch carrying forward-mode sensitivities + a few reductions)
+    vs ordinary back-propagation through the oracle's restatement of the reference's solver on the same path;
+    float64. Also: requesting gradients does not change a single bit of `ys`."""
+    from oracle import counter, solvers_ref
+    import torchsde_amd
+    B, d = shape
+    dt, steps = 2.0 ** -5, 12
+    dtype = torch.float64
+    levy = method == "srk"
+    ts_list = [0.0, 5 * dt, 7.5 * dt, steps * dt]
+    edges = np.arange(steps + 1) * dt
+    B_ref = min(B, 32)                     # the CPU oracle checks the first rows; RNG rows are addressed globally
+
+    def bm_cpu(ta, tb, return_U=False, return_A=False):
+        W, U, _ = counter.query(B_ref * d, 2025, edges, float(ta), float(tb), dtype=np.float64, have_h=levy)
+        W = torch.from_numpy(W).reshape(B_ref, d)
+        return (W, torch.from_numpy(U).reshape(B_ref, d)) if return_U else W
+
+    weight = torch.linspace(-1.0, 1.0, 4 * B * d, dtype=dtype).reshape(4, B, d)
+    weight[:, B_ref:] = 0.0               # the loss only sees the rows the oracle solves
+    sde_cpu = _sde(d, dtype, sde_type, device="cpu")
+    y0_cpu = torch.linspace(0.5, 1.5, B * d, dtype=dtype).reshape(B, d)[:B_ref].clone().requires_grad_(True)
+    ref = solvers_ref.integrate(sde_cpu, bm_cpu, y0_cpu, torch.tensor(ts_list, dtype=dtype), dt, method)
+    (ref * weight[:, :B_ref]).sum().backward()
+
+    sde = _sde(d, dtype, sde_type)
+    y0 = torch.linspace(0.5, 1.5, B * d, dtype=dtype, device=DEV).reshape(B, d).requires_grad_(True)
+    bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=dtype, device=DEV, entropy=2025,
+                                       levy_area_approximation="space-time" if levy else "none")
+    ys = torchsde_amd.sdeint(sde, y0, torch.tensor(ts_list, dtype=dtype, device=DEV), bm=bm, method=method, dt=dt)
+    assert ys.grad_fn is not None and type(ys.grad_fn).__name__ == "_TrajectoryFnBackward"
+    (ys * weight.to(DEV)).sum().backward()
+    torch.testing.assert_close(ys.detach().cpu()[:, :B_ref], ref.detach(), rtol=1e-12, atol=1e-13)
+    torch.testing.assert_close(y0.grad.cpu()[:B_ref], y0_cpu.grad, rtol=1e-10, atol=1e-12)
+    assert y0.grad[B_ref:].abs().max().item() == 0.0 if B > B_ref else True
+    for p, q in zip(sde.parameters(), sde_cpu.parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-9, atol=1e-11)
+    no_grad = _solve(sde, y0.detach(), torch.tensor(ts_list, dtype=dtype, device=DEV), method, dt, 2025,
+                     trajectory=True)
+    assert torch.equal(no_grad, ys.detach())
+
+
+def test_trajectory_gradients_with_scalar_coefficients_and_partial_requires_grad():
+    """Scalar (0-d) coefficients get the gradient summed over channels; inputs that do not require grad get none."""
+    import torchsde_amd
+    B, d = 64, 8
+    dtype = torch.float64
+    sde = torchsde_amd.AffineDiagonalSDE(0.3, -0.1, 0.4, 0.05, dtype=dtype, device=DEV)
+    sde.drift_shift.requires_grad_(False)
+    ts = torch.tensor([0.0, 0.25, 0.5], dtype=dtype, device=DEV)
+
+    def run(options):
+        y0 = torch.full((B, d), 0.7, dtype=dtype, device=DEV)         # y0 itself does not require grad
+        bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, d), dtype=dtype, device=DEV, entropy=3)
+        sde.zero_grad()
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="milstein", dt=2.0 ** -5, options=options)
+        (ys ** 2).sum().backward()
+        return ys.detach(), [None if p.grad is None else p.grad.clone() for p in sde.parameters()]
+
+    ys_a, grads_a = run({})                                  # sensitivity kernel
+    ys_b, grads_b = run({"trajectory_kernel": False})        # stepwise path + ordinary autograd
+    assert torch.equal(ys_a, ys_b)
+    assert grads_a[1] is None and grads_b[1] is None
+    for a, b in zip(grads_a, grads_b):
+        if a is not None:
+            assert a.shape == b.shape == ()
+            torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-11)

@@ -42,6 +42,10 @@ class AffineDiagonalSDE(nn.Module):
     def g(self, t, y):
         return self.diff_rate * y + self.diff_shift
 
+    def closed_form_parameters(self):
+        """The four coefficient tensors, in the order the kernels take them."""
+        return self.drift_rate, self.drift_shift, self.diff_rate, self.diff_shift
+
     def closed_form(self, d, dtype, device):
         """Coefficients as contiguous ``(d,)`` tensors, or None if they cannot be served in `dtype` as they are
         (then the stepwise path is used: torch's type promotion would change the arithmetic)."""

@@ -322,11 +322,10 @@ int tsde_error_norm(double* out, double* workspace, const void* y_full, const vo
                 tsde::launch_error_norm<double>(out, workspace, y_full, y_half, n, rtol, atol, eps, s));
 }
 
-int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
-                                const void* drift_shift, const void* diff_rate, const void* diff_shift, int method,
-                                const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
-                                const uint64_t* entropy_dev, int dtype, void* stream) {
-  const char* where = "tsde_trajectory_affine_diag";
+static int trajectory_affine_diag(const char* where, void* ys, void* sens, const void* y0, int64_t rows, int64_t d,
+                                  const void* drift_rate, const void* drift_shift, const void* diff_rate,
+                                  const void* diff_shift, int method, const tsde_traj_t* traj, uint64_t entropy,
+                                  uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
   if (!ys || !y0 || !drift_rate || !drift_shift || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
   if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
@@ -337,10 +336,27 @@ int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t 
   const tsde::NoiseKey key = make_key(entropy, elem0);
   ProfScope p(TSDE_KID_TRAJECTORY, s);
   TSDE_DISPATCH(dtype, where,
-                tsde::launch_trajectory_affine_diag<float>(ys, y0, rows, d, drift_rate, drift_shift, diff_rate,
+                tsde::launch_trajectory_affine_diag<float>(ys, sens, y0, rows, d, drift_rate, drift_shift, diff_rate,
                                                            diff_shift, method, traj, key, entropy_dev, s),
-                tsde::launch_trajectory_affine_diag<double>(ys, y0, rows, d, drift_rate, drift_shift, diff_rate,
+                tsde::launch_trajectory_affine_diag<double>(ys, sens, y0, rows, d, drift_rate, drift_shift, diff_rate,
                                                             diff_shift, method, traj, key, entropy_dev, s));
+}
+
+int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
+                                const void* drift_shift, const void* diff_rate, const void* diff_shift, int method,
+                                const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                const uint64_t* entropy_dev, int dtype, void* stream) {
+  return trajectory_affine_diag("tsde_trajectory_affine_diag", ys, nullptr, y0, rows, d, drift_rate, drift_shift,
+                                diff_rate, diff_shift, method, traj, entropy, elem0, entropy_dev, dtype, stream);
+}
+
+int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64_t rows, int64_t d,
+                                     const void* drift_rate, const void* drift_shift, const void* diff_rate,
+                                     const void* diff_shift, int method, const tsde_traj_t* traj, uint64_t entropy,
+                                     uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+  if (!sens) return bad_arg("tsde_trajectory_affine_diag_sens", "null argument");
+  return trajectory_affine_diag("tsde_trajectory_affine_diag_sens", ys, sens, y0, rows, d, drift_rate, drift_shift,
+                                diff_rate, diff_shift, method, traj, entropy, elem0, entropy_dev, dtype, stream);
 }
 
 int tsde_prof_begin(int kid, int capacity) {

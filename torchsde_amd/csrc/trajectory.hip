@@ -13,15 +13,100 @@
 //   Euler      _core/methods/euler.py:31-36         Midpoint  _core/methods/midpoint.py:31-43
 //   Milstein   _core/methods/milstein.py:52-74      SRK       _core/methods/srk.py:57-88 (SRID2)
 //   outputs    _core/base_solver.py:131-134 + _core/interp.py:19-26 (linear interpolation inside a step)
+//
+// Gradients: the same kernel instantiated on forward-mode dual numbers carries, next to every state element, its
+// path-wise sensitivities d y / d (y0, a, b, c, e) through exactly the same operations (the recursions are
+// element-wise, so each tangent is one more scalar recursion in registers). This is what back-propagation
+// through the solver (ordinary autograd through torchsde.sdeint) computes for such an SDE, in the same single launch.
+#include <type_traits>
+
 #include "tsde_common.h"
 #include "tsde_launch.h"
 #include "tsde_schemes.h"
 
 namespace tsde {
 
+constexpr int kSens = 5;   // tangents per element: d/dy0, d/da, d/db, d/dc, d/de
+
+// Value + tangents. Only the operations an affine SDE needs: the state is never multiplied by the state.
+template <typename T>
+struct Dual {
+  T v;
+  T d[kSens];
+  Dual() = default;
+  TSDE_D explicit Dual(T value) : v(value) {
+#pragma unroll
+    for (int i = 0; i < kSens; ++i) d[i] = (T)0;
+  }
+};
+
+// A coefficient: a plain value whose own tangent slot K is 1 (and every other 0), kept symbolic so that products and
+// sums with it cost one extra add instead of a dense tangent update.
+template <typename T, int K>
+struct Seed {
+  T v;
+};
+
+template <typename T>
+TSDE_D Dual<T> operator+(const Dual<T>& x, const Dual<T>& y) {
+  Dual<T> r;
+  r.v = x.v + y.v;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = x.d[i] + y.d[i];
+  return r;
+}
+template <typename T>
+TSDE_D Dual<T> operator+(const Dual<T>& x, T s) {
+  Dual<T> r = x;
+  r.v = x.v + s;
+  return r;
+}
+template <typename T>
+TSDE_D Dual<T> operator*(const Dual<T>& x, T s) {
+  Dual<T> r;
+  r.v = x.v * s;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = x.d[i] * s;
+  return r;
+}
+template <typename T>
+TSDE_D Dual<T> operator*(T s, const Dual<T>& x) {
+  Dual<T> r;
+  r.v = s * x.v;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = s * x.d[i];
+  return r;
+}
+template <typename T, int K>
+TSDE_D Dual<T> operator*(const Seed<T, K>& p, const Dual<T>& x) {
+  Dual<T> r;
+  r.v = p.v * x.v;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = p.v * x.d[i];
+  r.d[K] = r.d[K] + x.v;
+  return r;
+}
+template <typename T, int K>
+TSDE_D Dual<T> operator*(const Dual<T>& x, const Seed<T, K>& p) {
+  Dual<T> r;
+  r.v = x.v * p.v;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = x.d[i] * p.v;
+  r.d[K] = r.d[K] + x.v;
+  return r;
+}
+template <typename T, int K>
+TSDE_D Dual<T> operator+(const Dual<T>& x, const Seed<T, K>& p) {
+  Dual<T> r = x;
+  r.v = x.v + p.v;
+  r.d[K] = r.d[K] + (T)1;
+  return r;
+}
+
 template <typename T>
 struct TrajArgs {
   T* ys;                    // (n_out, n) outputs after t0
+  T* sens;                  // (n_out, kSens, n) sensitivities of those outputs, or nullptr
   const T* y0;              // (n)
   const T *a, *b, *c, *e;   // (d) per-channel coefficients
   const T* rows;            // (n_steps, 8): dt, dt/2, 1/dt, sqrt(dt), sqrt(h), sqrt(h/12), h, 0
@@ -37,57 +122,76 @@ struct TrajArgs {
 enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStrat = TSDE_TRAJ_MILSTEIN_STRAT,
              kMidpoint = TSDE_TRAJ_MIDPOINT, kSrk = TSDE_TRAJ_SRK };
 
-// One step of one element. `w` = W, `u` = U (SRK only).
-template <typename T, int METHOD>
-TSDE_D T affine_step(const T y, const T a, const T b, const T c, const T e, const T w, const T u, const T dt,
+// One step of one element. `w` = W, `u` = U (SRK only). S is T (values only) or Dual<T>; the coefficient types
+// A..E are T or Seed<T, 1..4> accordingly.
+template <typename T, int METHOD, typename S, typename A, typename B, typename C, typename E>
+TSDE_D S affine_step(const S y, const A a, const B b, const C c, const E e, const T w, const T u, const T dt,
                      const T half_dt, const T rdt, const T sqrt_dt) {
-  auto F = [&](T x) { return a * x + b; };
-  auto G = [&](T x) { return c * x + e; };
+  auto F = [&](const S& x) { return a * x + b; };
+  auto G = [&](const S& x) { return c * x + e; };
   if constexpr (METHOD == kEuler) {
-    return drift_diffusion_update<T>(y, F(y), G(y), w, dt, (T)1);
+    return drift_diffusion_update<T, S>(y, F(y), G(y), w, dt, (T)1);
   } else if constexpr (METHOD == kMilIto || METHOD == kMilStrat) {
     const T v2 = milstein_v<T>(w, dt, (T)0.5, METHOD == kMilIto);
-    const T g = G(y);
-    const T gdg = (g * v2) * c;        // vjp of y -> c*y + e with cotangent g*v2 (base_sde.py:147-152)
-    return milstein_update<T>(y, F(y), g, gdg, w, dt);
+    const S g = G(y);
+    const S gdg = (g * v2) * c;        // vjp of y -> c*y + e with cotangent g*v2 (base_sde.py:147-152)
+    return milstein_update<T, S>(y, F(y), g, gdg, w, dt);
   } else if constexpr (METHOD == kMidpoint) {
-    const T yp = drift_diffusion_update<T>(y, F(y), G(y), w, half_dt, (T)0.5);
-    return drift_diffusion_update<T>(y, F(yp), G(yp), w, dt, (T)1);
+    const S yp = drift_diffusion_update<T, S>(y, F(y), G(y), w, half_dt, (T)0.5);
+    return drift_diffusion_update<T, S>(y, F(yp), G(yp), w, dt, (T)1);
   } else {
-    T f[3], g[4], h0, h1;
-    T fz[3] = {(T)0, (T)0, (T)0};
+    const S zero = S((T)0);
+    S f[3], g[4], h0, h1;
+    S fz[3] = {zero, zero, zero};
     f[0] = F(y);
     g[0] = G(y);
-    fz[0] = Srid2::need_f(1, 0) ? f[0] : (T)0;
-    srid2_stage_states<T, 1>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
+    fz[0] = Srid2::need_f(1, 0) ? f[0] : zero;
+    srid2_stage_states<T, 1, S>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
     f[1] = F(h0);
     g[1] = G(h1);
-    fz[0] = Srid2::need_f(2, 0) ? f[0] : (T)0;
-    fz[1] = Srid2::need_f(2, 1) ? f[1] : (T)0;
-    srid2_stage_states<T, 2>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
+    fz[0] = Srid2::need_f(2, 0) ? f[0] : zero;
+    fz[1] = Srid2::need_f(2, 1) ? f[1] : zero;
+    srid2_stage_states<T, 2, S>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
     f[2] = F(h0);
     g[2] = G(h1);
-    fz[0] = Srid2::need_f(3, 0) ? f[0] : (T)0;
-    fz[1] = Srid2::need_f(3, 1) ? f[1] : (T)0;
-    fz[2] = Srid2::need_f(3, 2) ? f[2] : (T)0;
-    srid2_stage_states<T, 3>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
+    fz[0] = Srid2::need_f(3, 0) ? f[0] : zero;
+    fz[1] = Srid2::need_f(3, 1) ? f[1] : zero;
+    fz[2] = Srid2::need_f(3, 2) ? f[2] : zero;
+    srid2_stage_states<T, 3, S>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
     g[3] = G(h1);
-    return srid2_final<T>(y, f, g, w, u, dt, rdt, sqrt_dt);
+    return srid2_final<T, S>(y, f, g, w, u, dt, rdt, sqrt_dt);
   }
 }
 
+template <typename T>
+TSDE_D T primal(const T& x) { return x; }
+template <typename T>
+TSDE_D T primal(const Dual<T>& x) { return x.v; }
+
 // W = 4: a lane owns one 16-byte group (needs d % 4 == 0 so the group stays inside one row).
 // W = 1: a lane owns one element (any d; also used for small problems, where it exposes 4x the lanes).
-template <typename T, int METHOD, int W>
+// SENS : carry the kSens path-wise sensitivities of every element and write them next to the outputs.
+template <typename T, int METHOD, int W, bool SENS>
 __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p) {
   constexpr bool kNeedU = METHOD == kSrk;
+  using S = typename std::conditional<SENS, Dual<T>, T>::type;
+  using A = typename std::conditional<SENS, Seed<T, 1>, T>::type;
+  using B = typename std::conditional<SENS, Seed<T, 2>, T>::type;
+  using C = typename std::conditional<SENS, Seed<T, 3>, T>::type;
+  using E = typename std::conditional<SENS, Seed<T, 4>, T>::type;
   const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t i = lane * W;
   if (i >= p.n) return;
   const int64_t col = i % p.d;
   const Pack<T, W> a = load<T, W>(p.a, col), b = load<T, W>(p.b, col), c = load<T, W>(p.c, col),
                    e = load<T, W>(p.e, col);
-  Pack<T, W> y = load<T, W>(p.y0, i);
+  const Pack<T, W> y_init = load<T, W>(p.y0, i);
+  S y[W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) {
+    y[q] = S(y_init.v[q]);
+    if constexpr (SENS) y[q].d[0] = (T)1;
+  }
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
     const uint64_t ent = *p.key_dev;
@@ -97,7 +201,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
   const uint64_t elem = key.elem0 + (uint64_t)i;
   int j = 0;
   for (int k = 0; k < p.n_steps; ++k) {
-    const T* row = p.rows + (int64_t)k * 8;   // wave-uniform: scalar loads
+    const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
     const uint32_t cell = p.cells[k];
     Pack<T, W> w, u;
@@ -115,37 +219,53 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
       w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
       if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
     }
-    Pack<T, W> y1;
+    S y1[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-      y1.v[q] = affine_step<T, METHOD>(y.v[q], a.v[q], b.v[q], c.v[q], e.v[q], w.v[q], kNeedU ? u.v[q] : (T)0, dt,
-                                       half_dt, rdt, sqrt_dt);
+      y1[q] = affine_step<T, METHOD, S, A, B, C, E>(y[q], A{a.v[q]}, B{b.v[q]}, C{c.v[q]}, E{e.v[q]}, w.v[q],
+                                                     kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
     }
     while (j < p.n_out && p.out_step[j] == k + 1) {
       const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
-      Pack<T, W> o = y1;
-      if (!(w0 == (T)0 && w1 == (T)1)) {
+      const bool exact = (w0 == (T)0 && w1 == (T)1);
+      S o[W];
 #pragma unroll
-        for (int q = 0; q < W; ++q) o.v[q] = w0 * y.v[q] + w1 * y1.v[q];
+      for (int q = 0; q < W; ++q) o[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
+      Pack<T, W> ov;
+#pragma unroll
+      for (int q = 0; q < W; ++q) ov.v[q] = primal<T>(o[q]);
+      store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
+      if constexpr (SENS) {
+#pragma unroll
+        for (int s = 0; s < kSens; ++s) {
+#pragma unroll
+          for (int q = 0; q < W; ++q) ov.v[q] = o[q].d[s];
+          store<T, W>(p.sens + ((int64_t)j * kSens + s) * p.n, i, ov);
+        }
       }
-      store<T, W>(p.ys + (int64_t)j * p.n, i, o);
       ++j;
     }
-    y = y1;
+#pragma unroll
+    for (int q = 0; q < W; ++q) y[q] = y1[q];
   }
+}
+
+template <typename T, int METHOD, bool SENS>
+static hipError_t launch_traj_ms(const TrajArgs<T>& p, bool vec, hipStream_t s) {
+  if (vec) {
+    const int64_t lanes = p.n >> 2;
+    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 4, SENS>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 1, SENS>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  }
+  return hipGetLastError();
 }
 
 template <typename T, int METHOD>
 static hipError_t launch_traj_m(const TrajArgs<T>& p, bool vec, hipStream_t s) {
-  if (vec) {
-    const int64_t lanes = p.n >> 2;
-    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 4>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s, p);
-  } else {
-    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 1>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)), dim3(kBlock),
-                       0, s, p);
-  }
-  return hipGetLastError();
+  return p.sens ? launch_traj_ms<T, METHOD, true>(p, vec, s) : launch_traj_ms<T, METHOD, false>(p, vec, s);
 }
 
 // Below this many 16-byte groups the one-element-per-lane form is used even when the vector form is legal:
@@ -153,11 +273,12 @@ static hipError_t launch_traj_m(const TrajArgs<T>& p, bool vec, hipStream_t s) {
 constexpr int64_t kTrajVecMinGroups = 256 * 8 * 64;
 
 template <typename T>
-hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* a,
+hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const void* a,
                                          const void* b, const void* c, const void* e, int method,
                                          const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
   TrajArgs<T> p;
   p.ys = (T*)ys;
+  p.sens = (T*)sens;
   p.y0 = (const T*)y0;
   p.a = (const T*)a;
   p.b = (const T*)b;
@@ -175,7 +296,8 @@ hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows,
   p.key_dev = key_dev;
   if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
   const bool can_vec = (d % 4 == 0) && (key.elem0 % 4 == 0) && aligned16(ys) && aligned16(y0) && aligned16(a) &&
-                       aligned16(b) && aligned16(c) && aligned16(e) && ((p.n * sizeof(T)) % 16 == 0);
+                       aligned16(b) && aligned16(c) && aligned16(e) && ((p.n * sizeof(T)) % 16 == 0) &&
+                       (!sens || aligned16(sens));
   const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
   switch (method) {
     case kEuler: return launch_traj_m<T, kEuler>(p, vec, s);
@@ -187,10 +309,10 @@ hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows,
   }
 }
 
-template hipError_t launch_trajectory_affine_diag<float>(void*, const void*, int64_t, int64_t, const void*,
+template hipError_t launch_trajectory_affine_diag<float>(void*, void*, const void*, int64_t, int64_t, const void*,
                                                          const void*, const void*, const void*, int,
                                                          const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
-template hipError_t launch_trajectory_affine_diag<double>(void*, const void*, int64_t, int64_t, const void*,
+template hipError_t launch_trajectory_affine_diag<double>(void*, void*, const void*, int64_t, int64_t, const void*,
                                                           const void*, const void*, const void*, int,
                                                           const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
 

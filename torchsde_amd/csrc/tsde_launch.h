@@ -91,7 +91,7 @@ hipError_t launch_error_norm(double* out, double* workspace, const void* yf, con
                              double atol, double eps, hipStream_t s);
 // trajectory.hip
 template <typename T>
-hipError_t launch_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* a,
+hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const void* a,
                                          const void* b, const void* c, const void* e, int method,
                                          const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 }  // namespace tsde

@@ -10,9 +10,13 @@
 
 namespace tsde {
 
+// The functions are generic in the STATE type S (default: the scalar type T). The trajectory kernel instantiates
+// them with a forward-mode dual number (value + tangents, trajectory.hip) to carry path-wise sensitivities through
+// exactly the same sequence of operations; time steps and Brownian increments stay plain T.
+
 // y1 = (y0 + cf*f) + cg*(g*dW)      (Euler: cf = dt, cg = 1; midpoint predictor: cf = dt/2, cg = 1/2)
-template <typename T>
-TSDE_D T drift_diffusion_update(T y, T f, T g, T w, T cf, T cg) {
+template <typename T, typename S = T>
+TSDE_D S drift_diffusion_update(S y, S f, S g, T w, T cf, T cg) {
   return (y + f * cf) + cg * (g * w);
 }
 
@@ -24,8 +28,8 @@ TSDE_D T milstein_v(T w, T dt, T scale, int ito) {
 }
 
 // y1 = ((y0 + f*dt) + g*W) + gdg
-template <typename T>
-TSDE_D T milstein_update(T y, T f, T g, T gdg, T w, T dt) {
+template <typename T, typename S = T>
+TSDE_D S milstein_update(S y, S f, S g, S gdg, T w, T dt) {
   return ((y + f * dt) + g * w) + gdg;
 }
 
@@ -71,30 +75,33 @@ struct Srid2 {
   static TSDE_HD constexpr bool need_f(int s, int j) { return A0(s, j) != 0.0 || A1(s, j) != 0.0; }
 };
 
-// Stage states H0_S, H1_S (srk.py:69-77) from the S earlier stages; f[j] must be 0 where !need_f(S, j).
-template <typename T, int S>
-TSDE_D void srid2_stage_states(T y, const T* f, const T* g, T u, T dt, T rdt, T sqrt_dt, T& h0, T& h1) {
+// Stage states H0_s, H1_s (srk.py:69-77) from the s = STAGE earlier stages; f[j] must be 0 where !need_f(s, j).
+template <typename T, int STAGE, typename S = T>
+TSDE_D void srid2_stage_states(S y, const S* f, const S* g, T u, T dt, T rdt, T sqrt_dt, S& h0, S& h1) {
   h0 = y;
   h1 = y;
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    h0 = (h0 + ((T)Srid2::A0(S, j) * f[j]) * dt) + (((T)Srid2::B0(S, j) * g[j]) * u) * rdt;
-    h1 = (h1 + ((T)Srid2::A1(S, j) * f[j]) * dt) + ((T)Srid2::B1(S, j) * g[j]) * sqrt_dt;
+  for (int j = 0; j < STAGE; ++j) {
+    h0 = (h0 + ((T)Srid2::A0(STAGE, j) * f[j]) * dt) + (((T)Srid2::B0(STAGE, j) * g[j]) * u) * rdt;
+    h1 = (h1 + ((T)Srid2::A1(STAGE, j) * f[j]) * dt) + ((T)Srid2::B1(STAGE, j) * g[j]) * sqrt_dt;
   }
 }
 
 // y1 = y0 + sum_s [alpha_s f_s dt + g_s * g_weight_s]   (srk.py:79-87); alpha_3 = 0 so f_3 does not exist.
-template <typename T>
-TSDE_D T srid2_final(T y, const T* f, const T* g, T Ik, T u, T dt, T rdt, T sqrt_dt) {
-  T acc = y;
+template <typename T, typename S = T>
+TSDE_D S srid2_final(S y, const S* f, const S* g, T Ik, T u, T dt, T rdt, T sqrt_dt) {
+  S acc = y;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const T Ikk = (Ik * Ik - dt) * (T)0.5;
     const T Ikkk = ((Ik * Ik) * Ik - ((T)3 * dt) * Ik) * (T)(1.0 / 6);
     const T gw = ((((T)Srid2::beta1(s) * Ik) + ((T)Srid2::beta2(s) * Ikk) / sqrt_dt) + ((T)Srid2::beta3(s) * u) * rdt) +
                  ((T)Srid2::beta4(s) * Ikkk) * rdt;
-    const T drift = (s < 3) ? ((T)Srid2::alpha(s) * f[s]) * dt : (T)0;
-    acc = (acc + drift) + g[s] * gw;
+    if (s < 3) {
+      acc = (acc + ((T)Srid2::alpha(s) * f[s]) * dt) + g[s] * gw;
+    } else {
+      acc = (acc + (T)0) + g[s] * gw;       // alpha_3 = 0: the reference still adds the zero drift term
+    }
   }
   return acc;
 }

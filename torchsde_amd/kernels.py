@@ -457,10 +457,12 @@ class TrajectorySchedule:
         return ctypes.byref(self._struct)
 
 
-def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm):
+def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm, sens=None):
     """All steps of an affine diagonal SDE in one launch (``tsde_trajectory_affine_diag``); writes ys[j] for the
-    schedule's outputs. `bm` is the native BrownianInterval whose generated cells drive the steps."""
-    _native.require_device(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift)
+    schedule's outputs. `bm` is the native BrownianInterval whose generated cells drive the steps. With
+    `sens` (n_out, 5, rows, d) the path-wise sensitivities d ys / d (y0, the four coefficients) are written too
+    (``tsde_trajectory_affine_diag_sens``)."""
+    _native.require_device(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, sens)
     rows, d = y0.shape
     for c in (drift_rate, drift_shift, diff_rate, diff_shift):
         if c.dtype != y0.dtype or c.numel() != d or not c.is_contiguous():
@@ -471,12 +473,60 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
         raise ValueError("ys must be a contiguous (n_out, rows, d) tensor and y0 contiguous")
     lib, dt_code, stream = _launch_env(y0)
     entropy_dev = bm._entropy_dev
-    code = lib.tsde_trajectory_affine_diag(
-        ys.data_ptr(), y0.data_ptr(), rows, d, drift_rate.data_ptr(), drift_shift.data_ptr(), diff_rate.data_ptr(),
-        diff_shift.data_ptr(), int(method), schedule.struct(), bm._key, bm._elem0,
-        None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    tail = (rows, d, drift_rate.data_ptr(), drift_shift.data_ptr(), diff_rate.data_ptr(), diff_shift.data_ptr(),
+            int(method), schedule.struct(), bm._key, bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
+            dt_code, stream)
+    if sens is None:
+        code = lib.tsde_trajectory_affine_diag(ys.data_ptr(), y0.data_ptr(), *tail)
+    else:
+        if (sens.dtype != y0.dtype or not sens.is_contiguous()
+                or sens.shape != (schedule.n_out, _native.TRAJ_SENS, rows, d)):
+            raise ValueError("sens must be a contiguous (n_out, 5, rows, d) tensor in the state dtype")
+        code = lib.tsde_trajectory_affine_diag_sens(ys.data_ptr(), sens.data_ptr(), y0.data_ptr(), *tail)
     _native.check(code, "tsde_trajectory_affine_diag")
     return ys
+
+
+class _TrajectoryFn(torch.autograd.Function):
+    """Differentiable whole-trajectory solve of an affine diagonal SDE: the forward launch also produces the
+    path-wise sensitivities of every output element (forward-mode tangents carried in registers), and the backward
+    pass is a handful of torch reductions of cotangent x sensitivity -- the gradient back-propagation through the
+    stepwise solver would give, without storing or revisiting a single step."""
+
+    @staticmethod
+    def forward(ctx, method, schedule, bm, y0, *params):
+        rows, d = y0.shape
+        y0c = _native.contiguous(y0.detach())
+        coefs = [p.detach().reshape(-1).expand(d).contiguous() for p in params]
+        ys = torch.empty((schedule.n_out + 1, rows, d), dtype=y0.dtype, device=y0.device)
+        sens = torch.empty((schedule.n_out, _native.TRAJ_SENS, rows, d), dtype=y0.dtype, device=y0.device)
+        ys[0].copy_(y0c)
+        trajectory_affine_diag(ys[1:], y0c, *coefs, method, schedule, bm, sens=sens)
+        ctx.save_for_backward(sens)
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return ys
+
+    @staticmethod
+    def backward(ctx, gys):
+        sens, = ctx.saved_tensors
+        g = gys[1:].unsqueeze(1)                                      # (n_out, 1, rows, d)
+        weighted = (g * sens).sum(dim=0)                              # (5, rows, d)
+        grad_y0 = gys[0] + weighted[0] if ctx.needs_input_grad[3] else None
+        per_channel = weighted[1:].sum(dim=1)                         # (4, d): the batch shares the coefficients
+        grads = []
+        for k, shape in enumerate(ctx.param_shapes):
+            if not ctx.needs_input_grad[4 + k]:
+                grads.append(None)
+            elif len(shape) == 1 and shape[0] == per_channel.shape[1]:
+                grads.append(per_channel[k])
+            else:                                                     # scalar coefficient broadcast over channels
+                grads.append(per_channel[k].sum().reshape(shape))
+        return (None, None, None, grad_y0) + tuple(grads)
+
+
+def trajectory_affine_diag_differentiable(y0, params, method, schedule, bm):
+    """ys (n_out + 1, rows, d) with a grad_fn towards y0 and the four coefficient tensors."""
+    return _TrajectoryFn.apply(method, schedule, bm, y0, *params)
 
 
 # ---- in-library event timing (bench.py's roofline) ----------------------------------------------------------

@@ -234,11 +234,18 @@ class BaseSDESolver:
             return None
         bm = self._native_bm()
         if (self._trajectory_code() is None or bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape)
-                or y0.dtype not in (torch.float32, torch.float64) or self._tracks_grad(y0)):
+                or y0.dtype not in (torch.float32, torch.float64)):
             return None
         spec = base.closed_form(y0.shape[1], y0.dtype, y0.device)
         if spec is None or spec[0] != "affine_diagonal":
             return None
+        if self._tracks_grad(y0):
+            # gradients flow to y0 and to the module's own four coefficients through the sensitivity kernel; any
+            # other parameter on the module (a subclass adding some) would be lost, so such solves go stepwise
+            own = list(base.closed_form_parameters())
+            if {id(p) for p in base.parameters()} != {id(p) for p in own}:
+                return None
+            return ("differentiable",) + tuple(own)
         return spec[1:]
 
     def _integrate_trajectory(self, coefficients, y0, ts):
@@ -268,6 +275,8 @@ class BaseSDESolver:
         out_step = [kc for (_, kc, _, _) in grid.outputs]
         out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
         schedule = K.TrajectorySchedule(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        if coefficients[0] == "differentiable":
+            return K.trajectory_affine_diag_differentiable(y0, coefficients[1:], self._trajectory_code(), schedule, bm)
         y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
         ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
         ys[0].copy_(y0c)
