@@ -143,6 +143,10 @@ int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, 
 /* Milstein helper: v_out = scale * (W^2 - dt) (ito != 0) or scale * W^2; W_out optional. */
 int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
                     const tsde_noise_t* noise, int dtype, void* stream);
+/* The cotangent of the diffusion VJP in one pass: out = g * (scale * (W^2 - dt)) (ito != 0) or g * (scale * W^2)
+ * (base_sde.py:147-152 `g * v`, with v of milstein.py:56,70), W generated in registers. */
+int tsde_milstein_weight(void* out, const void* g, int64_t n, double dt, int ito, double scale,
+                         const tsde_noise_t* noise, int dtype, void* stream);
 /* y1 = ((y0 + f*dt) + g*W) + gdg        derivative form, diagonal noise. */
 int tsde_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n,
                        double dt, const tsde_noise_t* noise, int dtype, void* stream);

@@ -69,6 +69,8 @@ SIGNATURES = {
                                      _c_int, _c_dbl, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_milstein_v": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_dbl, ctypes.POINTER(Noise), _c_int,
                                  _c_ptr]),
+    "tsde_milstein_weight": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_dbl, ctypes.POINTER(Noise), _c_int,
+                                      _c_ptr]),
     "tsde_milstein_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, ctypes.POINTER(Noise),
                                     _c_int, _c_ptr]),
     "tsde_milstein_gf_prime": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int, _c_int,

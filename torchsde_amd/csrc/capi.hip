@@ -167,8 +167,18 @@ int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, dou
                     int dtype, void* stream) {
   if (!v_out || !noise) return bad_arg("tsde_milstein_v", "null argument");
   const hipStream_t s = (hipStream_t)stream;
-  TSDE_DISPATCH(dtype, "tsde_milstein_v", tsde::launch_milstein_v<float>(v_out, W_out, n, dt, ito, scale, noise, s),
-                tsde::launch_milstein_v<double>(v_out, W_out, n, dt, ito, scale, noise, s));
+  TSDE_DISPATCH(dtype, "tsde_milstein_v",
+                tsde::launch_milstein_v<float>(v_out, W_out, nullptr, n, dt, ito, scale, noise, s),
+                tsde::launch_milstein_v<double>(v_out, W_out, nullptr, n, dt, ito, scale, noise, s));
+}
+
+int tsde_milstein_weight(void* out, const void* g, int64_t n, double dt, int ito, double scale,
+                         const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!out || !g || !noise) return bad_arg("tsde_milstein_weight", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_milstein_weight",
+                tsde::launch_milstein_v<float>(out, nullptr, g, n, dt, ito, scale, noise, s),
+                tsde::launch_milstein_v<double>(out, nullptr, g, n, dt, ito, scale, noise, s));
 }
 
 int tsde_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n, double dt,

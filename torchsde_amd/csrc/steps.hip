@@ -69,6 +69,7 @@ struct CellIncrementOp {
 template <typename T>
 struct MilsteinVOp {
   T *v_out, *W_out;
+  const T* g;      // optional: write the cotangent g * v of the diffusion VJP instead of v (base_sde.py:147-152)
   T dt, scale;
   int ito;
   CellNoise<T> nz;
@@ -78,6 +79,11 @@ struct MilsteinVOp {
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
     for (int j = 0; j < W; ++j) o.v[j] = milstein_v<T>(w.v[j], dt, scale, ito);
+    if (g) {
+      const Pack<T, W> gg = load<T, W, NT>(g, i);
+#pragma unroll
+      for (int j = 0; j < W; ++j) o.v[j] = gg.v[j] * o.v[j];
+    }
     store<T, W, NT>(v_out, i, o);
     if (W_out) store<T, W, NT>(W_out, i, w);
   }
@@ -535,10 +541,11 @@ hipError_t launch_step_prod(void* y1, const void* y0, const void* f, const void*
 }
 
 template <typename T>
-hipError_t launch_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
+hipError_t launch_milstein_v(void* v_out, void* W_out, const void* g, int64_t n, double dt, int ito, double scale,
                              const tsde_noise_t* nz, hipStream_t s) {
-  MilsteinVOp<T> op{(T*)v_out, (T*)W_out, (T)dt, (T)scale, ito, make_noise<T>(nz)};
-  const bool vec = (n % 4 == 0) && aligned16(v_out) && (!W_out || aligned16(W_out)) && noise_vec_ok(nz, false);
+  MilsteinVOp<T> op{(T*)v_out, (T*)W_out, (const T*)g, (T)dt, (T)scale, ito, make_noise<T>(nz)};
+  const bool vec = (n % 4 == 0) && aligned16(v_out) && (!W_out || aligned16(W_out)) && (!g || aligned16(g)) &&
+                   noise_vec_ok(nz, false);
   return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
@@ -711,8 +718,8 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   template hipError_t launch_step_general<T>(void*, const void*, const void*, const void*, int64_t, int64_t, int64_t, \
                                              double, double, double, int, double, double, double,                    \
                                              const tsde_noise_t*, hipStream_t);                                      \
-  template hipError_t launch_milstein_v<T>(void*, void*, int64_t, double, int, double, const tsde_noise_t*,          \
-                                           hipStream_t);                                                             \
+  template hipError_t launch_milstein_v<T>(void*, void*, const void*, int64_t, double, int, double,                  \
+                                           const tsde_noise_t*, hipStream_t);                                        \
   template hipError_t launch_milstein_diag<T>(void*, const void*, const void*, const void*, const void*, int64_t,    \
                                               double, const tsde_noise_t*, hipStream_t);                             \
   template hipError_t launch_milstein_gf_prime<T>(void*, const void*, const void*, const void*, int64_t, double,     \

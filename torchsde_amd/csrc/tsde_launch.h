@@ -37,7 +37,7 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
                                double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
                                const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
-hipError_t launch_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
+hipError_t launch_milstein_v(void* v_out, void* W_out, const void* g, int64_t n, double dt, int ito, double scale,
                              const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
 hipError_t launch_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n,

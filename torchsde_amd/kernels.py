@@ -265,6 +265,17 @@ def milstein_v(noise, dt, ito, scale, like, want_W=False):
     return v, Wt
 
 
+def milstein_weight(g, noise, dt, ito, scale):
+    """g * scale*(W^2 - dt) (Ito) or g * scale*W^2: the cotangent of Milstein's diffusion VJP, in one launch."""
+    g = _native.contiguous(g.detach())
+    out = torch.empty_like(g)
+    lib, dt_code, stream = _launch_env(g)
+    code = lib.tsde_milstein_weight(out.data_ptr(), g.data_ptr(), g.numel(), float(dt), 1 if ito else 0, float(scale),
+                                    noise.struct(), dt_code, stream)
+    _native.check(code, "tsde_milstein_weight")
+    return out
+
+
 class _MilsteinDiagFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y0, f, g, gdg, dt, noise):

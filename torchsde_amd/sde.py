@@ -145,7 +145,8 @@ class ForwardSDE(BaseSDE):
         with torch.enable_grad():
             y = y if y.requires_grad else y.detach().requires_grad_(True)
             g = self.g(t, y)
-            weight = g * (v2.unsqueeze(-2) if scalar_like else v2)
+            # `v2` is the tensor v/2, or a callable that forms the cotangent g * v/2 itself (one fused kernel)
+            weight = v2(g) if callable(v2) else g * (v2.unsqueeze(-2) if scalar_like else v2)
             gdg, = vjp(outputs=g, inputs=y, grad_outputs=weight, retain_graph=True, create_graph=keep_graph,
                        allow_unused=True)
         return g, gdg

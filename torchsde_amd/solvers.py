@@ -547,9 +547,14 @@ class _Milstein(BaseSDESolver):
             g_prime = g_prime.squeeze(2) if g_prime.dim() == 3 else g_prime
             return K.milstein_gf_diag(y0, f, g_, g_prime, dt, sqrt_dt, self.ito, noise, out=out)
         # derivative form: the VJP (dg/dy)^T (g * v/2) stays in autograd, everything else is fused
-        v2, _ = K.milstein_v(noise if not scalar else NoiseSpec.external(noise.W), dt, self.ito, 0.5, like=y0)
-        if scalar:
-            v2 = v2.reshape(-1, 1)
+        if not scalar and not torch.is_grad_enabled():
+            # forward-only solve: g * v/2 in ONE kernel (W regenerated in registers), no v tensor in HBM
+            def v2(g):
+                return K.milstein_weight(g, noise, dt, self.ito, 0.5)
+        else:
+            v2, _ = K.milstein_v(noise if not scalar else NoiseSpec.external(noise.W), dt, self.ito, 0.5, like=y0)
+            if scalar:
+                v2 = v2.reshape(-1, 1)
         f = sde.f(t0, y0)
         g, gdg = sde._g_and_gdg(t0, y0, v2, scalar_like=scalar)
         g_ = g.squeeze(2) if g.dim() == 3 else g
