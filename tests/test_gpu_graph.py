@@ -245,3 +245,61 @@ def test_latent_sde_training_step_with_graphs():
     assert loss_g == pytest.approx(loss_e, rel=1e-5)
     for a, b in zip(params_g, params_e):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("method,adjoint_method", [("euler", None), ("reversible_heun", "adjoint_reversible_heun")])
+def test_adjoint_graphs_with_logqp_names_and_extra(method, adjoint_method):
+    """The wrappers of the reference's API (`logqp=True` augments the state with the KL column, `names=` renames the
+    methods, `extra=True` returns the solver state) compose with the recorded forward and backward sweeps."""
+    import torchsde_amd
+
+    class Latent(torch.nn.Module):
+        noise_type = "diagonal"
+
+        def __init__(self, sde_type):
+            super().__init__()
+            self.sde_type = sde_type
+            gen = torch.Generator().manual_seed(1)
+            self.net = torch.nn.Linear(4, 4)
+            self.prior_net = torch.nn.Linear(4, 4)
+            with torch.no_grad():
+                for p in self.parameters():
+                    p.copy_(0.3 * torch.randn(p.shape, generator=gen))
+
+        def posterior_drift(self, t, y):
+            return torch.tanh(self.net(y))
+
+        def prior_drift(self, t, y):
+            return torch.tanh(self.prior_net(y))
+
+        def diffusion(self, t, y):
+            return 0.4 + 0.1 * torch.sigmoid(y)
+
+    sde_type = "ito" if method == "euler" else "stratonovich"
+    B = 32
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 8 * dt, 16 * dt], device=DEV)
+    names = {"drift": "posterior_drift", "prior_drift": "prior_drift", "diffusion": "diffusion"}
+
+    def run(graph, entropy):
+        torch.manual_seed(0)
+        sde = getattr(run, "sde", None)
+        if sde is None:
+            sde = run.sde = Latent(sde_type).to(DEV)
+        y0 = torch.full((B, 4), 0.2, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 16 * dt, size=(B, 5), device=DEV, dtype=torch.float32, entropy=entropy)
+        opts = {"hip_graph": True} if graph else {}
+        out = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt,
+                                          logqp=True, names=names, extra=True, options=dict(opts),
+                                          adjoint_options=dict(opts))
+        ys, logqp, extra = out
+        sde.zero_grad()
+        ((ys[-1] ** 2).mean() + logqp.sum(0).mean()).backward()
+        return [ys.detach(), logqp.detach(), y0.grad] + [p.grad.clone() for p in sde.parameters()], extra
+
+    for entropy in (1, 2, 3):
+        (got, extra_g), (ref, extra_e) = run(True, entropy), run(False, entropy)
+        assert len(extra_g) == len(extra_e)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), entropy
+        for a, b in zip(got[2:], ref[2:]):
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6)
