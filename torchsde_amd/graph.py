@@ -11,9 +11,18 @@ What changes between solves is the initial state (copied into the graph's static
 seed: the kernels read the entropy from one device word (``tsde_noise_t.entropy_dev``) that is rewritten before
 each replay, so a new ``BrownianInterval`` (new entropy) reuses the captured graph.
 
-Constraints (checked, with a loud fallback to the eager path otherwise): forward solve without autograd
-tracking; a native ``BrownianInterval``; the user's ``f``/``g`` must be capture-safe torch code (static shapes,
-no host sync, no Python-side state that changes between solves).
+Three things are recorded this way:
+
+* ``_CapturedSolve``          a forward solve without autograd (``sdeint`` under ``no_grad``, the forward pass of
+                              ``sdeint_adjoint``), including solvers that carry state between steps;
+* ``_CapturedBackward``       the whole backward sweep of ``sdeint_adjoint`` (``adjoint_options={"hip_graph": True}``);
+* ``_CapturedTrainingSolve``  a forward solve recorded WITH its autograd graph plus the back-propagation through it
+                              (``sdeint`` with gradients on), as two graphs sharing a memory pool.
+
+Constraints (checked, with a loud fallback to the eager path otherwise): a native ``BrownianInterval`` without
+pinned ``W``/``H``; every trainable tensor is ``y0`` or a parameter of the SDE module; the user's ``f``/``g`` must be
+capture-safe torch code (static shapes, no host sync, no Python-side state that changes between solves). Graphs
+are cached on the user's SDE object, keyed by the structure of the solve (at most ``_MAX_GRAPHS_PER_SDE``).
 """
 import contextlib
 import gc
