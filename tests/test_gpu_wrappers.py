@@ -151,3 +151,28 @@ def test_batch_broadcast_diffusion_uses_one_gemm(method, sde_type):
         with torch.no_grad():
             outs.append(torchsde_amd.sdeint(Shared(expand), y0, ts, bm=bm, method=method, dt=2.0 ** -5))
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("levy,method", [("none", "milstein"), ("space-time", "srk")])
+def test_step_doubling_increment_is_the_merge_of_its_halves(levy, method):
+    """Adaptive stepping queries the generator twice per attempt; the whole step's (W, U) is merged from the halves
+    and equals a direct query of the whole step up to rounding."""
+    import torchsde_amd
+    from torchsde_amd import solvers
+    from torchsde_amd.sde import ForwardSDE
+    from tests import problems
+    B, d = 64, 8
+    dtype = torch.float64
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, d), dtype=dtype, device=DEV, entropy=12,
+                                       levy_area_approximation=levy)
+    sde = ForwardSDE(problems.make("gbm_ito", dtype=dtype, d=d).to(DEV))
+    solver = solvers.select(method, "ito")(sde=sde, bm=bm, dt=0.1, adaptive=True, rtol=1e-3, atol=1e-4, dt_min=1e-5,
+                                           options={})
+    solver._state_dtype = dtype
+    ta, tm, tb = 0.1234, 0.1234 + 0.5 * 0.0377, 0.1234 + 0.0377
+    whole, first, second = solver._step_doubling_noise(ta, tm, tb)
+    W, U = bm(ta, tb, return_U=True) if levy != "none" else (bm(ta, tb), None)
+    torch.testing.assert_close(whole.W, W, rtol=1e-12, atol=1e-14)
+    assert torch.equal(first.W, bm(ta, tm)) and torch.equal(second.W, bm(tm, tb))
+    if U is not None:
+        torch.testing.assert_close(whole.U, U, rtol=1e-11, atol=1e-14)

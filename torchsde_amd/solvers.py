@@ -133,7 +133,9 @@ class BaseSDESolver:
         return x.to(dtype)
 
     # ---- public single-step API (the reference's solver seam) --------------------------------------
-    def step(self, t0, t1, y0, extra0):
+    def step(self, t0, t1, y0, extra0, noise=None):
+        """One step (the reference's solver seam). `noise`: a prepared NoiseSpec of [t0, t1] (step doubling hands in
+        the whole step's increment merged from its halves); by default the Brownian motion is queried here."""
         self._extra = tuple(extra0) if extra0 is not None else ()
         self._state_dtype = y0.dtype
         np_dtype = timegrid._NP.get(y0.dtype if not torch.is_tensor(t0) else t0.dtype, np.float64)
@@ -143,14 +145,16 @@ class BaseSDESolver:
         dev = y0.device
         t0_t = t0 if torch.is_tensor(t0) else torch.tensor(ta, dtype=y0.dtype, device=dev)
         t1_t = t1 if torch.is_tensor(t1) else torch.tensor(tb, dtype=y0.dtype, device=dev)
-        cell = None
-        bm = self._native_bm()
-        if bm is not None and bm.frozen:
-            cells = bm.match_grid(np.array([ta, tb]))
-            cell = None if cells is None else int(cells[0])
+        if noise is None:
+            cell = None
+            bm = self._native_bm()
+            if bm is not None and bm.frozen:
+                cells = bm.match_grid(np.array([ta, tb]))
+                cell = None if cells is None else int(cells[0])
+            noise = self._noise_for(ta, tb, t0_t, t1_t, cell)
         times = tuple(t0_t if frac == 0 else torch.tensor(t0n + np_dtype(frac) * dt, dtype=t0_t.dtype, device=dev)
                       for frac in self.stage_fracs) + (t1_t,)
-        st = _Step(times, dt, self._noise_for(ta, tb, t0_t, t1_t, cell), tb - ta, ta)
+        st = _Step(times, dt, noise, tb - ta, ta)
         y1 = self._advance(y0, st, None)
         return y1, self._extra
 
@@ -196,9 +200,10 @@ class BaseSDESolver:
                 nxt = curr_t + np_dtype(step_size)
                 next_t = nxt if nxt <= t_end else t_end
                 midpoint_t = np_dtype(0.5) * (curr_t + next_t)
-                y_full, _ = self.step(curr_t, next_t, curr_y, curr_extra)
-                y_mid, mid_extra = self.step(curr_t, midpoint_t, curr_y, curr_extra)
-                y_next, next_extra = self.step(midpoint_t, next_t, y_mid, mid_extra)
+                n_full, n_a, n_b = self._step_doubling_noise(float(curr_t), float(midpoint_t), float(next_t))
+                y_full, _ = self.step(curr_t, next_t, curr_y, curr_extra, noise=n_full)
+                y_mid, mid_extra = self.step(curr_t, midpoint_t, curr_y, curr_extra, noise=n_a)
+                y_next, next_extra = self.step(midpoint_t, next_t, y_mid, mid_extra, noise=n_b)
                 with torch.no_grad():
                     error_estimate = _error_estimate(y_full, y_next, self.rtol, self.atol)
                     step_size, prev_error_ratio = _update_step_size(error_estimate, step_size, prev_error_ratio)
@@ -213,6 +218,34 @@ class BaseSDESolver:
             w1 = (out_t - prev_t) / (curr_t - prev_t)
             ys.append(K.linear_interp(prev_y, curr_y, float(w0), float(w1)))
         return torch.stack(ys, dim=0), curr_extra
+
+    merges_half_steps = True   # False for solvers that draw more than (W, U) per step (Levy area)
+
+    def _step_doubling_noise(self, ta, tm, tb):
+        """(whole, first half, second half) increments of one attempt of step doubling from TWO generator queries:
+        the whole step's (W, H) is the concatenation of its halves, by the formula the generator itself uses to
+        join pieces (brownian_interval.py:647-672) -- the third bridge-tree walk of the reference's loop
+        (base_solver.py:120-123) is saved. Foreign Brownian motions keep the reference's three queries."""
+        bm = self._native_bm()
+        if bm is None or not self.merges_half_steps or self.options.get("general_noise", False):
+            return None, None, None
+        want_U = self.needs_U and bm._have_H
+        if not want_U:
+            Wa, _ = bm.increment(ta, tm)
+            Wb, _ = bm.increment(tm, tb)
+            Wa, Wb = self._as_state_dtype(Wa), self._as_state_dtype(Wb)
+            return NoiseSpec.external(Wa + Wb), NoiseSpec.external(Wa), NoiseSpec.external(Wb)
+        Ha = torch.empty(bm.shape, dtype=bm.dtype, device=bm.device)
+        Hb = torch.empty_like(Ha)
+        Wa, Ua = bm.increment(ta, tm, want_U=True, out_H=Ha)
+        Wb, Ub = bm.increment(tm, tb, want_U=True, out_H=Hb)
+        ha, hb = bm._round(tm) - bm._round(ta), bm._round(tb) - bm._round(tm)
+        W = Wa + Wb
+        H = (hb * (Hb + 0.5 * Wa) + ha * (Ha - 0.5 * Wb)) / (ha + hb)
+        U = (ha + hb) * (0.5 * W + H)                      # _H_to_U, brownian_interval.py:102-103
+        cast = self._as_state_dtype
+        return (NoiseSpec.external(cast(W), cast(U)), NoiseSpec.external(cast(Wa), cast(Ua)),
+                NoiseSpec.external(cast(Wb), cast(Ub)))
 
     def _tracks_grad(self, y0):
         return torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in self._params()))
@@ -704,6 +737,7 @@ class LogODEMidpoint(BaseSDESolver):
     noise_types = NOISE_TYPES.all()
     levy_area_approximations = (LEVY_AREA_APPROXIMATIONS.davie, LEVY_AREA_APPROXIMATIONS.foster)
     stage_fracs = (0, 0.5)
+    merges_half_steps = False
 
     def __init__(self, sde, **kwargs):
         from . import adjoint
