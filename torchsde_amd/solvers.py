@@ -133,9 +133,15 @@ class BaseSDESolver:
         return x.to(dtype)
 
     # ---- public single-step API (the reference's solver seam) --------------------------------------
-    def step(self, t0, t1, y0, extra0, noise=None):
+    def _stage_times_host(self, t0n, t1n):
+        """Stage times of the step [t0n, t1n] (numpy scalars in ts.dtype): t0 + frac*dt per stage, then t1."""
+        dt = type(t0n)(t1n - t0n)
+        return [t0n if frac == 0 else t0n + type(t0n)(frac) * dt for frac in self.stage_fracs] + [t1n]
+
+    def step(self, t0, t1, y0, extra0, noise=None, times=None):
         """One step (the reference's solver seam). `noise`: a prepared NoiseSpec of [t0, t1] (step doubling hands in
-        the whole step's increment merged from its halves); by default the Brownian motion is queried here."""
+        the whole step's increment merged from its halves); by default the Brownian motion is queried here.
+        `times`: the step's stage times already on the device (one upload per attempt of step doubling)."""
         self._extra = tuple(extra0) if extra0 is not None else ()
         self._state_dtype = y0.dtype
         np_dtype = timegrid._NP.get(y0.dtype if not torch.is_tensor(t0) else t0.dtype, np.float64)
@@ -143,17 +149,19 @@ class BaseSDESolver:
         t0n, t1n = np_dtype(ta), np_dtype(tb)
         dt = np_dtype(t1n - t0n)
         dev = y0.device
-        t0_t = t0 if torch.is_tensor(t0) else torch.tensor(ta, dtype=y0.dtype, device=dev)
-        t1_t = t1 if torch.is_tensor(t1) else torch.tensor(tb, dtype=y0.dtype, device=dev)
+        if times is None:
+            t0_t = t0 if torch.is_tensor(t0) else torch.tensor(ta, dtype=y0.dtype, device=dev)
+            t1_t = t1 if torch.is_tensor(t1) else torch.tensor(tb, dtype=y0.dtype, device=dev)
+            times = tuple(t0_t if frac == 0 else
+                          torch.tensor(t0n + np_dtype(frac) * dt, dtype=t0_t.dtype, device=dev)
+                          for frac in self.stage_fracs) + (t1_t,)
         if noise is None:
             cell = None
             bm = self._native_bm()
             if bm is not None and bm.frozen:
                 cells = bm.match_grid(np.array([ta, tb]))
                 cell = None if cells is None else int(cells[0])
-            noise = self._noise_for(ta, tb, t0_t, t1_t, cell)
-        times = tuple(t0_t if frac == 0 else torch.tensor(t0n + np_dtype(frac) * dt, dtype=t0_t.dtype, device=dev)
-                      for frac in self.stage_fracs) + (t1_t,)
+            noise = self._noise_for(ta, tb, times[0], times[-1], cell)
         st = _Step(times, dt, noise, tb - ta, ta)
         y1 = self._advance(y0, st, None)
         return y1, self._extra
@@ -201,9 +209,16 @@ class BaseSDESolver:
                 next_t = nxt if nxt <= t_end else t_end
                 midpoint_t = np_dtype(0.5) * (curr_t + next_t)
                 n_full, n_a, n_b = self._step_doubling_noise(float(curr_t), float(midpoint_t), float(next_t))
-                y_full, _ = self.step(curr_t, next_t, curr_y, curr_extra, noise=n_full)
-                y_mid, mid_extra = self.step(curr_t, midpoint_t, curr_y, curr_extra, noise=n_a)
-                y_next, next_extra = self.step(midpoint_t, next_t, y_mid, mid_extra, noise=n_b)
+                # the stage times of the three steps of this attempt, in ONE host->device copy
+                host = (self._stage_times_host(curr_t, next_t) + self._stage_times_host(curr_t, midpoint_t) +
+                        self._stage_times_host(midpoint_t, next_t))
+                dev_times = torch.tensor(np.asarray(host, dtype=ts_host.dtype), device=y0.device).to(ts.dtype).unbind(0)
+                k = len(host) // 3
+                y_full, _ = self.step(curr_t, next_t, curr_y, curr_extra, noise=n_full, times=dev_times[:k])
+                y_mid, mid_extra = self.step(curr_t, midpoint_t, curr_y, curr_extra, noise=n_a,
+                                             times=dev_times[k:2 * k])
+                y_next, next_extra = self.step(midpoint_t, next_t, y_mid, mid_extra, noise=n_b,
+                                               times=dev_times[2 * k:])
                 with torch.no_grad():
                     error_estimate = _error_estimate(y_full, y_next, self.rtol, self.atol)
                     step_size, prev_error_ratio = _update_step_size(error_estimate, step_size, prev_error_ratio)
