@@ -24,6 +24,9 @@ CASES = [
     ("general_strat", "reversible_heun", None, (12, 4, 4)),
     ("scalar_ito", "milstein", None, (12, 4, 1)),
     ("additive_ito", "euler", None, (12, 4, 3)),
+    ("gbm_ito", "srk", None, (16, 4, 4)),            # SRID2 stages: differentiable torch twin of the stage kernels
+    ("scalar_ito", "srk", None, (12, 4, 1)),
+    ("additive_ito", "srk", None, (12, 4, 3)),       # SRA1
 ]
 
 
@@ -35,6 +38,7 @@ def test_backprop_through_solver_matches_oracle(prob, method, options, shape):
     steps, dt = 8, 2.0 ** -4
     ts_list = [0.0, 3 * dt, steps * dt]
     edges = np.arange(steps + 1) * dt
+    levy = method == "srk"
 
     def loss_and_grads(device):
         sde = problems.make(prob, dtype=dtype, d=d, m=m).to(device)
@@ -42,13 +46,14 @@ def test_backprop_through_solver_matches_oracle(prob, method, options, shape):
         ts = torch.tensor(ts_list, dtype=dtype, device=device)
         if device == DEV:
             bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, m), dtype=dtype, device=DEV, entropy=31,
-                                               dt=dt)
+                                               dt=dt, levy_area_approximation="space-time" if levy else "none")
             ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt,
                                      options=None if options is None else dict(options))
         else:
             def bm_cpu(ta, tb, return_U=False):
-                W, _, _ = counter.query(B * m, 31, edges, float(ta), float(tb), dtype=np.float64)
-                return torch.from_numpy(W).reshape(B, m)
+                W, U, _ = counter.query(B * m, 31, edges, float(ta), float(tb), dtype=np.float64, have_h=levy)
+                W = torch.from_numpy(W).reshape(B, m)
+                return (W, torch.from_numpy(U).reshape(B, m)) if return_U else W
             if method == "reversible_heun":
                 ys, _ = solvers_ref.integrate_reversible_heun(sde, bm_cpu, y0, ts, dt)
             else:

@@ -359,11 +359,44 @@ def milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out=None):
 
 
 # ---- SRK ---------------------------------------------------------------------------------------------------
+# SRID2 tableau (tableaus/srid2.py:19-54), the Python twin of csrc/tsde_schemes.h `Srid2`
+_SRID2_A0 = ((), (1,), (1 / 4, 1 / 4), (0, 0, 0))
+_SRID2_A1 = ((), (1 / 4,), (1, 0), (0, 0, 1 / 4))
+_SRID2_B0 = ((), (0,), (1, 1 / 2), (0, 0, 0))
+_SRID2_B1 = ((), (-1 / 2,), (1, 0), (2, -1, 1 / 2))
+_SRID2_ALPHA = (1 / 6, 1 / 6, 2 / 3, 0)
+_SRID2_BETA = ((-1, 4 / 3, 2 / 3, 0), (1, -4 / 3, 1 / 3, 0), (2, -4 / 3, -2 / 3, 0), (-2, 5 / 3, -2 / 3, 1))
+
+
+def _srk_diag_stage_autograd(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0, want1):
+    """The stage arithmetic of `tsde_srk_diag_stage` as differentiable torch ops on the re-materialised (W, U), for
+    back-propagation THROUGH the solver (same operation order as the kernel)."""
+    W, U = noise.materialise(need_U=True)
+    if noise.bcast_d:
+        W, U = W.reshape(-1, 1), U.reshape(-1, 1)
+    dt, rdt, sqrt_dt = float(dt), float(rdt), float(sqrt_dt)
+    if stage < 4:
+        h0 = h1 = y0
+        for j in range(stage):
+            f = fs[j] if (_SRID2_A0[stage][j] != 0 or _SRID2_A1[stage][j] != 0) else torch.zeros_like(y0)
+            h0 = (h0 + (_SRID2_A0[stage][j] * f) * dt) + ((_SRID2_B0[stage][j] * gs[j]) * U) * rdt
+            h1 = (h1 + (_SRID2_A1[stage][j] * f) * dt) + (_SRID2_B1[stage][j] * gs[j]) * sqrt_dt
+        return (h0 if want0 else None), (h1 if want1 else None)
+    Ikk = (W * W - dt) * 0.5
+    Ikkk = ((W * W) * W - (3 * dt) * W) * (1.0 / 6)
+    acc = y0
+    for s in range(4):
+        gw = (((_SRID2_BETA[0][s] * W) + (_SRID2_BETA[1][s] * Ikk) / sqrt_dt) + (_SRID2_BETA[2][s] * U) * rdt) + \
+             (_SRID2_BETA[3][s] * Ikkk) * rdt
+        drift = (_SRID2_ALPHA[s] * fs[s]) * dt if s < 3 else 0.0
+        acc = (acc + drift) + gs[s] * gw
+    return acc, None
+
+
 def srk_diag_stage(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0=True, want1=True, out0=None):
     """One SRID2 stage kernel; returns (out0, out1) (None where not requested)."""
     if _needs_grad(y0, *fs, *gs):
-        raise NotImplementedError("torchsde_amd: back-propagating through the SRK solver is not supported; use "
-                                  "`method='milstein'`/'euler' or `sdeint_adjoint`.")
+        return _srk_diag_stage_autograd(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0, want1)
     y0 = _native.contiguous(y0)
     fs = _prep(y0, *fs) + [None] * (4 - len(fs))
     gs = _prep(y0, *gs) + [None] * (4 - len(gs))
