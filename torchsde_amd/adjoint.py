@@ -360,6 +360,7 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                 dt_min, adjoint_options, len_extras, y0, *extras_and_adjoint_params):
         ctx.sde, ctx.dt, ctx.bm = sde, dt, bm
         ctx.adjoint_method, ctx.adjoint_options = adjoint_method, adjoint_options
+        ctx.adjoint_adaptive = (adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min)
         ctx.len_extras = len_extras
         extra_solver_state = extras_and_adjoint_params[:len_extras]
         adjoint_params = extras_and_adjoint_params[len_extras:]
@@ -387,7 +388,13 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                        for gr, x in zip(grad_extra_solver_state, forward_extras)]
         inputs = [ys, grad_ys] + list(forward_extras) + grad_extras
         captured = ctx.captured_backward
-        if captured is not None:
+        if ctx.adjoint_adaptive[0]:
+            _, rtol, atol, dt_min = ctx.adjoint_adaptive
+            kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
+            a_y, a_theta = _run_backward_adaptive(AdjointSDE(ctx.sde, adjoint_params), kind, ctx.bm,
+                                                  timegrid.ts_to_host(ts), ctx.dt, rtol, atol, dt_min, ys, grad_ys)
+            out = [a_y] + list(a_theta)
+        elif captured is not None:
             out = captured.replay(ctx.bm, inputs)
         else:
             kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
@@ -492,6 +499,28 @@ def _plan_backward(ts_host, dt, native, device):
     return intervals
 
 
+def _aug_step(adjoint_sde, kind, ito, src, dst, mid, t_fwd, t_fwd_half, step_dt, v):
+    """One backward step of the augmented state `src` -> `dst` over a step of size `step_dt` that starts at forward
+    time `t_fwd` (0-d device tensor; `t_fwd_half`: the midpoint stage's), with the reversed increment `v`."""
+    y, a = src.t[0], src.t[1]
+    none_tail = [None] * (len(src.t) - 1)
+    if kind == "euler":
+        # y' = y - f~ dt - g.v ;  (a, theta)' += dt*vjp(f~) + vjp(g.v)  (one reverse sweep, one launch)
+        ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(step_dt), 1.0)
+        _update(dst, src, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
+    elif kind == "midpoint":
+        half_dt = type(step_dt)(0.5) * step_dt
+        ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(half_dt), 0.5)
+        _update(mid, src, [ft] + none_tail, [gp] + none_tail, [None] + tot, half_dt, 0.5)
+        ft, gp, tot = adjoint_sde.fused_terms(t_fwd_half, mid.t[0], mid.t[1], v, float(step_dt), 1.0)
+        _update(dst, src, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
+    else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
+        v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
+        F = adjoint_sde.f(t_fwd, y, a)
+        G, D = adjoint_sde.g_prod_and_gdg_prod(t_fwd, y, a, v, v2)
+        _update(dst, src, F, G, D, step_dt, 1.0)
+
+
 def _run_backward(adjoint_sde, kind, bm, plan, ys, grad_ys):
     """Launch-only part of the backward sweep (capturable in a HIP graph): returns (a_y0, [a_theta...])."""
     sde = adjoint_sde.forward_sde
@@ -503,13 +532,10 @@ def _run_backward(adjoint_sde, kind, bm, plan, ys, grad_ys):
                       [torch.zeros_like(p) for p in adjoint_params])
     other = _AugState.like(state)
     mid = _AugState.like(state) if kind == "midpoint" else None
-    none_tail = [None] * (len(state.t) - 1)
 
     for (i, grid, tau64, stage_rows, cells, tau_dev) in plan:
         n = grid.n_steps
-        np_dtype = grid.t.dtype.type
         for k in range(n):
-            step_dt = grid.dt[k]
             if native is not None:
                 if cells is not None:
                     c = int(cells[n - 1 - k])
@@ -519,29 +545,70 @@ def _run_backward(adjoint_sde, kind, bm, plan, ys, grad_ys):
                     v, _ = native.increment(-tau64[k + 1], -tau64[k])
             else:
                 v = reverse_bm(tau_dev[k], tau_dev[k + 1])
-            y, a = state.t[0], state.t[1]
-            t_fwd = stage_rows[k][0]
-            if kind == "euler":
-                # y' = y - f~ dt - g.v ;  (a, theta)' += dt*vjp(f~) + vjp(g.v)  (one reverse sweep, one launch)
-                ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(step_dt), 1.0)
-                _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
-            elif kind == "midpoint":
-                half_dt = np_dtype(0.5) * step_dt
-                ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(half_dt), 0.5)
-                _update(mid, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, half_dt, 0.5)
-                ft, gp, tot = adjoint_sde.fused_terms(stage_rows[k][1], mid.t[0], mid.t[1], v, float(step_dt), 1.0)
-                _update(other, state, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
-            else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
-                v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
-                F = adjoint_sde.f(t_fwd, y, a)
-                G, D = adjoint_sde.g_prod_and_gdg_prod(t_fwd, y, a, v, v2)
-                _update(other, state, F, G, D, step_dt, 1.0)
+            _aug_step(adjoint_sde, kind, ito, state, other, mid, stage_rows[k][0], stage_rows[k][1], grid.dt[k], v)
             state, other = other, state
         # adjoint.py:114-116
         state.t[0].copy_(ys[i - 1])
         state.t[1].add_(grad_ys[i - 1])
 
     _SEG_CACHE.clear()   # drop the references to this pass's buffers
+    return state.t[1], state.t[2:]
+
+
+def _run_backward_adaptive(adjoint_sde, kind, bm, ts_host, dt, rtol, atol, dt_min, ys, grad_ys):
+    """The backward sweep with step doubling on the augmented state (`adjoint_adaptive=True`; reference: the generic
+    adaptive loop of base_solver.py:117-142 applied to the flat augmented state, adjoint.py:97-112). The error norm
+    is taken over all segments together, like the reference's single flat tensor. One host sync per attempt."""
+    sde = adjoint_sde.forward_sde
+    ito = sde.sde_type == SDE_TYPES.ito
+    native = bm if isinstance(bm, BrownianInterval) else None
+    reverse_bm = None if native is not None else ReverseBrownian(bm)
+    device = ys.device
+    np_dtype = ts_host.dtype.type
+    state = _AugState([ys[-1].clone(), grad_ys[-1].contiguous().clone()] +
+                      [torch.zeros_like(p) for p in adjoint_sde.params])
+    full, half, nxt_state = _AugState.like(state), _AugState.like(state), _AugState.like(state)
+    mid = _AugState.like(state) if kind == "midpoint" else None
+
+    def increment(ta, tb):                       # reversed increment of the backward-time interval [ta, tb]
+        if native is not None:
+            return native.increment(-float(tb), -float(ta))[0]
+        return reverse_bm(torch.tensor(ta, device=device), torch.tensor(tb, device=device))
+
+    def flat(x):
+        return torch.cat([t.reshape(-1) for t in x.t])
+
+    step_size = dt if not torch.is_tensor(dt) else float(dt)
+    for i in range(len(ts_host) - 1, 0, -1):
+        curr_t, t_end = -ts_host[i], -ts_host[i - 1]
+        prev_error_ratio = None
+        while curr_t < t_end:
+            nxt = curr_t + np_dtype(step_size)
+            next_t = nxt if nxt <= t_end else t_end
+            mid_t = np_dtype(0.5) * (curr_t + next_t)
+            v_a, v_b = increment(curr_t, mid_t), increment(mid_t, next_t)
+            v_full = v_a + v_b if native is not None else increment(curr_t, next_t)
+            h_full, h_a, h_b = np_dtype(next_t - curr_t), np_dtype(mid_t - curr_t), np_dtype(next_t - mid_t)
+            stage = np.asarray([-curr_t, -(curr_t + np_dtype(0.5) * h_full), -(curr_t + np_dtype(0.5) * h_a),
+                                -mid_t, -(mid_t + np_dtype(0.5) * h_b)], dtype=ts_host.dtype)
+            t_dev = torch.from_numpy(stage).to(device).unbind(0)
+            _aug_step(adjoint_sde, kind, ito, state, full, mid, t_dev[0], t_dev[1], h_full, v_full)
+            _aug_step(adjoint_sde, kind, ito, state, half, mid, t_dev[0], t_dev[2], h_a, v_a)
+            _aug_step(adjoint_sde, kind, ito, half, nxt_state, mid, t_dev[3], t_dev[4], h_b, v_b)
+            error_estimate = solvers._error_estimate(flat(full), flat(nxt_state), rtol, atol)
+            step_size, prev_error_ratio = solvers._update_step_size(error_estimate, step_size, prev_error_ratio)
+            if step_size < dt_min:
+                warnings.warn("Hitting minimum allowed step size in adaptive time-stepping.")
+                step_size = dt_min
+                prev_error_ratio = None
+            if error_estimate <= 1 or step_size <= dt_min:
+                curr_t = next_t
+                state, nxt_state = nxt_state, state
+        # adjoint.py:114-116
+        state.t[0].copy_(ys[i - 1])
+        state.t[1].add_(grad_ys[i - 1])
+
+    _SEG_CACHE.clear()
     return state.t[1], state.t[2:]
 
 
@@ -566,9 +633,9 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e
     adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
     adjoint_method = _select_default_adjoint_method(sde, method, adjoint_method)
     adjoint_options = {} if adjoint_options is None else adjoint_options.copy()
-    if adjoint_adaptive:
-        raise NotImplementedError("torchsde_amd: adaptive stepping of the adjoint is not part of the hot path built "
-                                  "so far; use `adjoint_adaptive=False`.")
+    if adjoint_adaptive and adjoint_method == METHODS.adjoint_reversible_heun:
+        raise NotImplementedError("torchsde_amd: `adjoint_adaptive=True` is not available for "
+                                  "`adjoint_reversible_heun` (its backward pass retraces the forward grid).")
     if method == METHODS.reversible_heun:   # adjoint.py:243-257
         if adjoint_method != METHODS.adjoint_reversible_heun:
             warnings.warn(f"method={repr(method)}, but adjoint_method!={repr(METHODS.adjoint_reversible_heun)}.")
@@ -591,7 +658,8 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e
     ys, *extra_solver_state = _SdeintAdjointMethod.apply(
         sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
-    if adjoint_options.get("hip_graph", False) and ys.grad_fn is not None and isinstance(bm, BrownianInterval):
+    if (adjoint_options.get("hip_graph", False) and not adjoint_adaptive and ys.grad_fn is not None
+            and isinstance(bm, BrownianInterval)):
         # The backward sweep replays ONE HIP graph, captured HERE (on the caller's thread, outside the autograd
         # Function) with zero cotangents; `backward` only copies ys / grad_ys into the graph's static inputs and
         # replays. `ys.grad_fn` is the Function's ctx.
