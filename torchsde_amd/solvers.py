@@ -821,8 +821,4 @@ def select(method, sde_type):
         return LogODEMidpoint
     if method == METHODS.adjoint_reversible_heun:
         raise ValueError(f"{METHODS.adjoint_reversible_heun} can only be used for adjoint_method.")
-    if method in METHODS:
-        raise NotImplementedError(
-            f"torchsde_amd: method '{method}' is outside the MI355X hot path built so far (euler, milstein, srk, "
-            f"midpoint -- SURVEY.md section 8); see section 8(f) for what comes next.")
     raise ValueError(f"Method '{method}' does not match any known method.")
