@@ -200,10 +200,10 @@ def main():
     adjoint = cfg.get("adjoint", False)
     # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
     # the derivative form of Milstein runs its diffusion VJP through autograd INSIDE the captured region (fine: same
-    # kernels every step); the adjoint replays one graph for the forward solve and one for the backward sweep.
-    # The general-noise Milstein extension (16 JVPs per step) stays eager.
+    # kernels every step), and so does the Levy-area JVP of the general-noise Milstein extension; the adjoint replays
+    # one graph for the forward solve and one for the backward sweep.
     trajectory = cfg.get("trajectory", False)
-    use_graph = (not args.eager) and not cfg.get("options") and not trajectory
+    use_graph = (not args.eager) and not trajectory
     extra_options = dict(cfg.get("options") or {})
     sde = _make_problem(cfg["problem"], d, m, dev)
     y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
