@@ -253,6 +253,22 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
                                      const void* diff_shift, int method, const tsde_traj_t* traj, uint64_t entropy,
                                      uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
 
+/* All fixed steps of a diagonal-noise SDE whose drift is a two-layer perceptron shared by the batch,
+ *   f(t, y) = W2 . act(W1 . y + b1) + b2,   g(t, y) = diff_rate * y + diff_shift,
+ * in ONE launch (neural-SDE sampling): a wave keeps 32 batch rows in registers for the whole solve, the weights
+ * live in LDS and both layers run on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 accumulation).
+ *   w1 (d, hidden) and w2 (hidden, d) are stored input-major: w1[k][m] multiplies input channel k into unit m
+ *   (the transpose of torch.nn.Linear.weight). d, hidden in {32, 64, 128}; dtype must be TSDE_F32;
+ *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT}.
+ * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
+ * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
+#define TSDE_ACT_TANH 0
+#define TSDE_ACT_SOFTPLUS 1
+int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t hidden, const void* w1,
+                             const void* b1, const void* w2, const void* b2, const void* diff_rate,
+                             const void* diff_shift, int activation, int method, const tsde_traj_t* traj,
+                             uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
 #define TSDE_KID_STEP_DIAG 1
 #define TSDE_KID_STEP_GENERAL 2

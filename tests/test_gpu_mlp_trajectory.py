@@ -1,0 +1,87 @@
+"""GPU parity of the perceptron-drift sampling kernel (``tsde_trajectory_mlp_diag``, both layers on the f32 matrix
+cores; run with ``-m gpu``) against the stepwise path of the same module (torch ``Linear`` layers between the per-step
+kernels) on the same Brownian path. The two differ only in the summation order of the matrix products."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _sde(d, hidden, activation, sde_type="ito", seed=0):
+    import torchsde_amd
+    torch.manual_seed(seed)
+    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, sde_type=sde_type,
+                                           diff_rate=0.2 * torch.rand(d) - 0.1, diff_shift=0.1 + 0.2 * torch.rand(d))
+    with torch.no_grad():       # asymmetric, well-scaled weights (a transposed operand cannot pass)
+        sde.lin1.weight.copy_(torch.randn(hidden, d) / d ** 0.5)
+        sde.lin2.weight.copy_(torch.randn(d, hidden) / hidden ** 0.5)
+        sde.lin1.bias.copy_(0.3 * torch.randn(hidden))
+        sde.lin2.bias.copy_(0.3 * torch.randn(d))
+    return sde.to(DEV)
+
+
+def _solve(sde, y0, ts, method, dt, entropy, trajectory, row_offset=0):
+    import torchsde_amd
+    bm = torchsde_amd.BrownianInterval(float(ts[0]), float(ts[-1]), size=tuple(y0.shape), dtype=y0.dtype, device=DEV,
+                                       entropy=entropy, row_offset=row_offset)
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt, options={"trajectory_kernel": trajectory})
+
+
+@pytest.mark.parametrize("activation", ["tanh", "softplus"])
+@pytest.mark.parametrize("d,hidden", [(32, 32), (64, 64), (128, 128), (32, 128), (128, 64), (64, 32)])
+@pytest.mark.parametrize("method", ["euler", "milstein"])
+def test_matches_stepwise_path(method, d, hidden, activation):
+    B = 300                                   # not a multiple of the 32-row wave tile or the 128-row block
+    sde = _sde(d, hidden, activation)
+    y0 = (0.5 * torch.randn(B, d, generator=torch.Generator().manual_seed(1))).to(DEV)
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 4 * dt, 5 * dt, 16 * dt], device=DEV)
+    fast = _solve(sde, y0, ts, method, dt, 3, trajectory=True)
+    ref = _solve(sde, y0, ts, method, dt, 3, trajectory=False)
+    assert fast.shape == (4, B, d) and torch.isfinite(fast).all() and torch.equal(fast[0], y0)
+    torch.testing.assert_close(fast, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_stratonovich_milstein_and_long_solve():
+    d, hidden, B = 64, 128, 4096
+    sde = _sde(d, hidden, "tanh", sde_type="stratonovich")
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    dt = 2.0 ** -7
+    ts = torch.tensor([0.0, 128 * dt], device=DEV)
+    fast = _solve(sde, y0, ts, "milstein", dt, 8, trajectory=True)
+    ref = _solve(sde, y0, ts, "milstein", dt, 8, trajectory=False)
+    torch.testing.assert_close(fast, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_sharding_invariance_and_fallbacks():
+    """Rows solved with `row_offset` equal the same rows of the full solve bit for bit; an output time inside a step, a
+    method without an in-kernel form, or gradients send the solve down the stepwise path."""
+    import torchsde_amd
+    d, hidden, B = 32, 64, 512
+    sde = _sde(d, hidden, "softplus")
+    y0 = (0.3 * torch.randn(B, d, generator=torch.Generator().manual_seed(2))).to(DEV)
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 8 * dt], device=DEV)
+    full = _solve(sde, y0, ts, "euler", dt, 5, trajectory=True)
+    part = _solve(sde, y0[200:328], ts, "euler", dt, 5, trajectory=True, row_offset=200)
+    assert torch.equal(full[:, 200:328], part)
+    off_grid = torch.tensor([0.0, 2.5 * dt, 8 * dt], device=DEV)
+    assert torch.equal(_solve(sde, y0, off_grid, "euler", dt, 5, trajectory=True),
+                       _solve(sde, y0, off_grid, "euler", dt, 5, trajectory=False))
+    y_grad = y0.clone().requires_grad_(True)
+    bm = torchsde_amd.BrownianInterval(0.0, 8 * dt, size=(B, d), device=DEV, dtype=torch.float32, entropy=5)
+    ys = torchsde_amd.sdeint(sde, y_grad, ts, bm=bm, method="euler", dt=dt)
+    ys[-1].sum().backward()
+    assert y_grad.grad is not None and sde.lin1.weight.grad is not None
+    torch.testing.assert_close(ys.detach(), full, rtol=2e-4, atol=2e-5)
+
+
+def test_c_abi_rejects_unsupported_shapes():
+    from torchsde_amd import _native
+    lib = _native.load()
+    x = torch.zeros(64, 48, device=DEV)
+    traj = _native.Traj()
+    args = (x.data_ptr(),) * 2 + (64, 48, 32) + (x.data_ptr(),) * 6 + (0, 0, traj, 1, 0, None, 0, None)
+    assert lib.tsde_trajectory_mlp_diag(*args) != 0 and b"32, 64 or 128" in lib.tsde_last_error()

@@ -16,6 +16,7 @@ KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDAT
 KID_RHEUN, KID_TRAJECTORY = 7, 8
 ERROR_NORM_WORKSPACE = 1024
 TRAJ_SENS = 5
+ACT_TANH, ACT_SOFTPLUS = 0, 1
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 
 _c_i64 = ctypes.c_int64
@@ -101,6 +102,9 @@ SIGNATURES = {
     "tsde_trajectory_affine_diag_sens": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr,
                                                   _c_ptr, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                                   _c_ptr]),
+    "tsde_trajectory_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                          _c_ptr, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
+                                          _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),

@@ -55,3 +55,58 @@ class AffineDiagonalSDE(nn.Module):
                 return None
             out.append(p.detach().reshape(-1).expand(d).contiguous())
         return ("affine_diagonal",) + tuple(out)
+
+
+class MLPDriftDiagonalSDE(nn.Module):
+    """Diagonal-noise neural SDE with a two-layer perceptron drift shared by the batch and affine diffusion:
+
+        f(t, y) = lin2(act(lin1(y)))          g(t, y) = diff_rate * y + diff_shift
+
+    An ordinary module for every solver, for autograd and for ``sdeint_adjoint`` (train it as usual). For SAMPLING --
+    forward solves without autograd, Euler or Milstein, float32, ``d`` and ``hidden`` in {32, 64, 128} -- ``sdeint`` runs
+    the whole solve in one launch of ``tsde_trajectory_mlp_diag``: the state stays in registers, the weights in LDS,
+    both layers on the f32 matrix cores. Results agree with the stepwise path up to the summation order of the two
+    matrix products (same Brownian path).
+    """
+    noise_type = "diagonal"
+    _ACTIVATIONS = {"tanh": (0, torch.tanh), "softplus": (1, nn.functional.softplus)}
+
+    def __init__(self, d, hidden, activation="softplus", diff_rate=0.0, diff_shift=0.1, sde_type="ito", dtype=None,
+                 device=None):
+        super().__init__()
+        if sde_type not in ("ito", "stratonovich"):
+            raise ValueError(f"Expected sde_type 'ito' or 'stratonovich', got {sde_type!r}.")
+        if activation not in self._ACTIVATIONS:
+            raise ValueError(f"Expected activation in {sorted(self._ACTIVATIONS)}, got {activation!r}.")
+        self.sde_type, self.activation = sde_type, activation
+        self.lin1 = nn.Linear(d, hidden, dtype=dtype, device=device)
+        self.lin2 = nn.Linear(hidden, d, dtype=dtype, device=device)
+        for name, value in (("diff_rate", diff_rate), ("diff_shift", diff_shift)):
+            value = torch.as_tensor(value, dtype=self.lin1.weight.dtype, device=device)
+            if value.dim() > 1:
+                raise ValueError(f"`{name}` must be a scalar or a 1-D tensor over the state channels.")
+            setattr(self, name, nn.Parameter(value.detach().clone()))
+
+    def f(self, t, y):
+        return self.lin2(self._ACTIVATIONS[self.activation][1](self.lin1(y)))
+
+    def g(self, t, y):
+        return self.diff_rate * y + self.diff_shift
+
+    def closed_form(self, d, dtype, device):
+        """("mlp_diagonal", W1 (d, hidden) input-major, b1, W2 (hidden, d), b2, diff_rate (d,), diff_shift (d,), act) for
+        the sampling kernel, or None when it does not apply (then the stepwise path runs)."""
+        hidden = self.lin1.out_features
+        params = list(self.parameters())
+        if (dtype != torch.float32 or any(p.dtype != dtype or p.device != device for p in params)
+                or self.lin1.in_features != d or d not in (32, 64, 128) or hidden not in (32, 64, 128)
+                or self.lin1.bias is None or self.lin2.bias is None):
+            return None
+        coefs = []
+        for p in (self.diff_rate, self.diff_shift):
+            if p.dim() == 1 and p.numel() not in (1, d):
+                return None
+            coefs.append(p.detach().reshape(-1).expand(d).contiguous())
+        return ("mlp_diagonal", self.lin1.weight.detach().t().contiguous(), self.lin1.bias.detach().contiguous(),
+                self.lin2.weight.detach().t().contiguous(), self.lin2.bias.detach().contiguous(), coefs[0], coefs[1],
+                self._ACTIVATIONS[self.activation][0])

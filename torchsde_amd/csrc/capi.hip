@@ -369,6 +369,30 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
                                 diff_rate, diff_shift, method, traj, entropy, elem0, entropy_dev, dtype, stream);
 }
 
+int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t hidden, const void* w1,
+                             const void* b1, const void* w2, const void* b2, const void* diff_rate,
+                             const void* diff_shift, int activation, int method, const tsde_traj_t* traj,
+                             uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_trajectory_mlp_diag";
+  if (!ys || !y0 || !w1 || !b1 || !w2 || !b2 || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (rows < 0) return bad_arg(where, "need rows >= 0");
+  if ((d != 32 && d != 64 && d != 128) || (hidden != 32 && hidden != 64 && hidden != 128))
+    return bad_arg(where, "d and hidden must be 32, 64 or 128");
+  if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
+  if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MILSTEIN_ITO && method != TSDE_TRAJ_MILSTEIN_STRAT)
+    return bad_arg(where, "method must be Euler or Milstein");
+  if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
+  if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  return fail(tsde::launch_trajectory_mlp_diag(ys, y0, rows, d, hidden, w1, b1, w2, b2, diff_rate, diff_shift,
+                                               activation, method, traj, make_key(entropy, elem0), entropy_dev, s),
+              where);
+}
+
 int tsde_prof_begin(int kid, int capacity) {
   if (capacity <= 0) return bad_arg("tsde_prof_begin", "capacity must be positive");
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);

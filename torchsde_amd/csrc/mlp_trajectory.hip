@@ -1,0 +1,254 @@
+// Whole-trajectory kernel for diagonal-noise SDEs with a two-layer perceptron drift (neural-SDE sampling) on gfx950:
+//
+//     f(t, y) = W2 . act(W1 . y + b1) + b2          g(t, y) = c * y + e   (per channel)
+//
+// The drift is the one GEMM-shaped object on the torchsde hot path that is shared by the whole batch, so it is the one
+// place where the matrix cores apply: a wave owns 32 batch rows for ALL steps of the solve, the weights live in LDS,
+// and both layers run on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact f32, the reference's precision).
+//
+// Everything between the two GEMMs stays in registers, with no transpose and no LDS round trip, by computing the
+// TRANSPOSED products  H^T = W1^T Y^T  and  F^T = W2^T H^T:
+//   * the MFMA accumulator holds, in lane l and register r, the element (row m, column n) with
+//         n = l & 31                      (the batch row)
+//         m = 32*tile + (r & 3) + 8*(r >> 2) + 4*(l >> 5)        (the channel / hidden unit)
+//   * the B operand of the 32x32x2 instruction wants, in lane l, the element (k = l >> 5, n = l & 31): for a fixed
+//     register r the two lane halves hold the channels m(r, 0) and m(r, 1) = m(r, 0) + 4 of batch row n, which is
+//     exactly a legal (k0, k1) pair -- if the A operand (the weights, read from LDS) is addressed with the same
+//     pairing. So the state y, kept in accumulator layout, IS the B operand of layer 1; the activated accumulators
+//     of layer 1 ARE the B operand of layer 2; and the accumulators of layer 2 come out in the layout of y.
+//   * four consecutive registers (r & 3 = 0..3) of a lane are four consecutive channels of one batch row: one Philox
+//     quad of the counter RNG, so the Brownian increments are the same field every other kernel draws from
+//     (same path as the stepwise solve, sharding-invariant).
+//
+// Reference being replaced: the stepping loop torchsde/_core/base_solver.py:114-134 with euler.py:31-36 /
+// milstein.py:52-74 as the step, evaluated for an SDE whose f, g are the torch modules above.
+#include "tsde_common.h"
+#include "tsde_launch.h"
+#include "tsde_schemes.h"
+
+namespace tsde {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MlpArgs {
+  float* ys;                // (n_out, B, D)
+  const float* y0;          // (B, D)
+  const float* W1;          // (D, H): W1[k][m] = weight of input channel k into hidden unit m
+  const float* b1;          // (H)
+  const float* W2;          // (H, D)
+  const float* b2;          // (D)
+  const float *c, *e;       // (D) diffusion g = c*y + e
+  const float* rows;        // (n_steps, 8) schedule rows as in tsde_traj_t
+  const uint32_t* cells;
+  const int32_t* out_step;
+  const float* out_w;
+  int64_t B;
+  int32_t n_steps, n_out;
+  int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT
+  NoiseKey key;
+  const uint64_t* key_dev;
+};
+
+template <int ACT>
+TSDE_D float activate(float x) {
+  if constexpr (ACT == TSDE_ACT_TANH) {
+    return tanhf(x);
+  } else {   // softplus, torch's threshold-20 form (aten/src/ATen/native/cuda/ActivationSoftplusKernel.cu)
+    return x > 20.0f ? x : log1pf(expf(x));
+  }
+}
+
+// channel (or hidden unit) held by register r of a lane in half `hlf`, within a 32-wide tile
+TSDE_D constexpr int tile_row(int r, int hlf) { return (r & 3) + 8 * (r >> 2) + 4 * hlf; }
+
+template <int D, int H, int ACT>
+__global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p) {
+  constexpr int TD = D / 32, TH = H / 32;
+  extern __shared__ float lds[];
+  float* W1s = lds;                 // D*H
+  float* W2s = W1s + D * H;         // H*D
+  float* b1s = W2s + H * D;         // H
+  float* b2s = b1s + H;             // D
+  float* cs = b2s + D;              // D
+  float* es = cs + D;               // D
+  for (int i = threadIdx.x; i < D * H; i += kBlock) {
+    W1s[i] = p.W1[i];
+    W2s[i] = p.W2[i];
+  }
+  for (int i = threadIdx.x; i < H; i += kBlock) b1s[i] = p.b1[i];
+  for (int i = threadIdx.x; i < D; i += kBlock) {
+    b2s[i] = p.b2[i];
+    cs[i] = p.c[i];
+    es[i] = p.e[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hlf = lane >> 5, n = lane & 31;
+  const int64_t row = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * 32 + n;
+  const bool live = row < p.B;
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+
+  // state in accumulator layout: y[t][r] = y(row, 32 t + tile_row(r, hlf))
+  f32x16 y[TD];
+#pragma unroll
+  for (int t = 0; t < TD; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = 32 * t + 8 * q + 4 * hlf;      // channels ch .. ch+3 = registers 4q .. 4q+3
+      Pack<float, 4> v;
+      if (live) v = load<float, 4>(p.y0, row * D + ch);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y[t][4 * q + s] = live ? v.v[s] : 0.0f;
+    }
+  }
+
+  int jout = 0;
+  for (int k = 0; k < p.n_steps; ++k) {
+    const float* srow = p.rows + (int64_t)k * 8;
+    const float dt = srow[0], sw = srow[4];
+    const uint32_t cell = p.cells[k];
+
+    // ---- layer 1: hid^T = W1^T y^T ------------------------------------------------------------------------
+    // (the scheduling barriers keep the compiler from hoisting hundreds of LDS reads ahead of the MFMAs that use
+    //  them: without them the unrolled body needs > 512 registers and spills)
+    f32x16 hid[TH];
+#pragma unroll
+    for (int th = 0; th < TH; ++th) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[th][r] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = W1s[(32 * t + tile_row(r, hlf)) * H + 32 * th + n];
+          hid[th] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y[t][r], hid[th], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[th][r] = activate<ACT>(hid[th][r] + b1s[32 * th + tile_row(r, hlf)]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- layer 2: f^T = W2^T hid^T, then the step (in place: tile t of the state is only read by its own update) --
+    const bool due = jout < p.n_out && p.out_step[jout] == k + 1;
+#pragma unroll
+    for (int t = 0; t < TD; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int th = 0; th < TH; ++th) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a = W2s[(32 * th + tile_row(r, hlf)) * D + 32 * t + n];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hid[th][r], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = 32 * t + 8 * q + 4 * hlf;
+        float z[4];
+        normal4<float>(key, (key.elem0 + (uint64_t)(row * D + ch)) >> 2, cell, 0, kStreamW, z);
+        Pack<float, 4> o;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = 4 * q + s;
+          const float yy = y[t][r];
+          const float f = acc[r] + b2s[ch + s];
+          const float cc = cs[ch + s];
+          const float g = cc * yy + es[ch + s];
+          const float w = z[s] * sw;
+          float yn;
+          if (p.method == TSDE_TRAJ_EULER) {
+            yn = drift_diffusion_update<float>(yy, f, g, w, dt, 1.0f);
+          } else {
+            const float v2 = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
+            yn = milstein_update<float>(yy, f, g, (g * v2) * cc, w, dt);
+          }
+          y[t][r] = yn;
+          o.v[s] = yn;
+        }
+        if (due && live) store<float, 4>(p.ys + (int64_t)jout * p.B * D, row * D + ch, o);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // every output time of this kernel sits on a step boundary (the host sends anything else down the stepwise
+    // path); several outputs may share one boundary only if ts repeats, which the contract forbids
+    if (due) ++jout;
+  }
+}
+
+template <int D, int H, int ACT>
+static hipError_t launch_mlp_dh(const MlpArgs& p, hipStream_t s) {
+  const size_t lds_bytes = (size_t)(2 * D * H + H + 3 * D) * sizeof(float);
+  static bool configured = false;   // per instantiation
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  const int64_t rows_per_block = (kBlock / 64) * 32;
+  const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, p);
+  return hipGetLastError();
+}
+
+template <int D, int H>
+static hipError_t launch_mlp_act(const MlpArgs& p, int act, hipStream_t s) {
+  if (act == TSDE_ACT_TANH) return launch_mlp_dh<D, H, TSDE_ACT_TANH>(p, s);
+  if (act == TSDE_ACT_SOFTPLUS) return launch_mlp_dh<D, H, TSDE_ACT_SOFTPLUS>(p, s);
+  return hipErrorInvalidValue;
+}
+
+template <int D>
+static hipError_t launch_mlp_h(const MlpArgs& p, int64_t h, int act, hipStream_t s) {
+  switch (h) {
+    case 32: return launch_mlp_act<D, 32>(p, act, s);
+    case 64: return launch_mlp_act<D, 64>(p, act, s);
+    case 128: return launch_mlp_act<D, 128>(p, act, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t h, const void* W1,
+                                      const void* b1, const void* W2, const void* b2, const void* c, const void* e,
+                                      int act, int method, const tsde_traj_t* tr, NoiseKey key,
+                                      const uint64_t* key_dev, hipStream_t s) {
+  MlpArgs p;
+  p.ys = (float*)ys;
+  p.y0 = (const float*)y0;
+  p.W1 = (const float*)W1;
+  p.b1 = (const float*)b1;
+  p.W2 = (const float*)W2;
+  p.b2 = (const float*)b2;
+  p.c = (const float*)c;
+  p.e = (const float*)e;
+  p.rows = (const float*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const float*)tr->out_w;
+  p.B = rows;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.method = method;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (rows <= 0 || tr->n_steps <= 0) return hipSuccess;
+  switch (d) {
+    case 32: return launch_mlp_h<32>(p, h, act, s);
+    case 64: return launch_mlp_h<64>(p, h, act, s);
+    case 128: return launch_mlp_h<128>(p, h, act, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace tsde

@@ -531,6 +531,27 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
     return ys
 
 
+def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, method, schedule, bm):
+    """All steps of a diagonal SDE with a two-layer perceptron drift in one launch (``tsde_trajectory_mlp_diag``);
+    writes ys[j] for the schedule's outputs, which must all sit on step boundaries."""
+    tensors = (ys, y0, w1, b1, w2, b2, diff_rate, diff_shift)
+    _native.require_device(*tensors)
+    rows, d = y0.shape
+    hidden = b1.numel()
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        raise ValueError("the perceptron-drift kernel takes contiguous float32 tensors")
+    if w1.shape != (d, hidden) or w2.shape != (hidden, d) or b2.numel() != d or ys.shape != (schedule.n_out, rows, d):
+        raise ValueError("shape mismatch: w1 (d, hidden), w2 (hidden, d), ys (n_out, rows, d)")
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    code = lib.tsde_trajectory_mlp_diag(
+        ys.data_ptr(), y0.data_ptr(), rows, d, hidden, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+        diff_rate.data_ptr(), diff_shift.data_ptr(), int(activation), int(method), schedule.struct(), bm._key,
+        bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    _native.check(code, "tsde_trajectory_mlp_diag")
+    return ys
+
+
 class _TrajectoryFn(torch.autograd.Function):
     """Differentiable whole-trajectory solve of an affine diagonal SDE: the forward launch also produces the
     path-wise sensitivities of every output element (forward-mode tangents carried in registers), and the backward

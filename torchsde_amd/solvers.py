@@ -285,7 +285,16 @@ class BaseSDESolver:
                 or y0.dtype not in (torch.float32, torch.float64)):
             return None
         spec = base.closed_form(y0.shape[1], y0.dtype, y0.device)
-        if spec is None or spec[0] != "affine_diagonal":
+        if spec is None:
+            return None
+        if spec[0] == "mlp_diagonal":
+            # perceptron drift: sampling kernel on the matrix cores (forward only, Euler / Milstein)
+            code = self._trajectory_code()
+            if self._tracks_grad(y0) or code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO,
+                                                      _native.TRAJ_MILSTEIN_STRAT) or bm._elem0 % 4 != 0:
+                return None
+            return spec
+        if spec[0] != "affine_diagonal":
             return None
         if self._tracks_grad(y0):
             # gradients flow to y0 and to the module's own four coefficients through the sensitivity kernel; any
@@ -323,6 +332,14 @@ class BaseSDESolver:
         out_step = [kc for (_, kc, _, _) in grid.outputs]
         out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
         schedule = K.TrajectorySchedule(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        if coefficients[0] == "mlp_diagonal":
+            if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
+                return None      # an output time inside a step: the stepwise path interpolates it
+            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            K.trajectory_mlp_diag(ys[1:], y0c, *coefficients[1:], self._trajectory_code(), schedule, bm)
+            return ys
         if coefficients[0] == "differentiable":
             return K.trajectory_affine_diag_differentiable(y0, coefficients[1:], self._trajectory_code(), schedule, bm)
         y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
