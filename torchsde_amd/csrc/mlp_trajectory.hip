@@ -49,12 +49,22 @@ struct MlpArgs {
   const uint64_t* key_dev;
 };
 
+// Activations on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): the libm forms
+// (tanhf, log1pf(expf)) expand to ~100 instructions with divergent special-case branches, which made the
+// activation -- not the matrix products -- the longest part of a step. Absolute error <= 3e-7, well inside the
+// tolerance at which this kernel is compared with the stepwise path (summation order already differs).
 template <int ACT>
 TSDE_D float activate(float x) {
+  constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
   if constexpr (ACT == TSDE_ACT_TANH) {
-    return tanhf(x);
-  } else {   // softplus, torch's threshold-20 form (aten/src/ATen/native/cuda/ActivationSoftplusKernel.cu)
-    return x > 20.0f ? x : log1pf(expf(x));
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); exp(2x) = 2^(2x log2 e); saturates cleanly to +-1
+    const float e2x = __builtin_amdgcn_exp2f(x * (2.0f * kLog2e));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2x + 1.0f);
+  } else {
+    // softplus, torch's threshold-20 form (aten/src/ATen/native/cuda/ActivationSoftplusKernel.cu): log(1 + e^x)
+    const float ex = __builtin_amdgcn_exp2f(x * kLog2e);
+    const float sp = __builtin_amdgcn_logf(1.0f + ex) * kLn2;
+    return x > 20.0f ? x : sp;
   }
 }
 
