@@ -9,7 +9,11 @@ import torch  # noqa: E402
 import torchsde_amd  # noqa: E402
 
 dev = torch.device("cuda")
-for (B, d, hidden, n) in ((32768, 128, 128, 500), (65536, 64, 64, 500), (262144, 32, 32, 200), (1024, 64, 64, 500)):
+only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None
+stepwise = "--no-stepwise" not in sys.argv
+for idx, (B, d, hidden, n) in enumerate(((32768, 128, 128, 500), (65536, 64, 64, 500), (262144, 32, 32, 200), (1024, 64, 64, 500))):
+    if only is not None and idx != only:
+        continue
     dt = 2.0 ** -9
     torch.manual_seed(0)
     sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation="softplus", diff_rate=0.0, diff_shift=0.1).to(dev)
@@ -29,11 +33,12 @@ for (B, d, hidden, n) in ((32768, 128, 128, 500), (65536, 64, 64, 500), (262144,
         for i in range(reps):
             out = solve(10 + i, options)
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t
         assert torch.isfinite(out).all()
-        return (time.perf_counter() - t) / reps * 1e3
+        return elapsed / reps * 1e3
 
     fast = timed({})
-    slow = timed({"trajectory_kernel": False, "hip_graph": True})
+    slow = timed({"trajectory_kernel": False, "hip_graph": True}) if stepwise else float("nan")
     flops = 4.0 * B * d * hidden * n
     print(f"B={B} d={d} hidden={hidden} steps={n}: kernel {fast:8.2f} ms ({flops / fast / 1e9:6.1f} TFLOP/s f32, "
           f"{B * n / fast * 1e3:.3e} traj-steps/s)   stepwise graph {slow:8.2f} ms   x{slow / fast:.1f}")

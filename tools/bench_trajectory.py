@@ -47,8 +47,9 @@ def main():
                 for i in range(args.reps):
                     out = solve(10 + i, options)
                 torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t
                 assert torch.isfinite(out).all()
-                return (time.perf_counter() - t) / args.reps * 1e3
+                return elapsed / args.reps * 1e3
 
             rec = {"dtype": str(dtype).split(".")[-1], "method": method, "trajectory_ms": timed({})}
             if args.stepwise and not (method == "milstein"):

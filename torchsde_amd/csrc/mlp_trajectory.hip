@@ -68,25 +68,61 @@ TSDE_D float activate(float x) {
   }
 }
 
-// channel (or hidden unit) held by register r of a lane in half `hlf`, within a 32-wide tile
-TSDE_D constexpr int tile_row(int r, int hlf) { return (r & 3) + 8 * (r >> 2) + 4 * hlf; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int D, int H, int ACT>
-__global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p) {
-  constexpr int TD = D / 32, TH = H / 32;
+// The two f32 MFMA shapes. R = rows of the batch one wave owns = the tile edge.
+//   R = 32: v_mfma_f32_32x32x2_f32, 16 accumulator registers per tile, two lane halves  (K = 2 per instruction)
+//   R = 16: v_mfma_f32_16x16x4_f32,  4 accumulator registers per tile, four lane quarters (K = 4 per instruction)
+// `part` = lane / R selects the K index a lane feeds and the rows of the accumulator it holds; for a fixed register
+// the parts hold channels that differ by 4, which is the K grouping both operands are addressed with.
+template <int R>
+struct Tile;
+template <>
+struct Tile<32> {
+  static constexpr int kRegs = 16, kQuads = 4;
+  using acc_t = f32x16;
+  TSDE_D static constexpr int row(int r, int part) { return (r & 3) + 8 * (r >> 2) + 4 * part; }
+  TSDE_D static constexpr int quad_base(int q, int part) { return 8 * q + 4 * part; }   // channels of regs 4q..4q+3
+  TSDE_D static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Tile<16> {
+  static constexpr int kRegs = 4, kQuads = 1;
+  using acc_t = f32x4;
+  TSDE_D static constexpr int row(int r, int part) { return 4 * part + r; }
+  TSDE_D static constexpr int quad_base(int q, int part) { return 4 * part; }
+  TSDE_D static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+
+template <int R>
+struct MlpLds {
+  static constexpr int kPad = (R == 16) ? 4 : 0;
+  static constexpr size_t bytes(int d, int h) { return (size_t)(d * (h + kPad) + h * (d + kPad) + h + 3 * d) * sizeof(float); }
+};
+
+// NW = waves per block: all of them share one copy of the weights in LDS.
+template <int D, int H, int ACT, int R, int NW>
+__global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p) {
+  using TL = Tile<R>;
+  using acc_t = typename TL::acc_t;
+  constexpr int TD = D / R, TH = H / R, kRegs = TL::kRegs, kThreads = NW * 64;
+  // LDS row strides. The parts of a wave read weight rows 4 apart; with a stride that is a multiple of 32 floats all
+  // of them hit the same banks. Padding the stride to 4 (mod 8) floats spreads the four quarters of a 16-row wave
+  // over both halves of the 32 banks (2 lanes per bank: the minimum for 64 lanes).
+  constexpr int S1 = H + MlpLds<R>::kPad, S2 = D + MlpLds<R>::kPad;
   extern __shared__ float lds[];
-  float* W1s = lds;                 // D*H
-  float* W2s = W1s + D * H;         // H*D
-  float* b1s = W2s + H * D;         // H
+  float* W1s = lds;                 // D rows of S1
+  float* W2s = W1s + D * S1;        // H rows of S2
+  float* b1s = W2s + H * S2;        // H
   float* b2s = b1s + H;             // D
   float* cs = b2s + D;              // D
   float* es = cs + D;               // D
-  for (int i = threadIdx.x; i < D * H; i += kBlock) {
-    W1s[i] = p.W1[i];
-    W2s[i] = p.W2[i];
+  for (int i = threadIdx.x; i < D * H; i += kThreads) {
+    W1s[(i / H) * S1 + (i % H)] = p.W1[i];
+    W2s[(i / D) * S2 + (i % D)] = p.W2[i];
   }
-  for (int i = threadIdx.x; i < H; i += kBlock) b1s[i] = p.b1[i];
-  for (int i = threadIdx.x; i < D; i += kBlock) {
+  for (int i = threadIdx.x; i < H; i += kThreads) b1s[i] = p.b1[i];
+  for (int i = threadIdx.x; i < D; i += kThreads) {
     b2s[i] = p.b2[i];
     cs[i] = p.c[i];
     es[i] = p.e[i];
@@ -94,8 +130,8 @@ __global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p)
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hlf = lane >> 5, n = lane & 31;
-  const int64_t row = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * 32 + n;
+  const int part = lane / R, n = lane % R;
+  const int64_t row = ((int64_t)blockIdx.x * NW + wave) * R + n;
   const bool live = row < p.B;
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
@@ -104,13 +140,13 @@ __global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p)
     key.k1 = (uint32_t)(ent >> 32);
   }
 
-  // state in accumulator layout: y[t][r] = y(row, 32 t + tile_row(r, hlf))
-  f32x16 y[TD];
+  // state in accumulator layout: y[t][r] = y(row, R t + TL::row(r, part))
+  acc_t y[TD];
 #pragma unroll
   for (int t = 0; t < TD; ++t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ch = 32 * t + 8 * q + 4 * hlf;      // channels ch .. ch+3 = registers 4q .. 4q+3
+    for (int q = 0; q < TL::kQuads; ++q) {
+      const int ch = R * t + TL::quad_base(q, part);      // channels ch .. ch+3 = registers 4q .. 4q+3
       Pack<float, 4> v;
       if (live) v = load<float, 4>(p.y0, row * D + ch);
 #pragma unroll
@@ -127,22 +163,22 @@ __global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p)
     // ---- layer 1: hid^T = W1^T y^T ------------------------------------------------------------------------
     // (the scheduling barriers keep the compiler from hoisting hundreds of LDS reads ahead of the MFMAs that use
     //  them: without them the unrolled body needs > 512 registers and spills)
-    f32x16 hid[TH];
+    acc_t hid[TH];
 #pragma unroll
     for (int th = 0; th < TH; ++th) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hid[th][r] = 0.0f;
+      for (int r = 0; r < kRegs; ++r) hid[th][r] = 0.0f;
 #pragma unroll
       for (int t = 0; t < TD; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float a = W1s[(32 * t + tile_row(r, hlf)) * H + 32 * th + n];
-          hid[th] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, y[t][r], hid[th], 0, 0, 0);
+        for (int r = 0; r < kRegs; ++r) {
+          const float a = W1s[(R * t + TL::row(r, part)) * S1 + R * th + n];
+          hid[th] = TL::mfma(a, y[t][r], hid[th]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if ((t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hid[th][r] = activate<ACT>(hid[th][r] + b1s[32 * th + tile_row(r, hlf)]);
+      for (int r = 0; r < kRegs; ++r) hid[th][r] = activate<ACT>(hid[th][r] + b1s[R * th + TL::row(r, part)]);
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -150,21 +186,21 @@ __global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p)
     const bool due = jout < p.n_out && p.out_step[jout] == k + 1;
 #pragma unroll
     for (int t = 0; t < TD; ++t) {
-      f32x16 acc;
+      acc_t acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      for (int r = 0; r < kRegs; ++r) acc[r] = 0.0f;
 #pragma unroll
       for (int th = 0; th < TH; ++th) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float a = W2s[(32 * th + tile_row(r, hlf)) * D + 32 * t + n];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, hid[th][r], acc, 0, 0, 0);
+        for (int r = 0; r < kRegs; ++r) {
+          const float a = W2s[(R * th + TL::row(r, part)) * S2 + R * t + n];
+          acc = TL::mfma(a, hid[th][r], acc);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if ((th + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ch = 32 * t + 8 * q + 4 * hlf;
+      for (int q = 0; q < TL::kQuads; ++q) {
+        const int ch = R * t + TL::quad_base(q, part);
         float z[4];
         normal4<float>(key, (key.elem0 + (uint64_t)(row * D + ch)) >> 2, cell, 0, kStreamW, z);
         Pack<float, 4> o;
@@ -196,20 +232,35 @@ __global__ void __launch_bounds__(kBlock) mlp_trajectory_kernel(const MlpArgs p)
   }
 }
 
-template <int D, int H, int ACT>
-static hipError_t launch_mlp_dh(const MlpArgs& p, hipStream_t s) {
-  const size_t lds_bytes = (size_t)(2 * D * H + H + 3 * D) * sizeof(float);
+template <int D, int H, int ACT, int R, int NW>
+static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
+  const size_t lds_bytes = MlpLds<R>::bytes(D, H);
   static bool configured = false;   // per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     configured = true;
   }
-  const int64_t rows_per_block = (kBlock / 64) * 32;
+  const int64_t rows_per_block = NW * R;
   const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, p);
+  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, s, p);
   return hipGetLastError();
+}
+
+// Variant choice (tools/bench_mlp_trajectory.py, MI355X): 16-row waves in 8-wave blocks everywhere. The weights of a
+// d = hidden = 128 net fill the LDS of a CU, so all waves of a CU share one block; 16-row waves then put two waves
+// on every SIMD (one's RNG / activation / update overlaps the other's MFMAs) at the same 128 rows per CU: 10.9 ms
+// vs 12.1 ms for 32-row waves at B 32768 x 500 steps, 6.6 vs 6.9 ms at d = hidden = 64. TSDE_MLP_VARIANT=32
+// selects the 32x32x2 form (kept for the tests: both layouts must agree).
+template <int D, int H, int ACT>
+static hipError_t launch_mlp_dh(const MlpArgs& p, hipStream_t s) {
+  static const int forced = [] {
+    const char* e = getenv("TSDE_MLP_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4>(p, s);
+  return launch_mlp_variant<D, H, ACT, 16, 8>(p, s);
 }
 
 template <int D, int H>
