@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-in/f32-accumulate matrix rate (same guide)
 
 WORKLOADS = {
     # BASELINE.json configs[1] -- the headline (default) workload
@@ -73,6 +74,13 @@ WORKLOADS = {
         problem="gbm_closed_form_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000,
         dt=2.0 ** -10, kid=8, trajectory=True,
         kernel="tsde_trajectory_affine_diag<float, midpoint> (trajectory_kernel)"),
+    # Neural-SDE SAMPLING at the configs[4] shape (forward only): drift = Linear(128,128)-Softplus-Linear(128,128) like the
+    # latent-SDE workload below, affine diagonal diffusion, handed over as torchsde_amd.MLPDriftDiagonalSDE: one launch
+    # of the perceptron-drift kernel, both layers on the f32 matrix cores. MFMA-bound: 4*d*hidden flop per trajectory-step.
+    "c5_sampling_mlp_b32768_d128_s500": dict(
+        problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
+        kid=8, trajectory=True, mfma_flops_per_traj_step=4 * 128 * 128,
+        kernel="tsde_trajectory_mlp_diag<128, 128, softplus> (mlp_trajectory_kernel, v_mfma_f32_16x16x4_f32)"),
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
@@ -105,6 +113,10 @@ def _make_problem(name, d, m, dev):
             def g(self, t, y):
                 return 0.1 * torch.sigmoid(self.w * y + self.b)
         return Latent().to(dev)
+    if name == "mlp_drift":
+        import torchsde_amd
+        torch.manual_seed(0)
+        return torchsde_amd.MLPDriftDiagonalSDE(d, 128, activation="softplus", diff_rate=0.0, diff_shift=0.1).to(dev)
     if name.startswith("gbm_closed_form"):
         import torchsde_amd
         strat = name.endswith("_strat")
@@ -296,9 +308,18 @@ def main():
         # bound by the VALU work of the counter RNG (Philox-4x32-10 + Box-Muller per element-step), so its HBM
         # roofline fraction is ~0 by design; `valu_*` restate the same launch against the vector-ALU issue peak.
         avg_s = k_ms * 1e-3 / k_launches
+        if cfg.get("mfma_flops_per_traj_step"):
+            flops = cfg["mfma_flops_per_traj_step"] * B * nsteps
+            achieved = flops / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": cfg["kernel"], "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "flops_per_launch": flops, "avg_launch_us": avg_s * 1e6, "launches_timed": k_launches,
+                        "note": "f32-in / f32-accumulate MFMA (exact f32); peak = dense f32 matrix rate of "
+                                "guides/MI355X_MICROARCH.md",
+                        "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
         bytes_per_launch = 2 * B * d * 4
         achieved = bytes_per_launch / avg_s / 1e9
-        roofline = {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roofline = roofline or {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_s * 1e6, "launches_timed": k_launches,
                     "element_steps_per_s": B * d * nsteps / avg_s,
