@@ -258,7 +258,8 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  * in ONE launch (neural-SDE sampling): a wave keeps 32 batch rows in registers for the whole solve, the weights
  * live in LDS and both layers run on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 accumulation).
  *   w1 (d, hidden) and w2 (hidden, d) are stored input-major: w1[k][m] multiplies input channel k into unit m
- *   (the transpose of torch.nn.Linear.weight). d, hidden in {32, 64, 128}; dtype must be TSDE_F32;
+ *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 (both are zero-padded
+ *   to the MFMA tile sizes inside the kernel); ys, y0 16-byte aligned; dtype must be TSDE_F32;
  *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT}.
  * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */

@@ -63,7 +63,7 @@ class MLPDriftDiagonalSDE(nn.Module):
         f(t, y) = lin2(act(lin1(y)))          g(t, y) = diff_rate * y + diff_shift
 
     An ordinary module for every solver, for autograd and for ``sdeint_adjoint`` (train it as usual). For SAMPLING --
-    forward solves without autograd, Euler or Milstein, float32, ``d`` and ``hidden`` in {32, 64, 128} -- ``sdeint`` runs
+    forward solves without autograd, Euler or Milstein, float32, ``d`` a multiple of 4, ``d, hidden <= 128`` -- ``sdeint`` runs
     the whole solve in one launch of ``tsde_trajectory_mlp_diag``: the state stays in registers, the weights in LDS,
     both layers on the f32 matrix cores. Results agree with the stepwise path up to the summation order of the two
     matrix products (same Brownian path).
@@ -99,7 +99,7 @@ class MLPDriftDiagonalSDE(nn.Module):
         hidden = self.lin1.out_features
         params = list(self.parameters())
         if (dtype != torch.float32 or any(p.dtype != dtype or p.device != device for p in params)
-                or self.lin1.in_features != d or d not in (32, 64, 128) or hidden not in (32, 64, 128)
+                or self.lin1.in_features != d or d % 4 != 0 or d > 128 or hidden > 128
                 or self.lin1.bias is None or self.lin2.bias is None):
             return None
         coefs = []

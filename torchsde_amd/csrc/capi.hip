@@ -377,8 +377,10 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
   if (!ys || !y0 || !w1 || !b1 || !w2 || !b2 || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
-  if ((d != 32 && d != 64 && d != 128) || (hidden != 32 && hidden != 64 && hidden != 128))
-    return bad_arg(where, "d and hidden must be 32, 64 or 128");
+  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 1 || hidden > 128)
+    return bad_arg(where, "need d a multiple of 4 in [4, 128] and hidden in [1, 128]");
+  if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
+    return bad_arg(where, "ys and y0 must be 16-byte aligned");
   if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
   if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MILSTEIN_ITO && method != TSDE_TRAJ_MILSTEIN_STRAT)
     return bad_arg(where, "method must be Euler or Milstein");

@@ -43,6 +43,7 @@ struct MlpArgs {
   const int32_t* out_step;
   const float* out_w;
   int64_t B;
+  int32_t d, h;             // true state / hidden sizes (d % 4 == 0); the kernel pads them to its tile sizes D, H
   int32_t n_steps, n_out;
   int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT
   NoiseKey key;
@@ -117,15 +118,19 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
   float* b2s = b1s + H;             // D
   float* cs = b2s + D;              // D
   float* es = cs + D;               // D
+  // weights into LDS, zero-padded from (d, h) to the tile sizes (D, H): padded hidden units feed zero rows of W2 and
+  // padded state channels have zero drift, zero diffusion and no noise, so they stay exactly 0
+  const int dT = p.d, hT = p.h;
   for (int i = threadIdx.x; i < D * H; i += kThreads) {
-    W1s[(i / H) * S1 + (i % H)] = p.W1[i];
-    W2s[(i / D) * S2 + (i % D)] = p.W2[i];
+    const int k1 = i / H, m1 = i % H, k2 = i / D, m2 = i % D;
+    W1s[k1 * S1 + m1] = (k1 < dT && m1 < hT) ? p.W1[k1 * hT + m1] : 0.0f;
+    W2s[k2 * S2 + m2] = (k2 < hT && m2 < dT) ? p.W2[k2 * dT + m2] : 0.0f;
   }
-  for (int i = threadIdx.x; i < H; i += kThreads) b1s[i] = p.b1[i];
+  for (int i = threadIdx.x; i < H; i += kThreads) b1s[i] = i < hT ? p.b1[i] : 0.0f;
   for (int i = threadIdx.x; i < D; i += kThreads) {
-    b2s[i] = p.b2[i];
-    cs[i] = p.c[i];
-    es[i] = p.e[i];
+    b2s[i] = i < dT ? p.b2[i] : 0.0f;
+    cs[i] = i < dT ? p.c[i] : 0.0f;
+    es[i] = i < dT ? p.e[i] : 0.0f;
   }
   __syncthreads();
 
@@ -148,9 +153,10 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
     for (int q = 0; q < TL::kQuads; ++q) {
       const int ch = R * t + TL::quad_base(q, part);      // channels ch .. ch+3 = registers 4q .. 4q+3
       Pack<float, 4> v;
-      if (live) v = load<float, 4>(p.y0, row * D + ch);
+      const bool real = live && ch < dT;                // a quad of channels is real or padding as a whole
+      if (real) v = load<float, 4>(p.y0, row * dT + ch);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) y[t][4 * q + s] = live ? v.v[s] : 0.0f;
+      for (int s = 0; s < 4; ++s) y[t][4 * q + s] = real ? v.v[s] : 0.0f;
     }
   }
 
@@ -201,8 +207,8 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 #pragma unroll
       for (int q = 0; q < TL::kQuads; ++q) {
         const int ch = R * t + TL::quad_base(q, part);
-        float z[4];
-        normal4<float>(key, (key.elem0 + (uint64_t)(row * D + ch)) >> 2, cell, 0, kStreamW, z);
+        float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (ch < dT) normal4<float>(key, (key.elem0 + (uint64_t)(row * dT + ch)) >> 2, cell, 0, kStreamW, z);
         Pack<float, 4> o;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -222,7 +228,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
           y[t][r] = yn;
           o.v[s] = yn;
         }
-        if (due && live) store<float, 4>(p.ys + (int64_t)jout * p.B * D, row * D + ch, o);
+        if (due && live && ch < dT) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, row * dT + ch, o);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -271,13 +277,11 @@ static hipError_t launch_mlp_act(const MlpArgs& p, int act, hipStream_t s) {
 }
 
 template <int D>
-static hipError_t launch_mlp_h(const MlpArgs& p, int64_t h, int act, hipStream_t s) {
-  switch (h) {
-    case 32: return launch_mlp_act<D, 32>(p, act, s);
-    case 64: return launch_mlp_act<D, 64>(p, act, s);
-    case 128: return launch_mlp_act<D, 128>(p, act, s);
-    default: return hipErrorInvalidValue;
-  }
+static hipError_t launch_mlp_h(const MlpArgs& p, int act, hipStream_t s) {
+  if (p.h <= 32) return launch_mlp_act<D, 32>(p, act, s);
+  if (p.h <= 64) return launch_mlp_act<D, 64>(p, act, s);
+  if (p.h <= 128) return launch_mlp_act<D, 128>(p, act, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t h, const void* W1,
@@ -298,18 +302,18 @@ hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, in
   p.out_step = tr->out_step;
   p.out_w = (const float*)tr->out_w;
   p.B = rows;
+  p.d = (int32_t)d;
+  p.h = (int32_t)h;
   p.n_steps = tr->n_steps;
   p.n_out = tr->n_out;
   p.method = method;
   p.key = key;
   p.key_dev = key_dev;
   if (rows <= 0 || tr->n_steps <= 0) return hipSuccess;
-  switch (d) {
-    case 32: return launch_mlp_h<32>(p, h, act, s);
-    case 64: return launch_mlp_h<64>(p, h, act, s);
-    case 128: return launch_mlp_h<128>(p, h, act, s);
-    default: return hipErrorInvalidValue;
-  }
+  if (d <= 32) return launch_mlp_h<32>(p, act, s);
+  if (d <= 64) return launch_mlp_h<64>(p, act, s);
+  if (d <= 128) return launch_mlp_h<128>(p, act, s);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace tsde
