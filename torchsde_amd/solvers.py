@@ -5,7 +5,8 @@ Solver protocol as in the reference (torchsde/_core/base_solver.py:29-149): clas
 ``(sde, bm, dt, adaptive, rtol, atol, dt_min, options)`` with the same compatibility errors (:49-58);
 ``init_extra_solver_state``; ``step(t0, t1, y0, extra0) -> (y1, extra1)``; ``integrate(y0, ts, extra0)``.
 
-``integrate`` is a different program from the reference's loop (:114-149): the time grid, per-step ``dt``,
+``integrate`` is a different program from the reference's loop (:114-149). Closed-form SDEs (closed_form.py) run all
+their steps in one launch of a trajectory kernel (`_integrate_trajectory`). For everything else the time grid, per-step ``dt``,
 stage times and interpolation weights are computed once on the host (timegrid.py); each step is the user's
 ``f``/``g`` torch ops plus ONE fused kernel per solver stage that reads ``y, f, g``, generates the Brownian
 increment of the step's grid cell in registers and writes the new state straight into its destination
@@ -271,9 +272,11 @@ class BaseSDESolver:
         return None
 
     def _closed_form_coefficients(self, y0):
-        """Coefficient tensors if the whole solve can run as ONE launch of the trajectory kernel: a closed-form
-        SDE handed to `sdeint` as is (closed_form.py), forward only, this package's BrownianInterval generating
-        the increments. `options={"trajectory_kernel": False}` keeps the stepwise path."""
+        """What `_integrate_trajectory` needs if the whole solve can run as ONE launch of a trajectory kernel, else
+        None: a closed-form SDE handed to `sdeint` as is (closed_form.py) and this package's BrownianInterval
+        generating the increments. Affine SDEs: the coefficient tensors, or ("differentiable", parameters...) when
+        autograd is on (sensitivity kernel); perceptron drift: the ("mlp_diagonal", ...) spec, forward only.
+        `options={"trajectory_kernel": False}` keeps the stepwise path."""
         from .sde import ForwardSDE
         if not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful:
             return None
