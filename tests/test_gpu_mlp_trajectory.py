@@ -87,3 +87,27 @@ def test_c_abi_rejects_unsupported_shapes():
     for d, hidden in ((6, 32), (132, 32), (32, 129)):
         args = (x.data_ptr(),) * 2 + (64, d, hidden) + (x.data_ptr(),) * 6 + (0, 0, traj, 1, 0, None, 0, None)
         assert lib.tsde_trajectory_mlp_diag(*args) != 0 and b"multiple of 4" in lib.tsde_last_error()
+
+
+def test_training_paths_still_work_on_the_module():
+    """`sdeint_adjoint` (its forward pass runs the sampling kernel, its backward sweep the stepwise adjoint) and
+    back-propagation through the stepwise solver agree on the gradients of the same module."""
+    import torchsde_amd
+    d, hidden, B = 32, 64, 256
+    sde = _sde(d, hidden, "tanh", sde_type="stratonovich")
+    dt = 2.0 ** -7
+    ts = torch.tensor([0.0, 32 * dt], device=DEV)
+
+    def grads(fn, **kw):
+        y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 32 * dt, size=(B, d), device=DEV, dtype=torch.float32, entropy=4)
+        sde.zero_grad()
+        ys = fn(sde, y0, ts, bm=bm, method="midpoint", dt=dt, **kw)
+        ys[-1].sum().backward()
+        return ys.detach(), y0.grad, sde.lin1.weight.grad.clone()
+
+    ys_a, gy_a, gw_a = grads(torchsde_amd.sdeint_adjoint)
+    ys_b, gy_b, gw_b = grads(torchsde_amd.sdeint)
+    torch.testing.assert_close(ys_a, ys_b, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gy_a, gy_b, rtol=5e-2, atol=5e-3)
+    assert ((gw_a - gw_b).abs().max() / gw_b.abs().max()).item() < 5e-2

@@ -6,8 +6,8 @@ Solver protocol as in the reference (torchsde/_core/base_solver.py:29-149): clas
 ``init_extra_solver_state``; ``step(t0, t1, y0, extra0) -> (y1, extra1)``; ``integrate(y0, ts, extra0)``.
 
 ``integrate`` is a different program from the reference's loop (:114-149). Closed-form SDEs (closed_form.py) run all
-their steps in one launch of a trajectory kernel (`_integrate_trajectory`). For everything else the time grid, per-step ``dt``,
-stage times and interpolation weights are computed once on the host (timegrid.py); each step is the user's
+their steps in one launch of a trajectory kernel (`_integrate_trajectory`). For everything else the time grid,
+per-step ``dt``, stage times and interpolation weights are computed once on the host (timegrid.py); each step is the user's
 ``f``/``g`` torch ops plus ONE fused kernel per solver stage that reads ``y, f, g``, generates the Brownian
 increment of the step's grid cell in registers and writes the new state straight into its destination
 (the next ``ys[i]`` slot when the step lands on an output time). No host sync, no per-step allocation of
