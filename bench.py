@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2_euler_diag_b65536_d64_s1000")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short side measurements reported under `also`")
     ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
@@ -362,6 +363,37 @@ def main():
                                "that includes marker-packet latency") if b2b_us is not None else
                               "HIP events bracketing every launch of one eagerly issued solve (upper bound)",
                     "launches_timed": k_launches}
+    also = None
+    if world == 1 and not args.no_also and args.workload == "c2_euler_diag_b65536_d64_s1000":
+        # Side measurements, outside the timed region of the headline and NOT part of `value`: the same job when the
+        # SDE is handed over in closed form (whole solve in one launch), and neural-SDE sampling on the matrix cores.
+        also = {}
+        for name in ("c2_euler_closed_form_b65536_d64_s1000", "c5_sampling_mlp_b32768_d128_s500"):
+            c = WORKLOADS[name]
+            side_sde = _make_problem(c["problem"], c["d"], c["m"], dev)
+            side_y0 = torch.full((c["B"], c["d"]), 0.1, device=dev)
+            side_ts = torch.tensor([0.0, c["nsteps"] * c["dt"]], device=dev)
+
+            def side_solve(i):
+                side_bm = torchsde_amd.BrownianInterval(t0=0.0, t1=c["nsteps"] * c["dt"], size=(c["B"], c["m"]),
+                                                        dtype=torch.float32, device=dev, entropy=777 + i, dt=c["dt"],
+                                                        levy_area_approximation=c["levy"])
+                with torch.no_grad():
+                    return torchsde_amd.sdeint(side_sde, side_y0, side_ts, bm=side_bm, method=c["method"], dt=c["dt"])
+
+            for i in range(2):
+                side_solve(i)
+            torch.cuda.synchronize()
+            t_side = time.perf_counter()
+            for i in range(5):
+                side_out = side_solve(10 + i)
+            torch.cuda.synchronize()
+            side_ms = (time.perf_counter() - t_side) / 5 * 1e3
+            assert torch.isfinite(side_out).all()
+            also[name] = {"ms_per_solve": side_ms, "trajectory_steps_per_s": c["B"] * c["nsteps"] / side_ms * 1e3,
+                          "kernel": c["kernel"]}
+            if c.get("mfma_flops_per_traj_step"):
+                also[name]["tflops_f32"] = c["mfma_flops_per_traj_step"] * c["B"] * c["nsteps"] / side_ms / 1e9
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -382,6 +414,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if also is not None:
+            line["also"] = also
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
