@@ -260,7 +260,7 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  *   w1 (d, hidden) and w2 (hidden, d) are stored input-major: w1[k][m] multiplies input channel k into unit m
  *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 (both are zero-padded
  *   to the MFMA tile sizes inside the kernel); ys, y0 16-byte aligned; dtype must be TSDE_F32;
- *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT}.
+ *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT, TSDE_TRAJ_MIDPOINT}.
  * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
 #define TSDE_ACT_TANH 0

@@ -32,10 +32,10 @@ def _solve(sde, y0, ts, method, dt, entropy, trajectory, row_offset=0):
 @pytest.mark.parametrize("activation", ["tanh", "softplus"])
 @pytest.mark.parametrize("d,hidden", [(32, 32), (64, 64), (128, 128), (32, 128), (128, 64), (64, 32),
                                       (4, 16), (8, 100), (20, 50), (100, 7), (36, 33)])     # padded to the MFMA tiles
-@pytest.mark.parametrize("method", ["euler", "milstein"])
-def test_matches_stepwise_path(method, d, hidden, activation):
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("milstein", "ito"), ("midpoint", "stratonovich")])
+def test_matches_stepwise_path(method, sde_type, d, hidden, activation):
     B = 300                                   # not a multiple of the 32-row wave tile or the 128-row block
-    sde = _sde(d, hidden, activation)
+    sde = _sde(d, hidden, activation, sde_type=sde_type)
     y0 = (0.5 * torch.randn(B, d, generator=torch.Generator().manual_seed(1))).to(DEV)
     dt = 2.0 ** -5
     ts = torch.tensor([0.0, 4 * dt, 5 * dt, 16 * dt], device=DEV)

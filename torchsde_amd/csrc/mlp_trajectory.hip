@@ -45,7 +45,7 @@ struct MlpArgs {
   int64_t B;
   int32_t d, h;             // true state / hidden sizes (d % 4 == 0); the kernel pads them to its tile sizes D, H
   int32_t n_steps, n_out;
-  int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT
+  int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT / _MIDPOINT
   NoiseKey key;
   const uint64_t* key_dev;
 };
@@ -102,7 +102,8 @@ struct MlpLds {
 };
 
 // NW = waves per block: all of them share one copy of the weights in LDS.
-template <int D, int H, int ACT, int R, int NW>
+// MID: the two-stage Stratonovich midpoint scheme (midpoint.py:31-43) instead of the one-stage Euler / Milstein step.
+template <int D, int H, int ACT, int R, int NW, bool MID>
 __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p) {
   using TL = Tile<R>;
   using acc_t = typename TL::acc_t;
@@ -166,32 +167,34 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
     const float dt = srow[0], sw = srow[4];
     const uint32_t cell = p.cells[k];
 
-    // ---- layer 1: hid^T = W1^T y^T ------------------------------------------------------------------------
+    const float half_dt = srow[1];
+    const bool due = jout < p.n_out && p.out_step[jout] == k + 1;
+
+    // ---- layer 1: hid^T = W1^T x^T ------------------------------------------------------------------------
     // (the scheduling barriers keep the compiler from hoisting hundreds of LDS reads ahead of the MFMAs that use
     //  them: without them the unrolled body needs > 512 registers and spills)
     acc_t hid[TH];
+    auto hidden_layer = [&](const acc_t* x) {
 #pragma unroll
-    for (int th = 0; th < TH; ++th) {
+      for (int th = 0; th < TH; ++th) {
 #pragma unroll
-      for (int r = 0; r < kRegs; ++r) hid[th][r] = 0.0f;
+        for (int r = 0; r < kRegs; ++r) hid[th][r] = 0.0f;
 #pragma unroll
-      for (int t = 0; t < TD; ++t) {
+        for (int t = 0; t < TD; ++t) {
 #pragma unroll
-        for (int r = 0; r < kRegs; ++r) {
-          const float a = W1s[(R * t + TL::row(r, part)) * S1 + R * th + n];
-          hid[th] = TL::mfma(a, y[t][r], hid[th]);
+          for (int r = 0; r < kRegs; ++r) {
+            const float a = W1s[(R * t + TL::row(r, part)) * S1 + R * th + n];
+            hid[th] = TL::mfma(a, x[t][r], hid[th]);
+          }
+          if ((t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
         }
-        if ((t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < kRegs; ++r) hid[th][r] = activate<ACT>(hid[th][r] + b1s[R * th + TL::row(r, part)]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int r = 0; r < kRegs; ++r) hid[th][r] = activate<ACT>(hid[th][r] + b1s[R * th + TL::row(r, part)]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- layer 2: f^T = W2^T hid^T, then the step (in place: tile t of the state is only read by its own update) --
-    const bool due = jout < p.n_out && p.out_step[jout] == k + 1;
-#pragma unroll
-    for (int t = 0; t < TD; ++t) {
+    };
+    // ---- layer 2, one tile of channels: f^T tile = W2^T hid^T ---------------------------------------------------
+    auto drift_tile = [&](int t) {
       acc_t acc;
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) acc[r] = 0.0f;
@@ -204,31 +207,86 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
         }
         if ((th + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
       }
+      return acc;
+    };
+
+    if constexpr (!MID) {
+      // one stage; in place: tile t of the state is only read by its own update
+      hidden_layer(y);
 #pragma unroll
-      for (int q = 0; q < TL::kQuads; ++q) {
-        const int ch = R * t + TL::quad_base(q, part);
-        float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (ch < dT) normal4<float>(key, (key.elem0 + (uint64_t)(row * dT + ch)) >> 2, cell, 0, kStreamW, z);
-        Pack<float, 4> o;
+      for (int t = 0; t < TD; ++t) {
+        const acc_t acc = drift_tile(t);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int r = 4 * q + s;
-          const float yy = y[t][r];
-          const float f = acc[r] + b2s[ch + s];
-          const float cc = cs[ch + s];
-          const float g = cc * yy + es[ch + s];
-          const float w = z[s] * sw;
-          float yn;
-          if (p.method == TSDE_TRAJ_EULER) {
-            yn = drift_diffusion_update<float>(yy, f, g, w, dt, 1.0f);
-          } else {
-            const float v2 = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
-            yn = milstein_update<float>(yy, f, g, (g * v2) * cc, w, dt);
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const int ch = R * t + TL::quad_base(q, part);
+          float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (ch < dT) normal4<float>(key, (key.elem0 + (uint64_t)(row * dT + ch)) >> 2, cell, 0, kStreamW, z);
+          Pack<float, 4> o;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int r = 4 * q + s;
+            const float yy = y[t][r];
+            const float f = acc[r] + b2s[ch + s];
+            const float cc = cs[ch + s];
+            const float g = cc * yy + es[ch + s];
+            const float w = z[s] * sw;
+            float yn;
+            if (p.method == TSDE_TRAJ_EULER) {
+              yn = drift_diffusion_update<float>(yy, f, g, w, dt, 1.0f);
+            } else {
+              const float v2 = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
+              yn = milstein_update<float>(yy, f, g, (g * v2) * cc, w, dt);
+            }
+            y[t][r] = yn;
+            o.v[s] = yn;
           }
-          y[t][r] = yn;
-          o.v[s] = yn;
+          if (due && live && ch < dT) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, row * dT + ch, o);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (due && live && ch < dT) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, row * dT + ch, o);
+      }
+    } else {
+      // stage 1: y' = (y + f(y) dt/2) + (g(y) W)/2, keeping W for stage 2
+      acc_t yp[TD], wk[TD];
+      hidden_layer(y);
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const acc_t acc = drift_tile(t);
+#pragma unroll
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const int ch = R * t + TL::quad_base(q, part);
+          float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (ch < dT) normal4<float>(key, (key.elem0 + (uint64_t)(row * dT + ch)) >> 2, cell, 0, kStreamW, z);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int r = 4 * q + s;
+            const float yy = y[t][r];
+            const float w = z[s] * sw;
+            wk[t][r] = w;
+            yp[t][r] = drift_diffusion_update<float>(yy, acc[r] + b2s[ch + s], cs[ch + s] * yy + es[ch + s], w, half_dt,
+                                                     0.5f);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // stage 2: y1 = (y + f(y') dt) + g(y') W
+      hidden_layer(yp);
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const acc_t acc = drift_tile(t);
+#pragma unroll
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const int ch = R * t + TL::quad_base(q, part);
+          Pack<float, 4> o;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int r = 4 * q + s;
+            const float yn = drift_diffusion_update<float>(y[t][r], acc[r] + b2s[ch + s],
+                                                           cs[ch + s] * yp[t][r] + es[ch + s], wk[t][r], dt, 1.0f);
+            y[t][r] = yn;
+            o.v[s] = yn;
+          }
+          if (due && live && ch < dT) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, row * dT + ch, o);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -238,19 +296,20 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
   }
 }
 
-template <int D, int H, int ACT, int R, int NW>
+template <int D, int H, int ACT, int R, int NW, bool MID>
 static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
   const size_t lds_bytes = MlpLds<R>::bytes(D, H);
   static bool configured = false;   // per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, MID>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     configured = true;
   }
   const int64_t rows_per_block = NW * R;
   const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, s, p);
+  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, MID>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, s,
+                     p);
   return hipGetLastError();
 }
 
@@ -265,8 +324,12 @@ static hipError_t launch_mlp_dh(const MlpArgs& p, hipStream_t s) {
     const char* e = getenv("TSDE_MLP_VARIANT");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4>(p, s);
-  return launch_mlp_variant<D, H, ACT, 16, 8>(p, s);
+  if (p.method == TSDE_TRAJ_MIDPOINT) {
+    if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4, true>(p, s);
+    return launch_mlp_variant<D, H, ACT, 16, 8, true>(p, s);
+  }
+  if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4, false>(p, s);
+  return launch_mlp_variant<D, H, ACT, 16, 8, false>(p, s);
 }
 
 template <int D, int H>

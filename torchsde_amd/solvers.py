@@ -291,10 +291,11 @@ class BaseSDESolver:
         if spec is None:
             return None
         if spec[0] == "mlp_diagonal":
-            # perceptron drift: sampling kernel on the matrix cores (forward only, Euler / Milstein)
+            # perceptron drift: sampling kernel on the matrix cores (forward only; Euler, Milstein, midpoint)
             code = self._trajectory_code()
             if self._tracks_grad(y0) or code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO,
-                                                      _native.TRAJ_MILSTEIN_STRAT) or bm._elem0 % 4 != 0:
+                                                      _native.TRAJ_MILSTEIN_STRAT, _native.TRAJ_MIDPOINT) \
+                    or bm._elem0 % 4 != 0:
                 return None
             return spec
         if spec[0] != "affine_diagonal":
