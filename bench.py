@@ -12,7 +12,9 @@ unsharded run would produce) and the final states are all-gathered once per solv
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: tsde_step_diag; algorithmic bytes per launch
 = 16*d bytes per trajectory-step x batch = 4 streams x B*d*4 B, over the kernel's average duration measured
 with HIP events inside the library) and `cpu_baseline` (the oracle's port of the reference's CPU algorithm,
-timed on this host's cores on a bounded sample).
+timed on this host's cores on a bounded sample). The default single-GPU run also carries `also`: two short side
+measurements taken after the timed region (the same job with the SDE in closed form, and perceptron-drift sampling
+on the matrix cores); they are not part of `value`, and `--no-also` skips them.
 """
 import argparse
 import json
@@ -177,6 +179,49 @@ def _cpu_baseline(cfg, budget_s=20.0):
                       f"oracle port of the reference CPU algorithm (tree BrownianInterval + Euler loop, torch CPU "
                       f"ops), best of thread counts {candidates} -> {best} threads"}
 
+
+
+def _side_measurements(dev):
+    """Short measurements reported under `also`: outside the headline's timed region and NOT part of `value`.
+
+    The headline job when the SDE is handed over in closed form (whole solve in one launch), and neural-SDE sampling
+    on the matrix cores. A failure here is reported in place and never takes the headline down with it.
+    """
+    also = {}
+    for name in ("c2_euler_closed_form_b65536_d64_s1000", "c5_sampling_mlp_b32768_d128_s500"):
+        try:
+            also[name] = _side_measurement(dev, WORKLOADS[name])
+        except Exception as e:
+            also[name] = {"error": f"{type(e).__name__}: {e}"}
+    return also
+
+
+def _side_measurement(dev, c):
+    import torchsde_amd
+    sde = _make_problem(c["problem"], c["d"], c["m"], dev)
+    y0 = torch.full((c["B"], c["d"]), 0.1, device=dev)
+    t1 = c["nsteps"] * c["dt"]
+    ts = torch.tensor([0.0, t1], device=dev)
+
+    def solve(i):
+        bm = torchsde_amd.BrownianInterval(t0=0.0, t1=t1, size=(c["B"], c["m"]), dtype=torch.float32, device=dev,
+                                           entropy=777 + i, dt=c["dt"], levy_area_approximation=c["levy"])
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=c["method"], dt=c["dt"])
+
+    for i in range(2):
+        solve(i)
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for i in range(5):
+        out = solve(10 + i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - start) / 5 * 1e3
+    assert torch.isfinite(out).all()
+    rec = {"ms_per_solve": ms, "trajectory_steps_per_s": c["B"] * c["nsteps"] / ms * 1e3, "kernel": c["kernel"]}
+    if c.get("mfma_flops_per_traj_step"):
+        rec["tflops_f32"] = c["mfma_flops_per_traj_step"] * c["B"] * c["nsteps"] / ms / 1e9
+    return rec
 
 def main():
     ap = argparse.ArgumentParser()
@@ -365,35 +410,7 @@ def main():
                     "launches_timed": k_launches}
     also = None
     if world == 1 and not args.no_also and args.workload == "c2_euler_diag_b65536_d64_s1000":
-        # Side measurements, outside the timed region of the headline and NOT part of `value`: the same job when the
-        # SDE is handed over in closed form (whole solve in one launch), and neural-SDE sampling on the matrix cores.
-        also = {}
-        for name in ("c2_euler_closed_form_b65536_d64_s1000", "c5_sampling_mlp_b32768_d128_s500"):
-            c = WORKLOADS[name]
-            side_sde = _make_problem(c["problem"], c["d"], c["m"], dev)
-            side_y0 = torch.full((c["B"], c["d"]), 0.1, device=dev)
-            side_ts = torch.tensor([0.0, c["nsteps"] * c["dt"]], device=dev)
-
-            def side_solve(i):
-                side_bm = torchsde_amd.BrownianInterval(t0=0.0, t1=c["nsteps"] * c["dt"], size=(c["B"], c["m"]),
-                                                        dtype=torch.float32, device=dev, entropy=777 + i, dt=c["dt"],
-                                                        levy_area_approximation=c["levy"])
-                with torch.no_grad():
-                    return torchsde_amd.sdeint(side_sde, side_y0, side_ts, bm=side_bm, method=c["method"], dt=c["dt"])
-
-            for i in range(2):
-                side_solve(i)
-            torch.cuda.synchronize()
-            t_side = time.perf_counter()
-            for i in range(5):
-                side_out = side_solve(10 + i)
-            torch.cuda.synchronize()
-            side_ms = (time.perf_counter() - t_side) / 5 * 1e3
-            assert torch.isfinite(side_out).all()
-            also[name] = {"ms_per_solve": side_ms, "trajectory_steps_per_s": c["B"] * c["nsteps"] / side_ms * 1e3,
-                          "kernel": c["kernel"]}
-            if c.get("mfma_flops_per_traj_step"):
-                also[name]["tflops_f32"] = c["mfma_flops_per_traj_step"] * c["B"] * c["nsteps"] / side_ms / 1e9
+        also = _side_measurements(dev)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
