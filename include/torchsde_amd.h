@@ -255,8 +255,8 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
 
 /* All fixed steps of a diagonal-noise SDE whose drift is a two-layer perceptron shared by the batch,
  *   f(t, y) = W2 . act(W1 . y + b1) + b2,   g(t, y) = diff_rate * y + diff_shift,
- * in ONE launch (neural-SDE sampling): a wave keeps 32 batch rows in registers for the whole solve, the weights
- * live in LDS and both layers run on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 accumulation).
+ * in ONE launch (neural-SDE sampling): a wave keeps 16 batch rows in registers for the whole solve, the weights
+ * live in LDS and both layers run on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 accumulation).
  *   w1 (d, hidden) and w2 (hidden, d) are stored input-major: w1[k][m] multiplies input channel k into unit m
  *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 (both are zero-padded
  *   to the MFMA tile sizes inside the kernel); ys, y0 16-byte aligned; dtype must be TSDE_F32;
@@ -269,6 +269,40 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
                              const void* b1, const void* w2, const void* b2, const void* diff_rate,
                              const void* diff_shift, int activation, int method, const tsde_traj_t* traj,
                              uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+
+/* Reverse sweep of the gradient of tsde_trajectory_mlp_diag with method TSDE_TRAJ_EULER: back-propagation through
+ * the solver, i.e. what loss.backward() computes when autograd records the reference's stepping loop
+ * (torchsde/_core/base_solver.py:114-134 with methods/euler.py:31-36) for this SDE. Processes steps k_hi-1 ... k_lo
+ * (call it on consecutive chunks, last steps first); with lam = dL/dy_{k+1}:
+ *     u = W2^T lam,  delta = u * act'(W1 y_k + b1) * dt_k,   dL/dy_k = lam + W1^T delta + lam * diff_rate * dW_k.
+ *   lam          (rows, d)  in: dL/dy at boundary k_hi WITHOUT the cotangent of an output at k_hi (the kernel adds
+ *                           the cotangents of outputs at boundaries k_lo+1 ... k_hi itself); out: dL/dy at k_lo,
+ *                           without the cotangent of an output at k_lo
+ *   stash_lam    (k_hi-k_lo, rows, d)       out: dt_k * dL/dy_{k+1}       (slot k - k_lo)
+ *   stash_hid    (k_hi-k_lo, rows, hidden)  out: act(W1 y_k + b1)
+ *   stash_delta  (k_hi-k_lo, rows, hidden)  out: delta_k
+ *       => dL/dW2 = sum stash_lam^T stash_hid, dL/dW1 = sum stash_delta^T y_k (tsde_gram_partials),
+ *          dL/db2 = column sums of stash_lam,   dL/db1 = column sums of stash_delta
+ *   row_rate, row_shift (rows, d)  accumulated in place: sum_k lam*y_k*dW_k and sum_k lam*dW_k per trajectory
+ *                                  (their batch sums are dL/d diff_rate, dL/d diff_shift)
+ *   ys_all       (n_steps+1, rows, d)  the state at EVERY step boundary (run the forward kernel with one output per step)
+ *   grad_ys      (n_grad, rows, d), grad_step (n_grad, ascending, device): cotangent of the output at boundary
+ *                grad_step[j]; grad_last = index of the last entry with grad_step <= k_hi, or -1
+ * d, hidden multiples of 4 up to 128; w1, w2 in the layout of tsde_trajectory_mlp_diag; all buffers 16-byte aligned. */
+int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
+                                      void* row_shift, const void* ys_all, const void* grad_ys,
+                                      const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,
+                                      int64_t hidden, const void* w1, const void* b1, const void* w2,
+                                      const void* diff_rate, int activation, const tsde_traj_t* traj, int32_t k_lo,
+                                      int32_t k_hi, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
+                                      int dtype, void* stream);
+
+/* partials[b] = sum over the b-th contiguous range of the k rows of a[row, :]^T b[row, :]   (a (k, m), b (k, n)
+ * row-major, m, n <= 128; partials (blocks, m, n)): the weight-gradient sums of the call above -- a product with a
+ * 128 x 128 result and k in the tens of millions, the shape BLAS libraries serve worst. f32 MFMA; the caller adds the
+ * partials up in a fixed order (deterministic). */
+int tsde_gram_partials(void* partials, const void* a, const void* b, int64_t k, int64_t m, int64_t n, int32_t blocks,
+                       int dtype, void* stream);
 
 /* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
 #define TSDE_KID_STEP_DIAG 1

@@ -1,0 +1,168 @@
+"""GPU parity of the gradient of the perceptron-drift trajectory kernel (``tsde_trajectory_mlp_diag_backward`` +
+``tsde_gram_partials``; run with ``-m gpu``): ``sdeint`` with autograd on, Euler, on an ``MLPDriftDiagonalSDE`` must
+return the gradients autograd gives when it records the stepwise solve of the same module on the same Brownian path
+(the reference's way: torchsde/_core/base_solver.py:114-134 + methods/euler.py:31-36 under ``loss.backward()``). The
+two differ in the summation order of the matrix products (and of the batch reductions of the parameter gradients)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _sde(d, hidden, activation, seed=0, scalar_diffusion=False):
+    import torchsde_amd
+    torch.manual_seed(seed)
+    rate = 0.05 if scalar_diffusion else 0.2 * torch.rand(d) - 0.1
+    shift = 0.2 if scalar_diffusion else 0.1 + 0.2 * torch.rand(d)
+    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, diff_rate=rate, diff_shift=shift)
+    with torch.no_grad():       # asymmetric, well-scaled weights (a transposed operand cannot pass)
+        sde.lin1.weight.copy_(torch.randn(hidden, d) / d ** 0.5)
+        sde.lin2.weight.copy_(torch.randn(d, hidden) / hidden ** 0.5)
+        sde.lin1.bias.copy_(0.3 * torch.randn(hidden))
+        sde.lin2.bias.copy_(0.3 * torch.randn(d))
+    return sde.to(DEV)
+
+
+def _gradients(sde, y0, ts, dt, entropy, trajectory, weights):
+    """Loss = sum_j <weights[j], ys[j]> over ALL outputs (so every cotangent entry point is exercised)."""
+    import torchsde_amd
+    y = y0.clone().requires_grad_(True)
+    bm = torchsde_amd.BrownianInterval(float(ts[0]), float(ts[-1]), size=tuple(y0.shape), dtype=y0.dtype, device=DEV,
+                                       entropy=entropy)
+    sde.zero_grad()
+    ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method="euler", dt=dt, options={"trajectory_kernel": trajectory})
+    (ys * weights).sum().backward()
+    named = {name: p.grad.clone() for name, p in sde.named_parameters()}
+    named["y0"] = y.grad.clone()
+    return ys.detach(), named
+
+
+def _assert_gradients_close(fast, ref, rtol=2e-3):
+    for name, g_ref in ref.items():
+        scale = g_ref.abs().max().item()
+        err = (fast[name] - g_ref).abs().max().item()
+        assert err <= rtol * scale + 1e-6, f"{name}: max error {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("activation", ["tanh", "softplus"])
+@pytest.mark.parametrize("d,hidden", [(32, 32), (64, 64), (128, 128), (32, 128), (128, 64), (64, 32),
+                                      (4, 16), (8, 100), (20, 52), (100, 8), (36, 44), (124, 120)])   # padded tiles
+def test_gradients_match_autograd_of_the_stepwise_solve(d, hidden, activation):
+    B = 300                                   # not a multiple of the 16-row wave tile or the 128-row block
+    sde = _sde(d, hidden, activation)
+    gen = torch.Generator().manual_seed(1)
+    y0 = (0.5 * torch.randn(B, d, generator=gen)).to(DEV)
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 4 * dt, 5 * dt, 16 * dt], device=DEV)
+    weights = torch.randn(4, B, d, generator=gen).to(DEV)
+    ys_fast, fast = _gradients(sde, y0, ts, dt, 3, True, weights)
+    ys_ref, ref = _gradients(sde, y0, ts, dt, 3, False, weights)
+    torch.testing.assert_close(ys_fast, ys_ref, rtol=2e-4, atol=2e-5)
+    assert set(fast) == set(ref) == {"lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "diff_rate", "diff_shift",
+                                     "y0"}
+    _assert_gradients_close(fast, ref)
+
+
+def test_chunked_sweep_and_scalar_diffusion_parameters(monkeypatch):
+    """A stash budget of a few steps forces many chunks (state, cotangent pointer and accumulators carried between
+    launches); scalar diffusion parameters receive the sum over channels."""
+    from torchsde_amd import kernels as K
+    d, hidden, B = 64, 32, 1000
+    sde = _sde(d, hidden, "softplus", scalar_diffusion=True)
+    gen = torch.Generator().manual_seed(4)
+    y0 = (0.5 * torch.randn(B, d, generator=gen)).to(DEV)
+    dt = 2.0 ** -6
+    ts = torch.tensor([0.0, 3 * dt, 7 * dt, 8 * dt, 21 * dt, 40 * dt], device=DEV)
+    weights = torch.randn(6, B, d, generator=gen).to(DEV)
+    _, whole = _gradients(sde, y0, ts, dt, 9, True, weights)
+    monkeypatch.setattr(K._MlpTrajectoryFn, "STASH_BYTES", 7 * B * (d + 2 * hidden) * 4)     # 7 steps per chunk
+    _, chunked = _gradients(sde, y0, ts, dt, 9, True, weights)
+    _, ref = _gradients(sde, y0, ts, dt, 9, False, weights)
+    assert whole["diff_rate"].shape == ref["diff_rate"].shape == ()
+    _assert_gradients_close(chunked, ref)
+    _assert_gradients_close(whole, ref)
+    # the sweep itself is chunk-invariant (same kernels, same order per row); only the weight sums regroup
+    torch.testing.assert_close(chunked["y0"], whole["y0"], rtol=0, atol=0)
+
+
+def test_long_solve_training_shape():
+    """Many steps at a latent-SDE-like shape: error growth stays at the level of the summation-order difference."""
+    d, hidden, B = 128, 128, 2048
+    sde = _sde(d, hidden, "softplus")
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    dt = 2.0 ** -9
+    ts = torch.tensor([0.0, 200 * dt], device=DEV)
+    weights = torch.ones(2, B, d, device=DEV)
+    weights[0] = 0.0
+    _, fast = _gradients(sde, y0, ts, dt, 11, True, weights)
+    _, ref = _gradients(sde, y0, ts, dt, 11, False, weights)
+    _assert_gradients_close(fast, ref, rtol=5e-3)
+
+
+@pytest.mark.parametrize("k,m,n", [(1, 4, 4), (17, 128, 128), (1000, 64, 32), (4099, 100, 7), (70000, 128, 64),
+                                   (33000, 36, 128)])
+def test_gram_matches_float64(k, m, n):
+    from torchsde_amd import kernels as K
+    gen = torch.Generator().manual_seed(k)
+    a = torch.randn(k, m, generator=gen).to(DEV)
+    b = torch.randn(k, n, generator=gen).to(DEV)
+    ref = (a.double().t() @ b.double())
+    out = K.gram(a, b)
+    assert out.shape == (m, n) and out.dtype == torch.float32
+    assert (out.double() - ref).abs().max().item() <= 1e-5 * (k ** 0.5) * 8 + 1e-5
+    assert torch.equal(out, K.gram(a, b))          # fixed summation order: bit-reproducible
+
+
+def test_falls_back_when_the_sweep_does_not_apply():
+    """Milstein / midpoint, a hidden width that is not a multiple of 4, or an extra parameter on a subclass: gradients
+    still come out (stepwise path), and agree with the Euler sweep where both apply."""
+    import torchsde_amd
+    d, B = 32, 128
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 8 * dt], device=DEV)
+
+    def run(sde, method):
+        y = torch.full((B, d), 0.2, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 8 * dt, size=(B, d), device=DEV, dtype=torch.float32, entropy=2)
+        sde.zero_grad()
+        ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method=method, dt=dt)
+        ys[-1].sum().backward()
+        return ys.grad_fn, y.grad
+
+    fn, g = run(_sde(d, 64, "tanh"), "euler")
+    assert "MlpTrajectoryFn" in type(fn).__name__ and torch.isfinite(g).all()
+    fn, g = run(_sde(d, 64, "tanh"), "milstein")
+    assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
+    fn, g = run(_sde(d, 30, "tanh"), "euler")
+    assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
+
+    class Extra(torchsde_amd.MLPDriftDiagonalSDE):
+        def __init__(self):
+            super().__init__(d, 64)
+            self.gain = torch.nn.Parameter(torch.tensor(1.0))
+
+        def f(self, t, y):
+            return self.gain * super().f(t, y)
+
+        def closed_form(self, d, dtype, device):
+            return super().closed_form(d, dtype, device) if float(self.gain.detach()) == 1.0 else None
+
+    extra = Extra().to(DEV)
+    fn, g = run(extra, "euler")
+    assert "MlpTrajectoryFn" not in type(fn).__name__ and extra.gain.grad is not None
+
+
+def test_c_abi_rejects_unsupported_arguments():
+    from torchsde_amd import _native
+    lib = _native.load()
+    x = torch.zeros(64, 64, device=DEV)
+    traj = _native.Traj()
+    ptr = x.data_ptr()
+    for d, hidden, fragment in ((6, 32, b"multiples of 4"), (32, 30, b"multiples of 4"), (132, 32, b"multiples of 4")):
+        args = (ptr,) * 9 + (-1, 64, d, hidden) + (ptr,) * 4 + (0, traj, 0, 0, 1, 0, None, 0, None)
+        assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and fragment in lib.tsde_last_error()
+    args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 4 + (0, traj, 0, 5, 1, 0, None, 0, None)
+    assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"k_hi" in lib.tsde_last_error()
+    assert lib.tsde_gram_partials(ptr, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
+    assert b"[1, 128]" in lib.tsde_last_error()

@@ -57,8 +57,9 @@ def test_stratonovich_milstein_and_long_solve():
 
 
 def test_sharding_invariance_and_fallbacks():
-    """Rows solved with `row_offset` equal the same rows of the full solve bit for bit; an output time inside a step, a
-    method without an in-kernel form, or gradients send the solve down the stepwise path."""
+    """Rows solved with `row_offset` equal the same rows of the full solve bit for bit; an output time inside a step
+    sends the solve down the stepwise path; with autograd on, gradients come out either way
+    (tests/test_gpu_mlp_backward.py)."""
     import torchsde_amd
     d, hidden, B = 32, 64, 512
     sde = _sde(d, hidden, "softplus")

@@ -22,6 +22,7 @@ TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0,
 _c_i64 = ctypes.c_int64
 _c_u64 = ctypes.c_uint64
 _c_u32 = ctypes.c_uint32
+_c_i32 = ctypes.c_int32
 _c_dbl = ctypes.c_double
 _c_ptr = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -105,6 +106,11 @@ SIGNATURES = {
     "tsde_trajectory_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_ptr, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                           _c_ptr]),
+    "tsde_trajectory_mlp_diag_backward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                   _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                   _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
+                                                   _c_ptr, _c_int, _c_ptr]),
+    "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),

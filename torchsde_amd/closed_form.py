@@ -93,6 +93,10 @@ class MLPDriftDiagonalSDE(nn.Module):
     def g(self, t, y):
         return self.diff_rate * y + self.diff_shift
 
+    def closed_form_parameters(self):
+        """The six parameters the differentiable trajectory path returns gradients for."""
+        return (self.lin1.weight, self.lin1.bias, self.lin2.weight, self.lin2.bias, self.diff_rate, self.diff_shift)
+
     def closed_form(self, d, dtype, device):
         """("mlp_diagonal", W1 (d, hidden) input-major, b1, W2 (hidden, d), b2, diff_rate (d,), diff_shift (d,), act) for
         the sampling kernel, or None when it does not apply (then the stepwise path runs)."""

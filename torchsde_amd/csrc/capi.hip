@@ -396,6 +396,47 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
               where);
 }
 
+int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
+                                      void* row_shift, const void* ys_all, const void* grad_ys,
+                                      const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,
+                                      int64_t hidden, const void* w1, const void* b1, const void* w2,
+                                      const void* diff_rate, int activation, const tsde_traj_t* traj, int32_t k_lo,
+                                      int32_t k_hi, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
+                                      int dtype, void* stream) {
+  const char* where = "tsde_trajectory_mlp_diag_backward";
+  if (!lam || !stash_lam || !stash_hid || !stash_delta || !row_rate || !row_shift || !ys_all || !w1 || !b1 || !w2 ||
+      !diff_rate || !traj)
+    return bad_arg(where, "null argument");
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (rows < 0) return bad_arg(where, "need rows >= 0");
+  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 4 || hidden > 128 || hidden % 4 != 0)
+    return bad_arg(where, "need d and hidden multiples of 4 in [4, 128]");
+  const void* aligned[] = {lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift, ys_all, grad_ys};
+  for (const void* q : aligned)
+    if (reinterpret_cast<uintptr_t>(q) & 15u) return bad_arg(where, "state-shaped buffers must be 16-byte aligned");
+  if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
+  if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
+  if (k_lo < 0 || k_hi < k_lo || k_hi > traj->n_steps) return bad_arg(where, "need 0 <= k_lo <= k_hi <= n_steps");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (grad_last >= 0 && (!grad_ys || !grad_step)) return bad_arg(where, "grad_last >= 0 without cotangents");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  return fail(tsde::launch_trajectory_mlp_diag_backward(lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift,
+                                                        ys_all, grad_ys, grad_step, grad_last, rows, d, hidden, w1, b1,
+                                                        w2, diff_rate, activation, traj, k_lo, k_hi,
+                                                        make_key(entropy, elem0), entropy_dev, s),
+              where);
+}
+
+int tsde_gram_partials(void* partials, const void* a, const void* b, int64_t k, int64_t m, int64_t n, int32_t blocks,
+                       int dtype, void* stream) {
+  const char* where = "tsde_gram_partials";
+  if (!partials || !a || !b) return bad_arg(where, "null argument");
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (k < 1 || m < 1 || m > 128 || n < 1 || n > 128 || blocks < 1) return bad_arg(where, "need k, blocks >= 1 and m, n in [1, 128]");
+  return fail(tsde::launch_gram_partials(partials, a, b, k, m, n, blocks, (hipStream_t)stream), where);
+}
+
 int tsde_prof_begin(int kid, int capacity) {
   if (capacity <= 0) return bad_arg("tsde_prof_begin", "capacity must be positive");
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);

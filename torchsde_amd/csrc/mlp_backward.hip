@@ -1,0 +1,381 @@
+// Gradient of the perceptron-drift trajectory kernel (mlp_trajectory.hip), Euler-Maruyama: back-propagation through
+// the solver, the gradient `loss.backward()` yields when autograd records torchsde's stepping loop
+// (base_solver.py:114-134 with euler.py:31-36) -- as two kernels instead of a tape of ~20 torch ops per step.
+//
+//   step k (forward):   z = W1 y_k + b1,  h = act(z),  f = W2 h + b2,  g = c*y_k + e,
+//                       y_{k+1} = y_k + f dt_k + g dW_k
+//   step k (reverse):   lam = dL/dy_{k+1}
+//                       u     = W2^T lam                 delta = u * act'(z) * dt_k
+//                       dL/dy_k = lam + W1^T delta + lam * c * dW_k
+//                       dL/dW2 += (dt_k lam) h^T         dL/dW1 += delta y_k^T
+//                       dL/db2 += dt_k lam               dL/db1 += delta
+//                       dL/dc  += lam * y_k * dW_k       dL/de  += lam * dW_k
+//
+// 1. mlp_backward_kernel -- the reverse sweep. A wave owns 16 batch rows for all steps; lam stays in registers in the
+//    MFMA accumulator layout (the layout of the sampling kernel: it is the B operand of the next product as it
+//    stands); the three products per step run on v_mfma_f32_16x16x4_f32 against the SAME two LDS weight arrays the
+//    sampling kernel uses -- layer 1 reads W1 as stored, the two transposed products read 16-byte rows (four
+//    consecutive K per lane, one ds_read_b128 feeding four MFMAs; conflict-free with the +4 row padding). The states
+//    y_k come from the forward launch (which wrote every step: 288 GB of HBM is what pays for this), dW_k is
+//    regenerated from the counter RNG, and the per-step factors of the weight gradients (dt lam, h, delta) are
+//    stashed in HBM for:
+// 2. gram_kernel -- C += A^T B over a very tall K (K = steps x batch rows, M, N <= 128): the weight-gradient sums.
+//    Each block owns a contiguous K range and accumulates the whole M x N result in MFMA accumulators across its 8
+//    waves, reading both operands straight from HBM in MFMA operand layout; per-block partials are written out and
+//    summed in a fixed order by the caller (deterministic, unlike atomics).
+#include "tsde_common.h"
+#include "tsde_launch.h"
+#include "tsde_mlp.h"
+
+namespace tsde {
+
+struct MlpBackArgs {
+  float* lam;               // (B, d)  in: dL/dy at boundary k_hi (before that boundary's own cotangent); out: at k_lo
+  float* stash_lam;         // (k_hi - k_lo, B, d)   dt_k * dL/dy_{k+1}
+  float* stash_hid;         // (k_hi - k_lo, B, h)   act(W1 y_k + b1)
+  float* stash_delta;       // (k_hi - k_lo, B, h)   delta_k
+  float* row_rate;          // (B, d)  += sum_k lam * y_k * dW_k   (per trajectory; the caller sums over the batch)
+  float* row_shift;         // (B, d)  += sum_k lam * dW_k
+  const float* ys_all;      // (n_steps + 1, B, d) states at every step boundary
+  const float* grad_ys;     // (n_grad, B, d) cotangents of the outputs
+  const int32_t* grad_step; // (n_grad) ascending boundary index of each output
+  int32_t grad_last;        // index of the last output at a boundary <= k_hi (-1: none)
+  const float* W1;          // (d, h) as in MlpArgs
+  const float* b1;          // (h)
+  const float* W2;          // (h, d)
+  const float* c;           // (d)
+  const float* rows;        // (n_steps, 8)
+  const uint32_t* cells;
+  int64_t B;
+  int32_t d, h;
+  int32_t k_lo, k_hi;
+  NoiseKey key;
+  const uint64_t* key_dev;
+};
+
+// FULL: d == D and h == H (no channel padding inside the kernel), which removes every per-tile bounds test.
+template <int D, int H, int ACT, int NW, bool FULL>
+__global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs p) {
+  constexpr int R = 16;
+  using TL = Tile<R>;
+  constexpr int TD = D / R, TH = H / R, kThreads = NW * 64;
+  constexpr int S1 = H + MlpLds<R>::kPad, S2 = D + MlpLds<R>::kPad;
+  extern __shared__ float lds[];
+  float* W1s = lds;                 // D rows of S1: W1s[channel][hidden]
+  float* W2s = W1s + D * S1;        // H rows of S2: W2s[hidden][channel]
+  float* b1s = W2s + H * S2;        // H
+  float* cs = b1s + H;              // D
+  const int dT = p.d, hT = p.h;
+  for (int i = threadIdx.x; i < D * H; i += kThreads) {
+    const int k1 = i / H, m1 = i % H, k2 = i / D, m2 = i % D;
+    W1s[k1 * S1 + m1] = (k1 < dT && m1 < hT) ? p.W1[k1 * hT + m1] : 0.0f;
+    W2s[k2 * S2 + m2] = (k2 < hT && m2 < dT) ? p.W2[k2 * dT + m2] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < H; i += kThreads) b1s[i] = i < hT ? p.b1[i] : 0.0f;
+  for (int i = threadIdx.x; i < D; i += kThreads) cs[i] = i < dT ? p.c[i] : 0.0f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane / R, n = lane % R;
+  // A wave with no batch row left is done; in the last partial wave the surplus lanes shadow the last row: they read
+  // what its lane reads, draw the same noise, and (re)write the same values to the same addresses -- no lane masks.
+  const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * R;
+  if (row0 >= p.B) return;
+  const int64_t row = row0 + n < p.B ? row0 + n : p.B - 1;
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+
+  // register r of tile t in this lane = channel 16 t + 4 part + r of batch row `row` (one 16-byte quad per tile).
+  // Addresses are a wave-uniform base (SGPRs) + ONE 32-bit lane offset per row width + a constant per tile, so that
+  // no per-tile 64-bit address lives in vector registers across the sweep (the caller keeps rows * width < 2^30).
+  const uint32_t off_d = (uint32_t)(row * dT) + 4 * part, off_h = (uint32_t)(row * hT) + 4 * part;
+  const uint64_t quad0 = (key.elem0 + (uint64_t)(row * dT) + 4 * part) >> 2;   // RNG quad of tile 0; tile t: + 4 t
+  auto real_d = [&](int t) { return FULL || R * t + 4 * part < dT; };
+  auto real_h = [&](int th) { return FULL || R * th + 4 * part < hT; };
+  auto load_tile = [&](const float* base, int t) {
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (real_d(t)) v = *reinterpret_cast<const f32x4*>(base + off_d + R * t);
+    return v;
+  };
+  auto store_tile = [&](float* base, int t, const f32x4& v) {
+    if (real_d(t)) *reinterpret_cast<f32x4*>(base + off_d + R * t) = v;
+  };
+  auto store_hidden = [&](float* base, int th, const f32x4& v) {
+    if (real_h(th)) *reinterpret_cast<f32x4*>(base + off_h + R * th) = v;
+  };
+
+  f32x4 lam[TD], acc_rate[TD], acc_shift[TD];
+#pragma unroll
+  for (int t = 0; t < TD; ++t) {
+    lam[t] = load_tile(p.lam, t);
+    acc_rate[t] = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc_shift[t] = {0.0f, 0.0f, 0.0f, 0.0f};
+  }
+
+  int jg = p.grad_last;
+  for (int k = p.k_hi - 1; k >= p.k_lo; --k) {
+    const float* srow = p.rows + (int64_t)k * 8;
+    const float dt = srow[0], sw = srow[4];
+    const uint32_t cell = p.cells[k];
+    const int64_t slot = k - p.k_lo;
+    const bool arrives = jg >= 0 && p.grad_step[jg] == k + 1;     // an output sits on boundary k + 1
+
+    f32x4 y[TD];
+#pragma unroll
+    for (int t = 0; t < TD; ++t) {
+      if (arrives) lam[t] += load_tile(p.grad_ys + (int64_t)jg * p.B * dT, t);
+      y[t] = load_tile(p.ys_all + (int64_t)k * p.B * dT, t);
+      store_tile(p.stash_lam + slot * p.B * dT, t, lam[t] * dt);
+    }
+    if (arrives) --jg;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- hidden layer: z^T = W1^T y^T; keep act'(z), stash act(z) ---------------------------------------------------
+    f32x4 hid[TH];
+#pragma unroll
+    for (int th = 0; th < TH; ++th) {
+      f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z = TL::mfma(W1s[(R * t + 4 * part + r) * S1 + R * th + n], y[t][r], z);
+        if ((t + 1) % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4 value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v, slope;
+        activate_with_slope<ACT>(z[r] + b1s[R * th + 4 * part + r], v, slope);
+        value[r] = v;
+        hid[th][r] = slope;
+      }
+      store_hidden(p.stash_hid + slot * p.B * hT, th, value);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- u^T = W2 lam^T (rows of W2s, four consecutive channels per lane); delta = u * act'(z) * dt ----------------
+#pragma unroll
+    for (int th = 0; th < TH; ++th) {
+      f32x4 u = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&W2s[(R * th + n) * S2 + R * t + 4 * part]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u = TL::mfma(a[r], lam[t][r], u);
+        if ((t + 1) % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      hid[th] = (u * hid[th]) * dt;
+      store_hidden(p.stash_delta + slot * p.B * hT, th, hid[th]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- diffusion: dW_k again from the counter RNG; lam <- lam + lam c dW ------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TD; ++t) {
+      const int ch = R * t + 4 * part;
+      float zn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      // (opaque to the optimiser: otherwise the step-invariant first Philox round of every tile is hoisted out of the
+      //  sweep and pinned in ~4 registers per tile)
+      uint64_t quad = quad0 + 4 * t;
+      asm volatile("" : "+v"(quad));
+      if (real_d(t)) normal4<float>(key, quad, cell, 0, kStreamW, zn);
+      // y_k once more (from L2): keeping the tiles of the first load alive across the two products above costs more
+      // registers than the kernel has
+      const f32x4 yt = load_tile(p.ys_all + (int64_t)k * p.B * dT, t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float lw = lam[t][r] * (zn[r] * sw);
+        acc_shift[t][r] += lw;
+        acc_rate[t][r] += lw * yt[r];
+        lam[t][r] += lw * cs[ch + r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- lam^T += W1 delta^T (rows of W1s, four consecutive hidden units per lane) ------------------------------------
+#pragma unroll
+    for (int t = 0; t < TD; ++t) {
+      f32x4 back = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int th = 0; th < TH; ++th) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&W1s[(R * t + n) * S1 + R * th + 4 * part]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) back = TL::mfma(a[r], hid[th][r], back);
+        if ((th + 1) % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      lam[t] += back;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < TD; ++t) {
+    store_tile(p.lam, t, lam[t]);
+    store_tile(p.row_rate, t, load_tile(p.row_rate, t) + acc_rate[t]);
+    store_tile(p.row_shift, t, load_tile(p.row_shift, t) + acc_shift[t]);
+  }
+}
+
+template <int D, int H, int ACT, int NW, bool FULL>
+static hipError_t launch_back_variant(const MlpBackArgs& p, hipStream_t s) {
+  constexpr int R = 16;
+  const size_t lds_bytes = (size_t)(D * (H + MlpLds<R>::kPad) + H * (D + MlpLds<R>::kPad) + H + D) * sizeof(float);
+  static bool configured = false;   // per instantiation
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_kernel<D, H, ACT, NW, FULL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  const int64_t rows_per_block = NW * R;
+  const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((mlp_backward_kernel<D, H, ACT, NW, FULL>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, s, p);
+  return hipGetLastError();
+}
+
+// 8-wave blocks (two waves per SIMD, 256 registers each) everywhere except the padded 128-channel case, whose bounds
+// tests push the sweep past 256 registers: 4-wave blocks there (one wave per SIMD, 512 registers) instead of spilling.
+template <int D, int H, int ACT>
+static hipError_t launch_back_shape(const MlpBackArgs& p, hipStream_t s) {
+  if (p.d == D && p.h == H) return launch_back_variant<D, H, ACT, 8, true>(p, s);
+  if constexpr (D == 128) return launch_back_variant<D, H, ACT, 4, false>(p, s);
+  else return launch_back_variant<D, H, ACT, 8, false>(p, s);
+}
+
+template <int D, int H>
+static hipError_t launch_back_act(const MlpBackArgs& p, int act, hipStream_t s) {
+  if (act == TSDE_ACT_TANH) return launch_back_shape<D, H, TSDE_ACT_TANH>(p, s);
+  if (act == TSDE_ACT_SOFTPLUS) return launch_back_shape<D, H, TSDE_ACT_SOFTPLUS>(p, s);
+  return hipErrorInvalidValue;
+}
+
+template <int D>
+static hipError_t launch_back_h(const MlpBackArgs& p, int act, hipStream_t s) {
+  if (p.h <= 32) return launch_back_act<D, 32>(p, act, s);
+  if (p.h <= 64) return launch_back_act<D, 64>(p, act, s);
+  if (p.h <= 128) return launch_back_act<D, 128>(p, act, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta,
+                                               void* row_rate, void* row_shift, const void* ys_all,
+                                               const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
+                                               int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
+                                               const void* W2, const void* c, int act, const tsde_traj_t* tr,
+                                               int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
+                                               hipStream_t s) {
+  MlpBackArgs p;
+  p.lam = (float*)lam;
+  p.stash_lam = (float*)stash_lam;
+  p.stash_hid = (float*)stash_hid;
+  p.stash_delta = (float*)stash_delta;
+  p.row_rate = (float*)row_rate;
+  p.row_shift = (float*)row_shift;
+  p.ys_all = (const float*)ys_all;
+  p.grad_ys = (const float*)grad_ys;
+  p.grad_step = grad_step;
+  p.grad_last = grad_last;
+  p.W1 = (const float*)W1;
+  p.b1 = (const float*)b1;
+  p.W2 = (const float*)W2;
+  p.c = (const float*)c;
+  p.rows = (const float*)tr->step_rows;
+  p.cells = tr->cells;
+  p.B = rows;
+  p.d = (int32_t)d;
+  p.h = (int32_t)h;
+  p.k_lo = k_lo;
+  p.k_hi = k_hi;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (rows <= 0 || k_hi <= k_lo) return hipSuccess;
+  if (d <= 32) return launch_back_h<32>(p, act, s);
+  if (d <= 64) return launch_back_h<64>(p, act, s);
+  if (d <= 128) return launch_back_h<128>(p, act, s);
+  return hipErrorInvalidValue;
+}
+
+// ---- C = A^T B over a tall K ----------------------------------------------------------------------------------------
+// Waves are arranged 4 (along M) x 2 (along N); a wave holds MT x NT accumulator tiles of 16 x 16.
+//   A operand of v_mfma_f32_16x16x4_f32: lane l supplies A^T[i = l % 16][k = l / 16] = A[k0 + l / 16][16 ti + l % 16]
+//   B operand:                           lane l supplies B[k = l / 16][j = l % 16]   = B[k0 + l / 16][16 tj + l % 16]
+// i.e. both are 64-byte row segments of four consecutive K rows: coalesced as they lie in HBM.
+template <int MT, int NT>
+__global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials, const float* __restrict__ A,
+                                                   const float* __restrict__ Bm, int64_t K, int32_t M, int32_t N,
+                                                   int64_t rows_per_block) {
+  using TL = Tile<16>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane >> 4, n = lane & 15;
+  const int wm = wave & 3, wn = wave >> 2;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = {0.0f, 0.0f, 0.0f, 0.0f};
+  int col_a[MT], col_b[NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) col_a[a] = 16 * (wm * MT + a) + n;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) col_b[b] = 16 * (wn * NT + b) + n;
+
+  const int64_t k0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t k1 = k0 + rows_per_block < K ? k0 + rows_per_block : K;
+  // 16 rows of K per trip: all loads of the trip are issued before its MFMAs (rows_per_block is a multiple of 16; the
+  // `krow < k1` guard only bites in the last block)
+  for (int64_t kk = k0; kk < k1; kk += 16) {
+    float fa[4][MT], fb[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t krow = kk + 4 * g + part;
+      const bool ok = krow < k1;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) fa[g][a] = (ok && col_a[a] < M) ? A[krow * M + col_a[a]] : 0.0f;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) fb[g][b] = (ok && col_b[b] < N) ? Bm[krow * N + col_b[b]] : 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = TL::mfma(fa[g][a], fb[g][b], acc[a][b]);
+  }
+
+  float* out = partials + (int64_t)blockIdx.x * M * N;
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * (wm * MT + a) + 4 * part + r, j = col_b[b];
+        if (i < M && j < N) out[(int64_t)i * N + j] = acc[a][b][r];
+      }
+}
+
+template <int MT>
+static hipError_t launch_gram_n(float* partials, const float* A, const float* Bm, int64_t K, int32_t M, int32_t N,
+                                int32_t blocks, int64_t rows_per_block, hipStream_t s) {
+  if (N <= 32) hipLaunchKernelGGL((gram_kernel<MT, 1>), dim3(blocks), dim3(512), 0, s, partials, A, Bm, K, M, N, rows_per_block);
+  else if (N <= 64) hipLaunchKernelGGL((gram_kernel<MT, 2>), dim3(blocks), dim3(512), 0, s, partials, A, Bm, K, M, N, rows_per_block);
+  else if (N <= 128) hipLaunchKernelGGL((gram_kernel<MT, 4>), dim3(blocks), dim3(512), 0, s, partials, A, Bm, K, M, N, rows_per_block);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_gram_partials(void* partials, const void* A, const void* Bm, int64_t K, int64_t M, int64_t N,
+                                int32_t blocks, hipStream_t s) {
+  if (K <= 0 || M <= 0 || N <= 0 || blocks <= 0) return hipErrorInvalidValue;
+  int64_t rows_per_block = (K + blocks - 1) / blocks;
+  rows_per_block = (rows_per_block + 15) / 16 * 16;       // whole groups of the unrolled K loop
+  if (M <= 64) return launch_gram_n<1>((float*)partials, (const float*)A, (const float*)Bm, K, (int32_t)M, (int32_t)N, blocks, rows_per_block, s);
+  if (M <= 128) return launch_gram_n<2>((float*)partials, (const float*)A, (const float*)Bm, K, (int32_t)M, (int32_t)N, blocks, rows_per_block, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace tsde

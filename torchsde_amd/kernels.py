@@ -594,6 +594,108 @@ def trajectory_affine_diag_differentiable(y0, params, method, schedule, bm):
     return _TrajectoryFn.apply(method, schedule, bm, y0, *params)
 
 
+def gram(a, b, blocks=512):
+    """a^T b for tall a (k, m), b (k, n) with m, n <= 128 (``tsde_gram_partials`` + a fixed-order sum of its partials):
+    the weight-gradient reduction of the perceptron-drift backward sweep."""
+    _native.require_device(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("gram takes contiguous float32 matrices")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.shape[1] > 128 or b.shape[1] > 128:
+        raise ValueError("gram takes a (k, m) and b (k, n) with m, n <= 128")
+    k, m, n = a.shape[0], a.shape[1], b.shape[1]
+    blocks = int(max(1, min(blocks, (k + 63) // 64)))
+    partials = torch.empty((blocks, m, n), dtype=torch.float32, device=a.device)
+    lib, dt_code, stream = _launch_env(a)
+    _native.check(lib.tsde_gram_partials(partials.data_ptr(), a.data_ptr(), b.data_ptr(), k, m, n, blocks, dt_code,
+                                         stream), "tsde_gram_partials")
+    return partials.sum(dim=0)
+
+
+class _MlpTrajectoryFn(torch.autograd.Function):
+    """Differentiable whole-trajectory Euler solve of a perceptron-drift diagonal SDE. Forward: the sampling kernel,
+    writing the state at EVERY step (HBM is plentiful on this part; the reverse sweep needs them). Backward: the
+    reverse sweep kernel over chunks of steps (last first), each followed by the two weight-gradient products over that
+    chunk's stash -- the gradient back-propagation through the stepwise solver gives, without an autograd tape."""
+
+    # per-chunk stash budget of the reverse sweep (three (steps, rows, width) float32 arrays)
+    STASH_BYTES = 3 << 30
+
+    @staticmethod
+    def forward(ctx, activation, method, schedule_all, out_steps, bm, y0, w1, b1, w2, b2, rate, shift):
+        rows, d = y0.shape
+        hidden = b1.numel()
+        y0c = _native.contiguous(y0.detach())
+        coefs = [p.detach().reshape(-1).expand(d).contiguous() for p in (rate, shift)]
+        w1_in = w1.detach().t().contiguous()                # (d, hidden): input-major, as the kernels read it
+        w2_in = w2.detach().t().contiguous()                # (hidden, d)
+        b1c, b2c = b1.detach().contiguous(), b2.detach().contiguous()
+        ys_all = torch.empty((schedule_all.n_steps + 1, rows, d), dtype=y0.dtype, device=y0.device)
+        ys_all[0].copy_(y0c)
+        trajectory_mlp_diag(ys_all[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, method,
+                            schedule_all, bm)
+        ctx.save_for_backward(ys_all, w1_in, b1c, w2_in, coefs[0])
+        ctx.activation, ctx.schedule, ctx.bm, ctx.out_steps, ctx.hidden = activation, schedule_all, bm, out_steps, hidden
+        ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
+        ctx.key = (bm._key, bm._elem0, bm._entropy_dev)
+        index = torch.as_tensor([0] + list(out_steps), device=y0.device)
+        return ys_all.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, gys):
+        ys_all, w1_in, b1c, w2_in, rate = ctx.saved_tensors
+        n_steps, rows, d = ys_all.shape[0] - 1, ys_all.shape[1], ys_all.shape[2]
+        hidden, schedule = ctx.hidden, ctx.schedule
+        dev = ys_all.device
+        gys = _native.contiguous(gys)
+        boundaries = np.asarray([0] + list(ctx.out_steps), dtype=np.int32)
+        grad_step = torch.from_numpy(boundaries).to(dev)
+        per_step = rows * (d + 2 * hidden) * 4
+        chunk = int(max(1, min(n_steps, _MlpTrajectoryFn.STASH_BYTES // max(per_step, 1))))
+        stash_lam = torch.empty((chunk, rows, d), dtype=torch.float32, device=dev)
+        stash_hid = torch.empty((chunk, rows, hidden), dtype=torch.float32, device=dev)
+        stash_delta = torch.empty((chunk, rows, hidden), dtype=torch.float32, device=dev)
+        lam = torch.zeros((rows, d), dtype=torch.float32, device=dev)
+        row_rate, row_shift = torch.zeros_like(lam), torch.zeros_like(lam)
+        g_w1 = torch.zeros((hidden, d), dtype=torch.float32, device=dev)
+        g_w2 = torch.zeros((d, hidden), dtype=torch.float32, device=dev)
+        g_b1 = torch.zeros(hidden, dtype=torch.float32, device=dev)
+        g_b2 = torch.zeros(d, dtype=torch.float32, device=dev)
+        lib, dt_code, stream = _launch_env(ys_all)
+        key, elem0, entropy_dev = ctx.key
+        for k_hi in range(n_steps, 0, -chunk):
+            k_lo = max(0, k_hi - chunk)
+            n = k_hi - k_lo
+            grad_last = int(np.searchsorted(boundaries, k_hi, side="right")) - 1
+            code = lib.tsde_trajectory_mlp_diag_backward(
+                lam.data_ptr(), stash_lam.data_ptr(), stash_hid.data_ptr(), stash_delta.data_ptr(), row_rate.data_ptr(),
+                row_shift.data_ptr(), ys_all.data_ptr(), gys.data_ptr(), grad_step.data_ptr(), grad_last, rows, d,
+                hidden, w1_in.data_ptr(), b1c.data_ptr(), w2_in.data_ptr(), rate.data_ptr(), int(ctx.activation),
+                schedule.struct(), k_lo, k_hi, key, elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
+                dt_code, stream)
+            _native.check(code, "tsde_trajectory_mlp_diag_backward")
+            flat_lam = stash_lam[:n].reshape(n * rows, d)
+            flat_hid = stash_hid[:n].reshape(n * rows, hidden)
+            flat_delta = stash_delta[:n].reshape(n * rows, hidden)
+            g_w2 += gram(flat_lam, flat_hid)
+            g_w1 += gram(flat_delta, ys_all[k_lo:k_hi].reshape(n * rows, d))
+            g_b2 += flat_lam.sum(dim=0)
+            g_b1 += flat_delta.sum(dim=0)
+        grad_y0 = lam + gys[0] if ctx.needs_input_grad[5] else None
+        diffusion = []
+        for acc, shape in zip((row_rate, row_shift), ctx.param_shapes):
+            per_channel = acc.sum(dim=0)
+            diffusion.append(per_channel.reshape(shape) if int(np.prod(shape, dtype=np.int64)) == d and len(shape) == 1
+                             else per_channel.sum().reshape(shape))
+        return (None, None, None, None, None, grad_y0, g_w1, g_b1, g_w2, g_b2, diffusion[0], diffusion[1])
+
+
+def trajectory_mlp_diag_differentiable(y0, module_params, activation, method, schedule_all, out_steps, bm):
+    """ys (len(out_steps) + 1, rows, d) with a grad_fn towards y0 and the six parameters
+    (lin1.weight, lin1.bias, lin2.weight, lin2.bias, diff_rate, diff_shift)."""
+    return _MlpTrajectoryFn.apply(activation, method, schedule_all, tuple(int(k) for k in out_steps), bm, y0,
+                                  *module_params)
+
+
 # ---- in-library event timing (bench.py's roofline) ----------------------------------------------------------
 def prof_begin(kid, capacity):
     _native.check(_native.load().tsde_prof_begin(kid, capacity), "tsde_prof_begin")

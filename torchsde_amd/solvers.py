@@ -275,7 +275,8 @@ class BaseSDESolver:
         """What `_integrate_trajectory` needs if the whole solve can run as ONE launch of a trajectory kernel, else
         None: a closed-form SDE handed to `sdeint` as is (closed_form.py) and this package's BrownianInterval
         generating the increments. Affine SDEs: the coefficient tensors, or ("differentiable", parameters...) when
-        autograd is on (sensitivity kernel); perceptron drift: the ("mlp_diagonal", ...) spec, forward only.
+        autograd is on (sensitivity kernel); perceptron drift: the ("mlp_diagonal", ...) spec, or
+        ("mlp_differentiable", activation, parameters...) when autograd is on (Euler: reverse-sweep kernel).
         `options={"trajectory_kernel": False}` keeps the stepwise path."""
         from .sde import ForwardSDE
         if not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful:
@@ -293,10 +294,18 @@ class BaseSDESolver:
         if spec[0] == "mlp_diagonal":
             # perceptron drift: sampling kernel on the matrix cores (forward only; Euler, Milstein, midpoint)
             code = self._trajectory_code()
-            if self._tracks_grad(y0) or code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO,
-                                                      _native.TRAJ_MILSTEIN_STRAT, _native.TRAJ_MIDPOINT) \
-                    or bm._elem0 % 4 != 0:
+            if code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT,
+                            _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0:
                 return None
+            if self._tracks_grad(y0):
+                # training: Euler only, through the reverse-sweep kernel; gradients reach y0 and the module's own six
+                # parameters, so a subclass with more of them (or shapes the sweep does not take) goes stepwise
+                own = list(base.closed_form_parameters())
+                hidden = own[1].numel()
+                if (code != _native.TRAJ_EULER or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30
+                        or {id(p) for p in base.parameters()} != {id(p) for p in own}):
+                    return None
+                return ("mlp_differentiable", spec[-1]) + tuple(own)
             return spec
         if spec[0] != "affine_diagonal":
             return None
@@ -344,6 +353,14 @@ class BaseSDESolver:
             ys[0].copy_(y0c)
             K.trajectory_mlp_diag(ys[1:], y0c, *coefficients[1:], self._trajectory_code(), schedule, bm)
             return ys
+        if coefficients[0] == "mlp_differentiable":
+            if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
+                return None
+            every_step = list(range(1, grid.n_steps + 1))
+            schedule_all = K.TrajectorySchedule(rows, cells, every_step, [(0.0, 1.0)] * grid.n_steps, y0.device,
+                                                y0.dtype)
+            return K.trajectory_mlp_diag_differentiable(y0, coefficients[2:], coefficients[1], self._trajectory_code(),
+                                                        schedule_all, out_step, bm)
         if coefficients[0] == "differentiable":
             return K.trajectory_affine_diag_differentiable(y0, coefficients[1:], self._trajectory_code(), schedule, bm)
         y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
