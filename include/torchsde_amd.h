@@ -297,12 +297,13 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
                                       int32_t k_hi, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
                                       int dtype, void* stream);
 
-/* partials[b] = sum over the b-th contiguous range of the k rows of a[row, :]^T b[row, :]   (a (k, m), b (k, n)
- * row-major, m, n <= 128; partials (blocks, m, n)): the weight-gradient sums of the call above -- a product with a
- * 128 x 128 result and k in the tens of millions, the shape BLAS libraries serve worst. f32 MFMA; the caller adds the
- * partials up in a fixed order (deterministic). */
-int tsde_gram_partials(void* partials, const void* a, const void* b, int64_t k, int64_t m, int64_t n, int32_t blocks,
-                       int dtype, void* stream);
+/* partials[i] = sum over the i-th contiguous range of the k rows of a[row, :]^T b[row, :]   (a (k, m), b (k, n)
+ * row-major, m, n <= 128; partials (blocks, m, n)) and, if colsum_partials (blocks, m) is not NULL, the column sums of
+ * a over the same range: the weight- and bias-gradient sums of the call above -- a product with a 128 x 128 result
+ * and k in the tens of millions, the shape BLAS libraries serve worst. f32 MFMA; the caller adds the partials up in a
+ * fixed order (deterministic). */
+int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, const void* b, int64_t k, int64_t m,
+                       int64_t n, int32_t blocks, int dtype, void* stream);
 
 /* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
 #define TSDE_KID_STEP_DIAG 1

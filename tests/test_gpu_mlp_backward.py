@@ -108,10 +108,17 @@ def test_gram_matches_float64(k, m, n):
     a = torch.randn(k, m, generator=gen).to(DEV)
     b = torch.randn(k, n, generator=gen).to(DEV)
     ref = (a.double().t() @ b.double())
-    out = K.gram(a, b)
-    assert out.shape == (m, n) and out.dtype == torch.float32
+    out, sums = K.gram(a, b, column_sums=True)
+    assert out.shape == (m, n) and out.dtype == torch.float32 and sums.shape == (m,)
     assert (out.double() - ref).abs().max().item() <= 1e-5 * (k ** 0.5) * 8 + 1e-5
+    assert (sums.double() - a.double().sum(0)).abs().max().item() <= 1e-5 * (k ** 0.5) * 8 + 1e-5
     assert torch.equal(out, K.gram(a, b))          # fixed summation order: bit-reproducible
+    # unaligned operands (a row offset of one float) take the scalar loader
+    if k > 4 and m % 4 == 0:
+        a1, b1 = a.reshape(-1)[1:1 + (k - 1) * m].reshape(k - 1, m), b[1:].contiguous()
+        assert a1.data_ptr() % 16 != 0 and a1.is_contiguous()
+        shifted = K.gram(a1, b1)
+        assert (shifted.double() - a1.double().t() @ b1.double()).abs().max().item() <= 1e-5 * (k ** 0.5) * 8 + 1e-5
 
 
 def test_falls_back_when_the_sweep_does_not_apply():
@@ -164,5 +171,5 @@ def test_c_abi_rejects_unsupported_arguments():
         assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and fragment in lib.tsde_last_error()
     args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 4 + (0, traj, 0, 5, 1, 0, None, 0, None)
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"k_hi" in lib.tsde_last_error()
-    assert lib.tsde_gram_partials(ptr, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
+    assert lib.tsde_gram_partials(ptr, None, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
     assert b"[1, 128]" in lib.tsde_last_error()

@@ -428,13 +428,13 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
               where);
 }
 
-int tsde_gram_partials(void* partials, const void* a, const void* b, int64_t k, int64_t m, int64_t n, int32_t blocks,
-                       int dtype, void* stream) {
+int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, const void* b, int64_t k, int64_t m,
+                       int64_t n, int32_t blocks, int dtype, void* stream) {
   const char* where = "tsde_gram_partials";
   if (!partials || !a || !b) return bad_arg(where, "null argument");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (k < 1 || m < 1 || m > 128 || n < 1 || n > 128 || blocks < 1) return bad_arg(where, "need k, blocks >= 1 and m, n in [1, 128]");
-  return fail(tsde::launch_gram_partials(partials, a, b, k, m, n, blocks, (hipStream_t)stream), where);
+  return fail(tsde::launch_gram_partials(partials, colsum_partials, a, b, k, m, n, blocks, (hipStream_t)stream), where);
 }
 
 int tsde_prof_begin(int kid, int capacity) {

@@ -19,10 +19,10 @@
 //    y_k come from the forward launch (which wrote every step: 288 GB of HBM is what pays for this), dW_k is
 //    regenerated from the counter RNG, and the per-step factors of the weight gradients (dt lam, h, delta) are
 //    stashed in HBM for:
-// 2. gram_kernel -- C += A^T B over a very tall K (K = steps x batch rows, M, N <= 128): the weight-gradient sums.
-//    Each block owns a contiguous K range and accumulates the whole M x N result in MFMA accumulators across its 8
-//    waves, reading both operands straight from HBM in MFMA operand layout; per-block partials are written out and
-//    summed in a fixed order by the caller (deterministic, unlike atomics).
+// 2. gram_kernel -- C = A^T B and the column sums of A over a very tall K (K = steps x batch rows, M, N <= 128): the
+//    weight- and bias-gradient sums. Each block owns a contiguous K range and accumulates the whole M x N result in
+//    MFMA accumulators across its 8 waves, streaming both operands through a double-buffered LDS tile; per-block
+//    partials are written out and summed in a fixed order by the caller (deterministic, unlike atomics).
 #include "tsde_common.h"
 #include "tsde_launch.h"
 #include "tsde_mlp.h"
@@ -299,51 +299,105 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
   return hipErrorInvalidValue;
 }
 
-// ---- C = A^T B over a tall K ----------------------------------------------------------------------------------------
-// Waves are arranged 4 (along M) x 2 (along N); a wave holds MT x NT accumulator tiles of 16 x 16.
-//   A operand of v_mfma_f32_16x16x4_f32: lane l supplies A^T[i = l % 16][k = l / 16] = A[k0 + l / 16][16 ti + l % 16]
-//   B operand:                           lane l supplies B[k = l / 16][j = l % 16]   = B[k0 + l / 16][16 tj + l % 16]
-// i.e. both are 64-byte row segments of four consecutive K rows: coalesced as they lie in HBM.
-template <int MT, int NT>
-__global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials, const float* __restrict__ A,
-                                                   const float* __restrict__ Bm, int64_t K, int32_t M, int32_t N,
-                                                   int64_t rows_per_block) {
+// ---- C = A^T B (and the column sums of A) over a tall K --------------------------------------------------------------
+// A block owns a contiguous K range and walks it in tiles of 32 rows: 16-byte coalesced loads of both operands into
+// registers (the NEXT tile's loads are in flight while the current one is multiplied), one LDS copy per tile, double
+// buffered (one barrier per tile). Waves are arranged 4 (along M) x 2 (along N); a wave holds MT x NT accumulator tiles
+// of 16 x 16 and reads its operands from LDS in MFMA layout:
+//   A operand of v_mfma_f32_16x16x4_f32: lane l supplies A^T[i = l % 16][k = l / 16] = tile[k0 + l / 16][16 ti + l % 16]
+//   B operand:                           lane l supplies B[k = l / 16][j = l % 16]   = tile[k0 + l / 16][16 tj + l % 16]
+// (row stride padded by 16 floats: the two K rows of a half-wave then sit in opposite halves of the 32 banks).
+// The loader's threads keep fixed columns, so the column sums of A (the bias gradients) cost one add per loaded value.
+constexpr int kGramRows = 32;
+
+template <int MT, int NT, bool VEC>
+__global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials, float* __restrict__ colsums,
+                                                   const float* __restrict__ A, const float* __restrict__ Bm, int64_t K,
+                                                   int32_t M, int32_t N, int64_t rows_per_block) {
   using TL = Tile<16>;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int MP = 64 * MT, NP = 32 * NT;                 // padded widths
+  constexpr int SA = MP + 16, SB = NP + 16;                 // LDS row strides (floats)
+  constexpr int QA = MP / 4, QB = NP / 4;                   // 16-byte slots per tile row
+  constexpr int LA = (kGramRows * QA + 511) / 512, LB = (kGramRows * QB + 511) / 512;   // slots per thread
+  __shared__ float As[2][kGramRows * SA];
+  __shared__ float Bs[2][kGramRows * SB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int part = lane >> 4, n = lane & 15;
   const int wm = wave & 3, wn = wave >> 2;
+
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = {0.0f, 0.0f, 0.0f, 0.0f};
-  int col_a[MT], col_b[NT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a) col_a[a] = 16 * (wm * MT + a) + n;
-#pragma unroll
-  for (int b = 0; b < NT; ++b) col_b[b] = 16 * (wn * NT + b) + n;
+  f32x4 csum = {0.0f, 0.0f, 0.0f, 0.0f};                    // columns 4 (tid % QA) .. + 3 of A, this thread's rows
 
   const int64_t k0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t k1 = k0 + rows_per_block < K ? k0 + rows_per_block : K;
-  // 16 rows of K per trip: all loads of the trip are issued before its MFMAs (rows_per_block is a multiple of 16; the
-  // `krow < k1` guard only bites in the last block)
-  for (int64_t kk = k0; kk < k1; kk += 16) {
-    float fa[4][MT], fb[4][NT];
+  const int ntiles = k1 > k0 ? (int)((k1 - k0 + kGramRows - 1) / kGramRows) : 0;
+
+  f32x4 ra[LA], rb[LB];
+  auto fetch = [&](const float* __restrict__ src, int32_t width, int q_per_row, int slot, int64_t kk) {
+    const int r = slot / q_per_row, c = 4 * (slot % q_per_row);
+    const int64_t krow = kk + r;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (r < kGramRows && krow < k1) {
+      const float* q = src + krow * width + c;
+      if constexpr (VEC) {
+        if (c < width) v = *reinterpret_cast<const f32x4*>(q);
+      } else {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int64_t krow = kk + 4 * g + part;
-      const bool ok = krow < k1;
+        for (int e = 0; e < 4; ++e)
+          if (c + e < width) v[e] = q[e];
+      }
+    }
+    return v;
+  };
+  auto load_tile = [&](int tile) {
+    const int64_t kk = k0 + (int64_t)tile * kGramRows;
 #pragma unroll
-      for (int a = 0; a < MT; ++a) fa[g][a] = (ok && col_a[a] < M) ? A[krow * M + col_a[a]] : 0.0f;
-#pragma unroll
-      for (int b = 0; b < NT; ++b) fb[g][b] = (ok && col_b[b] < N) ? Bm[krow * N + col_b[b]] : 0.0f;
+    for (int i = 0; i < LA; ++i) {
+      ra[i] = fetch(A, M, QA, tid + 512 * i, kk);
+      csum += ra[i];
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int i = 0; i < LB; ++i) rb[i] = fetch(Bm, N, QB, tid + 512 * i, kk);
+  };
+  auto stage_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int slot = tid + 512 * i;
+      if (slot < kGramRows * QA) *reinterpret_cast<f32x4*>(&As[buf][(slot / QA) * SA + 4 * (slot % QA)]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int slot = tid + 512 * i;
+      if (slot < kGramRows * QB) *reinterpret_cast<f32x4*>(&Bs[buf][(slot / QB) * SB + 4 * (slot % QB)]) = rb[i];
+    }
+  };
+
+  if (ntiles > 0) {
+    load_tile(0);
+    stage_tile(0);
+  }
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) load_tile(tile + 1);
+#pragma unroll
+    for (int g = 0; g < kGramRows / 4; ++g) {
+      float fa[MT], fb[NT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) fa[a] = As[buf][(4 * g + part) * SA + 16 * (wm * MT + a) + n];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) fb[b] = Bs[buf][(4 * g + part) * SB + 16 * (wn * NT + b) + n];
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = TL::mfma(fa[g][a], fb[g][b], acc[a][b]);
+        for (int b = 0; b < NT; ++b) acc[a][b] = TL::mfma(fa[a], fb[b], acc[a][b]);
+    }
+    if (tile + 1 < ntiles) stage_tile(buf ^ 1);
+    __syncthreads();
   }
 
   float* out = partials + (int64_t)blockIdx.x * M * N;
@@ -353,28 +407,57 @@ __global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials,
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = 16 * (wm * MT + a) + 4 * part + r, j = col_b[b];
+        const int i = 16 * (wm * MT + a) + 4 * part + r, j = 16 * (wn * NT + b) + n;
         if (i < M && j < N) out[(int64_t)i * N + j] = acc[a][b][r];
       }
+
+  if (colsums != nullptr) {
+    // thread tid summed columns 4 (tid % QA) ..+3 over its rows: 512 / QA threads per column quad, added up in a
+    // fixed order through LDS (the tile buffers are free now: the loop ended on a barrier)
+    float* scratch = &As[0][0];                             // (512 / QA) x MP floats <= 2 * 32 * SA
+    *reinterpret_cast<f32x4*>(&scratch[(tid / QA) * MP + 4 * (tid % QA)]) = csum;
+    __syncthreads();
+    if (tid < M) {
+      float total = 0.0f;
+      for (int j = 0; j < 512 / QA; ++j) total += scratch[j * MP + tid];
+      colsums[(int64_t)blockIdx.x * M + tid] = total;
+    }
+  }
 }
 
-template <int MT>
-static hipError_t launch_gram_n(float* partials, const float* A, const float* Bm, int64_t K, int32_t M, int32_t N,
-                                int32_t blocks, int64_t rows_per_block, hipStream_t s) {
-  if (N <= 32) hipLaunchKernelGGL((gram_kernel<MT, 1>), dim3(blocks), dim3(512), 0, s, partials, A, Bm, K, M, N, rows_per_block);
-  else if (N <= 64) hipLaunchKernelGGL((gram_kernel<MT, 2>), dim3(blocks), dim3(512), 0, s, partials, A, Bm, K, M, N, rows_per_block);
-  else if (N <= 128) hipLaunchKernelGGL((gram_kernel<MT, 4>), dim3(blocks), dim3(512), 0, s, partials, A, Bm, K, M, N, rows_per_block);
-  else return hipErrorInvalidValue;
+template <int MT, int NT>
+static hipError_t launch_gram_vec(float* partials, float* colsums, const float* A, const float* Bm, int64_t K, int32_t M,
+                                  int32_t N, int32_t blocks, int64_t rows_per_block, hipStream_t s) {
+  const bool vec = M % 4 == 0 && N % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15u) == 0;
+  if (vec)
+    hipLaunchKernelGGL((gram_kernel<MT, NT, true>), dim3(blocks), dim3(512), 0, s, partials, colsums, A, Bm, K, M, N,
+                       rows_per_block);
+  else
+    hipLaunchKernelGGL((gram_kernel<MT, NT, false>), dim3(blocks), dim3(512), 0, s, partials, colsums, A, Bm, K, M, N,
+                       rows_per_block);
   return hipGetLastError();
 }
 
-hipError_t launch_gram_partials(void* partials, const void* A, const void* Bm, int64_t K, int64_t M, int64_t N,
-                                int32_t blocks, hipStream_t s) {
+template <int MT>
+static hipError_t launch_gram_n(float* partials, float* colsums, const float* A, const float* Bm, int64_t K, int32_t M,
+                                int32_t N, int32_t blocks, int64_t rows_per_block, hipStream_t s) {
+  if (N <= 32) return launch_gram_vec<MT, 1>(partials, colsums, A, Bm, K, M, N, blocks, rows_per_block, s);
+  if (N <= 64) return launch_gram_vec<MT, 2>(partials, colsums, A, Bm, K, M, N, blocks, rows_per_block, s);
+  if (N <= 128) return launch_gram_vec<MT, 4>(partials, colsums, A, Bm, K, M, N, blocks, rows_per_block, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, const void* Bm, int64_t K, int64_t M,
+                                int64_t N, int32_t blocks, hipStream_t s) {
   if (K <= 0 || M <= 0 || N <= 0 || blocks <= 0) return hipErrorInvalidValue;
   int64_t rows_per_block = (K + blocks - 1) / blocks;
-  rows_per_block = (rows_per_block + 15) / 16 * 16;       // whole groups of the unrolled K loop
-  if (M <= 64) return launch_gram_n<1>((float*)partials, (const float*)A, (const float*)Bm, K, (int32_t)M, (int32_t)N, blocks, rows_per_block, s);
-  if (M <= 128) return launch_gram_n<2>((float*)partials, (const float*)A, (const float*)Bm, K, (int32_t)M, (int32_t)N, blocks, rows_per_block, s);
+  rows_per_block = (rows_per_block + kGramRows - 1) / kGramRows * kGramRows;       // whole tiles
+  if (M <= 64)
+    return launch_gram_n<1>((float*)partials, (float*)colsums, (const float*)A, (const float*)Bm, K, (int32_t)M,
+                            (int32_t)N, blocks, rows_per_block, s);
+  if (M <= 128)
+    return launch_gram_n<2>((float*)partials, (float*)colsums, (const float*)A, (const float*)Bm, K, (int32_t)M,
+                            (int32_t)N, blocks, rows_per_block, s);
   return hipErrorInvalidValue;
 }
 

@@ -56,17 +56,6 @@ template <typename T>
 hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, double cG, hipStream_t s);
 template <typename T>
 hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s);
-
-// mlp_backward.hip
-hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta,
-                                               void* row_rate, void* row_shift, const void* ys_all,
-                                               const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
-                                               int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
-                                               const void* W2, const void* c, int act, const tsde_traj_t* tr,
-                                               int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
-                                               hipStream_t s);
-hipError_t launch_gram_partials(void* partials, const void* A, const void* Bm, int64_t K, int64_t M, int64_t N,
-                                int32_t blocks, hipStream_t s);
 }  // namespace tsde
 
 namespace tsde {
@@ -117,6 +106,6 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
                                                const void* W2, const void* c, int act, const tsde_traj_t* tr,
                                                int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
                                                hipStream_t s);
-hipError_t launch_gram_partials(void* partials, const void* A, const void* Bm, int64_t K, int64_t M, int64_t N,
-                                int32_t blocks, hipStream_t s);
+hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, const void* Bm, int64_t K, int64_t M,
+                                int64_t N, int32_t blocks, hipStream_t s);
 }  // namespace tsde

@@ -594,9 +594,10 @@ def trajectory_affine_diag_differentiable(y0, params, method, schedule, bm):
     return _TrajectoryFn.apply(method, schedule, bm, y0, *params)
 
 
-def gram(a, b, blocks=512):
+def gram(a, b, blocks=512, column_sums=False):
     """a^T b for tall a (k, m), b (k, n) with m, n <= 128 (``tsde_gram_partials`` + a fixed-order sum of its partials):
-    the weight-gradient reduction of the perceptron-drift backward sweep."""
+    the weight-gradient reduction of the perceptron-drift backward sweep. With `column_sums`, also a.sum(0) (the bias
+    gradient), from the same pass over a."""
     _native.require_device(a, b)
     if a.dtype != torch.float32 or b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):
         raise ValueError("gram takes contiguous float32 matrices")
@@ -605,9 +606,12 @@ def gram(a, b, blocks=512):
     k, m, n = a.shape[0], a.shape[1], b.shape[1]
     blocks = int(max(1, min(blocks, (k + 63) // 64)))
     partials = torch.empty((blocks, m, n), dtype=torch.float32, device=a.device)
+    sums = torch.empty((blocks, m), dtype=torch.float32, device=a.device) if column_sums else None
     lib, dt_code, stream = _launch_env(a)
-    _native.check(lib.tsde_gram_partials(partials.data_ptr(), a.data_ptr(), b.data_ptr(), k, m, n, blocks, dt_code,
-                                         stream), "tsde_gram_partials")
+    _native.check(lib.tsde_gram_partials(partials.data_ptr(), None if sums is None else sums.data_ptr(), a.data_ptr(),
+                                         b.data_ptr(), k, m, n, blocks, dt_code, stream), "tsde_gram_partials")
+    if column_sums:
+        return partials.sum(dim=0), sums.sum(dim=0)
     return partials.sum(dim=0)
 
 
@@ -676,10 +680,11 @@ class _MlpTrajectoryFn(torch.autograd.Function):
             flat_lam = stash_lam[:n].reshape(n * rows, d)
             flat_hid = stash_hid[:n].reshape(n * rows, hidden)
             flat_delta = stash_delta[:n].reshape(n * rows, hidden)
-            g_w2 += gram(flat_lam, flat_hid)
-            g_w1 += gram(flat_delta, ys_all[k_lo:k_hi].reshape(n * rows, d))
-            g_b2 += flat_lam.sum(dim=0)
-            g_b1 += flat_delta.sum(dim=0)
+            for g_w, g_b, a, b in ((g_w2, g_b2, flat_lam, flat_hid),
+                                   (g_w1, g_b1, flat_delta, ys_all[k_lo:k_hi].reshape(n * rows, d))):
+                weight, bias = gram(a, b, column_sums=True)
+                g_w += weight
+                g_b += bias
         grad_y0 = lam + gys[0] if ctx.needs_input_grad[5] else None
         diffusion = []
         for acc, shape in zip((row_rate, row_shift), ctx.param_shapes):
