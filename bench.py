@@ -83,6 +83,14 @@ WORKLOADS = {
         problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
         kid=8, trajectory=True, mfma_flops_per_traj_step=4 * 128 * 128,
         kernel="tsde_trajectory_mlp_diag<128, 128, softplus> (mlp_trajectory_kernel, v_mfma_f32_16x16x4_f32)"),
+    # The TRAINING step of the same neural SDE (forward + loss.backward() through the solver, Euler): sampling kernel
+    # writing every step, reverse sweep (three products per step on the matrix cores), tall-K weight-gradient products.
+    # Roofline: the reverse sweep, 3 * 2*d*hidden flop per trajectory-step.
+    "c5_training_mlp_b32768_d128_s500": dict(
+        problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
+        bytes_per_traj_step=0, kid=9, launches_per_step=1, trajectory=True, train=True,
+        mfma_flops_per_traj_step=6 * 128 * 128,
+        kernel="tsde_trajectory_mlp_diag_backward<128, 128, softplus> (mlp_backward_kernel, v_mfma_f32_16x16x4_f32)"),
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
@@ -138,9 +146,9 @@ def _cpu_baseline(cfg, budget_s=20.0):
     except Exception as e:  # oracle piece missing: report, don't fake
         return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": f"unavailable: {e}"}
-    if cfg.get("adjoint"):
+    if cfg.get("adjoint") or cfg.get("train"):
         return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": "not timed for the adjoint workload"}
+                "sample": "not timed for the forward + backward workloads"}
     B, d, dt = cfg["B"], cfg["d"], cfg["dt"]
     sde = _make_problem(cfg["problem"], d, cfg["m"], "cpu")
     y0 = torch.full((B, d), 0.1)
@@ -264,7 +272,8 @@ def main():
     use_graph = (not args.eager) and not trajectory
     extra_options = dict(cfg.get("options") or {})
     sde = _make_problem(cfg["problem"], d, m, dev)
-    y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint)
+    train = cfg.get("train", False)
+    y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint or train)
     ts = torch.tensor([0.0, nsteps * dt], device=dev)
     gathered = torch.empty((world * B, d), device=dev) if use_dist else None
 
@@ -280,6 +289,16 @@ def main():
                                                  adjoint_method=cfg["adjoint_method"], dt=dt, options=dict(gopt),
                                                  adjoint_options=dict(gopt))
                 y0.grad = None
+                ys[-1].sum().backward()
+            if use_dist:
+                from torchsde_amd import sharding
+                sharding.all_reduce_gradients(list(sde.parameters()))
+            return y0.grad
+        if train:
+            with torch.enable_grad():
+                ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt)
+                y0.grad = None
+                sde.zero_grad()
                 ys[-1].sum().backward()
             if use_dist:
                 from torchsde_amd import sharding
@@ -315,7 +334,7 @@ def main():
         # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
         # (issued eagerly: event records are host-side calls and are not part of a replayed graph)
         if trajectory:
-            K.prof_begin(cfg["kid"], 16)
+            K.prof_begin(cfg["kid"], 16 if not train else 8 * (nsteps + 1))
             for i in range(8):
                 one_solve(5000 + i, graph=False)
         else:
@@ -355,14 +374,15 @@ def main():
         # roofline fraction is ~0 by design; `valu_*` restate the same launch against the vector-ALU issue peak.
         avg_s = k_ms * 1e-3 / k_launches
         if cfg.get("mfma_flops_per_traj_step"):
-            flops = cfg["mfma_flops_per_traj_step"] * B * nsteps
+            # 8 solves were timed; a solve is one launch, or (reverse sweep) one launch per chunk of steps
+            flops = cfg["mfma_flops_per_traj_step"] * B * nsteps * 8 / k_launches
             achieved = flops / avg_s / 1e12
             roofline = {"bound": "mfma", "kernel": cfg["kernel"], "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                         "flops_per_launch": flops, "avg_launch_us": avg_s * 1e6, "launches_timed": k_launches,
                         "note": "f32-in / f32-accumulate MFMA (exact f32); peak = dense f32 matrix rate of "
                                 "guides/MI355X_MICROARCH.md",
-                        "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
+                        "timing": "HIP events bracketing every launch of this kernel in 8 eagerly issued solves"}
         bytes_per_launch = 2 * B * d * 4
         achieved = bytes_per_launch / avg_s / 1e9
         roofline = roofline or {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -422,10 +442,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "sde": cfg["problem"] + (" (closed-form coefficients; f, g evaluated in the kernel)" if trajectory
                                                           else " (f, g are user torch ops)"),
-                       "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else ""),
+                       "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else "") +
+                                 (" + loss.backward() through the solver" if train else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "state": d, "brownian_channels": m,
                        "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
-                       "launch": ("one trajectory-kernel launch per solve" if trajectory else
+                       "launch": ("trajectory kernels: one forward launch, the reverse sweep in chunks of steps, two weight-gradient "
+                                  "products per chunk" if train else
+                                  "one trajectory-kernel launch per solve" if trajectory else
                                   "HIP graph replay of the whole solve" + (" and of the backward sweep" if adjoint else "")
                                   if use_graph else "eager launches"),
                        "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},

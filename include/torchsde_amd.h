@@ -314,6 +314,8 @@ int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, con
 #define TSDE_KID_BROWNIAN_QUERY 6
 #define TSDE_KID_RHEUN 7
 #define TSDE_KID_TRAJECTORY 8
+#define TSDE_KID_MLP_BACKWARD 9
+#define TSDE_KID_MLP_BACKWARD 9
 /* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
 int tsde_prof_begin(int kid, int capacity);
 /* Occupies `stream` with a single-thread kernel for about `microseconds` (<= 2 s). bench.py queues one before

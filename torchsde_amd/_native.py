@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtorchsde_amd.so")
 
 F32, F64 = 0, 1
 KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDATE, KID_BROWNIAN_QUERY = 1, 2, 3, 4, 5, 6
-KID_RHEUN, KID_TRAJECTORY = 7, 8
+KID_RHEUN, KID_TRAJECTORY, KID_MLP_BACKWARD = 7, 8, 9
 ERROR_NORM_WORKSPACE = 1024
 TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1

@@ -420,7 +420,7 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
   if (grad_last >= 0 && (!grad_ys || !grad_step)) return bad_arg(where, "grad_last >= 0 without cotangents");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  ProfScope p(TSDE_KID_MLP_BACKWARD, s);
   return fail(tsde::launch_trajectory_mlp_diag_backward(lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift,
                                                         ys_all, grad_ys, grad_step, grad_last, rows, d, hidden, w1, b1,
                                                         w2, diff_rate, activation, traj, k_lo, k_hi,
