@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ["train_latent_sde.py", "--steps", "4", "--adjoint"],
     ["monte_carlo_closed_form.py"],
     ["sample_neural_sde.py"],
+    ["train_neural_sde.py", "--iters", "12"],
 ])
 def test_example_runs(argv):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "examples", argv[0])] + argv[1:], capture_output=True,
