@@ -211,3 +211,22 @@ def test_adjoint_argument_errors():
         torchsde_amd.sdeint_adjoint(sde, torch.zeros(2, 4), [0.0, 1.0], adjoint_method="milstein")
     with pytest.raises(ValueError, match="Runge"):
         torchsde_amd.sdeint_adjoint(problems.make("gbm_ito"), torch.zeros(2, 4), [0.0, 1.0], adjoint_method="srk")
+
+
+def test_output_times_reach_the_host_once():
+    """`ts` is copied to the host once per tensor VERSION (a training loop reusing its `ts` never synchronises on it),
+    and the monotonicity check of the contract runs on that copy."""
+    import numpy as np
+    from torchsde_amd import contract, timegrid
+    ts = torch.tensor([0.0, 0.25, 1.0])
+    first = timegrid.ts_to_host(ts)
+    assert timegrid.ts_to_host(ts) is first and not first.flags.writeable
+    np.testing.assert_array_equal(first, np.asarray([0.0, 0.25, 1.0], dtype=np.float32))
+    assert contract.is_strictly_increasing(ts)
+    ts[1] = 2.0                                        # in-place edit: the version counter moves, the copy is redone
+    second = timegrid.ts_to_host(ts)
+    assert second is not first and second[1] == 2.0 and first[1] == 0.25
+    assert not contract.is_strictly_increasing(ts)
+    assert not contract.is_strictly_increasing(torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64))
+    assert contract.is_strictly_increasing([0.0, 0.5, 2.0]) and not contract.is_strictly_increasing((0.0, 0.0))
+    assert timegrid.ts_to_host(ts.clone()) is not second            # a different tensor object never shares a copy

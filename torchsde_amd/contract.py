@@ -8,9 +8,12 @@ created for ``bm=None`` (:262-270). Runs once per solve; not a performance path.
 """
 import warnings
 
+import numpy as np
+
 import torch
 
 from . import sde as sde_lib
+from . import timegrid
 from .brownian import BrownianInterval
 from .settings import LEVY_AREA_APPROXIMATIONS, METHODS, NOISE_TYPES, SDE_TYPES
 
@@ -36,6 +39,13 @@ def assert_no_grad(names, maybe_tensors):
 
 
 def is_strictly_increasing(ts):
+    """misc.is_strictly_increasing of the reference, on ONE host copy of `ts` (the reference's element-wise Python
+    comparison of a device tensor synchronises once per output time)."""
+    if torch.is_tensor(ts):
+        if ts.dim() != 1:
+            return all(x < y for x, y in zip(ts[:-1], ts[1:]))       # let the reference's semantics decide
+        host = timegrid.ts_to_host(ts) if ts.dtype in timegrid._NP else ts.detach().cpu().double().numpy()
+        return bool((host[:-1] < host[1:]).all())
     return all(x < y for x, y in zip(ts[:-1], ts[1:]))
 
 
@@ -111,7 +121,12 @@ def check_contract(sde, y0, ts, bm, method, adaptive, options, names, logqp, bm_
     if not torch.is_tensor(ts):
         if not isinstance(ts, (tuple, list)) or not all(isinstance(t, (float, int)) for t in ts):
             raise ValueError("Evaluation times `ts` must be a 1-D Tensor or list/tuple of floats.")
-        ts = torch.tensor(ts, dtype=y0.dtype, device=y0.device)
+        if y0.dtype in timegrid._NP:
+            host = np.asarray(ts, dtype=timegrid._NP[y0.dtype])
+            ts = torch.from_numpy(host.copy()).to(y0.device)
+            timegrid.remember(ts, host)
+        else:
+            ts = torch.tensor(ts, dtype=y0.dtype, device=y0.device)
     if not is_strictly_increasing(ts):
         raise ValueError("Evaluation times `ts` must be strictly increasing.")
 

@@ -6,6 +6,7 @@ Every update of the solver state goes through a function here, which launches a 
 expressed with differentiable torch ops on the re-materialised increment (the step maps are linear in
 ``y0, f, g``), so higher-order derivatives work too.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -500,6 +501,24 @@ class TrajectorySchedule:
     def struct(self):
         return ctypes.byref(self._struct)
 
+    _recent = collections.OrderedDict()      # (host contents, device, dtype) -> schedule; device tensors are read-only
+
+    @classmethod
+    def cached(cls, step_rows, cells, out_step, out_w, device, dtype):
+        """The schedule of a solve the process has seen before (same steps, cells and outputs -- every iteration of a
+        training loop) without its four blocking host->device copies; otherwise a new one, remembered (8 most recent)."""
+        key = (np.ascontiguousarray(step_rows).tobytes(), np.ascontiguousarray(cells).tobytes(),
+               tuple(int(k) for k in out_step), tuple((float(a), float(b)) for a, b in out_w), str(device), dtype)
+        hit = cls._recent.get(key)
+        if hit is not None:
+            cls._recent.move_to_end(key)
+            return hit
+        made = cls(step_rows, cells, out_step, out_w, device, dtype)
+        cls._recent[key] = made
+        while len(cls._recent) > 8:
+            cls._recent.popitem(last=False)
+        return made
+
 
 def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm, sens=None):
     """All steps of an affine diagonal SDE in one launch (``tsde_trajectory_affine_diag``); writes ys[j] for the
@@ -615,6 +634,21 @@ def gram(a, b, blocks=512, column_sums=False):
     return partials.sum(dim=0)
 
 
+_boundary_tables = collections.OrderedDict()
+
+
+def _boundary_table(out_steps, device):
+    """Device table [0, *out_steps] (int32) of the step boundaries the outputs sit on; remembered like the schedules."""
+    key = (tuple(out_steps), str(device))
+    table = _boundary_tables.get(key)
+    if table is None:
+        table = torch.from_numpy(np.asarray((0,) + tuple(out_steps), dtype=np.int32)).to(device)
+        _boundary_tables[key] = table
+        while len(_boundary_tables) > 8:
+            _boundary_tables.popitem(last=False)
+    return table
+
+
 class _MlpTrajectoryFn(torch.autograd.Function):
     """Differentiable whole-trajectory Euler solve of a perceptron-drift diagonal SDE. Forward: the sampling kernel,
     writing the state at EVERY step (HBM is plentiful on this part; the reverse sweep needs them). Backward: the
@@ -637,12 +671,14 @@ class _MlpTrajectoryFn(torch.autograd.Function):
         ys_all[0].copy_(y0c)
         trajectory_mlp_diag(ys_all[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, method,
                             schedule_all, bm)
+        ctx.grad_step = _boundary_table(out_steps, y0.device)
         ctx.save_for_backward(ys_all, w1_in, b1c, w2_in, coefs[0])
         ctx.activation, ctx.schedule, ctx.bm, ctx.out_steps, ctx.hidden = activation, schedule_all, bm, out_steps, hidden
         ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
         ctx.key = (bm._key, bm._elem0, bm._entropy_dev)
-        index = torch.as_tensor([0] + list(out_steps), device=y0.device)
-        return ys_all.index_select(0, index)
+        # (a stack of views, not index_select: building an index tensor is a blocking host->device copy that would wait
+        #  for the forward launch)
+        return torch.stack([ys_all[k] for k in (0,) + tuple(out_steps)], dim=0)
 
     @staticmethod
     def backward(ctx, gys):
@@ -652,7 +688,7 @@ class _MlpTrajectoryFn(torch.autograd.Function):
         dev = ys_all.device
         gys = _native.contiguous(gys)
         boundaries = np.asarray([0] + list(ctx.out_steps), dtype=np.int32)
-        grad_step = torch.from_numpy(boundaries).to(dev)
+        grad_step = ctx.grad_step
         per_step = rows * (d + 2 * hidden) * 4
         chunk = int(max(1, min(n_steps, _MlpTrajectoryFn.STASH_BYTES // max(per_step, 1))))
         stash_lam = torch.empty((chunk, rows, d), dtype=torch.float32, device=dev)

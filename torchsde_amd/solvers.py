@@ -344,7 +344,15 @@ class BaseSDESolver:
         rows[:, 6] = h
         out_step = [kc for (_, kc, _, _) in grid.outputs]
         out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
-        schedule = K.TrajectorySchedule(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        if coefficients[0] == "mlp_differentiable":
+            if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
+                return None
+            every_step = list(range(1, grid.n_steps + 1))
+            schedule_all = K.TrajectorySchedule.cached(rows, cells, every_step, [(0.0, 1.0)] * grid.n_steps, y0.device,
+                                                       y0.dtype)
+            return K.trajectory_mlp_diag_differentiable(y0, coefficients[2:], coefficients[1], self._trajectory_code(),
+                                                        schedule_all, out_step, bm)
+        schedule = K.TrajectorySchedule.cached(rows, cells, out_step, out_w, y0.device, y0.dtype)
         if coefficients[0] == "mlp_diagonal":
             if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
                 return None      # an output time inside a step: the stepwise path interpolates it
@@ -353,14 +361,6 @@ class BaseSDESolver:
             ys[0].copy_(y0c)
             K.trajectory_mlp_diag(ys[1:], y0c, *coefficients[1:], self._trajectory_code(), schedule, bm)
             return ys
-        if coefficients[0] == "mlp_differentiable":
-            if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
-                return None
-            every_step = list(range(1, grid.n_steps + 1))
-            schedule_all = K.TrajectorySchedule(rows, cells, every_step, [(0.0, 1.0)] * grid.n_steps, y0.device,
-                                                y0.dtype)
-            return K.trajectory_mlp_diag_differentiable(y0, coefficients[2:], coefficients[1], self._trajectory_code(),
-                                                        schedule_all, out_step, bm)
         if coefficients[0] == "differentiable":
             return K.trajectory_affine_diag_differentiable(y0, coefficients[1:], self._trajectory_code(), schedule, bm)
         y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()

@@ -77,7 +77,25 @@ def build(ts_host: np.ndarray, dt) -> TimeGrid:
 
 
 def ts_to_host(ts: torch.Tensor) -> np.ndarray:
-    """One device->host copy of the output times (the only sync of a fixed-step solve)."""
+    """The output times on the host (read-only array): one device->host copy, the only sync of a fixed-step solve --
+    and none at all when the same `ts` tensor comes back unchanged (every iteration of a training loop): the copy is
+    remembered ON the tensor object together with its version counter, which every in-place op bumps."""
     if ts.dtype not in _NP:
         raise ValueError(f"Unsupported dtype for `ts`: {ts.dtype}")
-    return ts.detach().cpu().numpy()
+    cached = getattr(ts, "_tsde_host", None)
+    if cached is not None and cached[0] == ts._version:
+        return cached[1]
+    host = ts.detach().cpu().numpy()
+    if host.base is not None or ts.device.type == "cpu":
+        host = host.copy()          # a CPU tensor shares its memory with `.numpy()`: keep a private snapshot
+    remember(ts, host)
+    return host
+
+
+def remember(ts: torch.Tensor, host: np.ndarray) -> None:
+    """Attach a host copy of `ts` to the tensor (for callers that built the tensor FROM host values)."""
+    host.setflags(write=False)
+    try:
+        ts._tsde_host = (ts._version, host)
+    except (AttributeError, RuntimeError):      # a tensor subclass that refuses attributes: just do not cache
+        pass
