@@ -259,7 +259,7 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  * live in LDS and both layers run on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 accumulation).
  *   w1 (d, hidden) and w2 (hidden, d) are stored input-major: w1[k][m] multiplies input channel k into unit m
  *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 (both are zero-padded
- *   to the MFMA tile sizes inside the kernel); ys, y0 16-byte aligned; dtype must be TSDE_F32;
+ *   to the MFMA tile sizes inside the kernel); rows * d < 2^30; ys, y0 16-byte aligned; dtype must be TSDE_F32;
  *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT, TSDE_TRAJ_MIDPOINT}.
  * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
@@ -288,7 +288,8 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
  *   ys_all       (n_steps+1, rows, d)  the state at EVERY step boundary (run the forward kernel with one output per step)
  *   grad_ys      (n_grad, rows, d), grad_step (n_grad, ascending, device): cotangent of the output at boundary
  *                grad_step[j]; grad_last = index of the last entry with grad_step <= k_hi, or -1
- * d, hidden multiples of 4 up to 128; w1, w2 in the layout of tsde_trajectory_mlp_diag; all buffers 16-byte aligned. */
+ * d, hidden multiples of 4 up to 128, rows * max(d, hidden) < 2^30; w1, w2 in the layout of
+ * tsde_trajectory_mlp_diag; all buffers 16-byte aligned. */
 int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
                                       void* row_shift, const void* ys_all, const void* grad_ys,
                                       const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,

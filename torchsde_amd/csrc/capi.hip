@@ -381,6 +381,7 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
     return bad_arg(where, "need d a multiple of 4 in [4, 128] and hidden in [1, 128]");
   if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
     return bad_arg(where, "ys and y0 must be 16-byte aligned");
+  if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
   if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
   if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MILSTEIN_ITO && method != TSDE_TRAJ_MILSTEIN_STRAT &&
       method != TSDE_TRAJ_MIDPOINT)
@@ -411,6 +412,8 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
   if (rows < 0) return bad_arg(where, "need rows >= 0");
   if (d < 4 || d > 128 || d % 4 != 0 || hidden < 4 || hidden > 128 || hidden % 4 != 0)
     return bad_arg(where, "need d and hidden multiples of 4 in [4, 128]");
+  if (rows * (d > hidden ? d : hidden) >= (int64_t(1) << 30))
+    return bad_arg(where, "need rows * max(d, hidden) < 2^30 (32-bit lane offsets)");
   const void* aligned[] = {lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift, ys_all, grad_ys};
   for (const void* q : aligned)
     if (reinterpret_cast<uintptr_t>(q) & 15u) return bad_arg(where, "state-shaped buffers must be 16-byte aligned");

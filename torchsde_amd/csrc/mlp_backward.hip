@@ -146,10 +146,11 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
         if ((t + 1) % 4 == 0) __builtin_amdgcn_sched_barrier(0);
       }
       f32x4 value;
+      const f32x4 bias = lds_quad(b1s, R * th + 4 * part);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v, slope;
-        activate_with_slope<ACT>(z[r] + b1s[R * th + 4 * part + r], v, slope);
+        activate_with_slope<ACT>(z[r] + bias[r], v, slope);
         value[r] = v;
         hid[th][r] = slope;
       }
@@ -186,12 +187,13 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       // y_k once more (from L2): keeping the tiles of the first load alive across the two products above costs more
       // registers than the kernel has
       const f32x4 yt = load_tile(p.ys_all + (int64_t)k * p.B * dT, t);
+      const f32x4 cq = lds_quad(cs, ch);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float lw = lam[t][r] * (zn[r] * sw);
         acc_shift[t][r] += lw;
         acc_rate[t][r] += lw * yt[r];
-        lam[t][r] += lw * cs[ch + r];
+        lam[t][r] += lw * cq[r];
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -53,7 +53,8 @@ struct MlpArgs {
 
 // NW = waves per block: all of them share one copy of the weights in LDS.
 // MID: the two-stage Stratonovich midpoint scheme (midpoint.py:31-43) instead of the one-stage Euler / Milstein step.
-template <int D, int H, int ACT, int R, int NW, bool MID>
+// FULL: d == D and h == H (no channel padding inside the kernel), which removes every per-tile bounds test.
+template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL>
 __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p) {
   using TL = Tile<R>;
   using acc_t = typename TL::acc_t;
@@ -87,14 +88,22 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int part = lane / R, n = lane % R;
-  const int64_t row = ((int64_t)blockIdx.x * NW + wave) * R + n;
-  const bool live = row < p.B;
+  // A wave with no batch row left is done; in the last partial wave the surplus lanes shadow the last row: they read
+  // what its lane reads, draw the same noise and write the same values to the same addresses -- no lane masks.
+  const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * R;
+  if (row0 >= p.B) return;
+  const int64_t row = row0 + n < p.B ? row0 + n : p.B - 1;
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
     const uint64_t ent = *p.key_dev;
     key.k0 = (uint32_t)ent;
     key.k1 = (uint32_t)(ent >> 32);
   }
+  // Addresses are a wave-uniform base (SGPRs) + ONE 32-bit lane offset + a constant per quad, so that no per-tile
+  // 64-bit address lives in vector registers across the solve (the C ABI keeps rows * d < 2^30).
+  const uint32_t off_d = (uint32_t)(row * dT);
+  const uint64_t quad_row = (key.elem0 + (uint64_t)(row * dT)) >> 2;      // RNG quad of channel 0 of this row
+  auto real = [&](int ch) { return FULL || ch < dT; };                    // a quad of channels is real or padding
 
   // state in accumulator layout: y[t][r] = y(row, R t + TL::row(r, part))
   acc_t y[TD];
@@ -103,11 +112,10 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 #pragma unroll
     for (int q = 0; q < TL::kQuads; ++q) {
       const int ch = R * t + TL::quad_base(q, part);      // channels ch .. ch+3 = registers 4q .. 4q+3
-      Pack<float, 4> v;
-      const bool real = live && ch < dT;                // a quad of channels is real or padding as a whole
-      if (real) v = load<float, 4>(p.y0, row * dT + ch);
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (real(ch)) v = *reinterpret_cast<const f32x4*>(p.y0 + off_d + ch);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) y[t][4 * q + s] = real ? v.v[s] : 0.0f;
+      for (int s = 0; s < 4; ++s) y[t][4 * q + s] = v[s];
     }
   }
 
@@ -139,7 +147,11 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
           if ((t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int r = 0; r < kRegs; ++r) hid[th][r] = activate<ACT>(hid[th][r] + b1s[R * th + TL::row(r, part)]);
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const f32x4 bias = lds_quad(b1s, R * th + TL::quad_base(q, part));
+#pragma unroll
+          for (int s = 0; s < 4; ++s) hid[th][4 * q + s] = activate<ACT>(hid[th][4 * q + s] + bias[s]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -170,15 +182,20 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
         for (int q = 0; q < TL::kQuads; ++q) {
           const int ch = R * t + TL::quad_base(q, part);
           float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (ch < dT) normal4<float>(key, (key.elem0 + (uint64_t)(row * dT + ch)) >> 2, cell, 0, kStreamW, z);
+          // (opaque to the optimiser: otherwise the step-invariant first Philox round of every quad is hoisted out
+          //  of the step loop and pinned in ~4 registers per quad)
+          uint64_t quad = quad_row + (ch >> 2);
+          asm volatile("" : "+v"(quad));
+          if (real(ch)) normal4<float>(key, quad, cell, 0, kStreamW, z);
+          const f32x4 b2q = lds_quad(b2s, ch), cq = lds_quad(cs, ch), eq = lds_quad(es, ch);
           Pack<float, 4> o;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int r = 4 * q + s;
             const float yy = y[t][r];
-            const float f = acc[r] + b2s[ch + s];
-            const float cc = cs[ch + s];
-            const float g = cc * yy + es[ch + s];
+            const float f = acc[r] + b2q[s];
+            const float cc = cq[s];
+            const float g = cc * yy + eq[s];
             const float w = z[s] * sw;
             float yn;
             if (p.method == TSDE_TRAJ_EULER) {
@@ -190,7 +207,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             y[t][r] = yn;
             o.v[s] = yn;
           }
-          if (due && live && ch < dT) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, row * dT + ch, o);
+          if (due && real(ch)) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -205,15 +222,19 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
         for (int q = 0; q < TL::kQuads; ++q) {
           const int ch = R * t + TL::quad_base(q, part);
           float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (ch < dT) normal4<float>(key, (key.elem0 + (uint64_t)(row * dT + ch)) >> 2, cell, 0, kStreamW, z);
+          // (opaque to the optimiser: otherwise the step-invariant first Philox round of every quad is hoisted out
+          //  of the step loop and pinned in ~4 registers per quad)
+          uint64_t quad = quad_row + (ch >> 2);
+          asm volatile("" : "+v"(quad));
+          if (real(ch)) normal4<float>(key, quad, cell, 0, kStreamW, z);
+          const f32x4 b2q = lds_quad(b2s, ch), cq = lds_quad(cs, ch), eq = lds_quad(es, ch);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int r = 4 * q + s;
             const float yy = y[t][r];
             const float w = z[s] * sw;
             wk[t][r] = w;
-            yp[t][r] = drift_diffusion_update<float>(yy, acc[r] + b2s[ch + s], cs[ch + s] * yy + es[ch + s], w, half_dt,
-                                                     0.5f);
+            yp[t][r] = drift_diffusion_update<float>(yy, acc[r] + b2q[s], cq[s] * yy + eq[s], w, half_dt, 0.5f);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -226,16 +247,17 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 #pragma unroll
         for (int q = 0; q < TL::kQuads; ++q) {
           const int ch = R * t + TL::quad_base(q, part);
+          const f32x4 b2q = lds_quad(b2s, ch), cq = lds_quad(cs, ch), eq = lds_quad(es, ch);
           Pack<float, 4> o;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int r = 4 * q + s;
-            const float yn = drift_diffusion_update<float>(y[t][r], acc[r] + b2s[ch + s],
-                                                           cs[ch + s] * yp[t][r] + es[ch + s], wk[t][r], dt, 1.0f);
+            const float yn = drift_diffusion_update<float>(y[t][r], acc[r] + b2q[s], cq[s] * yp[t][r] + eq[s],
+                                                           wk[t][r], dt, 1.0f);
             y[t][r] = yn;
             o.v[s] = yn;
           }
-          if (due && live && ch < dT) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, row * dT + ch, o);
+          if (due && real(ch)) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -246,21 +268,32 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
   }
 }
 
-template <int D, int H, int ACT, int R, int NW, bool MID>
-static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
+template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL>
+static hipError_t launch_mlp_full(const MlpArgs& p, hipStream_t s) {
   const size_t lds_bytes = MlpLds<R>::bytes(D, H);
   static bool configured = false;   // per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, MID>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const hipError_t e =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     configured = true;
   }
   const int64_t rows_per_block = NW * R;
   const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, MID>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, s,
-                     p);
+  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL>), dim3((unsigned)blocks), dim3(NW * 64),
+                     lds_bytes, s, p);
   return hipGetLastError();
+}
+
+template <int D, int H, int ACT, int R, int NW, bool MID>
+static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
+  // (the two-stage scheme keeps the bounds tests even for unpadded shapes: without them hipcc's schedule of the wider
+  //  basic blocks needs MORE registers -- 390 spilled dwords instead of 62 at d = hidden = 128)
+  if constexpr (!MID) {
+    if (p.d == D && p.h == H) return launch_mlp_full<D, H, ACT, R, NW, MID, true>(p, s);
+  }
+  return launch_mlp_full<D, H, ACT, R, NW, MID, false>(p, s);
 }
 
 // Variant choice (tools/bench_mlp_trajectory.py, MI355X): 16-row waves in 8-wave blocks everywhere. The weights of a

@@ -69,6 +69,15 @@ struct Tile<16> {
   TSDE_D static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 
+// Four consecutive per-channel constants (biases, diffusion coefficients) from LDS, re-read at every use: the index is
+// made opaque so that the loads are NOT hoisted out of the step loop -- hoisted, the constants of all tiles pin more
+// than a hundred registers per lane for the whole solve (one ds_read_b128 per quad and step is noise next to the
+// hundreds of operand reads of the matrix products).
+TSDE_D f32x4 lds_quad(const float* base, int index) {
+  asm volatile("" : "+v"(index));
+  return *reinterpret_cast<const f32x4*>(base + index);
+}
+
 template <int R>
 struct MlpLds {
   static constexpr int kPad = (R == 16) ? 4 : 0;

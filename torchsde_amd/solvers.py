@@ -295,7 +295,7 @@ class BaseSDESolver:
             # perceptron drift: sampling kernel on the matrix cores (forward only; Euler, Milstein, midpoint)
             code = self._trajectory_code()
             if code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT,
-                            _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0:
+                            _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
                 return None
             if self._tracks_grad(y0):
                 # training: Euler only, through the reverse-sweep kernel; gradients reach y0 and the module's own six
