@@ -13,8 +13,8 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: tsde_step_diag; 
 = 16*d bytes per trajectory-step x batch = 4 streams x B*d*4 B, over the kernel's average duration measured
 with HIP events inside the library) and `cpu_baseline` (the oracle's port of the reference's CPU algorithm,
 timed on this host's cores on a bounded sample). The default single-GPU run also carries `also`: two short side
-measurements taken after the timed region (the same job with the SDE in closed form, and perceptron-drift sampling
-on the matrix cores); they are not part of `value`, and `--no-also` skips them.
+measurements taken after the timed region (the same job with the SDE in closed form; perceptron-drift sampling and
+a perceptron-drift training step on the matrix cores); they are not part of `value`, and `--no-also` skips them.
 """
 import argparse
 import json
@@ -196,7 +196,8 @@ def _side_measurements(dev):
     on the matrix cores. A failure here is reported in place and never takes the headline down with it.
     """
     also = {}
-    for name in ("c2_euler_closed_form_b65536_d64_s1000", "c5_sampling_mlp_b32768_d128_s500"):
+    for name in ("c2_euler_closed_form_b65536_d64_s1000", "c5_sampling_mlp_b32768_d128_s500",
+                 "c5_training_mlp_b32768_d128_s500"):
         try:
             also[name] = _side_measurement(dev, WORKLOADS[name])
         except Exception as e:
@@ -207,13 +208,20 @@ def _side_measurements(dev):
 def _side_measurement(dev, c):
     import torchsde_amd
     sde = _make_problem(c["problem"], c["d"], c["m"], dev)
-    y0 = torch.full((c["B"], c["d"]), 0.1, device=dev)
+    train = c.get("train", False)
+    y0 = torch.full((c["B"], c["d"]), 0.1, device=dev, requires_grad=train)
     t1 = c["nsteps"] * c["dt"]
     ts = torch.tensor([0.0, t1], device=dev)
 
     def solve(i):
         bm = torchsde_amd.BrownianInterval(t0=0.0, t1=t1, size=(c["B"], c["m"]), dtype=torch.float32, device=dev,
                                            entropy=777 + i, dt=c["dt"], levy_area_approximation=c["levy"])
+        if train:               # forward + loss.backward() through the solver
+            ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=c["method"], dt=c["dt"])
+            y0.grad = None
+            sde.zero_grad()
+            ys[-1].sum().backward()
+            return y0.grad
         with torch.no_grad():
             return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=c["method"], dt=c["dt"])
 
@@ -227,7 +235,9 @@ def _side_measurement(dev, c):
     ms = (time.perf_counter() - start) / 5 * 1e3
     assert torch.isfinite(out).all()
     rec = {"ms_per_solve": ms, "trajectory_steps_per_s": c["B"] * c["nsteps"] / ms * 1e3, "kernel": c["kernel"]}
-    if c.get("mfma_flops_per_traj_step"):
+    if train:
+        rec["what"] = "forward + backward per training step"
+    elif c.get("mfma_flops_per_traj_step"):
         rec["tflops_f32"] = c["mfma_flops_per_traj_step"] * c["B"] * c["nsteps"] / ms / 1e9
     return rec
 
