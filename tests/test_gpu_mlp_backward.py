@@ -1,5 +1,6 @@
 """GPU parity of the gradient of the perceptron-drift trajectory kernel (``tsde_trajectory_mlp_diag_backward`` +
-``tsde_gram_partials``; run with ``-m gpu``): ``sdeint`` with autograd on, Euler, on an ``MLPDriftDiagonalSDE`` must
+``tsde_gram_partials``; run with ``-m gpu``): ``sdeint`` with autograd on, Euler or Milstein, on an
+``MLPDriftDiagonalSDE`` must
 return the gradients autograd gives when it records the stepwise solve of the same module on the same Brownian path
 (the reference's way: torchsde/_core/base_solver.py:114-134 + methods/euler.py:31-36 under ``loss.backward()``). The
 two differ in the summation order of the matrix products (and of the batch reductions of the parameter gradients)."""
@@ -10,12 +11,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _sde(d, hidden, activation, seed=0, scalar_diffusion=False):
+def _sde(d, hidden, activation, seed=0, scalar_diffusion=False, sde_type="ito"):
     import torchsde_amd
     torch.manual_seed(seed)
     rate = 0.05 if scalar_diffusion else 0.2 * torch.rand(d) - 0.1
     shift = 0.2 if scalar_diffusion else 0.1 + 0.2 * torch.rand(d)
-    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, diff_rate=rate, diff_shift=shift)
+    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, diff_rate=rate, diff_shift=shift,
+                                           sde_type=sde_type)
     with torch.no_grad():       # asymmetric, well-scaled weights (a transposed operand cannot pass)
         sde.lin1.weight.copy_(torch.randn(hidden, d) / d ** 0.5)
         sde.lin2.weight.copy_(torch.randn(d, hidden) / hidden ** 0.5)
@@ -24,14 +26,15 @@ def _sde(d, hidden, activation, seed=0, scalar_diffusion=False):
     return sde.to(DEV)
 
 
-def _gradients(sde, y0, ts, dt, entropy, trajectory, weights):
+def _gradients(sde, y0, ts, dt, entropy, trajectory, weights, method="euler"):
     """Loss = sum_j <weights[j], ys[j]> over ALL outputs (so every cotangent entry point is exercised)."""
     import torchsde_amd
     y = y0.clone().requires_grad_(True)
     bm = torchsde_amd.BrownianInterval(float(ts[0]), float(ts[-1]), size=tuple(y0.shape), dtype=y0.dtype, device=DEV,
                                        entropy=entropy)
     sde.zero_grad()
-    ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method="euler", dt=dt, options={"trajectory_kernel": trajectory})
+    ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method=method, dt=dt, options={"trajectory_kernel": trajectory})
+    assert ("MlpTrajectoryFn" in type(ys.grad_fn).__name__) == trajectory
     (ys * weights).sum().backward()
     named = {name: p.grad.clone() for name, p in sde.named_parameters()}
     named["y0"] = y.grad.clone()
@@ -61,6 +64,23 @@ def test_gradients_match_autograd_of_the_stepwise_solve(d, hidden, activation):
     torch.testing.assert_close(ys_fast, ys_ref, rtol=2e-4, atol=2e-5)
     assert set(fast) == set(ref) == {"lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "diff_rate", "diff_shift",
                                      "y0"}
+    _assert_gradients_close(fast, ref)
+
+
+@pytest.mark.parametrize("activation", ["tanh", "softplus"])
+@pytest.mark.parametrize("d,hidden", [(64, 64), (128, 128), (20, 52), (124, 120)])
+@pytest.mark.parametrize("sde_type", ["ito", "stratonovich"])
+def test_milstein_gradients_match_autograd_of_the_stepwise_solve(sde_type, d, hidden, activation):
+    B = 200
+    sde = _sde(d, hidden, activation, sde_type=sde_type)
+    gen = torch.Generator().manual_seed(2)
+    y0 = (0.5 * torch.randn(B, d, generator=gen)).to(DEV)
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 3 * dt, 12 * dt], device=DEV)
+    weights = torch.randn(3, B, d, generator=gen).to(DEV)
+    ys_fast, fast = _gradients(sde, y0, ts, dt, 6, True, weights, method="milstein")
+    ys_ref, ref = _gradients(sde, y0, ts, dt, 6, False, weights, method="milstein")
+    torch.testing.assert_close(ys_fast, ys_ref, rtol=2e-4, atol=2e-5)
     _assert_gradients_close(fast, ref)
 
 
@@ -100,6 +120,51 @@ def test_long_solve_training_shape():
     _assert_gradients_close(fast, ref, rtol=5e-3)
 
 
+@pytest.mark.parametrize("activation", ["tanh", "softplus"])
+def test_gradients_match_the_cpu_oracle_in_float64(activation):
+    """The chain to the reference: its stepping loop restated on the CPU (oracle/solvers_ref.py, euler.py:31-36) in
+    float64 under autograd, fed the SAME increments by the C twin of the generator (oracle/counter.py)."""
+    import copy
+
+    import numpy as np
+
+    import torchsde_amd
+    from oracle import counter, solvers_ref
+    d, hidden, B, steps, dt, entropy = 32, 64, 64, 16, 2.0 ** -5, 777
+    sde = _sde(d, hidden, activation)
+    gen = torch.Generator().manual_seed(5)
+    y0 = (0.5 * torch.randn(B, d, generator=gen)).to(DEV)
+    weights = torch.randn(3, B, d, generator=gen).to(DEV)
+    ts = torch.tensor([0.0, 5 * dt, steps * dt], device=DEV)
+
+    y = y0.clone().requires_grad_(True)
+    bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=torch.float32, device=DEV, entropy=entropy,
+                                       dt=dt)
+    sde.zero_grad()
+    ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method="euler", dt=dt)
+    assert "MlpTrajectoryFn" in type(ys.grad_fn).__name__
+    (ys * weights).sum().backward()
+    fast = {name: p.grad.detach().cpu().double() for name, p in sde.named_parameters()}
+    fast["y0"] = y.grad.detach().cpu().double()
+
+    ref_sde = copy.deepcopy(sde).cpu().double()
+    ref_sde.zero_grad()
+    edges = np.arange(steps + 1) * dt
+
+    def bm_cpu(ta, tb, return_U=False):
+        W, _, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float32, have_h=False)
+        return torch.from_numpy(W).reshape(B, d).double()
+
+    y_ref = y0.detach().cpu().double().requires_grad_(True)
+    with torch.enable_grad():
+        ys_ref = solvers_ref.integrate(ref_sde, bm_cpu, y_ref, ts.cpu().double(), dt, "euler", None)
+        (ys_ref * weights.cpu().double()).sum().backward()
+    torch.testing.assert_close(ys.detach().cpu().double(), ys_ref.detach(), rtol=1e-4, atol=1e-5)
+    ref = {name: p.grad for name, p in ref_sde.named_parameters()}
+    ref["y0"] = y_ref.grad
+    _assert_gradients_close(fast, ref, rtol=1e-3)
+
+
 @pytest.mark.parametrize("k,m,n", [(1, 4, 4), (17, 128, 128), (1000, 64, 32), (4099, 100, 7), (70000, 128, 64),
                                    (33000, 36, 128)])
 def test_gram_matches_float64(k, m, n):
@@ -122,7 +187,7 @@ def test_gram_matches_float64(k, m, n):
 
 
 def test_falls_back_when_the_sweep_does_not_apply():
-    """Milstein / midpoint, a hidden width that is not a multiple of 4, or an extra parameter on a subclass: gradients
+    """Midpoint, a hidden width that is not a multiple of 4, or an extra parameter on a subclass: gradients
     still come out (stepwise path), and agree with the Euler sweep where both apply."""
     import torchsde_amd
     d, B = 32, 128
@@ -140,6 +205,8 @@ def test_falls_back_when_the_sweep_does_not_apply():
     fn, g = run(_sde(d, 64, "tanh"), "euler")
     assert "MlpTrajectoryFn" in type(fn).__name__ and torch.isfinite(g).all()
     fn, g = run(_sde(d, 64, "tanh"), "milstein")
+    assert "MlpTrajectoryFn" in type(fn).__name__ and torch.isfinite(g).all()
+    fn, g = run(_sde(d, 64, "tanh", sde_type="stratonovich"), "midpoint")
     assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
     fn, g = run(_sde(d, 30, "tanh"), "euler")
     assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
@@ -167,9 +234,11 @@ def test_c_abi_rejects_unsupported_arguments():
     traj = _native.Traj()
     ptr = x.data_ptr()
     for d, hidden, fragment in ((6, 32, b"multiples of 4"), (32, 30, b"multiples of 4"), (132, 32, b"multiples of 4")):
-        args = (ptr,) * 9 + (-1, 64, d, hidden) + (ptr,) * 4 + (0, traj, 0, 0, 1, 0, None, 0, None)
+        args = (ptr,) * 9 + (-1, 64, d, hidden) + (ptr,) * 5 + (0, 0, traj, 0, 0, 1, 0, None, 0, None)
         assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and fragment in lib.tsde_last_error()
-    args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 4 + (0, traj, 0, 5, 1, 0, None, 0, None)
+    args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 5 + (0, 0, traj, 0, 5, 1, 0, None, 0, None)
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"k_hi" in lib.tsde_last_error()
+    args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 5 + (0, 3, traj, 0, 0, 1, 0, None, 0, None)       # midpoint
+    assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"Euler or Milstein" in lib.tsde_last_error()
     assert lib.tsde_gram_partials(ptr, None, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
     assert b"[1, 128]" in lib.tsde_last_error()

@@ -10,6 +10,8 @@
 //                       dL/dW2 += (dt_k lam) h^T         dL/dW1 += delta y_k^T
 //                       dL/db2 += dt_k lam               dL/db1 += delta
 //                       dL/dc  += lam * y_k * dW_k       dL/de  += lam * dW_k
+//   Milstein (milstein.py:52-74 for this g: gdg = g c) adds (g v) c with v = (dW^2 - dt)/2 (Ito) or dW^2/2:
+//                       dL/dy_k += lam c^2 v             dL/dc += lam v (g + c y_k)       dL/de += lam c v
 //
 // 1. mlp_backward_kernel -- the reverse sweep. A wave owns 16 batch rows for all steps; lam stays in registers in the
 //    MFMA accumulator layout (the layout of the sampling kernel: it is the B operand of the next product as it
@@ -26,6 +28,7 @@
 #include "tsde_common.h"
 #include "tsde_launch.h"
 #include "tsde_mlp.h"
+#include "tsde_schemes.h"
 
 namespace tsde {
 
@@ -43,7 +46,8 @@ struct MlpBackArgs {
   const float* W1;          // (d, h) as in MlpArgs
   const float* b1;          // (h)
   const float* W2;          // (h, d)
-  const float* c;           // (d)
+  const float *c, *e;       // (d) diffusion g = c*y + e (e is only read by the Milstein terms)
+  int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT
   const float* rows;        // (n_steps, 8)
   const uint32_t* cells;
   int64_t B;
@@ -65,6 +69,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
   float* W2s = W1s + D * S1;        // H rows of S2: W2s[hidden][channel]
   float* b1s = W2s + H * S2;        // H
   float* cs = b1s + H;              // D
+  float* es = cs + D;               // D
   const int dT = p.d, hT = p.h;
   for (int i = threadIdx.x; i < D * H; i += kThreads) {
     const int k1 = i / H, m1 = i % H, k2 = i / D, m2 = i % D;
@@ -72,7 +77,10 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
     W2s[k2 * S2 + m2] = (k2 < hT && m2 < dT) ? p.W2[k2 * dT + m2] : 0.0f;
   }
   for (int i = threadIdx.x; i < H; i += kThreads) b1s[i] = i < hT ? p.b1[i] : 0.0f;
-  for (int i = threadIdx.x; i < D; i += kThreads) cs[i] = i < dT ? p.c[i] : 0.0f;
+  for (int i = threadIdx.x; i < D; i += kThreads) {
+    cs[i] = i < dT ? p.c[i] : 0.0f;
+    es[i] = i < dT ? p.e[i] : 0.0f;
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,12 +196,26 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       // registers than the kernel has
       const f32x4 yt = load_tile(p.ys_all + (int64_t)k * p.B * dT, t);
       const f32x4 cq = lds_quad(cs, ch);
+      if (p.method == TSDE_TRAJ_EULER) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float lw = lam[t][r] * (zn[r] * sw);
-        acc_shift[t][r] += lw;
-        acc_rate[t][r] += lw * yt[r];
-        lam[t][r] += lw * cq[r];
+        for (int r = 0; r < 4; ++r) {
+          const float lw = lam[t][r] * (zn[r] * sw);
+          acc_shift[t][r] += lw;
+          acc_rate[t][r] += lw * yt[r];
+          lam[t][r] += lw * cq[r];
+        }
+      } else {
+        const f32x4 eq = lds_quad(es, ch);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float w = zn[r] * sw, cc = cq[r];
+          const float v = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
+          const float cy = cc * yt[r];
+          const float l = lam[t][r];
+          acc_shift[t][r] += l * (w + cc * v);
+          acc_rate[t][r] += l * (yt[r] * w + v * ((cy + eq[r]) + cy));
+          lam[t][r] += l * (cc * w + (cc * cc) * v);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -225,7 +247,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
 template <int D, int H, int ACT, int NW, bool FULL>
 static hipError_t launch_back_variant(const MlpBackArgs& p, hipStream_t s) {
   constexpr int R = 16;
-  const size_t lds_bytes = (size_t)(D * (H + MlpLds<R>::kPad) + H * (D + MlpLds<R>::kPad) + H + D) * sizeof(float);
+  const size_t lds_bytes = (size_t)(D * (H + MlpLds<R>::kPad) + H * (D + MlpLds<R>::kPad) + H + 2 * D) * sizeof(float);
   static bool configured = false;   // per instantiation
   if (!configured) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_backward_kernel<D, H, ACT, NW, FULL>),
@@ -267,7 +289,8 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
                                                void* row_rate, void* row_shift, const void* ys_all,
                                                const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
                                                int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
-                                               const void* W2, const void* c, int act, const tsde_traj_t* tr,
+                                               const void* W2, const void* c, const void* e, int act, int method,
+                                               const tsde_traj_t* tr,
                                                int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
                                                hipStream_t s) {
   MlpBackArgs p;
@@ -285,6 +308,8 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
   p.b1 = (const float*)b1;
   p.W2 = (const float*)W2;
   p.c = (const float*)c;
+  p.e = (const float*)e;
+  p.method = method;
   p.rows = (const float*)tr->step_rows;
   p.cells = tr->cells;
   p.B = rows;

@@ -650,7 +650,7 @@ def _boundary_table(out_steps, device):
 
 
 class _MlpTrajectoryFn(torch.autograd.Function):
-    """Differentiable whole-trajectory Euler solve of a perceptron-drift diagonal SDE. Forward: the sampling kernel,
+    """Differentiable whole-trajectory Euler / Milstein solve of a perceptron-drift diagonal SDE. Forward: the sampling kernel,
     writing the state at EVERY step (HBM is plentiful on this part; the reverse sweep needs them). Backward: the
     reverse sweep kernel over chunks of steps (last first), each followed by the two weight-gradient products over that
     chunk's stash -- the gradient back-propagation through the stepwise solver gives, without an autograd tape."""
@@ -672,7 +672,8 @@ class _MlpTrajectoryFn(torch.autograd.Function):
         trajectory_mlp_diag(ys_all[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, method,
                             schedule_all, bm)
         ctx.grad_step = _boundary_table(out_steps, y0.device)
-        ctx.save_for_backward(ys_all, w1_in, b1c, w2_in, coefs[0])
+        ctx.save_for_backward(ys_all, w1_in, b1c, w2_in, coefs[0], coefs[1])
+        ctx.method = int(method)
         ctx.activation, ctx.schedule, ctx.bm, ctx.out_steps, ctx.hidden = activation, schedule_all, bm, out_steps, hidden
         ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
         ctx.key = (bm._key, bm._elem0, bm._entropy_dev)
@@ -682,7 +683,7 @@ class _MlpTrajectoryFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gys):
-        ys_all, w1_in, b1c, w2_in, rate = ctx.saved_tensors
+        ys_all, w1_in, b1c, w2_in, rate, shift = ctx.saved_tensors
         n_steps, rows, d = ys_all.shape[0] - 1, ys_all.shape[1], ys_all.shape[2]
         hidden, schedule = ctx.hidden, ctx.schedule
         dev = ys_all.device
@@ -709,8 +710,8 @@ class _MlpTrajectoryFn(torch.autograd.Function):
             code = lib.tsde_trajectory_mlp_diag_backward(
                 lam.data_ptr(), stash_lam.data_ptr(), stash_hid.data_ptr(), stash_delta.data_ptr(), row_rate.data_ptr(),
                 row_shift.data_ptr(), ys_all.data_ptr(), gys.data_ptr(), grad_step.data_ptr(), grad_last, rows, d,
-                hidden, w1_in.data_ptr(), b1c.data_ptr(), w2_in.data_ptr(), rate.data_ptr(), int(ctx.activation),
-                schedule.struct(), k_lo, k_hi, key, elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
+                hidden, w1_in.data_ptr(), b1c.data_ptr(), w2_in.data_ptr(), rate.data_ptr(), shift.data_ptr(),
+                int(ctx.activation), ctx.method, schedule.struct(), k_lo, k_hi, key, elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
                 dt_code, stream)
             _native.check(code, "tsde_trajectory_mlp_diag_backward")
             flat_lam = stash_lam[:n].reshape(n * rows, d)

@@ -298,11 +298,11 @@ class BaseSDESolver:
                             _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
                 return None
             if self._tracks_grad(y0):
-                # training: Euler only, through the reverse-sweep kernel; gradients reach y0 and the module's own six
+                # training: Euler and Milstein, through the reverse-sweep kernel; gradients reach y0 and the module's own six
                 # parameters, so a subclass with more of them (or shapes the sweep does not take) goes stepwise
                 own = list(base.closed_form_parameters())
                 hidden = own[1].numel()
-                if (code != _native.TRAJ_EULER or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30
+                if (code == _native.TRAJ_MIDPOINT or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30
                         or {id(p) for p in base.parameters()} != {id(p) for p in own}):
                     return None
                 return ("mlp_differentiable", spec[-1]) + tuple(own)
