@@ -286,13 +286,15 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
  *          dL/db2 = column sums of stash_lam,   dL/db1 = column sums of stash_delta
  *   row_rate, row_shift (rows, d)  accumulated in place: sum_k lam*y_k*dW_k and sum_k lam*dW_k per trajectory
  *                                  (their batch sums are dL/d diff_rate, dL/d diff_shift)
- *   ys_all       (n_steps+1, rows, d)  the state at EVERY step boundary (run the forward kernel with one output per step)
+ *   ys_all       (.., rows, d)  the states at step boundaries ys_first, ys_first+1, ..., k_hi-1 at least (run the
+ *                forward kernel with one output per step -- over the whole solve with ys_first = 0, or again over
+ *                each chunk from a state kept at its start, ys_first = k_lo)
  *   grad_ys      (n_grad, rows, d), grad_step (n_grad, ascending, device): cotangent of the output at boundary
  *                grad_step[j]; grad_last = index of the last entry with grad_step <= k_hi, or -1
  * d, hidden multiples of 4 up to 128, rows * max(d, hidden) < 2^30; w1, w2 in the layout of
  * tsde_trajectory_mlp_diag; all buffers 16-byte aligned. */
 int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
-                                      void* row_shift, const void* ys_all, const void* grad_ys,
+                                      void* row_shift, const void* ys_all, int32_t ys_first, const void* grad_ys,
                                       const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,
                                       int64_t hidden, const void* w1, const void* b1, const void* w2,
                                       const void* diff_rate, const void* diff_shift, int activation, int method,

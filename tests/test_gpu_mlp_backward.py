@@ -106,6 +106,29 @@ def test_chunked_sweep_and_scalar_diffusion_parameters(monkeypatch):
     torch.testing.assert_close(chunked["y0"], whole["y0"], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("method", ["euler", "milstein"])
+def test_states_recomputed_per_chunk_give_the_same_bits(monkeypatch, method):
+    """Without room for every step's state the forward launch keeps the chunk boundaries only and the backward pass
+    re-runs the sampling kernel per chunk: same kernel, same increments -> every gradient bit-identical."""
+    from torchsde_amd import kernels as K
+    d, hidden, B = 32, 64, 500
+    sde = _sde(d, hidden, "tanh")
+    gen = torch.Generator().manual_seed(8)
+    y0 = (0.5 * torch.randn(B, d, generator=gen)).to(DEV)
+    dt = 2.0 ** -6
+    ts = torch.tensor([0.0, 2 * dt, 9 * dt, 14 * dt, 37 * dt], device=DEV)       # outputs inside and on chunk edges
+    weights = torch.randn(5, B, d, generator=gen).to(DEV)
+    monkeypatch.setattr(K._MlpTrajectoryFn, "STASH_BYTES", 7 * B * (d + 2 * hidden) * 4)     # 7 steps per chunk
+    ys_all, keep_all = _gradients(sde, y0, ts, dt, 13, True, weights, method=method)
+    monkeypatch.setattr(K._MlpTrajectoryFn, "STATE_BYTES", 1)                                # nothing fits
+    ys_ck, recomputed = _gradients(sde, y0, ts, dt, 13, True, weights, method=method)
+    assert torch.equal(ys_all, ys_ck)
+    for name in keep_all:
+        assert torch.equal(keep_all[name], recomputed[name]), name
+    _, ref = _gradients(sde, y0, ts, dt, 13, False, weights, method=method)
+    _assert_gradients_close(recomputed, ref)
+
+
 def test_long_solve_training_shape():
     """Many steps at a latent-SDE-like shape: error growth stays at the level of the summation-order difference."""
     d, hidden, B = 128, 128, 2048
@@ -234,11 +257,11 @@ def test_c_abi_rejects_unsupported_arguments():
     traj = _native.Traj()
     ptr = x.data_ptr()
     for d, hidden, fragment in ((6, 32, b"multiples of 4"), (32, 30, b"multiples of 4"), (132, 32, b"multiples of 4")):
-        args = (ptr,) * 9 + (-1, 64, d, hidden) + (ptr,) * 5 + (0, 0, traj, 0, 0, 1, 0, None, 0, None)
+        args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, d, hidden) + (ptr,) * 5 + (0, 0, traj, 0, 0, 1, 0, None, 0, None)
         assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and fragment in lib.tsde_last_error()
-    args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 5 + (0, 0, traj, 0, 5, 1, 0, None, 0, None)
+    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (0, 0, traj, 0, 5, 1, 0, None, 0, None)
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"k_hi" in lib.tsde_last_error()
-    args = (ptr,) * 9 + (-1, 64, 32, 32) + (ptr,) * 5 + (0, 3, traj, 0, 0, 1, 0, None, 0, None)       # midpoint
+    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (0, 3, traj, 0, 0, 1, 0, None, 0, None)   # midpoint
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"Euler or Milstein" in lib.tsde_last_error()
     assert lib.tsde_gram_partials(ptr, None, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
     assert b"[1, 128]" in lib.tsde_last_error()

@@ -106,8 +106,8 @@ SIGNATURES = {
     "tsde_trajectory_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_ptr, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                           _c_ptr]),
-    "tsde_trajectory_mlp_diag_backward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
-                                                   _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+    "tsde_trajectory_mlp_diag_backward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i32, _c_ptr,
+                                                   _c_ptr, _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                    _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
                                                    _c_ptr, _c_int, _c_ptr]),
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),

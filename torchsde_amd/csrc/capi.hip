@@ -398,7 +398,7 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
 }
 
 int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
-                                      void* row_shift, const void* ys_all, const void* grad_ys,
+                                      void* row_shift, const void* ys_all, int32_t ys_first, const void* grad_ys,
                                       const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,
                                       int64_t hidden, const void* w1, const void* b1, const void* w2,
                                       const void* diff_rate, const void* diff_shift, int activation, int method,
@@ -422,12 +422,13 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
   if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
   if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
   if (k_lo < 0 || k_hi < k_lo || k_hi > traj->n_steps) return bad_arg(where, "need 0 <= k_lo <= k_hi <= n_steps");
+  if (ys_first < 0 || ys_first > k_lo) return bad_arg(where, "need 0 <= ys_first <= k_lo");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
   if (grad_last >= 0 && (!grad_ys || !grad_step)) return bad_arg(where, "grad_last >= 0 without cotangents");
   const hipStream_t s = (hipStream_t)stream;
   ProfScope p(TSDE_KID_MLP_BACKWARD, s);
   return fail(tsde::launch_trajectory_mlp_diag_backward(lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift,
-                                                        ys_all, grad_ys, grad_step, grad_last, rows, d, hidden, w1, b1,
+                                                        ys_all, ys_first, grad_ys, grad_step, grad_last, rows, d, hidden, w1, b1,
                                                         w2, diff_rate, diff_shift, activation, method, traj, k_lo, k_hi,
                                                         make_key(entropy, elem0), entropy_dev, s),
               where);

@@ -39,7 +39,8 @@ struct MlpBackArgs {
   float* stash_delta;       // (k_hi - k_lo, B, h)   delta_k
   float* row_rate;          // (B, d)  += sum_k lam * y_k * dW_k   (per trajectory; the caller sums over the batch)
   float* row_shift;         // (B, d)  += sum_k lam * dW_k
-  const float* ys_all;      // (n_steps + 1, B, d) states at every step boundary
+  const float* ys_all;      // (.., B, d) states at step boundaries ys_first, ys_first + 1, ... (at least up to k_hi - 1)
+  int32_t ys_first;
   const float* grad_ys;     // (n_grad, B, d) cotangents of the outputs
   const int32_t* grad_step; // (n_grad) ascending boundary index of each output
   int32_t grad_last;        // index of the last output at a boundary <= k_hi (-1: none)
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
 #pragma unroll
     for (int t = 0; t < TD; ++t) {
       if (arrives) lam[t] += load_tile(p.grad_ys + (int64_t)jg * p.B * dT, t);
-      y[t] = load_tile(p.ys_all + (int64_t)k * p.B * dT, t);
+      y[t] = load_tile(p.ys_all + (int64_t)(k - p.ys_first) * p.B * dT, t);
       store_tile(p.stash_lam + slot * p.B * dT, t, lam[t] * dt);
     }
     if (arrives) --jg;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       if (real_d(t)) normal4<float>(key, quad, cell, 0, kStreamW, zn);
       // y_k once more (from L2): keeping the tiles of the first load alive across the two products above costs more
       // registers than the kernel has
-      const f32x4 yt = load_tile(p.ys_all + (int64_t)k * p.B * dT, t);
+      const f32x4 yt = load_tile(p.ys_all + (int64_t)(k - p.ys_first) * p.B * dT, t);
       const f32x4 cq = lds_quad(cs, ch);
       if (p.method == TSDE_TRAJ_EULER) {
 #pragma unroll
@@ -287,7 +288,7 @@ static hipError_t launch_back_h(const MlpBackArgs& p, int act, hipStream_t s) {
 
 hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta,
                                                void* row_rate, void* row_shift, const void* ys_all,
-                                               const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
+                                               int32_t ys_first, const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
                                                int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
                                                const void* W2, const void* c, const void* e, int act, int method,
                                                const tsde_traj_t* tr,
@@ -301,6 +302,7 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
   p.row_rate = (float*)row_rate;
   p.row_shift = (float*)row_shift;
   p.ys_all = (const float*)ys_all;
+  p.ys_first = ys_first;
   p.grad_ys = (const float*)grad_ys;
   p.grad_step = grad_step;
   p.grad_last = grad_last;

@@ -101,7 +101,7 @@ hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, in
 // mlp_backward.hip
 hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta,
                                                void* row_rate, void* row_shift, const void* ys_all,
-                                               const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
+                                               int32_t ys_first, const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
                                                int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
                                                const void* W2, const void* c, const void* e, int act, int method,
                                                const tsde_traj_t* tr,

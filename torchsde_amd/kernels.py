@@ -488,8 +488,10 @@ class TrajectorySchedule:
         assert rows.ndim == 2 and rows.shape[1] == 8
         self.n_steps, self.n_out = rows.shape[0], len(out_step)
         self.dtype = dtype
+        self.host_rows, self.host_cells = rows, np.ascontiguousarray(cells, dtype=np.uint32)
+        self.device = device
         self.rows = torch.from_numpy(rows).to(device)
-        self.cells = torch.from_numpy(np.ascontiguousarray(cells, dtype=np.uint32).view(np.int32)).to(device)
+        self.cells = torch.from_numpy(self.host_cells.view(np.int32)).to(device)
         self.out_step = torch.from_numpy(np.ascontiguousarray(out_step, dtype=np.int32)).to(device)
         self.out_w = torch.from_numpy(np.ascontiguousarray(out_w, dtype=np_dtype).reshape(-1, 2)).to(device)
         s = _native.Traj()
@@ -506,7 +508,7 @@ class TrajectorySchedule:
     @classmethod
     def cached(cls, step_rows, cells, out_step, out_w, device, dtype):
         """The schedule of a solve the process has seen before (same steps, cells and outputs -- every iteration of a
-        training loop) without its four blocking host->device copies; otherwise a new one, remembered (8 most recent)."""
+        training loop) without its four blocking host->device copies; otherwise a new one, remembered (64 most recent)."""
         key = (np.ascontiguousarray(step_rows).tobytes(), np.ascontiguousarray(cells).tobytes(),
                tuple(int(k) for k in out_step), tuple((float(a), float(b)) for a, b in out_w), str(device), dtype)
         hit = cls._recent.get(key)
@@ -515,9 +517,15 @@ class TrajectorySchedule:
             return hit
         made = cls(step_rows, cells, out_step, out_w, device, dtype)
         cls._recent[key] = made
-        while len(cls._recent) > 8:
+        while len(cls._recent) > 64:
             cls._recent.popitem(last=False)
         return made
+
+    def window(self, k_lo, k_hi):
+        """The schedule of steps k_lo .. k_hi - 1 alone, with one output per step (re-running a stretch of a solve)."""
+        n = k_hi - k_lo
+        return TrajectorySchedule.cached(self.host_rows[k_lo:k_hi], self.host_cells[k_lo:k_hi], range(1, n + 1),
+                                         [(0.0, 1.0)] * n, self.device, self.dtype)
 
 
 def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm, sens=None):
@@ -650,75 +658,106 @@ def _boundary_table(out_steps, device):
 
 
 class _MlpTrajectoryFn(torch.autograd.Function):
-    """Differentiable whole-trajectory Euler / Milstein solve of a perceptron-drift diagonal SDE. Forward: the sampling kernel,
-    writing the state at EVERY step (HBM is plentiful on this part; the reverse sweep needs them). Backward: the
-    reverse sweep kernel over chunks of steps (last first), each followed by the two weight-gradient products over that
-    chunk's stash -- the gradient back-propagation through the stepwise solver gives, without an autograd tape."""
+    """Differentiable whole-trajectory Euler / Milstein solve of a perceptron-drift diagonal SDE. Forward: the sampling
+    kernel, writing the state at EVERY step (HBM is plentiful on this part; the reverse sweep needs them). Backward:
+    the reverse sweep kernel over chunks of steps (last first), each followed by the two weight-gradient products over
+    that chunk's stash -- the gradient back-propagation through the stepwise solver gives, without an autograd tape.
+
+    When every step's state would not fit the budget (very large batch x steps), the forward launch keeps only the
+    states at the chunk boundaries and the backward pass re-runs the sampling kernel over each chunk first (same
+    kernel, same increments: the recomputed states are bit-identical), trading one more forward for O(steps / chunk +
+    chunk) states instead of O(steps)."""
 
     # per-chunk stash budget of the reverse sweep (three (steps, rows, width) float32 arrays)
     STASH_BYTES = 3 << 30
+    # budget for keeping the state of every step; None = half of the device memory that is free at forward time
+    STATE_BYTES = None
+
+    @staticmethod
+    def _chunk(n_steps, rows, d, hidden):
+        per_step = rows * (d + 2 * hidden) * 4
+        return int(max(1, min(n_steps, _MlpTrajectoryFn.STASH_BYTES // max(per_step, 1))))
 
     @staticmethod
     def forward(ctx, activation, method, schedule_all, out_steps, bm, y0, w1, b1, w2, b2, rate, shift):
         rows, d = y0.shape
-        hidden = b1.numel()
+        hidden, n_steps = b1.numel(), schedule_all.n_steps
         y0c = _native.contiguous(y0.detach())
         coefs = [p.detach().reshape(-1).expand(d).contiguous() for p in (rate, shift)]
         w1_in = w1.detach().t().contiguous()                # (d, hidden): input-major, as the kernels read it
         w2_in = w2.detach().t().contiguous()                # (hidden, d)
         b1c, b2c = b1.detach().contiguous(), b2.detach().contiguous()
-        ys_all = torch.empty((schedule_all.n_steps + 1, rows, d), dtype=y0.dtype, device=y0.device)
-        ys_all[0].copy_(y0c)
-        trajectory_mlp_diag(ys_all[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, method,
-                            schedule_all, bm)
+        budget = _MlpTrajectoryFn.STATE_BYTES
+        if budget is None:
+            budget = torch.cuda.mem_get_info(y0.device)[0] // 2
+        if (n_steps + 1) * rows * d * 4 <= budget:
+            kept_at = None                                  # states[k] is the state at boundary k
+            schedule = schedule_all
+        else:
+            chunk = _MlpTrajectoryFn._chunk(n_steps, rows, d, hidden)
+            marks = sorted(set(range(n_steps, 0, -chunk)) | set(out_steps))
+            kept_at = {0: 0}
+            kept_at.update((k, i + 1) for i, k in enumerate(marks))
+            schedule = TrajectorySchedule.cached(schedule_all.host_rows, schedule_all.host_cells, marks,
+                                                 [(0.0, 1.0)] * len(marks), y0.device, y0.dtype)
+        states = torch.empty((schedule.n_out + 1, rows, d), dtype=y0.dtype, device=y0.device)
+        states[0].copy_(y0c)
+        trajectory_mlp_diag(states[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, method, schedule,
+                            bm)
         ctx.grad_step = _boundary_table(out_steps, y0.device)
-        ctx.save_for_backward(ys_all, w1_in, b1c, w2_in, coefs[0], coefs[1])
-        ctx.method = int(method)
-        ctx.activation, ctx.schedule, ctx.bm, ctx.out_steps, ctx.hidden = activation, schedule_all, bm, out_steps, hidden
+        ctx.save_for_backward(states, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1])
+        ctx.method, ctx.activation, ctx.hidden = int(method), int(activation), hidden
+        ctx.schedule, ctx.bm, ctx.out_steps, ctx.kept_at = schedule_all, bm, out_steps, kept_at
         ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
-        ctx.key = (bm._key, bm._elem0, bm._entropy_dev)
         # (a stack of views, not index_select: building an index tensor is a blocking host->device copy that would wait
         #  for the forward launch)
-        return torch.stack([ys_all[k] for k in (0,) + tuple(out_steps)], dim=0)
+        return torch.stack([states[k if kept_at is None else kept_at[k]] for k in (0,) + tuple(out_steps)], dim=0)
 
     @staticmethod
     def backward(ctx, gys):
-        ys_all, w1_in, b1c, w2_in, rate, shift = ctx.saved_tensors
-        n_steps, rows, d = ys_all.shape[0] - 1, ys_all.shape[1], ys_all.shape[2]
-        hidden, schedule = ctx.hidden, ctx.schedule
-        dev = ys_all.device
+        states, w1_in, b1c, w2_in, b2c, rate, shift = ctx.saved_tensors
+        rows, d = states.shape[1], states.shape[2]
+        hidden, schedule, kept_at, bm = ctx.hidden, ctx.schedule, ctx.kept_at, ctx.bm
+        n_steps = schedule.n_steps
+        dev = states.device
         gys = _native.contiguous(gys)
         boundaries = np.asarray([0] + list(ctx.out_steps), dtype=np.int32)
-        grad_step = ctx.grad_step
-        per_step = rows * (d + 2 * hidden) * 4
-        chunk = int(max(1, min(n_steps, _MlpTrajectoryFn.STASH_BYTES // max(per_step, 1))))
+        chunk = _MlpTrajectoryFn._chunk(n_steps, rows, d, hidden)
         stash_lam = torch.empty((chunk, rows, d), dtype=torch.float32, device=dev)
         stash_hid = torch.empty((chunk, rows, hidden), dtype=torch.float32, device=dev)
         stash_delta = torch.empty((chunk, rows, hidden), dtype=torch.float32, device=dev)
+        rerun = None if kept_at is None else torch.empty((chunk + 1, rows, d), dtype=torch.float32, device=dev)
         lam = torch.zeros((rows, d), dtype=torch.float32, device=dev)
         row_rate, row_shift = torch.zeros_like(lam), torch.zeros_like(lam)
         g_w1 = torch.zeros((hidden, d), dtype=torch.float32, device=dev)
         g_w2 = torch.zeros((d, hidden), dtype=torch.float32, device=dev)
         g_b1 = torch.zeros(hidden, dtype=torch.float32, device=dev)
         g_b2 = torch.zeros(d, dtype=torch.float32, device=dev)
-        lib, dt_code, stream = _launch_env(ys_all)
-        key, elem0, entropy_dev = ctx.key
+        lib, dt_code, stream = _launch_env(states)
+        entropy_dev = bm._entropy_dev
         for k_hi in range(n_steps, 0, -chunk):
             k_lo = max(0, k_hi - chunk)
             n = k_hi - k_lo
+            if kept_at is None:
+                ys, ys_first = states, 0
+            else:                                   # the states of this chunk again, from the state kept at its start
+                rerun[0].copy_(states[kept_at[k_lo]])
+                trajectory_mlp_diag(rerun[1:n + 1], rerun[0], w1_in, b1c, w2_in, b2c, rate, shift, ctx.activation,
+                                    ctx.method, schedule.window(k_lo, k_hi), bm)
+                ys, ys_first = rerun, k_lo
             grad_last = int(np.searchsorted(boundaries, k_hi, side="right")) - 1
             code = lib.tsde_trajectory_mlp_diag_backward(
                 lam.data_ptr(), stash_lam.data_ptr(), stash_hid.data_ptr(), stash_delta.data_ptr(), row_rate.data_ptr(),
-                row_shift.data_ptr(), ys_all.data_ptr(), gys.data_ptr(), grad_step.data_ptr(), grad_last, rows, d,
-                hidden, w1_in.data_ptr(), b1c.data_ptr(), w2_in.data_ptr(), rate.data_ptr(), shift.data_ptr(),
-                int(ctx.activation), ctx.method, schedule.struct(), k_lo, k_hi, key, elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
-                dt_code, stream)
+                row_shift.data_ptr(), ys.data_ptr(), ys_first, gys.data_ptr(), ctx.grad_step.data_ptr(), grad_last,
+                rows, d, hidden, w1_in.data_ptr(), b1c.data_ptr(), w2_in.data_ptr(), rate.data_ptr(), shift.data_ptr(),
+                ctx.activation, ctx.method, schedule.struct(), k_lo, k_hi, bm._key, bm._elem0,
+                None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
             _native.check(code, "tsde_trajectory_mlp_diag_backward")
             flat_lam = stash_lam[:n].reshape(n * rows, d)
             flat_hid = stash_hid[:n].reshape(n * rows, hidden)
             flat_delta = stash_delta[:n].reshape(n * rows, hidden)
-            for g_w, g_b, a, b in ((g_w2, g_b2, flat_lam, flat_hid),
-                                   (g_w1, g_b1, flat_delta, ys_all[k_lo:k_hi].reshape(n * rows, d))):
+            flat_y = ys[k_lo - ys_first:k_hi - ys_first].reshape(n * rows, d)
+            for g_w, g_b, a, b in ((g_w2, g_b2, flat_lam, flat_hid), (g_w1, g_b1, flat_delta, flat_y)):
                 weight, bias = gram(a, b, column_sums=True)
                 g_w += weight
                 g_b += bias
