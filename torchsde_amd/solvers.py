@@ -276,7 +276,7 @@ class BaseSDESolver:
         None: a closed-form SDE handed to `sdeint` as is (closed_form.py) and this package's BrownianInterval
         generating the increments. Affine SDEs: the coefficient tensors, or ("differentiable", parameters...) when
         autograd is on (sensitivity kernel); perceptron drift: the ("mlp_diagonal", ...) spec, or
-        ("mlp_differentiable", activation, parameters...) when autograd is on (Euler: reverse-sweep kernel).
+        ("mlp_differentiable", activation, parameters...) when autograd is on (Euler, Milstein: reverse-sweep kernel).
         `options={"trajectory_kernel": False}` keeps the stepwise path."""
         from .sde import ForwardSDE
         if not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful:
@@ -292,7 +292,8 @@ class BaseSDESolver:
         if spec is None:
             return None
         if spec[0] == "mlp_diagonal":
-            # perceptron drift: sampling kernel on the matrix cores (forward only; Euler, Milstein, midpoint)
+            # perceptron drift on the matrix cores: sampling kernel (Euler, Milstein, midpoint); with autograd on,
+            # sampling kernel + reverse sweep (Euler, Milstein)
             code = self._trajectory_code()
             if code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT,
                             _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
