@@ -54,7 +54,9 @@ struct MlpArgs {
 // NW = waves per block: all of them share one copy of the weights in LDS.
 // MID: the two-stage Stratonovich midpoint scheme (midpoint.py:31-43) instead of the one-stage Euler / Milstein step.
 // FULL: d == D and h == H (no channel padding inside the kernel), which removes every per-tile bounds test.
-template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL>
+// IL: explicitly scheduled step (operand reads ahead of use, noise generation between the matrix instructions) for
+// one-stage schemes, unpadded shapes, 16-row waves: see the step loop. TSDE_MLP_INTERLEAVE=0 selects the plain form.
+template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL, bool IL = false>
 __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p) {
   using TL = Tile<R>;
   using acc_t = typename TL::acc_t;
@@ -75,8 +77,17 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
   const int dT = p.d, hT = p.h;
   for (int i = threadIdx.x; i < D * H; i += kThreads) {
     const int k1 = i / H, m1 = i % H, k2 = i / D, m2 = i % D;
-    W1s[k1 * S1 + m1] = (k1 < dT && m1 < hT) ? p.W1[k1 * hT + m1] : 0.0f;
-    W2s[k2 * S2 + m2] = (k2 < hT && m2 < dT) ? p.W2[k2 * dT + m2] : 0.0f;
+    const float w1 = (k1 < dT && m1 < hT) ? p.W1[k1 * hT + m1] : 0.0f;
+    const float w2 = (k2 < hT && m2 < dT) ? p.W2[k2 * dT + m2] : 0.0f;
+    if constexpr (IL) {
+      // K-contiguous rows (the transposes of the arrays above, same footprint): W1s[unit][channel] in H rows of S2,
+      // W2s[channel][unit] in D rows of S1 -- a lane's four K values of a quad are one 16-byte read
+      W1s[m1 * S2 + k1] = w1;
+      (W1s + H * S2)[m2 * S1 + k2] = w2;
+    } else {
+      W1s[k1 * S1 + m1] = w1;
+      W2s[k2 * S2 + m2] = w2;
+    }
   }
   for (int i = threadIdx.x; i < H; i += kThreads) b1s[i] = i < hT ? p.b1[i] : 0.0f;
   for (int i = threadIdx.x; i < D; i += kThreads) {
@@ -172,7 +183,86 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
       return acc;
     };
 
-    if constexpr (!MID) {
+    if constexpr (IL) {
+      // One stage, laid out as straight-line regions whose instruction order is spelled out to the scheduler with
+      // scheduling-group barriers. Weights sit K-contiguous in LDS, so the four K values a lane feeds to the four
+      // MFMAs of a quad are ONE 16-byte read; reads are issued two ahead of the MFMAs that consume them (left to
+      // itself hipcc emits read -> wait -> two MFMAs, exposing the LDS latency 128 times per step), and the vector
+      // work of tile t (Philox + Box-Muller, ~130 VALU instructions) is issued between the dependent MFMAs of the
+      // same tile's drift instead of in a phase of its own. d = hidden = 128: 11.6 -> 10.6 ms per 500-step solve.
+      static_assert(!MID && FULL && R == 16, "interleaved path: one-stage schemes, unpadded shapes, 16-row waves");
+      const float* W1t = W1s;                 // H rows of S2: [unit][channel]
+      const float* W2t = W1s + H * S2;        // D rows of S1: [channel][unit]
+      // layer 1: per tile of hidden units, TD 16-byte operand reads feed 4 TD MFMAs; the reads run two ahead of the
+      // MFMAs that consume them (the LDS latency hides behind matrix instructions instead of a wait before each pair)
+#pragma unroll
+      for (int th = 0; th < TH; ++th) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc_t h4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&W1t[(R * th + n) * S2 + R * t + 4 * part]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h4 = TL::mfma(a[r], y[t][r], h4);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int i = 0; i < TD - 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 bias = lds_quad(b1s, R * th + 4 * part);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[th][r] = activate<ACT>(h4[r] + bias[r]);
+      }
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const int ch = R * t + 4 * part;
+        uint64_t quad = quad_row + (ch >> 2);
+        asm volatile("" : "+v"(quad));
+        __builtin_amdgcn_sched_barrier(0);
+        acc_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int th = 0; th < TH; ++th) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&W2t[(R * t + n) * S1 + R * th + 4 * part]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = TL::mfma(a[r], hid[th][r], acc);
+        }
+        float z[4];
+        normal4<float>(key, quad, cell, 0, kStreamW, z);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // operand reads two ahead
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // the four MFMAs of one operand read
+          __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);   // sixteen VALU of the noise generation
+          if (i < TH - 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 b2q = lds_quad(b2s, ch), cq = lds_quad(cs, ch), eq = lds_quad(es, ch);
+        Pack<float, 4> o;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float yy = y[t][s];
+          const float f = acc[s] + b2q[s];
+          const float cc = cq[s];
+          const float g = cc * yy + eq[s];
+          const float w = z[s] * sw;
+          float yn;
+          if (p.method == TSDE_TRAJ_EULER) {
+            yn = drift_diffusion_update<float>(yy, f, g, w, dt, 1.0f);
+          } else {
+            const float v2 = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
+            yn = milstein_update<float>(yy, f, g, (g * v2) * cc, w, dt);
+          }
+          y[t][s] = yn;
+          o.v[s] = yn;
+        }
+        if (due) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (!MID) {
       // one stage; in place: tile t of the state is only read by its own update
       hidden_layer(y);
 #pragma unroll
@@ -268,20 +358,20 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
   }
 }
 
-template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL>
+template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL, bool IL = false>
 static hipError_t launch_mlp_full(const MlpArgs& p, hipStream_t s) {
   const size_t lds_bytes = MlpLds<R>::bytes(D, H);
   static bool configured = false;   // per instantiation
   if (!configured) {
     const hipError_t e =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL, IL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     configured = true;
   }
   const int64_t rows_per_block = NW * R;
   const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL>), dim3((unsigned)blocks), dim3(NW * 64),
+  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL, IL>), dim3((unsigned)blocks), dim3(NW * 64),
                      lds_bytes, s, p);
   return hipGetLastError();
 }
@@ -291,7 +381,16 @@ static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
   // (the two-stage scheme keeps the bounds tests even for unpadded shapes: without them hipcc's schedule of the wider
   //  basic blocks needs MORE registers -- 390 spilled dwords instead of 62 at d = hidden = 128)
   if constexpr (!MID) {
-    if (p.d == D && p.h == H) return launch_mlp_full<D, H, ACT, R, NW, MID, true>(p, s);
+    if (p.d == D && p.h == H) {
+      if constexpr (R == 16) {
+        static const bool interleave = [] {
+          const char* e = getenv("TSDE_MLP_INTERLEAVE");
+          return e == nullptr || atoi(e) != 0;
+        }();
+        if (interleave) return launch_mlp_full<D, H, ACT, R, NW, MID, true, true>(p, s);
+      }
+      return launch_mlp_full<D, H, ACT, R, NW, MID, true>(p, s);
+    }
   }
   return launch_mlp_full<D, H, ACT, R, NW, MID, false>(p, s);
 }
