@@ -599,6 +599,7 @@ class _TrajectoryFn(torch.autograd.Function):
         return ys
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # kernels, not torch ops: no graph of the backward pass exists
     def backward(ctx, gys):
         sens, = ctx.saved_tensors
         g = gys[1:].unsqueeze(1)                                      # (n_out, 1, rows, d)
@@ -714,6 +715,7 @@ class _MlpTrajectoryFn(torch.autograd.Function):
         return torch.stack([states[k if kept_at is None else kept_at[k]] for k in (0,) + tuple(out_steps)], dim=0)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # kernels, not torch ops: no graph of the backward pass exists
     def backward(ctx, gys):
         states, w1_in, b1c, w2_in, b2c, rate, shift = ctx.saved_tensors
         rows, d = states.shape[1], states.shape[2]
