@@ -83,11 +83,12 @@ WORKLOADS = {
         problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
         kid=8, trajectory=True, mfma_flops_per_traj_step=4 * 128 * 128,
         kernel="tsde_trajectory_mlp_diag<128, 128, softplus> (mlp_trajectory_kernel, v_mfma_f32_16x16x4_f32)"),
-    # The TRAINING step of the same neural SDE (forward + loss.backward() through the solver, Euler): sampling kernel
-    # writing every step, reverse sweep (three products per step on the matrix cores), tall-K weight-gradient products.
+    # The TRAINING step of the SDE of c5_adjoint_latent below (same parameter values, stated as the closed-form module):
+    # forward + loss.backward() through the solver, Euler: sampling kernel writing every step, reverse sweep (three
+    # products per step on the matrix cores), tall-K weight-gradient products.
     # Roofline: the reverse sweep, 3 * 2*d*hidden flop per trajectory-step.
     "c5_training_mlp_b32768_d128_s500": dict(
-        problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
+        problem="latent_diag_closed_form", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
         bytes_per_traj_step=0, kid=9, launches_per_step=1, trajectory=True, train=True,
         mfma_flops_per_traj_step=6 * 128 * 128,
         kernel="tsde_trajectory_mlp_diag_backward<128, 128, softplus> (mlp_backward_kernel, v_mfma_f32_16x16x4_f32)"),
@@ -123,6 +124,18 @@ def _make_problem(name, d, m, dev):
             def g(self, t, y):
                 return 0.1 * torch.sigmoid(self.w * y + self.b)
         return Latent().to(dev)
+    if name == "latent_diag_closed_form":
+        # the SAME SDE as "latent_diag" (same parameter values), stated as the closed-form module the trajectory kernels
+        # take: drift Linear-Softplus-Linear, diffusion 0.1 * sigmoid(w * y + b)
+        import torchsde_amd
+        latent = _make_problem("latent_diag", d, m, "cpu")
+        sde = torchsde_amd.MLPDriftDiagonalSDE(d, d, activation="softplus", diffusion="sigmoid", diff_scale=0.1,
+                                               diff_rate=latent.w.detach(), diff_shift=latent.b.detach())
+        with torch.no_grad():
+            for dst, src in ((sde.lin1, latent.net[0]), (sde.lin2, latent.net[2])):
+                dst.weight.copy_(src.weight)
+                dst.bias.copy_(src.bias)
+        return sde.to(dev)
     if name == "mlp_drift":
         import torchsde_amd
         torch.manual_seed(0)

@@ -265,17 +265,25 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
 #define TSDE_ACT_TANH 0
 #define TSDE_ACT_SOFTPLUS 1
+/* diffusion of the perceptron-drift kernels, per channel:
+ *   TSDE_DIFF_AFFINE   g = diff_rate * y + diff_shift
+ *   TSDE_DIFF_SIGMOID  g = diff_amp * sigmoid(diff_rate * y + diff_shift)   (the elementwise diffusion nets of
+ *                      examples/latent_sde_lorenz.py:137-148 reduced to one unit; diff_amp is ignored for AFFINE) */
+#define TSDE_DIFF_AFFINE 0
+#define TSDE_DIFF_SIGMOID 1
 int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t hidden, const void* w1,
                              const void* b1, const void* w2, const void* b2, const void* diff_rate,
-                             const void* diff_shift, int activation, int method, const tsde_traj_t* traj,
-                             uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+                             const void* diff_shift, int diff_kind, double diff_amp, int activation, int method,
+                             const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
+                             int dtype, void* stream);
 
 /* Reverse sweep of the gradient of tsde_trajectory_mlp_diag with method TSDE_TRAJ_EULER or TSDE_TRAJ_MILSTEIN_*:
  * back-propagation through the solver, i.e. what loss.backward() computes when autograd records the reference's
  * stepping loop (torchsde/_core/base_solver.py:114-134 with methods/euler.py:31-36 or milstein.py:52-74) for this SDE.
  * Processes steps k_hi-1 ... k_lo (call it on consecutive chunks, last steps first); with lam = dL/dy_{k+1}:
  *     u = W2^T lam,  delta = u * act'(W1 y_k + b1) * dt_k,   dL/dy_k = lam + W1^T delta + lam * diff_rate * dW_k
- *     (Milstein: + lam * diff_rate^2 * v_k, v = (dW^2 - dt)/2 for Ito, dW^2/2 for Stratonovich).
+ *     (Milstein: + lam * diff_rate^2 * v_k, v = (dW^2 - dt)/2 for Ito, dW^2/2 for Stratonovich; a sigmoid
+ *     diffusion -- Euler only -- replaces diff_rate by dg/dy = diff_amp s (1 - s) diff_rate).
  *   lam          (rows, d)  in: dL/dy at boundary k_hi WITHOUT the cotangent of an output at k_hi (the kernel adds
  *                           the cotangents of outputs at boundaries k_lo+1 ... k_hi itself); out: dL/dy at k_lo,
  *                           without the cotangent of an output at k_lo
@@ -297,9 +305,10 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
                                       void* row_shift, const void* ys_all, int32_t ys_first, const void* grad_ys,
                                       const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,
                                       int64_t hidden, const void* w1, const void* b1, const void* w2,
-                                      const void* diff_rate, const void* diff_shift, int activation, int method,
-                                      const tsde_traj_t* traj, int32_t k_lo, int32_t k_hi, uint64_t entropy,
-                                      uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+                                      const void* diff_rate, const void* diff_shift, int diff_kind, double diff_amp,
+                                      int activation, int method, const tsde_traj_t* traj, int32_t k_lo, int32_t k_hi,
+                                      uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                                      void* stream);
 
 /* partials[i] = sum over the i-th contiguous range of the k rows of a[row, :]^T b[row, :]   (a (k, m), b (k, n)
  * row-major, m, n <= 128; partials (blocks, m, n)) and, if colsum_partials (blocks, m) is not NULL, the column sums of

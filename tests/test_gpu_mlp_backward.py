@@ -11,13 +11,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _sde(d, hidden, activation, seed=0, scalar_diffusion=False, sde_type="ito"):
+def _sde(d, hidden, activation, seed=0, scalar_diffusion=False, sde_type="ito", diffusion="affine"):
     import torchsde_amd
     torch.manual_seed(seed)
-    rate = 0.05 if scalar_diffusion else 0.2 * torch.rand(d) - 0.1
+    sigmoid = diffusion == "sigmoid"
+    rate = 0.05 if scalar_diffusion else (2.0 if sigmoid else 0.2) * torch.rand(d) - 0.1
     shift = 0.2 if scalar_diffusion else 0.1 + 0.2 * torch.rand(d)
     sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, diff_rate=rate, diff_shift=shift,
-                                           sde_type=sde_type)
+                                           sde_type=sde_type, diffusion=diffusion, diff_scale=0.4 if sigmoid else 1.0)
     with torch.no_grad():       # asymmetric, well-scaled weights (a transposed operand cannot pass)
         sde.lin1.weight.copy_(torch.randn(hidden, d) / d ** 0.5)
         sde.lin2.weight.copy_(torch.randn(d, hidden) / hidden ** 0.5)
@@ -65,6 +66,59 @@ def test_gradients_match_autograd_of_the_stepwise_solve(d, hidden, activation):
     assert set(fast) == set(ref) == {"lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "diff_rate", "diff_shift",
                                      "y0"}
     _assert_gradients_close(fast, ref)
+
+
+@pytest.mark.parametrize("d,hidden", [(32, 32), (64, 64), (128, 128), (20, 52), (124, 120)])
+def test_sigmoid_diffusion_gradients_match_autograd_of_the_stepwise_solve(d, hidden):
+    """The latent-SDE-style module of BASELINE configs[4]: perceptron drift, g = scale * sigmoid(w*y + b)."""
+    B = 300
+    sde = _sde(d, hidden, "softplus", diffusion="sigmoid")
+    gen = torch.Generator().manual_seed(3)
+    y0 = (0.5 * torch.randn(B, d, generator=gen)).to(DEV)
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 4 * dt, 16 * dt], device=DEV)
+    weights = torch.randn(3, B, d, generator=gen).to(DEV)
+    ys_fast, fast = _gradients(sde, y0, ts, dt, 4, True, weights)
+    ys_ref, ref = _gradients(sde, y0, ts, dt, 4, False, weights)
+    torch.testing.assert_close(ys_fast, ys_ref, rtol=2e-4, atol=2e-5)
+    _assert_gradients_close(fast, ref)
+    # Milstein with this diffusion has no reverse sweep: stepwise path, gradients all the same
+    import torchsde_amd
+    y = y0.clone().requires_grad_(True)
+    bm = torchsde_amd.BrownianInterval(0.0, 16 * dt, size=(B, d), dtype=torch.float32, device=DEV, entropy=4)
+    ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method="milstein", dt=dt)
+    assert "MlpTrajectoryFn" not in type(ys.grad_fn).__name__
+
+
+def test_the_two_statements_of_the_latent_sde_of_the_benchmark_agree():
+    """bench.py's adjoint workload (a user module: nn.Sequential drift, 0.1 * sigmoid(w*y + b) diffusion) and its
+    training workload (the closed-form module with the same parameter values) are the same SDE: bit-identical on the
+    stepwise path, and the trajectory kernels reproduce the user module's solve and its autograd gradients."""
+    import bench
+    import torchsde_amd
+    d, B, steps, dt = 128, 512, 24, 2.0 ** -9
+    user = bench._make_problem("latent_diag", d, d, DEV)
+    closed = bench._make_problem("latent_diag_closed_form", d, d, DEV)
+    ts = torch.tensor([0.0, steps * dt], device=DEV)
+
+    def solve(sde, options):
+        y = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=torch.float32, device=DEV, entropy=21,
+                                           dt=dt)
+        sde.zero_grad()
+        ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method="euler", dt=dt, options=options)
+        ys[-1].sum().backward()
+        return ys.detach(), y.grad
+
+    ys_user, gy_user = solve(user, None)
+    ys_step, gy_step = solve(closed, {"trajectory_kernel": False})
+    assert torch.equal(ys_user, ys_step) and torch.equal(gy_user, gy_step)
+    ys_fast, gy_fast = solve(closed, None)
+    torch.testing.assert_close(ys_fast, ys_user, rtol=2e-4, atol=2e-5)
+    named = {"y0": (gy_fast, gy_user), "lin1.weight": (closed.lin1.weight.grad, user.net[0].weight.grad),
+             "lin2.bias": (closed.lin2.bias.grad, user.net[2].bias.grad), "diff_rate": (closed.diff_rate.grad, user.w.grad),
+             "diff_shift": (closed.diff_shift.grad, user.b.grad)}
+    _assert_gradients_close({k: v[0] for k, v in named.items()}, {k: v[1] for k, v in named.items()})
 
 
 @pytest.mark.parametrize("activation", ["tanh", "softplus"])
@@ -257,11 +311,13 @@ def test_c_abi_rejects_unsupported_arguments():
     traj = _native.Traj()
     ptr = x.data_ptr()
     for d, hidden, fragment in ((6, 32, b"multiples of 4"), (32, 30, b"multiples of 4"), (132, 32, b"multiples of 4")):
-        args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, d, hidden) + (ptr,) * 5 + (0, 0, traj, 0, 0, 1, 0, None, 0, None)
+        args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, d, hidden) + (ptr,) * 5 + (0, 1.0, 0, 0, traj, 0, 0, 1, 0, None, 0, None)
         assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and fragment in lib.tsde_last_error()
-    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (0, 0, traj, 0, 5, 1, 0, None, 0, None)
+    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (0, 1.0, 0, 0, traj, 0, 5, 1, 0, None, 0, None)
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"k_hi" in lib.tsde_last_error()
-    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (0, 3, traj, 0, 0, 1, 0, None, 0, None)   # midpoint
+    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (0, 1.0, 0, 3, traj, 0, 0, 1, 0, None, 0, None)   # midpoint
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"Euler or Milstein" in lib.tsde_last_error()
+    args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (1, 1.0, 0, 1, traj, 0, 0, 1, 0, None, 0, None)
+    assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"sigmoid with Euler" in lib.tsde_last_error()
     assert lib.tsde_gram_partials(ptr, None, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
     assert b"[1, 128]" in lib.tsde_last_error()

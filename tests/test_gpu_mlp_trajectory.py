@@ -8,11 +8,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _sde(d, hidden, activation, sde_type="ito", seed=0):
+def _sde(d, hidden, activation, sde_type="ito", seed=0, diffusion="affine"):
     import torchsde_amd
     torch.manual_seed(seed)
-    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, sde_type=sde_type,
-                                           diff_rate=0.2 * torch.rand(d) - 0.1, diff_shift=0.1 + 0.2 * torch.rand(d))
+    sigmoid = diffusion == "sigmoid"
+    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=activation, sde_type=sde_type, diffusion=diffusion,
+                                           diff_scale=0.4 if sigmoid else 1.0,
+                                           diff_rate=(2.0 if sigmoid else 0.2) * torch.rand(d) - 0.1,
+                                           diff_shift=0.1 + 0.2 * torch.rand(d))
     with torch.no_grad():       # asymmetric, well-scaled weights (a transposed operand cannot pass)
         sde.lin1.weight.copy_(torch.randn(hidden, d) / d ** 0.5)
         sde.lin2.weight.copy_(torch.randn(d, hidden) / hidden ** 0.5)
@@ -42,6 +45,21 @@ def test_matches_stepwise_path(method, sde_type, d, hidden, activation):
     fast = _solve(sde, y0, ts, method, dt, 3, trajectory=True)
     ref = _solve(sde, y0, ts, method, dt, 3, trajectory=False)
     assert fast.shape == (4, B, d) and torch.isfinite(fast).all() and torch.equal(fast[0], y0)
+    torch.testing.assert_close(fast, ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("d,hidden", [(64, 64), (128, 128), (20, 50)])
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("milstein", "ito"), ("milstein", "stratonovich"),
+                                             ("midpoint", "stratonovich")])
+def test_sigmoid_diffusion_matches_stepwise_path(method, sde_type, d, hidden):
+    """g = diff_scale * sigmoid(diff_rate * y + diff_shift): the per-channel diffusion of latent-SDE models."""
+    B = 300
+    sde = _sde(d, hidden, "softplus", sde_type=sde_type, diffusion="sigmoid")
+    y0 = (0.5 * torch.randn(B, d, generator=torch.Generator().manual_seed(1))).to(DEV)
+    dt = 2.0 ** -5
+    ts = torch.tensor([0.0, 4 * dt, 16 * dt], device=DEV)
+    fast = _solve(sde, y0, ts, method, dt, 3, trajectory=True)
+    ref = _solve(sde, y0, ts, method, dt, 3, trajectory=False)
     torch.testing.assert_close(fast, ref, rtol=2e-4, atol=2e-5)
 
 
@@ -86,7 +104,7 @@ def test_c_abi_rejects_unsupported_shapes():
     x = torch.zeros(64, 48, device=DEV)
     traj = _native.Traj()
     for d, hidden in ((6, 32), (132, 32), (32, 129)):
-        args = (x.data_ptr(),) * 2 + (64, d, hidden) + (x.data_ptr(),) * 6 + (0, 0, traj, 1, 0, None, 0, None)
+        args = (x.data_ptr(),) * 2 + (64, d, hidden) + (x.data_ptr(),) * 6 + (0, 1.0, 0, 0, traj, 1, 0, None, 0, None)
         assert lib.tsde_trajectory_mlp_diag(*args) != 0 and b"multiple of 4" in lib.tsde_last_error()
 
 

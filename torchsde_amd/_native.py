@@ -17,6 +17,7 @@ KID_RHEUN, KID_TRAJECTORY, KID_MLP_BACKWARD = 7, 8, 9
 ERROR_NORM_WORKSPACE = 1024
 TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1
+DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 
 _c_i64 = ctypes.c_int64
@@ -104,11 +105,11 @@ SIGNATURES = {
                                                   _c_ptr, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                                   _c_ptr]),
     "tsde_trajectory_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
-                                          _c_ptr, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
+                                          _c_ptr, _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                           _c_ptr]),
     "tsde_trajectory_mlp_diag_backward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i32, _c_ptr,
                                                    _c_ptr, _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
-                                                   _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
+                                                   _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
                                                    _c_ptr, _c_int, _c_ptr]),
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),

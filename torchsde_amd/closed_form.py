@@ -58,15 +58,18 @@ class AffineDiagonalSDE(nn.Module):
 
 
 class MLPDriftDiagonalSDE(nn.Module):
-    """Diagonal-noise neural SDE with a two-layer perceptron drift shared by the batch and affine diffusion:
+    """Diagonal-noise neural SDE with a two-layer perceptron drift shared by the batch and an elementwise diffusion:
 
-        f(t, y) = lin2(act(lin1(y)))          g(t, y) = diff_rate * y + diff_shift
+        f(t, y) = lin2(act(lin1(y)))          g(t, y) = diff_rate * y + diff_shift                         ("affine")
+                                              g(t, y) = diff_scale * sigmoid(diff_rate * y + diff_shift)   ("sigmoid":
+                                              the per-channel diffusion of latent-SDE models, bounded and positive;
+                                              `diff_scale` is a fixed number, not a parameter)
 
     An ordinary module for every solver, for autograd and for ``sdeint_adjoint`` (train it as usual). For SAMPLING --
     forward solves without autograd, Euler, Milstein or midpoint, float32, ``d`` a multiple of 4, ``d, hidden <= 128``
     -- ``sdeint`` runs the whole solve in one launch of ``tsde_trajectory_mlp_diag``: the state stays in registers, the
-    weights in LDS, both layers on the f32 matrix cores. For TRAINING through ``sdeint`` (autograd on, Euler or
-    Milstein, ``hidden`` a multiple of 4) the backward pass is ``tsde_trajectory_mlp_diag_backward`` + ``tsde_gram_partials``:
+    weights in LDS, both layers on the f32 matrix cores. For TRAINING through ``sdeint`` (autograd on, Euler -- with the
+    affine diffusion also Milstein --, ``hidden`` a multiple of 4) the backward pass is ``tsde_trajectory_mlp_diag_backward`` + ``tsde_gram_partials``:
     the gradients back-propagation through the stepwise solver gives, without a tape (the forward launch keeps the
     state of every step in HBM: steps x batch x d floats). Results agree with the stepwise path up to the summation
     order of the matrix products (same Brownian path).
@@ -75,8 +78,11 @@ class MLPDriftDiagonalSDE(nn.Module):
     _ACTIVATIONS = {"tanh": (0, torch.tanh), "softplus": (1, nn.functional.softplus)}
 
     def __init__(self, d, hidden, activation="softplus", diff_rate=0.0, diff_shift=0.1, sde_type="ito", dtype=None,
-                 device=None):
+                 device=None, diffusion="affine", diff_scale=1.0):
         super().__init__()
+        if diffusion not in ("affine", "sigmoid"):
+            raise ValueError(f"Expected diffusion 'affine' or 'sigmoid', got {diffusion!r}.")
+        self.diffusion, self.diff_scale = diffusion, float(diff_scale)
         if sde_type not in ("ito", "stratonovich"):
             raise ValueError(f"Expected sde_type 'ito' or 'stratonovich', got {sde_type!r}.")
         if activation not in self._ACTIVATIONS:
@@ -94,14 +100,16 @@ class MLPDriftDiagonalSDE(nn.Module):
         return self.lin2(self._ACTIVATIONS[self.activation][1](self.lin1(y)))
 
     def g(self, t, y):
-        return self.diff_rate * y + self.diff_shift
+        u = self.diff_rate * y + self.diff_shift
+        return self.diff_scale * torch.sigmoid(u) if self.diffusion == "sigmoid" else u
 
     def closed_form_parameters(self):
         """The six parameters the differentiable trajectory path returns gradients for."""
         return (self.lin1.weight, self.lin1.bias, self.lin2.weight, self.lin2.bias, self.diff_rate, self.diff_shift)
 
     def closed_form(self, d, dtype, device):
-        """("mlp_diagonal", W1 (d, hidden) input-major, b1, W2 (hidden, d), b2, diff_rate (d,), diff_shift (d,), act) for
+        """("mlp_diagonal", W1 (d, hidden) input-major, b1, W2 (hidden, d), b2, diff_rate (d,), diff_shift (d,), act,
+        (diffusion kind, diff_scale)) for
         the sampling kernel, or None when it does not apply (then the stepwise path runs)."""
         hidden = self.lin1.out_features
         params = list(self.parameters())
@@ -116,4 +124,4 @@ class MLPDriftDiagonalSDE(nn.Module):
             coefs.append(p.detach().reshape(-1).expand(d).contiguous())
         return ("mlp_diagonal", self.lin1.weight.detach().t().contiguous(), self.lin1.bias.detach().contiguous(),
                 self.lin2.weight.detach().t().contiguous(), self.lin2.bias.detach().contiguous(), coefs[0], coefs[1],
-                self._ACTIVATIONS[self.activation][0])
+                self._ACTIVATIONS[self.activation][0], (1 if self.diffusion == "sigmoid" else 0, self.diff_scale))

@@ -371,9 +371,11 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
 
 int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t hidden, const void* w1,
                              const void* b1, const void* w2, const void* b2, const void* diff_rate,
-                             const void* diff_shift, int activation, int method, const tsde_traj_t* traj,
-                             uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+                             const void* diff_shift, int diff_kind, double diff_amp, int activation, int method,
+                             const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
+                             int dtype, void* stream) {
   const char* where = "tsde_trajectory_mlp_diag";
+  if (diff_kind != TSDE_DIFF_AFFINE && diff_kind != TSDE_DIFF_SIGMOID) return bad_arg(where, "unknown diffusion kind");
   if (!ys || !y0 || !w1 || !b1 || !w2 || !b2 || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
@@ -393,7 +395,7 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
   const hipStream_t s = (hipStream_t)stream;
   ProfScope p(TSDE_KID_TRAJECTORY, s);
   return fail(tsde::launch_trajectory_mlp_diag(ys, y0, rows, d, hidden, w1, b1, w2, b2, diff_rate, diff_shift,
-                                               activation, method, traj, make_key(entropy, elem0), entropy_dev, s),
+                                               diff_kind, diff_amp, activation, method, traj, make_key(entropy, elem0), entropy_dev, s),
               where);
 }
 
@@ -401,15 +403,18 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
                                       void* row_shift, const void* ys_all, int32_t ys_first, const void* grad_ys,
                                       const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,
                                       int64_t hidden, const void* w1, const void* b1, const void* w2,
-                                      const void* diff_rate, const void* diff_shift, int activation, int method,
-                                      const tsde_traj_t* traj, int32_t k_lo, int32_t k_hi, uint64_t entropy,
-                                      uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+                                      const void* diff_rate, const void* diff_shift, int diff_kind, double diff_amp,
+                                      int activation, int method, const tsde_traj_t* traj, int32_t k_lo, int32_t k_hi,
+                                      uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                                      void* stream) {
   const char* where = "tsde_trajectory_mlp_diag_backward";
   if (!lam || !stash_lam || !stash_hid || !stash_delta || !row_rate || !row_shift || !ys_all || !w1 || !b1 || !w2 ||
       !diff_rate || !diff_shift || !traj)
     return bad_arg(where, "null argument");
   if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MILSTEIN_ITO && method != TSDE_TRAJ_MILSTEIN_STRAT)
     return bad_arg(where, "method must be Euler or Milstein");
+  if (diff_kind != TSDE_DIFF_AFFINE && !(diff_kind == TSDE_DIFF_SIGMOID && method == TSDE_TRAJ_EULER))
+    return bad_arg(where, "diffusion kind must be affine, or sigmoid with Euler");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
   if (d < 4 || d > 128 || d % 4 != 0 || hidden < 4 || hidden > 128 || hidden % 4 != 0)
@@ -429,7 +434,8 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
   ProfScope p(TSDE_KID_MLP_BACKWARD, s);
   return fail(tsde::launch_trajectory_mlp_diag_backward(lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift,
                                                         ys_all, ys_first, grad_ys, grad_step, grad_last, rows, d, hidden, w1, b1,
-                                                        w2, diff_rate, diff_shift, activation, method, traj, k_lo, k_hi,
+                                                        w2, diff_rate, diff_shift, diff_kind, diff_amp, activation, method,
+                                                        traj, k_lo, k_hi,
                                                         make_key(entropy, elem0), entropy_dev, s),
               where);
 }

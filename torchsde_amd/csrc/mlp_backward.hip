@@ -49,6 +49,8 @@ struct MlpBackArgs {
   const float* W2;          // (h, d)
   const float *c, *e;       // (d) diffusion g = c*y + e (e is only read by the Milstein terms)
   int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT
+  int32_t diff_kind;        // TSDE_DIFF_AFFINE / TSDE_DIFF_SIGMOID (the latter with Euler only)
+  float diff_amp;
   const float* rows;        // (n_steps, 8)
   const uint32_t* cells;
   int64_t B;
@@ -197,16 +199,18 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       // registers than the kernel has
       const f32x4 yt = load_tile(p.ys_all + (int64_t)(k - p.ys_first) * p.B * dT, t);
       const f32x4 cq = lds_quad(cs, ch);
+      const f32x4 eq = lds_quad(es, ch);
       if (p.method == TSDE_TRAJ_EULER) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float lw = lam[t][r] * (zn[r] * sw);
+          // dg/de = q, dg/dc = q y, dg/dy = q c   (affine: q = 1)
+          const float q = diffusion_value(p.diff_kind == TSDE_DIFF_SIGMOID, p.diff_amp, cq[r], eq[r], yt[r]).q;
+          const float lw = (lam[t][r] * (zn[r] * sw)) * q;
           acc_shift[t][r] += lw;
           acc_rate[t][r] += lw * yt[r];
           lam[t][r] += lw * cq[r];
         }
       } else {
-        const f32x4 eq = lds_quad(es, ch);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float w = zn[r] * sw, cc = cq[r];
@@ -290,8 +294,8 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
                                                void* row_rate, void* row_shift, const void* ys_all,
                                                int32_t ys_first, const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
                                                int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
-                                               const void* W2, const void* c, const void* e, int act, int method,
-                                               const tsde_traj_t* tr,
+                                               const void* W2, const void* c, const void* e, int diff_kind,
+                                               double diff_amp, int act, int method, const tsde_traj_t* tr,
                                                int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
                                                hipStream_t s) {
   MlpBackArgs p;
@@ -312,6 +316,8 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
   p.c = (const float*)c;
   p.e = (const float*)e;
   p.method = method;
+  p.diff_kind = diff_kind;
+  p.diff_amp = (float)diff_amp;
   p.rows = (const float*)tr->step_rows;
   p.cells = tr->cells;
   p.B = rows;

@@ -46,6 +46,8 @@ struct MlpArgs {
   int32_t d, h;             // true state / hidden sizes (d % 4 == 0); the kernel pads them to its tile sizes D, H
   int32_t n_steps, n_out;
   int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT / _MIDPOINT
+  int32_t diff_kind;        // TSDE_DIFF_AFFINE: g = c*y + e;  TSDE_DIFF_SIGMOID: g = diff_amp * sigmoid(c*y + e)
+  float diff_amp;
   NoiseKey key;
   const uint64_t* key_dev;
 };
@@ -130,6 +132,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
     }
   }
 
+  const bool sigmoid_diffusion = p.diff_kind == TSDE_DIFF_SIGMOID;
   int jout = 0;
   for (int k = 0; k < p.n_steps; ++k) {
     const float* srow = p.rows + (int64_t)k * 8;
@@ -247,14 +250,15 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
           const float yy = y[t][s];
           const float f = acc[s] + b2q[s];
           const float cc = cq[s];
-          const float g = cc * yy + eq[s];
+          const DiffusionValue dv = diffusion_value(false, 0.0f, cc, eq[s], yy);     // affine only on this path
+          const float g = dv.g;
           const float w = z[s] * sw;
           float yn;
           if (p.method == TSDE_TRAJ_EULER) {
             yn = drift_diffusion_update<float>(yy, f, g, w, dt, 1.0f);
           } else {
             const float v2 = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
-            yn = milstein_update<float>(yy, f, g, (g * v2) * cc, w, dt);
+            yn = milstein_update<float>(yy, f, g, (g * v2) * (dv.q * cc), w, dt);
           }
           y[t][s] = yn;
           o.v[s] = yn;
@@ -285,14 +289,15 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             const float yy = y[t][r];
             const float f = acc[r] + b2q[s];
             const float cc = cq[s];
-            const float g = cc * yy + eq[s];
+            const DiffusionValue dv = diffusion_value(sigmoid_diffusion, p.diff_amp, cc, eq[s], yy);
+            const float g = dv.g;
             const float w = z[s] * sw;
             float yn;
             if (p.method == TSDE_TRAJ_EULER) {
               yn = drift_diffusion_update<float>(yy, f, g, w, dt, 1.0f);
             } else {
               const float v2 = milstein_v<float>(w, dt, 0.5f, p.method == TSDE_TRAJ_MILSTEIN_ITO);
-              yn = milstein_update<float>(yy, f, g, (g * v2) * cc, w, dt);
+              yn = milstein_update<float>(yy, f, g, (g * v2) * (dv.q * cc), w, dt);
             }
             y[t][r] = yn;
             o.v[s] = yn;
@@ -324,7 +329,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             const float yy = y[t][r];
             const float w = z[s] * sw;
             wk[t][r] = w;
-            yp[t][r] = drift_diffusion_update<float>(yy, acc[r] + b2q[s], cq[s] * yy + eq[s], w, half_dt, 0.5f);
+            yp[t][r] = drift_diffusion_update<float>(yy, acc[r] + b2q[s],
+                                                     diffusion_value(sigmoid_diffusion, p.diff_amp, cq[s], eq[s], yy).g, w,
+                                                     half_dt, 0.5f);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -342,8 +349,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int r = 4 * q + s;
-            const float yn = drift_diffusion_update<float>(y[t][r], acc[r] + b2q[s], cq[s] * yp[t][r] + eq[s],
-                                                           wk[t][r], dt, 1.0f);
+            const float yn = drift_diffusion_update<float>(
+                y[t][r], acc[r] + b2q[s], diffusion_value(sigmoid_diffusion, p.diff_amp, cq[s], eq[s], yp[t][r]).g, wk[t][r],
+                dt, 1.0f);
             y[t][r] = yn;
             o.v[s] = yn;
           }
@@ -387,7 +395,7 @@ static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
           const char* e = getenv("TSDE_MLP_INTERLEAVE");
           return e == nullptr || atoi(e) != 0;
         }();
-        if (interleave) return launch_mlp_full<D, H, ACT, R, NW, MID, true, true>(p, s);
+        if (interleave && p.diff_kind == TSDE_DIFF_AFFINE) return launch_mlp_full<D, H, ACT, R, NW, MID, true, true>(p, s);
       }
       return launch_mlp_full<D, H, ACT, R, NW, MID, true>(p, s);
     }
@@ -431,8 +439,8 @@ static hipError_t launch_mlp_h(const MlpArgs& p, int act, hipStream_t s) {
 
 hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t h, const void* W1,
                                       const void* b1, const void* W2, const void* b2, const void* c, const void* e,
-                                      int act, int method, const tsde_traj_t* tr, NoiseKey key,
-                                      const uint64_t* key_dev, hipStream_t s) {
+                                      int diff_kind, double diff_amp, int act, int method, const tsde_traj_t* tr,
+                                      NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
   MlpArgs p;
   p.ys = (float*)ys;
   p.y0 = (const float*)y0;
@@ -452,6 +460,8 @@ hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, in
   p.n_steps = tr->n_steps;
   p.n_out = tr->n_out;
   p.method = method;
+  p.diff_kind = diff_kind;
+  p.diff_amp = (float)diff_amp;
   p.key = key;
   p.key_dev = key_dev;
   if (rows <= 0 || tr->n_steps <= 0) return hipSuccess;

@@ -96,15 +96,15 @@ hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, i
 // mlp_trajectory.hip
 hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t h, const void* W1,
                                       const void* b1, const void* W2, const void* b2, const void* c, const void* e,
-                                      int act, int method, const tsde_traj_t* tr, NoiseKey key,
-                                      const uint64_t* key_dev, hipStream_t s);
+                                      int diff_kind, double diff_amp, int act, int method, const tsde_traj_t* tr,
+                                      NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 // mlp_backward.hip
 hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta,
                                                void* row_rate, void* row_shift, const void* ys_all,
                                                int32_t ys_first, const void* grad_ys, const int32_t* grad_step, int32_t grad_last,
                                                int64_t rows, int64_t d, int64_t h, const void* W1, const void* b1,
-                                               const void* W2, const void* c, const void* e, int act, int method,
-                                               const tsde_traj_t* tr,
+                                               const void* W2, const void* c, const void* e, int diff_kind,
+                                               double diff_amp, int act, int method, const tsde_traj_t* tr,
                                                int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
                                                hipStream_t s);
 hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, const void* Bm, int64_t K, int64_t M,

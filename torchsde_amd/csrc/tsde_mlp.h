@@ -78,6 +78,24 @@ TSDE_D f32x4 lds_quad(const float* base, int index) {
   return *reinterpret_cast<const f32x4*>(base + index);
 }
 
+// Diagonal diffusion of one channel and its derivative w.r.t. the shift e (q: then dg/dc = q*y and dg/dy = q*c):
+//   affine   g = c*y + e                      q = 1
+//   sigmoid  g = amp * sigmoid(c*y + e)       q = amp * s * (1 - s)
+// `sigmoid` is uniform over the launch (a scalar branch); the explicitly scheduled sampling kernel passes a constant.
+struct DiffusionValue {
+  float g, q;
+};
+TSDE_D DiffusionValue diffusion_value(bool sigmoid, float amp, float c, float e, float y) {
+  const float u = c * y + e;
+  DiffusionValue v = {u, 1.0f};
+  if (sigmoid) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+    v.g = amp * s;
+    v.q = v.g * (1.0f - s);
+  }
+  return v;
+}
+
 template <int R>
 struct MlpLds {
   static constexpr int kPad = (R == 16) ? 4 : 0;

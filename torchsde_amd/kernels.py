@@ -558,7 +558,7 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
     return ys
 
 
-def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, method, schedule, bm):
+def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, diffusion, method, schedule, bm):
     """All steps of a diagonal SDE with a two-layer perceptron drift in one launch (``tsde_trajectory_mlp_diag``);
     writes ys[j] for the schedule's outputs, which must all sit on step boundaries."""
     tensors = (ys, y0, w1, b1, w2, b2, diff_rate, diff_shift)
@@ -573,7 +573,8 @@ def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activatio
     entropy_dev = bm._entropy_dev
     code = lib.tsde_trajectory_mlp_diag(
         ys.data_ptr(), y0.data_ptr(), rows, d, hidden, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-        diff_rate.data_ptr(), diff_shift.data_ptr(), int(activation), int(method), schedule.struct(), bm._key,
+        diff_rate.data_ptr(), diff_shift.data_ptr(), int(diffusion[0]), float(diffusion[1]), int(activation),
+        int(method), schedule.struct(), bm._key,
         bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
     _native.check(code, "tsde_trajectory_mlp_diag")
     return ys
@@ -680,7 +681,7 @@ class _MlpTrajectoryFn(torch.autograd.Function):
         return int(max(1, min(n_steps, _MlpTrajectoryFn.STASH_BYTES // max(per_step, 1))))
 
     @staticmethod
-    def forward(ctx, activation, method, schedule_all, out_steps, bm, y0, w1, b1, w2, b2, rate, shift):
+    def forward(ctx, activation, diffusion, method, schedule_all, out_steps, bm, y0, w1, b1, w2, b2, rate, shift):
         rows, d = y0.shape
         hidden, n_steps = b1.numel(), schedule_all.n_steps
         y0c = _native.contiguous(y0.detach())
@@ -703,11 +704,12 @@ class _MlpTrajectoryFn(torch.autograd.Function):
                                                  [(0.0, 1.0)] * len(marks), y0.device, y0.dtype)
         states = torch.empty((schedule.n_out + 1, rows, d), dtype=y0.dtype, device=y0.device)
         states[0].copy_(y0c)
-        trajectory_mlp_diag(states[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, method, schedule,
-                            bm)
+        trajectory_mlp_diag(states[1:], y0c, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1], activation, diffusion, method,
+                            schedule, bm)
         ctx.grad_step = _boundary_table(out_steps, y0.device)
         ctx.save_for_backward(states, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1])
         ctx.method, ctx.activation, ctx.hidden = int(method), int(activation), hidden
+        ctx.diffusion = (int(diffusion[0]), float(diffusion[1]))
         ctx.schedule, ctx.bm, ctx.out_steps, ctx.kept_at = schedule_all, bm, out_steps, kept_at
         ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
         # (a stack of views, not index_select: building an index tensor is a blocking host->device copy that would wait
@@ -745,14 +747,15 @@ class _MlpTrajectoryFn(torch.autograd.Function):
             else:                                   # the states of this chunk again, from the state kept at its start
                 rerun[0].copy_(states[kept_at[k_lo]])
                 trajectory_mlp_diag(rerun[1:n + 1], rerun[0], w1_in, b1c, w2_in, b2c, rate, shift, ctx.activation,
-                                    ctx.method, schedule.window(k_lo, k_hi), bm)
+                                    ctx.diffusion, ctx.method, schedule.window(k_lo, k_hi), bm)
                 ys, ys_first = rerun, k_lo
             grad_last = int(np.searchsorted(boundaries, k_hi, side="right")) - 1
             code = lib.tsde_trajectory_mlp_diag_backward(
                 lam.data_ptr(), stash_lam.data_ptr(), stash_hid.data_ptr(), stash_delta.data_ptr(), row_rate.data_ptr(),
                 row_shift.data_ptr(), ys.data_ptr(), ys_first, gys.data_ptr(), ctx.grad_step.data_ptr(), grad_last,
                 rows, d, hidden, w1_in.data_ptr(), b1c.data_ptr(), w2_in.data_ptr(), rate.data_ptr(), shift.data_ptr(),
-                ctx.activation, ctx.method, schedule.struct(), k_lo, k_hi, bm._key, bm._elem0,
+                ctx.diffusion[0], ctx.diffusion[1], ctx.activation, ctx.method, schedule.struct(), k_lo, k_hi, bm._key,
+                bm._elem0,
                 None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
             _native.check(code, "tsde_trajectory_mlp_diag_backward")
             flat_lam = stash_lam[:n].reshape(n * rows, d)
@@ -763,20 +766,20 @@ class _MlpTrajectoryFn(torch.autograd.Function):
                 weight, bias = gram(a, b, column_sums=True)
                 g_w += weight
                 g_b += bias
-        grad_y0 = lam + gys[0] if ctx.needs_input_grad[5] else None
+        grad_y0 = lam + gys[0] if ctx.needs_input_grad[6] else None
         diffusion = []
         for acc, shape in zip((row_rate, row_shift), ctx.param_shapes):
             per_channel = acc.sum(dim=0)
             diffusion.append(per_channel.reshape(shape) if int(np.prod(shape, dtype=np.int64)) == d and len(shape) == 1
                              else per_channel.sum().reshape(shape))
-        return (None, None, None, None, None, grad_y0, g_w1, g_b1, g_w2, g_b2, diffusion[0], diffusion[1])
+        return (None, None, None, None, None, None, grad_y0, g_w1, g_b1, g_w2, g_b2, diffusion[0], diffusion[1])
 
 
-def trajectory_mlp_diag_differentiable(y0, module_params, activation, method, schedule_all, out_steps, bm):
+def trajectory_mlp_diag_differentiable(y0, module_params, activation, diffusion, method, schedule_all, out_steps, bm):
     """ys (len(out_steps) + 1, rows, d) with a grad_fn towards y0 and the six parameters
     (lin1.weight, lin1.bias, lin2.weight, lin2.bias, diff_rate, diff_shift)."""
-    return _MlpTrajectoryFn.apply(activation, method, schedule_all, tuple(int(k) for k in out_steps), bm, y0,
-                                  *module_params)
+    return _MlpTrajectoryFn.apply(activation, tuple(diffusion), method, schedule_all, tuple(int(k) for k in out_steps),
+                                  bm, y0, *module_params)
 
 
 # ---- in-library event timing (bench.py's roofline) ----------------------------------------------------------

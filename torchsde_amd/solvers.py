@@ -303,10 +303,11 @@ class BaseSDESolver:
                 # parameters, so a subclass with more of them (or shapes the sweep does not take) goes stepwise
                 own = list(base.closed_form_parameters())
                 hidden = own[1].numel()
-                if (code == _native.TRAJ_MIDPOINT or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30
+                sigmoid = spec[-1][0] == _native.DIFF_SIGMOID         # its reverse sweep exists for Euler only
+                if (code == _native.TRAJ_MIDPOINT or (sigmoid and code != _native.TRAJ_EULER) or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30
                         or {id(p) for p in base.parameters()} != {id(p) for p in own}):
                     return None
-                return ("mlp_differentiable", spec[-1]) + tuple(own)
+                return ("mlp_differentiable", spec[-2], spec[-1]) + tuple(own)
             return spec
         if spec[0] != "affine_diagonal":
             return None
@@ -351,8 +352,8 @@ class BaseSDESolver:
             every_step = list(range(1, grid.n_steps + 1))
             schedule_all = K.TrajectorySchedule.cached(rows, cells, every_step, [(0.0, 1.0)] * grid.n_steps, y0.device,
                                                        y0.dtype)
-            return K.trajectory_mlp_diag_differentiable(y0, coefficients[2:], coefficients[1], self._trajectory_code(),
-                                                        schedule_all, out_step, bm)
+            return K.trajectory_mlp_diag_differentiable(y0, coefficients[3:], coefficients[1], coefficients[2],
+                                                        self._trajectory_code(), schedule_all, out_step, bm)
         schedule = K.TrajectorySchedule.cached(rows, cells, out_step, out_w, y0.device, y0.dtype)
         if coefficients[0] == "mlp_diagonal":
             if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
