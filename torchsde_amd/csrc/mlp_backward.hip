@@ -371,43 +371,52 @@ __global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials,
   const int64_t k1 = k0 + rows_per_block < K ? k0 + rows_per_block : K;
   const int ntiles = k1 > k0 ? (int)((k1 - k0 + kGramRows - 1) / kGramRows) : 0;
 
+  // Loader: a slot is 16 bytes of one tile row. `fetch` only ISSUES the load (from a clamped, always valid address);
+  // whether the slot lies inside the tile is applied when the registers are copied to LDS, one tile of matrix
+  // instructions later -- anything that touches the loaded value earlier (a select, the column sum) would put the
+  // wait for the load in front of those instructions.
   f32x4 ra[LA], rb[LB];
-  auto fetch = [&](const float* __restrict__ src, int32_t width, int q_per_row, int slot, int64_t kk) {
+  bool in_a[LA], in_b[LB];
+  auto fetch = [&](const float* __restrict__ src, int32_t width, int q_per_row, int slot, int64_t kk, bool& inside) {
     const int r = slot / q_per_row, c = 4 * (slot % q_per_row);
     const int64_t krow = kk + r;
-    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (r < kGramRows && krow < k1) {
-      const float* q = src + krow * width + c;
-      if constexpr (VEC) {
-        if (c < width) v = *reinterpret_cast<const f32x4*>(q);
-      } else {
+    inside = r < kGramRows && krow < k1 && c < width;
+    if constexpr (VEC) {
+      const int64_t row_c = krow < K ? krow : K - 1;        // (k1 > k0 >= 0 here: K - 1 is a valid row)
+      const int col_c = c < width ? c : width - 4;
+      return *reinterpret_cast<const f32x4*>(src + row_c * width + col_c);
+    } else {
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (inside) {
+        const float* q = src + krow * width + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (c + e < width) v[e] = q[e];
       }
+      return v;
     }
-    return v;
   };
   auto load_tile = [&](int tile) {
     const int64_t kk = k0 + (int64_t)tile * kGramRows;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      ra[i] = fetch(A, M, QA, tid + 512 * i, kk);
-      csum += ra[i];
-    }
+    for (int i = 0; i < LA; ++i) ra[i] = fetch(A, M, QA, tid + 512 * i, kk, in_a[i]);
 #pragma unroll
-    for (int i = 0; i < LB; ++i) rb[i] = fetch(Bm, N, QB, tid + 512 * i, kk);
+    for (int i = 0; i < LB; ++i) rb[i] = fetch(Bm, N, QB, tid + 512 * i, kk, in_b[i]);
   };
   auto stage_tile = [&](int buf) {
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int slot = tid + 512 * i;
-      if (slot < kGramRows * QA) *reinterpret_cast<f32x4*>(&As[buf][(slot / QA) * SA + 4 * (slot % QA)]) = ra[i];
+      const f32x4 v = in_a[i] ? ra[i] : zero;
+      if (slot < kGramRows * QA) *reinterpret_cast<f32x4*>(&As[buf][(slot / QA) * SA + 4 * (slot % QA)]) = v;
+      csum += v;
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int slot = tid + 512 * i;
-      if (slot < kGramRows * QB) *reinterpret_cast<f32x4*>(&Bs[buf][(slot / QB) * SB + 4 * (slot % QB)]) = rb[i];
+      const f32x4 v = in_b[i] ? rb[i] : zero;
+      if (slot < kGramRows * QB) *reinterpret_cast<f32x4*>(&Bs[buf][(slot / QB) * SB + 4 * (slot % QB)]) = v;
     }
   };
 
