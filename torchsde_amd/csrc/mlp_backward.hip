@@ -127,6 +127,12 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
     acc_shift[t] = {0.0f, 0.0f, 0.0f, 0.0f};
   }
 
+  // y_k is loaded one step ahead (issued before the last product of the previous step, which does not read it): a
+  // load consumed right behind its issue would expose the memory latency once per step -- and per tile in the diffusion
+  // terms, which use the same registers again instead of re-reading.
+  f32x4 y[TD];
+#pragma unroll
+  for (int t = 0; t < TD; ++t) y[t] = load_tile(p.ys_all + (int64_t)(p.k_hi - 1 - p.ys_first) * p.B * dT, t);
   int jg = p.grad_last;
   for (int k = p.k_hi - 1; k >= p.k_lo; --k) {
     const float* srow = p.rows + (int64_t)k * 8;
@@ -135,11 +141,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
     const int64_t slot = k - p.k_lo;
     const bool arrives = jg >= 0 && p.grad_step[jg] == k + 1;     // an output sits on boundary k + 1
 
-    f32x4 y[TD];
 #pragma unroll
     for (int t = 0; t < TD; ++t) {
       if (arrives) lam[t] += load_tile(p.grad_ys + (int64_t)jg * p.B * dT, t);
-      y[t] = load_tile(p.ys_all + (int64_t)(k - p.ys_first) * p.B * dT, t);
       store_tile(p.stash_lam + slot * p.B * dT, t, lam[t] * dt);
     }
     if (arrives) --jg;
@@ -195,9 +199,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       uint64_t quad = quad0 + 4 * t;
       asm volatile("" : "+v"(quad));
       if (real_d(t)) normal4<float>(key, quad, cell, 0, kStreamW, zn);
-      // y_k once more (from L2): keeping the tiles of the first load alive across the two products above costs more
-      // registers than the kernel has
-      const f32x4 yt = load_tile(p.ys_all + (int64_t)(k - p.ys_first) * p.B * dT, t);
+      const f32x4 yt = y[t];
       const f32x4 cq = lds_quad(cs, ch);
       const f32x4 eq = lds_quad(es, ch);
       if (p.method == TSDE_TRAJ_EULER) {
@@ -224,6 +226,12 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+
+    if (k > p.k_lo) {
+#pragma unroll
+      for (int t = 0; t < TD; ++t) y[t] = load_tile(p.ys_all + (int64_t)(k - 1 - p.ys_first) * p.B * dT, t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- lam^T += W1 delta^T (rows of W1s, four consecutive hidden units per lane) ------------------------------------
 #pragma unroll
