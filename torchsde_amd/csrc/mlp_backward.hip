@@ -158,8 +158,16 @@ __global__ void __launch_bounds__(NW * 64) mlp_backward_kernel(const MlpBackArgs
       for (int t = 0; t < TD; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z = TL::mfma(W1s[(R * t + 4 * part + r) * S1 + R * th + n], y[t][r], z);
-        if ((t + 1) % 4 == 0) __builtin_amdgcn_sched_barrier(0);
       }
+      // the A operands arrive as 2 TD two-address reads (ds_read2_b32: rows r, r+1 of W1s), each feeding two MFMAs: keep
+      // four of them in flight ahead of the MFMAs instead of hipcc's read -> wait -> two MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * TD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (i < 2 * TD - 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 value;
       const f32x4 bias = lds_quad(b1s, R * th + 4 * part);
 #pragma unroll
