@@ -145,6 +145,17 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
     // ---- layer 1: hid^T = W1^T x^T ------------------------------------------------------------------------
     // (the scheduling barriers keep the compiler from hoisting hundreds of LDS reads ahead of the MFMAs that use
     //  them: without them the unrolled body needs > 512 registers and spills)
+    // 16-row waves: the A operands of a tile arrive as `pairs` two-address reads (ds_read2_b32: weight rows r, r+1), each
+    // feeding two MFMAs; four of them are kept in flight ahead of the MFMAs (hipcc alone: read -> wait -> two MFMAs)
+    auto reads_ahead = [](int pairs) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < pairs) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (i < pairs - 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
     acc_t hid[TH];
     auto hidden_layer = [&](const acc_t* x) {
 #pragma unroll
@@ -158,8 +169,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             const float a = W1s[(R * t + TL::row(r, part)) * S1 + R * th + n];
             hid[th] = TL::mfma(a, x[t][r], hid[th]);
           }
-          if ((t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
+          if (R != 16 && (t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (R == 16) reads_ahead(2 * TD);
 #pragma unroll
         for (int q = 0; q < TL::kQuads; ++q) {
           const f32x4 bias = lds_quad(b1s, R * th + TL::quad_base(q, part));
@@ -181,8 +193,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
           const float a = W2s[(R * th + TL::row(r, part)) * S2 + R * t + n];
           acc = TL::mfma(a, hid[th][r], acc);
         }
-        if ((th + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
+        if (R != 16 && (th + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (R == 16) reads_ahead(2 * TH);
       return acc;
     };
 
