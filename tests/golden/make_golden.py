@@ -10,6 +10,8 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   bridge.npz          (parent, normals, children) tuples recorded inside the reference's bridge code and
                       multi-interval merge results
   brownian_seq.npz    reference BrownianInterval outputs for fixed entropy and query sequences
+  closed_form_mlp_<case>.npz   reference `sdeint` (+ autograd gradients) of the perceptron-drift module in float64, on
+                      the counter-RNG path the trajectory kernels generate for themselves
 """
 import os
 import sys
@@ -370,8 +372,75 @@ def gen_brownian_seq():
     print("brownian_seq.npz:", len(out), "arrays")
 
 
+# ------------------------------------------------------------------------------------- closed-form neural SDE
+# The perceptron-drift module (torchsde_amd.MLPDriftDiagonalSDE: an ordinary nn.Module with f, g, noise_type,
+# sde_type) solved and differentiated by the REAL reference in float64, on the increments of the counter-RNG path
+# (entropy, one cell per step) served by the C twin of the generator -- the path the trajectory kernels generate for
+# themselves on the GPU. Pins tsde_trajectory_mlp_diag and its reverse sweep against the reference itself.
+CLOSED_FORM_CASES = [
+    # name, activation, diffusion, sde_type, method, with gradients
+    ("euler_tanh_affine", "tanh", "affine", "ito", "euler", True),
+    ("euler_softplus_sigmoid", "softplus", "sigmoid", "ito", "euler", True),
+    ("milstein_softplus_affine", "softplus", "affine", "ito", "milstein", True),
+    ("milstein_strat_tanh_affine", "tanh", "affine", "stratonovich", "milstein", True),
+    ("midpoint_tanh_sigmoid", "tanh", "sigmoid", "stratonovich", "midpoint", False),
+]
+
+
+def gen_closed_form():
+    import torchsde_amd
+    from oracle import counter
+    B, d, hidden, steps, dt, entropy = 48, 32, 64, 16, 2.0 ** -5, 4242
+    edges = np.arange(steps + 1) * dt
+    ts = [0.0, 5 * dt, steps * dt]
+
+    class CounterPath(torchsde.BaseBrownian):
+        def __call__(self, ta, tb=None, return_U=False, return_A=False):
+            W, _, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float32, have_h=False)
+            return torch.from_numpy(W).reshape(B, d).double()
+
+        def __repr__(self):
+            return "CounterPath"
+
+        dtype = property(lambda self: torch.float64)
+        device = property(lambda self: torch.device("cpu"))
+        shape = property(lambda self: (B, d))
+        levy_area_approximation = property(lambda self: "none")
+
+    for name, activation, diffusion, sde_type, method, with_grads in CLOSED_FORM_CASES:
+        gen = torch.Generator().manual_seed(sum(map(ord, name)))
+        sigmoid = diffusion == "sigmoid"
+        sde = torchsde_amd.MLPDriftDiagonalSDE(
+            d, hidden, activation=activation, sde_type=sde_type, diffusion=diffusion,
+            diff_scale=0.4 if sigmoid else 1.0, dtype=torch.float64,
+            diff_rate=(2.0 if sigmoid else 0.2) * torch.rand(d, generator=gen, dtype=torch.float64) - 0.1,
+            diff_shift=0.1 + 0.2 * torch.rand(d, generator=gen, dtype=torch.float64))
+        with torch.no_grad():
+            sde.lin1.weight.copy_(torch.randn(hidden, d, generator=gen, dtype=torch.float64) / d ** 0.5)
+            sde.lin2.weight.copy_(torch.randn(d, hidden, generator=gen, dtype=torch.float64) / hidden ** 0.5)
+            sde.lin1.bias.copy_(0.3 * torch.randn(hidden, generator=gen, dtype=torch.float64))
+            sde.lin2.bias.copy_(0.3 * torch.randn(d, generator=gen, dtype=torch.float64))
+        y0 = (0.5 * torch.randn(B, d, generator=gen, dtype=torch.float64)).requires_grad_(True)
+        weights = torch.randn(len(ts), B, d, generator=gen, dtype=torch.float64)
+        ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method, dt=dt)
+        out = {"activation": activation, "diffusion": diffusion, "sde_type": sde_type, "method": method,
+               "diff_scale": np.float64(sde.diff_scale), "with_grads": with_grads, "entropy": np.int64(entropy),
+               "dt": np.float64(dt), "ts": np.asarray(ts), "shape": np.array([B, d, hidden, steps]),
+               "y0": y0.detach().numpy(), "weights": weights.numpy(), "ys": ys.detach().numpy()}
+        for pname, p in sde.named_parameters():
+            out["param__" + pname] = p.detach().numpy()
+        if with_grads:
+            (ys * weights).sum().backward()
+            out["grad__y0"] = y0.grad.numpy()
+            for pname, p in sde.named_parameters():
+                out["grad__" + pname] = p.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, f"closed_form_mlp_{name}.npz"), **out)
+        print(f"closed_form_mlp_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}"
+              + (f"  |grad lin1.weight|={np.abs(out['grad__lin1.weight']).mean():.4f}" if with_grads else ""))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq"]
+    which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

@@ -93,3 +93,17 @@ def make_replay_bm(table, shape, dtype, device, levy):
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+def mlp_module_from(z, dtype, device):
+    """The perceptron-drift module of a closed_form_mlp_*.npz fixture, with the fixture's parameter values."""
+    import torchsde_amd
+    B, d, hidden, steps = (int(v) for v in z["shape"])
+    sde = torchsde_amd.MLPDriftDiagonalSDE(d, hidden, activation=str(z["activation"]), sde_type=str(z["sde_type"]),
+                                           diffusion=str(z["diffusion"]), diff_scale=float(z["diff_scale"]),
+                                           diff_rate=torch.tensor(z["param__diff_rate"]),
+                                           diff_shift=torch.tensor(z["param__diff_shift"]), dtype=dtype)
+    with torch.no_grad():
+        for name, p in sde.named_parameters():
+            p.copy_(torch.tensor(z["param__" + name]).to(dtype))
+    return sde.to(device)

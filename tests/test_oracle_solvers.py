@@ -42,3 +42,37 @@ def test_oracle_adaptive_matches_reference(name, tag):
         ys = solvers_ref.integrate(case.sde(), bm, case.y0(), case.ts, case.dt, case.method, adaptive=True,
                                    rtol=float(case.z["rtol"]), atol=float(case.z["atol"]))
     torch.testing.assert_close(ys, case.ys, rtol=0, atol=0)
+
+
+def _closed_form_cases():
+    import os
+    return sorted(f[len("closed_form_mlp_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("closed_form_mlp_"))
+
+
+@pytest.mark.parametrize("name", _closed_form_cases())
+def test_oracle_matches_reference_on_the_counter_path(name):
+    """The oracle's stepping loop + the C twin of the counter RNG reproduce what the REAL reference computed for the
+    perceptron-drift module on that path (tests/golden/make_golden.py: gen_closed_form), gradients included -- the
+    chain the GPU tests of the trajectory kernels hang from."""
+    import numpy as np
+
+    from oracle import counter
+    z = helpers.load(f"closed_form_mlp_{name}.npz")
+    B, d, hidden, steps = (int(v) for v in z["shape"])
+    dt, with_grads = float(z["dt"]), bool(z["with_grads"])
+    sde = helpers.mlp_module_from(z, torch.float64, "cpu")
+    edges = np.arange(steps + 1) * dt
+
+    def bm(ta, tb, return_U=False):
+        W, _, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float32, have_h=False)
+        return torch.from_numpy(W).reshape(B, d).double()
+
+    y0 = torch.tensor(z["y0"], requires_grad=with_grads)
+    with torch.set_grad_enabled(with_grads):
+        ys = solvers_ref.integrate(sde, bm, y0, torch.tensor(z["ts"]), dt, str(z["method"]), None)
+    torch.testing.assert_close(ys.detach(), torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
+    if with_grads:
+        (ys * torch.tensor(z["weights"])).sum().backward()
+        torch.testing.assert_close(y0.grad, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
+        for pname, p in sde.named_parameters():
+            torch.testing.assert_close(p.grad, torch.tensor(z["grad__" + pname]), rtol=1e-10, atol=1e-12)
