@@ -12,6 +12,7 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   brownian_seq.npz    reference BrownianInterval outputs for fixed entropy and query sequences
   closed_form_mlp_<case>.npz   reference `sdeint` (+ autograd gradients) of the perceptron-drift module in float64, on
                       the counter-RNG path the trajectory kernels generate for themselves
+  closed_form_affine_<case>.npz   the same for the affine diagonal module (all five schemes of its trajectory kernel)
 """
 import os
 import sys
@@ -439,8 +440,63 @@ def gen_closed_form():
               + (f"  |grad lin1.weight|={np.abs(out['grad__lin1.weight']).mean():.4f}" if with_grads else ""))
 
 
+AFFINE_CASES = [
+    # name, sde_type, method, levy
+    ("euler", "ito", "euler", "none"),
+    ("milstein", "ito", "milstein", "none"),
+    ("milstein_strat", "stratonovich", "milstein", "none"),
+    ("srk", "ito", "srk", "space-time"),
+    ("midpoint", "stratonovich", "midpoint", "none"),
+]
+
+
+def gen_closed_form_affine():
+    """torchsde_amd.AffineDiagonalSDE (per-channel affine drift and diffusion) solved and differentiated by the REAL
+    reference in float64 on the counter-RNG path: pins tsde_trajectory_affine_diag and its sensitivity variant."""
+    import torchsde_amd
+    from oracle import counter
+    B, d, steps, dt, entropy = 40, 12, 16, 2.0 ** -5, 777001
+    edges = np.arange(steps + 1) * dt
+    ts = [0.0, 5 * dt, steps * dt]
+
+    for name, sde_type, method, levy in AFFINE_CASES:
+        class CounterPath(torchsde.BaseBrownian):
+            def __call__(self, ta, tb=None, return_U=False, return_A=False):
+                W, U, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float64,
+                                        have_h=levy != "none")
+                W = torch.from_numpy(W).reshape(B, d)
+                return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+            def __repr__(self):
+                return "CounterPath"
+
+            dtype = property(lambda self: torch.float64)
+            device = property(lambda self: torch.device("cpu"))
+            shape = property(lambda self: (B, d))
+            levy_area_approximation = property(lambda self: levy)
+
+        gen = torch.Generator().manual_seed(sum(map(ord, name)))
+        rnd = lambda lo, hi: lo + (hi - lo) * torch.rand(d, generator=gen, dtype=torch.float64)   # noqa: E731
+        sde = torchsde_amd.AffineDiagonalSDE(rnd(-0.8, 0.2), rnd(-0.3, 0.3), rnd(0.1, 0.5), rnd(0.0, 0.2),
+                                             sde_type=sde_type, dtype=torch.float64)
+        y0 = (0.5 + torch.rand(B, d, generator=gen, dtype=torch.float64)).requires_grad_(True)
+        weights = torch.randn(len(ts), B, d, generator=gen, dtype=torch.float64)
+        ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method, dt=dt)
+        (ys * weights).sum().backward()
+        out = {"sde_type": sde_type, "method": method, "levy": levy, "entropy": np.int64(entropy), "dt": np.float64(dt),
+               "ts": np.asarray(ts), "shape": np.array([B, d, steps]), "y0": y0.detach().numpy(),
+               "weights": weights.numpy(), "ys": ys.detach().numpy(), "grad__y0": y0.grad.numpy()}
+        for pname, p in sde.named_parameters():
+            out["param__" + pname] = p.detach().numpy()
+            out["grad__" + pname] = p.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, f"closed_form_affine_{name}.npz"), **out)
+        print(f"closed_form_affine_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}  "
+              f"|grad drift_rate|={np.abs(out['grad__drift_rate']).mean():.4f}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form"]
+    which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
+                             "closed_form_affine"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

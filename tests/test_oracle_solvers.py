@@ -76,3 +76,39 @@ def test_oracle_matches_reference_on_the_counter_path(name):
         torch.testing.assert_close(y0.grad, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
         for pname, p in sde.named_parameters():
             torch.testing.assert_close(p.grad, torch.tensor(z["grad__" + pname]), rtol=1e-10, atol=1e-12)
+
+
+def _affine_cases():
+    import os
+    return sorted(f[len("closed_form_affine_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("closed_form_affine_"))
+
+
+@pytest.mark.parametrize("name", _affine_cases())
+def test_oracle_matches_reference_on_the_counter_path_affine(name):
+    """Same chain for the affine diagonal module: every scheme of its trajectory kernel (SRK with the space-time Levy
+    area of the counter path included)."""
+    import numpy as np
+
+    import torchsde_amd
+    from oracle import counter
+    z = helpers.load(f"closed_form_affine_{name}.npz")
+    B, d, steps = (int(v) for v in z["shape"])
+    dt, levy = float(z["dt"]), str(z["levy"])
+    sde = torchsde_amd.AffineDiagonalSDE(*(torch.tensor(z["param__" + k]) for k in
+                                           ("drift_rate", "drift_shift", "diff_rate", "diff_shift")),
+                                         sde_type=str(z["sde_type"]), dtype=torch.float64)
+    edges = np.arange(steps + 1) * dt
+
+    def bm(ta, tb, return_U=False):
+        W, U, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float64,
+                                have_h=levy != "none")
+        W = torch.from_numpy(W).reshape(B, d)
+        return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+    y0 = torch.tensor(z["y0"], requires_grad=True)
+    ys = solvers_ref.integrate(sde, bm, y0, torch.tensor(z["ts"]), dt, str(z["method"]), None)
+    torch.testing.assert_close(ys.detach(), torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
+    (ys * torch.tensor(z["weights"])).sum().backward()
+    torch.testing.assert_close(y0.grad, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
+    for pname, p in sde.named_parameters():
+        torch.testing.assert_close(p.grad, torch.tensor(z["grad__" + pname]), rtol=1e-10, atol=1e-12)
