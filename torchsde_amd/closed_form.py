@@ -69,8 +69,8 @@ class MLPDriftDiagonalSDE(nn.Module):
     forward solves without autograd, Euler, Milstein or midpoint, float32, ``d`` a multiple of 4, ``d, hidden <= 128``
     -- ``sdeint`` runs the whole solve in one launch of ``tsde_trajectory_mlp_diag``: the state stays in registers, the
     weights in LDS, both layers on the f32 matrix cores. For TRAINING through ``sdeint`` (autograd on, Euler -- with the
-    affine diffusion also Milstein --, ``hidden`` a multiple of 4) the backward pass is ``tsde_trajectory_mlp_diag_backward`` + ``tsde_gram_partials``:
-    the gradients back-propagation through the stepwise solver gives, without a tape (the forward launch keeps the
+    affine diffusion also Milstein --, ``hidden`` a multiple of 4) the backward pass is
+    ``tsde_trajectory_mlp_diag_backward`` + ``tsde_gram_partials``: the gradients back-propagation through the stepwise solver gives, without a tape (the forward launch keeps the
     state of every step in HBM: steps x batch x d floats). Results agree with the stepwise path up to the summation
     order of the matrix products (same Brownian path).
     """

@@ -508,7 +508,8 @@ class TrajectorySchedule:
     @classmethod
     def cached(cls, step_rows, cells, out_step, out_w, device, dtype):
         """The schedule of a solve the process has seen before (same steps, cells and outputs -- every iteration of a
-        training loop) without its four blocking host->device copies; otherwise a new one, remembered (64 most recent)."""
+        training loop) without its four blocking host->device copies; otherwise a new one, remembered (the 64 most
+        recent)."""
         key = (np.ascontiguousarray(step_rows).tobytes(), np.ascontiguousarray(cells).tobytes(),
                tuple(int(k) for k in out_step), tuple((float(a), float(b)) for a, b in out_w), str(device), dtype)
         hit = cls._recent.get(key)

@@ -299,13 +299,14 @@ class BaseSDESolver:
                             _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
                 return None
             if self._tracks_grad(y0):
-                # training: Euler and Milstein, through the reverse-sweep kernel; gradients reach y0 and the module's own six
-                # parameters, so a subclass with more of them (or shapes the sweep does not take) goes stepwise
+                # training: Euler and Milstein, through the reverse-sweep kernel; gradients reach y0 and the module's own
+                # six parameters, so a subclass with more of them (or shapes the sweep does not take) goes stepwise
                 own = list(base.closed_form_parameters())
                 hidden = own[1].numel()
                 sigmoid = spec[-1][0] == _native.DIFF_SIGMOID         # its reverse sweep exists for Euler only
-                if (code == _native.TRAJ_MIDPOINT or (sigmoid and code != _native.TRAJ_EULER) or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30
-                        or {id(p) for p in base.parameters()} != {id(p) for p in own}):
+                too_large = y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30        # 32-bit lane offsets in the sweep
+                if (code == _native.TRAJ_MIDPOINT or (sigmoid and code != _native.TRAJ_EULER) or hidden % 4 != 0
+                        or too_large or {id(p) for p in base.parameters()} != {id(p) for p in own}):
                     return None
                 return ("mlp_differentiable", spec[-2], spec[-1]) + tuple(own)
             return spec
