@@ -1,7 +1,8 @@
 """The trajectory kernels of the closed-form SDEs against the REAL reference (run with ``-m gpu``): ``tests/golden/
 closed_form_mlp_*.npz`` and ``closed_form_affine_*.npz`` hold ``torchsde.sdeint`` outputs -- and, through autograd,
-the gradients -- of the same module in float64, computed by the reference itself (tests/golden/make_golden.py: gen_closed_form) on the increments of the
-counter-RNG path that the kernels regenerate on the GPU from (entropy, cell)."""
+the gradients -- of the same module in float64, computed by the reference itself (tests/golden/make_golden.py:
+gen_closed_form, gen_closed_form_affine) on the increments of the counter-RNG path that the kernels regenerate on the
+GPU from (entropy, cell)."""
 import os
 
 import numpy as np
