@@ -258,7 +258,8 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  * in ONE launch (neural-SDE sampling): a wave keeps 16 batch rows in registers for the whole solve, the weights
  * live in LDS and both layers run on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 accumulation).
  *   w1 (d, hidden) and w2 (hidden, d) are stored input-major: w1[k][m] multiplies input channel k into unit m
- *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 (both are zero-padded
+ *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 -- up to 256 when
+ *   d <= 64: both weight arrays have to fit the LDS of a CU -- (both are zero-padded
  *   to the MFMA tile sizes inside the kernel); rows * d < 2^30; ys, y0 16-byte aligned; dtype must be TSDE_F32;
  *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT, TSDE_TRAJ_MIDPOINT}.
  * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
@@ -299,7 +300,7 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
  *                each chunk from a state kept at its start, ys_first = k_lo)
  *   grad_ys      (n_grad, rows, d), grad_step (n_grad, ascending, device): cotangent of the output at boundary
  *                grad_step[j]; grad_last = index of the last entry with grad_step <= k_hi, or -1
- * d, hidden multiples of 4 up to 128, rows * max(d, hidden) < 2^30; w1, w2 in the layout of
+ * d, hidden multiples of 4 up to 128 (hidden up to 256 when d <= 64), rows * max(d, hidden) < 2^30; w1, w2 in the layout of
  * tsde_trajectory_mlp_diag; all buffers 16-byte aligned. */
 int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
                                       void* row_shift, const void* ys_all, int32_t ys_first, const void* grad_ys,
@@ -310,13 +311,13 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
                                       uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
                                       void* stream);
 
-/* partials[i] = sum over the i-th contiguous range of the k rows of a[row, :]^T b[row, :]   (a (k, m), b (k, n)
- * row-major, m, n <= 128; partials (blocks, m, n)) and, if colsum_partials (blocks, m) is not NULL, the column sums of
- * a over the same range: the weight- and bias-gradient sums of the call above -- a product with a 128 x 128 result
+/* partials[i] = sum over the i-th contiguous range of the k rows of a[row, :m]^T b[row, :n]   (a, b row-major with
+ * row strides lda >= m, ldb >= n floats -- column blocks of wider matrices are served in place --, m, n <= 128;
+ * partials (blocks, m, n)) and, if colsum_partials (blocks, m) is not NULL, the column sums of a over the same range: the weight- and bias-gradient sums of the call above -- a product with a 128 x 128 result
  * and k in the tens of millions, the shape BLAS libraries serve worst. f32 MFMA; the caller adds the partials up in a
  * fixed order (deterministic). */
-int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, const void* b, int64_t k, int64_t m,
-                       int64_t n, int32_t blocks, int dtype, void* stream);
+int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int64_t lda, const void* b, int64_t ldb,
+                       int64_t k, int64_t m, int64_t n, int32_t blocks, int dtype, void* stream);
 
 /* ---- in-library timing of one kernel family with HIP events (used by bench.py's roofline) ---- */
 #define TSDE_KID_STEP_DIAG 1

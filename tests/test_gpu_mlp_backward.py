@@ -51,7 +51,8 @@ def _assert_gradients_close(fast, ref, rtol=2e-3):
 
 @pytest.mark.parametrize("activation", ["tanh", "softplus"])
 @pytest.mark.parametrize("d,hidden", [(32, 32), (64, 64), (128, 128), (32, 128), (128, 64), (64, 32),
-                                      (4, 16), (8, 100), (20, 52), (100, 8), (36, 44), (124, 120)])   # padded tiles
+                                      (4, 16), (8, 100), (20, 52), (100, 8), (36, 44), (124, 120),    # padded tiles
+                                      (32, 256), (64, 256), (16, 200)])       # wide hidden layers (d <= 64)
 def test_gradients_match_autograd_of_the_stepwise_solve(d, hidden, activation):
     B = 300                                   # not a multiple of the 16-row wave tile or the 128-row block
     sde = _sde(d, hidden, activation)
@@ -243,7 +244,7 @@ def test_gradients_match_the_cpu_oracle_in_float64(activation):
 
 
 @pytest.mark.parametrize("k,m,n", [(1, 4, 4), (17, 128, 128), (1000, 64, 32), (4099, 100, 7), (70000, 128, 64),
-                                   (33000, 36, 128)])
+                                   (33000, 36, 128), (5000, 256, 64), (3000, 40, 200), (2000, 130, 129)])
 def test_gram_matches_float64(k, m, n):
     from torchsde_amd import kernels as K
     gen = torch.Generator().manual_seed(k)
@@ -287,6 +288,8 @@ def test_falls_back_when_the_sweep_does_not_apply():
     assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
     fn, g = run(_sde(d, 30, "tanh"), "euler")
     assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
+    fn, g = run(_sde(d, 260, "tanh"), "euler")                  # wider than the LDS takes
+    assert "MlpTrajectoryFn" not in type(fn).__name__ and torch.isfinite(g).all()
 
     class Extra(torchsde_amd.MLPDriftDiagonalSDE):
         def __init__(self):
@@ -319,5 +322,5 @@ def test_c_abi_rejects_unsupported_arguments():
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"Euler or Milstein" in lib.tsde_last_error()
     args = (ptr,) * 7 + (0, ptr, ptr, -1, 64, 32, 32) + (ptr,) * 5 + (1, 1.0, 0, 1, traj, 0, 0, 1, 0, None, 0, None)
     assert lib.tsde_trajectory_mlp_diag_backward(*args) != 0 and b"sigmoid with Euler" in lib.tsde_last_error()
-    assert lib.tsde_gram_partials(ptr, None, ptr, ptr, 10, 129, 4, 1, 0, None) != 0
+    assert lib.tsde_gram_partials(ptr, None, ptr, 129, ptr, 4, 10, 129, 4, 1, 0, None) != 0
     assert b"[1, 128]" in lib.tsde_last_error()

@@ -34,7 +34,8 @@ def _solve(sde, y0, ts, method, dt, entropy, trajectory, row_offset=0):
 
 @pytest.mark.parametrize("activation", ["tanh", "softplus"])
 @pytest.mark.parametrize("d,hidden", [(32, 32), (64, 64), (128, 128), (32, 128), (128, 64), (64, 32),
-                                      (4, 16), (8, 100), (20, 50), (100, 7), (36, 33)])     # padded to the MFMA tiles
+                                      (4, 16), (8, 100), (20, 50), (100, 7), (36, 33),     # padded to the MFMA tiles
+                                      (32, 256), (64, 256), (16, 200)])                     # wide hidden layers
 @pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("milstein", "ito"), ("midpoint", "stratonovich")])
 def test_matches_stepwise_path(method, sde_type, d, hidden, activation):
     B = 300                                   # not a multiple of the 32-row wave tile or the 128-row block
@@ -103,7 +104,7 @@ def test_c_abi_rejects_unsupported_shapes():
     lib = _native.load()
     x = torch.zeros(64, 48, device=DEV)
     traj = _native.Traj()
-    for d, hidden in ((6, 32), (132, 32), (32, 129)):
+    for d, hidden in ((6, 32), (132, 32), (128, 129), (32, 257)):
         args = (x.data_ptr(),) * 2 + (64, d, hidden) + (x.data_ptr(),) * 6 + (0, 1.0, 0, 0, traj, 1, 0, None, 0, None)
         assert lib.tsde_trajectory_mlp_diag(*args) != 0 and b"multiple of 4" in lib.tsde_last_error()
 

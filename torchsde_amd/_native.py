@@ -111,7 +111,7 @@ SIGNATURES = {
                                                    _c_ptr, _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                    _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
                                                    _c_ptr, _c_int, _c_ptr]),
-    "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
+    "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),

@@ -67,7 +67,7 @@ class MLPDriftDiagonalSDE(nn.Module):
 
     An ordinary module for every solver, for autograd and for ``sdeint_adjoint`` (train it as usual). For SAMPLING --
     forward solves without autograd, Euler, Milstein or midpoint, float32, ``d`` a multiple of 4, ``d, hidden <= 128``
-    -- ``sdeint`` runs the whole solve in one launch of ``tsde_trajectory_mlp_diag``: the state stays in registers, the
+    (``hidden <= 256`` for ``d <= 64``: both weight matrices live in the LDS of a compute unit) -- ``sdeint`` runs the whole solve in one launch of ``tsde_trajectory_mlp_diag``: the state stays in registers, the
     weights in LDS, both layers on the f32 matrix cores. For TRAINING through ``sdeint`` (autograd on, Euler -- with the
     affine diffusion also Milstein --, ``hidden`` a multiple of 4) the backward pass is
     ``tsde_trajectory_mlp_diag_backward`` + ``tsde_gram_partials``: the gradients back-propagation through the stepwise solver gives, without a tape (the forward launch keeps the
@@ -114,7 +114,7 @@ class MLPDriftDiagonalSDE(nn.Module):
         hidden = self.lin1.out_features
         params = list(self.parameters())
         if (dtype != torch.float32 or any(p.dtype != dtype or p.device != device for p in params)
-                or self.lin1.in_features != d or d % 4 != 0 or d > 128 or hidden > 128
+                or self.lin1.in_features != d or d % 4 != 0 or d > 128 or hidden > (256 if d <= 64 else 128)
                 or self.lin1.bias is None or self.lin2.bias is None):
             return None
         coefs = []

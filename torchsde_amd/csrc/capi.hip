@@ -379,8 +379,8 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
   if (!ys || !y0 || !w1 || !b1 || !w2 || !b2 || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
-  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 1 || hidden > 128)
-    return bad_arg(where, "need d a multiple of 4 in [4, 128] and hidden in [1, 128]");
+  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 1 || hidden > 256 || (hidden > 128 && d > 64))
+    return bad_arg(where, "need d a multiple of 4 in [4, 128] and hidden in [1, 128] (up to 256 for d <= 64)");
   if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
     return bad_arg(where, "ys and y0 must be 16-byte aligned");
   if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
@@ -417,8 +417,8 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
     return bad_arg(where, "diffusion kind must be affine, or sigmoid with Euler");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
-  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 4 || hidden > 128 || hidden % 4 != 0)
-    return bad_arg(where, "need d and hidden multiples of 4 in [4, 128]");
+  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 4 || hidden > 256 || hidden % 4 != 0 || (hidden > 128 && d > 64))
+    return bad_arg(where, "need d and hidden multiples of 4, d in [4, 128], hidden in [4, 128] (up to 256 for d <= 64)");
   if (rows * (d > hidden ? d : hidden) >= (int64_t(1) << 30))
     return bad_arg(where, "need rows * max(d, hidden) < 2^30 (32-bit lane offsets)");
   const void* aligned[] = {lam, stash_lam, stash_hid, stash_delta, row_rate, row_shift, ys_all, grad_ys};
@@ -440,13 +440,15 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
               where);
 }
 
-int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, const void* b, int64_t k, int64_t m,
-                       int64_t n, int32_t blocks, int dtype, void* stream) {
+int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int64_t lda, const void* b, int64_t ldb,
+                       int64_t k, int64_t m, int64_t n, int32_t blocks, int dtype, void* stream) {
   const char* where = "tsde_gram_partials";
   if (!partials || !a || !b) return bad_arg(where, "null argument");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (k < 1 || m < 1 || m > 128 || n < 1 || n > 128 || blocks < 1) return bad_arg(where, "need k, blocks >= 1 and m, n in [1, 128]");
-  return fail(tsde::launch_gram_partials(partials, colsum_partials, a, b, k, m, n, blocks, (hipStream_t)stream), where);
+  if (lda < m || ldb < n) return bad_arg(where, "need lda >= m and ldb >= n");
+  return fail(tsde::launch_gram_partials(partials, colsum_partials, a, lda, b, ldb, k, m, n, blocks, (hipStream_t)stream),
+              where);
 }
 
 int tsde_prof_begin(int kid, int capacity) {

@@ -303,6 +303,9 @@ static hipError_t launch_back_h(const MlpBackArgs& p, int act, hipStream_t s) {
   if (p.h <= 32) return launch_back_act<D, 32>(p, act, s);
   if (p.h <= 64) return launch_back_act<D, 64>(p, act, s);
   if (p.h <= 128) return launch_back_act<D, 128>(p, act, s);
+  if constexpr (D <= 64) {                 // both weight arrays must fit the LDS of a CU: d * hidden <= 16384
+    if (p.h <= 256) return launch_back_act<D, 256>(p, act, s);
+  }
   return hipErrorInvalidValue;
 }
 
@@ -363,8 +366,9 @@ constexpr int kGramRows = 32;
 
 template <int MT, int NT, bool VEC>
 __global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials, float* __restrict__ colsums,
-                                                   const float* __restrict__ A, const float* __restrict__ Bm, int64_t K,
-                                                   int32_t M, int32_t N, int64_t rows_per_block) {
+                                                   const float* __restrict__ A, int64_t lda,
+                                                   const float* __restrict__ Bm, int64_t ldb, int64_t K, int32_t M,
+                                                   int32_t N, int64_t rows_per_block) {
   using TL = Tile<16>;
   constexpr int MP = 64 * MT, NP = 32 * NT;                 // padded widths
   constexpr int SA = MP + 16, SB = NP + 16;                 // LDS row strides (floats)
@@ -393,18 +397,19 @@ __global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials,
   // wait for the load in front of those instructions.
   f32x4 ra[LA], rb[LB];
   bool in_a[LA], in_b[LB];
-  auto fetch = [&](const float* __restrict__ src, int32_t width, int q_per_row, int slot, int64_t kk, bool& inside) {
+  auto fetch = [&](const float* __restrict__ src, int64_t ld, int32_t width, int q_per_row, int slot, int64_t kk,
+                   bool& inside) {
     const int r = slot / q_per_row, c = 4 * (slot % q_per_row);
     const int64_t krow = kk + r;
     inside = r < kGramRows && krow < k1 && c < width;
     if constexpr (VEC) {
       const int64_t row_c = krow < K ? krow : K - 1;        // (k1 > k0 >= 0 here: K - 1 is a valid row)
       const int col_c = c < width ? c : width - 4;
-      return *reinterpret_cast<const f32x4*>(src + row_c * width + col_c);
+      return *reinterpret_cast<const f32x4*>(src + row_c * ld + col_c);
     } else {
       f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
       if (inside) {
-        const float* q = src + krow * width + c;
+        const float* q = src + krow * ld + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (c + e < width) v[e] = q[e];
@@ -415,9 +420,9 @@ __global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials,
   auto load_tile = [&](int tile) {
     const int64_t kk = k0 + (int64_t)tile * kGramRows;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) ra[i] = fetch(A, M, QA, tid + 512 * i, kk, in_a[i]);
+    for (int i = 0; i < LA; ++i) ra[i] = fetch(A, lda, M, QA, tid + 512 * i, kk, in_a[i]);
 #pragma unroll
-    for (int i = 0; i < LB; ++i) rb[i] = fetch(Bm, N, QB, tid + 512 * i, kk, in_b[i]);
+    for (int i = 0; i < LB; ++i) rb[i] = fetch(Bm, ldb, N, QB, tid + 512 * i, kk, in_b[i]);
   };
   auto stage_tile = [&](int buf) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -486,38 +491,41 @@ __global__ void __launch_bounds__(512) gram_kernel(float* __restrict__ partials,
 }
 
 template <int MT, int NT>
-static hipError_t launch_gram_vec(float* partials, float* colsums, const float* A, const float* Bm, int64_t K, int32_t M,
-                                  int32_t N, int32_t blocks, int64_t rows_per_block, hipStream_t s) {
-  const bool vec = M % 4 == 0 && N % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15u) == 0;
+static hipError_t launch_gram_vec(float* partials, float* colsums, const float* A, int64_t lda, const float* Bm,
+                                  int64_t ldb, int64_t K, int32_t M, int32_t N, int32_t blocks, int64_t rows_per_block,
+                                  hipStream_t s) {
+  const bool vec = M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15u) == 0;
   if (vec)
-    hipLaunchKernelGGL((gram_kernel<MT, NT, true>), dim3(blocks), dim3(512), 0, s, partials, colsums, A, Bm, K, M, N,
-                       rows_per_block);
+    hipLaunchKernelGGL((gram_kernel<MT, NT, true>), dim3(blocks), dim3(512), 0, s, partials, colsums, A, lda, Bm, ldb, K,
+                       M, N, rows_per_block);
   else
-    hipLaunchKernelGGL((gram_kernel<MT, NT, false>), dim3(blocks), dim3(512), 0, s, partials, colsums, A, Bm, K, M, N,
-                       rows_per_block);
+    hipLaunchKernelGGL((gram_kernel<MT, NT, false>), dim3(blocks), dim3(512), 0, s, partials, colsums, A, lda, Bm, ldb,
+                       K, M, N, rows_per_block);
   return hipGetLastError();
 }
 
 template <int MT>
-static hipError_t launch_gram_n(float* partials, float* colsums, const float* A, const float* Bm, int64_t K, int32_t M,
-                                int32_t N, int32_t blocks, int64_t rows_per_block, hipStream_t s) {
-  if (N <= 32) return launch_gram_vec<MT, 1>(partials, colsums, A, Bm, K, M, N, blocks, rows_per_block, s);
-  if (N <= 64) return launch_gram_vec<MT, 2>(partials, colsums, A, Bm, K, M, N, blocks, rows_per_block, s);
-  if (N <= 128) return launch_gram_vec<MT, 4>(partials, colsums, A, Bm, K, M, N, blocks, rows_per_block, s);
+static hipError_t launch_gram_n(float* partials, float* colsums, const float* A, int64_t lda, const float* Bm,
+                                int64_t ldb, int64_t K, int32_t M, int32_t N, int32_t blocks, int64_t rows_per_block,
+                                hipStream_t s) {
+  if (N <= 32) return launch_gram_vec<MT, 1>(partials, colsums, A, lda, Bm, ldb, K, M, N, blocks, rows_per_block, s);
+  if (N <= 64) return launch_gram_vec<MT, 2>(partials, colsums, A, lda, Bm, ldb, K, M, N, blocks, rows_per_block, s);
+  if (N <= 128) return launch_gram_vec<MT, 4>(partials, colsums, A, lda, Bm, ldb, K, M, N, blocks, rows_per_block, s);
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, const void* Bm, int64_t K, int64_t M,
-                                int64_t N, int32_t blocks, hipStream_t s) {
+hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, int64_t lda, const void* Bm, int64_t ldb,
+                                int64_t K, int64_t M, int64_t N, int32_t blocks, hipStream_t s) {
   if (K <= 0 || M <= 0 || N <= 0 || blocks <= 0) return hipErrorInvalidValue;
   int64_t rows_per_block = (K + blocks - 1) / blocks;
   rows_per_block = (rows_per_block + kGramRows - 1) / kGramRows * kGramRows;       // whole tiles
   if (M <= 64)
-    return launch_gram_n<1>((float*)partials, (float*)colsums, (const float*)A, (const float*)Bm, K, (int32_t)M,
-                            (int32_t)N, blocks, rows_per_block, s);
+    return launch_gram_n<1>((float*)partials, (float*)colsums, (const float*)A, lda, (const float*)Bm, ldb, K,
+                            (int32_t)M, (int32_t)N, blocks, rows_per_block, s);
   if (M <= 128)
-    return launch_gram_n<2>((float*)partials, (float*)colsums, (const float*)A, (const float*)Bm, K, (int32_t)M,
-                            (int32_t)N, blocks, rows_per_block, s);
+    return launch_gram_n<2>((float*)partials, (float*)colsums, (const float*)A, lda, (const float*)Bm, ldb, K,
+                            (int32_t)M, (int32_t)N, blocks, rows_per_block, s);
   return hipErrorInvalidValue;
 }
 

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
     auto reads_ahead = [](int pairs) {
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 32; ++i) {
         if (i < pairs) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         if (i < pairs - 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
@@ -447,6 +447,9 @@ static hipError_t launch_mlp_h(const MlpArgs& p, int act, hipStream_t s) {
   if (p.h <= 32) return launch_mlp_act<D, 32>(p, act, s);
   if (p.h <= 64) return launch_mlp_act<D, 64>(p, act, s);
   if (p.h <= 128) return launch_mlp_act<D, 128>(p, act, s);
+  if constexpr (D <= 64) {                 // both weight arrays must fit the LDS of a CU: d * hidden <= 16384
+    if (p.h <= 256) return launch_mlp_act<D, 256>(p, act, s);
+  }
   return hipErrorInvalidValue;
 }
 

@@ -107,6 +107,6 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
                                                double diff_amp, int act, int method, const tsde_traj_t* tr,
                                                int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
                                                hipStream_t s);
-hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, const void* Bm, int64_t K, int64_t M,
-                                int64_t N, int32_t blocks, hipStream_t s);
+hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, int64_t lda, const void* Bm, int64_t ldb,
+                                int64_t K, int64_t M, int64_t N, int32_t blocks, hipStream_t s);
 }  // namespace tsde

@@ -625,24 +625,36 @@ def trajectory_affine_diag_differentiable(y0, params, method, schedule, bm):
 
 
 def gram(a, b, blocks=512, column_sums=False):
-    """a^T b for tall a (k, m), b (k, n) with m, n <= 128 (``tsde_gram_partials`` + a fixed-order sum of its partials):
-    the weight-gradient reduction of the perceptron-drift backward sweep. With `column_sums`, also a.sum(0) (the bias
-    gradient), from the same pass over a."""
+    """a^T b for tall row-major a (k, m), b (k, n) (``tsde_gram_partials`` + a fixed-order sum of its partials): the
+    weight-gradient reduction of the perceptron-drift backward sweep. The kernel produces results of up to 128 x 128;
+    wider operands are served in place as column blocks (row strides = the full widths). With `column_sums`, also
+    a.sum(0) (the bias gradient), from the same pass over a."""
     _native.require_device(a, b)
     if a.dtype != torch.float32 or b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):
         raise ValueError("gram takes contiguous float32 matrices")
-    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.shape[1] > 128 or b.shape[1] > 128:
-        raise ValueError("gram takes a (k, m) and b (k, n) with m, n <= 128")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError("gram takes a (k, m) and b (k, n)")
     k, m, n = a.shape[0], a.shape[1], b.shape[1]
     blocks = int(max(1, min(blocks, (k + 63) // 64)))
-    partials = torch.empty((blocks, m, n), dtype=torch.float32, device=a.device)
-    sums = torch.empty((blocks, m), dtype=torch.float32, device=a.device) if column_sums else None
     lib, dt_code, stream = _launch_env(a)
-    _native.check(lib.tsde_gram_partials(partials.data_ptr(), None if sums is None else sums.data_ptr(), a.data_ptr(),
-                                         b.data_ptr(), k, m, n, blocks, dt_code, stream), "tsde_gram_partials")
-    if column_sums:
-        return partials.sum(dim=0), sums.sum(dim=0)
-    return partials.sum(dim=0)
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    sums = torch.empty(m, dtype=torch.float32, device=a.device) if column_sums else None
+    partials = torch.empty((blocks, min(m, 128), min(n, 128)), dtype=torch.float32, device=a.device)
+    sum_partials = torch.empty((blocks, min(m, 128)), dtype=torch.float32, device=a.device) if column_sums else None
+    for i0 in range(0, m, 128):
+        mi = min(128, m - i0)
+        for j0 in range(0, n, 128):
+            nj = min(128, n - j0)
+            want_sums = column_sums and j0 == 0
+            p_view = partials.reshape(-1)[:blocks * mi * nj].view(blocks, mi, nj)
+            s_view = sum_partials.reshape(-1)[:blocks * mi].view(blocks, mi) if want_sums else None
+            _native.check(lib.tsde_gram_partials(p_view.data_ptr(), None if s_view is None else s_view.data_ptr(),
+                                                 a.data_ptr() + 4 * i0, m, b.data_ptr() + 4 * j0, n, k, mi, nj, blocks,
+                                                 dt_code, stream), "tsde_gram_partials")
+            out[i0:i0 + mi, j0:j0 + nj] = p_view.sum(dim=0)
+            if want_sums:
+                sums[i0:i0 + mi] = s_view.sum(dim=0)
+    return (out, sums) if column_sums else out
 
 
 _boundary_tables = collections.OrderedDict()
