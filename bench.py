@@ -432,7 +432,7 @@ def main():
         traffic = rocprof_us = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and args.workload == "c2_euler_diag_b65536_d64_s1000":
-            # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools_profile.sh), corrected as
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/profile.sh), corrected as
             # guides/MI355X_MICROARCH.md prescribes; collected offline because counters need their own passes.
             try:
                 with open(tpath) as fh:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiling recipe used for profiles/ (run on the GPU box through gpurun). Usage: tools_profile.sh <tag>
+# Profiling recipe used for profiles/ (run on the GPU box through gpurun). Usage: tools/profile.sh <tag>
 set -u
 TAG=${1:-r1}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,6 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2> $OUT/pmc_write.log
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
-python $R/tools_profile_summary.py $OUT > $OUT/summary.txt 2>&1
+python $R/tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 find $OUT -name "*counter_collection.csv" -size +4M -delete

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes for the whole-trajectory kernel (run on the GPU box through gpurun).
-# Usage: tools_profile_trajectory.sh <tag> [workload]
+# Usage: tools/profile_trajectory.sh <tag> [workload]
 set -u
 TAG=${1:-r1}
 WL=${2:-c2_euler_closed_form_b65536_d64_s1000}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats for one bench workload: tools_profile_workload.sh <workload> <tag> [extra bench args]
+# rocprofv3 kernel stats for one bench workload: tools/profile_workload.sh <workload> <tag> [extra bench args]
 set -u
 W=$1; TAG=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
