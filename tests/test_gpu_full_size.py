@@ -148,3 +148,38 @@ def test_c5_adjoint_b32768_d128_s500():
     assert torch.isfinite(y0.grad).all() and rel < 1e-2, rel
     for p in sde.parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+def test_c5_latent_sde_through_the_trajectory_kernels_full_size():
+    """The latent SDE of configs[4] at B 32768 x d 128 x 500 steps, stated as the closed-form module: the matrix-core
+    kernels against the stepwise path of the same module on the same Brownian path -- the final state, the loss
+    gradients w.r.t. y0 and all six parameters (autograd over the 500 recorded steps is the comparison), sharding
+    invariance of a block of rows (bit-exact), and a second backward pass reproducing the first bit for bit."""
+    import bench
+    import torchsde_amd
+    B, d, n, dt = 32768, 128, 500, 2.0 ** -9
+    sde = bench._make_problem("latent_diag_closed_form", d, d, DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def solve(options, rows=slice(None), row_offset=0):
+        y = torch.full((B, d), 0.1, device=DEV)[rows].clone().requires_grad_(True)
+        bm = torchsde_amd.BrownianInterval(0.0, n * dt, size=tuple(y.shape), dtype=torch.float32, device=DEV, entropy=77,
+                                           dt=dt, row_offset=row_offset)
+        sde.zero_grad()
+        ys = torchsde_amd.sdeint(sde, y, ts, bm=bm, method="euler", dt=dt, options=options)
+        (ys[-1] ** 2).mean().backward()
+        grads = {name: p.grad.clone() for name, p in sde.named_parameters()}
+        grads["y0"] = y.grad.clone()
+        return ys[-1].detach(), grads
+
+    fast, g_fast = solve(None)
+    again, g_again = solve(None)
+    assert torch.equal(fast, again) and all(torch.equal(g_fast[k], g_again[k]) for k in g_fast)
+    part, _ = solve(None, rows=slice(4096, 4096 + 2048), row_offset=4096)
+    assert torch.equal(part, fast[4096:4096 + 2048])
+    ref, g_ref = solve({"trajectory_kernel": False})
+    assert torch.isfinite(fast).all()
+    torch.testing.assert_close(fast, ref, rtol=1e-3, atol=1e-4)
+    for key, want in g_ref.items():
+        err = (g_fast[key] - want).abs().max().item()
+        assert err <= 5e-3 * want.abs().max().item() + 1e-9, f"{key}: {err:.3e} vs scale {want.abs().max().item():.3e}"
