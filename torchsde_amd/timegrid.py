@@ -82,12 +82,15 @@ def ts_to_host(ts: torch.Tensor) -> np.ndarray:
     remembered ON the tensor object together with its version counter, which every in-place op bumps."""
     if ts.dtype not in _NP:
         raise ValueError(f"Unsupported dtype for `ts`: {ts.dtype}")
+    if ts.device.type == "cpu":
+        # no sync to save, and a CPU tensor can be edited through its numpy alias without its version moving
+        host = ts.detach().numpy().copy()
+        host.setflags(write=False)
+        return host
     cached = getattr(ts, "_tsde_host", None)
     if cached is not None and cached[0] == ts._version:
         return cached[1]
     host = ts.detach().cpu().numpy()
-    if host.base is not None or ts.device.type == "cpu":
-        host = host.copy()          # a CPU tensor shares its memory with `.numpy()`: keep a private snapshot
     remember(ts, host)
     return host
 
