@@ -79,7 +79,8 @@ def build(ts_host: np.ndarray, dt) -> TimeGrid:
 def ts_to_host(ts: torch.Tensor) -> np.ndarray:
     """The output times on the host (read-only array): one device->host copy, the only sync of a fixed-step solve --
     and none at all when the same `ts` tensor comes back unchanged (every iteration of a training loop): the copy is
-    remembered ON the tensor object together with its version counter, which every in-place op bumps."""
+    remembered ON the tensor object together with its version counter, which every in-place op bumps (writes through
+    `ts.data` bypass that counter, as they bypass autograd's own checks: do not edit `ts` that way between solves)."""
     if ts.dtype not in _NP:
         raise ValueError(f"Unsupported dtype for `ts`: {ts.dtype}")
     if ts.device.type == "cpu":
