@@ -1,0 +1,88 @@
+"""The batch-sharding path with the REAL kernels under several processes (run with ``-m gpu``): two and three ranks
+share the one GPU of the test box (gloo carries the collectives -- RCCL refuses two ranks on one device -- staging
+through the host; the data path is what is under test: row partition, global-row RNG offsets, the gather, the gradient
+all-reduce of a sharded adjoint). The gathered result must equal the unsharded solve bit for bit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+B, D, STEPS, DT, ENTROPY = 1000, 64, 32, 2.0 ** -6, 990077
+
+
+def _problem():
+    from tests import problems
+    return problems.make("gbm_ito", d=D).to("cuda")
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torchsde_amd
+        from torchsde_amd import sharding
+        sde = _problem()
+        y0 = torch.linspace(0.05, 0.2, B * D, device="cuda").reshape(B, D)
+        ts = torch.tensor([0.0, 8 * DT, STEPS * DT], device="cuda")
+        with torch.no_grad():
+            final = sharding.sdeint_sharded(sde, y0, ts, entropy=ENTROPY, method="euler", dt=DT)
+            every = sharding.sdeint_sharded(sde, y0, ts, entropy=ENTROPY, method="srk", dt=DT, gather="all")
+        # sharded adjoint: local rows, then one all-reduce of the parameter gradients
+        r0, r1 = sharding.shard_rows(B, world, rank)
+        y_local = y0[r0:r1].clone().requires_grad_(True)
+        bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(r1 - r0, D), dtype=torch.float32, device="cuda",
+                                           entropy=ENTROPY, row_offset=r0)
+        ys = torchsde_amd.sdeint_adjoint(sde, y_local, ts, bm=bm, method="euler", adjoint_method="euler", dt=DT)
+        ys[-1].sum().backward()
+        params = list(sde.parameters())
+        sharding.all_reduce_gradients(params)
+        # (numpy: pickled by value -- tensors would travel as shared-memory handles that die with this process)
+        q.put((rank, final.cpu().numpy(), every.cpu().numpy(), [p.grad.cpu().numpy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_processes_reproduce_the_unsharded_solve(world):
+    import torchsde_amd
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    sde = _problem()
+    y0 = torch.linspace(0.05, 0.2, B * D, device="cuda").reshape(B, D)
+    ts = torch.tensor([0.0, 8 * DT, STEPS * DT], device="cuda")
+
+    def bm(levy="none"):
+        return torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, D), dtype=torch.float32, device="cuda",
+                                             entropy=ENTROPY, levy_area_approximation=levy)
+    with torch.no_grad():
+        full_euler = torchsde_amd.sdeint(sde, y0, ts, bm=bm(), method="euler", dt=DT)
+        full_srk = torchsde_amd.sdeint(sde, y0, ts, bm=bm("space-time"), method="srk", dt=DT)
+    y = y0.clone().requires_grad_(True)
+    ys = torchsde_amd.sdeint_adjoint(sde, y, ts, bm=bm(), method="euler", adjoint_method="euler", dt=DT)
+    ys[-1].sum().backward()
+    want = [p.grad.cpu() for p in sde.parameters()]
+    for rank, final, every, grads in results:
+        assert torch.equal(torch.from_numpy(final), full_euler[-1].cpu()), rank
+        assert torch.equal(torch.from_numpy(every), full_srk.cpu()), rank
+        for got, ref in zip(grads, want):          # a sum over rows regrouped by rank: equal up to summation order
+            torch.testing.assert_close(torch.from_numpy(got), ref, rtol=1e-5, atol=1e-6)
