@@ -271,15 +271,22 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TSDE_BENCH_SHARE_GPU=1 (tests only): all ranks use device 0 and gloo carries the collectives, so that the
+    # multi-rank logic of this file can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("TSDE_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     # launched by torch.distributed.run (also with a single rank): use the collective path, so that the very same
     # code runs at N = 1, 2, 4, 8
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import torchsde_amd
     from torchsde_amd import kernels as K

@@ -86,3 +86,27 @@ def test_sharded_processes_reproduce_the_unsharded_solve(world):
         assert torch.equal(torch.from_numpy(every), full_srk.cpu()), rank
         for got, ref in zip(grads, want):          # a sum over rows regrouped by rank: equal up to summation order
             torch.testing.assert_close(torch.from_numpy(got), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_bench_multi_rank_logic_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with two ranks
+    sharing the one device and gloo for the collectives (TSDE_BENCH_SHARE_GPU=1): one JSON line from rank 0, the whole
+    job's trajectory-steps counted, weak scaling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSDE_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 2 * rec["config"]["batch_per_gpu"]
+    expected = rec["config"]["global_batch"] * rec["config"]["solver_steps"] / (rec["ms_per_step"] * 1e-3)
+    assert abs(rec["value"] - expected) <= 1e-6 * expected
+    assert rec["roofline"]["frac"] > 0 and rec["cpu_baseline"] is None and "also" not in rec
