@@ -248,3 +248,18 @@ def test_output_times_reach_the_host_once():
     assert timegrid.ts_to_host(fake) is a and fake.copies == 1
     fake._version = 1                                  # an in-place op happened: the copy is redone
     assert timegrid.ts_to_host(fake) is not a and fake.copies == 2
+
+
+def test_bench_latent_sde_statements_agree_on_cpu():
+    """bench.py's two statements of the configs[4] latent SDE (user module / closed-form module) have the same
+    parameters and the same f, g (plain torch on the CPU: this is about the modules, not the kernels)."""
+    import bench
+    user = bench._make_problem("latent_diag", 16, 16, "cpu")
+    closed = bench._make_problem("latent_diag_closed_form", 16, 16, "cpu")
+    y = torch.randn(5, 16, generator=torch.Generator().manual_seed(0))
+    t = torch.tensor(0.0)
+    assert torch.equal(user.f(t, y), closed.f(t, y)) and torch.equal(user.g(t, y), closed.g(t, y))
+    assert closed.noise_type == user.noise_type == "diagonal" and closed.sde_type == user.sde_type == "ito"
+    assert sum(p.numel() for p in user.parameters()) == sum(p.numel() for p in closed.parameters())
+    spec = closed.closed_form(16, torch.float32, torch.device("cpu"))
+    assert spec[0] == "mlp_diagonal" and spec[-1] == (1, 0.1) and spec[1].shape == (16, 16)
