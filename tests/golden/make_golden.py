@@ -30,7 +30,7 @@ sys.dont_write_bytecode = True
 import torchsde  # noqa: E402  (the reference)
 from torchsde._brownian import brownian_interval as ref_bi  # noqa: E402
 
-from tests import problems  # noqa: E402
+from workloads import problems  # noqa: E402
 
 DT = {"f32": torch.float32, "f64": torch.float64}
 

@@ -40,7 +40,7 @@ class Case:
         self.param_checksum = float(z[f"{tag}__param_checksum"])
 
     def sde(self, device="cpu"):
-        from tests import problems
+        from workloads import problems
         sde = problems.make(self.problem, dtype=self.dtype, d=self.d, m=self.m)
         got = float(sum(p.detach().double().abs().sum() for p in sde.parameters()))
         assert abs(got - self.param_checksum) <= 1e-9 * max(1.0, abs(got)), "test problem parameters drifted"

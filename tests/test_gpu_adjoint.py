@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests import helpers, problems
+from tests import helpers
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import counter, solvers_ref
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -7,7 +7,7 @@ import pytest
 import torch
 from scipy.stats import kstest, linregress
 
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -11,7 +11,7 @@ import pytest
 import torch
 from torch import nn
 
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -155,10 +155,10 @@ def test_c5_latent_sde_through_the_trajectory_kernels_full_size():
     kernels against the stepwise path of the same module on the same Brownian path -- the final state, the loss
     gradients w.r.t. y0 and all six parameters (autograd over the 500 recorded steps is the comparison), sharding
     invariance of a block of rows (bit-exact), and a second backward pass reproducing the first bit for bit."""
-    import bench
+    from workloads import configs
     import torchsde_amd
     B, d, n, dt = 32768, 128, 500, 2.0 ** -9
-    sde = bench._make_problem("latent_diag_closed_form", d, d, DEV)
+    sde = configs.make_problem("latent_diag_closed_form", d, d, DEV)
     ts = torch.tensor([0.0, n * dt], device=DEV)
 
     def solve(options, rows=slice(None), row_offset=0):

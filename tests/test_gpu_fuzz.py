@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import counter, solvers_ref
-from tests import problems
+from workloads import problems
 from torchsde_amd import timegrid
 
 pytestmark = pytest.mark.gpu

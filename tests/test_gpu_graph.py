@@ -3,7 +3,7 @@ after changing the Brownian seed, the initial state and the SDE parameters betwe
 import pytest
 import torch
 
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

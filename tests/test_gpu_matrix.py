@@ -6,7 +6,7 @@ compatibility table SURVEY.md appendix A.4)."""
 import pytest
 import torch
 
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

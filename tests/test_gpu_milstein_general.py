@@ -7,7 +7,7 @@ import torch
 from scipy.stats import linregress
 from torch import nn
 
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

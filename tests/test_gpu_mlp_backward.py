@@ -95,11 +95,11 @@ def test_the_two_statements_of_the_latent_sde_of_the_benchmark_agree():
     """bench.py's adjoint workload (a user module: nn.Sequential drift, 0.1 * sigmoid(w*y + b) diffusion) and its
     training workload (the closed-form module with the same parameter values) are the same SDE: bit-identical on the
     stepwise path, and the trajectory kernels reproduce the user module's solve and its autograd gradients."""
-    import bench
+    from workloads import configs
     import torchsde_amd
     d, B, steps, dt = 128, 512, 24, 2.0 ** -9
-    user = bench._make_problem("latent_diag", d, d, DEV)
-    closed = bench._make_problem("latent_diag_closed_form", d, d, DEV)
+    user = configs.make_problem("latent_diag", d, d, DEV)
+    closed = configs.make_problem("latent_diag_closed_form", d, d, DEV)
     ts = torch.tensor([0.0, steps * dt], device=DEV)
 
     def solve(sde, options):

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import counter, solvers_ref
-from tests import helpers, problems
+from tests import helpers
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 

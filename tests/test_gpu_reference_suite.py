@@ -7,7 +7,7 @@
 import pytest
 import torch
 
-from tests import problems
+from workloads import problems
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

@@ -15,7 +15,7 @@ B, D, STEPS, DT, ENTROPY = 1000, 64, 32, 2.0 ** -6, 990077
 
 
 def _problem():
-    from tests import problems
+    from workloads import problems
     return problems.make("gbm_ito", d=D).to("cuda")
 
 

@@ -104,7 +104,7 @@ def test_closed_form_gbm_equals_user_module_gbm():
     """The headline benchmark's SDE (tests/problems.py GBMDiag: f = mu*y, g = sigma*y as user torch code, stepwise
     path) and the same coefficients handed over in closed form (one trajectory launch) give the same bits."""
     import torchsde_amd
-    from tests import problems
+    from workloads import problems
     B, d = 8192, 64
     gbm = problems.make("gbm_ito", d=d).to(DEV)
     closed = torchsde_amd.AffineDiagonalSDE(gbm.mu.detach(), 0.0, gbm.sigma.detach(), 0.0, dtype=torch.float32).to(DEV)

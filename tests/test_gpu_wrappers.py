@@ -160,7 +160,7 @@ def test_step_doubling_increment_is_the_merge_of_its_halves(levy, method):
     import torchsde_amd
     from torchsde_amd import solvers
     from torchsde_amd.sde import ForwardSDE
-    from tests import problems
+    from workloads import problems
     B, d = 64, 8
     dtype = torch.float64
     bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, d), dtype=dtype, device=DEV, entropy=12,

@@ -10,7 +10,8 @@ import pytest
 import torch
 
 import torchsde_amd
-from tests import helpers, problems
+from tests import helpers
+from workloads import problems
 from torchsde_amd import _native, contract, solvers, timegrid
 from torchsde_amd.brownian import BrownianInterval, uniform_edges
 from torchsde_amd.sde import ForwardSDE
@@ -253,9 +254,9 @@ def test_output_times_reach_the_host_once():
 def test_bench_latent_sde_statements_agree_on_cpu():
     """bench.py's two statements of the configs[4] latent SDE (user module / closed-form module) have the same
     parameters and the same f, g (plain torch on the CPU: this is about the modules, not the kernels)."""
-    import bench
-    user = bench._make_problem("latent_diag", 16, 16, "cpu")
-    closed = bench._make_problem("latent_diag_closed_form", 16, 16, "cpu")
+    from workloads import configs
+    user = configs.make_problem("latent_diag", 16, 16, "cpu")
+    closed = configs.make_problem("latent_diag_closed_form", 16, 16, "cpu")
     y = torch.randn(5, 16, generator=torch.Generator().manual_seed(0))
     t = torch.tensor(0.0)
     assert torch.equal(user.f(t, y), closed.f(t, y)) and torch.equal(user.g(t, y), closed.g(t, y))

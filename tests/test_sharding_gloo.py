@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import counter, solvers_ref
-from tests import problems
+from workloads import problems
 
 B, D, STEPS, DT, ENTROPY = 10, 4, 8, 2.0 ** -4, 424242
 

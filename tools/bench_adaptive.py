@@ -1,7 +1,7 @@
 import sys, time, torch
 sys.path.insert(0, "/root/repo")
 import torchsde_amd
-from tests import problems
+from workloads import problems
 dev = "cuda"
 for (B, d) in ((1024, 16), (65536, 64)):
     sde = problems.make("gbm_ito", d=d).to(dev)

@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from tests import problems  # noqa: E402
+from workloads import problems  # noqa: E402
 from torchsde_amd.sde import ForwardSDE  # noqa: E402
 
 dev = "cuda"

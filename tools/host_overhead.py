@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, ".")
 import torchsde_amd  # noqa: E402
-from tests import problems  # noqa: E402
+from workloads import problems  # noqa: E402
 
 dev = "cuda"
 B, d, n, dt = 64, 64, 1000, 2.0 ** -10

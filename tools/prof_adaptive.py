@@ -1,7 +1,7 @@
 import sys, time, torch, cProfile, pstats
 sys.path.insert(0, "/root/repo")
 import torchsde_amd
-from tests import problems
+from workloads import problems
 dev = "cuda"
 B, d = 1024, 16
 sde = problems.make("gbm_ito", d=d).to(dev)

@@ -1,0 +1,105 @@
+"""The benchmark workloads: BASELINE.json's configurations at their single-GPU sizes (and the variants DESIGN.md
+measures), and the synthetic SDEs they run on. Shared by bench.py, tools/ and the full-size parity tests."""
+import torch
+
+WORKLOADS = {
+    # BASELINE.json configs[1] -- the headline (default) workload
+    "c2_euler_diag_b65536_d64_s1000": dict(
+        problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
+    # the other BASELINE configs at their single-GPU size (parity-test cases; measured for DESIGN.md, not the headline)
+    "c2_milstein_diag": dict(
+        problem="gbm_ito", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=20 * 64, kid=3, launches_per_step=1,
+        kernel="tsde_milstein_diag<float>"),
+    "c2_srk_diag": dict(
+        problem="gbm_ito", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=108 * 64, kid=4, launches_per_step=4,
+        kernel="tsde_srk_diag_stage<float> (4 stage kernels)"),
+    "c3_euler_general_b16384_d32_m16": dict(
+        problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1,
+        kernel="tsde_step_general<float> (general_fast_kernel)"),
+    # BASELINE configs[2] as literally worded: Milstein for GENERAL noise does not exist in the reference (it raises
+    # ValueError, milstein.py:25); this is the opt-in extension pinned by reduction tests (tests/test_gpu_milstein_general.py)
+    "c3_milstein_general_b16384_d32_m16": dict(
+        problem="general_big", method="milstein", levy="foster", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1, options={"general_noise": True},
+        kernel="tsde_step_general<float> (+ tsde_levy_area, tsde_iterated_integrals, 16 user JVPs per step)"),
+    "c4_midpoint_diag_b32768_d64": dict(
+        problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
+        kernel="tsde_step_diag<float> (two stages per step)"),
+    # The headline dynamics (same mu, sigma, seed addressing: bit-identical final states) handed over as a closed-form
+    # SDE (torchsde_amd.AffineDiagonalSDE): the whole solve is ONE launch of the trajectory kernel, state in
+    # registers. VALU-bound (Philox + Box-Muller), so the HBM roofline fraction is ~0 by design.
+    "c2_euler_closed_form_b65536_d64_s1000": dict(
+        problem="gbm_closed_form", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, euler> (trajectory_kernel)"),
+    "c2_milstein_closed_form": dict(
+        problem="gbm_closed_form", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, milstein> (trajectory_kernel)"),
+    "c2_srk_closed_form": dict(
+        problem="gbm_closed_form", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, srk> (trajectory_kernel)"),
+    "c4_midpoint_closed_form_b32768_d64": dict(
+        problem="gbm_closed_form_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000,
+        dt=2.0 ** -10, kid=8, trajectory=True,
+        kernel="tsde_trajectory_affine_diag<float, midpoint> (trajectory_kernel)"),
+    # Neural-SDE SAMPLING at the configs[4] shape (forward only): drift = Linear(128,128)-Softplus-Linear(128,128) like the
+    # latent-SDE workload below, affine diagonal diffusion, handed over as torchsde_amd.MLPDriftDiagonalSDE: one launch
+    # of the perceptron-drift kernel, both layers on the f32 matrix cores. MFMA-bound: 4*d*hidden flop per trajectory-step.
+    "c5_sampling_mlp_b32768_d128_s500": dict(
+        problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
+        kid=8, trajectory=True, mfma_flops_per_traj_step=4 * 128 * 128,
+        kernel="tsde_trajectory_mlp_diag<128, 128, softplus> (mlp_trajectory_kernel, v_mfma_f32_16x16x4_f32)"),
+    # The TRAINING step of the SDE of c5_adjoint_latent below (same parameter values, stated as the closed-form module):
+    # forward + loss.backward() through the solver, Euler: sampling kernel writing every step, reverse sweep (three
+    # products per step on the matrix cores), tall-K weight-gradient products.
+    # Roofline: the reverse sweep, 3 * 2*d*hidden flop per trajectory-step.
+    "c5_training_mlp_b32768_d128_s500": dict(
+        problem="latent_diag_closed_form", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
+        bytes_per_traj_step=0, kid=9, launches_per_step=1, trajectory=True, train=True,
+        mfma_flops_per_traj_step=6 * 128 * 128,
+        kernel="tsde_trajectory_mlp_diag_backward<128, 128, softplus> (mlp_backward_kernel, v_mfma_f32_16x16x4_f32)"),
+    "c5_adjoint_latent_b32768_d128_s500": dict(
+        problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
+        kernel="tsde_aug_update<float> (aug_multi_kernel, backward sweep)"),
+}
+
+
+def make_problem(name, d, m, dev):
+    from . import problems
+    if name == "general_big":      # NeuralGeneral-style: hidden 64
+        return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
+    if name == "latent_diag":      # latent-SDE-style diagonal SDE
+        return problems.LatentDiag(d).to(dev)
+    if name == "exp_diffusion":    # the reference's own benchmark SDE (benchmarks/brownian.py:131-139): f = y, g = exp(-y)
+        return problems.ExpDiffusion().to(dev)
+    if name == "latent_diag_closed_form":
+        # the SAME SDE as "latent_diag" (same parameter values), stated as the closed-form module the trajectory kernels
+        # take: drift Linear-Softplus-Linear, diffusion 0.1 * sigmoid(w * y + b)
+        import torchsde_amd
+        latent = make_problem("latent_diag", d, m, "cpu")
+        sde = torchsde_amd.MLPDriftDiagonalSDE(d, d, activation="softplus", diffusion="sigmoid", diff_scale=0.1,
+                                               diff_rate=latent.w.detach(), diff_shift=latent.b.detach())
+        with torch.no_grad():
+            for dst, src in ((sde.lin1, latent.net[0]), (sde.lin2, latent.net[2])):
+                dst.weight.copy_(src.weight)
+                dst.bias.copy_(src.bias)
+        return sde.to(dev)
+    if name == "mlp_drift":
+        import torchsde_amd
+        torch.manual_seed(0)
+        return torchsde_amd.MLPDriftDiagonalSDE(d, 128, activation="softplus", diff_rate=0.0, diff_shift=0.1).to(dev)
+    if name.startswith("gbm_closed_form"):
+        import torchsde_amd
+        strat = name.endswith("_strat")
+        gbm = problems.make("gbm_strat" if strat else "gbm_ito", d=d, m=m)
+        mu, sigma = gbm.mu.detach(), gbm.sigma.detach()
+        rate = mu - 0.5 * sigma ** 2 if strat else mu
+        return torchsde_amd.AffineDiagonalSDE(rate, 0.0, sigma, 0.0, sde_type="stratonovich" if strat else "ito",
+                                              dtype=torch.float32).to(dev)
+    return problems.make(name, d=d, m=m).to(dev)

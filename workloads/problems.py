@@ -135,6 +135,40 @@ class MLPDiag(nn.Module):
         return 0.1 * torch.sigmoid(self.w * y + self.b)
 
 
+class LatentDiag(nn.Module):
+    """Latent-SDE-style diagonal Ito SDE (BASELINE configs[4]; cf. reference examples/latent_sde_lorenz.py:122-148):
+    drift Linear(d,d)-Softplus-Linear(d,d), elementwise diffusion 0.1 * sigmoid(w*y + b)."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, d, seed=0):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.net = nn.Sequential(nn.Linear(d, d), nn.Softplus(), nn.Linear(d, d))
+        with torch.no_grad():
+            for p in self.net.parameters():
+                p.copy_(torch.randn(p.shape, generator=gen) / (d ** 0.5))
+        self.w = nn.Parameter(torch.randn(d, generator=gen))
+        self.b = nn.Parameter(0.1 * torch.randn(d, generator=gen))
+
+    def f(self, t, y):
+        return self.net(y)
+
+    def g(self, t, y):
+        return 0.1 * torch.sigmoid(self.w * y + self.b)
+
+
+class ExpDiffusion(nn.Module):
+    """The SDE the reference's own benchmark integrates (benchmarks/brownian.py:131-139): f = y, g = exp(-y),
+    diagonal Ito noise, no parameters."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def f(self, t, y):
+        return y
+
+    def g(self, t, y):
+        return torch.exp(-y)
+
+
 class ReadmeSDE(nn.Module):
     """The README quick example: general Ito noise, linear drift, linear diffusion reshaped to (B, d, m)."""
     noise_type = "general"
