@@ -318,3 +318,49 @@ def integrate_reversible_heun(sde, bm, y0, ts, dt):
             curr_t = next_t
         ys.append((curr_t - out_t) / (curr_t - prev_t) * prev_y + (out_t - prev_t) / (curr_t - prev_t) * curr_y)
     return torch.stack(ys, dim=0), extra
+
+
+# ---- logqp (v0.1.1 compatibility path) ------------------------------------------------------------------------
+class LogqpRef:
+    """base_sde.py:240-306 (`SDELogqp`): the state gains one column, the running KL integrand 0.5 |u|^2 with
+    u = (f - h) / g (diagonal; misc.stable_division, misc.py:66-68) or pinv(g) (f - h) (other noise types);
+    its diffusion row is zero. `names` follows base_sde.py:212-237 (`RenameMethodsSDE`)."""
+
+    def __init__(self, sde, names=None):
+        names = names or {}
+        self.noise_type, self.sde_type = sde.noise_type, sde.sde_type
+        self._f = getattr(sde, names.get("drift", "f"))
+        self._g = getattr(sde, names.get("diffusion", "g"))
+        self._h = getattr(sde, names.get("prior_drift", "h"))
+        self._params = list(sde.parameters()) if hasattr(sde, "parameters") else []
+
+    def parameters(self):
+        return iter(self._params)
+
+    def f_and_g(self, t, y):
+        y = y[:, :-1]
+        f, g, h = self._f(t, y), self._g(t, y), self._h(t, y)
+        if self.noise_type == "diagonal":
+            eps = 1e-7
+            safe = torch.where(g.abs().detach() > eps, g, torch.full_like(g, fill_value=eps) * g.sign())
+            u = (f - h) / safe
+            g_pad = y.new_zeros(size=(y.size(0), 1))
+        else:
+            u = torch.bmm(g.pinverse(), (f - h).unsqueeze(-1)).squeeze(-1)
+            g_pad = y.new_zeros(size=(g.size(0), 1, g.size(-1)))
+        f_logqp = .5 * (u ** 2).sum(dim=1, keepdim=True)
+        return torch.cat([f, f_logqp], dim=1), torch.cat([g, g_pad], dim=1)
+
+    def f(self, t, y):
+        return self.f_and_g(t, y)[0]
+
+    def g(self, t, y):
+        return self.f_and_g(t, y)[1]
+
+
+def integrate_logqp(sde, bm, y0, ts, dt, method, names=None, options=None):
+    """sdeint.py:142-144 (augment) + sdeint.py:284-295 (`parse_return`): returns (ys, log_ratio increments)."""
+    aug = torch.cat((y0, y0.new_zeros(size=(y0.size(0), 1))), dim=1)
+    ys = integrate(LogqpRef(sde, names), bm, aug, ts, dt, method, options)
+    ys, log_ratio = ys.split(split_size=(y0.size(1), 1), dim=2)
+    return ys, log_ratio.squeeze(dim=2)[1:] - log_ratio.squeeze(dim=2)[:-1]

@@ -13,6 +13,7 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   closed_form_mlp_<case>.npz   reference `sdeint` (+ autograd gradients) of the perceptron-drift module in float64, on
                       the counter-RNG path the trajectory kernels generate for themselves
   closed_form_affine_<case>.npz   the same for the affine diagonal module (all five schemes of its trajectory kernel)
+  logqp_<case>.npz    reference `sdeint(..., logqp=True)` / `sdeint_adjoint(..., logqp=True[, names=])`: ys, log-ratio, gradients
 """
 import os
 import sys
@@ -494,9 +495,66 @@ def gen_closed_form_affine():
               f"|grad drift_rate|={np.abs(out['grad__drift_rate']).mean():.4f}")
 
 
+# ---------------------------------------------------------------------------------------------------- logqp
+# `logqp=True` (reference sdeint.py:142-144, 284-295; base_sde.py:240-306): the state carries one more column, the
+# running KL integrand 0.5 |u|^2 with u = (f - h) / g (diagonal) or pinv(g) (f - h) (general); the Brownian motion
+# therefore has d + 1 channels for diagonal noise. Forward values, and for the adjoint cases the gradients of
+# sum(ys * w) + sum(log_ratio * v), from the real reference under replayed increments.
+LOGQP_CASES = [
+    # name, problem, method, adjoint (None = plain sdeint), names, (B, d, m), ts, dt
+    ("euler_gbm", "gbm_ito", "euler", None, None, (5, 4, 5), [0., 0.25, 0.5, 0.77], 0.1),
+    ("midpoint_mlpdiag", "mlpdiag_strat", "midpoint", None, None, (5, 4, 5), [0., 0.5, 1.0], 2.0 ** -4),
+    ("euler_general", "general_ito", "euler", None, None, (6, 4, 4), [0., 0.5], 0.05),
+    ("srk_gbm", "gbm_ito", "srk", None, None, (5, 4, 5), [0., 0.5], 0.05),
+    ("adjoint_mlpdiag_names", "mlpdiag_ito", "euler", "default", {"prior_drift": "prior"}, (5, 4, 5), [0., 0.5, 1.0],
+     2.0 ** -4),
+    ("adjoint_gbm_strat", "gbm_strat", "midpoint", "default", None, (5, 4, 5), [0., 0.5, 1.0], 2.0 ** -4),
+    ("backprop_mlpdiag", "mlpdiag_ito", "euler", "backprop", None, (5, 4, 5), [0., 0.5, 1.0], 2.0 ** -4),
+]
+
+
+def gen_logqp():
+    for name, prob, method, adjoint, names, (B, d, m), ts, dt in LOGQP_CASES:
+        levy = "space-time" if method == "srk" else "none"
+        out = {"problem": prob, "method": method, "levy": levy, "dt": np.float64(dt), "grad_free": False,
+               "shape": np.array([B, d, m]), "adjoint": adjoint or "",
+               "names": "" if names is None else ",".join(f"{k}={v}" for k, v in names.items())}
+        for tag, dtype in DT.items():
+            sde = problems.make(prob, dtype=dtype, d=d, m=m)
+            y0 = torch.full((B, d), 0.1, dtype=dtype, requires_grad=adjoint is not None)
+            tst = torch.tensor(ts, dtype=dtype)
+            bm = ReplayBM((B, m), dtype, seed=sum(map(ord, "logqp_" + name)), levy=levy)
+            if adjoint == "default":
+                ys, log_ratio = torchsde.sdeint_adjoint(sde, y0, tst, bm=bm, method=method, dt=dt, logqp=True, names=names)
+            elif adjoint == "backprop":
+                ys, log_ratio = torchsde.sdeint(sde, y0, tst, bm=bm, method=method, dt=dt, logqp=True, names=names)
+            else:
+                with torch.no_grad():
+                    ys, log_ratio = torchsde.sdeint(sde, y0, tst, bm=bm, method=method, dt=dt, logqp=True, names=names)
+            if adjoint is not None:
+                rng = np.random.default_rng(11)
+                wy = torch.tensor(rng.standard_normal(tuple(ys.shape)), dtype=dtype)
+                wl = torch.tensor(rng.standard_normal(tuple(log_ratio.shape)), dtype=dtype)
+                ((ys * wy).sum() + (log_ratio * wl).sum()).backward()
+                out[f"{tag}__wy"], out[f"{tag}__wl"] = wy.numpy(), wl.numpy()
+                out[f"{tag}__grad_y0"] = y0.grad.numpy()
+                for j, p in enumerate(sde.parameters()):
+                    out[f"{tag}__grad_p{j}"] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy()
+            keys, W, U = bm.dump()
+            out[f"{tag}__ts"] = tst.numpy()
+            out[f"{tag}__queries"] = keys
+            out[f"{tag}__W"] = W
+            out[f"{tag}__U"] = U
+            out[f"{tag}__ys"] = ys.detach().numpy()
+            out[f"{tag}__log_ratio"] = log_ratio.detach().numpy()
+            out[f"{tag}__param_checksum"] = np.float64(param_checksum(sde))
+        np.savez_compressed(os.path.join(HERE, f"logqp_{name}.npz"), **out)
+        print(f"logqp_{name}.npz  queries={len(keys)}  log_ratio[:, 0]={out['f32__log_ratio'][:, 0]}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
-                             "closed_form_affine"]
+                             "closed_form_affine", "logqp"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

@@ -107,3 +107,49 @@ def mlp_module_from(z, dtype, device):
         for name, p in sde.named_parameters():
             p.copy_(torch.tensor(z["param__" + name]).to(dtype))
     return sde.to(device)
+
+
+def sampled_rows(B, n=64, seed=0, seams=()):
+    """~n global rows of a B-row batch: the first and last rows, both sides of every kernel / shard seam handed in
+    (`seams`), both sides of the 256-row tile boundaries next to them, and random rows in between."""
+    rows = {0, 1, B - 2, B - 1}
+    for s in tuple(seams) + (B // 2, 256, 512, B - 256):
+        rows.update(r for r in (s - 1, s, s + 1) if 0 <= r < B)
+    gen = np.random.default_rng(seed)
+    while len(rows) < n:
+        rows.add(int(gen.integers(0, B)))
+    return np.array(sorted(rows), dtype=np.int64)
+
+
+def counter_rows_bm(rows, m, entropy, edges, dtype, levy=False):
+    """The counter-RNG Brownian path of GLOBAL batch rows `rows` (m channels each) from the oracle's C twin of the
+    generator, as the callable the oracle's solvers take: ``bm(ta, tb, return_U=False) -> (len(rows), m)`` tensors.
+    Row r of an unsharded (B, m) BrownianInterval is elements r*m .. r*m + m - 1 of the counter field."""
+    from oracle import counter
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    edges = np.ascontiguousarray(edges, dtype=np.float64)
+
+    def bm(ta, tb, return_U=False, return_A=False):
+        W = np.empty((len(rows), m), dtype=npdt)
+        U = np.empty((len(rows), m), dtype=npdt) if levy else None
+        for k, r in enumerate(rows):
+            w, u, _ = counter.query(m, entropy, edges, float(ta), float(tb), dtype=npdt, elem0=int(r) * m, have_h=levy)
+            W[k] = w
+            if levy:
+                U[k] = u
+        W = torch.from_numpy(W)
+        return (W, torch.from_numpy(U)) if return_U else W
+
+    return bm
+
+
+def assert_within_reference_rounding(new32, ref32, ref64, what="", factor=4.0, floor=1e-6):
+    """the float32 HIP result may differ from the float64 oracle by at most `factor` times what
+    the oracle's own float32 run differs from it, plus `floor` (scaled by the magnitude of the compared quantity)."""
+    new32, ref32, ref64 = (torch.as_tensor(x).detach().double().cpu() for x in (new32, ref32, ref64))
+    scale = max(1.0, ref64.abs().max().item())
+    err_new = (new32 - ref64).abs().max().item()
+    err_ref = (ref32 - ref64).abs().max().item()
+    assert err_new <= factor * err_ref + floor * scale, \
+        f"{what}: |hip32 - ref64| = {err_new:.3e} > {factor} * |ref32 - ref64| ({err_ref:.3e}) + {floor * scale:.1e}"
+    return err_new, err_ref

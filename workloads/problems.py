@@ -36,6 +36,10 @@ class GBMDiag(nn.Module):
     def g(self, t, y):
         return self.sigma * y
 
+    def h(self, t, y):
+        """A prior drift for `logqp=True` (KL between this SDE and the one with drift h; sdeint.py:142-144)."""
+        return -0.5 * y + 0.05
+
     def exact(self, y0, t, W_t):
         """Closed form y0 * exp((mu - sigma^2/2) t + sigma W_t) on the same Brownian path."""
         return y0 * torch.exp((self.mu - 0.5 * self.sigma ** 2) * t + self.sigma * W_t)
@@ -115,6 +119,10 @@ class MLPGeneral(nn.Module):
     def g(self, t, y):
         return self.g_net(self._ty(t, y)).reshape(y.size(0), self.d, self.m)
 
+    def h(self, t, y):
+        """Prior drift for `logqp=True` (general noise: u = pinv(g) (f - h), base_sde.py:283-287)."""
+        return -y
+
 
 class MLPDiag(nn.Module):
     """Diagonal noise with an elementwise diffusion g_i(y_i) (a valid diagonal SDE for Milstein/adjoint)."""
@@ -133,6 +141,14 @@ class MLPDiag(nn.Module):
 
     def g(self, t, y):
         return 0.1 * torch.sigmoid(self.w * y + self.b)
+
+    def h(self, t, y):
+        """Prior drift for `logqp=True`."""
+        return 0.5 * torch.tanh(y) - 0.1 * torch.cos(t)
+
+    def prior(self, t, y):
+        """A second prior drift, reached through `names={"prior_drift": "prior"}`."""
+        return -y * torch.sigmoid(self.b)
 
 
 class LatentDiag(nn.Module):
