@@ -105,6 +105,11 @@ class AdjointSDERef:
                 gp = solvers_ref.prod(self.fwd, g, v)
             return self._f_parts(f, g, y, a), self._g_parts(gp, y, a)
 
+    def g_prod(self, t, y_aug, v):                                         # :283-287
+        y, a = self._state(y_aug)
+        with torch.enable_grad():
+            return self._g_parts(solvers_ref.g_prod(self.fwd, -t, y, v), y, a)
+
     def g_prod_and_gdg_prod(self, t, y_aug, v1, v2):                       # :332-377 (diagonal noise)
         y, a = self._state(y_aug)
         inputs = [y] + self.params
@@ -121,7 +126,8 @@ class AdjointSDERef:
 
 
 def _aug_step(adj, method, bm, t0, t1, aug):
-    """The generic solver steps (euler.py:29-37, midpoint.py:29-45, milstein.py:52-74) on the flat state."""
+    """The generic solver steps (euler.py:29-37, midpoint.py:29-45, milstein.py:52-74, heun.py:35-48,
+    euler_heun.py:29-42) on the flat state."""
     dt = t1 - t0
     I_k = bm(t0, t1)
     if method == "euler":
@@ -138,6 +144,16 @@ def _aug_step(adj, method, bm, t0, t1, aug):
         F = adj.f(t0, aug)
         G, D = adj.g_prod_and_gdg_prod(t0, aug, I_k, 0.5 * v)
         return aug + F * dt + G + D
+    if method == "heun":                           # methods/heun.py:35-48
+        F, G = adj.f_and_g_prod(t0, aug, I_k)
+        aug_prime = aug + dt * F + G
+        F2, G2 = adj.f_and_g_prod(t1, aug_prime, I_k)
+        return aug + (dt * (F + F2) + G + G2) * 0.5
+    if method == "euler_heun":                     # methods/euler_heun.py:29-42
+        F, G = adj.f_and_g_prod(t0, aug, I_k)
+        aug_prime = aug + G
+        G2 = adj.g_prod(t1, aug_prime, I_k)
+        return aug + dt * F + (G + G2) * 0.5
     raise ValueError(method)
 
 

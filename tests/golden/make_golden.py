@@ -260,6 +260,12 @@ ADJOINT_CASES = [
     ("mlpdiag_strat_rheun", "mlpdiag_strat", "reversible_heun", None, "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
     ("general_strat_rheun", "general_strat", "reversible_heun", None, "none", (6, 4, 4), [0., 1.0], 2.0 ** -4),
     ("scalar_strat_rheun", "scalar_strat", "reversible_heun", None, "none", (5, 4, 1), [0., 1.0], 2.0 ** -4),
+    # the other solvers the reference can run on an adjoint SDE (they only need f_and_g_prod / g_prod)
+    ("gbm_strat_heun", "gbm_strat", "heun", "heun", "none", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -4),
+    ("mlpdiag_strat_euler_heun", "mlpdiag_strat", "euler_heun", "euler_heun", "none", (5, 4, 4), [0., 0.5, 1.0],
+     2.0 ** -4),
+    ("general_strat_adj_heun", "general_strat", "midpoint", "heun", "none", (6, 4, 4), [0., 1.0], 2.0 ** -4),
+    ("scalar_strat_adj_euler_heun", "scalar_strat", "midpoint", "euler_heun", "none", (5, 4, 1), [0., 1.0], 2.0 ** -4),
 ]
 
 

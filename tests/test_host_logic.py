@@ -264,3 +264,69 @@ def test_bench_latent_sde_statements_agree_on_cpu():
     assert sum(p.numel() for p in user.parameters()) == sum(p.numel() for p in closed.parameters())
     spec = closed.closed_form(16, torch.float32, torch.device("cpu"))
     assert spec[0] == "mlp_diagonal" and spec[-1] == (1, 0.1) and spec[1].shape == (16, 16)
+
+
+# ---- which backward sweep an `adjoint_method` string selects (no kernels involved) -----------------------------
+def _fake_bm(levy="none"):
+    class BM:
+        levy_area_approximation = levy
+    return BM()
+
+
+@pytest.mark.parametrize("problem,adjoint_method,want", [
+    ("gbm_ito", "euler", "euler"), ("gbm_ito", "milstein", "milstein"), ("general_ito", "euler", "euler"),
+    ("gbm_strat", "midpoint", "midpoint"), ("gbm_strat", "milstein", "milstein"), ("gbm_strat", "heun", "heun"),
+    ("gbm_strat", "euler_heun", "euler_heun"), ("general_strat", "heun", "heun"),
+    ("general_strat", "euler_heun", "euler_heun"), ("scalar_strat", "heun", "heun"),
+])
+def test_adjoint_method_selects_its_own_backward_sweep(problem, adjoint_method, want):
+    """Every solver the reference can run on an adjoint SDE (adjoint.py:83-93) maps to ITS backward sweep -- not to
+    Milstein by default."""
+    from torchsde_amd import adjoint
+    sde = ForwardSDE(problems.make(problem))
+    assert adjoint._backward_kind(sde, _fake_bm(), adjoint_method, {}, list(sde.parameters())) == want
+
+
+@pytest.mark.parametrize("problem,adjoint_method,error,match", [
+    ("gbm_strat", "log_ode", ValueError, "Log-ODE schemes cannot be used for adjoint SDEs"),      # log_ode.py:32-35
+    ("gbm_strat", "reversible_heun", RuntimeError, "Adjoint `f_and_g` not defined"),      # adjoint_sde.py:262-264
+    ("gbm_ito", "srk", ValueError, "Stochastic Runge"),                                          # srk.py:40-43
+    ("gbm_ito", "heun", ValueError, "SDE is of type ito but solver is for type stratonovich"),
+    ("general_strat", "milstein", ValueError, "noise type"),                                     # milstein.py:38-41
+    ("gbm_strat", "adjoint_reversible_heun", None, None),
+])
+def test_unusable_adjoint_methods_fail_at_call_time(problem, adjoint_method, error, match):
+    from torchsde_amd import adjoint
+    sde = ForwardSDE(problems.make(problem))
+    levy = "foster" if adjoint_method == "log_ode" else "none"
+    if error is None:
+        assert adjoint._backward_kind(sde, _fake_bm(), adjoint_method, {}, []) == "reversible_heun"
+        return
+    with pytest.raises(error, match=match):
+        adjoint._check_adjoint_method(adjoint.AdjointSDE(sde, []), adjoint_method, {}, _fake_bm(levy))
+
+
+# ---- the closed-form route is taken only for the dynamics the module itself states ---------------------------------
+def test_closed_form_route_ignores_subclasses_that_change_the_dynamics():
+    from torchsde_amd import closed_form
+
+    class TimeDependentDrift(torchsde_amd.AffineDiagonalSDE):
+        def f(self, t, y):
+            return torch.sin(t) * y
+
+    class OwnProduct(torchsde_amd.MLPDriftDiagonalSDE):
+        def g_prod(self, t, y, v):
+            return 2.0 * v
+
+    class SameDynamics(torchsde_amd.AffineDiagonalSDE):
+        def extra_report(self):
+            return "nothing the solver sees"
+
+    assert closed_form.publishes_its_own_dynamics(torchsde_amd.AffineDiagonalSDE(1.0, 0.0, 0.5, 0.0))
+    assert closed_form.publishes_its_own_dynamics(torchsde_amd.MLPDriftDiagonalSDE(4, 4))
+    assert closed_form.publishes_its_own_dynamics(SameDynamics(1.0, 0.0, 0.5, 0.0))
+    assert not closed_form.publishes_its_own_dynamics(TimeDependentDrift(1.0, 0.0, 0.5, 0.0))
+    assert not closed_form.publishes_its_own_dynamics(OwnProduct(4, 4))
+    patched = torchsde_amd.AffineDiagonalSDE(1.0, 0.0, 0.5, 0.0)
+    patched.g = lambda t, y: y * 0.0 + 1.0
+    assert not closed_form.publishes_its_own_dynamics(patched)

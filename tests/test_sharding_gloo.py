@@ -44,8 +44,17 @@ def _worker(rank, world, port, q):
                                         solve_fn=_oracle_solve)
         p = torch.nn.Parameter(torch.ones(3))
         p.grad = torch.full((3,), float(rank + 1))
-        sharding.all_reduce_gradients([p])
-        q.put((rank, final.numpy(), every.numpy(), p.grad.numpy()))
+        # a parameter only rank 0 has a gradient for, and a float64 one next to the float32 ones: every rank must
+        # reduce over the same flat layout (zeros for the missing gradient), per dtype
+        lonely = torch.nn.Parameter(torch.ones(2))
+        if rank == 0:
+            lonely.grad = torch.full((2,), 5.0)
+        wide = torch.nn.Parameter(torch.ones(2, dtype=torch.float64))
+        wide.grad = torch.full((2,), 1.0 + 2.0 ** -40, dtype=torch.float64)
+        frozen = torch.nn.Parameter(torch.ones(1), requires_grad=False)
+        sharding.all_reduce_gradients([p, lonely, wide, frozen])
+        assert frozen.grad is None and wide.grad.dtype == torch.float64
+        q.put((rank, final.numpy(), every.numpy(), p.grad.numpy(), lonely.grad.numpy(), wide.grad.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -75,10 +84,12 @@ def test_sharded_equals_unsharded(world):
     y0 = torch.linspace(0.05, 0.2, B * D).reshape(B, D)
     ts = torch.tensor([0.0, STEPS * DT])
     full = _oracle_solve(sde, y0, ts, _BM, "euler", DT).numpy()
-    for rank, final, every, grad in results:
+    for rank, final, every, grad, lonely, wide in results:
         assert np.array_equal(final, full[-1]), rank
         assert np.array_equal(every, full), rank
         assert np.array_equal(grad, np.full(3, sum(range(1, world + 1)), dtype=np.float32))
+        assert np.array_equal(lonely, np.full(2, 5.0, dtype=np.float32))
+        assert np.array_equal(wide, np.full(2, world * (1.0 + 2.0 ** -40)))        # not rounded through float32
 
 
 def test_shard_rows_partition():

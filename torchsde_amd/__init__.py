@@ -5,5 +5,6 @@ from .adjoint import sdeint_adjoint
 from .closed_form import AffineDiagonalSDE, MLPDriftDiagonalSDE
 from .integrate import sdeint
 from .sde import BaseSDE, SDEIto, SDEStratonovich
+from . import types  # noqa: F401
 
 __version__ = "0.1.0"

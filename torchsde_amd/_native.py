@@ -171,6 +171,31 @@ def require_device(*tensors):
                 f"'{t.device}'). This package is the MI355X hot path of torchsde and has no CPU fallback.")
 
 
+class on_device_of:
+    """Make the device of `tensor_or_device` current for the duration of the block. Launches go to that device's
+    current stream (`stream_ptr`, kernels._launch_env); HIP wants the launching thread's current device to be the
+    stream's, so every public entry point (sdeint, sdeint_adjoint, BrownianInterval queries) runs inside this guard.
+    Costs two cheap calls when the device is already current."""
+
+    def __init__(self, tensor_or_device):
+        dev = tensor_or_device.device if torch.is_tensor(tensor_or_device) else torch.device(tensor_or_device)
+        self._index = dev.index if dev.type == "cuda" else None
+        self._prev = None
+
+    def __enter__(self):
+        if self._index is not None:
+            prev = torch.cuda.current_device()
+            if prev != self._index:
+                self._prev = prev
+                torch.cuda.set_device(self._index)
+        return self
+
+    def __exit__(self, *exc):
+        if self._prev is not None:
+            torch.cuda.set_device(self._prev)
+        return False
+
+
 def stream_ptr(device=None):
     """The HIP stream torch is currently issuing work on (so launches order with the user's f/g ops
     and are captured by an enclosing HIP graph)."""

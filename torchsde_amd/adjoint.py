@@ -138,6 +138,12 @@ class AdjointSDE(BaseSDE):
             grads = [torch.zeros_like(x) if gr is None else gr for gr, x in zip(grads, inputs)]
             return f.detach(), g_prod.detach(), grads
 
+    def g_prod(self, t, y, a, v):
+        """Diffusion-product parts only (adjoint_sde.py:283-287): what Euler-Heun's second stage asks for."""
+        y = self._leaf(y)
+        with torch.enable_grad():
+            return self._diffusion_parts(self.forward_sde.g_prod(t, y, v), y, a)
+
     def f(self, t, y, a):
         """Drift parts only (adjoint_sde.py:236-252)."""
         fwd = self.forward_sde
@@ -239,6 +245,16 @@ def _check_adjoint_method(adjoint_sde, adjoint_method, adjoint_options, bm):
             raise ValueError(f"SDE is of type {adjoint_sde.sde_type} but solver is for type {SDE_TYPES.stratonovich}")
         return _ReversibleHeunBackward
     cls = solvers.select(adjoint_method, adjoint_sde.sde_type)
+    if cls is solvers.LogODEMidpoint:    # methods/log_ode.py:32-35
+        raise ValueError("Log-ODE schemes cannot be used for adjoint SDEs, because they require "
+                         "direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
+                         "diffusion-vector product. Use a different method instead.")
+    if cls is solvers.ReversibleHeun:
+        # the reference builds the solver and fails inside backward() when it asks the adjoint SDE for `f_and_g`
+        # (methods/reversible_heun.py:58-59 -> adjoint_sde.py:262-264); same error, raised at call time
+        raise RuntimeError("Adjoint `f_and_g` not defined: `reversible_heun` cannot integrate an adjoint SDE; use "
+                           f"adjoint_method={repr(METHODS.adjoint_reversible_heun)} (with method="
+                           f"{repr(METHODS.reversible_heun)}) instead.")
     if cls is solvers.SRK:
         raise ValueError("Stochastic Runge–Kutta methods cannot be used for adjoint SDEs, because it requires "
                          "direct access to the diffusion, whilst adjoint SDEs rely on a more efficient "
@@ -380,6 +396,12 @@ class _SdeintAdjointMethod(torch.autograd.Function):
     def backward(ctx, grad_ys, *grad_extra_solver_state):
         if torch.is_grad_enabled():
             raise NotImplementedError("torchsde_amd: double backward through sdeint_adjoint is not supported.")
+        from . import _native
+        with _native.on_device_of(grad_ys):
+            return _SdeintAdjointMethod._backward(ctx, grad_ys, *grad_extra_solver_state)
+
+    @staticmethod
+    def _backward(ctx, grad_ys, *grad_extra_solver_state):
         ys, ts, *rest = ctx.saved_tensors
         reversible = ctx.saved_extras_for_backward
         forward_extras = rest[:ctx.len_extras] if reversible else []
@@ -443,7 +465,11 @@ def _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params):
     method_cls = _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
     if method_cls is _ReversibleHeunBackward:
         return "reversible_heun"
-    return "euler" if method_cls is solvers.Euler else "midpoint" if method_cls is solvers.Midpoint else "milstein"
+    for cls, kind in ((solvers.Euler, "euler"), (solvers.Midpoint, "midpoint"), (solvers._Milstein, "milstein"),
+                      (solvers.Heun, "heun"), (solvers.EulerHeun, "euler_heun")):
+        if issubclass(method_cls, cls):
+            return kind
+    raise NotImplementedError(f"torchsde_amd: no backward sweep for adjoint_method={repr(adjoint_method)}.")
 
 
 def _backward_runner(sde, bm, dt, kind, adjoint_params, ts_host, device):
@@ -480,9 +506,11 @@ def _plan_backward(ts_host, dt, native, device):
         np_dtype = grid.t.dtype.type
         tau64 = grid.t_f64()
         # forward-time stage tensors: -(tau0), and for midpoint -(tau0 + dt/2)   (adjoint_sde.py passes -t)
-        stage = np.empty((max(n, 1), 2), dtype=grid.t.dtype)
+        # ... and -(tau1) for the second stage of Heun / Euler-Heun
+        stage = np.empty((max(n, 1), 3), dtype=grid.t.dtype)
         stage[:n, 0] = -grid.t[:-1]
         stage[:n, 1] = -(grid.t[:-1] + np_dtype(0.5) * grid.dt)
+        stage[:n, 2] = -grid.t[1:]
         stage_dev = torch.from_numpy(stage).to(device)
         stage_rows = [r.unbind(0) for r in stage_dev.unbind(0)]
         tau_dev = None
@@ -499,9 +527,10 @@ def _plan_backward(ts_host, dt, native, device):
     return intervals
 
 
-def _aug_step(adjoint_sde, kind, ito, src, dst, mid, t_fwd, t_fwd_half, step_dt, v):
+def _aug_step(adjoint_sde, kind, ito, src, dst, mid, t_fwd, t_fwd_half, t_fwd_end, step_dt, v):
     """One backward step of the augmented state `src` -> `dst` over a step of size `step_dt` that starts at forward
-    time `t_fwd` (0-d device tensor; `t_fwd_half`: the midpoint stage's), with the reversed increment `v`."""
+    time `t_fwd` (0-d device tensor; `t_fwd_half`: the midpoint stage's, `t_fwd_end`: the step's end, for the second
+    stage of Heun / Euler-Heun), with the reversed increment `v`."""
     y, a = src.t[0], src.t[1]
     none_tail = [None] * (len(src.t) - 1)
     if kind == "euler":
@@ -514,6 +543,21 @@ def _aug_step(adjoint_sde, kind, ito, src, dst, mid, t_fwd, t_fwd_half, step_dt,
         _update(mid, src, [ft] + none_tail, [gp] + none_tail, [None] + tot, half_dt, 0.5)
         ft, gp, tot = adjoint_sde.fused_terms(t_fwd_half, mid.t[0], mid.t[1], v, float(step_dt), 1.0)
         _update(dst, src, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
+    elif kind == "heun":
+        # heun.py:35-48 on the augmented state: prime = s + dt F + G ; s1 = s + (dt (F + F') + G + G') / 2
+        half_dt = type(step_dt)(0.5) * step_dt
+        ft, gp, tot = adjoint_sde.fused_terms(t_fwd, y, a, v, float(step_dt), 1.0)
+        _update(mid, src, [ft] + none_tail, [gp] + none_tail, [None] + tot, step_dt, 1.0)
+        ft2, gp2, tot2 = adjoint_sde.fused_terms(t_fwd_end, mid.t[0], mid.t[1], v, float(step_dt), 1.0)
+        both = [K.lincomb2(p, q, 0.5, 0.5) for p, q in zip(tot, tot2)]
+        _update(dst, src, [K.lincomb2(ft, ft2, 1.0, 1.0)] + none_tail, [K.lincomb2(gp, gp2, 1.0, 1.0)] + none_tail,
+                [None] + both, half_dt, 0.5)
+    elif kind == "euler_heun":
+        # euler_heun.py:29-42: prime = s + G ; G' = g_prod(t1, prime) ; s1 = s + dt F + (G + G') / 2
+        F, G = adjoint_sde.f_and_g_prod(t_fwd, y, a, v)
+        _update(mid, src, None, G, None, 0.0, 1.0)
+        G2 = adjoint_sde.g_prod(t_fwd_end, mid.t[0], mid.t[1], v)
+        _update(dst, src, F, [K.lincomb2(p, q, 1.0, 1.0) for p, q in zip(G, G2)], None, step_dt, 0.5)
     else:  # milstein (diagonal noise): v_term = I^2 - dt (Ito) or I^2, halved (milstein.py:56,70)
         v2, _ = K.milstein_v(NoiseSpec.external(v), step_dt, ito, 0.5, like=y)
         F = adjoint_sde.f(t_fwd, y, a)
@@ -531,7 +575,7 @@ def _run_backward(adjoint_sde, kind, bm, plan, ys, grad_ys):
     state = _AugState([ys[-1].clone(), grad_ys[-1].contiguous().clone()] +
                       [torch.zeros_like(p) for p in adjoint_params])
     other = _AugState.like(state)
-    mid = _AugState.like(state) if kind == "midpoint" else None
+    mid = _AugState.like(state) if kind in ("midpoint", "heun", "euler_heun") else None
 
     for (i, grid, tau64, stage_rows, cells, tau_dev) in plan:
         n = grid.n_steps
@@ -545,7 +589,7 @@ def _run_backward(adjoint_sde, kind, bm, plan, ys, grad_ys):
                     v, _ = native.increment(-tau64[k + 1], -tau64[k])
             else:
                 v = reverse_bm(tau_dev[k], tau_dev[k + 1])
-            _aug_step(adjoint_sde, kind, ito, state, other, mid, stage_rows[k][0], stage_rows[k][1], grid.dt[k], v)
+            _aug_step(adjoint_sde, kind, ito, state, other, mid, *stage_rows[k], grid.dt[k], v)
             state, other = other, state
         # adjoint.py:114-116
         state.t[0].copy_(ys[i - 1])
@@ -568,7 +612,7 @@ def _run_backward_adaptive(adjoint_sde, kind, bm, ts_host, dt, rtol, atol, dt_mi
     state = _AugState([ys[-1].clone(), grad_ys[-1].contiguous().clone()] +
                       [torch.zeros_like(p) for p in adjoint_sde.params])
     full, half, nxt_state = _AugState.like(state), _AugState.like(state), _AugState.like(state)
-    mid = _AugState.like(state) if kind == "midpoint" else None
+    mid = _AugState.like(state) if kind in ("midpoint", "heun", "euler_heun") else None
 
     def increment(ta, tb):                       # reversed increment of the backward-time interval [ta, tb]
         if native is not None:
@@ -590,11 +634,11 @@ def _run_backward_adaptive(adjoint_sde, kind, bm, ts_host, dt, rtol, atol, dt_mi
             v_full = v_a + v_b if native is not None else increment(curr_t, next_t)
             h_full, h_a, h_b = np_dtype(next_t - curr_t), np_dtype(mid_t - curr_t), np_dtype(next_t - mid_t)
             stage = np.asarray([-curr_t, -(curr_t + np_dtype(0.5) * h_full), -(curr_t + np_dtype(0.5) * h_a),
-                                -mid_t, -(mid_t + np_dtype(0.5) * h_b)], dtype=ts_host.dtype)
+                                -mid_t, -(mid_t + np_dtype(0.5) * h_b), -next_t], dtype=ts_host.dtype)
             t_dev = torch.from_numpy(stage).to(device).unbind(0)
-            _aug_step(adjoint_sde, kind, ito, state, full, mid, t_dev[0], t_dev[1], h_full, v_full)
-            _aug_step(adjoint_sde, kind, ito, state, half, mid, t_dev[0], t_dev[2], h_a, v_a)
-            _aug_step(adjoint_sde, kind, ito, half, nxt_state, mid, t_dev[3], t_dev[4], h_b, v_b)
+            _aug_step(adjoint_sde, kind, ito, state, full, mid, t_dev[0], t_dev[1], t_dev[5], h_full, v_full)
+            _aug_step(adjoint_sde, kind, ito, state, half, mid, t_dev[0], t_dev[2], t_dev[3], h_a, v_a)
+            _aug_step(adjoint_sde, kind, ito, half, nxt_state, mid, t_dev[3], t_dev[4], t_dev[5], h_b, v_b)
             error_estimate = solvers._error_estimate(flat(full), flat(nxt_state), rtol, atol)
             step_size, prev_error_ratio = solvers._update_step_size(error_estimate, step_size, prev_error_ratio)
             if step_size < dt_min:
@@ -619,7 +663,16 @@ def sdeint_adjoint(sde, y0, ts, bm=None, method=None, adjoint_method=None, dt=1e
     """Numerically integrate an SDE with stochastic-adjoint gradients (see ``torchsde.sdeint_adjoint``)."""
     contract.handle_unused_kwargs(unused_kwargs, msg="`sdeint_adjoint`")
     del unused_kwargs
+    from . import _native
+    with _native.on_device_of(y0 if torch.is_tensor(y0) else "cpu"):
+        return _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, rtol,
+                               adjoint_rtol, atol, adjoint_atol, dt_min, options, adjoint_options, adjoint_params, names,
+                               logqp, extra, extra_solver_state)
 
+
+def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, rtol, adjoint_rtol, atol,
+                    adjoint_atol, dt_min, options, adjoint_options, adjoint_params, names, logqp, extra,
+                    extra_solver_state):
     if adjoint_params is None and not isinstance(sde, nn.Module):
         raise ValueError("`sde` must be an instance of nn.Module to specify the adjoint parameters; alternatively they "
                          "can be specified explicitly via the `adjoint_params` argument. If there are no parameters "

@@ -262,10 +262,11 @@ class BrownianInterval(BaseBrownian):
         if ta > tb:
             raise RuntimeError(f"Query times ta={ta:.3f} and tb={tb:.3f} must respect ta <= tb.")
         A = None
-        if return_A and self._have_A:
-            W, U, A = self.increment_with_levy_area(ta, tb)
-        else:
-            W, U = self.increment(ta, tb, want_U=self._have_H)
+        with _native.on_device_of(self._device):
+            if return_A and self._have_A:
+                W, U, A = self.increment_with_levy_area(ta, tb)
+            else:
+                W, U = self.increment(ta, tb, want_U=self._have_H)
         if return_U:
             return (W, U, A) if return_A else (W, U)
         return (W, A) if return_A else W

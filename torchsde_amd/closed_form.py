@@ -12,6 +12,27 @@ import torch
 from torch import nn
 
 
+def publishes_its_own_dynamics(sde):
+    """True when the `closed_form()` an SDE object publishes is a statement of the `f` / `g` it would be integrated
+    with: the same class defines `closed_form`, `f` and `g` (a subclass that overrides the drift or the diffusion --
+    say, makes it time-dependent -- without restating `closed_form` still inherits the parent's coefficients), and
+    nothing on the class or the instance adds another drift / diffusion provider (`f_and_g`, `g_prod`,
+    `f_and_g_prod`), which `ForwardSDE` would prefer over `f` and `g` (base_sde.py:51-73)."""
+    def owner(name):
+        if name in getattr(sde, "__dict__", {}):
+            return "instance"
+        for klass in type(sde).__mro__:
+            if name in klass.__dict__:
+                return klass
+        return None
+    home = owner("closed_form")
+    if home is None or home == "instance":
+        return False
+    if owner("f") is not home or owner("g") is not home or owner("closed_form_parameters") is not home:
+        return False
+    return all(owner(name) is None for name in ("f_and_g", "g_prod", "f_and_g_prod"))
+
+
 class AffineDiagonalSDE(nn.Module):
     """Diagonal-noise SDE with per-channel affine coefficients:
 

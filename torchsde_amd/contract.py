@@ -87,6 +87,20 @@ class _ShapeLedger:
                 raise ValueError(f"{label} sizes not consistent.")
 
 
+def default_method(sde):
+    """sdeint.py:146-157."""
+    return _DEFAULT_METHOD[sde.sde_type][sde.noise_type]
+
+
+def default_levy_area_approximation(method):
+    """The Levy-area approximation of the Brownian motion `sdeint` builds for `bm=None` (sdeint.py:260-267)."""
+    if method == METHODS.srk:
+        return LEVY_AREA_APPROXIMATIONS.space_time
+    if method == METHODS.log_ode_midpoint:
+        return LEVY_AREA_APPROXIMATIONS.foster
+    return LEVY_AREA_APPROXIMATIONS.none
+
+
 def check_contract(sde, y0, ts, bm, method, adaptive, options, names, logqp, bm_dt=None, bm_row_offset=0):
     """Returns (ForwardSDE, y0, ts, bm, method, options) or raises ValueError.
 
@@ -178,12 +192,7 @@ def check_contract(sde, y0, ts, bm, method, adaptive, options, names, logqp, bm_
     sde = sde_lib.ForwardSDE(sde)
 
     if bm is None:
-        if method == METHODS.srk:
-            levy = LEVY_AREA_APPROXIMATIONS.space_time
-        elif method == METHODS.log_ode_midpoint:
-            levy = LEVY_AREA_APPROXIMATIONS.foster
-        else:
-            levy = LEVY_AREA_APPROXIMATIONS.none
+        levy = default_levy_area_approximation(method)
         # Like the reference, no `dt` hint: a fixed-step solve will hand its own time grid to the
         # Brownian motion (BrownianInterval.adopt_grid), which is exact for any dt and dtype.
         bm = BrownianInterval(t0=ts[0], t1=ts[-1], size=(ledger.batch[0], ledger.noise[0]), dtype=y0.dtype,

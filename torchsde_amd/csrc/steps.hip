@@ -283,10 +283,14 @@ struct InterpOp {
 };
 
 // ---- general-noise contraction: y1 = (y0 + cf*f) + cg * sum_j g[b,i,j] dW[b,j] ---------------------
-// HBM-bound on g (d*m*4 B per row vs 12*d for y0,f,y1): g is streamed with perfectly coalesced 16-B
-// loads, the row's increment vector is generated once per block into LDS (one Philox call per 4
-// channels) and the m-long dot products are reduced across the m/4 neighbouring lanes with DPP shuffles.
-constexpr int kGenMaxNoise = 2048;  // LDS floats/doubles of staged increments per block
+// HBM-bound on g (d*m*4 B per row vs 12*d for y0,f,y1). The two vector kernels below (general_fast_kernel,
+// general_rows_kernel) stream g with coalesced 16-B loads, keep the row's increments in REGISTERS (lane L sits on
+// channel quad L % (m/4) of its row: one Philox call per row per lane, issued under the loads) and finish the m-long
+// dot products with an xor-shuffle reduction over the m/4 neighbouring lanes: no LDS, no barrier. The LDS-staged
+// design (increments generated once per block into LDS, two barriers per tile) measured 2x slower at the C3 shape,
+// because g has no reuse across rows (tools/microbench_general.hip, profiles/r2_c3_lds_vs_registers.txt); only the
+// generic fallback for odd shapes (general_generic_kernel: any d, m, scalar loads) still stages them.
+constexpr int kGenMaxNoise = 2048;  // LDS floats/doubles of staged increments per block (generic kernel only)
 
 template <typename T>
 struct GeneralArgs {

@@ -110,9 +110,26 @@ class _CapturedSolve:
         return self.result()
 
 
+def _wrapper_chain(sde):
+    """What the per-call wrappers around the user's SDE object do: (wrapper class, renamed methods) from the outside
+    in. Two calls on the same object with different `names=` (RenameMethodsSDE) or `logqp=` (SDELogqp) run different
+    drift / diffusion code, so they must not share a captured graph."""
+    chain = []
+    while hasattr(sde, "_base_sde"):
+        renamed = tuple(sorted((k, getattr(v, "__name__", repr(v))) for k, v in vars(sde).items()
+                               if k in ("f", "g", "h", "g_prod", "f_and_g", "f_and_g_prod") and callable(v)))
+        chain.append((type(sde).__name__, renamed))
+        sde = sde._base_sde
+    return tuple(chain), sde
+
+
 def _signature(solver, y0, ts_host):
     bm = solver.bm
-    return (type(solver).__name__, tuple(y0.shape), y0.dtype, str(y0.device), tuple(ts_host.tolist()),
+    chain, base = _wrapper_chain(solver.sde)
+    # the captured kernels read parameter STORAGE: a re-bound or moved parameter (`.to()`, `p.data = ...`) is another graph
+    params = tuple(p.data_ptr() for p in base.parameters()) if hasattr(base, "parameters") else ()
+    return (type(solver).__name__, chain, getattr(solver.sde, "sde_type", None), getattr(solver.sde, "noise_type", None),
+            params, tuple(y0.shape), y0.dtype, str(y0.device), tuple(ts_host.tolist()),
             float(solver.dt), tuple(bm.shape), bm.levy_area_approximation, bm.row_offset,
             None if bm._edges is None else bm._edges.tobytes(), bm._max_depth, bm._snap,
             tuple(sorted((k, v) for k, v in solver.options.items() if isinstance(v, (bool, int, float, str)))))

@@ -1,5 +1,8 @@
 """``sdeint``: the forward solve entry point (same signature and return convention as the reference's
 torchsde/_core/sdeint.py:27-112)."""
+import torch
+
+from . import _native
 from . import contract
 from . import solvers
 
@@ -14,7 +17,13 @@ def sdeint(sde, y0, ts, bm=None, method=None, dt=1e-3, adaptive=False, rtol=1e-5
     """
     contract.handle_unused_kwargs(unused_kwargs, msg="`sdeint`")
     del unused_kwargs
+    with _native.on_device_of(y0 if torch.is_tensor(y0) else "cpu"):
+        return _sdeint(sde, y0, ts, bm, method, dt, adaptive, rtol, atol, dt_min, options, names, logqp, extra,
+                       extra_solver_state)
 
+
+def _sdeint(sde, y0, ts, bm, method, dt, adaptive, rtol, atol, dt_min, options, names, logqp, extra,
+            extra_solver_state):
     sde, y0, ts, bm, method, options = contract.check_contract(sde, y0, ts, bm, method, adaptive, options, names,
                                                                logqp)
     contract.assert_no_grad(["ts", "dt", "rtol", "atol", "dt_min"], [ts, dt, rtol, atol, dt_min])

@@ -10,9 +10,10 @@ is one ``all_gather_into_tensor`` of the requested outputs after the last step (
 import torch
 import torch.distributed as dist
 
+from . import contract
 from .brownian import BrownianInterval
 from .integrate import sdeint
-from .settings import LEVY_AREA_APPROXIMATIONS, METHODS, NOISE_TYPES
+from .settings import NOISE_TYPES
 
 
 def shard_rows(global_batch, world_size, rank):
@@ -71,17 +72,22 @@ def sdeint_sharded(sde, y0_global, ts, *, entropy, method=None, dt=1e-3, group=N
     r0, r1 = shard_rows(B, world, rank)
     y0 = y0_global[r0:r1].contiguous()
     ts_t = ts if torch.is_tensor(ts) else torch.tensor(ts, dtype=y0.dtype, device=y0.device)
-    if levy_area_approximation is None:
-        if method == METHODS.srk or (method is None and getattr(sde, "sde_type", None) == "ito"
-                                     and sde.noise_type != NOISE_TYPES.general):
-            levy_area_approximation = LEVY_AREA_APPROXIMATIONS.space_time
-        else:
-            levy_area_approximation = LEVY_AREA_APPROXIMATIONS.none
+    if levy_area_approximation is None:      # what `sdeint` itself would pick for bm=None
+        levy_area_approximation = contract.default_levy_area_approximation(
+            method if method is not None else contract.default_method(sde))
     m = _noise_channels(sde, y0, ts_t)
+    if kwargs.get("logqp") and sde.noise_type == NOISE_TYPES.diagonal:
+        m += 1          # the KL column is a state channel, and diagonal noise has one Brownian channel per state channel
     bm = BrownianInterval(t0=ts_t[0], t1=ts_t[-1], size=(r1 - r0, m), dtype=y0.dtype, device=y0.device,
                           entropy=entropy, levy_area_approximation=levy_area_approximation, row_offset=r0)
     solve = sdeint if solve_fn is None else solve_fn
     ys = solve(sde, y0, ts_t, bm=bm, method=method, dt=dt, **kwargs)
+    if isinstance(ys, tuple):        # logqp=True / extra=True: gather the trajectory, hand the rest back as it is
+        return (_gather_ys(ys[0], B, world, gather, group),) + tuple(ys[1:])
+    return _gather_ys(ys, B, world, gather, group)
+
+
+def _gather_ys(ys, B, world, gather, group):
     if gather is None or world == 1:
         return ys if gather != "final" else ys[-1]
     if gather == "final":
@@ -90,15 +96,26 @@ def sdeint_sharded(sde, y0_global, ts, *, entropy, method=None, dt=1e-3, group=N
 
 
 def all_reduce_gradients(params, group=None):
-    """Sum parameter gradients over ranks after a sharded ``sdeint_adjoint`` backward (a_theta is a sum over rows)."""
+    """Sum parameter gradients over ranks after a sharded ``sdeint_adjoint`` backward (a_theta is a sum over rows).
+
+    Every rank reduces over the SAME list: all parameters that require a gradient, a missing `.grad` counting as zeros
+    (a rank whose rows never touched a parameter must still take part, or the collective would mismatch), one flat
+    buffer per dtype (no silent promotion of mixed-precision parameters)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, group=group)
-    offset = 0
-    for g in grads:
-        g.copy_(flat[offset:offset + g.numel()].view_as(g))
-        offset += g.numel()
+    params = [p for p in params if p.requires_grad]
+    by_dtype = {}
+    for p in params:
+        by_dtype.setdefault(p.dtype, []).append(p)
+    for dtype in sorted(by_dtype, key=str):
+        group_params = by_dtype[dtype]
+        flat = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in group_params])
+        dist.all_reduce(flat, group=group)
+        offset = 0
+        for p in group_params:
+            chunk = flat[offset:offset + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = chunk.clone()
+            else:
+                p.grad.copy_(chunk)
+            offset += p.numel()

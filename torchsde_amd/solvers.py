@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _native
+from . import closed_form
 from . import kernels as K
 from . import timegrid
 from .brownian import BrownianInterval
@@ -282,7 +283,8 @@ class BaseSDESolver:
         if not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful:
             return None
         base = getattr(self.sde, "_base_sde", None)
-        if type(self.sde) is not ForwardSDE or not hasattr(base, "closed_form"):
+        if (type(self.sde) is not ForwardSDE or not hasattr(base, "closed_form")
+                or not closed_form.publishes_its_own_dynamics(base)):
             return None
         bm = self._native_bm()
         if (self._trajectory_code() is None or bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape)
