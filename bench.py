@@ -6,19 +6,34 @@ One bench "step" = one full solve of the workload: BASELINE.json configs[1], dia
 Euler-Maruyama, batch 65536 x state 64, 1000 fixed solver steps (dyadic dt = 2^-10 so the count is exact
 in float32), geometric Brownian motion f = mu*y, g = sigma*y as user torch code, Brownian increments
 generated in registers by the fused step kernel. Inputs are resident in HBM before the timed region.
-N > 1: every rank solves its own 65536 rows (weak scaling; RNG rows are global, so results are the rows an
+N > 1: every rank solves its own rows (weak scaling; RNG rows are global, so results are the rows an
 unsharded run would produce) and the final states are all-gathered once per solve over RCCL.
+BASELINE configs[3] (Stratonovich midpoint, 262144 x 64 sharded over 8 GPUs) is
+`--gpus 8 --workload c4_midpoint_diag_b32768_d64`: 32768 rows per GPU.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: tsde_step_diag; algorithmic bytes per launch
-= 16*d bytes per trajectory-step x batch = 4 streams x B*d*4 B, over the kernel's average duration measured
-with HIP events inside the library) and `cpu_baseline` (the oracle's port of the reference's CPU algorithm,
-timed on this host's cores on a bounded sample). The default single-GPU run also carries `also`: two short side
-measurements taken after the timed region (the same job with the SDE in closed form; perceptron-drift sampling and
-a perceptron-drift training step on the matrix cores); they are not part of `value`, and `--no-also` skips them.
+Prints ONE JSON line (rank 0):
+
+* `value` = trajectory-steps/s over the K timed solves (barrier + synchronize on both sides, max over ranks);
+  `median_ms_per_step` / `value_median` restate it from the median of the per-solve times (HIP events recorded
+  between the solves of the same timed region);
+* `roofline`: two fractions of the 8 TB/s HBM peak, named for what they are --
+    `frac`        KERNEL level: the dominant kernel's algorithmic bytes per launch / its average duration, measured
+                  live with HIP events on the launch stream (for the headline: 200 back-to-back launches on live data);
+    `solve_frac`  SOLVE level: algorithmic bytes per trajectory-step x `value` / (N x 8e12), i.e.
+                  with the user's f and g torch kernels and every launch gap inside;
+  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is taken from profiles/traffic_latest.json ONLY when that
+  file was collected on the kernel sources this run uses (`traffic_source` names file and source digest);
+* `cpu_baseline`: the oracle's port of the reference's CPU algorithm, timed on this host's cores on a bounded sample;
+* `also` (single-GPU default run): every other BASELINE configuration at its single-GPU size on the stepwise path
+  (configs[2] Euler-general, the configs[3] shard, configs[4] sdeint_adjoint), each with ms per solve (median of 5),
+  the dominant kernel's duration from HIP-event brackets, bytes per launch and both fractions; then the same jobs
+  when the SDE is handed over in closed form. Not part of `value`; `--no-also` skips them.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,10 +43,29 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+from workloads.configs import WORKLOADS, make_problem as _make_problem  # noqa: E402
+
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-in/f32-accumulate matrix rate (same guide)
+HEADLINE = "c2_euler_diag_b65536_d64_s1000"
+# the stepwise BASELINE configurations, then what the closed-form route makes of the same jobs
+ALSO = ("c3_euler_general_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
+        "c2_euler_expdiff_b65536_d64_s1000",
+        "c2_euler_closed_form_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000",
+        "c5_sampling_mlp_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500")
 
-from workloads.configs import WORKLOADS, make_problem as _make_problem  # noqa: E402
+
+def csrc_digest():
+    """sha256 over the kernel sources and the C header (what a PMC measurement is a measurement OF)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "torchsde_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "torchsde_amd.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _cpu_baseline(cfg, budget_s=20.0):
@@ -81,68 +115,235 @@ def _cpu_baseline(cfg, budget_s=20.0):
             "host_cpus": ncpu,
             "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}) in {el:.1f} s; "
                       f"oracle port of the reference CPU algorithm (tree BrownianInterval + Euler loop, torch CPU "
-                      f"ops), best of thread counts {candidates} -> {best} threads"}
+                      f"ops; same-thread-count A/B against the real reference: profiles/r2_cpu_port_vs_reference.txt), "
+                      f"best of thread counts {candidates} -> {best} threads"}
 
+
+class Job:
+    """One workload set up on one device: `solve(i)` runs one full solve (forward, or forward + backward) with the
+    Brownian seed of solve i; inputs live in HBM before any timing starts."""
+
+    def __init__(self, name, dev, rank=0, world=1, dist=None, graph=True):
+        import torchsde_amd
+        self.name, self.cfg, self.dev, self.rank, self.world, self.dist = name, WORKLOADS[name], dev, rank, world, dist
+        c = self.cfg
+        self.trajectory = c.get("trajectory", False)
+        self.adjoint, self.train = c.get("adjoint", False), c.get("train", False)
+        # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture); the
+        # adjoint replays one graph for the forward solve and one for the backward sweep; trajectory kernels are one
+        # launch per solve anyway.
+        self.use_graph = graph and not self.trajectory
+        self.sde = _make_problem(c["problem"], c["d"], c["m"], dev)
+        self.y0 = torch.full((c["B"], c["d"]), 0.1, device=dev, requires_grad=self.adjoint or self.train)
+        self.ts = torch.tensor([0.0, c["nsteps"] * c["dt"]], device=dev)
+        self.gathered = torch.empty((world * c["B"], c["d"]), device=dev) if dist is not None else None
+        self._sdeint, self._sdeint_adjoint = torchsde_amd.sdeint, torchsde_amd.sdeint_adjoint
+        self._BM = torchsde_amd.BrownianInterval
+
+    def solve(self, i, graph=None):
+        c = self.cfg
+        graph = self.use_graph if graph is None else graph
+        bm = self._BM(t0=0.0, t1=c["nsteps"] * c["dt"], size=(c["B"], c["m"]), dtype=torch.float32, device=self.dev,
+                      entropy=20240601 + i, dt=c["dt"], levy_area_approximation=c["levy"], row_offset=self.rank * c["B"])
+        extra_options = dict(c.get("options") or {})
+        if self.adjoint or self.train:
+            with torch.enable_grad():
+                if self.adjoint:
+                    gopt = {"hip_graph": True} if graph else {}
+                    ys = self._sdeint_adjoint(self.sde, self.y0, self.ts, bm=bm, method=c["method"],
+                                              adjoint_method=c["adjoint_method"], dt=c["dt"], options=dict(gopt),
+                                              adjoint_options=dict(gopt))
+                else:
+                    ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"])
+                self.y0.grad = None
+                self.sde.zero_grad()
+                ys[-1].sum().backward()
+            if self.dist is not None:
+                from torchsde_amd import sharding
+                sharding.all_reduce_gradients(list(self.sde.parameters()))
+            return self.y0.grad
+        with torch.no_grad():
+            ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
+                              options=dict(extra_options, hip_graph=True) if graph else (extra_options or None))
+            if self.dist is not None:
+                self.dist.all_gather_into_tensor(self.gathered, ys[-1])
+                return self.gathered
+            return ys[-1]
+
+    # ---- dominant kernel -----------------------------------------------------------------------------------------
+    def bracket_dominant_kernel(self):
+        """(total ms, launches): every launch of the dominant kernel in eagerly issued solve(s) bracketed by HIP events
+        on the launch stream inside the library (tsde_prof_begin / tsde_prof_end). Event records are host-side calls,
+        so this cannot be done inside a replayed graph."""
+        from torchsde_amd import kernels as K
+        c = self.cfg
+        if self.trajectory:
+            K.prof_begin(c["kid"], 16 if not self.train else 8 * (c["nsteps"] + 1))
+            for i in range(8):
+                self.solve(5000 + i, graph=False)
+        else:
+            per_step = c["launches_per_step"]
+            K.prof_begin(c["kid"], c["nsteps"] * per_step + 8)
+            # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
+            K.gpu_delay(min(2.0e6, 40.0 * c["nsteps"] * (2 + per_step)), self.dev)
+            self.solve(5000, graph=False)
+        torch.cuda.synchronize()
+        return K.prof_end()
+
+    def back_to_back_step_diag_us(self, live_state):
+        """Second HIP-event measurement of tsde_step_diag without per-launch markers: ONE event pair around 200
+        back-to-back launches on live data (a solve's last state and its f, g), marker latency amortised away."""
+        from torchsde_amd import kernels as K
+        from torchsde_amd.kernels import NoiseSpec, _raw_step_diag
+        c, dev = self.cfg, self.dev
+        B, d, m, dt = c["B"], c["d"], c["m"], c["dt"]
+        yy = [live_state[:B].clone().contiguous(), torch.empty(B, d, device=dev)]
+        with torch.no_grad():
+            ff, gg = self.sde.f(self.ts[0], yy[0]).contiguous(), self.sde.g(self.ts[0], yy[0]).contiguous()
+        specs = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(220)]
+        for i in range(20):
+            _raw_step_diag(yy[i & 1], ff, gg, float(dt), 1.0, specs[i], yy[(i + 1) & 1])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        K.gpu_delay(3000.0, dev)          # let the host enqueue all launches first
+        e0.record()
+        for i in range(20, 220):
+            _raw_step_diag(yy[i & 1], ff, gg, float(dt), 1.0, specs[i], yy[(i + 1) & 1])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / 200
+
+    def roofline(self, value, k_ms, k_launches, b2b_us=None):
+        """The `roofline` object of this workload given its measured trajectory-steps/s and kernel brackets."""
+        c = self.cfg
+        B, d, nsteps = c["B"], c["d"], c["nsteps"]
+        if k_launches <= 0:
+            return None
+        raw_s = k_ms * 1e-3 / k_launches
+        if self.trajectory and c.get("mfma_flops_per_traj_step"):
+            # 8 solves were timed; a solve is one launch, or (reverse sweep) one launch per chunk of steps
+            flops = c["mfma_flops_per_traj_step"] * B * nsteps * 8 / k_launches
+            achieved = flops / raw_s / 1e12
+            return {"bound": "mfma", "kernel": c["kernel"], "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "flops_per_launch": flops, "avg_launch_us": raw_s * 1e6, "launches_timed": k_launches,
+                    "note": "f32-in / f32-accumulate MFMA (exact f32); peak = dense f32 matrix rate of "
+                            "guides/MI355X_MICROARCH.md",
+                    "timing": "HIP events bracketing every launch of this kernel in 8 eagerly issued solves"}
+        if self.trajectory:
+            # One launch per solve: it reads y0 and writes the requested outputs, nothing else touches HBM. The kernel is
+            # bound by the VALU work of the counter RNG (Philox-4x32-10 + Box-Muller per element-step) and of f, g.
+            bytes_per_launch = 2 * B * d * 4
+            achieved = bytes_per_launch / raw_s / 1e9
+            return {"bound": "hbm", "kernel": c["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                    "avg_launch_us": raw_s * 1e6, "launches_timed": k_launches,
+                    "element_steps_per_s": B * d * nsteps / raw_s,
+                    "note": "VALU-bound by design (state in registers, increments from the counter RNG, f and g evaluated "
+                            "in the kernel): the step's 16*d bytes per trajectory-step never reach HBM, so neither "
+                            "fraction of the HBM peak describes this kernel; see DESIGN.md for its VALU utilisation",
+                    "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
+        # Each bracket is (event record, kernel, event record) on the launch stream of an eagerly issued solve that
+        # was fully enqueued behind a delay kernel (the queue never runs dry). A bracket = kernel + the marker
+        # packets' latency, i.e. an UPPER bound on the kernel time, so the fraction from it is a LOWER bound. The
+        # headline also has the back-to-back figure, which agrees with the rocprofv3 kernel trace (profiles/).
+        avg_s = raw_s if b2b_us is None else b2b_us * 1e-6
+        bytes_per_launch = c["bytes_per_traj_step"] * B / c["launches_per_step"]
+        achieved = bytes_per_launch / avg_s / 1e9
+        solve_achieved = c["bytes_per_traj_step"] * value / self.world / 1e9
+        return {"bound": "hbm", "kernel": c["kernel"],
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "frac_is": "KERNEL level: algorithmic bytes per launch of the dominant kernel / its average duration",
+                "solve_achieved": solve_achieved, "solve_frac": solve_achieved / HBM_PEAK_GBPS,
+                "solve_frac_is": "SOLVE level (SURVEY 8d): bytes_per_traj_step x value / (n_gpus x peak); includes the "
+                                 "user's f, g torch kernels and all launch gaps",
+                "bytes_per_traj_step": c["bytes_per_traj_step"],
+                "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
+                "bracket_us_in_situ": raw_s * 1e6, "launches_timed": k_launches,
+                "timing": ("HIP events around 200 back-to-back launches on live data (avg_launch_us); bracket_us_in_situ = "
+                           "HIP events bracketing each of the launches of one eagerly issued solve, an upper bound "
+                           "that includes marker-packet latency") if b2b_us is not None else
+                          "HIP events bracketing every launch of one eagerly issued solve (upper bound: includes "
+                          "marker-packet latency)"}
+
+
+def _attach_offline_traffic(roofline, workload):
+    """HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/profile.sh), corrected as
+    guides/MI355X_MICROARCH.md prescribes -- collected offline because counters need their own passes, and attached
+    only if the file says it was collected on the kernel sources this run uses."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if roofline is None or workload != HEADLINE or not os.path.exists(tpath):
+        return
+    try:
+        with open(tpath) as fh:
+            rec = json.load(fh)
+        digest = csrc_digest()
+        if rec.get("csrc_sha") != digest:
+            roofline["traffic_source"] = (f"profiles/traffic_latest.json is for kernel sources {rec.get('csrc_sha')}, "
+                                          f"this run uses {digest}: stale, not reported (re-run tools/profile.sh)")
+            return
+        for kname, k in rec.get("kernels", {}).items():
+            if "StepDiagOp<float>" in kname:
+                roofline["traffic"] = k["traffic_bytes_per_launch"]
+                roofline["kernel_us_rocprofv3"] = k.get("kernel_avg_us")
+                roofline["traffic_source"] = (f"offline: profiles/traffic_latest.json @ csrc {digest} "
+                                              f"({rec.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})")
+    except Exception as e:
+        roofline["traffic_source"] = f"profiles/traffic_latest.json unreadable: {e}"
+
+
+def _side_measurement(dev, name):
+    """One `also` entry: 2 warm-up solves, 5 timed solves (median), then the dominant kernel's brackets."""
+    job = Job(name, dev)
+    c = job.cfg
+    for i in range(2):
+        job.solve(i)
+    torch.cuda.synchronize()
+    times = []
+    for i in range(5):
+        start = time.perf_counter()
+        out = job.solve(10 + i)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - start) * 1e3)
+    assert torch.isfinite(out).all()
+    ms = statistics.median(times)
+    value = c["B"] * c["nsteps"] / ms * 1e3
+    rec = {"ms_per_solve": ms, "ms_per_solve_all": times, "trajectory_steps_per_s": value, "kernel": c["kernel"],
+           "launch": "one trajectory-kernel launch per solve" if job.trajectory else "HIP graph replay"}
+    if job.train or job.adjoint:
+        rec["what"] = "forward + backward per solve"
+    k_ms, k_launches = job.bracket_dominant_kernel()
+    roof = job.roofline(value, k_ms, k_launches)
+    if roof is not None:
+        for key in ("bound", "achieved", "unit", "frac", "solve_achieved", "solve_frac", "bytes_per_traj_step",
+                    "bytes_per_launch", "flops_per_launch", "avg_launch_us", "launches_timed"):
+            if key in roof:
+                rec[("kernel_" + key) if key in ("achieved", "frac") else key] = roof[key]
+        if roof["bound"] == "mfma":
+            rec["tflops_f32"] = roof["achieved"]
+    return rec
 
 
 def _side_measurements(dev):
-    """Short measurements reported under `also`: outside the headline's timed region and NOT part of `value`.
-
-    The headline job when the SDE is handed over in closed form (whole solve in one launch), and neural-SDE sampling
-    on the matrix cores. A failure here is reported in place and never takes the headline down with it.
-    """
+    """Short measurements reported under `also`: outside the headline's timed region and NOT part of `value`. A
+    failure here is reported in place and never takes the headline down with it."""
     also = {}
-    for name in ("c2_euler_closed_form_b65536_d64_s1000", "c5_sampling_mlp_b32768_d128_s500",
-                 "c5_training_mlp_b32768_d128_s500"):
+    for name in ALSO:
+        if name not in WORKLOADS:
+            continue
         try:
-            also[name] = _side_measurement(dev, WORKLOADS[name])
+            also[name] = _side_measurement(dev, name)
         except Exception as e:
             also[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     return also
 
-
-def _side_measurement(dev, c):
-    import torchsde_amd
-    sde = _make_problem(c["problem"], c["d"], c["m"], dev)
-    train = c.get("train", False)
-    y0 = torch.full((c["B"], c["d"]), 0.1, device=dev, requires_grad=train)
-    t1 = c["nsteps"] * c["dt"]
-    ts = torch.tensor([0.0, t1], device=dev)
-
-    def solve(i):
-        bm = torchsde_amd.BrownianInterval(t0=0.0, t1=t1, size=(c["B"], c["m"]), dtype=torch.float32, device=dev,
-                                           entropy=777 + i, dt=c["dt"], levy_area_approximation=c["levy"])
-        if train:               # forward + loss.backward() through the solver
-            ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=c["method"], dt=c["dt"])
-            y0.grad = None
-            sde.zero_grad()
-            ys[-1].sum().backward()
-            return y0.grad
-        with torch.no_grad():
-            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=c["method"], dt=c["dt"])
-
-    for i in range(2):
-        solve(i)
-    torch.cuda.synchronize()
-    start = time.perf_counter()
-    for i in range(5):
-        out = solve(10 + i)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - start) / 5 * 1e3
-    assert torch.isfinite(out).all()
-    rec = {"ms_per_solve": ms, "trajectory_steps_per_s": c["B"] * c["nsteps"] / ms * 1e3, "kernel": c["kernel"]}
-    if train:
-        rec["what"] = "forward + backward per training step"
-    elif c.get("mfma_flops_per_traj_step"):
-        rec["tflops_f32"] = c["mfma_flops_per_traj_step"] * c["B"] * c["nsteps"] / ms / 1e9
-    return rec
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2_euler_diag_b65536_d64_s1000")
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short side measurements reported under `also`")
     ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
@@ -163,6 +364,7 @@ def main():
     # launched by torch.distributed.run (also with a single rank): use the collective path, so that the very same
     # code runs at N = 1, 2, 4, 8
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    dist = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -171,200 +373,71 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
-    import torchsde_amd
-    from torchsde_amd import kernels as K
-
-    cfg = WORKLOADS[args.workload]
+    job = Job(args.workload, dev, rank=rank, world=world, dist=dist, graph=not args.eager)
+    cfg = job.cfg
     B, d, m, nsteps, dt = cfg["B"], cfg["d"], cfg["m"], cfg["nsteps"], cfg["dt"]
-    adjoint = cfg.get("adjoint", False)
-    # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture);
-    # the derivative form of Milstein runs its diffusion VJP through autograd INSIDE the captured region (fine: same
-    # kernels every step), and so does the Levy-area JVP of the general-noise Milstein extension; the adjoint replays
-    # one graph for the forward solve and one for the backward sweep.
-    trajectory = cfg.get("trajectory", False)
-    use_graph = (not args.eager) and not trajectory
-    extra_options = dict(cfg.get("options") or {})
-    sde = _make_problem(cfg["problem"], d, m, dev)
-    train = cfg.get("train", False)
-    y0 = torch.full((B, d), 0.1, device=dev, requires_grad=adjoint or train)
-    ts = torch.tensor([0.0, nsteps * dt], device=dev)
-    gathered = torch.empty((world * B, d), device=dev) if use_dist else None
-
-    def one_solve(i, graph=None):
-        graph = use_graph if graph is None else graph
-        bm = torchsde_amd.BrownianInterval(t0=0.0, t1=nsteps * dt, size=(B, m), dtype=torch.float32, device=dev,
-                                           entropy=20240601 + i, dt=dt, levy_area_approximation=cfg["levy"],
-                                           row_offset=rank * B)
-        if adjoint:
-            with torch.enable_grad():
-                gopt = {"hip_graph": True} if graph else {}
-                ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=cfg["method"],
-                                                 adjoint_method=cfg["adjoint_method"], dt=dt, options=dict(gopt),
-                                                 adjoint_options=dict(gopt))
-                y0.grad = None
-                ys[-1].sum().backward()
-            if use_dist:
-                from torchsde_amd import sharding
-                sharding.all_reduce_gradients(list(sde.parameters()))
-            return y0.grad
-        if train:
-            with torch.enable_grad():
-                ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt)
-                y0.grad = None
-                sde.zero_grad()
-                ys[-1].sum().backward()
-            if use_dist:
-                from torchsde_amd import sharding
-                sharding.all_reduce_gradients(list(sde.parameters()))
-            return y0.grad
-        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=cfg["method"], dt=dt,
-                                 options=dict(extra_options, hip_graph=True) if graph else (extra_options or None))
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, ys[-1])
-            return gathered
-        return ys[-1]
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            one_solve(i)
-        barrier()
-        t_start = time.perf_counter()
-        for i in range(args.steps):
-            out = one_solve(1000 + i)
-        barrier()
-        elapsed = time.perf_counter() - t_start
-        if use_dist:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = t.item()
-
-        # roofline of the dominant kernel: every launch of the step kernel in one more solve is bracketed by
-        # HIP events on the launch stream inside the library (tsde_prof_begin / tsde_prof_end).
-        # (issued eagerly: event records are host-side calls and are not part of a replayed graph)
-        if trajectory:
-            K.prof_begin(cfg["kid"], 16 if not train else 8 * (nsteps + 1))
-            for i in range(8):
-                one_solve(5000 + i, graph=False)
-        else:
-            K.prof_begin(cfg["kid"], nsteps * cfg["launches_per_step"] + 8)
-            # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
-            K.gpu_delay(min(2.0e6, 40.0 * nsteps * (2 + cfg["launches_per_step"])), dev)
-            one_solve(5000, graph=False)
-        torch.cuda.synchronize()
-        k_ms, k_launches = K.prof_end()
-
-        # Second HIP-event measurement of the same kernel without per-launch markers: ONE event pair around a run
-        # of back-to-back launches on live data (the last state and its f, g), so marker latency is amortised away.
-        b2b_us = None
-        if cfg["kid"] == 1:
-            from torchsde_amd.kernels import NoiseSpec, _raw_step_diag
-            yy = [out[:B].clone().contiguous(), torch.empty(B, d, device=dev)]
-            ff, gg = sde.f(ts[0], yy[0]).contiguous(), sde.g(ts[0], yy[0]).contiguous()
-            cf = float(dt) if cfg["method"] != "midpoint" else float(dt)
-            specs = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(220)]
-            for i in range(20):
-                _raw_step_diag(yy[i & 1], ff, gg, cf, 1.0, specs[i], yy[(i + 1) & 1])
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            K.gpu_delay(3000.0, dev)          # let the host enqueue all launches first
-            e0.record()
-            for i in range(20, 220):
-                _raw_step_diag(yy[i & 1], ff, gg, cf, 1.0, specs[i], yy[(i + 1) & 1])
-            e1.record()
-            torch.cuda.synchronize()
-            b2b_us = e0.elapsed_time(e1) * 1e3 / 200
+    for i in range(args.warmup):
+        job.solve(i)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        marks[i].record()
+        out = job.solve(1000 + i)
+    marks[args.steps].record()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    per_solve_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    median_ms = statistics.median(per_solve_ms)
+    if use_dist:
+        t = torch.tensor([elapsed, median_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, median_ms = t[0].item(), t[1].item()
     assert torch.isfinite(out).all()
-
     value = world * B * nsteps * args.steps / elapsed
-    roofline = None
-    if k_launches > 0 and trajectory:
-        # One launch per solve: it reads y0 and writes the requested outputs, nothing else touches HBM. The kernel is
-        # bound by the VALU work of the counter RNG (Philox-4x32-10 + Box-Muller per element-step), so its HBM
-        # roofline fraction is ~0 by design; `valu_*` restate the same launch against the vector-ALU issue peak.
-        avg_s = k_ms * 1e-3 / k_launches
-        if cfg.get("mfma_flops_per_traj_step"):
-            # 8 solves were timed; a solve is one launch, or (reverse sweep) one launch per chunk of steps
-            flops = cfg["mfma_flops_per_traj_step"] * B * nsteps * 8 / k_launches
-            achieved = flops / avg_s / 1e12
-            roofline = {"bound": "mfma", "kernel": cfg["kernel"], "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                        "flops_per_launch": flops, "avg_launch_us": avg_s * 1e6, "launches_timed": k_launches,
-                        "note": "f32-in / f32-accumulate MFMA (exact f32); peak = dense f32 matrix rate of "
-                                "guides/MI355X_MICROARCH.md",
-                        "timing": "HIP events bracketing every launch of this kernel in 8 eagerly issued solves"}
-        bytes_per_launch = 2 * B * d * 4
-        achieved = bytes_per_launch / avg_s / 1e9
-        roofline = roofline or {"bound": "hbm", "kernel": cfg["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
-                    "avg_launch_us": avg_s * 1e6, "launches_timed": k_launches,
-                    "element_steps_per_s": B * d * nsteps / avg_s,
-                    "note": "VALU-bound by design (state in registers, increments from the counter RNG); see DESIGN.md "
-                            "for the VALU utilisation measured with rocprofv3 PMC counters",
-                    "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
-    elif k_launches > 0:
-        # Each bracket is (event record, kernel, event record) on the launch stream of an eagerly issued solve that
-        # was fully enqueued behind a delay kernel (the queue never runs dry). A bracket = kernel + the marker
-        # packets' latency, i.e. an UPPER bound on the kernel time, and `achieved` is therefore a LOWER bound.
-        # The marker latency cannot be calibrated away reliably on this stack (a bracket around a self-timed
-        # single-thread spin kernel costs `event_bracket_overhead_us`, more than around a streaming kernel), so
-        # nothing is subtracted; the pure kernel duration is in the rocprofv3 kernel trace of this same command
-        # (profiles/, `kernel_us_rocprofv3` below when the summary is present).
-        raw_s = k_ms * 1e-3 / k_launches
-        # `achieved` uses the back-to-back HIP-event figure when it exists: it is the one that agrees with the
-        # rocprofv3 kernel trace of this command (profiles/); the per-launch bracket is kept as an upper bound.
-        avg_s = raw_s if b2b_us is None else b2b_us * 1e-6
-        bytes_per_launch = cfg["bytes_per_traj_step"] * B / cfg["launches_per_step"]
-        achieved = bytes_per_launch / avg_s / 1e9
-        traffic = rocprof_us = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and args.workload == "c2_euler_diag_b65536_d64_s1000":
-            # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/profile.sh), corrected as
-            # guides/MI355X_MICROARCH.md prescribes; collected offline because counters need their own passes.
-            try:
-                with open(tpath) as fh:
-                    for kname, rec in json.load(fh).items():
-                        if "StepDiagOp<float>" in kname:
-                            traffic = rec["traffic_bytes_per_launch"]
-                            rocprof_us = rec.get("kernel_avg_us")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": cfg["kernel"],
-                    "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": traffic, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "bracket_us_in_situ": raw_s * 1e6,
-                    "kernel_us_rocprofv3": rocprof_us,
-                    "timing": ("HIP events around 200 back-to-back launches on live data (avg_launch_us); bracket_us_in_situ = "
-                               "HIP events bracketing each of the launches of one eagerly issued solve, an upper bound "
-                               "that includes marker-packet latency") if b2b_us is not None else
-                              "HIP events bracketing every launch of one eagerly issued solve (upper bound)",
-                    "launches_timed": k_launches}
+
+    k_ms, k_launches = job.bracket_dominant_kernel()
+    b2b_us = job.back_to_back_step_diag_us(out) if cfg["kid"] == 1 and cfg["launches_per_step"] == 1 else None
+    roofline = job.roofline(value, k_ms, k_launches, b2b_us)
+    _attach_offline_traffic(roofline, args.workload)
+
     also = None
-    if world == 1 and not args.no_also and args.workload == "c2_euler_diag_b65536_d64_s1000":
+    if world == 1 and not args.no_also and args.workload == HEADLINE:
+        del job
+        torch.cuda.empty_cache()
         also = _side_measurements(dev)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = _cpu_baseline(cfg)
+        trajectory, adjoint, train = cfg.get("trajectory", False), cfg.get("adjoint", False), cfg.get("train", False)
         line = {
             "metric": "SDE steps/sec (batch x timesteps / sec)", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "median_ms_per_step": median_ms,
+            "value_median": world * B * nsteps / median_ms * 1e3,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "sde": cfg["problem"] + (" (closed-form coefficients; f, g evaluated in the kernel)" if trajectory
-                                                          else " (f, g are user torch ops)"),
+            "config": {"workload": args.workload,
+                       "sde": cfg["problem"] + (" (closed-form coefficients; f, g evaluated in the kernel)" if trajectory
+                                                else " (f, g are user torch ops)"),
                        "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else "") +
                                  (" + loss.backward() through the solver" if train else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "state": d, "brownian_channels": m,
                        "solver_steps": nsteps, "dt": dt, "brownian": "counter-RNG, generated in the step kernel",
-                       "launch": ("trajectory kernels: one forward launch, the reverse sweep in chunks of steps, two weight-gradient "
-                                  "products per chunk" if train else
+                       "launch": ("trajectory kernels: one forward launch, the reverse sweep in chunks of steps, two "
+                                  "weight-gradient products per chunk" if train else
                                   "one trajectory-kernel launch per solve" if trajectory else
                                   "HIP graph replay of the whole solve" + (" and of the backward sweep" if adjoint else "")
-                                  if use_graph else "eager launches"),
-                       "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve"},
+                                  if not args.eager else "eager launches"),
+                       "parallelism": f"batch-sharded x{world}, one all_gather of final states per solve",
+                       "csrc_sha": csrc_digest()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if also is not None:

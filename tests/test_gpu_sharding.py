@@ -88,10 +88,12 @@ def test_sharded_processes_reproduce_the_unsharded_solve(world):
             torch.testing.assert_close(torch.from_numpy(got), ref, rtol=1e-5, atol=1e-6)
 
 
-def test_bench_multi_rank_logic_on_one_gpu():
+@pytest.mark.parametrize("workload", [None, "c4_midpoint_diag_b32768_d64"])
+def test_bench_multi_rank_logic_on_one_gpu(workload):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with two ranks
     sharing the one device and gloo for the collectives (TSDE_BENCH_SHARE_GPU=1): one JSON line from rank 0, the whole
-    job's trajectory-steps counted, weak scaling."""
+    job's trajectory-steps counted, weak scaling. Run for the default workload and for THE configs[3] run
+    (`--workload c4_midpoint_diag_b32768_d64`: Stratonovich midpoint, 32768 rows per rank)."""
     import json
     import subprocess
     import sys
@@ -99,7 +101,7 @@ def test_bench_multi_rank_logic_on_one_gpu():
     env = dict(os.environ, TSDE_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1"]
+           "--warmup", "1"] + ([] if workload is None else ["--workload", workload])
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
@@ -107,6 +109,13 @@ def test_bench_multi_rank_logic_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["config"]["global_batch"] == 2 * rec["config"]["batch_per_gpu"]
+    if workload is not None:
+        assert rec["config"]["workload"] == workload and rec["config"]["batch_per_gpu"] == 32768
+        assert rec["config"]["method"] == "midpoint"
     expected = rec["config"]["global_batch"] * rec["config"]["solver_steps"] / (rec["ms_per_step"] * 1e-3)
     assert abs(rec["value"] - expected) <= 1e-6 * expected
-    assert rec["roofline"]["frac"] > 0 and rec["cpu_baseline"] is None and "also" not in rec
+    roof = rec["roofline"]
+    assert roof["frac"] > 0 and rec["cpu_baseline"] is None and "also" not in rec
+    # the solve-level fraction is the SURVEY 8d definition: bytes per trajectory-step x value / (n_gpus x peak)
+    want = roof["bytes_per_traj_step"] * rec["value"] / 2 / (roof["peak"] * 1e9)
+    assert abs(roof["solve_frac"] - want) <= 1e-9 + 1e-6 * want

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
 import torchsde_amd
 from workloads import problems
 dev = "cuda"

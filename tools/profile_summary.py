@@ -58,6 +58,12 @@ for k, v in traffic.items():
                        "traffic_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
                        "kernel_avg_us": kernel_avg_us.get(k),
                        "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), units KiB"}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_digest: what these counters are a measurement OF)
+out_json = {"csrc_sha": bench.csrc_digest(),
+            "collected": "tools/profile.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                         "`bench.py --steps 1 --warmup 0`, kernel_avg_us from the --kernel-trace --stats pass",
+            "kernels": out_json}
 with open(os.path.join(out, "traffic.json"), "w") as f:
     json.dump(out_json, f, indent=1)
 print("== traffic.json ==")

@@ -166,13 +166,15 @@ __global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const 
 }
 
 // Per-stream size above which the streaming (nontemporal, uncapped-grid) variant is used: 96 MiB per stream, i.e.
-// a 4-stream kernel whose live data no longer fits the 256 MiB Infinity Cache. TSDE_FORCE_NT=1 forces it (tests).
+// a 4-stream kernel whose live data no longer fits the 256 MiB Infinity Cache. TSDE_FORCE_NT=1 forces it on and
+// TSDE_FORCE_NT=0 off (tests, and the on/off measurement of tools/bench_kernels.py).
 inline bool use_streaming_variant(int64_t n, size_t elem_size) {
   static const int forced = [] {
     const char* e = getenv("TSDE_FORCE_NT");
-    return (e && e[0] == '1') ? 1 : 0;
+    return (e && e[0] == '1') ? 1 : (e && e[0] == '0') ? 0 : -1;
   }();
-  return forced || (uint64_t)n * elem_size >= (96ull << 20);
+  if (forced >= 0) return forced == 1;
+  return (uint64_t)n * elem_size >= (96ull << 20);
 }
 
 template <typename Op>

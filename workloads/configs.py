@@ -31,6 +31,12 @@ WORKLOADS = {
         problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
         kernel="tsde_step_diag<float> (two stages per step)"),
+    # SURVEY 8d's nonlinear second workload: the SDE the reference's own benchmark integrates (benchmarks/brownian.py:
+    # 131-139), f = y, g = exp(-y), at the headline's shape -- stepwise, f and g are user torch ops
+    "c2_euler_expdiff_b65536_d64_s1000": dict(
+        problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
     # The headline dynamics (same mu, sigma, seed addressing: bit-identical final states) handed over as a closed-form
     # SDE (torchsde_amd.AffineDiagonalSDE): the whole solve is ONE launch of the trajectory kernel, state in
     # registers. VALU-bound (Philox + Box-Muller), so the HBM roofline fraction is ~0 by design.
