@@ -33,7 +33,7 @@ def _oracle_forward(sde32, rows, d, m, entropy, n, dt, method, y0_value, levy=Fa
     from oracle import solvers_ref
     out = {}
     for dtype in (torch.float32, torch.float64):
-        sde = copy.deepcopy(sde32).cpu().to(dtype)
+        sde = copy.deepcopy(sde32).cpu().to(dtype)      # same parameter values, widened
         bm = helpers.counter_rows_bm(rows, m, entropy, _edges(n, dt), dtype, levy=levy)
         y0 = torch.full((len(rows), d), y0_value, dtype=dtype)
         tt = torch.tensor([0.0, n * dt] if ts is None else ts, dtype=dtype)

@@ -126,3 +126,27 @@ def test_tensors_on_a_device_that_is_not_current():
     on_1 = solve(dev)
     assert torch.cuda.current_device() == 0 and on_1.device == dev
     assert torch.equal(on_1.cpu(), solve(torch.device("cuda", 0)).cpu())
+
+
+def test_module_is_copyable_after_a_graph_solve():
+    """`hip_graph=True` keeps its captured graphs on the SDE object; `copy.deepcopy` / pickling of that module (EMA
+    copies, checkpoints) must keep working and the copy must capture graphs of its own."""
+    import copy
+    import pickle
+    import torchsde_amd
+    sde = problems.make("gbm_ito", d=8).to(DEV)
+    B, d, dt = 64, 8, 2.0 ** -5
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, 1.0], device=DEV)
+
+    def solve(module):
+        with torch.no_grad():
+            return torchsde_amd.sdeint(module, y0, ts, bm=_bm(B, d, 1.0), method="euler", dt=dt,
+                                       options={"hip_graph": True})
+    a = solve(sde)
+    twin = copy.deepcopy(sde)
+    restored = pickle.loads(pickle.dumps(sde))
+    assert torch.equal(solve(twin), a) and torch.equal(solve(restored.to(DEV)), a)
+    with torch.no_grad():
+        twin.mu.mul_(2.0)                    # the copy has its own parameters and its own graph
+    assert not torch.equal(solve(twin), a) and torch.equal(solve(sde), a)

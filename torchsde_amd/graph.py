@@ -52,6 +52,26 @@ def _no_gc():
             gc.enable()
 
 
+class _GraphCache(dict):
+    """The captured graphs of one SDE object, kept on that object. A copy of the module (`copy.deepcopy` for an EMA or
+    a checkpoint, pickling, `torch.save`) must not try to copy HIP graphs: the copy starts with an empty cache and
+    captures its own graphs (its parameters live in other storage anyway)."""
+
+    def __deepcopy__(self, memo):
+        return _GraphCache()
+
+    def __reduce__(self):
+        return (_GraphCache, ())
+
+
+def _cache_of(base):
+    cache = getattr(base, _CACHE_ATTR, None)
+    if cache is None:
+        cache = _GraphCache()
+        setattr(base, _CACHE_ATTR, cache)
+    return cache
+
+
 def _remember(cache, sig, captured):
     """Each captured graph pins its memory pool; a caller that keeps changing the structure (e.g. random `ts`) must
     not grow the cache without bound: the oldest entry goes first."""
@@ -147,10 +167,7 @@ def replay_or_capture(solver, y0, ts, extra0=()):
     base = solver.sde
     while hasattr(base, "_base_sde"):    # ForwardSDE / RenameMethodsSDE / SDELogqp wrappers are rebuilt per call
         base = base._base_sde
-    cache = getattr(base, _CACHE_ATTR, None)
-    if cache is None:
-        cache = {}
-        setattr(base, _CACHE_ATTR, cache)
+    cache = _cache_of(base)
     # the grid the Brownian motion will have after adoption is part of the signature
     probe_plan_needed = not bm.frozen
     if probe_plan_needed:
@@ -215,10 +232,7 @@ def cached_backward(sde, bm, signature, capture):
     base = sde
     while hasattr(base, "_base_sde"):
         base = base._base_sde
-    cache = getattr(base, _CACHE_ATTR, None)
-    if cache is None:
-        cache = {}
-        setattr(base, _CACHE_ATTR, cache)
+    cache = _cache_of(base)
     sig = signature + (tuple(bm.shape), bm.levy_area_approximation, bm.row_offset,
                        None if bm._edges is None else bm._edges.tobytes(), bm._max_depth, bm._snap)
     captured = cache.get(sig)
@@ -368,10 +382,7 @@ def replay_or_capture_training(solver, y0, ts, extra0, params):
     base = solver.sde
     while hasattr(base, "_base_sde"):
         base = base._base_sde
-    cache = getattr(base, _CACHE_ATTR, None)
-    if cache is None:
-        cache = {}
-        setattr(base, _CACHE_ATTR, cache)
+    cache = _cache_of(base)
     if not bm.frozen:
         bm.adopt_grid(timegrid.build(ts_host, solver.dt).t_f64())
     sig = ("training",) + _signature(solver, y0, ts_host) + (
