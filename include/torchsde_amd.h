@@ -17,6 +17,8 @@
  *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
  *   tsde_linear_interp   _core/interp.py:15-18
  *   tsde_error_norm      _core/adaptive_stepping.py:42-76 (error estimate of step doubling, base_solver.py:125-128)
+ *   tsde_adaptive_*      _core/base_solver.py:117-142 + adaptive_stepping.py:21-39 (accept / reject and the step-size
+ *                        controller, decided on the device between attempts)
  *   tsde_trajectory_*    _core/base_solver.py:114-134 (the whole stepping loop of `integrate`) for SDEs whose
  *                        drift and diffusion are given in closed form instead of as Python callables
  *
@@ -221,6 +223,73 @@ int tsde_linear_interp(void* out, const void* ya, const void* yb, int64_t n, dou
 #define TSDE_ERROR_NORM_WORKSPACE 1024
 int tsde_error_norm(double* out, double* workspace, const void* y_full, const void* y_half, int64_t n, double rtol,
                     double atol, double eps, int dtype, void* stream);
+
+/* ---- adaptive stepping with the control flow on the device ------------------------------------
+ * Replaces the host side of _core/base_solver.py:117-142 + _core/adaptive_stepping.py:21-39: between two attempted
+ * steps a one-thread controller kernel reads the error norm, applies the PI controller, accepts or rejects, and
+ * writes what the next attempt's kernels need into two device tables, so that the host can enqueue a budget of
+ * attempts without synchronising and look at the state once per output time.
+ *
+ *   ctl  : TSDE_CTL_SIZE doubles (state + the bounds of the two half-step Brownian queries)
+ *   scal : TSDE_SCAL_SIZE words of `dtype`: for sub-step s in {0: whole step, 1: first half, 2: second half}, at
+ *          s * TSDE_SUB_STRIDE: dt, dt/2, sqrt(dt), 1/dt, then the stage times t0 + frac_j*dt (j < n_fracs) and the
+ *          step end; then TSDE_SCAL_W0, TSDE_SCAL_W1 (interpolation weights, _core/interp.py:15-18) and
+ *          TSDE_SCAL_ACCEPT.
+ *
+ * A step kernel reads such a word when its scalar argument is TSDE_DEV_SCALAR(address): every `double` coefficient of
+ * tsde_step_diag / _prod / _general / _general_w, tsde_milstein_*, tsde_srk_diag_stage, tsde_heun_final and
+ * tsde_linear_interp may be passed as a quiet NaN whose low 48 bits are the device address of the value (of the
+ * launch's dtype) instead of the value itself. */
+#define TSDE_DEV_SCALAR_TAG 0x7FFCull /* bits 63..48 of the double; bits 47..0 = the device address */
+#define TSDE_ADAPTIVE_MAX_STAGES 6
+#define TSDE_CTL_CURR_T 0
+#define TSDE_CTL_PREV_T 1
+#define TSDE_CTL_STEP_SIZE 2
+#define TSDE_CTL_PREV_ERROR_RATIO 3 /* NaN = none yet */
+#define TSDE_CTL_OUT_T 4
+#define TSDE_CTL_T_END 5
+#define TSDE_CTL_DT_MIN 6
+#define TSDE_CTL_ATTEMPTS 7
+#define TSDE_CTL_ACCEPTED 8
+#define TSDE_CTL_DT_MIN_HITS 9
+#define TSDE_CTL_NAN_SEEN 10
+#define TSDE_CTL_ACTIVE 11 /* 1 while curr_t < out_t */
+#define TSDE_CTL_BOUNDS_A 12 /* (a, b) of the first half step */
+#define TSDE_CTL_BOUNDS_B 14 /* (a, b) of the second half step */
+#define TSDE_CTL_WIDTHS 16   /* (ha, hb) */
+#define TSDE_CTL_SIZE 18
+#define TSDE_SUB_DT 0
+#define TSDE_SUB_HALF_DT 1
+#define TSDE_SUB_SQRT_DT 2
+#define TSDE_SUB_RDT 3
+#define TSDE_SUB_TIMES 4
+#define TSDE_SUB_STRIDE (TSDE_SUB_TIMES + TSDE_ADAPTIVE_MAX_STAGES)
+#define TSDE_SCAL_W0 (3 * TSDE_SUB_STRIDE)
+#define TSDE_SCAL_W1 (TSDE_SCAL_W0 + 1)
+#define TSDE_SCAL_ACCEPT (TSDE_SCAL_W0 + 2)
+#define TSDE_SCAL_SIZE (TSDE_SCAL_W0 + 3)
+
+/* Start stepping towards output time `out_t`: sets ctl[OUT_T], ctl[ACTIVE] and the tables of the first attempt (or the
+ * interpolation weights if the state is already past out_t). The caller initialises CURR_T, PREV_T, STEP_SIZE,
+ * PREV_ERROR_RATIO (NaN), T_END, DT_MIN and zeroes the counters once per solve. `stage_fracs`: HOST array of the
+ * solver's n_fracs stage offsets as multiples of dt (the first is 0). */
+int tsde_adaptive_begin(double* ctl, void* scal, double out_t, const double* stage_fracs, int n_fracs, int dtype,
+                        void* stream);
+/* After an attempt (`error`: DEVICE double written by tsde_error_norm): base_solver.py:125-142. Inert once
+ * ctl[ACTIVE] == 0. */
+int tsde_adaptive_control(double* ctl, void* scal, const double* error, const double* stage_fracs, int n_fracs,
+                          int dtype, void* stream);
+/* prev_y <- curr_y, curr_y <- y_next if the controller accepted the attempt; moves nothing otherwise. */
+int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal, int dtype,
+                         void* stream);
+/* (W, U) of the whole step from its halves (brownian_interval.py:647-672; U optional), widths from ctl. */
+int tsde_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb, int64_t n,
+                      const double* ctl, int dtype, void* stream);
+/* tsde_brownian_query with the interval read from device memory: ab_dev[0] = a, ab_dev[1] = b (clamped to the grid;
+ * the cells are located on the device; a >= b gives zeros). Exact-split leaf rule only (no `tol` snapping). */
+int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,
+                            int64_t n_cells, const double* ab_dev, int have_h, int max_depth,
+                            const uint64_t* entropy_dev, int dtype, void* stream);
 
 /* ---- whole-trajectory kernels (closed-form SDEs) ---------------------------------------------- */
 #define TSDE_TRAJ_EULER 0

@@ -1,0 +1,103 @@
+"""Adaptive stepping with accept / reject decided on the device (``-m gpu``; torchsde_amd/adaptive.py,
+csrc/adaptive.hip) against the host-driven form of the same loop (`options={"device_adaptive": False}`: one sync per
+attempt), which tests/test_gpu_parity.py pins to the oracle's restatement of the reference's adaptive branch
+(base_solver.py:117-142, adaptive_stepping.py:21-76; golden: tests/golden/adaptive_*.npz).
+
+Both forms run the same kernels on the same Brownian path; the only arithmetic that differs is the controller's two
+`pow` calls (device libm vs CPython), i.e. the proposed step sizes agree to an ulp of a double and the solutions to
+rounding."""
+import pytest
+import torch
+
+from workloads import problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = [
+    # problem, method, levy, (B, d, m), rtol, atol
+    ("gbm_ito", "milstein", "none", (64, 8, 8), 1e-3, 1e-3),
+    ("gbm_ito", "srk", "space-time", (64, 8, 8), 1e-4, 1e-4),
+    ("gbm_ito", "euler", "none", (64, 8, 8), 1e-2, 1e-2),
+    ("gbm_strat", "midpoint", "none", (64, 8, 8), 1e-3, 1e-3),
+    ("gbm_strat", "heun", "none", (48, 4, 4), 1e-3, 1e-3),
+    ("gbm_strat", "euler_heun", "none", (48, 4, 4), 1e-3, 1e-3),
+    ("gbm_strat", "milstein", "none", (48, 4, 4), 1e-3, 1e-3),
+    ("additive_ito", "euler", "none", (48, 4, 3), 1e-3, 1e-3),
+    ("additive_ito", "srk", "space-time", (48, 4, 3), 1e-4, 1e-4),
+    ("scalar_ito", "milstein", "none", (48, 4, 1), 1e-3, 1e-3),
+    ("scalar_ito", "srk", "space-time", (48, 4, 1), 1e-3, 1e-3),
+    ("general_ito", "euler", "none", (48, 4, 4), 1e-2, 1e-2),
+    ("general_strat", "midpoint", "none", (48, 4, 4), 1e-3, 1e-3),
+    ("mlpdiag_ito", "milstein", "none", (48, 4, 4), 1e-3, 1e-3),
+]
+
+
+def _solve(prob, method, levy, shape, rtol, atol, dtype, device_control, ts_list=(0.0, 0.3, 0.35, 1.0), options=None):
+    import torchsde_amd
+    from torchsde_amd import adaptive
+    B, d, m = shape
+    sde = problems.make(prob, dtype=dtype, d=d, m=m).to(DEV)
+    y0 = torch.full((B, d), 0.1, dtype=dtype, device=DEV)
+    ts = torch.tensor(ts_list, dtype=dtype, device=DEV)
+    bm = torchsde_amd.BrownianInterval(ts_list[0], ts_list[-1], size=(B, m), dtype=dtype, device=DEV, entropy=99,
+                                       levy_area_approximation=levy)
+    adaptive.last_stats = None
+    opts = dict(options or {}, device_adaptive=device_control)
+    with torch.no_grad():
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.1, adaptive=True, rtol=rtol, atol=atol,
+                                 options=opts)
+    return ys, adaptive.last_stats
+
+
+@pytest.mark.filterwarnings("ignore:Numerical solution is not guaranteed")
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("prob,method,levy,shape,rtol,atol", CASES)
+def test_device_control_equals_host_control(prob, method, levy, shape, rtol, atol, dtype):
+    on_device, stats = _solve(prob, method, levy, shape, rtol, atol, dtype, True)
+    on_host, none = _solve(prob, method, levy, shape, rtol, atol, dtype, False)
+    assert none is None and stats is not None and stats["control"] == "device"
+    assert torch.isfinite(on_device).all() and on_device.shape == on_host.shape
+    tol = dict(rtol=2e-5, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(on_device, on_host, **tol)
+    # one synchronisation per round of attempts: at most a few per output time, never one per attempt
+    assert stats["host_syncs"] <= 3 * stats["output_times"] + 2, stats
+    assert stats["attempts_used"] > stats["host_syncs"] or stats["attempts_used"] <= 3, stats
+    assert stats["accepted"] <= stats["attempts_used"] <= stats["attempts_enqueued"]
+
+
+def test_c2_size_adaptive_solve_syncs_once_per_output_time():
+    """The headline shape (65536 x 64, GBM), adaptive Milstein over [0, 1] with 4 output times: the number of host
+    synchronisations is of the order of the output times, not of the attempted steps."""
+    ys, stats = _solve("gbm_ito", "milstein", "none", (65536, 64, 64), 1e-3, 1e-4, torch.float32, True,
+                       ts_list=(0.0, 0.25, 0.5, 0.75, 1.0))
+    assert torch.isfinite(ys).all() and stats["output_times"] == 4
+    assert stats["attempts_used"] >= 12 and stats["host_syncs"] <= 8, stats
+    host, _ = _solve("gbm_ito", "milstein", "none", (65536, 64, 64), 1e-3, 1e-4, torch.float32, False,
+                     ts_list=(0.0, 0.25, 0.5, 0.75, 1.0))
+    torch.testing.assert_close(ys, host, rtol=2e-5, atol=2e-6)
+
+
+def test_two_output_times_inside_one_step_and_dt_min():
+    """Output times closer together than a step (the second needs no further step: interpolation only), and a tolerance
+    so tight that the controller runs into dt_min and warns like the reference (base_solver.py:134-137)."""
+    ys, stats = _solve("gbm_ito", "milstein", "none", (32, 4, 4), 1e-2, 1e-2, torch.float64, True,
+                       ts_list=(0.0, 0.01, 0.02, 0.5))
+    host, _ = _solve("gbm_ito", "milstein", "none", (32, 4, 4), 1e-2, 1e-2, torch.float64, False,
+                     ts_list=(0.0, 0.01, 0.02, 0.5))
+    torch.testing.assert_close(ys, host, rtol=1e-9, atol=1e-11)
+    import torchsde_amd
+    sde = problems.make("gbm_ito", dtype=torch.float64, d=4).to(DEV)
+    y0 = torch.full((16, 4), 0.1, dtype=torch.float64, device=DEV)
+    ts = torch.tensor([0.0, 0.05], dtype=torch.float64, device=DEV)
+
+    def run(device_control):
+        bm = torchsde_amd.BrownianInterval(0.0, 0.05, size=(16, 4), dtype=torch.float64, device=DEV, entropy=3)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=0.01, adaptive=True, rtol=1e-12,
+                                       atol=1e-12, dt_min=2e-3, options={"device_adaptive": device_control})
+    with pytest.warns(UserWarning, match="Hitting minimum allowed step size"):
+        a = run(True)
+    with pytest.warns(UserWarning, match="Hitting minimum allowed step size"):
+        b = run(False)
+    torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-11)

@@ -20,6 +20,16 @@ ACT_TANH, ACT_SOFTPLUS = 0, 1
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 
+# include/torchsde_amd.h: the device tables of adaptive stepping (TSDE_CTL_*, TSDE_SUB_*, TSDE_SCAL_*)
+ADAPTIVE_MAX_STAGES = 6
+CTL_CURR_T, CTL_PREV_T, CTL_STEP_SIZE, CTL_PREV_ERROR_RATIO, CTL_OUT_T, CTL_T_END, CTL_DT_MIN = range(7)
+CTL_ATTEMPTS, CTL_ACCEPTED, CTL_DT_MIN_HITS, CTL_NAN_SEEN, CTL_ACTIVE = 7, 8, 9, 10, 11
+CTL_BOUNDS_A, CTL_BOUNDS_B, CTL_WIDTHS, CTL_SIZE = 12, 14, 16, 18
+SUB_DT, SUB_HALF_DT, SUB_SQRT_DT, SUB_RDT, SUB_TIMES = 0, 1, 2, 3, 4
+SUB_STRIDE = SUB_TIMES + ADAPTIVE_MAX_STAGES
+SCAL_W0, SCAL_W1, SCAL_ACCEPT, SCAL_SIZE = 3 * SUB_STRIDE, 3 * SUB_STRIDE + 1, 3 * SUB_STRIDE + 2, 3 * SUB_STRIDE + 3
+DEV_SCALAR_TAG = 0x7FFC
+
 _c_i64 = ctypes.c_int64
 _c_u64 = ctypes.c_uint64
 _c_u32 = ctypes.c_uint32
@@ -112,6 +122,12 @@ SIGNATURES = {
                                                    _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
                                                    _c_ptr, _c_int, _c_ptr]),
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
+    "tsde_adaptive_begin": (_c_int, [_c_ptr, _c_ptr, _c_dbl, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
+    "tsde_adaptive_control": (_c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
+    "tsde_adaptive_commit": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_merge_halves": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_brownian_query_dev": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_u64, _c_u64, _c_ptr, _c_i64, _c_ptr, _c_int,
+                                         _c_int, _c_ptr, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),
@@ -169,6 +185,17 @@ def require_device(*tensors):
             raise NativeLibraryError(
                 "torchsde_amd: tensors must live on a ROCm device (got device "
                 f"'{t.device}'). This package is the MI355X hot path of torchsde and has no CPU fallback.")
+
+
+def dev_scalar(tensor, index=0):
+    """TSDE_DEV_SCALAR: the `double` that tells a step kernel to read its coefficient from element `index` of the
+    device tensor `tensor` (of the launch's dtype) instead of taking a value: a quiet NaN whose low 48 bits are the
+    address. It is an ordinary Python float, so it passes through every wrapper that takes a coefficient."""
+    import struct
+    address = tensor.data_ptr() + index * tensor.element_size()
+    if not 0 < address < (1 << 48):
+        raise NativeLibraryError(f"torchsde_amd: device address {address:#x} does not fit a boxed scalar")
+    return struct.unpack("<d", struct.pack("<Q", (DEV_SCALAR_TAG << 48) | address))[0]
 
 
 class on_device_of:

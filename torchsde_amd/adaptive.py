@@ -1,0 +1,192 @@
+"""Adaptive step doubling with the control flow on the device.
+
+The reference's adaptive branch (torchsde/_core/base_solver.py:117-142 + _core/adaptive_stepping.py:21-76) decides
+accept / reject on the host after every attempted step -- one `.item()` per attempt -- and derives the next attempt's
+times from that decision. Here the decision is taken by a one-thread controller kernel between the attempts
+(csrc/adaptive.hip): it reads the error norm from device memory, applies the reference's PI controller, advances the
+time, and writes the scalars the NEXT attempt needs into a small device table. Every kernel of an attempt reads its
+scalars from that table (step size, dt/2, sqrt(dt), 1/dt through `TSDE_DEV_SCALAR` coefficients; the user's ``f`` and
+``g`` get the stage times as 0-d views of it; the Brownian query kernel reads the half-step bounds from it), so an
+attempt is the SAME sequence of launches with the SAME arguments every time. The host enqueues a budget of attempts
+without synchronising and reads the controller's state back once per output time; attempts left over after the output
+time has been reached are inert (the controller leaves the state alone, the commit kernel copies nothing).
+
+Used by ``BaseSDESolver._integrate_adaptive`` whenever this package's ``BrownianInterval`` generates the path, autograd is
+off and the solver keeps no state between steps; everything else takes the host-driven loop (one sync per attempt).
+"""
+import ctypes
+import math
+import warnings
+
+import numpy as np
+import torch
+
+from . import _native
+from . import kernels as K
+from . import timegrid
+from .kernels import NoiseSpec
+
+
+class DeviceController:
+    """The two device tables of one adaptive solve (`ctl`: float64 state, `scal`: scalars of the solve's dtype) and the
+    launches that maintain them."""
+
+    def __init__(self, device, dtype, t0, t_end, step_size, dt_min, stage_fracs):
+        host = np.zeros(_native.CTL_SIZE, dtype=np.float64)
+        host[_native.CTL_CURR_T] = host[_native.CTL_PREV_T] = t0
+        host[_native.CTL_STEP_SIZE] = step_size
+        host[_native.CTL_PREV_ERROR_RATIO] = np.nan
+        host[_native.CTL_T_END] = t_end
+        host[_native.CTL_DT_MIN] = dt_min
+        self.ctl = torch.from_numpy(host).to(device)             # the one host->device copy of the solve
+        self.scal = torch.zeros(_native.SCAL_SIZE, dtype=dtype, device=device)
+        self.dtype, self.device = dtype, device
+        self.n_fracs = len(stage_fracs)
+        self._fracs = (ctypes.c_double * max(self.n_fracs, 1))(*[float(f) for f in stage_fracs])
+        self._lib, self._dt_code, _ = K._launch_env(self.scal)
+
+    def _stream(self):
+        return K._launch_env(self.scal)[2]
+
+    def begin(self, out_t):
+        code = self._lib.tsde_adaptive_begin(self.ctl.data_ptr(), self.scal.data_ptr(), float(out_t), self._fracs,
+                                             self.n_fracs, self._dt_code, self._stream())
+        _native.check(code, "tsde_adaptive_begin")
+
+    def control(self, error):
+        code = self._lib.tsde_adaptive_control(self.ctl.data_ptr(), self.scal.data_ptr(), error.data_ptr(), self._fracs,
+                                               self.n_fracs, self._dt_code, self._stream())
+        _native.check(code, "tsde_adaptive_control")
+
+    def commit(self, prev_y, curr_y, y_next):
+        code = self._lib.tsde_adaptive_commit(prev_y.data_ptr(), curr_y.data_ptr(), y_next.data_ptr(), curr_y.numel(),
+                                              self.scal.data_ptr(), self._dt_code, self._stream())
+        _native.check(code, "tsde_adaptive_commit")
+
+    def merge_halves(self, W, U, Wa, Ha, Wb, Hb):
+        code = self._lib.tsde_merge_halves(W.data_ptr(), _native.ptr(U), Wa.data_ptr(), _native.ptr(Ha), Wb.data_ptr(),
+                                           _native.ptr(Hb), W.numel(), self.ctl.data_ptr(),
+                                           _native.dtype_code(W.dtype), self._stream())
+        _native.check(code, "tsde_merge_halves")
+
+    def bounds_ptr(self, half):
+        offset = _native.CTL_BOUNDS_A if half == 0 else _native.CTL_BOUNDS_B
+        return self.ctl.data_ptr() + 8 * offset
+
+    def scalar(self, sub, which):
+        """TSDE_DEV_SCALAR of entry `which` (SUB_DT, ...) of sub-step `sub` (0 whole, 1 first half, 2 second half)."""
+        return _native.dev_scalar(self.scal, sub * _native.SUB_STRIDE + which)
+
+    def times(self, sub):
+        """The stage times of sub-step `sub` as 0-d views of the table (what the user's f(t, y), g(t, y) receive)."""
+        base = sub * _native.SUB_STRIDE + _native.SUB_TIMES
+        return tuple(self.scal[base + j] for j in range(self.n_fracs + 1))
+
+    def read(self):
+        """The controller's state on the host: the one synchronisation per round of attempts."""
+        return self.ctl.cpu().numpy()
+
+
+last_stats = None     # of the most recent device-controlled solve (tests, tools/bench_adaptive.py)
+
+
+def query_dev(bm, bounds_ptr, out_W, out_U, out_H):
+    """`BrownianInterval.increment` with the interval read from device memory (tsde_brownian_query_dev)."""
+    lib = _native.load()
+    edges = bm._device_edges()
+    code = lib.tsde_brownian_query_dev(
+        _native.ptr(out_W), _native.ptr(out_U), _native.ptr(out_H), bm._numel, bm._key, bm._elem0, _native.ptr(edges),
+        bm._edges.size - 1, bounds_ptr, 1 if bm._have_H else 0, bm._max_depth,
+        None if bm._entropy_dev is None else bm._entropy_dev.data_ptr(), _native.dtype_code(bm._dtype),
+        _native.stream_ptr(bm._device))
+    _native.check(code, "tsde_brownian_query_dev")
+
+
+def usable(solver, y0, ts):
+    """Can this solve run with device-side control? (Otherwise: the host-driven loop, one sync per attempt.)"""
+    bm = solver._native_bm()
+    return (bm is not None and solver.options.get("device_adaptive", True)
+            and bm._snap == 0 and bm._tol == 0. and bm._rootW is None and bm._rootH is None
+            and not solver.stateful and solver.merges_half_steps and not solver.options.get("general_noise", False)
+            and not solver._tracks_grad(y0)
+            and y0.dtype == ts.dtype == bm.dtype and y0.dtype in (torch.float32, torch.float64)
+            and len(solver.stage_fracs) <= _native.ADAPTIVE_MAX_STAGES - 1 and y0.numel() > 0)
+
+
+def integrate(solver, y0, ts, extra0, step_cls):
+    """The adaptive solve of `solver` (see the module docstring). Returns (ys, extra solver state)."""
+    bm = solver._native_bm()
+    device, dtype = y0.device, y0.dtype
+    ts_host = timegrid.ts_to_host(ts)
+    np_dtype = ts_host.dtype.type
+    step_size = solver.dt if not torch.is_tensor(solver.dt) else float(solver.dt)
+    solver._state_dtype = dtype
+    solver._extra = tuple(extra0) if extra0 is not None else ()
+    bm.locate(float(ts_host[0]), float(ts_host[-1]))        # freezes a generator that never saw a grid
+    bm._device_edges()
+    ctrl = DeviceController(device, dtype, float(ts_host[0]), float(ts_host[-1]), float(step_size),
+                            float(solver.dt_min), solver.stage_fracs)
+
+    T = len(ts_host)
+    ys = torch.empty((T,) + tuple(y0.shape), dtype=dtype, device=device)
+    ys[0].copy_(y0)
+    curr_y, prev_y = y0.detach().clone().contiguous(), y0.detach().clone().contiguous()
+    y_full, y_mid, y_next = (torch.empty_like(curr_y) for _ in range(3))
+    want_U = solver.needs_U and bm._have_H
+    shape = tuple(bm.shape)
+
+    def buf():
+        return torch.empty(shape, dtype=bm.dtype, device=device)
+    W, Wa, Wb = buf(), buf(), buf()
+    U, Ua, Ub, Ha, Hb = (buf(), buf(), buf(), buf(), buf()) if want_U else (None,) * 5
+    noises = (NoiseSpec.external(W, U), NoiseSpec.external(Wa, Ua), NoiseSpec.external(Wb, Ub))
+    steps = [step_cls(ctrl.times(s), ctrl.scalar(s, _native.SUB_DT), noises[s], None, None,
+                      half_dt=ctrl.scalar(s, _native.SUB_HALF_DT), sqrt_dt=ctrl.scalar(s, _native.SUB_SQRT_DT),
+                      rdt=ctrl.scalar(s, _native.SUB_RDT)) for s in range(3)]
+    w0, w1 = _native.dev_scalar(ctrl.scal, _native.SCAL_W0), _native.dev_scalar(ctrl.scal, _native.SCAL_W1)
+    rtol, atol = solver.rtol, solver.atol
+
+    def advance(y, st, out):
+        res = solver._advance(y, st, out)
+        if res.data_ptr() != out.data_ptr():      # a path that allocates its own result
+            out.copy_(res)
+
+    def attempt():
+        # two generator queries (the halves), the whole step merged from them; three steps; error norm; decision
+        query_dev(bm, ctrl.bounds_ptr(0), Wa, Ua, Ha)
+        query_dev(bm, ctrl.bounds_ptr(1), Wb, Ub, Hb)
+        ctrl.merge_halves(W, U, Wa, Ha, Wb, Hb)
+        advance(curr_y, steps[0], y_full)
+        advance(curr_y, steps[1], y_mid)
+        advance(y_mid, steps[2], y_next)
+        ctrl.control(K.error_norm(y_full, y_next, rtol, atol))
+        ctrl.commit(prev_y, curr_y, y_next)
+
+    curr_t, dt_min_hits, syncs, attempts, state = float(ts_host[0]), 0.0, 0, 0, None
+    with torch.no_grad():
+        for i in range(1, T):
+            out_t = ts_host[i]
+            ctrl.begin(float(out_t))
+            while curr_t < float(out_t):
+                # as many attempts as the current step size needs to get there, plus one; the tail that turns out not
+                # to be needed is inert, and a shortfall (rejections, shrinking steps) costs one more round
+                budget = min(int(math.ceil((float(out_t) - curr_t) / max(step_size, solver.dt_min))) + 1, 256)
+                for _ in range(budget):
+                    attempt()
+                attempts += budget
+                state = ctrl.read()
+                syncs += 1
+                if state[_native.CTL_NAN_SEEN] != 0.0:
+                    raise AssertionError("Found nans in the error estimate. Try increasing the tolerance or "
+                                         "regularizing the dynamics.")
+                if state[_native.CTL_DT_MIN_HITS] > dt_min_hits:
+                    dt_min_hits = state[_native.CTL_DT_MIN_HITS]
+                    warnings.warn("Hitting minimum allowed step size in adaptive time-stepping.")
+                curr_t, step_size = float(state[_native.CTL_CURR_T]), float(state[_native.CTL_STEP_SIZE])
+            K.linear_interp(prev_y, curr_y, w0, w1, out=ys[i])
+    global last_stats
+    final = ctrl.read() if state is None else state
+    last_stats = {"control": "device", "host_syncs": syncs, "output_times": T - 1, "attempts_enqueued": attempts,
+                  "attempts_used": int(final[_native.CTL_ATTEMPTS]), "accepted": int(final[_native.CTL_ACCEPTED]),
+                  "dtype": np_dtype.__name__}
+    return ys, solver._extra

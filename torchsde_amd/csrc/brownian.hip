@@ -25,6 +25,34 @@ __global__ void __launch_bounds__(kBlock) normals_kernel(T* __restrict__ out, in
 }
 
 // ---- general interval query ----------------------------------------------------------------------
+struct QueryBounds {
+  double a, b;
+  int64_t ca, cb;
+};
+
+// BrownianInterval.locate on the device: a, b clamped to the grid; ca = (number of edges <= a) - 1 and
+// cb = (number of edges < b) - 1, both clamped to [0, n_cells - 1]. Wave-uniform (every thread does the same walk).
+TSDE_D QueryBounds locate_bounds(const double* __restrict__ edges, int64_t n_cells, double a, double b) {
+  const double lo = edges[0], hi = edges[n_cells];
+  a = a < lo ? lo : (a > hi ? hi : a);
+  b = b < lo ? lo : (b > hi ? hi : b);
+  int64_t l = 0, r = n_cells + 1;          // first index with edges[i] > a
+  while (l < r) {
+    const int64_t mid = (l + r) >> 1;
+    if (edges[mid] <= a) l = mid + 1; else r = mid;
+  }
+  int64_t ca = l - 1;
+  l = 0, r = n_cells + 1;                  // first index with edges[i] >= b
+  while (l < r) {
+    const int64_t mid = (l + r) >> 1;
+    if (edges[mid] < b) l = mid + 1; else r = mid;
+  }
+  int64_t cb = l - 1;
+  ca = ca < 0 ? 0 : (ca > n_cells - 1 ? n_cells - 1 : ca);
+  cb = cb < 0 ? 0 : (cb > n_cells - 1 ? n_cells - 1 : cb);
+  return QueryBounds{a, b, ca, cb};
+}
+
 template <typename T, bool HAVE_H>
 __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __restrict__ U, T* __restrict__ H,
                                                        int64_t n, NoiseKey key, QueryArgs qa, int vec) {
@@ -36,15 +64,30 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
   const uint64_t q0 = key.elem0 >> 2;
   const uint64_t q1 = (key.elem0 + (uint64_t)n + 3) >> 2;
   const int64_t nq = (int64_t)(q1 - q0);
-  const double hq = qa.b - qa.a;
+  // The interval: launch-time constants, or two doubles in device memory written by an earlier kernel on the stream
+  // (adaptive stepping: the attempt's bounds come from the controller kernel, csrc/adaptive.hip). In that case the
+  // cells are located here, with the host's rule (BrownianInterval.locate): ca = last edge <= a, cb = last edge < b.
+  QueryBounds qb{qa.a, qa.b, qa.ca, qa.cb};
+  if (qa.ab_dev != nullptr) {
+    qb = locate_bounds(qa.edges, qa.n_cells, qa.ab_dev[0], qa.ab_dev[1]);
+    if (!(qb.a < qb.b)) {       // empty interval (an attempt after the last output time): the increment is zero
+      for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        W[i] = (T)0;
+        if (HAVE_H && U) U[i] = (T)0;
+        if (HAVE_H && H) H[i] = (T)0;
+      }
+      return;
+    }
+  }
+  const double hq = qb.b - qb.a;
   // Bridge-split coefficients of every tree level on the way to a (in cell ca) and to b (in cell cb): computed
   // once per block by threads 0..max_depth, shared through LDS (tsde_bridge.h: DescentTable).
   __shared__ T rows_a[kMaxLevels * DescentTable<T, HAVE_H>::N];
   __shared__ T rows_b[kMaxLevels * DescentTable<T, HAVE_H>::N];
   const DescentTable<T, HAVE_H> ta{rows_a}, tb{rows_b};
   // (an end point that sits on a cell edge needs no split, so its table is neither built nor read)
-  if (qa.a != qa.edges[qa.ca]) ta.template build<false>(qa.edges[qa.ca], qa.edges[qa.ca + 1], qa.a, qa.cfg);
-  if (qa.b != qa.edges[qa.cb + 1]) tb.template build<true>(qa.edges[qa.cb], qa.edges[qa.cb + 1], qa.b, qa.cfg);
+  if (qb.a != qa.edges[qb.ca]) ta.template build<false>(qa.edges[qb.ca], qa.edges[qb.ca + 1], qb.a, qa.cfg);
+  if (qb.b != qa.edges[qb.cb + 1]) tb.template build<true>(qa.edges[qb.cb], qa.edges[qb.cb + 1], qb.b, qa.cfg);
   __syncthreads();
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kBlock) {
     const uint64_t quad = q0 + (uint64_t)t;
@@ -52,8 +95,8 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
     acc.clear();
     WH4<T> root;
     {
-      const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
-      cell_root<T, HAVE_H>(key, quad, (uint32_t)qa.ca, e - s, root);
+      const double s = qa.edges[qb.ca], e = qa.edges[qb.ca + 1];
+      cell_root<T, HAVE_H>(key, quad, (uint32_t)qb.ca, e - s, root);
       if (qa.rootW != nullptr) {
         // Pinned top-level interval: the user supplied W (and maybe H) of the single cell
         // (brownian_interval.py:553-561, arguments `W=` / `H=`).
@@ -69,25 +112,25 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
         }
       }
     }
-    if (qa.ca == qa.cb) {
-      const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
-      cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, qa.b, root, qa.cfg, ta, tb, acc);
+    if (qb.ca == qb.cb) {
+      const double s = qa.edges[qb.ca], e = qa.edges[qb.ca + 1];
+      cell_range<T, HAVE_H>(key, quad, (uint32_t)qb.ca, s, e, qb.a, qb.b, root, qa.cfg, ta, tb, acc);
     } else {
       {
-        const double s = qa.edges[qa.ca], e = qa.edges[qa.ca + 1];
-        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.ca, s, e, qa.a, e, root, qa.cfg, ta, tb, acc);
+        const double s = qa.edges[qb.ca], e = qa.edges[qb.ca + 1];
+        cell_range<T, HAVE_H>(key, quad, (uint32_t)qb.ca, s, e, qb.a, e, root, qa.cfg, ta, tb, acc);
       }
-      for (int64_t c = qa.ca + 1; c < qa.cb; ++c) {
+      for (int64_t c = qb.ca + 1; c < qb.cb; ++c) {
         const double h = qa.edges[c + 1] - qa.edges[c];
         WH4<T> P;
         cell_root<T, HAVE_H>(key, quad, (uint32_t)c, h, P);
         acc.push_right(P, h);
       }
       {
-        const double s = qa.edges[qa.cb], e = qa.edges[qa.cb + 1];
+        const double s = qa.edges[qb.cb], e = qa.edges[qb.cb + 1];
         WH4<T> P;
-        cell_root<T, HAVE_H>(key, quad, (uint32_t)qa.cb, e - s, P);
-        cell_range<T, HAVE_H>(key, quad, (uint32_t)qa.cb, s, e, s, qa.b, P, qa.cfg, ta, tb, acc);
+        cell_root<T, HAVE_H>(key, quad, (uint32_t)qb.cb, e - s, P);
+        cell_range<T, HAVE_H>(key, quad, (uint32_t)qb.cb, s, e, s, qb.b, P, qa.cfg, ta, tb, acc);
       }
     }
     Pack<T, 4> w, u, hh;

@@ -112,10 +112,36 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
   qa.rootW = rootW;
   qa.rootH = rootH;
   qa.key_dev = entropy_dev;
+  qa.ab_dev = nullptr;
+  qa.n_cells = 0;
   qa.cfg.max_depth = max_depth;
   qa.cfg.snap = snap;
   ProfScope p(TSDE_KID_BROWNIAN_QUERY, s);
   TSDE_DISPATCH(dtype, "tsde_brownian_query", tsde::launch_query<float>(W, U, H, n, key, qa, have_h != 0, s),
+                tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
+}
+
+int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,
+                            int64_t n_cells, const double* ab_dev, int have_h, int max_depth,
+                            const uint64_t* entropy_dev, int dtype, void* stream) {
+  if (!W || !edges || !ab_dev) return bad_arg("tsde_brownian_query_dev", "W, edges and ab_dev are required");
+  if (n_cells < 1) return bad_arg("tsde_brownian_query_dev", "need at least one cell");
+  if ((U || H) && !have_h) return bad_arg("tsde_brownian_query_dev", "U/H requested without have_h");
+  if (max_depth < 0 || max_depth > 40) return bad_arg("tsde_brownian_query_dev", "max_depth must be in [0, 40]");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  tsde::QueryArgs qa;
+  qa.edges = edges;
+  qa.ca = qa.cb = 0;
+  qa.a = qa.b = 0.0;
+  qa.rootW = qa.rootH = nullptr;
+  qa.key_dev = entropy_dev;
+  qa.ab_dev = ab_dev;
+  qa.n_cells = n_cells;
+  qa.cfg.max_depth = max_depth;
+  qa.cfg.snap = 0;
+  ProfScope p(TSDE_KID_BROWNIAN_QUERY, s);
+  TSDE_DISPATCH(dtype, "tsde_brownian_query_dev", tsde::launch_query<float>(W, U, H, n, key, qa, have_h != 0, s),
                 tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
 }
 
@@ -330,6 +356,43 @@ int tsde_error_norm(double* out, double* workspace, const void* y_full, const vo
   TSDE_DISPATCH(dtype, "tsde_error_norm",
                 tsde::launch_error_norm<float>(out, workspace, y_full, y_half, n, rtol, atol, eps, s),
                 tsde::launch_error_norm<double>(out, workspace, y_full, y_half, n, rtol, atol, eps, s));
+}
+
+int tsde_adaptive_begin(double* ctl, void* scal, double out_t, const double* stage_fracs, int n_fracs, int dtype,
+                        void* stream) {
+  if (!ctl || !scal || (n_fracs > 0 && !stage_fracs)) return bad_arg("tsde_adaptive_begin", "null argument");
+  if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg("tsde_adaptive_begin", "bad number of stages");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_adaptive_begin",
+                tsde::launch_adaptive_begin<float>(ctl, scal, out_t, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_begin<double>(ctl, scal, out_t, stage_fracs, n_fracs, s));
+}
+
+int tsde_adaptive_control(double* ctl, void* scal, const double* error, const double* stage_fracs, int n_fracs,
+                          int dtype, void* stream) {
+  if (!ctl || !scal || !error || !stage_fracs) return bad_arg("tsde_adaptive_control", "null argument");
+  if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg("tsde_adaptive_control", "bad number of stages");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_adaptive_control",
+                tsde::launch_adaptive_control<float>(ctl, scal, error, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_control<double>(ctl, scal, error, stage_fracs, n_fracs, s));
+}
+
+int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal, int dtype,
+                         void* stream) {
+  if (!prev_y || !curr_y || !y_next || !scal) return bad_arg("tsde_adaptive_commit", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_adaptive_commit", tsde::launch_adaptive_commit<float>(prev_y, curr_y, y_next, n, scal, s),
+                tsde::launch_adaptive_commit<double>(prev_y, curr_y, y_next, n, scal, s));
+}
+
+int tsde_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb, int64_t n,
+                      const double* ctl, int dtype, void* stream) {
+  if (!W || !Wa || !Wb || !ctl) return bad_arg("tsde_merge_halves", "null argument");
+  if (U && (!Ha || !Hb)) return bad_arg("tsde_merge_halves", "U needs the space-time Levy areas of both halves");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_merge_halves", tsde::launch_merge_halves<float>(W, U, Wa, Ha, Wb, Hb, n, ctl, s),
+                tsde::launch_merge_halves<double>(W, U, Wa, Ha, Wb, Hb, n, ctl, s));
 }
 
 static int trajectory_affine_diag(const char* where, void* ys, void* sens, const void* y0, int64_t rows, int64_t d,

@@ -16,7 +16,7 @@ static CellNoise<T> rh_noise(const tsde_noise_t* nz) {
   c.key.k1 = (uint32_t)(nz->entropy >> 32);
   c.key.elem0 = nz->elem0;
   c.cell = nz->cell;
-  c.h = nz->h;
+  set_width<T>(c, nz->h);
   c.bcast_d = nz->bcast_d;
   c.key_dev = nz->entropy_dev;
   return c;
@@ -143,11 +143,12 @@ template <typename T, bool PROD>
 struct HeunFinalOp {
   T* y1;
   const T *y0, *f, *fp, *g, *gp;
-  T dt;
+  Coef<T> dt_;
   int mode;
   CellNoise<T> nz;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T dt = dt_.get();
     const Pack<T, W> y = load<T, W, NT>(y0, i), a = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i), d = load<T, W, NT>(gp, i);
     Pack<T, W> b, w, u, o;
     if (mode == 0) b = load<T, W, NT>(fp, i);
@@ -172,11 +173,11 @@ hipError_t launch_heun_final(void* y1, const void* y0, const void* f, const void
   bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && (!fp || aligned16(fp)) && aligned16(g) &&
              aligned16(gp);
   if (prod) {
-    HeunFinalOp<T, true> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, (T)dt, mode,
+    HeunFinalOp<T, true> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, coef<T>(dt), mode,
                             CellNoise<T>{}};
     return launch_elementwise(op, n, vec, s, sizeof(T));
   }
-  HeunFinalOp<T, false> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, (T)dt, mode,
+  HeunFinalOp<T, false> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)fp, (const T*)g, (const T*)gp, coef<T>(dt), mode,
                            rh_noise<T>(nz)};
   vec = vec && rh_noise_vec(nz);
   return launch_elementwise(op, n, vec, s, sizeof(T));

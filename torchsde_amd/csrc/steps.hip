@@ -18,10 +18,12 @@ template <typename T>
 struct StepDiagOp {
   T* y1;
   const T *y0, *f, *g;
-  T cf, cg;
+  Coef<T> cf_;
+  T cg;
   CellNoise<T> nz;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T cf = cf_.get();
     const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
@@ -36,9 +38,11 @@ template <typename T>
 struct StepProdOp {
   T* y1;
   const T *y0, *f, *gp;
-  T cf, cg;
+  Coef<T> cf_;
+  T cg;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T cf = cf_.get();
     const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(gp, i);
     Pack<T, W> o;
 #pragma unroll
@@ -70,11 +74,13 @@ template <typename T>
 struct MilsteinVOp {
   T *v_out, *W_out;
   const T* g;      // optional: write the cotangent g * v of the diffusion VJP instead of v (base_sde.py:147-152)
-  T dt, scale;
+  Coef<T> dt_;
+  T scale;
   int ito;
   CellNoise<T> nz;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T dt = dt_.get();
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
 #pragma unroll
@@ -93,10 +99,11 @@ template <typename T>
 struct MilsteinDiagOp {
   T* y1;
   const T *y0, *f, *g, *gdg;
-  T dt;
+  Coef<T> dt_;
   CellNoise<T> nz;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T dt = dt_.get();
     const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i), d = load<T, W, NT>(gdg, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
@@ -110,10 +117,11 @@ template <typename T>
 struct MilsteinGfPrimeOp {
   T* yp;
   const T *y0, *f, *g;
-  T dt, sqrt_dt;
+  Coef<T> dt_, sqrt_dt_;
   int ito;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T dt = dt_.get(), sqrt_dt = sqrt_dt_.get();
     const Pack<T, W> a = load<T, W, NT>(y0, i), c = load<T, W, NT>(g, i);
     Pack<T, W> o;
     if (ito) {
@@ -132,11 +140,13 @@ template <typename T>
 struct MilsteinGfDiagOp {
   T* y1;
   const T *y0, *f, *g, *gp;
-  T dt, two_sqrt_dt;
+  Coef<T> dt_, sqrt_dt_;
   int ito;
   CellNoise<T> nz;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    // `2 * sqrt_dt` is a 0-d tensor product in the reference (milstein.py:67): rounded in T (exact: a power of two)
+    const T dt = dt_.get(), two_sqrt_dt = (T)2 * sqrt_dt_.get();
     const Pack<T, W> a = load<T, W, NT>(y0, i), b = load<T, W, NT>(f, i), c = load<T, W, NT>(g, i), d = load<T, W, NT>(gp, i);
     Pack<T, W> w, u, o;
     cell_noise<T, W, false>(nz, i, w, u);
@@ -158,11 +168,12 @@ struct SrkDiagOp {
   const T* y0;
   const T* fs[4];
   const T* gs[4];
-  T dt, rdt, sqrt_dt;
+  Coef<T> dt_, rdt_, sqrt_dt_;
   CellNoise<T> nz;
 
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T dt = dt_.get(), rdt = rdt_.get(), sqrt_dt = sqrt_dt_.get();
     const Pack<T, W> y = load<T, W, NT>(y0, i);
     Pack<T, W> w, u;
     cell_noise<T, W, true>(nz, i, w, u);
@@ -271,9 +282,10 @@ template <typename T>
 struct InterpOp {
   T* out;
   const T *ya, *yb;
-  T w0, w1;
+  Coef<T> w0_, w1_;
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
+    const T w0 = w0_.get(), w1 = w1_.get();
     const Pack<T, W> a = load<T, W, NT>(ya, i), b = load<T, W, NT>(yb, i);
     Pack<T, W> o;
 #pragma unroll
@@ -297,11 +309,12 @@ struct GeneralArgs {
   T* y1;
   const T *y0, *f, *g;
   int64_t B, d, m;
-  T ca, cf, cg;        // drift term is (ca*f)*cf: the reference's `alpha * f * dt` rounding order
+  T ca, cg;            // drift term is (ca*f)*cf: the reference's `alpha * f * dt` rounding order
+  Coef<T> cf_, rdt_;   // the step size and its reciprocal may live in device memory (tsde_common.h: Coef)
   // weight vector the diffusion row is contracted with (SRA1, srk.py:96-109):
   //   mode 0: W      mode 1: (cu*U)*rdt      mode 2: (cw*W) + (cu*U)*rdt
   int weight_mode;
-  T cw, cu, rdt;
+  T cw, cu;
   CellNoise<T> nz;
   int rows_per_tile;
 };
@@ -309,8 +322,9 @@ struct GeneralArgs {
 template <typename T>
 TSDE_D T row_weight(const GeneralArgs<T>& a, T W, T U) {
   if (a.weight_mode == 0) return W;
-  if (a.weight_mode == 1) return (a.cu * U) * a.rdt;
-  return (a.cw * W) + (a.cu * U) * a.rdt;
+  const T rdt = a.rdt_.get();
+  if (a.weight_mode == 1) return (a.cu * U) * rdt;
+  return (a.cw * W) + (a.cu * U) * rdt;
 }
 
 template <typename T>
@@ -328,7 +342,7 @@ TSDE_D void stage_noise(const GeneralArgs<T>& a, T* lds, int64_t row0, int rows)
       lds[t] = row_weight<T>(a, W, U);
     }
   } else {
-    const T sw = (T)sqrt(nz.h), sh = (T)sqrt(nz.h / 12.0), th = (T)nz.h;
+    const T sw = nz.sw, sh = nz.sh, th = nz.th;
     const NoiseKey key = live_key(nz);
     const uint64_t e0 = key.elem0 + (uint64_t)base;
     const uint64_t q0 = e0 >> 2, q1 = (e0 + (uint64_t)cnt + 3) >> 2;
@@ -370,7 +384,7 @@ TSDE_D void lane_weights(const GeneralArgs<T>& a, int64_t row, int lp, T (&wq)[4
       for (int j = 0; j < 4; ++j) Uv[j] = u.v[j];
     }
   } else {
-    const T sw = (T)sqrt(nz.h), sh = (T)sqrt(nz.h / 12.0), th = (T)nz.h;
+    const T sw = nz.sw, sh = nz.sh, th = nz.th;
     const NoiseKey key = live_key(nz);
     const uint64_t quad = (key.elem0 + (uint64_t)off) >> 2;
     T n[4];
@@ -391,6 +405,7 @@ constexpr int kGenUnroll = 4;
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<T> a) {
+  const T cf = a.cf_.get();
   const int G = (int)(a.m >> 2);
   const int logG = __builtin_ctz(G);
   const int64_t row4 = a.d * G;            // 16-B groups of g per batch row
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<
       for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
       if (live && lp == 0) {
         const int64_t o = row[u] * a.d + (rem[u] >> logG);
-        a.y1[o] = (a.y0[o] + (a.ca * a.f[o]) * a.cf) + a.cg * part;
+        a.y1[o] = (a.y0[o] + (a.ca * a.f[o]) * cf) + a.cg * part;
       }
     }
   }
@@ -440,6 +455,7 @@ __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<
 // issued before the Philox call so that the RNG hides under the memory latency.
 template <typename T, int NC>
 __global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<T> a) {
+  const T cf = a.cf_.get();
   const int G = (int)(a.m >> 2);
   const int logG = __builtin_ctz(G);
   const int lane = threadIdx.x & 63;
@@ -468,7 +484,7 @@ __global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<
       for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
       if (lp == 0) {
         const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
-        a.y1[o] = (y0v[c] + (a.ca * fv[c]) * a.cf) + a.cg * part;
+        a.y1[o] = (y0v[c] + (a.ca * fv[c]) * cf) + a.cg * part;
       }
     }
   }
@@ -477,6 +493,7 @@ __global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<
 // Generic path: any d, m (m*rows_per_tile <= kGenMaxNoise): one thread per output, scalar loads of g.
 template <typename T>
 __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralArgs<T> a) {
+  const T cf = a.cf_.get();
   __shared__ T lds[kGenMaxNoise];
   const int64_t n_tiles = (a.B + a.rows_per_tile - 1) / a.rows_per_tile;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -493,7 +510,7 @@ __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralAr
       const T* wrow = lds + r * a.m;
       T acc = (T)0;
       for (int64_t j = 0; j < a.m; ++j) acc += grow[j] * wrow[j];
-      a.y1[idx] = (a.y0[idx] + (a.ca * a.f[idx]) * a.cf) + a.cg * acc;
+      a.y1[idx] = (a.y0[idx] + (a.ca * a.f[idx]) * cf) + a.cg * acc;
     }
   }
 }
@@ -508,7 +525,7 @@ static CellNoise<T> make_noise(const tsde_noise_t* nz) {
   c.key.k1 = (uint32_t)(nz->entropy >> 32);
   c.key.elem0 = nz->elem0;
   c.cell = nz->cell;
-  c.h = nz->h;
+  set_width<T>(c, nz->h);
   c.bcast_d = nz->bcast_d;
   c.key_dev = nz->entropy_dev;
   return c;
@@ -523,7 +540,7 @@ static bool noise_vec_ok(const tsde_noise_t* nz, bool need_u) {
 template <typename T>
 hipError_t launch_step_diag(void* y1, const void* y0, const void* f, const void* g, int64_t n, double cf, double cg,
                             const tsde_noise_t* nz, hipStream_t s) {
-  StepDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (T)cf, (T)cg, make_noise<T>(nz)};
+  StepDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, coef<T>(cf), (T)cg, make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) &&
                    noise_vec_ok(nz, false);
   return launch_elementwise(op, n, vec, s, sizeof(T));
@@ -539,7 +556,7 @@ hipError_t launch_cell_increment(void* W_out, void* U_out, int64_t n, const tsde
 template <typename T>
 hipError_t launch_step_prod(void* y1, const void* y0, const void* f, const void* gp, int64_t n, double cf, double cg,
                             hipStream_t s) {
-  StepProdOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)gp, (T)cf, (T)cg};
+  StepProdOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)gp, coef<T>(cf), (T)cg};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(gp);
   return launch_elementwise(op, n, vec, s, sizeof(T));
 }
@@ -547,7 +564,7 @@ hipError_t launch_step_prod(void* y1, const void* y0, const void* f, const void*
 template <typename T>
 hipError_t launch_milstein_v(void* v_out, void* W_out, const void* g, int64_t n, double dt, int ito, double scale,
                              const tsde_noise_t* nz, hipStream_t s) {
-  MilsteinVOp<T> op{(T*)v_out, (T*)W_out, (const T*)g, (T)dt, (T)scale, ito, make_noise<T>(nz)};
+  MilsteinVOp<T> op{(T*)v_out, (T*)W_out, (const T*)g, coef<T>(dt), (T)scale, ito, make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(v_out) && (!W_out || aligned16(W_out)) && (!g || aligned16(g)) &&
                    noise_vec_ok(nz, false);
   return launch_elementwise(op, n, vec, s, sizeof(T));
@@ -556,7 +573,7 @@ hipError_t launch_milstein_v(void* v_out, void* W_out, const void* g, int64_t n,
 template <typename T>
 hipError_t launch_milstein_diag(void* y1, const void* y0, const void* f, const void* g, const void* gdg, int64_t n,
                                 double dt, const tsde_noise_t* nz, hipStream_t s) {
-  MilsteinDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gdg, (T)dt, make_noise<T>(nz)};
+  MilsteinDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gdg, coef<T>(dt), make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) && aligned16(gdg) &&
                    noise_vec_ok(nz, false);
   return launch_elementwise(op, n, vec, s, sizeof(T));
@@ -565,7 +582,7 @@ hipError_t launch_milstein_diag(void* y1, const void* y0, const void* f, const v
 template <typename T>
 hipError_t launch_milstein_gf_prime(void* yp, const void* y0, const void* f, const void* g, int64_t n, double dt,
                                     double sqrt_dt, int ito, hipStream_t s) {
-  MilsteinGfPrimeOp<T> op{(T*)yp, (const T*)y0, (const T*)f, (const T*)g, (T)dt, (T)sqrt_dt, ito};
+  MilsteinGfPrimeOp<T> op{(T*)yp, (const T*)y0, (const T*)f, (const T*)g, coef<T>(dt), coef<T>(sqrt_dt), ito};
   const bool vec = (n % 4 == 0) && aligned16(yp) && aligned16(y0) && aligned16(f) && aligned16(g);
   return launch_elementwise(op, n, vec, s, sizeof(T));
 }
@@ -573,10 +590,8 @@ hipError_t launch_milstein_gf_prime(void* yp, const void* y0, const void* f, con
 template <typename T>
 hipError_t launch_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gp, int64_t n,
                                    double dt, double sqrt_dt, int ito, const tsde_noise_t* nz, hipStream_t s) {
-  // `2 * sqrt_dt` is a 0-d tensor product in the reference (milstein.py:67): rounded in T.
-  const T two_sqrt = (T)2 * (T)sqrt_dt;
-  MilsteinGfDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gp, (T)dt, two_sqrt, ito,
-                         make_noise<T>(nz)};
+  MilsteinGfDiagOp<T> op{(T*)y1, (const T*)y0, (const T*)f, (const T*)g, (const T*)gp, coef<T>(dt), coef<T>(sqrt_dt),
+                         ito,          make_noise<T>(nz)};
   const bool vec = (n % 4 == 0) && aligned16(y1) && aligned16(y0) && aligned16(f) && aligned16(g) && aligned16(gp) &&
                    noise_vec_ok(nz, false);
   return launch_elementwise(op, n, vec, s, sizeof(T));
@@ -597,9 +612,9 @@ static hipError_t launch_srk_stage_t(void* out0, void* out1, const void* y0, con
     op.gs[j] = (const T*)gs[j];
     vec = vec && (!fs[j] || aligned16(fs[j])) && (!gs[j] || aligned16(gs[j]));
   }
-  op.dt = (T)dt;
-  op.rdt = (T)rdt;
-  op.sqrt_dt = (T)sqrt_dt;
+  op.dt_ = coef<T>(dt);
+  op.rdt_ = coef<T>(rdt);
+  op.sqrt_dt_ = coef<T>(sqrt_dt);
   op.nz = make_noise<T>(nz);
   return launch_elementwise(op, n, vec, s, sizeof(T));
 }
@@ -650,7 +665,7 @@ hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, doub
 
 template <typename T>
 hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s) {
-  InterpOp<T> op{(T*)out, (const T*)ya, (const T*)yb, (T)w0, (T)w1};
+  InterpOp<T> op{(T*)out, (const T*)ya, (const T*)yb, coef<T>(w0), coef<T>(w1)};
   const bool vec = (n % 4 == 0) && aligned16(out) && aligned16(ya) && aligned16(yb);
   return launch_elementwise(op, n, vec, s, sizeof(T));
 }
@@ -670,12 +685,12 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   a.d = d;
   a.m = m;
   a.ca = (T)ca;
-  a.cf = (T)cf;
+  a.cf_ = coef<T>(cf);
   a.cg = (T)cg;
   a.weight_mode = weight_mode;
   a.cw = (T)cw;
   a.cu = (T)cu;
-  a.rdt = (T)rdt;
+  a.rdt_ = coef<T>(rdt);
   a.nz = make_noise<T>(nz);
   const int64_t G = m / 4;
   const bool pow2 = (m % 4 == 0) && G >= 1 && G <= 64 && ((G & (G - 1)) == 0);

@@ -1,8 +1,10 @@
 // Shared launch plumbing for the gfx950 kernels: 16-byte packs, grid sizing, noise sources.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tsde_bridge.h"
 #include "tsde_rng.h"
@@ -63,6 +65,35 @@ TSDE_D void store(T* __restrict__ p, int64_t i, const Pack<T, W>& r) {
   }
 }
 
+// A scalar coefficient of a step kernel: a launch-time constant, or a word in DEVICE memory that an earlier kernel on
+// the stream wrote (adaptive stepping without a host round trip per attempt: the step size, dt/2, sqrt(dt), 1/dt and
+// the interpolation weights of an attempt are produced by the controller kernel, csrc/adaptive.hip). On the C ABI such
+// a coefficient travels in the SAME `double` argument as a constant would, as a quiet NaN whose low 48 bits are the
+// device address (include/torchsde_amd.h: TSDE_DEV_SCALAR); `coef<T>()` decodes it on the host side of the launch.
+template <typename T>
+struct Coef {
+  T v;
+  const T* p;
+  TSDE_D T get() const { return p ? *p : v; }
+};
+
+constexpr uint64_t kDevScalarTag = 0x7FFCull;   // sign 0, exponent all ones, quiet bit and bit 50 set
+
+inline bool is_dev_scalar(double x) {
+  uint64_t bits;
+  memcpy(&bits, &x, sizeof(bits));
+  return (bits >> 48) == kDevScalarTag;
+}
+
+template <typename T>
+inline Coef<T> coef(double x) {
+  uint64_t bits;
+  memcpy(&bits, &x, sizeof(bits));
+  if ((bits >> 48) == kDevScalarTag)
+    return Coef<T>{(T)0, reinterpret_cast<const T*>((uintptr_t)(bits & 0xFFFFFFFFFFFFull))};
+  return Coef<T>{(T)x, nullptr};
+}
+
 // The Brownian increment of ONE grid cell, as the step kernels consume it.
 //   dW  == nullptr : generate in registers from (key, cell, h)              [fused, 0 bytes of HBM]
 //   dW  != nullptr : read a materialised increment (foreign bm / replay).   [+4 B per element]
@@ -74,9 +105,21 @@ struct CellNoise {
   NoiseKey key;
   uint32_t cell;
   double h;
+  T sw, sh, th;      // sqrt(h), sqrt(h/12), h rounded to T -- on the HOST (set_width), so that no kernel runs a
+                     // double-precision sqrt / divide per row (general_rows_kernel: 8.4 -> 6 us at the C3 shape)
   int64_t bcast_d;
   const uint64_t* key_dev;   // optional run-time entropy (HIP-graph replay with a new seed)
 };
+
+// Width of the cell and the scale factors derived from it (host side; IEEE sqrt and divide are correctly rounded on
+// both sides, so these are the bits the kernels used to compute for themselves).
+template <typename T>
+inline void set_width(CellNoise<T>& c, double h) {
+  c.h = h;
+  c.sw = (T)sqrt(h);
+  c.sh = (T)sqrt(h / 12.0);
+  c.th = (T)h;
+}
 
 // The key a kernel actually draws with: the baked one, or the device word if present (wave-uniform load).
 template <typename T>
@@ -107,9 +150,7 @@ TSDE_D void cell_noise(const CellNoise<T>& nz, int64_t i, Pack<T, W>& w, Pack<T,
     }
     return;
   }
-  const T sw = (T)sqrt(nz.h);
-  const T sh = (T)sqrt(nz.h / 12.0);
-  const T th = (T)nz.h;
+  const T sw = nz.sw, sh = nz.sh, th = nz.th;
   const NoiseKey key = live_key(nz);
   const uint64_t e = key.elem0 + (uint64_t)i;
   if constexpr (W == 4) {

@@ -15,6 +15,8 @@ struct QueryArgs {
   const void* rootW;    // optional pinned (W,H) of the single top-level cell
   const void* rootH;
   const uint64_t* key_dev;  // optional run-time entropy
+  const double* ab_dev;     // optional: (a, b) in device memory; then ca, cb, a, b above are ignored
+  int64_t n_cells;          // number of cells behind `edges` (needed to locate a, b on the device)
   WalkCfg cfg;
 };
 
@@ -88,6 +90,19 @@ hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const 
 template <typename T>
 hipError_t launch_error_norm(double* out, double* workspace, const void* yf, const void* yh, int64_t n, double rtol,
                              double atol, double eps, hipStream_t s);
+// adaptive.hip
+template <typename T>
+hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const double* fracs, int n_fracs,
+                                 hipStream_t s);
+template <typename T>
+hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* fracs, int n_fracs,
+                                   hipStream_t s);
+template <typename T>
+hipError_t launch_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal,
+                                  hipStream_t s);
+template <typename T>
+hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb,
+                               int64_t n, const double* ctl, hipStream_t s);
 // trajectory.hip
 template <typename T>
 hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const void* a,

@@ -26,15 +26,38 @@ from .settings import LEVY_AREA_APPROXIMATIONS, METHOD_OPTIONS, METHODS, NOISE_T
 
 
 class _Step:
-    """Everything one solver step needs besides the state."""
-    __slots__ = ("times", "dt", "noise", "h64", "t0_64")
+    """Everything one solver step needs besides the state.
 
-    def __init__(self, times, dt, noise, h64, t0_64=None):
+    `dt` and the scalars derived from it are numpy scalars of ts.dtype (rounded like the reference's 0-d tensor
+    arithmetic) -- or, when an adaptive solve is controlled on the device (adaptive.py), TSDE_DEV_SCALAR floats: the
+    kernels then read the values from the controller's table, and `times` are 0-d views of the same table."""
+    __slots__ = ("times", "dt", "noise", "h64", "t0_64", "_half_dt", "_sqrt_dt", "_rdt")
+
+    def __init__(self, times, dt, noise, h64, t0_64=None, half_dt=None, sqrt_dt=None, rdt=None):
         self.t0_64 = t0_64   # float(t0) on the host
         self.times = times   # tuple of 0-d device tensors: stage times (times[0] = t0)
-        self.dt = dt         # numpy scalar in ts.dtype: t1 - t0
+        self.dt = dt         # t1 - t0
         self.noise = noise   # NoiseSpec
         self.h64 = h64       # float(t1) - float(t0) in double (what the Brownian motion sees)
+        self._half_dt, self._sqrt_dt, self._rdt = half_dt, sqrt_dt, rdt
+
+    @property
+    def half_dt(self):       # `0.5 * dt` (midpoint.py:35, reversible_heun.py:71)
+        if self._half_dt is None:
+            self._half_dt = type(self.dt)(0.5) * self.dt
+        return self._half_dt
+
+    @property
+    def sqrt_dt(self):       # `dt.sqrt()` (milstein.py:60, srk.py:62)
+        if self._sqrt_dt is None:
+            self._sqrt_dt = np.sqrt(self.dt)
+        return self._sqrt_dt
+
+    @property
+    def rdt(self):           # `1 / dt` (srk.py:59)
+        if self._rdt is None:
+            self._rdt = type(self.dt)(1) / self.dt
+        return self._rdt
 
 
 def _error_estimate(y_full, y_half, rtol, atol, eps=1e-7):
@@ -193,9 +216,17 @@ class BaseSDESolver:
         """Step-doubling adaptive stepping (reference: base_solver.py:114-149 adaptive branch +
         adaptive_stepping.py:21-76): one full step vs two half steps on the SAME Brownian path (the virtual bridge
         tree serves the half-interval queries), PI step-size controller, accept when the scaled RMS error <= 1.
-        The accept/reject decision is data dependent, so this path synchronises once per attempted step; the
-        state updates themselves are the same HIP kernels as the fixed-step path."""
+        With this package's BrownianInterval (and autograd off) the accept / reject decision and the step-size
+        controller run on the device between the attempts and the host synchronises once per output time
+        (adaptive.py, csrc/adaptive.hip). The loop below is the host-driven form of the same algorithm, for foreign
+        Brownian motions (their `bm(ta, tb)` needs the times on the host), stateful solvers and solves that track
+        gradients: it synchronises once per attempted step. Either way the state updates are the HIP kernels of the
+        fixed-step path."""
         import warnings
+        from . import adaptive
+        if adaptive.usable(self, y0, ts):
+            # the same loop with accept / reject decided ON THE DEVICE: no sync per attempt (adaptive.py)
+            return adaptive.integrate(self, y0, ts, extra0, _Step)
         np_dtype = timegrid._NP[ts.dtype]
         ts_host = timegrid.ts_to_host(ts)
         t_end = ts_host[-1]
@@ -513,8 +544,7 @@ class Midpoint(BaseSDESolver):
         return _native.TRAJ_MIDPOINT if self._diag() else None
 
     def _advance(self, y0, st, out):
-        dt = st.dt
-        half_dt = type(dt)(0.5) * dt
+        dt, half_dt = st.dt, st.half_dt
         if self.sde.user_product:
             W, _ = st.noise.materialise()
             f, gp = self.sde.f_and_g_prod(st.times[0], y0, W)
@@ -546,8 +576,7 @@ class ReversibleHeun(BaseSDESolver):
 
     def _advance(self, y0, st, out):
         f0, g0, z0 = self._extra
-        sde, dt, noise = self.sde, st.dt, st.noise
-        half_dt = type(dt)(0.5) * dt
+        sde, dt, noise, half_dt = self.sde, st.dt, st.noise, st.half_dt
         t1 = st.times[-1]
         if self._diag():
             z1 = K.rheun_z(y0, z0, f0, g0, dt, 1.0, noise)
@@ -636,7 +665,7 @@ class _Milstein(BaseSDESolver):
         if scalar:
             noise = self._row_noise(noise, y0.shape[1])
         if self.options[METHOD_OPTIONS.grad_free]:
-            sqrt_dt = np.sqrt(dt)
+            sqrt_dt = st.sqrt_dt
             f, g = sde.f_and_g(t0, y0)
             g_ = g.squeeze(2) if g.dim() == 3 else g
             y_prime = K.milstein_gf_prime(y0, f, g_, dt, sqrt_dt, self.ito)
@@ -699,9 +728,7 @@ class SRK(BaseSDESolver):
             return self._advance_additive(y0, st, out)
         sde, dt, noise = self.sde, st.dt, st.noise
         t_0, t_q, t_h, _t_3q, t_1, _t_end = st.times
-        one = type(dt)(1)
-        rdt = one / dt
-        sqrt_dt = np.sqrt(dt)
+        rdt, sqrt_dt = st.rdt, st.sqrt_dt
         if sde.noise_type == NOISE_TYPES.scalar:
             W, U = noise.materialise(need_U=True)
             noise = NoiseSpec.external(W.reshape(-1), U.reshape(-1), bcast_d=y0.shape[1])
@@ -728,7 +755,7 @@ class SRK(BaseSDESolver):
         beta2 = (-1, 1). The diffusion always comes from `g` (a user `g_prod` computes the same product)."""
         sde, dt, noise = self.sde, st.dt, st.noise
         t_0, _t_q, _t_h, t_3q, t_1, _t_end = st.times
-        rdt = type(dt)(1) / dt
+        rdt = st.rdt
         f0 = sde.f(t_0, y0)
         g_a = sde.g(t_1, y0)     # t0 + C1[0]*dt
         H0_1 = K.step_general_weighted(y0, f0, g_a, 3 / 4, dt, 1.0, 1, 0.0, 3 / 2, rdt, noise)
@@ -755,7 +782,7 @@ class _TwoStageStratonovich(BaseSDESolver):
         sde, dt, noise = self.sde, st.dt, st.noise
         t0, t1 = st.times[0], st.times[-1]
         heun = self.mode == 0
-        cf = dt if heun else type(dt)(0)     # predictor: y0 + dt*f + g.dW (Heun) or y0 + g.dW (Euler-Heun)
+        cf = dt if heun else 0.0             # predictor: y0 + dt*f + g.dW (Heun) or y0 + g.dW (Euler-Heun)
         if sde.user_product or not self._diag():
             # products are formed by the user / the contraction kernel; the corrector combines them elementwise
             if sde.user_product:
@@ -826,7 +853,7 @@ class LogODEMidpoint(BaseSDESolver):
     def _advance(self, y0, st, out):
         sde, dt, noise = self.sde, st.dt, st.noise
         A = self._levy_area
-        half_dt = type(dt)(0.5) * dt
+        half_dt = st.half_dt
         t0, t_prime = st.times[0], st.times[1]
         y_prime = self._drift_diffusion_update(t0, y0, half_dt, 0.5, noise, None)
         dg_ga = sde.dg_ga_jvp_column_sum(t_prime, y_prime, A)
