@@ -282,9 +282,10 @@ int tsde_adaptive_control(double* ctl, void* scal, const double* error, const do
 /* prev_y <- curr_y, curr_y <- y_next if the controller accepted the attempt; moves nothing otherwise. */
 int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal, int dtype,
                          void* stream);
-/* (W, U) of the whole step from its halves (brownian_interval.py:647-672; U optional), widths from ctl. */
+/* (W, U) of the whole step from its halves (brownian_interval.py:647-672; U optional). The half widths come from
+ * ctl[TSDE_CTL_WIDTHS..] (device) or, with ctl == NULL, from (ha, hb). */
 int tsde_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb, int64_t n,
-                      const double* ctl, int dtype, void* stream);
+                      const double* ctl, double ha, double hb, int dtype, void* stream);
 /* tsde_brownian_query with the interval read from device memory: ab_dev[0] = a, ab_dev[1] = b (clamped to the grid;
  * the cells are located on the device; a >= b gives zeros). Exact-split leaf rule only (no `tol` snapping). */
 int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,

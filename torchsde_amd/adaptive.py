@@ -64,10 +64,7 @@ class DeviceController:
         _native.check(code, "tsde_adaptive_commit")
 
     def merge_halves(self, W, U, Wa, Ha, Wb, Hb):
-        code = self._lib.tsde_merge_halves(W.data_ptr(), _native.ptr(U), Wa.data_ptr(), _native.ptr(Ha), Wb.data_ptr(),
-                                           _native.ptr(Hb), W.numel(), self.ctl.data_ptr(),
-                                           _native.dtype_code(W.dtype), self._stream())
-        _native.check(code, "tsde_merge_halves")
+        K.merge_halves(W, U, Wa, Ha, Wb, Hb, ctl=self.ctl)
 
     def bounds_ptr(self, half):
         offset = _native.CTL_BOUNDS_A if half == 0 else _native.CTL_BOUNDS_B
@@ -162,17 +159,26 @@ def integrate(solver, y0, ts, extra0, step_cls):
         ctrl.control(K.error_norm(y_full, y_next, rtol, atol))
         ctrl.commit(prev_y, curr_y, y_next)
 
+    # (Replaying the attempt as a HIP graph was measured and dropped: an attempt is ~30 launches, capturing them costs
+    # 30-45 ms per solve, far more than a solve's 25-30 attempts save -- it would only pay with the graph cached across
+    # solves, i.e. with every buffer above made static per SDE object.)
+    def run_attempts(n):
+        for _ in range(n):
+            attempt()
+
     curr_t, dt_min_hits, syncs, attempts, state = float(ts_host[0]), 0.0, 0, 0, None
     with torch.no_grad():
         for i in range(1, T):
             out_t = ts_host[i]
             ctrl.begin(float(out_t))
             while curr_t < float(out_t):
-                # as many attempts as the current step size needs to get there, plus one; the tail that turns out not
-                # to be needed is inert, and a shortfall (rejections, shrinking steps) costs one more round
-                budget = min(int(math.ceil((float(out_t) - curr_t) / max(step_size, solver.dt_min))) + 1, 256)
-                for _ in range(budget):
-                    attempt()
+                # The attempts the current step size needs to get there, less one when that is more than two: accepted
+                # steps only ever grow (adaptive_stepping.py:35-37), so the estimate is an upper bound unless attempts
+                # are rejected; an attempt enqueued after the output time is reached is inert but still costs its
+                # kernels, while a shortfall costs one more (cheap) round.
+                need = int(math.ceil((float(out_t) - curr_t) / max(step_size, solver.dt_min)))
+                budget = min(max(1, need - 1 if need > 2 else need), 256)
+                run_attempts(budget)
                 attempts += budget
                 state = ctrl.read()
                 syncs += 1

@@ -166,7 +166,8 @@ template <typename T>
 struct MergeHalvesOp {
   T *W, *U;
   const T *Wa, *Ha, *Wb, *Hb;
-  const double* widths;     // (ha, hb)
+  const double* widths;     // (ha, hb) in device memory, or null: the two values below
+  double ha_host, hb_host;
   template <int Wd, bool NT = false>
   TSDE_D void run(int64_t i) const {
     const Pack<T, Wd> wa = load<T, Wd, NT>(Wa, i), wb = load<T, Wd, NT>(Wb, i);
@@ -176,7 +177,8 @@ struct MergeHalvesOp {
     store<T, Wd, NT>(W, i, w);
     if (U) {
       // the host forms ha + hb in double before it meets the tensors (solvers._step_doubling_noise)
-      const T ha = (T)widths[0], hb = (T)widths[1], hsum = (T)(widths[0] + widths[1]);
+      const double wa_ = widths ? widths[0] : ha_host, wb_ = widths ? widths[1] : hb_host;
+      const T ha = (T)wa_, hb = (T)wb_, hsum = (T)(wa_ + wb_);       // as tsde_bridge.h: interval_merge
       const Pack<T, Wd> xa = load<T, Wd, NT>(Ha, i), xb = load<T, Wd, NT>(Hb, i);
 #pragma unroll
       for (int j = 0; j < Wd; ++j) {
@@ -218,8 +220,9 @@ hipError_t launch_adaptive_commit(void* prev_y, void* curr_y, const void* y_next
 
 template <typename T>
 hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb,
-                               int64_t n, const double* ctl, hipStream_t s) {
-  MergeHalvesOp<T> op{(T*)W, (T*)U, (const T*)Wa, (const T*)Ha, (const T*)Wb, (const T*)Hb, ctl + kHa};
+                               int64_t n, const double* ctl, double ha, double hb, hipStream_t s) {
+  MergeHalvesOp<T> op{(T*)W, (T*)U, (const T*)Wa, (const T*)Ha, (const T*)Wb, (const T*)Hb, ctl ? ctl + kHa : nullptr,
+                      ha,    hb};
   const bool vec = (n % 4 == 0) && aligned16(W) && (!U || aligned16(U)) && aligned16(Wa) && aligned16(Wb) &&
                    (!U || (aligned16(Ha) && aligned16(Hb)));
   return launch_elementwise(op, n, vec, s, sizeof(T));
@@ -230,7 +233,7 @@ hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha,
   template hipError_t launch_adaptive_control<T>(double*, void*, const double*, const double*, int, hipStream_t); \
   template hipError_t launch_adaptive_commit<T>(void*, void*, const void*, int64_t, const void*, hipStream_t);    \
   template hipError_t launch_merge_halves<T>(void*, void*, const void*, const void*, const void*, const void*,    \
-                                             int64_t, const double*, hipStream_t);
+                                             int64_t, const double*, double, double, hipStream_t);
 TSDE_ADAPTIVE_INSTANTIATE(float)
 TSDE_ADAPTIVE_INSTANTIATE(double)
 

@@ -387,12 +387,13 @@ int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t
 }
 
 int tsde_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb, int64_t n,
-                      const double* ctl, int dtype, void* stream) {
-  if (!W || !Wa || !Wb || !ctl) return bad_arg("tsde_merge_halves", "null argument");
+                      const double* ctl, double ha, double hb, int dtype, void* stream) {
+  if (!W || !Wa || !Wb) return bad_arg("tsde_merge_halves", "null argument");
+  if (!ctl && !(ha + hb > 0.0)) return bad_arg("tsde_merge_halves", "need ctl or positive widths");
   if (U && (!Ha || !Hb)) return bad_arg("tsde_merge_halves", "U needs the space-time Levy areas of both halves");
   const hipStream_t s = (hipStream_t)stream;
-  TSDE_DISPATCH(dtype, "tsde_merge_halves", tsde::launch_merge_halves<float>(W, U, Wa, Ha, Wb, Hb, n, ctl, s),
-                tsde::launch_merge_halves<double>(W, U, Wa, Ha, Wb, Hb, n, ctl, s));
+  TSDE_DISPATCH(dtype, "tsde_merge_halves", tsde::launch_merge_halves<float>(W, U, Wa, Ha, Wb, Hb, n, ctl, ha, hb, s),
+                tsde::launch_merge_halves<double>(W, U, Wa, Ha, Wb, Hb, n, ctl, ha, hb, s));
 }
 
 static int trajectory_affine_diag(const char* where, void* ys, void* sens, const void* y0, int64_t rows, int64_t d,

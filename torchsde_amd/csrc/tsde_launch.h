@@ -102,7 +102,7 @@ hipError_t launch_adaptive_commit(void* prev_y, void* curr_y, const void* y_next
                                   hipStream_t s);
 template <typename T>
 hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const void* Wb, const void* Hb,
-                               int64_t n, const double* ctl, hipStream_t s);
+                               int64_t n, const double* ctl, double ha, double hb, hipStream_t s);
 // trajectory.hip
 template <typename T>
 hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const void* a,

@@ -458,6 +458,17 @@ def linear_interp(ya, yb, w0, w1, out=None):
     return out
 
 
+def merge_halves(W, U, Wa, Ha, Wb, Hb, ha=0.0, hb=0.0, ctl=None):
+    """(W, U) of a whole step from the (W, H) of its halves, by the generator's own concatenation rule
+    (brownian_interval.py:647-672); widths from the host (ha, hb) or from an adaptive controller's device table."""
+    lib, dt_code, stream = _launch_env(W)
+    code = lib.tsde_merge_halves(W.data_ptr(), _native.ptr(U), Wa.data_ptr(), _native.ptr(Ha), Wb.data_ptr(),
+                                 _native.ptr(Hb), W.numel(), None if ctl is None else ctl.data_ptr(), float(ha), float(hb),
+                                 dt_code, stream)
+    _native.check(code, "tsde_merge_halves")
+    return W, U
+
+
 _ERROR_NORM_SCRATCH = {}
 
 

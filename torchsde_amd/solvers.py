@@ -278,20 +278,20 @@ class BaseSDESolver:
         if bm is None or not self.merges_half_steps or self.options.get("general_noise", False):
             return None, None, None
         want_U = self.needs_U and bm._have_H
+        cast = self._as_state_dtype
+        ha, hb = bm._round(tm) - bm._round(ta), bm._round(tb) - bm._round(tm)
         if not want_U:
             Wa, _ = bm.increment(ta, tm)
             Wb, _ = bm.increment(tm, tb)
-            Wa, Wb = self._as_state_dtype(Wa), self._as_state_dtype(Wb)
-            return NoiseSpec.external(Wa + Wb), NoiseSpec.external(Wa), NoiseSpec.external(Wb)
+            W, _ = K.merge_halves(torch.empty_like(Wa), None, Wa, None, Wb, None, ha, hb)
+            return NoiseSpec.external(cast(W)), NoiseSpec.external(cast(Wa)), NoiseSpec.external(cast(Wb))
         Ha = torch.empty(bm.shape, dtype=bm.dtype, device=bm.device)
         Hb = torch.empty_like(Ha)
         Wa, Ua = bm.increment(ta, tm, want_U=True, out_H=Ha)
         Wb, Ub = bm.increment(tm, tb, want_U=True, out_H=Hb)
-        ha, hb = bm._round(tm) - bm._round(ta), bm._round(tb) - bm._round(tm)
-        W = Wa + Wb
-        H = (hb * (Hb + 0.5 * Wa) + ha * (Ha - 0.5 * Wb)) / (ha + hb)
-        U = (ha + hb) * (0.5 * W + H)                      # _H_to_U, brownian_interval.py:102-103
-        cast = self._as_state_dtype
+        # one kernel, the generator's own arithmetic (tsde_bridge.h: interval_merge) -- and the same kernel the
+        # device-controlled loop uses, so both forms of the loop see the same increments bit for bit
+        W, U = K.merge_halves(torch.empty_like(Wa), torch.empty_like(Wa), Wa, Ha, Wb, Hb, ha, hb)
         return (NoiseSpec.external(cast(W), cast(U)), NoiseSpec.external(cast(Wa), cast(Ua)),
                 NoiseSpec.external(cast(Wb), cast(Ub)))
 
