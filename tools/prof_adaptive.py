@@ -6,11 +6,12 @@
 `host`: the reference's structure, one read-back (`.item()`) per attempted step. The HIP API statistics of the two runs
 differ in the number of device->host copies / stream synchronisations, the kernel statistics in the controller,
 commit and merge kernels."""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torchsde_amd  # noqa: E402
 from torchsde_amd import adaptive  # noqa: E402
 from workloads import problems  # noqa: E402
