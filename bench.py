@@ -52,7 +52,7 @@ HEADLINE = "c2_euler_diag_b65536_d64_s1000"
 ALSO = ("c3_euler_general_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c2_euler_closed_form_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000",
-        "c5_sampling_mlp_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500")
+        "c5_sampling_mlp_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500")
 
 
 def csrc_digest():
@@ -178,7 +178,7 @@ class Job:
         from torchsde_amd import kernels as K
         c = self.cfg
         if self.trajectory:
-            K.prof_begin(c["kid"], 16 if not self.train else 8 * (c["nsteps"] + 1))
+            K.prof_begin(c["kid"], 16 if not (self.train or self.adjoint) else 8 * (c["nsteps"] + 1))
             for i in range(8):
                 self.solve(5000 + i, graph=False)
         else:

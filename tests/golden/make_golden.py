@@ -13,6 +13,8 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   closed_form_mlp_<case>.npz   reference `sdeint` (+ autograd gradients) of the perceptron-drift module in float64, on
                       the counter-RNG path the trajectory kernels generate for themselves
   closed_form_affine_<case>.npz   the same for the affine diagonal module (all five schemes of its trajectory kernel)
+  closed_form_adjoint_<case>.npz   reference `sdeint_adjoint(adjoint_method="euler")` of the perceptron-drift module, float64,
+                      counter-RNG path: ys and all gradients
   logqp_<case>.npz    reference `sdeint(..., logqp=True)` / `sdeint_adjoint(..., logqp=True[, names=])`: ys, log-ratio, gradients
 """
 import os
@@ -558,9 +560,71 @@ def gen_logqp():
         print(f"logqp_{name}.npz  queries={len(keys)}  log_ratio[:, 0]={out['f32__log_ratio'][:, 0]}")
 
 
+# ------------------------------------------------------------------------------ closed-form neural SDE, adjoint
+# `torchsde.sdeint_adjoint(..., adjoint_method="euler")` of the REAL reference on the perceptron-drift module, float64,
+# on the counter-RNG path (forward and time-reversed queries served by the C twin of the generator): pins
+# tsde_adjoint_mlp_diag, the stochastic adjoint on the matrix cores.
+CLOSED_FORM_ADJOINT_CASES = [
+    # name, activation, diffusion, forward method, ts (multiples of dt)
+    ("euler_softplus_sigmoid", "softplus", "sigmoid", "euler", [0.0, 16]),
+    ("euler_tanh_affine_outputs", "tanh", "affine", "euler", [0.0, 5, 11, 16]),
+    ("milstein_softplus_affine", "softplus", "affine", "milstein", [0.0, 8, 16]),
+]
+
+
+def gen_closed_form_adjoint():
+    import torchsde_amd
+    from oracle import counter
+    B, d, hidden, steps, dt, entropy = 48, 32, 64, 16, 2.0 ** -5, 515151
+    edges = np.arange(steps + 1) * dt
+
+    class CounterPath(torchsde.BaseBrownian):
+        def __call__(self, ta, tb=None, return_U=False, return_A=False):
+            W, _, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float32, have_h=False)
+            return torch.from_numpy(W).reshape(B, d).double()
+
+        def __repr__(self):
+            return "CounterPath"
+
+        dtype = property(lambda self: torch.float64)
+        device = property(lambda self: torch.device("cpu"))
+        shape = property(lambda self: (B, d))
+        levy_area_approximation = property(lambda self: "none")
+
+    for name, activation, diffusion, method, marks in CLOSED_FORM_ADJOINT_CASES:
+        gen = torch.Generator().manual_seed(sum(map(ord, "adjoint_" + name)))
+        sigmoid = diffusion == "sigmoid"
+        sde = torchsde_amd.MLPDriftDiagonalSDE(
+            d, hidden, activation=activation, sde_type="ito", diffusion=diffusion,
+            diff_scale=0.4 if sigmoid else 1.0, dtype=torch.float64,
+            diff_rate=(2.0 if sigmoid else 0.2) * torch.rand(d, generator=gen, dtype=torch.float64) - 0.1,
+            diff_shift=0.1 + 0.2 * torch.rand(d, generator=gen, dtype=torch.float64))
+        with torch.no_grad():
+            sde.lin1.weight.copy_(torch.randn(hidden, d, generator=gen, dtype=torch.float64) / d ** 0.5)
+            sde.lin2.weight.copy_(torch.randn(d, hidden, generator=gen, dtype=torch.float64) / hidden ** 0.5)
+            sde.lin1.bias.copy_(0.3 * torch.randn(hidden, generator=gen, dtype=torch.float64))
+            sde.lin2.bias.copy_(0.3 * torch.randn(d, generator=gen, dtype=torch.float64))
+        ts = [float(marks[0])] + [k * dt for k in marks[1:]]
+        y0 = (0.5 * torch.randn(B, d, generator=gen, dtype=torch.float64)).requires_grad_(True)
+        weights = torch.randn(len(ts), B, d, generator=gen, dtype=torch.float64)
+        ys = torchsde.sdeint_adjoint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method,
+                                     adjoint_method="euler", dt=dt)
+        (ys * weights).sum().backward()
+        out = {"activation": activation, "diffusion": diffusion, "sde_type": "ito", "method": method,
+               "diff_scale": np.float64(sde.diff_scale), "entropy": np.int64(entropy), "dt": np.float64(dt),
+               "ts": np.asarray(ts), "shape": np.array([B, d, hidden, steps]), "y0": y0.detach().numpy(),
+               "weights": weights.numpy(), "ys": ys.detach().numpy(), "grad__y0": y0.grad.numpy()}
+        for pname, p in sde.named_parameters():
+            out["param__" + pname] = p.detach().numpy()
+            out["grad__" + pname] = p.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, f"closed_form_adjoint_{name}.npz"), **out)
+        print(f"closed_form_adjoint_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}  "
+              f"|grad lin1.weight|={np.abs(out['grad__lin1.weight']).mean():.4f}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
-                             "closed_form_affine", "logqp"]
+                             "closed_form_affine", "logqp", "closed_form_adjoint"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

@@ -243,3 +243,44 @@ def test_c5_parameter_gradients_b256_vs_oracle():
     helpers.assert_within_reference_rounding(y0.grad, gy32, gy64, "dL/dy0")
     for (name, p), g32, g64 in zip(sde.named_parameters(), gp32, gp64):
         helpers.assert_within_reference_rounding(p.grad, g32, g64, f"dL/d{name}")
+
+
+def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle():
+    """configs[4] through `sdeint_adjoint(method="euler", adjoint_method="euler")` with the latent SDE stated as the
+    closed-form module: the forward sampling kernel and the stochastic adjoint on the matrix cores
+    (tsde_adjoint_mlp_diag) at 32768 x 128 x 500 steps. Final states and dL/dy0 of sampled rows against the oracle's
+    restatement of the reference's adjoint on the user-module statement of the same SDE; the six parameter gradients
+    against the stepwise stochastic adjoint of the full batch (pinned to the oracle by the tests above)."""
+    import torchsde_amd
+    c = configs.WORKLOADS["c5_adjoint_mlp_b32768_d128_s500"]
+    B, d, n, dt = c["B"], c["d"], c["nsteps"], c["dt"]
+    closed = configs.make_problem(c["problem"], d, d, DEV)
+    user = configs.make_problem("latent_diag", d, d, DEV)
+    wt = _loss_weights(B, d)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def run(sde):
+        y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
+        sde.zero_grad()
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(B, d, n, dt, 20240601), method="euler",
+                                         adjoint_method="euler", dt=dt)
+        (ys[-1] * wt.to(DEV, torch.float32)).sum().backward()
+        return ys, y0.grad, [p.grad.clone() for p in sde.parameters()]
+
+    ys, gy, gp = run(closed)
+    assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn")
+    rows = helpers.sampled_rows(B, 64, seed=8, seams=(16, 64, 128))
+    idx = torch.from_numpy(rows).to(DEV)
+    (ys32, gy32, _), (ys64, gy64, _) = _oracle_adjoint(user, rows, d, 20240601, n, dt, "euler", "euler",
+                                                        wt[torch.from_numpy(rows)])
+    # (the matrix products accumulate in another order than the oracle's float32 GEMMs: a wider factor than for the
+    #  elementwise kernels, still relative to the oracle's own float32 rounding)
+    helpers.assert_within_reference_rounding(ys[-1][idx], ys32[-1], ys64[-1], "final state", factor=8.0, floor=1e-5)
+    helpers.assert_within_reference_rounding(gy[idx], gy32, gy64, "dL/dy0", factor=8.0, floor=1e-5)
+    _, _, gp_user = run(user)
+    names = [name for name, _ in closed.named_parameters()]
+    # parameter order: closed-form (lin1.weight, lin1.bias, lin2.weight, lin2.bias, diff_rate, diff_shift) =
+    # user module (net.0.weight, net.0.bias, net.2.weight, net.2.bias, w, b)
+    for name, got, want in zip(names, gp, gp_user):
+        err = (got - want).abs().max().item()
+        assert err <= 2e-3 * want.abs().max().item() + 1e-6, f"{name}: {err:.3e} vs scale {want.abs().max().item():.3e}"

@@ -27,3 +27,35 @@ def test_oracle_adjoint_matches_reference(name, tag):
     for j, g in enumerate(grad_params):
         torch.testing.assert_close(g, torch.tensor(z[f"{tag}__grad_p{j}"], dtype=case.dtype), rtol=rtol,
                                    atol=atol * 10)
+
+
+def _closed_form_adjoint_cases():
+    import os
+    return sorted(f[len("closed_form_adjoint_"):-4] for f in os.listdir(helpers.GOLDEN)
+                  if f.startswith("closed_form_adjoint_"))
+
+
+@pytest.mark.parametrize("name", _closed_form_adjoint_cases())
+def test_oracle_adjoint_matches_reference_on_the_counter_path(name):
+    """The oracle's adjoint + the C twin of the counter RNG reproduce what the REAL reference's
+    `sdeint_adjoint(adjoint_method="euler")` computed for the perceptron-drift module on that path
+    (tests/golden/make_golden.py: gen_closed_form_adjoint) -- the chain tsde_adjoint_mlp_diag hangs from."""
+    import numpy as np
+
+    from oracle import counter
+    z = helpers.load(f"closed_form_adjoint_{name}.npz")
+    B, d, hidden, steps = (int(v) for v in z["shape"])
+    dt = float(z["dt"])
+    sde = helpers.mlp_module_from(z, torch.float64, "cpu")
+    edges = np.arange(steps + 1) * dt
+
+    def bm(ta, tb, return_U=False):
+        W, _, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float32, have_h=False)
+        return torch.from_numpy(W).reshape(B, d).double()
+
+    ys, grad_y0, grad_params = adjoint_ref.adjoint_gradients(sde, torch.tensor(z["y0"]), torch.tensor(z["ts"]), bm, dt,
+                                                             str(z["method"]), "euler", torch.tensor(z["weights"]))
+    torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
+    torch.testing.assert_close(grad_y0, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
+    for (pname, _), g in zip(sde.named_parameters(), grad_params):
+        torch.testing.assert_close(g, torch.tensor(z["grad__" + pname]), rtol=1e-10, atol=1e-11)

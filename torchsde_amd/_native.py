@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtorchsde_amd.so")
 
 F32, F64 = 0, 1
 KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDATE, KID_BROWNIAN_QUERY = 1, 2, 3, 4, 5, 6
-KID_RHEUN, KID_TRAJECTORY, KID_MLP_BACKWARD = 7, 8, 9
+KID_RHEUN, KID_TRAJECTORY, KID_MLP_BACKWARD, KID_MLP_ADJOINT = 7, 8, 9, 10
 ERROR_NORM_WORKSPACE = 1024
 TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1
@@ -121,6 +121,9 @@ SIGNATURES = {
                                                    _c_ptr, _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                    _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
                                                    _c_ptr, _c_int, _c_ptr]),
+    "tsde_adjoint_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                       _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_dbl, _c_int, _c_int,
+                                       ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_adaptive_begin": (_c_int, [_c_ptr, _c_ptr, _c_dbl, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
     "tsde_adaptive_control": (_c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),

@@ -705,6 +705,13 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
                         options=options)
     # fail early (at call time, like the reference would at backward time) on unusable adjoint methods
     _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
+    # the perceptron-drift module with adjoint_method="euler": forward and backward solves on the matrix cores
+    if torch.is_grad_enabled() and (y0.requires_grad or adjoint_params):
+        from . import mlp_adjoint
+        ys = mlp_adjoint.route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, options,
+                               adjoint_options, adjoint_params, extra_solver_state)
+        if ys is not None:
+            return contract.parse_return(y0, ys, (), extra, logqp)
     if extra_solver_state is None:
         extra_solver_state = solver.init_extra_solver_state(ts[0], y0)
 

@@ -463,6 +463,39 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
               where);
 }
 
+int tsde_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void* stash_delta, void* stash_y,
+                          void* row_rate, void* row_shift, int64_t rows, int64_t d, int64_t hidden, const void* w1,
+                          const void* b1, const void* w2, const void* b2, const void* diff_rate, const void* diff_shift,
+                          int diff_kind, double diff_amp, int activation, int ito, const tsde_traj_t* traj, int32_t k_lo,
+                          int32_t k_hi, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                          void* stream) {
+  const char* where = "tsde_adjoint_mlp_diag";
+  if (!y || !a || !stash_a || !stash_hid || !stash_delta || !stash_y || !row_rate || !row_shift || !w1 || !b1 || !w2 ||
+      !b2 || !diff_rate || !diff_shift || !traj)
+    return bad_arg(where, "null argument");
+  if (diff_kind != TSDE_DIFF_AFFINE && diff_kind != TSDE_DIFF_SIGMOID) return bad_arg(where, "unknown diffusion kind");
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (rows < 0) return bad_arg(where, "need rows >= 0");
+  if (d < 4 || d > 128 || d % 4 != 0 || hidden < 4 || hidden > 256 || hidden % 4 != 0 || (hidden > 128 && d > 64))
+    return bad_arg(where, "need d and hidden multiples of 4, d in [4, 128], hidden in [4, 128] (up to 256 for d <= 64)");
+  if (rows * (d > hidden ? d : hidden) >= (int64_t(1) << 30))
+    return bad_arg(where, "need rows * max(d, hidden) < 2^30 (32-bit lane offsets)");
+  const void* aligned[] = {y, a, stash_a, stash_hid, stash_delta, stash_y, row_rate, row_shift};
+  for (const void* q : aligned)
+    if (reinterpret_cast<uintptr_t>(q) & 15u) return bad_arg(where, "state-shaped buffers must be 16-byte aligned");
+  if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
+  if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
+  if (k_lo < 0 || k_hi < k_lo || k_hi > traj->n_steps) return bad_arg(where, "need 0 <= k_lo <= k_hi <= n_steps");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_MLP_ADJOINT, s);
+  return fail(tsde::launch_adjoint_mlp_diag(y, a, stash_a, stash_hid, stash_delta, stash_y, row_rate, row_shift, rows, d,
+                                            hidden, w1, b1, w2, b2, diff_rate, diff_shift, diff_kind, diff_amp,
+                                            activation, ito ? 1 : 0, traj, k_lo, k_hi, make_key(entropy, elem0),
+                                            entropy_dev, s),
+              where);
+}
+
 int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta, void* row_rate,
                                       void* row_shift, const void* ys_all, int32_t ys_first, const void* grad_ys,
                                       const int32_t* grad_step, int32_t grad_last, int64_t rows, int64_t d,

@@ -122,6 +122,12 @@ hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void*
                                                double diff_amp, int act, int method, const tsde_traj_t* tr,
                                                int32_t k_lo, int32_t k_hi, NoiseKey key, const uint64_t* key_dev,
                                                hipStream_t s);
+// mlp_adjoint.hip
+hipError_t launch_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void* stash_delta, void* stash_y,
+                                   void* row_rate, void* row_shift, int64_t rows, int64_t d, int64_t h, const void* W1,
+                                   const void* b1, const void* W2, const void* b2, const void* c, const void* e,
+                                   int diff_kind, double diff_amp, int act, int ito, const tsde_traj_t* tr, int32_t k_lo,
+                                   int32_t k_hi, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, int64_t lda, const void* Bm, int64_t ldb,
                                 int64_t K, int64_t M, int64_t N, int32_t blocks, hipStream_t s);
 }  // namespace tsde

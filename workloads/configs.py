@@ -71,6 +71,15 @@ WORKLOADS = {
         bytes_per_traj_step=0, kid=9, launches_per_step=1, trajectory=True, train=True,
         mfma_flops_per_traj_step=6 * 128 * 128,
         kernel="tsde_trajectory_mlp_diag_backward<128, 128, softplus> (mlp_backward_kernel, v_mfma_f32_16x16x4_f32)"),
+    # BASELINE configs[4] through the API it names -- sdeint_adjoint, method = adjoint_method = "euler" -- with the latent
+    # SDE stated as the closed-form module: forward = the sampling kernel (outputs only), backward = the stochastic
+    # adjoint on the matrix cores (tsde_adjoint_mlp_diag: y reconstructed, four products per step) + the weight-gradient
+    # products. Roofline: the adjoint kernel, 4 * 2*d*hidden flop per trajectory-step.
+    "c5_adjoint_mlp_b32768_d128_s500": dict(
+        problem="latent_diag_closed_form", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=0, kid=10, launches_per_step=1, trajectory=True, adjoint=True,
+        mfma_flops_per_traj_step=8 * 128 * 128,
+        kernel="tsde_adjoint_mlp_diag<128, 128, softplus> (mlp_adjoint_kernel, v_mfma_f32_16x16x4_f32)"),
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
