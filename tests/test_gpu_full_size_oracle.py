@@ -279,8 +279,8 @@ def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle():
     helpers.assert_within_reference_rounding(gy[idx], gy32, gy64, "dL/dy0", factor=8.0, floor=1e-5)
     _, _, gp_user = run(user)
     names = [name for name, _ in closed.named_parameters()]
-    # parameter order: closed-form (lin1.weight, lin1.bias, lin2.weight, lin2.bias, diff_rate, diff_shift) =
-    # user module (net.0.weight, net.0.bias, net.2.weight, net.2.bias, w, b)
+    # parameter order: closed-form (diff_rate, diff_shift, lin1.weight, lin1.bias, lin2.weight, lin2.bias) =
+    # user module (w, b, net.0.weight, net.0.bias, net.2.weight, net.2.bias)
     for name, got, want in zip(names, gp, gp_user):
         err = (got - want).abs().max().item()
         assert err <= 2e-3 * want.abs().max().item() + 1e-6, f"{name}: {err:.3e} vs scale {want.abs().max().item():.3e}"
