@@ -348,6 +348,22 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
                              const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
                              int dtype, void* stream);
 
+/* tsde_trajectory_affine_diag for drift and diffusion given as elementwise expressions per state channel:
+ *     f = coef[0] * phi_f(coef[1] * y + coef[2]) + coef[3]        g = coef[4] * phi_g(coef[5] * y + coef[6]) + coef[7]
+ * with phi_f, phi_g one of TSDE_FN_* (torchsde_amd.ElementwiseDiagonalSDE; e.g. the SDE the reference's own benchmark
+ * integrates, f = y, g = exp(-y): benchmarks/brownian.py:131-139). coef: 8 device arrays of d values in `dtype`.
+ * Same schedule, methods, outputs and Brownian path as the affine kernel; values only (no sensitivities). */
+#define TSDE_FN_IDENTITY 0
+#define TSDE_FN_EXP 1
+#define TSDE_FN_SIGMOID 2
+#define TSDE_FN_TANH 3
+#define TSDE_FN_SOFTPLUS 4
+#define TSDE_FN_SIN 5
+#define TSDE_FN_COS 6
+int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8], int f_kind,
+                              int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                              const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* The stochastic adjoint of the perceptron-drift SDE of tsde_trajectory_mlp_diag, Euler-Maruyama backwards in time:
  * what `sdeint_adjoint(..., adjoint_method="euler")` integrates for this module (torchsde/_core/adjoint.py:64-127
  * driving adjoint_sde.py:177-230, 296-323 through methods/euler.py:29-37), one launch per chunk of steps. Processes

@@ -13,6 +13,8 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   closed_form_mlp_<case>.npz   reference `sdeint` (+ autograd gradients) of the perceptron-drift module in float64, on
                       the counter-RNG path the trajectory kernels generate for themselves
   closed_form_affine_<case>.npz   the same for the affine diagonal module (all five schemes of its trajectory kernel)
+  closed_form_expr_<case>.npz   reference `sdeint` of the elementwise-expression module (incl. the reference's own
+                      benchmark SDE f = y, g = exp(-y)), float64, counter-RNG path
   closed_form_adjoint_<case>.npz   reference `sdeint_adjoint(adjoint_method="euler")` of the perceptron-drift module, float64,
                       counter-RNG path: ys and all gradients
   logqp_<case>.npz    reference `sdeint(..., logqp=True)` / `sdeint_adjoint(..., logqp=True[, names=])`: ys, log-ratio, gradients
@@ -622,9 +624,69 @@ def gen_closed_form_adjoint():
               f"|grad lin1.weight|={np.abs(out['grad__lin1.weight']).mean():.4f}")
 
 
+# --------------------------------------------------------------------------------- closed-form elementwise SDE
+# torchsde_amd.ElementwiseDiagonalSDE solved by the REAL reference in float64 on the counter-RNG path: pins
+# tsde_trajectory_expr_diag. The first three cases are the SDE of the reference's own benchmark
+# (benchmarks/brownian.py:131-139: f = y, g = exp(-y)).
+EXPR_CASES = [
+    # name, drift fn, diffusion fn, drift coefs (scale, rate, shift, offset), diffusion coefs, sde_type, method, levy
+    ("benchmark_euler", "identity", "exp", (1.0, 1.0, 0.0, 0.0), (1.0, -1.0, 0.0, 0.0), "ito", "euler", "none"),
+    ("benchmark_milstein", "identity", "exp", (1.0, 1.0, 0.0, 0.0), (1.0, -1.0, 0.0, 0.0), "ito", "milstein", "none"),
+    ("benchmark_srk", "identity", "exp", (1.0, 1.0, 0.0, 0.0), (1.0, -1.0, 0.0, 0.0), "ito", "srk", "space-time"),
+    ("tanh_sigmoid_midpoint", "tanh", "sigmoid", None, None, "stratonovich", "midpoint", "none"),
+    ("sin_softplus_milstein_strat", "sin", "softplus", None, None, "stratonovich", "milstein", "none"),
+    ("softplus_cos_euler", "softplus", "cos", None, None, "ito", "euler", "none"),
+]
+
+
+def gen_closed_form_expr():
+    import torchsde_amd
+    from oracle import counter
+    B, d, steps, entropy = 40, 12, 16, 909090
+
+    for name, fk, gk, fc, gc, sde_type, method, levy in EXPR_CASES:
+        # (explicit schemes on f = y, g = exp(-y) blow up once a path wanders to y << 0, where exp(-y) explodes: the
+        #  benchmark SDE gets a short horizon)
+        dt = 2.0 ** -8 if name.startswith("benchmark") else 2.0 ** -5
+        edges = np.arange(steps + 1) * dt
+        ts = [0.0, 5 * dt, 7.5 * dt, steps * dt]
+
+        class CounterPath(torchsde.BaseBrownian):
+            def __call__(self, ta, tb=None, return_U=False, return_A=False):
+                W, U, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float64,
+                                        have_h=levy != "none")
+                W = torch.from_numpy(W).reshape(B, d)
+                return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+            def __repr__(self):
+                return "CounterPath"
+
+            dtype = property(lambda self: torch.float64)
+            device = property(lambda self: torch.device("cpu"))
+            shape = property(lambda self: (B, d))
+            levy_area_approximation = property(lambda self: levy)
+
+        gen = torch.Generator().manual_seed(sum(map(ord, "expr_" + name)))
+        rnd = lambda lo, hi: lo + (hi - lo) * torch.rand(d, generator=gen, dtype=torch.float64)   # noqa: E731
+        if fc is None:
+            fc = (rnd(-0.8, 0.8), rnd(0.5, 1.5), rnd(-0.3, 0.3), rnd(-0.2, 0.2))
+            gc = (rnd(0.2, 0.6), rnd(-1.5, 1.5), rnd(-0.3, 0.3), rnd(0.05, 0.2))
+        sde = torchsde_amd.ElementwiseDiagonalSDE(fk, gk, fc, gc, sde_type=sde_type, dtype=torch.float64)
+        y0 = 0.6 * torch.rand(B, d, generator=gen, dtype=torch.float64) - 0.3
+        with torch.no_grad():
+            ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method, dt=dt)
+        out = {"drift": fk, "diffusion": gk, "sde_type": sde_type, "method": method, "levy": levy,
+               "entropy": np.int64(entropy), "dt": np.float64(dt), "ts": np.asarray(ts), "shape": np.array([B, d, steps]),
+               "y0": y0.numpy(), "ys": ys.numpy()}
+        for pname, p in sde.named_parameters():
+            out["param__" + pname] = p.detach().numpy()
+        np.savez_compressed(os.path.join(HERE, f"closed_form_expr_{name}.npz"), **out)
+        print(f"closed_form_expr_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
-                             "closed_form_affine", "logqp", "closed_form_adjoint"]
+                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

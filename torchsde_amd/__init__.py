@@ -2,7 +2,7 @@
 from .brownian import (BaseBrownian, BrownianInterval, BrownianPath, BrownianTree, ReverseBrownian,
                        brownian_interval_like)
 from .adjoint import sdeint_adjoint
-from .closed_form import AffineDiagonalSDE, MLPDriftDiagonalSDE
+from .closed_form import AffineDiagonalSDE, ElementwiseDiagonalSDE, MLPDriftDiagonalSDE
 from .integrate import sdeint
 from .sde import BaseSDE, SDEIto, SDEStratonovich
 from . import types  # noqa: F401

@@ -19,6 +19,7 @@ TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
+FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6}
 
 # include/torchsde_amd.h: the device tables of adaptive stepping (TSDE_CTL_*, TSDE_SUB_*, TSDE_SCAL_*)
 ADAPTIVE_MAX_STAGES = 6
@@ -121,6 +122,8 @@ SIGNATURES = {
                                                    _c_ptr, _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                    _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,
                                                    _c_ptr, _c_int, _c_ptr]),
+    "tsde_trajectory_expr_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr * 8, _c_int, _c_int, _c_int,
+                                           ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_adjoint_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,
                                        _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_dbl, _c_int, _c_int,
                                        ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),

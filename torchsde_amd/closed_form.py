@@ -78,6 +78,65 @@ class AffineDiagonalSDE(nn.Module):
         return ("affine_diagonal",) + tuple(out)
 
 
+class ElementwiseDiagonalSDE(nn.Module):
+    """Diagonal-noise SDE whose drift and diffusion are elementwise expressions, per state channel:
+
+        f(t, y) = f_scale * phi_f(f_rate * y + f_shift) + f_offset
+        g(t, y) = g_scale * phi_g(g_rate * y + g_shift) + g_offset
+
+    with ``phi`` one of ``identity, exp, sigmoid, tanh, softplus, sin, cos`` -- e.g. the SDE the reference's own
+    benchmark integrates (benchmarks/brownian.py:131-139), ``f = y, g = exp(-y)``:
+    ``ElementwiseDiagonalSDE("identity", "exp", diffusion_coefficients=(1., -1., 0., 0.))``; geometric Brownian
+    motion; bounded (sigmoid / tanh) diffusions and drifts. Every coefficient is a scalar or a length-``d`` tensor and
+    is registered as a parameter. An ordinary module for the reference, for autograd and for ``sdeint_adjoint``;
+    forward solves without autograd run all their steps in one launch of ``tsde_trajectory_expr_diag`` (Euler,
+    Milstein, midpoint, SRK), the kernel evaluating ``phi`` with the formulas torch uses for it.
+    """
+    noise_type = "diagonal"
+    _FUNCTIONS = {"identity": lambda u: u, "exp": torch.exp, "sigmoid": torch.sigmoid, "tanh": torch.tanh,
+                  "softplus": nn.functional.softplus, "sin": torch.sin, "cos": torch.cos}
+    _NAMES = ("f_scale", "f_rate", "f_shift", "f_offset", "g_scale", "g_rate", "g_shift", "g_offset")
+
+    def __init__(self, drift="identity", diffusion="identity", drift_coefficients=(1.0, 1.0, 0.0, 0.0),
+                 diffusion_coefficients=(1.0, 1.0, 0.0, 0.0), sde_type="ito", dtype=None, device=None):
+        super().__init__()
+        if sde_type not in ("ito", "stratonovich"):
+            raise ValueError(f"Expected sde_type 'ito' or 'stratonovich', got {sde_type!r}.")
+        for name in (drift, diffusion):
+            if name not in self._FUNCTIONS:
+                raise ValueError(f"Expected a function in {sorted(self._FUNCTIONS)}, got {name!r}.")
+        if len(drift_coefficients) != 4 or len(diffusion_coefficients) != 4:
+            raise ValueError("coefficients are (scale, rate, shift, offset)")
+        self.sde_type, self.drift, self.diffusion = sde_type, drift, diffusion
+        for name, value in zip(self._NAMES, tuple(drift_coefficients) + tuple(diffusion_coefficients)):
+            value = torch.as_tensor(value, dtype=dtype, device=device)
+            if not value.is_floating_point():
+                value = value.to(torch.get_default_dtype())
+            if value.dim() > 1:
+                raise ValueError(f"`{name}` must be a scalar or a 1-D tensor over the state channels.")
+            setattr(self, name, nn.Parameter(value.detach().clone()))
+
+    def f(self, t, y):
+        return self.f_scale * self._FUNCTIONS[self.drift](self.f_rate * y + self.f_shift) + self.f_offset
+
+    def g(self, t, y):
+        return self.g_scale * self._FUNCTIONS[self.diffusion](self.g_rate * y + self.g_shift) + self.g_offset
+
+    def closed_form_parameters(self):
+        return tuple(getattr(self, name) for name in self._NAMES)
+
+    def closed_form(self, d, dtype, device):
+        """("elementwise_diagonal", drift code, diffusion code, eight contiguous (d,) coefficient tensors), or None
+        if the coefficients cannot be served in `dtype` as they are."""
+        from . import _native
+        out = []
+        for p in self.closed_form_parameters():
+            if p.dtype != dtype or p.device != device or (p.dim() == 1 and p.numel() not in (1, d)):
+                return None
+            out.append(p.detach().reshape(-1).expand(d).contiguous())
+        return ("elementwise_diagonal", _native.FN_CODES[self.drift], _native.FN_CODES[self.diffusion]) + tuple(out)
+
+
 class MLPDriftDiagonalSDE(nn.Module):
     """Diagonal-noise neural SDE with a two-layer perceptron drift shared by the batch and an elementwise diffusion:
 

@@ -463,6 +463,30 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
               where);
 }
 
+int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8], int f_kind,
+                              int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                              const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_trajectory_expr_diag";
+  if (!ys || !y0 || !coef || !traj) return bad_arg(where, "null argument");
+  for (int c = 0; c < 8; ++c)
+    if (!coef[c]) return bad_arg(where, "null coefficient array");
+  if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
+  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
+  if (f_kind < TSDE_FN_IDENTITY || f_kind > TSDE_FN_COS || g_kind < TSDE_FN_IDENTITY || g_kind > TSDE_FN_COS)
+    return bad_arg(where, "unknown function code");
+  if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  TSDE_DISPATCH(dtype, where,
+                tsde::launch_trajectory_expr_diag<float>(ys, y0, rows, d, coef, f_kind, g_kind, method, traj, key,
+                                                         entropy_dev, s),
+                tsde::launch_trajectory_expr_diag<double>(ys, y0, rows, d, coef, f_kind, g_kind, method, traj, key,
+                                                          entropy_dev, s));
+}
+
 int tsde_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void* stash_delta, void* stash_y,
                           void* row_rate, void* row_shift, int64_t rows, int64_t d, int64_t hidden, const void* w1,
                           const void* b1, const void* w2, const void* b2, const void* diff_rate, const void* diff_shift,

@@ -122,19 +122,20 @@ struct TrajArgs {
 enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStrat = TSDE_TRAJ_MILSTEIN_STRAT,
              kMidpoint = TSDE_TRAJ_MIDPOINT, kSrk = TSDE_TRAJ_SRK };
 
-// One step of one element. `w` = W, `u` = U (SRK only). S is T (values only) or Dual<T>; the coefficient types
-// A..E are T or Seed<T, 1..4> accordingly.
-template <typename T, int METHOD, typename S, typename A, typename B, typename C, typename E>
-TSDE_D S affine_step(const S y, const A a, const B b, const C c, const E e, const T w, const T u, const T dt,
-                     const T half_dt, const T rdt, const T sqrt_dt) {
-  auto F = [&](const S& x) { return a * x + b; };
-  auto G = [&](const S& x) { return c * x + e; };
+// One step of one element of a diagonal SDE whose drift and diffusion the kernel can evaluate itself. `w` = W, `u` = U
+// (SRK only). S is T (values only) or Dual<T>. `M` supplies f(x), g(x) and gdg(x, g, v) = (g * v) * g'(x), the
+// diffusion VJP with cotangent g * v that derivative-form Milstein takes through autograd (base_sde.py:147-152).
+template <typename T, int METHOD, typename S, typename M>
+TSDE_D S scheme_step(const S y, const M& m, const T w, const T u, const T dt, const T half_dt, const T rdt,
+                     const T sqrt_dt) {
+  auto F = [&](const S& x) { return m.f(x); };
+  auto G = [&](const S& x) { return m.g(x); };
   if constexpr (METHOD == kEuler) {
     return drift_diffusion_update<T, S>(y, F(y), G(y), w, dt, (T)1);
   } else if constexpr (METHOD == kMilIto || METHOD == kMilStrat) {
     const T v2 = milstein_v<T>(w, dt, (T)0.5, METHOD == kMilIto);
     const S g = G(y);
-    const S gdg = (g * v2) * c;        // vjp of y -> c*y + e with cotangent g*v2 (base_sde.py:147-152)
+    const S gdg = m.gdg(y, g, v2);
     return milstein_update<T, S>(y, F(y), g, gdg, w, dt);
   } else if constexpr (METHOD == kMidpoint) {
     const S yp = drift_diffusion_update<T, S>(y, F(y), G(y), w, half_dt, (T)0.5);
@@ -162,6 +163,70 @@ TSDE_D S affine_step(const S y, const A a, const B b, const C c, const E e, cons
     return srid2_final<T, S>(y, f, g, w, u, dt, rdt, sqrt_dt);
   }
 }
+
+// Affine drift and diffusion, f = a*x + b, g = c*x + e; the coefficient types A..E are T or Seed<T, 1..4>.
+template <typename T, typename S, typename A, typename B, typename C, typename E>
+struct AffineModel {
+  A a;
+  B b;
+  C c;
+  E e;
+  TSDE_D S f(const S& x) const { return a * x + b; }
+  TSDE_D S g(const S& x) const { return c * x + e; }
+  TSDE_D S gdg(const S&, const S& gv, T v2) const { return (gv * v2) * c; }   // vjp of y -> c*y + e with cotangent g*v2
+};
+
+template <typename T, int METHOD, typename S, typename A, typename B, typename C, typename E>
+TSDE_D S affine_step(const S y, const A a, const B b, const C c, const E e, const T w, const T u, const T dt,
+                     const T half_dt, const T rdt, const T sqrt_dt) {
+  const AffineModel<T, S, A, B, C, E> m{a, b, c, e};
+  return scheme_step<T, METHOD, S>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
+}
+
+// ---- elementwise expressions ------------------------------------------------------------------------------------------
+// f = fa * phi_f(fp * x + fq) + fb and g = ga * phi_g(gp * x + gq) + gb per channel, phi from a fixed set
+// (closed_form.py: ElementwiseDiagonalSDE). The function codes are uniform over the launch (scalar branches). The
+// evaluation mirrors what torch computes for the module's f / g on the stepwise path, operation by operation
+// (`scale * phi(rate * y + shift) + offset`; sigmoid as 1 / (1 + exp(-u)), softplus with torch's threshold 20).
+template <typename T>
+TSDE_D T expr_phi(int kind, T u) {
+  switch (kind) {
+    case TSDE_FN_EXP: return exp(u);
+    case TSDE_FN_SIGMOID: return (T)1 / ((T)1 + exp(-u));
+    case TSDE_FN_TANH: return tanh(u);
+    case TSDE_FN_SOFTPLUS: return u > (T)20 ? u : log1p(exp(u));
+    case TSDE_FN_SIN: return sin(u);
+    case TSDE_FN_COS: return cos(u);
+    default: return u;
+  }
+}
+
+// phi'(u), given phi(u) = v where that is cheaper
+template <typename T>
+TSDE_D T expr_dphi(int kind, T u, T v) {
+  switch (kind) {
+    case TSDE_FN_EXP: return v;
+    case TSDE_FN_SIGMOID: return v * ((T)1 - v);
+    case TSDE_FN_TANH: return (T)1 - v * v;
+    case TSDE_FN_SOFTPLUS: return u > (T)20 ? (T)1 : (T)1 / ((T)1 + exp(-u));
+    case TSDE_FN_SIN: return cos(u);
+    case TSDE_FN_COS: return -sin(u);
+    default: return (T)1;
+  }
+}
+
+template <typename T>
+struct ExprModel {
+  T fa, fp, fq, fb, ga, gp, gq, gb;
+  int fk, gk;
+  TSDE_D T f(const T& x) const { return fa * expr_phi<T>(fk, fp * x + fq) + fb; }
+  TSDE_D T g(const T& x) const { return ga * expr_phi<T>(gk, gp * x + gq) + gb; }
+  // (g v) g'(x), the chain rule in the order autograd walks scale * phi(rate * x + shift) + offset backwards
+  TSDE_D T gdg(const T& x, const T& gv, T v2) const {
+    const T u = gp * x + gq;
+    return (((gv * v2) * ga) * expr_dphi<T>(gk, u, expr_phi<T>(gk, u))) * gp;
+  }
+};
 
 template <typename T>
 TSDE_D T primal(const T& x) { return x; }
@@ -308,6 +373,142 @@ hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, i
     default: return hipErrorInvalidValue;
   }
 }
+
+template <typename T>
+struct ExprArgs {
+  T* ys;                    // (n_out, n) outputs after t0
+  const T* y0;              // (n)
+  const T* coef[8];         // (d) each: drift scale, rate, shift, offset; diffusion scale, rate, shift, offset
+  int32_t f_kind, g_kind;
+  const T* rows;
+  const uint32_t* cells;
+  const int32_t* out_step;
+  const T* out_w;
+  int64_t n, d;
+  int32_t n_steps, n_out;
+  NoiseKey key;
+  const uint64_t* key_dev;
+};
+
+// The affine trajectory kernel's loop with the expression model in place of the affine one (values only).
+template <typename T, int METHOD, int W>
+__global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<T> p) {
+  constexpr bool kNeedU = METHOD == kSrk;
+  const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = lane * W;
+  if (i >= p.n) return;
+  const int64_t col = i % p.d;
+  Pack<T, W> cf[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cf[c] = load<T, W>(p.coef[c], col);
+  const Pack<T, W> y_init = load<T, W>(p.y0, i);
+  T y[W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) y[q] = y_init.v[q];
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+  const uint64_t elem = key.elem0 + (uint64_t)i;
+  int j = 0;
+  for (int k = 0; k < p.n_steps; ++k) {
+    const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
+    const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
+    const uint32_t cell = p.cells[k];
+    Pack<T, W> w, u;
+    if constexpr (W == 4) {
+      T z[4];
+      normal4<T>(key, elem >> 2, cell, 0, kStreamW, z);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w.v[q] = z[q] * sw;
+      if constexpr (kNeedU) {
+        normal4<T>(key, elem >> 2, cell, 0, kStreamH, z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.v[q] = th * ((T)0.5 * w.v[q] + z[q] * sh);
+      }
+    } else {
+      w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
+      if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+    }
+    T y1[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const ExprModel<T> m{cf[0].v[q], cf[1].v[q], cf[2].v[q], cf[3].v[q], cf[4].v[q], cf[5].v[q],
+                           cf[6].v[q], cf[7].v[q], p.f_kind,  p.g_kind};
+      y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+    }
+    while (j < p.n_out && p.out_step[j] == k + 1) {
+      const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+      const bool exact = (w0 == (T)0 && w1 == (T)1);
+      Pack<T, W> ov;
+#pragma unroll
+      for (int q = 0; q < W; ++q) ov.v[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
+      store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
+      ++j;
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) y[q] = y1[q];
+  }
+}
+
+template <typename T, int METHOD>
+static hipError_t launch_expr_m(const ExprArgs<T>& p, bool vec, hipStream_t s) {
+  if (vec) {
+    const int64_t lanes = p.n >> 2;
+    hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 4>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 1>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8],
+                                       int f_kind, int g_kind, int method, const tsde_traj_t* tr, NoiseKey key,
+                                       const uint64_t* key_dev, hipStream_t s) {
+  ExprArgs<T> p;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  bool aligned = aligned16(ys) && aligned16(y0);
+  for (int c = 0; c < 8; ++c) {
+    p.coef[c] = (const T*)coef[c];
+    aligned = aligned && aligned16(coef[c]);
+  }
+  p.f_kind = f_kind;
+  p.g_kind = g_kind;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
+  const bool can_vec = (d % 4 == 0) && (key.elem0 % 4 == 0) && aligned && ((p.n * sizeof(T)) % 16 == 0);
+  const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
+  switch (method) {
+    case kEuler: return launch_expr_m<T, kEuler>(p, vec, s);
+    case kMilIto: return launch_expr_m<T, kMilIto>(p, vec, s);
+    case kMilStrat: return launch_expr_m<T, kMilStrat>(p, vec, s);
+    case kMidpoint: return launch_expr_m<T, kMidpoint>(p, vec, s);
+    case kSrk: return launch_expr_m<T, kSrk>(p, vec, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t launch_trajectory_expr_diag<float>(void*, const void*, int64_t, int64_t, const void* const[8], int,
+                                                       int, int, const tsde_traj_t*, NoiseKey, const uint64_t*,
+                                                       hipStream_t);
+template hipError_t launch_trajectory_expr_diag<double>(void*, const void*, int64_t, int64_t, const void* const[8], int,
+                                                        int, int, const tsde_traj_t*, NoiseKey, const uint64_t*,
+                                                        hipStream_t);
 
 template hipError_t launch_trajectory_affine_diag<float>(void*, void*, const void*, int64_t, int64_t, const void*,
                                                          const void*, const void*, const void*, int,

@@ -570,6 +570,27 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
     return ys
 
 
+def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
+    """All steps of a diagonal SDE with elementwise-expression drift and diffusion in one launch
+    (``tsde_trajectory_expr_diag``); writes ys[j] for the schedule's outputs."""
+    _native.require_device(ys, y0, *coefs)
+    rows, d = y0.shape
+    if len(coefs) != 8 or any(c.dtype != y0.dtype or c.numel() != d or not c.is_contiguous() for c in coefs):
+        raise ValueError("coefficients must be eight contiguous (d,) tensors in the state dtype")
+    if schedule.dtype != y0.dtype or ys.dtype != y0.dtype:
+        raise ValueError("schedule / output dtype must equal the state dtype")
+    if not (ys.is_contiguous() and y0.is_contiguous()) or ys.shape != (schedule.n_out, rows, d):
+        raise ValueError("ys must be a contiguous (n_out, rows, d) tensor and y0 contiguous")
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    arr = (ctypes.c_void_p * 8)(*[c.data_ptr() for c in coefs])
+    code = lib.tsde_trajectory_expr_diag(ys.data_ptr(), y0.data_ptr(), rows, d, arr, int(f_kind), int(g_kind),
+                                         int(method), schedule.struct(), bm._key, bm._elem0,
+                                         None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    _native.check(code, "tsde_trajectory_expr_diag")
+    return ys
+
+
 def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, diffusion, method, schedule, bm):
     """All steps of a diagonal SDE with a two-layer perceptron drift in one launch (``tsde_trajectory_mlp_diag``);
     writes ys[j] for the schedule's outputs, which must all sit on step boundaries."""

@@ -343,6 +343,9 @@ class BaseSDESolver:
                     return None
                 return ("mlp_differentiable", spec[-2], spec[-1]) + tuple(own)
             return spec
+        if spec[0] == "elementwise_diagonal":
+            # values only: with autograd on, torch differentiates the module's own f, g on the stepwise path
+            return None if self._tracks_grad(y0) else spec
         if spec[0] != "affine_diagonal":
             return None
         if self._tracks_grad(y0):
@@ -396,6 +399,13 @@ class BaseSDESolver:
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
             ys[0].copy_(y0c)
             K.trajectory_mlp_diag(ys[1:], y0c, *coefficients[1:], self._trajectory_code(), schedule, bm)
+            return ys
+        if coefficients[0] == "elementwise_diagonal":
+            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            K.trajectory_expr_diag(ys[1:], y0c, coefficients[1], coefficients[2], coefficients[3:],
+                                   self._trajectory_code(), schedule, bm)
             return ys
         if coefficients[0] == "differentiable":
             return K.trajectory_affine_diag_differentiable(y0, coefficients[1:], self._trajectory_code(), schedule, bm)

@@ -45,6 +45,12 @@ WORKLOADS = {
     "c2_euler_closed_form_b65536_d64_s1000": dict(
         problem="gbm_closed_form", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, euler> (trajectory_kernel)"),
+    # ... and the reference's benchmark SDE (c2_euler_expdiff above) stated as an elementwise-expression module
+    # (torchsde_amd.ElementwiseDiagonalSDE): the whole solve is one launch of tsde_trajectory_expr_diag
+    "c2_euler_expdiff_closed_form_b65536_d64_s1000": dict(
+        problem="exp_diffusion_closed_form", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000,
+        dt=2.0 ** -13, kid=8, trajectory=True,
+        kernel="tsde_trajectory_expr_diag<float, euler> (trajectory_expr_kernel: f = y, g = exp(-y) in the kernel)"),
     "c2_milstein_closed_form": dict(
         problem="gbm_closed_form", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         kid=8, trajectory=True, kernel="tsde_trajectory_affine_diag<float, milstein> (trajectory_kernel)"),
@@ -95,6 +101,10 @@ def make_problem(name, d, m, dev):
         return problems.LatentDiag(d).to(dev)
     if name == "exp_diffusion":    # the reference's own benchmark SDE (benchmarks/brownian.py:131-139): f = y, g = exp(-y)
         return problems.ExpDiffusion().to(dev)
+    if name == "exp_diffusion_closed_form":
+        import torchsde_amd
+        return torchsde_amd.ElementwiseDiagonalSDE("identity", "exp", (1.0, 1.0, 0.0, 0.0), (1.0, -1.0, 0.0, 0.0),
+                                                   dtype=torch.float32).to(dev)
     if name == "latent_diag_closed_form":
         # the SAME SDE as "latent_diag" (same parameter values), stated as the closed-form module the trajectory kernels
         # take: drift Linear-Softplus-Linear, diffusion 0.1 * sigmoid(w * y + b)
