@@ -112,3 +112,34 @@ def test_oracle_matches_reference_on_the_counter_path_affine(name):
     torch.testing.assert_close(y0.grad, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
     for pname, p in sde.named_parameters():
         torch.testing.assert_close(p.grad, torch.tensor(z["grad__" + pname]), rtol=1e-10, atol=1e-12)
+
+
+def _expr_cases():
+    import os
+    return sorted(f[len("closed_form_expr_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("closed_form_expr_"))
+
+
+@pytest.mark.parametrize("name", _expr_cases())
+def test_oracle_matches_reference_on_the_counter_path_expressions(name):
+    """Same chain for the elementwise-expression module (three cases: the SDE of the reference's own benchmark)."""
+    import numpy as np
+
+    import torchsde_amd
+    from oracle import counter
+    z = helpers.load(f"closed_form_expr_{name}.npz")
+    B, d, steps = (int(v) for v in z["shape"])
+    dt, levy = float(z["dt"]), str(z["levy"])
+    coefs = [torch.tensor(z["param__" + n]) for n in torchsde_amd.ElementwiseDiagonalSDE._NAMES]
+    sde = torchsde_amd.ElementwiseDiagonalSDE(str(z["drift"]), str(z["diffusion"]), coefs[:4], coefs[4:],
+                                              sde_type=str(z["sde_type"]), dtype=torch.float64)
+    edges = np.arange(steps + 1) * dt
+
+    def bm(ta, tb, return_U=False):
+        W, U, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float64,
+                                have_h=levy != "none")
+        W = torch.from_numpy(W).reshape(B, d)
+        return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+    with torch.no_grad():
+        ys = solvers_ref.integrate(sde, bm, torch.tensor(z["y0"]), torch.tensor(z["ts"]), dt, str(z["method"]), None)
+    torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
