@@ -72,8 +72,10 @@ def test_every_function_and_scheme_against_the_stepwise_path(diffusion, method, 
     for (B, d) in ((8192, 8), (33, 5)):
         gen = torch.Generator().manual_seed(d)
         rnd = lambda lo, hi: lo + (hi - lo) * torch.rand(d, generator=gen)   # noqa: E731
+        # (an exponential diffusion with a steep rate runs away under explicit schemes: keep its argument gentle)
+        steep = 0.4 if "exp" in (drift, diffusion) else 1.0
         sde = torchsde_amd.ElementwiseDiagonalSDE(drift, diffusion, (rnd(-0.5, 0.5), rnd(0.5, 1.2), rnd(-0.2, 0.2), 0.05),
-                                                  (rnd(0.1, 0.4), rnd(-1.0, 1.0), rnd(-0.2, 0.2), 0.05),
+                                                  (rnd(0.1, 0.4), rnd(-steep, steep), rnd(-0.2, 0.2), 0.05),
                                                   sde_type=sde_type).to(DEV)
         y0 = (0.4 * torch.rand(B, d, generator=gen) - 0.2).to(DEV)
         ts = torch.tensor([0.0, 0.1, 0.26, 0.5], device=DEV)

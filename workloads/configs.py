@@ -32,11 +32,12 @@ WORKLOADS = {
         bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
         kernel="tsde_step_diag<float> (two stages per step)"),
     # SURVEY 8d's nonlinear second workload: the SDE the reference's own benchmark integrates (benchmarks/brownian.py:
-    # 131-139), f = y, g = exp(-y), at the headline's shape -- stepwise, f and g are user torch ops. Horizon 1000 * 2^-13:
-    # over a longer one some of the 4M paths run into g = exp(-y) >> 1 and Euler diverges (the reference's benchmark
-    # takes 100 steps of 512 x 256 paths)
+    # 131-139), f = y, g = exp(-y), at the headline's shape -- stepwise, f and g are user torch ops. Horizon 1000 * 2^-16:
+    # the noise amplitude exp(-y) grows as a path moves down, and by 1000 * 2^-14 the lowest of the 4M paths has
+    # run away to -inf under explicit Euler (the reference's benchmark takes 100 steps of at most 512 x 256 paths and
+    # only times them)
     "c2_euler_expdiff_b65536_d64_s1000": dict(
-        problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -13,
+        problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -16,
         bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
         kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
     # The headline dynamics (same mu, sigma, seed addressing: bit-identical final states) handed over as a closed-form
@@ -49,7 +50,7 @@ WORKLOADS = {
     # (torchsde_amd.ElementwiseDiagonalSDE): the whole solve is one launch of tsde_trajectory_expr_diag
     "c2_euler_expdiff_closed_form_b65536_d64_s1000": dict(
         problem="exp_diffusion_closed_form", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000,
-        dt=2.0 ** -13, kid=8, trajectory=True,
+        dt=2.0 ** -16, kid=8, trajectory=True,
         kernel="tsde_trajectory_expr_diag<float, euler> (trajectory_expr_kernel: f = y, g = exp(-y) in the kernel)"),
     "c2_milstein_closed_form": dict(
         problem="gbm_closed_form", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
