@@ -150,3 +150,25 @@ def test_module_is_copyable_after_a_graph_solve():
     with torch.no_grad():
         twin.mu.mul_(2.0)                    # the copy has its own parameters and its own graph
     assert not torch.equal(solve(twin), a) and torch.equal(solve(sde), a)
+
+
+def test_graph_with_drift_and_diffusion_as_parallel_branches_is_bit_identical():
+    """Inside a captured solve f and g are recorded as parallel branches of the HIP graph (sde.py: _f_beside_g); the
+    result is the eager solve's, bit for bit, also over many replays with new seeds, and `overlap_f_g=False` restores
+    the sequential recording."""
+    import torchsde_amd
+    B, d, n, dt = 4096, 64, 64, 2.0 ** -8
+    sde = problems.make("gbm_ito", d=d).to(DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def solve(entropy, **options):
+        bm = torchsde_amd.BrownianInterval(0.0, n * dt, size=(B, d), dtype=torch.float32, device=DEV, entropy=entropy,
+                                           dt=dt)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="midpoint" if sde.sde_type != "ito" else "euler", dt=dt,
+                                       options=options or None)
+    for entropy in (1, 2, 3, 4):
+        eager = solve(entropy)
+        assert torch.equal(solve(entropy, hip_graph=True), eager)
+        assert torch.equal(solve(entropy, hip_graph=True, overlap_f_g=False), eager)

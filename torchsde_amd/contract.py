@@ -199,6 +199,8 @@ def check_contract(sde, y0, ts, bm, method, adaptive, options, names, logqp, bm_
                               device=y0.device, levy_area_approximation=levy, dt=bm_dt, row_offset=bm_row_offset)
 
     options = {} if options is None else options.copy()
+    if not options.get("overlap_f_g", True):
+        sde.overlap_f_g = False     # drift and diffusion recorded in sequence inside a captured graph (sde.py)
 
     if adaptive and method == METHODS.euler and sde.noise_type != NOISE_TYPES.additive:
         warnings.warn("Numerical solution is not guaranteed to converge to the correct solution when using adaptive "

@@ -119,7 +119,36 @@ class ForwardSDE(BaseSDE):
         raise RuntimeError("Method `g` has not been provided, but is required for this method.")
 
     def _f_then_g(self, t, y):
+        if self.overlap_f_g and y.is_cuda and torch.cuda.is_current_stream_capturing():
+            return self._f_beside_g(t, y)
         return self.f(t, y), self.g(t, y)
+
+    # While a solve is being captured into a HIP graph (options={"hip_graph": True}) the user's drift and diffusion are
+    # recorded as two PARALLEL branches of the graph instead of one after the other: both only read (t, y), and each
+    # is a handful of short memory-bound kernels that leave most of the chip idle while they ramp up and drain (the
+    # headline's `mu * y` and `sigma * y`: 7.4 us each, 4.5 TB/s). Fork and join are graph edges -- they cost nothing
+    # at replay. No `record_stream`: g's output is consumed on the main stream before the next fork event, and the
+    # side stream touches memory again only behind that event. `options={"overlap_f_g": False}` records them in
+    # sequence (for drift and diffusion methods that write to shared buffers).
+    overlap_f_g = True
+    _side_streams = {}
+
+    def _f_beside_g(self, t, y):
+        device = y.device
+        main = torch.cuda.current_stream(device)
+        side = ForwardSDE._side_streams.get(device)
+        if side is None:
+            side = ForwardSDE._side_streams[device] = torch.cuda.Stream(device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            g = self.g(t, y)
+        f = self.f(t, y)
+        join = torch.cuda.Event()
+        join.record(side)
+        main.wait_event(join)
+        return f, g
 
     def _g_then_prod(self, t, y, v):
         return self.prod(self.g(t, y), v)
