@@ -458,7 +458,11 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
         with torch.no_grad(), _reparametrize_module(sde, swapped):
             return graph._CapturedBackward(run, bm, inputs, keepalive=(run.plan,))
 
-    return graph.cached_backward(sde, bm, signature, capture)
+    def tuned_capture():       # drift and diffusion in sequence or as parallel graph branches: whichever replays faster
+        from .sde import ForwardSDE
+        return graph.faster_of_sequential_and_parallel(sde if isinstance(sde, ForwardSDE) else None, capture, ys.device)
+
+    return graph.cached_backward(sde, bm, signature, tuned_capture)
 
 
 def _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params):

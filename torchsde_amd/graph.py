@@ -80,6 +80,49 @@ def _remember(cache, sig, captured):
     cache[sig] = captured
 
 
+def _replay_ms(graph, device, repeats=2):
+    """Duration of one replay of a captured graph (best of `repeats`), timed with events on the current stream."""
+    best = float("inf")
+    for _ in range(repeats):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        graph.replay()
+        stop.record()
+        stop.synchronize()
+        best = min(best, start.elapsed_time(stop))
+    return best
+
+
+def faster_of_sequential_and_parallel(forward_sde, capture, device):
+    """Capture a solve (or a backward sweep) twice -- the user's drift and diffusion recorded one after the other, and
+    as parallel branches of the graph (sde.ForwardSDE._f_beside_g) -- replay both, keep the faster one.
+
+    Whether the parallel form pays depends on the user's code: two branches of several kernels each (perceptron drift
+    and diffusion: -18 % on BASELINE configs[2]) overlap their ramp-up and drain, while for one short kernel per branch
+    the graph's fork / join edges cost more than they hide (+30 % on the headline's `mu * y`, `sigma * y`). It is
+    measured once per cached graph, on the first solve with that structure. `capture()` -> an object with `.graph`."""
+    tunable = (forward_sde is not None and getattr(forward_sde, "overlap_f_g", False)
+               and getattr(forward_sde.f_and_g, "__func__", None) is type(forward_sde)._f_then_g)
+    if not tunable:
+        return capture()
+    try:
+        forward_sde.overlap_f_g = False
+        sequential = capture()
+        if sequential is None:
+            return None
+        forward_sde.overlap_f_g = True
+        parallel = capture()
+    finally:
+        forward_sde.overlap_f_g = True
+    if parallel is None:
+        return sequential
+    t_seq, t_par = _replay_ms(sequential.graph, device), _replay_ms(parallel.graph, device)
+    keep, drop = (parallel, sequential) if t_par < t_seq else (sequential, parallel)
+    keep.tuning = {"sequential_ms": t_seq, "parallel_ms": t_par, "kept": "parallel" if keep is parallel else "sequential"}
+    del drop
+    return keep
+
+
 class _CapturedSolve:
     def __init__(self, solver, y0, ts, extra0=()):
         bm = solver.bm
@@ -175,7 +218,8 @@ def replay_or_capture(solver, y0, ts, extra0=()):
     sig = _signature(solver, y0, ts_host)
     captured = cache.get(sig)
     if captured is None:
-        captured = _CapturedSolve(solver, y0, ts, extra0)
+        captured = faster_of_sequential_and_parallel(solver.sde if hasattr(solver.sde, "_f_then_g") else None,
+                                                     lambda: _CapturedSolve(solver, y0, ts, extra0), y0.device)
         _remember(cache, sig, captured)
         return captured.result()
     return captured.replay(bm, y0, extra0)
@@ -390,7 +434,16 @@ def replay_or_capture_training(solver, y0, ts, extra0, params):
     captured = cache.get(sig)
     if captured is None:
         try:
-            captured = _CapturedTrainingSolve(solver, y0, ts, extra0, params)
+            # (drift and diffusion stay in sequence here: the recorded autograd graph of the forward solve is replayed
+            #  by a second graph, and its stream semantics are those of one stream)
+            parallel_allowed = getattr(solver.sde, "overlap_f_g", False)
+            if parallel_allowed:
+                solver.sde.overlap_f_g = False
+            try:
+                captured = _CapturedTrainingSolve(solver, y0, ts, extra0, params)
+            finally:
+                if parallel_allowed:
+                    solver.sde.overlap_f_g = True
         except _NotCapturable as e:
             warnings.warn(f"hip_graph=True: {e}; running eagerly.")
             return None
