@@ -24,6 +24,8 @@
 // regenerated from the counter RNG; the per-step factors of the weight gradients (dt a, h, delta, y) go to a stash in
 // HBM for tsde_gram_partials (mlp_backward.hip), and the diffusion-parameter sums ride in registers. Memory is O(chunk),
 // independent of the number of steps: nothing of the forward pass is kept but the states at the output times.
+#include <type_traits>
+
 #include "tsde_common.h"
 #include "tsde_launch.h"
 #include "tsde_mlp.h"
@@ -196,39 +198,46 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
     }
 
     // ---- elementwise: dW of the forward cell again, the diffusion terms, the reconstruction of y --------------------
+    // (the diffusion kind is uniform over the launch: ONE branch around the whole phase, not one per element -- with
+    //  the test inside the loops the phase was 70 basic blocks and the register allocator gave up on it)
+    auto elementwise = [&](auto is_sigmoid) {
+      constexpr bool kSigmoid = decltype(is_sigmoid)::value;
 #pragma unroll
-    for (int t = 0; t < TD; ++t) {
-      const int ch = R * t + 4 * part;
-      float zn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      uint64_t quad = quad0 + 4 * t;
-      asm volatile("" : "+v"(quad));          // (keeps the step-invariant first Philox round inside the loop)
-      if (real_d(t)) normal4<float>(key, quad, cell, 0, kStreamW, zn);
-      const f32x4 cq = lds_quad(cs, ch);
-      const f32x4 eq = lds_quad(es, ch);
-      const f32x4 bq = lds_quad(b2s, ch);
+      for (int t = 0; t < TD; ++t) {
+        const int ch = R * t + 4 * part;
+        float zn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint64_t quad = quad0 + 4 * t;
+        asm volatile("" : "+v"(quad));          // (keeps the step-invariant first Philox round inside the loop)
+        if (real_d(t)) normal4<float>(key, quad, cell, 0, kStreamW, zn);
+        const f32x4 cq = lds_quad(cs, ch);
+        const f32x4 eq = lds_quad(es, ch);
+        const f32x4 bq = lds_quad(b2s, ch);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float yt = y[t][r], at = a[t][r], cc = cq[r];
-        const float w = zn[r] * sw;
-        // g, q = dg/de; then dg/dc = q y, g' = q c; for the sigmoid q' := dq/du = q (1 - 2 s): g'' = q' c^2,
-        // dg'/de = q' c, dg'/dc = q' c y + q   (affine: q = 1, q' = 0)
-        const float u = cc * yt + eq[r];
-        float g = u, q = 1.0f, qp = 0.0f;
-        if (sigmoid) {
-          const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
-          g = p.diff_amp * s;
-          q = g * (1.0f - s);
-          qp = q * (1.0f - 2.0f * s);
+        for (int r = 0; r < 4; ++r) {
+          const float yt = y[t][r], at = a[t][r], cc = cq[r];
+          const float w = zn[r] * sw;
+          // g, q = dg/de; then dg/dc = q y, g' = q c; for the sigmoid q' := dq/du = q (1 - 2 s): g'' = q' c^2
+          // (affine: q = 1, q' = 0)
+          const float u = cc * yt + eq[r];
+          float g = u, q = 1.0f, qp = 0.0f;
+          if constexpr (kSigmoid) {
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+            g = p.diff_amp * sg;
+            q = g * (1.0f - sg);
+            qp = q * (1.0f - 2.0f * sg);
+          }
+          const float gp = q * cc;
+          const float drift = (f[t][r] + bq[r]) - ito * (g * gp);           // f~
+          const float aw = at * w;                                            // a dW
+          const float adg = ito * ((at * dt) * g);                           // dt a g   (Ito correction terms)
+          a[t][r] = at + (aw * gp - adg * (qp * (cc * cc)));
+          y[t][r] = (yt - drift * dt) - g * w;
         }
-        const float gp = q * cc;
-        const float drift = (f[t][r] + bq[r]) - ito * (g * gp);           // f~
-        const float aw = at * w;                                            // a dW
-        const float adg = ito * ((at * dt) * g);                           // dt a g   (Ito correction terms)
-        a[t][r] = at + (aw * gp - adg * (qp * (cc * cc)));
-        y[t][r] = (yt - drift * dt) - g * w;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    if (sigmoid) elementwise(std::true_type{});
+    else elementwise(std::false_type{});
 
     // ---- a^T += W1 delta^T (rows of W1s, four consecutive hidden units per lane) --------------------------------------
 #pragma unroll
@@ -303,10 +312,6 @@ __global__ void __launch_bounds__(kBlock) adjoint_diffusion_sums_kernel(const Ml
   }
 }
 
-#ifndef ADJ_NW
-#define ADJ_NW(D, H) (((D) >= 128 || (H) >= 256) ? 4 : 8)
-#endif
-
 template <int D, int H, int ACT, int NW, bool FULL>
 static hipError_t launch_adj_variant(const MlpAdjArgs& p, hipStream_t s) {
   constexpr int R = 16;
@@ -325,12 +330,23 @@ static hipError_t launch_adj_variant(const MlpAdjArgs& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-// y, a, the f accumulators and act'(z) are 3 x D/4 + H/4 live registers per lane (128 at d = hidden = 128).
+// y, a, the f accumulators and act'(z) are 3 x D/4 + H/4 live registers per lane (128 at d = hidden = 128). The large
+// shapes exist as 8-wave blocks (two waves per SIMD, 256 registers: the unpadded 128 x 128 kernel spills 14 dwords) and
+// as 4-wave blocks (one wave per SIMD, up to 512 registers: no spills); TSDE_ADJ_WAVES=4|8 picks one (default: see below).
 template <int D, int H, int ACT>
 static hipError_t launch_adj_shape(const MlpAdjArgs& p, hipStream_t s) {
-  constexpr int NW = ADJ_NW(D, H);
-  if (p.d == D && p.h == H) return launch_adj_variant<D, H, ACT, NW, true>(p, s);
-  return launch_adj_variant<D, H, ACT, NW, false>(p, s);
+  const bool full = p.d == D && p.h == H;
+  if constexpr (D >= 128 || H >= 256) {
+    static const int waves = [] {
+      const char* e = getenv("TSDE_ADJ_WAVES");
+      return e ? atoi(e) : 0;
+    }();
+    const bool eight = waves == 8 || (waves != 4 && full);      // padded shapes: the bounds tests cost registers
+    if (eight) return full ? launch_adj_variant<D, H, ACT, 8, true>(p, s) : launch_adj_variant<D, H, ACT, 8, false>(p, s);
+    return full ? launch_adj_variant<D, H, ACT, 4, true>(p, s) : launch_adj_variant<D, H, ACT, 4, false>(p, s);
+  } else {
+    return full ? launch_adj_variant<D, H, ACT, 8, true>(p, s) : launch_adj_variant<D, H, ACT, 8, false>(p, s);
+  }
 }
 
 template <int D, int H>
