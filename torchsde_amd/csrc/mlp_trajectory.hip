@@ -22,6 +22,8 @@
 //
 // Reference being replaced: the stepping loop torchsde/_core/base_solver.py:114-134 with euler.py:31-36 /
 // milstein.py:52-74 as the step, evaluated for an SDE whose f, g are the torch modules above.
+#include <type_traits>
+
 #include "tsde_common.h"
 #include "tsde_launch.h"
 #include "tsde_schemes.h"
@@ -233,6 +235,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[th][r] = activate<ACT>(h4[r] + bias[r]);
       }
+      // (the diffusion kind is uniform over the launch: one branch around the tile loop, two straight-line copies)
+      auto drift_noise_update = [&](auto is_sigmoid) {
+      constexpr bool kSigmoid = decltype(is_sigmoid)::value;
 #pragma unroll
       for (int t = 0; t < TD; ++t) {
         const int ch = R * t + 4 * part;
@@ -263,7 +268,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
           const float yy = y[t][s];
           const float f = acc[s] + b2q[s];
           const float cc = cq[s];
-          const DiffusionValue dv = diffusion_value(false, 0.0f, cc, eq[s], yy);     // affine only on this path
+          const DiffusionValue dv = diffusion_value(kSigmoid, p.diff_amp, cc, eq[s], yy);
           const float g = dv.g;
           const float w = z[s] * sw;
           float yn;
@@ -279,6 +284,9 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
         if (due) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
         __builtin_amdgcn_sched_barrier(0);
       }
+      };
+      if (sigmoid_diffusion) drift_noise_update(std::true_type{});
+      else drift_noise_update(std::false_type{});
     } else if constexpr (!MID) {
       // one stage; in place: tile t of the state is only read by its own update
       hidden_layer(y);
@@ -408,7 +416,7 @@ static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
           const char* e = getenv("TSDE_MLP_INTERLEAVE");
           return e == nullptr || atoi(e) != 0;
         }();
-        if (interleave && p.diff_kind == TSDE_DIFF_AFFINE) return launch_mlp_full<D, H, ACT, R, NW, MID, true, true>(p, s);
+        if (interleave) return launch_mlp_full<D, H, ACT, R, NW, MID, true, true>(p, s);
       }
       return launch_mlp_full<D, H, ACT, R, NW, MID, true>(p, s);
     }
