@@ -22,6 +22,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _few_cpu_threads():
+    """The oracle integrates 64-256 rows: torch's CPU ops on such sizes are several times SLOWER with the hundreds of
+    threads of the GPU box's host than with 8."""
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    yield
+    torch.set_num_threads(before)
+
+
 def _edges(n, dt):
     return np.arange(n + 1) * dt
 
