@@ -300,6 +300,48 @@ def gen_adjoint():
         print(f"adjoint_{name}.npz  queries={len(keys)}  |grad_y0|={np.abs(out['f32__grad_y0']).sum():.4f}")
 
 
+# second derivatives through sdeint_adjoint: the reference nests a second adjoint solve (adjoint.py:97-112)
+DOUBLE_BACKWARD_CASES = [
+    # name, problem, method, adjoint_method, (B, d, m), ts, dt
+    # (for an Ito SDE the reference's nested solve stops with "Adjoint `f_and_g` not defined": the corrected drift of
+    # the adjoint of the adjoint asks for it, adjoint_sde.py:308,318 -> :271; only Stratonovich SDEs get through)
+    ("gbm_strat_midpoint", "gbm_strat", "midpoint", None, (5, 4, 4), [0., 0.25, 0.5], 2.0 ** -7),
+    ("mlpdiag_strat_midpoint", "mlpdiag_strat", "midpoint", None, (5, 4, 4), [0., 0.5], 2.0 ** -7),
+    ("general_strat_heun", "general_strat", "heun", "heun", (6, 4, 4), [0., 0.5], 2.0 ** -7),
+    ("scalar_strat_euler_heun", "scalar_strat", "midpoint", "euler_heun", (5, 4, 1), [0., 0.5], 2.0 ** -7),
+]
+
+
+def gen_double_backward():
+    dtype = torch.float64
+    for name, prob, method, adjoint_method, (B, d, m), ts, dt in DOUBLE_BACKWARD_CASES:
+        sde = problems.make(prob, dtype=dtype, d=d, m=m)
+        params = list(sde.parameters())
+        y0 = torch.full((B, d), 0.1, dtype=dtype, requires_grad=True)
+        tst = torch.tensor(ts, dtype=dtype)
+        bm = ReplayBM((B, m), dtype, seed=sum(map(ord, name)), levy="none")
+        ys = torchsde.sdeint_adjoint(sde, y0, tst, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt)
+        rng = np.random.default_rng(11)
+        wt = torch.tensor(rng.standard_normal(tuple(ys.shape)), dtype=dtype)
+        loss = (ys ** 2 * wt).sum()
+        first = torch.autograd.grad(loss, [y0] + params, create_graph=True, allow_unused=True)
+        mix = [torch.tensor(rng.standard_normal(tuple(x.shape)), dtype=dtype) for x in [y0] + params]
+        phi = sum((g * w).sum() for g, w in zip(first, mix) if g is not None)
+        second = torch.autograd.grad(phi, [y0] + params, allow_unused=True)
+        keys, W, U = bm.dump()
+        out = {"problem": prob, "method": method, "adjoint_method": adjoint_method or "", "levy": "none",
+               "dt": np.float64(dt), "grad_free": False, "shape": np.array([B, d, m]),
+               "f64__ts": tst.numpy(), "f64__queries": keys, "f64__W": W, "f64__U": U, "f64__ys": ys.detach().numpy(),
+               "f64__loss_weights": wt.numpy(), "f64__param_checksum": np.float64(param_checksum(sde))}
+        for j, (g, w, h, x) in enumerate(zip(first, mix, second, [y0] + params)):
+            out[f"f64__first{j}"] = (torch.zeros_like(x) if g is None else g.detach()).numpy()
+            out[f"f64__mix{j}"] = w.numpy()
+            out[f"f64__second{j}"] = (torch.zeros_like(x) if h is None else h).numpy()
+        np.savez_compressed(os.path.join(HERE, f"double_backward_{name}.npz"), **out)
+        print(f"double_backward_{name}.npz  queries={len(keys)}  |second|="
+              f"{sum(float(np.abs(out[f'f64__second{j}']).sum()) for j in range(len(first))):.4f}")
+
+
 # --------------------------------------------------------------------------------------------------- bridge
 def gen_bridge():
     """Record what the reference's bridge code does with known normals, and multi-interval merges."""
@@ -686,7 +728,7 @@ def gen_closed_form_expr():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
-                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr"]
+                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr", "double_backward"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

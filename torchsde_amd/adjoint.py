@@ -394,11 +394,25 @@ class _SdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_ys, *grad_extra_solver_state):
-        if torch.is_grad_enabled():
-            raise NotImplementedError("torchsde_amd: double backward through sdeint_adjoint is not supported.")
         from . import _native
         with _native.on_device_of(grad_ys):
+            if torch.is_grad_enabled():      # create_graph=True: a differentiable statement of the same sweep
+                return _SdeintAdjointMethod._backward_with_graph(ctx, grad_ys)
             return _SdeintAdjointMethod._backward(ctx, grad_ys, *grad_extra_solver_state)
+
+    @staticmethod
+    def _backward_with_graph(ctx, grad_ys):
+        """Second derivatives (reference: the nested apply of adjoint.py:97-112); see adjoint_double.py."""
+        from . import adjoint_double
+        if ctx.saved_extras_for_backward or ctx.adjoint_adaptive[0]:
+            raise NotImplementedError("torchsde_amd: double backward is available for the fixed-step adjoint methods "
+                                      f"{adjoint_double.SUPPORTED} only.")
+        ys, ts, *adjoint_params = ctx.saved_tensors
+        kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
+        native = ctx.bm if isinstance(ctx.bm, BrownianInterval) else None
+        plan = _plan_backward(timegrid.ts_to_host(ts), ctx.dt, native, ys.device)
+        a_y, a_theta = adjoint_double.run(AdjointSDE(ctx.sde, adjoint_params), kind, ctx.bm, plan, ys, grad_ys)
+        return (None,) * 13 + (a_y,) + (None,) * ctx.len_extras + tuple(a_theta)
 
     @staticmethod
     def _backward(ctx, grad_ys, *grad_extra_solver_state):

@@ -67,11 +67,13 @@ class _MlpAdjointFn(torch.autograd.Function):
         ctx.activation, ctx.diffusion, ctx.ito = int(activation), (int(diffusion[0]), float(diffusion[1])), bool(ito)
         ctx.schedule, ctx.bm, ctx.out_steps = backward_schedule, bm, tuple(out_steps)
         ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
+        ctx.generic = None
         return ys
 
     @staticmethod
-    @torch.autograd.function.once_differentiable      # kernels, not torch ops: no graph of the backward pass exists
     def backward(ctx, gys):
+        if torch.is_grad_enabled():    # create_graph=True: the kernels below leave no graph; see adjoint_double.py
+            return _MlpAdjointFn._backward_with_graph(ctx, gys)
         ys, w1_in, b1c, w2_in, b2c, rate, shift = ctx.saved_tensors
         rows, d = ys.shape[1], ys.shape[2]
         hidden = b1c.numel()
@@ -116,6 +118,22 @@ class _MlpAdjointFn(torch.autograd.Function):
                              else per_channel.sum().reshape(shape))
         grad_y0 = a if ctx.needs_input_grad[8] else None
         return (None,) * 8 + (grad_y0, g_w1, g_b1, g_w2, g_b2, diffusion[0], diffusion[1])
+
+
+    @staticmethod
+    def _backward_with_graph(ctx, gys):
+        from . import adjoint, adjoint_double
+        if ctx.generic is None:
+            raise NotImplementedError("torchsde_amd: no differentiable backward pass was prepared for this call.")
+        sde, ts_host, dt, own = ctx.generic
+        ys = ctx.saved_tensors[0]
+        params = [p for p in own if p.requires_grad]
+        with _native.on_device_of(ys):
+            plan = adjoint._plan_backward(ts_host, dt, ctx.bm, ys.device)
+            a_y, a_theta = adjoint_double.run(adjoint.AdjointSDE(sde, params), "euler", ctx.bm, plan, ys, gys)
+        a_theta = iter(a_theta)
+        grads = [next(a_theta) if p.requires_grad else None for p in own]
+        return (None,) * 8 + (a_y if ctx.needs_input_grad[8] else None, *grads)
 
 
 def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, options, adjoint_options,
@@ -190,5 +208,8 @@ def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptiv
                                            y0.dtype)
     backward_schedule = K.TrajectorySchedule.cached(rows_for(backward_dt), cells, out_steps,
                                                     [(0.0, 1.0)] * len(out_steps), y0.device, y0.dtype)
-    return _MlpAdjointFn.apply(spec[-2], tuple(spec[-1]), code, sde.sde_type == SDE_TYPES.ito, schedule,
-                               backward_schedule, tuple(int(k) for k in out_steps), bm, y0, *own)
+    ys = _MlpAdjointFn.apply(spec[-2], tuple(spec[-1]), code, sde.sde_type == SDE_TYPES.ito, schedule,
+                             backward_schedule, tuple(int(k) for k in out_steps), bm, y0, *own)
+    if ys.grad_fn is not None:           # what a second-order backward pass needs (`ys.grad_fn` is the Function's ctx)
+        ys.grad_fn.generic = (sde, ts_host, dt, own)
+    return ys
