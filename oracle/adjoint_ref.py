@@ -164,8 +164,11 @@ def default_adjoint_method(sde, method):
     return "milstein" if sde.noise_type == "diagonal" else "euler"
 
 
-def adjoint_gradients(sde, y0, ts, bm, dt, method, adjoint_method, loss_weights, options=None):
-    """Forward solve + the reference's backward pass. Returns (ys, dL/dy0, [dL/dtheta]) for L = sum(ys * w)."""
+def adjoint_gradients(sde, y0, ts, bm, dt, method, adjoint_method, loss_weights, options=None, adjoint_adaptive=False,
+                      adjoint_rtol=1e-5, adjoint_atol=1e-4, dt_min=1e-5, record=None):
+    """Forward solve + the reference's backward pass. Returns (ys, dL/dy0, [dL/dtheta]) for L = sum(ys * w).
+    `adjoint_adaptive`: the step-doubling branch of base_solver.py:117-142 on the flat augmented state, one
+    integrate() call -- hence a restart from `dt` -- per output interval (adjoint.py:97-112)."""
     params = [p for p in sde.parameters() if p.requires_grad]
     adjoint_method = adjoint_method or default_adjoint_method(sde, method)
     with torch.no_grad():
@@ -183,13 +186,116 @@ def adjoint_gradients(sde, y0, ts, bm, dt, method, adjoint_method, loss_weights,
     for i in range(T - 1, 0, -1):
         t_lo, t_hi = -ts[i], -ts[i - 1]
         curr_t = t_lo
-        while curr_t < t_hi:                        # base_solver.py:114-116 on [-ts[i], -ts[i-1]]
-            next_t = min(curr_t + dt, t_hi)
-            aug = _aug_step(adj, adjoint_method, reverse_bm, curr_t, next_t, aug).detach()
-            curr_t = next_t
+        step_size, prev_error_ratio = dt, None
+        while curr_t < t_hi:                        # base_solver.py:114-142 on [-ts[i], -ts[i-1]]
+            next_t = min(curr_t + step_size, t_hi)
+            if record is not None:
+                record.append((float(curr_t), float(next_t)))
+            if not adjoint_adaptive:
+                aug = _aug_step(adj, adjoint_method, reverse_bm, curr_t, next_t, aug).detach()
+                curr_t = next_t
+                continue
+            full = _aug_step(adj, adjoint_method, reverse_bm, curr_t, next_t, aug).detach()
+            mid_t = 0.5 * (curr_t + next_t)
+            half = _aug_step(adj, adjoint_method, reverse_bm, curr_t, mid_t, aug).detach()
+            two = _aug_step(adj, adjoint_method, reverse_bm, mid_t, next_t, half).detach()
+            error_estimate = solvers_ref._compute_error(full, two, adjoint_rtol, adjoint_atol)
+            step_size, prev_error_ratio = solvers_ref._update_step_size(error_estimate, step_size,
+                                                                        prev_error_ratio=prev_error_ratio)
+            if step_size < dt_min:
+                step_size, prev_error_ratio = dt_min, None
+            if error_estimate <= 1 or step_size <= dt_min:
+                curr_t, aug = next_t, two
         parts = _flat_to_shape(aug.squeeze(0), shapes)
         parts[0] = ys[i - 1]
         parts[1] = parts[1] + grad_ys[i - 1]
         aug = _flatten(parts).unsqueeze(0)
     parts = _flat_to_shape(aug.squeeze(0), shapes)
     return ys, parts[1], parts[2:]
+
+
+# ---- the reversible-Heun pair (method="reversible_heun", adjoint_method="adjoint_reversible_heun") -----------------
+def _rheun_adjoint_step(sde, params, bm, t0, t1, state):
+    """methods/reversible_heun.py:98-144 on the unflattened state
+    (y, a_y, a_f, a_g, a_z, [a_theta]) + carried (f, g, z); `bm` is the time-reversed Brownian motion."""
+    (y0, a_y0, a_f0, a_g0, a_z0, a_theta), (f0, g0, z0) = state
+    diagonal = sde.noise_type == "diagonal"
+
+    def adjoint_of_prod(a, v):                                             # :85-88
+        return a * v if diagonal else a.unsqueeze(-1) * v.unsqueeze(-2)
+
+    dt = t1 - t0
+    dW = bm(t0, t1)
+    half_dt, half_dW = 0.5 * dt, 0.5 * dW
+    a_y0_half_dt = a_y0 * half_dt
+    a_y0_half_dW = adjoint_of_prod(a_y0, half_dW)
+    z1 = 2 * y0 - z0 - f0 * dt - solvers_ref.prod(sde, g0, dW)
+    a_f1, a_g1 = a_y0_half_dt, a_y0_half_dW
+    a_f0 = a_f0 + a_y0_half_dt
+    a_g0 = a_g0 + a_y0_half_dW
+    z_leaf = z0.detach().requires_grad_(True)
+    with torch.enable_grad():
+        re_f, re_g = solvers_ref.f_and_g(sde, -t0, z_leaf)
+        vjp_z, *vjp_theta = _vjp((re_f, re_g), [z_leaf] + list(params), grad_outputs=[a_f0, a_g0])
+    a_z0 = a_z0 + vjp_z
+    a_theta = [p + q for p, q in zip(a_theta, vjp_theta)]
+    with torch.no_grad():
+        f1, g1 = solvers_ref.f_and_g(sde, -t1, z1)
+    y1 = y0 - (f0 + f1) * half_dt - solvers_ref.prod(sde, g0 + g1, half_dW)
+    a_y1 = a_y0 + 2 * a_z0
+    a_z1 = -a_z0
+    a_f1 = a_f1 + a_z0 * dt
+    a_g1 = a_g1 + adjoint_of_prod(a_z0, dW)
+    return (y1.detach(), a_y1.detach(), a_f1.detach(), a_g1.detach(), a_z1.detach(),
+            [p.detach() for p in a_theta]), (f1.detach(), g1.detach(), z1.detach())
+
+
+def reversible_heun_adjoint_gradients(sde, y0, ts, bm, dt, loss_weights, adjoint_adaptive=False, adjoint_rtol=1e-5,
+                                      adjoint_atol=1e-4, dt_min=1e-5):
+    """Forward reversible-Heun solve + its algebraically reversed backward pass (adjoint.py:64-127 driving
+    methods/reversible_heun.py:76-144). Returns (ys, dL/dy0, [dL/dtheta]) for L = sum(ys * w). With
+    `adjoint_adaptive` the step goes through the generic step-doubling loop (base_solver.py:117-142), the error
+    norm over the flat (y, a_y, a_f, a_g, a_z, a_theta), restarted from `dt` on every output interval."""
+    params = [p for p in sde.parameters() if p.requires_grad]
+    with torch.no_grad():
+        ys, (f, g, z) = solvers_ref.integrate_reversible_heun(sde, bm, y0.detach(), ts, dt)
+    grad_ys = loss_weights
+
+    def reverse_bm(ta, tb, return_U=False):
+        return bm(-tb, -ta, return_U=return_U)
+
+    def flat(head):
+        return _flatten(list(head[:5]) + list(head[5])).unsqueeze(0)
+
+    head = (ys[-1], grad_ys[-1], torch.zeros_like(f), torch.zeros_like(g), torch.zeros_like(z),
+            [torch.zeros_like(p) for p in params])
+    extra = (f, g, z)
+    for i in range(ys.size(0) - 1, 0, -1):
+        curr_t, t_hi = -ts[i], -ts[i - 1]
+        step_size, prev_error_ratio = dt, None
+        while curr_t < t_hi:
+            next_t = min(curr_t + step_size, t_hi)
+            if not adjoint_adaptive:
+                head, extra = _rheun_adjoint_step(sde, params, reverse_bm, curr_t, next_t, (head, extra))
+                curr_t = next_t
+                continue
+            full, _ = _rheun_adjoint_step(sde, params, reverse_bm, curr_t, next_t, (head, extra))
+            mid_t = 0.5 * (curr_t + next_t)
+            half = _rheun_adjoint_step(sde, params, reverse_bm, curr_t, mid_t, (head, extra))
+            two, two_extra = _rheun_adjoint_step(sde, params, reverse_bm, mid_t, next_t, half)
+            error_estimate = solvers_ref._compute_error(flat(full), flat(two), adjoint_rtol, adjoint_atol)
+            step_size, prev_error_ratio = solvers_ref._update_step_size(error_estimate, step_size,
+                                                                        prev_error_ratio=prev_error_ratio)
+            if step_size < dt_min:
+                step_size, prev_error_ratio = dt_min, None
+            if error_estimate <= 1 or step_size <= dt_min:
+                curr_t, head, extra = next_t, two, two_extra
+        head = (ys[i - 1], head[1] + grad_ys[i - 1]) + tuple(head[2:])              # adjoint.py:114-116
+    # the solver's initial (f, g, z) = (f(t0, y0), g(t0, y0), y0) are computed OUTSIDE the autograd Function
+    # (adjoint.py:262-264 -> reversible_heun.py:58-59), so their cotangents reach y0 and theta by plain autograd
+    _, a_y, a_f, a_g, a_z, a_theta = head
+    y_leaf = y0.detach().requires_grad_(True)
+    with torch.enable_grad():
+        f0, g0 = solvers_ref.f_and_g(sde, ts[0], y_leaf)
+        vjp_y, *vjp_theta = _vjp((f0, g0), [y_leaf] + params, grad_outputs=[a_f, a_g])
+    return ys, a_y + a_z + vjp_y, [p + q for p, q in zip(a_theta, vjp_theta)]

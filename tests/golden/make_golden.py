@@ -300,6 +300,54 @@ def gen_adjoint():
         print(f"adjoint_{name}.npz  queries={len(keys)}  |grad_y0|={np.abs(out['f32__grad_y0']).sum():.4f}")
 
 
+# adjoint_adaptive=True: step doubling on the flat augmented state, restarted from `dt` on every output interval
+# (adjoint.py:83-112 builds one solver and calls its integrate() per interval; base_solver.py:105,117-142)
+ADJOINT_ADAPTIVE_CASES = [
+    # name, problem, method, adjoint_method, (B, d, m), ts, dt, adjoint_rtol, adjoint_atol
+    # (tolerances chosen so that attempts are both accepted and rejected without the whole sweep sitting on dt_min)
+    ("gbm_ito_euler", "gbm_ito", "euler", "euler", (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -3, 1e-1, 1e-2),
+    ("mlpdiag_ito_milstein", "mlpdiag_ito", "milstein", None, (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -3, 3e-2, 3e-3),
+    ("gbm_strat_midpoint", "gbm_strat", "midpoint", None, (5, 4, 4), [0., 0.25, 1.0], 2.0 ** -3, 1e-1, 1e-2),
+    ("general_strat_heun", "general_strat", "midpoint", "heun", (6, 4, 4), [0., 1.0], 2.0 ** -3, 1.0, 1e-1),
+    ("mlpdiag_strat_rheun", "mlpdiag_strat", "reversible_heun", None, (5, 4, 4), [0., 0.5, 1.0], 2.0 ** -3, 1e-1,
+     1e-2),
+    ("general_strat_rheun", "general_strat", "reversible_heun", None, (6, 4, 4), [0., 1.0], 2.0 ** -3, 1.0, 1e-1),
+]
+ADJOINT_ADAPTIVE_DT_MIN = 2.0 ** -9
+
+
+def gen_adjoint_adaptive():
+    import warnings
+    dtype = torch.float64
+    for name, prob, method, adjoint_method, (B, d, m), ts, dt, rtol, atol in ADJOINT_ADAPTIVE_CASES:
+        sde = problems.make(prob, dtype=dtype, d=d, m=m)
+        y0 = torch.full((B, d), 0.1, dtype=dtype, requires_grad=True)
+        tst = torch.tensor(ts, dtype=dtype)
+        bm = ReplayBM((B, m), dtype, seed=sum(map(ord, name)), levy="none")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ys = torchsde.sdeint_adjoint(sde, y0, tst, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt,
+                                         adjoint_adaptive=True, adjoint_rtol=rtol, adjoint_atol=atol,
+                                         dt_min=ADJOINT_ADAPTIVE_DT_MIN)
+            wt = torch.tensor(np.random.default_rng(5).standard_normal(tuple(ys.shape)), dtype=dtype)
+            forward_queries = len(bm.order)
+            (ys * wt).sum().backward()
+        keys, W, U = bm.dump()
+        out = {"problem": prob, "method": method, "adjoint_method": adjoint_method or "", "levy": "none",
+               "dt": np.float64(dt), "grad_free": False, "shape": np.array([B, d, m]),
+               "adjoint_rtol": np.float64(rtol), "adjoint_atol": np.float64(atol),
+               "dt_min": np.float64(ADJOINT_ADAPTIVE_DT_MIN),
+               "f64__ts": tst.numpy(), "f64__queries": keys, "f64__W": W, "f64__U": U, "f64__ys": ys.detach().numpy(),
+               "f64__loss_weights": wt.numpy(), "f64__grad_y0": y0.grad.numpy(),
+               "f64__param_checksum": np.float64(param_checksum(sde)),
+               "backward_queries": np.int64(len(keys) - forward_queries)}
+        for j, p in enumerate(sde.parameters()):
+            out[f"f64__grad_p{j}"] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy()
+        np.savez_compressed(os.path.join(HERE, f"adjoint_adaptive_{name}.npz"), **out)
+        print(f"adjoint_adaptive_{name}.npz  forward queries={forward_queries}  backward queries="
+              f"{len(keys) - forward_queries}  |grad_y0|={np.abs(out['f64__grad_y0']).sum():.4f}")
+
+
 # second derivatives through sdeint_adjoint: the reference nests a second adjoint solve (adjoint.py:97-112)
 DOUBLE_BACKWARD_CASES = [
     # name, problem, method, adjoint_method, (B, d, m), ts, dt
@@ -728,7 +776,7 @@ def gen_closed_form_expr():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
-                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr", "double_backward"]
+                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr", "double_backward", "adjoint_adaptive"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

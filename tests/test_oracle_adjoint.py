@@ -59,3 +59,56 @@ def test_oracle_adjoint_matches_reference_on_the_counter_path(name):
     torch.testing.assert_close(grad_y0, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
     for (pname, _), g in zip(sde.named_parameters(), grad_params):
         torch.testing.assert_close(g, torch.tensor(z["grad__" + pname]), rtol=1e-10, atol=1e-11)
+
+
+def _adaptive_cases():
+    import os
+    return sorted(f[len("adjoint_adaptive_"):-4] for f in os.listdir(helpers.GOLDEN)
+                  if f.startswith("adjoint_adaptive_") and not f.endswith("_rheun.npz"))
+
+
+@pytest.mark.parametrize("name", _adaptive_cases())
+def test_oracle_adaptive_adjoint_matches_reference(name):
+    """`adjoint_adaptive=True`: the replay table holds only the intervals the reference asked for, so the oracle has to
+    take the reference's accept / reject decisions to get through at all; then the gradients to rounding."""
+    case = helpers.Case(name, "f64", prefix="adjoint_adaptive_")
+    z = case.z
+    sde = case.sde()
+    bm = solvers_ref.ReplayBrownian(case.table())
+    wt = torch.tensor(z["f64__loss_weights"])
+    ys, grad_y0, grad_params = adjoint_ref.adjoint_gradients(
+        sde, case.y0(), case.ts, bm, case.dt, case.method, str(z["adjoint_method"]) or None, wt, adjoint_adaptive=True,
+        adjoint_rtol=float(z["adjoint_rtol"]), adjoint_atol=float(z["adjoint_atol"]), dt_min=float(z["dt_min"]))
+    torch.testing.assert_close(ys, case.ys, rtol=1e-11, atol=1e-13)
+    torch.testing.assert_close(grad_y0, torch.tensor(z["f64__grad_y0"]), rtol=1e-9, atol=1e-11)
+    for j, g in enumerate(grad_params):
+        torch.testing.assert_close(g, torch.tensor(z[f"f64__grad_p{j}"]), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", [n for n in helpers.adjoint_cases() if n.endswith("_rheun")])
+def test_oracle_reversible_heun_adjoint_matches_reference(name):
+    case = helpers.Case(name, "f64", prefix="adjoint_")
+    z = case.z
+    sde = case.sde()
+    bm = solvers_ref.ReplayBrownian(case.table())
+    ys, grad_y0, grad_params = adjoint_ref.reversible_heun_adjoint_gradients(
+        sde, case.y0(), case.ts, bm, case.dt, torch.tensor(z["f64__loss_weights"]))
+    torch.testing.assert_close(ys, case.ys, rtol=1e-11, atol=1e-13)
+    torch.testing.assert_close(grad_y0, torch.tensor(z["f64__grad_y0"]), rtol=1e-10, atol=1e-12)
+    for j, g in enumerate(grad_params):
+        torch.testing.assert_close(g, torch.tensor(z[f"f64__grad_p{j}"]), rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["mlpdiag_strat_rheun", "general_strat_rheun"])
+def test_oracle_adaptive_reversible_heun_adjoint_matches_reference(name):
+    case = helpers.Case(name, "f64", prefix="adjoint_adaptive_")
+    z = case.z
+    sde = case.sde()
+    bm = solvers_ref.ReplayBrownian(case.table())
+    ys, grad_y0, grad_params = adjoint_ref.reversible_heun_adjoint_gradients(
+        sde, case.y0(), case.ts, bm, case.dt, torch.tensor(z["f64__loss_weights"]), adjoint_adaptive=True,
+        adjoint_rtol=float(z["adjoint_rtol"]), adjoint_atol=float(z["adjoint_atol"]), dt_min=float(z["dt_min"]))
+    torch.testing.assert_close(ys, case.ys, rtol=1e-11, atol=1e-13)
+    torch.testing.assert_close(grad_y0, torch.tensor(z["f64__grad_y0"]), rtol=1e-9, atol=1e-11)
+    for j, g in enumerate(grad_params):
+        torch.testing.assert_close(g, torch.tensor(z[f"f64__grad_p{j}"]), rtol=1e-9, atol=1e-10)

@@ -302,27 +302,57 @@ def _plan_reversible_heun_backward(ts_host, dt, native, device):
     return intervals
 
 
+def _reversible_heun_backward_step(sde, params, diag, state, noise, step_dt, t0_fwd, t1_fwd):
+    """One backward step of the reversible-Heun pair (reference: methods/reversible_heun.py:98-144): reconstruct
+    (y, f, g, z) algebraically while propagating (a_y, a_f, a_g, a_z); one VJP through f_and_g. `state` is
+    (y, f, g, z, a_y, a_f, a_g, a_z); returns the next state and the step's parameter cotangents. Diagonal noise runs
+    entirely on fused HIP kernels (tsde_rheun_*); other noise types use the contraction kernel for the state and torch
+    ops for the (B, d, m) outer products of the adjoint. Nothing is updated in place."""
+    y, f, g, z, a_y, a_f, a_g, a_z = state
+    half_dt = type(step_dt)(0.5) * step_dt
+    if diag:
+        a_f0, a_g0 = K.rheun_adj_a(a_y, a_f, a_g, half_dt, noise)
+        z1 = K.rheun_z(y, z, f, g, step_dt, -1.0, noise)
+    else:
+        dW, _ = noise.materialise()
+        half_dW = 0.5 * dW
+        a_y_half_dW = a_y.unsqueeze(-1) * half_dW.unsqueeze(-2)
+        a_f0 = a_f + a_y * half_dt
+        a_g0 = a_g + a_y_half_dW
+        z1 = K.step_general_weighted(K.lincomb2(y, z, 2.0, -1.0), f, g, -1.0, step_dt, -1.0, 0, 0.0, 0.0, 0.0, noise)
+    z_leaf = z.detach().requires_grad_(True)
+    with torch.enable_grad():
+        re_f, re_g = sde.f_and_g(t0_fwd, z_leaf)
+        vjp_z, *vjp_theta = vjp((re_f, re_g), [z_leaf] + params, grad_outputs=[a_f0, a_g0], allow_unused=True)
+    f1, g1 = sde.f_and_g(t1_fwd, z1)
+    if diag:
+        y1 = K.rheun_y(y, f, f1, g, g1, half_dt, -1.0, noise)
+        a_y, a_z, a_f, a_g = K.rheun_adj_b(a_y, a_z, vjp_z, step_dt, half_dt, noise)
+    else:
+        y1 = K.step_general_weighted(y, K.lincomb2(f, f1, 1.0, 1.0), K.lincomb2(g, g1, 1.0, 1.0), -1.0, half_dt, -0.5,
+                                     0, 0.0, 0.0, 0.0, noise)
+        zz = a_z + vjp_z
+        a_f = a_y * half_dt + zz * step_dt
+        a_g = a_y_half_dW + zz.unsqueeze(-1) * dW.unsqueeze(-2)
+        a_y = a_y + 2 * zz
+        a_z = -zz
+    return (y1, f1, g1, z1, a_y, a_f, a_g, a_z), vjp_theta
+
+
 def _run_reversible_heun_backward(sde, bm, params, plan, ys, grad_ys, f, g, z, a_f, a_g, a_z):
     """Exact-gradient backward pass of reversible Heun (reference: methods/reversible_heun.py:98-144 driven by
-    adjoint.py:64-127), launch-only part: reconstruct (y, f, g, z) algebraically step by step while propagating
-    (a_y, a_f, a_g, a_z, a_theta); one VJP through f_and_g per step. Diagonal noise runs entirely on fused HIP
-    kernels (tsde_rheun_*); other noise types use the contraction kernel for the state and torch ops for the
-    (B, d, m) outer products of the adjoint. Returns [a_y, a_f, a_g, a_z, *a_theta]."""
+    adjoint.py:64-127), launch-only part. Returns [a_y, a_f, a_g, a_z, *a_theta]."""
     diag = sde.noise_type == NOISE_TYPES.diagonal
     native = bm if isinstance(bm, BrownianInterval) else None
     reverse_bm = None if native is not None else ReverseBrownian(bm)
     params = list(params)
-    y = ys[-1]
-    a_y = grad_ys[-1].contiguous().clone()
-    a_f, a_g, a_z = a_f.contiguous().clone(), a_g.contiguous().clone(), a_z.contiguous().clone()
+    state = (ys[-1], f, g, z, grad_ys[-1].contiguous().clone(), a_f.contiguous().clone(), a_g.contiguous().clone(),
+             a_z.contiguous().clone())
     a_theta = [torch.zeros_like(p) for p in params]
 
     for (i, grid, tau64, fwd_times, cells, tau_dev) in plan:
         n = grid.n_steps
-        np_dtype = grid.t.dtype.type
         for k in range(n):
-            step_dt = grid.dt[k]
-            half_dt = np_dtype(0.5) * step_dt
             if native is not None:
                 if cells is not None:
                     c = int(cells[n - 1 - k])
@@ -332,41 +362,68 @@ def _run_reversible_heun_backward(sde, bm, params, plan, ys, grad_ys, f, g, z, a
                     noise = NoiseSpec.external(W)
             else:
                 noise = NoiseSpec.external(reverse_bm(tau_dev[k], tau_dev[k + 1]))
-            if diag:
-                a_f0, a_g0 = K.rheun_adj_a(a_y, a_f, a_g, half_dt, noise)
-                z1 = K.rheun_z(y, z, f, g, step_dt, -1.0, noise)
-            else:
-                dW, _ = noise.materialise()
-                half_dW = 0.5 * dW
-                a_y_half_dW = a_y.unsqueeze(-1) * half_dW.unsqueeze(-2)
-                a_f0 = a_f + a_y * half_dt
-                a_g0 = a_g + a_y_half_dW
-                z1 = K.step_general_weighted(K.lincomb2(y, z, 2.0, -1.0), f, g, -1.0, step_dt, -1.0, 0, 0.0, 0.0, 0.0,
-                                             noise)
-            z_leaf = z.detach().requires_grad_(True)
-            with torch.enable_grad():
-                re_f, re_g = sde.f_and_g(fwd_times[k], z_leaf)
-                vjp_z, *vjp_theta = vjp((re_f, re_g), [z_leaf] + params, grad_outputs=[a_f0, a_g0],
-                                        allow_unused=True)
+            state, vjp_theta = _reversible_heun_backward_step(sde, params, diag, state, noise, grid.dt[k], fwd_times[k],
+                                                              fwd_times[k + 1])
             for acc, v in zip(a_theta, vjp_theta):
                 acc.add_(v)
-            f1, g1 = sde.f_and_g(fwd_times[k + 1], z1)
-            if diag:
-                y1 = K.rheun_y(y, f, f1, g, g1, half_dt, -1.0, noise)
-                a_y, a_z, a_f, a_g = K.rheun_adj_b(a_y, a_z, vjp_z, step_dt, half_dt, noise)
-            else:
-                y1 = K.step_general_weighted(y, K.lincomb2(f, f1, 1.0, 1.0), K.lincomb2(g, g1, 1.0, 1.0), -1.0,
-                                             half_dt, -0.5, 0, 0.0, 0.0, 0.0, noise)
-                zz = a_z + vjp_z
-                a_f = a_y * half_dt + zz * step_dt
-                a_g = a_y_half_dW + zz.unsqueeze(-1) * dW.unsqueeze(-2)
-                a_y = a_y + 2 * zz
-                a_z = -zz
-            y, f, g, z = y1, f1, g1, z1
         # adjoint.py:114-116
-        y = ys[i - 1]
-        a_y = a_y + grad_ys[i - 1]
-    return [a_y, a_f, a_g, a_z] + a_theta
+        state = (ys[i - 1],) + state[1:4] + (state[4] + grad_ys[i - 1],) + state[5:]
+    return [state[4], state[5], state[6], state[7]] + a_theta
+
+
+def _run_reversible_heun_backward_adaptive(sde, bm, params, ts_host, dt, rtol, atol, dt_min, ys, grad_ys, f, g, z, a_f,
+                                           a_g, a_z):
+    """`adjoint_adaptive=True` with `adjoint_reversible_heun`: the reference pushes this solver's step through its
+    generic step-doubling loop like any other (base_solver.py:117-142): per attempt one full and two half steps from
+    the same state, the error norm over the flat (y, a_y, a_f, a_g, a_z, a_theta), the carried (f, g, z) following the
+    two half steps; every output interval starts again from `dt` (adjoint.py:97-112 calls integrate() per interval).
+    (The gradients are then no longer the exact ones of the forward solve -- the backward steps do not retrace it.)"""
+    diag = sde.noise_type == NOISE_TYPES.diagonal
+    native = bm if isinstance(bm, BrownianInterval) else None
+    reverse_bm = None if native is not None else ReverseBrownian(bm)
+    params = list(params)
+    device = ys.device
+    np_dtype = ts_host.dtype.type
+    state = (ys[-1], f, g, z, grad_ys[-1].contiguous().clone(), a_f.contiguous().clone(), a_g.contiguous().clone(),
+             a_z.contiguous().clone())
+    a_theta = [torch.zeros_like(p) for p in params]
+
+    def noise_of(ta, tb):                       # the increment of the forward interval [-tb, -ta]
+        if native is not None:
+            return NoiseSpec.external(native.increment(-float(tb), -float(ta))[0])
+        return NoiseSpec.external(reverse_bm(torch.tensor(ta, device=device), torch.tensor(tb, device=device)))
+
+    def flat(st, theta):
+        return torch.cat([st[0].reshape(-1)] + [x.reshape(-1) for x in st[4:]] + [x.reshape(-1) for x in theta])
+
+    for i in range(len(ts_host) - 1, 0, -1):
+        curr_t, t_end = -ts_host[i], -ts_host[i - 1]
+        step_size = dt if not torch.is_tensor(dt) else float(dt)
+        prev_error_ratio = None
+        while curr_t < t_end:
+            nxt = curr_t + np_dtype(step_size)
+            next_t = nxt if nxt <= t_end else t_end
+            mid_t = np_dtype(0.5) * (curr_t + next_t)
+            t_dev = torch.from_numpy(np.asarray([-curr_t, -mid_t, -next_t], dtype=ts_host.dtype)).to(device).unbind(0)
+            full, th_full = _reversible_heun_backward_step(sde, params, diag, state, noise_of(curr_t, next_t),
+                                                           np_dtype(next_t - curr_t), t_dev[0], t_dev[2])
+            half, th_a = _reversible_heun_backward_step(sde, params, diag, state, noise_of(curr_t, mid_t),
+                                                        np_dtype(mid_t - curr_t), t_dev[0], t_dev[1])
+            two, th_b = _reversible_heun_backward_step(sde, params, diag, half, noise_of(mid_t, next_t),
+                                                       np_dtype(next_t - mid_t), t_dev[1], t_dev[2])
+            theta_full = [acc + v for acc, v in zip(a_theta, th_full)]
+            theta_two = [acc + va + vb for acc, va, vb in zip(a_theta, th_a, th_b)]
+            error_estimate = solvers._error_estimate(flat(full, theta_full), flat(two, theta_two), rtol, atol)
+            step_size, prev_error_ratio = solvers._update_step_size(error_estimate, step_size, prev_error_ratio)
+            if step_size < dt_min:
+                warnings.warn("Hitting minimum allowed step size in adaptive time-stepping.")
+                step_size = dt_min
+                prev_error_ratio = None
+            if error_estimate <= 1 or step_size <= dt_min:
+                curr_t, state, a_theta = next_t, two, theta_two
+        # adjoint.py:114-116
+        state = (ys[i - 1],) + state[1:4] + (state[4] + grad_ys[i - 1],) + state[5:]
+    return [state[4], state[5], state[6], state[7]] + a_theta
 
 
 class _SdeintAdjointMethod(torch.autograd.Function):
@@ -427,9 +484,13 @@ class _SdeintAdjointMethod(torch.autograd.Function):
         if ctx.adjoint_adaptive[0]:
             _, rtol, atol, dt_min = ctx.adjoint_adaptive
             kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
-            a_y, a_theta = _run_backward_adaptive(AdjointSDE(ctx.sde, adjoint_params), kind, ctx.bm,
-                                                  timegrid.ts_to_host(ts), ctx.dt, rtol, atol, dt_min, ys, grad_ys)
-            out = [a_y] + list(a_theta)
+            if kind == "reversible_heun":
+                out = _run_reversible_heun_backward_adaptive(ctx.sde, ctx.bm, adjoint_params, timegrid.ts_to_host(ts),
+                                                             ctx.dt, rtol, atol, dt_min, *inputs)
+            else:
+                a_y, a_theta = _run_backward_adaptive(AdjointSDE(ctx.sde, adjoint_params), kind, ctx.bm,
+                                                      timegrid.ts_to_host(ts), ctx.dt, rtol, atol, dt_min, ys, grad_ys)
+                out = [a_y] + list(a_theta)
         elif captured is not None:
             out = captured.replay(ctx.bm, inputs)
         else:
@@ -640,9 +701,10 @@ def _run_backward_adaptive(adjoint_sde, kind, bm, ts_host, dt, rtol, atol, dt_mi
     def flat(x):
         return torch.cat([t.reshape(-1) for t in x.t])
 
-    step_size = dt if not torch.is_tensor(dt) else float(dt)
     for i in range(len(ts_host) - 1, 0, -1):
         curr_t, t_end = -ts_host[i], -ts_host[i - 1]
+        # every output interval is its own integrate() call in the reference (adjoint.py:97-112): back to `dt`
+        step_size = dt if not torch.is_tensor(dt) else float(dt)
         prev_error_ratio = None
         while curr_t < t_end:
             nxt = curr_t + np_dtype(step_size)
@@ -704,9 +766,6 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
     adjoint_params = tuple(p for p in adjoint_params if p.requires_grad)
     adjoint_method = _select_default_adjoint_method(sde, method, adjoint_method)
     adjoint_options = {} if adjoint_options is None else adjoint_options.copy()
-    if adjoint_adaptive and adjoint_method == METHODS.adjoint_reversible_heun:
-        raise NotImplementedError("torchsde_amd: `adjoint_adaptive=True` is not available for "
-                                  "`adjoint_reversible_heun` (its backward pass retraces the forward grid).")
     if method == METHODS.reversible_heun:   # adjoint.py:243-257
         if adjoint_method != METHODS.adjoint_reversible_heun:
             warnings.warn(f"method={repr(method)}, but adjoint_method!={repr(METHODS.adjoint_reversible_heun)}.")
