@@ -294,3 +294,42 @@ def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle():
     for name, got, want in zip(names, gp, gp_user):
         err = (got - want).abs().max().item()
         assert err <= 2e-3 * want.abs().max().item() + 1e-6, f"{name}: {err:.3e} vs scale {want.abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("name", ["c2_euler_expdiff_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000"])
+def test_c2_reference_benchmark_sde_rows_vs_oracle(name):
+    """SURVEY 8d's nonlinear second workload -- the SDE of the reference's own benchmark, f = y, g = exp(-y)
+    (benchmarks/brownian.py:131-139) -- at the headline's shape, stepwise (user torch ops + tsde_step_diag) and as an
+    elementwise-expression module (one launch of tsde_trajectory_expr_diag), rows against the oracle."""
+    import torchsde_amd
+    c = configs.WORKLOADS[name]
+    B, d, n, dt = c["B"], c["d"], c["nsteps"], c["dt"]
+    sde = configs.make_problem(c["problem"], d, d, DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+    with torch.no_grad():
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, d, n, dt, 20240601), method="euler", dt=dt)
+    assert bool(torch.isfinite(ys[-1]).all())
+    rows = helpers.sampled_rows(B, 64, seed=8, seams=(32, 2048 * 32 // d, B - 32))
+    plain = configs.make_problem("exp_diffusion", d, d, "cpu")          # the oracle integrates the plain torch module
+    ref32, ref64 = _oracle_forward(plain, rows, d, d, 20240601, n, dt, "euler", 0.1)
+    helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1], name)
+
+
+def test_c5_sampling_kernel_b32768_d128_s500_rows_vs_oracle():
+    """The perceptron-drift sampling kernel (both layers on the f32 matrix cores, one launch per solve) at the configs[4]
+    shape, rows against the oracle integrating the same module's torch statement of f and g."""
+    import torchsde_amd
+    c = configs.WORKLOADS["c5_sampling_mlp_b32768_d128_s500"]
+    B, d, n, dt = c["B"], c["d"], c["nsteps"], c["dt"]
+    sde = configs.make_problem(c["problem"], d, d, DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, 200 * dt, n * dt], device=DEV)
+    with torch.no_grad():
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, d, n, dt, 4242), method="euler", dt=dt)
+    # workgroups own 64-row (and, on small grids, 32-row) tiles: rows either side of the first and the last seam
+    rows = helpers.sampled_rows(B, 64, seed=9, seams=(32, 64, 128, B - 64))
+    ref32, ref64 = _oracle_forward(sde, rows, d, d, 4242, n, dt, "euler", 0.1, ts=[0.0, 200 * dt, n * dt])
+    idx = torch.from_numpy(rows).to(DEV)
+    for k in (1, 2):
+        helpers.assert_within_reference_rounding(ys[k][idx], ref32[k], ref64[k], f"C5 sampling kernel, output {k}")
