@@ -333,3 +333,38 @@ def test_c5_sampling_kernel_b32768_d128_s500_rows_vs_oracle():
     idx = torch.from_numpy(rows).to(DEV)
     for k in (1, 2):
         helpers.assert_within_reference_rounding(ys[k][idx], ref32[k], ref64[k], f"C5 sampling kernel, output {k}")
+
+
+def test_c5_training_kernels_b32768_d128_s500_rows_vs_oracle():
+    """The configs[4] SDE trained by back-propagation THROUGH the solver (`sdeint` + `loss.backward()`, the reference's
+    discretise-then-optimise route): sampling kernel writing every step, reverse sweep and weight-gradient products on
+    the matrix cores, 32768 x 128 x 500 steps. dL/dy0 of sampled rows against autograd through the oracle's Euler loop
+    on the same path (rows are independent, so a row's input gradient needs only that row). (Parameter gradients sum
+    over all rows; they are pinned at sizes the oracle can take whole, tests/test_gpu_mlp_backward.py.)"""
+    import copy
+
+    import torchsde_amd
+    from oracle import solvers_ref
+    c = configs.WORKLOADS["c5_training_mlp_b32768_d128_s500"]
+    B, d, n, dt = c["B"], c["d"], c["nsteps"], c["dt"]
+    closed = configs.make_problem(c["problem"], d, d, DEV)
+    wt = _loss_weights(B, d)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
+    ys = torchsde_amd.sdeint(closed, y0, ts, bm=_bm(B, d, n, dt, 777), method="euler", dt=dt)
+    assert "Mlp" in type(ys.grad_fn).__name__, type(ys.grad_fn).__name__
+    (ys[-1] * wt.to(DEV, torch.float32)).sum().backward()
+    rows = helpers.sampled_rows(B, 48, seed=10, seams=(16, 64, 128))
+    idx = torch.from_numpy(rows).to(DEV)
+    got = {}
+    for dtype in (torch.float32, torch.float64):
+        sde = copy.deepcopy(closed).cpu().to(dtype)
+        bm = helpers.counter_rows_bm(rows, d, 777, _edges(n, dt), dtype)
+        y_rows = torch.full((len(rows), d), 0.1, dtype=dtype, requires_grad=True)
+        out = solvers_ref.integrate(sde, bm, y_rows, torch.tensor([0.0, n * dt], dtype=dtype), dt, "euler")
+        (out[-1] * wt[torch.from_numpy(rows)].to(dtype)).sum().backward()
+        got[dtype] = (out[-1].detach(), y_rows.grad)
+    helpers.assert_within_reference_rounding(ys[-1][idx].detach(), got[torch.float32][0], got[torch.float64][0],
+                                             "final state", factor=8.0, floor=1e-5)
+    helpers.assert_within_reference_rounding(y0.grad[idx], got[torch.float32][1], got[torch.float64][1], "dL/dy0",
+                                             factor=8.0, floor=1e-5)
