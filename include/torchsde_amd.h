@@ -364,14 +364,17 @@ int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d,
                               int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                               const uint64_t* entropy_dev, int dtype, void* stream);
 
-/* The stochastic adjoint of the perceptron-drift SDE of tsde_trajectory_mlp_diag, Euler-Maruyama backwards in time:
- * what `sdeint_adjoint(..., adjoint_method="euler")` integrates for this module (torchsde/_core/adjoint.py:64-127
- * driving adjoint_sde.py:177-230, 296-323 through methods/euler.py:29-37), one launch per chunk of steps. Processes
+/* The stochastic adjoint of the perceptron-drift SDE of tsde_trajectory_mlp_diag, Euler-Maruyama or Milstein backwards
+ * in time: what `sdeint_adjoint(..., adjoint_method="euler" | "milstein")` integrates for this module
+ * (torchsde/_core/adjoint.py:64-127 driving adjoint_sde.py:177-230, 296-323, 332-377 through methods/euler.py:29-37 /
+ * milstein.py:52-74), one launch per chunk of steps. `ito`: bit 0 set = Ito SDE (below: ito = 1), clear =
+ * Stratonovich (ito = 0; Milstein only, like the reference); bit 1 set = Milstein backward step, clear = Euler. Processes
  * steps k_hi-1 ... k_lo of the FORWARD grid (step k walks back over Brownian cell traj->cells[k], width traj row k);
  * with dW that cell's increment, g the diagonal diffusion, everything evaluated at the current reconstructed y:
  *     f~ = f - ito * g g'                          (adjoint_sde.py:177-216)
  *     delta = (W2 a) * act'(W1^T y + b1) * dt
  *     y <- y - f~ dt - g dW ;   a <- a + W1 delta + a (g' dW - ito * dt g g'')
+ *     Milstein, v = (dW^2 - ito * dt) / 2:   y <- ... + v g g' ;   a <- ... + a v (g'^2 - g g'')
  *   y, a         (rows, d)  in: the state and dL/dy at boundary k_hi; out: at boundary k_lo. The caller resets y to the
  *                stored forward state and adds the output's cotangent to a at every output time (adjoint.py:114-116).
  *   stash_a      (k_hi-k_lo, rows, d)       out: dt_k * a                      (slot k - k_lo)
@@ -381,7 +384,8 @@ int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d,
  *       => dL/dW2 += stash_a^T stash_hid, dL/dW1 += stash_delta^T stash_y (tsde_gram_partials),
  *          dL/db2 += column sums of stash_a, dL/db1 += column sums of stash_delta
  *   row_rate, row_shift (rows, d)  accumulated in place: per trajectory sums of a (dW dg/dc - ito dt g dg'/dc) and of
- *                a (dW dg/de - ito dt g dg'/de); their batch sums are dL/d diff_rate, dL/d diff_shift
+ *                a (dW dg/de - ito dt g dg'/de) (Milstein: + a v (g' dg/dtheta - g dg'/dtheta)); their batch sums are
+ *                dL/d diff_rate, dL/d diff_shift
  * Shapes, layouts and limits as tsde_trajectory_mlp_diag_backward; b2 (d) is the output bias of the drift. */
 int tsde_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void* stash_delta, void* stash_y,
                           void* row_rate, void* row_shift, int64_t rows, int64_t d, int64_t hidden, const void* w1,

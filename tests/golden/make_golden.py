@@ -661,6 +661,12 @@ CLOSED_FORM_ADJOINT_CASES = [
     ("euler_softplus_sigmoid", "softplus", "sigmoid", "euler", [0.0, 16]),
     ("euler_tanh_affine_outputs", "tanh", "affine", "euler", [0.0, 5, 11, 16]),
     ("milstein_softplus_affine", "softplus", "affine", "milstein", [0.0, 8, 16]),
+    # adjoint_method="milstein" (the default for diagonal Ito noise, adjoint.py:281-296), Ito and Stratonovich:
+    # name, activation, diffusion, forward method, ts, sde_type, adjoint_method
+    ("adjmil_softplus_sigmoid", "softplus", "sigmoid", "milstein", [0.0, 16], "ito", "milstein"),
+    ("adjmil_tanh_affine_outputs", "tanh", "affine", "euler", [0.0, 5, 11, 16], "ito", "milstein"),
+    ("adjmil_strat_softplus_sigmoid", "softplus", "sigmoid", "midpoint", [0.0, 7, 16], "stratonovich", "milstein"),
+    ("adjmil_strat_tanh_affine", "tanh", "affine", "milstein", [0.0, 16], "stratonovich", "milstein"),
 ]
 
 
@@ -683,11 +689,12 @@ def gen_closed_form_adjoint():
         shape = property(lambda self: (B, d))
         levy_area_approximation = property(lambda self: "none")
 
-    for name, activation, diffusion, method, marks in CLOSED_FORM_ADJOINT_CASES:
+    for name, activation, diffusion, method, marks, *rest in CLOSED_FORM_ADJOINT_CASES:
+        sde_type, adjoint_method = rest if rest else ("ito", "euler")
         gen = torch.Generator().manual_seed(sum(map(ord, "adjoint_" + name)))
         sigmoid = diffusion == "sigmoid"
         sde = torchsde_amd.MLPDriftDiagonalSDE(
-            d, hidden, activation=activation, sde_type="ito", diffusion=diffusion,
+            d, hidden, activation=activation, sde_type=sde_type, diffusion=diffusion,
             diff_scale=0.4 if sigmoid else 1.0, dtype=torch.float64,
             diff_rate=(2.0 if sigmoid else 0.2) * torch.rand(d, generator=gen, dtype=torch.float64) - 0.1,
             diff_shift=0.1 + 0.2 * torch.rand(d, generator=gen, dtype=torch.float64))
@@ -700,9 +707,10 @@ def gen_closed_form_adjoint():
         y0 = (0.5 * torch.randn(B, d, generator=gen, dtype=torch.float64)).requires_grad_(True)
         weights = torch.randn(len(ts), B, d, generator=gen, dtype=torch.float64)
         ys = torchsde.sdeint_adjoint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method,
-                                     adjoint_method="euler", dt=dt)
+                                     adjoint_method=adjoint_method, dt=dt)
         (ys * weights).sum().backward()
-        out = {"activation": activation, "diffusion": diffusion, "sde_type": "ito", "method": method,
+        out = {"activation": activation, "diffusion": diffusion, "sde_type": sde_type, "method": method,
+               "adjoint_method": adjoint_method,
                "diff_scale": np.float64(sde.diff_scale), "entropy": np.int64(entropy), "dt": np.float64(dt),
                "ts": np.asarray(ts), "shape": np.array([B, d, hidden, steps]), "y0": y0.detach().numpy(),
                "weights": weights.numpy(), "ys": ys.detach().numpy(), "grad__y0": y0.grad.numpy()}

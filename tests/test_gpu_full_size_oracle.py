@@ -255,8 +255,9 @@ def test_c5_parameter_gradients_b256_vs_oracle():
         helpers.assert_within_reference_rounding(p.grad, g32, g64, f"dL/d{name}")
 
 
-def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle():
-    """configs[4] through `sdeint_adjoint(method="euler", adjoint_method="euler")` with the latent SDE stated as the
+@pytest.mark.parametrize("adjoint_method", ["euler", "milstein"])
+def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle(adjoint_method):
+    """configs[4] through `sdeint_adjoint(method="euler", adjoint_method="euler" | "milstein")` with the latent SDE stated as the
     closed-form module: the forward sampling kernel and the stochastic adjoint on the matrix cores
     (tsde_adjoint_mlp_diag) at 32768 x 128 x 500 steps. Final states and dL/dy0 of sampled rows against the oracle's
     restatement of the reference's adjoint on the user-module statement of the same SDE; the six parameter gradients
@@ -273,7 +274,7 @@ def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle():
         y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
         sde.zero_grad()
         ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(B, d, n, dt, 20240601), method="euler",
-                                         adjoint_method="euler", dt=dt)
+                                         adjoint_method=adjoint_method, dt=dt)
         (ys[-1] * wt.to(DEV, torch.float32)).sum().backward()
         return ys, y0.grad, [p.grad.clone() for p in sde.parameters()]
 
@@ -281,7 +282,7 @@ def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle():
     assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn")
     rows = helpers.sampled_rows(B, 64, seed=8, seams=(16, 64, 128))
     idx = torch.from_numpy(rows).to(DEV)
-    (ys32, gy32, _), (ys64, gy64, _) = _oracle_adjoint(user, rows, d, 20240601, n, dt, "euler", "euler",
+    (ys32, gy32, _), (ys64, gy64, _) = _oracle_adjoint(user, rows, d, 20240601, n, dt, "euler", adjoint_method,
                                                         wt[torch.from_numpy(rows)])
     # (the matrix products accumulate in another order than the oracle's float32 GEMMs: a wider factor than for the
     #  elementwise kernels, still relative to the oracle's own float32 rounding)

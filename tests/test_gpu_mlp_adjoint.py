@@ -1,4 +1,4 @@
-"""``sdeint_adjoint(..., adjoint_method="euler")`` on the perceptron-drift module through the matrix-core kernels
+"""``sdeint_adjoint(..., adjoint_method="euler" | "milstein")`` on the perceptron-drift module through the matrix-core kernels
 (``-m gpu``; torchsde_amd/mlp_adjoint.py, csrc/mlp_adjoint.hip: tsde_adjoint_mlp_diag) against
 
 * the REAL reference's `sdeint_adjoint` on the same Brownian path (tests/golden/closed_form_adjoint_*.npz, float64);
@@ -40,7 +40,8 @@ def test_matches_the_reference_adjoint(name):
     ts = torch.tensor(z["ts"], dtype=torch.float32, device=DEV)
     bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=torch.float32, device=DEV,
                                        entropy=int(z["entropy"]), dt=dt)
-    ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=str(z["method"]), adjoint_method="euler", dt=dt)
+    ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=str(z["method"]),
+                                     adjoint_method=str(z["adjoint_method"]), dt=dt)
     assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn"), "the matrix-core route was not taken"
     (ys * torch.tensor(z["weights"], dtype=torch.float32, device=DEV)).sum().backward()
     _close(ys.detach(), torch.tensor(z["ys"]), "ys", tol=1e-3)
@@ -49,24 +50,31 @@ def test_matches_the_reference_adjoint(name):
         _close(p.grad, torch.tensor(z["grad__" + pname]), f"dL/d{pname}")
 
 
-SHAPES = [  # B, d, hidden, activation, diffusion, forward method, steps, output marks
-    (64, 32, 32, "tanh", "affine", "euler", 24, (0, 24)),
-    (100, 64, 64, "softplus", "sigmoid", "euler", 24, (0, 7, 24)),
-    (48, 128, 128, "softplus", "sigmoid", "euler", 16, (0, 16)),
-    (37, 20, 36, "tanh", "sigmoid", "milstein", 16, (0, 4, 9, 16)),          # padded channels, ragged batch
-    (48, 64, 256, "softplus", "affine", "euler", 12, (0, 12)),
-    (33, 128, 100, "tanh", "affine", "euler", 12, (0, 6, 12)),
+SHAPES = [  # B, d, hidden, activation, diffusion, forward method, steps, output marks, sde type, adjoint method
+    (64, 32, 32, "tanh", "affine", "euler", 24, (0, 24), "ito", "euler"),
+    (100, 64, 64, "softplus", "sigmoid", "euler", 24, (0, 7, 24), "ito", "euler"),
+    (48, 128, 128, "softplus", "sigmoid", "euler", 16, (0, 16), "ito", "euler"),
+    (37, 20, 36, "tanh", "sigmoid", "milstein", 16, (0, 4, 9, 16), "ito", "euler"),   # padded channels, ragged batch
+    (48, 64, 256, "softplus", "affine", "euler", 12, (0, 12), "ito", "euler"),
+    (33, 128, 100, "tanh", "affine", "euler", 12, (0, 6, 12), "ito", "euler"),
+    # Milstein backward steps (the default adjoint method of a diagonal Ito SDE), Ito and Stratonovich
+    (100, 64, 64, "softplus", "sigmoid", "milstein", 24, (0, 7, 24), "ito", "milstein"),
+    (48, 128, 128, "softplus", "sigmoid", "euler", 16, (0, 16), "ito", "milstein"),
+    (37, 20, 36, "tanh", "sigmoid", "milstein", 16, (0, 4, 9, 16), "ito", None),
+    (64, 32, 32, "tanh", "affine", "midpoint", 24, (0, 24), "stratonovich", "milstein"),
+    (33, 128, 100, "softplus", "sigmoid", "milstein", 12, (0, 6, 12), "stratonovich", "milstein"),
 ]
 
 
-@pytest.mark.parametrize("B,d,hidden,activation,diffusion,method,steps,marks", SHAPES)
-def test_matches_the_stepwise_stochastic_adjoint(B, d, hidden, activation, diffusion, method, steps, marks):
+@pytest.mark.parametrize("B,d,hidden,activation,diffusion,method,steps,marks,sde_type,adjoint_method", SHAPES)
+def test_matches_the_stepwise_stochastic_adjoint(B, d, hidden, activation, diffusion, method, steps, marks, sde_type,
+                                                 adjoint_method):
     import torchsde_amd
     dt = 2.0 ** -6
     gen = torch.Generator().manual_seed(B * 1000 + d)
     sigmoid = diffusion == "sigmoid"
     sde = torchsde_amd.MLPDriftDiagonalSDE(
-        d, hidden, activation=activation, diffusion=diffusion, diff_scale=0.4 if sigmoid else 1.0,
+        d, hidden, activation=activation, diffusion=diffusion, diff_scale=0.4 if sigmoid else 1.0, sde_type=sde_type,
         diff_rate=(2.0 if sigmoid else 0.2) * torch.rand(d, generator=gen) - 0.1,
         diff_shift=0.1 + 0.2 * torch.rand(d, generator=gen)).to(DEV)
     ts = torch.tensor([k * dt for k in marks], device=DEV)
@@ -82,7 +90,7 @@ def test_matches_the_stepwise_stochastic_adjoint(B, d, hidden, activation, diffu
         if chunk_bytes is not None:
             mlp_adjoint._MlpAdjointFn.STASH_BYTES = chunk_bytes
         try:
-            ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=method, adjoint_method="euler", dt=dt,
+            ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt,
                                              adjoint_options={"trajectory_kernel": fast})
             assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn") == fast
             (ys * weights).sum().backward()
@@ -106,8 +114,8 @@ def test_matches_the_stepwise_stochastic_adjoint(B, d, hidden, activation, diffu
 
 
 def test_other_calls_keep_the_stepwise_adjoint():
-    """The default adjoint method (Milstein for Ito-diagonal), a subset of the parameters, or a grid the backward
-    solver does not walk cell by cell: the stepwise stochastic adjoint runs, as before."""
+    """Another adjoint method than Euler / Milstein, a subset of the parameters, or a grid the backward solver does not
+    walk cell by cell: the stepwise stochastic adjoint runs, as before."""
     import torchsde_amd
     B, d, dt = 32, 32, 2.0 ** -5
     sde = torchsde_amd.MLPDriftDiagonalSDE(d, 32, activation="tanh").to(DEV)
@@ -121,6 +129,7 @@ def test_other_calls_keep_the_stepwise_adjoint():
         return type(ys.grad_fn).__name__
 
     assert grad_fn_of(adjoint_method="euler").startswith("_MlpAdjointFn")
-    assert not grad_fn_of().startswith("_MlpAdjointFn")                                    # default: milstein
+    assert grad_fn_of().startswith("_MlpAdjointFn")                                        # default: milstein
+    assert not grad_fn_of(adjoint_options={"grad_free": False, "trajectory_kernel": False}).startswith("_MlpAdjointFn")
     assert not grad_fn_of(adjoint_method="euler", adjoint_params=[sde.lin1.weight]).startswith("_MlpAdjointFn")
     assert not grad_fn_of(adjoint_method="euler", ts=torch.tensor([0.0, 0.1], device=DEV)).startswith("_MlpAdjointFn")

@@ -54,7 +54,8 @@ def test_oracle_adjoint_matches_reference_on_the_counter_path(name):
         return torch.from_numpy(W).reshape(B, d).double()
 
     ys, grad_y0, grad_params = adjoint_ref.adjoint_gradients(sde, torch.tensor(z["y0"]), torch.tensor(z["ts"]), bm, dt,
-                                                             str(z["method"]), "euler", torch.tensor(z["weights"]))
+                                                             str(z["method"]), str(z["adjoint_method"]),
+                                                             torch.tensor(z["weights"]))
     torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
     torch.testing.assert_close(grad_y0, torch.tensor(z["grad__y0"]), rtol=1e-10, atol=1e-12)
     for (pname, _), g in zip(sde.named_parameters(), grad_params):

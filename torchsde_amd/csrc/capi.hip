@@ -515,7 +515,7 @@ int tsde_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void
   ProfScope p(TSDE_KID_MLP_ADJOINT, s);
   return fail(tsde::launch_adjoint_mlp_diag(y, a, stash_a, stash_hid, stash_delta, stash_y, row_rate, row_shift, rows, d,
                                             hidden, w1, b1, w2, b2, diff_rate, diff_shift, diff_kind, diff_amp,
-                                            activation, ito ? 1 : 0, traj, k_lo, k_hi, make_key(entropy, elem0),
+                                            activation, ito & 3, traj, k_lo, k_hi, make_key(entropy, elem0),
                                             entropy_dev, s),
               where);
 }

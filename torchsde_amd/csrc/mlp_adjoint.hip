@@ -11,6 +11,14 @@
 //   a_th_f <- a_th_f + dt a^T df/dtheta_f                          (perceptron weights and biases)
 //   a_th_g <- a_th_g + a (dW dg/dtheta_g - dt g dg'/dtheta_g)      (diffusion rate c and shift e; Stratonovich: first term)
 //
+// and with `adjoint_method="milstein"` (methods/milstein.py:52-74 on adjoint_sde.py:332-377; the default for diagonal
+// Ito noise) the step gains, with v = (dW^2 - dt) / 2 (Ito) or dW^2 / 2 (Stratonovich), the ELEMENTWISE terms
+//
+//   y      <- ... + v g g'            a <- ... + a v (g'^2 - g g'')
+//   a_th_g <- ... + a v (g' dg/dtheta_g - g dg'/dtheta_g)
+//
+// (g is diagonal: Milstein's correction never touches the perceptron, so the matrix products are Euler's)
+//
 // everything evaluated at the current reconstructed y, dW the increment of the forward cell the step walks back over.
 // With f = W2^T act(W1^T y + b1) + b2 that is four matrix products per step, on v_mfma_f32_16x16x4_f32 against the
 // same two LDS weight arrays the sampling and reverse-sweep kernels use (mlp_trajectory.hip, mlp_backward.hip):
@@ -48,7 +56,7 @@ struct MlpAdjArgs {
   const float *c, *e;       // (d) diffusion coefficients
   int32_t diff_kind;        // TSDE_DIFF_AFFINE / TSDE_DIFF_SIGMOID
   float diff_amp;
-  int32_t ito;              // 1: Ito (corrected drift), 0: Stratonovich
+  int32_t ito;              // bit 0: Ito (corrected drift) / Stratonovich; bit 1: Milstein backward step / Euler
   const float* rows;        // (n_steps, 8) schedule rows of the FORWARD cells: [0] = dt, [4] = sqrt(h)
   const uint32_t* cells;
   int64_t B;
@@ -58,7 +66,7 @@ struct MlpAdjArgs {
   const uint64_t* key_dev;
 };
 
-template <int D, int H, int ACT, int NW, bool FULL>
+template <int D, int H, int ACT, int NW, bool FULL, bool MILSTEIN>
 __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p) {
   constexpr int R = 16;
   using TL = Tile<R>;
@@ -120,7 +128,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
     a[t] = load_tile(p.a, t);
   }
   const bool sigmoid = p.diff_kind == TSDE_DIFF_SIGMOID;
-  const float ito = p.ito ? 1.0f : 0.0f;
+  const float ito = (p.ito & 1) ? 1.0f : 0.0f;
 
   for (int k = p.k_hi - 1; k >= p.k_lo; --k) {
     const float* srow = p.rows + (int64_t)k * 8;
@@ -200,8 +208,10 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
     // ---- elementwise: dW of the forward cell again, the diffusion terms, the reconstruction of y --------------------
     // (the diffusion kind is uniform over the launch: ONE branch around the whole phase, not one per element -- with
     //  the test inside the loops the phase was 70 basic blocks and the register allocator gave up on it)
+    // (the backward scheme is a template parameter, not a second uniform branch: with four instances of this phase in
+    //  one kernel the 8-wave 128 x 128 variant went from 15 to 210 spilled dwords)
     auto elementwise = [&](auto is_sigmoid) {
-      constexpr bool kSigmoid = decltype(is_sigmoid)::value;
+      constexpr bool kSigmoid = decltype(is_sigmoid)::value, kMilstein = MILSTEIN;
 #pragma unroll
       for (int t = 0; t < TD; ++t) {
         const int ch = R * t + 4 * part;
@@ -230,8 +240,15 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
           const float drift = (f[t][r] + bq[r]) - ito * (g * gp);           // f~
           const float aw = at * w;                                            // a dW
           const float adg = ito * ((at * dt) * g);                           // dt a g   (Ito correction terms)
-          a[t][r] = at + (aw * gp - adg * (qp * (cc * cc)));
-          y[t][r] = (yt - drift * dt) - g * w;
+          const float gpp = qp * (cc * cc);                                  // g''
+          float a1 = at + (aw * gp - adg * gpp), y1 = (yt - drift * dt) - g * w;
+          if constexpr (kMilstein) {
+            const float v = 0.5f * (w * w - ito * dt);
+            a1 += (at * v) * (gp * gp - g * gpp);
+            y1 += v * (g * gp);
+          }
+          a[t][r] = a1;
+          y[t][r] = y1;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -274,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) adjoint_diffusion_sums_kernel(const Ml
     key.k1 = (uint32_t)(ent >> 32);
   }
   const bool sigmoid = p.diff_kind == TSDE_DIFF_SIGMOID;
-  const float ito = p.ito ? 1.0f : 0.0f;
+  const float ito = (p.ito & 1) ? 1.0f : 0.0f, mil = (p.ito & 2) ? 1.0f : 0.0f;
   const int64_t nq = p.B * p.d / 4, plane = p.B * p.d;
   for (int64_t qi = (int64_t)blockIdx.x * kBlock + threadIdx.x; qi < nq; qi += (int64_t)gridDim.x * kBlock) {
     const int64_t i = qi * 4;
@@ -303,8 +320,11 @@ __global__ void __launch_bounds__(kBlock) adjoint_diffusion_sums_kernel(const Ml
           qp = q * (1.0f - 2.0f * s);
         }
         const float aw = at * w, adg = ito * (adt * g);
-        shift[r] += aw * q - adg * (qp * cc);
-        rate[r] += (aw * q) * yt - adg * ((qp * cc) * yt + q);
+        // Milstein: + a v (g' dg/dtheta - g dg'/dtheta), g' = q c, dg/de = q, dg'/de = q' c, dg/dc = q y, dg'/dc = q + q' c y
+        const float av = mil * (at * (0.5f * (w * w - ito * dt)));
+        const float gp = q * cc, dgp_de = qp * cc, dgp_dc = dgp_de * yt + q;
+        shift[r] += (aw * q - adg * dgp_de) + av * (gp * q - g * dgp_de);
+        rate[r] += ((aw * q) * yt - adg * dgp_dc) + av * (gp * (q * yt) - g * dgp_dc);
       }
     }
     *reinterpret_cast<f32x4*>(p.row_rate + i) = rate;
@@ -312,22 +332,29 @@ __global__ void __launch_bounds__(kBlock) adjoint_diffusion_sums_kernel(const Ml
   }
 }
 
-template <int D, int H, int ACT, int NW, bool FULL>
-static hipError_t launch_adj_variant(const MlpAdjArgs& p, hipStream_t s) {
+template <int D, int H, int ACT, int NW, bool FULL, bool MILSTEIN>
+static hipError_t launch_adj_scheme(const MlpAdjArgs& p, hipStream_t s) {
   constexpr int R = 16;
   const size_t lds_bytes =
       (size_t)(D * (H + MlpLds<R>::kPad) + H * (D + MlpLds<R>::kPad) + H + 3 * D) * sizeof(float);
   static bool configured = false;   // per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_adjoint_kernel<D, H, ACT, NW, FULL>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_adjoint_kernel<D, H, ACT, NW, FULL, MILSTEIN>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     configured = true;
   }
   const int64_t rows_per_block = NW * R;
   const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((mlp_adjoint_kernel<D, H, ACT, NW, FULL>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, s, p);
+  hipLaunchKernelGGL((mlp_adjoint_kernel<D, H, ACT, NW, FULL, MILSTEIN>), dim3((unsigned)blocks), dim3(NW * 64), lds_bytes,
+                     s, p);
   return hipGetLastError();
+}
+
+template <int D, int H, int ACT, int NW, bool FULL>
+static hipError_t launch_adj_variant(const MlpAdjArgs& p, hipStream_t s) {
+  return (p.ito & 2) ? launch_adj_scheme<D, H, ACT, NW, FULL, true>(p, s)
+                     : launch_adj_scheme<D, H, ACT, NW, FULL, false>(p, s);
 }
 
 // y, a, the f accumulators and act'(z) are 3 x D/4 + H/4 live registers per lane (128 at d = hidden = 128). The large
@@ -341,7 +368,9 @@ static hipError_t launch_adj_shape(const MlpAdjArgs& p, hipStream_t s) {
       const char* e = getenv("TSDE_ADJ_WAVES");
       return e ? atoi(e) : 0;
     }();
-    const bool eight = waves == 8 || (waves != 4 && full);      // padded shapes: the bounds tests cost registers
+    // padded shapes: the bounds tests cost registers; Milstein steps: so do their extra terms (195 spilled dwords in
+    // the 8-wave 128 x 128 variant, none with 4 waves)
+    const bool eight = waves == 8 || (waves != 4 && full && !(p.ito & 2));
     if (eight) return full ? launch_adj_variant<D, H, ACT, 8, true>(p, s) : launch_adj_variant<D, H, ACT, 8, false>(p, s);
     return full ? launch_adj_variant<D, H, ACT, 4, true>(p, s) : launch_adj_variant<D, H, ACT, 4, false>(p, s);
   } else {

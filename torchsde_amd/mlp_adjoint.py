@@ -19,18 +19,22 @@ from . import closed_form
 from . import kernels as K
 from . import timegrid
 from .brownian import BrownianInterval
-from .settings import METHODS, SDE_TYPES
+from .settings import METHOD_OPTIONS, METHODS, SDE_TYPES
 
-# forward methods the sampling kernel has, for the SDE type `adjoint_method="euler"` exists for (Euler-Maruyama is an
-# Ito scheme: the reference rejects it for a Stratonovich adjoint SDE, adjoint.py:83-93)
+# forward methods the sampling kernel has. (Backward: Euler-Maruyama is an Ito scheme -- the reference rejects it for a
+# Stratonovich adjoint SDE, adjoint.py:83-93, and `_check_adjoint_method` has already done the same -- Milstein steps
+# exist for both SDE types.)
 _FORWARD_CODES = {
     (METHODS.euler, SDE_TYPES.ito): _native.TRAJ_EULER,
     (METHODS.milstein, SDE_TYPES.ito): _native.TRAJ_MILSTEIN_ITO,
+    (METHODS.milstein, SDE_TYPES.stratonovich): _native.TRAJ_MILSTEIN_STRAT,
+    (METHODS.midpoint, SDE_TYPES.stratonovich): _native.TRAJ_MIDPOINT,
 }
+_BACKWARD_KINDS = {METHODS.euler: "euler", METHODS.milstein: "milstein"}
 
 
 def adjoint_mlp_diag(y, a, stashes, row_rate, row_shift, w1, b1, w2, b2, rate, shift, diffusion, activation, ito,
-                     schedule, k_lo, k_hi, bm):
+                     schedule, k_lo, k_hi, bm, milstein=False):
     """One launch of ``tsde_adjoint_mlp_diag`` over steps k_hi-1 ... k_lo (y, a updated in place)."""
     stash_a, stash_hid, stash_delta, stash_y = stashes
     rows, d = y.shape
@@ -40,19 +44,20 @@ def adjoint_mlp_diag(y, a, stashes, row_rate, row_shift, w1, b1, w2, b2, rate, s
         y.data_ptr(), a.data_ptr(), stash_a.data_ptr(), stash_hid.data_ptr(), stash_delta.data_ptr(), stash_y.data_ptr(),
         row_rate.data_ptr(), row_shift.data_ptr(), rows, d, b1.numel(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
         b2.data_ptr(), rate.data_ptr(), shift.data_ptr(), int(diffusion[0]), float(diffusion[1]), int(activation),
-        1 if ito else 0, schedule.struct(), int(k_lo), int(k_hi), bm._key, bm._elem0,
+        (1 if ito else 0) | (2 if milstein else 0), schedule.struct(), int(k_lo), int(k_hi), bm._key, bm._elem0,
         None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
     _native.check(code, "tsde_adjoint_mlp_diag")
 
 
 class _MlpAdjointFn(torch.autograd.Function):
-    """Forward: the sampling kernel, outputs only. Backward: the stochastic adjoint, Euler, on the matrix cores."""
+    """Forward: the sampling kernel, outputs only. Backward: the stochastic adjoint (Euler or Milstein steps) on the
+    matrix cores."""
 
     STASH_BYTES = 3 << 30      # per-chunk stash of the backward sweep (four (steps, rows, width) float32 arrays)
 
     @staticmethod
-    def forward(ctx, activation, diffusion, method_code, ito, schedule, backward_schedule, out_steps, bm, y0, w1, b1, w2,
-                b2, rate, shift):
+    def forward(ctx, activation, diffusion, method_code, ito, backward_kind, schedule, backward_schedule, out_steps, bm,
+                y0, w1, b1, w2, b2, rate, shift):
         rows, d = y0.shape
         y0c = _native.contiguous(y0.detach())
         coefs = [p.detach().reshape(-1).expand(d).contiguous() for p in (rate, shift)]
@@ -65,6 +70,7 @@ class _MlpAdjointFn(torch.autograd.Function):
                               schedule, bm)
         ctx.save_for_backward(ys, w1_in, b1c, w2_in, b2c, coefs[0], coefs[1])
         ctx.activation, ctx.diffusion, ctx.ito = int(activation), (int(diffusion[0]), float(diffusion[1])), bool(ito)
+        ctx.backward_kind = backward_kind
         ctx.schedule, ctx.bm, ctx.out_steps = backward_schedule, bm, tuple(out_steps)
         ctx.param_shapes = (tuple(rate.shape), tuple(shift.shape))
         ctx.generic = None
@@ -99,7 +105,8 @@ class _MlpAdjointFn(torch.autograd.Function):
                 k_lo = max(boundaries[i - 1], k_hi - chunk)
                 n = k_hi - k_lo
                 adjoint_mlp_diag(y, a, stashes, row_rate, row_shift, w1_in, b1c, w2_in, b2c, rate, shift, ctx.diffusion,
-                                 ctx.activation, ctx.ito, ctx.schedule, k_lo, k_hi, ctx.bm)
+                                 ctx.activation, ctx.ito, ctx.schedule, k_lo, k_hi, ctx.bm,
+                                 milstein=ctx.backward_kind == "milstein")
                 flat_a = stashes[0][:n].reshape(n * rows, d)
                 flat_hid = stashes[1][:n].reshape(n * rows, hidden)
                 flat_delta = stashes[2][:n].reshape(n * rows, hidden)
@@ -116,8 +123,8 @@ class _MlpAdjointFn(torch.autograd.Function):
             per_channel = acc.sum(dim=0)
             diffusion.append(per_channel.reshape(shape) if int(np.prod(shape, dtype=np.int64)) == d and len(shape) == 1
                              else per_channel.sum().reshape(shape))
-        grad_y0 = a if ctx.needs_input_grad[8] else None
-        return (None,) * 8 + (grad_y0, g_w1, g_b1, g_w2, g_b2, diffusion[0], diffusion[1])
+        grad_y0 = a if ctx.needs_input_grad[9] else None
+        return (None,) * 9 + (grad_y0, g_w1, g_b1, g_w2, g_b2, diffusion[0], diffusion[1])
 
 
     @staticmethod
@@ -130,10 +137,10 @@ class _MlpAdjointFn(torch.autograd.Function):
         params = [p for p in own if p.requires_grad]
         with _native.on_device_of(ys):
             plan = adjoint._plan_backward(ts_host, dt, ctx.bm, ys.device)
-            a_y, a_theta = adjoint_double.run(adjoint.AdjointSDE(sde, params), "euler", ctx.bm, plan, ys, gys)
+            a_y, a_theta = adjoint_double.run(adjoint.AdjointSDE(sde, params), ctx.backward_kind, ctx.bm, plan, ys, gys)
         a_theta = iter(a_theta)
         grads = [next(a_theta) if p.requires_grad else None for p in own]
-        return (None,) * 8 + (a_y if ctx.needs_input_grad[8] else None, *grads)
+        return (None,) * 9 + (a_y if ctx.needs_input_grad[9] else None, *grads)
 
 
 def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, options, adjoint_options,
@@ -141,7 +148,8 @@ def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptiv
     """`ys` with a grad_fn towards y0 and the module's six parameters if this call can take the kernels above, else
     None (the caller then runs the stepwise stochastic adjoint)."""
     from .sde import ForwardSDE
-    if (adaptive or adjoint_adaptive or extra_solver_state is not None or adjoint_method != METHODS.euler
+    if (adaptive or adjoint_adaptive or extra_solver_state is not None or adjoint_method not in _BACKWARD_KINDS
+            or adjoint_options.get(METHOD_OPTIONS.grad_free, False) or options.get(METHOD_OPTIONS.grad_free, False)
             or not options.get("trajectory_kernel", True) or not adjoint_options.get("trajectory_kernel", True)):
         return None
     base = getattr(sde, "_base_sde", None)
@@ -208,8 +216,9 @@ def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptiv
                                            y0.dtype)
     backward_schedule = K.TrajectorySchedule.cached(rows_for(backward_dt), cells, out_steps,
                                                     [(0.0, 1.0)] * len(out_steps), y0.device, y0.dtype)
-    ys = _MlpAdjointFn.apply(spec[-2], tuple(spec[-1]), code, sde.sde_type == SDE_TYPES.ito, schedule,
-                             backward_schedule, tuple(int(k) for k in out_steps), bm, y0, *own)
+    ys = _MlpAdjointFn.apply(spec[-2], tuple(spec[-1]), code, sde.sde_type == SDE_TYPES.ito,
+                             _BACKWARD_KINDS[adjoint_method], schedule, backward_schedule,
+                             tuple(int(k) for k in out_steps), bm, y0, *own)
     if ys.grad_fn is not None:           # what a second-order backward pass needs (`ys.grad_fn` is the Function's ctx)
         ys.grad_fn.generic = (sde, ts_host, dt, own)
     return ys
