@@ -5,7 +5,6 @@ gen_closed_form, gen_closed_form_affine) on the increments of the counter-RNG pa
 GPU from (entropy, cell)."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -8,7 +8,6 @@ torchsde_amd.ElementwiseDiagonalSDE; ``-m gpu``) against
 """
 import os
 
-import numpy as np
 import pytest
 import torch
 
