@@ -330,3 +330,25 @@ def test_closed_form_route_ignores_subclasses_that_change_the_dynamics():
     patched = torchsde_amd.AffineDiagonalSDE(1.0, 0.0, 0.5, 0.0)
     patched.g = lambda t, y: y * 0.0 + 1.0
     assert not closed_form.publishes_its_own_dynamics(patched)
+
+
+# ---- an empty batch launches nothing (so it runs here): shapes of every return form -----------------------------------
+def test_empty_batch_returns_the_reference_shapes():
+    ts = torch.tensor([0.0, 0.25, 0.5])
+    y = torch.zeros(0, 4)
+    assert torchsde_amd.sdeint(problems.make("gbm_ito"), y, ts, dt=0.1, method="euler").shape == (3, 0, 4)
+    ys, extras = torchsde_amd.sdeint(problems.make("gbm_strat"), y, ts, dt=0.1, method="reversible_heun", extra=True)
+    assert ys.shape == (3, 0, 4) and [tuple(e.shape) for e in extras] == [(0, 4)] * 3
+    ys, log_ratio = torchsde_amd.sdeint(problems.make("gbm_ito"), y, ts, dt=0.1, method="euler", logqp=True)
+    assert ys.shape == (3, 0, 4) and log_ratio.shape == (2, 0)
+    y_grad = torch.zeros(0, 4, requires_grad=True)
+    sde = problems.make("general_ito", d=4, m=3)
+    out = torchsde_amd.sdeint_adjoint(sde, y_grad, ts, dt=0.1)
+    out.sum().backward()
+    assert out.shape == (3, 0, 4) and y_grad.grad.shape == (0, 4)
+
+
+def test_empty_brownian_interval_answers_without_a_device():
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(0, 3), levy_area_approximation="space-time")
+    W, U = bm(0.1, 0.7, return_U=True)
+    assert W.shape == (0, 3) and U.shape == (0, 3)

@@ -791,6 +791,9 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
             return contract.parse_return(y0, ys, (), extra, logqp)
     if extra_solver_state is None:
         extra_solver_state = solver.init_extra_solver_state(ts[0], y0)
+    if y0.numel() == 0:      # an empty batch: nothing to launch, and no trajectory for a gradient to come from
+        ys = y0.unsqueeze(0).repeat(len(ts), *([1] * y0.dim()))
+        return contract.parse_return(y0, ys, tuple(extra_solver_state), extra, logqp)
 
     ys, *extra_solver_state = _SdeintAdjointMethod.apply(
         sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,

@@ -302,7 +302,7 @@ class BrownianInterval(BaseBrownian):
             out_W = torch.empty(self._size, dtype=self._dtype, device=self._device)
         if want_U and out_U is None:
             out_U = torch.empty(self._size, dtype=self._dtype, device=self._device)
-        if not (ta < tb):
+        if not (ta < tb) or self._numel == 0:     # (an empty batch: empty increments, nothing to launch)
             out_W.zero_()
             if want_U:
                 out_U.zero_()

@@ -33,5 +33,8 @@ def _sdeint(sde, y0, ts, bm, method, dt, adaptive, rtol, atol, dt_min, options, 
                         options=options)
     if extra_solver_state is None:
         extra_solver_state = solver.init_extra_solver_state(ts[0], y0)
+    if y0.numel() == 0:      # an empty batch: nothing to launch (the reference's loop runs on empty tensors)
+        ys = y0.unsqueeze(0).repeat(len(ts), *([1] * y0.dim()))
+        return contract.parse_return(y0, ys, tuple(extra_solver_state), extra, logqp)
     ys, extra_solver_state = solver.integrate(y0, ts, extra_solver_state)
     return contract.parse_return(y0, ys, extra_solver_state, extra, logqp)
