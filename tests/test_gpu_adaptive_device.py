@@ -128,3 +128,36 @@ def test_two_output_times_inside_one_step_and_dt_min():
     torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-11)      # pinned at dt_min: both take the same steps
 
 
+
+
+@pytest.mark.parametrize("method,levy", [("milstein", "none"), ("srk", "space-time"), ("euler", "none")])
+def test_attempt_replayed_as_a_cached_graph_is_bit_identical(method, levy):
+    """``options={"hip_graph": True}`` on a device-controlled adaptive solve: the attempt is captured once per SDE object
+    and structure and replayed by later solves (other entropy, other y0, other output times and tolerances of the
+    controller's state) -- the same launches, so the same bits as the eagerly issued solve."""
+    import warnings
+    import torchsde_amd
+    from torchsde_amd import adaptive
+    B, d = 96, 8
+    sde = problems.make("gbm_ito", d=d).to(DEV)
+
+    def solve(entropy, y_value, ts, graph):
+        bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, d), device=DEV, dtype=torch.float32, entropy=entropy,
+                                           levy_area_approximation=levy)
+        y0 = torch.full((B, d), y_value, device=DEV)
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ys = torchsde_amd.sdeint(sde, y0, torch.tensor(ts, device=DEV), bm=bm, method=method, dt=0.05, adaptive=True,
+                                     rtol=1e-3, atol=1e-4, options={"hip_graph": graph})
+        return ys, dict(adaptive.last_stats)
+
+    for k, (entropy, y_value, ts) in enumerate([(5, 0.1, [0.0, 0.5, 1.0]), (6, 0.3, [0.0, 0.25, 0.5, 1.0]),
+                                                (7, 0.2, [0.0, 1.0])]):
+        eager, stats_eager = solve(entropy, y_value, ts, False)
+        graphed, stats_graph = solve(entropy, y_value, ts, True)
+        assert stats_eager["launch"] == "eager" and stats_graph["launch"] == "graph replay"
+        assert stats_graph["attempts_used"] == stats_eager["attempts_used"] > 3
+        assert torch.equal(eager, graphed), (k, (eager - graphed).abs().max().item())
+    from torchsde_amd import graph as graph_module
+    cached = [key for key in graph_module._cache_of(sde) if key[0] == "adaptive-attempt"]
+    assert len(cached) == 1                                     # three solves, one capture

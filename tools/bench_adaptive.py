@@ -1,5 +1,6 @@
 """Adaptive solves (step doubling, Milstein on GBM over [0, 1], 4 output times): accept / reject decided on the device
-(adaptive.py: the host synchronises once per round of attempts) vs decided on the host (one sync per attempt)."""
+(adaptive.py: the host synchronises once per round of attempts; eagerly issued, or with the attempt replayed as a
+cached HIP graph) vs decided on the host (one sync per attempt)."""
 import sys
 import time
 
@@ -16,18 +17,19 @@ for (B, d) in ((1024, 16), (65536, 64)):
     y0 = torch.full((B, d), 0.1, device=dev)
     ts = torch.tensor([0.0, 0.25, 0.5, 0.75, 1.0], device=dev)
 
-    def solve(i, device_control):
+    def solve(i, device_control, graph):
         bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, d), device=dev, dtype=torch.float32, entropy=i)
         with torch.no_grad():
             return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="milstein", dt=0.05, adaptive=True, rtol=1e-3,
-                                       atol=1e-4, options={"device_adaptive": device_control})
-    for device_control, label in ((True, "device"), (False, "host  ")):
-        solve(0, device_control)
+                                       atol=1e-4, options={"device_adaptive": device_control, "hip_graph": graph})
+    for device_control, graph, label in ((True, False, "device             "), (True, True, "device, graph replay"),
+                                         (False, False, "host               ")):
+        solve(0, device_control, graph)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        for i in range(3):
-            out = solve(1 + i, device_control)
+        for i in range(5):
+            out = solve(1 + i, device_control, graph)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / 3 * 1e3
+        ms = (time.perf_counter() - t) / 5 * 1e3
         stats = adaptive.last_stats if device_control else "one sync per attempt"
         print(f"B={B} d={d} adaptive milstein, control on the {label}: {ms:8.2f} ms per solve   {stats}")

@@ -31,19 +31,23 @@ class DeviceController:
     """The two device tables of one adaptive solve (`ctl`: float64 state, `scal`: scalars of the solve's dtype) and the
     launches that maintain them."""
 
-    def __init__(self, device, dtype, t0, t_end, step_size, dt_min, stage_fracs):
+    def __init__(self, device, dtype, stage_fracs):
+        self.ctl = torch.zeros(_native.CTL_SIZE, dtype=torch.float64, device=device)
+        self.scal = torch.zeros(_native.SCAL_SIZE, dtype=dtype, device=device)
+        self.dtype, self.device = dtype, device
+        self.n_fracs = len(stage_fracs)
+        self._fracs = (ctypes.c_double * max(self.n_fracs, 1))(*[float(f) for f in stage_fracs])
+        self._lib, self._dt_code, _ = K._launch_env(self.scal)
+
+    def load(self, t0, t_end, step_size, dt_min):
+        """The state a solve starts from: the one host->device copy of the solve."""
         host = np.zeros(_native.CTL_SIZE, dtype=np.float64)
         host[_native.CTL_CURR_T] = host[_native.CTL_PREV_T] = t0
         host[_native.CTL_STEP_SIZE] = step_size
         host[_native.CTL_PREV_ERROR_RATIO] = np.nan
         host[_native.CTL_T_END] = t_end
         host[_native.CTL_DT_MIN] = dt_min
-        self.ctl = torch.from_numpy(host).to(device)             # the one host->device copy of the solve
-        self.scal = torch.zeros(_native.SCAL_SIZE, dtype=dtype, device=device)
-        self.dtype, self.device = dtype, device
-        self.n_fracs = len(stage_fracs)
-        self._fracs = (ctypes.c_double * max(self.n_fracs, 1))(*[float(f) for f in stage_fracs])
-        self._lib, self._dt_code, _ = K._launch_env(self.scal)
+        self.ctl.copy_(torch.from_numpy(host))
 
     def _stream(self):
         return K._launch_env(self.scal)[2]
@@ -110,6 +114,127 @@ def usable(solver, y0, ts):
             and len(solver.stage_fracs) <= _native.ADAPTIVE_MAX_STAGES - 1 and y0.numel() > 0)
 
 
+class _Attempt:
+    """The buffers of a device-controlled adaptive solve and the launch sequence of ONE attempted step: two generator
+    queries (the halves), the whole step merged from them, three steps, the error norm, the decision, the commit. Every
+    launch reads what changes between attempts from the controller's tables, so the sequence is the same every time."""
+
+    def __init__(self, solver, y0, step_cls):
+        bm = solver._native_bm()
+        device, dtype = y0.device, y0.dtype
+        self.ctrl = ctrl = DeviceController(device, dtype, solver.stage_fracs)
+        self.curr_y, self.prev_y = (torch.empty_like(y0, memory_format=torch.contiguous_format) for _ in range(2))
+        self.y_full, self.y_mid, self.y_next = (torch.empty_like(self.curr_y) for _ in range(3))
+        want_U = solver.needs_U and bm._have_H
+        shape = tuple(bm.shape)
+
+        def buf():
+            return torch.empty(shape, dtype=bm.dtype, device=device)
+        self.W, self.Wa, self.Wb = buf(), buf(), buf()
+        self.U, self.Ua, self.Ub, self.Ha, self.Hb = (buf(), buf(), buf(), buf(), buf()) if want_U else (None,) * 5
+        noises = (NoiseSpec.external(self.W, self.U), NoiseSpec.external(self.Wa, self.Ua),
+                  NoiseSpec.external(self.Wb, self.Ub))
+        self.steps = [step_cls(ctrl.times(s), ctrl.scalar(s, _native.SUB_DT), noises[s], None, None,
+                               half_dt=ctrl.scalar(s, _native.SUB_HALF_DT), sqrt_dt=ctrl.scalar(s, _native.SUB_SQRT_DT),
+                               rdt=ctrl.scalar(s, _native.SUB_RDT)) for s in range(3)]
+        self.w0 = _native.dev_scalar(ctrl.scal, _native.SCAL_W0)
+        self.w1 = _native.dev_scalar(ctrl.scal, _native.SCAL_W1)
+        self.rtol, self.atol = solver.rtol, solver.atol
+        self.norm_scratch = K.error_norm_scratch(device)
+
+    def load(self, y0, t0, t_end, step_size, dt_min, bm):
+        self.ctrl.load(t0, t_end, step_size, dt_min)
+        self.curr_y.copy_(y0)
+        self.prev_y.copy_(y0)
+
+    def _launch(self, solver, bm):
+        ctrl = self.ctrl
+
+        def advance(y, st, out):
+            res = solver._advance(y, st, out)
+            if res.data_ptr() != out.data_ptr():      # a path that allocates its own result
+                out.copy_(res)
+
+        query_dev(bm, ctrl.bounds_ptr(0), self.Wa, self.Ua, self.Ha)
+        query_dev(bm, ctrl.bounds_ptr(1), self.Wb, self.Ub, self.Hb)
+        ctrl.merge_halves(self.W, self.U, self.Wa, self.Ha, self.Wb, self.Hb)
+        advance(self.curr_y, self.steps[0], self.y_full)
+        advance(self.curr_y, self.steps[1], self.y_mid)
+        advance(self.y_mid, self.steps[2], self.y_next)
+        ctrl.control(K.error_norm(self.y_full, self.y_next, self.rtol, self.atol, scratch=self.norm_scratch))
+        ctrl.commit(self.prev_y, self.curr_y, self.y_next)
+
+    def run(self, solver, bm, n):
+        for _ in range(n):
+            self._launch(solver, bm)
+
+
+class _GraphedAttempt(_Attempt):
+    """``options={"hip_graph": True}``: the attempt as a HIP graph, cached on the user's SDE object like the graphs of
+    fixed-step solves (graph.py) and replayed by every later solve of the same structure. An attempt is ~30 short
+    launches; capturing them costs 30-45 ms, so this only pays across solves -- then an attempt costs one launch of
+    the host. What a new solve brings is loaded into the static buffers: the controller's state, y0, and the
+    Brownian motion's entropy (the generator kernels read it from one device word)."""
+
+    def __init__(self, solver, y0, step_cls):
+        super().__init__(solver, y0, step_cls)
+        bm = solver._native_bm()
+        device = y0.device
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self._keepalive = bm            # the captured kernels read this generator's device copy of its cell edges
+        self._set_seed(bm)
+        bm._entropy_dev = self.seed_dev
+        try:
+            # any consistent state will do for the warm-up and the capture: the launches read it from the tables
+            self.load(y0, float(bm._t0), float(bm._t1), float(bm._t1 - bm._t0), 0.0, bm)
+            self.ctrl.begin(float(bm._t1))
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
+                self._launch(solver, bm)
+            torch.cuda.current_stream(device).wait_stream(side)
+            from . import graph as graph_module
+            self.graph = torch.cuda.CUDAGraph()
+            with graph_module._no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self._launch(solver, bm)
+        finally:
+            bm._entropy_dev = None
+        self.steps = None               # (they reference the solver's SDE: no cycle through the cache on that object)
+
+    def _set_seed(self, bm):
+        key = bm._key
+        self.seed_dev.fill_(key - (1 << 64) if key >= (1 << 63) else key)
+
+    def load(self, y0, t0, t_end, step_size, dt_min, bm):
+        super().load(y0, t0, t_end, step_size, dt_min, bm)
+        self._set_seed(bm)
+
+    def run(self, solver, bm, n):
+        for _ in range(n):
+            self.graph.replay()
+
+
+def _attempt_for(solver, y0, ts_host, step_cls):
+    """This solve's `_Attempt`: a fresh one, or with ``hip_graph`` the cached graph of the same structure."""
+    if not solver.options.get("hip_graph", False):
+        return _Attempt(solver, y0, step_cls)
+    from . import graph as graph_module
+    bm = solver._native_bm()
+    chain, base = graph_module._wrapper_chain(solver.sde)
+    params = tuple(p.data_ptr() for p in base.parameters()) if hasattr(base, "parameters") else ()
+    sig = ("adaptive-attempt", type(solver).__name__, chain, getattr(solver.sde, "sde_type", None),
+           getattr(solver.sde, "noise_type", None), params, tuple(y0.shape), y0.dtype, str(y0.device),
+           float(solver.rtol), float(solver.atol), tuple(bm.shape), bm.levy_area_approximation, bm.row_offset,
+           bm._edges.tobytes(), bm._max_depth,
+           tuple(sorted((k, v) for k, v in solver.options.items() if isinstance(v, (bool, int, float, str)))))
+    cache = graph_module._cache_of(base)
+    attempt = cache.get(sig)
+    if attempt is None:
+        attempt = _GraphedAttempt(solver, y0, step_cls)
+        graph_module._remember(cache, sig, attempt)
+    return attempt
+
+
 def integrate(solver, y0, ts, extra0, step_cls):
     """The adaptive solve of `solver` (see the module docstring). Returns (ys, extra solver state)."""
     bm = solver._native_bm()
@@ -121,53 +246,15 @@ def integrate(solver, y0, ts, extra0, step_cls):
     solver._extra = tuple(extra0) if extra0 is not None else ()
     bm.locate(float(ts_host[0]), float(ts_host[-1]))        # freezes a generator that never saw a grid
     bm._device_edges()
-    ctrl = DeviceController(device, dtype, float(ts_host[0]), float(ts_host[-1]), float(step_size),
-                            float(solver.dt_min), solver.stage_fracs)
-
     T = len(ts_host)
     ys = torch.empty((T,) + tuple(y0.shape), dtype=dtype, device=device)
     ys[0].copy_(y0)
-    curr_y, prev_y = y0.detach().clone().contiguous(), y0.detach().clone().contiguous()
-    y_full, y_mid, y_next = (torch.empty_like(curr_y) for _ in range(3))
-    want_U = solver.needs_U and bm._have_H
-    shape = tuple(bm.shape)
-
-    def buf():
-        return torch.empty(shape, dtype=bm.dtype, device=device)
-    W, Wa, Wb = buf(), buf(), buf()
-    U, Ua, Ub, Ha, Hb = (buf(), buf(), buf(), buf(), buf()) if want_U else (None,) * 5
-    noises = (NoiseSpec.external(W, U), NoiseSpec.external(Wa, Ua), NoiseSpec.external(Wb, Ub))
-    steps = [step_cls(ctrl.times(s), ctrl.scalar(s, _native.SUB_DT), noises[s], None, None,
-                      half_dt=ctrl.scalar(s, _native.SUB_HALF_DT), sqrt_dt=ctrl.scalar(s, _native.SUB_SQRT_DT),
-                      rdt=ctrl.scalar(s, _native.SUB_RDT)) for s in range(3)]
-    w0, w1 = _native.dev_scalar(ctrl.scal, _native.SCAL_W0), _native.dev_scalar(ctrl.scal, _native.SCAL_W1)
-    rtol, atol = solver.rtol, solver.atol
-
-    def advance(y, st, out):
-        res = solver._advance(y, st, out)
-        if res.data_ptr() != out.data_ptr():      # a path that allocates its own result
-            out.copy_(res)
-
-    def attempt():
-        # two generator queries (the halves), the whole step merged from them; three steps; error norm; decision
-        query_dev(bm, ctrl.bounds_ptr(0), Wa, Ua, Ha)
-        query_dev(bm, ctrl.bounds_ptr(1), Wb, Ub, Hb)
-        ctrl.merge_halves(W, U, Wa, Ha, Wb, Hb)
-        advance(curr_y, steps[0], y_full)
-        advance(curr_y, steps[1], y_mid)
-        advance(y_mid, steps[2], y_next)
-        ctrl.control(K.error_norm(y_full, y_next, rtol, atol))
-        ctrl.commit(prev_y, curr_y, y_next)
-
-    # (Replaying the attempt as a HIP graph was measured and dropped: an attempt is ~30 launches, capturing them costs
-    # 30-45 ms per solve, far more than a solve's 25-30 attempts save -- it would only pay with the graph cached across
-    # solves, i.e. with every buffer above made static per SDE object.)
-    def run_attempts(n):
-        for _ in range(n):
-            attempt()
 
     curr_t, dt_min_hits, syncs, attempts, state = float(ts_host[0]), 0.0, 0, 0, None
     with torch.no_grad():
+        attempt = _attempt_for(solver, y0, ts_host, step_cls)
+        attempt.load(y0.detach(), float(ts_host[0]), float(ts_host[-1]), float(step_size), float(solver.dt_min), bm)
+        ctrl = attempt.ctrl
         for i in range(1, T):
             out_t = ts_host[i]
             ctrl.begin(float(out_t))
@@ -178,7 +265,7 @@ def integrate(solver, y0, ts, extra0, step_cls):
                 # kernels, while a shortfall costs one more (cheap) round.
                 need = int(math.ceil((float(out_t) - curr_t) / max(step_size, solver.dt_min)))
                 budget = min(max(1, need - 1 if need > 2 else need), 256)
-                run_attempts(budget)
+                attempt.run(solver, bm, budget)
                 attempts += budget
                 state = ctrl.read()
                 syncs += 1
@@ -189,10 +276,10 @@ def integrate(solver, y0, ts, extra0, step_cls):
                     dt_min_hits = state[_native.CTL_DT_MIN_HITS]
                     warnings.warn("Hitting minimum allowed step size in adaptive time-stepping.")
                 curr_t, step_size = float(state[_native.CTL_CURR_T]), float(state[_native.CTL_STEP_SIZE])
-            K.linear_interp(prev_y, curr_y, w0, w1, out=ys[i])
+            K.linear_interp(attempt.prev_y, attempt.curr_y, attempt.w0, attempt.w1, out=ys[i])
     global last_stats
     final = ctrl.read() if state is None else state
     last_stats = {"control": "device", "host_syncs": syncs, "output_times": T - 1, "attempts_enqueued": attempts,
                   "attempts_used": int(final[_native.CTL_ATTEMPTS]), "accepted": int(final[_native.CTL_ACCEPTED]),
-                  "dtype": np_dtype.__name__}
+                  "dtype": np_dtype.__name__, "launch": "graph replay" if hasattr(attempt, "graph") else "eager"}
     return ys, solver._extra

@@ -472,15 +472,20 @@ def merge_halves(W, U, Wa, Ha, Wb, Hb, ha=0.0, hb=0.0, ctl=None):
 _ERROR_NORM_SCRATCH = {}
 
 
-def error_norm(y_full, y_half, rtol, atol, eps=1e-7):
+def error_norm_scratch(device):
+    """A workspace + result buffer for `error_norm` (callers that replay their launches keep their own)."""
+    return torch.empty(_native.ERROR_NORM_WORKSPACE + 1, dtype=torch.float64, device=device)
+
+
+def error_norm(y_full, y_half, rtol, atol, eps=1e-7, scratch=None):
     """Scaled RMS difference of a full step and two half steps (adaptive_stepping.py:42-76) as a 0-d float64
     device tensor: one fused, deterministic reduction (``tsde_error_norm``). The caller reads it with ``.item()``."""
     y_full = _native.contiguous(y_full.detach())
     y_half, = _prep(y_full, y_half.detach())
     lib, dt_code, stream = _launch_env(y_full)
     dev = y_full.device
-    buf = _ERROR_NORM_SCRATCH.get((dev, stream))   # one scratch per stream: launches on a stream are ordered
-    if buf is None:
+    buf = scratch if scratch is not None else _ERROR_NORM_SCRATCH.get((dev, stream))   # one scratch per stream:
+    if buf is None:                                                                    # launches on a stream are ordered
         buf = torch.empty(_native.ERROR_NORM_WORKSPACE + 1, dtype=torch.float64, device=dev)
         _ERROR_NORM_SCRATCH[(dev, stream)] = buf
     out = buf[_native.ERROR_NORM_WORKSPACE:]
