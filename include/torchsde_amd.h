@@ -331,7 +331,10 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  *   (the transpose of torch.nn.Linear.weight). d a multiple of 4 up to 128, hidden up to 128 -- up to 256 when
  *   d <= 64: both weight arrays have to fit the LDS of a CU -- (both are zero-padded
  *   to the MFMA tile sizes inside the kernel); rows * d < 2^30; ys, y0 16-byte aligned; dtype must be TSDE_F32;
- *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT, TSDE_TRAJ_MIDPOINT}.
+ *   method in {TSDE_TRAJ_EULER, TSDE_TRAJ_MILSTEIN_ITO, TSDE_TRAJ_MILSTEIN_STRAT, TSDE_TRAJ_MIDPOINT, TSDE_TRAJ_SRK}
+ *   (SRK = SRID2, torchsde/_core/methods/srk.py:57-88: three drift evaluations per step -- the tableau's alpha_3 = 0 --
+ *   and, the diffusion being diagonal, all four diffusion stages elementwise; the increments' second stream H gives the
+ *   space-time Levy area U = h (W/2 + H) of the cell).
  * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
 #define TSDE_ACT_TANH 0
@@ -383,9 +386,10 @@ int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d,
  *   stash_y      (k_hi-k_lo, rows, d)       out: the y the step was evaluated at
  *       => dL/dW2 += stash_a^T stash_hid, dL/dW1 += stash_delta^T stash_y (tsde_gram_partials),
  *          dL/db2 += column sums of stash_a, dL/db1 += column sums of stash_delta
- *   row_rate, row_shift (rows, d)  accumulated in place: per trajectory sums of a (dW dg/dc - ito dt g dg'/dc) and of
- *                a (dW dg/de - ito dt g dg'/de) (Milstein: + a v (g' dg/dtheta - g dg'/dtheta)); their batch sums are
- *                dL/d diff_rate, dL/d diff_shift
+ *   row_rate, row_shift (rows, d)  accumulated in place: sums over the steps AND over each aligned group of 16 rows (row
+ *                16 k receives rows 16 k .. 16 k + 15; the other rows are left as they are) of
+ *                a (dW dg/dc - ito dt g dg'/dc) and a (dW dg/de - ito dt g dg'/de) (Milstein: + a v (g' dg/dtheta -
+ *                g dg'/dtheta)); their sums over all rows are dL/d diff_rate, dL/d diff_shift
  * Shapes, layouts and limits as tsde_trajectory_mlp_diag_backward; b2 (d) is the output bias of the drift. */
 int tsde_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void* stash_delta, void* stash_y,
                           void* row_rate, void* row_shift, int64_t rows, int64_t d, int64_t hidden, const void* w1,

@@ -450,8 +450,8 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
   if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
   if (activation != TSDE_ACT_TANH && activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
   if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MILSTEIN_ITO && method != TSDE_TRAJ_MILSTEIN_STRAT &&
-      method != TSDE_TRAJ_MIDPOINT)
-    return bad_arg(where, "method must be Euler, Milstein or midpoint");
+      method != TSDE_TRAJ_MIDPOINT && method != TSDE_TRAJ_SRK)
+    return bad_arg(where, "method must be Euler, Milstein, midpoint or SRK");
   if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");

@@ -30,7 +30,8 @@
 //
 // A wave owns 16 batch rows for all steps of the launch; y and a stay in registers in the MFMA accumulator layout; dW is
 // regenerated from the counter RNG; the per-step factors of the weight gradients (dt a, h, delta, y) go to a stash in
-// HBM for tsde_gram_partials (mlp_backward.hip), and the diffusion-parameter sums ride in registers. Memory is O(chunk),
+// HBM for tsde_gram_partials (mlp_backward.hip); the diffusion-parameter terms are summed over the wave's 16 rows with
+// DPP row shifts and accumulated per wave in LDS. Memory is O(chunk),
 // independent of the number of steps: nothing of the forward pass is kept but the states at the output times.
 #include <type_traits>
 
@@ -47,8 +48,8 @@ struct MlpAdjArgs {
   float* stash_hid;         // (k_hi - k_lo, B, h)   act(W1^T y + b1)
   float* stash_delta;       // (k_hi - k_lo, B, h)   delta
   float* stash_y;           // (k_hi - k_lo, B, d)   the y the step was evaluated at
-  float* row_rate;          // (B, d)  += per-trajectory sums for dL/dc   (the caller sums over the batch)
-  float* row_shift;         // (B, d)  += ... for dL/de
+  float* row_rate;          // (B, d)  row 16 k += the sums of rows 16 k .. 16 k + 15 for dL/dc (the caller sums over the batch)
+  float* row_shift;         // (B, d)  ... for dL/de
   const float* W1;          // (d, h) input-major, as MlpArgs
   const float* b1;          // (h)
   const float* W2;          // (h, d)
@@ -66,6 +67,16 @@ struct MlpAdjArgs {
   const uint64_t* key_dev;
 };
 
+// Sum of `v` over the 16 lanes of a DPP row, valid in the row's last lane (inclusive scan by row_shr 1, 2, 4, 8; lanes
+// shifted in from outside the row read 0).
+TSDE_D float row_total(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+
 template <int D, int H, int ACT, int NW, bool FULL, bool MILSTEIN>
 __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p) {
   constexpr int R = 16;
@@ -79,6 +90,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
   float* b2s = b1s + H;             // D
   float* cs = b2s + D;              // D
   float* es = cs + D;               // D
+  float* sums = es + D;             // NW x 2 x D: per wave, the diffusion-parameter sums (rate, shift) of its 16 rows
   const int dT = p.d, hT = p.h;
   for (int i = threadIdx.x; i < D * H; i += kThreads) {
     const int k1 = i / H, m1 = i % H, k2 = i / D, m2 = i % D;
@@ -91,6 +103,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
     cs[i] = i < dT ? p.c[i] : 0.0f;
     es[i] = i < dT ? p.e[i] : 0.0f;
   }
+  for (int i = threadIdx.x; i < NW * 2 * D; i += kThreads) sums[i] = 0.0f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,6 +112,8 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
   const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * R;
   if (row0 >= p.B) return;
   const int64_t row = row0 + n < p.B ? row0 + n : p.B - 1;
+  const float own_row = row0 + n < p.B ? 1.0f : 0.0f;     // (a shadow lane of the last partial wave adds nothing to the sums)
+  float* wave_sums = sums + wave * 2 * D;
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
     const uint64_t ent = *p.key_dev;
@@ -222,6 +237,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
         const f32x4 cq = lds_quad(cs, ch);
         const f32x4 eq = lds_quad(es, ch);
         const f32x4 bq = lds_quad(b2s, ch);
+        float rate_terms[4], shift_terms[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float yt = y[t][r], at = a[t][r], cc = cq[r];
@@ -242,13 +258,33 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
           const float adg = ito * ((at * dt) * g);                           // dt a g   (Ito correction terms)
           const float gpp = qp * (cc * cc);                                  // g''
           float a1 = at + (aw * gp - adg * gpp), y1 = (yt - drift * dt) - g * w;
+          // the terms of dL/de, dL/dc: a (dW dg/dtheta - ito dt g dg'/dtheta), with dg/de = q, dg'/de = q' c, dg/dc = q y,
+          // dg'/dc = q + q' c y (Milstein: + a v (g' dg/dtheta - g dg'/dtheta))
+          const float dgp_de = qp * cc, dgp_dc = dgp_de * yt + q;
+          float to_shift = aw * q - adg * dgp_de, to_rate = (aw * q) * yt - adg * dgp_dc;
           if constexpr (kMilstein) {
-            const float v = 0.5f * (w * w - ito * dt);
-            a1 += (at * v) * (gp * gp - g * gpp);
+            const float v = 0.5f * (w * w - ito * dt), av = at * v;
+            a1 += av * (gp * gp - g * gpp);
             y1 += v * (g * gp);
+            to_shift += av * (gp * q - g * dgp_de);
+            to_rate += av * (gp * (q * yt) - g * dgp_dc);
           }
+          rate_terms[r] = row_total(to_rate * own_row);
+          shift_terms[r] = row_total(to_shift * own_row);
           a[t][r] = a1;
           y[t][r] = y1;
+          // (materialised HERE: left alone, the compiler sinks this arithmetic past the last product of the step and
+          //  keeps its inputs alive until then -- 226 spilled dwords in the 8-wave 128 x 128 Milstein variant, 10 with)
+          asm volatile("" : "+v"(a[t][r]), "+v"(y[t][r]));
+        }
+        // summed over the 16 rows of the wave (the 16 lanes of a DPP row hold one channel quad of 16 rows); the row's last
+        // lane adds the totals to the wave's LDS accumulators (ds_add_f32: one lane per address, in order per wave)
+        if (n == R - 1 && real_d(t)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(&wave_sums[ch + r], rate_terms[r]);
+            atomicAdd(&wave_sums[D + ch + r], shift_terms[r]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -277,58 +313,10 @@ __global__ void __launch_bounds__(NW * 64) mlp_adjoint_kernel(const MlpAdjArgs p
     store_tile(p.y, t, y[t]);
     store_tile(p.a, t, a[t]);
   }
-}
-
-// The diffusion-parameter sums of the steps of one chunk, from that chunk's stash: per trajectory and channel
-//   row_rate  += sum_k a (dW dg/dc - ito dt g dg'/dc)        row_shift += sum_k a (dW dg/de - ito dt g dg'/de)
-// with a = stash_a / dt, y = stash_y, dW regenerated. Kept out of the sweep: as 2 x D/4 more live registers per lane
-// they pushed it past 512 registers at d = 128; here they cost one more pass over two of the four stash arrays.
-__global__ void __launch_bounds__(kBlock) adjoint_diffusion_sums_kernel(const MlpAdjArgs p) {
-  NoiseKey key = p.key;
-  if (p.key_dev != nullptr) {
-    const uint64_t ent = *p.key_dev;
-    key.k0 = (uint32_t)ent;
-    key.k1 = (uint32_t)(ent >> 32);
-  }
-  const bool sigmoid = p.diff_kind == TSDE_DIFF_SIGMOID;
-  const float ito = (p.ito & 1) ? 1.0f : 0.0f, mil = (p.ito & 2) ? 1.0f : 0.0f;
-  const int64_t nq = p.B * p.d / 4, plane = p.B * p.d;
-  for (int64_t qi = (int64_t)blockIdx.x * kBlock + threadIdx.x; qi < nq; qi += (int64_t)gridDim.x * kBlock) {
-    const int64_t i = qi * 4;
-    const int ch = (int)(i % p.d);
-    const f32x4 cq = *reinterpret_cast<const f32x4*>(p.c + ch), eq = *reinterpret_cast<const f32x4*>(p.e + ch);
-    f32x4 rate = *reinterpret_cast<const f32x4*>(p.row_rate + i), shift = *reinterpret_cast<const f32x4*>(p.row_shift + i);
-    const uint64_t quad = (key.elem0 + (uint64_t)i) >> 2;
-    for (int k = p.k_hi - 1; k >= p.k_lo; --k) {
-      const float* srow = p.rows + (int64_t)k * 8;
-      const float dt = srow[0], rdt = srow[2], sw = srow[4];
-      const int64_t slot = k - p.k_lo;
-      const f32x4 sa = *reinterpret_cast<const f32x4*>(p.stash_a + slot * plane + i);
-      const f32x4 sy = *reinterpret_cast<const f32x4*>(p.stash_y + slot * plane + i);
-      float zn[4];
-      normal4<float>(key, quad, p.cells[k], 0, kStreamW, zn);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float yt = sy[r], adt = sa[r], cc = cq[r];
-        const float at = adt * rdt, w = zn[r] * sw;
-        const float u = cc * yt + eq[r];
-        float g = u, q = 1.0f, qp = 0.0f;
-        if (sigmoid) {
-          const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
-          g = p.diff_amp * s;
-          q = g * (1.0f - s);
-          qp = q * (1.0f - 2.0f * s);
-        }
-        const float aw = at * w, adg = ito * (adt * g);
-        // Milstein: + a v (g' dg/dtheta - g dg'/dtheta), g' = q c, dg/de = q, dg'/de = q' c, dg/dc = q y, dg'/dc = q + q' c y
-        const float av = mil * (at * (0.5f * (w * w - ito * dt)));
-        const float gp = q * cc, dgp_de = qp * cc, dgp_dc = dgp_de * yt + q;
-        shift[r] += (aw * q - adg * dgp_de) + av * (gp * q - g * dgp_de);
-        rate[r] += ((aw * q) * yt - adg * dgp_dc) + av * (gp * (q * yt) - g * dgp_dc);
-      }
-    }
-    *reinterpret_cast<f32x4*>(p.row_rate + i) = rate;
-    *reinterpret_cast<f32x4*>(p.row_shift + i) = shift;
+  // the wave's sums join row `row0` of (row_rate, row_shift)
+  for (int i = lane; i < dT; i += 64) {
+    p.row_rate[row0 * dT + i] += wave_sums[i];
+    p.row_shift[row0 * dT + i] += wave_sums[D + i];
   }
 }
 
@@ -336,7 +324,7 @@ template <int D, int H, int ACT, int NW, bool FULL, bool MILSTEIN>
 static hipError_t launch_adj_scheme(const MlpAdjArgs& p, hipStream_t s) {
   constexpr int R = 16;
   const size_t lds_bytes =
-      (size_t)(D * (H + MlpLds<R>::kPad) + H * (D + MlpLds<R>::kPad) + H + 3 * D) * sizeof(float);
+      (size_t)(D * (H + MlpLds<R>::kPad) + H * (D + MlpLds<R>::kPad) + H + 3 * D + NW * 2 * D) * sizeof(float);
   static bool configured = false;   // per instantiation
   if (!configured) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_adjoint_kernel<D, H, ACT, NW, FULL, MILSTEIN>),
@@ -358,8 +346,8 @@ static hipError_t launch_adj_variant(const MlpAdjArgs& p, hipStream_t s) {
 }
 
 // y, a, the f accumulators and act'(z) are 3 x D/4 + H/4 live registers per lane (128 at d = hidden = 128). The large
-// shapes exist as 8-wave blocks (two waves per SIMD, 256 registers: the unpadded 128 x 128 kernel spills 14 dwords) and
-// as 4-wave blocks (one wave per SIMD, up to 512 registers: no spills); TSDE_ADJ_WAVES=4|8 picks one (default: see below).
+// shapes exist as 8-wave blocks (two waves per SIMD, 256 registers: at most 10 spilled dwords) and as 4-wave blocks (one
+// wave per SIMD, up to 512 registers: no spills); TSDE_ADJ_WAVES=4 picks the latter (default: 8).
 template <int D, int H, int ACT>
 static hipError_t launch_adj_shape(const MlpAdjArgs& p, hipStream_t s) {
   const bool full = p.d == D && p.h == H;
@@ -368,9 +356,7 @@ static hipError_t launch_adj_shape(const MlpAdjArgs& p, hipStream_t s) {
       const char* e = getenv("TSDE_ADJ_WAVES");
       return e ? atoi(e) : 0;
     }();
-    // padded shapes: the bounds tests cost registers; Milstein steps: so do their extra terms (195 spilled dwords in
-    // the 8-wave 128 x 128 variant, none with 4 waves)
-    const bool eight = waves == 8 || (waves != 4 && full && !(p.ito & 2));
+    const bool eight = waves != 4;
     if (eight) return full ? launch_adj_variant<D, H, ACT, 8, true>(p, s) : launch_adj_variant<D, H, ACT, 8, false>(p, s);
     return full ? launch_adj_variant<D, H, ACT, 4, true>(p, s) : launch_adj_variant<D, H, ACT, 4, false>(p, s);
   } else {
@@ -433,9 +419,7 @@ hipError_t launch_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_
   if (d <= 32) r = launch_adj_h<32>(p, act, s);
   else if (d <= 64) r = launch_adj_h<64>(p, act, s);
   else if (d <= 128) r = launch_adj_h<128>(p, act, s);
-  if (r != hipSuccess) return r;
-  hipLaunchKernelGGL(adjoint_diffusion_sums_kernel, dim3(grid_for(rows * d / 4)), dim3(kBlock), 0, s, p);
-  return hipGetLastError();
+  return r;
 }
 
 }  // namespace tsde

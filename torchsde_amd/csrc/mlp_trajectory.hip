@@ -47,7 +47,7 @@ struct MlpArgs {
   int64_t B;
   int32_t d, h;             // true state / hidden sizes (d % 4 == 0); the kernel pads them to its tile sizes D, H
   int32_t n_steps, n_out;
-  int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT / _MIDPOINT
+  int32_t method;           // TSDE_TRAJ_EULER / _MILSTEIN_ITO / _MILSTEIN_STRAT / _MIDPOINT / _SRK
   int32_t diff_kind;        // TSDE_DIFF_AFFINE: g = c*y + e;  TSDE_DIFF_SIGMOID: g = diff_amp * sigmoid(c*y + e)
   float diff_amp;
   NoiseKey key;
@@ -56,12 +56,14 @@ struct MlpArgs {
 
 
 // NW = waves per block: all of them share one copy of the weights in LDS.
-// MID: the two-stage Stratonovich midpoint scheme (midpoint.py:31-43) instead of the one-stage Euler / Milstein step.
+// SCHEME: 0 = the one-stage Euler / Milstein step, 1 = the two-stage Stratonovich midpoint scheme (midpoint.py:31-43),
+// 2 = the stochastic Runge-Kutta scheme SRID2 (srk.py:57-88, tableaus/srid2.py; Ito, needs the space-time Levy area).
 // FULL: d == D and h == H (no channel padding inside the kernel), which removes every per-tile bounds test.
 // IL: explicitly scheduled step (operand reads ahead of use, noise generation between the matrix instructions) for
 // one-stage schemes, unpadded shapes, 16-row waves: see the step loop. TSDE_MLP_INTERLEAVE=0 selects the plain form.
-template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL, bool IL = false>
+template <int D, int H, int ACT, int R, int NW, int SCHEME, bool FULL, bool IL = false>
 __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p) {
+  constexpr bool MID = SCHEME == 1, SRK = SCHEME == 2;
   using TL = Tile<R>;
   using acc_t = typename TL::acc_t;
   constexpr int TD = D / R, TH = H / R, kRegs = TL::kRegs, kThreads = NW * 64;
@@ -160,6 +162,10 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
     };
     acc_t hid[TH];
     auto hidden_layer = [&](const acc_t* x) {
+      // (an opaque zero in every weight address: a multi-stage scheme evaluates the drift several times per step, and
+      //  without it the compiler merges the identical LDS reads of all evaluations -- and keeps thousands of weights)
+      int o1 = 0;
+      asm volatile("" : "+v"(o1));
 #pragma unroll
       for (int th = 0; th < TH; ++th) {
 #pragma unroll
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
         for (int t = 0; t < TD; ++t) {
 #pragma unroll
           for (int r = 0; r < kRegs; ++r) {
-            const float a = W1s[(R * t + TL::row(r, part)) * S1 + R * th + n];
+            const float a = W1s[o1 + (R * t + TL::row(r, part)) * S1 + R * th + n];
             hid[th] = TL::mfma(a, x[t][r], hid[th]);
           }
           if (R != 16 && (t + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
@@ -184,7 +190,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
       }
     };
     // ---- layer 2, one tile of channels: f^T tile = W2^T hid^T ---------------------------------------------------
-    auto drift_tile = [&](int t) {
+    auto drift_tile = [&](int t, int o2 = 0) {
       acc_t acc;
 #pragma unroll
       for (int r = 0; r < kRegs; ++r) acc[r] = 0.0f;
@@ -192,7 +198,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
       for (int th = 0; th < TH; ++th) {
 #pragma unroll
         for (int r = 0; r < kRegs; ++r) {
-          const float a = W2s[(R * th + TL::row(r, part)) * S2 + R * t + n];
+          const float a = W2s[o2 + (R * th + TL::row(r, part)) * S2 + R * t + n];
           acc = TL::mfma(a, hid[th][r], acc);
         }
         if (R != 16 && (th + 1) * kRegs % 16 == 0) __builtin_amdgcn_sched_barrier(0);
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
       // itself hipcc emits read -> wait -> two MFMAs, exposing the LDS latency 128 times per step), and the vector
       // work of tile t (Philox + Box-Muller, ~130 VALU instructions) is issued between the dependent MFMAs of the
       // same tile's drift instead of in a phase of its own. d = hidden = 128: 11.6 -> 10.6 ms per 500-step solve.
-      static_assert(!MID && FULL && R == 16, "interleaved path: one-stage schemes, unpadded shapes, 16-row waves");
+      static_assert(SCHEME == 0 && FULL && R == 16, "interleaved path: one-stage schemes, unpadded shapes, 16-row waves");
       const float* W1t = W1s;                 // H rows of S2: [unit][channel]
       const float* W2t = W1s + H * S2;        // D rows of S1: [channel][unit]
       // layer 1: per tile of hidden units, TD 16-byte operand reads feed 4 TD MFMAs; the reads run two ahead of the
@@ -287,6 +293,116 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
       };
       if (sigmoid_diffusion) drift_noise_update(std::true_type{});
       else drift_noise_update(std::false_type{});
+    } else if constexpr (SRK) {
+      // SRID2 (srk.py:57-88). The diffusion is diagonal, so every stage state H1_s is elementwise in the state and the
+      // drifts already known: only the three drift evaluations f(H0_0 = y), f(H0_1), f(H0_2) are matrix products (the
+      // tableau's alpha_3 = 0: f(H0_3) never contributes). After stage 0 of a tile everything that depends on (y, f0,
+      // W, U) is folded into four running arrays, so y, W, U and the g_s never live across a drift evaluation:
+      //   acc   = y + alpha_0 f0 dt + sum_{s<3} g_s gw_s          (the step's result once alpha_1 f1, alpha_2 f2, g_3 gw_3 join)
+      //   h02   = y + A0_20 f0 dt + (B0_20 g0 + B0_21 g1) U/dt     (H0_2 once A0_21 f1 dt joins)
+      //   h13   = y + (B1_30 g0 + B1_31 g1 + B1_32 g2) sqrt(dt)    (H1_3 once A1_32 f2 dt joins)
+      //   gw3   = beta4_3 I_kkk / dt                               (the weight of g_3 = g(H1_3))
+      // and y itself is overwritten by H0_1 = y + f0 dt, the next drift evaluation's input.
+      const float rdt = srow[2], sqrt_dt = srow[3], sh = srow[5], th = srow[6];
+      acc_t accum[TD], h02[TD], h13[TD], gw3[TD];
+      int oA = 0, oB = 0, oC = 0;               // (see hidden_layer: one opaque zero per drift evaluation)
+      asm volatile("" : "+v"(oA), "+v"(oB), "+v"(oC));
+      auto g_of = [&](float cc, float ee, float x) { return diffusion_value(sigmoid_diffusion, p.diff_amp, cc, ee, x).g; };
+      hidden_layer(y);
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const acc_t f0 = drift_tile(t, oA);
+#pragma unroll
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const int ch = R * t + TL::quad_base(q, part);
+          float zw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          uint64_t quad = quad_row + (ch >> 2);
+          asm volatile("" : "+v"(quad));
+          if (real(ch)) {
+            normal4<float>(key, quad, cell, 0, kStreamW, zw);
+            normal4<float>(key, quad, cell, 0, kStreamH, zh);
+          }
+          const f32x4 b2q = lds_quad(b2s, ch), cq = lds_quad(cs, ch), eq = lds_quad(es, ch);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int r = 4 * q + s;
+            const float yy = y[t][r], cc = cq[s], ee = eq[s];
+            const float f = f0[r] + b2q[s];
+            const float w = zw[s] * sw;
+            const float u = th * (0.5f * w + zh[s] * sh);
+            const float g0 = g_of(cc, ee, yy);
+            // H1_1, H1_2 need f0 only (A1 rows (1/4), (1, 0)); their diffusions are known right here
+            const float h11 = (yy + ((float)Srid2::A1(1, 0) * f) * dt) + ((float)Srid2::B1(1, 0) * g0) * sqrt_dt;
+            const float g1 = g_of(cc, ee, h11);
+            const float h12 = (yy + ((float)Srid2::A1(2, 0) * f) * dt) + ((float)Srid2::B1(2, 0) * g0) * sqrt_dt;
+            const float g2 = g_of(cc, ee, h12);
+            const float Ikk = (w * w - dt) * 0.5f;
+            const float Ikkk = ((w * w) * w - (3.0f * dt) * w) * (float)(1.0 / 6);
+            auto weight = [&](int st) {
+              return ((((float)Srid2::beta1(st) * w) + ((float)Srid2::beta2(st) * Ikk) / sqrt_dt) +
+                      ((float)Srid2::beta3(st) * u) * rdt) + ((float)Srid2::beta4(st) * Ikkk) * rdt;
+            };
+            float a0 = (yy + ((float)Srid2::alpha(0) * f) * dt) + g0 * weight(0);
+            a0 = a0 + g1 * weight(1);
+            a0 = a0 + g2 * weight(2);
+            accum[t][r] = a0;
+            gw3[t][r] = weight(3);
+            h02[t][r] = ((yy + ((float)Srid2::A0(2, 0) * f) * dt) + (((float)Srid2::B0(2, 0) * g0) * u) * rdt) +
+                        (((float)Srid2::B0(2, 1) * g1) * u) * rdt;
+            h13[t][r] = ((yy + ((float)Srid2::B1(3, 0) * g0) * sqrt_dt) + ((float)Srid2::B1(3, 1) * g1) * sqrt_dt) +
+                        ((float)Srid2::B1(3, 2) * g2) * sqrt_dt;
+            y[t][r] = yy + ((float)Srid2::A0(1, 0) * f) * dt;                       // H0_1
+            // (materialise the running values HERE: left alone, the compiler sinks their arithmetic to the first use,
+            //  past the next drift evaluation, and keeps its six inputs per element alive until then -- 480 spilled
+            //  dwords at d = hidden = 128 instead of none)
+            asm volatile("" : "+v"(accum[t][r]), "+v"(gw3[t][r]), "+v"(h02[t][r]), "+v"(h13[t][r]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // f1 = f(H0_1): joins the result and H0_2 (which replaces H0_1 as the drift's input, tile by tile)
+      hidden_layer(y);
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const acc_t f1 = drift_tile(t, oB);
+#pragma unroll
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const int ch = R * t + TL::quad_base(q, part);
+          const f32x4 b2q = lds_quad(b2s, ch);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int r = 4 * q + s;
+            const float f = f1[r] + b2q[s];
+            accum[t][r] = accum[t][r] + ((float)Srid2::alpha(1) * f) * dt;
+            y[t][r] = h02[t][r] + ((float)Srid2::A0(2, 1) * f) * dt;              // H0_2
+            asm volatile("" : "+v"(accum[t][r]), "+v"(y[t][r]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // f2 = f(H0_2): joins the result and completes H1_3, whose diffusion is the last term
+      hidden_layer(y);
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const acc_t f2 = drift_tile(t, oC);
+#pragma unroll
+        for (int q = 0; q < TL::kQuads; ++q) {
+          const int ch = R * t + TL::quad_base(q, part);
+          const f32x4 b2q = lds_quad(b2s, ch), cq = lds_quad(cs, ch), eq = lds_quad(es, ch);
+          Pack<float, 4> o;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int r = 4 * q + s;
+            const float f = f2[r] + b2q[s];
+            const float g3 = g_of(cq[s], eq[s], h13[t][r] + ((float)Srid2::A1(3, 2) * f) * dt);
+            const float yn = (accum[t][r] + ((float)Srid2::alpha(2) * f) * dt) + g3 * gw3[t][r];
+            y[t][r] = yn;
+            o.v[s] = yn;
+          }
+          if (due && real(ch)) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else if constexpr (!MID) {
       // one stage; in place: tile t of the state is only read by its own update
       hidden_layer(y);
@@ -387,41 +503,41 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
   }
 }
 
-template <int D, int H, int ACT, int R, int NW, bool MID, bool FULL, bool IL = false>
+template <int D, int H, int ACT, int R, int NW, int SCHEME, bool FULL, bool IL = false>
 static hipError_t launch_mlp_full(const MlpArgs& p, hipStream_t s) {
   const size_t lds_bytes = MlpLds<R>::bytes(D, H);
   static bool configured = false;   // per instantiation
   if (!configured) {
     const hipError_t e =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL, IL>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_trajectory_kernel<D, H, ACT, R, NW, SCHEME, FULL, IL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     configured = true;
   }
   const int64_t rows_per_block = NW * R;
   const int64_t blocks = (p.B + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, MID, FULL, IL>), dim3((unsigned)blocks), dim3(NW * 64),
+  hipLaunchKernelGGL((mlp_trajectory_kernel<D, H, ACT, R, NW, SCHEME, FULL, IL>), dim3((unsigned)blocks), dim3(NW * 64),
                      lds_bytes, s, p);
   return hipGetLastError();
 }
 
-template <int D, int H, int ACT, int R, int NW, bool MID>
+template <int D, int H, int ACT, int R, int NW, int SCHEME>
 static hipError_t launch_mlp_variant(const MlpArgs& p, hipStream_t s) {
-  // (the two-stage scheme keeps the bounds tests even for unpadded shapes: without them hipcc's schedule of the wider
-  //  basic blocks needs MORE registers -- 390 spilled dwords instead of 62 at d = hidden = 128)
-  if constexpr (!MID) {
+  // (the multi-stage schemes keep the bounds tests even for unpadded shapes: without them hipcc's schedule of the wider
+  //  basic blocks needs MORE registers -- 390 spilled dwords instead of 62 for the midpoint scheme at d = hidden = 128)
+  if constexpr (SCHEME == 0) {
     if (p.d == D && p.h == H) {
       if constexpr (R == 16) {
         static const bool interleave = [] {
           const char* e = getenv("TSDE_MLP_INTERLEAVE");
           return e == nullptr || atoi(e) != 0;
         }();
-        if (interleave) return launch_mlp_full<D, H, ACT, R, NW, MID, true, true>(p, s);
+        if (interleave) return launch_mlp_full<D, H, ACT, R, NW, SCHEME, true, true>(p, s);
       }
-      return launch_mlp_full<D, H, ACT, R, NW, MID, true>(p, s);
+      return launch_mlp_full<D, H, ACT, R, NW, SCHEME, true>(p, s);
     }
   }
-  return launch_mlp_full<D, H, ACT, R, NW, MID, false>(p, s);
+  return launch_mlp_full<D, H, ACT, R, NW, SCHEME, false>(p, s);
 }
 
 // Variant choice (tools/bench_mlp_trajectory.py, MI355X): 16-row waves in 8-wave blocks everywhere. The weights of a
@@ -436,11 +552,25 @@ static hipError_t launch_mlp_dh(const MlpArgs& p, hipStream_t s) {
     return e ? atoi(e) : 0;
   }();
   if (p.method == TSDE_TRAJ_MIDPOINT) {
-    if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4, true>(p, s);
-    return launch_mlp_variant<D, H, ACT, 16, 8, true>(p, s);
+    if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4, 1>(p, s);
+    return launch_mlp_variant<D, H, ACT, 16, 8, 1>(p, s);
   }
-  if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4, false>(p, s);
-  return launch_mlp_variant<D, H, ACT, 16, 8, false>(p, s);
+  if (p.method == TSDE_TRAJ_SRK) {
+    // five state-sized arrays live across the drift evaluations. d = hidden = 128, 32768 x 500 steps: 8-wave blocks (two
+    // waves per SIMD, 70 spilled dwords) 43.0 ms, 4-wave blocks (one wave per SIMD, no spills) 49.0 ms
+    if constexpr (D >= 128) {
+      static const int waves = [] {
+        const char* e = getenv("TSDE_MLP_SRK_WAVES");
+        return e ? atoi(e) : 0;
+      }();
+      if (waves == 4) return launch_mlp_variant<D, H, ACT, 16, 4, 2>(p, s);
+      return launch_mlp_variant<D, H, ACT, 16, 8, 2>(p, s);
+    } else {
+      return launch_mlp_variant<D, H, ACT, 16, 8, 2>(p, s);
+    }
+  }
+  if (forced == 32) return launch_mlp_variant<D, H, ACT, 32, 4, 0>(p, s);
+  return launch_mlp_variant<D, H, ACT, 16, 8, 0>(p, s);
 }
 
 template <int D, int H>

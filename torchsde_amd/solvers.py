@@ -325,11 +325,13 @@ class BaseSDESolver:
         if spec is None:
             return None
         if spec[0] == "mlp_diagonal":
-            # perceptron drift on the matrix cores: sampling kernel (Euler, Milstein, midpoint); with autograd on,
+            # perceptron drift on the matrix cores: sampling kernel (Euler, Milstein, midpoint, SRK); with autograd on,
             # sampling kernel + reverse sweep (Euler, Milstein)
             code = self._trajectory_code()
             if code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT,
-                            _native.TRAJ_MIDPOINT) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
+                            _native.TRAJ_MIDPOINT, _native.TRAJ_SRK) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
+                return None
+            if code == _native.TRAJ_SRK and (not bm._have_H or y0.dtype != torch.float32):
                 return None
             if self._tracks_grad(y0):
                 # training: Euler and Milstein, through the reverse-sweep kernel; gradients reach y0 and the module's own
@@ -338,7 +340,8 @@ class BaseSDESolver:
                 hidden = own[1].numel()
                 sigmoid = spec[-1][0] == _native.DIFF_SIGMOID         # its reverse sweep exists for Euler only
                 too_large = y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30        # 32-bit lane offsets in the sweep
-                if (code == _native.TRAJ_MIDPOINT or (sigmoid and code != _native.TRAJ_EULER) or hidden % 4 != 0
+                if (code in (_native.TRAJ_MIDPOINT, _native.TRAJ_SRK) or (sigmoid and code != _native.TRAJ_EULER)
+                        or hidden % 4 != 0
                         or too_large or {id(p) for p in base.parameters()} != {id(p) for p in own}):
                     return None
                 return ("mlp_differentiable", spec[-2], spec[-1]) + tuple(own)
