@@ -53,7 +53,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c3_euler_general_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c2_euler_closed_form_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000",
-        "c5_sampling_mlp_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
+        "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
         "c5_adjoint_mlp_milstein_b32768_d128_s500")
 
 

@@ -486,6 +486,9 @@ CLOSED_FORM_CASES = [
     ("milstein_softplus_affine", "softplus", "affine", "ito", "milstein", True),
     ("milstein_strat_tanh_affine", "tanh", "affine", "stratonovich", "milstein", True),
     ("midpoint_tanh_sigmoid", "tanh", "sigmoid", "stratonovich", "midpoint", False),
+    # SRK (SRID2) needs the space-time Levy area of the path: the C twin serves (W, U)
+    ("srk_softplus_sigmoid", "softplus", "sigmoid", "ito", "srk", False),
+    ("srk_tanh_affine", "tanh", "affine", "ito", "srk", False),
 ]
 
 
@@ -497,9 +500,15 @@ def gen_closed_form():
     ts = [0.0, 5 * dt, steps * dt]
 
     class CounterPath(torchsde.BaseBrownian):
+        def __init__(self, levy):
+            super().__init__()
+            self.levy = levy
+
         def __call__(self, ta, tb=None, return_U=False, return_A=False):
-            W, _, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float32, have_h=False)
-            return torch.from_numpy(W).reshape(B, d).double()
+            W, U, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float32,
+                                    have_h=self.levy != "none")
+            W = torch.from_numpy(W).reshape(B, d).double()
+            return (W, torch.from_numpy(U).reshape(B, d).double()) if return_U else W
 
         def __repr__(self):
             return "CounterPath"
@@ -507,9 +516,10 @@ def gen_closed_form():
         dtype = property(lambda self: torch.float64)
         device = property(lambda self: torch.device("cpu"))
         shape = property(lambda self: (B, d))
-        levy_area_approximation = property(lambda self: "none")
+        levy_area_approximation = property(lambda self: self.levy)
 
     for name, activation, diffusion, sde_type, method, with_grads in CLOSED_FORM_CASES:
+        levy = "space-time" if method == "srk" else "none"
         gen = torch.Generator().manual_seed(sum(map(ord, name)))
         sigmoid = diffusion == "sigmoid"
         sde = torchsde_amd.MLPDriftDiagonalSDE(
@@ -524,8 +534,8 @@ def gen_closed_form():
             sde.lin2.bias.copy_(0.3 * torch.randn(d, generator=gen, dtype=torch.float64))
         y0 = (0.5 * torch.randn(B, d, generator=gen, dtype=torch.float64)).requires_grad_(True)
         weights = torch.randn(len(ts), B, d, generator=gen, dtype=torch.float64)
-        ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method, dt=dt)
-        out = {"activation": activation, "diffusion": diffusion, "sde_type": sde_type, "method": method,
+        ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(levy), method=method, dt=dt)
+        out = {"activation": activation, "diffusion": diffusion, "sde_type": sde_type, "method": method, "levy": levy,
                "diff_scale": np.float64(sde.diff_scale), "with_grads": with_grads, "entropy": np.int64(entropy),
                "dt": np.float64(dt), "ts": np.asarray(ts), "shape": np.array([B, d, hidden, steps]),
                "y0": y0.detach().numpy(), "weights": weights.numpy(), "ys": ys.detach().numpy()}

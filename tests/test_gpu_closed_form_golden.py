@@ -16,7 +16,7 @@ CASES = sorted(f[len("closed_form_mlp_"):-4] for f in os.listdir(helpers.GOLDEN)
 
 
 def test_fixtures_present():
-    assert len(CASES) == 5
+    assert len(CASES) == 7
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -29,9 +29,13 @@ def test_trajectory_kernels_match_the_reference(name):
     y0 = torch.tensor(z["y0"], dtype=torch.float32, device=DEV, requires_grad=with_grads)
     ts = torch.tensor(z["ts"], dtype=torch.float32, device=DEV)
     bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=torch.float32, device=DEV,
-                                       entropy=int(z["entropy"]), dt=dt)
+                                       entropy=int(z["entropy"]), dt=dt, levy_area_approximation=str(z["levy"]))
     with torch.set_grad_enabled(with_grads):
         ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=str(z["method"]), dt=dt)
+        if not with_grads:                   # the one-launch kernel and the stepwise path of this package agree too
+            again = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=str(z["method"]), dt=dt,
+                                        options={"trajectory_kernel": False})
+            torch.testing.assert_close(ys, again, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(ys.detach().cpu().double(), torch.tensor(z["ys"]), rtol=1e-4, atol=1e-5)
     if not with_grads:
         return

@@ -317,9 +317,11 @@ def test_c2_reference_benchmark_sde_rows_vs_oracle(name):
     helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1], name)
 
 
-def test_c5_sampling_kernel_b32768_d128_s500_rows_vs_oracle():
+@pytest.mark.parametrize("method,levy", [("euler", "none"), ("srk", "space-time")])
+def test_c5_sampling_kernel_b32768_d128_s500_rows_vs_oracle(method, levy):
     """The perceptron-drift sampling kernel (both layers on the f32 matrix cores, one launch per solve) at the configs[4]
-    shape, rows against the oracle integrating the same module's torch statement of f and g."""
+    shape, Euler and SRK (three drift evaluations per step), rows against the oracle integrating the same module's
+    torch statement of f and g."""
     import torchsde_amd
     c = configs.WORKLOADS["c5_sampling_mlp_b32768_d128_s500"]
     B, d, n, dt = c["B"], c["d"], c["nsteps"], c["dt"]
@@ -327,13 +329,14 @@ def test_c5_sampling_kernel_b32768_d128_s500_rows_vs_oracle():
     y0 = torch.full((B, d), 0.1, device=DEV)
     ts = torch.tensor([0.0, 200 * dt, n * dt], device=DEV)
     with torch.no_grad():
-        ys = torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, d, n, dt, 4242), method="euler", dt=dt)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, d, n, dt, 4242, levy=levy), method=method, dt=dt)
     # workgroups own 64-row (and, on small grids, 32-row) tiles: rows either side of the first and the last seam
     rows = helpers.sampled_rows(B, 64, seed=9, seams=(32, 64, 128, B - 64))
-    ref32, ref64 = _oracle_forward(sde, rows, d, d, 4242, n, dt, "euler", 0.1, ts=[0.0, 200 * dt, n * dt])
+    ref32, ref64 = _oracle_forward(sde, rows, d, d, 4242, n, dt, method, 0.1, levy=levy != "none",
+                                   ts=[0.0, 200 * dt, n * dt])
     idx = torch.from_numpy(rows).to(DEV)
     for k in (1, 2):
-        helpers.assert_within_reference_rounding(ys[k][idx], ref32[k], ref64[k], f"C5 sampling kernel, output {k}")
+        helpers.assert_within_reference_rounding(ys[k][idx], ref32[k], ref64[k], f"C5 sampling kernel {method}, output {k}")
 
 
 def test_c5_training_kernels_b32768_d128_s500_rows_vs_oracle():

@@ -63,9 +63,12 @@ def test_oracle_matches_reference_on_the_counter_path(name):
     sde = helpers.mlp_module_from(z, torch.float64, "cpu")
     edges = np.arange(steps + 1) * dt
 
+    have_h = str(z["levy"]) != "none"
+
     def bm(ta, tb, return_U=False):
-        W, _, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float32, have_h=False)
-        return torch.from_numpy(W).reshape(B, d).double()
+        W, U, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float32, have_h=have_h)
+        W = torch.from_numpy(W).reshape(B, d).double()
+        return (W, torch.from_numpy(U).reshape(B, d).double()) if return_U else W
 
     y0 = torch.tensor(z["y0"], requires_grad=with_grads)
     with torch.set_grad_enabled(with_grads):

@@ -69,6 +69,11 @@ WORKLOADS = {
         problem="mlp_drift", method="euler", levy="none", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
         kid=8, trajectory=True, mfma_flops_per_traj_step=4 * 128 * 128,
         kernel="tsde_trajectory_mlp_diag<128, 128, softplus> (mlp_trajectory_kernel, v_mfma_f32_16x16x4_f32)"),
+    # ... and with the reference's DEFAULT method for a diagonal Ito SDE, SRK (SRID2): three drift evaluations per step
+    "c5_sampling_mlp_srk_b32768_d128_s500": dict(
+        problem="mlp_drift", method="srk", levy="space-time", B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9,
+        kid=8, trajectory=True, mfma_flops_per_traj_step=12 * 128 * 128,
+        kernel="tsde_trajectory_mlp_diag<128, 128, softplus, srk> (mlp_trajectory_kernel, v_mfma_f32_16x16x4_f32)"),
     # The TRAINING step of the SDE of c5_adjoint_latent below (same parameter values, stated as the closed-form module):
     # forward + loss.backward() through the solver, Euler: sampling kernel writing every step, reverse sweep (three
     # products per step on the matrix cores), tall-K weight-gradient products.
