@@ -63,6 +63,9 @@ SHAPES = [  # B, d, hidden, activation, diffusion, forward method, steps, output
     (37, 20, 36, "tanh", "sigmoid", "milstein", 16, (0, 4, 9, 16), "ito", None),
     (64, 32, 32, "tanh", "affine", "midpoint", 24, (0, 24), "stratonovich", "milstein"),
     (33, 128, 100, "softplus", "sigmoid", "milstein", 12, (0, 6, 12), "stratonovich", "milstein"),
+    # every default: forward SRK (needs the space-time Levy area), backward Milstein
+    (64, 64, 64, "softplus", "sigmoid", None, 24, (0, 7, 24), "ito", None),
+    (48, 128, 128, "tanh", "affine", "srk", 16, (0, 16), "ito", "euler"),
 ]
 
 
@@ -85,7 +88,8 @@ def test_matches_the_stepwise_stochastic_adjoint(B, d, hidden, activation, diffu
         from torchsde_amd import mlp_adjoint
         y0 = y0_init.clone().requires_grad_(True)
         sde.zero_grad()
-        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=torch.float32, device=DEV, entropy=808)
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, d), dtype=torch.float32, device=DEV, entropy=808,
+                                           levy_area_approximation="space-time" if method in (None, "srk") else "none")
         keep = mlp_adjoint._MlpAdjointFn.STASH_BYTES
         if chunk_bytes is not None:
             mlp_adjoint._MlpAdjointFn.STASH_BYTES = chunk_bytes

@@ -29,6 +29,7 @@ _FORWARD_CODES = {
     (METHODS.milstein, SDE_TYPES.ito): _native.TRAJ_MILSTEIN_ITO,
     (METHODS.milstein, SDE_TYPES.stratonovich): _native.TRAJ_MILSTEIN_STRAT,
     (METHODS.midpoint, SDE_TYPES.stratonovich): _native.TRAJ_MIDPOINT,
+    (METHODS.srk, SDE_TYPES.ito): _native.TRAJ_SRK,        # the reference's default for diagonal Ito noise
 }
 _BACKWARD_KINDS = {METHODS.euler: "euler", METHODS.milstein: "milstein"}
 
@@ -159,7 +160,8 @@ def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptiv
     code = _FORWARD_CODES.get((method, sde.sde_type))
     if (code is None or not isinstance(bm, BrownianInterval) or bm._rootW is not None or bm._rootH is not None
             or bm._snap or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or y0.dtype != torch.float32
-            or bm.dtype != torch.float32 or bm._elem0 % 4 != 0 or y0.numel() == 0):
+            or bm.dtype != torch.float32 or bm._elem0 % 4 != 0 or y0.numel() == 0
+            or (code == _native.TRAJ_SRK and not bm._have_H)):
         return None
     spec = base.closed_form(y0.shape[1], y0.dtype, y0.device)
     if spec is None or spec[0] != "mlp_diagonal":
