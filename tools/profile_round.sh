@@ -37,7 +37,7 @@ import csv, glob, os, sys
 out = sys.argv[1]
 print("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY -- bench.py --workload c5_adjoint_mlp_b32768_d128_s500")
 for p in glob.glob(os.path.join(out, "pmc_adjoint", "**", "*counter_collection.csv"), recursive=True):
-    for kernel in ("mlp_adjoint_kernel", "adjoint_diffusion_sums_kernel", "gram_kernel", "mlp_trajectory_kernel"):
+    for kernel in ("mlp_adjoint_kernel", "gram_kernel", "mlp_trajectory_kernel"):
         agg, n = {}, {}
         for row in csv.DictReader(open(p)):
             if kernel not in row.get("Kernel_Name", ""):
