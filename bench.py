@@ -54,7 +54,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c2_euler_closed_form_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
-        "c5_adjoint_mlp_milstein_b32768_d128_s500")
+        "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500")
 
 
 def csrc_digest():

@@ -99,6 +99,13 @@ WORKLOADS = {
         m=128, nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=0, kid=10, launches_per_step=1, trajectory=True,
         adjoint=True, mfma_flops_per_traj_step=8 * 128 * 128,
         kernel="tsde_adjoint_mlp_diag<128, 128, softplus, milstein> (mlp_adjoint_kernel, v_mfma_f32_16x16x4_f32)"),
+    # ... and with EVERY default of `sdeint_adjoint(sde, y0, ts)` for a diagonal Ito SDE: forward SRK (adjoint.py /
+    # sdeint.py:246-253), backward Milstein
+    "c5_adjoint_mlp_defaults_b32768_d128_s500": dict(
+        problem="latent_diag_closed_form", method="srk", adjoint_method="milstein", levy="space-time", B=32768, d=128,
+        m=128, nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=0, kid=10, launches_per_step=1, trajectory=True,
+        adjoint=True, mfma_flops_per_traj_step=8 * 128 * 128,
+        kernel="tsde_adjoint_mlp_diag<128, 128, softplus, milstein> (mlp_adjoint_kernel, v_mfma_f32_16x16x4_f32)"),
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
