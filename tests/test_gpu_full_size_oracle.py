@@ -178,13 +178,13 @@ def _loss_weights(B, d):
     return torch.cos(0.37 * r + 0.11 * c)
 
 
-def _oracle_adjoint(sde32, rows, d, entropy, n, dt, method, adjoint_method, wt_rows):
+def _oracle_adjoint(sde32, rows, d, entropy, n, dt, method, adjoint_method, wt_rows, levy=False):
     import copy
     from oracle import adjoint_ref
     out = {}
     for dtype in (torch.float32, torch.float64):
         sde = copy.deepcopy(sde32).cpu().to(dtype)
-        bm = helpers.counter_rows_bm(rows, d, entropy, _edges(n, dt), dtype)
+        bm = helpers.counter_rows_bm(rows, d, entropy, _edges(n, dt), dtype, levy=levy)
         y0 = torch.full((len(rows), d), 0.1, dtype=dtype)
         w = torch.stack([torch.zeros_like(wt_rows), wt_rows]).to(dtype)
         out[dtype] = adjoint_ref.adjoint_gradients(sde, y0, torch.tensor([0.0, n * dt], dtype=dtype), bm, dt, method,
@@ -255,9 +255,10 @@ def test_c5_parameter_gradients_b256_vs_oracle():
         helpers.assert_within_reference_rounding(p.grad, g32, g64, f"dL/d{name}")
 
 
-@pytest.mark.parametrize("adjoint_method", ["euler", "milstein"])
-def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle(adjoint_method):
-    """configs[4] through `sdeint_adjoint(method="euler", adjoint_method="euler" | "milstein")` with the latent SDE stated as the
+@pytest.mark.parametrize("method,adjoint_method", [("euler", "euler"), ("euler", "milstein"), (None, None)])
+def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle(method, adjoint_method):
+    """configs[4] through `sdeint_adjoint` -- (euler, euler), (euler, milstein) and with EVERY default (forward SRK,
+    backward Milstein) -- with the latent SDE stated as the
     closed-form module: the forward sampling kernel and the stochastic adjoint on the matrix cores
     (tsde_adjoint_mlp_diag) at 32768 x 128 x 500 steps. Final states and dL/dy0 of sampled rows against the oracle's
     restatement of the reference's adjoint on the user-module statement of the same SDE; the six parameter gradients
@@ -273,7 +274,8 @@ def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle(adjoint_meth
     def run(sde):
         y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
         sde.zero_grad()
-        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(B, d, n, dt, 20240601), method="euler",
+        levy = "space-time" if method is None else "none"
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(B, d, n, dt, 20240601, levy=levy), method=method,
                                          adjoint_method=adjoint_method, dt=dt)
         (ys[-1] * wt.to(DEV, torch.float32)).sum().backward()
         return ys, y0.grad, [p.grad.clone() for p in sde.parameters()]
@@ -282,8 +284,9 @@ def test_c5_sdeint_adjoint_on_the_closed_form_module_rows_vs_oracle(adjoint_meth
     assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn")
     rows = helpers.sampled_rows(B, 64, seed=8, seams=(16, 64, 128))
     idx = torch.from_numpy(rows).to(DEV)
-    (ys32, gy32, _), (ys64, gy64, _) = _oracle_adjoint(user, rows, d, 20240601, n, dt, "euler", adjoint_method,
-                                                        wt[torch.from_numpy(rows)])
+    (ys32, gy32, _), (ys64, gy64, _) = _oracle_adjoint(user, rows, d, 20240601, n, dt, method or "srk",
+                                                        adjoint_method or "milstein", wt[torch.from_numpy(rows)],
+                                                        levy=method is None)
     # (the matrix products accumulate in another order than the oracle's float32 GEMMs: a wider factor than for the
     #  elementwise kernels, still relative to the oracle's own float32 rounding)
     helpers.assert_within_reference_rounding(ys[-1][idx], ys32[-1], ys64[-1], "final state", factor=8.0, floor=1e-5)
