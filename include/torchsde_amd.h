@@ -335,6 +335,9 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  *   (SRK = SRID2, torchsde/_core/methods/srk.py:57-88: three drift evaluations per step -- the tableau's alpha_3 = 0 --
  *   and, the diffusion being diagonal, all four diffusion stages elementwise; the increments' second stream H gives the
  *   space-time Levy area U = h (W/2 + H) of the cell).
+ * Outputs as tsde_trajectory_affine_diag: output j is traj->out_w[2j] * y_k + traj->out_w[2j+1] * y_{k+1} of the step
+ * k + 1 = traj->out_step[j] (the reference's linear interpolation, interp.py:15-18; weights (0, 1) = the step's result
+ * itself); several outputs may share a step.
  * Increments: the generated cells (entropy, elem0 + i, cells[k]) of the counter RNG, i.e. the path the stepwise
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
 #define TSDE_ACT_TANH 0

@@ -76,9 +76,8 @@ def test_stratonovich_milstein_and_long_solve():
 
 
 def test_sharding_invariance_and_fallbacks():
-    """Rows solved with `row_offset` equal the same rows of the full solve bit for bit; an output time inside a step
-    sends the solve down the stepwise path; with autograd on, gradients come out either way
-    (tests/test_gpu_mlp_backward.py)."""
+    """Rows solved with `row_offset` equal the same rows of the full solve bit for bit; with autograd on, gradients come
+    out either way (tests/test_gpu_mlp_backward.py)."""
     import torchsde_amd
     d, hidden, B = 32, 64, 512
     sde = _sde(d, hidden, "softplus")
@@ -88,9 +87,6 @@ def test_sharding_invariance_and_fallbacks():
     full = _solve(sde, y0, ts, "euler", dt, 5, trajectory=True)
     part = _solve(sde, y0[200:328], ts, "euler", dt, 5, trajectory=True, row_offset=200)
     assert torch.equal(full[:, 200:328], part)
-    off_grid = torch.tensor([0.0, 2.5 * dt, 8 * dt], device=DEV)
-    assert torch.equal(_solve(sde, y0, off_grid, "euler", dt, 5, trajectory=True),
-                       _solve(sde, y0, off_grid, "euler", dt, 5, trajectory=False))
     y_grad = y0.clone().requires_grad_(True)
     bm = torchsde_amd.BrownianInterval(0.0, 8 * dt, size=(B, d), device=DEV, dtype=torch.float32, entropy=5)
     ys = torchsde_amd.sdeint(sde, y_grad, ts, bm=bm, method="euler", dt=dt)
@@ -131,3 +127,27 @@ def test_training_paths_still_work_on_the_module():
     torch.testing.assert_close(ys_a, ys_b, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gy_a, gy_b, rtol=5e-2, atol=5e-3)
     assert ((gw_a - gw_b).abs().max() / gw_b.abs().max()).item() < 5e-2
+
+
+@pytest.mark.parametrize("d,hidden", [(32, 64), (128, 128), (20, 50)])
+@pytest.mark.parametrize("method,sde_type,levy", [("euler", "ito", "none"), ("milstein", "ito", "none"),
+                                                  ("midpoint", "stratonovich", "none"), ("srk", "ito", "space-time")])
+def test_output_times_inside_steps_are_interpolated_in_the_kernel(method, sde_type, levy, d, hidden):
+    """Arbitrary `ts` (the common case: `linspace` against a `dt` that does not divide it): the reference interpolates
+    linearly between the step boundaries either side (base_solver.py:147, interp.py:15-18). The kernel writes w0 y_k at
+    the start of the step and adds w1 y_{k+1} at its end; several outputs may fall into one step."""
+    import torchsde_amd
+    B, dt = 150, 2.0 ** -5
+    sde = _sde(d, hidden, "softplus", sde_type=sde_type, diffusion="sigmoid")
+    y0 = (0.5 * torch.randn(B, d, generator=torch.Generator().manual_seed(4))).to(DEV)
+    ts = torch.tensor([0.0, 0.3 * dt, 2.5 * dt, 2.75 * dt, 6 * dt, 9.01 * dt, 12.9 * dt], device=DEV)
+
+    def solve(trajectory):
+        bm = torchsde_amd.BrownianInterval(0.0, float(ts[-1]), size=(B, d), dtype=torch.float32, device=DEV, entropy=21,
+                                           levy_area_approximation=levy)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt, options={"trajectory_kernel": trajectory})
+
+    fast, ref = solve(True), solve(False)
+    assert torch.isfinite(fast).all() and torch.equal(fast[0], y0)
+    torch.testing.assert_close(fast, ref, rtol=2e-4, atol=2e-5)

@@ -145,6 +145,43 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
 
     const float half_dt = srow[1];
     const bool due = jout < p.n_out && p.out_step[jout] == k + 1;
+    // Outputs that fall INSIDE this step are the reference's linear interpolation w0 y_k + w1 y_{k+1}
+    // (base_solver.py:147, interp.py:15-18; weights from the host). y_k is gone by the time y_{k+1} exists (the schemes
+    // update in place), so its share w0 y_k goes to the output's place in `ys` now and the end of the step adds w1 y_{k+1}
+    // to it -- the same lane, in program order, (w0 y_k) + (w1 y_{k+1}) rounded like the reference's expression.
+    if (due) {
+      for (int j = jout; j < p.n_out && p.out_step[j] == k + 1; ++j) {
+        const float w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        if (w0 == 0.0f && w1 == 1.0f) continue;
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+#pragma unroll
+          for (int q = 0; q < TL::kQuads; ++q) {
+            const int ch = R * t + TL::quad_base(q, part);
+            Pack<float, 4> o;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) o.v[c4] = w0 * y[t][4 * q + c4];
+            if (real(ch)) store<float, 4>(p.ys + (int64_t)j * p.B * dT, off_d + ch, o);
+          }
+        }
+      }
+    }
+    // ... and the end of the step: every output of this step receives y_{k+1}, or its weighted share
+    auto emit = [&](int ch, const Pack<float, 4>& o) {
+      for (int j = jout; j < p.n_out && p.out_step[j] == k + 1; ++j) {
+        const float w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        float* dst = p.ys + (int64_t)j * p.B * dT;
+        if (w0 == 0.0f && w1 == 1.0f) {
+          store<float, 4>(dst, off_d + ch, o);
+        } else {
+          const f32x4 prev = *reinterpret_cast<const f32x4*>(dst + off_d + ch);
+          Pack<float, 4> mixed;
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) mixed.v[c4] = prev[c4] + w1 * o.v[c4];
+          store<float, 4>(dst, off_d + ch, mixed);
+        }
+      }
+    };
 
     // ---- layer 1: hid^T = W1^T x^T ------------------------------------------------------------------------
     // (the scheduling barriers keep the compiler from hoisting hundreds of LDS reads ahead of the MFMAs that use
@@ -287,7 +324,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
           y[t][s] = yn;
           o.v[s] = yn;
         }
-        if (due) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
+        if (due) emit(ch, o);
         __builtin_amdgcn_sched_barrier(0);
       }
       };
@@ -399,7 +436,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             y[t][r] = yn;
             o.v[s] = yn;
           }
-          if (due && real(ch)) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
+          if (due && real(ch)) emit(ch, o);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -439,7 +476,7 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             y[t][r] = yn;
             o.v[s] = yn;
           }
-          if (due && real(ch)) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
+          if (due && real(ch)) emit(ch, o);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -492,14 +529,12 @@ __global__ void __launch_bounds__(NW * 64) mlp_trajectory_kernel(const MlpArgs p
             y[t][r] = yn;
             o.v[s] = yn;
           }
-          if (due && real(ch)) store<float, 4>(p.ys + (int64_t)jout * p.B * dT, off_d + ch, o);
+          if (due && real(ch)) emit(ch, o);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // every output time of this kernel sits on a step boundary (the host sends anything else down the stepwise
-    // path); several outputs may share one boundary only if ts repeats, which the contract forbids
-    if (due) ++jout;
+    while (jout < p.n_out && p.out_step[jout] == k + 1) ++jout;
   }
 }
 

@@ -396,8 +396,6 @@ class BaseSDESolver:
                                                         self._trajectory_code(), schedule_all, out_step, bm)
         schedule = K.TrajectorySchedule.cached(rows, cells, out_step, out_w, y0.device, y0.dtype)
         if coefficients[0] == "mlp_diagonal":
-            if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
-                return None      # an output time inside a step: the stepwise path interpolates it
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
             ys[0].copy_(y0c)
