@@ -151,3 +151,35 @@ def test_output_times_inside_steps_are_interpolated_in_the_kernel(method, sde_ty
     fast, ref = solve(True), solve(False)
     assert torch.isfinite(fast).all() and torch.equal(fast[0], y0)
     torch.testing.assert_close(fast, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_every_default_of_sdeint_takes_the_kernel():
+    """`sdeint(sde, y0, torch.linspace(0, 1, 7))` as a user would write it: default method (SRK for diagonal Ito noise),
+    default dt = 1e-3 (1001 float32 steps, the last one tiny), outputs inside steps."""
+    import torchsde_amd
+    from torchsde_amd import kernels as K
+    B, d, hidden = 96, 32, 64
+    sde = _sde(d, hidden, "tanh", diffusion="sigmoid")
+    y0 = (0.5 * torch.randn(B, d, generator=torch.Generator().manual_seed(6))).to(DEV)
+    ts = torch.linspace(0, 1, 7, device=DEV)
+    launches = []
+    original = K.trajectory_mlp_diag
+
+    def spy(*args, **kwargs):
+        launches.append(1)
+        return original(*args, **kwargs)
+
+    def solve(**options):
+        bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, d), dtype=torch.float32, device=DEV, entropy=33,
+                                           levy_area_approximation="space-time")
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, options=options or None)
+
+    K.trajectory_mlp_diag = spy
+    try:
+        fast = solve()
+    finally:
+        K.trajectory_mlp_diag = original
+    assert launches == [1], "the default call did not take the one-launch kernel"
+    ref = solve(trajectory_kernel=False)
+    torch.testing.assert_close(fast, ref, rtol=5e-4, atol=5e-5)
