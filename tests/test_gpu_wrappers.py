@@ -176,3 +176,34 @@ def test_step_doubling_increment_is_the_merge_of_its_halves(levy, method):
     assert torch.equal(first.W, bm(ta, tm)) and torch.equal(second.W, bm(tm, tb))
     if U is not None:
         torch.testing.assert_close(whole.U, U, rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("kind", ["path", "tree"])
+def test_bridge_law_of_path_and_tree(kind):
+    """The reference's `test_normality` for BrownianPath / BrownianTree (tests/test_brownian_path.py:73-100,
+    test_brownian_tree.py:80-108): query the end first, then an interior time; given both ends the interior value is
+    Brownian-bridge distributed. Also: t0 / t1 given as 0-d device tensors, a (batch, d) shape."""
+    import numpy as np
+    import torchsde_amd
+    rng = np.random.default_rng(7)
+    B = 32768
+    for rep in range(3):
+        w0_ = float(rng.standard_normal())
+        w0 = torch.full((B,), w0_, dtype=F64, device=DEV)
+        if kind == "path":
+            bm = torchsde_amd.BrownianPath(t0=torch.tensor(0.0, device=DEV), w0=w0)
+        else:
+            bm = torchsde_amd.BrownianTree(t0=torch.tensor(0.0, device=DEV), w0=w0, t1=torch.tensor(1.0, device=DEV),
+                                           entropy=40 + rep)
+        with pytest.warns(UserWarning):
+            w1 = bm(1.0).cpu().numpy()
+        t = float(rng.uniform(0.01, 0.99))
+        with pytest.warns(UserWarning):
+            sample = bm(t).cpu().numpy()
+        mean = ((1.0 - t) * w0_ + t * w1)
+        std = math.sqrt((1.0 - t) * t)
+        _, pval = kstest((sample - mean) / std, "norm")
+        assert pval >= 1e-5, (kind, rep, t, pval)
+    two_d = torchsde_amd.BrownianPath(t0=0.0, w0=torch.zeros(64, 5, device=DEV))
+    with pytest.warns(UserWarning):
+        assert two_d(0.4).shape == (64, 5)
