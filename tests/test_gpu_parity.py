@@ -244,6 +244,50 @@ def test_specialised_functions_bit_identical(method, sde_type):
         assert torch.equal(outs[0], o)
 
 
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich")])
+def test_specialised_functions_general_noise(method, sde_type):
+    """The same for GENERAL noise, with the six provider combinations of the reference's test (tests/problems.py:356-440):
+    f + g, f_and_g, f + g_prod (no g at all), f_and_g_prod, and f_and_g together with either product. Where the module
+    supplies the product, the user's `bmm` sums the m terms, elsewhere the contraction kernel does: same path, the sums
+    in another order -- float32 rounding, not bit equality."""
+    import torchsde_amd
+    B, d, m, steps, dt = 32, 5, 3, 8, 2.0 ** -4
+    vector = torch.randn(m, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def drift(y):
+        return -y
+
+    def diffusion(y):
+        return y.unsqueeze(-1).sigmoid() * vector
+
+    def product(y, v):
+        return diffusion(y).bmm(v.unsqueeze(-1)).squeeze(-1)
+
+    def module(**methods):
+        cls = type("Provided", (torch.nn.Module,), dict(noise_type="general", sde_type=sde_type, **methods))
+        return cls()
+
+    forms = [
+        module(f=lambda self, t, y: drift(y), g=lambda self, t, y: diffusion(y)),
+        module(f_and_g=lambda self, t, y: (drift(y), diffusion(y))),
+        module(f=lambda self, t, y: drift(y), g_prod=lambda self, t, y, v: product(y, v)),
+        module(f_and_g_prod=lambda self, t, y, v: (drift(y), product(y, v))),
+        module(f_and_g=lambda self, t, y: (drift(y), diffusion(y)), g_prod=lambda self, t, y, v: product(y, v)),
+        module(f_and_g=lambda self, t, y: (drift(y), diffusion(y)),
+               f_and_g_prod=lambda self, t, y, v: (drift(y), product(y, v))),
+    ]
+    ts = torch.tensor([0.0, steps * dt], device=DEV)
+    y0 = torch.randn(B, d, generator=torch.Generator().manual_seed(4)).to(DEV)
+    outs = []
+    for sde in forms:
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(B, m), device=DEV, dtype=torch.float32, entropy=45678)
+        with torch.no_grad():
+            outs.append(torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=dt)[1])
+    for o in outs[1:]:
+        assert o.shape == outs[0].shape
+        torch.testing.assert_close(o, outs[0], rtol=2e-6, atol=2e-6)
+
+
 def test_logqp_and_names():
     """logqp=True appends the KL column and returns log-ratio increments; names= renames drift/diffusion
     (reference sdeint.py:142-144,284-295; base_sde.py:212-306). Numbers against the reference itself are in
