@@ -58,3 +58,44 @@ def test_method_matrix(noise, sde_type, levy, adaptive):
         assert ys.shape == (3, B, d), (method, ys.shape)
         assert torch.isfinite(ys).all(), method
         assert torch.equal(ys[0], y0)
+
+
+ALL_METHODS = ["blah", "euler", "milstein", "milstein_grad_free", "srk", "euler_heun", "heun", "midpoint", "log_ode"]
+
+
+@pytest.mark.parametrize("logqp", [False, True])
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("sde_type", ["ito", "stratonovich"])
+@pytest.mark.parametrize("noise", list(PROBLEMS))
+def test_method_matrix_without_a_brownian_motion_with_logqp_and_other_drifts(noise, sde_type, adaptive, logqp):
+    """The rest of `test_sdeint_run_shape_method` (reference tests/test_sdeint.py:101-216): `bm=None` (sdeint builds the
+    BrownianInterval the method needs, sdeint.py:246-270), an unknown method name, derivative-free Milstein, `logqp=True`
+    (shape (T - 1, batch) of the log-ratio) and `names={"drift": "h"}`."""
+    import warnings
+    import torchsde_amd
+    B, d, T = 4, 4, 3
+    m = {"diagonal": d, "scalar": 1, "additive": 3, "general": 4}[noise]
+    tag = "ito" if sde_type == "ito" else "strat"
+    sde = problems.make(f"{PROBLEMS[noise]}_{tag}", d=d, m=m).to(DEV)
+    if not hasattr(sde, "h"):
+        sde.h = lambda t, y: -0.5 * y
+    y0 = torch.ones(B, d, device=DEV)
+    ts = torch.linspace(0.0, 0.5, T, device=DEV)
+    for name in ALL_METHODS:
+        method, options = ("milstein", {"grad_free": True}) if name == "milstein_grad_free" else (name, {})
+        # with bm=None the solver gets the Levy area it needs, so only the method / type rules can fail
+        fail = name == "blah" or _should_fail(noise, sde_type, method, "foster")
+        for names in (None, {"drift": "h"}):
+            kw = dict(method=method, dt=0.1, adaptive=adaptive, rtol=1e-2, atol=1e-2, logqp=logqp, options=options,
+                      names=names)
+            with torch.no_grad(), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                if fail:
+                    with pytest.raises(ValueError):
+                        torchsde_amd.sdeint(sde, y0, ts, **kw)
+                    continue
+                ans = torchsde_amd.sdeint(sde, y0, ts, **kw)
+            if logqp:
+                ans, log_ratio = ans
+                assert log_ratio.shape == (T - 1, B), (name, log_ratio.shape)
+            assert ans.shape == (T, B, d) and torch.isfinite(ans).all(), name
