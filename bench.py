@@ -1,6 +1,11 @@
 """Headline benchmark: SDE steps/sec (batch x timesteps / sec) of the fixed-step hot path.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL, either way it is started: under the driver's `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`, or as the plain command above, in which case bench.py starts the N ranks
+itself (and refuses, exit code 3, when the node has fewer than N GPUs). The line reports what the process group
+really was (`ranks_seen`, `rank_devices`, `collective_backend`) and the all-gather's own time per solve.
 
 One bench "step" = one full solve of the workload: BASELINE.json configs[1], diagonal-noise Ito
 Euler-Maruyama, batch 65536 x state 64, 1000 fixed solver steps (dyadic dt = 2^-10 so the count is exact
@@ -340,6 +345,58 @@ def _side_measurements(dev):
     return also
 
 
+def _what_the_ranks_saw(job, dev, dist, share_gpu):
+    """What a reader needs to believe an N-rank line: how many ranks the process group really had, which device each
+    one ran on, the backend, and what the one collective of a solve (the all-gather of final states) costs by itself."""
+    name = torch.cuda.get_device_name(dev)
+    if dist is None:
+        return {"ranks_seen": 1, "rank_devices": [f"rank 0: cuda:{dev.index} {name}"], "collective_backend": None,
+                "all_gather_ms_per_solve": None}
+    seen = [None] * dist.get_world_size()
+    dist.all_gather_object(seen, f"rank {dist.get_rank()}: cuda:{dev.index} {name} (pid {os.getpid()})")
+    gather_ms = None
+    if job.gathered is not None and not (job.adjoint or job.train):
+        local = torch.zeros((job.cfg["B"], job.cfg["d"]), device=dev)
+        for _ in range(3):
+            dist.all_gather_into_tensor(job.gathered, local)
+        dist.barrier()
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        for _ in range(20):
+            dist.all_gather_into_tensor(job.gathered, local)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - start) / 20 * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_ms = t.item()
+    return {"ranks_seen": dist.get_world_size(), "rank_devices": seen,
+            "collective_backend": dist.get_backend() + (" (TSDE_BENCH_SHARE_GPU: every rank on device 0)" if share_gpu
+                                                        else " (RCCL)" if dist.get_backend() == "nccl" else ""),
+            "all_gather_ms_per_solve": gather_ms,
+            "all_gather_bytes_per_rank": job.cfg["B"] * job.cfg["d"] * 4 if gather_ms is not None else None}
+
+
+def _self_launch(n_gpus, share_gpu):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here, exactly as the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    would, and hand back its exit code. Refuses to start when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if not share_gpu and have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} asked for, this node shows {have} GPU(s): not starting "
+              f"(one rank per GPU; RCCL refuses two ranks on one device)", file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -351,15 +408,19 @@ def main():
     ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
+    # TSDE_BENCH_SHARE_GPU=1 (tests only): all ranks use device 0 and gloo carries the collectives, so that the
+    # multi-rank logic of this file can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("TSDE_BENCH_SHARE_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU, RCCL)
+        raise SystemExit(_self_launch(args.gpus, share_gpu))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    # TSDE_BENCH_SHARE_GPU=1 (tests only): all ranks use device 0 and gloo carries the collectives, so that the
-    # multi-rank logic of this file can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
-    share_gpu = os.environ.get("TSDE_BENCH_SHARE_GPU") == "1"
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not share_gpu and torch.cuda.device_count() < local_rank + 1:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     device_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
@@ -403,6 +464,7 @@ def main():
         elapsed, median_ms = t[0].item(), t[1].item()
     assert torch.isfinite(out).all()
     value = world * B * nsteps * args.steps / elapsed
+    ranks = _what_the_ranks_saw(job, dev, dist if use_dist else None, share_gpu)
 
     k_ms, k_launches = job.bracket_dominant_kernel()
     b2b_us = job.back_to_back_step_diag_us(out) if cfg["kid"] == 1 and cfg["launches_per_step"] == 1 else None
@@ -442,6 +504,7 @@ def main():
                        "csrc_sha": csrc_digest()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        line.update(ranks)
         if also is not None:
             line["also"] = also
         print(json.dumps(line))

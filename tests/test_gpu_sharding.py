@@ -88,26 +88,34 @@ def test_sharded_processes_reproduce_the_unsharded_solve(world):
             torch.testing.assert_close(torch.from_numpy(got), ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "self"])
 @pytest.mark.parametrize("workload", [None, "c4_midpoint_diag_b32768_d64"])
-def test_bench_multi_rank_logic_on_one_gpu(workload):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with two ranks
-    sharing the one device and gloo for the collectives (TSDE_BENCH_SHARE_GPU=1): one JSON line from rank 0, the whole
-    job's trajectory-steps counted, weak scaling. Run for the default workload and for THE configs[3] run
-    (`--workload c4_midpoint_diag_b32768_d64`: Stratonovich midpoint, 32768 rows per rank)."""
+def test_bench_multi_rank_logic_on_one_gpu(workload, launcher):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) and as the PLAIN command
+    `python bench.py --gpus 2` (bench.py starts its own ranks), here with two ranks sharing the one device and gloo for
+    the collectives (TSDE_BENCH_SHARE_GPU=1): one JSON line from rank 0, the whole job's trajectory-steps counted,
+    weak scaling, and the line says how many ranks the process group really had. Run for the default workload and
+    for THE configs[3] run (`--workload c4_midpoint_diag_b32768_d64`: Stratonovich midpoint, 32768 rows per rank)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TSDE_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1"] + ([] if workload is None else ["--workload", workload])
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(key, None)
+    head = [sys.executable] if launcher == "self" else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+        "127.0.0.1", "--master-port", str(_free_port())]
+    cmd = head + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                  "--warmup", "1"] + ([] if workload is None else ["--workload", workload])
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1, proc.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["ranks_seen"] == 2 and len(rec["rank_devices"]) == 2 and rec["collective_backend"].startswith("gloo")
+    assert rec["all_gather_ms_per_solve"] > 0
     assert rec["config"]["global_batch"] == 2 * rec["config"]["batch_per_gpu"]
     if workload is not None:
         assert rec["config"]["workload"] == workload and rec["config"]["batch_per_gpu"] == 32768

@@ -352,3 +352,19 @@ def test_empty_brownian_interval_answers_without_a_device():
     bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(0, 3), levy_area_approximation="space-time")
     W, U = bm(0.1, 0.7, return_U=True)
     assert W.shape == (0, 3) and U.shape == (0, 3)
+
+
+def test_bench_refuses_to_start_more_ranks_than_gpus():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs: a clear message and a non-zero exit code BEFORE any
+    rank is started (RCCL would otherwise fail somewhere inside init with two ranks on one device)."""
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() + 1
+    if n < 2:
+        n = 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TSDE_BENCH_SHARE_GPU")}
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1"],
+                          capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert proc.returncode not in (0, None)
+    assert "not starting" in proc.stderr and not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
