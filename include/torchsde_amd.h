@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define TSDE_ABI_VERSION 1
+#define TSDE_ABI_VERSION 2
 #define TSDE_F32 0
 #define TSDE_F64 1
 
@@ -159,14 +159,17 @@ int tsde_milstein_gf_prime(void* yp, const void* y0, const void* f, const void* 
 int tsde_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gprime, int64_t n,
                           double dt, double sqrt_dt, int ito, const tsde_noise_t* noise, int dtype, void* stream);
 
-/* SRID2 stage kernels (diagonal noise). fs/gs: arrays of 4 device pointers (unused entries NULL).
- *   stage 1: out0=H0_1, out1=H1_1   from y0,f0,g0
- *   stage 2: out0=H0_2, out1=H1_2   from y0,f0,g0,f1,g1
- *   stage 3: out1=H1_3              from y0,g0,g1,f2,g2
- *   stage 4: out0=y1                from y0,f0..f2,g0..g3 */
-int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
-                        const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
-                        const tsde_noise_t* noise, int dtype, void* stream);
+/* SRID2 stage kernels (diagonal noise), wrapped around the caller's 3 drift and 4 diffusion evaluations
+ * (f0 = f(t0, y0), g0 = g(t0, y0), f1 = f(t0+dt, H0_1), g1 = g(t0+dt/4, H1_1), f2 = f(t0+dt/2, H0_2),
+ * g2 = g(t0+dt, H1_2), g3 = g(t0+dt/4, H1_3); srid2.py:21-22). Partial sums travel between the kernels, so a step
+ * moves 23 streams (6 + 8 + 6 + 3); every sum is formed in the reference's order (srk.py:70-87):
+ *   stage 1: in = {y0, f0, g0}           out = {H0_1, H1_1, H1_2}
+ *   stage 2: in = {y0, f0, g0, f1, g1}   out = {H0_2, acc, P}     acc = y1 after s = 0, 1; P = H1_3 after j = 0, 1
+ *   stage 3: in = {P, acc, f2, g2}       out = {H1_3, acc'}       acc' = y1 after s = 2 (may alias acc)
+ *   stage 4: in = {acc', g3}             out = {y1}
+ * (H1_2's j = 1 term has zero coefficients, srid2.py:36,48, and is not added: equal for finite f1, g1.) */
+int tsde_srk_diag_stage(int stage, void* const out[3], const void* const in[5], int64_t n, double dt, double rdt,
+                        double sqrt_dt, const tsde_noise_t* noise, int dtype, void* stream);
 
 /* Final stage of the Stratonovich predictor-corrector schemes, diagonal noise (or products when `prod`):
  *   mode 0, Heun       (_core/methods/heun.py:35-48):        y1 = y0 + (((dt*(f + fp)) + g*dW) + gp*dW) * 0.5

@@ -1,0 +1,211 @@
+"""The drop-in default ``hip_graph="auto"``: a caller who passes no options gets graph replay from the third solve
+of a structure on -- and exactly the eager results, also when the SDE object's Python-side state changes between
+calls, when its code cannot be captured, and when it is not deterministic. (`options={"hip_graph": False}` is the
+eager path these are compared with.)"""
+import warnings
+
+import pytest
+import torch
+from torch import nn
+
+from workloads import problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, D, STEPS, DT = 128, 8, 16, 2.0 ** -6
+
+
+def _bm(entropy, levy="none", shape=(B, D)):
+    import torchsde_amd
+    return torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=shape, device=DEV, dtype=torch.float32, entropy=entropy,
+                                         levy_area_approximation=levy)
+
+
+def _entries(sde, kind):
+    from torchsde_amd import graph
+    return [v for v in getattr(sde, graph._CACHE_ATTR, {}).values() if isinstance(v, kind)]
+
+
+def _solve(sde, entropy, y0, eager, method="euler", levy="none", **kw):
+    import torchsde_amd
+    ts = torch.tensor([0.0, 5 * DT, STEPS * DT], device=DEV)
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=_bm(entropy, levy), method=method, dt=DT,
+                                   options={"hip_graph": False} if eager else None, **kw)
+
+
+@pytest.mark.parametrize("prob,method,levy", [("gbm_ito", "euler", "none"), ("gbm_ito", "srk", "space-time"),
+                                              ("gbm_strat", "midpoint", "none"), ("mlpdiag_ito", "milstein", "none")])
+def test_no_options_reaches_graph_replay_and_equals_eager(prob, method, levy):
+    from torchsde_amd import graph
+    sde = problems.make(prob, d=D).to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for k, entropy in enumerate((11, 12, 13, 14)):
+        got = _solve(sde, entropy, y0 + 0.01 * k, eager=False, method=method, levy=levy)
+        assert torch.equal(got, _solve(sde, entropy, y0 + 0.01 * k, eager=True, method=method, levy=levy)), k
+        want = 0 if k == 0 else 1           # solve 0: eager and watched; solve 1: captured; then replays
+        assert len(_entries(sde, graph._CapturedSolve)) == want, k
+    with torch.no_grad():                   # parameters are read in place: an optimiser step needs no new graph
+        for p in sde.parameters():
+            p.mul_(0.9)
+    assert torch.equal(_solve(sde, 15, y0, eager=False, method=method, levy=levy),
+                       _solve(sde, 15, y0, eager=True, method=method, levy=levy))
+    assert len(_entries(sde, graph._CapturedSolve)) == 1
+
+
+class _Scaled(nn.Module):
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        super().__init__()
+        self.mu = nn.Parameter(torch.full((D,), -0.3))
+        self.scale = 1.0                                   # plain Python state
+        self.shift = torch.zeros(D, device=DEV)            # a tensor attribute that callers re-bind
+
+    def f(self, t, y):
+        return self.scale * self.mu * y + self.shift
+
+    def g(self, t, y):
+        return 0.2 * y
+
+
+def test_python_side_state_is_part_of_the_key():
+    sde = _Scaled().to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for entropy in (1, 2, 3):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    sde.scale = 2.5                                        # a graph recorded with scale = 1 must not serve this
+    for entropy in (4, 5, 6):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    sde.shift = torch.full((D,), 0.05, device=DEV)         # re-bound tensor: other storage
+    for entropy in (7, 8, 9):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    sde.shift.add_(0.01)                                   # in-place update: read live by the replay
+    assert torch.equal(_solve(sde, 10, y0, False), _solve(sde, 10, y0, True))
+
+
+class _Syncing(_Scaled):
+    def f(self, t, y):
+        if float(y.abs().max()) > 1e6:                     # host synchronisation inside the drift: not capturable
+            return torch.zeros_like(y)
+        return self.mu * y
+
+
+def test_code_that_synchronises_with_the_host_stays_eager_silently():
+    from torchsde_amd import graph
+    sde = _Syncing().to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                     # "silently": no warning from the fallback either
+        for entropy in (1, 2, 3, 4):
+            assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    assert not _entries(sde, graph._CapturedSolve) and len(_entries(sde, graph._Refused)) == 1
+    assert torch.cuda.get_sync_debug_mode() == 0
+
+
+_CALLS = []
+
+
+class _HiddenState(_Scaled):
+    def f(self, t, y):
+        _CALLS.append(1)                                   # state the fingerprint cannot see (a module-level list) ...
+        return (1.0 + 1e-3 * (len(_CALLS) % 7)) * self.mu * y     # ... that changes the numbers
+
+
+def test_a_replay_that_differs_from_the_eager_solve_is_refused():
+    from torchsde_amd import graph
+    sde = _HiddenState().to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for entropy in (1, 2, 3):
+        out = _solve(sde, entropy, y0, False)
+        assert torch.isfinite(out).all()
+    assert not _entries(sde, graph._CapturedSolve) and _entries(sde, graph._Refused)
+
+
+@pytest.mark.parametrize("prob,method,adjoint_method", [("mlpdiag_ito", "euler", "euler"), ("mlpdiag_ito", None, None),
+                                                        ("mlpdiag_strat", "midpoint", None),
+                                                        ("mlpdiag_strat", "reversible_heun", "adjoint_reversible_heun")])
+def test_sdeint_adjoint_with_no_options_replays_both_sweeps(prob, method, adjoint_method):
+    import torchsde_amd
+    from torchsde_amd import graph
+    sde = problems.make(prob, d=D).to(DEV)
+    ts = torch.tensor([0.0, 5 * DT, STEPS * DT], device=DEV)
+    levy = "space-time" if (method is None and "ito" in prob) else "none"
+
+    def grads(entropy, eager):
+        y0 = torch.full((B, D), 0.1, device=DEV, requires_grad=True)
+        opts = {"hip_graph": False} if eager else None
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(entropy, levy), method=method, adjoint_method=adjoint_method,
+                                         dt=DT, options=opts, adjoint_options=opts)
+        sde.zero_grad()
+        (ys[-1].sum() + 0.5 * ys[1].pow(2).sum()).backward()
+        return ys.detach(), [y0.grad] + [p.grad.clone() for p in sde.parameters()]
+
+    for k, entropy in enumerate((21, 22, 23, 24)):
+        ys_a, g_a = grads(entropy, False)
+        ys_e, g_e = grads(entropy, True)
+        assert torch.equal(ys_a, ys_e), k
+        for a, e in zip(g_a, g_e):
+            torch.testing.assert_close(a, e, rtol=1e-4, atol=1e-6)
+    assert len(_entries(sde, graph._CapturedSolve)) == 1 and len(_entries(sde, graph._CapturedBackward)) == 1
+
+
+def test_adaptive_solve_with_no_options_replays_the_attempt():
+    import torchsde_amd
+    from torchsde_amd import adaptive
+    sde = problems.make("gbm_ito", d=D).to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    ts = torch.tensor([0.0, 0.1, 0.25], device=DEV)
+
+    def solve(entropy, eager):
+        bm = torchsde_amd.BrownianInterval(0.0, 0.25, size=(B, D), device=DEV, dtype=torch.float32, entropy=entropy)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="milstein", dt=0.01, adaptive=True, rtol=1e-3,
+                                       atol=1e-4, options={"hip_graph": False} if eager else None)
+    for k, entropy in enumerate((1, 2, 3, 4)):
+        got = solve(entropy, False)
+        assert adaptive.last_stats["launch"] == ("eager" if k == 0 else "graph replay"), k
+        assert torch.equal(got, solve(entropy, True)), k
+
+
+class _PlainLeaf:
+    """Not an nn.Module: its trainable tensor is a plain attribute, invisible to `parameters()`."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        self.theta = torch.full((D,), -0.4, device=DEV, requires_grad=True)
+
+    def f(self, t, y):
+        return self.theta * y
+
+    def g(self, t, y):
+        return 0.1 * y
+
+
+def test_adaptive_solve_keeps_gradients_of_non_parameter_leaves():
+    """the device-controlled adaptive loop runs under no_grad; a solve whose f / g results require grad
+    through a tensor that is neither y0 nor a module parameter must take the host loop and keep its graph."""
+    import torchsde_amd
+    sde = _PlainLeaf()
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    ts = torch.tensor([0.0, 0.25], device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, 0.25, size=(B, D), device=DEV, dtype=torch.float32, entropy=3)
+    ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=0.01, adaptive=True, rtol=1e-2, atol=1e-3)
+    assert ys.requires_grad
+    ys[-1].sum().backward()
+    assert sde.theta.grad is not None and torch.isfinite(sde.theta.grad).all() and sde.theta.grad.abs().sum() > 0
+
+
+def test_unusable_adjoint_method_only_fails_when_a_backward_pass_can_follow():
+    """The reference raises for an adjoint method it cannot use when backward() runs (adjoint.py:64-96), so forward-only
+    calls work; here the error comes at call time, but not under no_grad."""
+    import torchsde_amd
+    sde = problems.make("mlpdiag_ito", d=D).to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    ts = torch.tensor([0.0, STEPS * DT], device=DEV)
+    with torch.no_grad():
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(1), method="euler", adjoint_method="reversible_heun", dt=DT)
+    assert ys.shape == (2, B, D)
+    with pytest.raises((ValueError, RuntimeError)):
+        torchsde_amd.sdeint_adjoint(sde, y0.clone().requires_grad_(True), ts, bm=_bm(1), method="euler",
+                                    adjoint_method="reversible_heun", dt=DT)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_binding_covers_header():
     assert sorted(_native.SIGNATURES) == _header_symbols()
-    assert _native.load().tsde_abi_version() == 1
+    assert _native.load().tsde_abi_version() == 2
 
 
 def test_noise_struct_layout_matches_header():
@@ -368,3 +368,38 @@ def test_bench_refuses_to_start_more_ranks_than_gpus():
                           capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert proc.returncode not in (0, None)
     assert "not starting" in proc.stderr and not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_srk_stage_decomposition_equals_the_reference_step(dtype):
+    """The four SRID2 stage kernels hand partial sums to each other (H1_2 from stage 1, y1's running sum and H1_3's
+    first two terms from stage 2, ...). Their torch twin (the differentiable form used when autograd runs through the
+    solver; same operation order as csrc/steps.hip SrkDiagOp) must give the bits of the reference's step as the oracle
+    restates it (oracle/solvers_ref.py srk_step <- methods/srk.py:57-88)."""
+    from oracle import solvers_ref
+    from torchsde_amd import kernels as K
+    torch.manual_seed(5)
+    B, d, dt = 37, 8, 2.0 ** -4
+    sde = problems.make("gbm_ito", d=d).to(dtype)
+    y0 = (0.1 + torch.rand(B, d)).to(dtype)
+    W = (torch.randn(B, d) * dt ** 0.5).to(dtype)
+    U = (dt * (0.5 * W + torch.randn(B, d).to(dtype) * (dt / 12) ** 0.5)).to(dtype)
+    t0, t1 = torch.tensor(0.25, dtype=dtype), torch.tensor(0.25 + dt, dtype=dtype)
+
+    def bm(ta, tb, return_U=False):
+        return (W, U) if return_U else W
+    with torch.no_grad():
+        want = solvers_ref.srk_step(sde, bm, t0, t1, y0)
+    noise = K.NoiseSpec.external(W, U)
+    h = t1 - t0
+    dtn, rdt, sqrt_dt = float(h), float(1 / h), float(h.sqrt())
+    y = y0.clone().requires_grad_(True)      # grad mode: the torch twin of the stage kernels runs (CPU tensors)
+    t_q, t_h = t0 + 0.25 * h, t0 + 0.5 * h
+    f0, g0 = sde.f(t0, y), sde.g(t0, y)
+    H0_1, H1_1, H1_2 = K.srk_diag_stage(1, (y, f0, g0), dtn, rdt, sqrt_dt, noise)
+    f1, g1 = sde.f(t1, H0_1), sde.g(t_q, H1_1)
+    H0_2, acc, P = K.srk_diag_stage(2, (y, f0, g0, f1, g1), dtn, rdt, sqrt_dt, noise)
+    f2, g2 = sde.f(t_h, H0_2), sde.g(t1, H1_2)
+    H1_3, acc = K.srk_diag_stage(3, (P, acc, f2, g2), dtn, rdt, sqrt_dt, noise)
+    (y1,) = K.srk_diag_stage(4, (acc, sde.g(t_q, H1_3)), dtn, rdt, sqrt_dt, noise)
+    assert torch.equal(y1.detach(), want)

@@ -63,6 +63,8 @@ class Traj(ctypes.Structure):
 
 
 _PTR4 = _c_ptr * 4
+_PTR3 = _c_ptr * 3
+_PTR5 = _c_ptr * 5
 
 # name -> (restype, argtypes); mirrors include/torchsde_amd.h one to one.
 SIGNATURES = {
@@ -91,8 +93,8 @@ SIGNATURES = {
                                         _c_ptr]),
     "tsde_milstein_gf_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_int,
                                        ctypes.POINTER(Noise), _c_int, _c_ptr]),
-    "tsde_srk_diag_stage": (_c_int, [_c_int, _c_ptr, _c_ptr, _c_ptr, _PTR4, _PTR4, _c_i64, _c_dbl, _c_dbl, _c_dbl,
-                                     ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_srk_diag_stage": (_c_int, [_c_int, _PTR3, _PTR5, _c_i64, _c_dbl, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int,
+                                     _c_ptr]),
     "tsde_heun_final": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_int,
                                  ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_iterated_integrals": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_dbl, _c_int, _c_int, _c_ptr]),
@@ -165,7 +167,7 @@ def load():
             raise NativeLibraryError(f"torchsde_amd: {LIB_PATH} does not export `{name}`; rebuild it.") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.tsde_abi_version() != 1:
+    if lib.tsde_abi_version() != 2:
         raise NativeLibraryError("torchsde_amd: ABI version mismatch between the Python host code and the .so")
     _lib = lib
     return lib

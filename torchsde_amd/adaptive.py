@@ -103,15 +103,32 @@ def query_dev(bm, bounds_ptr, out_W, out_U, out_H):
     _native.check(code, "tsde_brownian_query_dev")
 
 
+def _no_gradient_can_flow(solver, y0, ts):
+    """The device-controlled loop runs under no_grad, so it may only take solves that autograd would not record anyway.
+    `_tracks_grad` sees y0 and the module's parameters; a trainable tensor that is neither (a plain attribute with
+    requires_grad=True, a leaf captured in a closure) only shows in what f and g return, so with grad mode on they
+    are probed once (the reference and the host loop propagate such gradients: base_solver.py:117-142)."""
+    if not torch.is_grad_enabled():
+        return True
+    if solver._tracks_grad(y0):
+        return False
+    try:
+        probes = solver.sde.f_and_g_prod(ts[0], y0, torch.zeros(solver.bm.shape, dtype=y0.dtype, device=y0.device)) \
+            if solver.sde.user_product else solver.sde.f_and_g(ts[0], y0)
+    except Exception:     # a provider the probe cannot call: leave the solve to the host loop
+        return False
+    return not any(torch.is_tensor(p) and p.requires_grad for p in probes)
+
+
 def usable(solver, y0, ts):
     """Can this solve run with device-side control? (Otherwise: the host-driven loop, one sync per attempt.)"""
     bm = solver._native_bm()
     return (bm is not None and solver.options.get("device_adaptive", True)
             and bm._snap == 0 and bm._tol == 0. and bm._rootW is None and bm._rootH is None
             and not solver.stateful and solver.merges_half_steps and not solver.options.get("general_noise", False)
-            and not solver._tracks_grad(y0)
             and y0.dtype == ts.dtype == bm.dtype and y0.dtype in (torch.float32, torch.float64)
-            and len(solver.stage_fracs) <= _native.ADAPTIVE_MAX_STAGES - 1 and y0.numel() > 0)
+            and len(solver.stage_fracs) <= _native.ADAPTIVE_MAX_STAGES - 1 and y0.numel() > 0
+            and _no_gradient_can_flow(solver, y0, ts))
 
 
 class _Attempt:
@@ -216,10 +233,13 @@ class _GraphedAttempt(_Attempt):
 
 def _attempt_for(solver, y0, ts_host, step_cls):
     """This solve's `_Attempt`: a fresh one, or with ``hip_graph`` the cached graph of the same structure."""
-    if not solver.options.get("hip_graph", False):
-        return _Attempt(solver, y0, step_cls)
     from . import graph as graph_module
     bm = solver._native_bm()
+    mode = graph_module.mode_of(solver.options)
+    if mode == "auto" and not graph_module._auto_eligible(bm, y0, len(ts_host)):
+        mode = False
+    if not mode:
+        return _Attempt(solver, y0, step_cls)
     chain, base = graph_module._wrapper_chain(solver.sde)
     params = tuple(p.data_ptr() for p in base.parameters()) if hasattr(base, "parameters") else ()
     sig = ("adaptive-attempt", type(solver).__name__, chain, getattr(solver.sde, "sde_type", None),
@@ -228,6 +248,28 @@ def _attempt_for(solver, y0, ts_host, step_cls):
            bm._edges.tobytes(), bm._max_depth,
            tuple(sorted((k, v) for k, v in solver.options.items() if isinstance(v, (bool, int, float, str)))))
     cache = graph_module._cache_of(base)
+    if mode == "auto":
+        # the drop-in default (graph.py): the first solve of a structure runs eagerly, the second records the attempt,
+        # later ones replay it; the Python-side state of the SDE object is part of the key, and code that cannot be
+        # captured (it synchronises with the host, say) stays eager for good
+        state = graph_module.python_state(base)
+        if state is None:
+            return _Attempt(solver, y0, step_cls)
+        sig = ("auto", state) + sig
+        entry = cache.get(sig)
+        if entry is None:
+            graph_module._remember(cache, sig, graph_module._Seen())
+            return _Attempt(solver, y0, step_cls)
+        if isinstance(entry, graph_module._Refused):
+            return _Attempt(solver, y0, step_cls)
+        if isinstance(entry, graph_module._Seen):
+            try:
+                with graph_module._drift_then_diffusion(solver.sde):
+                    cache[sig] = entry = _GraphedAttempt(solver, y0, step_cls)
+            except Exception as e:
+                cache[sig] = graph_module._Refused(f"capture failed: {type(e).__name__}: {e}")
+                return _Attempt(solver, y0, step_cls)
+        return entry
     attempt = cache.get(sig)
     if attempt is None:
         attempt = _GraphedAttempt(solver, y0, step_cls)

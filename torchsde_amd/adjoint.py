@@ -446,7 +446,8 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                                          adjoint_method == METHODS.adjoint_reversible_heun)
         extras_for_backward = tuple(extra_solver_state) if ctx.saved_extras_for_backward else ()
         ctx.save_for_backward(ys, ts, *extras_for_backward, *adjoint_params)
-        ctx.captured_backward = None   # set by `sdeint_adjoint` when adjoint_options={"hip_graph": True}
+        ctx.captured_backward = None   # set by `sdeint_adjoint` when the backward sweep is to replay a HIP graph
+        ctx.watch_backward = None      # ... or ("auto") when an eager sweep is to report whether it synchronised
         return (ys, *extra_solver_state)
 
     @staticmethod
@@ -496,13 +497,18 @@ class _SdeintAdjointMethod(torch.autograd.Function):
         else:
             kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
             run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
-            out = run(*inputs)
+            if ctx.watch_backward is not None:
+                from . import graph
+                out, synced = graph.run_watching_for_host_syncs(lambda: run(*inputs))
+                ctx.watch_backward(synced)
+            else:
+                out = run(*inputs)
         if reversible:      # a_y, (a_f, a_g, a_z), a_theta...
             return (None,) * 13 + tuple(out)
         return (None,) * 13 + tuple([out[0]] + ([None] * ctx.len_extras) + list(out[1:]))
 
 
-def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys, forward_extras):
+def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys, forward_extras, auto=False):
     """HIP graph of the backward sweep (cached per structure on the SDE object), or None -> eager backward.
 
     The VJPs of the sweep are taken w.r.t. the parameters. The real parameters already carry AccumulateGrad nodes
@@ -513,7 +519,7 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
     from torch.nn.utils.stateless import _reparametrize_module
     from . import graph
     if not isinstance(sde, nn.Module):
-        return None
+        return (None, None) if auto else None
     ts_host = timegrid.ts_to_host(ts)
     kind = _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params)
     signature = ("adjoint-backward", kind, sde.sde_type, sde.noise_type, tuple(ys.shape), ys.dtype, str(ys.device),
@@ -524,20 +530,24 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
         swapped = {name: alias_of[id(p)] for name, p in sde.named_parameters(remove_duplicate=False)
                    if id(p) in alias_of}
         if len({id(a) for a in swapped.values()}) != len(alias_of):
-            warnings.warn("adjoint_options['hip_graph'] needs every adjoint parameter to be a parameter of the SDE "
-                          "module; running the backward pass eagerly.")
+            if not auto:
+                warnings.warn("adjoint_options['hip_graph'] needs every adjoint parameter to be a parameter of the SDE "
+                              "module; running the backward pass eagerly.")
             return None
         run = _backward_runner(sde, bm, dt, kind, [alias_of[id(p)] for p in adjoint_params], ts_host, ys.device)
-        # zero cotangents: the capture only records; `backward` copies the real ones in before each replay
-        inputs = [ys, torch.zeros_like(ys)] + list(forward_extras) + [torch.zeros_like(x) for x in forward_extras]
+        # The capture only records; `backward` copies the real cotangents in before each replay. Zero cotangents
+        # will do -- except for "auto", which compares a replay with the eager sweep and needs gradients that are
+        # not identically zero for that.
+        fill = torch.ones_like if auto else torch.zeros_like
+        inputs = [ys, fill(ys)] + list(forward_extras) + [fill(x) for x in forward_extras]
         with torch.no_grad(), _reparametrize_module(sde, swapped):
-            return graph._CapturedBackward(run, bm, inputs, keepalive=(run.plan,))
+            return graph._CapturedBackward(run, bm, inputs, keepalive=(run.plan,), verify=auto)
 
     def tuned_capture():       # drift and diffusion in sequence or as parallel graph branches: whichever replays faster
         from .sde import ForwardSDE
         return graph.faster_of_sequential_and_parallel(sde if isinstance(sde, ForwardSDE) else None, capture, ys.device)
 
-    return graph.cached_backward(sde, bm, signature, tuned_capture)
+    return graph.cached_backward(sde, bm, signature, capture if auto else tuned_capture, auto=auto)
 
 
 def _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params):
@@ -780,8 +790,11 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
     solver_cls = solvers.select(method=method, sde_type=sde.sde_type)
     solver = solver_cls(sde=sde, bm=bm, dt=dt, adaptive=adaptive, rtol=rtol, atol=atol, dt_min=dt_min,
                         options=options)
-    # fail early (at call time, like the reference would at backward time) on unusable adjoint methods
-    _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
+    # An unusable adjoint method fails in the reference when backward() constructs the backward solver
+    # (adjoint.py:64-96), so forward-only and no-grad calls go through there; here it is reported at call time, but
+    # only when a backward pass can follow at all.
+    if torch.is_grad_enabled() and (y0.requires_grad or adjoint_params):
+        _check_adjoint_method(AdjointSDE(sde, adjoint_params), adjoint_method, adjoint_options, bm)
     # the perceptron-drift module with adjoint_method="euler": forward and backward solves on the matrix cores
     if torch.is_grad_enabled() and (y0.requires_grad or adjoint_params):
         from . import mlp_adjoint
@@ -798,15 +811,23 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
     ys, *extra_solver_state = _SdeintAdjointMethod.apply(
         sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
-    if (adjoint_options.get("hip_graph", False) and not adjoint_adaptive and ys.grad_fn is not None
-            and isinstance(bm, BrownianInterval)):
+    from . import graph
+    graph_mode = graph.mode_of(adjoint_options)
+    if graph_mode == "auto" and not (isinstance(sde, nn.Module) and graph._auto_eligible(bm, y0, len(ts))):
+        graph_mode = False
+    if graph_mode and not adjoint_adaptive and ys.grad_fn is not None and isinstance(bm, BrownianInterval):
         # The backward sweep replays ONE HIP graph, captured HERE (on the caller's thread, outside the autograd
-        # Function) with zero cotangents; `backward` only copies ys / grad_ys into the graph's static inputs and
-        # replays. `ys.grad_fn` is the Function's ctx.
+        # Function); `backward` only copies ys / grad_ys into the graph's static inputs and replays. `ys.grad_fn` is
+        # the Function's ctx. "auto" (the default): the first sweep of a structure runs eagerly and is watched for
+        # host synchronisation, the second is captured and checked against an eager sweep, later ones replay.
         reversible = method == METHODS.reversible_heun and adjoint_method == METHODS.adjoint_reversible_heun
-        ys.grad_fn.captured_backward = _capture_backward(
+        captured = _capture_backward(
             sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys.detach(),
-            [x.detach() for x in extra_solver_state] if reversible else [])
+            [x.detach() for x in extra_solver_state] if reversible else [], auto=graph_mode == "auto")
+        if graph_mode == "auto":
+            ys.grad_fn.captured_backward, ys.grad_fn.watch_backward = captured
+        else:
+            ys.grad_fn.captured_backward = captured
     return contract.parse_return(y0, ys, tuple(extra_solver_state), extra, logqp)
 
 

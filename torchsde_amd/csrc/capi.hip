@@ -235,22 +235,20 @@ int tsde_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g
                 tsde::launch_milstein_gf_diag<double>(y1, y0, f, g, gprime, n, dt, sqrt_dt, ito, noise, s));
 }
 
-int tsde_srk_diag_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
-                        const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
-                        const tsde_noise_t* noise, int dtype, void* stream) {
-  if (!y0 || !fs || !gs || !noise) return bad_arg("tsde_srk_diag_stage", "null argument");
+int tsde_srk_diag_stage(int stage, void* const out[3], const void* const in[5], int64_t n, double dt, double rdt,
+                        double sqrt_dt, const tsde_noise_t* noise, int dtype, void* stream) {
+  if (!out || !in || !noise) return bad_arg("tsde_srk_diag_stage", "null argument");
   if (stage < 1 || stage > 4) return bad_arg("tsde_srk_diag_stage", "stage must be 1..4");
-  for (int j = 0; j < stage && j < 4; ++j) {
-    const bool need_g = (stage < 4) ? (j < stage) : true;
-    if (need_g && !gs[j]) return bad_arg("tsde_srk_diag_stage", "missing g pointer");
-  }
-  if (stage == 4 && (!fs[0] || !fs[1] || !fs[2] || !gs[3] || !out0))
-    return bad_arg("tsde_srk_diag_stage", "stage 4 needs f0..f2, g0..g3, out0");
+  static const int n_in[5] = {0, 3, 5, 4, 2}, n_out[5] = {0, 3, 3, 2, 1};
+  for (int j = 0; j < n_in[stage]; ++j)
+    if (!in[j]) return bad_arg("tsde_srk_diag_stage", "missing input pointer (stage 1: 3, 2: 5, 3: 4, 4: 2 inputs)");
+  for (int j = 0; j < n_out[stage]; ++j)
+    if (!out[j]) return bad_arg("tsde_srk_diag_stage", "missing output pointer (stage 1: 3, 2: 3, 3: 2, 4: 1 outputs)");
   const hipStream_t s = (hipStream_t)stream;
   ProfScope p(TSDE_KID_SRK_STAGE, s);
   TSDE_DISPATCH(dtype, "tsde_srk_diag_stage",
-                tsde::launch_srk_stage<float>(stage, out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, noise, s),
-                tsde::launch_srk_stage<double>(stage, out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, noise, s));
+                tsde::launch_srk_stage<float>(stage, out, in, n, dt, rdt, sqrt_dt, noise, s),
+                tsde::launch_srk_stage<double>(stage, out, in, n, dt, rdt, sqrt_dt, noise, s));
 }
 
 int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp, int64_t n,

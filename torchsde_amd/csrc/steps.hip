@@ -162,58 +162,77 @@ struct MilsteinGfDiagOp {
 };
 
 // ---- SRK (SRID2, diagonal noise): tableau and per-element arithmetic live in tsde_schemes.h -----------
+// Four kernels around the user's f, g evaluations (3 f + 4 g per step). Partial sums travel between them so that a
+// later kernel never re-reads what an earlier one already folded in -- 23 streams per step (6 + 8 + 6 + 3):
+//   stage 1: in  y0, f0, g0             out H0_1, H1_1, H1_2
+//   stage 2: in  y0, f0, g0, f1, g1     out H0_2, acc = y1 after s = 0, 1 (srk.py:87), P = H1_3 after j = 0, 1
+//   stage 3: in  P, acc, f2, g2         out H1_3, acc = y1 after s = 2
+//   stage 4: in  acc, g3                out y1
+// Every sum is formed in the reference's own order (H_s over j ascending, y1 over s ascending, srk.py:70-87), so the
+// bits are the reference's. One liberty, as for the drift terms `Srid2::need_f` already drops: H1_2's j = 1 term has
+// A1 = B1 = 0 (srid2.py:36,48) and is not added -- `x + 0*f1*dt + 0*g1*sqrt_dt == x` for finite f1, g1 (torch.equal;
+// only the sign of an exact zero could differ) -- which is what lets stage 1 emit H1_2 before f1, g1 exist.
 template <typename T, int STAGE>
 struct SrkDiagOp {
-  T *out0, *out1;
-  const T* y0;
-  const T* fs[4];
-  const T* gs[4];
+  T* out[3];
+  const T* in[5];
   Coef<T> dt_, rdt_, sqrt_dt_;
   CellNoise<T> nz;
 
   template <int W, bool NT = false>
   TSDE_D void run(int64_t i) const {
     const T dt = dt_.get(), rdt = rdt_.get(), sqrt_dt = sqrt_dt_.get();
-    const Pack<T, W> y = load<T, W, NT>(y0, i);
-    Pack<T, W> w, u;
-    cell_noise<T, W, true>(nz, i, w, u);
-    if constexpr (STAGE < 4) {
-      // Stage states H0_s, H1_s for s = STAGE. f-terms whose A-coefficient is zero for every j are not
-      // loaded (they only add +0.0).
-      constexpr int s = STAGE;
-      Pack<T, W> fj[3], gj[3];
-#pragma unroll
-      for (int j = 0; j < s; ++j) {
-        if (Srid2::need_f(s, j)) fj[j] = load<T, W, NT>(fs[j], i);
-        gj[j] = load<T, W, NT>(gs[j], i);
-      }
-      Pack<T, W> h0, h1;
+    constexpr T zero = (T)0;
+    if constexpr (STAGE == 1) {
+      const Pack<T, W> y = load<T, W, NT>(in[0], i), f0 = load<T, W, NT>(in[1], i), g0 = load<T, W, NT>(in[2], i);
+      Pack<T, W> w, u, h01, h11, h12;
+      cell_noise<T, W, true>(nz, i, w, u);
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        T f[3], g[3];
-#pragma unroll
-        for (int j = 0; j < s; ++j) {
-          f[j] = Srid2::need_f(s, j) ? fj[j].v[k] : (T)0;
-          g[j] = gj[j].v[k];
-        }
-        srid2_stage_states<T, s>(y.v[k], f, g, u.v[k], dt, rdt, sqrt_dt, h0.v[k], h1.v[k]);
+        h01.v[k] = srid2_h0_term<T, 1, 0>(y.v[k], f0.v[k], g0.v[k], u.v[k], dt, rdt);
+        h11.v[k] = srid2_h1_term<T, 1, 0>(y.v[k], f0.v[k], g0.v[k], dt, sqrt_dt);
+        h12.v[k] = srid2_h1_term<T, 2, 0>(y.v[k], f0.v[k], g0.v[k], dt, sqrt_dt);
       }
-      if (out0) store<T, W, NT>(out0, i, h0);
-      if (out1) store<T, W, NT>(out1, i, h1);
+      store<T, W, NT>(out[0], i, h01);
+      store<T, W, NT>(out[1], i, h11);
+      store<T, W, NT>(out[2], i, h12);
+    } else if constexpr (STAGE == 2) {
+      const Pack<T, W> y = load<T, W, NT>(in[0], i), f0 = load<T, W, NT>(in[1], i), g0 = load<T, W, NT>(in[2], i),
+                       f1 = load<T, W, NT>(in[3], i), g1 = load<T, W, NT>(in[4], i);
+      Pack<T, W> w, u, h02, acc, p13;
+      cell_noise<T, W, true>(nz, i, w, u);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        T h = srid2_h0_term<T, 2, 0>(y.v[k], f0.v[k], g0.v[k], u.v[k], dt, rdt);
+        h02.v[k] = srid2_h0_term<T, 2, 1>(h, f1.v[k], g1.v[k], u.v[k], dt, rdt);
+        T a = srid2_final_term<T, 0>(y.v[k], f0.v[k], g0.v[k], w.v[k], u.v[k], dt, rdt, sqrt_dt);
+        acc.v[k] = srid2_final_term<T, 1>(a, f1.v[k], g1.v[k], w.v[k], u.v[k], dt, rdt, sqrt_dt);
+        T p = srid2_h1_term<T, 3, 0>(y.v[k], zero, g0.v[k], dt, sqrt_dt);      // A1(3,0) = A1(3,1) = 0: need_f is false
+        p13.v[k] = srid2_h1_term<T, 3, 1>(p, zero, g1.v[k], dt, sqrt_dt);
+      }
+      store<T, W, NT>(out[0], i, h02);
+      store<T, W, NT>(out[1], i, acc);
+      store<T, W, NT>(out[2], i, p13);
+    } else if constexpr (STAGE == 3) {
+      const Pack<T, W> p = load<T, W, NT>(in[0], i), a = load<T, W, NT>(in[1], i), f2 = load<T, W, NT>(in[2], i),
+                       g2 = load<T, W, NT>(in[3], i);
+      Pack<T, W> w, u, h13, acc;
+      cell_noise<T, W, true>(nz, i, w, u);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        h13.v[k] = srid2_h1_term<T, 3, 2>(p.v[k], f2.v[k], g2.v[k], dt, sqrt_dt);
+        acc.v[k] = srid2_final_term<T, 2>(a.v[k], f2.v[k], g2.v[k], w.v[k], u.v[k], dt, rdt, sqrt_dt);
+      }
+      store<T, W, NT>(out[0], i, h13);
+      store<T, W, NT>(out[1], i, acc);
     } else {
-      Pack<T, W> fj[3], gj[4], acc;
+      const Pack<T, W> a = load<T, W, NT>(in[0], i), g3 = load<T, W, NT>(in[1], i);
+      Pack<T, W> w, u, y1;
+      cell_noise<T, W, true>(nz, i, w, u);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        gj[s] = load<T, W, NT>(gs[s], i);
-        if (s < 3) fj[s] = load<T, W, NT>(fs[s], i);
-      }
-#pragma unroll
-      for (int k = 0; k < W; ++k) {
-        const T f[3] = {fj[0].v[k], fj[1].v[k], fj[2].v[k]};
-        const T g[4] = {gj[0].v[k], gj[1].v[k], gj[2].v[k], gj[3].v[k]};
-        acc.v[k] = srid2_final<T>(y.v[k], f, g, w.v[k], u.v[k], dt, rdt, sqrt_dt);
-      }
-      store<T, W, NT>(out0, i, acc);
+      for (int k = 0; k < W; ++k)
+        y1.v[k] = srid2_final_term<T, 3>(a.v[k], zero, g3.v[k], w.v[k], u.v[k], dt, rdt, sqrt_dt);
+      store<T, W, NT>(out[0], i, y1);
     }
   }
 };
@@ -597,20 +616,20 @@ hipError_t launch_milstein_gf_diag(void* y1, const void* y0, const void* f, cons
   return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
+constexpr int kSrkIn[5] = {0, 3, 5, 4, 2}, kSrkOut[5] = {0, 3, 3, 2, 1};   // operand counts of stages 1..4
+
 template <typename T, int STAGE>
-static hipError_t launch_srk_stage_t(void* out0, void* out1, const void* y0, const void* const fs[4],
-                                     const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
-                                     const tsde_noise_t* nz, hipStream_t s) {
+static hipError_t launch_srk_stage_t(void* const out[3], const void* const in[5], int64_t n, double dt, double rdt,
+                                     double sqrt_dt, const tsde_noise_t* nz, hipStream_t s) {
   SrkDiagOp<T, STAGE> op;
-  op.out0 = (T*)out0;
-  op.out1 = (T*)out1;
-  op.y0 = (const T*)y0;
-  bool vec = (n % 4 == 0) && aligned16(y0) && (!out0 || aligned16(out0)) && (!out1 || aligned16(out1)) &&
-             noise_vec_ok(nz, true);
-  for (int j = 0; j < 4; ++j) {
-    op.fs[j] = (const T*)fs[j];
-    op.gs[j] = (const T*)gs[j];
-    vec = vec && (!fs[j] || aligned16(fs[j])) && (!gs[j] || aligned16(gs[j]));
+  bool vec = (n % 4 == 0) && noise_vec_ok(nz, true);
+  for (int j = 0; j < 3; ++j) {
+    op.out[j] = j < kSrkOut[STAGE] ? (T*)out[j] : nullptr;
+    vec = vec && aligned16(op.out[j]);
+  }
+  for (int j = 0; j < 5; ++j) {
+    op.in[j] = j < kSrkIn[STAGE] ? (const T*)in[j] : nullptr;
+    vec = vec && aligned16(op.in[j]);
   }
   op.dt_ = coef<T>(dt);
   op.rdt_ = coef<T>(rdt);
@@ -620,14 +639,13 @@ static hipError_t launch_srk_stage_t(void* out0, void* out1, const void* y0, con
 }
 
 template <typename T>
-hipError_t launch_srk_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
-                            const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
-                            const tsde_noise_t* nz, hipStream_t s) {
+hipError_t launch_srk_stage(int stage, void* const out[3], const void* const in[5], int64_t n, double dt, double rdt,
+                            double sqrt_dt, const tsde_noise_t* nz, hipStream_t s) {
   switch (stage) {
-    case 1: return launch_srk_stage_t<T, 1>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
-    case 2: return launch_srk_stage_t<T, 2>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
-    case 3: return launch_srk_stage_t<T, 3>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
-    case 4: return launch_srk_stage_t<T, 4>(out0, out1, y0, fs, gs, n, dt, rdt, sqrt_dt, nz, s);
+    case 1: return launch_srk_stage_t<T, 1>(out, in, n, dt, rdt, sqrt_dt, nz, s);
+    case 2: return launch_srk_stage_t<T, 2>(out, in, n, dt, rdt, sqrt_dt, nz, s);
+    case 3: return launch_srk_stage_t<T, 3>(out, in, n, dt, rdt, sqrt_dt, nz, s);
+    case 4: return launch_srk_stage_t<T, 4>(out, in, n, dt, rdt, sqrt_dt, nz, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -745,8 +763,8 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
                                                   double, int, hipStream_t);                                         \
   template hipError_t launch_milstein_gf_diag<T>(void*, const void*, const void*, const void*, const void*, int64_t, \
                                                  double, double, int, const tsde_noise_t*, hipStream_t);             \
-  template hipError_t launch_srk_stage<T>(int, void*, void*, const void*, const void* const[4], const void* const[4], \
-                                          int64_t, double, double, double, const tsde_noise_t*, hipStream_t);        \
+  template hipError_t launch_srk_stage<T>(int, void* const[3], const void* const[5], int64_t, double, double, double, \
+                                          const tsde_noise_t*, hipStream_t);                                         \
   template hipError_t launch_aug_segments<T>(const tsde_seg_t*, int, double, double, hipStream_t);                   \
   template hipError_t launch_interp<T>(void*, const void*, const void*, int64_t, double, double, hipStream_t);
 

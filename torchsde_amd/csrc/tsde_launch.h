@@ -51,9 +51,8 @@ template <typename T>
 hipError_t launch_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g, const void* gp, int64_t n,
                                    double dt, double sqrt_dt, int ito, const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
-hipError_t launch_srk_stage(int stage, void* out0, void* out1, const void* y0, const void* const fs[4],
-                            const void* const gs[4], int64_t n, double dt, double rdt, double sqrt_dt,
-                            const tsde_noise_t* nz, hipStream_t s);
+hipError_t launch_srk_stage(int stage, void* const out[3], const void* const in[5], int64_t n, double dt, double rdt,
+                            double sqrt_dt, const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
 hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, double cG, hipStream_t s);
 template <typename T>

@@ -75,34 +75,53 @@ struct Srid2 {
   static TSDE_HD constexpr bool need_f(int s, int j) { return A0(s, j) != 0.0 || A1(s, j) != 0.0; }
 };
 
+// One term of the stage-state recursion (srk.py:74-75), stage STAGE, earlier stage J. `f` must be 0 where
+// !need_f(STAGE, J) (the reference multiplies the real f by a zero coefficient: +0 for finite f).
+template <typename T, int STAGE, int J, typename S = T>
+TSDE_D S srid2_h0_term(S h0, S f, S g, T u, T dt, T rdt) {
+  return (h0 + ((T)Srid2::A0(STAGE, J) * f) * dt) + (((T)Srid2::B0(STAGE, J) * g) * u) * rdt;
+}
+template <typename T, int STAGE, int J, typename S = T>
+TSDE_D S srid2_h1_term(S h1, S f, S g, T dt, T sqrt_dt) {
+  return (h1 + ((T)Srid2::A1(STAGE, J) * f) * dt) + ((T)Srid2::B1(STAGE, J) * g) * sqrt_dt;
+}
+
 // Stage states H0_s, H1_s (srk.py:69-77) from the s = STAGE earlier stages; f[j] must be 0 where !need_f(s, j).
 template <typename T, int STAGE, typename S = T>
 TSDE_D void srid2_stage_states(S y, const S* f, const S* g, T u, T dt, T rdt, T sqrt_dt, S& h0, S& h1) {
   h0 = y;
   h1 = y;
-#pragma unroll
-  for (int j = 0; j < STAGE; ++j) {
-    h0 = (h0 + ((T)Srid2::A0(STAGE, j) * f[j]) * dt) + (((T)Srid2::B0(STAGE, j) * g[j]) * u) * rdt;
-    h1 = (h1 + ((T)Srid2::A1(STAGE, j) * f[j]) * dt) + ((T)Srid2::B1(STAGE, j) * g[j]) * sqrt_dt;
-  }
+  if constexpr (STAGE > 0) { h0 = srid2_h0_term<T, STAGE, 0, S>(h0, f[0], g[0], u, dt, rdt); h1 = srid2_h1_term<T, STAGE, 0, S>(h1, f[0], g[0], dt, sqrt_dt); }
+  if constexpr (STAGE > 1) { h0 = srid2_h0_term<T, STAGE, 1, S>(h0, f[1], g[1], u, dt, rdt); h1 = srid2_h1_term<T, STAGE, 1, S>(h1, f[1], g[1], dt, sqrt_dt); }
+  if constexpr (STAGE > 2) { h0 = srid2_h0_term<T, STAGE, 2, S>(h0, f[2], g[2], u, dt, rdt); h1 = srid2_h1_term<T, STAGE, 2, S>(h1, f[2], g[2], dt, sqrt_dt); }
 }
 
-// y1 = y0 + sum_s [alpha_s f_s dt + g_s * g_weight_s]   (srk.py:79-87); alpha_3 = 0 so f_3 does not exist.
+// The weight g_s is multiplied with in the final sum (srk.py:80-85), stage S_.
+template <typename T, int S_>
+TSDE_D T srid2_g_weight(T Ik, T u, T dt, T rdt, T sqrt_dt) {
+  const T Ikk = (Ik * Ik - dt) * (T)0.5;
+  const T Ikkk = ((Ik * Ik) * Ik - ((T)3 * dt) * Ik) * (T)(1.0 / 6);
+  return ((((T)Srid2::beta1(S_) * Ik) + ((T)Srid2::beta2(S_) * Ikk) / sqrt_dt) + ((T)Srid2::beta3(S_) * u) * rdt) +
+         ((T)Srid2::beta4(S_) * Ikkk) * rdt;
+}
+
+// One term of the final sum (srk.py:87): acc + alpha_s f_s dt + g_s * gw_s. alpha_3 = 0: f_3 does not exist and the
+// reference still adds the zero drift term.
+template <typename T, int S_, typename S = T>
+TSDE_D S srid2_final_term(S acc, S f, S g, T Ik, T u, T dt, T rdt, T sqrt_dt) {
+  const T gw = srid2_g_weight<T, S_>(Ik, u, dt, rdt, sqrt_dt);
+  if constexpr (S_ < 3) return (acc + ((T)Srid2::alpha(S_) * f) * dt) + g * gw;
+  else return (acc + (T)0) + g * gw;
+}
+
+// y1 = y0 + sum_s [alpha_s f_s dt + g_s * g_weight_s]   (srk.py:79-87), summed in stage order like the reference.
 template <typename T, typename S = T>
 TSDE_D S srid2_final(S y, const S* f, const S* g, T Ik, T u, T dt, T rdt, T sqrt_dt) {
   S acc = y;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const T Ikk = (Ik * Ik - dt) * (T)0.5;
-    const T Ikkk = ((Ik * Ik) * Ik - ((T)3 * dt) * Ik) * (T)(1.0 / 6);
-    const T gw = ((((T)Srid2::beta1(s) * Ik) + ((T)Srid2::beta2(s) * Ikk) / sqrt_dt) + ((T)Srid2::beta3(s) * u) * rdt) +
-                 ((T)Srid2::beta4(s) * Ikkk) * rdt;
-    if (s < 3) {
-      acc = (acc + ((T)Srid2::alpha(s) * f[s]) * dt) + g[s] * gw;
-    } else {
-      acc = (acc + (T)0) + g[s] * gw;       // alpha_3 = 0: the reference still adds the zero drift term
-    }
-  }
+  acc = srid2_final_term<T, 0, S>(acc, f[0], g[0], Ik, u, dt, rdt, sqrt_dt);
+  acc = srid2_final_term<T, 1, S>(acc, f[1], g[1], Ik, u, dt, rdt, sqrt_dt);
+  acc = srid2_final_term<T, 2, S>(acc, f[2], g[2], Ik, u, dt, rdt, sqrt_dt);
+  acc = srid2_final_term<T, 3, S>(acc, g[3], g[3], Ik, u, dt, rdt, sqrt_dt);   // (f slot unused for s = 3)
   return acc;
 }
 

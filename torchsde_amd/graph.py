@@ -1,4 +1,13 @@
-"""HIP-graph capture of a whole fixed-step solve (opt-in: ``options={"hip_graph": True}``).
+"""HIP-graph capture of a whole fixed-step solve (``options={"hip_graph": "auto" | True | False}``, default "auto").
+
+``"auto"`` (the drop-in default): the second solve with the same structure on the same SDE object is captured and every
+later one replays the graph -- provided the capture is legal (see the constraints below) AND safe to do silently: the
+first solve runs eagerly under torch's sync-debug mode (drift / diffusion code that synchronises with the host is never
+captured), the Python-side state of the SDE object (plain attributes, tensor identities, `training` flags) is part
+of the cache key, the captured graph's first replay must reproduce the eager solve it was recorded beside bit for bit,
+very large states stay eager (launch overhead does not matter there and a graph pins a second memory pool), and any
+failure along the way falls back to the eager path without a word. ``True``: capture on first use, warn when
+impossible (the caller vouches for capture-safe code). ``False``: never.
 
 A solve is thousands of short kernels (the user's ``f``/``g`` torch ops plus one fused step kernel per stage).
 For small and medium batches the GPU finishes each of them faster than Python can issue the next one; the
@@ -80,6 +89,181 @@ def _remember(cache, sig, captured):
     cache[sig] = captured
 
 
+# ---- "auto" mode ------------------------------------------------------------------------------------------------------
+_AUTO_MAX_STATE = 1 << 23               # elements of y0 above which "auto" stays eager
+_AUTO_MAX_OUTPUT_BYTES = 1 << 30        # ... or bytes of ys
+
+
+def mode_of(options, key="hip_graph"):
+    """True / False / "auto" from the option (absent = "auto")."""
+    value = options.get(key, "auto") if options is not None else "auto"
+    if value is True or value is False:
+        return value
+    if value is None or value == "auto":
+        return "auto"
+    raise ValueError(f"options[{key!r}] must be True, False or 'auto', got {value!r}.")
+
+
+class _Seen:
+    """Cache entry of a structure that was solved (eagerly) once: the next solve of it is captured."""
+
+
+class _Refused:
+    """Cache entry of a structure that must stay eager (why: `reason`)."""
+
+    def __init__(self, reason):
+        self.reason = reason
+
+
+class _TooMuchState(Exception):
+    pass
+
+
+_SIMPLE = (bool, int, float, complex, str, bytes, type(None), torch.dtype, torch.device, torch.Size)
+
+
+def python_state(obj, budget=4096):
+    """A hashable fingerprint of the Python-side state a captured graph would bake in: plain attribute values, the
+    identity (storage, shape, dtype) of every tensor reachable from `obj`, flags such as `training` -- NOT tensor
+    contents, which replays read live. None when the object is too large to fingerprint cheaply (then "auto" stays
+    eager). A re-bound attribute (`sde.scale = 2.0`, `sde.ctx = new_tensor`) changes the fingerprint, hence the graph."""
+    out, seen = [], set()
+    left = [budget]
+
+    def walk(x, depth):
+        left[0] -= 1
+        if left[0] < 0:
+            raise _TooMuchState
+        if isinstance(x, _SIMPLE):
+            out.append(x)
+        elif torch.is_tensor(x):
+            out.append(("T", x.data_ptr(), tuple(x.shape), x.dtype, x.requires_grad))
+        elif id(x) in seen or depth > 8:
+            out.append(("O", id(x)))
+        elif isinstance(x, (list, tuple, set, frozenset)):
+            seen.add(id(x))
+            out.append((type(x).__name__, len(x)))
+            for e in x:
+                walk(e, depth + 1)
+        elif isinstance(x, dict):
+            seen.add(id(x))
+            out.append(("dict", len(x)))
+            for k, v in x.items():
+                if isinstance(k, str) and k.startswith("_tsde"):
+                    continue            # this package's own caches on the object
+                out.append(k if isinstance(k, _SIMPLE) else ("O", id(k)))
+                walk(v, depth + 1)
+        elif hasattr(x, "__dict__") and not isinstance(x, type) and not callable(getattr(x, "__call__", None)) \
+                or isinstance(x, torch.nn.Module):
+            seen.add(id(x))
+            out.append((type(x).__qualname__,))
+            walk(vars(x), depth + 1)
+        else:
+            out.append(("O", id(x)))     # functions, generators, foreign objects: identity only
+
+    try:
+        walk(obj, 0)
+    except _TooMuchState:
+        return None
+    try:
+        return hash(tuple(out)), len(out)
+    except TypeError:
+        return None
+
+
+def _same_tensors(xs, ys, exact=True):
+    """Do two lists of tensors agree (NaNs in the same places count as agreement)? One host sync."""
+    ok = True
+    for a, b in zip(xs, ys):
+        if a.shape != b.shape:
+            return False
+        if exact:
+            ok = ok & ((a == b) | (a.isnan() & b.isnan())).all()
+        else:
+            scale = torch.nan_to_num(b.abs()).max().clamp_min(1e-30)
+            ok = ok & ((torch.nan_to_num(a - b).abs().max() <= 1e-3 * scale) & (a.isnan() == b.isnan()).all())
+    return bool(ok)
+
+
+def run_watching_for_host_syncs(fn):
+    """`fn()` under torch's sync-debug mode: (result, synchronised?). Other warnings raised meanwhile are re-issued."""
+    previous = torch.cuda.get_sync_debug_mode()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            result = fn()
+        finally:
+            torch.cuda.set_sync_debug_mode(previous)
+    synced = False
+    for w in caught:
+        if "synchronizing" in str(w.message):
+            synced = True
+        else:
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+    return result, synced
+
+
+def _auto_eligible(bm, y0, n_out):
+    return (y0.is_cuda and isinstance(bm, BrownianInterval) and bm._rootW is None and bm._rootH is None
+            and 0 < y0.numel() <= _AUTO_MAX_STATE and n_out * y0.numel() * y0.element_size() <= _AUTO_MAX_OUTPUT_BYTES
+            and not torch.cuda.is_current_stream_capturing())
+
+
+@contextlib.contextmanager
+def _drift_then_diffusion(sde):
+    """Inside: the user's drift and diffusion are recorded one after the other (no parallel graph branches)."""
+    had = getattr(sde, "overlap_f_g", None)
+    if had:
+        sde.overlap_f_g = False
+    try:
+        yield
+    finally:
+        if had:
+            sde.overlap_f_g = True
+
+
+def auto_solve(solver, y0, ts, extra0=()):
+    """The "auto" route of a forward solve without autograd: None -> the caller runs it eagerly; else (ys, extras)."""
+    bm = solver.bm
+    from . import timegrid
+    ts_host = timegrid.ts_to_host(ts)
+    if not _auto_eligible(bm, y0, len(ts_host)):
+        return None
+    _, base = _wrapper_chain(solver.sde)
+    state = python_state(base)
+    if state is None:
+        return None
+    cache = _cache_of(base)
+    if not bm.frozen:
+        bm.adopt_grid(timegrid.build(ts_host, solver.dt).t_f64())
+    sig = ("auto", state) + _signature(solver, y0, ts_host)
+    entry = cache.get(sig)
+    if entry is None:
+        # first solve of this structure: eager, and watched -- code that synchronises with the host cannot be captured
+        plan = solver._plan(y0, ts)
+        solver._extra = tuple(extra0)
+        ys, synced = run_watching_for_host_syncs(lambda: solver._run(plan, y0))
+        _remember(cache, sig, _Refused("drift / diffusion synchronise with the host") if synced else _Seen())
+        return ys, solver._extra
+    if isinstance(entry, _Refused):
+        return None
+    if isinstance(entry, _Seen):
+        try:
+            with _drift_then_diffusion(solver.sde):
+                captured = _CapturedSolve(solver, y0, ts, extra0, verify=True)
+        except Exception as e:     # capture-unsafe user code, out of memory for the second pool, ...: stay eager
+            cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")
+            solver._extra = tuple(extra0)
+            return None
+        if not captured.verified:
+            cache[sig] = _Refused("the captured graph did not reproduce the eager solve")
+            return captured.eager_result
+        cache[sig] = captured
+        return captured.result()
+    return entry.replay(bm, y0, extra0)
+
+
 def _replay_ms(graph, device, repeats=2):
     """Duration of one replay of a captured graph (best of `repeats`), timed with events on the current stream."""
     best = float("inf")
@@ -117,14 +301,27 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
     if parallel is None:
         return sequential
     t_seq, t_par = _replay_ms(sequential.graph, device), _replay_ms(parallel.graph, device)
-    keep, drop = (parallel, sequential) if t_par < t_seq else (sequential, parallel)
-    keep.tuning = {"sequential_ms": t_seq, "parallel_ms": t_par, "kept": "parallel" if keep is parallel else "sequential"}
-    del drop
+    # the parallel form is only an option if it computes the same thing: drift and diffusion code that shares buffers,
+    # caches or a random generator gives other values when its two halves run side by side
+    agree = _same_tensors(parallel.outputs(), sequential.outputs(), exact=parallel.exact_outputs)
+    tuning = {"sequential_ms": t_seq, "parallel_ms": t_par, "parallel_agrees": agree}
+    if agree and t_par < t_seq:
+        sequential = None              # (drops the losing graph and its memory pool now, not at the caller's return)
+        keep, tuning["kept"] = parallel, "parallel"
+    else:
+        parallel = None
+        keep, tuning["kept"] = sequential, "sequential"
+    keep.tuning = tuning
     return keep
 
 
 class _CapturedSolve:
-    def __init__(self, solver, y0, ts, extra0=()):
+    exact_outputs = True
+
+    def outputs(self):
+        return [self.ys] + list(self.extra_out)
+
+    def __init__(self, solver, y0, ts, extra0=(), verify=False):
         bm = solver.bm
         device = y0.device
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
@@ -144,8 +341,11 @@ class _CapturedSolve:
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
                 solver._extra = tuple(self.extra_in)
-                solver._run(self.plan, self.y_in)
+                warm = solver._run(self.plan, self.y_in)
+                warm_extra = tuple(solver._extra)
             torch.cuda.current_stream(device).wait_stream(side)
+            if not verify:
+                del warm, warm_extra
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls from other threads (e.g. the RCCL watchdog of a multi-GPU run) must not
             # invalidate this capture
@@ -156,6 +356,9 @@ class _CapturedSolve:
         finally:
             bm._entropy_dev = None
         self.graph.replay()     # capture only records: run once so that `ys` holds this solve's result
+        if verify:              # "auto": the replay must be the eager solve it was recorded beside, bit for bit
+            self.verified = _same_tensors(self.outputs(), [warm] + list(warm_extra))
+            self.eager_result = None if self.verified else (warm, warm_extra)
 
     def _set_seed(self, bm):
         key = bm._key
@@ -232,7 +435,12 @@ class _CapturedBackward:
     final (f, g, z) and their cotangents -- (copied in before each replay), the Brownian seed
     (device word) and the parameters themselves (read in place: an optimiser step is seen by the next replay)."""
 
-    def __init__(self, run, bm, inputs, keepalive=()):
+    exact_outputs = False     # autograd orders the sums of a recorded sweep by per-thread sequence numbers
+
+    def outputs(self):
+        return list(self.out)
+
+    def __init__(self, run, bm, inputs, keepalive=(), verify=False):
         device = inputs[0].device
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
         self.static = [torch.empty_like(x, memory_format=torch.contiguous_format) for x in inputs]
@@ -246,11 +454,17 @@ class _CapturedBackward:
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
-                run(*self.static)
+                warm = [o.clone() for o in run(*self.static)]
             torch.cuda.current_stream(device).wait_stream(side)
+            if not verify:
+                del warm
             self.graph = torch.cuda.CUDAGraph()
             with _no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = list(run(*self.static))
+            if verify:          # "auto": a replay on the same inputs must give the eager sweep's gradients
+                self._load(bm, inputs)
+                self.graph.replay()
+                self.verified = _same_tensors(self.out, warm, exact=False)
         finally:
             bm._entropy_dev = None
 
@@ -266,25 +480,54 @@ class _CapturedBackward:
         return [o.clone() for o in self.out]
 
 
-def cached_backward(sde, bm, signature, capture):
+def cached_backward(sde, bm, signature, capture, auto=False):
     """The cached HIP graph of the adjoint's backward sweep for this structure; `capture()` builds it on a miss
     (and may return None: then nothing is cached and the backward pass runs eagerly).
-    `signature` identifies the sweep's structure; the Brownian structure is appended here."""
+    `signature` identifies the sweep's structure; the Brownian structure is appended here.
+    `auto`: the "auto" rules of this module -- returns (graph or None, watch) where `watch`, if not None, is a callable
+    the eager backward pass must report to (`watch(synchronised)`) so that the NEXT call knows whether to capture."""
     if bm._rootW is not None or bm._rootH is not None:
-        warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
-        return None
+        if not auto:
+            warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
+        return (None, None) if auto else None
     base = sde
     while hasattr(base, "_base_sde"):
         base = base._base_sde
     cache = _cache_of(base)
     sig = signature + (tuple(bm.shape), bm.levy_area_approximation, bm.row_offset,
                        None if bm._edges is None else bm._edges.tobytes(), bm._max_depth, bm._snap)
-    captured = cache.get(sig)
-    if captured is None:
-        captured = capture()
-        if captured is not None:
-            _remember(cache, sig, captured)
-    return captured
+    if not auto:
+        captured = cache.get(sig)
+        if captured is None:
+            captured = capture()
+            if captured is not None:
+                _remember(cache, sig, captured)
+        return captured
+    state = python_state(base)
+    if state is None:
+        return None, None
+    sig = ("auto", state) + sig
+    entry = cache.get(sig)
+    if entry is None:            # first sweep of this structure: eager, watched by `backward`
+
+        def watch(synced):
+            _remember(cache, sig, _Refused("the backward sweep synchronises with the host") if synced else _Seen())
+        return None, watch
+    if isinstance(entry, _Refused):
+        return None, None
+    if isinstance(entry, _Seen):
+        try:
+            with _drift_then_diffusion(sde):
+                captured = capture()
+        except Exception as e:
+            captured = None
+            cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")
+        else:
+            cache[sig] = captured if captured is not None and captured.verified else \
+                _Refused("the captured sweep did not reproduce the eager one")
+        entry = cache[sig]
+        return (entry if isinstance(entry, _CapturedBackward) else None), None
+    return entry, None
 
 
 # ---- back-propagation THROUGH the solver (sdeint with autograd) as two HIP graphs -------------------------------

@@ -369,48 +369,71 @@ _SRID2_ALPHA = (1 / 6, 1 / 6, 2 / 3, 0)
 _SRID2_BETA = ((-1, 4 / 3, 2 / 3, 0), (1, -4 / 3, 1 / 3, 0), (2, -4 / 3, -2 / 3, 0), (-2, 5 / 3, -2 / 3, 1))
 
 
-def _srk_diag_stage_autograd(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0, want1):
+_SRK_N_IN, _SRK_N_OUT = (0, 3, 5, 4, 2), (0, 3, 3, 2, 1)
+
+
+def _srk_diag_stage_autograd(stage, ins, dt, rdt, sqrt_dt, noise):
     """The stage arithmetic of `tsde_srk_diag_stage` as differentiable torch ops on the re-materialised (W, U), for
     back-propagation THROUGH the solver (same operation order as the kernel)."""
     W, U = noise.materialise(need_U=True)
     if noise.bcast_d:
         W, U = W.reshape(-1, 1), U.reshape(-1, 1)
     dt, rdt, sqrt_dt = float(dt), float(rdt), float(sqrt_dt)
-    if stage < 4:
-        h0 = h1 = y0
-        for j in range(stage):
-            f = fs[j] if (_SRID2_A0[stage][j] != 0 or _SRID2_A1[stage][j] != 0) else torch.zeros_like(y0)
-            h0 = (h0 + (_SRID2_A0[stage][j] * f) * dt) + ((_SRID2_B0[stage][j] * gs[j]) * U) * rdt
-            h1 = (h1 + (_SRID2_A1[stage][j] * f) * dt) + (_SRID2_B1[stage][j] * gs[j]) * sqrt_dt
-        return (h0 if want0 else None), (h1 if want1 else None)
-    Ikk = (W * W - dt) * 0.5
-    Ikkk = ((W * W) * W - (3 * dt) * W) * (1.0 / 6)
-    acc = y0
-    for s in range(4):
+    A0, A1, B0, B1 = _SRID2_A0, _SRID2_A1, _SRID2_B0, _SRID2_B1
+
+    def h0_term(h, s, j, f, g):
+        return (h + (A0[s][j] * f) * dt) + ((B0[s][j] * g) * U) * rdt
+
+    def h1_term(h, s, j, f, g):
+        return (h + (A1[s][j] * f) * dt) + (B1[s][j] * g) * sqrt_dt
+
+    def final_term(acc, s, f, g):
+        Ikk = (W * W - dt) * 0.5
+        Ikkk = ((W * W) * W - (3 * dt) * W) * (1.0 / 6)
         gw = (((_SRID2_BETA[0][s] * W) + (_SRID2_BETA[1][s] * Ikk) / sqrt_dt) + (_SRID2_BETA[2][s] * U) * rdt) + \
              (_SRID2_BETA[3][s] * Ikkk) * rdt
-        drift = (_SRID2_ALPHA[s] * fs[s]) * dt if s < 3 else 0.0
-        acc = (acc + drift) + gs[s] * gw
-    return acc, None
+        drift = (_SRID2_ALPHA[s] * f) * dt if s < 3 else 0.0
+        return (acc + drift) + g * gw
+
+    if stage == 1:
+        y0, f0, g0 = ins
+        return h0_term(y0, 1, 0, f0, g0), h1_term(y0, 1, 0, f0, g0), h1_term(y0, 2, 0, f0, g0)
+    if stage == 2:
+        y0, f0, g0, f1, g1 = ins
+        zero = torch.zeros_like(y0)
+        h02 = h0_term(h0_term(y0, 2, 0, f0, g0), 2, 1, f1, g1)
+        acc = final_term(final_term(y0, 0, f0, g0), 1, f1, g1)
+        p13 = h1_term(h1_term(y0, 3, 0, zero, g0), 3, 1, zero, g1)
+        return h02, acc, p13
+    if stage == 3:
+        p13, acc, f2, g2 = ins
+        return h1_term(p13, 3, 2, f2, g2), final_term(acc, 2, f2, g2)
+    acc, g3 = ins
+    return (final_term(acc, 3, None, g3),)
 
 
-def srk_diag_stage(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0=True, want1=True, out0=None):
-    """One SRID2 stage kernel; returns (out0, out1) (None where not requested)."""
-    if _needs_grad(y0, *fs, *gs):
-        return _srk_diag_stage_autograd(stage, y0, fs, gs, dt, rdt, sqrt_dt, noise, want0, want1)
-    y0 = _native.contiguous(y0)
-    fs = _prep(y0, *fs) + [None] * (4 - len(fs))
-    gs = _prep(y0, *gs) + [None] * (4 - len(gs))
-    if out0 is None:
-        out0 = torch.empty_like(y0) if want0 else None
-    out1 = torch.empty_like(y0) if want1 else None
-    lib, dt_code, stream = _launch_env(y0)
-    f_arr = _native._PTR4(*[None if t is None else t.data_ptr() for t in fs])
-    g_arr = _native._PTR4(*[None if t is None else t.data_ptr() for t in gs])
-    code = lib.tsde_srk_diag_stage(stage, _native.ptr(out0), _native.ptr(out1), _native.ptr(y0), f_arr, g_arr,
-                                   y0.numel(), float(dt), float(rdt), float(sqrt_dt), noise.struct(), dt_code, stream)
+def srk_diag_stage(stage, ins, dt, rdt, sqrt_dt, noise, out_last=None):
+    """One SRID2 stage kernel (include/torchsde_amd.h: 1: y0,f0,g0 -> H0_1,H1_1,H1_2; 2: y0,f0,g0,f1,g1 -> H0_2,acc,P;
+    3: P,acc,f2,g2 -> H1_3,acc (updated in place); 4: acc,g3 -> y1). Returns the tuple of outputs; `out_last`: where
+    stage 4 writes y1."""
+    if _needs_grad(*ins):
+        return _srk_diag_stage_autograd(stage, ins, dt, rdt, sqrt_dt, noise)
+    ref = _native.contiguous(ins[0])
+    ins = [ref] + _prep(ref, *ins[1:])
+    n_out = _SRK_N_OUT[stage]
+    if stage == 3:
+        outs = [torch.empty_like(ref), ins[1]]          # acc is advanced in place: one buffer for s = 0..2
+    elif stage == 4:
+        outs = [_new_like(ref, out_last)]
+    else:
+        outs = [torch.empty_like(ref) for _ in range(n_out)]
+    lib, dt_code, stream = _launch_env(ref)
+    in_arr = _native._PTR5(*([t.data_ptr() for t in ins] + [None] * (5 - len(ins))))
+    out_arr = _native._PTR3(*([t.data_ptr() for t in outs] + [None] * (3 - n_out)))
+    code = lib.tsde_srk_diag_stage(stage, out_arr, in_arr, ref.numel(), float(dt), float(rdt), float(sqrt_dt),
+                                   noise.struct(), dt_code, stream)
     _native.check(code, "tsde_srk_diag_stage")
-    return out0, out1
+    return tuple(outs)
 
 
 # ---- adjoint / output --------------------------------------------------------------------------------------
@@ -598,7 +621,8 @@ def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
 
 def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, diffusion, method, schedule, bm):
     """All steps of a diagonal SDE with a two-layer perceptron drift in one launch (``tsde_trajectory_mlp_diag``);
-    writes ys[j] for the schedule's outputs, which must all sit on step boundaries."""
+    writes ys[j] for the schedule's outputs (an output time inside a step is interpolated in the kernel with the
+    schedule's weights, _core/interp.py:15-18)."""
     tensors = (ys, y0, w1, b1, w2, b2, diff_rate, diff_shift)
     _native.require_device(*tensors)
     rows, d = y0.shape

@@ -142,9 +142,9 @@ class ForwardSDE(BaseSDE):
         fork = torch.cuda.Event()
         fork.record(main)
         side.wait_event(fork)
+        f = self.f(t, y)                 # Python order stays drift, then diffusion (as in `_f_then_g`)
         with torch.cuda.stream(side):
             g = self.g(t, y)
-        f = self.f(t, y)
         join = torch.cuda.Event()
         join.record(side)
         main.wait_event(join)

@@ -100,13 +100,20 @@ def all_reduce_gradients(params, group=None):
 
     Every rank reduces over the SAME list: all parameters that require a gradient, a missing `.grad` counting as zeros
     (a rank whose rows never touched a parameter must still take part, or the collective would mismatch), one flat
-    buffer per dtype (no silent promotion of mixed-precision parameters)."""
+    buffer per dtype (no silent promotion of mixed-precision parameters). A parameter that NO rank touched keeps
+    `.grad = None`, as in an unsharded run (an optimiser skips it instead of applying weight decay / Adam moments to
+    it): one more small all-reduce carries, per parameter, whether any rank had a gradient."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     params = [p for p in params if p.requires_grad]
     by_dtype = {}
     for p in params:
         by_dtype.setdefault(p.dtype, []).append(p)
+    if not params:
+        return
+    touched = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
+    dist.all_reduce(touched, group=group)
+    touched = dict(zip(map(id, params), touched.tolist()))
     for dtype in sorted(by_dtype, key=str):
         group_params = by_dtype[dtype]
         flat = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in group_params])
@@ -114,8 +121,8 @@ def all_reduce_gradients(params, group=None):
         offset = 0
         for p in group_params:
             chunk = flat[offset:offset + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = chunk.clone()
-            else:
+            if p.grad is not None:
                 p.grad.copy_(chunk)
+            elif touched[id(p)] > 0:
+                p.grad = chunk.clone()
             offset += p.numel()

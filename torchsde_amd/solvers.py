@@ -202,11 +202,19 @@ class BaseSDESolver:
             ys = self._integrate_trajectory(coefficients, y0, ts)
             if ys is not None:
                 return ys, self._extra
-        if self.options.get("hip_graph", False):
-            from . import graph
+        from . import graph
+        mode = graph.mode_of(self.options)
+        if mode is True:
             if not self._tracks_grad(y0):
                 return graph.replay_or_capture(self, y0, ts, self._extra)
             graphed = graph.replay_or_capture_training(self, y0, ts, self._extra, self._params())
+            if graphed is not None:
+                return graphed
+        elif mode == "auto" and not torch.is_grad_enabled():
+            # the drop-in default: replay a HIP graph of this solve from its third occurrence on, when that is legal
+            # and provably the same computation (graph.py); autograd THROUGH the solver stays eager unless asked for
+            # (a replayed backward pass constrains the order of the caller's forward and backward calls)
+            graphed = graph.auto_solve(self, y0, ts, self._extra)
             if graphed is not None:
                 return graphed
         ys = self._run(self._plan(y0, ts), y0)
@@ -712,7 +720,8 @@ class SRK(BaseSDESolver):
     """Roessler's strong-order-1.5 SRI (diagonal/scalar, tableau SRID2) scheme (reference: methods/srk.py:30-88).
 
     The reference re-evaluates f and g of every earlier stage inside its double loop (10 f + 6 g + 4 g_prod
-    per step); identical values are obtained here with 3 f and 4 g evaluations and four stage kernels.
+    per step); identical values are obtained here with 3 f and 4 g evaluations and four stage kernels that hand
+    partial sums to each other (23 streams per step).
     """
     strong_order = 1.5
     weak_order = 1.5
@@ -750,14 +759,13 @@ class SRK(BaseSDESolver):
 
         # C0 = (0, 1, 1/2, 0) for f, C1 = (0, 1/4, 1, 1/4) for g   (srid2.py:21-22)
         f0, g0 = sde.f(t_0, y0), g_of(t_0, y0)
-        H0_1, H1_1 = K.srk_diag_stage(1, y0, [f0], [g0], dt, rdt, sqrt_dt, noise)
+        H0_1, H1_1, H1_2 = K.srk_diag_stage(1, (y0, f0, g0), dt, rdt, sqrt_dt, noise)
         f1, g1 = sde.f(t_1, H0_1), g_of(t_q, H1_1)
-        H0_2, H1_2 = K.srk_diag_stage(2, y0, [f0, f1], [g0, g1], dt, rdt, sqrt_dt, noise)
+        H0_2, acc, P1_3 = K.srk_diag_stage(2, (y0, f0, g0, f1, g1), dt, rdt, sqrt_dt, noise)
         f2, g2 = sde.f(t_h, H0_2), g_of(t_1, H1_2)
-        _, H1_3 = K.srk_diag_stage(3, y0, [f0, f1, f2], [g0, g1, g2], dt, rdt, sqrt_dt, noise, want0=False)
+        H1_3, acc = K.srk_diag_stage(3, (P1_3, acc, f2, g2), dt, rdt, sqrt_dt, noise)
         g3 = g_of(t_q, H1_3)
-        y1, _ = K.srk_diag_stage(4, y0, [f0, f1, f2], [g0, g1, g2, g3], dt, rdt, sqrt_dt, noise, want1=False,
-                                 out0=out)
+        (y1,) = K.srk_diag_stage(4, (acc, g3), dt, rdt, sqrt_dt, noise, out_last=out)
         return y1
 
     def _advance_additive(self, y0, st, out):

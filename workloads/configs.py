@@ -15,7 +15,9 @@ WORKLOADS = {
         kernel="tsde_milstein_diag<float>"),
     "c2_srk_diag": dict(
         problem="gbm_ito", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
-        bytes_per_traj_step=108 * 64, kid=4, launches_per_step=4,
+        # SURVEY 8d's figure for SRID2 is 64*d (every operand touched once); with user code between the stages the four
+        # kernels move 23 streams = 92*d (6 + 8 + 6 + 3, include/torchsde_amd.h) -- both are reported
+        bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
         kernel="tsde_srk_diag_stage<float> (4 stage kernels)"),
     "c3_euler_general_b16384_d32_m16": dict(
         problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
