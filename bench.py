@@ -22,17 +22,19 @@ Prints ONE JSON line (rank 0):
   `median_ms_per_step` / `value_median` restate it from the median of the per-solve times (HIP events recorded
   between the solves of the same timed region);
 * `roofline`: two fractions of the 8 TB/s HBM peak, named for what they are --
-    `frac`        KERNEL level: the dominant kernel's algorithmic bytes per launch / its average duration, measured
-                  live with HIP events on the launch stream (for the headline: 200 back-to-back launches on live data);
+    `frac`        KERNEL level: the dominant kernel's SURVEY-8d algorithmic bytes per solver step / what its launches cost
+                  inside a step, measured live with HIP events on the launch stream: a HIP graph of 50 solver steps (the
+                  SDE's f, g torch kernels + the kernel, live operands) minus the same graph without the kernel;
     `solve_frac`  SOLVE level: algorithmic bytes per trajectory-step x `value` / (N x 8e12), i.e.
                   with the user's f and g torch kernels and every launch gap inside;
-  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is taken from profiles/traffic_latest.json ONLY when that
-  file was collected on the kernel sources this run uses (`traffic_source` names file and source digest);
+  `traffic` (HBM bytes per launch from rocprofv3 PMC passes, tools/profile_traffic.sh) and `kernel_us_rocprofv3` are
+  taken from profiles/traffic_latest.json ONLY when that file was collected on the kernel sources this run uses
+  (`traffic_source` names file and source digest);
 * `cpu_baseline`: the oracle's port of the reference's CPU algorithm, timed on this host's cores on a bounded sample;
 * `also` (single-GPU default run): every other BASELINE configuration at its single-GPU size on the stepwise path
-  (configs[2] Euler-general, the configs[3] shard, configs[4] sdeint_adjoint), each with ms per solve (median of 5),
-  the dominant kernel's duration from HIP-event brackets, bytes per launch and both fractions; then the same jobs
-  when the SDE is handed over in closed form. Not part of `value`; `--no-also` skips them.
+  (configs[2] Euler-general and the Milstein-general extension, the configs[3] shard, configs[4] sdeint_adjoint), each
+  with ms per solve (median of 5) and the same kernel-level measurement, bytes, fractions and counter traffic as the
+  headline; then the same jobs when the SDE is handed over in closed form. Not part of `value`; `--no-also` skips them.
 """
 import argparse
 import hashlib
@@ -75,55 +77,82 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
-def _cpu_baseline(cfg, budget_s=20.0):
-    """The oracle's restatement of the reference CPU path (tree-based BrownianInterval + Euler loop), timed on
-    this host with all cores on a bounded number of solver steps of the same workload."""
+def _reference_package():
+    """The REAL reference (google-research/torchsde) if this host has it: /root/reference (or $TORCHSDE_REFERENCE) with
+    the `trampoline` stand-in of tests/golden/_ref_shim ahead of it on the path. None elsewhere -- the
+    GPU box has no /root/reference -- and then the baseline is the oracle's port (`kind: "port"`)."""
+    root = os.environ.get("TORCHSDE_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(root, "torchsde")):
+        return None
+    sys.dont_write_bytecode = True       # the reference tree is read-only
+    for path in (root, os.path.join(ROOT, "tests", "golden", "_ref_shim")):
+        if path not in sys.path:
+            sys.path.insert(0, path)
     try:
-        from oracle import brownian_ref, solvers_ref
-    except Exception as e:  # oracle piece missing: report, don't fake
-        return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": f"unavailable: {e}"}
+        import torchsde
+        return torchsde
+    except Exception:
+        return None
+
+
+def _cpu_baseline(cfg, budget_s=20.0):
+    """The reference's CPU path on this host's cores, on a bounded number of solver steps of the same workload: the real
+    package when the host has it (`kind: "reference"`: torchsde.sdeint under no_grad, BrownianInterval built for the full
+    horizon with the dt hint, ts shortened to the sample), else the oracle's restatement of it (`kind:
+    "port"`: tree-based BrownianInterval + solver loop, same torch CPU ops; the two run at the same speed and give the
+    same bits at equal thread counts, profiles/r2_cpu_port_vs_reference.txt)."""
+    ncpu = os.cpu_count() or 1
+    base = {"value": None, "unit": "trajectory-steps/s", "cores": None, "host_cpus": ncpu, "kind": "port"}
     if cfg.get("adjoint") or cfg.get("train"):
-        return {"value": None, "unit": "trajectory-steps/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": "not timed for the forward + backward workloads"}
+        return dict(base, sample="not timed for the forward + backward workloads")
     B, d, dt = cfg["B"], cfg["d"], cfg["dt"]
     sde = _make_problem(cfg["problem"], d, cfg["m"], "cpu")
     y0 = torch.full((B, d), 0.1)
     t1 = cfg["nsteps"] * dt
-    step = solvers_ref.STEPS[cfg["method"]]
+    reference = _reference_package()
+    if reference is not None:
+        kind, what = "reference", "the reference package itself (torchsde.sdeint, CPU)"
 
-    def run(threads, budget, min_steps):
-        torch.set_num_threads(threads)
-        bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, cfg["m"]), dtype=torch.float32, entropy=20240601,
-                                              dt=dt, levy_area_approximation=cfg["levy"])
-        n, y, t = 0, y0, torch.tensor(0.0)
-        start = time.perf_counter()
-        with torch.no_grad():
-            while n < cfg["nsteps"]:
-                t_next = t + dt
-                y = step(sde, bm, t, t_next, y)
-                t = t_next
-                n += 1
-                if n >= min_steps and time.perf_counter() - start > budget:
-                    break
-        return n, time.perf_counter() - start
+        def run(threads, n):
+            torch.set_num_threads(threads)
+            bm = reference.BrownianInterval(t0=0.0, t1=t1, size=(B, cfg["m"]), dtype=torch.float32, entropy=20240601,
+                                            dt=dt, levy_area_approximation=cfg["levy"])
+            start = time.perf_counter()
+            with torch.no_grad():
+                reference.sdeint(sde, y0, torch.tensor([0.0, n * dt]), bm=bm, method=cfg["method"], dt=dt)
+            return time.perf_counter() - start
+    else:
+        try:
+            from oracle import brownian_ref, solvers_ref
+        except Exception as e:  # oracle piece missing: report, don't fake
+            return dict(base, sample=f"unavailable: {e}")
+        kind, what = "port", ("oracle port of the reference CPU algorithm (tree BrownianInterval + solver loop, torch CPU "
+                              "ops; same-thread-count A/B against the real reference: profiles/r2_cpu_port_vs_reference.txt)")
+        step = solvers_ref.STEPS[cfg["method"]]
 
-    # torch CPU elementwise ops on 4M-element tensors do not scale to hundreds of threads; give the
-    # baseline its best thread count (probed on a few steps each) and report the count used.
-    ncpu = os.cpu_count() or 1
+        def run(threads, n):
+            torch.set_num_threads(threads)
+            bm = brownian_ref.BrownianIntervalRef(t0=0.0, t1=t1, size=(B, cfg["m"]), dtype=torch.float32,
+                                                  entropy=20240601, dt=dt, levy_area_approximation=cfg["levy"])
+            y, t = y0, torch.tensor(0.0)
+            start = time.perf_counter()
+            with torch.no_grad():
+                for _ in range(n):
+                    y = step(sde, bm, t, t + dt, y)
+                    t = t + dt
+            return time.perf_counter() - start
+
+    # torch CPU elementwise ops on 4M-element tensors do not scale to hundreds of threads; give the baseline its
+    # best thread count (probed on a few steps each) and report the count used
     candidates = sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)})
-    best, best_rate = candidates[0], 0.0
-    for c in candidates:
-        n, el = run(c, 1.5, 2)
-        if n / el > best_rate:
-            best, best_rate = c, n / el
-    n, el = run(best, budget_s, 8)
-    return {"value": B * n / el, "unit": "trajectory-steps/s", "cores": best, "kind": "port",
-            "host_cpus": ncpu,
-            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}) in {el:.1f} s; "
-                      f"oracle port of the reference CPU algorithm (tree BrownianInterval + Euler loop, torch CPU "
-                      f"ops; same-thread-count A/B against the real reference: profiles/r2_cpu_port_vs_reference.txt), "
-                      f"best of thread counts {candidates} -> {best} threads"}
+    run(candidates[0], 1)                      # lazy initialisation out of the way
+    probe = {c: run(c, 3) / 3 for c in candidates}
+    best = min(probe, key=probe.get)
+    n = int(max(8, min(cfg["nsteps"], budget_s / probe[best])))
+    elapsed = run(best, n)
+    return {"value": B * n / elapsed, "unit": "trajectory-steps/s", "cores": best, "host_cpus": ncpu, "kind": kind,
+            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}, method {cfg['method']}) "
+                      f"in {elapsed:.1f} s; {what}; best of thread counts {candidates} -> {best} threads"}
 
 
 class Job:
@@ -179,48 +208,120 @@ class Job:
 
     # ---- dominant kernel -----------------------------------------------------------------------------------------
     def bracket_dominant_kernel(self):
-        """(total ms, launches): every launch of the dominant kernel in eagerly issued solve(s) bracketed by HIP events
-        on the launch stream inside the library (tsde_prof_begin / tsde_prof_end). Event records are host-side calls,
-        so this cannot be done inside a replayed graph."""
+        """Trajectory kernels only (one launch of milliseconds per solve, so the ~2.5 us of marker latency a bracket adds
+        is noise): (total ms, launches) of the dominant kernel in 8 eagerly issued solves, bracketed by HIP events on
+        the launch stream inside the library (tsde_prof_begin / tsde_prof_end)."""
         from torchsde_amd import kernels as K
         c = self.cfg
-        if self.trajectory:
-            K.prof_begin(c["kid"], 16 if not (self.train or self.adjoint) else 8 * (c["nsteps"] + 1))
-            for i in range(8):
-                self.solve(5000 + i, graph=False)
-        else:
-            per_step = c["launches_per_step"]
-            K.prof_begin(c["kid"], c["nsteps"] * per_step + 8)
-            # park the stream while the host enqueues the whole solve, so that no bracket contains queue-empty time
-            K.gpu_delay(min(2.0e6, 40.0 * c["nsteps"] * (2 + per_step)), self.dev)
-            self.solve(5000, graph=False)
+        assert self.trajectory
+        K.prof_begin(c["kid"], 16 if not (self.train or self.adjoint) else 8 * (c["nsteps"] + 1))
+        for i in range(8):
+            self.solve(5000 + i, graph=False)
         torch.cuda.synchronize()
         return K.prof_end()
 
-    def back_to_back_step_diag_us(self, live_state):
-        """Second HIP-event measurement of tsde_step_diag without per-launch markers: ONE event pair around 200
-        back-to-back launches on live data (a solve's last state and its f, g), marker latency amortised away."""
+    def in_situ_us(self, live_state):
+        """THE kernel-level timing of every stepwise workload: what the dominant kernel costs INSIDE a solver step.
+        `reps` solver steps on live operands -- the SDE's own f and g evaluated (by the user's torch code) before every
+        launch, exactly as in a solve, so the kernel reads operands another kernel has just written -- are recorded
+        into ONE HIP graph and replayed between one pair of HIP events; the same graph without this package's kernel
+        is timed the same way; the kernel's figure is the difference. No marker packets between launches, no host
+        launch rate, no stream-parking kernel in a trace -- and no operand that stays cache-resident across launches
+        (constant f, g are partly retained by the per-XCD L2 at shard sizes: a plain back-to-back loop showed 4.1 us
+        = "103 % of peak" where the solve's kernel takes 6.6). Returns {label: us per launch} (one entry, or the four
+        SRK stages + the whole step), best of three replays each."""
         from torchsde_amd import kernels as K
-        from torchsde_amd.kernels import NoiseSpec, _raw_step_diag
-        c, dev = self.cfg, self.dev
-        B, d, m, dt = c["B"], c["d"], c["m"], c["dt"]
-        yy = [live_state[:B].clone().contiguous(), torch.empty(B, d, device=dev)]
-        with torch.no_grad():
-            ff, gg = self.sde.f(self.ts[0], yy[0]).contiguous(), self.sde.g(self.ts[0], yy[0]).contiguous()
-        specs = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(220)]
-        for i in range(20):
-            _raw_step_diag(yy[i & 1], ff, gg, float(dt), 1.0, specs[i], yy[(i + 1) & 1])
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        K.gpu_delay(3000.0, dev)          # let the host enqueue all launches first
-        e0.record()
-        for i in range(20, 220):
-            _raw_step_diag(yy[i & 1], ff, gg, float(dt), 1.0, specs[i], yy[(i + 1) & 1])
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / 200
+        from torchsde_amd.kernels import NoiseSpec
+        c, dev, sde = self.cfg, self.dev, self.sde
+        B, d, m, dt, kid = c["B"], c["d"], c["m"], float(c["dt"]), c["kid"]
+        reps = 50
+        y = live_state[:B].detach().clone().contiguous()
+        t0 = self.ts[0]
+        spec = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(reps)]
+        yy = [y, y.clone()]
 
-    def roofline(self, value, k_ms, k_launches, b2b_us=None):
-        """The `roofline` object of this workload given its measured trajectory-steps/s and kernel brackets."""
+        def timed(step):
+            """us per solver step with and without the kernel(s)"""
+            full = _graph_replay_us([(lambda i=i: step(i, True)) for i in range(reps)], dev)
+            bare = _graph_replay_us([(lambda i=i: step(i, False)) for i in range(reps)], dev)
+            return full - bare, bare
+
+        if kid == 1:
+            coefs = [(dt, 1.0)] if c["launches_per_step"] == 1 else [(0.5 * dt, 0.5), (dt, 1.0)]   # midpoint: two stages
+
+            def step(i, launch):
+                for cf, cg in coefs:
+                    f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
+                    if launch:
+                        K._raw_step_diag(yy[i & 1], f, g, cf, cg, spec[i], yy[(i + 1) & 1])
+            per_step, bare = timed(step)
+            return {"tsde_step_diag": per_step / len(coefs), "f, g evaluations alone (per step)": bare}
+        if kid == 2:
+            def step(i, launch):
+                f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
+                if launch:
+                    K._raw_step_general(yy[i & 1], f, g, dt, 1.0, spec[i], yy[(i + 1) & 1])
+            per_step, bare = timed(step)
+            return {"tsde_step_general": per_step, "f, g evaluations alone (per step)": bare}
+        if kid == 3:
+            def step(i, launch):
+                f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
+                gdg = g * g          # stand-in producer of the diffusion VJP's result (one torch kernel writing (B, d))
+                if launch:
+                    K._raw_milstein_diag(yy[i & 1], f, g, gdg, dt, spec[i], yy[(i + 1) & 1])
+            per_step, bare = timed(step)
+            return {"tsde_milstein_diag": per_step, "f, g, gdg producers alone (per step)": bare}
+        if kid == 4:
+            rdt, sqrt_dt = 1.0 / dt, dt ** 0.5
+            with torch.no_grad():      # inputs of the evaluations in the graph WITHOUT the stage kernels
+                f0, g0 = sde.f(t0, y), sde.g(t0, y)
+                h01, h11, h12 = K.srk_diag_stage(1, (y, f0, g0), dt, rdt, sqrt_dt, spec[0])
+                h02, acc0, p13 = K.srk_diag_stage(2, (y, f0, g0, sde.f(t0, h01), sde.g(t0, h11)), dt, rdt, sqrt_dt, spec[0])
+                h13, _ = K.srk_diag_stage(3, (p13, acc0.clone(), sde.f(t0, h02), sde.g(t0, h12)), dt, rdt, sqrt_dt, spec[0])
+
+            def step(i, launch, only=None):
+                """one SRID2 step as solvers.SRK._advance issues it; `only`: launch just that stage kernel"""
+                def want(k):
+                    return launch and (only is None or only == k)
+                yi = yy[i & 1]
+                f0, g0 = sde.f(t0, yi), sde.g(t0, yi)
+                s1 = K.srk_diag_stage(1, (yi, f0, g0), dt, rdt, sqrt_dt, spec[i]) if want(1) else (h01, h11, h12)
+                f1, g1 = sde.f(t0, s1[0]), sde.g(t0, s1[1])
+                s2 = K.srk_diag_stage(2, (yi, f0, g0, f1, g1), dt, rdt, sqrt_dt, spec[i]) if want(2) else (h02, acc0, p13)
+                f2, g2 = sde.f(t0, s2[0]), sde.g(t0, s1[2])
+                s3 = K.srk_diag_stage(3, (s2[2], s2[1], f2, g2), dt, rdt, sqrt_dt, spec[i]) if want(3) else (h13, acc0)
+                g3 = sde.g(t0, s3[0])
+                if want(4):
+                    K.srk_diag_stage(4, (s3[1], g3), dt, rdt, sqrt_dt, spec[i], out_last=yy[(i + 1) & 1])
+            bare = _graph_replay_us([(lambda i=i: step(i, False)) for i in range(reps)], dev)
+            out = {}
+            for k in (1, 2, 3, 4):
+                out[f"tsde_srk_diag_stage {k}"] = _graph_replay_us(
+                    [(lambda i=i, k=k: step(i, True, only=k)) for i in range(reps)], dev) - bare
+            out["whole step (4 stages in order)"] = _graph_replay_us(
+                [(lambda i=i: step(i, True)) for i in range(reps)], dev) - bare
+            out["3 f + 4 g evaluations alone (per step)"] = bare
+            return out
+        if kid == 5:
+            params = [p for p in sde.parameters() if p.requires_grad]
+            st = [torch.rand(B, d, device=dev) for _ in range(4)]
+            pst = [[torch.zeros_like(p), torch.zeros_like(p), torch.randn_like(p), torch.randn_like(p)] for p in params]
+
+            def step(i, launch):
+                a, b = (0, 2) if i & 1 == 0 else (2, 0)
+                # stand-ins for the sweep's producers (f, g.v and their VJPs w.r.t. y): four torch kernels writing (B, d)
+                terms = [st[a] * 0.5, st[a] * 0.25, st[a + 1] * 0.5, st[a + 1] * 0.25]
+                if launch:
+                    segs = [dict(out=st[b], s=st[a], F=terms[0], G=terms[1], sF=-1.0, sG=-1.0),
+                            dict(out=st[b + 1], s=st[a + 1], F=terms[2], G=terms[3])]
+                    segs += [dict(out=q[b // 2], s=q[a // 2], F=q[2], G=q[3]) for q in pst]
+                    K.aug_update(segs, dt, 1.0, torch.float32, dev)
+            per_step, bare = timed(step)
+            return {"tsde_aug_update": per_step, "producers alone (per step)": bare}
+        return None
+
+    def roofline(self, value, k_ms, k_launches):
+        """The `roofline` object of a trajectory-kernel workload given its trajectory-steps/s and kernel brackets."""
         c = self.cfg
         B, d, nsteps = c["B"], c["d"], c["nsteps"]
         if k_launches <= 0:
@@ -249,36 +350,80 @@ class Job:
                             "in the kernel): the step's 16*d bytes per trajectory-step never reach HBM, so neither "
                             "fraction of the HBM peak describes this kernel; see DESIGN.md for its VALU utilisation",
                     "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
-        # Each bracket is (event record, kernel, event record) on the launch stream of an eagerly issued solve that
-        # was fully enqueued behind a delay kernel (the queue never runs dry). A bracket = kernel + the marker
-        # packets' latency, i.e. an UPPER bound on the kernel time, so the fraction from it is a LOWER bound. The
-        # headline also has the back-to-back figure, which agrees with the rocprofv3 kernel trace (profiles/).
-        avg_s = raw_s if b2b_us is None else b2b_us * 1e-6
-        bytes_per_launch = c["bytes_per_traj_step"] * B / c["launches_per_step"]
-        achieved = bytes_per_launch / avg_s / 1e9
-        solve_achieved = c["bytes_per_traj_step"] * value / self.world / 1e9
-        return {"bound": "hbm", "kernel": c["kernel"],
+        raise AssertionError("stepwise workloads use roofline_stepwise")
+
+    def roofline_stepwise(self, value, b2b):
+        """The `roofline` object of a stepwise workload from its trajectory-steps/s and the back-to-back kernel times.
+        `frac` prices the dominant kernel(s) with SURVEY 8d's ALGORITHMIC bytes per trajectory-step; where the
+        implementation moves more than that (SRK: partial sums between the four stage kernels) `moved_frac` says what
+        the memory system actually carried."""
+        c = self.cfg
+        B, per_step = c["B"], c["launches_per_step"]
+        contract = c["bytes_per_traj_step"]
+        moved = c.get("bytes_moved_per_traj_step", contract)
+        if c["kid"] == 4:
+            step_us = b2b["whole step (4 stages in order)"]      # (already the sum over the step's four launches)
+        else:
+            step_us = next(iter(b2b.values())) * per_step
+        achieved = contract * B / (step_us * 1e-6) / 1e9
+        solve_achieved = contract * value / self.world / 1e9
+        roof = {"bound": "hbm", "kernel": c["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "frac_is": "KERNEL level: algorithmic bytes per launch of the dominant kernel / its average duration",
+                "frac_is": "KERNEL level: SURVEY 8d algorithmic bytes of one solver step (all rows) / the in-situ duration "
+                           "of the step's launches of the dominant kernel",
                 "solve_achieved": solve_achieved, "solve_frac": solve_achieved / HBM_PEAK_GBPS,
                 "solve_frac_is": "SOLVE level (SURVEY 8d): bytes_per_traj_step x value / (n_gpus x peak); includes the "
                                  "user's f, g torch kernels and all launch gaps",
-                "bytes_per_traj_step": c["bytes_per_traj_step"],
-                "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
-                "bracket_us_in_situ": raw_s * 1e6, "launches_timed": k_launches,
-                "timing": ("HIP events around 200 back-to-back launches on live data (avg_launch_us); bracket_us_in_situ = "
-                           "HIP events bracketing each of the launches of one eagerly issued solve, an upper bound "
-                           "that includes marker-packet latency") if b2b_us is not None else
-                          "HIP events bracketing every launch of one eagerly issued solve (upper bound: includes "
-                          "marker-packet latency)"}
+                "bytes_per_traj_step": contract, "bytes_per_launch": contract * B / per_step,
+                "launches_per_step": per_step, "avg_launch_us": step_us / per_step,
+                "launch_us": {k: round(v, 3) for k, v in b2b.items()},
+                "traffic": None,
+                "timing": "in situ: HIP events around ONE replay of a HIP graph holding 50 solver steps (the SDE's f, g torch "
+                          "kernels + this kernel, live operands) minus the same graph without this kernel; best of 3 "
+                          "replays each; no marker packets, no host launch rate, no cache-resident operands"}
+        if moved != contract:
+            roof["bytes_moved_per_traj_step"] = moved
+            roof["moved_achieved"] = moved * B / (step_us * 1e-6) / 1e9
+            roof["moved_frac"] = roof["moved_achieved"] / HBM_PEAK_GBPS
+            roof["moved_is"] = ("bytes the implementation's kernels stream per trajectory-step (DESIGN.md: 23 streams for "
+                                "SRID2 with user code between the stages vs the 16 of SURVEY 8d)")
+        return roof
+
+
+def _graph_replay_us(launches, dev, replays=3):
+    """Average microseconds per launch of `launches` (zero-argument callables, one kernel launch each) recorded into
+    one HIP graph and replayed: best of `replays`, HIP events around the replay on the replay's stream."""
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side), torch.no_grad():
+        for fn in launches[:8]:
+            fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        for fn in launches:
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del graph
+    return best * 1e3 / len(launches)
 
 
 def _attach_offline_traffic(roofline, workload):
-    """HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/profile.sh), corrected as
-    guides/MI355X_MICROARCH.md prescribes -- collected offline because counters need their own passes, and attached
-    only if the file says it was collected on the kernel sources this run uses."""
+    """HBM bytes per launch from rocprofv3 PMC passes of `bench.py --workload <this one>` (tools/profile_traffic.sh),
+    corrected as guides/MI355X_MICROARCH.md prescribes -- collected offline because counters need their own passes,
+    and attached only if the file says it was collected on the kernel sources this run uses."""
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if roofline is None or workload != HEADLINE or not os.path.exists(tpath):
+    cfg = WORKLOADS[workload]
+    if roofline is None or not cfg.get("kernel_match") or not os.path.exists(tpath):
         return
     try:
         with open(tpath) as fh:
@@ -286,20 +431,42 @@ def _attach_offline_traffic(roofline, workload):
         digest = csrc_digest()
         if rec.get("csrc_sha") != digest:
             roofline["traffic_source"] = (f"profiles/traffic_latest.json is for kernel sources {rec.get('csrc_sha')}, "
-                                          f"this run uses {digest}: stale, not reported (re-run tools/profile.sh)")
+                                          f"this run uses {digest}: stale, not reported (re-run tools/profile_traffic.sh)")
             return
-        for kname, k in rec.get("kernels", {}).items():
-            if "StepDiagOp<float>" in kname:
-                roofline["traffic"] = k["traffic_bytes_per_launch"]
-                roofline["kernel_us_rocprofv3"] = k.get("kernel_avg_us")
-                roofline["traffic_source"] = (f"offline: profiles/traffic_latest.json @ csrc {digest} "
-                                              f"({rec.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})")
+        kernels = rec.get("workloads", {}).get(workload, {}).get("kernels")
+        if kernels is None and workload == HEADLINE:
+            kernels = rec.get("kernels")          # (the one-workload layout of rounds 1-2)
+        if not kernels:
+            roofline["traffic_source"] = f"profiles/traffic_latest.json has no counters for {workload}"
+            return
+        # one row per dominant kernel of a step (one, or the four SRK stages): every pattern must find its kernel
+        rows = []
+        for pattern in cfg["kernel_match"]:
+            hit = [k for name, k in kernels.items() if pattern in name]
+            if not hit:
+                roofline["traffic_source"] = f"profiles/traffic_latest.json: no kernel matching {pattern!r} for {workload}"
+                return
+            rows.append(max(hit, key=lambda k: k.get("launches", 0)))
+        per_step = cfg["launches_per_step"]
+        launches_each = per_step // len(rows)
+        step_bytes = sum(k["traffic_bytes_per_launch"] for k in rows) * launches_each
+        roofline["traffic"] = step_bytes / per_step
+        roofline["traffic_per_traj_step"] = step_bytes / cfg["B"]
+        roofline["traffic_over_algorithmic"] = roofline["traffic_per_traj_step"] / cfg["bytes_per_traj_step"]
+        us = [k.get("kernel_avg_us") for k in rows]
+        if all(u is not None for u in us):
+            roofline["kernel_us_rocprofv3"] = sum(us) / len(us)
+            roofline["frac_rocprofv3"] = (cfg["bytes_per_traj_step"] * cfg["B"] / (sum(us) * launches_each * 1e-6) / 1e9
+                                          / HBM_PEAK_GBPS)
+        roofline["traffic_source"] = (f"offline: profiles/traffic_latest.json @ csrc {digest} "
+                                      f"({rec.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})")
     except Exception as e:
         roofline["traffic_source"] = f"profiles/traffic_latest.json unreadable: {e}"
 
 
 def _side_measurement(dev, name):
-    """One `also` entry: 2 warm-up solves, 5 timed solves (median), then the dominant kernel's brackets."""
+    """One `also` entry: 2 warm-up solves, 5 timed solves (median), then the dominant kernel timed back to back (the
+    headline's method) with the counter traffic of profiles/traffic_latest.json attached."""
     job = Job(name, dev)
     c = job.cfg
     for i in range(2):
@@ -318,11 +485,18 @@ def _side_measurement(dev, name):
            "launch": "one trajectory-kernel launch per solve" if job.trajectory else "HIP graph replay"}
     if job.train or job.adjoint:
         rec["what"] = "forward + backward per solve"
-    k_ms, k_launches = job.bracket_dominant_kernel()
-    roof = job.roofline(value, k_ms, k_launches)
+    if job.trajectory:
+        k_ms, k_launches = job.bracket_dominant_kernel()
+        roof = job.roofline(value, k_ms, k_launches)
+    else:
+        live = out if out.shape == job.y0.shape else job.y0.detach()     # (the adjoint returns dL/dy0: use y0 itself)
+        roof = job.roofline_stepwise(value, job.in_situ_us(live))
+        _attach_offline_traffic(roof, name)
     if roof is not None:
         for key in ("bound", "achieved", "unit", "frac", "solve_achieved", "solve_frac", "bytes_per_traj_step",
-                    "bytes_per_launch", "flops_per_launch", "avg_launch_us", "launches_timed"):
+                    "bytes_per_launch", "flops_per_launch", "avg_launch_us", "launches_timed", "launch_us",
+                    "launches_per_step", "bytes_moved_per_traj_step", "moved_frac", "traffic", "traffic_per_traj_step",
+                    "traffic_over_algorithmic", "kernel_us_rocprofv3", "frac_rocprofv3", "traffic_source", "timing"):
             if key in roof:
                 rec[("kernel_" + key) if key in ("achieved", "frac") else key] = roof[key]
         if roof["bound"] == "mfma":
@@ -406,6 +580,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short side measurements reported under `also`")
     ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
+    ap.add_argument("--profile-steps", type=int, default=0,
+                    help="tools/profile_traffic.sh only: solve this many solver steps of the workload and print a line "
+                         "marked profile_run (per-launch counters do not need the full 1000 steps); NOT a measurement")
     args = ap.parse_args()
 
     # TSDE_BENCH_SHARE_GPU=1 (tests only): all ranks use device 0 and gloo carries the collectives, so that the
@@ -437,6 +614,15 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     job = Job(args.workload, dev, rank=rank, world=world, dist=dist, graph=not args.eager)
+    if args.profile_steps > 0:
+        job.cfg = dict(job.cfg, nsteps=args.profile_steps)
+        job.ts = torch.tensor([0.0, args.profile_steps * job.cfg["dt"]], device=dev)
+        for i in range(args.warmup + args.steps):
+            job.solve(i)
+        torch.cuda.synchronize()
+        print(json.dumps({"profile_run": True, "workload": args.workload, "solver_steps": args.profile_steps,
+                          "solves": args.warmup + args.steps, "csrc_sha": csrc_digest()}))
+        return
     cfg = job.cfg
     B, d, m, nsteps, dt = cfg["B"], cfg["d"], cfg["m"], cfg["nsteps"], cfg["dt"]
 
@@ -466,10 +652,13 @@ def main():
     value = world * B * nsteps * args.steps / elapsed
     ranks = _what_the_ranks_saw(job, dev, dist if use_dist else None, share_gpu)
 
-    k_ms, k_launches = job.bracket_dominant_kernel()
-    b2b_us = job.back_to_back_step_diag_us(out) if cfg["kid"] == 1 and cfg["launches_per_step"] == 1 else None
-    roofline = job.roofline(value, k_ms, k_launches, b2b_us)
-    _attach_offline_traffic(roofline, args.workload)
+    if job.trajectory:
+        k_ms, k_launches = job.bracket_dominant_kernel()
+        roofline = job.roofline(value, k_ms, k_launches)
+    else:
+        live = out[:B] if out.shape[-1] == d and out.shape[0] >= B and not (job.adjoint or job.train) else job.y0.detach()
+        roofline = job.roofline_stepwise(value, job.in_situ_us(live))
+        _attach_offline_traffic(roofline, args.workload)
 
     also = None
     if world == 1 and not args.no_also and args.workload == HEADLINE:

@@ -403,3 +403,40 @@ def test_srk_stage_decomposition_equals_the_reference_step(dtype):
     H1_3, acc = K.srk_diag_stage(3, (P, acc, f2, g2), dtn, rdt, sqrt_dt, noise)
     (y1,) = K.srk_diag_stage(4, (acc, sde.g(t_q, H1_3)), dtn, rdt, sqrt_dt, noise)
     assert torch.equal(y1.detach(), want)
+
+
+def test_python_state_fingerprint_of_an_sde_object():
+    """The key of the default ("auto") HIP-graph cache holds a fingerprint of the SDE object's Python-side state: stable
+    across calls (also once this package's own cache sits on the object), changed by re-binding a plain attribute or a
+    tensor, unchanged by in-place tensor updates (replays read tensor contents live)."""
+    from torchsde_amd import graph
+    sde = problems.make("gbm_ito", d=4)
+    first = graph.python_state(sde)
+    graph._cache_of(sde)
+    sde.f(torch.tensor(0.0), torch.ones(2, 4))
+    assert graph.python_state(sde) == first
+    with torch.no_grad():
+        for p in sde.parameters():
+            p.mul_(0.5)
+    assert graph.python_state(sde) == first
+    sde.some_scale = 2.0
+    second = graph.python_state(sde)
+    assert second != first
+    sde.some_scale = 3.0
+    assert graph.python_state(sde) != second
+    sde.some_scale = 2.0
+    sde.ctx = (torch.zeros(3), [1, 2])
+    third = graph.python_state(sde)
+    sde.ctx[0].add_(1.0)
+    assert graph.python_state(sde) == third
+    sde.ctx = (torch.zeros(3), [1, 2])
+    assert graph.python_state(sde) != third
+    sde.train(False)
+    assert graph.python_state(sde) != third
+    big = problems.make("gbm_ito", d=4)
+    big.table = list(range(10000))
+    assert graph.python_state(big) is None          # too much state to fingerprint cheaply: "auto" stays eager
+    assert graph.mode_of({}) == "auto" and graph.mode_of({"hip_graph": True}) is True
+    assert graph.mode_of({"hip_graph": False}) is False and graph.mode_of(None) == "auto"
+    with pytest.raises(ValueError):
+        graph.mode_of({"hip_graph": "yes"})

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torchsde_amd  # noqa: E402
 from torchsde_amd import adaptive  # noqa: E402
 from workloads import problems  # noqa: E402

@@ -1,7 +1,7 @@
 """Timing of BrownianInterval queries (aligned cell, multi-cell, misaligned) at C2 size."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torchsde_amd  # noqa: E402
 
 dev = "cuda"

@@ -19,7 +19,10 @@ stats = find("trace", "*kernel_stats.csv")
 if stats:
     print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1): per-kernel totals ==")
     with open(stats) as f:
-        rows = list(csv.DictReader(f))
+        rows = [r for r in csv.DictReader(f) if "delay_kernel" not in r.get("Name", "")]   # (a bench helper, not the path)
+    total_ns = sum(float(r.get("TotalDurationNs") or 0) for r in rows) or 1.0
+    for r in rows:
+        r["Percentage"] = f"{float(r.get('TotalDurationNs') or 0) / total_ns * 100:.2f}"
     for r in rows:
         try:
             kernel_avg_us[r.get("Name", "")] = float(r.get("AverageNs")) / 1e3

@@ -147,10 +147,10 @@ def python_state(obj, budget=4096):
                 walk(e, depth + 1)
         elif isinstance(x, dict):
             seen.add(id(x))
-            out.append(("dict", len(x)))
-            for k, v in x.items():
-                if isinstance(k, str) and k.startswith("_tsde"):
-                    continue            # this package's own caches on the object
+            # (this package's own caches on the object -- `_tsde_*` attributes -- are not its state)
+            items = [(k, v) for k, v in x.items() if not (isinstance(k, str) and k.startswith("_tsde"))]
+            out.append(("dict", len(items)))
+            for k, v in items:
                 out.append(k if isinstance(k, _SIMPLE) else ("O", id(k)))
                 walk(v, depth + 1)
         elif hasattr(x, "__dict__") and not isinstance(x, type) and not callable(getattr(x, "__call__", None)) \

@@ -6,23 +6,24 @@ WORKLOADS = {
     # BASELINE.json configs[1] -- the headline (default) workload
     "c2_euler_diag_b65536_d64_s1000": dict(
         problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
-        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1, kernel_match=["StepDiagOp<float>"],
         kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
     # the other BASELINE configs at their single-GPU size (parity-test cases; measured for DESIGN.md, not the headline)
     "c2_milstein_diag": dict(
         problem="gbm_ito", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
-        bytes_per_traj_step=20 * 64, kid=3, launches_per_step=1,
+        bytes_per_traj_step=20 * 64, kid=3, launches_per_step=1, kernel_match=["MilsteinDiagOp<float>"],
         kernel="tsde_milstein_diag<float>"),
     "c2_srk_diag": dict(
         problem="gbm_ito", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         # SURVEY 8d's figure for SRID2 is 64*d (every operand touched once); with user code between the stages the four
         # kernels move 23 streams = 92*d (6 + 8 + 6 + 3, include/torchsde_amd.h) -- both are reported
         bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
+        kernel_match=["SrkDiagOp<float, 1>", "SrkDiagOp<float, 2>", "SrkDiagOp<float, 3>", "SrkDiagOp<float, 4>"],
         kernel="tsde_srk_diag_stage<float> (4 stage kernels)"),
     "c3_euler_general_b16384_d32_m16": dict(
         problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
-        bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1,
-        kernel="tsde_step_general<float> (general_fast_kernel)"),
+        bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1, kernel_match=["general_rows_kernel<float"],
+        kernel="tsde_step_general<float> (general_rows_kernel)"),
     # BASELINE configs[2] as literally worded: Milstein for GENERAL noise does not exist in the reference (it raises
     # ValueError, milstein.py:25); this is the opt-in extension pinned by reduction tests (tests/test_gpu_milstein_general.py)
     "c3_milstein_general_b16384_d32_m16": dict(
@@ -31,7 +32,7 @@ WORKLOADS = {
         kernel="tsde_step_general<float> (+ tsde_levy_area, tsde_iterated_integrals, 16 user JVPs per step)"),
     "c4_midpoint_diag_b32768_d64": dict(
         problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
-        bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2,
+        bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2, kernel_match=["StepDiagOp<float>"],
         kernel="tsde_step_diag<float> (two stages per step)"),
     # SURVEY 8d's nonlinear second workload: the SDE the reference's own benchmark integrates (benchmarks/brownian.py:
     # 131-139), f = y, g = exp(-y), at the headline's shape -- stepwise, f and g are user torch ops. Horizon 1000 * 2^-16:
@@ -111,6 +112,7 @@ WORKLOADS = {
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
+        kernel_match=["aug_multi_kernel<float>"],
         kernel="tsde_aug_update<float> (aug_multi_kernel, backward sweep)"),
 }
 
