@@ -57,7 +57,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-in/f32-accumulate matrix rate (same g
 HEADLINE = "c2_euler_diag_b65536_d64_s1000"
 # the stepwise BASELINE configurations, then what the closed-form route makes of the same jobs
 ALSO = ("c2_milstein_diag", "c2_srk_diag",
-        "c3_euler_general_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
+        "c3_euler_general_b16384_d32_m16", "c3_milstein_general_b16384_d32_m16",
+        "c3_milstein_general_gradfree_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c2_euler_closed_form_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
@@ -168,7 +169,7 @@ class Job:
         # Forward solves are captured once into a HIP graph and replayed (the warm-up solves pay for the capture); the
         # adjoint replays one graph for the forward solve and one for the backward sweep; trajectory kernels are one
         # launch per solve anyway.
-        self.use_graph = graph and not self.trajectory
+        self.use_graph = graph and not self.trajectory and not c.get("eager", False)
         self.sde = _make_problem(c["problem"], c["d"], c["m"], dev)
         self.y0 = torch.full((c["B"], c["d"]), 0.1, device=dev, requires_grad=self.adjoint or self.train)
         self.ts = torch.tensor([0.0, c["nsteps"] * c["dt"]], device=dev)
@@ -302,6 +303,17 @@ class Job:
                 [(lambda i=i: step(i, True)) for i in range(reps)], dev) - bare
             out["3 f + 4 g evaluations alone (per step)"] = bare
             return out
+        if kid == 11:      # derivative-free Milstein for general noise: the correction kernel behind g on m*B rows
+            integrals = torch.randn(B, m, m, device=dev) * dt
+
+            def step(i, launch):
+                f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
+                support = K.milstein_gf_general_support(yy[i & 1], f, g, dt, dt ** 0.5, True)
+                gk = sde.g(t0, support.reshape(m * B, d)).reshape(m, B, d, m)
+                if launch:
+                    K.milstein_gf_general_correction(g, gk, integrals, dt ** 0.5)
+            per_step, bare = timed(step)
+            return {"tsde_milstein_gf_general_correction": per_step, "f, g, support, g(support) alone (per step)": bare}
         if kid == 5:
             params = [p for p in sde.parameters() if p.requires_grad]
             st = [torch.rand(B, d, device=dev) for _ in range(4)]
@@ -468,6 +480,11 @@ def _side_measurement(dev, name):
     """One `also` entry: 2 warm-up solves, 5 timed solves (median), then the dominant kernel timed back to back (the
     headline's method) with the counter traffic of profiles/traffic_latest.json attached."""
     job = Job(name, dev)
+    full_steps = job.cfg["nsteps"]
+    budget = job.cfg.get("bench_steps")
+    if budget:          # a workload too slow to time whole: a fixed number of its (homogeneous) solver steps, extrapolated
+        job.cfg = dict(job.cfg, nsteps=budget)
+        job.ts = torch.tensor([0.0, budget * job.cfg["dt"]], device=dev)
     c = job.cfg
     for i in range(2):
         job.solve(i)
@@ -482,7 +499,13 @@ def _side_measurement(dev, name):
     ms = statistics.median(times)
     value = c["B"] * c["nsteps"] / ms * 1e3
     rec = {"ms_per_solve": ms, "ms_per_solve_all": times, "trajectory_steps_per_s": value, "kernel": c["kernel"],
-           "launch": "one trajectory-kernel launch per solve" if job.trajectory else "HIP graph replay"}
+           "launch": "one trajectory-kernel launch per solve" if job.trajectory else
+                     "HIP graph replay" if job.use_graph else "eager launches"}
+    if budget:
+        scale = full_steps / budget
+        rec.update(ms_per_solve=ms * scale, ms_per_solve_all=[t * scale for t in times],
+                   extrapolated=f"timed {budget} of the {full_steps} solver steps per solve (ms as measured: {ms:.2f}), "
+                                f"x{scale:g}: the stepping loop is homogeneous")
     if job.train or job.adjoint:
         rec["what"] = "forward + backward per solve"
     if job.trajectory:

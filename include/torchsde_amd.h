@@ -185,6 +185,18 @@ int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, con
 int tsde_iterated_integrals(void* I, const void* W, const void* A, int64_t B, int64_t m, double dt, int ito, int dtype,
                             void* stream);
 
+/* Derivative-free form of the same EXTENSION: the reference's derivative-free Milstein (milstein.py:58-67: g' evaluated at
+ * y0 + dt*f + g*sqrt_dt, gdg = (g' - g) * v / (2*sqrt_dt)) applied per Brownian channel -- the explicit order-1.0 scheme
+ * of Kloeden & Platen -- instead of m Jacobian-vector products per step (base_sde.py:164-183):
+ *   support:     yk[k,b,i] = (y0[b,i] + dt*f[b,i]) + g[b,i,k]*sqrt_dt   (ito != 0; else (y0 + 0) + g*sqrt_dt),
+ *                laid out (m, B, d) so that ONE call of the caller's g on (m*B, d) rows evaluates every supporting state;
+ *   correction:  corr[b,i] = (sum_{k,l} (gk[k,b,i,l] - g[b,i,l]) * I[b,k,l]) / sqrt_dt, gk = that call's (m, B, d, m) result,
+ *                I from tsde_iterated_integrals. The step is then tsde_step_general(y0, f, g, W) + corr. */
+int tsde_milstein_gf_general_support(void* yk, const void* y0, const void* f, const void* g, int64_t B, int64_t d,
+                                     int64_t m, double dt, double sqrt_dt, int ito, int dtype, void* stream);
+int tsde_milstein_gf_general_correction(void* corr, const void* g, const void* gk, const void* I, int64_t B, int64_t d,
+                                        int64_t m, double sqrt_dt, int dtype, void* stream);
+
 /* Davie (foster=0) / Foster (foster=1) approximation of the Levy area of one interval of width h from its
  * (W, H): A:(B,m,m) (_brownian/brownian_interval.py:78-99); antisymmetric noise keyed on (entropy, cell, node). */
 int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster, uint64_t entropy,

@@ -92,3 +92,199 @@ def test_strong_order_beats_euler():
                 ys_.append(0.5 * math.log(((out[-1] - exact) ** 2).sum(1).mean().item()))
         slopes[method] = linregress(xs, ys_).slope
     assert abs(slopes["milstein"] - 1.0) < 0.15 and slopes["euler"] < 0.75, slopes
+
+
+# ---- the derivative-free form (options={"general_noise": True, "grad_free": True}) -----------------------------------
+GF = {"general_noise": True, "grad_free": True}
+
+
+class _ZeroDrift(nn.Module):
+    """`base` with its drift removed (the supporting states of the Ito derivative-free scheme are y0 + dt*f + g_k*sqrt_dt:
+    with f = 0 a diagonal g embedded as general is perturbed in channel k only, so the reduction is exact)."""
+
+    def __init__(self, base):
+        super().__init__()
+        self.base, self.sde_type, self.noise_type = base, base.sde_type, base.noise_type
+
+    def f(self, t, y):
+        return torch.zeros_like(y)
+
+    def g(self, t, y):
+        return self.base.g(t, y)
+
+
+@pytest.mark.parametrize("sde_type", ["ito", "stratonovich"])
+@pytest.mark.parametrize("dtype,rtol", [(F64, 1e-9), (torch.float32, 2e-4)])
+def test_grad_free_reduces_to_the_reference_backed_diagonal_grad_free_milstein(sde_type, dtype, rtol):
+    """(i) diagonal g embedded as general, derivative-free == the diagonal derivative-free Milstein (milstein.py:58-67,
+    pinned to reference goldens elsewhere) on the same increments. Stratonovich: any drift (its supporting state has no
+    drift term); Ito: zero drift, see _ZeroDrift."""
+    import torchsde_amd
+    B, d, steps, dt = 32, 4, 16, 2.0 ** -5
+    base = problems.GBMDiag(d, sde_type, dtype=dtype).to(DEV)
+    if sde_type == "ito":
+        base = _ZeroDrift(base)
+    y0 = torch.full((B, d), 0.1, dtype=dtype, device=DEV)
+    ts = torch.tensor([0.0, steps * dt], dtype=dtype, device=DEV)
+    kw = dict(t0=0.0, t1=steps * dt, size=(B, d), dtype=dtype, device=DEV, entropy=5, dt=dt)
+    with torch.no_grad():
+        ref = torchsde_amd.sdeint(base, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="milstein", dt=dt,
+                                  options={"grad_free": True})
+        gen = torchsde_amd.sdeint(DiagAsGeneral(base), y0, ts, bm=torchsde_amd.BrownianInterval(**kw),
+                                  method="milstein", dt=dt, options=GF)
+    torch.testing.assert_close(gen, ref, rtol=rtol, atol=rtol * 1e-2)
+
+
+def test_grad_free_with_additive_diffusion_is_euler_bit_for_bit():
+    """(ii) a state-independent g: every supporting evaluation returns g itself, the correction is exactly zero."""
+    import torchsde_amd
+
+    class AdditiveAsGeneral(nn.Module):
+        noise_type, sde_type = "general", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.sigma = nn.Parameter(torch.linspace(0.1, 0.6, 8 * 4).reshape(8, 4))
+
+        def f(self, t, y):
+            return -0.5 * y
+
+        def g(self, t, y):
+            return self.sigma.unsqueeze(0).repeat(y.shape[0], 1, 1)
+
+    B, steps, dt = 64, 16, 2.0 ** -5
+    sde = AdditiveAsGeneral().to(DEV)
+    y0 = torch.full((B, 8), 0.1, device=DEV)
+    ts = torch.tensor([0.0, steps * dt], device=DEV)
+    kw = dict(t0=0.0, t1=steps * dt, size=(B, 4), dtype=torch.float32, device=DEV, entropy=5, dt=dt,
+              levy_area_approximation="foster")
+    with torch.no_grad():
+        mil = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="milstein", dt=dt, options=GF)
+        eul = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="euler", dt=dt)
+    assert torch.equal(mil, eul)
+
+
+@pytest.mark.parametrize("shape", [(16, 4, 4), (8, 32, 16), (5, 3, 2)])       # rows kernel (NC 1, 2) and the generic one
+def test_grad_free_kernels_equal_their_torch_statement(shape):
+    """The two kernels of the derivative-free step against the same sums written with torch ops in float64."""
+    from torchsde_amd import kernels as K
+    B, d, m = shape
+    torch.manual_seed(3)
+    dt, sqrt_dt = 2.0 ** -6, 2.0 ** -3
+    for dtype, tol in ((F64, 1e-12), (torch.float32, 1e-5)):
+        y0, f = torch.randn(B, d, dtype=dtype, device=DEV), torch.randn(B, d, dtype=dtype, device=DEV)
+        g = torch.randn(B, d, m, dtype=dtype, device=DEV)
+        gk = g.unsqueeze(0) + 0.1 * torch.randn(m, B, d, m, dtype=dtype, device=DEV)
+        integrals = torch.randn(B, m, m, dtype=dtype, device=DEV) * dt
+        for ito in (True, False):
+            got = K.milstein_gf_general_support(y0, f, g, dt, sqrt_dt, ito)
+            want = ((y0 + dt * f) if ito else y0).unsqueeze(0) + g.permute(2, 0, 1) * sqrt_dt
+            assert torch.equal(got, want)
+        got = K.milstein_gf_general_correction(g, gk, integrals, sqrt_dt)
+        want = torch.einsum("kbil,bkl->bi", (gk - g.unsqueeze(0)).double(), integrals.double()) / sqrt_dt
+        torch.testing.assert_close(got.double(), want, rtol=tol, atol=tol * want.abs().max().item())
+
+
+def test_grad_free_levy_term_approximates_the_jvp_form():
+    """(iii) one step on a smooth general-noise SDE: the derivative-free correction is a finite difference of the JVP
+    form's (dg_ga_jvp_column_sum) with increment g_k*sqrt_dt (+ dt*f): they agree to O(sqrt_dt) relative."""
+    import torchsde_amd
+    B, d, m = 64, 4, 4
+    sde = problems.make("general_ito", dtype=F64, d=d, m=m).to(DEV)
+    y0 = torch.full((B, d), 0.1, dtype=F64, device=DEV)
+    errs = []
+    for dt in (2.0 ** -6, 2.0 ** -10):
+        ts = torch.tensor([0.0, dt], dtype=F64, device=DEV)
+        kw = dict(t0=0.0, t1=dt, size=(B, m), dtype=F64, device=DEV, entropy=9, dt=dt, levy_area_approximation="foster")
+        with torch.no_grad():
+            jvp = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="milstein", dt=dt,
+                                      options={"general_noise": True})
+            gf = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="milstein", dt=dt,
+                                     options=GF)
+            eul = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="euler", dt=dt)
+        term = (jvp[-1] - eul[-1]).norm().item()
+        errs.append((gf[-1] - jvp[-1]).norm().item() / term)
+    assert errs[0] < 0.25 and errs[1] < errs[0] / 2.5, errs       # 16x smaller dt -> ~4x smaller relative difference
+
+
+def test_grad_free_strong_order_beats_euler():
+    """(iv) strong order ~1.0 on the commutative general-noise SDE with drift (vs ~0.5 for Euler)."""
+    import torchsde_amd
+    B, d, t1 = 4096, 4, 1.0
+    base = problems.GBMDiag(d, "ito", dtype=F64).to(DEV)
+    sde = DiagAsGeneral(base)
+    y0 = torch.full((B, d), 0.1, dtype=F64, device=DEV)
+    ts = torch.tensor([0.0, t1], dtype=F64, device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, t1, size=(B, d), dtype=F64, device=DEV, entropy=271, dt=2.0 ** -8)
+    exact = base.exact(y0, t1, bm(0.0, t1))
+    xs, ys_ = [], []
+    with torch.no_grad():
+        for k in range(3, 9):
+            dt = 2.0 ** -k
+            out = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="milstein", dt=dt, options=GF)
+            xs.append(math.log(dt))
+            ys_.append(0.5 * math.log(((out[-1] - exact) ** 2).sum(1).mean().item()))
+    assert abs(linregress(xs, ys_).slope - 1.0) < 0.15
+
+
+def test_general_milstein_at_full_size_reduces_to_the_oracle_step():
+    """configs[2] as worded, at its full shape (16384 x 32 x 16): a diagonal g embedded as general noise, JVP form and
+    derivative-free form, sampled rows against the ORACLE's Milstein step (oracle/solvers_ref.py milstein_step <-
+    milstein.py:52-94) on the same increments."""
+    import torchsde_amd
+    from oracle import solvers_ref
+    B, d, m, steps, dt = 16384, 32, 16, 4, 2.0 ** -10
+
+    class Embedded(nn.Module):
+        """d = 32 state channels, m = 16 Brownian channels: channel j drives state channels j and j + 16."""
+        noise_type, sde_type = "general", "ito"
+
+        def __init__(self):
+            super().__init__()
+            gen = torch.Generator().manual_seed(0)
+            self.mu = nn.Parameter(-torch.rand(d, generator=gen))
+            self.sigma = nn.Parameter(0.2 + 0.5 * torch.rand(d, generator=gen))
+
+        def f(self, t, y):
+            return self.mu * y
+
+        def g(self, t, y):
+            s = self.sigma * y                                  # (B, d)
+            out = y.new_zeros(y.shape[0], d, m)
+            idx = torch.arange(d, device=y.device)
+            out[:, idx, idx % m] = s
+            return out
+
+    sde = Embedded().to(DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, steps * dt], device=DEV)
+    kw = dict(t0=0.0, t1=steps * dt, size=(B, m), dtype=torch.float32, device=DEV, entropy=77, dt=dt)
+    bm = torchsde_amd.BrownianInterval(**kw)
+    Ws = [bm(k * dt, (k + 1) * dt) for k in range(steps)]
+    rows = torch.arange(0, B, 257, device=DEV)
+
+    # oracle: the same SDE is DIAGONAL noise in the 32 channels with dW_i = W_{i mod 16} (commutative: A drops out)
+    class AsDiagonal(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def f(self, t, y):
+            return sde.mu.detach().cpu().double() * y
+
+        def g(self, t, y):
+            return sde.sigma.detach().cpu().double() * y
+
+    y = y0[rows].cpu().double()
+    t = torch.tensor(0.0, dtype=F64)
+    for k in range(steps):
+        Wk = Ws[k][rows].cpu().double()
+        y = solvers_ref.milstein_step(AsDiagonal(), lambda a, b, W=Wk: torch.cat([W, W], dim=1), t, t + dt, y)
+        t = t + dt
+    with torch.no_grad():
+        jvp = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="milstein", dt=dt,
+                                  options={"general_noise": True})[-1][rows].cpu().double()
+        gf = torchsde_amd.sdeint(sde, y0, ts, bm=torchsde_amd.BrownianInterval(**kw), method="milstein", dt=dt,
+                                 options=GF)[-1][rows].cpu().double()
+    torch.testing.assert_close(jvp, y, rtol=2e-5, atol=1e-7)
+    # the derivative-free form differs from the derivative form by its O(dt^1.5) finite-difference error per step
+    torch.testing.assert_close(gf, y, rtol=1e-3, atol=1e-6)
+    assert (gf - y).abs().max() > 0

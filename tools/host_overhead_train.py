@@ -36,27 +36,41 @@ cases = [("backprop euler", torchsde_amd.sdeint, "euler", "ito", {}),
          ("adjoint midpoint", torchsde_amd.sdeint_adjoint, "midpoint", "stratonovich", {}),
          ("adjoint reversible_heun", torchsde_amd.sdeint_adjoint, "reversible_heun", "stratonovich",
           {"adjoint_method": "adjoint_reversible_heun"})]
-for name, fn, method, sde_type, kw in cases:
-    go = iteration(fn, method, sde_type, **kw)
+OFF = {"hip_graph": False}
+for name, fn, method, sde_type, kw in cases:       # every launch issued eagerly (what round 2's default was)
+    extra = dict(options=OFF, adjoint_options=OFF) if fn is torchsde_amd.sdeint_adjoint else dict(options=OFF)
+    go = iteration(fn, method, sde_type, **extra, **kw)
     go(0)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(3):
         go(1 + i)
     torch.cuda.synchronize()
-    print(f"{name:28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 3 / n * 1e6:7.1f} us")
+    print(f"{name + ' [eager]':40s} fwd+bwd per solver step: {(time.perf_counter() - t) / 3 / n * 1e6:7.1f} us")
 
-which = sys.argv[1] if len(sys.argv) > 1 else "adjoint midpoint"
-for name, fn, method, sde_type, kw in cases:
-    if name == which:
-        go = iteration(fn, method, sde_type, **kw)
-        go(0)
-        pr = cProfile.Profile()
-        pr.enable()
-        go(1)
-        torch.cuda.synchronize()
-        pr.disable()
-        pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+for name, fn, method, sde_type, kw in cases:       # NO options: the drop-in call (hip_graph = "auto")
+    go = iteration(fn, method, sde_type, **kw)
+    for i in range(3):                             # eager + watched, capture, first replay
+        go(i)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(5):
+        go(3 + i)
+    torch.cuda.synchronize()
+    print(f"{name + ' [no options]':40s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
+
+if len(sys.argv) > 1:
+    which = sys.argv[1]
+    for name, fn, method, sde_type, kw in cases:
+        if name == which:
+            go = iteration(fn, method, sde_type, **kw)
+            go(0)
+            pr = cProfile.Profile()
+            pr.enable()
+            go(1)
+            torch.cuda.synchronize()
+            pr.disable()
+            pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 
 # the same adjoint cases with forward solve and backward sweep replayed as HIP graphs
 for name, fn, method, sde_type, kw in cases:
@@ -70,7 +84,7 @@ for name, fn, method, sde_type, kw in cases:
     for i in range(5):
         go(2 + i)
     torch.cuda.synchronize()
-    print(f"{name + ' [graphs]':28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
+    print(f"{name + ' [hip_graph=True]':40s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
 
 # back-propagation through the solver with the forward solve and its backward recorded as two HIP graphs
 for name, fn, method, sde_type, kw in cases:
@@ -84,4 +98,4 @@ for name, fn, method, sde_type, kw in cases:
     for i in range(5):
         go(2 + i)
     torch.cuda.synchronize()
-    print(f"{name + ' [graphs]':28s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
+    print(f"{name + ' [hip_graph=True]':40s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")

@@ -95,6 +95,10 @@ SIGNATURES = {
                                        ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_srk_diag_stage": (_c_int, [_c_int, _PTR3, _PTR5, _c_i64, _c_dbl, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int,
                                      _c_ptr]),
+    "tsde_milstein_gf_general_support": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl,
+                                                  _c_int, _c_int, _c_ptr]),
+    "tsde_milstein_gf_general_correction": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl,
+                                                     _c_int, _c_ptr]),
     "tsde_heun_final": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_int,
                                  ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_iterated_integrals": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_dbl, _c_int, _c_int, _c_ptr]),

@@ -251,6 +251,24 @@ int tsde_srk_diag_stage(int stage, void* const out[3], const void* const in[5], 
                 tsde::launch_srk_stage<double>(stage, out, in, n, dt, rdt, sqrt_dt, noise, s));
 }
 
+int tsde_milstein_gf_general_support(void* yk, const void* y0, const void* f, const void* g, int64_t B, int64_t d,
+                                     int64_t m, double dt, double sqrt_dt, int ito, int dtype, void* stream) {
+  if (!yk || !y0 || !f || !g) return bad_arg("tsde_milstein_gf_general_support", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_milstein_gf_general_support",
+                tsde::launch_milstein_gf_general_support<float>(yk, y0, f, g, B, d, m, dt, sqrt_dt, ito, s),
+                tsde::launch_milstein_gf_general_support<double>(yk, y0, f, g, B, d, m, dt, sqrt_dt, ito, s));
+}
+
+int tsde_milstein_gf_general_correction(void* corr, const void* g, const void* gk, const void* I, int64_t B, int64_t d,
+                                        int64_t m, double sqrt_dt, int dtype, void* stream) {
+  if (!corr || !g || !gk || !I) return bad_arg("tsde_milstein_gf_general_correction", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, "tsde_milstein_gf_general_correction",
+                tsde::launch_milstein_gf_general_correction<float>(corr, g, gk, I, B, d, m, sqrt_dt, s),
+                tsde::launch_milstein_gf_general_correction<double>(corr, g, gk, I, B, d, m, sqrt_dt, s));
+}
+
 int tsde_heun_final(void* y1, const void* y0, const void* f, const void* fp, const void* g, const void* gp, int64_t n,
                     double dt, int mode, int prod, const tsde_noise_t* noise, int dtype, void* stream) {
   if (!y1 || !y0 || !f || !g || !gp) return bad_arg("tsde_heun_final", "null argument");

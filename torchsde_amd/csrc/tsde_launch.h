@@ -54,6 +54,12 @@ template <typename T>
 hipError_t launch_srk_stage(int stage, void* const out[3], const void* const in[5], int64_t n, double dt, double rdt,
                             double sqrt_dt, const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
+hipError_t launch_milstein_gf_general_support(void* yk, const void* y0, const void* f, const void* g, int64_t B,
+                                              int64_t d, int64_t m, double dt, double sqrt_dt, int ito, hipStream_t s);
+template <typename T>
+hipError_t launch_milstein_gf_general_correction(void* corr, const void* g, const void* gk, const void* I, int64_t B,
+                                                 int64_t d, int64_t m, double sqrt_dt, hipStream_t s);
+template <typename T>
 hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, double cG, hipStream_t s);
 template <typename T>
 hipError_t launch_interp(void* out, const void* ya, const void* yb, int64_t n, double w0, double w1, hipStream_t s);

@@ -359,6 +359,40 @@ def milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out=None):
     return _raw_milstein_gf_diag(y0, f, g, gprime, dt, sqrt_dt, ito, noise, out)
 
 
+def milstein_gf_general_support(y0, f, g, dt, sqrt_dt, ito):
+    """All m supporting states of derivative-free Milstein for general noise as one (m, B, d) batch:
+    yk[k] = (y0 + dt*f) + g[:, :, k]*sqrt_dt (Ito) / (y0 + 0) + g[:, :, k]*sqrt_dt (Stratonovich)."""
+    B, d, m = g.shape
+    if _needs_grad(y0, f, g):
+        base = (y0 + float(dt) * f) if ito else y0
+        return base.unsqueeze(0) + g.permute(2, 0, 1) * float(sqrt_dt)
+    y0 = _native.contiguous(y0)
+    f, = _prep(y0, f)
+    g = _native.contiguous(g if g.dtype == y0.dtype else g.to(y0.dtype))
+    out = torch.empty((m, B, d), dtype=y0.dtype, device=y0.device)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_milstein_gf_general_support(out.data_ptr(), y0.data_ptr(), f.data_ptr(), g.data_ptr(), B, d, m,
+                                                float(dt), float(sqrt_dt), 1 if ito else 0, dt_code, stream)
+    _native.check(code, "tsde_milstein_gf_general_support")
+    return out
+
+
+def milstein_gf_general_correction(g, gk, integrals, sqrt_dt):
+    """corr[b, i] = (sum_{k,l} (gk[k, b, i, l] - g[b, i, l]) * I[b, k, l]) / sqrt_dt;  g (B, d, m), gk (m, B, d, m)."""
+    B, d, m = g.shape
+    if _needs_grad(g, gk, integrals):
+        return torch.einsum("kbil,bkl->bi", gk - g.unsqueeze(0), integrals) / float(sqrt_dt)
+    g = _native.contiguous(g)
+    gk = _native.contiguous(gk if gk.dtype == g.dtype else gk.to(g.dtype))
+    integrals = _native.contiguous(integrals if integrals.dtype == g.dtype else integrals.to(g.dtype))
+    out = torch.empty((B, d), dtype=g.dtype, device=g.device)
+    lib, dt_code, stream = _launch_env(g)
+    code = lib.tsde_milstein_gf_general_correction(out.data_ptr(), g.data_ptr(), gk.data_ptr(), integrals.data_ptr(),
+                                                   B, d, m, float(sqrt_dt), dt_code, stream)
+    _native.check(code, "tsde_milstein_gf_general_correction")
+    return out
+
+
 # ---- SRK ---------------------------------------------------------------------------------------------------
 # SRID2 tableau (tableaus/srid2.py:19-54), the Python twin of csrc/tsde_schemes.h `Srid2`
 _SRID2_A0 = ((), (1,), (1 / 4, 1 / 4), (0, 0, 0))

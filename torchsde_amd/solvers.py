@@ -658,6 +658,17 @@ class _Milstein(BaseSDESolver):
             W, _ = st.noise.materialise()
         integrals = K.iterated_integrals(W, A, dt, self.ito)
         f, g = sde.f_and_g(t0, y0)
+        if self.options[METHOD_OPTIONS.grad_free]:
+            # Derivative-free form (the reference's own idea for diagonal noise, milstein.py:58-67, per channel): the m
+            # supporting states y0 + dt*f + g[:, :, k]*sqrt_dt as ONE batch of m*B rows through the user's g, then
+            # corr = sum_{k,l} (g_l(Y_k) - g_l(y0)) I_kl / sqrt_dt in one kernel that streams that result once
+            # (csrc/milstein_general.hip) -- no autograd in the step.
+            B, d, m = g.shape
+            support = K.milstein_gf_general_support(y0, f, g, dt, st.sqrt_dt, self.ito)
+            g_support = sde.g(t0, support.reshape(m * B, d)).reshape(m, B, d, m)
+            correction = K.milstein_gf_general_correction(g, g_support, integrals, st.sqrt_dt)
+            y1 = K.step_general(y0, f, g, dt, 1.0, NoiseSpec.external(W))
+            return K.lincomb2(y1, correction, 1.0, 1.0, out=out)
         # The m directional derivatives: the reference's batched formulation (base_sde.py:186-209, one JVP over an
         # m-times replicated batch) is 2.5x faster on this GPU than m separate JVPs (tools/bench_levy_jvp.py); it is
         # used for forward-only solves while the replicated diffusion stays under 4 GiB.

@@ -29,7 +29,17 @@ WORKLOADS = {
     "c3_milstein_general_b16384_d32_m16": dict(
         problem="general_big", method="milstein", levy="foster", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1, options={"general_noise": True},
+        eager=True,          # (the JVPs run double backward through autograd inside every step: issued eagerly)
+        bench_steps=50,      # 16 double-backward JVPs per step: 50 of the 1000 steps are timed and the rest extrapolated
         kernel="tsde_step_general<float> (+ tsde_levy_area, tsde_iterated_integrals, 16 user JVPs per step)"),
+    # ... and its derivative-free form (the reference's derivative-free idea, milstein.py:58-67, per Brownian channel): all m
+    # supporting states through ONE call of the user's g on m*B rows, the correction in one kernel that streams that
+    # call's (m, B, d, m) result once: per trajectory-step g (d*m) + g at the supporting states (m*d*m) + I (m*m) + y, f, corr
+    "c3_milstein_general_gradfree_b16384_d32_m16": dict(
+        problem="general_big", method="milstein", levy="foster", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (32 * 16 * 17 + 16 * 16 + 32), kid=11, launches_per_step=1,
+        options={"general_noise": True, "grad_free": True}, kernel_match=["gf_correction_rows_kernel<float"],
+        kernel="tsde_milstein_gf_general_correction<float> (gf_correction_rows_kernel) + tsde_step_general"),
     "c4_midpoint_diag_b32768_d64": dict(
         problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=32 * 64, kid=1, launches_per_step=2, kernel_match=["StepDiagOp<float>"],
