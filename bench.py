@@ -22,9 +22,9 @@ Prints ONE JSON line (rank 0):
   `median_ms_per_step` / `value_median` restate it from the median of the per-solve times (HIP events recorded
   between the solves of the same timed region);
 * `roofline`: two fractions of the 8 TB/s HBM peak, named for what they are --
-    `frac`        KERNEL level: the dominant kernel's SURVEY-8d algorithmic bytes per solver step / what its launches cost
-                  inside a step, measured live with HIP events on the launch stream: a HIP graph of 50 solver steps (the
-                  SDE's f, g torch kernels + the kernel, live operands) minus the same graph without the kernel;
+    `frac`        KERNEL level: the dominant kernel's SURVEY-8d algorithmic bytes per solver step / the duration of its
+                  launches inside a solve, measured live with HIP events bound to each DISPATCH (hipExtLaunchKernel on
+                  the launch stream: the kernel's own start-to-end interval, as a rocprofv3 kernel trace reports it);
     `solve_frac`  SOLVE level: algorithmic bytes per trajectory-step x `value` / (N x 8e12), i.e.
                   with the user's f and g torch kernels and every launch gap inside;
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes, tools/profile_traffic.sh) and `kernel_us_rocprofv3` are
@@ -186,12 +186,13 @@ class Job:
         if self.adjoint or self.train:
             with torch.enable_grad():
                 if self.adjoint:
-                    gopt = {"hip_graph": True} if graph else {}
+                    gopt = {"hip_graph": bool(graph)}      # (False, not absent: the default is "auto")
                     ys = self._sdeint_adjoint(self.sde, self.y0, self.ts, bm=bm, method=c["method"],
                                               adjoint_method=c["adjoint_method"], dt=c["dt"], options=dict(gopt),
                                               adjoint_options=dict(gopt))
                 else:
-                    ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"])
+                    ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
+                                      options=dict(extra_options) or None)
                 self.y0.grad = None
                 self.sde.zero_grad()
                 ys[-1].sum().backward()
@@ -201,7 +202,7 @@ class Job:
             return self.y0.grad
         with torch.no_grad():
             ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
-                              options=dict(extra_options, hip_graph=True) if graph else (extra_options or None))
+                              options=dict(extra_options, hip_graph=bool(graph)))
             if self.dist is not None:
                 self.dist.all_gather_into_tensor(self.gathered, ys[-1])
                 return self.gathered
@@ -221,116 +222,33 @@ class Job:
         torch.cuda.synchronize()
         return K.prof_end()
 
-    def in_situ_us(self, live_state):
-        """THE kernel-level timing of every stepwise workload: what the dominant kernel costs INSIDE a solver step.
-        `reps` solver steps on live operands -- the SDE's own f and g evaluated (by the user's torch code) before every
-        launch, exactly as in a solve, so the kernel reads operands another kernel has just written -- are recorded
-        into ONE HIP graph and replayed between one pair of HIP events; the same graph without this package's kernel
-        is timed the same way; the kernel's figure is the difference. No marker packets between launches, no host
-        launch rate, no stream-parking kernel in a trace -- and no operand that stays cache-resident across launches
-        (constant f, g are partly retained by the per-XCD L2 at shard sizes: a plain back-to-back loop showed 4.1 us
-        = "103 % of peak" where the solve's kernel takes 6.6). Returns {label: us per launch} (one entry, or the four
-        SRK stages + the whole step), best of three replays each."""
+    def dispatch_us(self):
+        """THE kernel-level timing of every stepwise workload: each launch of the dominant kernel in ONE eagerly issued
+        solve, timed PER DISPATCH -- the library issues those launches with hipExtLaunchKernel, which binds a pair of
+        events to the dispatch itself (tsde_prof_begin, csrc/tsde_common.h TSDE_LAUNCH), so a launch's time is its own
+        start-to-end interval as the packet processor stamps it: what a rocprofv3 kernel trace of this command reports,
+        with no marker packets on the stream (a hipEventRecord bracket adds ~2.5 us to a 6 us kernel) -- and in situ: the
+        kernel reads operands the SDE's own f and g kernels have just written (constant operands stay partly resident in
+        the per-XCD L2 at shard sizes: a back-to-back loop shows 4.1 us where the solve's kernel takes 6.6). The stream
+        is parked behind a delay kernel while the host enqueues the solve, so no kernel starts on an idle queue.
+        Returns {label: us per launch} (one entry, or the four SRK stages)."""
         from torchsde_amd import kernels as K
-        from torchsde_amd.kernels import NoiseSpec
-        c, dev, sde = self.cfg, self.dev, self.sde
-        B, d, m, dt, kid = c["B"], c["d"], c["m"], float(c["dt"]), c["kid"]
-        reps = 50
-        y = live_state[:B].detach().clone().contiguous()
-        t0 = self.ts[0]
-        spec = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(reps)]
-        yy = [y, y.clone()]
-
-        def timed(step):
-            """us per solver step with and without the kernel(s)"""
-            full = _graph_replay_us([(lambda i=i: step(i, True)) for i in range(reps)], dev)
-            bare = _graph_replay_us([(lambda i=i: step(i, False)) for i in range(reps)], dev)
-            return full - bare, bare
-
-        if kid == 1:
-            coefs = [(dt, 1.0)] if c["launches_per_step"] == 1 else [(0.5 * dt, 0.5), (dt, 1.0)]   # midpoint: two stages
-
-            def step(i, launch):
-                for cf, cg in coefs:
-                    f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
-                    if launch:
-                        K._raw_step_diag(yy[i & 1], f, g, cf, cg, spec[i], yy[(i + 1) & 1])
-            per_step, bare = timed(step)
-            return {"tsde_step_diag": per_step / len(coefs), "f, g evaluations alone (per step)": bare}
-        if kid == 2:
-            def step(i, launch):
-                f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
-                if launch:
-                    K._raw_step_general(yy[i & 1], f, g, dt, 1.0, spec[i], yy[(i + 1) & 1])
-            per_step, bare = timed(step)
-            return {"tsde_step_general": per_step, "f, g evaluations alone (per step)": bare}
-        if kid == 3:
-            def step(i, launch):
-                f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
-                gdg = g * g          # stand-in producer of the diffusion VJP's result (one torch kernel writing (B, d))
-                if launch:
-                    K._raw_milstein_diag(yy[i & 1], f, g, gdg, dt, spec[i], yy[(i + 1) & 1])
-            per_step, bare = timed(step)
-            return {"tsde_milstein_diag": per_step, "f, g, gdg producers alone (per step)": bare}
-        if kid == 4:
-            rdt, sqrt_dt = 1.0 / dt, dt ** 0.5
-            with torch.no_grad():      # inputs of the evaluations in the graph WITHOUT the stage kernels
-                f0, g0 = sde.f(t0, y), sde.g(t0, y)
-                h01, h11, h12 = K.srk_diag_stage(1, (y, f0, g0), dt, rdt, sqrt_dt, spec[0])
-                h02, acc0, p13 = K.srk_diag_stage(2, (y, f0, g0, sde.f(t0, h01), sde.g(t0, h11)), dt, rdt, sqrt_dt, spec[0])
-                h13, _ = K.srk_diag_stage(3, (p13, acc0.clone(), sde.f(t0, h02), sde.g(t0, h12)), dt, rdt, sqrt_dt, spec[0])
-
-            def step(i, launch, only=None):
-                """one SRID2 step as solvers.SRK._advance issues it; `only`: launch just that stage kernel"""
-                def want(k):
-                    return launch and (only is None or only == k)
-                yi = yy[i & 1]
-                f0, g0 = sde.f(t0, yi), sde.g(t0, yi)
-                s1 = K.srk_diag_stage(1, (yi, f0, g0), dt, rdt, sqrt_dt, spec[i]) if want(1) else (h01, h11, h12)
-                f1, g1 = sde.f(t0, s1[0]), sde.g(t0, s1[1])
-                s2 = K.srk_diag_stage(2, (yi, f0, g0, f1, g1), dt, rdt, sqrt_dt, spec[i]) if want(2) else (h02, acc0, p13)
-                f2, g2 = sde.f(t0, s2[0]), sde.g(t0, s1[2])
-                s3 = K.srk_diag_stage(3, (s2[2], s2[1], f2, g2), dt, rdt, sqrt_dt, spec[i]) if want(3) else (h13, acc0)
-                g3 = sde.g(t0, s3[0])
-                if want(4):
-                    K.srk_diag_stage(4, (s3[1], g3), dt, rdt, sqrt_dt, spec[i], out_last=yy[(i + 1) & 1])
-            bare = _graph_replay_us([(lambda i=i: step(i, False)) for i in range(reps)], dev)
-            out = {}
-            for k in (1, 2, 3, 4):
-                out[f"tsde_srk_diag_stage {k}"] = _graph_replay_us(
-                    [(lambda i=i, k=k: step(i, True, only=k)) for i in range(reps)], dev) - bare
-            out["whole step (4 stages in order)"] = _graph_replay_us(
-                [(lambda i=i: step(i, True)) for i in range(reps)], dev) - bare
-            out["3 f + 4 g evaluations alone (per step)"] = bare
-            return out
-        if kid == 11:      # derivative-free Milstein for general noise: the correction kernel behind g on m*B rows
-            integrals = torch.randn(B, m, m, device=dev) * dt
-
-            def step(i, launch):
-                f, g = sde.f(t0, yy[i & 1]), sde.g(t0, yy[i & 1])
-                support = K.milstein_gf_general_support(yy[i & 1], f, g, dt, dt ** 0.5, True)
-                gk = sde.g(t0, support.reshape(m * B, d)).reshape(m, B, d, m)
-                if launch:
-                    K.milstein_gf_general_correction(g, gk, integrals, dt ** 0.5)
-            per_step, bare = timed(step)
-            return {"tsde_milstein_gf_general_correction": per_step, "f, g, support, g(support) alone (per step)": bare}
-        if kid == 5:
-            params = [p for p in sde.parameters() if p.requires_grad]
-            st = [torch.rand(B, d, device=dev) for _ in range(4)]
-            pst = [[torch.zeros_like(p), torch.zeros_like(p), torch.randn_like(p), torch.randn_like(p)] for p in params]
-
-            def step(i, launch):
-                a, b = (0, 2) if i & 1 == 0 else (2, 0)
-                # stand-ins for the sweep's producers (f, g.v and their VJPs w.r.t. y): four torch kernels writing (B, d)
-                terms = [st[a] * 0.5, st[a] * 0.25, st[a + 1] * 0.5, st[a + 1] * 0.25]
-                if launch:
-                    segs = [dict(out=st[b], s=st[a], F=terms[0], G=terms[1], sF=-1.0, sG=-1.0),
-                            dict(out=st[b + 1], s=st[a + 1], F=terms[2], G=terms[3])]
-                    segs += [dict(out=q[b // 2], s=q[a // 2], F=q[2], G=q[3]) for q in pst]
-                    K.aug_update(segs, dt, 1.0, torch.float32, dev)
-            per_step, bare = timed(step)
-            return {"tsde_aug_update": per_step, "producers alone (per step)": bare}
-        return None
+        c = self.cfg
+        per_step = c["launches_per_step"]
+        capacity = c["nsteps"] * per_step + 8
+        self.solve(4999, graph=False)          # (lazy initialisation of the eager path out of the way)
+        torch.cuda.synchronize()
+        K.prof_begin(c["kid"], capacity)
+        K.gpu_delay(min(2.0e6, 40.0 * c["nsteps"] * (2 + per_step)), self.dev)
+        self.solve(5000, graph=False)
+        torch.cuda.synchronize()
+        times = K.prof_read(capacity)
+        K.prof_end()
+        if not times:
+            return None
+        if c["kid"] == 4:
+            return {f"tsde_srk_diag_stage {k + 1}": 1e3 * statistics.mean(times[k::4]) for k in range(4)}
+        return {c["kernel"].split(" ")[0]: 1e3 * statistics.mean(times)}
 
     def roofline(self, value, k_ms, k_launches):
         """The `roofline` object of a trajectory-kernel workload given its trajectory-steps/s and kernel brackets."""
@@ -373,16 +291,15 @@ class Job:
         B, per_step = c["B"], c["launches_per_step"]
         contract = c["bytes_per_traj_step"]
         moved = c.get("bytes_moved_per_traj_step", contract)
-        if c["kid"] == 4:
-            step_us = b2b["whole step (4 stages in order)"]      # (already the sum over the step's four launches)
-        else:
-            step_us = next(iter(b2b.values())) * per_step
+        if b2b is None:
+            return None
+        step_us = sum(b2b.values()) if c["kid"] == 4 else next(iter(b2b.values())) * per_step
         achieved = contract * B / (step_us * 1e-6) / 1e9
         solve_achieved = contract * value / self.world / 1e9
         roof = {"bound": "hbm", "kernel": c["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "frac_is": "KERNEL level: SURVEY 8d algorithmic bytes of one solver step (all rows) / the in-situ duration "
-                           "of the step's launches of the dominant kernel",
+                "frac_is": "KERNEL level: SURVEY 8d algorithmic bytes of one solver step (all rows) / the summed dispatch "
+                           "durations of the step's launches of the dominant kernel inside a solve",
                 "solve_achieved": solve_achieved, "solve_frac": solve_achieved / HBM_PEAK_GBPS,
                 "solve_frac_is": "SOLVE level (SURVEY 8d): bytes_per_traj_step x value / (n_gpus x peak); includes the "
                                  "user's f, g torch kernels and all launch gaps",
@@ -390,9 +307,10 @@ class Job:
                 "launches_per_step": per_step, "avg_launch_us": step_us / per_step,
                 "launch_us": {k: round(v, 3) for k, v in b2b.items()},
                 "traffic": None,
-                "timing": "in situ: HIP events around ONE replay of a HIP graph holding 50 solver steps (the SDE's f, g torch "
-                          "kernels + this kernel, live operands) minus the same graph without this kernel; best of 3 "
-                          "replays each; no marker packets, no host launch rate, no cache-resident operands"}
+                "timing": "per dispatch, in situ: every launch of the kernel in one eagerly issued solve (stream parked "
+                          "while the host enqueues it) issued with hipExtLaunchKernel, whose events are bound to the "
+                          "dispatch itself -- the kernel's own start-to-end interval, as in a rocprofv3 kernel trace; "
+                          "mean over the solve's launches"}
         if moved != contract:
             roof["bytes_moved_per_traj_step"] = moved
             roof["moved_achieved"] = moved * B / (step_us * 1e-6) / 1e9
@@ -400,33 +318,6 @@ class Job:
             roof["moved_is"] = ("bytes the implementation's kernels stream per trajectory-step (DESIGN.md: 23 streams for "
                                 "SRID2 with user code between the stages vs the 16 of SURVEY 8d)")
         return roof
-
-
-def _graph_replay_us(launches, dev, replays=3):
-    """Average microseconds per launch of `launches` (zero-argument callables, one kernel launch each) recorded into
-    one HIP graph and replayed: best of `replays`, HIP events around the replay on the replay's stream."""
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side), torch.no_grad():
-        for fn in launches[:8]:
-            fn()
-    torch.cuda.current_stream(dev).wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.no_grad(), torch.cuda.graph(graph):
-        for fn in launches:
-            fn()
-    graph.replay()
-    torch.cuda.synchronize()
-    best = float("inf")
-    for _ in range(replays):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        graph.replay()
-        e1.record()
-        e1.synchronize()
-        best = min(best, e0.elapsed_time(e1))
-    del graph
-    return best * 1e3 / len(launches)
 
 
 def _attach_offline_traffic(roofline, workload):
@@ -512,8 +403,7 @@ def _side_measurement(dev, name):
         k_ms, k_launches = job.bracket_dominant_kernel()
         roof = job.roofline(value, k_ms, k_launches)
     else:
-        live = out if out.shape == job.y0.shape else job.y0.detach()     # (the adjoint returns dL/dy0: use y0 itself)
-        roof = job.roofline_stepwise(value, job.in_situ_us(live))
+        roof = job.roofline_stepwise(value, job.dispatch_us())
         _attach_offline_traffic(roof, name)
     if roof is not None:
         for key in ("bound", "achieved", "unit", "frac", "solve_achieved", "solve_frac", "bytes_per_traj_step",
@@ -679,8 +569,7 @@ def main():
         k_ms, k_launches = job.bracket_dominant_kernel()
         roofline = job.roofline(value, k_ms, k_launches)
     else:
-        live = out[:B] if out.shape[-1] == d and out.shape[0] >= B and not (job.adjoint or job.train) else job.y0.detach()
-        roofline = job.roofline_stepwise(value, job.in_situ_us(live))
+        roofline = job.roofline_stepwise(value, job.dispatch_us())
         _attach_offline_traffic(roofline, args.workload)
 
     also = None

@@ -468,8 +468,15 @@ int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int
 #define TSDE_KID_TRAJECTORY 8
 #define TSDE_KID_MLP_BACKWARD 9
 #define TSDE_KID_MLP_ADJOINT 10
-/* Start bracketing every launch of kernel family `kid` with hipEvents (at most `capacity` launches). */
+#define TSDE_KID_MILSTEIN_GF_GENERAL 11
+/* Start timing every launch of kernel family `kid` (at most `capacity` launches). Families 1-6 and 11 are timed PER
+ * DISPATCH: the launch is issued with hipExtLaunchKernel and the two events are bound to that dispatch, so their elapsed
+ * time is the kernel's own start-to-end interval (what a rocprofv3 kernel trace reports) with no marker packets on the
+ * stream. The other families (one long kernel per call) are bracketed by hipEventRecord calls around the launch. */
 int tsde_prof_begin(int kid, int capacity);
+/* The per-launch times (ms) recorded so far, in launch order (`*used` of them, at most `capacity`); synchronises on
+ * them. Call before tsde_prof_end. */
+int tsde_prof_read(double* ms, int capacity, int* used);
 /* Occupies `stream` with a single-thread kernel for about `microseconds` (<= 2 s). bench.py queues one before
  * its event-timed pass so that the host can enqueue the whole solve first and no bracket contains queue-empty
  * time. */

@@ -212,7 +212,7 @@ class _GraphedAttempt(_Attempt):
             torch.cuda.current_stream(device).wait_stream(side)
             from . import graph as graph_module
             self.graph = torch.cuda.CUDAGraph()
-            with graph_module._no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with graph_module._capturing(self.graph, device):
                 self._launch(solver, bm)
         finally:
             bm._entropy_dev = None
@@ -258,8 +258,12 @@ def _attempt_for(solver, y0, ts_host, step_cls):
         sig = ("auto", state) + sig
         entry = cache.get(sig)
         if entry is None:
-            graph_module._remember(cache, sig, graph_module._Seen())
-            return _Attempt(solver, y0, step_cls)
+            # this solve runs eagerly; its FIRST round of attempts is screened (graph.run_screened) and decides
+            # whether the next solve of this structure may record the attempt
+            attempt = _Attempt(solver, y0, step_cls)
+            attempt.screen = lambda reason: graph_module._remember(
+                cache, sig, graph_module._Seen() if reason is None else graph_module._Refused(reason))
+            return attempt
         if isinstance(entry, graph_module._Refused):
             return _Attempt(solver, y0, step_cls)
         if isinstance(entry, graph_module._Seen):
@@ -307,7 +311,14 @@ def integrate(solver, y0, ts, extra0, step_cls):
                 # kernels, while a shortfall costs one more (cheap) round.
                 need = int(math.ceil((float(out_t) - curr_t) / max(step_size, solver.dt_min)))
                 budget = min(max(1, need - 1 if need > 2 else need), 256)
-                attempt.run(solver, bm, budget)
+                screen = getattr(attempt, "screen", None)
+                if screen is not None:      # (hip_graph="auto", first solve of this structure)
+                    from . import graph as graph_module
+                    _, reason = graph_module.run_screened(lambda: attempt.run(solver, bm, budget))
+                    screen(reason)
+                    attempt.screen = None
+                else:
+                    attempt.run(solver, bm, budget)
                 attempts += budget
                 state = ctrl.read()
                 syncs += 1

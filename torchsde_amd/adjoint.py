@@ -499,8 +499,8 @@ class _SdeintAdjointMethod(torch.autograd.Function):
             run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
             if ctx.watch_backward is not None:
                 from . import graph
-                out, synced = graph.run_watching_for_host_syncs(lambda: run(*inputs))
-                ctx.watch_backward(synced)
+                out, reason = graph.run_screened(lambda: run(*inputs))
+                ctx.watch_backward(reason)
             else:
                 out = run(*inputs)
         if reversible:      # a_y, (a_f, a_g, a_z), a_theta...

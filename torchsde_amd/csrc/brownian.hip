@@ -176,10 +176,10 @@ hipError_t launch_query(void* W, void* U, void* H, int64_t n, NoiseKey key, cons
                    (!H || aligned16(H));
   const dim3 grid(grid_for((n + 3) / 4 + 1));
   if (have_h) {
-    hipLaunchKernelGGL((query_kernel<T, true>), grid, dim3(kBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa,
+    TSDE_LAUNCH((query_kernel<T, true>), grid, dim3(kBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa,
                        vec ? 1 : 0);
   } else {
-    hipLaunchKernelGGL((query_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key,
+    TSDE_LAUNCH((query_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key,
                        qa, vec ? 1 : 0);
   }
   return hipGetLastError();

@@ -37,19 +37,34 @@ struct Prof {
   std::vector<hipEvent_t> ev;  // 2 per launch
 } g_prof;
 
+// `dispatch_timed`: the entry point's launcher goes through TSDE_LAUNCH (tsde_common.h), so the events are bound to the
+// kernel dispatch itself; otherwise they are recorded on the stream around the call (a bracket: + marker latency).
 struct ProfScope {
   bool on;
   hipStream_t s;
   int slot;
-  ProfScope(int kid, hipStream_t stream) : on(false), s(stream), slot(0) {
+  ProfScope(int kid, hipStream_t stream, bool dispatch_timed = false) : on(false), s(stream), slot(0) {
     if (g_prof.kid == kid && g_prof.used < g_prof.cap) {
-      on = true;
       slot = g_prof.used++;
-      (void)hipEventRecord(g_prof.ev[2 * slot], s);
+      if (dispatch_timed) {
+        tsde::LaunchTiming& lt = tsde::launch_timing();
+        lt.start = g_prof.ev[2 * slot];
+        lt.stop = g_prof.ev[2 * slot + 1];
+        lt.armed = true;
+      } else {
+        on = true;
+        (void)hipEventRecord(g_prof.ev[2 * slot], s);
+      }
     }
   }
   ~ProfScope() {
     if (on) (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+    tsde::LaunchTiming& lt = tsde::launch_timing();
+    if (lt.armed) {      // the call launched nothing (an empty problem): stamp the pair so that it reads as zero time
+      lt.armed = false;
+      (void)hipEventRecord(lt.start, s);
+      (void)hipEventRecord(lt.stop, s);
+    }
   }
 };
 
@@ -116,7 +131,7 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
   qa.n_cells = 0;
   qa.cfg.max_depth = max_depth;
   qa.cfg.snap = snap;
-  ProfScope p(TSDE_KID_BROWNIAN_QUERY, s);
+  ProfScope p(TSDE_KID_BROWNIAN_QUERY, s, true);
   TSDE_DISPATCH(dtype, "tsde_brownian_query", tsde::launch_query<float>(W, U, H, n, key, qa, have_h != 0, s),
                 tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
 }
@@ -140,7 +155,7 @@ int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entro
   qa.n_cells = n_cells;
   qa.cfg.max_depth = max_depth;
   qa.cfg.snap = 0;
-  ProfScope p(TSDE_KID_BROWNIAN_QUERY, s);
+  ProfScope p(TSDE_KID_BROWNIAN_QUERY, s, true);
   TSDE_DISPATCH(dtype, "tsde_brownian_query_dev", tsde::launch_query<float>(W, U, H, n, key, qa, have_h != 0, s),
                 tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
 }
@@ -157,7 +172,7 @@ int tsde_step_diag(void* y1, const void* y0, const void* f, const void* g, int64
                    const tsde_noise_t* noise, int dtype, void* stream) {
   if (!y1 || !y0 || !f || !g || !noise) return bad_arg("tsde_step_diag", "null argument");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_STEP_DIAG, s);
+  ProfScope p(TSDE_KID_STEP_DIAG, s, true);
   TSDE_DISPATCH(dtype, "tsde_step_diag", tsde::launch_step_diag<float>(y1, y0, f, g, n, cf, cg, noise, s),
                 tsde::launch_step_diag<double>(y1, y0, f, g, n, cf, cg, noise, s));
 }
@@ -182,7 +197,7 @@ int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, 
   if (weight_mode < 0 || weight_mode > 2) return bad_arg("tsde_step_general", "weight_mode must be 0, 1 or 2");
   if (weight_mode != 0 && noise->dW && !noise->dU) return bad_arg("tsde_step_general", "weights need dU");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_STEP_GENERAL, s);
+  ProfScope p(TSDE_KID_STEP_GENERAL, s, true);
   TSDE_DISPATCH(dtype, "tsde_step_general",
                 tsde::launch_step_general<float>(y1, y0, f, g, B, d, m, ca, cf, cg, weight_mode, cw, cu, rdt, noise, s),
                 tsde::launch_step_general<double>(y1, y0, f, g, B, d, m, ca, cf, cg, weight_mode, cw, cu, rdt, noise,
@@ -211,7 +226,7 @@ int tsde_milstein_diag(void* y1, const void* y0, const void* f, const void* g, c
                        const tsde_noise_t* noise, int dtype, void* stream) {
   if (!y1 || !y0 || !f || !g || !gdg || !noise) return bad_arg("tsde_milstein_diag", "null argument");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_MILSTEIN_DIAG, s);
+  ProfScope p(TSDE_KID_MILSTEIN_DIAG, s, true);
   TSDE_DISPATCH(dtype, "tsde_milstein_diag", tsde::launch_milstein_diag<float>(y1, y0, f, g, gdg, n, dt, noise, s),
                 tsde::launch_milstein_diag<double>(y1, y0, f, g, gdg, n, dt, noise, s));
 }
@@ -229,7 +244,7 @@ int tsde_milstein_gf_diag(void* y1, const void* y0, const void* f, const void* g
                           double dt, double sqrt_dt, int ito, const tsde_noise_t* noise, int dtype, void* stream) {
   if (!y1 || !y0 || !f || !g || !gprime || !noise) return bad_arg("tsde_milstein_gf_diag", "null argument");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_MILSTEIN_DIAG, s);
+  ProfScope p(TSDE_KID_MILSTEIN_DIAG, s, true);
   TSDE_DISPATCH(dtype, "tsde_milstein_gf_diag",
                 tsde::launch_milstein_gf_diag<float>(y1, y0, f, g, gprime, n, dt, sqrt_dt, ito, noise, s),
                 tsde::launch_milstein_gf_diag<double>(y1, y0, f, g, gprime, n, dt, sqrt_dt, ito, noise, s));
@@ -245,7 +260,7 @@ int tsde_srk_diag_stage(int stage, void* const out[3], const void* const in[5], 
   for (int j = 0; j < n_out[stage]; ++j)
     if (!out[j]) return bad_arg("tsde_srk_diag_stage", "missing output pointer (stage 1: 3, 2: 3, 3: 2, 4: 1 outputs)");
   const hipStream_t s = (hipStream_t)stream;
-  ProfScope p(TSDE_KID_SRK_STAGE, s);
+  ProfScope p(TSDE_KID_SRK_STAGE, s, true);
   TSDE_DISPATCH(dtype, "tsde_srk_diag_stage",
                 tsde::launch_srk_stage<float>(stage, out, in, n, dt, rdt, sqrt_dt, noise, s),
                 tsde::launch_srk_stage<double>(stage, out, in, n, dt, rdt, sqrt_dt, noise, s));
@@ -264,6 +279,7 @@ int tsde_milstein_gf_general_correction(void* corr, const void* g, const void* g
                                         int64_t m, double sqrt_dt, int dtype, void* stream) {
   if (!corr || !g || !gk || !I) return bad_arg("tsde_milstein_gf_general_correction", "null argument");
   const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_MILSTEIN_GF_GENERAL, s, true);
   TSDE_DISPATCH(dtype, "tsde_milstein_gf_general_correction",
                 tsde::launch_milstein_gf_general_correction<float>(corr, g, gk, I, B, d, m, sqrt_dt, s),
                 tsde::launch_milstein_gf_general_correction<double>(corr, g, gk, I, B, d, m, sqrt_dt, s));
@@ -351,7 +367,7 @@ int tsde_aug_update(const tsde_seg_t* segs, int nseg, double cF, double cG, int 
   for (int i = 0; i < nseg; ++i) {
     if (segs[i].n > 0 && (!segs[i].out || !segs[i].s)) return bad_arg("tsde_aug_update", "segment without state");
   }
-  ProfScope p(TSDE_KID_AUG_UPDATE, s);
+  ProfScope p(TSDE_KID_AUG_UPDATE, s, true);
   if (dtype == TSDE_F32) return fail(tsde::launch_aug_segments<float>(segs, nseg, cF, cG, s), "tsde_aug_update");
   return fail(tsde::launch_aug_segments<double>(segs, nseg, cF, cG, s), "tsde_aug_update");
 }
@@ -661,6 +677,18 @@ int tsde_prof_bracket_overhead(int n, double spin_us, double* overhead_ms, void*
   (void)hipFree(measured);
   *overhead_ms = sum / n;
   return fail(r, "tsde_prof_bracket_overhead");
+}
+
+int tsde_prof_read(double* ms, int capacity, int* used) {
+  hipError_t r = hipSuccess;
+  if (used) *used = g_prof.used < capacity ? g_prof.used : capacity;
+  for (int i = 0; i < g_prof.used && i < capacity && r == hipSuccess; ++i) {
+    r = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+    float t = 0.f;
+    if (r == hipSuccess) r = hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    ms[i] = t;
+  }
+  return fail(r, "tsde_prof_read");
 }
 
 int tsde_prof_end(double* total_ms, int64_t* launches) {

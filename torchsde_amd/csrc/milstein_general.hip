@@ -146,12 +146,12 @@ hipError_t launch_milstein_gf_general_correction(void* corr, const void* g, cons
   if (fast && (nc == 1 || nc == 2 || nc == 4)) {
     int64_t blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);   // one wave per row; B/4 blocks, uncapped below 2^20
     if (blocks > (1 << 20)) blocks = 1 << 20;
-    if (nc == 1) hipLaunchKernelGGL((gf_correction_rows_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
-    else if (nc == 2) hipLaunchKernelGGL((gf_correction_rows_kernel<T, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((gf_correction_rows_kernel<T, 4>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    if (nc == 1) TSDE_LAUNCH((gf_correction_rows_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    else if (nc == 2) TSDE_LAUNCH((gf_correction_rows_kernel<T, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    else TSDE_LAUNCH((gf_correction_rows_kernel<T, 4>), dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(gf_correction_generic_kernel<T>, dim3(grid_for(B * d)), dim3(kBlock), 0, s, a);
+  TSDE_LAUNCH(gf_correction_generic_kernel<T>, dim3(grid_for(B * d)), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

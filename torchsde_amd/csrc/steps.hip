@@ -674,7 +674,7 @@ hipError_t launch_aug_segments(const tsde_seg_t* segs, int nseg, double cF, doub
     if (tb.nseg == 0) break;
     const int total = tb.chunk_begin[tb.nseg];
     const int grid = total < kMaxGrid ? total : kMaxGrid;
-    hipLaunchKernelGGL(aug_multi_kernel<T>, dim3(grid), dim3(kBlock), 0, s, tb);
+    TSDE_LAUNCH(aug_multi_kernel<T>, dim3(grid), dim3(kBlock), 0, s, tb);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -720,9 +720,9 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
     int64_t blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);   // one wave per row
     if (blocks > kMaxGrid) blocks = kMaxGrid;
     a.rows_per_tile = 0;
-    if (nc == 1) hipLaunchKernelGGL((general_rows_kernel<T, 1>), dim3((int)blocks), dim3(kBlock), 0, s, a);
-    else if (nc == 2) hipLaunchKernelGGL((general_rows_kernel<T, 2>), dim3((int)blocks), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((general_rows_kernel<T, 4>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    if (nc == 1) TSDE_LAUNCH((general_rows_kernel<T, 1>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    else if (nc == 2) TSDE_LAUNCH((general_rows_kernel<T, 2>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    else TSDE_LAUNCH((general_rows_kernel<T, 4>), dim3((int)blocks), dim3(kBlock), 0, s, a);
     return hipGetLastError();
   }
   if (fast) {
@@ -731,7 +731,7 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
     int64_t blocks = (spans + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks > kMaxGrid) blocks = kMaxGrid;
     a.rows_per_tile = 0;
-    hipLaunchKernelGGL(general_fast_kernel<T>, dim3((int)blocks), dim3(kBlock), 0, s, a);
+    TSDE_LAUNCH(general_fast_kernel<T>, dim3((int)blocks), dim3(kBlock), 0, s, a);
     return hipGetLastError();
   }
   // generic path: rows per tile bounded by the LDS staging buffer
@@ -742,7 +742,7 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   a.rows_per_tile = (int)rows;
   const int64_t n_tiles = (B + rows - 1) / rows;
   const int grid = (int)(n_tiles < kMaxGrid ? n_tiles : kMaxGrid);
-  hipLaunchKernelGGL(general_generic_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
+  TSDE_LAUNCH(general_generic_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

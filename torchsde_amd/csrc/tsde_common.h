@@ -1,6 +1,7 @@
 // Shared launch plumbing for the gfx950 kernels: 16-byte packs, grid sizing, noise sources.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -10,6 +11,29 @@
 #include "tsde_rng.h"
 
 namespace tsde {
+
+// Per-dispatch timing for bench.py's roofline (tsde_prof_begin / _end in capi.hip): when a C-ABI entry point has armed
+// a pair of events, the next kernel launch is issued with hipExtLaunchKernelGGL, which binds the events to THAT dispatch
+// -- their elapsed time is the dispatch's own start-to-end interval, what rocprofv3's kernel trace reports, without
+// the marker packets (and their ~2.5 us) that hipEventRecord calls around a launch put on the stream.
+struct LaunchTiming {
+  hipEvent_t start, stop;
+  bool armed;
+};
+inline LaunchTiming& launch_timing() {
+  static thread_local LaunchTiming t{nullptr, nullptr, false};
+  return t;
+}
+#define TSDE_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                   \
+  do {                                                                                                         \
+    ::tsde::LaunchTiming& lt_ = ::tsde::launch_timing();                                                       \
+    if (lt_.armed) {                                                                                           \
+      lt_.armed = false;                                                                                       \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, lt_.start, lt_.stop, 0, __VA_ARGS__);          \
+    } else {                                                                                                   \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                     \
+    }                                                                                                          \
+  } while (0)
 
 constexpr int kBlock = 256;         // 4 waves of 64 lanes
 constexpr int kMaxGrid = 256 * 8;   // 256 CUs x 8 resident blocks; the rest is grid-stride
@@ -225,12 +249,12 @@ inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStrea
   if (vec && use_streaming_variant(n, elem_size)) {
     int64_t blocks = (nq + kBlock - 1) / kBlock;                 // one 16-B group per thread, no grid cap
     if (blocks > (1 << 30)) blocks = 1 << 30;
-    hipLaunchKernelGGL((elementwise_kernel<Op, 1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, op, n, 1);
+    TSDE_LAUNCH((elementwise_kernel<Op, 1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, op, n, 1);
   } else if (vec && nq >= (int64_t)2 * kBlock * kMaxGrid) {
-    hipLaunchKernelGGL((elementwise_kernel<Op, 2, false>), dim3(grid_for((nq + 1) / 2)), dim3(kBlock), 0, stream, op,
+    TSDE_LAUNCH((elementwise_kernel<Op, 2, false>), dim3(grid_for((nq + 1) / 2)), dim3(kBlock), 0, stream, op,
                        n, 1);
   } else {
-    hipLaunchKernelGGL((elementwise_kernel<Op, 1, false>), dim3(grid_for(vec ? nq : n)), dim3(kBlock), 0, stream, op,
+    TSDE_LAUNCH((elementwise_kernel<Op, 1, false>), dim3(grid_for(vec ? nq : n)), dim3(kBlock), 0, stream, op,
                        n, vec ? 1 : 0);
   }
   return hipGetLastError();

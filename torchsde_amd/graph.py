@@ -2,8 +2,9 @@
 
 ``"auto"`` (the drop-in default): the second solve with the same structure on the same SDE object is captured and every
 later one replays the graph -- provided the capture is legal (see the constraints below) AND safe to do silently: the
-first solve runs eagerly under torch's sync-debug mode (drift / diffusion code that synchronises with the host is never
-captured), the Python-side state of the SDE object (plain attributes, tensor identities, `training` flags) is part
+first solve runs eagerly and screened (`run_screened`: code that synchronises with the host, or uses operators other than
+the elementwise / matmul / reduction family, is never captured -- a failed capture cannot be recovered from on this
+stack), the Python-side state of the SDE object (plain attributes, tensor identities, `training` flags) is part
 of the cache key, the captured graph's first replay must reproduce the eager solve it was recorded beside bit for bit,
 very large states stay eager (launch overhead does not matter there and a graph pins a second memory pool), and any
 failure along the way falls back to the eager path without a word. ``True``: capture on first use, warn when
@@ -38,6 +39,7 @@ import gc
 import warnings
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 from .brownian import BrownianInterval
 
@@ -185,23 +187,73 @@ def _same_tensors(xs, ys, exact=True):
     return bool(ok)
 
 
-def run_watching_for_host_syncs(fn):
-    """`fn()` under torch's sync-debug mode: (result, synchronised?). Other warnings raised meanwhile are re-issued."""
+# Operators a drift / diffusion may use and still be recorded silently: what elementwise networks are made of. Anything
+# else (factorisations, FFT plans, sorting, random numbers, custom extension ops ...) MAY be capture-safe, but a capture
+# that fails poisons the HIP context of the whole process on ROCm 7.2 (every later call reports
+# hipErrorStreamCaptureInvalidated), so "auto" only records code it has SEEN to consist of these. (base names of
+# `aten::` operators; in-place and `.out` variants are covered by stripping the trailing underscore / overload.)
+_CAPTURE_SAFE = frozenset("""
+add sub rsub mul div true_divide floor_divide neg abs absolute exp exp2 expm1 log log1p log2 log10 sqrt rsqrt pow square
+reciprocal sin cos tan sinh cosh tanh asin acos atan atan2 asinh acosh atanh sigmoid silu relu relu6 gelu elu selu celu
+leaky_relu prelu softplus hardtanh hardsigmoid hardswish mish log_sigmoid log_sigmoid_forward logit clamp clamp_min
+clamp_max clip minimum maximum fmin fmax where sign sgn floor ceil round trunc frac fmod remainder lerp addcmul addcdiv erf
+erfc erfinv lgamma digamma nan_to_num threshold softshrink hardshrink logical_and logical_or logical_not logical_xor eq ne lt
+le gt ge isnan isinf isfinite isneginf isposinf bitwise_and bitwise_or bitwise_xor bitwise_not heaviside hypot xlogy
+copy fill zero _to_copy to type_as positive conj real imag
+empty empty_like empty_strided zeros zeros_like ones ones_like full full_like new_empty new_zeros new_ones new_full
+new_empty_strided arange linspace scalar_tensor lift_fresh lift clone contiguous detach alias eye
+view _unsafe_view reshape _reshape_alias expand expand_as permute transpose t squeeze unsqueeze slice select narrow split
+split_with_sizes chunk unbind unfold as_strided diagonal flatten unflatten view_as movedim swapaxes swapdims numpy_T mT mH
+unsafe_split unsafe_chunk unsafe_split_with_sizes tensor_split hsplit vsplit
+mm bmm addmm baddbmm matmul linear mv addmv dot vdot outer ger addr addbmm einsum tensordot bilinear _addmm_activation
+sum mean prod amax amin max min norm linalg_vector_norm var std var_mean std_mean logsumexp softmax _softmax log_softmax
+_log_softmax cumsum cumprod logcumsumexp argmax argmin all any count_nonzero nansum nanmean
+cat concat concatenate stack hstack vstack repeat tile flip roll index_select gather scatter scatter_add scatter_reduce
+index_add index_copy index_fill masked_fill diag_embed tril triu diag broadcast_to broadcast_tensors expand_copy constant_pad_nd pad
+layer_norm native_layer_norm group_norm native_group_norm rms_norm _fused_rms_norm
+softmax_backward_data _softmax_backward_data tanh_backward sigmoid_backward softplus_backward silu_backward gelu_backward
+elu_backward threshold_backward leaky_relu_backward hardtanh_backward native_layer_norm_backward sum_to_size
+""".split())
+
+
+class _OperatorRecorder(TorchDispatchMode):
+    """Notes every operator that runs under it which is not in `_CAPTURE_SAFE`."""
+
+    def __init__(self):
+        super().__init__()
+        self.unknown = set()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = getattr(getattr(func, "_schema", None), "name", str(func))
+        namespace, _, base = name.partition("::")
+        if namespace != "aten" or (base.rstrip("_") not in _CAPTURE_SAFE and base not in _CAPTURE_SAFE):
+            self.unknown.add(name)
+        return func(*args, **(kwargs or {}))
+
+
+def run_screened(fn):
+    """`fn()` -- the launch-only part of an eager solve -- watched for everything that would make recording it unsafe:
+    host synchronisation (torch's sync-debug mode) and operators outside `_CAPTURE_SAFE` (a dispatch-mode recorder).
+    Returns (result, reason): `reason` is None if the code may be recorded. Other warnings raised meanwhile are re-issued."""
     previous = torch.cuda.get_sync_debug_mode()
+    recorder = _OperatorRecorder()
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         torch.cuda.set_sync_debug_mode("warn")
         try:
-            result = fn()
+            with recorder:
+                result = fn()
         finally:
             torch.cuda.set_sync_debug_mode(previous)
-    synced = False
+    reason = None
     for w in caught:
         if "synchronizing" in str(w.message):
-            synced = True
+            reason = "the code synchronises with the host"
         else:
             warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
-    return result, synced
+    if reason is None and recorder.unknown:
+        reason = "operators that are not known to be capture-safe: " + ", ".join(sorted(recorder.unknown)[:6])
+    return result, reason
 
 
 def _auto_eligible(bm, y0, n_out):
@@ -243,8 +295,8 @@ def auto_solve(solver, y0, ts, extra0=()):
         # first solve of this structure: eager, and watched -- code that synchronises with the host cannot be captured
         plan = solver._plan(y0, ts)
         solver._extra = tuple(extra0)
-        ys, synced = run_watching_for_host_syncs(lambda: solver._run(plan, y0))
-        _remember(cache, sig, _Refused("drift / diffusion synchronise with the host") if synced else _Seen())
+        ys, reason = run_screened(lambda: solver._run(plan, y0))
+        _remember(cache, sig, _Seen() if reason is None else _Refused(reason))
         return ys, solver._extra
     if isinstance(entry, _Refused):
         return None
@@ -315,6 +367,20 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
     return keep
 
 
+@contextlib.contextmanager
+def _capturing(graph, device, **kwargs):
+    """`torch.cuda.graph(graph, capture_error_mode="thread_local")` with the cyclic GC paused -- and the caller's stream
+    restored when the capture fails: `torch.cuda.graph.__exit__` raises from `capture_end()` BEFORE it leaves its stream
+    context, which would leave every later launch of the process on the dead capture stream."""
+    previous = torch.cuda.current_stream(device)
+    try:
+        with _no_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local", **kwargs):
+            yield
+    except BaseException:
+        torch.cuda.set_stream(previous)
+        raise
+
+
 class _CapturedSolve:
     exact_outputs = True
 
@@ -349,7 +415,7 @@ class _CapturedSolve:
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: API calls from other threads (e.g. the RCCL watchdog of a multi-GPU run) must not
             # invalidate this capture
-            with _no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with _capturing(self.graph, device):
                 solver._extra = tuple(self.extra_in)
                 self.ys = solver._run(self.plan, self.y_in)
                 self.extra_out = tuple(solver._extra)
@@ -459,7 +525,7 @@ class _CapturedBackward:
             if not verify:
                 del warm
             self.graph = torch.cuda.CUDAGraph()
-            with _no_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with _capturing(self.graph, device):
                 self.out = list(run(*self.static))
             if verify:          # "auto": a replay on the same inputs must give the eager sweep's gradients
                 self._load(bm, inputs)
@@ -485,7 +551,8 @@ def cached_backward(sde, bm, signature, capture, auto=False):
     (and may return None: then nothing is cached and the backward pass runs eagerly).
     `signature` identifies the sweep's structure; the Brownian structure is appended here.
     `auto`: the "auto" rules of this module -- returns (graph or None, watch) where `watch`, if not None, is a callable
-    the eager backward pass must report to (`watch(synchronised)`) so that the NEXT call knows whether to capture."""
+    the eager backward pass must report to (`watch(reason or None)`, see `run_screened`) so that the NEXT call knows
+    whether to capture."""
     if bm._rootW is not None or bm._rootH is not None:
         if not auto:
             warnings.warn("hip_graph=True needs a torchsde_amd.BrownianInterval without pinned W/H; running eagerly.")
@@ -510,8 +577,8 @@ def cached_backward(sde, bm, signature, capture, auto=False):
     entry = cache.get(sig)
     if entry is None:            # first sweep of this structure: eager, watched by `backward`
 
-        def watch(synced):
-            _remember(cache, sig, _Refused("the backward sweep synchronises with the host") if synced else _Seen())
+        def watch(reason):
+            _remember(cache, sig, _Seen() if reason is None else _Refused("backward sweep: " + reason))
         return None, watch
     if isinstance(entry, _Refused):
         return None, None
@@ -583,11 +650,10 @@ class _CapturedTrainingSolve:
                     del outs
                 torch.cuda.current_stream(device).wait_stream(side)
                 self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with _no_gc(), torch.cuda.graph(self.fwd_graph, capture_error_mode="thread_local"):
+                with _capturing(self.fwd_graph, device):
                     self.outs = forward()
                 self.cotangents = [torch.zeros_like(o) for o in self.outs]
-                with _no_gc(), torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(),
-                                                capture_error_mode="thread_local"):
+                with _capturing(self.bwd_graph, device, pool=self.fwd_graph.pool()):
                     self.grads = backward(self.outs, self.cotangents)
         finally:
             bm._entropy_dev = None

@@ -909,6 +909,14 @@ def prof_bracket_overhead(n=100, spin_us=12.0, device=None):
     return ms.value
 
 
+def prof_read(capacity):
+    """The per-launch times (ms) of the running profile, in launch order (at most `capacity`)."""
+    arr = (ctypes.c_double * capacity)()
+    used = ctypes.c_int(0)
+    _native.check(_native.load().tsde_prof_read(arr, capacity, ctypes.byref(used)), "tsde_prof_read")
+    return list(arr[:used.value])
+
+
 def prof_end():
     ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
     _native.check(_native.load().tsde_prof_end(ctypes.byref(ms), ctypes.byref(n)), "tsde_prof_end")
