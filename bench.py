@@ -23,8 +23,8 @@ Prints ONE JSON line (rank 0):
   between the solves of the same timed region);
 * `roofline`: two fractions of the 8 TB/s HBM peak, named for what they are --
     `frac`        KERNEL level: the dominant kernel's SURVEY-8d algorithmic bytes per solver step / the duration of its
-                  launches inside a solve, measured live with HIP events bound to each DISPATCH (hipExtLaunchKernel on
-                  the launch stream: the kernel's own start-to-end interval, as a rocprofv3 kernel trace reports it);
+                  launches, measured live with HIP events around the replay of a HIP graph of 200 launches on live,
+                  rotating operands (agrees with the rocprofv3 kernel trace of the solve under profiles/);
     `solve_frac`  SOLVE level: algorithmic bytes per trajectory-step x `value` / (N x 8e12), i.e.
                   with the user's f and g torch kernels and every launch gap inside;
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes, tools/profile_traffic.sh) and `kernel_us_rocprofv3` are
@@ -208,6 +208,13 @@ class Job:
                 return self.gathered
             return ys[-1]
 
+    def live_state(self, out):
+        """A state tensor of this workload's shape with live values: the solve's final state where `out` is one."""
+        B, d = self.cfg["B"], self.cfg["d"]
+        if not (self.adjoint or self.train) and out.dim() == 2 and out.shape[1] == d and out.shape[0] >= B:
+            return out[:B].detach()
+        return self.y0.detach()
+
     # ---- dominant kernel -----------------------------------------------------------------------------------------
     def bracket_dominant_kernel(self):
         """Trajectory kernels only (one launch of milliseconds per solve, so the ~2.5 us of marker latency a bracket adds
@@ -222,33 +229,94 @@ class Job:
         torch.cuda.synchronize()
         return K.prof_end()
 
-    def dispatch_us(self):
-        """THE kernel-level timing of every stepwise workload: each launch of the dominant kernel in ONE eagerly issued
-        solve, timed PER DISPATCH -- the library issues those launches with hipExtLaunchKernel, which binds a pair of
-        events to the dispatch itself (tsde_prof_begin, csrc/tsde_common.h TSDE_LAUNCH), so a launch's time is its own
-        start-to-end interval as the packet processor stamps it: what a rocprofv3 kernel trace of this command reports,
-        with no marker packets on the stream (a hipEventRecord bracket adds ~2.5 us to a 6 us kernel) -- and in situ: the
-        kernel reads operands the SDE's own f and g kernels have just written (constant operands stay partly resident in
-        the per-XCD L2 at shard sizes: a back-to-back loop shows 4.1 us where the solve's kernel takes 6.6). The stream
-        is parked behind a delay kernel while the host enqueues the solve, so no kernel starts on an idle queue.
-        Returns {label: us per launch} (one entry, or the four SRK stages)."""
+    def back_to_back_us(self, live_state):
+        """THE kernel-level timing of every stepwise workload: 200 launches of the dominant kernel recorded into ONE HIP
+        graph (the launch regime of the timed region) and replayed between one pair of HIP events on the replay's stream
+        -- no marker packets between launches, no host launch rate in the figure. The operands are live (a solve's
+        last state, the SDE's f and g there) and ROTATE over enough distinct copies that a launch never finds its inputs in
+        the per-XCD L2 from the launch before (a loop over constant f, g shows 4.1 us = "103 % of the HBM peak" at the
+        8 MiB-per-stream shard size where the solve's kernel takes 6.7 us; with the rotation the figure agrees with the
+        rocprofv3 kernel trace of the solve, profiles/). Returns {label: us per launch} (one entry, or the four SRK
+        stages), each the best of three replays."""
         from torchsde_amd import kernels as K
-        c = self.cfg
-        per_step = c["launches_per_step"]
-        capacity = c["nsteps"] * per_step + 8
-        self.solve(4999, graph=False)          # (lazy initialisation of the eager path out of the way)
-        torch.cuda.synchronize()
-        K.prof_begin(c["kid"], capacity)
-        K.gpu_delay(min(2.0e6, 40.0 * c["nsteps"] * (2 + per_step)), self.dev)
-        self.solve(5000, graph=False)
-        torch.cuda.synchronize()
-        times = K.prof_read(capacity)
-        K.prof_end()
-        if not times:
-            return None
-        if c["kid"] == 4:
-            return {f"tsde_srk_diag_stage {k + 1}": 1e3 * statistics.mean(times[k::4]) for k in range(4)}
-        return {c["kernel"].split(" ")[0]: 1e3 * statistics.mean(times)}
+        from torchsde_amd.kernels import NoiseSpec
+        c, dev, sde = self.cfg, self.dev, self.sde
+        B, d, m, dt, kid = c["B"], c["d"], c["m"], float(c["dt"]), c["kid"]
+        n = 200
+        y = live_state[:B].detach().clone().contiguous()
+        t0 = self.ts[0]
+        spec = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(n)]
+        with torch.no_grad():
+            f, g = (None, None) if kid == 5 else (sde.f(t0, y).contiguous(), sde.g(t0, y).contiguous())
+
+        def copies(*tensors):
+            """Enough distinct copies of an operand set that the rotation's working set is >= 128 MiB (4x the L2s)."""
+            nbytes = sum(t.numel() * t.element_size() for t in tensors)
+            k = max(2, min(32, -(-(128 << 20) // max(nbytes, 1))))
+            return [tuple(t.clone() for t in tensors) for _ in range(k)]
+
+        if kid == 1:
+            sets = copies(y, f, g)
+            coefs = [(dt, 1.0)] if c["launches_per_step"] == 1 else [(0.5 * dt, 0.5), (dt, 1.0)]   # midpoint: two stages
+
+            def launch(i):
+                (ya, fa, ga), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
+                cf, cg = coefs[i % len(coefs)]
+                K._raw_step_diag(ya, fa, ga, cf, cg, spec[i], yb)
+            return {"tsde_step_diag": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+        if kid == 2:
+            sets = copies(y, f, g)
+
+            def launch(i):
+                (ya, fa, ga), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
+                K._raw_step_general(ya, fa, ga, dt, 1.0, spec[i], yb)
+            return {"tsde_step_general": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+        if kid == 3:
+            sets = copies(y, f, g, (g * f * dt).contiguous())
+
+            def launch(i):
+                (ya, fa, ga, da), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
+                K._raw_milstein_diag(ya, fa, ga, da, dt, spec[i], yb)
+            return {"tsde_milstein_diag": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+        if kid == 4:
+            rdt, sqrt_dt = 1.0 / dt, dt ** 0.5
+            with torch.no_grad():      # one real step's intermediates as the later stages' operands
+                _, acc, p13 = K.srk_diag_stage(2, (y, f, g, f.clone(), g.clone()), dt, rdt, sqrt_dt, spec[0])
+            # y0, f0, g0, f1, g1, f2, g2, g3, acc, P: ten operands per step
+            sets = copies(y, f, g, f, g, f, g, g, acc, p13)
+
+            def stage(k, i):
+                y0, f0, g0, f1, g1, f2, g2, g3, ac, p = sets[i % len(sets)]
+                if k == 1:
+                    return lambda: K.srk_diag_stage(1, (y0, f0, g0), dt, rdt, sqrt_dt, spec[i])
+                if k == 2:
+                    return lambda: K.srk_diag_stage(2, (y0, f0, g0, f1, g1), dt, rdt, sqrt_dt, spec[i])
+                if k == 3:
+                    return lambda: K.srk_diag_stage(3, (p, ac, f2, g2), dt, rdt, sqrt_dt, spec[i])
+                return lambda: K.srk_diag_stage(4, (ac, g3), dt, rdt, sqrt_dt, spec[i], out_last=y0)
+            return {f"tsde_srk_diag_stage {k}": _graph_replay_us([stage(k, i) for i in range(n)], dev) for k in (1, 2, 3, 4)}
+        if kid == 11:
+            integrals = torch.randn(B, m, m, device=dev) * dt
+            with torch.no_grad():
+                support = K.milstein_gf_general_support(y, f, g, dt, dt ** 0.5, True)
+                gk = sde.g(t0, support.reshape(m * B, d)).reshape(m, B, d, m).contiguous()
+            sets = copies(g, gk, integrals)
+            return {"tsde_milstein_gf_general_correction": _graph_replay_us(
+                [(lambda i=i: K.milstein_gf_general_correction(*sets[i % len(sets)], dt ** 0.5)) for i in range(50)], dev)}
+        if kid == 5:
+            params = [p for p in sde.parameters() if p.requires_grad]
+            base = [torch.rand(B, d, device=dev) for _ in range(2)] + [torch.randn(B, d, device=dev) for _ in range(4)]
+            sets = copies(*base)
+            pst = [[torch.zeros_like(p), torch.zeros_like(p), torch.randn_like(p), torch.randn_like(p)] for p in params]
+
+            def launch(i):
+                ya, aa, t0_, t1_, t2_, t3_ = sets[i % len(sets)]
+                yb, ab = sets[(i + 1) % len(sets)][:2]
+                segs = [dict(out=yb, s=ya, F=t0_, G=t1_, sF=-1.0, sG=-1.0), dict(out=ab, s=aa, F=t2_, G=t3_)]
+                segs += [dict(out=q[(i + 1) & 1], s=q[i & 1], F=q[2], G=q[3]) for q in pst]
+                K.aug_update(segs, dt, 1.0, torch.float32, dev)
+            return {"tsde_aug_update": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+        return None
 
     def roofline(self, value, k_ms, k_launches):
         """The `roofline` object of a trajectory-kernel workload given its trajectory-steps/s and kernel brackets."""
@@ -298,8 +366,8 @@ class Job:
         solve_achieved = contract * value / self.world / 1e9
         roof = {"bound": "hbm", "kernel": c["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "frac_is": "KERNEL level: SURVEY 8d algorithmic bytes of one solver step (all rows) / the summed dispatch "
-                           "durations of the step's launches of the dominant kernel inside a solve",
+                "frac_is": "KERNEL level: SURVEY 8d algorithmic bytes of one solver step (all rows) / the summed durations "
+                           "of the step's launches of the dominant kernel",
                 "solve_achieved": solve_achieved, "solve_frac": solve_achieved / HBM_PEAK_GBPS,
                 "solve_frac_is": "SOLVE level (SURVEY 8d): bytes_per_traj_step x value / (n_gpus x peak); includes the "
                                  "user's f, g torch kernels and all launch gaps",
@@ -307,10 +375,9 @@ class Job:
                 "launches_per_step": per_step, "avg_launch_us": step_us / per_step,
                 "launch_us": {k: round(v, 3) for k, v in b2b.items()},
                 "traffic": None,
-                "timing": "per dispatch, in situ: every launch of the kernel in one eagerly issued solve (stream parked "
-                          "while the host enqueues it) issued with hipExtLaunchKernel, whose events are bound to the "
-                          "dispatch itself -- the kernel's own start-to-end interval, as in a rocprofv3 kernel trace; "
-                          "mean over the solve's launches"}
+                "timing": "HIP events around ONE replay of a HIP graph of 200 launches of this kernel on live operands that "
+                          "rotate over >= 128 MiB of distinct copies (no marker packets, no host launch rate, no operand "
+                          "left in L2 by the previous launch); best of 3 replays"}
         if moved != contract:
             roof["bytes_moved_per_traj_step"] = moved
             roof["moved_achieved"] = moved * B / (step_us * 1e-6) / 1e9
@@ -318,6 +385,34 @@ class Job:
             roof["moved_is"] = ("bytes the implementation's kernels stream per trajectory-step (DESIGN.md: 23 streams for "
                                 "SRID2 with user code between the stages vs the 16 of SURVEY 8d)")
         return roof
+
+
+def _graph_replay_us(launches, dev, replays=3):
+    """Average microseconds per launch of `launches` (zero-argument callables, one kernel launch each) recorded into
+    one HIP graph and replayed: best of `replays`, HIP events around the replay on the replay's stream."""
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side), torch.no_grad():
+        for fn in launches[:8]:
+            fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    # thread_local: API calls from other threads (the RCCL watchdog of a multi-GPU run) must not invalidate the capture
+    with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        for fn in launches:
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del graph
+    return best * 1e3 / len(launches)
 
 
 def _attach_offline_traffic(roofline, workload):
@@ -403,7 +498,7 @@ def _side_measurement(dev, name):
         k_ms, k_launches = job.bracket_dominant_kernel()
         roof = job.roofline(value, k_ms, k_launches)
     else:
-        roof = job.roofline_stepwise(value, job.dispatch_us())
+        roof = job.roofline_stepwise(value, job.back_to_back_us(job.live_state(out)))
         _attach_offline_traffic(roof, name)
     if roof is not None:
         for key in ("bound", "achieved", "unit", "frac", "solve_achieved", "solve_frac", "bytes_per_traj_step",
@@ -569,7 +664,7 @@ def main():
         k_ms, k_launches = job.bracket_dominant_kernel()
         roofline = job.roofline(value, k_ms, k_launches)
     else:
-        roofline = job.roofline_stepwise(value, job.dispatch_us())
+        roofline = job.roofline_stepwise(value, job.back_to_back_us(job.live_state(out)))
         _attach_offline_traffic(roofline, args.workload)
 
     also = None

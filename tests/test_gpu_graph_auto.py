@@ -209,3 +209,60 @@ def test_unusable_adjoint_method_only_fails_when_a_backward_pass_can_follow():
     with pytest.raises((ValueError, RuntimeError)):
         torchsde_amd.sdeint_adjoint(sde, y0.clone().requires_grad_(True), ts, bm=_bm(1), method="euler",
                                     adjoint_method="reversible_heun", dt=DT)
+
+
+class _SharedEvaluation(nn.Module):
+    """The diffusion reuses what the drift computed (one network evaluation serves both): correct when the two run in
+    sequence, a race if they were recorded as parallel branches of a graph."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(D, D)
+
+    def f(self, t, y):
+        self.h = torch.tanh(self.lin(y))
+        return -self.h
+
+    def g(self, t, y):
+        return 0.1 * self.h
+
+
+def test_drift_and_diffusion_that_share_memory_stay_in_sequence():
+    from torchsde_amd import graph
+    sde = _SharedEvaluation().to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for entropy in (1, 2, 3, 4):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    (captured,) = _entries(sde, graph._CapturedSolve)
+    assert getattr(captured, "tuning", None) is None            # the parallel form was never tried
+
+
+def test_independent_drift_and_diffusion_may_run_as_parallel_branches():
+    from torchsde_amd import graph
+    sde = problems.make("mlpdiag_ito", d=D).to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for entropy in (1, 2, 3, 4):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    (captured,) = _entries(sde, graph._CapturedSolve)
+    assert captured.tuning["parallel_agrees"] and captured.tuning["kept"] in ("parallel", "sequential")
+
+
+def test_operators_outside_the_known_family_are_never_recorded():
+    """A failed capture aborts the process on this stack (tools/probe_failed_capture.py), so "auto" only records code it
+    has seen to consist of known capture-safe operators; `pinverse` (a factorisation that allocates through the
+    solver library) is not one of them -- the reference's own logqp path for general noise uses it."""
+    import torchsde_amd
+    from torchsde_amd import graph
+
+    class WithPinv(_Scaled):
+        def g(self, t, y):
+            return 0.2 * y + 0.0 * torch.linalg.pinv(torch.eye(D, device=y.device) * 2.0).diagonal()
+
+    sde = WithPinv().to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for entropy in (1, 2, 3):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    assert not _entries(sde, graph._CapturedSolve)
+    (refused,) = _entries(sde, graph._Refused)
+    assert "capture-safe" in refused.reason

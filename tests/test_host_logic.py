@@ -440,3 +440,61 @@ def test_python_state_fingerprint_of_an_sde_object():
     assert graph.mode_of({"hip_graph": False}) is False and graph.mode_of(None) == "auto"
     with pytest.raises(ValueError):
         graph.mode_of({"hip_graph": "yes"})
+
+
+def test_screening_tells_independent_drift_and_diffusion_from_code_that_shares_memory():
+    """hip_graph="auto" may record drift and diffusion as parallel graph branches only if the screened eager run saw them
+    touch disjoint memory (graph._OperatorRecorder, fed by ForwardSDE._f_then_g); and it only records operators it
+    knows to be capture-safe."""
+    from torch import nn
+    from torchsde_amd import graph
+
+    class Shared(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+
+        def f(self, t, y):
+            self.h = torch.tanh(self.lin(y))       # cached for g: one network evaluation serves both
+            return -self.h
+
+        def g(self, t, y):
+            return 0.1 * self.h
+
+    class Scratch(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.buf = torch.zeros(3, 4)
+
+        def f(self, t, y):
+            return torch.mul(y, -0.5, out=self.buf) + 0.0     # both write the same scratch buffer
+
+        def g(self, t, y):
+            return torch.mul(y, 0.2, out=self.buf) + 0.0
+
+    def screen(sde, extra=None):
+        fs = ForwardSDE(sde)
+        rec = graph._OperatorRecorder()
+        graph._RECORDER = rec
+        try:
+            with rec, torch.no_grad():
+                for _ in range(6):
+                    fs.f_and_g(torch.tensor(0.0), torch.ones(3, 4))
+                if extra is not None:
+                    extra()
+        finally:
+            graph._RECORDER = None
+        return rec
+
+    for name in ("mlpdiag_ito", "gbm_ito"):
+        rec = screen(problems.make(name, d=4))
+        assert rec.independent() and not rec.unknown and rec.pairs == 6
+    assert not screen(Shared()).independent()
+    assert not screen(Scratch()).independent()
+    rec = screen(problems.make("gbm_ito", d=4), extra=lambda: torch.linalg.pinv(torch.rand(3, 3)))
+    assert any("pinv" in op or "svd" in op for op in rec.unknown)
+    assert not graph._OperatorRecorder().independent()            # no drift / diffusion pair seen: not independent

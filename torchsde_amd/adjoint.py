@@ -499,8 +499,9 @@ class _SdeintAdjointMethod(torch.autograd.Function):
             run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
             if ctx.watch_backward is not None:
                 from . import graph
-                out, reason = graph.run_screened(lambda: run(*inputs))
-                ctx.watch_backward(reason)
+                verdict = {}
+                out, reason = graph.run_screened(lambda: run(*inputs), verdict)
+                ctx.watch_backward(reason, verdict["independent"])
             else:
                 out = run(*inputs)
         if reversible:      # a_y, (a_f, a_g, a_z), a_theta...
@@ -547,7 +548,8 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
         from .sde import ForwardSDE
         return graph.faster_of_sequential_and_parallel(sde if isinstance(sde, ForwardSDE) else None, capture, ys.device)
 
-    return graph.cached_backward(sde, bm, signature, capture if auto else tuned_capture, auto=auto)
+    return graph.cached_backward(sde, bm, signature, capture if auto else tuned_capture, auto=auto,
+                                 tuned_capture=tuned_capture)
 
 
 def _backward_kind(sde, bm, adjoint_method, adjoint_options, adjoint_params):

@@ -107,7 +107,12 @@ def mode_of(options, key="hip_graph"):
 
 
 class _Seen:
-    """Cache entry of a structure that was solved (eagerly) once: the next solve of it is captured."""
+    """Cache entry of a structure that was solved (eagerly) once: the next solve of it is captured. `independent`: the
+    screened run saw the drift and the diffusion touch disjoint memory, so the capture may try them as parallel
+    branches (and keep that form if it is faster AND reproduces the sequential one)."""
+
+    def __init__(self, independent=False):
+        self.independent = independent
 
 
 class _Refused:
@@ -216,35 +221,101 @@ elu_backward threshold_backward leaky_relu_backward hardtanh_backward native_lay
 """.split())
 
 
+_RECORDER = None      # the recorder of the screened run in progress (sde.ForwardSDE reports its drift / diffusion phases)
+
+
+def _storages(obj, out):
+    """Data pointers of every tensor in a (nested) argument / result structure."""
+    if torch.is_tensor(obj):
+        try:
+            out.add(obj.untyped_storage().data_ptr())
+        except Exception:       # meta / fake tensors: nothing to alias
+            pass
+    elif isinstance(obj, (list, tuple)):
+        for x in obj:
+            _storages(x, out)
+    elif isinstance(obj, dict):
+        for x in obj.values():
+            _storages(x, out)
+
+
 class _OperatorRecorder(TorchDispatchMode):
-    """Notes every operator that runs under it which is not in `_CAPTURE_SAFE`."""
+    """Watches a screened eager run: notes every operator outside `_CAPTURE_SAFE`, and -- for the first few drift /
+    diffusion evaluations, whose phases `sde.ForwardSDE._f_then_g` announces -- which storages each phase reads and
+    writes. Drift and diffusion are INDEPENDENT if neither touches what the other writes (a diffusion that reuses a
+    tensor the drift computed and cached, a shared scratch buffer ...): only then may they be recorded as parallel
+    branches of a graph. Results of a tracked pair are kept alive until the pair ends, so that the allocator cannot hand
+    the drift's freed temporaries to the diffusion and fake a dependence."""
+
+    TRACKED_PAIRS = 4
 
     def __init__(self):
         super().__init__()
         self.unknown = set()
+        self.phase = None
+        self.pairs = 0
+        self.shared = False
+        self.touched = {"f": set(), "g": set()}
+        self.written = {"f": set(), "g": set()}
+        self.keep = []
+
+    def enter_phase(self, phase):
+        """phase: "f", "g" or None (the pair is over: it is judged by itself, and its tensors are let go)."""
+        if phase is None:
+            if (self.written["f"] & self.touched["g"]) or (self.written["g"] & self.touched["f"]):
+                self.shared = True
+            for table in (self.touched, self.written):
+                table["f"].clear()
+                table["g"].clear()
+            self.keep.clear()
+            self.pairs += 1
+        self.phase = phase if self.pairs < self.TRACKED_PAIRS else None
+
+    def independent(self):
+        """Did at least one drift / diffusion pair run, and none with a storage written by one and touched by the other?"""
+        return self.pairs > 0 and not self.shared
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = getattr(getattr(func, "_schema", None), "name", str(func))
         namespace, _, base = name.partition("::")
         if namespace != "aten" or (base.rstrip("_") not in _CAPTURE_SAFE and base not in _CAPTURE_SAFE):
             self.unknown.add(name)
-        return func(*args, **(kwargs or {}))
+        result = func(*args, **(kwargs or {}))
+        phase = self.phase
+        if phase is not None:
+            ins, outs = set(), set()
+            _storages(args, ins)
+            _storages(kwargs, ins)
+            _storages(result, outs)
+            self.touched[phase] |= ins | outs
+            # what an operator returns it has written (fresh memory, or an input it modified in place / through out=);
+            # views alias their base, which then counts as written too: conservative, never the other way
+            self.written[phase] |= outs
+            self.keep.append(result)
+        return result
 
 
-def run_screened(fn):
+def run_screened(fn, verdict=None):
     """`fn()` -- the launch-only part of an eager solve -- watched for everything that would make recording it unsafe:
     host synchronisation (torch's sync-debug mode) and operators outside `_CAPTURE_SAFE` (a dispatch-mode recorder).
-    Returns (result, reason): `reason` is None if the code may be recorded. Other warnings raised meanwhile are re-issued."""
+    Returns (result, reason): `reason` is None if the code may be recorded. Other warnings raised meanwhile are re-issued.
+    `verdict`: a dict that receives `independent` (may drift and diffusion be recorded as parallel branches?)."""
+    global _RECORDER
     previous = torch.cuda.get_sync_debug_mode()
     recorder = _OperatorRecorder()
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
         torch.cuda.set_sync_debug_mode("warn")
+        _RECORDER = recorder
         try:
             with recorder:
                 result = fn()
         finally:
+            _RECORDER = None
             torch.cuda.set_sync_debug_mode(previous)
+    if verdict is not None:
+        verdict["independent"] = recorder.independent()
+    recorder.keep.clear()
     reason = None
     for w in caught:
         if "synchronizing" in str(w.message):
@@ -295,16 +366,22 @@ def auto_solve(solver, y0, ts, extra0=()):
         # first solve of this structure: eager, and watched -- code that synchronises with the host cannot be captured
         plan = solver._plan(y0, ts)
         solver._extra = tuple(extra0)
-        ys, reason = run_screened(lambda: solver._run(plan, y0))
-        _remember(cache, sig, _Seen() if reason is None else _Refused(reason))
+        verdict = {}
+        ys, reason = run_screened(lambda: solver._run(plan, y0), verdict)
+        _remember(cache, sig, _Seen(verdict["independent"]) if reason is None else _Refused(reason))
         return ys, solver._extra
     if isinstance(entry, _Refused):
         return None
     if isinstance(entry, _Seen):
         try:
-            with _drift_then_diffusion(solver.sde):
-                captured = _CapturedSolve(solver, y0, ts, extra0, verify=True)
-        except Exception as e:     # capture-unsafe user code, out of memory for the second pool, ...: stay eager
+            if entry.independent:
+                captured = faster_of_sequential_and_parallel(
+                    solver.sde if hasattr(solver.sde, "_f_then_g") else None,
+                    lambda: _CapturedSolve(solver, y0, ts, extra0, verify=True), y0.device)
+            else:
+                with _drift_then_diffusion(solver.sde):
+                    captured = _CapturedSolve(solver, y0, ts, extra0, verify=True)
+        except Exception as e:     # (a Python-level failure inside the recording; out of memory for the second pool)
             cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")
             solver._extra = tuple(extra0)
             return None
@@ -344,13 +421,13 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
     try:
         forward_sde.overlap_f_g = False
         sequential = capture()
-        if sequential is None:
-            return None
+        if sequential is None or getattr(sequential, "verified", True) is False:
+            return sequential
         forward_sde.overlap_f_g = True
         parallel = capture()
     finally:
         forward_sde.overlap_f_g = True
-    if parallel is None:
+    if parallel is None or getattr(parallel, "verified", True) is False:
         return sequential
     t_seq, t_par = _replay_ms(sequential.graph, device), _replay_ms(parallel.graph, device)
     # the parallel form is only an option if it computes the same thing: drift and diffusion code that shares buffers,
@@ -546,11 +623,13 @@ class _CapturedBackward:
         return [o.clone() for o in self.out]
 
 
-def cached_backward(sde, bm, signature, capture, auto=False):
+def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None):
     """The cached HIP graph of the adjoint's backward sweep for this structure; `capture()` builds it on a miss
     (and may return None: then nothing is cached and the backward pass runs eagerly).
     `signature` identifies the sweep's structure; the Brownian structure is appended here.
-    `auto`: the "auto" rules of this module -- returns (graph or None, watch) where `watch`, if not None, is a callable
+    `auto`: the "auto" rules of this module (`tuned_capture`: the variant that also tries drift and diffusion as
+    parallel branches, used when the screened sweep found them independent) -- returns (graph or None, watch) where
+    `watch`, if not None, is a callable
     the eager backward pass must report to (`watch(reason or None)`, see `run_screened`) so that the NEXT call knows
     whether to capture."""
     if bm._rootW is not None or bm._rootH is not None:
@@ -577,15 +656,18 @@ def cached_backward(sde, bm, signature, capture, auto=False):
     entry = cache.get(sig)
     if entry is None:            # first sweep of this structure: eager, watched by `backward`
 
-        def watch(reason):
-            _remember(cache, sig, _Seen() if reason is None else _Refused("backward sweep: " + reason))
+        def watch(reason, independent=False):
+            _remember(cache, sig, _Seen(independent) if reason is None else _Refused("backward sweep: " + reason))
         return None, watch
     if isinstance(entry, _Refused):
         return None, None
     if isinstance(entry, _Seen):
         try:
-            with _drift_then_diffusion(sde):
-                captured = capture()
+            if entry.independent and tuned_capture is not None:
+                captured = tuned_capture()
+            else:
+                with _drift_then_diffusion(sde):
+                    captured = capture()
         except Exception as e:
             captured = None
             cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")

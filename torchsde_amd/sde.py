@@ -121,7 +121,20 @@ class ForwardSDE(BaseSDE):
     def _f_then_g(self, t, y):
         if self.overlap_f_g and y.is_cuda and torch.cuda.is_current_stream_capturing():
             return self._f_beside_g(t, y)
-        return self.f(t, y), self.g(t, y)
+        from . import graph
+        recorder = graph._RECORDER
+        if recorder is None:
+            return self.f(t, y), self.g(t, y)
+        # a screened eager solve (hip_graph="auto"): tell the recorder which of the two is running, so that it can
+        # tell whether they share memory (only independent drift and diffusion may become parallel graph branches)
+        try:
+            recorder.enter_phase("f")
+            f = self.f(t, y)
+            recorder.enter_phase("g")
+            g = self.g(t, y)
+        finally:
+            recorder.enter_phase(None)
+        return f, g
 
     # While a solve is being captured into a HIP graph (options={"hip_graph": True}) the user's drift and diffusion are
     # recorded as two PARALLEL branches of the graph instead of one after the other: both only read (t, y), and each
