@@ -250,16 +250,16 @@ def test_independent_drift_and_diffusion_may_run_as_parallel_branches():
 
 def test_operators_outside_the_known_family_are_never_recorded():
     """A failed capture aborts the process on this stack (tools/probe_failed_capture.py), so "auto" only records code it
-    has seen to consist of known capture-safe operators; `pinverse` (a factorisation that allocates through the
-    solver library) is not one of them -- the reference's own logqp path for general noise uses it."""
+    has seen to consist of known capture-safe operators (`pinverse`, which the reference's own logqp path for general
+    noise calls, both synchronises and allocates through the solver library; here: a sort)."""
     import torchsde_amd
     from torchsde_amd import graph
 
-    class WithPinv(_Scaled):
+    class WithSort(_Scaled):
         def g(self, t, y):
-            return 0.2 * y + 0.0 * torch.linalg.pinv(torch.eye(D, device=y.device) * 2.0).diagonal()
+            return 0.2 * y + 0.0 * torch.sort(y, dim=1).values      # (no host sync, but not an operator "auto" knows)
 
-    sde = WithPinv().to(DEV)
+    sde = WithSort().to(DEV)
     y0 = torch.full((B, D), 0.1, device=DEV)
     for entropy in (1, 2, 3):
         assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
