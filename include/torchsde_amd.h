@@ -116,6 +116,11 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
                         const void* rootH, int have_h, int max_depth, int snap, const uint64_t* entropy_dev,
                         int dtype, void* stream);
 
+/* Diagnostics: which of the two (bit-identical) query kernels tsde_brownian_query / _dev launch. 0 (default): the tree
+ * walk is done once per block and run by the lanes as a list of operations (csrc/tsde_query_program.h); 1: every lane
+ * walks the tree itself (csrc/tsde_bridge.h) -- the original form, kept as the checker of the other. Process-wide. */
+void tsde_set_query_walk(int legacy);
+
 /* W (and U, optional) of ONE whole cell written to memory: the aligned fast path of a query, for
  * callers that must hand the increment to user torch code (g_prod, adjoint VJPs). `noise->dW` must be NULL. */
 int tsde_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* noise, int dtype, void* stream);
@@ -201,6 +206,13 @@ int tsde_milstein_gf_general_correction(void* corr, const void* g, const void* g
  * (W, H): A:(B,m,m) (_brownian/brownian_interval.py:78-99); antisymmetric noise keyed on (entropy, cell, node). */
 int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster, uint64_t entropy,
                    uint64_t elem0, uint32_t cell, uint64_t node, const uint64_t* entropy_dev, int dtype, void* stream);
+/* The two calls above fused for the general-noise Milstein step: I[b,k,l] = 0.5*(W_k W_l - [k==l]*dt) + A[b,k,l] with the
+ * Davie / Foster A of the same (entropy, cell, node), written directly (A never reaches memory; same bits as
+ * tsde_levy_area followed by tsde_iterated_integrals). Served for even m <= 64 with elem0*m % 4 == 0; returns
+ * hipErrorNotSupported (801) otherwise -- then make the two calls. */
+int tsde_levy_iterated_integrals(void* I, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
+                                 uint64_t entropy, uint64_t elem0, uint32_t cell, uint64_t node,
+                                 const uint64_t* entropy_dev, double dt, int ito, int dtype, void* stream);
 
 /* ---- reversible Heun (Stratonovich) and its exact-gradient adjoint: _core/methods/reversible_heun.py ---- */
 

@@ -288,3 +288,46 @@ def test_general_milstein_at_full_size_reduces_to_the_oracle_step():
     # the derivative-free form differs from the derivative form by its O(dt^1.5) finite-difference error per step
     torch.testing.assert_close(gf, y, rtol=1e-3, atol=1e-6)
     assert (gf - y).abs().max() > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, F64])
+@pytest.mark.parametrize("shape,row_offset", [((64, 16), 0), ((33, 4), 0), ((20, 6), 2), ((16, 16), 7), ((9, 3), 0)])
+@pytest.mark.parametrize("levy", ["davie", "foster"])
+def test_levy_area_kernels_equal_their_definition_and_the_fused_integrals(dtype, shape, row_offset, levy):
+    """The row-per-wave Levy-area kernel (one Philox call per four entries) and its fused form I = (W W^T - dt Id)/2 + A
+    against the definition written with torch ops on the generator's raw normals (tsde_brownian_normals): the same
+    bits as the per-entry kernel it replaces (odd m and unaligned shards still take that one)."""
+    import torchsde_amd
+    from torchsde_amd import _native, kernels as K
+    B, m = shape
+    h = 2.0 ** -5
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), dtype=dtype, device=DEV, entropy=1234, dt=h,
+                                       levy_area_approximation=levy, row_offset=row_offset)
+    W, U, A = bm.increment_with_levy_area(3 * h, 4 * h)
+    H = torch.empty(B, m, dtype=dtype, device=DEV)
+    bm.increment(3 * h, 4 * h, want_U=True, out_H=H)
+    # the node key of the interval, as increment_with_levy_area forms it
+    import struct
+    bits_a, bits_b = (struct.unpack("<Q", struct.pack("<d", x))[0] for x in (bm._round(3 * h), bm._round(4 * h)))
+    mix = (bits_a * 0x9E3779B97F4A7C15 + ((bits_b << 31) | (bits_b >> 33)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+    node = (mix ^ (mix >> 29)) & ((1 << 42) - 1)
+    ca, _ = bm.locate(bm._round(3 * h), bm._round(4 * h))
+    N = torch.empty(B * m * m, dtype=dtype, device=DEV)
+    lib = _native.load()
+    _native.check(lib.tsde_brownian_normals(_native.ptr(N), N.numel(), bm._key, bm._elem0 * m, ca, node, 2,
+                                            _native.dtype_code(dtype), _native.stream_ptr(N.device)), "normals")
+    N = N.reshape(B, m, m)
+    Wi, Wj, Hi, Hj = W.unsqueeze(2), W.unsqueeze(1), H.unsqueeze(2), H.unsqueeze(1)
+    if levy == "foster":
+        tenth = torch.tensor(0.1 * h, dtype=dtype, device=DEV)
+        sd = (tenth * (tenth + (Hi * Hi + Hj * Hj))).double().sqrt().to(dtype)
+    else:
+        sd = torch.full((B, m, m), (h * h / 12.0) ** 0.5, dtype=dtype, device=DEV)
+    want = (Hi * Wj - Wi * Hj) + sd * (N - N.transpose(1, 2))
+    eye = torch.eye(m, dtype=torch.bool, device=DEV)
+    want = torch.where(eye, Hi * Wj - Wi * Hj, want)
+    assert torch.equal(A, want)
+    assert torch.equal(A, -A.transpose(1, 2))
+    for ito in (True, False):
+        _, _, integrals = bm.increment_with_levy_area(3 * h, 4 * h, iterated=(h, ito))
+        assert torch.equal(integrals, K.iterated_integrals(W, A, h, ito))

@@ -34,3 +34,18 @@ for levy in ("none", "space-time"):
                                                                        out_W=W, out_U=U)))
     print(levy, "misaligned in-cell  %.1f us" % t(lambda: bm.increment(5.1 * dt + 1e-7, 5.7 * dt, want_U=wu,
                                                                        out_W=W, out_U=U)))
+
+# the same misaligned queries with every lane walking the tree itself (the form before round 3)
+from torchsde_amd import _native  # noqa: E402
+_native.load().tsde_set_query_walk(1)
+for levy in ("none", "space-time"):
+    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), device=dev, dtype=torch.float32, entropy=1, dt=dt,
+                                       levy_area_approximation=levy)
+    W = torch.empty(B, m, device=dev)
+    U = torch.empty(B, m, device=dev)
+    wu = levy != "none"
+    print(levy, "[per-lane walk] misaligned 2 cells  %.1f us" % t(lambda: bm.increment(5.3 * dt + 1e-7, 6.3 * dt + 1e-7,
+                                                                                       want_U=wu, out_W=W, out_U=U)))
+    print(levy, "[per-lane walk] misaligned in-cell  %.1f us" % t(lambda: bm.increment(5.1 * dt + 1e-7, 5.7 * dt,
+                                                                                       want_U=wu, out_W=W, out_U=U)))
+_native.load().tsde_set_query_walk(0)

@@ -271,10 +271,12 @@ class BrownianInterval(BaseBrownian):
             return (W, U, A) if return_A else (W, U)
         return (W, A) if return_A else W
 
-    def increment_with_levy_area(self, ta, tb):
+    def increment_with_levy_area(self, ta, tb, iterated=None):
         """(W, U, A) with A the Davie / Foster approximation of the Levy area of [ta, tb] built from the exact
         (W, H) of that interval (brownian_interval.py:78-99). Like the reference's, A is an approximation and is
-        not additive over sub-intervals; its antisymmetric noise is keyed on the interval so re-queries agree."""
+        not additive over sub-intervals; its antisymmetric noise is keyed on the interval so re-queries agree.
+        `iterated=(dt, ito)`: the third result is the matrix of iterated integrals I = (W W^T - [diag] dt)/2 + A
+        (Ito; Stratonovich: no dt term) of the general-noise Milstein step instead, in one kernel where it applies."""
         import struct
         from . import kernels as K
         ta_r, tb_r = self._round(ta), self._round(tb)
@@ -283,15 +285,27 @@ class BrownianInterval(BaseBrownian):
         if len(self._size) in (0, 1):   # one Brownian channel per batch element: no Levy area (:81-84)
             return W, U, torch.zeros_like(W)
         if not (ta_r < tb_r):
-            return W, U, torch.zeros(self._size + self._size[-1:], dtype=self._dtype, device=self._device)
+            A = torch.zeros(self._size + self._size[-1:], dtype=self._dtype, device=self._device)
+            if iterated is not None:
+                m = self._size[-1]
+                A = K.iterated_integrals(W.reshape(-1, m), A.reshape(-1, m, m), iterated[0], iterated[1]).reshape(A.shape)
+            return W, U, A
         ca, _ = self.locate(ta_r, tb_r)
         bits_a, bits_b = (struct.unpack("<Q", struct.pack("<d", x))[0] for x in (ta_r, tb_r))
         mix = (bits_a * 0x9E3779B97F4A7C15 + ((bits_b << 31) | (bits_b >> 33)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
         node = (mix ^ (mix >> 29)) & ((1 << 42) - 1)
         m = self._size[-1]
-        A = K.levy_area(W.reshape(-1, m), out_H.reshape(-1, m), tb_r - ta_r,
-                        self._levy == LEVY_AREA_APPROXIMATIONS.foster, self._key, self._elem0, ca, node,
+        foster = self._levy == LEVY_AREA_APPROXIMATIONS.foster
+        if iterated is not None:      # the general-noise Milstein step wants I = (W W^T - [diag] dt)/2 + A, not A itself
+            dt, ito = iterated
+            fused = K.levy_iterated_integrals(W.reshape(-1, m), out_H.reshape(-1, m), tb_r - ta_r, foster, self._key,
+                                              self._elem0, ca, node, dt, ito, self._entropy_dev)
+            if fused is not None:
+                return W, U, fused.reshape(self._size + (m,))
+        A = K.levy_area(W.reshape(-1, m), out_H.reshape(-1, m), tb_r - ta_r, foster, self._key, self._elem0, ca, node,
                         self._entropy_dev)
+        if iterated is not None:
+            return W, U, K.iterated_integrals(W.reshape(-1, m), A, iterated[0], iterated[1]).reshape(self._size + (m,))
         return W, U, A.reshape(self._size + (m,))
 
     def increment(self, ta, tb, want_U=False, out_W=None, out_U=None, out_H=None):

@@ -136,6 +136,8 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
                 tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
 }
 
+void tsde_set_query_walk(int legacy) { tsde::set_query_walk(legacy); }
+
 int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,
                             int64_t n_cells, const double* ab_dev, int have_h, int max_depth,
                             const uint64_t* entropy_dev, int dtype, void* stream) {
@@ -312,6 +314,17 @@ int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, 
   TSDE_DISPATCH(dtype, "tsde_levy_area",
                 tsde::launch_levy_area<float>(A, W, H, B, m, h, foster, key, entropy_dev, cell, node, s),
                 tsde::launch_levy_area<double>(A, W, H, B, m, h, foster, key, entropy_dev, cell, node, s));
+}
+
+int tsde_levy_iterated_integrals(void* I, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
+                                 uint64_t entropy, uint64_t elem0, uint32_t cell, uint64_t node,
+                                 const uint64_t* entropy_dev, double dt, int ito, int dtype, void* stream) {
+  if (!I || !W || !H) return bad_arg("tsde_levy_iterated_integrals", "null argument");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  TSDE_DISPATCH(dtype, "tsde_levy_iterated_integrals",
+                tsde::launch_levy_area<float>(I, W, H, B, m, h, foster, key, entropy_dev, cell, node, s, 1, dt, ito),
+                tsde::launch_levy_area<double>(I, W, H, B, m, h, foster, key, entropy_dev, cell, node, s, 1, dt, ito));
 }
 
 int tsde_rheun_z_diag(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,

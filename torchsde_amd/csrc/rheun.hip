@@ -218,6 +218,71 @@ __global__ void __launch_bounds__(kBlock) levy_area_kernel(T* __restrict__ A, co
   }
 }
 
+// The same values, one wave per batch row: the row's m*m normals are drawn ONCE -- m*m/4 Philox calls, four normals each,
+// the very quads `normal1` above indexes into -- and staged in LDS, from where entry (i, j) picks N_ij and N_ji. The
+// kernel above makes two Philox calls per entry and keeps one of the eight normals they produce (33 us at the C3 shape
+// for a 16 MiB result; this one is write-bound). Needs the row's first entry on a quad boundary (m even) and the row
+// in 16 KB of LDS (m <= 64). `Idt` != nullptr fuses tsde_iterated_integrals: I = 0.5*(W_i W_j - [i==j] dt) + A is
+// written instead of A (same operation order as the two kernels in sequence), saving A's round trip through HBM.
+constexpr int kLevyRowsPerBlock = kBlock / 64;
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) levy_area_rows_kernel(T* __restrict__ out, const T* __restrict__ W,
+                                                                const T* __restrict__ H, int64_t B, int m, double h,
+                                                                int foster, NoiseKey key, const uint64_t* key_dev,
+                                                                uint32_t cell, uint64_t node, int fuse, T dt, int ito) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  if (key_dev != nullptr) {
+    const uint64_t e = *key_dev;
+    key.k0 = (uint32_t)e;
+    key.k1 = (uint32_t)(e >> 32);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mm = m * m;
+  T* nrow = lds + (int64_t)wave * (mm + 2 * m);   // [mm normals | m of W | m of H]
+  T* wrow = nrow + mm;
+  T* hrow = wrow + m;
+  const T tenth_h = (T)(0.1 * h);
+  const T davie_std = (T)sqrt(h * h / 12.0);
+  for (int64_t row0 = (int64_t)blockIdx.x * kLevyRowsPerBlock; row0 < B; row0 += (int64_t)gridDim.x * kLevyRowsPerBlock) {
+    const int64_t b = row0 + wave;
+    const bool live = b < B;
+    if (live) {
+      const uint64_t base = key.elem0 * (uint64_t)m + (uint64_t)b * (uint64_t)mm;   // % 4 == 0 (checked by the launcher)
+      for (int q = lane; q < mm / 4; q += 64) {
+        T n[4];
+        normal4<T>(key, (base >> 2) + (uint64_t)q, cell, node, kStreamA, n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nrow[4 * q + c] = n[c];
+      }
+      for (int i = lane; i < m; i += 64) {
+        wrow[i] = W[b * m + i];
+        hrow[i] = H[b * m + i];
+      }
+    }
+    __syncthreads();
+    if (live) {
+      for (int t = lane; t < mm; t += 64) {
+        const int i = t / m, j = t - i * m;
+        const T Wi = wrow[i], Wj = wrow[j], Hi = hrow[i], Hj = hrow[j];
+        T a = Hi * Wj - Wi * Hj;
+        if (i != j) {
+          const T sd = foster ? (T)sqrt((double)(tenth_h * (tenth_h + (Hi * Hi + Hj * Hj)))) : davie_std;
+          a += sd * (nrow[t] - nrow[j * m + i]);
+        }
+        if (fuse) {
+          T v = Wi * Wj;
+          if (ito && i == j) v = v - dt;
+          a = (T)0.5 * v + a;
+        }
+        out[b * (int64_t)mm + t] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- iterated integrals for general-noise Milstein (extension, SURVEY.md section 8 note N1) ----------------------
 //   I[b,k,l] = 0.5*(W_k W_l - [k==l] dt) + A[b,k,l]   (Ito; Stratonovich drops the dt term; A may be absent)
 template <typename T>
@@ -247,11 +312,25 @@ hipError_t launch_iterated_integrals(void* I, const void* W, const void* A, int6
   return hipGetLastError();
 }
 
+// `fuse`: write I = 0.5*(W W^T - [diag] dt) + A instead of A (tsde_levy_iterated_integrals). Returns
+// hipErrorNotSupported when the fused form is asked for a shape only the per-entry kernel serves.
 template <typename T>
 hipError_t launch_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
-                            NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s) {
+                            NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s,
+                            int fuse, double dt, int ito) {
   const int64_t total = B * m * m;
   if (total <= 0) return hipSuccess;
+  static const bool rows_off = [] { const char* e = getenv("TSDE_LEVY_ROWS"); return e && e[0] == '0'; }();
+  const bool rows_ok = !rows_off && (m % 2 == 0) && m <= 64 && ((key.elem0 * (uint64_t)m) % 4 == 0);
+  if (rows_ok) {
+    const size_t lds = (size_t)kLevyRowsPerBlock * (size_t)(m * m + 2 * m) * sizeof(T);
+    int64_t blocks = (B + kLevyRowsPerBlock - 1) / kLevyRowsPerBlock;
+    if (blocks > kMaxGrid * 4) blocks = kMaxGrid * 4;
+    hipLaunchKernelGGL(levy_area_rows_kernel<T>, dim3((unsigned)blocks), dim3(kBlock), lds, s, (T*)A, (const T*)W,
+                       (const T*)H, B, (int)m, h, foster, key, key_dev, cell, node, fuse, (T)dt, ito);
+    return hipGetLastError();
+  }
+  if (fuse) return hipErrorNotSupported;
   hipLaunchKernelGGL(levy_area_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (T*)A, (const T*)W, (const T*)H, B,
                      m, h, foster, key, key_dev, cell, node);
   return hipGetLastError();
@@ -309,7 +388,7 @@ hipError_t launch_rheun_adj_b(void* ay1, void* az1, void* af1, void* ag1, const 
   template hipError_t launch_iterated_integrals<T>(void*, const void*, const void*, int64_t, int64_t, double, int,   \
                                                    hipStream_t);                                                     \
   template hipError_t launch_levy_area<T>(void*, const void*, const void*, int64_t, int64_t, double, int, NoiseKey,  \
-                                          const uint64_t*, uint32_t, uint64_t, hipStream_t);                         \
+                                          const uint64_t*, uint32_t, uint64_t, hipStream_t, int, double, int);       \
   template hipError_t launch_rheun_z<T>(void*, const void*, const void*, const void*, const void*, int64_t, double,  \
                                         double, const tsde_noise_t*, hipStream_t);                                   \
   template hipError_t launch_rheun_y<T>(void*, const void*, const void*, const void*, const void*, const void*,      \

@@ -20,6 +20,7 @@ struct QueryArgs {
   WalkCfg cfg;
 };
 
+void set_query_walk(int legacy);
 template <typename T>
 hipError_t launch_normals(void* out, int64_t n, NoiseKey key, uint32_t cell, uint64_t node, uint32_t stream_id,
                           hipStream_t s);
@@ -75,7 +76,8 @@ hipError_t launch_iterated_integrals(void* I, const void* W, const void* A, int6
                                      hipStream_t s);
 template <typename T>
 hipError_t launch_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
-                            NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s);
+                            NoiseKey key, const uint64_t* key_dev, uint32_t cell, uint64_t node, hipStream_t s,
+                            int fuse = 0, double dt = 0.0, int ito = 0);
 template <typename T>
 hipError_t launch_rheun_z(void* z1, const void* y0, const void* z0, const void* f0, const void* g0, int64_t n, double dt,
                           double sgn, const tsde_noise_t* nz, hipStream_t s);

@@ -1036,6 +1036,25 @@ def levy_area(W, H, h, foster, entropy, elem0, cell, node, entropy_dev=None):
     return A
 
 
+def levy_iterated_integrals(W, H, h, foster, entropy, elem0, cell, node, dt, ito, entropy_dev=None):
+    """I = 0.5*(W W^T - [diag] dt) + A with the Davie / Foster A of (W, H) in ONE kernel (`tsde_levy_iterated_integrals`);
+    None where the fused kernel does not serve the shape (the caller then makes the two calls)."""
+    W = _native.contiguous(W)
+    H, = _prep(W, H)
+    B, m = W.shape
+    out = torch.empty((B, m, m), dtype=W.dtype, device=W.device)
+    lib, dt_code, stream = _launch_env(W)
+    code = lib.tsde_levy_iterated_integrals(out.data_ptr(), W.data_ptr(), H.data_ptr(), B, m, float(h),
+                                            1 if foster else 0, entropy, elem0, cell, node,
+                                            None if entropy_dev is None else entropy_dev.data_ptr(), float(dt),
+                                            1 if ito else 0, dt_code, stream)
+    if code == 801:          # hipErrorNotSupported
+        return None
+    if code:
+        _native.check(code, "tsde_levy_iterated_integrals")
+    return out
+
+
 def iterated_integrals(W, A, dt, ito):
     """I[b,k,l] = 0.5*(W_k W_l - [k==l] dt) + A[b,k,l] (Ito) / 0.5*W_k W_l + A (Stratonovich); A may be None."""
     W = _native.contiguous(W)

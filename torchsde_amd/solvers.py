@@ -651,12 +651,11 @@ class _Milstein(BaseSDESolver):
         sde, dt = self.sde, st.dt
         t0 = st.times[0]
         bm = self._native_bm()
-        A = None
         if bm is not None and bm._have_A:
-            W, _, A = bm.increment_with_levy_area(st.t0_64, st.t0_64 + st.h64)
+            W, _, integrals = bm.increment_with_levy_area(st.t0_64, st.t0_64 + st.h64, iterated=(float(dt), self.ito))
         else:
             W, _ = st.noise.materialise()
-        integrals = K.iterated_integrals(W, A, dt, self.ito)
+            integrals = K.iterated_integrals(W, None, dt, self.ito)
         f, g = sde.f_and_g(t0, y0)
         if self.options[METHOD_OPTIONS.grad_free]:
             # Derivative-free form (the reference's own idea for diagonal noise, milstein.py:58-67, per channel): the m
