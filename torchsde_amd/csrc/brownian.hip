@@ -161,8 +161,13 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
 }
 
 // The same query with the tree walk done once per block (tsde_query_program.h) instead of once per lane.
+// Few, long-lived blocks: the program is built once per block (a serial walk by one thread), so a block should serve
+// many quads -- 512 threads, at most two blocks per CU.
+constexpr int kQueryBlock = 512;
+constexpr int kQueryMaxGrid = 512;
+
 template <typename T, bool HAVE_H>
-__global__ void __launch_bounds__(kBlock) query_program_kernel(T* __restrict__ W, T* __restrict__ U, T* __restrict__ H,
+__global__ void __launch_bounds__(kQueryBlock) query_program_kernel(T* __restrict__ W, T* __restrict__ U, T* __restrict__ H,
                                                                int64_t n, NoiseKey key, QueryArgs qa, int vec) {
   if (qa.key_dev != nullptr) {
     const uint64_t e = *qa.key_dev;
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(kBlock) query_program_kernel(T* __restrict__ W
   if (qa.ab_dev != nullptr) {
     qb = locate_bounds(qa.edges, qa.n_cells, qa.ab_dev[0], qa.ab_dev[1]);
     if (!(qb.a < qb.b)) {       // empty interval (an attempt after the last output time): the increment is zero
-      for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+      for (int64_t i = (int64_t)blockIdx.x * kQueryBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kQueryBlock) {
         W[i] = (T)0;
         if (HAVE_H && U) U[i] = (T)0;
         if (HAVE_H && H) H[i] = (T)0;
@@ -185,18 +190,18 @@ __global__ void __launch_bounds__(kBlock) query_program_kernel(T* __restrict__ W
     }
   }
   const double hq = qb.b - qb.a;
-  constexpr int NC = QueryProgram<T, HAVE_H>::NC;
+  __shared__ OpRow<T, HAVE_H> p_rows[kMaxOps];
   __shared__ uint32_t p_code[kMaxOps], p_cell[kMaxOps];
   __shared__ uint64_t p_node[kMaxOps];
   __shared__ double p_times[kMaxOps * 3], p_merge64[kMaxOps * 3];
-  __shared__ T p_coef[kMaxOps * NC], p_merge[kMaxOps * 3];
   __shared__ int p_n, p_split;
   __shared__ double p_len_mid;
-  const QueryProgram<T, HAVE_H> pg{p_code, p_cell, p_node, p_times, p_coef, p_merge, &p_n};
-  build_query_program<T, HAVE_H>(pg, p_merge64, qa.edges, qb.ca, qb.cb, qb.a, qb.b, qa.cfg, qa.rootW != nullptr,
-                                 &p_split, &p_len_mid);
+  const QueryProgram<T, HAVE_H> pg{p_rows, p_times, &p_n};
+  const ProgramScratch sc{p_code, p_cell, p_node, p_merge64};
+  build_query_program<T, HAVE_H>(pg, sc, qa.edges, qb.ca, qb.cb, qb.a, qb.b, qa.cfg, qa.rootW != nullptr, &p_split,
+                                 &p_len_mid);
   const int n_ops = p_n, split_at = p_split;
-  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kBlock) {
+  for (int64_t t = (int64_t)blockIdx.x * kQueryBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kQueryBlock) {
     const uint64_t quad = q0 + (uint64_t)t;
     const int64_t i0 = (int64_t)(quad * 4) - (int64_t)key.elem0;
     WH4<T> P, saved, acc, left;
@@ -268,11 +273,17 @@ hipError_t launch_query(void* W, void* U, void* H, int64_t n, NoiseKey key, cons
       TSDE_LAUNCH((query_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key, qa,
                   vec ? 1 : 0);
     }
-  } else if (have_h) {
-    TSDE_LAUNCH((query_program_kernel<T, true>), grid, dim3(kBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa, vec ? 1 : 0);
   } else {
-    TSDE_LAUNCH((query_program_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key, qa,
-                vec ? 1 : 0);
+    int64_t blocks = ((n + 3) / 4 + 1 + kQueryBlock - 1) / kQueryBlock;
+    if (blocks > kQueryMaxGrid) blocks = kQueryMaxGrid;
+    const dim3 pgrid((unsigned)blocks);
+    if (have_h) {
+      TSDE_LAUNCH((query_program_kernel<T, true>), pgrid, dim3(kQueryBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa,
+                  vec ? 1 : 0);
+    } else {
+      TSDE_LAUNCH((query_program_kernel<T, false>), pgrid, dim3(kQueryBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n,
+                  key, qa, vec ? 1 : 0);
+    }
   }
   return hipGetLastError();
 }

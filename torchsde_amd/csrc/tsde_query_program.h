@@ -33,16 +33,30 @@ enum : uint32_t {
   kOpPinned = 1u << 13,      // root: overwrite the draw with the user's pinned (W, H)
 };
 
+// One operation as the lanes read it: 16-byte aligned, so that a row is a few ds_read_b128 (wave-uniform address:
+// broadcast reads, no bank conflicts).
+template <typename T, bool HAVE_H>
+struct alignas(16) OpRow {
+  static constexpr int NC = HAVE_H ? 11 : 3;
+  uint32_t code, cell, node_lo, node_hi;
+  T c[NC];     // split coefficients (root: c[0] = sqrt(h), c[1] = sqrt(h/12))
+  T m[3];      // (T)ha, (T)hb, (T)(ha + hb) of interval_merge(A, ha, B, hb)
+};
+
 template <typename T, bool HAVE_H>
 struct QueryProgram {
   static constexpr int NC = HAVE_H ? 11 : 3;
-  uint32_t* code;    // [kMaxOps]
-  uint32_t* cell;    // [kMaxOps]
-  uint64_t* node;    // [kMaxOps]
-  double* times;     // [kMaxOps][3]: (lo, x, hi) of a split, (h, -, -) of a root -- input of the coefficient pass
-  T* coef;           // [kMaxOps][NC]
-  T* merge;          // [kMaxOps][3]: (T)ha, (T)hb, (T)(ha + hb) of interval_merge(A, ha, B, hb)
-  int* n_ops;        // [1]
+  OpRow<T, HAVE_H>* rows;   // [kMaxOps]
+  double* times;            // [kMaxOps][3]: (lo, x, hi) of a split, (h, -, -) of a root -- input of the coefficient pass
+  int* n_ops;               // [1]
+};
+
+// The builder's scratch (LDS, doubles): what the skeleton pass leaves for the coefficient pass.
+struct ProgramScratch {
+  uint32_t* code;
+  uint32_t* cell;
+  uint64_t* node;
+  double* merge64;
 };
 
 // Host-of-the-block side: the skeleton. Mirrors cell_range / walk_suffix / walk_prefix / PieceAcc statement by
@@ -192,11 +206,11 @@ struct ProgramBuilder {
 // the program (there may be thousands): the kernel loops over them between the two halves; `split_at` receives the
 // index of the first operation of the last cell's part (n_ops if the query lives in one cell).
 template <typename T, bool HAVE_H>
-TSDE_D void build_query_program(const QueryProgram<T, HAVE_H>& pg, double* merge64, const double* __restrict__ edges,
-                                int64_t ca, int64_t cb, double a, double b, const WalkCfg& cfg, bool pinned,
-                                int* split_at, double* acc_len_mid) {
+TSDE_D void build_query_program(const QueryProgram<T, HAVE_H>& pg, const ProgramScratch& sc,
+                                const double* __restrict__ edges, int64_t ca, int64_t cb, double a, double b,
+                                const WalkCfg& cfg, bool pinned, int* split_at, double* acc_len_mid) {
   if (threadIdx.x == 0) {
-    ProgramBuilder pb{pg.code, pg.cell, pg.node, pg.times, merge64, 0, 0.0, 0.0};
+    ProgramBuilder pb{sc.code, sc.cell, sc.node, pg.times, sc.merge64, 0, 0.0, 0.0};
     const double s = edges[ca], e = edges[ca + 1];
     pb.emit(kOpRoot | (pinned ? kOpPinned : 0u), (uint32_t)ca, 0, e - s, 0.0, 0.0);
     if (ca == cb) {
@@ -217,20 +231,29 @@ TSDE_D void build_query_program(const QueryProgram<T, HAVE_H>& pg, double* merge
   }
   __syncthreads();
   const int n = *pg.n_ops;
+  constexpr int NC = QueryProgram<T, HAVE_H>::NC;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint32_t c = pg.code[i] & kOpCodeMask;
+    OpRow<T, HAVE_H> row;
+    row.code = sc.code[i];
+    row.cell = sc.cell[i];
+    row.node_lo = (uint32_t)sc.node[i];
+    row.node_hi = (uint32_t)(sc.node[i] >> 32);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) row.c[j] = (T)0;
+    const uint32_t c = row.code & kOpCodeMask;
     if (c == kOpSplit) {
       const SplitCoef<T, HAVE_H> k = split_coef<T, HAVE_H>(pg.times[3 * i], pg.times[3 * i + 1], pg.times[3 * i + 2]);
 #pragma unroll
-      for (int j = 0; j < QueryProgram<T, HAVE_H>::NC; ++j) pg.coef[i * QueryProgram<T, HAVE_H>::NC + j] = k.c[j];
+      for (int j = 0; j < NC; ++j) row.c[j] = k.c[j];
     } else if (c == kOpRoot) {
       const double h = pg.times[3 * i];
-      pg.coef[i * QueryProgram<T, HAVE_H>::NC] = (T)sqrt(h);
-      pg.coef[i * QueryProgram<T, HAVE_H>::NC + 1] = (T)sqrt(h / 12.0);
+      row.c[0] = (T)sqrt(h);
+      row.c[1] = (T)sqrt(h / 12.0);
     }
-    pg.merge[3 * i] = (T)merge64[3 * i];
-    pg.merge[3 * i + 1] = (T)merge64[3 * i + 1];
-    pg.merge[3 * i + 2] = (T)merge64[3 * i + 2];
+    row.m[0] = (T)sc.merge64[3 * i];
+    row.m[1] = (T)sc.merge64[3 * i + 1];
+    row.m[2] = (T)sc.merge64[3 * i + 2];
+    pg.rows[i] = row;
   }
   __syncthreads();
 }
@@ -271,41 +294,47 @@ TSDE_D void program_push(uint32_t flags, const T* __restrict__ m, const WH4<T>& 
   }
 }
 
-// Operations [first, last) of the program for one Philox quad.
+// Operations [first, last) of the program for one Philox quad. The next row is fetched while the current one runs.
 template <typename T, bool HAVE_H>
 TSDE_D void run_query_program(const QueryProgram<T, HAVE_H>& pg, int first, int last, const NoiseKey& key, uint64_t quad,
                               const T* __restrict__ pinW, const T* __restrict__ pinH, int64_t i0, int64_t n,
                               WH4<T>& P, WH4<T>& saved, WH4<T>& acc, WH4<T>& left) {
   constexpr int NC = QueryProgram<T, HAVE_H>::NC;
+  if (first >= last) return;
+  OpRow<T, HAVE_H> next = pg.rows[first];
   for (int i = first; i < last; ++i) {
-    const uint32_t flags = __builtin_amdgcn_readfirstlane(pg.code[i]);
+    const OpRow<T, HAVE_H> row = next;
+    if (i + 1 < last) next = pg.rows[i + 1];
+    // wave-uniform by construction: into scalar registers, so that the control flow below is scalar branches
+    const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)row.code);
     const uint32_t c = flags & kOpCodeMask;
     if (c == kOpSplit) {
-      const uint32_t cl = __builtin_amdgcn_readfirstlane(pg.cell[i]);
-      const uint64_t nd = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pg.node[i] >> 32)) << 32) |
-                          (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)pg.node[i]);
+      const uint32_t cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)row.cell);
+      const uint64_t nd = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)row.node_hi) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)row.node_lo);
       SplitCoef<T, HAVE_H> k;
 #pragma unroll
-      for (int j = 0; j < NC; ++j) k.c[j] = pg.coef[i * NC + j];
+      for (int j = 0; j < NC; ++j) k.c[j] = row.c[j];
       WH4<T> L, R;
       bridge_split<T, HAVE_H>(key, quad, cl, nd, k, P, L, R);
       if (flags & kOpKeepRight) {
-        if (flags & kOpOtherPush) program_push<T, HAVE_H>(flags, pg.merge + 3 * i, L, acc, left);
+        if (flags & kOpOtherPush) program_push<T, HAVE_H>(flags, row.m, L, acc, left);
         P = R;
       } else {
-        if (flags & kOpOtherPush) program_push<T, HAVE_H>(flags, pg.merge + 3 * i, R, acc, left);
+        if (flags & kOpOtherPush) program_push<T, HAVE_H>(flags, row.m, R, acc, left);
         if (flags & kOpOtherSave) saved = R;
         P = L;
       }
     } else if (c == kOpPushP) {
-      program_push<T, HAVE_H>(flags, pg.merge + 3 * i, P, acc, left);
+      program_push<T, HAVE_H>(flags, row.m, P, acc, left);
     } else if (c == kOpLeftToAcc) {
-      program_push<T, HAVE_H>(flags, pg.merge + 3 * i, left, acc, left);
+      const WH4<T> piece = left;
+      program_push<T, HAVE_H>(flags, row.m, piece, acc, left);
     } else if (c == kOpRestore) {
       P = saved;
     } else if (c == kOpRoot) {
-      const uint32_t cl = __builtin_amdgcn_readfirstlane(pg.cell[i]);
-      const T sw = pg.coef[i * NC], sh = pg.coef[i * NC + 1];
+      const uint32_t cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)row.cell);
+      const T sw = row.c[0], sh = row.c[1];
       T nrm[4];
       normal4<T>(key, quad, cl, 0, kStreamW, nrm);
 #pragma unroll
