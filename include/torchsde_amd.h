@@ -116,11 +116,6 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
                         const void* rootH, int have_h, int max_depth, int snap, const uint64_t* entropy_dev,
                         int dtype, void* stream);
 
-/* Diagnostics: which of the two (bit-identical) query kernels tsde_brownian_query / _dev launch. 0 (default): the tree
- * walk is done once per block and run by the lanes as a list of operations (csrc/tsde_query_program.h); 1: every lane
- * walks the tree itself (csrc/tsde_bridge.h) -- the original form, kept as the checker of the other. Process-wide. */
-void tsde_set_query_walk(int legacy);
-
 /* W (and U, optional) of ONE whole cell written to memory: the aligned fast path of a query, for
  * callers that must hand the increment to user torch code (g_prod, adjoint VJPs). `noise->dW` must be NULL. */
 int tsde_cell_increment(void* W_out, void* U_out, int64_t n, const tsde_noise_t* noise, int dtype, void* stream);

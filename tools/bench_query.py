@@ -35,26 +35,3 @@ for levy in ("none", "space-time"):
     print(levy, "misaligned in-cell  %.1f us" % t(lambda: bm.increment(5.1 * dt + 1e-7, 5.7 * dt, want_U=wu,
                                                                        out_W=W, out_U=U)))
 
-# the same misaligned queries with every lane walking the tree itself (the form before round 3)
-from torchsde_amd import _native  # noqa: E402
-_native.load().tsde_set_query_walk(1)
-for levy in ("none", "space-time"):
-    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), device=dev, dtype=torch.float32, entropy=1, dt=dt,
-                                       levy_area_approximation=levy)
-    W = torch.empty(B, m, device=dev)
-    U = torch.empty(B, m, device=dev)
-    wu = levy != "none"
-    print(levy, "[per-lane walk] misaligned 2 cells  %.1f us" % t(lambda: bm.increment(5.3 * dt + 1e-7, 6.3 * dt + 1e-7,
-                                                                                       want_U=wu, out_W=W, out_U=U)))
-    print(levy, "[per-lane walk] misaligned in-cell  %.1f us" % t(lambda: bm.increment(5.1 * dt + 1e-7, 5.7 * dt,
-                                                                                       want_U=wu, out_W=W, out_U=U)))
-_native.load().tsde_set_query_walk(0)
-
-# one block's worth of elements: what the per-block prologue (table / program build) costs by itself
-for legacy in (1, 0):
-    _native.load().tsde_set_query_walk(legacy)
-    bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(256, 4), device=dev, dtype=torch.float32, entropy=1, dt=dt)
-    Wt = torch.empty(256, 4, device=dev)
-    print("tiny (1024 elements)", "[per-lane walk]" if legacy else "[program]",
-          "misaligned in-cell  %.1f us" % t(lambda: bm.increment(5.1 * dt + 1e-7, 5.7 * dt, out_W=Wt), n=200))
-_native.load().tsde_set_query_walk(0)

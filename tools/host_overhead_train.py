@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torchsde_amd  # noqa: E402
+from torchsde_amd import graph  # noqa: E402
 from workloads import problems  # noqa: E402
 
 dev = "cuda"
@@ -26,6 +27,7 @@ def iteration(fn, method, sde_type, **kw):
                                            levy_area_approximation=levy)
         ys = fn(sde, y0, ts, bm=bm, method=method, dt=dt, **kw)
         ys[-1].sum().backward()
+    go.sde = sde
     return go
 
 
@@ -58,6 +60,8 @@ for name, fn, method, sde_type, kw in cases:       # NO options: the drop-in cal
         go(3 + i)
     torch.cuda.synchronize()
     print(f"{name + ' [no options]':40s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
+    for line in graph.describe_cache(go.sde):
+        print("      ", line[:200])
 
 if len(sys.argv) > 1:
     which = sys.argv[1]

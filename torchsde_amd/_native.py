@@ -69,7 +69,6 @@ _PTR5 = _c_ptr * 5
 # name -> (restype, argtypes); mirrors include/torchsde_amd.h one to one.
 SIGNATURES = {
     "tsde_abi_version": (_c_int, []),
-    "tsde_set_query_walk": (None, [_c_int]),
     "tsde_last_error": (ctypes.c_char_p, []),
     "tsde_philox4x32_10": (None, [ctypes.POINTER(_c_u32), ctypes.POINTER(_c_u32), ctypes.POINTER(_c_u32)]),
     "tsde_noise_counter": (None, [_c_u64, _c_u32, _c_u64, _c_u32, ctypes.POINTER(_c_u32)]),

@@ -2,7 +2,6 @@
 // (replaces torchsde/_brownian/brownian_interval.py:589-687 and the tree/LRU/seed machinery under it).
 #include "tsde_common.h"
 #include "tsde_launch.h"
-#include "tsde_query_program.h"
 
 namespace tsde {
 
@@ -160,96 +159,6 @@ __global__ void __launch_bounds__(kBlock) query_kernel(T* __restrict__ W, T* __r
   }
 }
 
-// The same query with the tree walk done once per block (tsde_query_program.h) instead of once per lane.
-// Few, long-lived blocks: the program is built once per block (a serial walk by one thread), so a block should serve
-// many quads -- 512 threads, at most two blocks per CU.
-constexpr int kQueryBlock = 512;
-constexpr int kQueryMaxGrid = 512;
-
-template <typename T, bool HAVE_H>
-__global__ void __launch_bounds__(kQueryBlock) query_program_kernel(T* __restrict__ W, T* __restrict__ U, T* __restrict__ H,
-                                                               int64_t n, NoiseKey key, QueryArgs qa, int vec) {
-  if (qa.key_dev != nullptr) {
-    const uint64_t e = *qa.key_dev;
-    key.k0 = (uint32_t)e;
-    key.k1 = (uint32_t)(e >> 32);
-  }
-  const uint64_t q0 = key.elem0 >> 2;
-  const uint64_t q1 = (key.elem0 + (uint64_t)n + 3) >> 2;
-  const int64_t nq = (int64_t)(q1 - q0);
-  QueryBounds qb{qa.a, qa.b, qa.ca, qa.cb};
-  if (qa.ab_dev != nullptr) {
-    qb = locate_bounds(qa.edges, qa.n_cells, qa.ab_dev[0], qa.ab_dev[1]);
-    if (!(qb.a < qb.b)) {       // empty interval (an attempt after the last output time): the increment is zero
-      for (int64_t i = (int64_t)blockIdx.x * kQueryBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kQueryBlock) {
-        W[i] = (T)0;
-        if (HAVE_H && U) U[i] = (T)0;
-        if (HAVE_H && H) H[i] = (T)0;
-      }
-      return;
-    }
-  }
-  const double hq = qb.b - qb.a;
-  __shared__ OpRow<T, HAVE_H> p_rows[kMaxOps];
-  __shared__ uint32_t p_code[kMaxOps], p_cell[kMaxOps];
-  __shared__ uint64_t p_node[kMaxOps];
-  __shared__ double p_times[kMaxOps * 3], p_merge64[kMaxOps * 3];
-  __shared__ int p_n, p_split;
-  __shared__ double p_len_mid;
-  const QueryProgram<T, HAVE_H> pg{p_rows, p_times, &p_n};
-  const ProgramScratch sc{p_code, p_cell, p_node, p_merge64};
-  build_query_program<T, HAVE_H>(pg, sc, qa.edges, qb.ca, qb.cb, qb.a, qb.b, qa.cfg, qa.rootW != nullptr, &p_split,
-                                 &p_len_mid);
-  const int n_ops = p_n, split_at = p_split;
-  for (int64_t t = (int64_t)blockIdx.x * kQueryBlock + threadIdx.x; t < nq; t += (int64_t)gridDim.x * kQueryBlock) {
-    const uint64_t quad = q0 + (uint64_t)t;
-    const int64_t i0 = (int64_t)(quad * 4) - (int64_t)key.elem0;
-    WH4<T> P, saved, acc, left;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) P.W[j] = P.H[j] = saved.W[j] = saved.H[j] = acc.W[j] = acc.H[j] = left.W[j] = left.H[j] = (T)0;
-    run_query_program<T, HAVE_H>(pg, 0, split_at, key, quad, (const T*)qa.rootW, (const T*)qa.rootH, i0, n, P, saved, acc,
-                                 left);
-    if (qb.ca != qb.cb) {
-      double len = p_len_mid;       // whole cells strictly between the end cells: PieceAcc::push_right of their roots
-      for (int64_t c = qb.ca + 1; c < qb.cb; ++c) {
-        const double h = qa.edges[c + 1] - qa.edges[c];
-        WH4<T> R;
-        cell_root<T, HAVE_H>(key, quad, (uint32_t)c, h, R);
-        if (len == 0.0) acc = R;
-        else interval_merge<T, HAVE_H>(acc, len, R, h);
-        len += h;
-      }
-      run_query_program<T, HAVE_H>(pg, split_at, n_ops, key, quad, nullptr, nullptr, i0, n, P, saved, acc, left);
-    }
-    Pack<T, 4> w, u, hh;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      w.v[j] = acc.W[j];
-      hh.v[j] = acc.H[j];
-      u.v[j] = (T)hq * ((T)0.5 * acc.W[j] + acc.H[j]);  // _H_to_U, brownian_interval.py:102-103
-    }
-    if (vec) {
-      store<T, 4>(W, i0, w);
-      if (HAVE_H && U) store<T, 4>(U, i0, u);
-      if (HAVE_H && H) store<T, 4>(H, i0, hh);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t i = i0 + j;
-        if (i >= 0 && i < n) {
-          W[i] = w.v[j];
-          if (HAVE_H && U) U[i] = u.v[j];
-          if (HAVE_H && H) H[i] = hh.v[j];
-        }
-      }
-    }
-  }
-}
-
-// 0: the query as a per-block program (default); 1: the per-lane walk of tsde_bridge.h (the checker; diagnostics).
-static int g_query_walk_legacy = 0;
-void set_query_walk(int legacy) { g_query_walk_legacy = legacy ? 1 : 0; }
-
 template <typename T>
 hipError_t launch_normals(void* out, int64_t n, NoiseKey key, uint32_t cell, uint64_t node, uint32_t stream_id,
                           hipStream_t s) {
@@ -266,24 +175,11 @@ hipError_t launch_query(void* W, void* U, void* H, int64_t n, NoiseKey key, cons
   const bool vec = (key.elem0 % 4 == 0) && (n % 4 == 0) && aligned16(W) && (!U || aligned16(U)) &&
                    (!H || aligned16(H));
   const dim3 grid(grid_for((n + 3) / 4 + 1));
-  if (g_query_walk_legacy) {
-    if (have_h) {
-      TSDE_LAUNCH((query_kernel<T, true>), grid, dim3(kBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa, vec ? 1 : 0);
-    } else {
-      TSDE_LAUNCH((query_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key, qa,
-                  vec ? 1 : 0);
-    }
+  if (have_h) {
+    TSDE_LAUNCH((query_kernel<T, true>), grid, dim3(kBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa, vec ? 1 : 0);
   } else {
-    int64_t blocks = ((n + 3) / 4 + 1 + kQueryBlock - 1) / kQueryBlock;
-    if (blocks > kQueryMaxGrid) blocks = kQueryMaxGrid;
-    const dim3 pgrid((unsigned)blocks);
-    if (have_h) {
-      TSDE_LAUNCH((query_program_kernel<T, true>), pgrid, dim3(kQueryBlock), 0, s, (T*)W, (T*)U, (T*)H, n, key, qa,
-                  vec ? 1 : 0);
-    } else {
-      TSDE_LAUNCH((query_program_kernel<T, false>), pgrid, dim3(kQueryBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n,
-                  key, qa, vec ? 1 : 0);
-    }
+    TSDE_LAUNCH((query_kernel<T, false>), grid, dim3(kBlock), 0, s, (T*)W, (T*)nullptr, (T*)nullptr, n, key, qa,
+                vec ? 1 : 0);
   }
   return hipGetLastError();
 }

@@ -136,8 +136,6 @@ int tsde_brownian_query(void* W, void* U, void* H, int64_t n, uint64_t entropy, 
                 tsde::launch_query<double>(W, U, H, n, key, qa, have_h != 0, s));
 }
 
-void tsde_set_query_walk(int legacy) { tsde::set_query_walk(legacy); }
-
 int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entropy, uint64_t elem0, const double* edges,
                             int64_t n_cells, const double* ab_dev, int have_h, int max_depth,
                             const uint64_t* entropy_dev, int dtype, void* stream) {

@@ -20,7 +20,6 @@ struct QueryArgs {
   WalkCfg cfg;
 };
 
-void set_query_walk(int legacy);
 template <typename T>
 hipError_t launch_normals(void* out, int64_t n, NoiseKey key, uint32_t cell, uint64_t node, uint32_t stream_id,
                           hipStream_t s);

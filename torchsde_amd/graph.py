@@ -83,6 +83,27 @@ def _cache_of(base):
     return cache
 
 
+def describe_cache(sde):
+    """What the HIP-graph cache on `sde` holds, one line per structure: the answer to "why is my solve (not) replayed?"."""
+    base = sde
+    while hasattr(base, "_base_sde"):
+        base = base._base_sde
+    lines = []
+    for sig, entry in getattr(base, _CACHE_ATTR, {}).items():
+        kind = next((x for x in sig if isinstance(x, str) and x not in ("auto",)), "?")
+        mode = "auto" if sig and sig[0] == "auto" else "explicit"
+        if isinstance(entry, _Refused):
+            what = f"stays eager: {entry.reason}"
+        elif isinstance(entry, _Seen):
+            what = ("seen once, next solve records it (drift and diffusion independent: "
+                    f"{'yes' if entry.independent else 'no'})")
+        else:
+            tuning = getattr(entry, "tuning", None)
+            what = type(entry).__name__.lstrip("_") + (f", {tuning}" if tuning else "")
+        lines.append(f"[{mode}] {kind}: {what}")
+    return lines
+
+
 def _remember(cache, sig, captured):
     """Each captured graph pins its memory pool; a caller that keeps changing the structure (e.g. random `ts`) must
     not grow the cache without bound: the oldest entry goes first."""
@@ -288,9 +309,11 @@ class _OperatorRecorder(TorchDispatchMode):
             _storages(kwargs, ins)
             _storages(result, outs)
             self.touched[phase] |= ins | outs
-            # what an operator returns it has written (fresh memory, or an input it modified in place / through out=);
-            # views alias their base, which then counts as written too: conservative, never the other way
-            self.written[phase] |= outs
+            # what an operator returns in memory that was not among its inputs it has written (fresh); what it returns
+            # in an input's memory is a view -- unless the schema says the operator mutates (in place, out=)
+            self.written[phase] |= (outs - ins)
+            if getattr(getattr(func, "_schema", None), "is_mutable", False):
+                self.written[phase] |= (outs & ins)
             self.keep.append(result)
         return result
 
