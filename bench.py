@@ -186,7 +186,7 @@ class Job:
         if self.adjoint or self.train:
             with torch.enable_grad():
                 if self.adjoint:
-                    gopt = {"hip_graph": bool(graph)}      # (False, not absent: the default is "auto")
+                    gopt = dict(extra_options, hip_graph=bool(graph))      # (False, not absent: the default is "auto")
                     ys = self._sdeint_adjoint(self.sde, self.y0, self.ts, bm=bm, method=c["method"],
                                               adjoint_method=c["adjoint_method"], dt=c["dt"], options=dict(gopt),
                                               adjoint_options=dict(gopt))
@@ -623,7 +623,8 @@ def main():
 
     job = Job(args.workload, dev, rank=rank, world=world, dist=dist, graph=not args.eager)
     if args.profile_steps > 0:
-        job.cfg = dict(job.cfg, nsteps=args.profile_steps)
+        # (counters serialise every kernel: skip the capture-time tuning that replays whole solves several times)
+        job.cfg = dict(job.cfg, nsteps=args.profile_steps, options=dict(job.cfg.get("options") or {}, overlap_f_g=False))
         job.ts = torch.tensor([0.0, args.profile_steps * job.cfg["dt"]], device=dev)
         for i in range(args.warmup + args.steps):
             job.solve(i)

@@ -203,7 +203,7 @@ int tsde_levy_area(void* A, const void* W, const void* H, int64_t B, int64_t m, 
                    uint64_t elem0, uint32_t cell, uint64_t node, const uint64_t* entropy_dev, int dtype, void* stream);
 /* The two calls above fused for the general-noise Milstein step: I[b,k,l] = 0.5*(W_k W_l - [k==l]*dt) + A[b,k,l] with the
  * Davie / Foster A of the same (entropy, cell, node), written directly (A never reaches memory; same bits as
- * tsde_levy_area followed by tsde_iterated_integrals). Served for even m <= 64 with elem0*m % 4 == 0; returns
+ * tsde_levy_area followed by tsde_iterated_integrals). Served for even m whose m*m + 2m entries fit 12 KB (m <= 54 in float32) with elem0*m % 4 == 0; returns
  * hipErrorNotSupported (801) otherwise -- then make the two calls. */
 int tsde_levy_iterated_integrals(void* I, const void* W, const void* H, int64_t B, int64_t m, double h, int foster,
                                  uint64_t entropy, uint64_t elem0, uint32_t cell, uint64_t node,

@@ -213,7 +213,8 @@ def test_unusable_adjoint_method_only_fails_when_a_backward_pass_can_follow():
 
 class _SharedEvaluation(nn.Module):
     """The diffusion reuses what the drift computed (one network evaluation serves both): correct when the two run in
-    sequence, a race if they were recorded as parallel branches of a graph."""
+    sequence, a race if they were recorded as parallel branches of a graph. (The cached tensor is re-bound on every call,
+    so the object's Python-side state never repeats: "auto" never records this module at all.)"""
     noise_type, sde_type = "diagonal", "ito"
 
     def __init__(self):
@@ -228,14 +229,38 @@ class _SharedEvaluation(nn.Module):
         return 0.1 * self.h
 
 
+class _SharedScratch(nn.Module):
+    """Drift and diffusion both compute through ONE persistent scratch buffer (in place: the object's state repeats, so
+    the solve is recorded) -- fine in sequence, a race side by side."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        super().__init__()
+        self.mu = nn.Parameter(torch.full((D,), -0.4))
+        self.register_buffer("scratch", torch.zeros(B, D))
+
+    def f(self, t, y):
+        torch.mul(y, self.mu, out=self.scratch)
+        return self.scratch + 0.0
+
+    def g(self, t, y):
+        torch.mul(y, 0.3, out=self.scratch)
+        return torch.sigmoid(self.scratch)
+
+
 def test_drift_and_diffusion_that_share_memory_stay_in_sequence():
     from torchsde_amd import graph
-    sde = _SharedEvaluation().to(DEV)
     y0 = torch.full((B, D), 0.1, device=DEV)
+    cached = _SharedEvaluation().to(DEV)
     for entropy in (1, 2, 3, 4):
-        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
-    (captured,) = _entries(sde, graph._CapturedSolve)
+        assert torch.equal(_solve(cached, entropy, y0, False), _solve(cached, entropy, y0, True))
+    assert not _entries(cached, graph._CapturedSolve)
+    scratch = _SharedScratch().to(DEV)
+    for entropy in (1, 2, 3, 4):
+        assert torch.equal(_solve(scratch, entropy, y0, False), _solve(scratch, entropy, y0, True))
+    (captured,) = _entries(scratch, graph._CapturedSolve)
     assert getattr(captured, "tuning", None) is None            # the parallel form was never tried
+    assert any("independent: no" in line or "CapturedSolve" in line for line in graph.describe_cache(scratch))
 
 
 def test_independent_drift_and_diffusion_may_run_as_parallel_branches():

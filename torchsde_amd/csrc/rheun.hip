@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(kBlock) levy_area_kernel(T* __restrict__ A, co
 // the very quads `normal1` above indexes into -- and staged in LDS, from where entry (i, j) picks N_ij and N_ji. The
 // kernel above makes two Philox calls per entry and keeps one of the eight normals they produce (33 us at the C3 shape
 // for a 16 MiB result; this one is write-bound). Needs the row's first entry on a quad boundary (m even) and the row
-// in 16 KB of LDS (m <= 64). `Idt` != nullptr fuses tsde_iterated_integrals: I = 0.5*(W_i W_j - [i==j] dt) + A is
+// in a quarter of 48 KB of LDS (m <= 54 in float32, m <= 38 in float64). `Idt` != nullptr fuses tsde_iterated_integrals: I = 0.5*(W_i W_j - [i==j] dt) + A is
 // written instead of A (same operation order as the two kernels in sequence), saving A's round trip through HBM.
 constexpr int kLevyRowsPerBlock = kBlock / 64;
 
@@ -321,9 +321,9 @@ hipError_t launch_levy_area(void* A, const void* W, const void* H, int64_t B, in
   const int64_t total = B * m * m;
   if (total <= 0) return hipSuccess;
   static const bool rows_off = [] { const char* e = getenv("TSDE_LEVY_ROWS"); return e && e[0] == '0'; }();
-  const bool rows_ok = !rows_off && (m % 2 == 0) && m <= 64 && ((key.elem0 * (uint64_t)m) % 4 == 0);
+  const size_t lds = (size_t)kLevyRowsPerBlock * (size_t)(m * m + 2 * m) * sizeof(T);
+  const bool rows_ok = !rows_off && (m % 2 == 0) && lds <= (48u << 10) && ((key.elem0 * (uint64_t)m) % 4 == 0);
   if (rows_ok) {
-    const size_t lds = (size_t)kLevyRowsPerBlock * (size_t)(m * m + 2 * m) * sizeof(T);
     int64_t blocks = (B + kLevyRowsPerBlock - 1) / kLevyRowsPerBlock;
     if (blocks > kMaxGrid * 4) blocks = kMaxGrid * 4;
     hipLaunchKernelGGL(levy_area_rows_kernel<T>, dim3((unsigned)blocks), dim3(kBlock), lds, s, (T*)A, (const T*)W,

@@ -416,14 +416,14 @@ def auto_solve(solver, y0, ts, extra0=()):
     return entry.replay(bm, y0, extra0)
 
 
-def _replay_ms(graphs, device, rounds=4):
-    """Duration of one replay of each of `graphs`: the best of `rounds` replays each, taken in alternation after one
-    untimed replay (so that clocks, caches and allocator state are the same for all of them), events on the current
-    stream."""
+def _replay_ms(graphs, device, max_rounds=3):
+    """Duration of one replay of each of `graphs`: the best of up to `max_rounds` replays each, taken in alternation
+    after one untimed replay (so that clocks, caches and allocator state are the same for all of them), events on the
+    current stream. Stops after the first round when that already separates the candidates by more than 10 %."""
     for g in graphs:
         g.replay()
     best = [float("inf")] * len(graphs)
-    for _ in range(rounds):
+    for _ in range(max_rounds):
         for i, g in enumerate(graphs):
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
@@ -431,6 +431,8 @@ def _replay_ms(graphs, device, rounds=4):
             stop.record()
             stop.synchronize()
             best[i] = min(best[i], start.elapsed_time(stop))
+        if max(best) > 1.1 * min(best):
+            break
     return best
 
 
