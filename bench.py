@@ -494,6 +494,9 @@ def _side_measurement(dev, name):
                                 f"x{scale:g}: the stepping loop is homogeneous")
     if job.train or job.adjoint:
         rec["what"] = "forward + backward per solve"
+    if job.use_graph:
+        from torchsde_amd import graph as graph_module
+        rec["graphs"] = [line[:240] for line in graph_module.describe_cache(job.sde)]
     if job.trajectory:
         k_ms, k_launches = job.bracket_dominant_kernel()
         roof = job.roofline(value, k_ms, k_launches)
