@@ -292,3 +292,60 @@ def test_operators_outside_the_known_family_are_never_recorded():
     assert not _entries(sde, graph._CapturedSolve)
     (refused,) = _entries(sde, graph._Refused)
     assert "capture-safe" in refused.reason
+
+
+@pytest.mark.parametrize("explicit", [False, True])
+def test_graphs_that_do_not_replay_stably_are_refused(explicit):
+    """On this stack a HIP graph holding several multi-block torch reductions is right on its first replay and wrong on
+    every later one (tools/probe_graph_reduction2.py) -- at B = 4096, d = 128 the backward sweep of `sdeint_adjoint`,
+    replayed, returned inf for per-channel parameters. Every recorded graph is therefore replayed a few times before
+    it is trusted (graph.replays_are_stable): gradients must equal the eager ones on EVERY iteration, with no options
+    and with hip_graph=True (which warns and runs eagerly), whatever the allocator and the reductions do."""
+    import torchsde_amd
+    Bb, Dd = 4096, 128
+    sde = problems.make("mlpdiag_ito", d=Dd).to(DEV)
+    ts = torch.tensor([0.0, 8 * DT], device=DEV)
+
+    def grads(entropy, opts):
+        y0 = torch.full((Bb, Dd), 0.1, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 8 * DT, size=(Bb, Dd), device=DEV, dtype=torch.float32, entropy=entropy)
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method="euler", adjoint_method="euler", dt=DT,
+                                         options=opts, adjoint_options=opts)
+        sde.zero_grad()
+        ys[-1].sum().backward()
+        return [y0.grad] + [p.grad.clone() for p in sde.parameters()]
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for entropy in (1, 2, 3, 4, 5):
+            got = grads(entropy, {"hip_graph": True} if explicit else None)
+            want = grads(entropy, {"hip_graph": False})
+            for a, e in zip(got, want):
+                assert torch.isfinite(a).all()
+                torch.testing.assert_close(a, e, rtol=1e-3, atol=1e-3 * e.abs().max().item())
+
+
+def test_a_reduction_in_the_drift_replays_stably_or_not_at_all():
+    import torchsde_amd
+
+    class Centred(_Scaled):
+        def f(self, t, y):
+            return self.mu * (y - y.mean(0)) + 0.0 * y.sum(0)          # column reductions over the batch
+
+    Bb, Dd = 4096, 128
+    sde = Centred()
+    sde.mu = nn.Parameter(torch.full((Dd,), -0.3))
+    sde.shift = torch.zeros(Dd)
+    sde = sde.to(DEV)
+    y0 = torch.rand(Bb, Dd, device=DEV)
+    ts = torch.tensor([0.0, 16 * DT], device=DEV)
+
+    def solve(entropy, opts):
+        bm = torchsde_amd.BrownianInterval(0.0, 16 * DT, size=(Bb, Dd), device=DEV, dtype=torch.float32, entropy=entropy)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=DT, options=opts)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for opts in (None, {"hip_graph": True}):
+            for entropy in (1, 2, 3, 4, 5):
+                assert torch.equal(solve(entropy, opts), solve(entropy, {"hip_graph": False})), (opts, entropy)

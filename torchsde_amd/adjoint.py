@@ -536,10 +536,10 @@ def _capture_backward(sde, bm, dt, adjoint_method, adjoint_options, adjoint_para
                               "module; running the backward pass eagerly.")
             return None
         run = _backward_runner(sde, bm, dt, kind, [alias_of[id(p)] for p in adjoint_params], ts_host, ys.device)
-        # The capture only records; `backward` copies the real cotangents in before each replay. Zero cotangents
-        # will do -- except for "auto", which compares a replay with the eager sweep and needs gradients that are
-        # not identically zero for that.
-        fill = torch.ones_like if auto else torch.zeros_like
+        # The capture only records; `backward` copies the real cotangents in before each replay. All-ones cotangents:
+        # the recorded graph is replayed a few times right away and must keep giving the same (and for "auto": the
+        # eager sweep's) gradients, which says nothing if they are identically zero.
+        fill = torch.ones_like
         inputs = [ys, fill(ys)] + list(forward_extras) + [fill(x) for x in forward_extras]
         with torch.no_grad(), _reparametrize_module(sde, swapped):
             return graph._CapturedBackward(run, bm, inputs, keepalive=(run.plan,), verify=auto)

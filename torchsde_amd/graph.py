@@ -318,6 +318,27 @@ class _OperatorRecorder(TorchDispatchMode):
         return result
 
 
+def replays_are_stable(replay, outputs, extra_replays=2):
+    """Does replaying a freshly recorded graph on the same inputs keep giving what its first replay gave? It should,
+    trivially -- but on this stack (ROCm 7.2, torch 2.10) a graph that contains several multi-block torch reductions
+    (`x.sum(0)` over a few thousand rows: the parameter gradients of a broadcast `w * y`) is right on its FIRST replay
+    and wrong, stably, on every later one (tools/probe_graph_reduction2.py, profiles/r3j_probe_graph_reduction.txt:
+    twenty column sums of a 4096 x 128 tensor in one graph are 23 % off from the second replay on; the backward sweep of
+    `sdeint_adjoint` at B = 4096, d = 128 returned inf for per-channel parameters). Nothing this package can repair, so
+    every graph it records is checked before it is trusted: `replay()` runs the graph, `outputs()` lists its result
+    tensors. NaN in the same place counts as equal."""
+    first = [o.clone() for o in outputs()]
+    for _ in range(extra_replays):
+        replay()
+        if not _same_tensors(outputs(), first, exact=True):
+            return False
+    return True
+
+
+_UNSTABLE = ("replaying the recorded graph does not reproduce its own first replay (a known fault of torch reductions "
+             "under HIP graphs on this stack: graph.replays_are_stable)")
+
+
 def run_screened(fn, verdict=None):
     """`fn()` -- the launch-only part of an eager solve -- watched for everything that would make recording it unsafe:
     host synchronisation (torch's sync-debug mode) and operators outside `_CAPTURE_SAFE` (a dispatch-mode recorder).
@@ -410,7 +431,7 @@ def auto_solve(solver, y0, ts, extra0=()):
             solver._extra = tuple(extra0)
             return None
         if not captured.verified:
-            cache[sig] = _Refused("the captured graph did not reproduce the eager solve")
+            cache[sig] = _Refused(_UNSTABLE if not captured.stable else "the recorded graph did not reproduce the eager solve")
             return captured.eager_result
         cache[sig] = captured
         return captured.result()
@@ -454,7 +475,7 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
         forward_sde.overlap_f_g = False
         reserved = torch.cuda.memory_reserved(device)
         sequential = capture()
-        if sequential is None or getattr(sequential, "verified", True) is False:
+        if sequential is None or getattr(sequential, "verified", True) is False or not getattr(sequential, "stable", True):
             return sequential
         # the second graph needs a memory pool of its own until the loser is dropped: no tuning when that does not
         # comfortably fit (a solve that fitted before must not run out of memory because of the tuner)
@@ -466,7 +487,7 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
         parallel = capture()
     finally:
         forward_sde.overlap_f_g = True
-    if parallel is None or getattr(parallel, "verified", True) is False:
+    if parallel is None or getattr(parallel, "verified", True) is False or not getattr(parallel, "stable", True):
         return sequential
     t_seq, t_par = _replay_ms([sequential.graph, parallel.graph], device)
     # the parallel form is only an option if it computes the same thing: drift and diffusion code that shares buffers,
@@ -538,8 +559,9 @@ class _CapturedSolve:
         finally:
             bm._entropy_dev = None
         self.graph.replay()     # capture only records: run once so that `ys` holds this solve's result
+        self.stable = replays_are_stable(self.graph.replay, self.outputs)
         if verify:              # "auto": the replay must be the eager solve it was recorded beside, bit for bit
-            self.verified = _same_tensors(self.outputs(), [warm] + list(warm_extra))
+            self.verified = self.stable and _same_tensors(self.outputs(), [warm] + list(warm_extra))
             self.eager_result = None if self.verified else (warm, warm_extra)
 
     def _set_seed(self, bm):
@@ -605,8 +627,17 @@ def replay_or_capture(solver, y0, ts, extra0=()):
     if captured is None:
         captured = faster_of_sequential_and_parallel(solver.sde if hasattr(solver.sde, "_f_then_g") else None,
                                                      lambda: _CapturedSolve(solver, y0, ts, extra0), y0.device)
+        if not captured.stable:
+            warnings.warn(f"hip_graph=True: {_UNSTABLE}; running eagerly.")
+            captured = _Refused(_UNSTABLE)
         _remember(cache, sig, captured)
+        if isinstance(captured, _Refused):
+            solver._extra = tuple(extra0)
+            return solver._run(solver._plan(y0, ts), y0), solver._extra
         return captured.result()
+    if isinstance(captured, _Refused):
+        solver._extra = tuple(extra0)
+        return solver._run(solver._plan(y0, ts), y0), solver._extra
     return captured.replay(bm, y0, extra0)
 
 
@@ -643,10 +674,13 @@ class _CapturedBackward:
             self.graph = torch.cuda.CUDAGraph()
             with _capturing(self.graph, device):
                 self.out = list(run(*self.static))
-            if verify:          # "auto": a replay on the same inputs must give the eager sweep's gradients
-                self._load(bm, inputs)
-                self.graph.replay()
-                self.verified = _same_tensors(self.out, warm, exact=False)
+            # a first replay, then the check that later ones repeat it (replays_are_stable); "auto" also wants the first
+            # one to give the eager sweep's gradients
+            self._load(bm, inputs)
+            self.graph.replay()
+            self.stable = replays_are_stable(self.graph.replay, self.outputs)
+            if verify:
+                self.verified = self.stable and _same_tensors(self.out, warm, exact=False)
         finally:
             bm._entropy_dev = None
 
@@ -685,9 +719,12 @@ def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None)
         captured = cache.get(sig)
         if captured is None:
             captured = capture()
+            if captured is not None and not captured.stable:
+                warnings.warn(f"adjoint_options['hip_graph']=True: {_UNSTABLE}; the backward pass runs eagerly.")
+                captured = _Refused(_UNSTABLE)
             if captured is not None:
                 _remember(cache, sig, captured)
-        return captured
+        return None if isinstance(captured, _Refused) else captured
     state = python_state(base)
     if state is None:
         return None, None
@@ -712,7 +749,8 @@ def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None)
             cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")
         else:
             cache[sig] = captured if captured is not None and captured.verified else \
-                _Refused("the captured sweep did not reproduce the eager one")
+                _Refused(_UNSTABLE if captured is not None and not captured.stable else
+                         "the recorded sweep did not reproduce the eager one")
         entry = cache[sig]
         return (entry if isinstance(entry, _CapturedBackward) else None), None
     return entry, None
@@ -776,6 +814,15 @@ class _CapturedTrainingSolve:
                 self.cotangents = [torch.zeros_like(o) for o in self.outs]
                 with _capturing(self.bwd_graph, device, pool=self.fwd_graph.pool()):
                     self.grads = backward(self.outs, self.cotangents)
+            # forward + backward replayed a few times with all-ones cotangents must keep giving the same gradients
+            for c in self.cotangents:
+                c.fill_(1.0)
+
+            def both():
+                self.fwd_graph.replay()
+                self.bwd_graph.replay()
+            both()
+            self.stable = replays_are_stable(both, lambda: list(self.outs) + list(self.grads))
         finally:
             bm._entropy_dev = None
 
@@ -874,9 +921,14 @@ def replay_or_capture_training(solver, y0, ts, extra0, params):
             finally:
                 if parallel_allowed:
                     solver.sde.overlap_f_g = True
+            if not captured.stable:
+                raise _NotCapturable(_UNSTABLE)
         except _NotCapturable as e:
             warnings.warn(f"hip_graph=True: {e}; running eagerly.")
+            _remember(cache, sig, _Refused(str(e)))
             return None
         _remember(cache, sig, captured)
+    if isinstance(captured, _Refused):
+        return None
     outs = _GraphedSolve.apply(captured, bm, len(extra0), y0, *extra0, *params)
     return outs[0], tuple(outs[1:])
