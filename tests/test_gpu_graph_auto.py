@@ -349,3 +349,30 @@ def test_a_reduction_in_the_drift_replays_stably_or_not_at_all():
         for opts in (None, {"hip_graph": True}):
             for entropy in (1, 2, 3, 4, 5):
                 assert torch.equal(solve(entropy, opts), solve(entropy, {"hip_graph": False})), (opts, entropy)
+
+
+def test_training_graphs_at_a_batch_with_multi_block_reductions():
+    """`options={"hip_graph": True}` with autograd THROUGH the solver (forward and backward recorded as two graphs): at
+    B = 4096, d = 128 the parameter gradients are multi-block column sums -- the case the replay checks exist for.
+    Gradients must equal the eager ones on every iteration."""
+    import torchsde_amd
+    Bb, Dd = 4096, 128
+    sde = problems.make("mlpdiag_ito", d=Dd).to(DEV)
+    ts = torch.tensor([0.0, 8 * DT], device=DEV)
+
+    def grads(entropy, opts):
+        y0 = torch.full((Bb, Dd), 0.1, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 8 * DT, size=(Bb, Dd), device=DEV, dtype=torch.float32, entropy=entropy)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=DT, options=opts)
+        sde.zero_grad()
+        ys[-1].sum().backward()
+        return [y0.grad] + [p.grad.clone() for p in sde.parameters()]
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for entropy in (1, 2, 3, 4):
+            got = grads(entropy, {"hip_graph": True})
+            want = grads(entropy, {"hip_graph": False})
+            for a, e in zip(got, want):
+                assert torch.isfinite(a).all()
+                torch.testing.assert_close(a, e, rtol=1e-3, atol=1e-3 * e.abs().max().item())

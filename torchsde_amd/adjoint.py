@@ -492,12 +492,24 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                 a_y, a_theta = _run_backward_adaptive(AdjointSDE(ctx.sde, adjoint_params), kind, ctx.bm,
                                                       timegrid.ts_to_host(ts), ctx.dt, rtol, atol, dt_min, ys, grad_ys)
                 out = [a_y] + list(a_theta)
-        elif captured is not None:
+        elif captured is not None and not getattr(captured, "broken", False):
             out = captured.replay(ctx.bm, inputs)
+            if captured.probation > 0:
+                # A recorded sweep has passed its checks at recording time (graph.replays_are_stable); its first replays
+                # in real use are still compared with the eager sweep -- the fault those checks exist for shows only
+                # after other work has run on the device -- and a graph that fails is never replayed again.
+                captured.probation -= 1
+                kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
+                run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
+                eager = run(*inputs)
+                from . import graph
+                if not graph._same_tensors(out, eager, exact=False):
+                    captured.broken = True
+                    out = eager
         else:
             kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
             run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
-            if ctx.watch_backward is not None:
+            if ctx.watch_backward is not None and captured is None:
                 from . import graph
                 verdict = {}
                 out, reason = graph.run_screened(lambda: run(*inputs), verdict)

@@ -318,17 +318,21 @@ class _OperatorRecorder(TorchDispatchMode):
         return result
 
 
-def replays_are_stable(replay, outputs, extra_replays=2):
-    """Does replaying a freshly recorded graph on the same inputs keep giving what its first replay gave? It should,
-    trivially -- but on this stack (ROCm 7.2, torch 2.10) a graph that contains several multi-block torch reductions
-    (`x.sum(0)` over a few thousand rows: the parameter gradients of a broadcast `w * y`) is right on its FIRST replay
-    and wrong, stably, on every later one (tools/probe_graph_reduction2.py, profiles/r3j_probe_graph_reduction.txt:
-    twenty column sums of a 4096 x 128 tensor in one graph are 23 % off from the second replay on; the backward sweep of
-    `sdeint_adjoint` at B = 4096, d = 128 returned inf for per-channel parameters). Nothing this package can repair, so
-    every graph it records is checked before it is trusted: `replay()` runs the graph, `outputs()` lists its result
-    tensors. NaN in the same place counts as equal."""
+def replays_are_stable(replay, outputs, disturb=None, extra_replays=2):
+    """Does replaying a freshly recorded graph keep giving what its first replay gave -- also after other work has run
+    on the device in between? It should, trivially. But on this stack (ROCm 7.2, torch 2.10) a graph that holds several
+    multi-block torch reductions (`x.sum(0)` over a few thousand rows: the parameter gradients of a broadcast `w * y`)
+    is right when first replayed and wrong, stably, once eager work has run between two replays
+    (tools/probe_graph_reduction2.py, profiles/r3j_probe_graph_reduction.txt: twenty column sums of a 4096 x 128 tensor
+    in one graph are 23 % off from the second replay on; the backward sweep of `sdeint_adjoint` at B = 4096, d = 128
+    returned inf for per-channel parameters). Nothing this package can repair, so every graph it records is checked
+    before it is trusted: `replay()` runs the graph, `outputs()` lists its result tensors, `disturb()` runs the same
+    computation eagerly (allocations, reductions and all: what a caller does between two solves) before each further
+    replay. NaN in the same place counts as equal."""
     first = [o.clone() for o in outputs()]
     for _ in range(extra_replays):
+        if disturb is not None:
+            disturb()
         replay()
         if not _same_tensors(outputs(), first, exact=True):
             return False
@@ -435,7 +439,7 @@ def auto_solve(solver, y0, ts, extra0=()):
             return captured.eager_result
         cache[sig] = captured
         return captured.result()
-    return entry.replay(bm, y0, extra0)
+    return _replay_on_probation(entry, cache, sig, solver, bm, y0, ts, extra0)
 
 
 def _replay_ms(graphs, device, max_rounds=4):
@@ -518,8 +522,25 @@ def _capturing(graph, device, **kwargs):
         raise
 
 
+def _replay_on_probation(captured, cache, sig, solver, bm, y0, ts, extra0):
+    """Replay a recorded forward solve; while it is on probation (its first replays in real use) also run the solve
+    eagerly and compare: the fault `replays_are_stable` looks for shows only after other work has run on the device. A
+    graph that fails is dropped for good and the eager result returned."""
+    out = captured.replay(bm, y0, extra0)
+    if captured.probation > 0:
+        captured.probation -= 1
+        solver._extra = tuple(extra0)
+        eager = solver._run(solver._plan(y0, ts), y0)
+        eager_extra = tuple(solver._extra)
+        if not _same_tensors([out[0]] + list(out[1]), [eager] + list(eager_extra)):
+            cache[sig] = _Refused(_UNSTABLE)
+            return eager, eager_extra
+    return out
+
+
 class _CapturedSolve:
     exact_outputs = True
+    probation = 2
 
     def outputs(self):
         return [self.ys] + list(self.extra_out)
@@ -559,7 +580,15 @@ class _CapturedSolve:
         finally:
             bm._entropy_dev = None
         self.graph.replay()     # capture only records: run once so that `ys` holds this solve's result
-        self.stable = replays_are_stable(self.graph.replay, self.outputs)
+
+        def eagerly():
+            solver._extra = tuple(self.extra_in)
+            solver._run(self.plan, self.y_in)
+        bm._entropy_dev = self.seed_dev
+        try:
+            self.stable = replays_are_stable(self.graph.replay, self.outputs, eagerly)
+        finally:
+            bm._entropy_dev = None
         if verify:              # "auto": the replay must be the eager solve it was recorded beside, bit for bit
             self.verified = self.stable and _same_tensors(self.outputs(), [warm] + list(warm_extra))
             self.eager_result = None if self.verified else (warm, warm_extra)
@@ -638,7 +667,7 @@ def replay_or_capture(solver, y0, ts, extra0=()):
     if isinstance(captured, _Refused):
         solver._extra = tuple(extra0)
         return solver._run(solver._plan(y0, ts), y0), solver._extra
-    return captured.replay(bm, y0, extra0)
+    return _replay_on_probation(captured, cache, sig, solver, bm, y0, ts, extra0)
 
 
 class _CapturedBackward:
@@ -649,6 +678,7 @@ class _CapturedBackward:
     (device word) and the parameters themselves (read in place: an optimiser step is seen by the next replay)."""
 
     exact_outputs = False     # autograd orders the sums of a recorded sweep by per-thread sequence numbers
+    probation = 2             # the first replays in real use are checked against the eager sweep (adjoint._backward)
 
     def outputs(self):
         return list(self.out)
@@ -678,7 +708,7 @@ class _CapturedBackward:
             # one to give the eager sweep's gradients
             self._load(bm, inputs)
             self.graph.replay()
-            self.stable = replays_are_stable(self.graph.replay, self.outputs)
+            self.stable = replays_are_stable(self.graph.replay, self.outputs, lambda: run(*self.static))
             if verify:
                 self.verified = self.stable and _same_tensors(self.out, warm, exact=False)
         finally:
@@ -822,7 +852,11 @@ class _CapturedTrainingSolve:
                 self.fwd_graph.replay()
                 self.bwd_graph.replay()
             both()
-            self.stable = replays_are_stable(both, lambda: list(self.outs) + list(self.grads))
+
+            def eagerly():
+                with torch.enable_grad():
+                    backward(forward(), self.cotangents)
+            self.stable = replays_are_stable(both, lambda: list(self.outs) + list(self.grads), eagerly)
         finally:
             bm._entropy_dev = None
 
