@@ -437,7 +437,7 @@ def auto_solve(solver, y0, ts, extra0=()):
         if not captured.verified:
             cache[sig] = _Refused(_UNSTABLE if not captured.stable else "the recorded graph did not reproduce the eager solve")
             return captured.eager_result
-        cache[sig] = captured
+        cache[sig] = captured.accept()
         return captured.result()
     return _replay_on_probation(entry, cache, sig, solver, bm, y0, ts, extra0)
 
@@ -505,6 +505,10 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
         parallel = None
         keep, tuning["kept"] = sequential, "sequential"
     keep.tuning = tuning
+    if not keep.still_right():      # (the timing replays ran next to another graph: the fault of replays_are_stable)
+        keep.stable = False
+        if hasattr(keep, "verified"):
+            keep.verified = False
     return keep
 
 
@@ -589,9 +593,21 @@ class _CapturedSolve:
             self.stable = replays_are_stable(self.graph.replay, self.outputs, eagerly)
         finally:
             bm._entropy_dev = None
+        # what the outputs must (still) be after any further replay on these inputs -- `still_right`, asked again after
+        # the tuner has replayed this graph next to another one: the eager solve ("auto"), else the first replay
+        self.reference = [warm] + list(warm_extra) if verify else [o.clone() for o in self.outputs()]
         if verify:              # "auto": the replay must be the eager solve it was recorded beside, bit for bit
-            self.verified = self.stable and _same_tensors(self.outputs(), [warm] + list(warm_extra))
-            self.eager_result = None if self.verified else (warm, warm_extra)
+            self.verified = self.stable and self.still_right()
+            self.eager_result = (warm, warm_extra)
+
+    def still_right(self):
+        return _same_tensors(self.outputs(), self.reference, exact=True)
+
+    def accept(self):
+        """Checks passed: let go of the reference copies."""
+        self.reference = None
+        self.eager_result = None
+        return self
 
     def _set_seed(self, bm):
         key = bm._key
@@ -659,6 +675,8 @@ def replay_or_capture(solver, y0, ts, extra0=()):
         if not captured.stable:
             warnings.warn(f"hip_graph=True: {_UNSTABLE}; running eagerly.")
             captured = _Refused(_UNSTABLE)
+        else:
+            captured.accept()
         _remember(cache, sig, captured)
         if isinstance(captured, _Refused):
             solver._extra = tuple(extra0)
@@ -709,10 +727,19 @@ class _CapturedBackward:
             self._load(bm, inputs)
             self.graph.replay()
             self.stable = replays_are_stable(self.graph.replay, self.outputs, lambda: run(*self.static))
+            self.reference = warm if verify else [o.clone() for o in self.out]
+            self.exact_reference = not verify      # (eager sweep: autograd's summation order; own first replay: exact)
             if verify:
-                self.verified = self.stable and _same_tensors(self.out, warm, exact=False)
+                self.verified = self.stable and self.still_right()
         finally:
             bm._entropy_dev = None
+
+    def still_right(self):
+        return _same_tensors(self.out, self.reference, exact=self.exact_reference)
+
+    def accept(self):
+        self.reference = None
+        return self
 
     def _load(self, bm, inputs):
         for dst, src in zip(self.static, inputs):
@@ -752,6 +779,8 @@ def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None)
             if captured is not None and not captured.stable:
                 warnings.warn(f"adjoint_options['hip_graph']=True: {_UNSTABLE}; the backward pass runs eagerly.")
                 captured = _Refused(_UNSTABLE)
+            elif captured is not None:
+                captured.accept()
             if captured is not None:
                 _remember(cache, sig, captured)
         return None if isinstance(captured, _Refused) else captured
@@ -778,7 +807,7 @@ def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None)
             captured = None
             cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")
         else:
-            cache[sig] = captured if captured is not None and captured.verified else \
+            cache[sig] = captured.accept() if captured is not None and captured.verified else \
                 _Refused(_UNSTABLE if captured is not None and not captured.stable else
                          "the recorded sweep did not reproduce the eager one")
         entry = cache[sig]
