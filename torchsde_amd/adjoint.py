@@ -827,7 +827,12 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
     from . import graph
     graph_mode = graph.mode_of(adjoint_options)
-    if graph_mode == "auto" and not (isinstance(sde, nn.Module) and graph._auto_eligible(bm, y0, len(ts))):
+    # "auto" records the backward sweep only for batches of at most 1024 rows: the parameter gradients of a sweep are
+    # sums over the batch, torch computes longer ones with multi-block reductions, and those are what replays wrongly
+    # on this stack (graph.replays_are_stable) -- the checks catch it, but a training loop should not depend on that;
+    # small batches are also where the launch overhead a graph removes is the cost that matters
+    if graph_mode == "auto" and not (isinstance(sde, nn.Module) and graph._auto_eligible(bm, y0, len(ts))
+                                     and y0.shape[0] <= graph._AUTO_MAX_BACKWARD_ROWS):
         graph_mode = False
     if graph_mode and not adjoint_adaptive and ys.grad_fn is not None and isinstance(bm, BrownianInterval):
         # The backward sweep replays ONE HIP graph, captured HERE (on the caller's thread, outside the autograd

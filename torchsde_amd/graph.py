@@ -115,6 +115,7 @@ def _remember(cache, sig, captured):
 # ---- "auto" mode ------------------------------------------------------------------------------------------------------
 _AUTO_MAX_STATE = 1 << 23               # elements of y0 above which "auto" stays eager
 _AUTO_MAX_OUTPUT_BYTES = 1 << 30        # ... or bytes of ys
+_AUTO_MAX_BACKWARD_ROWS = 1024          # batch rows above which "auto" leaves the adjoint's backward sweep eager
 
 
 def mode_of(options, key="hip_graph"):
