@@ -208,6 +208,15 @@ class Job:
                 return self.gathered
             return ys[-1]
 
+    def prepare(self):
+        """Everything a first solve pays once, before any warm-up or timing: recording the HIP graph(s) of this workload
+        (with the checks that come with it) and their probation -- the first two replays of a recorded graph run next
+        to the eager path and are compared with it (torchsde_amd/graph.py)."""
+        if self.use_graph:
+            for i in range(4):
+                self.solve(9000 + i)
+            torch.cuda.synchronize()
+
     def live_state(self, out):
         """A state tensor of this workload's shape with live values: the solve's final state where `out` is one."""
         B, d = self.cfg["B"], self.cfg["d"]
@@ -472,6 +481,7 @@ def _side_measurement(dev, name):
         job.cfg = dict(job.cfg, nsteps=budget)
         job.ts = torch.tensor([0.0, budget * job.cfg["dt"]], device=dev)
     c = job.cfg
+    job.prepare()
     for i in range(2):
         job.solve(i)
     torch.cuda.synchronize()
@@ -637,6 +647,7 @@ def main():
         return
     cfg = job.cfg
     B, d, m, nsteps, dt = cfg["B"], cfg["d"], cfg["m"], cfg["nsteps"], cfg["dt"]
+    job.prepare()
 
     def barrier():
         if use_dist:

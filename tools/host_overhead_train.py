@@ -52,12 +52,12 @@ for name, fn, method, sde_type, kw in cases:       # every launch issued eagerly
 
 for name, fn, method, sde_type, kw in cases:       # NO options: the drop-in call (hip_graph = "auto")
     go = iteration(fn, method, sde_type, **kw)
-    for i in range(3):                             # eager + watched, capture, first replay
+    for i in range(5):                             # eager + screened, recording, first replays (on probation)
         go(i)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(5):
-        go(3 + i)
+        go(5 + i)
     torch.cuda.synchronize()
     print(f"{name + ' [no options]':40s} fwd+bwd per solver step: {(time.perf_counter() - t) / 5 / n * 1e6:7.1f} us")
     for line in graph.describe_cache(go.sde):
@@ -81,8 +81,8 @@ for name, fn, method, sde_type, kw in cases:
     if fn is not torchsde_amd.sdeint_adjoint:
         continue
     go = iteration(fn, method, sde_type, options={"hip_graph": True}, adjoint_options={"hip_graph": True}, **kw)
-    go(0)
-    go(1)
+    for i in range(4):                             # recording, probation
+        go(20 + i)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(5):
