@@ -498,3 +498,32 @@ def test_screening_tells_independent_drift_and_diffusion_from_code_that_shares_m
     rec = screen(problems.make("gbm_ito", d=4), extra=lambda: torch.linalg.pinv(torch.rand(3, 3)))
     assert any("pinv" in op or "svd" in op for op in rec.unknown)
     assert not graph._OperatorRecorder().independent()            # no drift / diffusion pair seen: not independent
+
+
+def test_graph_cache_is_bounded_in_entries_and_bytes():
+    from torchsde_amd import graph
+
+    class Fake:
+        def __init__(self, nbytes):
+            self._t = torch.empty(nbytes // 4)
+
+        def outputs(self):
+            return [self._t]
+
+    cache = graph._GraphCache()
+    old_limit = graph._MAX_PINNED_BYTES
+    graph._MAX_PINNED_BYTES = 4000
+    try:
+        for k in range(6):
+            graph._remember(cache, ("sig", k), Fake(1000))
+        assert list(cache) == [("sig", k) for k in (2, 3, 4, 5)]         # 4 x 1000 bytes fit, the oldest two went
+        graph._remember(cache, ("big",), Fake(10000))                     # larger than the budget by itself: kept alone
+        assert list(cache) == [("big",)]
+    finally:
+        graph._MAX_PINNED_BYTES = old_limit
+    cache = graph._GraphCache()
+    for k in range(graph._MAX_GRAPHS_PER_SDE + 5):
+        graph._remember(cache, k, graph._Seen())
+    assert len(cache) == graph._MAX_GRAPHS_PER_SDE
+    import copy
+    assert len(copy.deepcopy(cache)) == 0

@@ -104,12 +104,31 @@ def describe_cache(sde):
     return lines
 
 
+_MAX_PINNED_BYTES = 8 << 30      # of result buffers of recorded graphs kept on ONE SDE object
+
+
+def _pinned_bytes(entry):
+    """Rough size of what a cache entry keeps allocated (its result buffers; the graph's pool is a small multiple)."""
+    outs = getattr(entry, "outputs", None)
+    if outs is None:
+        return 0
+    try:
+        return sum(o.numel() * o.element_size() for o in outs())
+    except Exception:
+        return 0
+
+
 def _remember(cache, sig, captured):
     """Each captured graph pins its memory pool; a caller that keeps changing the structure (e.g. random `ts`) must
-    not grow the cache without bound: the oldest entry goes first."""
+    not grow the cache without bound -- neither in entries nor in bytes: the oldest entries go first."""
     while len(cache) >= _MAX_GRAPHS_PER_SDE:
         cache.pop(next(iter(cache)))
     cache[sig] = captured
+    total = sum(_pinned_bytes(v) for v in cache.values())
+    for key in list(cache):
+        if total <= _MAX_PINNED_BYTES or key == sig:
+            break
+        total -= _pinned_bytes(cache.pop(key))
 
 
 # ---- "auto" mode ------------------------------------------------------------------------------------------------------
@@ -417,7 +436,14 @@ def auto_solve(solver, y0, ts, extra0=()):
         plan = solver._plan(y0, ts)
         solver._extra = tuple(extra0)
         verdict = {}
-        ys, reason = run_screened(lambda: solver._run(plan, y0), verdict)
+        try:
+            ys, reason = run_screened(lambda: solver._run(plan, y0), verdict)
+        except Exception as e:
+            # whatever went wrong under the screen (the user's own error, or code that does not run under a dispatch
+            # mode): this structure stays eager, and the plain eager run that follows reports the error if it is real
+            _remember(cache, sig, _Refused(f"the screened run raised {type(e).__name__}"))
+            solver._extra = tuple(extra0)
+            return None
         _remember(cache, sig, _Seen(verdict["independent"]) if reason is None else _Refused(reason))
         return ys, solver._extra
     if isinstance(entry, _Refused):
