@@ -484,6 +484,12 @@ int tsde_prof_begin(int kid, int capacity);
 /* The per-launch times (ms) recorded so far, in launch order (`*used` of them, at most `capacity`); synchronises on
  * them. Call before tsde_prof_end. */
 int tsde_prof_read(double* ms, int capacity, int* used);
+/* Launch graphs (no counterpart in the reference, whose loop `_core/base_solver.py:114-134` launches step by step): in a
+ * captured, NOT YET INSTANTIATED hipGraph_t, replaces every 1-D memset node by a kernel node that fills the same bytes,
+ * with the same incoming and outgoing edges. `*n_memset` = memset nodes found, `*n_replaced` = replaced (2-D memsets are
+ * left alone). Needed because recorded memset nodes -- ATen's reductions zero their semaphores with one -- stop working
+ * on this runtime once eager memsets and a host synchronisation have come between two replays (csrc/graph_nodes.hip). */
+int tsde_graph_memset_nodes_to_kernels(void* hip_graph, int* n_memset, int* n_replaced);
 /* Occupies `stream` with a single-thread kernel for about `microseconds` (<= 2 s). bench.py queues one before
  * its event-timed pass so that the host can enqueue the whole solve first and no bracket contains queue-empty
  * time. */

@@ -103,6 +103,37 @@ def test_code_that_synchronises_with_the_host_stays_eager_silently():
     assert torch.cuda.get_sync_debug_mode() == 0
 
 
+class _ShyOfDispatchModes(_Scaled):
+    def f(self, t, y):
+        from torch.utils._python_dispatch import _get_current_dispatch_mode
+        if _get_current_dispatch_mode() is not None:       # code that cannot run under the screen (the reference has none)
+            raise RuntimeError("not under a dispatch mode")
+        return self.mu * y
+
+
+def test_code_that_fails_under_the_screen_runs_eagerly_as_before():
+    from torchsde_amd import graph
+    sde = _ShyOfDispatchModes().to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    for entropy in (1, 2, 3):
+        assert torch.equal(_solve(sde, entropy, y0, False), _solve(sde, entropy, y0, True))
+    assert not _entries(sde, graph._CapturedSolve)
+    assert any("raised RuntimeError" in line for line in graph.describe_cache(sde))
+    # ... and in the adjoint's backward sweep
+    import torchsde_amd
+    ts = torch.tensor([0.0, STEPS * DT], device=DEV)
+    grads = []
+    for options in (None, {"hip_graph": False}):
+        for p in sde.parameters():
+            p.grad = None
+        for _ in range(2):
+            ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=_bm(5), method="euler", dt=DT, options=options,
+                                             adjoint_options=options)
+            ys[-1].sum().backward()
+        grads.append(sde.mu.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
 _CALLS = []
 
 
@@ -294,14 +325,17 @@ def test_operators_outside_the_known_family_are_never_recorded():
     assert "capture-safe" in refused.reason
 
 
+@pytest.mark.parametrize("rewrite", [True, False])
 @pytest.mark.parametrize("explicit", [False, True])
-def test_graphs_that_do_not_replay_stably_are_refused(explicit):
+def test_sweeps_with_multi_block_reductions_are_recorded_right_or_not_at_all(explicit, rewrite):
     """On this stack a HIP graph holding several multi-block torch reductions is right on its first replay and wrong on
-    every later one (tools/probe_graph_reduction2.py) -- at B = 4096, d = 128 the backward sweep of `sdeint_adjoint`,
-    replayed, returned inf for per-channel parameters. Every recorded graph is therefore replayed a few times before
-    it is trusted (graph.replays_are_stable): gradients must equal the eager ones on EVERY iteration, with no options
-    and with hip_graph=True (which warns and runs eagerly), whatever the allocator and the reductions do."""
+    later ones (tools/probe_graph_reduction2.py) -- at B = 4096, d = 128 the backward sweep of `sdeint_adjoint`,
+    replayed, returned inf for per-channel parameters. The nodes at fault are the memset nodes of those reductions:
+    `graph._capturing` rewrites them as kernels (csrc/graph_nodes.hip), and then the recorded sweep IS replayed, with the
+    eager gradients on EVERY iteration. With the rewriting switched off the second line of defence has to hold: the
+    graph fails `graph.replays_are_stable` and the sweep stays eager (hip_graph=True warns) -- same gradients."""
     import torchsde_amd
+    from torchsde_amd import graph
     Bb, Dd = 4096, 128
     sde = problems.make("mlpdiag_ito", d=Dd).to(DEV)
     ts = torch.tensor([0.0, 8 * DT], device=DEV)
@@ -315,14 +349,68 @@ def test_graphs_that_do_not_replay_stably_are_refused(explicit):
         ys[-1].sum().backward()
         return [y0.grad] + [p.grad.clone() for p in sde.parameters()]
 
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        for entropy in (1, 2, 3, 4, 5):
-            got = grads(entropy, {"hip_graph": True} if explicit else None)
-            want = grads(entropy, {"hip_graph": False})
-            for a, e in zip(got, want):
-                assert torch.isfinite(a).all()
-                torch.testing.assert_close(a, e, rtol=1e-3, atol=1e-3 * e.abs().max().item())
+    graph._REWRITE_MEMSET_NODES = rewrite
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for entropy in (1, 2, 3, 4, 5):
+                got = grads(entropy, {"hip_graph": True} if explicit else None)
+                want = grads(entropy, {"hip_graph": False})
+                for a, e in zip(got, want):
+                    assert torch.isfinite(a).all()
+                    torch.testing.assert_close(a, e, rtol=1e-3, atol=1e-3 * e.abs().max().item())
+    finally:
+        graph._REWRITE_MEMSET_NODES = True
+    sweeps = _entries(sde, graph._CapturedBackward)
+    if rewrite:
+        (sweep,) = sweeps
+        found, rewritten = sweep.graph.memset_nodes
+        assert found > 0 and rewritten == found and not getattr(sweep, "broken", False)
+    else:
+        assert not sweeps and any("memset" in r.reason for r in _entries(sde, graph._Refused))
+
+
+def test_recorded_memset_nodes_become_kernels_with_the_same_effect():
+    """`tsde_graph_memset_nodes_to_kernels` on a graph of [memset, kernel] pairs (1-, 2- and 4-byte elements, odd sizes):
+    the rewritten graph has no memset node left and computes what the eager sequence computes."""
+    import ctypes
+    import os
+    from torchsde_amd import graph
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetD16Async.argtypes = [ctypes.c_void_p, ctypes.c_ushort, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    buf = torch.zeros(5000, dtype=torch.int32, device=DEV)
+
+    def sequence():
+        stream = torch.cuda.current_stream().cuda_stream
+        acc = torch.zeros(5000, dtype=torch.int64, device=DEV)
+        buf.fill_(7)
+        assert hip.hipMemsetAsync(buf.data_ptr() + 4, 0xAB, 1237, stream) == 0                 # bytes, odd count
+        acc = acc + buf
+        assert hip.hipMemsetD32Async(buf.data_ptr() + 8000, 0x01020304, 999, stream) == 0      # 4-byte elements
+        acc = acc * 3 + buf
+        assert hip.hipMemsetD16Async(buf.data_ptr() + 12000, 0xBEEF, 1001, stream) == 0        # 2-byte elements
+        acc = acc * 5 + buf
+        assert hip.hipMemsetAsync(buf.data_ptr(), 0, 20000, stream) == 0                       # all of it
+        return acc * 7 + buf
+
+    want = sequence().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sequence()
+    torch.cuda.current_stream().wait_stream(side)
+    g = graph.new_graph()
+    with graph._capturing(g, torch.device(DEV)):
+        out = sequence()
+    found, rewritten = g.memset_nodes
+    assert found >= 4 and rewritten == found
+    for _ in range(3):
+        buf.fill_(-1)
+        g.replay()
+        assert torch.equal(out, want)
+        assert int(buf.abs().max()) == 0
 
 
 def test_a_reduction_in_the_drift_replays_stably_or_not_at_all():

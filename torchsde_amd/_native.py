@@ -145,6 +145,7 @@ SIGNATURES = {
                                          _c_int, _c_ptr, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
+    "tsde_graph_memset_nodes_to_kernels": (_c_int, [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),
     "tsde_prof_read": (_c_int, [ctypes.POINTER(_c_dbl), _c_int, ctypes.POINTER(_c_int)]),
     "tsde_prof_end": (_c_int, [ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),

@@ -211,7 +211,7 @@ class _GraphedAttempt(_Attempt):
                 self._launch(solver, bm)
             torch.cuda.current_stream(device).wait_stream(side)
             from . import graph as graph_module
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = graph_module.new_graph()
             with graph_module._capturing(self.graph, device):
                 self._launch(solver, bm)
         finally:

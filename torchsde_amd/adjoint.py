@@ -512,8 +512,15 @@ class _SdeintAdjointMethod(torch.autograd.Function):
             if ctx.watch_backward is not None and captured is None:
                 from . import graph
                 verdict = {}
-                out, reason = graph.run_screened(lambda: run(*inputs), verdict)
-                ctx.watch_backward(reason, verdict["independent"])
+                try:
+                    out, reason = graph.run_screened(lambda: run(*inputs), verdict)
+                except Exception as e:
+                    # the user's own error, or code that does not run under the screen: this structure stays eager, and
+                    # the plain sweep reports the error if it is real
+                    ctx.watch_backward(f"the screened sweep raised {type(e).__name__}")
+                    out = run(*inputs)
+                else:
+                    ctx.watch_backward(reason, verdict["independent"])
             else:
                 out = run(*inputs)
         if reversible:      # a_y, (a_f, a_g, a_z), a_theta...
@@ -827,12 +834,10 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
     from . import graph
     graph_mode = graph.mode_of(adjoint_options)
-    # "auto" records the backward sweep only for batches of at most 1024 rows: the parameter gradients of a sweep are
-    # sums over the batch, torch computes longer ones with multi-block reductions, and those are what replays wrongly
-    # on this stack (graph.replays_are_stable) -- the checks catch it, but a training loop should not depend on that;
-    # small batches are also where the launch overhead a graph removes is the cost that matters
-    if graph_mode == "auto" and not (isinstance(sde, nn.Module) and graph._auto_eligible(bm, y0, len(ts))
-                                     and y0.shape[0] <= graph._AUTO_MAX_BACKWARD_ROWS):
+    # (the parameter gradients of a sweep are sums over the batch; above ~1000 rows torch computes them with multi-block
+    #  reductions, whose semaphore memsets are the graph nodes that go wrong on this runtime: graph._capturing rewrites
+    #  them as kernels, and the recorded sweep still has to pass graph.replays_are_stable and its probation)
+    if graph_mode == "auto" and not (isinstance(sde, nn.Module) and graph._auto_eligible(bm, y0, len(ts))):
         graph_mode = False
     if graph_mode and not adjoint_adaptive and ys.grad_fn is not None and isinstance(bm, BrownianInterval):
         # The backward sweep replays ONE HIP graph, captured HERE (on the caller's thread, outside the autograd

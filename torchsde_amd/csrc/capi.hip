@@ -637,6 +637,12 @@ __global__ void delay_kernel(long long ticks) {
 }
 }  // namespace
 
+int tsde_graph_memset_nodes_to_kernels(void* hip_graph, int* n_memset, int* n_replaced) {
+  if (!hip_graph || !n_memset || !n_replaced) return bad_arg("tsde_graph_memset_nodes_to_kernels", "null argument");
+  return fail(tsde::memset_nodes_to_kernels((hipGraph_t)hip_graph, n_memset, n_replaced),
+              "tsde_graph_memset_nodes_to_kernels");
+}
+
 int tsde_delay_us(double microseconds, void* stream) {
   if (!(microseconds >= 0.0) || microseconds > 2.0e6) return bad_arg("tsde_delay_us", "delay must be in [0, 2 s]");
   hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long)(microseconds * 100.0));

@@ -140,4 +140,6 @@ hipError_t launch_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_
                                    int32_t k_hi, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, int64_t lda, const void* Bm, int64_t ldb,
                                 int64_t K, int64_t M, int64_t N, int32_t blocks, hipStream_t s);
+// graph_nodes.hip: memset nodes of a captured, not yet instantiated graph -> fill-kernel nodes with the same edges
+hipError_t memset_nodes_to_kernels(hipGraph_t graph, int* n_memset, int* n_replaced);
 }  // namespace tsde

@@ -121,7 +121,7 @@ def _pinned_bytes(entry):
 def _remember(cache, sig, captured):
     """Each captured graph pins its memory pool; a caller that keeps changing the structure (e.g. random `ts`) must
     not grow the cache without bound -- neither in entries nor in bytes: the oldest entries go first."""
-    while len(cache) >= _MAX_GRAPHS_PER_SDE:
+    while sig not in cache and len(cache) >= _MAX_GRAPHS_PER_SDE:
         cache.pop(next(iter(cache)))
     cache[sig] = captured
     total = sum(_pinned_bytes(v) for v in cache.values())
@@ -134,7 +134,6 @@ def _remember(cache, sig, captured):
 # ---- "auto" mode ------------------------------------------------------------------------------------------------------
 _AUTO_MAX_STATE = 1 << 23               # elements of y0 above which "auto" stays eager
 _AUTO_MAX_OUTPUT_BYTES = 1 << 30        # ... or bytes of ys
-_AUTO_MAX_BACKWARD_ROWS = 1024          # batch rows above which "auto" leaves the adjoint's backward sweep eager
 
 
 def mode_of(options, key="hip_graph"):
@@ -185,7 +184,11 @@ def python_state(obj, budget=4096):
         if isinstance(x, _SIMPLE):
             out.append(x)
         elif torch.is_tensor(x):
-            out.append(("T", x.data_ptr(), tuple(x.shape), x.dtype, x.requires_grad))
+            try:
+                where = x.data_ptr()
+            except Exception:           # sparse / nested layouts have no single data pointer: identity of the object
+                where = ("O", id(x))
+            out.append(("T", where, tuple(x.shape), x.dtype, x.requires_grad))
         elif id(x) in seen or depth > 8:
             out.append(("O", id(x)))
         elif isinstance(x, (list, tuple, set, frozenset)):
@@ -342,10 +345,13 @@ def replays_are_stable(replay, outputs, disturb=None, extra_replays=2):
     """Does replaying a freshly recorded graph keep giving what its first replay gave -- also after other work has run
     on the device in between? It should, trivially. But on this stack (ROCm 7.2, torch 2.10) a graph that holds several
     multi-block torch reductions (`x.sum(0)` over a few thousand rows: the parameter gradients of a broadcast `w * y`)
-    is right when first replayed and wrong, stably, once eager work has run between two replays
-    (tools/probe_graph_reduction2.py, profiles/r3j_probe_graph_reduction.txt: twenty column sums of a 4096 x 128 tensor
-    in one graph are 23 % off from the second replay on; the backward sweep of `sdeint_adjoint` at B = 4096, d = 128
-    returned inf for per-channel parameters). Nothing this package can repair, so every graph it records is checked
+    is right when first replayed and wrong, stably, once an eager reduction and a host synchronisation have come between
+    two replays (tools/probe_graph_reduction2.py, profiles/r3j_probe_graph_reduction.txt: twenty column sums of a
+    4096 x 128 tensor in one graph are 23 % off from the second replay on; the backward sweep of `sdeint_adjoint` at
+    B = 4096, d = 128 returned inf for per-channel parameters). The nodes at fault are the MEMSET nodes with which ATen
+    zeroes the semaphores of such reductions, and `_capturing` rewrites them as kernel nodes, which cures every case
+    found (tools/probe_graph_surgery.py, profiles/r3q_probe_graph_surgery.txt; the runtime flag
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 does too). This check stays as the second line: every recorded graph is verified
     before it is trusted: `replay()` runs the graph, `outputs()` lists its result tensors, `disturb()` runs the same
     computation eagerly (allocations, reductions and all: what a caller does between two solves) before each further
     replay. NaN in the same place counts as equal."""
@@ -359,8 +365,8 @@ def replays_are_stable(replay, outputs, disturb=None, extra_replays=2):
     return True
 
 
-_UNSTABLE = ("replaying the recorded graph does not reproduce its own first replay (a known fault of torch reductions "
-             "under HIP graphs on this stack: graph.replays_are_stable)")
+_UNSTABLE = ("replaying the recorded graph does not reproduce its own first replay (a known fault of recorded memset "
+             "nodes on this runtime: graph.replays_are_stable)")
 
 
 def run_screened(fn, verdict=None):
@@ -464,7 +470,7 @@ def auto_solve(solver, y0, ts, extra0=()):
         if not captured.verified:
             cache[sig] = _Refused(_UNSTABLE if not captured.stable else "the recorded graph did not reproduce the eager solve")
             return captured.eager_result
-        cache[sig] = captured.accept()
+        _remember(cache, sig, captured.accept())
         return captured.result()
     return _replay_on_probation(entry, cache, sig, solver, bm, y0, ts, extra0)
 
@@ -539,11 +545,36 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
     return keep
 
 
+def new_graph():
+    """A torch CUDAGraph that keeps its hipGraph_t after the capture and is instantiated by its first replay, so that
+    `_capturing` can rewrite its memset nodes in between."""
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    graph.memset_nodes = None
+    return graph
+
+
+def _memset_nodes_to_kernels(graph):
+    """Recorded MEMSET nodes -- ATen's multi-block reductions zero their semaphores with `hipMemsetAsync`, so a drift
+    with `y.mean(0)` in it has them, and so has every backward sweep whose parameter gradients are column sums over
+    more rows than one block reduces -- stop doing their work on this runtime once an eager memset and a host
+    synchronisation have come between two replays (tools/probe_graph_reduction4.py; the fault `replays_are_stable`
+    looks for). Kernel nodes do not have the problem: `tsde_graph_memset_nodes_to_kernels` (csrc/graph_nodes.hip) swaps
+    each memset node for a fill kernel with the same edges before the graph is instantiated."""
+    import ctypes
+    from . import _native
+    found, replaced = ctypes.c_int(0), ctypes.c_int(0)
+    _native.check(_native.load().tsde_graph_memset_nodes_to_kernels(
+        ctypes.c_void_p(graph.raw_cuda_graph()), ctypes.byref(found), ctypes.byref(replaced)),
+        "tsde_graph_memset_nodes_to_kernels")
+    graph.memset_nodes = (found.value, replaced.value)
+
+
 @contextlib.contextmanager
 def _capturing(graph, device, **kwargs):
     """`torch.cuda.graph(graph, capture_error_mode="thread_local")` with the cyclic GC paused -- and the caller's stream
     restored when the capture fails: `torch.cuda.graph.__exit__` raises from `capture_end()` BEFORE it leaves its stream
-    context, which would leave every later launch of the process on the dead capture stream."""
+    context, which would leave every later launch of the process on the dead capture stream. Graphs from `new_graph()`
+    have their memset nodes rewritten as kernels once the capture has ended."""
     previous = torch.cuda.current_stream(device)
     try:
         with _no_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local", **kwargs):
@@ -551,6 +582,11 @@ def _capturing(graph, device, **kwargs):
     except BaseException:
         torch.cuda.set_stream(previous)
         raise
+    if hasattr(graph, "memset_nodes") and _REWRITE_MEMSET_NODES:
+        _memset_nodes_to_kernels(graph)
+
+
+_REWRITE_MEMSET_NODES = True     # (tests and tools/probe_graph_surgery.py switch it off to show the fault)
 
 
 def _replay_on_probation(captured, cache, sig, solver, bm, y0, ts, extra0):
@@ -601,7 +637,7 @@ class _CapturedSolve:
             torch.cuda.current_stream(device).wait_stream(side)
             if not verify:
                 del warm, warm_extra
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = new_graph()
             # thread_local: API calls from other threads (e.g. the RCCL watchdog of a multi-GPU run) must not
             # invalidate this capture
             with _capturing(self.graph, device):
@@ -746,7 +782,7 @@ class _CapturedBackward:
             torch.cuda.current_stream(device).wait_stream(side)
             if not verify:
                 del warm
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = new_graph()
             with _capturing(self.graph, device):
                 self.out = list(run(*self.static))
             # a first replay, then the check that later ones repeat it (replays_are_stable); "auto" also wants the first
@@ -834,9 +870,9 @@ def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None)
             captured = None
             cache[sig] = _Refused(f"capture failed: {type(e).__name__}: {e}")
         else:
-            cache[sig] = captured.accept() if captured is not None and captured.verified else \
-                _Refused(_UNSTABLE if captured is not None and not captured.stable else
-                         "the recorded sweep did not reproduce the eager one")
+            _remember(cache, sig, captured.accept() if captured is not None and captured.verified else
+                      _Refused(_UNSTABLE if captured is not None and not captured.stable else
+                               "the recorded sweep did not reproduce the eager one"))
         entry = cache[sig]
         return (entry if isinstance(entry, _CapturedBackward) else None), None
     return entry, None
@@ -894,7 +930,7 @@ class _CapturedTrainingSolve:
                     backward(outs, [torch.zeros_like(o) for o in outs])
                     del outs
                 torch.cuda.current_stream(device).wait_stream(side)
-                self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                self.fwd_graph, self.bwd_graph = new_graph(), new_graph()
                 with _capturing(self.fwd_graph, device):
                     self.outs = forward()
                 self.cotangents = [torch.zeros_like(o) for o in self.outs]
