@@ -1,15 +1,16 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r3m
+TAG=${1:-r3r}
+OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_some.txt 2>&1
 tail -4 $OUT/pytest_some.txt
-timeout 900 bash tools/profile_traffic.sh r3m > $OUT/traffic_summary.txt 2>&1
-cp gpurun_out/traffic_r3m/traffic.json $OUT/traffic.json 2>/dev/null
-cp gpurun_out/traffic_r3m/traffic.json profiles/traffic_latest.json 2>/dev/null
-rm -rf gpurun_out/traffic_r3m
+timeout 900 bash tools/profile_traffic.sh $TAG > $OUT/traffic_summary.txt 2>&1
+cp gpurun_out/traffic_$TAG/traffic.json $OUT/traffic.json 2>/dev/null
+cp gpurun_out/traffic_$TAG/traffic.json profiles/traffic_latest.json 2>/dev/null
+rm -rf gpurun_out/traffic_$TAG
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "bench rc=$?"; tail -2 $OUT/bench_default.err | cut -c1-200
 timeout 300 python tools/host_overhead_train.py > $OUT/host_overhead_train.txt 2>&1
