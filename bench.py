@@ -609,6 +609,8 @@ def main():
     # TSDE_BENCH_SHARE_GPU=1 (tests only): all ranks use device 0 and gloo carries the collectives, so that the
     # multi-rank logic of this file can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
     share_gpu = os.environ.get("TSDE_BENCH_SHARE_GPU") == "1"
+    # dmabuf IPC is what RCCL needs on this host driver; read by the HSA runtime when the first rank touches its GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU, RCCL)
         raise SystemExit(_self_launch(args.gpus, share_gpu))
