@@ -100,6 +100,10 @@ def describe_cache(sde):
         else:
             tuning = getattr(entry, "tuning", None)
             what = type(entry).__name__.lstrip("_") + (f", {tuning}" if tuning else "")
+            nodes = [getattr(getattr(entry, name, None), "memset_nodes", None) for name in ("graph", "fwd_graph", "bwd_graph")]
+            found, rewritten = (sum(n[k] for n in nodes if n) for k in (0, 1))
+            if found:
+                what += f", {rewritten} of {found} memset nodes rewritten as kernels"
         lines.append(f"[{mode}] {kind}: {what}")
     return lines
 
