@@ -552,7 +552,10 @@ def faster_of_sequential_and_parallel(forward_sde, capture, device):
 def new_graph():
     """A torch CUDAGraph that keeps its hipGraph_t after the capture and is instantiated by its first replay, so that
     `_capturing` can rewrite its memset nodes in between."""
-    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    try:
+        graph = torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:       # a torch without `keep_graph` (< 2.8): no rewriting, the replay checks alone stand guard
+        return torch.cuda.CUDAGraph()
     graph.memset_nodes = None
     return graph
 
