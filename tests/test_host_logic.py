@@ -527,3 +527,28 @@ def test_graph_cache_is_bounded_in_entries_and_bytes():
     assert len(cache) == graph._MAX_GRAPHS_PER_SDE
     import copy
     assert len(copy.deepcopy(cache)) == 0
+
+
+def test_describe_cache_says_what_each_structure_does():
+    from torchsde_amd import graph
+
+    class FakeGraph:
+        memset_nodes = (40, 40)
+
+    class FakeSweep:
+        graph = FakeGraph()
+        tuning = {"kept": "sequential"}
+
+    class Holder:
+        pass
+
+    sde = Holder()
+    cache = graph._cache_of(sde)
+    cache[("auto", 1, "Euler")] = graph._Seen(independent=True)
+    cache[("auto", 2, "Midpoint")] = graph._Refused("the code synchronises with the host")
+    cache[("adjoint-backward", "euler")] = FakeSweep()
+    lines = graph.describe_cache(sde)
+    assert lines[0].startswith("[auto] Euler: seen once") and "independent: yes" in lines[0]
+    assert lines[1] == "[auto] Midpoint: stays eager: the code synchronises with the host"
+    assert lines[2].startswith("[explicit] adjoint-backward: FakeSweep") and "40 of 40 memset nodes rewritten" in lines[2]
+    assert graph.describe_cache(Holder()) == []
