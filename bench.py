@@ -16,7 +16,8 @@ unsharded run would produce) and the final states are all-gathered once per solv
 BASELINE configs[3] (Stratonovich midpoint, 262144 x 64 sharded over 8 GPUs) is
 `--gpus 8 --workload c4_midpoint_diag_b32768_d64`: 32768 rows per GPU.
 
-Prints ONE JSON line (rank 0):
+The LAST stdout line (rank 0) is the headline JSON, under 4 KB; the side measurements are printed before it, one short
+line per workload, and written whole to bench_also.json:
 
 * `value` = trajectory-steps/s over the K timed solves (barrier + synchronize on both sides, max over ranks);
   `median_ms_per_step` / `value_median` restate it from the median of the per-solve times (HIP events recorded
@@ -31,7 +32,7 @@ Prints ONE JSON line (rank 0):
   taken from profiles/traffic_latest.json ONLY when that file was collected on the kernel sources this run uses
   (`traffic_source` names file and source digest);
 * `cpu_baseline`: the oracle's port of the reference's CPU algorithm, timed on this host's cores on a bounded sample;
-* `also` (single-GPU default run): every other BASELINE configuration at its single-GPU size on the stepwise path
+* side measurements (single-GPU default run; `also` lines + bench_also.json): every other BASELINE configuration at its single-GPU size on the stepwise path
   (configs[2] Euler-general and the Milstein-general extension, the configs[3] shard, configs[4] sdeint_adjoint), each
   with ms per solve (median of 5) and the same kernel-level measurement, bytes, fractions and counter traffic as the
   headline; then the same jobs when the SDE is handed over in closed form. Not part of `value`; `--no-also` skips them.
@@ -127,8 +128,7 @@ def _cpu_baseline(cfg, budget_s=20.0):
             from oracle import brownian_ref, solvers_ref
         except Exception as e:  # oracle piece missing: report, don't fake
             return dict(base, sample=f"unavailable: {e}")
-        kind, what = "port", ("oracle port of the reference CPU algorithm (tree BrownianInterval + solver loop, torch CPU "
-                              "ops; same-thread-count A/B against the real reference: profiles/r2_cpu_port_vs_reference.txt)")
+        kind, what = "port", "oracle port of the reference CPU algorithm (A/B vs the reference: profiles/r2_cpu_port_vs_reference.txt)"
         step = solvers_ref.STEPS[cfg["method"]]
 
         def run(threads, n):
@@ -152,8 +152,8 @@ def _cpu_baseline(cfg, budget_s=20.0):
     n = int(max(8, min(cfg["nsteps"], budget_s / probe[best])))
     elapsed = run(best, n)
     return {"value": B * n / elapsed, "unit": "trajectory-steps/s", "cores": best, "host_cpus": ncpu, "kind": kind,
-            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}, method {cfg['method']}) "
-                      f"in {elapsed:.1f} s; {what}; best of thread counts {candidates} -> {best} threads"}
+            "sample": f"{n} of {cfg['nsteps']} solver steps of the same workload (B={B}, d={d}, {cfg['method']}) in "
+                      f"{elapsed:.1f} s; {what}; best of thread counts {candidates}"}
 
 
 class Job:
@@ -375,18 +375,15 @@ class Job:
         solve_achieved = contract * value / self.world / 1e9
         roof = {"bound": "hbm", "kernel": c["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "frac_is": "KERNEL level: SURVEY 8d algorithmic bytes of one solver step (all rows) / the summed durations "
-                           "of the step's launches of the dominant kernel",
+                "frac_is": "kernel level: SURVEY 8d bytes of one solver step / duration of the step's dominant-kernel launches",
                 "solve_achieved": solve_achieved, "solve_frac": solve_achieved / HBM_PEAK_GBPS,
-                "solve_frac_is": "SOLVE level (SURVEY 8d): bytes_per_traj_step x value / (n_gpus x peak); includes the "
-                                 "user's f, g torch kernels and all launch gaps",
+                "solve_frac_is": "solve level: bytes_per_traj_step x value / (n_gpus x peak), user f, g kernels and gaps inside",
                 "bytes_per_traj_step": contract, "bytes_per_launch": contract * B / per_step,
                 "launches_per_step": per_step, "avg_launch_us": step_us / per_step,
                 "launch_us": {k: round(v, 3) for k, v in b2b.items()},
                 "traffic": None,
-                "timing": "HIP events around ONE replay of a HIP graph of 200 launches of this kernel on live operands that "
-                          "rotate over >= 128 MiB of distinct copies (no marker packets, no host launch rate, no operand "
-                          "left in L2 by the previous launch); best of 3 replays"}
+                "timing": "HIP events around a replayed HIP graph of 200 launches on rotating live operands (>= 128 MiB), "
+                          "best of 3"}
         if moved != contract:
             roof["bytes_moved_per_traj_step"] = moved
             roof["moved_achieved"] = moved * B / (step_us * 1e-6) / 1e9
@@ -538,6 +535,52 @@ def _side_measurements(dev):
             also[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     return also
+
+
+HEADLINE_LIMIT = 4096      # the driver keeps only the tail of stdout: the headline is the LAST line and stays under this
+ALSO_LINE_LIMIT = 2048
+_ALSO_PROSE = ("timing", "traffic_source", "ms_per_solve_all", "graphs", "extrapolated", "frac_is", "solve_frac_is")
+
+
+def _emit_also(also):
+    """The side measurements go to `bench_also.json` (whole records; next to this file, and under gpurun_out/ when that
+    exists) and to stdout as one short line per workload BEFORE the headline -- never inside it."""
+    paths = [os.path.join(ROOT, "bench_also.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_also.json"))
+    written = None
+    for path in paths:
+        try:
+            with open(path, "w") as fh:
+                json.dump({"csrc_sha": csrc_digest(), "also": also}, fh, indent=1)
+            written = written or os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+    for name, rec in also.items():
+        short = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items() if k not in _ALSO_PROSE}
+        text = json.dumps({"also": name, **short})
+        if len(text) > ALSO_LINE_LIMIT:
+            text = json.dumps({"also": name, **{k: short[k] for k in ("ms_per_solve", "trajectory_steps_per_s", "kernel",
+                                                                      "kernel_frac", "solve_frac", "error") if k in short}})
+        print(text)
+    return written
+
+
+def _print_headline(line):
+    """The LAST stdout line: the headline with `roofline` and `cpu_baseline`, under HEADLINE_LIMIT bytes. Prose is
+    dropped before numbers if a future field ever pushes it over."""
+    text = json.dumps(line)
+    for key in ("timing", "traffic_source", "solve_frac_is", "frac_is", "moved_is", "note"):
+        if len(text) <= HEADLINE_LIMIT:
+            break
+        if isinstance(line.get("roofline"), dict):
+            line["roofline"].pop(key, None)
+        text = json.dumps(line)
+    if len(text) > HEADLINE_LIMIT and isinstance(line.get("cpu_baseline"), dict):
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"].get("sample", "")[:160]
+        text = json.dumps(line)
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def _what_the_ranks_saw(job, dev, dist, share_gpu):
@@ -719,8 +762,8 @@ def main():
         }
         line.update(ranks)
         if also is not None:
-            line["also"] = also
-        print(json.dumps(line))
+            line["also_file"] = _emit_also(also)
+        _print_headline(line)
     if use_dist:
         dist.destroy_process_group()
 

@@ -552,3 +552,37 @@ def test_describe_cache_says_what_each_structure_does():
     assert lines[1] == "[auto] Midpoint: stays eager: the code synchronises with the host"
     assert lines[2].startswith("[explicit] adjoint-backward: FakeSweep") and "40 of 40 memset nodes rewritten" in lines[2]
     assert graph.describe_cache(Holder()) == []
+
+
+def test_bench_headline_is_the_last_line_and_fits_the_drivers_window(capsys, tmp_path, monkeypatch):
+    """The driver keeps the tail of bench.py's stdout: round 3's line had grown to 21 KB (16 side measurements inside
+    it) and nothing was parsed. The record of that very run (profiles/r3r_bench_c2_default.json) through this round's
+    printer: side measurements as short lines BEFORE the headline and whole in bench_also.json, the headline LAST,
+    under 4 KB, with `roofline.frac` and `cpu_baseline` in it."""
+    import importlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    with open(os.path.join(root, "profiles", "r3r_bench_c2_default.json")) as fh:
+        line = json.load(fh)
+    also = line.pop("also")
+    assert len(also) >= 16
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "0" * 16)
+    # worst case: the prose of the old line kept, then doubled
+    line["roofline"]["timing"] = line["roofline"]["timing"] * 2
+    line["also_file"] = bench._emit_also(also)
+    bench._print_headline(line)
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == len(also) + 1
+    for text in out[:-1]:
+        assert len(text) <= bench.ALSO_LINE_LIMIT and "also" in json.loads(text)
+    assert len(out[-1]) < 4096
+    head = json.loads(out[-1])
+    assert head["roofline"]["frac"] > 0 and head["cpu_baseline"]["value"] > 0 and head["value"] > 0
+    assert "also" not in head and head["also_file"] == "bench_also.json"
+    with open(tmp_path / "bench_also.json") as fh:
+        assert set(json.load(fh)["also"]) == set(also)
+    assert sum(len(t) + 1 for t in out[-3:]) < 9000      # even a window of ~9 KB holds the headline whole
