@@ -586,3 +586,98 @@ def test_bench_headline_is_the_last_line_and_fits_the_drivers_window(capsys, tmp
     with open(tmp_path / "bench_also.json") as fh:
         assert set(json.load(fh)["also"]) == set(also)
     assert sum(len(t) + 1 for t in out[-3:]) < 9000      # even a window of ~9 KB holds the headline whole
+
+
+_FINGERPRINT_GLOBAL_SCALE = 1.5
+
+
+def _fingerprint_helper(y):
+    return _FINGERPRINT_GLOBAL_SCALE * y
+
+
+def test_python_state_sees_globals_closures_class_attributes_and_strides(monkeypatch):
+    """What round 3's fingerprint missed (VERDICT weak 2, ADVICE): a drift that reads a module-level number -- directly
+    or through a helper function --, a closed-over list element, a class attribute; values whose CPython hashes collide
+    (hash(-1) == hash(-2)); a square matrix re-bound to its transpose (same storage and shape, other strides)."""
+    import sys
+    from torchsde_amd import graph
+    this = sys.modules[__name__]
+    coefficients = [0.5, 2.0]
+
+    class SDE(torch.nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+        gain = 3.0
+
+        def __init__(self):
+            super().__init__()
+            self.sign = -1
+            self.W = torch.eye(3)
+            self.g = lambda t, y: coefficients[1] * y        # an instance attribute holding a closure
+
+        def f(self, t, y):
+            return _fingerprint_helper(y) * self.gain
+
+    sde = SDE()
+    state = graph.python_state(sde)
+    assert state is not None and graph.python_state(sde) == state and hash(state) == hash(graph.python_state(sde))
+
+    def changed(action, undo):
+        action()
+        differs = graph.python_state(sde) != state
+        undo()
+        assert graph.python_state(sde) == state
+        return differs
+
+    assert changed(lambda: monkeypatch.setattr(this, "_FINGERPRINT_GLOBAL_SCALE", 2.5),
+                   lambda: monkeypatch.setattr(this, "_FINGERPRINT_GLOBAL_SCALE", 1.5))
+    assert changed(lambda: coefficients.__setitem__(1, 4.0), lambda: coefficients.__setitem__(1, 2.0))
+    assert changed(lambda: setattr(SDE, "gain", 4.0), lambda: setattr(SDE, "gain", 3.0))
+    assert hash((1, -1, "a")) == hash((1, -2, "a"))           # the collision the old `hash(tuple(...))` key fell into
+    assert changed(lambda: setattr(sde, "sign", -2), lambda: setattr(sde, "sign", -1))
+    assert changed(lambda: setattr(sde, "sign", -1.0), lambda: setattr(sde, "sign", -1))       # 1 vs 1.0: other program
+    W = sde.W
+    assert changed(lambda: setattr(sde, "W", W.t()), lambda: setattr(sde, "W", W))
+    sde.rate = float("nan")
+    assert graph.python_state(sde) == graph.python_state(sde)       # nan is one value, not a miss on every solve
+    assert graph.process_state() == graph.process_state()
+    torch.set_float32_matmul_precision("high")
+    try:
+        assert graph.process_state() != ("x",) and graph.process_state()[2] == "high"
+    finally:
+        torch.set_float32_matmul_precision("highest")
+
+
+def test_auto_key_refuses_an_object_whose_state_never_repeats_and_schedule_of_checks(monkeypatch):
+    """An SDE object that changes on every call (a call counter) never reaches a replay: after 8 distinct states of one
+    structure the structure is refused and later solves skip the fingerprint walk. Accepted graphs are
+    re-checked against the eager path on replays 1, 2, 8, 64, 512, ... TSDE_HIP_GRAPH sets the default and 0 overrides."""
+    from torchsde_amd import graph
+    sde = problems.make("gbm_ito", d=4)
+    cache, structure = graph._GraphCache(), ("Euler", (4, 4), "float32")
+    first = graph.auto_key(cache, structure, sde)
+    cache[first] = graph._Seen()
+    assert first is not None and graph.auto_key(cache, structure, sde) == first
+    keys = set()
+    for i in range(graph._MAX_STATES_PER_STRUCTURE + 2):
+        sde.calls = i
+        key = graph.auto_key(cache, structure, sde)
+        if key is not None:
+            keys.add(key)
+            cache[key] = graph._Seen()
+    assert len(keys) == graph._MAX_STATES_PER_STRUCTURE - 1 and graph.auto_key(cache, structure, sde) is None
+    assert not [k for k in cache if k[0] == "auto"]                       # the churned entries are gone
+    walked = []
+    monkeypatch.setattr(graph, "python_state", lambda base: walked.append(1))
+    assert graph.auto_key(cache, structure, sde) is None and not walked   # refused before any fingerprinting
+    assert graph.auto_key(cache, ("Milstein",) + structure[1:], sde) is None and walked     # (other structure: not refused)
+    assert any("stays eager" in line for line in graph.describe_cache(type("S", (), {graph._CACHE_ATTR: cache})()))
+    assert [n for n in range(1, 5000) if graph.due_for_a_check(n)] == [1, 2, 8, 64, 512, 4096]
+    monkeypatch.setenv("TSDE_HIP_GRAPH", "0")
+    assert graph.mode_of({}) is False and graph.mode_of({"hip_graph": True}) is False and graph.mode_of(None) is False
+    monkeypatch.setenv("TSDE_HIP_GRAPH", "1")
+    assert graph.mode_of({}) is True and graph.mode_of({"hip_graph": False}) is False and graph.mode_of({"hip_graph": "auto"}) == "auto"
+    monkeypatch.setenv("TSDE_HIP_GRAPH", "auto")
+    assert graph.mode_of({}) == "auto"
+    monkeypatch.setenv("TSDE_HIP_GRAPH", "sometimes")
+    with pytest.raises(ValueError):
+        graph.mode_of({})

@@ -112,6 +112,26 @@ def _no_gradient_can_flow(solver, y0, ts):
         return True
     if solver._tracks_grad(y0):
         return False
+    # one probe per SDE object and state, not one per solve: the probe calls the user's code, which costs time and
+    # triggers its side effects (call counters) once more than the reference does
+    from . import graph as graph_module
+    _, base = graph_module._wrapper_chain(solver.sde)
+    key = ("grad-probe", graph_module.python_state(base), tuple(y0.shape), y0.dtype)
+    try:
+        verdicts = base.__dict__.setdefault("_tsde_grad_probe", {})
+    except AttributeError:
+        verdicts = {}
+    if key[1] is not None and key in verdicts:
+        return verdicts[key]
+    verdict = _probe_no_gradient(solver, y0, ts)
+    if key[1] is not None:
+        if len(verdicts) >= 8:
+            verdicts.clear()
+        verdicts[key] = verdict
+    return verdict
+
+
+def _probe_no_gradient(solver, y0, ts):
     try:
         probes = solver.sde.f_and_g_prod(ts[0], y0, torch.zeros(solver.bm.shape, dtype=y0.dtype, device=y0.device)) \
             if solver.sde.user_product else solver.sde.f_and_g(ts[0], y0)
@@ -193,7 +213,9 @@ class _GraphedAttempt(_Attempt):
     the host. What a new solve brings is loaded into the static buffers: the controller's state, y0, and the
     Brownian motion's entropy (the generator kernels read it from one device word)."""
 
-    def __init__(self, solver, y0, step_cls):
+    verified = True
+
+    def __init__(self, solver, y0, step_cls, verify=False):
         super().__init__(solver, y0, step_cls)
         bm = solver._native_bm()
         device = y0.device
@@ -214,6 +236,29 @@ class _GraphedAttempt(_Attempt):
             self.graph = graph_module.new_graph()
             with graph_module._capturing(self.graph, device):
                 self._launch(solver, bm)
+            if verify:
+                # "auto": the recorded attempt is trusted only if, from the same loaded state, it gives what the eager
+                # attempt gives (state, controller tables) and keeps giving it with eager work in between
+                # (graph.replays_are_stable: the second line of defence behind the memset-node rewrite)
+                def fresh():
+                    self.load(y0, float(bm._t0), float(bm._t1), float(bm._t1 - bm._t0), 0.0, bm)
+                    self.ctrl.begin(float(bm._t1))
+
+                def outputs():
+                    return [self.curr_y, self.prev_y, self.y_next, self.ctrl.ctl, self.ctrl.scal]
+
+                def replay():
+                    fresh()
+                    self.graph.replay()
+
+                def eagerly():
+                    fresh()
+                    self._launch(solver, bm)
+                eagerly()
+                want = [o.clone() for o in outputs()]
+                replay()
+                self.verified = (graph_module._same_tensors(outputs(), want, exact=True)
+                                 and graph_module.replays_are_stable(replay, outputs, eagerly))
         finally:
             bm._entropy_dev = None
         self.steps = None               # (they reference the solver's SDE: no cycle through the cache on that object)
@@ -249,13 +294,12 @@ def _attempt_for(solver, y0, ts_host, step_cls):
            tuple(sorted((k, v) for k, v in solver.options.items() if isinstance(v, (bool, int, float, str)))))
     cache = graph_module._cache_of(base)
     if mode == "auto":
-        # the drop-in default (graph.py): the first solve of a structure runs eagerly, the second records the attempt,
-        # later ones replay it; the Python-side state of the SDE object is part of the key, and code that cannot be
-        # captured (it synchronises with the host, say) stays eager for good
-        state = graph_module.python_state(base)
-        if state is None:
+        # the drop-in default (graph.py): the first solve of a structure runs eagerly, the second records the attempt
+        # and checks it against the eager one, later ones replay it; the Python-side state of the SDE object is part of
+        # the key, and code that cannot be captured (it synchronises with the host, say) stays eager for good
+        sig = graph_module.auto_key(cache, sig, base)
+        if sig is None:
             return _Attempt(solver, y0, step_cls)
-        sig = ("auto", state) + sig
         entry = cache.get(sig)
         if entry is None:
             # this solve runs eagerly; its FIRST round of attempts is screened (graph.run_screened) and decides
@@ -269,10 +313,14 @@ def _attempt_for(solver, y0, ts_host, step_cls):
         if isinstance(entry, graph_module._Seen):
             try:
                 with graph_module._drift_then_diffusion(solver.sde):
-                    cache[sig] = entry = _GraphedAttempt(solver, y0, step_cls)
+                    entry = _GraphedAttempt(solver, y0, step_cls, verify=True)
             except Exception as e:
                 cache[sig] = graph_module._Refused(f"capture failed: {type(e).__name__}: {e}")
                 return _Attempt(solver, y0, step_cls)
+            if not entry.verified:
+                cache[sig] = graph_module._Refused("the recorded attempt did not reproduce the eager one")
+                return _Attempt(solver, y0, step_cls)
+            cache[sig] = entry
         return entry
     attempt = cache.get(sig)
     if attempt is None:

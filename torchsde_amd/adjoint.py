@@ -494,15 +494,16 @@ class _SdeintAdjointMethod(torch.autograd.Function):
                 out = [a_y] + list(a_theta)
         elif captured is not None and not getattr(captured, "broken", False):
             out = captured.replay(ctx.bm, inputs)
-            if captured.probation > 0:
+            captured.replays += 1
+            from . import graph
+            if graph.due_for_a_check(captured.replays):
                 # A recorded sweep has passed its checks at recording time (graph.replays_are_stable); its first replays
-                # in real use are still compared with the eager sweep -- the fault those checks exist for shows only
-                # after other work has run on the device -- and a graph that fails is never replayed again.
-                captured.probation -= 1
+                # in real use -- and then every 8th, 64th, 512th ... -- are still compared with the eager sweep: the fault
+                # those checks exist for shows only after other work has run on the device, and state the cache key
+                # cannot see is caught late rather than never. A graph that fails is never replayed again.
                 kind = _backward_kind(ctx.sde, ctx.bm, ctx.adjoint_method, ctx.adjoint_options, adjoint_params)
                 run = _backward_runner(ctx.sde, ctx.bm, ctx.dt, kind, adjoint_params, timegrid.ts_to_host(ts), ys.device)
                 eager = run(*inputs)
-                from . import graph
                 if not graph._same_tensors(out, eager, exact=False):
                     captured.broken = True
                     out = eager

@@ -4,8 +4,10 @@
 later one replays the graph -- provided the capture is legal (see the constraints below) AND safe to do silently: the
 first solve runs eagerly and screened (`run_screened`: code that synchronises with the host, or uses operators other than
 the elementwise / matmul / reduction family, is never captured -- a failed capture cannot be recovered from on this
-stack), the Python-side state of the SDE object (plain attributes, tensor identities, `training` flags) is part
-of the cache key, the captured graph's first replay must reproduce the eager solve it was recorded beside bit for bit,
+stack), the Python-side state of the SDE object (plain attributes, tensor identities and strides, `training` flags,
+class attributes, and what its functions read from closures and module globals: `python_state`) is part of the cache key,
+the captured graph's first replay must reproduce the eager solve it was recorded beside bit for bit, its first two
+replays in real use and then every 8th, 64th, 512th ... run beside the eager path and are compared with it,
 very large states stay eager (launch overhead does not matter there and a graph pins a second memory pool), and any
 failure along the way falls back to the eager path without a word. ``True``: capture on first use, warn when
 impossible (the caller vouches for capture-safe code). ``False``: never.
@@ -90,8 +92,10 @@ def describe_cache(sde):
         base = base._base_sde
     lines = []
     for sig, entry in getattr(base, _CACHE_ATTR, {}).items():
-        kind = next((x for x in sig if isinstance(x, str) and x not in ("auto",)), "?")
-        mode = "auto" if sig and sig[0] == "auto" else "explicit"
+        if isinstance(entry, _StatesSeen):
+            continue
+        kind = next((x for x in sig if isinstance(x, str) and x not in ("auto", "auto-churn")), "?")
+        mode = "auto" if sig and sig[0] in ("auto", "auto-churn") else "explicit"
         if isinstance(entry, _Refused):
             what = f"stays eager: {entry.reason}"
         elif isinstance(entry, _Seen):
@@ -141,8 +145,17 @@ _AUTO_MAX_OUTPUT_BYTES = 1 << 30        # ... or bytes of ys
 
 
 def mode_of(options, key="hip_graph"):
-    """True / False / "auto" from the option (absent = "auto")."""
-    value = options.get(key, "auto") if options is not None else "auto"
+    """True / False / "auto" from the option. Absent: the environment's TSDE_HIP_GRAPH ("auto", the default; "1": record
+    on first use like `True`; "0"). TSDE_HIP_GRAPH=0 is also the kill switch: it wins over an explicit option, so a
+    deployment can rule graphs out without touching call sites."""
+    import os
+    env = os.environ.get("TSDE_HIP_GRAPH", "auto").strip().lower()
+    if env not in ("0", "1", "auto", "false", "true", "off", "on", ""):
+        raise ValueError(f"TSDE_HIP_GRAPH must be 0, 1 or auto, got {env!r}.")
+    if env in ("0", "false", "off"):
+        return False
+    default = True if env in ("1", "true", "on") else "auto"
+    value = options.get(key, default) if options is not None else default
     if value is True or value is False:
         return value
     if value is None or value == "auto":
@@ -170,26 +183,147 @@ class _TooMuchState(Exception):
     pass
 
 
+_MAX_STATES_PER_STRUCTURE = 8
+
+
+def auto_key(cache, structure, base):
+    """The "auto" cache key of a solve with structural signature `structure` on SDE object `base` -- ("auto", Python-side
+    state, process switches) + structure -- or None when this structure stays eager: the state cannot be fingerprinted,
+    or the object has shown more than `_MAX_STATES_PER_STRUCTURE` different states for this one structure (a counter
+    bumped in `f`, a list that grows, a per-batch `sde.ctx = new_tensor`). Such an object never reaches a replay; it
+    would pay for the screen and the fingerprint walk on every solve, so after that many misses the structure itself is
+    refused and later solves come straight back here and leave by the first test."""
+    churn = ("auto-churn",) + structure
+    if isinstance(cache.get(churn), _Refused):
+        return None
+    state = python_state(base)
+    if state is None:
+        return None
+    sig = ("auto", state, process_state()) + structure
+    if sig not in cache:
+        seen = cache.get(churn)
+        if seen is None:
+            seen = cache[churn] = _StatesSeen()
+        seen.count += 1
+        if seen.count > _MAX_STATES_PER_STRUCTURE:
+            for key in [k for k in cache if k[:1] == ("auto",) and k[3:] == structure]:
+                del cache[key]
+            cache[churn] = _Refused(f"the SDE object's Python-side state differed on each of {seen.count - 1} solves of this "
+                                    "structure (a counter, a growing list, a fresh tensor attribute per call?)")
+            return None
+    return sig
+
+
+class _StatesSeen:
+    """Cache entry counting the distinct Python-side states met for one structure (see `auto_key`)."""
+    count = 0
+
+
+def due_for_a_check(replays):
+    """Is replay number `replays` (1-based) of an accepted graph one that runs next to the eager path and is compared
+    with it? The first two (probation), then on a geometric schedule -- 8, 64, 512, ... -- for as long as the graph
+    lives: state the fingerprint cannot see (a C extension's global, an environment variable read in `f`) is caught
+    late rather than never, at an amortised cost under 1/7 of a solve per 8."""
+    if replays <= 2:
+        return True
+    while replays % 8 == 0:
+        replays //= 8
+    return replays == 1
+
+
 _SIMPLE = (bool, int, float, complex, str, bytes, type(None), torch.dtype, torch.device, torch.Size)
+# classes whose attributes are library code, not the caller's state
+_LIBRARY_MODULES = ("torch", "builtins", "numpy", "collections", "abc", "typing", "functools")
+
+
+def _is_library(x):
+    module = getattr(x, "__module__", None) or ""
+    return module.split(".")[0] in _LIBRARY_MODULES or module.startswith("torchsde_amd")
+
+
+def _simple(x):
+    """The entry of a plain value: with its type (1, 1.0 and True are different programs) and, for floats, by `repr`
+    (nan equals itself, -0.0 is not 0.0). Compared by EQUALITY as part of a tuple -- never reduced to `hash()`:
+    CPython hashes collide on everyday values (hash(-1) == hash(-2), hash(-1.0) == hash(-2.0))."""
+    if isinstance(x, (float, complex)):
+        return (type(x).__name__, repr(x))
+    return (type(x).__name__, x)
 
 
 def python_state(obj, budget=4096):
-    """A hashable fingerprint of the Python-side state a captured graph would bake in: plain attribute values, the
-    identity (storage, shape, dtype) of every tensor reachable from `obj`, flags such as `training` -- NOT tensor
-    contents, which replays read live. None when the object is too large to fingerprint cheaply (then "auto" stays
-    eager). A re-bound attribute (`sde.scale = 2.0`, `sde.ctx = new_tensor`) changes the fingerprint, hence the graph."""
+    """A hashable fingerprint -- compared by equality, it IS the cache key -- of the Python-side state a recorded graph
+    would bake in. For `obj` and everything reachable from it: plain attribute values; the identity (storage, shape,
+    STRIDES, offset, dtype) of every tensor -- not tensor contents, which replays read live; flags such as `training`;
+    plain class attributes along the MRO of user classes; and for every function or method found on the way (the
+    SDE's `f`, `g`, helpers they name) the code object, default arguments, the contents of closure cells and the values
+    of the module globals its code names -- a drift that reads a module-level `SCALE` or a closed-over coefficient is
+    re-recorded when that number changes (the reference re-runs user code every step, base_solver.py:114-149, and sees
+    the change at once). None when there is too much to fingerprint cheaply or something is unhashable: then "auto"
+    stays eager."""
+    import functools
+    import types
     out, seen = [], set()
     left = [budget]
+
+    def function(fn, depth):
+        """A Python function: its code, defaults, closure contents and the globals its code (and nested code) names."""
+        if id(fn) in seen:
+            out.append(("F", id(fn)))
+            return
+        seen.add(id(fn))
+        code = fn.__code__
+        out.append(("F", id(code)))
+        if fn.__defaults__:
+            walk(fn.__defaults__, depth + 1)
+        if fn.__kwdefaults__:
+            walk(fn.__kwdefaults__, depth + 1)
+        for cell in fn.__closure__ or ():
+            try:
+                walk(cell.cell_contents, depth + 1)
+            except ValueError:           # an empty cell
+                out.append(("empty-cell",))
+        names, stack = [], [code]
+        while stack:
+            c = stack.pop()
+            names.extend(c.co_names)
+            stack.extend(k for k in c.co_consts if isinstance(k, types.CodeType))
+        scope = fn.__globals__
+        for name in dict.fromkeys(names):            # (first occurrence order, no duplicates)
+            if name in scope:
+                value = scope[name]
+                out.append(("G", name))
+                if isinstance(value, (types.ModuleType, type)) or (callable(value) and _is_library(value)):
+                    out.append(("O", id(value)))
+                else:
+                    walk(value, depth + 1)
+
+    def class_attributes(cls, depth):
+        """Plain values, tensors and functions in the class bodies of the user's classes along the MRO."""
+        for klass in cls.__mro__:
+            if klass is object or _is_library(klass) or id(klass) in seen:
+                continue
+            seen.add(id(klass))
+            out.append(("C", klass.__qualname__))
+            for name, value in vars(klass).items():
+                if name.startswith("__") and name.endswith("__") and not callable(value):
+                    continue
+                if isinstance(value, (staticmethod, classmethod)):
+                    value = value.__func__
+                elif isinstance(value, property):
+                    value = value.fget
+                if isinstance(value, _SIMPLE) or torch.is_tensor(value) or isinstance(value, (types.FunctionType, list, tuple, dict)):
+                    out.append(("A", name))
+                    walk(value, depth + 1)
 
     def walk(x, depth):
         left[0] -= 1
         if left[0] < 0:
             raise _TooMuchState
         if isinstance(x, _SIMPLE):
-            out.append(x)
+            out.append(_simple(x))
         elif torch.is_tensor(x):
             try:
-                where = x.data_ptr()
+                where = (x.data_ptr(), tuple(x.stride()), x.storage_offset())
             except Exception:           # sparse / nested layouts have no single data pointer: identity of the object
                 where = ("O", id(x))
             out.append(("T", where, tuple(x.shape), x.dtype, x.requires_grad))
@@ -206,24 +340,46 @@ def python_state(obj, budget=4096):
             items = [(k, v) for k, v in x.items() if not (isinstance(k, str) and k.startswith("_tsde"))]
             out.append(("dict", len(items)))
             for k, v in items:
-                out.append(k if isinstance(k, _SIMPLE) else ("O", id(k)))
+                out.append(_simple(k) if isinstance(k, _SIMPLE) else ("O", id(k)))
                 walk(v, depth + 1)
-        elif hasattr(x, "__dict__") and not isinstance(x, type) and not callable(getattr(x, "__call__", None)) \
-                or isinstance(x, torch.nn.Module):
+        elif isinstance(x, types.FunctionType):
+            function(x, depth)
+        elif isinstance(x, types.MethodType):
+            out.append(("M",))
+            walk(x.__func__, depth + 1)
+            walk(x.__self__, depth + 1)
+        elif isinstance(x, functools.partial):
+            out.append(("P",))
+            walk(x.func, depth + 1)
+            walk(x.args, depth + 1)
+            walk(x.keywords, depth + 1)
+        elif isinstance(x, (types.ModuleType, type, types.BuiltinFunctionType)):
+            out.append(("O", id(x)))
+        elif isinstance(x, torch.nn.Module) or (hasattr(x, "__dict__") and not _is_library(type(x))):
             seen.add(id(x))
             out.append((type(x).__qualname__,))
+            class_attributes(type(x), depth)
             walk(vars(x), depth + 1)
+            call = getattr(type(x), "__call__", None)
+            if isinstance(call, types.FunctionType) and not _is_library(call):
+                function(call, depth + 1)
         else:
-            out.append(("O", id(x)))     # functions, generators, foreign objects: identity only
+            out.append(("O", id(x)))     # generators, foreign objects: identity only
 
     try:
         walk(obj, 0)
-    except _TooMuchState:
+        key = tuple(out)
+        hash(key)
+    except (_TooMuchState, TypeError, RecursionError):
         return None
-    try:
-        return hash(tuple(out)), len(out)
-    except TypeError:
-        return None
+    return key
+
+
+def process_state():
+    """Process-wide switches that change what the same torch code computes: part of every "auto" cache key."""
+    return (torch.is_autocast_enabled(), str(torch.get_autocast_dtype("cuda")), torch.get_float32_matmul_precision(),
+            torch.backends.cuda.matmul.allow_tf32, torch.are_deterministic_algorithms_enabled(),
+            str(torch.get_default_dtype()))
 
 
 def _same_tensors(xs, ys, exact=True):
@@ -433,13 +589,12 @@ def auto_solve(solver, y0, ts, extra0=()):
     if not _auto_eligible(bm, y0, len(ts_host)):
         return None
     _, base = _wrapper_chain(solver.sde)
-    state = python_state(base)
-    if state is None:
-        return None
     cache = _cache_of(base)
     if not bm.frozen:
         bm.adopt_grid(timegrid.build(ts_host, solver.dt).t_f64())
-    sig = ("auto", state) + _signature(solver, y0, ts_host)
+    sig = auto_key(cache, _signature(solver, y0, ts_host), base)
+    if sig is None:
+        return None
     entry = cache.get(sig)
     if entry is None:
         # first solve of this structure: eager, and watched -- code that synchronises with the host cannot be captured
@@ -601,8 +756,8 @@ def _replay_on_probation(captured, cache, sig, solver, bm, y0, ts, extra0):
     eagerly and compare: the fault `replays_are_stable` looks for shows only after other work has run on the device. A
     graph that fails is dropped for good and the eager result returned."""
     out = captured.replay(bm, y0, extra0)
-    if captured.probation > 0:
-        captured.probation -= 1
+    captured.replays += 1
+    if due_for_a_check(captured.replays):
         solver._extra = tuple(extra0)
         eager = solver._run(solver._plan(y0, ts), y0)
         eager_extra = tuple(solver._extra)
@@ -614,7 +769,7 @@ def _replay_on_probation(captured, cache, sig, solver, bm, y0, ts, extra0):
 
 class _CapturedSolve:
     exact_outputs = True
-    probation = 2
+    replays = 0               # replays in real use so far: `due_for_a_check` says which of them run beside the eager path
 
     def outputs(self):
         return [self.ys] + list(self.extra_out)
@@ -766,7 +921,7 @@ class _CapturedBackward:
     (device word) and the parameters themselves (read in place: an optimiser step is seen by the next replay)."""
 
     exact_outputs = False     # autograd orders the sums of a recorded sweep by per-thread sequence numbers
-    probation = 2             # the first replays in real use are checked against the eager sweep (adjoint._backward)
+    replays = 0               # `due_for_a_check`: which replays in real use are compared with the eager sweep
 
     def outputs(self):
         return list(self.out)
@@ -854,10 +1009,9 @@ def cached_backward(sde, bm, signature, capture, auto=False, tuned_capture=None)
             if captured is not None:
                 _remember(cache, sig, captured)
         return None if isinstance(captured, _Refused) else captured
-    state = python_state(base)
-    if state is None:
+    sig = auto_key(cache, sig, base)
+    if sig is None:
         return None, None
-    sig = ("auto", state) + sig
     entry = cache.get(sig)
     if entry is None:            # first sweep of this structure: eager, watched by `backward`
 
