@@ -127,3 +127,34 @@ def test_bench_multi_rank_logic_on_one_gpu(workload, launcher):
     # the solve-level fraction is the SURVEY 8d definition: bytes per trajectory-step x value / (n_gpus x peak)
     want = roof["bytes_per_traj_step"] * rec["value"] / 2 / (roof["peak"] * 1e9)
     assert abs(roof["solve_frac"] - want) <= 1e-9 + 1e-6 * want
+
+
+def _run_bench(cmd, env, root):
+    import json
+    import subprocess
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
+    assert lines and len(lines[-1]) < 4096, proc.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_one_rank_over_rccl_matches_the_plain_run():
+    """RCCL on the driver's box, every round: bench.py launched by torch.distributed.run with ONE rank opens the `nccl`
+    backend (init_process_group(device_id=...)), runs the all_gather_into_tensor of final states after every solve and
+    times it -- the same code path as N = 2, 4, 8 -- and its throughput is the plain single-process run's within 3 %
+    (so the N = 1 point of a scaling curve agrees with the headline). SURVEY 8(e)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TSDE_BENCH_SHARE_GPU"):
+        env.pop(key, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-also", "--no-cpu-baseline"]
+    dist = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail, env, root)
+    plain = _run_bench([sys.executable] + tail, env, root)
+    assert dist["collective_backend"].startswith("nccl") and dist["ranks_seen"] == 1 and dist["n_gpus"] == 1
+    assert dist["all_gather_ms_per_solve"] > 0 and dist["all_gather_bytes_per_rank"] == 65536 * 64 * 4
+    assert plain["collective_backend"] is None and plain["ranks_seen"] == 1
+    assert dist["roofline"]["frac"] > 0 and plain["roofline"]["frac"] > 0
+    assert abs(dist["value"] - plain["value"]) <= 0.03 * plain["value"], (dist["value"], plain["value"])
