@@ -462,8 +462,8 @@ def _attach_offline_traffic(roofline, workload):
             roofline["kernel_us_rocprofv3"] = sum(us) / len(us)
             roofline["frac_rocprofv3"] = (cfg["bytes_per_traj_step"] * cfg["B"] / (sum(us) * launches_each * 1e-6) / 1e9
                                           / HBM_PEAK_GBPS)
-        roofline["traffic_source"] = (f"offline: profiles/traffic_latest.json @ csrc {digest} "
-                                      f"({rec.get('collected', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})")
+        roofline["traffic_source"] = (f"profiles/traffic_latest.json @ csrc {digest}: separate rocprofv3 --pmc FETCH_SIZE / "
+                                      f"WRITE_SIZE passes, bytes = (2 x FETCH + WRITE) x 1024")
     except Exception as e:
         roofline["traffic_source"] = f"profiles/traffic_latest.json unreadable: {e}"
 

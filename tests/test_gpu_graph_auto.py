@@ -134,13 +134,15 @@ def test_code_that_fails_under_the_screen_runs_eagerly_as_before():
     assert torch.equal(grads[0], grads[1])
 
 
-_CALLS = []
+import itertools  # noqa: E402
+
+_CALLS = itertools.count()
 
 
 class _HiddenState(_Scaled):
     def f(self, t, y):
-        _CALLS.append(1)                                   # state the fingerprint cannot see (a module-level list) ...
-        return (1.0 + 1e-3 * (len(_CALLS) % 7)) * self.mu * y     # ... that changes the numbers
+        calls = next(_CALLS)                               # state the fingerprint cannot see (a C-level counter) ...
+        return (1.0 + 1e-3 * (calls % 7)) * self.mu * y    # ... that changes the numbers
 
 
 def test_a_replay_that_differs_from_the_eager_solve_is_refused():

@@ -496,7 +496,8 @@ class _SdeintAdjointMethod(torch.autograd.Function):
             out = captured.replay(ctx.bm, inputs)
             captured.replays += 1
             from . import graph
-            if graph.due_for_a_check(captured.replays):
+            if captured.replays <= 2 or (getattr(ctx, "backward_graph_is_auto", True)
+                                         and graph.due_for_a_check(captured.replays)):
                 # A recorded sweep has passed its checks at recording time (graph.replays_are_stable); its first replays
                 # in real use -- and then every 8th, 64th, 512th ... -- are still compared with the eager sweep: the fault
                 # those checks exist for shows only after other work has run on the device, and state the cache key
@@ -849,6 +850,7 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
         captured = _capture_backward(
             sde, bm, dt, adjoint_method, adjoint_options, adjoint_params, ts, ys.detach(),
             [x.detach() for x in extra_solver_state] if reversible else [], auto=graph_mode == "auto")
+        ys.grad_fn.backward_graph_is_auto = graph_mode == "auto"
         if graph_mode == "auto":
             ys.grad_fn.captured_backward, ys.grad_fn.watch_backward = captured
         else:

@@ -1,0 +1,350 @@
+"""Recognising elementwise drift / diffusion code, so that an UNCHANGED user module reaches the trajectory kernels.
+
+The reference's SDE contract is two Python callables (torchsde/_core/base_sde.py:24-64) that the solver calls at every
+step (base_solver.py:114-149). For the diagonal-noise SDEs people actually write --
+
+    def f(self, t, y): return self.mu * y                        # tests/problems.py:47-64 (ExDiagonal)
+    def g(self, t, y): return torch.exp(-y)                      # benchmarks/brownian.py:131-139
+
+-- both are per-channel expressions of the form ``scale * phi(rate * y + shift) + offset``, which the kernels
+``tsde_trajectory_affine_diag`` / ``tsde_trajectory_expr_diag`` integrate with the state in registers, one launch per
+solve. Until round 3 only modules restated as ``AffineDiagonalSDE`` / ``ElementwiseDiagonalSDE`` got there.
+
+This module finds that form by ABSTRACT INTERPRETATION of the user's code, once per solve: ``f`` and ``g`` run on a
+probe state of a few rows under a dispatch mode that follows every ATen operator touching a value derived from ``y``
+and keeps, for each such value, the five per-channel coefficient tensors of the form above. Operators among tensors that
+do not depend on ``y`` (parameters, buffers, Python numbers) simply execute -- on (d,)-sized data -- so the coefficients
+are computed from the LIVE parameter values of this very solve: an optimiser step, a changed module global or closure
+are seen because the user's code has just run. Anything else -- a value derived from ``t``, an operator outside the
+small elementwise table, a reshape of the state, an in-place update of it, a per-row constant, a host synchronisation --
+ends the interpretation and the solve takes the stepwise path, as before.
+
+Nothing here synchronises with the host. Whether a recognised form may be trusted is decided once per (Python-side state
+of the SDE object, form, scheme, shapes) by solving both ways and comparing (`solvers.BaseSDESolver._recognised`).
+"""
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from . import _native
+
+aten = torch.ops.aten
+
+
+class NotElementwise(Exception):
+    """The code is not (recognisably) of the per-channel form; the message says what stopped the interpretation."""
+
+
+class _Form:
+    """``scale * phi(rate * y + shift) + offset``. A coefficient is None (the neutral element: 1 for scale and rate, 0
+    for shift and offset) or a per-channel value: a Python number or a tensor of shape (), (1,), (d,) or (1, d).
+    `rate is ZERO` marks a value that does not depend on y at all (``torch.ones_like(y) * sigma``): then phi is the
+    identity and the value is `shift` (+ offset folded in). `exact`: the kernel's evaluation order reproduces the
+    user's operations one for one (no coefficient had to be folded with another)."""
+    __slots__ = ("phi", "scale", "rate", "shift", "offset", "exact")
+
+    def __init__(self, phi="identity", scale=None, rate=None, shift=None, offset=None, exact=True):
+        self.phi, self.scale, self.rate, self.shift, self.offset, self.exact = phi, scale, rate, shift, offset, exact
+
+    def constant(self):
+        return self.rate is ZERO
+
+
+ZERO = object()         # the rate of a y-independent value
+
+
+def _mul(a, b):
+    """Product of two coefficients (None = 1)."""
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return a * b
+
+
+def _add(a, b):
+    """Sum of two coefficients (None = 0)."""
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return a + b
+
+
+def _neg(a):
+    return None if a is None else -a
+
+
+class _Interpreter(TorchDispatchMode):
+    def __init__(self, y, t, rows, d):
+        super().__init__()
+        self.rows, self.d = rows, d
+        self.forms = {id(y): _Form()}
+        self.time = {id(t)}
+        self.keep = [y, t]              # every tracked tensor stays alive: ids are not reused during the run
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------------------
+    def form_of(self, x):
+        return self.forms.get(id(x)) if torch.is_tensor(x) else None
+
+    def track(self, tensor, form):
+        if tuple(tensor.shape) != (self.rows, self.d):
+            raise NotElementwise(f"a value derived from the state has shape {tuple(tensor.shape)}")
+        self.forms[id(tensor)] = form
+        self.keep.append(tensor)
+        return tensor
+
+    def coefficient(self, c):
+        """`c` as a per-channel coefficient: a Python number, or a tensor that broadcasts over the rows."""
+        if isinstance(c, (bool, int, float)):
+            return c
+        if not torch.is_tensor(c):
+            raise NotElementwise(f"an operand of type {type(c).__name__}")
+        if id(c) in self.time:
+            raise NotElementwise("the coefficients depend on t")
+        shape = tuple(c.shape)
+        if shape not in ((), (1,), (self.d,), (1, self.d), (1, 1)):
+            raise NotElementwise(f"an operand of shape {shape} is not one value per channel")
+        return c
+
+    # ---- the algebra ---------------------------------------------------------------------------------------------
+    def scaled(self, x, c, exact=True):
+        """x * c for a per-channel c."""
+        if x.constant():
+            return _Form(rate=ZERO, shift=_mul(_add(x.shift, x.offset), c), exact=x.exact)
+        if x.phi == "identity" and x.scale is None and x.offset is None:
+            if x.rate is None and x.shift is None:
+                return _Form(rate=c, exact=x.exact and exact)
+            return _Form(rate=_mul(x.rate, c), shift=_mul(x.shift, c), exact=False)
+        plain = x.scale is None and x.offset is None
+        return _Form(x.phi, _mul(x.scale, c), x.rate, x.shift, _mul(x.offset, c), exact=x.exact and plain and exact)
+
+    def shifted(self, x, c):
+        """x + c for a per-channel c."""
+        if x.constant():
+            return _Form(rate=ZERO, shift=_add(_add(x.shift, x.offset), c), exact=x.exact)
+        if x.phi == "identity" and x.scale is None and x.offset is None:
+            return _Form(rate=x.rate, shift=_add(x.shift, c), exact=x.exact and x.shift is None)
+        return _Form(x.phi, x.scale, x.rate, x.shift, _add(x.offset, c), exact=x.exact and x.offset is None)
+
+    def negated(self, x):
+        if x.constant():
+            return _Form(rate=ZERO, shift=_neg(_add(x.shift, x.offset)), exact=x.exact)
+        if x.phi == "identity" and x.scale is None and x.offset is None:
+            return _Form(rate=-1.0 if x.rate is None else -x.rate, shift=_neg(x.shift), exact=x.exact)
+        return _Form(x.phi, -1.0 if x.scale is None else -x.scale, x.rate, x.shift, _neg(x.offset), exact=x.exact)
+
+    def summed(self, x, z, sign=1.0):
+        """x + sign * z for two tracked values."""
+        if z.constant():
+            c = _add(z.shift, z.offset)
+            return self.shifted(x, c if sign == 1.0 else _neg(c)) if c is not None else x
+        if x.constant():
+            c = _add(x.shift, x.offset)
+            z = z if sign == 1.0 else self.negated(z)
+            return self.shifted(z, c) if c is not None else z
+        if x.phi == "identity" and z.phi == "identity" and all(v.scale is None and v.offset is None for v in (x, z)):
+            one = 1.0
+            zr, zs = (one if z.rate is None else z.rate), z.shift
+            if sign != 1.0:
+                zr, zs = -zr, _neg(zs)
+            return _Form(rate=(one if x.rate is None else x.rate) + zr, shift=_add(x.shift, zs), exact=False)
+        raise NotElementwise("a sum of two different functions of the state")
+
+    def product(self, x, z):
+        if z.constant():
+            c = _add(z.shift, z.offset)
+            return self.scaled(x, 0.0 if c is None else c)
+        if x.constant():
+            c = _add(x.shift, x.offset)
+            return self.scaled(z, 0.0 if c is None else c)
+        raise NotElementwise("a product of two functions of the state")
+
+    def applied(self, name, x):
+        if x.constant():
+            raise NotElementwise(f"{name} of a constant")         # (legal, rare; leave it to the stepwise path)
+        if x.phi != "identity" or x.scale is not None or x.offset is not None:
+            raise NotElementwise(f"{name} of {x.phi}: nested functions")
+        return _Form(name, None, x.rate, x.shift, None, exact=x.exact)
+
+    # ---- the dispatch hook ---------------------------------------------------------------------------------------
+    _UNARY = {"exp": "exp", "sigmoid": "sigmoid", "tanh": "tanh", "sin": "sin", "cos": "cos"}
+    _SAME = {"alias", "detach", "clone", "lift_fresh", "positive", "contiguous", "_to_copy", "view", "reshape",
+             "_unsafe_view", "expand", "_reshape_alias"}
+    _LIKE = {"zeros_like": 0.0, "ones_like": 1.0}
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        flat = list(args) + list(kwargs.values())
+        involved = [a for a in flat if torch.is_tensor(a)]
+        for a in flat:
+            if isinstance(a, (list, tuple)):
+                involved.extend(x for x in a if torch.is_tensor(x))
+        if any(id(a) in self.time for a in involved):
+            name = func._schema.name
+            if name in ("aten::_local_scalar_dense", "aten::item"):
+                raise NotElementwise("the code reads t on the host")
+            out = func(*args, **kwargs)
+            for o in (out if isinstance(out, (list, tuple)) else (out,)):
+                if torch.is_tensor(o):
+                    self.time.add(id(o))
+                    self.keep.append(o)
+            if any(id(a) in self.forms for a in involved):
+                raise NotElementwise("drift or diffusion depends on t")
+            return out
+        tracked = [a for a in involved if id(a) in self.forms]
+        if not tracked:
+            out = func(*args, **kwargs)
+            # a y-independent value stretched over the probe's rows (`sigma.expand_as(y)`, `sigma.expand(B, d)`)
+            if func._schema.name == "aten::expand" and torch.is_tensor(out) and tuple(out.shape) == (self.rows, self.d):
+                src = args[0]
+                if src.dim() <= 2 and (src.dim() < 2 or src.shape[0] == 1):
+                    return self.track(out, _Form(rate=ZERO, shift=self.coefficient(src if src.dim() < 2 else src[0])))
+            return out
+        schema = func._schema
+        name = schema.name.split("::")[1]
+        if schema.is_mutable:
+            raise NotElementwise(f"in-place {name} on a value derived from the state")
+        out = func(*args, **kwargs)
+        x = self.form_of(args[0]) if args else None
+        if name in self._LIKE or name in ("full_like", "empty_like", "new_zeros", "new_ones", "new_full", "new_empty"):
+            if name in self._LIKE and tuple(out.shape) == (self.rows, self.d) and out.dtype == args[0].dtype:
+                return self.track(out, _Form(rate=ZERO, shift=self._LIKE[name] or None))
+            if name == "full_like" and tuple(out.shape) == (self.rows, self.d) and out.dtype == args[0].dtype \
+                    and isinstance(args[1], (int, float)):
+                return self.track(out, _Form(rate=ZERO, shift=args[1]))
+            raise NotElementwise(f"{name} of the state")
+        if name in self._SAME:
+            if x is None or not torch.is_tensor(out) or tuple(out.shape) != (self.rows, self.d) \
+                    or out.dtype != args[0].dtype or out.device != args[0].device:
+                raise NotElementwise(f"{name} changes the shape, dtype or device of a value derived from the state")
+            return self.track(out, x)
+        if name in self._UNARY and x is not None and len(args) == 1:
+            return self.track(out, self.applied(self._UNARY[name], x))
+        if name == "softplus" and x is not None:
+            beta = args[1] if len(args) > 1 else kwargs.get("beta", 1)
+            threshold = args[2] if len(args) > 2 else kwargs.get("threshold", 20)
+            if beta != 1 or threshold != 20:
+                raise NotElementwise("softplus with a non-default beta or threshold")
+            return self.track(out, self.applied("softplus", x))
+        if name == "neg" and x is not None:
+            return self.track(out, self.negated(x))
+        if name in ("mul", "add", "sub", "rsub", "div") and len(args) >= 2:
+            a, b = args[0], args[1]
+            fa, fb = self.form_of(a), self.form_of(b)
+            alpha = kwargs.get("alpha", 1)
+            if name == "rsub":                          # rsub(a, b) = b - alpha * a
+                a, b, fa, fb, name = b, a, fb, fa, "sub"
+            if alpha != 1:
+                if not isinstance(alpha, (int, float)):
+                    raise NotElementwise("a tensor-valued alpha")
+                if fb is not None:
+                    fb = self.scaled(fb, alpha, exact=False)
+                else:
+                    b = self.coefficient(b) * alpha
+            if name == "mul":
+                form = self.product(fa, fb) if fa is not None and fb is not None else \
+                    self.scaled(fa, self.coefficient(b)) if fa is not None else self.scaled(fb, self.coefficient(a))
+            elif name == "div":
+                if fb is not None:
+                    raise NotElementwise("a division by a function of the state")
+                c = self.coefficient(b)
+                form = self.scaled(fa, 1.0 / c, exact=False)
+            elif name == "add":
+                form = self.summed(fa, fb) if fa is not None and fb is not None else \
+                    self.shifted(fa, self.coefficient(b)) if fa is not None else self.shifted(fb, self.coefficient(a))
+            else:       # sub
+                if fa is not None and fb is not None:
+                    form = self.summed(fa, fb, sign=-1.0)
+                elif fa is not None:
+                    form = self.shifted(fa, -self.coefficient(b))
+                else:
+                    form = self.shifted(self.negated(fb), self.coefficient(a))
+            return self.track(out, form)
+        if name == "pow" and x is not None and len(args) == 2 and isinstance(args[1], (int, float)) and args[1] == 1:
+            return self.track(out, x)
+        raise NotElementwise(f"operator {schema.name} on a value derived from the state")
+
+
+class Recognised:
+    """What the interpretation found: the function codes and, per function, the four coefficients (None = neutral)."""
+
+    def __init__(self, f, g, d, dtype, device):
+        self.f, self.g, self.d, self.dtype, self.device = f, g, d, dtype, device
+        self.exact = f.exact and g.exact
+
+    def structure(self):
+        """The part of the result that does not change when parameter VALUES change: key of the trust verdict."""
+        def shape(form):
+            return (form.phi, form.constant()) + tuple(
+                None if c is None else ("number", c) if isinstance(c, (int, float)) else "tensor"
+                for c in (form.scale, form.rate, form.shift, form.offset))
+        return shape(self.f), shape(self.g)
+
+    def _vector(self, c, neutral):
+        """One coefficient as a contiguous (d,) tensor of the state dtype."""
+        if c is None or isinstance(c, (bool, int, float)):
+            return _constant_vector(neutral if c is None else float(c), self.d, self.dtype, self.device)
+        if c.dtype != self.dtype:
+            raise NotElementwise(f"a coefficient of dtype {c.dtype} with a state of dtype {self.dtype}")
+        return c.detach().reshape(-1).expand(self.d).contiguous()
+
+    def _four(self, form):
+        if form.constant():         # the value is `shift (+ offset)`: rate 0, identity
+            return (self._vector(None, 1.0), self._vector(None, 0.0), self._vector(_add(form.shift, form.offset), 0.0),
+                    self._vector(None, 0.0))
+        return (self._vector(form.scale, 1.0), self._vector(form.rate, 1.0), self._vector(form.shift, 0.0),
+                self._vector(form.offset, 0.0))
+
+    def spec(self):
+        """The `closed_form()` tuple the trajectory launchers take (closed_form.py): affine kernel when both functions
+        are plain `rate * y + shift`, else the expression kernel."""
+        f4, g4 = self._four(self.f), self._four(self.g)
+        plain = all(v.phi == "identity" and v.scale is None and v.offset is None for v in (self.f, self.g))
+        if plain:
+            return ("affine_diagonal", f4[1], f4[2], g4[1], g4[2])
+        return ("elementwise_diagonal", _native.FN_CODES[self.f.phi], _native.FN_CODES[self.g.phi]) + f4 + g4
+
+
+_VECTORS = {}
+
+
+def _constant_vector(value, d, dtype, device):
+    key = (value, d, dtype, str(device))
+    hit = _VECTORS.get(key)
+    if hit is None:
+        if len(_VECTORS) > 256:
+            _VECTORS.clear()
+        hit = _VECTORS[key] = torch.full((d,), value, dtype=dtype, device=device)
+    return hit
+
+
+def recognise(sde, t, y0):
+    """Interpret ``sde.f_and_g`` (a ForwardSDE: whichever of f / g / f_and_g the user defined) on a probe of the state's
+    width; returns `Recognised` or raises `NotElementwise`. Launches a handful of tiny kernels, never synchronises."""
+    rows = 2 if y0.shape[0] != 2 else 3         # a per-ROW constant of the real batch cannot broadcast against the probe
+    d = y0.shape[1]
+    probe = y0.detach()[:1].expand(rows, d).clone() if y0.shape[0] > 0 else torch.zeros(rows, d, dtype=y0.dtype,
+                                                                                       device=y0.device)
+    t_probe = t.detach().clone()
+    interp = _Interpreter(probe, t_probe, rows, d)
+    previous = torch.cuda.get_sync_debug_mode() if y0.is_cuda else 0
+    try:
+        if y0.is_cuda:
+            torch.cuda.set_sync_debug_mode("error")       # a host synchronisation in f or g: not this route
+        try:
+            with torch.no_grad(), interp:
+                f, g = sde.f_and_g(t_probe, probe)
+        finally:
+            if y0.is_cuda:
+                torch.cuda.set_sync_debug_mode(previous)
+    except NotElementwise:
+        raise
+    except Exception as e:        # the user's code failed on the probe (a per-row buffer of the real batch, a sync ...)
+        raise NotElementwise(f"{type(e).__name__}: {e}") from None
+    forms = []
+    for name, value in (("drift", f), ("diffusion", g)):
+        form = interp.form_of(value)
+        if form is None:
+            raise NotElementwise(f"the {name} is not a tracked function of the state")
+        forms.append(form)
+    return Recognised(forms[0], forms[1], d, y0.dtype, y0.device)
