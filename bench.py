@@ -7,14 +7,17 @@ N > 1 runs one rank per GPU over RCCL, either way it is started: under the drive
 itself (and refuses, exit code 3, when the node has fewer than N GPUs). The line reports what the process group
 really was (`ranks_seen`, `rank_devices`, `collective_backend`) and the all-gather's own time per solve.
 
-One bench "step" = one full solve of the workload: BASELINE.json configs[1], diagonal-noise Ito
-Euler-Maruyama, batch 65536 x state 64, 1000 fixed solver steps (dyadic dt = 2^-10 so the count is exact
-in float32), geometric Brownian motion f = mu*y, g = sigma*y as user torch code, Brownian increments
-generated in registers by the fused step kernel. Inputs are resident in HBM before the timed region.
-N > 1: every rank solves its own rows (weak scaling; RNG rows are global, so results are the rows an
-unsharded run would produce) and the final states are all-gathered once per solve over RCCL.
+One bench "step" = one full solve of the workload: BASELINE.json configs[1], diagonal-noise Ito Euler-Maruyama, batch
+65536 x state 64, 1000 fixed solver steps (dyadic dt = 2^-10 so the count is exact in float32), geometric Brownian
+motion f = mu*y, g = sigma*y as an UNCHANGED user module of plain torch code, handed to `sdeint` with no options -- the
+drop-in call. torchsde_amd/recognise.py interprets f and g at every solve, finds them per-channel affine, and the solve
+is one launch of the trajectory kernel (state in registers, increments from the counter RNG). The same job on the
+STEPWISE route (user f, g as torch kernels between the per-step kernels; the route of every SDE that is not a
+per-channel expression) is measured right after and reported inside the line as `stepwise`. Inputs are resident in HBM
+before the timed region. N > 1: every rank solves its own rows (weak scaling; RNG rows are global, so results are the
+rows an unsharded run would produce) and the final states are all-gathered once per solve over RCCL.
 BASELINE configs[3] (Stratonovich midpoint, 262144 x 64 sharded over 8 GPUs) is
-`--gpus 8 --workload c4_midpoint_diag_b32768_d64`: 32768 rows per GPU.
+`--gpus 8 --workload c4_midpoint_diag_default_route_b32768_d64` (stepwise: `c4_midpoint_diag_b32768_d64`): 32768 rows per GPU.
 
 The LAST stdout line (rank 0) is the headline JSON, under 4 KB; the side measurements are printed before it, one short
 line per workload, and written whole to bench_also.json:
@@ -22,20 +25,23 @@ line per workload, and written whole to bench_also.json:
 * `value` = trajectory-steps/s over the K timed solves (barrier + synchronize on both sides, max over ranks);
   `median_ms_per_step` / `value_median` restate it from the median of the per-solve times (HIP events recorded
   between the solves of the same timed region);
-* `roofline`: two fractions of the 8 TB/s HBM peak, named for what they are --
+* `roofline` (trajectory kernel): `achieved` = SURVEY 8d's bytes per trajectory-step x the trajectory-steps one launch
+  processes / the launch's duration (HIP events inside the library, on the launch stream); `frac` = that / 8 TB/s and is
+  ABOVE 1, because a one-launch solve never moves those bytes -- `traffic` is what the launch really moves (y0 in,
+  final state out). The kernel is VALU-bound (Philox + Box-Muller per element-step);
+* `stepwise.roofline`: the per-step kernel's two fractions of the HBM peak, named for what they are --
     `frac`        KERNEL level: the dominant kernel's SURVEY-8d algorithmic bytes per solver step / the duration of its
                   launches, measured live with HIP events around the replay of a HIP graph of 200 launches on live,
                   rotating operands (agrees with the rocprofv3 kernel trace of the solve under profiles/);
     `solve_frac`  SOLVE level: algorithmic bytes per trajectory-step x `value` / (N x 8e12), i.e.
                   with the user's f and g torch kernels and every launch gap inside;
   `traffic` (HBM bytes per launch from rocprofv3 PMC passes, tools/profile_traffic.sh) and `kernel_us_rocprofv3` are
-  taken from profiles/traffic_latest.json ONLY when that file was collected on the kernel sources this run uses
-  (`traffic_source` names file and source digest);
+  taken from profiles/traffic_latest.json ONLY when that file was collected on the kernel sources this run uses;
 * `cpu_baseline`: the oracle's port of the reference's CPU algorithm, timed on this host's cores on a bounded sample;
-* side measurements (single-GPU default run; `also` lines + bench_also.json): every other BASELINE configuration at its single-GPU size on the stepwise path
-  (configs[2] Euler-general and the Milstein-general extension, the configs[3] shard, configs[4] sdeint_adjoint), each
-  with ms per solve (median of 5) and the same kernel-level measurement, bytes, fractions and counter traffic as the
-  headline; then the same jobs when the SDE is handed over in closed form. Not part of `value`; `--no-also` skips them.
+* side measurements (single-GPU default run; `also` lines + bench_also.json): every other BASELINE configuration at its
+  single-GPU size on the stepwise path (configs[2] Euler-general and the Milstein-general extension, the configs[3]
+  shard, configs[4] sdeint_adjoint), each with ms per solve (median of 5) and the same kernel-level measurement, bytes,
+  fractions and counter traffic; then the default-route and closed-form variants. Not part of `value`; `--no-also` skips them.
 """
 import argparse
 import hashlib
@@ -55,13 +61,14 @@ from workloads.configs import WORKLOADS, make_problem as _make_problem  # noqa: 
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-in/f32-accumulate matrix rate (same guide)
-HEADLINE = "c2_euler_diag_b65536_d64_s1000"
+HEADLINE = "c2_euler_diag_default_route_b65536_d64_s1000"
 # the stepwise BASELINE configurations, then what the closed-form route makes of the same jobs
 ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c3_euler_general_b16384_d32_m16", "c3_milstein_general_b16384_d32_m16",
         "c3_milstein_general_gradfree_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
-        "c2_euler_closed_form_b65536_d64_s1000", "c2_euler_expdiff_closed_form_b65536_d64_s1000",
+        "c2_milstein_diag_default_route", "c2_srk_diag_default_route", "c4_midpoint_diag_default_route_b32768_d64",
+        "c2_euler_expdiff_default_route_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
         "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500")
 
@@ -183,6 +190,10 @@ class Job:
         bm = self._BM(t0=0.0, t1=c["nsteps"] * c["dt"], size=(c["B"], c["m"]), dtype=torch.float32, device=self.dev,
                       entropy=20240601 + i, dt=c["dt"], levy_area_approximation=c["levy"], row_offset=self.rank * c["B"])
         extra_options = dict(c.get("options") or {})
+        if not self.trajectory:
+            # a stepwise measurement: the GBM / exp-diffusion user modules would otherwise be recognised as per-channel
+            # expressions and run as one trajectory launch (torchsde_amd/recognise.py) -- that is the headline's route
+            extra_options.setdefault("trajectory_kernel", False)
         if self.adjoint or self.train:
             with torch.enable_grad():
                 if self.adjoint:
@@ -201,8 +212,9 @@ class Job:
                 sharding.all_reduce_gradients(list(self.sde.parameters()))
             return self.y0.grad
         with torch.no_grad():
+            # (a recognised workload is the drop-in call: no options at all)
             ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
-                              options=dict(extra_options, hip_graph=bool(graph)))
+                              options=None if c.get("recognised") else dict(extra_options, hip_graph=bool(graph)))
             if self.dist is not None:
                 self.dist.all_gather_into_tensor(self.gathered, ys[-1])
                 return self.gathered
@@ -212,10 +224,16 @@ class Job:
         """Everything a first solve pays once, before any warm-up or timing: recording the HIP graph(s) of this workload
         (with the checks that come with it) and their probation -- the first two replays of a recorded graph run next
         to the eager path and are compared with it (torchsde_amd/graph.py)."""
-        if self.use_graph:
+        if self.use_graph or self.cfg.get("recognised"):
             for i in range(4):
                 self.solve(9000 + i)
             torch.cuda.synchronize()
+        if self.cfg.get("recognised"):
+            # the first solve ran both ways and compared (solvers._integrate_recognised); the timed ones must be launches
+            from torchsde_amd import solvers
+            book = getattr(self.sde, solvers.BaseSDESolver._RECOGNISED_ATTR, None)
+            if not book or list(book["trusted"].values()) != [True]:
+                raise RuntimeError(f"{self.name}: the user module was not routed to the trajectory kernel: {book}")
 
     def live_state(self, out):
         """A state tensor of this workload's shape with live values: the solve's final state where `out` is one."""
@@ -344,6 +362,26 @@ class Job:
                     "note": "f32-in / f32-accumulate MFMA (exact f32); peak = dense f32 matrix rate of "
                             "guides/MI355X_MICROARCH.md",
                     "timing": "HIP events bracketing every launch of this kernel in 8 eagerly issued solves"}
+        if self.trajectory and c.get("bytes_per_traj_step"):
+            # One launch is the whole solve: B x nsteps trajectory-steps. `achieved` prices it as the contract says --
+            # SURVEY 8d's bytes per trajectory-step x the units one launch processes / its duration -- and comes out ABOVE
+            # the HBM peak, because those bytes never reach HBM: the state lives in registers, the increments come from
+            # the counter RNG, f and g are evaluated in the kernel. `traffic` is what the launch really moves.
+            per_launch = c["bytes_per_traj_step"] * B * nsteps
+            achieved = per_launch / raw_s / 1e9
+            moved = 2 * B * d * 4
+            return {"bound": "hbm", "kernel": c["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS,
+                    "frac_is": "SURVEY 8d bytes per trajectory-step x trajectory-steps per launch / launch time / peak; above 1 "
+                               "because a one-launch solve keeps those bytes in registers (VALU-bound: Philox + Box-Muller)",
+                    "bytes_per_traj_step": c["bytes_per_traj_step"], "bytes_per_launch": per_launch,
+                    "solve_achieved": c["bytes_per_traj_step"] * value / self.world / 1e9,
+                    "solve_frac": c["bytes_per_traj_step"] * value / self.world / 1e9 / HBM_PEAK_GBPS,
+                    "traffic": moved, "traffic_is": "HBM bytes one launch really moves: y0 in, final state out",
+                    "traffic_over_algorithmic": moved / per_launch,
+                    "avg_launch_us": raw_s * 1e6, "launches_timed": k_launches, "launches_per_solve": 1,
+                    "element_steps_per_s": B * d * nsteps / raw_s,
+                    "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
         if self.trajectory:
             # One launch per solve: it reads y0 and writes the requested outputs, nothing else touches HBM. The kernel is
             # bound by the VALU work of the counter RNG (Philox-4x32-10 + Box-Muller per element-step) and of f, g.
@@ -522,6 +560,33 @@ def _side_measurement(dev, name):
     return rec
 
 
+def _stepwise_beside(dev, name, args):
+    """The same job on the STEPWISE route (options={"trajectory_kernel": False}: the user's f, g as torch kernels between
+    the per-step kernels, HIP-graph replay), reported inside a recognised headline: its trajectory-steps/s over the same
+    number of solves, the per-step kernel's HBM fraction (kernel level) and the solve-level fraction of SURVEY 8d."""
+    job = Job(name, dev, graph=not args.eager)
+    c = job.cfg
+    job.prepare()
+    for i in range(args.warmup):
+        job.solve(i)
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for i in range(args.steps):
+        out = job.solve(1000 + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - start
+    value = c["B"] * c["nsteps"] * args.steps / elapsed
+    roof = job.roofline_stepwise(value, job.back_to_back_us(job.live_state(out)))
+    _attach_offline_traffic(roof, name)
+    keep = ("kernel", "achieved", "frac", "solve_achieved", "solve_frac", "bytes_per_traj_step", "bytes_per_launch",
+            "avg_launch_us", "launches_per_step", "traffic", "traffic_over_algorithmic", "kernel_us_rocprofv3",
+            "frac_rocprofv3")
+    return {"workload": name, "value": value, "ms_per_step": elapsed / args.steps * 1e3,
+            "route": "options={'trajectory_kernel': False}: user f, g torch kernels + one fused step kernel per step, "
+                     "HIP graph replay",
+            "roofline": {k: roof[k] for k in keep if k in roof}}
+
+
 def _side_measurements(dev):
     """Short measurements reported under `also`: outside the headline's timed region and NOT part of `value`. A
     failure here is reported in place and never takes the headline down with it."""
@@ -643,6 +708,8 @@ def main():
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short side measurements reported under `also`")
+    ap.add_argument("--no-stepwise", action="store_true",
+                    help="skip the stepwise solve of the same workload reported beside a recognised headline")
     ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="tools/profile_traffic.sh only: solve this many solver steps of the workload and print a line "
@@ -727,6 +794,9 @@ def main():
         roofline = job.roofline_stepwise(value, job.back_to_back_us(job.live_state(out)))
         _attach_offline_traffic(roofline, args.workload)
 
+    stepwise = None
+    if world == 1 and cfg.get("stepwise") and not args.no_stepwise:
+        stepwise = _stepwise_beside(dev, cfg["stepwise"], args)
     also = None
     if world == 1 and not args.no_also and args.workload == HEADLINE:
         del job
@@ -745,7 +815,10 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload,
-                       "sde": cfg["problem"] + (" (closed-form coefficients; f, g evaluated in the kernel)" if trajectory
+                       "sde": cfg["problem"] + (" (UNCHANGED user module, f, g plain torch code; recognised as per-channel "
+                                                "expressions at every solve and evaluated in the kernel)"
+                                                if cfg.get("recognised") else
+                                                " (closed-form coefficients; f, g evaluated in the kernel)" if trajectory
                                                 else " (f, g are user torch ops)"),
                        "method": cfg["method"] + ("+adjoint:" + cfg["adjoint_method"] if adjoint else "") +
                                  (" + loss.backward() through the solver" if train else ""),
@@ -760,6 +833,8 @@ def main():
                        "csrc_sha": csrc_digest()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if stepwise is not None:
+            line["stepwise"] = stepwise
         line.update(ranks)
         if also is not None:
             line["also_file"] = _emit_also(also)

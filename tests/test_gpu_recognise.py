@@ -1,0 +1,216 @@
+"""An UNCHANGED user module whose drift and diffusion are per-channel expressions reaches the trajectory kernels
+(torchsde_amd/recognise.py; ``-m gpu``): the first solve of a form runs both ways and returns the stepwise result, later
+ones are one kernel launch -- with the parameter values, closures and globals of THAT solve --, everything that does not
+fit keeps the stepwise path, and `options={"trajectory_kernel": False}` opts out."""
+import pytest
+import torch
+from torch import nn
+
+from workloads import problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, D, STEPS, DT = 256, 8, 32, 2.0 ** -7
+
+
+def _solve(sde, entropy, y0=None, stepwise=False, method="euler", levy="none", ts=None, dtype=torch.float32):
+    import torchsde_amd
+    y0 = torch.full((B, D), 0.1, device=DEV, dtype=dtype) if y0 is None else y0
+    ts = torch.tensor([0.0, 11 * DT, STEPS * DT] if ts is None else ts, device=DEV, dtype=dtype)
+    bm = torchsde_amd.BrownianInterval(0.0, float(ts[-1]), size=tuple(y0.shape), device=DEV, dtype=dtype, entropy=entropy,
+                                       levy_area_approximation=levy)
+    options = {"hip_graph": False}
+    if stepwise:
+        options["trajectory_kernel"] = False
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=DT, options=options)
+
+
+def _book(sde):
+    from torchsde_amd import solvers
+    return getattr(sde, solvers.BaseSDESolver._RECOGNISED_ATTR, {"trusted": {}, "refused": {}})
+
+
+def _launches(fn):
+    """(fn(), number of trajectory-kernel launches it made): the library's profiling bracket of that kernel family."""
+    from torchsde_amd import kernels as K
+    K.prof_begin(8, 64)             # TSDE_KID_TRAJECTORY (include/torchsde_amd.h)
+    out = fn()
+    torch.cuda.synchronize()
+    return out, K.prof_end()[1]
+
+
+class _Benchmark(nn.Module):
+    """The SDE of the reference's own benchmark (benchmarks/brownian.py:131-139), verbatim."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def f(self, t, y):
+        return y
+
+    def g(self, t, y):
+        return torch.exp(-y)
+
+
+@pytest.mark.parametrize("method,levy,sde_type", [("euler", "none", "ito"), ("milstein", "none", "ito"),
+                                                  ("srk", "space-time", "ito"), ("midpoint", "none", "stratonovich"),
+                                                  ("milstein", "none", "stratonovich")])
+def test_headline_module_untouched_takes_the_affine_kernel_bit_for_bit(method, levy, sde_type):
+    """tests/problems.py ExDiagonal as bench.py states it (workloads.problems.GBMDiag: f = mu * y, g = sigma * y)."""
+    sde = problems.make("gbm_ito" if sde_type == "ito" else "gbm_strat", d=D).to(DEV)
+    first = _solve(sde, 1, method=method, levy=levy)
+    assert torch.equal(first, _solve(sde, 1, stepwise=True, method=method, levy=levy))      # the verifying solve
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    for entropy in (2, 3):
+        fast = _solve(sde, entropy, method=method, levy=levy)
+        slow = _solve(sde, entropy, stepwise=True, method=method, levy=levy)
+        if sde_type == "ito":       # plain rate * y: the kernel's operations are the stepwise path's, one for one
+            assert torch.equal(fast, slow), (method, (fast - slow).abs().max())
+        else:                        # mu*y - 0.5*sigma^2*y folds two rates into one: rounding-level agreement
+            torch.testing.assert_close(fast, slow, rtol=2e-6, atol=2e-7)
+
+
+def test_reference_benchmark_sde_and_float64():
+    for dtype, tol in ((torch.float32, dict(rtol=5e-6, atol=5e-7)), (torch.float64, dict(rtol=1e-13, atol=1e-14))):
+        sde = _Benchmark().to(DEV)
+        _solve(sde, 1, dtype=dtype)
+        assert list(_book(sde)["trusted"].values()) == [True]
+        fast, slow = _solve(sde, 2, dtype=dtype), _solve(sde, 2, stepwise=True, dtype=dtype)
+        torch.testing.assert_close(fast, slow, **tol)
+        assert not torch.equal(fast[-1], fast[0])
+
+
+_GAIN = 1.0
+
+
+class _Live(nn.Module):
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, schedule):
+        super().__init__()
+        self.theta = nn.Parameter(torch.linspace(0.5, 1.5, D))
+        self.mean = nn.Parameter(torch.full((D,), 0.3))
+        self.w = nn.Parameter(torch.full((1, D), 0.7))
+        self.b = torch.linspace(-0.2, 0.2, D, device=DEV)       # a plain tensor attribute
+        self.schedule = schedule
+
+    def f(self, t, y):
+        return _GAIN * self.theta * (self.mean - y)
+
+    def g(self, t, y):
+        return self.schedule[0] * torch.sigmoid(self.w * y + self.b)
+
+
+def test_every_solve_uses_the_live_values(monkeypatch):
+    """Parameters after an optimiser step, a re-bound tensor attribute, a closure list and a module global: the
+    interpretation runs the user's code at every solve, so each change shows in the next launch -- checked against the
+    stepwise path, which calls the user's code at every step like the reference (base_solver.py:143-149)."""
+    import sys
+    schedule = [0.2]
+    sde = _Live(schedule).to(DEV)
+    tol = dict(rtol=2e-5, atol=2e-6)
+    _solve(sde, 1)
+
+    def check(entropy):
+        fast, n = _launches(lambda: _solve(sde, entropy))
+        assert n == 1, n                                   # ONE trajectory launch was the whole solve
+        torch.testing.assert_close(fast, _solve(sde, entropy, stepwise=True), **tol)
+        return fast
+
+    a = check(2)
+    with torch.no_grad():
+        sde.theta.mul_(1.5)
+        sde.mean.add_(0.2)
+    b = check(2)
+    assert not torch.allclose(a, b)
+    schedule[0] = 0.4
+    c = check(2)
+    assert not torch.allclose(b, c)
+    monkeypatch.setattr(sys.modules[__name__], "_GAIN", 2.0)
+    e = check(2)
+    assert not torch.allclose(c, e)
+    sde.b = torch.zeros(D, device=DEV)
+    assert not torch.allclose(e, check(2))
+    assert list(_book(sde)["trusted"].values()) == [True]          # one form all along: verified once
+
+
+class _TimeDependent(_Live):
+    def f(self, t, y):
+        return torch.cos(t) * self.theta * y
+
+
+class _Counting(_Live):
+    calls = 0
+
+    def f(self, t, y):
+        self.calls += 1
+        return (1.0 + 0.01 * self.calls) * self.theta * y
+
+
+class _PerRow(_Live):
+    def g(self, t, y):
+        return self.rowscale * y
+
+
+def test_code_that_does_not_fit_keeps_the_stepwise_path():
+    for sde in (_TimeDependent([0.2]).to(DEV), problems.make("mlpdiag_ito", d=D).to(DEV), _Counting([0.2]).to(DEV)):
+        if isinstance(sde, _Counting):
+            # (its coefficients change with every call: only the comparison of two interpretations can tell)
+            for entropy in (1, 2, 3):
+                _, n = _launches(lambda: _solve(sde, entropy))
+                assert n == 0
+            assert not any(v is True for v in _book(sde)["trusted"].values()) or _book(sde)["refused"]
+            continue
+        for entropy in (1, 2, 3):
+            got, n = _launches(lambda: _solve(sde, entropy))
+            assert n == 0 and torch.equal(got, _solve(sde, entropy, stepwise=True))
+        assert len(_book(sde)["refused"]) == 1 and not _book(sde)["trusted"]
+    rows = _PerRow([0.2]).to(DEV)
+    rows.rowscale = torch.rand(B, 1, device=DEV)            # one value per ROW: not a per-channel coefficient
+    got, n = _launches(lambda: _solve(rows, 1))
+    assert n == 0 and torch.equal(got, _solve(rows, 1, stepwise=True)) and _book(rows)["refused"]
+
+
+def test_gradients_and_the_opt_out_keep_the_stepwise_path():
+    import torchsde_amd
+    sde = problems.make("gbm_ito", d=D).to(DEV)
+    _solve(sde, 1)
+    _, n = _launches(lambda: _solve(sde, 2))
+    assert n == 1
+    _, n = _launches(lambda: _solve(sde, 2, stepwise=True))
+    assert n == 0
+    y0 = torch.full((B, D), 0.1, device=DEV, requires_grad=True)
+    ts = torch.tensor([0.0, STEPS * DT], device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, D), device=DEV, entropy=3)
+    ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=DT)
+    ys[-1].sum().backward()
+    assert torch.isfinite(y0.grad).all() and all(p.grad is not None for p in sde.parameters())
+
+
+def test_full_size_headline_on_the_recognised_route_rows_vs_oracle():
+    """BASELINE configs[1] (65536 x 64, 1000 Euler steps), the untouched GBM module, through the recognised route: the
+    same sampled rows, the same oracle and the same bound as tests/test_gpu_full_size_oracle.py applies to the stepwise
+    route."""
+    import torchsde_amd
+    from tests import helpers
+    from tests.test_gpu_full_size_oracle import _bm, _oracle_forward
+    from workloads import configs
+    c = configs.WORKLOADS["c2_euler_diag_b65536_d64_s1000"]
+    Bf, d, n, dt = c["B"], c["d"], c["nsteps"], c["dt"]
+    sde = configs.make_problem(c["problem"], d, d, DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            first = torchsde_amd.sdeint(sde, y0, ts, bm=_bm(Bf, d, n, dt, 20240601), method="euler", dt=dt)
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=_bm(Bf, d, n, dt, 20240601),
+                                                                 method="euler", dt=dt))
+        assert launches == 1 and torch.equal(ys, first)         # kernel route == the stepwise solve it was verified against
+        rows = helpers.sampled_rows(Bf, 64, seed=2, seams=(32, 2048 * 32 // d, Bf - 32))
+        ref32, ref64 = _oracle_forward(sde, rows, d, d, 20240601, n, dt, "euler", 0.1)
+        new = ys[-1][torch.from_numpy(rows).to(DEV)]
+        helpers.assert_within_reference_rounding(new, ref32[-1], ref64[-1], "C2 Euler final state, recognised route")
+        assert (new.cpu() - ref32[-1]).abs().max().item() < 2e-6
+    finally:
+        torch.set_num_threads(before)

@@ -16,10 +16,9 @@ and keeps, for each such value, the five per-channel coefficient tensors of the 
 do not depend on ``y`` (parameters, buffers, Python numbers) simply execute -- on (d,)-sized data -- so the coefficients
 are computed from the LIVE parameter values of this very solve: an optimiser step, a changed module global or closure
 are seen because the user's code has just run. Anything else -- a value derived from ``t``, an operator outside the
-small elementwise table, a reshape of the state, an in-place update of it, a per-row constant, a host synchronisation --
-ends the interpretation and the solve takes the stepwise path, as before.
+small elementwise table, a reshape of the state, an in-place update of it, a per-row constant, `float(t)` -- ends the interpretation and the solve takes the stepwise path, as before.
 
-Nothing here synchronises with the host. Whether a recognised form may be trusted is decided once per (Python-side state
+Nothing here synchronises with the host (unless the user's code does, on its own constants). Whether a recognised form may be trusted is decided once per (Python-side state
 of the SDE object, form, scheme, shapes) by solving both ways and comparing (`solvers.BaseSDESolver._recognised`).
 """
 import torch
@@ -27,7 +26,9 @@ from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import _native
 
-aten = torch.ops.aten
+# TSDE_RECOGNISE=0 switches the route off for the process (tests of the stepwise machinery also clear `ENABLED`)
+import os as _os
+ENABLED = _os.environ.get("TSDE_RECOGNISE", "1").strip().lower() not in ("0", "false", "off")
 
 
 class NotElementwise(Exception):
@@ -74,6 +75,11 @@ def _neg(a):
     return None if a is None else -a
 
 
+def _times(a, c):
+    """An additive coefficient (None = 0) times c."""
+    return None if a is None else a * c
+
+
 class _Interpreter(TorchDispatchMode):
     def __init__(self, y, t, rows, d):
         super().__init__()
@@ -110,13 +116,13 @@ class _Interpreter(TorchDispatchMode):
     def scaled(self, x, c, exact=True):
         """x * c for a per-channel c."""
         if x.constant():
-            return _Form(rate=ZERO, shift=_mul(_add(x.shift, x.offset), c), exact=x.exact)
+            return _Form(rate=ZERO, shift=_times(_add(x.shift, x.offset), c), exact=x.exact)
         if x.phi == "identity" and x.scale is None and x.offset is None:
             if x.rate is None and x.shift is None:
                 return _Form(rate=c, exact=x.exact and exact)
-            return _Form(rate=_mul(x.rate, c), shift=_mul(x.shift, c), exact=False)
+            return _Form(rate=_mul(x.rate, c), shift=_times(x.shift, c), exact=False)
         plain = x.scale is None and x.offset is None
-        return _Form(x.phi, _mul(x.scale, c), x.rate, x.shift, _mul(x.offset, c), exact=x.exact and plain and exact)
+        return _Form(x.phi, _mul(x.scale, c), x.rate, x.shift, _times(x.offset, c), exact=x.exact and plain and exact)
 
     def shifted(self, x, c):
         """x + c for a per-channel c."""
@@ -284,8 +290,12 @@ class Recognised:
         """One coefficient as a contiguous (d,) tensor of the state dtype."""
         if c is None or isinstance(c, (bool, int, float)):
             return _constant_vector(neutral if c is None else float(c), self.d, self.dtype, self.device)
-        if c.dtype != self.dtype:
+        if c.dtype != self.dtype and c.dim() > 0:
             raise NotElementwise(f"a coefficient of dtype {c.dtype} with a state of dtype {self.dtype}")
+        if c.dtype != self.dtype and not c.is_floating_point():
+            raise NotElementwise(f"a 0-d coefficient of dtype {c.dtype}")
+        if c.dtype != self.dtype or c.device != self.device:      # a 0-d tensor takes part like a Python number
+            c = c.to(device=self.device, dtype=self.dtype)
         return c.detach().reshape(-1).expand(self.d).contiguous()
 
     def _four(self, form):
@@ -327,19 +337,12 @@ def recognise(sde, t, y0):
                                                                                        device=y0.device)
     t_probe = t.detach().clone()
     interp = _Interpreter(probe, t_probe, rows, d)
-    previous = torch.cuda.get_sync_debug_mode() if y0.is_cuda else 0
     try:
-        if y0.is_cuda:
-            torch.cuda.set_sync_debug_mode("error")       # a host synchronisation in f or g: not this route
-        try:
-            with torch.no_grad(), interp:
-                f, g = sde.f_and_g(t_probe, probe)
-        finally:
-            if y0.is_cuda:
-                torch.cuda.set_sync_debug_mode(previous)
+        with torch.no_grad(), interp:
+            f, g = sde.f_and_g(t_probe, probe)
     except NotElementwise:
         raise
-    except Exception as e:        # the user's code failed on the probe (a per-row buffer of the real batch, a sync ...)
+    except Exception as e:        # the user's code failed on the probe (a per-row buffer of the real batch, say)
         raise NotElementwise(f"{type(e).__name__}: {e}") from None
     forms = []
     for name, value in (("drift", f), ("diffusion", g)):

@@ -202,6 +202,10 @@ class BaseSDESolver:
             ys = self._integrate_trajectory(coefficients, y0, ts)
             if ys is not None:
                 return ys, self._extra
+        else:
+            ys = self._integrate_recognised(y0, ts)
+            if ys is not None:
+                return ys, self._extra
         from . import graph
         mode = graph.mode_of(self.options)
         if mode is True:
@@ -367,6 +371,98 @@ class BaseSDESolver:
                 return None
             return ("differentiable",) + tuple(own)
         return spec[1:]
+
+    # ---- unchanged user modules whose f and g are per-channel expressions (recognise.py) ----------------------
+    _RECOGNISED_ATTR = "_tsde_recognised"
+
+    def _integrate_recognised(self, y0, ts):
+        """The solve as ONE trajectory-kernel launch when the user's own, unchanged drift and diffusion turn out to be
+        per-channel expressions ``scale * phi(rate * y + shift) + offset`` (recognise.py interprets the code on a
+        probe of a few rows at every solve, so the coefficients are this solve's live parameter values); None when that
+        does not apply, and the caller goes on to the stepwise path.
+
+        Trust is earned once per (form, scheme, state width, dtype) on each SDE object: the first such solve also runs
+        stepwise -- the reference's arithmetic, base_solver.py:143-149 -- and the two must agree to the float32 tolerance
+        the closed-form routes are tested to (rtol 1e-4, atol 1e-5; float64: 1e-9, 1e-11); the interpretation must be
+        repeatable (same coefficients when run twice) and must leave the object's Python-side state alone (a call
+        counter that feeds the coefficients would make one interpretation per solve mean something else than one call
+        per step). That first solve returns the stepwise result. A refusal is remembered per Python-side state of the
+        object, so code that does not fit costs one interpretation, not one per solve.
+        `options={"trajectory_kernel": False}` opts out."""
+        from . import graph, recognise
+        from .sde import ForwardSDE
+        sde = self.sde
+        if (not recognise.ENABLED or not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful
+                or type(sde) is not ForwardSDE or sde.user_product or sde.noise_type != NOISE_TYPES.diagonal
+                or self._trajectory_code() is None or self._tracks_grad(y0)):
+            return None
+        bm = self._native_bm()
+        if (bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or not y0.is_cuda or y0.shape[0] < 8
+                or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
+                or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
+                or (self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
+            return None
+        chain, base = graph._wrapper_chain(sde)
+        try:
+            book = base.__dict__.setdefault(self._RECOGNISED_ATTR, {"refused": {}, "trusted": {}})
+        except AttributeError:
+            return None
+        state = None
+        if book["refused"]:
+            state = graph.python_state(base)
+            if state is None or (state, chain, type(self).__name__) in book["refused"]:
+                return None
+
+        def refuse(reason):
+            key = (state if state is not None else graph.python_state(base), chain, type(self).__name__)
+            if key[0] is not None:
+                if len(book["refused"]) >= 16:
+                    book["refused"].clear()
+                book["refused"][key] = reason
+            return None
+
+        try:
+            found = recognise.recognise(sde, ts[0], y0)
+            spec = found.spec()
+        except recognise.NotElementwise as e:
+            return refuse(str(e))
+        key = (found.structure(), chain, type(self).__name__, sde.sde_type, y0.shape[1], y0.dtype)
+        verdict = book["trusted"].get(key)
+        launch = spec[1:] if spec[0] == "affine_diagonal" else spec       # (what `_integrate_trajectory` takes)
+        if verdict is True:
+            return self._integrate_trajectory(launch, y0, ts)
+        if verdict is not None:
+            return None
+        # first solve of this form: is the interpretation repeatable and free of side effects, and does the kernel
+        # reproduce the stepwise solve?
+        before = graph.python_state(base)
+        try:
+            again = recognise.recognise(sde, ts[0], y0).spec()
+        except recognise.NotElementwise as e:
+            return refuse(str(e))
+        if before is None or graph.python_state(base) != before:
+            return refuse("calling f and g changes the object's Python-side state")
+        same = len(again) == len(spec) and all(
+            (torch.equal(a, b) if torch.is_tensor(a) else a == b) for a, b in zip(again, spec))
+        if not same:
+            book["trusted"][key] = "two interpretations of the same code gave different coefficients"
+            return None
+        fast = self._integrate_trajectory(launch, y0, ts)
+        if fast is None:
+            return None                  # (grid and Brownian cells do not line up: nothing learnt about the form)
+        self._extra = ()
+        stepwise = self._run(self._plan(y0, ts), y0)
+        rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
+        both_nan = fast.isnan() & stepwise.isnan()
+        close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
+        book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
+        return stepwise
+
+    def recognised_route(self):
+        """{form key: True | reason} and {state: reason} of the SDE object this solver integrates (diagnostics)."""
+        from . import graph
+        _, base = graph._wrapper_chain(self.sde)
+        return getattr(base, self._RECOGNISED_ATTR, None)
 
     def _integrate_trajectory(self, coefficients, y0, ts):
         """All steps in one kernel launch; None if the Brownian motion's cells do not line up with the steps."""

@@ -3,7 +3,34 @@ measures), and the synthetic SDEs they run on. Shared by bench.py, tools/ and th
 import torch
 
 WORKLOADS = {
-    # BASELINE.json configs[1] -- the headline (default) workload
+    # BASELINE.json configs[1] as a drop-in user gets it -- THE HEADLINE: the untouched GBM module (f = mu * y, g = sigma * y
+    # as user torch code) handed to sdeint with no options. torchsde_amd/recognise.py interprets f and g at every solve,
+    # finds them per-channel affine and the whole solve is ONE launch of the trajectory kernel (state in registers,
+    # increments from the counter RNG). `bytes_per_traj_step` is SURVEY 8d's figure for this configuration (what a
+    # one-kernel-per-step design streams); the kernel's real HBM traffic is y0 in + final state out.
+    "c2_euler_diag_default_route_b65536_d64_s1000": dict(
+        problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True, stepwise="c2_euler_diag_b65536_d64_s1000",
+        kernel="tsde_trajectory_affine_diag<float, euler> (trajectory_kernel; user module recognised by recognise.py)"),
+    "c2_milstein_diag_default_route": dict(
+        problem="gbm_ito", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=20 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_affine_diag<float, milstein> (user module recognised)"),
+    "c2_srk_diag_default_route": dict(
+        problem="gbm_ito", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=64 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_affine_diag<float, srk> (user module recognised)"),
+    "c4_midpoint_diag_default_route_b32768_d64": dict(
+        problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=32 * 64, kid=8, trajectory=True, recognised=True, stepwise="c4_midpoint_diag_b32768_d64",
+        kernel="tsde_trajectory_affine_diag<float, midpoint> (user module recognised)"),
+    # the reference's own benchmark SDE, verbatim (benchmarks/brownian.py:131-139: f = y, g = exp(-y)), no options
+    "c2_euler_expdiff_default_route_b65536_d64_s1000": dict(
+        problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -16,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_expr_diag<float, euler> (user module recognised: f = y, g = exp(-y) in the kernel)"),
+    # BASELINE.json configs[1], STEPWISE (options={"trajectory_kernel": False}): the user's f and g run as torch kernels
+    # between the per-step kernels -- the route of every SDE that is not a per-channel expression
     "c2_euler_diag_b65536_d64_s1000": dict(
         problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1, kernel_match=["StepDiagOp<float>"],
