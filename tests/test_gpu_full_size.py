@@ -119,12 +119,20 @@ def test_c4_midpoint_per_gpu_shard_b32768_d64():
     B, d, n, rank = 32768, 64, 1000, 3
     sde = problems.make("gbm_strat", d=d).to(DEV)
     y0 = torch.full((B, d), 0.1, device=DEV)
-    ys = _sdeint(sde, y0, n, "midpoint", _bm(B, d, n, row_offset=rank * B), {"hip_graph": True})
-    assert torch.isfinite(ys).all()
-    # rows of the shard are the rows a run over the global batch produces (sample 2048 global rows around the seam)
     lo = rank * B - 1024
-    seam = _sdeint(sde, torch.full((2048, d), 0.1, device=DEV), n, "midpoint", _bm(2048, d, n, row_offset=lo))
-    assert torch.equal(seam[-1, 1024:], ys[-1, :1024])
+    # on the stepwise route (graph replay / eager), then on the default route: the first default solve of the module also
+    # runs stepwise and compares (solvers._integrate_recognised), the later ones are one trajectory launch each
+    for route in ("stepwise", "default"):
+        stepwise = {"trajectory_kernel": False} if route == "stepwise" else {}
+        if route == "default":
+            _sdeint(sde, y0[:64], 8, "midpoint", _bm(64, d, 8))
+        ys = _sdeint(sde, y0, n, "midpoint", _bm(B, d, n, row_offset=rank * B),
+                     dict(stepwise, hip_graph=True) if stepwise else None)
+        assert torch.isfinite(ys).all()
+        # rows of the shard are the rows a run over the global batch produces (sample 2048 global rows around the seam)
+        seam = _sdeint(sde, torch.full((2048, d), 0.1, device=DEV), n, "midpoint", _bm(2048, d, n, row_offset=lo),
+                       stepwise or None)
+        assert torch.equal(seam[-1, 1024:], ys[-1, :1024]), route
     # Stratonovich GBM closed form (problems.GBMDiag subtracts the correction in f): order-1 strong error
     W_T = _bm(B, d, n, row_offset=rank * B)(0.0, n * DT)
     exact = sde.exact(y0, n * DT, W_T)

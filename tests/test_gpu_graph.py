@@ -6,6 +6,14 @@ import torch
 from workloads import problems
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _stepwise_route(monkeypatch):
+    """These tests are about the launch graph of a STEPWISE solve. Their little SDEs (mu * y, 0.2 * y) are per-channel
+    expressions, which the default route would run as one trajectory launch (tests/test_gpu_recognise.py): switched off."""
+    from torchsde_amd import recognise
+    monkeypatch.setattr(recognise, "ENABLED", False)
 DEV = "cuda"
 
 

@@ -282,7 +282,7 @@ class Recognised:
         """The part of the result that does not change when parameter VALUES change: key of the trust verdict."""
         def shape(form):
             return (form.phi, form.constant()) + tuple(
-                None if c is None else ("number", c) if isinstance(c, (int, float)) else "tensor"
+                None if c is None else "number" if isinstance(c, (int, float)) else "tensor"
                 for c in (form.scale, form.rate, form.shift, form.offset))
         return shape(self.f), shape(self.g)
 

@@ -455,6 +455,8 @@ class BaseSDESolver:
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
         both_nan = fast.isnan() & stepwise.isnan()
         close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
+        if len(book["trusted"]) >= 32:
+            book["trusted"].clear()
         book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
         return stepwise
 
