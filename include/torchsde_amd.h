@@ -13,6 +13,7 @@
  *   tsde_milstein_*      _core/methods/milstein.py:52-94 (+ base_sde.py:142-158)
  *   tsde_srk_diag_stage  _core/methods/srk.py:57-88 + tableaus/srid2.py
  *   tsde_step_general_w  _core/methods/srk.py:90-111 + tableaus/sra1.py (SRK for additive noise)
+ *   tsde_step_shared     both of the above when g is one matrix for the whole batch (misc.py:62-63 `bmm` -> one MFMA product)
  *   tsde_rheun_*         _core/methods/reversible_heun.py:48-144 (reversible Heun and its adjoint)
  *   tsde_aug_update      _core/adjoint.py:97-119 + adjoint_sde.py:111-128,218-230 (augmented state update)
  *   tsde_linear_interp   _core/interp.py:15-18
@@ -141,6 +142,16 @@ int tsde_step_general(void* y1, const void* y0, const void* f, const void* g, in
 int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, int64_t B, int64_t d, int64_t m,
                         double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
                         const tsde_noise_t* noise, int dtype, void* stream);
+
+/* The same two updates when the diffusion is ONE (d, m) matrix S for every batch row -- additive noise returned as
+ * `sigma.expand(B, d, m)` (base_sde.py:101-102 -> misc.py:62-63 runs `bmm` over B copies of it; SRA1's stages
+ * srk.py:96-109): y1 = (y0 + (ca*f)*cf) + cg*(S . w), i.e. out(B, d) = w(B, m) . S^T as ONE dense product on the matrix
+ * cores (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64), increments generated in registers as the B operand, S staged
+ * once per block in LDS, epilogue fused; 12*d bytes of HBM traffic per batch row. S: contiguous (d, m) row-major.
+ * Matrix cores for m % 4 == 0, m <= 64, d <= 128; other shapes run a per-output kernel (still no copies of S). */
+int tsde_step_shared(void* y1, const void* y0, const void* f, const void* S, int64_t B, int64_t d, int64_t m, double ca,
+                     double cf, double cg, int weight_mode, double cw, double cu, double rdt, const tsde_noise_t* noise,
+                     int dtype, void* stream);
 
 /* Milstein helper: v_out = scale * (W^2 - dt) (ito != 0) or scale * W^2; W_out optional. */
 int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale,
@@ -476,6 +487,7 @@ int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int
 #define TSDE_KID_MLP_BACKWARD 9
 #define TSDE_KID_MLP_ADJOINT 10
 #define TSDE_KID_MILSTEIN_GF_GENERAL 11
+#define TSDE_KID_STEP_SHARED 12
 /* Start timing every launch of kernel family `kid` (at most `capacity` launches). Families 1-6 and 11 are timed PER
  * DISPATCH: the launch is issued with hipExtLaunchKernel and the two events are bound to that dispatch, so their elapsed
  * time is the kernel's own start-to-end interval (what a rocprofv3 kernel trace reports) with no marker packets on the

@@ -83,6 +83,8 @@ SIGNATURES = {
                                    ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_step_general_w": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _c_dbl,
                                      _c_int, _c_dbl, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int, _c_ptr]),
+    "tsde_step_shared": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _c_dbl,
+                                  _c_int, _c_dbl, _c_dbl, _c_dbl, ctypes.POINTER(Noise), _c_int, _c_ptr]),
     "tsde_milstein_v": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_dbl, ctypes.POINTER(Noise), _c_int,
                                  _c_ptr]),
     "tsde_milstein_weight": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_dbl, _c_int, _c_dbl, ctypes.POINTER(Noise), _c_int,

@@ -204,6 +204,19 @@ int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, 
                                                   s));
 }
 
+int tsde_step_shared(void* y1, const void* y0, const void* f, const void* S, int64_t B, int64_t d, int64_t m, double ca,
+                     double cf, double cg, int weight_mode, double cw, double cu, double rdt, const tsde_noise_t* noise,
+                     int dtype, void* stream) {
+  if (!y1 || !y0 || !f || !S || !noise) return bad_arg("tsde_step_shared", "null argument");
+  if (weight_mode < 0 || weight_mode > 2) return bad_arg("tsde_step_shared", "weight_mode must be 0, 1 or 2");
+  if (weight_mode != 0 && noise->dW && !noise->dU) return bad_arg("tsde_step_shared", "weights need dU");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_STEP_SHARED, s, true);
+  TSDE_DISPATCH(dtype, "tsde_step_shared",
+                tsde::launch_step_shared<float>(y1, y0, f, S, B, d, m, ca, cf, cg, weight_mode, cw, cu, rdt, noise, s),
+                tsde::launch_step_shared<double>(y1, y0, f, S, B, d, m, ca, cf, cg, weight_mode, cw, cu, rdt, noise, s));
+}
+
 int tsde_milstein_v(void* v_out, void* W_out, int64_t n, double dt, int ito, double scale, const tsde_noise_t* noise,
                     int dtype, void* stream) {
   if (!v_out || !noise) return bad_arg("tsde_milstein_v", "null argument");

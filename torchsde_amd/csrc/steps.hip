@@ -339,6 +339,8 @@ struct GeneralArgs {
   T cw, cu;
   CellNoise<T> nz;
   int rows_per_tile;
+  int vec_io;          // MFMA kernel: y0, f, y1 are 16-B aligned and d % 4 == 0 (vector accesses)
+  int shared;          // g is ONE (d, m) matrix for every batch row (generic kernel; the MFMA kernel always reads it so)
 };
 
 template <typename T>
@@ -512,6 +514,119 @@ __global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<
   }
 }
 
+// ---- shared (batch-broadcast) diffusion on the matrix cores -----------------------------------------------------
+// Additive noise returned as `sigma.expand(B, d, m)`: every batch row is contracted with the SAME (d, m) matrix S, so
+// g . w is ONE dense product  out(B, d) = w(B, m) . S^T  -- the only matrix-core-shaped product on this path (the
+// reference: base_sde.py:101-102 -> misc.py:62-63 `bmm` over B copies of S; SRA1's stages srk.py:96-109). One launch:
+//   * S is staged once per block in LDS (rows padded to m16 + 4 so that the 16 lanes of a quarter-wave read distinct
+//     16-B slots), zero-padded to whole 16 x 16 tiles;
+//   * a wave owns 16 batch rows at a time. MFMA operands (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64):
+//       A (16 x 4)  = S[channel tile t][k]      lane L supplies S[16t + L%16][k(L/16)]     (ds_read_b128 per 4 steps)
+//       B (4 x 16)  = w[batch row][k]           lane L supplies w[row0 + L%16][k(L/16)]
+//     The sum over k does not care in which ORDER the k's are fed as long as A and B agree, so step (j, e) feeds
+//     k = 4*(L/16 + 4j) + e: lane (r, q) then needs exactly the four increments of Philox quad (row0 + r, q + 4j) --
+//     each quad of each row is generated ONCE, by one lane, in registers (`lane_weights`), never written anywhere;
+//   * f32 accumulator register v of lane L is out[row0 + L%16][16t + 4*(L/16) + v]: four CONSECUTIVE channels of one
+//     batch row, so y0, f and y1 move as 16-B vectors; (f64: register v is channel 16t + 4v + L/16, scalar accesses);
+//   * epilogue fused: y1 = (y0 + (ca*f)*cf) + cg*acc, the rounding order of the other step kernels.
+// HBM-bound (12*d bytes per row against 2*d*m flops): the matrix cores are there to keep the VALU free for the RNG.
+typedef float shared_f4 __attribute__((ext_vector_type(4)));
+typedef double shared_d4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct SharedMfma;
+template <>
+struct SharedMfma<float> {
+  using acc_t = shared_f4;
+  TSDE_D static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  TSDE_D static int channel(int part, int v) { return 4 * part + v; }     // of accumulator register v
+  static constexpr bool kVector = true;
+};
+template <>
+struct SharedMfma<double> {
+  using acc_t = shared_d4;
+  TSDE_D static acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  TSDE_D static int channel(int part, int v) { return 4 * v + part; }
+  static constexpr bool kVector = false;
+};
+
+template <typename T, int DT>      // DT = ceil(d / 16): channel tiles of a batch row, all held by one wave
+__global__ void __launch_bounds__(kBlock) shared_mfma_kernel(const GeneralArgs<T> a) {
+  using M = SharedMfma<T>;
+  extern __shared__ __align__(16) unsigned char shared_raw[];
+  T* S = reinterpret_cast<T*>(shared_raw);
+  const int d = (int)a.d, m = (int)a.m;
+  const int m16 = (m + 15) & ~15, ld = m16 + 4, MJ = m16 >> 4;
+  for (int idx = threadIdx.x; idx < DT * 16 * m16; idx += kBlock) {
+    const int i = idx / m16, k = idx - i * m16;
+    S[i * ld + k] = (i < d && k < m) ? a.g[(int64_t)i * m + k] : (T)0;
+  }
+  __syncthreads();
+  const T cf = a.cf_.get();
+  const int lane = threadIdx.x & 63, r = lane & 15, part = lane >> 4;
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  const int64_t n_tiles = (a.B + 15) >> 4;
+  const bool vec = M::kVector && a.vec_io != 0;
+  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const int64_t row = tile * 16 + r;
+    const bool live = row < a.B;
+    // all of this row's operands are requested before the RNG runs, so the Philox rounds hide the memory latency
+    Pack<T, 4> y0v[DT], fv[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int c0 = 16 * t + 4 * part;
+      if (vec) {
+        if (live && c0 < d) {
+          y0v[t] = load<T, 4>(a.y0, row * d + c0);
+          fv[t] = load<T, 4>(a.f, row * d + c0);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = 16 * t + M::channel(part, v);
+          const bool ok = live && c < d;
+          y0v[t].v[v] = ok ? a.y0[row * d + c] : (T)0;
+          fv[t].v[v] = ok ? a.f[row * d + c] : (T)0;
+        }
+      }
+    }
+    typename M::acc_t acc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc[t] = typename M::acc_t{(T)0, (T)0, (T)0, (T)0};
+    for (int j = 0; j < MJ; ++j) {
+      const int q = part + 4 * j;                 // Philox quad of this lane within its row
+      T wq[4] = {(T)0, (T)0, (T)0, (T)0};
+      if (live && 4 * q < m) lane_weights<T>(a, row, q, wq);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const T* srow = S + (16 * t + r) * ld + 4 * q;
+        const Pack<T, 4> sv = load<T, 4>(srow, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t] = M::mfma(sv.v[e], wq[e], acc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int c0 = 16 * t + 4 * part;
+      if (vec) {
+        if (live && c0 < d) {
+          Pack<T, 4> out;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) out.v[v] = (y0v[t].v[v] + (a.ca * fv[t].v[v]) * cf) + a.cg * acc[t][v];
+          store<T, 4>(a.y1, row * d + c0, out);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = 16 * t + M::channel(part, v);
+          if (live && c < d) a.y1[row * d + c] = (y0v[t].v[v] + (a.ca * fv[t].v[v]) * cf) + a.cg * acc[t][v];
+        }
+      }
+    }
+  }
+}
+
 // Generic path: any d, m (m*rows_per_tile <= kGenMaxNoise): one thread per output, scalar loads of g.
 template <typename T>
 __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralArgs<T> a) {
@@ -528,7 +643,7 @@ __global__ void __launch_bounds__(kBlock) general_generic_kernel(const GeneralAr
     for (int64_t o = threadIdx.x; o < nout; o += kBlock) {
       const int64_t r = o / a.d;
       const int64_t idx = row0 * a.d + o;
-      const T* grow = a.g + idx * a.m;
+      const T* grow = a.g + (a.shared ? (o - r * a.d) : idx) * a.m;
       const T* wrow = lds + r * a.m;
       T acc = (T)0;
       for (int64_t j = 0; j < a.m; ++j) acc += grow[j] * wrow[j];
@@ -713,6 +828,8 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   a.cu = (T)cu;
   a.rdt_ = coef<T>(rdt);
   a.nz = make_noise<T>(nz);
+  a.shared = 0;
+  a.vec_io = 0;
   const int64_t G = m / 4;
   const bool pow2 = (m % 4 == 0) && G >= 1 && G <= 64 && ((G & (G - 1)) == 0);
   // the fast path loads increments (external) or forms Philox quads at row*m + 4*lane: needs 16-B alignment there
@@ -749,6 +866,77 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   return hipGetLastError();
 }
 
+// S: (d, m) row-major, contiguous. Matrix cores for m % 4 == 0 (the counter RNG and external increments are addressed in
+// quads of one row), m <= 64, d <= 128; other shapes take the generic per-output kernel with S shared.
+template <typename T>
+hipError_t launch_step_shared(void* y1, const void* y0, const void* f, const void* S, int64_t B, int64_t d, int64_t m,
+                              double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
+                              const tsde_noise_t* nz, hipStream_t s) {
+  if (B <= 0 || d <= 0) return hipSuccess;
+  if (m <= 0 || m > kGenMaxNoise) return hipErrorInvalidValue;
+  const bool noise_ok = nz->dW ? (aligned16(nz->dW) && (!nz->dU || aligned16(nz->dU))) : (nz->elem0 % 4 == 0);
+  const bool mfma = m <= 64 && m % 4 == 0 && d <= 128 && noise_ok && aligned16(S);
+  GeneralArgs<T> a;
+  a.y1 = (T*)y1;
+  a.y0 = (const T*)y0;
+  a.f = (const T*)f;
+  a.g = (const T*)S;
+  a.B = B;
+  a.d = d;
+  a.m = m;
+  a.ca = (T)ca;
+  a.cf_ = coef<T>(cf);
+  a.cg = (T)cg;
+  a.weight_mode = weight_mode;
+  a.cw = (T)cw;
+  a.cu = (T)cu;
+  a.rdt_ = coef<T>(rdt);
+  a.nz = make_noise<T>(nz);
+  a.rows_per_tile = 0;
+  a.shared = 1;
+  a.vec_io = (d % 4 == 0) && aligned16(y0) && aligned16(f) && aligned16(y1);
+  if (!mfma) {
+    // shapes the tiles do not cover (m not a multiple of 4, m > 64, d > 128): one thread per output, the increments of
+    // a tile of rows staged in LDS, S read through the cache -- still without materialising B copies of it
+    int64_t rows = kGenMaxNoise / m;
+    const int64_t want = (2 * kBlock + d - 1) / d;
+    if (rows > want) rows = want;
+    if (rows < 1) rows = 1;
+    a.rows_per_tile = (int)rows;
+    const int64_t n_tiles = (B + rows - 1) / rows;
+    const int grid = (int)(n_tiles < kMaxGrid ? n_tiles : kMaxGrid);
+    TSDE_LAUNCH(general_generic_kernel<T>, dim3(grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+  }
+  const int dt = (int)((d + 15) / 16);
+  const int m16 = (int)((m + 15) & ~(int64_t)15);
+  const size_t lds = (size_t)dt * 16 * (m16 + 4) * sizeof(T);
+  const int64_t tiles = (B + 15) / 16;
+  int64_t blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);        // one 16-row tile per wave, then grid-stride
+  if (blocks > kMaxGrid) blocks = kMaxGrid;
+#define TSDE_SHARED_CASE(N)                                                                                          \
+  case N: {                                                                                                          \
+    if (lds > 64 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute((const void*)shared_mfma_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                                           \
+    TSDE_LAUNCH((shared_mfma_kernel<T, N>), dim3((int)blocks), dim3(kBlock), lds, s, a);                             \
+    break;                                                                                                           \
+  }
+  switch (dt) {
+    TSDE_SHARED_CASE(1)
+    TSDE_SHARED_CASE(2)
+    TSDE_SHARED_CASE(3)
+    TSDE_SHARED_CASE(4)
+    TSDE_SHARED_CASE(5)
+    TSDE_SHARED_CASE(6)
+    TSDE_SHARED_CASE(7)
+    TSDE_SHARED_CASE(8)
+    default: return hipErrorNotSupported;
+  }
+#undef TSDE_SHARED_CASE
+  return hipGetLastError();
+}
+
 #define TSDE_INSTANTIATE(T)                                                                                          \
   template hipError_t launch_cell_increment<T>(void*, void*, int64_t, const tsde_noise_t*, hipStream_t);             \
   template hipError_t launch_step_diag<T>(void*, const void*, const void*, const void*, int64_t, double, double,     \
@@ -758,6 +946,9 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   template hipError_t launch_step_general<T>(void*, const void*, const void*, const void*, int64_t, int64_t, int64_t, \
                                              double, double, double, int, double, double, double,                    \
                                              const tsde_noise_t*, hipStream_t);                                      \
+  template hipError_t launch_step_shared<T>(void*, const void*, const void*, const void*, int64_t, int64_t, int64_t, \
+                                            double, double, double, int, double, double, double,                     \
+                                            const tsde_noise_t*, hipStream_t);                                       \
   template hipError_t launch_milstein_v<T>(void*, void*, const void*, int64_t, double, int, double,                  \
                                            const tsde_noise_t*, hipStream_t);                                        \
   template hipError_t launch_milstein_diag<T>(void*, const void*, const void*, const void*, const void*, int64_t,    \

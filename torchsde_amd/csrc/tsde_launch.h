@@ -39,6 +39,10 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
                                double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
                                const tsde_noise_t* nz, hipStream_t s);
 template <typename T>
+hipError_t launch_step_shared(void* y1, const void* y0, const void* f, const void* S, int64_t B, int64_t d, int64_t m,
+                              double ca, double cf, double cg, int weight_mode, double cw, double cu, double rdt,
+                              const tsde_noise_t* nz, hipStream_t s);
+template <typename T>
 hipError_t launch_milstein_v(void* v_out, void* W_out, const void* g, int64_t n, double dt, int ito, double scale,
                              const tsde_noise_t* nz, hipStream_t s);
 template <typename T>

@@ -142,6 +142,20 @@ def _shared_diffusion(g, B):
     return None
 
 
+def _raw_step_shared(y0, f, S, ca, cf, cg, weight_mode, cw, cu, rdt, noise, out):
+    """y1 = (y0 + (ca*f)*cf) + cg*(S . w) for ONE (d, m) matrix S shared by the batch (``tsde_step_shared``)."""
+    S = _native.contiguous(S if S.dtype == y0.dtype else S.to(y0.dtype))
+    B, d = y0.shape
+    out = _new_like(y0, out)
+    lib, dt_code, stream = _launch_env(y0)
+    code = lib.tsde_step_shared(out.data_ptr(), y0.data_ptr(), f.data_ptr(), S.data_ptr(), B, d, S.shape[-1],
+                                float(ca), cf, cg, int(weight_mode), float(cw), float(cu), rdt, noise.struct(), dt_code,
+                                stream)
+    if code:
+        _native.check(code, "tsde_step_shared")
+    return out
+
+
 def _raw_step_general(y0, f, g, cf, cg, noise, out):
     if not y0.is_contiguous():
         y0 = y0.contiguous()
@@ -152,11 +166,10 @@ def _raw_step_general(y0, f, g, cf, cg, noise, out):
     m = g.shape[-1]
     shared = _shared_diffusion(g, B)
     if shared is not None:
-        # Batch-broadcast diffusion: g . dW is ONE dense (B, m) x (m, d) GEMM -- the only matrix-core-shaped
-        # product on this path -- instead of B copies of g streamed through the contraction
-        # kernel (B*d*m*4 bytes written by the expand and read back). Library GEMM + the fused update.
-        W, _ = noise.materialise()
-        return _raw_step_prod(y0, f, torch.matmul(W.to(y0.dtype), shared.t()), cf, cg, out)
+        # Batch-broadcast diffusion: g . dW is ONE dense (B, m) x (m, d) product -- the only matrix-core-shaped one on
+        # this path -- instead of B copies of g streamed through the contraction kernel. One
+        # launch: increments generated in registers as the MFMA B operand, the matrix staged in LDS, fused update.
+        return _raw_step_shared(y0, f, shared, 1.0, cf, cg, 0, 0.0, 0.0, 0.0, noise, out)
     if g.shape != (B, d, m):
         g = g.expand(B, d, m)
     if not g.is_contiguous():
@@ -242,6 +255,9 @@ def step_general_weighted(y0, f, g, ca, cf, cg, weight_mode, cw, cu, rdt, noise,
         g = g.to(y0.dtype)
     B, d = y0.shape
     m = g.shape[-1]
+    shared = _shared_diffusion(g, B)
+    if shared is not None:      # SRA1's stages on a batch-broadcast diffusion: the matrix-core kernel, weighted form
+        return _raw_step_shared(y0, f, shared, ca, float(cf), float(cg), weight_mode, cw, cu, float(rdt), noise, out)
     if g.shape != (B, d, m):
         g = g.expand(B, d, m)
     g = _native.contiguous(g)
