@@ -65,7 +65,8 @@ HEADLINE = "c2_euler_diag_default_route_b65536_d64_s1000"
 # the stepwise BASELINE configurations, then what the closed-form route makes of the same jobs
 ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c3_euler_general_b16384_d32_m16", "c3_milstein_general_b16384_d32_m16",
-        "c3_milstein_general_gradfree_b16384_d32_m16", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
+        "c3_milstein_general_gradfree_b16384_d32_m16", "c3_euler_additive_shared_b16384_d32_m16",
+        "c3_euler_additive_shared_b262144_d64_m32", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c2_milstein_diag_default_route", "c2_srk_diag_default_route", "c4_midpoint_diag_default_route_b32768_d64",
         "c2_euler_expdiff_default_route_b65536_d64_s1000",
@@ -274,7 +275,8 @@ class Job:
         t0 = self.ts[0]
         spec = [NoiseSpec((B, m), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(n)]
         with torch.no_grad():
-            f, g = (None, None) if kid == 5 else (sde.f(t0, y).contiguous(), sde.g(t0, y).contiguous())
+            f, g = (None, None) if kid == 5 else (sde.f(t0, y).contiguous(), sde.g(t0, y))
+            g = g if kid in (5, 12) else g.contiguous()
 
         def copies(*tensors):
             """Enough distinct copies of an operand set that the rotation's working set is >= 128 MiB (4x the L2s)."""
@@ -298,6 +300,14 @@ class Job:
                 (ya, fa, ga), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
                 K._raw_step_general(ya, fa, ga, dt, 1.0, spec[i], yb)
             return {"tsde_step_general": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+        if kid == 12:
+            S = g[0].contiguous()           # the one (d, m) matrix behind sigma.expand(B, d, m)
+            sets = copies(y, f)
+
+            def launch(i):
+                (ya, fa), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
+                K._raw_step_shared(ya, fa, S, 1.0, dt, 1.0, 0, 0.0, 0.0, 0.0, spec[i], yb)
+            return {"tsde_step_shared": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
         if kid == 3:
             sets = copies(y, f, g, (g * f * dt).contiguous())
 

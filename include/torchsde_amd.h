@@ -146,7 +146,7 @@ int tsde_step_general_w(void* y1, const void* y0, const void* f, const void* g, 
 /* The same two updates when the diffusion is ONE (d, m) matrix S for every batch row -- additive noise returned as
  * `sigma.expand(B, d, m)` (base_sde.py:101-102 -> misc.py:62-63 runs `bmm` over B copies of it; SRA1's stages
  * srk.py:96-109): y1 = (y0 + (ca*f)*cf) + cg*(S . w), i.e. out(B, d) = w(B, m) . S^T as ONE dense product on the matrix
- * cores (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64), increments generated in registers as the B operand, S staged
+ * cores (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64), increments generated in registers as the A operand, S staged
  * once per block in LDS, epilogue fused; 12*d bytes of HBM traffic per batch row. S: contiguous (d, m) row-major.
  * Matrix cores for m % 4 == 0, m <= 64, d <= 128; other shapes run a per-output kernel (still no copies of S). */
 int tsde_step_shared(void* y1, const void* y0, const void* f, const void* S, int64_t B, int64_t d, int64_t m, double ca,

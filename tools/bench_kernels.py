@@ -68,12 +68,23 @@ def main():
         gdg = torch.randn(B, d, device=dev)
         us = timeit(lambda i: K._raw_milstein_diag(y[i & 1], f, g, gdg, dt, specs[i], y[(i + 1) & 1]))
         rows.append((f"milstein_diag B={B} d={d}", us, 20 * B * d))
-    for (B, d, m) in [(16384, 32, 16), (16384, 64, 16), (65536, 16, 16), (16384, 32, 64)]:
+    for (B, d, m) in [(16384, 32, 16), (16384, 64, 16), (65536, 16, 16), (16384, 32, 64), (65536, 32, 16), (4096, 32, 16)]:
         y = [torch.rand(B, d, device=dev) for _ in range(2)]
         f, g = torch.randn(B, d, device=dev), torch.rand(B, d, m, device=dev)
         specs = [gen_noise((B, m), i, dt, dev) for i in range(200)]
         us = timeit(lambda i: K._raw_step_general(y[i & 1], f, g, dt, 1.0, specs[i], y[(i + 1) & 1]))
         rows.append((f"step_general B={B} d={d} m={m}", us, 4 * B * (d * m + 3 * d)))
+    # batch-broadcast diffusion on the matrix cores: reads y0, f, writes y1 (12*d bytes per row); operands rotate over
+    # enough copies that no launch finds its inputs in L2
+    for (B, d, m) in [(16384, 32, 16), (65536, 64, 16), (262144, 64, 32), (65536, 128, 64), (1048576, 32, 16)]:
+        k = max(2, min(16, (128 << 20) // (8 * B * d)))
+        ys = [torch.rand(B, d, device=dev) for _ in range(k + 1)]
+        fs = [torch.randn(B, d, device=dev) for _ in range(k)]
+        S = torch.randn(d, m, device=dev) / m ** 0.5
+        specs = [gen_noise((B, m), i, dt, dev) for i in range(200)]
+        us = timeit(lambda i: K._raw_step_shared(ys[i % k], fs[i % k], S, 1.0, dt, 1.0, 0, 0.0, 0.0, 0.0, specs[i],
+                                                 ys[i % k + 1]))
+        rows.append((f"step_shared (MFMA) B={B} d={d} m={m}", us, 12 * B * d))
     B, d = 32768, 128
     s = [torch.rand(B, d, device=dev) for _ in range(4)]
     F = [torch.randn(B, d, device=dev) for _ in range(4)]

@@ -339,7 +339,7 @@ struct GeneralArgs {
   T cw, cu;
   CellNoise<T> nz;
   int rows_per_tile;
-  int vec_io;          // MFMA kernel: y0, f, y1 are 16-B aligned and d % 4 == 0 (vector accesses)
+  int vec_io;          // (unused)
   int shared;          // g is ONE (d, m) matrix for every batch row (generic kernel; the MFMA kernel always reads it so)
 };
 
@@ -474,41 +474,73 @@ __global__ void __launch_bounds__(kBlock) general_fast_kernel(const GeneralArgs<
   }
 }
 
-// Row-per-wave variant for rows that are a whole number (NC = 1, 2 or 4) of 64-lane, 16-B vector loads
-// (C3: d*m/4 = 128 -> NC = 2): no index division, all of a row's loads (g, and y0/f for the output lanes) are
-// issued before the Philox call so that the RNG hides under the memory latency.
+// Rows that are a whole number (NC = 1, 2, 4 or 8) of 64-lane, 16-B vector loads (C3: d*m/4 = 128 -> NC = 2): no index
+// division, and ONE Philox call of the wave serves several rows. A row needs only G = m/4 quads of increments, so the 64
+// lanes of one call generate the quads of 64/G rows at once (lane L: quad L%G of row L/G); each row then picks its four
+// weights up from the lane that made them with a wave shuffle. Round 3's form made one call per row -- 64 lanes
+// computing G distinct quads -- and at the C3 shape that VALU work (~5 us per launch per SIMD) was as long as the HBM
+// time it was supposed to hide under (rocprofv3: 0.54 of the HBM peak with traffic = 1.00 x algorithmic). `rows_per_wave`
+// (1 .. 64/G, chosen by the launcher so that the launch still has a few waves per SIMD) rows share a call; their loads
+// go out in sub-batches of 8 vector loads per lane, the first one BEFORE the RNG. The weights, the order of the four
+// products and the xor-shuffle reduction are unchanged, hence the bits.
 template <typename T, int NC>
 __global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<T> a) {
+  constexpr int SB = NC >= 8 ? 1 : 8 / NC;      // rows per sub-batch: SB * NC = 8 loads of g in flight per lane
   const T cf = a.cf_.get();
   const int G = (int)(a.m >> 2);
   const int logG = __builtin_ctz(G);
   const int lane = threadIdx.x & 63;
   const int lp = lane & (G - 1);
+  const int RW = a.rows_per_tile;               // rows per wave iteration (a power of two, <= 64 / G)
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  const int64_t n_groups = (a.B + RW - 1) / RW;
   const int outs_per_chunk = 64 >> logG;        // outputs (b, i) finished by one 64-lane load
-  for (int64_t row = wave; row < a.B; row += n_waves) {
-    const T* grow = a.g + row * (int64_t)(NC * 64 * 4);
-    Pack<T, 4> gq[NC];
-    T y0v[NC], fv[NC];
+  for (int64_t group = wave; group < n_groups; group += n_waves) {
+    const int64_t row0 = group * RW;
+    const int rows_here = (int)((a.B - row0 < RW) ? (a.B - row0) : RW);
+    Pack<T, 4> gq[SB][NC];
+    T y0v[SB][NC], fv[SB][NC];
+    T wq[4] = {(T)0, (T)0, (T)0, (T)0};
+    for (int sb0 = 0; sb0 < rows_here; sb0 += SB) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      gq[c] = load<T, 4>(grow, (int64_t)(c * 64 + lane) * 4);
-      const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
-      if (lp == 0) {
-        y0v[c] = a.y0[o];
-        fv[c] = a.f[o];
+      for (int s = 0; s < SB; ++s) {
+        if (sb0 + s < rows_here) {
+          const int64_t row = row0 + sb0 + s;
+          const T* grow = a.g + row * (int64_t)(NC * 64 * 4);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            gq[s][c] = load<T, 4>(grow, (int64_t)(c * 64 + lane) * 4);
+            if (lp == 0) {
+              const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
+              y0v[s][c] = a.y0[o];
+              fv[s][c] = a.f[o];
+            }
+          }
+        }
       }
-    }
-    T wq[4];
-    lane_weights<T>(a, row, lp, wq);
+      if (sb0 == 0) {      // the increments of all rows of this group, after the first loads have been requested
+        const int mine = lane >> logG;
+        if (mine < rows_here) lane_weights<T>(a, row0 + mine, lp, wq);
+      }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      T part = ((gq[c].v[0] * wq[0] + gq[c].v[1] * wq[1]) + gq[c].v[2] * wq[2]) + gq[c].v[3] * wq[3];
-      for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
-      if (lp == 0) {
-        const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
-        a.y1[o] = (y0v[c] + (a.ca * fv[c]) * cf) + a.cg * part;
+      for (int s = 0; s < SB; ++s) {
+        if (sb0 + s < rows_here) {
+          const int64_t row = row0 + sb0 + s;
+          const int src = ((sb0 + s) << logG) + lp;
+          T w[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = __shfl(wq[j], src, 64);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            T part = ((gq[s][c].v[0] * w[0] + gq[s][c].v[1] * w[1]) + gq[s][c].v[2] * w[2]) + gq[s][c].v[3] * w[3];
+            for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
+            if (lp == 0) {
+              const int64_t o = row * a.d + c * outs_per_chunk + (lane >> logG);
+              a.y1[o] = (y0v[s][c] + (a.ca * fv[s][c]) * cf) + a.cg * part;
+            }
+          }
+        }
       }
     }
   }
@@ -521,13 +553,18 @@ __global__ void __launch_bounds__(kBlock) general_rows_kernel(const GeneralArgs<
 //   * S is staged once per block in LDS (rows padded to m16 + 4 so that the 16 lanes of a quarter-wave read distinct
 //     16-B slots), zero-padded to whole 16 x 16 tiles;
 //   * a wave owns 16 batch rows at a time. MFMA operands (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64):
-//       A (16 x 4)  = S[channel tile t][k]      lane L supplies S[16t + L%16][k(L/16)]     (ds_read_b128 per 4 steps)
-//       B (4 x 16)  = w[batch row][k]           lane L supplies w[row0 + L%16][k(L/16)]
+//       A (16 x 4)  = w[batch row][k]           lane L supplies w[row0 + L%16][k(L/16)]
+//       B (4 x 16)  = S^T[k][channel]           lane L supplies S[16t + L%16][k(L/16)]     (one ds_read_b128 per 4 steps)
 //     The sum over k does not care in which ORDER the k's are fed as long as A and B agree, so step (j, e) feeds
 //     k = 4*(L/16 + 4j) + e: lane (r, q) then needs exactly the four increments of Philox quad (row0 + r, q + 4j) --
 //     each quad of each row is generated ONCE, by one lane, in registers (`lane_weights`), never written anywhere;
-//   * f32 accumulator register v of lane L is out[row0 + L%16][16t + 4*(L/16) + v]: four CONSECUTIVE channels of one
-//     batch row, so y0, f and y1 move as 16-B vectors; (f64: register v is channel 16t + 4v + L/16, scalar accesses);
+//   * accumulator register v of lane L is out[row0 + rowof(L/16, v)][16t + L%16]: the 16 lanes of a quarter-wave sit on
+//     16 CONSECUTIVE channels of one batch row, so every y0 / f / y1 access of a quarter-wave is one contiguous 64-B
+//     (f64: 128-B) segment -- no layout change, no LDS round trip, three VALU operations per output;
+//     (two earlier forms, timed in profiles/r4_shared_mfma_forms.txt: channels on the M side -- a lane owns 4 channels of
+//     one row, 16-B accesses -- makes every load instruction touch 16 cache lines for 16 B each (0.50 of the HBM peak
+//     at d = 32..64, 0.28 at d = 128); the same with a coalesced fetch and an LDS patch to change layout costs ~300
+//     VALU operations and 8*DT registers per tile (0.65 at d = 32, 0.18 at d = 128));
 //   * epilogue fused: y1 = (y0 + (ca*f)*cf) + cg*acc, the rounding order of the other step kernels.
 // HBM-bound (12*d bytes per row against 2*d*m flops): the matrix cores are there to keep the VALU free for the RNG.
 typedef float shared_f4 __attribute__((ext_vector_type(4)));
@@ -539,15 +576,13 @@ template <>
 struct SharedMfma<float> {
   using acc_t = shared_f4;
   TSDE_D static acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  TSDE_D static int channel(int part, int v) { return 4 * part + v; }     // of accumulator register v
-  static constexpr bool kVector = true;
+  TSDE_D static int rowof(int part, int v) { return 4 * part + v; }     // M index of accumulator register v
 };
 template <>
 struct SharedMfma<double> {
   using acc_t = shared_d4;
   TSDE_D static acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  TSDE_D static int channel(int part, int v) { return 4 * v + part; }
-  static constexpr bool kVector = false;
+  TSDE_D static int rowof(int part, int v) { return 4 * v + part; }
 };
 
 template <typename T, int DT>      // DT = ceil(d / 16): channel tiles of a batch row, all held by one wave
@@ -557,9 +592,13 @@ __global__ void __launch_bounds__(kBlock) shared_mfma_kernel(const GeneralArgs<T
   T* S = reinterpret_cast<T*>(shared_raw);
   const int d = (int)a.d, m = (int)a.m;
   const int m16 = (m + 15) & ~15, ld = m16 + 4, MJ = m16 >> 4;
-  for (int idx = threadIdx.x; idx < DT * 16 * m16; idx += kBlock) {
-    const int i = idx / m16, k = idx - i * m16;
-    S[i * ld + k] = (i < d && k < m) ? a.g[(int64_t)i * m + k] : (T)0;
+  // 16 threads per row of S, 16 rows per pass, 16-B groups (m % 4 == 0 and S is 16-B aligned: the launcher checked)
+  for (int i = threadIdx.x >> 4; i < DT * 16; i += kBlock / 16) {
+    for (int k = (threadIdx.x & 15) * 4; k < m16; k += 64) {
+      Pack<T, 4> z = {{(T)0, (T)0, (T)0, (T)0}};
+      if (i < d && k < m) z = load<T, 4>(a.g, (int64_t)i * m + k);
+      store<T, 4>(S, i * ld + k, z);
+    }
   }
   __syncthreads();
   const T cf = a.cf_.get();
@@ -567,60 +606,62 @@ __global__ void __launch_bounds__(kBlock) shared_mfma_kernel(const GeneralArgs<T
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
   const int64_t n_tiles = (a.B + 15) >> 4;
-  const bool vec = M::kVector && a.vec_io != 0;
   for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
-    const int64_t row = tile * 16 + r;
-    const bool live = row < a.B;
-    // all of this row's operands are requested before the RNG runs, so the Philox rounds hide the memory latency
-    Pack<T, 4> y0v[DT], fv[DT];
+    const int64_t row0 = tile * 16;
+    const bool full = row0 + 16 <= a.B && d == 16 * DT;      // (wave-uniform) no guards, pointer arithmetic only
+    // all of this tile's operands are requested before the RNG runs, so the Philox rounds hide the memory latency
+    T y0v[DT][4], fv[DT][4];
+    int64_t at[4];                                            // element offset of (row of register v, channel r)
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-      const int c0 = 16 * t + 4 * part;
-      if (vec) {
-        if (live && c0 < d) {
-          y0v[t] = load<T, 4>(a.y0, row * d + c0);
-          fv[t] = load<T, 4>(a.f, row * d + c0);
-        }
-      } else {
+    for (int v = 0; v < 4; ++v) at[v] = (row0 + M::rowof(part, v)) * d + r;
+    if (full) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int c = 16 * t + M::channel(part, v);
-          const bool ok = live && c < d;
-          y0v[t].v[v] = ok ? a.y0[row * d + c] : (T)0;
-          fv[t].v[v] = ok ? a.f[row * d + c] : (T)0;
+          y0v[t][v] = a.y0[at[v] + 16 * t];
+          fv[t][v] = a.f[at[v] + 16 * t];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const bool ok = row0 + M::rowof(part, v) < a.B && 16 * t + r < d;
+          y0v[t][v] = ok ? a.y0[at[v] + 16 * t] : (T)0;
+          fv[t][v] = ok ? a.f[at[v] + 16 * t] : (T)0;
         }
       }
     }
     typename M::acc_t acc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) acc[t] = typename M::acc_t{(T)0, (T)0, (T)0, (T)0};
+    const int64_t wrow = row0 + r;                // the row whose increments this lane supplies (A operand)
     for (int j = 0; j < MJ; ++j) {
-      const int q = part + 4 * j;                 // Philox quad of this lane within its row
+      const int q = part + 4 * j;                 // Philox quad of this lane within that row
       T wq[4] = {(T)0, (T)0, (T)0, (T)0};
-      if (live && 4 * q < m) lane_weights<T>(a, row, q, wq);
+      if (wrow < a.B && 4 * q < m) lane_weights<T>(a, wrow, q, wq);
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        const T* srow = S + (16 * t + r) * ld + 4 * q;
-        const Pack<T, 4> sv = load<T, 4>(srow, 0);
+        const Pack<T, 4> sv = load<T, 4>(S + (16 * t + r) * ld + 4 * q, 0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t] = M::mfma(sv.v[e], wq[e], acc[t]);
+        for (int e = 0; e < 4; ++e) acc[t] = M::mfma(wq[e], sv.v[e], acc[t]);
       }
     }
+    if (full) {
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-      const int c0 = 16 * t + 4 * part;
-      if (vec) {
-        if (live && c0 < d) {
-          Pack<T, 4> out;
+      for (int t = 0; t < DT; ++t) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) out.v[v] = (y0v[t].v[v] + (a.ca * fv[t].v[v]) * cf) + a.cg * acc[t][v];
-          store<T, 4>(a.y1, row * d + c0, out);
-        }
-      } else {
+        for (int v = 0; v < 4; ++v) a.y1[at[v] + 16 * t] = (y0v[t][v] + (a.ca * fv[t][v]) * cf) + a.cg * acc[t][v];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int c = 16 * t + M::channel(part, v);
-          if (live && c < d) a.y1[row * d + c] = (y0v[t].v[v] + (a.ca * fv[t].v[v]) * cf) + a.cg * acc[t][v];
+          if (row0 + M::rowof(part, v) < a.B && 16 * t + r < d)
+            a.y1[at[v] + 16 * t] = (y0v[t][v] + (a.ca * fv[t][v]) * cf) + a.cg * acc[t][v];
         }
       }
     }
@@ -835,14 +876,24 @@ hipError_t launch_step_general(void* y1, const void* y0, const void* f, const vo
   // the fast path loads increments (external) or forms Philox quads at row*m + 4*lane: needs 16-B alignment there
   const bool noise_ok = nz->dW ? (aligned16(nz->dW) && (!nz->dU || aligned16(nz->dU))) : (nz->elem0 % 4 == 0);
   const bool fast = pow2 && aligned16(g) && noise_ok;
-  if (fast && (d * G) % 64 == 0 && ((d * G) / 64 == 1 || (d * G) / 64 == 2 || (d * G) / 64 == 4)) {
+  if (fast && (d * G) % 64 == 0 && ((d * G) / 64 == 1 || (d * G) / 64 == 2 || (d * G) / 64 == 4 || (d * G) / 64 == 8)) {
     const int nc = (int)((d * G) / 64);
-    int64_t blocks = (B + (kBlock / 64) - 1) / (kBlock / 64);   // one wave per row
+    // rows sharing one Philox call of their wave: as many as the call covers (64 / G), less while the launch would
+    // otherwise have fewer than ~4 waves per SIMD (1024 SIMDs) to overlap their loads with
+    static const int64_t min_waves = [] {
+      const char* e = getenv("TSDE_GENERAL_MIN_WAVES");      // (tuning knob of tools/bench_kernels.py; default below)
+      return e ? (int64_t)atoll(e) : (int64_t)4096;
+    }();
+    int64_t rw = 64 / G;
+    while (rw > 1 && (B + rw - 1) / rw < min_waves) rw >>= 1;
+    a.rows_per_tile = (int)rw;
+    const int64_t groups = (B + rw - 1) / rw;
+    int64_t blocks = (groups + (kBlock / 64) - 1) / (kBlock / 64);   // one wave per group of rows
     if (blocks > kMaxGrid) blocks = kMaxGrid;
-    a.rows_per_tile = 0;
     if (nc == 1) TSDE_LAUNCH((general_rows_kernel<T, 1>), dim3((int)blocks), dim3(kBlock), 0, s, a);
     else if (nc == 2) TSDE_LAUNCH((general_rows_kernel<T, 2>), dim3((int)blocks), dim3(kBlock), 0, s, a);
-    else TSDE_LAUNCH((general_rows_kernel<T, 4>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    else if (nc == 4) TSDE_LAUNCH((general_rows_kernel<T, 4>), dim3((int)blocks), dim3(kBlock), 0, s, a);
+    else TSDE_LAUNCH((general_rows_kernel<T, 8>), dim3((int)blocks), dim3(kBlock), 0, s, a);
     return hipGetLastError();
   }
   if (fast) {
@@ -894,7 +945,7 @@ hipError_t launch_step_shared(void* y1, const void* y0, const void* f, const voi
   a.nz = make_noise<T>(nz);
   a.rows_per_tile = 0;
   a.shared = 1;
-  a.vec_io = (d % 4 == 0) && aligned16(y0) && aligned16(f) && aligned16(y1);
+  a.vec_io = 0;
   if (!mfma) {
     // shapes the tiles do not cover (m not a multiple of 4, m > 64, d > 128): one thread per output, the increments of
     // a tile of rows staged in LDS, S read through the cache -- still without materialising B copies of it
@@ -912,8 +963,10 @@ hipError_t launch_step_shared(void* y1, const void* y0, const void* f, const voi
   const int m16 = (int)((m + 15) & ~(int64_t)15);
   const size_t lds = (size_t)dt * 16 * (m16 + 4) * sizeof(T);
   const int64_t tiles = (B + 15) / 16;
-  int64_t blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);        // one 16-row tile per wave, then grid-stride
-  if (blocks > kMaxGrid) blocks = kMaxGrid;
+  // one 16-row tile per wave, then grid-stride over at most as many blocks as are resident at once (4 per CU at the
+  // register count of the wider tiles): a block stages S once, however many tiles its waves go on to process
+  int64_t blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
+  if (blocks > 256 * 4) blocks = 256 * 4;
 #define TSDE_SHARED_CASE(N)                                                                                          \
   case N: {                                                                                                          \
     if (lds > 64 * 1024)                                                                                             \

@@ -51,6 +51,17 @@ WORKLOADS = {
         problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1, kernel_match=["general_rows_kernel<float"],
         kernel="tsde_step_general<float> (general_rows_kernel)"),
+    # The batch-broadcast diffusion of north_star's "MFMA ... for the dense g.dW batched matmul": additive noise returned
+    # as sigma.expand(B, d, m) at the configs[2] shape and at a larger one. One launch of the matrix-core kernel per
+    # step: reads y0, f, writes y1 (12*d bytes per trajectory-step), increments generated in registers, S in LDS.
+    "c3_euler_additive_shared_b16384_d32_m16": dict(
+        problem="additive_shared_ito", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=12 * 32, kid=12, launches_per_step=1, kernel_match=["shared_mfma_kernel<float"],
+        kernel="tsde_step_shared<float> (shared_mfma_kernel, v_mfma_f32_16x16x4_f32)"),
+    "c3_euler_additive_shared_b262144_d64_m32": dict(
+        problem="additive_shared_ito", method="euler", levy="none", B=262144, d=64, m=32, nsteps=200, dt=2.0 ** -10,
+        bytes_per_traj_step=12 * 64, kid=12, launches_per_step=1, kernel_match=["shared_mfma_kernel<float"],
+        kernel="tsde_step_shared<float> (shared_mfma_kernel, v_mfma_f32_16x16x4_f32)"),
     # BASELINE configs[2] as literally worded: Milstein for GENERAL noise does not exist in the reference (it raises
     # ValueError, milstein.py:25); this is the opt-in extension pinned by reduction tests (tests/test_gpu_milstein_general.py)
     "c3_milstein_general_b16384_d32_m16": dict(

@@ -84,6 +84,26 @@ class AdditiveDecay(nn.Module):
         return fill.unsqueeze(0).unsqueeze(-1).repeat(y.size(0), 1, self.m)
 
 
+class AdditiveShared(nn.Module):
+    """Additive noise the way the reference's examples return it (examples/cont_ddpm.py-style constant diffusion): ONE
+    (d, m) matrix for every batch row, handed back as `sigma.expand(B, d, m)` -- no per-row copies. Linear mean-reverting
+    drift."""
+    noise_type = "additive"
+
+    def __init__(self, d, m, sde_type="ito", seed=4, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.rate = nn.Parameter(_sigmoid_randn(gen, d).to(dtype))
+        self.sigma = nn.Parameter((0.5 * torch.randn(d, m, generator=gen) / m ** 0.5).to(dtype))
+        self.sde_type = sde_type
+
+    def f(self, t, y):
+        return -self.rate * y
+
+    def g(self, t, y):
+        return self.sigma.expand(y.size(0), -1, -1)
+
+
 def _mlp(gen, sizes, dtype, final=None):
     layers = []
     for i, (a, b) in enumerate(zip(sizes[:-1], sizes[1:])):
@@ -228,6 +248,7 @@ def make(name, dtype=torch.float32, **kw):
         "scalar_strat": lambda: ScalarTrig(kw.get("d", 4), "stratonovich", dtype=dtype),
         "additive_ito": lambda: AdditiveDecay(kw.get("d", 4), kw.get("m", 3), "ito", dtype=dtype),
         "additive_strat": lambda: AdditiveDecay(kw.get("d", 4), kw.get("m", 3), "stratonovich", dtype=dtype),
+        "additive_shared_ito": lambda: AdditiveShared(kw.get("d", 4), kw.get("m", 4), "ito", dtype=dtype),
         "general_ito": lambda: MLPGeneral(kw.get("d", 4), kw.get("m", 4), "ito", dtype=dtype),
         "general_strat": lambda: MLPGeneral(kw.get("d", 4), kw.get("m", 4), "stratonovich", dtype=dtype),
         "general_odd_ito": lambda: MLPGeneral(kw.get("d", 3), kw.get("m", 5), "ito", dtype=dtype),
