@@ -71,7 +71,8 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_milstein_diag_default_route", "c2_srk_diag_default_route", "c4_midpoint_diag_default_route_b32768_d64",
         "c2_euler_expdiff_default_route_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
-        "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500")
+        "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500",
+        "c5_adjoint_latent_default_route_b32768_d128_s500", "c5_adjoint_latent_defaults_default_route_b32768_d128_s500")
 
 
 def csrc_digest():
@@ -199,9 +200,13 @@ class Job:
             with torch.enable_grad():
                 if self.adjoint:
                     gopt = dict(extra_options, hip_graph=bool(graph))      # (False, not absent: the default is "auto")
+                    plain = bool(c.get("recognised"))                      # the drop-in call: no options at all
                     ys = self._sdeint_adjoint(self.sde, self.y0, self.ts, bm=bm, method=c["method"],
-                                              adjoint_method=c["adjoint_method"], dt=c["dt"], options=dict(gopt),
-                                              adjoint_options=dict(gopt))
+                                              adjoint_method=c["adjoint_method"], dt=c["dt"],
+                                              options=None if plain else dict(gopt),
+                                              adjoint_options=None if plain else dict(gopt))
+                    if plain and not type(ys.grad_fn).__name__.startswith("_MlpAdjointFn"):
+                        raise RuntimeError(f"{self.name}: sdeint_adjoint did not take the matrix-core route")
                 else:
                     ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
                                       options=dict(extra_options) or None)

@@ -214,3 +214,105 @@ def test_full_size_headline_on_the_recognised_route_rows_vs_oracle():
         assert (new.cpu() - ref32[-1]).abs().max().item() < 2e-6
     finally:
         torch.set_num_threads(before)
+
+
+class _Latent(nn.Module):
+    """A latent-SDE-style module as users write it (cf. the reference's examples/latent_sde_lorenz.py:122-148): a
+    two-layer perceptron drift in an nn.Sequential, an elementwise bounded diffusion. Nothing of this package in it."""
+    noise_type = "diagonal"
+
+    def __init__(self, d, hidden, sde_type="ito", activation=nn.Softplus, sigmoid=True):
+        super().__init__()
+        self.sde_type = sde_type
+        self.net = nn.Sequential(nn.Linear(d, hidden), activation(), nn.Linear(hidden, d))
+        gen = torch.Generator().manual_seed(d + hidden)
+        with torch.no_grad():
+            for p in self.net.parameters():
+                p.copy_(torch.randn(p.shape, generator=gen) / d ** 0.5)
+        self.w = nn.Parameter(torch.randn(d, generator=gen))
+        self.b = nn.Parameter(0.1 * torch.randn(d, generator=gen))
+        self.sigmoid = sigmoid
+
+    def f(self, t, y):
+        return self.net(y)
+
+    def g(self, t, y):
+        return 0.3 * torch.sigmoid(self.w * y + self.b) if self.sigmoid else self.w * y + self.b
+
+
+def _close(got, want, what, tol=2e-3):
+    err = (got.double() - want.double()).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= tol * scale + 1e-7, f"{what}: max error {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("d,hidden,activation,sigmoid,method,levy,sde_type", [
+    (16, 16, nn.Softplus, True, "euler", "none", "ito"), (32, 64, nn.Tanh, False, "milstein", "none", "ito"),
+    (128, 128, nn.Softplus, True, "srk", "space-time", "ito"), (64, 256, nn.Tanh, True, "midpoint", "none", "stratonovich")])
+def test_unchanged_latent_sde_module_samples_through_the_perceptron_kernel(d, hidden, activation, sigmoid, method, levy,
+                                                                          sde_type):
+    sde = _Latent(d, hidden, sde_type, activation, sigmoid).to(DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    first = _solve(sde, 1, y0=y0, method=method, levy=levy)
+    assert torch.equal(first, _solve(sde, 1, y0=y0, stepwise=True, method=method, levy=levy))
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast, n = _launches(lambda: _solve(sde, 2, y0=y0, method=method, levy=levy))
+    assert n == 1
+    _close(fast, _solve(sde, 2, y0=y0, stepwise=True, method=method, levy=levy), "ys", tol=1e-3)
+    with torch.no_grad():                       # an optimiser step: the next launch reads the new weights
+        for p in sde.parameters():
+            p.mul_(0.9)
+    _close(_solve(sde, 3, y0=y0, method=method, levy=levy), _solve(sde, 3, y0=y0, stepwise=True, method=method, levy=levy),
+           "ys after a parameter update", tol=1e-3)
+
+
+@pytest.mark.parametrize("d,hidden,method,adjoint_method,sde_type,sigmoid", [
+    (32, 32, "euler", "euler", "ito", True), (64, 64, None, None, "ito", True), (128, 128, "milstein", "milstein", "ito", False),
+    (32, 64, "midpoint", "milstein", "stratonovich", True)])
+def test_sdeint_adjoint_on_an_unchanged_latent_sde_module_takes_the_matrix_core_adjoint(d, hidden, method, adjoint_method,
+                                                                                        sde_type, sigmoid):
+    """Forward: tsde_trajectory_mlp_diag; backward: tsde_adjoint_mlp_diag + tsde_gram_partials -- gradients land on the
+    user's own nn.Linear weights and diffusion parameters, and agree with the stepwise stochastic adjoint of the same
+    module on the same path (`options={"trajectory_kernel": False}`) up to the summation order of the products."""
+    import torchsde_amd
+    Bn, steps, dt = 96, 24, 2.0 ** -6
+    sde = _Latent(d, hidden, sde_type, nn.Softplus, sigmoid).to(DEV)
+    ts = torch.tensor([0.0, 7 * dt, steps * dt], device=DEV)
+    weights = torch.randn(3, Bn, d, device=DEV)
+    levy = "space-time" if method is None and sde_type == "ito" else "none"
+    results = []
+    for stepwise in (False, True):
+        y0 = torch.full((Bn, d), 0.1, device=DEV, requires_grad=True)
+        sde.zero_grad()
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(Bn, d), device=DEV, entropy=9,
+                                           levy_area_approximation=levy)
+        opts = {"trajectory_kernel": False} if stepwise else None
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt,
+                                         options=opts, adjoint_options=opts)
+        assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn") != stepwise, type(ys.grad_fn).__name__
+        (ys * weights).sum().backward()
+        results.append((ys.detach(), y0.grad.clone(), {n: p.grad.clone() for n, p in sde.named_parameters()}))
+    (ys_a, gy_a, gp_a), (ys_b, gy_b, gp_b) = results
+    _close(ys_a, ys_b, "ys", tol=1e-3)
+    _close(gy_a, gy_b, "dL/dy0")
+    assert set(gp_a) == {"net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "w", "b"}
+    for name in gp_a:
+        _close(gp_a[name], gp_b[name], f"dL/d{name}")
+
+
+def test_perceptron_drifts_that_do_not_fit_stay_stepwise():
+    class Residual(_Latent):
+        def f(self, t, y):
+            return self.net(y) - y                          # not the kernel's form
+
+    class Deep(_Latent):
+        def __init__(self, d, hidden):
+            super().__init__(d, hidden)
+            self.net = nn.Sequential(nn.Linear(d, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                     nn.Linear(hidden, d))
+
+    for sde in (Residual(16, 16).to(DEV), Deep(16, 16).to(DEV), _Latent(12, 300).to(DEV)):
+        y0 = torch.full((B, sde.net[0].in_features), 0.1, device=DEV)
+        for entropy in (1, 2):
+            got, n = _launches(lambda: _solve(sde, entropy, y0=y0))
+            assert n == 0 and torch.equal(got, _solve(sde, entropy, y0=y0, stepwise=True))

@@ -822,7 +822,7 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
     if torch.is_grad_enabled() and (y0.requires_grad or adjoint_params):
         from . import mlp_adjoint
         ys = mlp_adjoint.route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, options,
-                               adjoint_options, adjoint_params, extra_solver_state)
+                               adjoint_options, adjoint_params, extra_solver_state, solver=solver)
         if ys is not None:
             return contract.parse_return(y0, ys, (), extra, logqp)
     if extra_solver_state is None:

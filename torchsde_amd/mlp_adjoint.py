@@ -145,7 +145,7 @@ class _MlpAdjointFn(torch.autograd.Function):
 
 
 def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptive, options, adjoint_options,
-          adjoint_params, extra_solver_state):
+          adjoint_params, extra_solver_state, solver=None):
     """`ys` with a grad_fn towards y0 and the module's six parameters if this call can take the kernels above, else
     None (the caller then runs the stepwise stochastic adjoint)."""
     from .sde import ForwardSDE
@@ -154,24 +154,38 @@ def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptiv
             or not options.get("trajectory_kernel", True) or not adjoint_options.get("trajectory_kernel", True)):
         return None
     base = getattr(sde, "_base_sde", None)
-    if (type(sde) is not ForwardSDE or not hasattr(base, "closed_form")
-            or not closed_form.publishes_its_own_dynamics(base)):
+    if type(sde) is not ForwardSDE:
         return None
+    published = hasattr(base, "closed_form") and closed_form.publishes_its_own_dynamics(base)
     code = _FORWARD_CODES.get((method, sde.sde_type))
     if (code is None or not isinstance(bm, BrownianInterval) or bm._rootW is not None or bm._rootH is not None
             or bm._snap or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or y0.dtype != torch.float32
             or bm.dtype != torch.float32 or bm._elem0 % 4 != 0 or y0.numel() == 0
             or (code == _native.TRAJ_SRK and not bm._have_H)):
         return None
-    spec = base.closed_form(y0.shape[1], y0.dtype, y0.device)
-    if spec is None or spec[0] != "mlp_diagonal":
-        return None
-    own = list(base.closed_form_parameters())
+    if published:
+        spec = base.closed_form(y0.shape[1], y0.dtype, y0.device)
+        if spec is None or spec[0] != "mlp_diagonal":
+            return None
+        own = list(base.closed_form_parameters())
+    else:
+        # an UNCHANGED user module whose drift turns out to be lin2(act(lin1(y))) with an affine / sigmoid diagonal
+        # diffusion (recognise.py), its forward solve through the sampling kernel verified against the stepwise one
+        if solver is None or not isinstance(base, torch.nn.Module) or options.get("hip_graph") is True:
+            return None
+        found = solver.recognised_perceptron(y0, ts)
+        if found is None:
+            return None
+        own = found.perceptron_parameters()
+        if own is None:
+            return None
+        spec = found.perceptron_spec()
     hidden = own[1].numel()
     # gradients go to exactly the module's own trainable parameters: a narrower or wider `adjoint_params` is the
     # stepwise adjoint's business
+    module_params = {id(p) for p in base.parameters()}
     if ({id(p) for p in adjoint_params} != {id(p) for p in own if p.requires_grad}
-            or {id(p) for p in base.parameters()} != {id(p) for p in own}
+            or module_params != {id(p) for p in own if id(p) in module_params or published}
             or hidden % 4 != 0 or y0.shape[0] * max(y0.shape[1], hidden) >= 2 ** 30):
         return None
 

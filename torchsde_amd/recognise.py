@@ -18,6 +18,12 @@ are computed from the LIVE parameter values of this very solve: an optimiser ste
 are seen because the user's code has just run. Anything else -- a value derived from ``t``, an operator outside the
 small elementwise table, a reshape of the state, an in-place update of it, a per-row constant, `float(t)` -- ends the interpretation and the solve takes the stepwise path, as before.
 
+A second form is followed the same way: a drift that is a two-layer perceptron of the state shared by the batch,
+``lin2(act(lin1(y)))`` with ``act`` tanh or softplus -- ``nn.Sequential(nn.Linear, nn.Softplus, nn.Linear)`` as in the
+reference's latent-SDE examples (examples/latent_sde_lorenz.py:122-128) -- with an affine or ``scale * sigmoid`` diagonal
+diffusion: the forms ``tsde_trajectory_mlp_diag`` (sampling) and ``tsde_adjoint_mlp_diag`` (``sdeint_adjoint``) integrate
+on the matrix cores. There the interpretation hands back the user's own parameter tensors, so that gradients reach them.
+
 Nothing here synchronises with the host (unless the user's code does, on its own constants). Whether a recognised form may be trusted is decided once per (Python-side state
 of the SDE object, form, scheme, shapes) by solving both ways and comparing (`solvers.BaseSDESolver._recognised`).
 """
@@ -51,6 +57,23 @@ class _Form:
 
 
 ZERO = object()         # the rate of a y-independent value
+
+
+class _Hidden:
+    """``act(y @ W1^T + b1)`` (act None: before the activation): a (rows, hidden) value of a perceptron drift."""
+    __slots__ = ("w1", "b1", "act")
+
+    def __init__(self, w1, b1, act=None):
+        self.w1, self.b1, self.act = w1, b1, act
+
+
+class _Perceptron:
+    """``act(y @ W1^T + b1) @ W2^T + b2``: weights as the (out, in) tensors `nn.Linear` holds."""
+    __slots__ = ("w1", "b1", "act", "w2", "b2", "exact")
+    phi = "perceptron"
+
+    def __init__(self, hidden, w2, b2):
+        self.w1, self.b1, self.act, self.w2, self.b2, self.exact = hidden.w1, hidden.b1, hidden.act, w2, b2, False
 
 
 def _mul(a, b):
@@ -87,6 +110,8 @@ class _Interpreter(TorchDispatchMode):
         self.forms = {id(y): _Form()}
         self.time = {id(t)}
         self.keep = [y, t]              # every tracked tensor stays alive: ids are not reused during the run
+        self.hidden = {}                # id -> _Hidden: (rows, hidden)-shaped values of a perceptron drift
+        self.transposed = {}            # id of `W.t()` -> W (nn.Linear hands addmm the transposed view of its weight)
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------------
     def form_of(self, x):
@@ -172,6 +197,80 @@ class _Interpreter(TorchDispatchMode):
             raise NotElementwise(f"{name} of {x.phi}: nested functions")
         return _Form(name, None, x.rate, x.shift, None, exact=x.exact)
 
+    # ---- a perceptron drift: lin2(act(lin1(y))) ------------------------------------------------------------------
+    def weight_of(self, operand, name):
+        """The (out, in) weight behind the second operand of a product `x @ operand` (nn.Linear passes `W.t()`)."""
+        if not torch.is_tensor(operand) or operand.dim() != 2 or id(operand) in self.forms or id(operand) in self.hidden:
+            raise NotElementwise(f"{name} with an operand that is not a weight matrix")
+        if id(operand) in self.time:
+            raise NotElementwise("the coefficients depend on t")
+        w = self.transposed.get(id(operand))
+        return w if w is not None else operand.t()
+
+    def layer_operands(self, name, args):
+        """(input, weight (out, in), bias or None) of addmm(bias, x, Wt) / mm(x, Wt) / linear(x, W, bias)."""
+        if name == "addmm":
+            if len(args) != 3:
+                raise NotElementwise("addmm with beta / alpha")
+            return args[1], self.weight_of(args[2], name), args[0]
+        if name == "mm":
+            return args[0], self.weight_of(args[1], name), None
+        w = args[1]
+        if not torch.is_tensor(w) or w.dim() != 2:
+            raise NotElementwise("linear with an operand that is not a weight matrix")
+        return args[0], w, (args[2] if len(args) > 2 else None)
+
+    def bias_of(self, b, width):
+        if b is None:
+            return None
+        if not torch.is_tensor(b) or id(b) in self.time or id(b) in self.forms or id(b) in self.hidden \
+                or tuple(b.shape) != (width,):
+            raise NotElementwise("a layer bias that is not one value per output channel")
+        return b
+
+    def first_layer(self, name, args, out):
+        x, w, b = self.layer_operands(name, args)
+        form = self.form_of(x)
+        if form is None or form.constant() or form.phi != "identity" or any(
+                c is not None for c in (form.scale, form.rate, form.shift, form.offset)):
+            raise NotElementwise("a matrix product of something other than the state itself")
+        if tuple(w.shape)[1:] != (self.d,) or tuple(out.shape) != (self.rows, w.shape[0]):
+            raise NotElementwise("a matrix product that does not act on the state channels")
+        self.hidden[id(out)] = _Hidden(w, self.bias_of(b, w.shape[0]))
+        self.keep.append(out)
+        return out
+
+    def perceptron_step(self, func, args, kwargs):
+        schema = func._schema
+        name = schema.name.split("::")[1]
+        if schema.is_mutable:
+            raise NotElementwise(f"in-place {name} inside the drift network")
+        out = func(*args, **kwargs)
+        h = self.hidden.get(id(args[0])) if args and torch.is_tensor(args[0]) else None
+        if name in ("tanh", "softplus") and h is not None and h.act is None:
+            if name == "softplus":
+                beta = args[1] if len(args) > 1 else kwargs.get("beta", 1)
+                threshold = args[2] if len(args) > 2 else kwargs.get("threshold", 20)
+                if beta != 1 or threshold != 20:
+                    raise NotElementwise("softplus with a non-default beta or threshold")
+            self.hidden[id(out)] = _Hidden(h.w1, h.b1, name)
+            self.keep.append(out)
+            return out
+        if name in ("addmm", "mm", "linear"):
+            x, w, b = self.layer_operands(name, args)
+            h = self.hidden.get(id(x))
+            if h is None or h.act is None:
+                raise NotElementwise("a second layer without an activation before it")
+            if tuple(w.shape) != (self.d, h.w1.shape[0]) or tuple(out.shape) != (self.rows, self.d):
+                raise NotElementwise("the drift network does not map back to the state channels")
+            return self.track(out, _Perceptron(h, w, self.bias_of(b, self.d)))
+        if name in self._SAME and h is not None and torch.is_tensor(out) and out.shape == args[0].shape \
+                and out.dtype == args[0].dtype:
+            self.hidden[id(out)] = h
+            self.keep.append(out)
+            return out
+        raise NotElementwise(f"operator {schema.name} inside the drift network")
+
     # ---- the dispatch hook ---------------------------------------------------------------------------------------
     _UNARY = {"exp": "exp", "sigmoid": "sigmoid", "tanh": "tanh", "sin": "sin", "cos": "cos"}
     _SAME = {"alias", "detach", "clone", "lift_fresh", "positive", "contiguous", "_to_copy", "view", "reshape",
@@ -197,9 +296,15 @@ class _Interpreter(TorchDispatchMode):
             if any(id(a) in self.forms for a in involved):
                 raise NotElementwise("drift or diffusion depends on t")
             return out
+        if any(id(a) in self.hidden for a in involved):
+            return self.perceptron_step(func, args, kwargs)
         tracked = [a for a in involved if id(a) in self.forms]
         if not tracked:
             out = func(*args, **kwargs)
+            if func._schema.name in ("aten::t", "aten::transpose") and torch.is_tensor(out) and out.dim() == 2 \
+                    and args[0].dim() == 2:
+                self.transposed[id(out)] = args[0]
+                self.keep.append(out)
             # a y-independent value stretched over the probe's rows (`sigma.expand_as(y)`, `sigma.expand(B, d)`)
             if func._schema.name == "aten::expand" and torch.is_tensor(out) and tuple(out.shape) == (self.rows, self.d):
                 src = args[0]
@@ -211,7 +316,14 @@ class _Interpreter(TorchDispatchMode):
         if schema.is_mutable:
             raise NotElementwise(f"in-place {name} on a value derived from the state")
         out = func(*args, **kwargs)
+        if name in ("addmm", "mm", "linear"):
+            return self.first_layer(name, args, out)
         x = self.form_of(args[0]) if args else None
+        if any(isinstance(self.form_of(v), _Perceptron) for v in args[:2]):
+            if name in self._SAME and isinstance(x, _Perceptron) and tuple(out.shape) == (self.rows, self.d) \
+                    and out.dtype == args[0].dtype:
+                return self.track(out, x)
+            raise NotElementwise(f"{name} applied to the output of the drift network")
         if name in self._LIKE or name in ("full_like", "empty_like", "new_zeros", "new_ones", "new_full", "new_empty"):
             if name in self._LIKE and tuple(out.shape) == (self.rows, self.d) and out.dtype == args[0].dtype:
                 return self.track(out, _Form(rate=ZERO, shift=self._LIKE[name] or None))
@@ -277,10 +389,18 @@ class Recognised:
     def __init__(self, f, g, d, dtype, device):
         self.f, self.g, self.d, self.dtype, self.device = f, g, d, dtype, device
         self.exact = f.exact and g.exact
+        if isinstance(g, _Perceptron):
+            raise NotElementwise("a perceptron diffusion")
+
+    @property
+    def perceptron(self):
+        return isinstance(self.f, _Perceptron)
 
     def structure(self):
         """The part of the result that does not change when parameter VALUES change: key of the trust verdict."""
         def shape(form):
+            if isinstance(form, _Perceptron):
+                return ("perceptron", form.act, tuple(form.w1.shape), form.b1 is None, form.b2 is None)
             return (form.phi, form.constant()) + tuple(
                 None if c is None else "number" if isinstance(c, (int, float)) else "tensor"
                 for c in (form.scale, form.rate, form.shift, form.offset))
@@ -305,9 +425,69 @@ class Recognised:
         return (self._vector(form.scale, 1.0), self._vector(form.rate, 1.0), self._vector(form.shift, 0.0),
                 self._vector(form.offset, 0.0))
 
+    _ACTIVATIONS = {"tanh": 0, "softplus": 1}              # closed_form.MLPDriftDiagonalSDE._ACTIVATIONS
+
+    def perceptron_diffusion(self):
+        """(kind code, amplitude, rate, shift) of a diffusion the perceptron kernels take: `rate * y + shift` (affine) or
+        `amplitude * sigmoid(rate * y + shift)` with a fixed number as amplitude; else NotElementwise."""
+        g = self.g
+        if isinstance(g, _Perceptron):
+            raise NotElementwise("a perceptron diffusion")
+        if g.constant():
+            return _native.DIFF_AFFINE, 1.0, 0.0, _add(g.shift, g.offset)
+        if g.phi == "identity" and g.scale is None and g.offset is None:
+            return _native.DIFF_AFFINE, 1.0, g.rate, g.shift
+        if g.phi == "sigmoid" and g.offset is None and (g.scale is None or isinstance(g.scale, (int, float))):
+            return _native.DIFF_SIGMOID, 1.0 if g.scale is None else float(g.scale), g.rate, g.shift
+        raise NotElementwise(f"a {g.phi} diffusion beside a perceptron drift")
+
+    def perceptron_supported(self, float32_only=True):
+        """The shape limits of the perceptron kernels (closed_form.MLPDriftDiagonalSDE.closed_form)."""
+        f = self.f
+        hidden = f.w1.shape[0]
+        tensors = [t for t in (f.w1, f.b1, f.w2, f.b2) if t is not None]
+        return (self.dtype == torch.float32 and all(t.dtype == torch.float32 and t.device == self.device for t in tensors)
+                and self.d % 4 == 0 and self.d <= 128 and hidden <= (256 if self.d <= 64 else 128))
+
+    def perceptron_spec(self):
+        """("mlp_diagonal", W1 (d, hidden) input-major, b1, W2 (hidden, d), b2, rate (d,), shift (d,), activation code,
+        (diffusion kind, amplitude)): what `kernels.trajectory_mlp_diag` takes (closed_form.py)."""
+        f = self.f
+        if not self.perceptron_supported():
+            raise NotElementwise("a perceptron drift outside the kernels' shapes")
+        kind, amplitude, rate, shift = self.perceptron_diffusion()
+        hidden = f.w1.shape[0]
+        b1 = f.b1.detach().contiguous() if f.b1 is not None else _constant_vector(0.0, hidden, self.dtype, self.device)
+        b2 = f.b2.detach().contiguous() if f.b2 is not None else _constant_vector(0.0, self.d, self.dtype, self.device)
+        return ("mlp_diagonal", f.w1.detach().t().contiguous(), b1, f.w2.detach().t().contiguous(), b2,
+                self._vector(rate, 1.0), self._vector(shift, 0.0), self._ACTIVATIONS[f.act], (kind, amplitude))
+
+    def perceptron_parameters(self):
+        """(lin1.weight, lin1.bias, lin2.weight, lin2.bias, rate, shift) as the tensors the user's module holds -- what
+        `sdeint_adjoint` through `tsde_adjoint_mlp_diag` returns gradients for -- or None when a coefficient of the
+        diffusion is not such a tensor as it stands (derived from parameters by arithmetic: the trace ran without
+        autograd, so its gradient could not be passed on) or a layer has no bias."""
+        f = self.f
+        _, _, rate, shift = self.perceptron_diffusion()
+        if f.b1 is None or f.b2 is None:
+            return None
+        own = [f.w1, f.b1, f.w2, f.b2]
+        for c, neutral in ((rate, 1.0), (shift, 0.0)):
+            if c is None or isinstance(c, (bool, int, float)):
+                own.append(torch.tensor(float(neutral if c is None else c), dtype=self.dtype, device=self.device))
+            elif c.dim() == 1 and c.numel() in (1, self.d) or c.dim() == 0:
+                own.append(c)
+            else:
+                return None
+        return own
+
     def spec(self):
         """The `closed_form()` tuple the trajectory launchers take (closed_form.py): affine kernel when both functions
-        are plain `rate * y + shift`, else the expression kernel."""
+        are plain `rate * y + shift`, else the expression kernel; perceptron drift: `perceptron_spec`."""
+        if self.perceptron:
+            return self.perceptron_spec()
+        if isinstance(self.g, _Perceptron):
+            raise NotElementwise("a perceptron diffusion")
         f4, g4 = self._four(self.f), self._four(self.g)
         plain = all(v.phi == "identity" and v.scale is None and v.offset is None for v in (self.f, self.g))
         if plain:

@@ -426,7 +426,13 @@ class BaseSDESolver:
             spec = found.spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
-        key = (found.structure(), chain, type(self).__name__, sde.sde_type, y0.shape[1], y0.dtype)
+        if spec[0] == "mlp_diagonal":
+            # perceptron drift: the sampling kernel's own limits (cf. `_closed_form_coefficients`)
+            code = self._trajectory_code()
+            if (code not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT,
+                             _native.TRAJ_MIDPOINT, _native.TRAJ_SRK) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30):
+                return None
+        key = self._recognised_key(found, chain, y0)
         verdict = book["trusted"].get(key)
         launch = spec[1:] if spec[0] == "affine_diagonal" else spec       # (what `_integrate_trajectory` takes)
         if verdict is True:
@@ -453,12 +459,48 @@ class BaseSDESolver:
         self._extra = ()
         stepwise = self._run(self._plan(y0, ts), y0)
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
+        if spec[0] == "mlp_diagonal":       # the matrix cores sum the layers' products in another order than the library
+            rtol, atol = 1e-3, 1e-4
         both_nan = fast.isnan() & stepwise.isnan()
         close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
         if len(book["trusted"]) >= 32:
             book["trusted"].clear()
         book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
         return stepwise
+
+    def _recognised_key(self, found, chain, y0):
+        return (found.structure(), chain, type(self).__name__, self.sde.sde_type, y0.shape[1], y0.dtype)
+
+    def recognised_perceptron(self, y0, ts):
+        """For `sdeint_adjoint` (mlp_adjoint.route): the interpretation of an unchanged user module whose drift is a
+        two-layer perceptron -- `recognise.Recognised` -- if this solver's forward solve of it through the sampling
+        kernel is TRUSTED (verified against the stepwise solve; the check runs here, once, if it has not yet), else None."""
+        from . import graph, recognise
+        from .sde import ForwardSDE
+        sde = self.sde
+        if (not recognise.ENABLED or type(sde) is not ForwardSDE or sde.user_product
+                or sde.noise_type != NOISE_TYPES.diagonal or y0.dim() != 2 or not y0.is_cuda):
+            return None
+        chain, base = graph._wrapper_chain(sde)
+        book = getattr(base, self._RECOGNISED_ATTR, None)
+        if book is not None and book["refused"]:
+            state = graph.python_state(base)
+            if state is None or (state, chain, type(self).__name__) in book["refused"]:
+                return None
+        try:
+            with torch.no_grad():
+                found = recognise.recognise(sde, ts[0], y0.detach())
+            if not found.perceptron:
+                return None
+            found.perceptron_spec()
+        except recognise.NotElementwise:
+            return None
+        key = self._recognised_key(found, chain, y0)
+        if book is None or key not in book["trusted"]:
+            with torch.no_grad():                                  # the verifying solve (both routes, compared)
+                self._integrate_recognised(y0.detach(), ts)
+            book = getattr(base, self._RECOGNISED_ATTR, None)
+        return found if book is not None and book["trusted"].get(key) is True else None
 
     def recognised_route(self):
         """{form key: True | reason} and {state: reason} of the SDE object this solver integrates (diagnostics)."""

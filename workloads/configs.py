@@ -157,6 +157,20 @@ WORKLOADS = {
         m=128, nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=0, kid=10, launches_per_step=1, trajectory=True,
         adjoint=True, mfma_flops_per_traj_step=8 * 128 * 128,
         kernel="tsde_adjoint_mlp_diag<128, 128, softplus, milstein> (mlp_adjoint_kernel, v_mfma_f32_16x16x4_f32)"),
+    # BASELINE configs[4] as a drop-in user gets it: the latent-SDE user module (nn.Sequential drift, 0.1 * sigmoid(w*y + b)
+    # diffusion; nothing of this package in it) through sdeint_adjoint with no options. recognise.py finds the perceptron
+    # form; forward = tsde_trajectory_mlp_diag, backward = tsde_adjoint_mlp_diag + tsde_gram_partials, gradients on the
+    # module's own parameters. Stepwise beside it: c5_adjoint_latent_b32768_d128_s500.
+    "c5_adjoint_latent_default_route_b32768_d128_s500": dict(
+        problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=0, kid=10, launches_per_step=1, trajectory=True, recognised=True,
+        adjoint=True, mfma_flops_per_traj_step=8 * 128 * 128,
+        kernel="tsde_adjoint_mlp_diag<128, 128, softplus> (mlp_adjoint_kernel, v_mfma_f32_16x16x4_f32; user module recognised)"),
+    "c5_adjoint_latent_defaults_default_route_b32768_d128_s500": dict(
+        problem="latent_diag", method="srk", adjoint_method="milstein", levy="space-time", B=32768, d=128, m=128,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=0, kid=10, launches_per_step=1, trajectory=True, recognised=True,
+        adjoint=True, mfma_flops_per_traj_step=8 * 128 * 128,
+        kernel="tsde_adjoint_mlp_diag<128, 128, softplus, milstein> (user module recognised; every default of sdeint_adjoint)"),
     "c5_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=128,
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
