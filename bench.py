@@ -438,6 +438,9 @@ class Job:
                 "timing": "HIP events around a replayed HIP graph of 200 launches on rotating live operands (>= 128 MiB), "
                           "best of 3"}
         if moved != contract:
+            d = c["d"]
+            roof["streams"] = {"survey_8d": contract // (4 * d), "implementation": moved // (4 * d),
+                               "why": "four stage kernels with user f, g between them: partial sums cross HBM (DESIGN.md)"}
             roof["bytes_moved_per_traj_step"] = moved
             roof["moved_achieved"] = moved * B / (step_us * 1e-6) / 1e9
             roof["moved_frac"] = roof["moved_achieved"] / HBM_PEAK_GBPS
@@ -504,6 +507,13 @@ def _attach_offline_traffic(roofline, workload):
                 roofline["traffic_source"] = f"profiles/traffic_latest.json: no kernel matching {pattern!r} for {workload}"
                 return
             rows.append(max(hit, key=lambda k: k.get("launches", 0)))
+        if cfg.get("trajectory"):
+            # one launch is the whole solve: the counters give what it really moves (y0 in, outputs out)
+            roofline["traffic"] = rows[0]["traffic_bytes_per_launch"]
+            roofline["traffic_is"] = "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)"
+            roofline["traffic_over_algorithmic"] = roofline["traffic"] / roofline["bytes_per_launch"]
+            roofline["traffic_source"] = f"profiles/traffic_latest.json @ csrc {digest}"
+            return
         per_step = cfg["launches_per_step"]
         launches_each = per_step // len(rows)
         step_bytes = sum(k["traffic_bytes_per_launch"] for k in rows) * launches_each
@@ -566,7 +576,7 @@ def _side_measurement(dev, name):
     if roof is not None:
         for key in ("bound", "achieved", "unit", "frac", "solve_achieved", "solve_frac", "bytes_per_traj_step",
                     "bytes_per_launch", "flops_per_launch", "avg_launch_us", "launches_timed", "launch_us",
-                    "launches_per_step", "bytes_moved_per_traj_step", "moved_frac", "traffic", "traffic_per_traj_step",
+                    "launches_per_step", "bytes_moved_per_traj_step", "moved_frac", "streams", "traffic", "traffic_per_traj_step",
                     "traffic_over_algorithmic", "kernel_us_rocprofv3", "frac_rocprofv3", "traffic_source", "timing"):
             if key in roof:
                 rec[("kernel_" + key) if key in ("achieved", "frac") else key] = roof[key]
@@ -805,6 +815,8 @@ def main():
     if job.trajectory:
         k_ms, k_launches = job.bracket_dominant_kernel()
         roofline = job.roofline(value, k_ms, k_launches)
+        if roofline is not None and roofline.get("bound") == "hbm" and cfg.get("kernel_match"):
+            _attach_offline_traffic(roofline, args.workload)
     else:
         roofline = job.roofline_stepwise(value, job.back_to_back_us(job.live_state(out)))
         _attach_offline_traffic(roofline, args.workload)

@@ -11,6 +11,7 @@ WORKLOADS = {
     "c2_euler_diag_default_route_b65536_d64_s1000": dict(
         problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True, stepwise="c2_euler_diag_b65536_d64_s1000",
+        kernel_match=["trajectory_kernel<float"], launches_per_step=1,
         kernel="tsde_trajectory_affine_diag<float, euler> (trajectory_kernel; user module recognised by recognise.py)"),
     "c2_milstein_diag_default_route": dict(
         problem="gbm_ito", method="milstein", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
