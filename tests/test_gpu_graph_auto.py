@@ -339,7 +339,7 @@ def test_operators_outside_the_known_family_are_never_recorded():
 @pytest.mark.parametrize("explicit", [False, True])
 def test_sweeps_with_multi_block_reductions_are_recorded_right_or_not_at_all(explicit, rewrite):
     """On this stack a HIP graph holding several multi-block torch reductions is right on its first replay and wrong on
-    later ones (tools/probe_graph_reduction2.py) -- at B = 4096, d = 128 the backward sweep of `sdeint_adjoint`,
+    later ones (tools/probe_graph_reduction4.py) -- at B = 4096, d = 128 the backward sweep of `sdeint_adjoint`,
     replayed, returned inf for per-channel parameters. The nodes at fault are the memset nodes of those reductions:
     `graph._capturing` rewrites them as kernels (csrc/graph_nodes.hip), and then the recorded sweep IS replayed, with the
     eager gradients on EVERY iteration. With the rewriting switched off the second line of defence has to hold: the

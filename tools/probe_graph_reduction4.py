@@ -1,4 +1,4 @@
-"""Which part of a recorded graph goes wrong (continues tools/probe_graph_reduction3.py)? torch's multi-block reductions
+"""THE reproducer of tools/REPORT_hip_graph_memset_nodes.md (needs only torch). Which part of a recorded graph goes wrong? torch's multi-block reductions
 zero their block-counting semaphores with a `hipMemsetAsync` before every launch (ATen/native/cuda/Reduce.cuh): under
 capture that is a MEMSET NODE, the only kind of node besides kernels in the graphs this package records.
   A  a graph of 20 x [memset node on a counter buffer, kernel that increments and accumulates it], replayed with a host

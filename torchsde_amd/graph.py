@@ -506,7 +506,7 @@ def replays_are_stable(replay, outputs, disturb=None, extra_replays=2):
     on the device in between? It should, trivially. But on this stack (ROCm 7.2, torch 2.10) a graph that holds several
     multi-block torch reductions (`x.sum(0)` over a few thousand rows: the parameter gradients of a broadcast `w * y`)
     is right when first replayed and wrong, stably, once an eager reduction and a host synchronisation have come between
-    two replays (tools/probe_graph_reduction2.py, profiles/r3j_probe_graph_reduction.txt: twenty column sums of a
+    two replays (tools/probe_graph_reduction4.py, profiles/r3j_probe_graph_reduction.txt: twenty column sums of a
     4096 x 128 tensor in one graph are 23 % off from the second replay on; the backward sweep of `sdeint_adjoint` at
     B = 4096, d = 128 returned inf for per-channel parameters). The nodes at fault are the MEMSET nodes with which ATen
     zeroes the semaphores of such reductions, and `_capturing` rewrites them as kernel nodes, which cures every case
