@@ -171,7 +171,7 @@ def route(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoint_adaptiv
     else:
         # an UNCHANGED user module whose drift turns out to be lin2(act(lin1(y))) with an affine / sigmoid diagonal
         # diffusion (recognise.py), its forward solve through the sampling kernel verified against the stepwise one
-        if solver is None or not isinstance(base, torch.nn.Module) or options.get("hip_graph") is True:
+        if solver is None or not isinstance(base, torch.nn.Module):
             return None
         found = solver.recognised_perceptron(y0, ts)
         if found is None:
