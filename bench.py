@@ -182,7 +182,9 @@ class Job:
         self.sde = _make_problem(c["problem"], c["d"], c["m"], dev)
         self.y0 = torch.full((c["B"], c["d"]), 0.1, device=dev, requires_grad=self.adjoint or self.train)
         self.ts = torch.tensor([0.0, c["nsteps"] * c["dt"]], device=dev)
-        self.gathered = torch.empty((world * c["B"], c["d"]), device=dev) if dist is not None else None
+        # two gather buffers: the all-gather of solve i runs (on RCCL's stream) while solve i + 1 computes
+        self.gathered = [torch.empty((world * c["B"], c["d"]), device=dev) for _ in range(2)] if dist is not None else None
+        self._gathers, self._pending = 0, []
         self._sdeint, self._sdeint_adjoint = torchsde_amd.sdeint, torchsde_amd.sdeint_adjoint
         self._BM = torchsde_amd.BrownianInterval
 
@@ -222,9 +224,24 @@ class Job:
             ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
                               options=None if c.get("recognised") else dict(extra_options, hip_graph=bool(graph)))
             if self.dist is not None:
-                self.dist.all_gather_into_tensor(self.gathered, ys[-1])
-                return self.gathered
+                # The one collective of a solve, issued asynchronously: it waits for this solve's kernels on RCCL's own
+                # stream and overlaps the NEXT solve's compute; at most two are in flight (double buffer), the one before
+                # the previous is waited for here, and `finish()` -- called before the closing barrier of every timed
+                # region -- waits for the rest. (With a 3 ms solve a blocking 8-rank gather of 128 MiB would be a
+                # visible part of every step; at 26 ms it was not.)
+                out = self.gathered[self._gathers & 1]
+                self._gathers += 1
+                work = self.dist.all_gather_into_tensor(out, ys[-1], async_op=True)
+                self._pending.append((work, ys))
+                while len(self._pending) > 1:
+                    self._pending.pop(0)[0].wait()
+                return out
             return ys[-1]
+
+    def finish(self):
+        """Wait (stream-wise) for every all-gather still in flight; the caller synchronises afterwards."""
+        while self._pending:
+            self._pending.pop(0)[0].wait()
 
     def prepare(self):
         """Everything a first solve pays once, before any warm-up or timing: recording the HIP graph(s) of this workload
@@ -686,12 +703,12 @@ def _what_the_ranks_saw(job, dev, dist, share_gpu):
     if job.gathered is not None and not (job.adjoint or job.train):
         local = torch.zeros((job.cfg["B"], job.cfg["d"]), device=dev)
         for _ in range(3):
-            dist.all_gather_into_tensor(job.gathered, local)
+            dist.all_gather_into_tensor(job.gathered[0], local)
         dist.barrier()
         torch.cuda.synchronize()
         start = time.perf_counter()
         for _ in range(20):
-            dist.all_gather_into_tensor(job.gathered, local)
+            dist.all_gather_into_tensor(job.gathered[0], local)
         torch.cuda.synchronize()
         t = torch.tensor([(time.perf_counter() - start) / 20 * 1e3], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -788,6 +805,8 @@ def main():
 
     def barrier():
         if use_dist:
+            job.finish()
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -149,7 +149,7 @@ def test_bench_one_rank_over_rccl_matches_the_plain_run():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TSDE_BENCH_SHARE_GPU"):
         env.pop(key, None)
-    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-also", "--no-cpu-baseline"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "2", "--no-also", "--no-cpu-baseline"]
     dist = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail, env, root)
     plain = _run_bench([sys.executable] + tail, env, root)
@@ -157,4 +157,5 @@ def test_bench_one_rank_over_rccl_matches_the_plain_run():
     assert dist["all_gather_ms_per_solve"] > 0 and dist["all_gather_bytes_per_rank"] == 65536 * 64 * 4
     assert plain["collective_backend"] is None and plain["ranks_seen"] == 1
     assert dist["roofline"]["frac"] > 0 and plain["roofline"]["frac"] > 0
+    # (20 solves of ~3 ms: the closing barrier over RCCL is the only extra in the timed region)
     assert abs(dist["value"] - plain["value"]) <= 0.03 * plain["value"], (dist["value"], plain["value"])
