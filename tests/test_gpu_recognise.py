@@ -316,3 +316,69 @@ def test_perceptron_drifts_that_do_not_fit_stay_stepwise():
         for entropy in (1, 2):
             got, n = _launches(lambda: _solve(sde, entropy, y0=y0))
             assert n == 0 and torch.equal(got, _solve(sde, entropy, y0=y0, stepwise=True))
+
+
+class _Derived(nn.Module):
+    """Coefficients the user's code derives from its parameters before they meet the state: autograd saw those steps."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        super().__init__()
+        self.theta = nn.Parameter(torch.linspace(0.3, 1.2, D))
+        self.log_sigma = nn.Parameter(torch.full((D,), -1.5))
+        self.level = nn.Parameter(torch.tensor(0.05))
+
+    def f(self, t, y):
+        return -self.theta * y + self.level
+
+    def g(self, t, y):
+        return self.log_sigma.exp() * y
+
+
+@pytest.mark.parametrize("make,method,levy", [(lambda: problems.make("gbm_ito", d=D), "euler", "none"),
+                                              (lambda: problems.make("gbm_ito", d=D), "milstein", "none"),
+                                              (_Derived, "euler", "none"), (_Derived, "srk", "space-time")])
+def test_training_through_sdeint_takes_the_sensitivity_kernel(make, method, levy):
+    """`sdeint` with autograd recording, unchanged module: values from `tsde_trajectory_affine_diag_sens`, gradients on
+    the user's own parameters (through the graph their code built on the way to the coefficients) -- against
+    back-propagation through the stepwise solver (`options={"trajectory_kernel": False}`)."""
+    import torchsde_amd
+    sde = make().to(DEV)
+    ts = torch.tensor([0.0, 11 * DT, STEPS * DT], device=DEV)
+    weights = torch.randn(3, B, D, device=DEV)
+
+    def run(entropy, options):
+        y0 = torch.full((B, D), 0.1, device=DEV, requires_grad=True)
+        sde.zero_grad()
+        bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, D), device=DEV, entropy=entropy,
+                                           levy_area_approximation=levy)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=DT, options=options)
+        (ys * weights).sum().backward()
+        return ys.detach(), y0.grad.clone(), {n: p.grad.clone() for n, p in sde.named_parameters()}, ys.grad_fn
+
+    first = run(1, {"hip_graph": False})                   # the verifying solve: stepwise values and graph
+    assert not type(first[3]).__name__.startswith("_TrajectoryFn")
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    (ys_a, gy_a, gp_a, fn_a), n = _launches(lambda: run(2, {"hip_graph": False}))
+    ys_b, gy_b, gp_b, _ = run(2, {"hip_graph": False, "trajectory_kernel": False})
+    assert n == 1 and type(fn_a).__name__.startswith("_TrajectoryFn"), type(fn_a).__name__
+    _close(ys_a, ys_b, "ys", tol=1e-5)
+    _close(gy_a, gy_b, "dL/dy0", tol=2e-4)
+    assert set(gp_a) == set(gp_b)
+    for name in gp_a:
+        _close(gp_a[name], gp_b[name], f"dL/d{name}", tol=5e-4)
+
+
+def test_folded_coefficients_train_on_the_stepwise_path():
+    """mu*y - 0.5*sigma^2*y: the rate is assembled inside the interpretation from two terms -- no graph behind it -- so
+    with autograd on the solve stays stepwise (and stays right); without autograd it takes the kernel as before."""
+    import torchsde_amd
+    sde = problems.make("gbm_strat", d=D).to(DEV)
+    y0 = torch.full((B, D), 0.1, device=DEV, requires_grad=True)
+    ts = torch.tensor([0.0, STEPS * DT], device=DEV)
+    for entropy in (1, 2):
+        bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, D), device=DEV, entropy=entropy)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="midpoint", dt=DT)
+        assert not type(ys.grad_fn).__name__.startswith("_TrajectoryFn")
+        ys[-1].sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sde.parameters())

@@ -110,6 +110,9 @@ class _Interpreter(TorchDispatchMode):
         self.forms = {id(y): _Form()}
         self.time = {id(t)}
         self.keep = [y, t]              # every tracked tensor stays alive: ids are not reused during the run
+        self.seen = set()               # ids of every tensor the USER's code handed to an operator (kept alive): a
+        #                                 coefficient among them is the user's own tensor -- a parameter, or something
+        #                                 their code computed from parameters with autograd watching -- not one folded here
         self.hidden = {}                # id -> _Hidden: (rows, hidden)-shaped values of a perceptron drift
         self.transposed = {}            # id of `W.t()` -> W (nn.Linear hands addmm the transposed view of its weight)
 
@@ -284,6 +287,10 @@ class _Interpreter(TorchDispatchMode):
         for a in flat:
             if isinstance(a, (list, tuple)):
                 involved.extend(x for x in a if torch.is_tensor(x))
+        for a in involved:
+            if id(a) not in self.seen:
+                self.seen.add(id(a))
+                self.keep.append(a)
         if any(id(a) in self.time for a in involved):
             name = func._schema.name
             if name in ("aten::_local_scalar_dense", "aten::item"):
@@ -481,6 +488,27 @@ class Recognised:
                 return None
         return own
 
+    def affine_leaves(self):
+        """For a solve that autograd records: (drift rate, drift shift, diffusion rate, diffusion shift) as tensors the
+        sensitivity kernel's gradients can be handed to (`kernels.trajectory_affine_diag_differentiable`), or None.
+        Only plain `rate * y + shift` forms qualify, and only when every tensor coefficient is the user's OWN tensor --
+        seen as an operand of their code, so a parameter or something autograd saw them compute -- of shape (d,) or one
+        element: a coefficient folded inside the interpretation (`mu - 0.5 * sigma ** 2` assembled from two terms) has
+        no graph behind it."""
+        if self.perceptron or not all(v.phi == "identity" and v.scale is None and v.offset is None and not v.constant()
+                                      for v in (self.f, self.g)):
+            return None
+        out = []
+        for c, neutral in ((self.f.rate, 1.0), (self.f.shift, 0.0), (self.g.rate, 1.0), (self.g.shift, 0.0)):
+            if c is None or isinstance(c, (bool, int, float)):
+                out.append(torch.tensor(float(neutral if c is None else c), dtype=self.dtype, device=self.device))
+            elif (id(c) in self.users_tensors and c.dtype == self.dtype and c.device == self.device
+                  and (c.numel() == 1 or tuple(c.shape) == (self.d,))):
+                out.append(c)
+            else:
+                return None
+        return out
+
     def spec(self):
         """The `closed_form()` tuple the trajectory launchers take (closed_form.py): affine kernel when both functions
         are plain `rate * y + shift`, else the expression kernel; perceptron drift: `perceptron_spec`."""
@@ -508,7 +536,7 @@ def _constant_vector(value, d, dtype, device):
     return hit
 
 
-def recognise(sde, t, y0):
+def recognise(sde, t, y0, differentiable=False):
     """Interpret ``sde.f_and_g`` (a ForwardSDE: whichever of f / g / f_and_g the user defined) on a probe of the state's
     width; returns `Recognised` or raises `NotElementwise`. Launches a handful of tiny kernels, never synchronises."""
     rows = 2 if y0.shape[0] != 2 else 3         # a per-ROW constant of the real batch cannot broadcast against the probe
@@ -518,7 +546,9 @@ def recognise(sde, t, y0):
     t_probe = t.detach().clone()
     interp = _Interpreter(probe, t_probe, rows, d)
     try:
-        with torch.no_grad(), interp:
+        # `differentiable`: autograd watches what the user's code computes from its parameters on the way (`-self.theta`,
+        # `self.sigma ** 2`), so that a coefficient which is such a tensor carries its graph (see `affine_leaves`)
+        with (torch.enable_grad() if differentiable else torch.no_grad()), interp:
             f, g = sde.f_and_g(t_probe, probe)
     except NotElementwise:
         raise
@@ -530,4 +560,7 @@ def recognise(sde, t, y0):
         if form is None:
             raise NotElementwise(f"the {name} is not a tracked function of the state")
         forms.append(form)
-    return Recognised(forms[0], forms[1], d, y0.dtype, y0.device)
+    found = Recognised(forms[0], forms[1], d, y0.dtype, y0.device)
+    found.users_tensors = interp.seen
+    found._alive = interp.keep        # (the ids above stay meaningful for as long as this object lives)
+    return found

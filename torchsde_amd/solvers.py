@@ -394,8 +394,10 @@ class BaseSDESolver:
         sde = self.sde
         if (not recognise.ENABLED or not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful
                 or type(sde) is not ForwardSDE or sde.user_product or sde.noise_type != NOISE_TYPES.diagonal
-                or self._trajectory_code() is None or self._tracks_grad(y0)):
+                or self._trajectory_code() is None):
             return None
+        if self._tracks_grad(y0):
+            return self._integrate_recognised_with_grad(y0, ts)
         bm = self._native_bm()
         if (bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or not y0.is_cuda or y0.shape[0] < 8
                 or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
@@ -466,6 +468,57 @@ class BaseSDESolver:
         if len(book["trusted"]) >= 32:
             book["trusted"].clear()
         book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
+        return stepwise
+
+    def _integrate_recognised_with_grad(self, y0, ts):
+        """Autograd is recording the solve (`sdeint` with trainable parameters or y0). A recognised module whose drift and
+        diffusion are plain `rate * y + shift` with the user's own tensors as coefficients takes the sensitivity kernel
+        (`tsde_trajectory_affine_diag_sens`: forward-mode tangents in registers, `backward()` a few reductions) and the
+        gradients land on those tensors -- through whatever graph the user's code built on the way to them. Trust as for
+        the forward route; the verifying solve compares the kernel's VALUES with the stepwise solve, which is the one
+        that is returned (with its graph). None: the stepwise path."""
+        from . import graph, recognise
+        sde, bm = self.sde, self._native_bm()
+        if (bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or not y0.is_cuda or y0.shape[0] < 8
+                or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
+                or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
+                or (self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
+            return None
+        chain, base = graph._wrapper_chain(sde)
+        try:
+            book = base.__dict__.setdefault(self._RECOGNISED_ATTR, {"refused": {}, "trusted": {}})
+        except AttributeError:
+            return None
+        if book["refused"]:
+            state = graph.python_state(base)
+            if state is None or (state, chain, type(self).__name__) in book["refused"]:
+                return None
+        try:
+            found = recognise.recognise(sde, ts[0], y0, differentiable=True)
+        except recognise.NotElementwise:
+            return None         # (the forward route records refusals; a training loop reaches it under no_grad or not at all)
+        leaves = found.affine_leaves()
+        if leaves is None:
+            return None
+        key = self._recognised_key(found, chain, y0) + ("autograd",)
+        verdict = book["trusted"].get(key)
+        if verdict is True:
+            return self._integrate_trajectory(("differentiable",) + tuple(leaves), y0, ts)
+        if verdict is not None:
+            return None
+        with torch.no_grad():
+            fast = self._integrate_trajectory(tuple(c.detach().reshape(-1).expand(y0.shape[1]).contiguous()
+                                                    for c in leaves), y0.detach(), ts)
+        if fast is None:
+            return None
+        self._extra = ()
+        stepwise = self._run(self._plan(y0, ts), y0)           # recorded by autograd: this is the result
+        rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
+        ref = stepwise.detach()
+        close = ((fast - ref).abs() <= atol + rtol * ref.abs()) | (fast.isnan() & ref.isnan()) | (fast == ref)
+        if len(book["trusted"]) >= 32:
+            book["trusted"].clear()
+        book["trusted"][key] = True if bool(close.all()) else "the sensitivity kernel's values differ from the stepwise solve"
         return stepwise
 
     def _recognised_key(self, found, chain, y0):
