@@ -170,7 +170,7 @@ def test_code_that_does_not_fit_keeps_the_stepwise_path():
     assert n == 0 and torch.equal(got, _solve(rows, 1, stepwise=True)) and _book(rows)["refused"]
 
 
-def test_gradients_and_the_opt_out_keep_the_stepwise_path():
+def test_the_opt_out_keeps_the_stepwise_path_and_gradients_flow():
     import torchsde_amd
     sde = problems.make("gbm_ito", d=D).to(DEV)
     _solve(sde, 1)

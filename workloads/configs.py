@@ -25,6 +25,12 @@ WORKLOADS = {
         problem="gbm_strat", method="midpoint", levy="none", B=32768, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=32 * 64, kid=8, trajectory=True, recognised=True, stepwise="c4_midpoint_diag_b32768_d64",
         kernel="tsde_trajectory_affine_diag<float, midpoint> (user module recognised)"),
+    # training through sdeint (autograd on, loss.backward()) on the same untouched module: the sensitivity kernel
+    # (forward-mode tangents in registers, backward() = a few reductions); stepwise beside it: c2_euler_training_stepwise
+    "c2_euler_training_default_route_b65536_d64_s1000": dict(
+        problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True, train=True,
+        kernel="tsde_trajectory_affine_diag_sens<float, euler> (user module recognised; sdeint + loss.backward())"),
     # the reference's own benchmark SDE, verbatim (benchmarks/brownian.py:131-139: f = y, g = exp(-y)), no options
     "c2_euler_expdiff_default_route_b65536_d64_s1000": dict(
         problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -16,
