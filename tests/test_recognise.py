@@ -1,0 +1,149 @@
+"""recognise.py on CPU tensors (the interpretation is plain torch: only the solvers' use of it needs the GPU): every form
+it follows evaluates to what the user's code computes, the coefficients are the live values, and everything it must
+not follow is refused with the reason."""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from torchsde_amd import recognise
+from torchsde_amd.sde import ForwardSDE
+from workloads import problems
+
+D = 6
+PHI = {"identity": lambda u: u, "exp": torch.exp, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "softplus": F.softplus,
+       "sin": torch.sin, "cos": torch.cos}
+
+
+def _value(form, y):
+    """scale * phi(rate * y + shift) + offset with None as the neutral element (what the kernels evaluate)."""
+    if form.constant():
+        c = recognise._add(form.shift, form.offset)
+        return torch.zeros_like(y) + (0.0 if c is None else c)
+    one = lambda c, n: n if c is None else c      # noqa: E731
+    return one(form.scale, 1.0) * PHI[form.phi](one(form.rate, 1.0) * y + one(form.shift, 0.0)) + one(form.offset, 0.0)
+
+
+class _M(nn.Module):
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, f, g):
+        super().__init__()
+        gen = torch.Generator().manual_seed(1)
+        self.mu = nn.Parameter(torch.randn(D, generator=gen))
+        self.sigma = nn.Parameter(torch.rand(D, generator=gen))
+        self.w = nn.Parameter(torch.randn(1, D, generator=gen))
+        self.b = torch.randn(D, generator=gen)
+        self._f, self._g = f, g
+
+    def f(self, t, y):
+        return self._f(self, t, y)
+
+    def g(self, t, y):
+        return self._g(self, t, y)
+
+
+FITS = {
+    "gbm": (lambda s, t, y: s.mu * y, lambda s, t, y: y * s.sigma, "affine_diagonal", True),
+    "reference benchmark": (lambda s, t, y: y, lambda s, t, y: torch.exp(-y), "elementwise_diagonal", True),
+    "ornstein-uhlenbeck": (lambda s, t, y: s.sigma * (s.mu - y), lambda s, t, y: s.sigma.expand_as(y), "affine_diagonal", False),
+    "latent diffusion": (lambda s, t, y: -0.5 * y + s.b, lambda s, t, y: 0.1 * torch.sigmoid(s.w * y + s.b),
+                         "elementwise_diagonal", True),
+    "ones_like": (lambda s, t, y: torch.tanh(y) * 2 - 1, lambda s, t, y: torch.ones_like(y) * s.sigma, "elementwise_diagonal", True),
+    "stratonovich gbm": (lambda s, t, y: s.mu * y - 0.5 * s.sigma ** 2 * y, lambda s, t, y: s.sigma * y, "affine_diagonal", False),
+    "softplus / sin": (lambda s, t, y: F.softplus(y / 2.0), lambda s, t, y: 0.3 - torch.sin(y), "elementwise_diagonal", False),
+    "constants": (lambda s, t, y: torch.zeros_like(y), lambda s, t, y: torch.full_like(y, 0.3), "affine_diagonal", True),
+    "negation": (lambda s, t, y: -(s.mu * y + 1.0), lambda s, t, y: (1.0 - y) * 0.5, "affine_diagonal", False),
+    "cos, alpha": (lambda s, t, y: torch.add(s.b, y, alpha=2.0), lambda s, t, y: torch.cos(y * s.mu) / 4, "elementwise_diagonal", False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FITS))
+def test_followed_forms_evaluate_to_the_users_code(name):
+    f, g, kernel, exact = FITS[name]
+    sde = _M(f, g)
+    y, t = torch.randn(16, D), torch.tensor(0.3)
+    found = recognise.recognise(ForwardSDE(sde), t, y)
+    torch.testing.assert_close(_value(found.f, y), sde.f(t, y), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(_value(found.g, y), sde.g(t, y), rtol=1e-6, atol=1e-6)
+    spec = found.spec()
+    assert spec[0] == kernel and found.exact == exact
+    assert all(c.shape == (D,) and c.is_contiguous() and c.dtype == y.dtype for c in spec[1:] if torch.is_tensor(c))
+    with torch.no_grad():                      # the next interpretation reads the new parameter values
+        sde.mu.mul_(2.0)
+        sde.sigma.add_(0.1)
+    again = recognise.recognise(ForwardSDE(sde), t, y)
+    torch.testing.assert_close(_value(again.f, y), sde.f(t, y), rtol=1e-6, atol=1e-6)
+    assert again.structure() == found.structure()
+
+
+REFUSED = {
+    "depends on t": (lambda s, t, y: torch.sin(t) * y, "depends on t"),
+    "reads t on the host": (lambda s, t, y: float(t) * y, "reads t on the host"),
+    "quadratic": (lambda s, t, y: y * y, "product of two functions"),
+    "matrix product": (lambda s, t, y: y @ torch.eye(D), "drift is not"),
+    "nested functions": (lambda s, t, y: torch.tanh(torch.exp(y)), "nested"),
+    "per-row constant": (lambda s, t, y: y * torch.ones(16, 1), "RuntimeError"),
+    "reduction over the batch": (lambda s, t, y: y - y.mean(0), "aten::mean"),
+    "in-place update": (lambda s, t, y: y.mul_(2), "in-place"),
+    "two functions summed": (lambda s, t, y: torch.tanh(y) + y, "sum of two different"),
+    "unsupported function": (lambda s, t, y: torch.relu(y), "aten::relu"),
+    "slice of the state": (lambda s, t, y: y[:, :1] * s.mu, "aten::slice"),
+    "constant with the probe's rows": (lambda s, t, y: y + torch.zeros(y.shape), "not one value per channel"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(REFUSED))
+def test_everything_else_is_refused_with_its_reason(name):
+    f, reason = REFUSED[name]
+    sde = _M(f, lambda s, t, y: y)
+    with pytest.raises(recognise.NotElementwise, match=reason):
+        recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D))
+
+
+def test_perceptron_drift_hands_back_the_users_own_parameters():
+    sde = problems.LatentDiag(8)
+    y = torch.randn(16, 8)
+    found = recognise.recognise(ForwardSDE(sde), torch.tensor(0.0), y)
+    assert found.perceptron and found.structure()[0][:2] == ("perceptron", "softplus")
+    kind, w1t, b1, w2t, b2, rate, shift, act, (diffusion, amplitude) = found.spec()
+    assert kind == "mlp_diagonal" and act == 1 and diffusion == 1 and amplitude == 0.1
+    torch.testing.assert_close(F.softplus(y @ w1t + b1) @ w2t + b2, sde.f(None, y))
+    torch.testing.assert_close(amplitude * torch.sigmoid(rate * y + shift), sde.g(None, y))
+    own = found.perceptron_parameters()
+    params = list(sde.parameters())
+    assert len(own) == 6 and all(any(o is p for p in params) for o in own)
+
+    class Residual(problems.LatentDiag):
+        def f(self, t, y):
+            return self.net(y) - y
+
+    with pytest.raises(recognise.NotElementwise, match="output of the drift network"):
+        recognise.recognise(ForwardSDE(Residual(8)), torch.tensor(0.0), y)
+    deep = problems.LatentDiag(8)
+    deep.net = nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8))
+    with pytest.raises(recognise.NotElementwise):
+        recognise.recognise(ForwardSDE(deep), torch.tensor(0.0), y)
+    mlp_with_time = problems.make("mlpdiag_ito", d=8)          # the reference's NeuralDiagonal: t is an input of the net
+    with pytest.raises(recognise.NotElementwise, match="depends on t"):
+        recognise.recognise(ForwardSDE(mlp_with_time), torch.tensor(0.0), y)
+
+
+def test_affine_leaves_are_the_users_tensors_or_nothing():
+    """Training route: coefficients must be tensors the user's code produced (a graph behind them), not folded here."""
+    gbm = problems.make("gbm_ito", d=D)
+    found = recognise.recognise(ForwardSDE(gbm), torch.tensor(0.0), torch.randn(16, D), differentiable=True)
+    leaves = found.affine_leaves()
+    assert leaves[0] is gbm.mu and leaves[2] is gbm.sigma and leaves[1].item() == 0.0 and leaves[3].item() == 0.0
+    derived = _M(lambda s, t, y: -s.mu * y, lambda s, t, y: s.sigma.exp() * y)
+    found = recognise.recognise(ForwardSDE(derived), torch.tensor(0.0), torch.randn(16, D), differentiable=True)
+    leaves = found.affine_leaves()
+    assert leaves[0].grad_fn is not None and leaves[2].grad_fn is not None          # NegBackward / ExpBackward
+    leaves[0].sum().backward()
+    assert torch.equal(derived.mu.grad, -torch.ones(D))
+    folded = problems.make("gbm_strat", d=D)
+    found = recognise.recognise(ForwardSDE(folded), torch.tensor(0.0), torch.randn(16, D), differentiable=True)
+    assert found.affine_leaves() is None                     # mu - 0.5 * sigma^2 was assembled inside the interpretation
+    nonlinear = _M(lambda s, t, y: y, lambda s, t, y: torch.exp(-y))
+    found = recognise.recognise(ForwardSDE(nonlinear), torch.tensor(0.0), torch.randn(16, D), differentiable=True)
+    assert found.affine_leaves() is None
