@@ -382,3 +382,22 @@ def test_folded_coefficients_train_on_the_stepwise_path():
         assert not type(ys.grad_fn).__name__.startswith("_TrajectoryFn")
         ys[-1].sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in sde.parameters())
+
+
+def test_the_literal_drop_in_call_without_bm_dt_or_options():
+    """`sdeint(sde, y0, ts)`: no Brownian motion, the reference's default dt = 1e-3 (not dyadic: 1001 steps in float32 over
+    [0, 1]), output times off the step grid. Same seed-free call twice cannot be compared (each call draws its own
+    entropy), so the route is checked by its launch count and the distribution of the result."""
+    import torchsde_amd
+    sde = problems.make("gbm_ito", d=D).to(DEV)
+    y0 = torch.full((4096, D), 0.1, device=DEV)
+    ts = torch.linspace(0, 1, 7, device=DEV)
+    with torch.no_grad():
+        first = torchsde_amd.sdeint(sde, y0, ts)
+        assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        ys, n = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts))
+    assert n == 1 and ys.shape == first.shape == (7, 4096, D) and torch.isfinite(ys).all()
+    # E[y_T] = y0 * exp(mu * T) for geometric Brownian motion: both routes' sample means agree with it
+    want = 0.1 * torch.exp(sde.mu.detach())
+    for out in (first, ys):
+        assert ((out[-1].mean(0) - want).abs() / want).max().item() < 0.05

@@ -147,3 +147,70 @@ def test_affine_leaves_are_the_users_tensors_or_nothing():
     nonlinear = _M(lambda s, t, y: y, lambda s, t, y: torch.exp(-y))
     found = recognise.recognise(ForwardSDE(nonlinear), torch.tensor(0.0), torch.randn(16, D), differentiable=True)
     assert found.affine_leaves() is None
+
+
+def _random_expression(rng, consts):
+    """A random chain of the operators the interpretation follows, as a Python function of y: affine steps, optionally one
+    function, more affine steps -- with per-channel tensors, (1, d) tensors, 0-d tensors and numbers as operands, on
+    either side. Returns (callable, description)."""
+    steps = []
+
+    def operand():
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            return float(rng.uniform(-1.5, 1.5))
+        return consts[int(rng.integers(0, len(consts)))]
+
+    def affine_step():
+        op = int(rng.integers(0, 8))
+        c = operand()
+        return {0: (lambda v: v * c, "v*c"), 1: (lambda v: c * v, "c*v"), 2: (lambda v: v + c, "v+c"),
+                3: (lambda v: c - v, "c-v"), 4: (lambda v: v - c, "v-c"), 5: (lambda v: -v, "-v"),
+                6: (lambda v: v / (2.0 + abs(c) if isinstance(c, float) else 2.0 + c.abs()), "v/c"),
+                7: (lambda v: torch.add(v, c, alpha=0.5), "add(alpha)")}[op]
+    for _ in range(int(rng.integers(0, 4))):
+        steps.append(affine_step())
+    if rng.random() < 0.7:
+        name = ["exp", "sigmoid", "tanh", "softplus", "sin", "cos"][int(rng.integers(0, 6))]
+        fn = {"exp": lambda v: torch.exp(0.3 * v), "softplus": F.softplus}.get(name, getattr(torch, name, None))
+        steps.append((fn, name))
+        for _ in range(int(rng.integers(0, 3))):
+            op = int(rng.integers(0, 4))
+            c = operand()
+            steps.append({0: (lambda v: v * c, "v*c"), 1: (lambda v: v + c, "v+c"), 2: (lambda v: -v, "-v"),
+                          3: (lambda v: c - v, "c-v")}[op])
+
+    def run(y):
+        v = y
+        for fn, _ in steps:
+            v = fn(v)
+        return v
+    return run, " ; ".join(d for _, d in steps)
+
+
+def test_random_expression_chains_are_followed_exactly():
+    """300 random chains: whatever the interpretation accepts evaluates (scale * phi(rate * y + shift) + offset) to what
+    the chain computes; none of these chains may be refused."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    gen = torch.Generator().manual_seed(7)
+    consts = [torch.randn(D, generator=gen), torch.rand(1, D, generator=gen) + 0.5, torch.tensor(0.7),
+              nn.Parameter(torch.randn(D, generator=gen)), torch.rand(1, generator=gen) + 0.2]
+    y = 0.5 * torch.randn(16, D, generator=gen)
+    for i in range(300):
+        f, what_f = _random_expression(rng, consts)
+        g, what_g = _random_expression(rng, consts)
+        sde = _M(lambda s, t, v, f=f: f(v), lambda s, t, v, g=g: g(v))
+        found = recognise.recognise(ForwardSDE(sde), torch.tensor(0.1), y)
+        for form, fn, what in ((found.f, f, what_f), (found.g, g, what_g)):
+            want = fn(y)
+            torch.testing.assert_close(_value(form, y), want.detach(), rtol=2e-5, atol=2e-5, msg=f"chain {i}: {what}")
+        spec = found.spec()          # ... and the kernels' coefficient vectors say the same
+        if spec[0] == "affine_diagonal":
+            torch.testing.assert_close(spec[1] * y + spec[2], f(y).detach(), rtol=2e-5, atol=2e-5)
+            torch.testing.assert_close(spec[3] * y + spec[4], g(y).detach(), rtol=2e-5, atol=2e-5)
+        else:
+            names = {v: k for k, v in __import__("torchsde_amd")._native.FN_CODES.items()}
+            for fn, code, c4 in ((f, spec[1], spec[3:7]), (g, spec[2], spec[7:11])):
+                got = c4[0] * PHI[names[code]](c4[1] * y + c4[2]) + c4[3]
+                torch.testing.assert_close(got, fn(y).detach(), rtol=2e-5, atol=2e-5)
