@@ -344,6 +344,16 @@ int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t 
                                 const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                                 const uint64_t* entropy_dev, int dtype, void* stream);
 
+/* The same solve for coefficients that depend on TIME, f(t, y) = rate(t) * y + shift(t): each of the four arrays holds one
+ * row of d values per step, `coef_step_stride` elements apart (0 = the constant-coefficient kernel above); step k uses row
+ * k, i.e. the coefficients at the step's start t_k, where torchsde's Euler and Milstein steps evaluate f and g
+ * (methods/euler.py:31, milstein.py:54). Euler and Milstein (Ito / Stratonovich) only: the other schemes evaluate at
+ * further stage times. Values only. */
+int tsde_trajectory_affine_diag_timed(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
+                                      const void* drift_shift, const void* diff_rate, const void* diff_shift,
+                                      int64_t coef_step_stride, int method, const tsde_traj_t* traj, uint64_t entropy,
+                                      uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* The same solve with path-wise sensitivities: next to every output element its derivatives with respect to its
  * own initial value and its channel's four coefficients are written to
  *   sens (n_out, TSDE_TRAJ_SENS, rows, d)   planes in the order  d/dy0, d/d drift_rate, d/d drift_shift,
@@ -402,6 +412,12 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
 int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8], int f_kind,
                               int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                               const uint64_t* entropy_dev, int dtype, void* stream);
+
+/* ... and with time-dependent coefficients (see tsde_trajectory_affine_diag_timed): eight tables of one row per step. */
+int tsde_trajectory_expr_diag_timed(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8],
+                                    int64_t coef_step_stride, int f_kind, int g_kind, int method,
+                                    const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                    const uint64_t* entropy_dev, int dtype, void* stream);
 
 /* The stochastic adjoint of the perceptron-drift SDE of tsde_trajectory_mlp_diag, Euler-Maruyama or Milstein backwards
  * in time: what `sdeint_adjoint(..., adjoint_method="euler" | "milstein")` integrates for this module

@@ -401,3 +401,73 @@ def test_the_literal_drop_in_call_without_bm_dt_or_options():
     want = 0.1 * torch.exp(sde.mu.detach())
     for out in (first, ys):
         assert ((out[-1].mean(0) - want).abs() / want).max().item() < 0.05
+
+
+class _Scheduled(nn.Module):
+    """Time enters through schedules only (the forward SDE of a variance-preserving diffusion model, mean reversion
+    towards a moving level ...): `t` is only ever broadcast."""
+    noise_type = "diagonal"
+
+    def __init__(self, sde_type="ito"):
+        super().__init__()
+        self.sde_type = sde_type
+        self.b0 = nn.Parameter(torch.tensor(0.1))
+        self.b1 = nn.Parameter(torch.tensor(2.0))
+        self.w = nn.Parameter(torch.linspace(0.5, 1.5, D))
+
+    def beta(self, t):
+        return self.b0 + t * (self.b1 - self.b0)
+
+    def f(self, t, y):
+        return -0.5 * self.beta(t) * y + torch.sin(3.0 * t) * self.w
+
+    def g(self, t, y):
+        return torch.sqrt(self.beta(t)) * 0.3 * torch.sigmoid(y * torch.exp(-t))
+
+
+class _ScheduledAffine(_Scheduled):
+    def g(self, t, y):
+        return torch.sqrt(self.beta(t)) * self.w * torch.ones_like(y)
+
+
+@pytest.mark.parametrize("make,method,sde_type", [(_Scheduled, "euler", "ito"), (_Scheduled, "milstein", "ito"),
+                                                  (_Scheduled, "milstein", "stratonovich"),
+                                                  (_ScheduledAffine, "euler", "ito"), (_ScheduledAffine, "milstein", "ito")])
+def test_time_dependent_coefficients_take_the_timed_kernels(make, method, sde_type):
+    """f(t, y), g(t, y) with t in the coefficients: interpreted once with all step times, one coefficient row per step
+    (tsde_trajectory_affine_diag_timed / _expr_diag_timed). Euler and Milstein evaluate f, g at each step's start, which
+    is what a row holds; output times off the step grid and a non-dyadic step size included."""
+    import torchsde_amd
+    sde = make(sde_type).to(DEV)
+    y0 = torch.full((B, D), 0.2, device=DEV)
+    ts = torch.tensor([0.0, 0.13, 0.5, 0.77], device=DEV)
+
+    def solve(entropy, stepwise=False):
+        bm = torchsde_amd.BrownianInterval(0.0, 0.77, size=(B, D), device=DEV, entropy=entropy)
+        options = {"hip_graph": False, "trajectory_kernel": False} if stepwise else {"hip_graph": False}
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.01, options=options)
+    assert torch.equal(solve(1), solve(1, stepwise=True))
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast, n = _launches(lambda: solve(2))
+    assert n == 1
+    torch.testing.assert_close(fast, solve(2, stepwise=True), rtol=2e-5, atol=2e-6)
+    with torch.no_grad():
+        sde.b1.mul_(0.5)                      # the schedule itself is re-read at every solve
+    torch.testing.assert_close(solve(3), solve(3, stepwise=True), rtol=2e-5, atol=2e-6)
+
+
+def test_schemes_with_further_stage_times_keep_time_dependent_sdes_stepwise():
+    import torchsde_amd
+    for method, levy, sde_type in (("srk", "space-time", "ito"), ("midpoint", "none", "stratonovich")):
+        sde = _Scheduled(sde_type).to(DEV)
+        y0 = torch.full((B, D), 0.2, device=DEV)
+        ts = torch.tensor([0.0, 0.5], device=DEV)
+        for entropy in (1, 2):
+            bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, D), device=DEV, entropy=entropy,
+                                               levy_area_approximation=levy)
+            with torch.no_grad():
+                _, n = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.01,
+                                                             options={"hip_graph": False}))
+            assert n == 0
+        assert _book(sde)["refused"] and not _book(sde)["trusted"]

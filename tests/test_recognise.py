@@ -214,3 +214,60 @@ def test_random_expression_chains_are_followed_exactly():
             for fn, code, c4 in ((f, spec[1], spec[3:7]), (g, spec[2], spec[7:11])):
                 got = c4[0] * PHI[names[code]](c4[1] * y + c4[2]) + c4[3]
                 torch.testing.assert_close(got, fn(y).detach(), rtol=2e-5, atol=2e-5)
+
+
+class _Scheduled(nn.Module):
+    """Coefficients that depend on t through a schedule (a variance-preserving diffusion's forward SDE, Hull-White-style
+    mean reversion ...): t only ever broadcasts."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        super().__init__()
+        self.b0 = nn.Parameter(torch.tensor(0.1))
+        self.b1 = nn.Parameter(torch.tensor(2.0))
+        self.w = nn.Parameter(torch.rand(D) + 0.5)
+
+    def beta(self, t):
+        return self.b0 + t * (self.b1 - self.b0)
+
+    def f(self, t, y):
+        return -0.5 * self.beta(t) * y + torch.sin(t) * self.w
+
+    def g(self, t, y):
+        return torch.sqrt(self.beta(t)) * 0.3 * torch.sigmoid(y * torch.exp(-t))
+
+
+def test_time_dependent_coefficients_come_back_as_one_row_per_step():
+    sde = _Scheduled()
+    y = torch.randn(16, D)
+    with pytest.raises(recognise.DependsOnTime):
+        recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), y)
+    times = torch.linspace(0, 1, 11)[:-1]
+    found = recognise.recognise(ForwardSDE(sde), torch.tensor(0.0), y, times=times)
+    assert found.timed and found.affine_leaves() is None
+    kind, fk, gk, *coefs = found.spec()
+    assert kind == "elementwise_diagonal" and all(c.shape == (10, D) and c.is_contiguous() for c in coefs)
+    names = {v: k for k, v in __import__("torchsde_amd")._native.FN_CODES.items()}
+    for k in (0, 4, 9):
+        f = coefs[0][k] * PHI[names[fk]](coefs[1][k] * y + coefs[2][k]) + coefs[3][k]
+        g = coefs[4][k] * PHI[names[gk]](coefs[5][k] * y + coefs[6][k]) + coefs[7][k]
+        torch.testing.assert_close(f, sde.f(times[k], y), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(g, sde.g(times[k], y), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,f", [
+    ("branch on t", lambda s, t, y: y if t > 0.5 else -y),
+    ("t on the host", lambda s, t, y: float(t) * y),
+    ("t reshaped", lambda s, t, y: t.reshape(-1)[:1] * y),
+    ("t concatenated with the state", lambda s, t, y: torch.cat([t.expand(y.shape[0], 1), y], 1)[:, 1:]),
+    ("reduction over t", lambda s, t, y: t.sum() * y),
+    ("t squeezed", lambda s, t, y: t.squeeze() * y),
+])
+def test_other_uses_of_t_end_the_interpretation(name, f):
+    sde = _M(f, lambda s, t, y: y)
+    times = torch.linspace(0, 1, 11)[:-1]
+    with pytest.raises(recognise.NotElementwise):
+        try:
+            recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D))
+        except recognise.DependsOnTime:
+            recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D), times=times)

@@ -122,6 +122,10 @@ SIGNATURES = {
     "tsde_error_norm": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_dbl, _c_dbl, _c_dbl, _c_int, _c_ptr]),
     "tsde_trajectory_affine_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
                                              ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_trajectory_affine_diag_timed": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                                   _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_trajectory_expr_diag_timed": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr * 8, _c_i64, _c_int, _c_int, _c_int,
+                                                 ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_trajectory_affine_diag_sens": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr,
                                                   _c_ptr, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                                   _c_ptr]),

@@ -454,9 +454,13 @@ int tsde_merge_halves(void* W, void* U, const void* Wa, const void* Ha, const vo
 
 static int trajectory_affine_diag(const char* where, void* ys, void* sens, const void* y0, int64_t rows, int64_t d,
                                   const void* drift_rate, const void* drift_shift, const void* diff_rate,
-                                  const void* diff_shift, int method, const tsde_traj_t* traj, uint64_t entropy,
-                                  uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+                                  const void* diff_shift, int64_t coef_step_stride, int method, const tsde_traj_t* traj,
+                                  uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                                  void* stream) {
   if (!ys || !y0 || !drift_rate || !drift_shift || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
+  if (coef_step_stride != 0 && coef_step_stride < d) return bad_arg(where, "coef_step_stride must be 0 or >= d");
+  if (coef_step_stride != 0 && (sens || method > TSDE_TRAJ_MILSTEIN_STRAT))
+    return bad_arg(where, "per-step coefficients: Euler and Milstein, values only");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
   if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
@@ -467,9 +471,10 @@ static int trajectory_affine_diag(const char* where, void* ys, void* sens, const
   ProfScope p(TSDE_KID_TRAJECTORY, s);
   TSDE_DISPATCH(dtype, where,
                 tsde::launch_trajectory_affine_diag<float>(ys, sens, y0, rows, d, drift_rate, drift_shift, diff_rate,
-                                                           diff_shift, method, traj, key, entropy_dev, s),
+                                                           diff_shift, coef_step_stride, method, traj, key, entropy_dev, s),
                 tsde::launch_trajectory_affine_diag<double>(ys, sens, y0, rows, d, drift_rate, drift_shift, diff_rate,
-                                                            diff_shift, method, traj, key, entropy_dev, s));
+                                                            diff_shift, coef_step_stride, method, traj, key, entropy_dev,
+                                                            s));
 }
 
 int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
@@ -477,7 +482,16 @@ int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t 
                                 const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                                 const uint64_t* entropy_dev, int dtype, void* stream) {
   return trajectory_affine_diag("tsde_trajectory_affine_diag", ys, nullptr, y0, rows, d, drift_rate, drift_shift,
-                                diff_rate, diff_shift, method, traj, entropy, elem0, entropy_dev, dtype, stream);
+                                diff_rate, diff_shift, 0, method, traj, entropy, elem0, entropy_dev, dtype, stream);
+}
+
+int tsde_trajectory_affine_diag_timed(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
+                                      const void* drift_shift, const void* diff_rate, const void* diff_shift,
+                                      int64_t coef_step_stride, int method, const tsde_traj_t* traj, uint64_t entropy,
+                                      uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+  return trajectory_affine_diag("tsde_trajectory_affine_diag_timed", ys, nullptr, y0, rows, d, drift_rate, drift_shift,
+                                diff_rate, diff_shift, coef_step_stride, method, traj, entropy, elem0, entropy_dev, dtype,
+                                stream);
 }
 
 int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64_t rows, int64_t d,
@@ -486,7 +500,7 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
                                      uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
   if (!sens) return bad_arg("tsde_trajectory_affine_diag_sens", "null argument");
   return trajectory_affine_diag("tsde_trajectory_affine_diag_sens", ys, sens, y0, rows, d, drift_rate, drift_shift,
-                                diff_rate, diff_shift, method, traj, entropy, elem0, entropy_dev, dtype, stream);
+                                diff_rate, diff_shift, 0, method, traj, entropy, elem0, entropy_dev, dtype, stream);
 }
 
 int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t hidden, const void* w1,
@@ -522,8 +536,18 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
 int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8], int f_kind,
                               int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                               const uint64_t* entropy_dev, int dtype, void* stream) {
-  const char* where = "tsde_trajectory_expr_diag";
+  return tsde_trajectory_expr_diag_timed(ys, y0, rows, d, coef, 0, f_kind, g_kind, method, traj, entropy, elem0,
+                                         entropy_dev, dtype, stream);
+}
+
+int tsde_trajectory_expr_diag_timed(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8],
+                                    int64_t coef_step_stride, int f_kind, int g_kind, int method,
+                                    const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                    const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = coef_step_stride ? "tsde_trajectory_expr_diag_timed" : "tsde_trajectory_expr_diag";
   if (!ys || !y0 || !coef || !traj) return bad_arg(where, "null argument");
+  if (coef_step_stride != 0 && (coef_step_stride < d || method > TSDE_TRAJ_MILSTEIN_STRAT))
+    return bad_arg(where, "per-step coefficients: stride >= d, Euler and Milstein only");
   for (int c = 0; c < 8; ++c)
     if (!coef[c]) return bad_arg(where, "null coefficient array");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
@@ -537,10 +561,10 @@ int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d,
   const tsde::NoiseKey key = make_key(entropy, elem0);
   ProfScope p(TSDE_KID_TRAJECTORY, s);
   TSDE_DISPATCH(dtype, where,
-                tsde::launch_trajectory_expr_diag<float>(ys, y0, rows, d, coef, f_kind, g_kind, method, traj, key,
-                                                         entropy_dev, s),
-                tsde::launch_trajectory_expr_diag<double>(ys, y0, rows, d, coef, f_kind, g_kind, method, traj, key,
-                                                          entropy_dev, s));
+                tsde::launch_trajectory_expr_diag<float>(ys, y0, rows, d, coef, coef_step_stride, f_kind, g_kind, method,
+                                                         traj, key, entropy_dev, s),
+                tsde::launch_trajectory_expr_diag<double>(ys, y0, rows, d, coef, coef_step_stride, f_kind, g_kind, method,
+                                                          traj, key, entropy_dev, s));
 }
 
 int tsde_adjoint_mlp_diag(void* y, void* a, void* stash_a, void* stash_hid, void* stash_delta, void* stash_y,

@@ -108,7 +108,8 @@ struct TrajArgs {
   T* ys;                    // (n_out, n) outputs after t0
   T* sens;                  // (n_out, kSens, n) sensitivities of those outputs, or nullptr
   const T* y0;              // (n)
-  const T *a, *b, *c, *e;   // (d) per-channel coefficients
+  const T *a, *b, *c, *e;   // (d) per-channel coefficients -- or (n_steps, d) tables when `cstride` = d (TIMED kernels)
+  int64_t cstride;          // elements between the coefficient rows of consecutive steps; 0: the same at every step
   const T* rows;            // (n_steps, 8): dt, dt/2, 1/dt, sqrt(dt), sqrt(h), sqrt(h/12), h, 0
   const uint32_t* cells;    // (n_steps)
   const int32_t* out_step;  // (n_out) ascending: output j is due once `out_step[j]` steps are complete
@@ -236,7 +237,10 @@ TSDE_D T primal(const Dual<T>& x) { return x.v; }
 // W = 4: a lane owns one 16-byte group (needs d % 4 == 0 so the group stays inside one row).
 // W = 1: a lane owns one element (any d; also used for small problems, where it exposes 4x the lanes).
 // SENS : carry the kSens path-wise sensitivities of every element and write them next to the outputs.
-template <typename T, int METHOD, int W, bool SENS>
+// TIMED: the coefficients are functions of time given as one row per step (f(t, y) = a(t) * y + b(t), evaluated at the
+//        step's start like the stepwise Euler / Milstein loop does: euler.py:31, milstein.py:54): re-read, through the
+//        L2, at the top of every step. A separate instantiation, so the constant-coefficient kernels are untouched.
+template <typename T, int METHOD, int W, bool SENS, bool TIMED = false>
 __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p) {
   constexpr bool kNeedU = METHOD == kSrk;
   using S = typename std::conditional<SENS, Dual<T>, T>::type;
@@ -248,8 +252,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
   const int64_t i = lane * W;
   if (i >= p.n) return;
   const int64_t col = i % p.d;
-  const Pack<T, W> a = load<T, W>(p.a, col), b = load<T, W>(p.b, col), c = load<T, W>(p.c, col),
-                   e = load<T, W>(p.e, col);
+  Pack<T, W> a = load<T, W>(p.a, col), b = load<T, W>(p.b, col), c = load<T, W>(p.c, col), e = load<T, W>(p.e, col);
   const Pack<T, W> y_init = load<T, W>(p.y0, i);
   S y[W];
 #pragma unroll
@@ -269,6 +272,15 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
     const uint32_t cell = p.cells[k];
+    if constexpr (TIMED) {
+      if (k > 0) {
+        const int64_t at = (int64_t)k * p.cstride + col;
+        a = load<T, W>(p.a, at);
+        b = load<T, W>(p.b, at);
+        c = load<T, W>(p.c, at);
+        e = load<T, W>(p.e, at);
+      }
+    }
     Pack<T, W> w, u;
     if constexpr (W == 4) {
       T z[4];
@@ -329,7 +341,29 @@ static hipError_t launch_traj_ms(const TrajArgs<T>& p, bool vec, hipStream_t s) 
 }
 
 template <typename T, int METHOD>
+static hipError_t launch_traj_timed(const TrajArgs<T>& p, bool vec, hipStream_t s) {
+  if (vec) {
+    const int64_t lanes = p.n >> 2;
+    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 4, false, true>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((trajectory_kernel<T, METHOD, 1, false, true>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+template <typename T, int METHOD>
 static hipError_t launch_traj_m(const TrajArgs<T>& p, bool vec, hipStream_t s) {
+  if (p.cstride != 0) {
+    // coefficient tables: the schemes that evaluate f, g at the step's start only, values only
+    if constexpr (METHOD == kEuler || METHOD == kMilIto || METHOD == kMilStrat) {
+      if (p.sens) return hipErrorNotSupported;
+      return launch_traj_timed<T, METHOD>(p, vec, s);
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
   return p.sens ? launch_traj_ms<T, METHOD, true>(p, vec, s) : launch_traj_ms<T, METHOD, false>(p, vec, s);
 }
 
@@ -339,9 +373,10 @@ constexpr int64_t kTrajVecMinGroups = 256 * 8 * 64;
 
 template <typename T>
 hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const void* a,
-                                         const void* b, const void* c, const void* e, int method,
+                                         const void* b, const void* c, const void* e, int64_t cstride, int method,
                                          const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
   TrajArgs<T> p;
+  p.cstride = cstride;
   p.ys = (T*)ys;
   p.sens = (T*)sens;
   p.y0 = (const T*)y0;
@@ -362,7 +397,7 @@ hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, i
   if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
   const bool can_vec = (d % 4 == 0) && (key.elem0 % 4 == 0) && aligned16(ys) && aligned16(y0) && aligned16(a) &&
                        aligned16(b) && aligned16(c) && aligned16(e) && ((p.n * sizeof(T)) % 16 == 0) &&
-                       (!sens || aligned16(sens));
+                       (!sens || aligned16(sens)) && (cstride % 4 == 0);
   const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
   switch (method) {
     case kEuler: return launch_traj_m<T, kEuler>(p, vec, s);
@@ -379,6 +414,7 @@ struct ExprArgs {
   T* ys;                    // (n_out, n) outputs after t0
   const T* y0;              // (n)
   const T* coef[8];         // (d) each: drift scale, rate, shift, offset; diffusion scale, rate, shift, offset
+  int64_t cstride;          // as TrajArgs::cstride: (n_steps, d) tables for coefficients that depend on t
   int32_t f_kind, g_kind;
   const T* rows;
   const uint32_t* cells;
@@ -391,7 +427,7 @@ struct ExprArgs {
 };
 
 // The affine trajectory kernel's loop with the expression model in place of the affine one (values only).
-template <typename T, int METHOD, int W>
+template <typename T, int METHOD, int W, bool TIMED = false>
 __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<T> p) {
   constexpr bool kNeedU = METHOD == kSrk;
   const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -417,6 +453,13 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
     const uint32_t cell = p.cells[k];
+    if constexpr (TIMED) {
+      if (k > 0) {
+        const int64_t at = (int64_t)k * p.cstride + col;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cf[c] = load<T, W>(p.coef[c], at);
+      }
+    }
     Pack<T, W> w, u;
     if constexpr (W == 4) {
       T z[4];
@@ -455,6 +498,21 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
 
 template <typename T, int METHOD>
 static hipError_t launch_expr_m(const ExprArgs<T>& p, bool vec, hipStream_t s) {
+  if (p.cstride != 0) {
+    if constexpr (METHOD == kEuler || METHOD == kMilIto || METHOD == kMilStrat) {
+      if (vec) {
+        const int64_t lanes = p.n >> 2;
+        hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 4, true>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, p);
+      } else {
+        hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 1, true>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, p);
+      }
+      return hipGetLastError();
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
   if (vec) {
     const int64_t lanes = p.n >> 2;
     hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 4>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
@@ -468,9 +526,10 @@ static hipError_t launch_expr_m(const ExprArgs<T>& p, bool vec, hipStream_t s) {
 
 template <typename T>
 hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8],
-                                       int f_kind, int g_kind, int method, const tsde_traj_t* tr, NoiseKey key,
-                                       const uint64_t* key_dev, hipStream_t s) {
+                                       int64_t cstride, int f_kind, int g_kind, int method, const tsde_traj_t* tr,
+                                       NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
   ExprArgs<T> p;
+  p.cstride = cstride;
   p.ys = (T*)ys;
   p.y0 = (const T*)y0;
   bool aligned = aligned16(ys) && aligned16(y0);
@@ -491,7 +550,8 @@ hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, i
   p.key = key;
   p.key_dev = key_dev;
   if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
-  const bool can_vec = (d % 4 == 0) && (key.elem0 % 4 == 0) && aligned && ((p.n * sizeof(T)) % 16 == 0);
+  const bool can_vec = (d % 4 == 0) && (key.elem0 % 4 == 0) && aligned && ((p.n * sizeof(T)) % 16 == 0) &&
+                       (cstride % 4 == 0);
   const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
   switch (method) {
     case kEuler: return launch_expr_m<T, kEuler>(p, vec, s);
@@ -503,18 +563,18 @@ hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, i
   }
 }
 
-template hipError_t launch_trajectory_expr_diag<float>(void*, const void*, int64_t, int64_t, const void* const[8], int,
-                                                       int, int, const tsde_traj_t*, NoiseKey, const uint64_t*,
-                                                       hipStream_t);
-template hipError_t launch_trajectory_expr_diag<double>(void*, const void*, int64_t, int64_t, const void* const[8], int,
-                                                        int, int, const tsde_traj_t*, NoiseKey, const uint64_t*,
-                                                        hipStream_t);
+template hipError_t launch_trajectory_expr_diag<float>(void*, const void*, int64_t, int64_t, const void* const[8],
+                                                       int64_t, int, int, int, const tsde_traj_t*, NoiseKey,
+                                                       const uint64_t*, hipStream_t);
+template hipError_t launch_trajectory_expr_diag<double>(void*, const void*, int64_t, int64_t, const void* const[8],
+                                                        int64_t, int, int, int, const tsde_traj_t*, NoiseKey,
+                                                        const uint64_t*, hipStream_t);
 
 template hipError_t launch_trajectory_affine_diag<float>(void*, void*, const void*, int64_t, int64_t, const void*,
-                                                         const void*, const void*, const void*, int,
+                                                         const void*, const void*, const void*, int64_t, int,
                                                          const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
 template hipError_t launch_trajectory_affine_diag<double>(void*, void*, const void*, int64_t, int64_t, const void*,
-                                                          const void*, const void*, const void*, int,
+                                                          const void*, const void*, const void*, int64_t, int,
                                                           const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
 
 }  // namespace tsde

@@ -116,12 +116,12 @@ hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha,
 // trajectory.hip
 template <typename T>
 hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const void* a,
-                                         const void* b, const void* c, const void* e, int method,
+                                         const void* b, const void* c, const void* e, int64_t cstride, int method,
                                          const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 template <typename T>
 hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8],
-                                       int f_kind, int g_kind, int method, const tsde_traj_t* tr, NoiseKey key,
-                                       const uint64_t* key_dev, hipStream_t s);
+                                       int64_t cstride, int f_kind, int g_kind, int method, const tsde_traj_t* tr,
+                                       NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 // mlp_trajectory.hip
 hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t h, const void* W1,
                                       const void* b1, const void* W2, const void* b2, const void* c, const void* e,

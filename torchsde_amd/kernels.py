@@ -618,6 +618,20 @@ class TrajectorySchedule:
                                          [(0.0, 1.0)] * n, self.device, self.dtype)
 
 
+def _coefficient_tables(coefs, d, schedule, dtype):
+    """False: every coefficient is a contiguous (d,) tensor (the same at every step). True: every one is a contiguous
+    (n_steps, d) table -- one row per step, for drift / diffusion coefficients that depend on t (the `_timed` entry
+    points). Anything else is an error."""
+    shapes = {tuple(c.shape) for c in coefs}
+    if any(c.dtype != dtype or not c.is_contiguous() for c in coefs):
+        raise ValueError("coefficients must be contiguous tensors in the state dtype")
+    if shapes == {(d,)}:
+        return False
+    if shapes == {(schedule.n_steps, d)}:
+        return True
+    raise ValueError(f"coefficients must all be (d,) tensors or all (n_steps, d) tables, got {sorted(shapes)}")
+
+
 def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm, sens=None):
     """All steps of an affine diagonal SDE in one launch (``tsde_trajectory_affine_diag``); writes ys[j] for the
     schedule's outputs. `bm` is the native BrownianInterval whose generated cells drive the steps. With
@@ -625,9 +639,10 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
     (``tsde_trajectory_affine_diag_sens``)."""
     _native.require_device(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, sens)
     rows, d = y0.shape
-    for c in (drift_rate, drift_shift, diff_rate, diff_shift):
-        if c.dtype != y0.dtype or c.numel() != d or not c.is_contiguous():
-            raise ValueError("coefficients must be contiguous (d,) tensors in the state dtype")
+    coefs = (drift_rate, drift_shift, diff_rate, diff_shift)
+    timed = _coefficient_tables(coefs, d, schedule, y0.dtype)
+    if timed and sens is not None:
+        raise ValueError("per-step coefficient tables: values only")
     if schedule.dtype != y0.dtype or ys.dtype != y0.dtype:
         raise ValueError("schedule / output dtype must equal the state dtype")
     if not (ys.is_contiguous() and y0.is_contiguous()) or ys.shape != (schedule.n_out, rows, d):
@@ -637,7 +652,9 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
     tail = (rows, d, drift_rate.data_ptr(), drift_shift.data_ptr(), diff_rate.data_ptr(), diff_shift.data_ptr(),
             int(method), schedule.struct(), bm._key, bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
             dt_code, stream)
-    if sens is None:
+    if timed:
+        code = lib.tsde_trajectory_affine_diag_timed(ys.data_ptr(), y0.data_ptr(), *tail[:6], d, *tail[6:])
+    elif sens is None:
         code = lib.tsde_trajectory_affine_diag(ys.data_ptr(), y0.data_ptr(), *tail)
     else:
         if (sens.dtype != y0.dtype or not sens.is_contiguous()
@@ -653,8 +670,9 @@ def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
     (``tsde_trajectory_expr_diag``); writes ys[j] for the schedule's outputs."""
     _native.require_device(ys, y0, *coefs)
     rows, d = y0.shape
-    if len(coefs) != 8 or any(c.dtype != y0.dtype or c.numel() != d or not c.is_contiguous() for c in coefs):
-        raise ValueError("coefficients must be eight contiguous (d,) tensors in the state dtype")
+    if len(coefs) != 8:
+        raise ValueError("eight coefficient tensors are needed")
+    timed = _coefficient_tables(coefs, d, schedule, y0.dtype)
     if schedule.dtype != y0.dtype or ys.dtype != y0.dtype:
         raise ValueError("schedule / output dtype must equal the state dtype")
     if not (ys.is_contiguous() and y0.is_contiguous()) or ys.shape != (schedule.n_out, rows, d):
@@ -662,9 +680,9 @@ def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
     lib, dt_code, stream = _launch_env(y0)
     entropy_dev = bm._entropy_dev
     arr = (ctypes.c_void_p * 8)(*[c.data_ptr() for c in coefs])
-    code = lib.tsde_trajectory_expr_diag(ys.data_ptr(), y0.data_ptr(), rows, d, arr, int(f_kind), int(g_kind),
-                                         int(method), schedule.struct(), bm._key, bm._elem0,
-                                         None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    code = lib.tsde_trajectory_expr_diag_timed(ys.data_ptr(), y0.data_ptr(), rows, d, arr, d if timed else 0, int(f_kind),
+                                               int(g_kind), int(method), schedule.struct(), bm._key, bm._elem0,
+                                               None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
     _native.check(code, "tsde_trajectory_expr_diag")
     return ys
 

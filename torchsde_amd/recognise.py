@@ -18,6 +18,13 @@ are computed from the LIVE parameter values of this very solve: an optimiser ste
 are seen because the user's code has just run. Anything else -- a value derived from ``t``, an operator outside the
 small elementwise table, a reshape of the state, an in-place update of it, a per-row constant, `float(t)` -- ends the interpretation and the solve takes the stepwise path, as before.
 
+Time. With t a 0-d tensor any arithmetic on t ends the interpretation (`DependsOnTime`). For the schemes that evaluate f
+and g at the start of a step only (Euler, Milstein) the caller then interprets once more with t = the (K, 1, 1) tensor of
+ALL step times: code that only ever broadcasts t (`beta(t) * y`, `torch.sqrt(self.b0 + t * self.b1)`) runs unchanged,
+values derived from the state become (K, rows, d), coefficients (K, 1, 1) or (K, 1, d) -- one row per step -- and the
+`_timed` trajectory kernels read row k at step k. Code that does anything else with t (`float(t)`, `if t > 0.5`, `cat`
+with the state, an index) fails on the (K, 1, 1) tensor by itself or leaves these shapes, and the solve stays stepwise.
+
 A second form is followed the same way: a drift that is a two-layer perceptron of the state shared by the batch,
 ``lin2(act(lin1(y)))`` with ``act`` tanh or softplus -- ``nn.Sequential(nn.Linear, nn.Softplus, nn.Linear)`` as in the
 reference's latent-SDE examples (examples/latent_sde_lorenz.py:122-128) -- with an affine or ``scale * sigmoid`` diagonal
@@ -39,6 +46,11 @@ ENABLED = _os.environ.get("TSDE_RECOGNISE", "1").strip().lower() not in ("0", "f
 
 class NotElementwise(Exception):
     """The code is not (recognisably) of the per-channel form; the message says what stopped the interpretation."""
+
+
+class DependsOnTime(NotElementwise):
+    """Raised by the interpretation with a scalar t when drift or diffusion use t in their arithmetic: the caller may
+    interpret again with ALL step times at once (`recognise(..., times=...)`), which yields one coefficient row per step."""
 
 
 class _Form:
@@ -104,9 +116,9 @@ def _times(a, c):
 
 
 class _Interpreter(TorchDispatchMode):
-    def __init__(self, y, t, rows, d):
+    def __init__(self, y, t, rows, d, steps=None):
         super().__init__()
-        self.rows, self.d = rows, d
+        self.rows, self.d, self.steps = rows, d, steps        # steps = K: t is the (K, 1, 1) tensor of all step times
         self.forms = {id(y): _Form()}
         self.time = {id(t)}
         self.keep = [y, t]              # every tracked tensor stays alive: ids are not reused during the run
@@ -120,8 +132,15 @@ class _Interpreter(TorchDispatchMode):
     def form_of(self, x):
         return self.forms.get(id(x)) if torch.is_tensor(x) else None
 
+    def state_shaped(self, tensor):
+        shape = tuple(tensor.shape)
+        return shape == (self.rows, self.d) or (self.steps is not None and shape == (self.steps, self.rows, self.d))
+
+    def time_shaped(self, tensor):
+        return self.steps is not None and tuple(tensor.shape) in ((self.steps, 1, 1), (self.steps, 1, self.d))
+
     def track(self, tensor, form):
-        if tuple(tensor.shape) != (self.rows, self.d):
+        if not self.state_shaped(tensor):
             raise NotElementwise(f"a value derived from the state has shape {tuple(tensor.shape)}")
         self.forms[id(tensor)] = form
         self.keep.append(tensor)
@@ -134,7 +153,11 @@ class _Interpreter(TorchDispatchMode):
         if not torch.is_tensor(c):
             raise NotElementwise(f"an operand of type {type(c).__name__}")
         if id(c) in self.time:
-            raise NotElementwise("the coefficients depend on t")
+            if self.steps is None:
+                raise DependsOnTime("drift or diffusion depends on t")
+            if not self.time_shaped(c):
+                raise NotElementwise(f"a function of t of shape {tuple(c.shape)} is not one value per step and channel")
+            return c
         shape = tuple(c.shape)
         if shape not in ((), (1,), (self.d,), (1, self.d), (1, 1)):
             raise NotElementwise(f"an operand of shape {shape} is not one value per channel")
@@ -291,18 +314,25 @@ class _Interpreter(TorchDispatchMode):
             if id(a) not in self.seen:
                 self.seen.add(id(a))
                 self.keep.append(a)
-        if any(id(a) in self.time for a in involved):
+        timed = any(id(a) in self.time for a in involved)
+        if timed and not any(id(a) in self.forms or id(a) in self.hidden for a in involved):
+            # arithmetic among t and constants: executes; its results are functions of t
             name = func._schema.name
             if name in ("aten::_local_scalar_dense", "aten::item"):
                 raise NotElementwise("the code reads t on the host")
             out = func(*args, **kwargs)
             for o in (out if isinstance(out, (list, tuple)) else (out,)):
                 if torch.is_tensor(o):
+                    if self.steps is not None and not self.time_shaped(o):
+                        raise NotElementwise(f"{name} makes a function of t of shape {tuple(o.shape)}: not one value per "
+                                             "step and channel")
                     self.time.add(id(o))
                     self.keep.append(o)
-            if any(id(a) in self.forms for a in involved):
-                raise NotElementwise("drift or diffusion depends on t")
             return out
+        if timed and self.steps is None:
+            raise DependsOnTime("drift or diffusion depends on t")
+        if timed and any(id(a) in self.hidden for a in involved):
+            raise NotElementwise("the drift network depends on t")
         if any(id(a) in self.hidden for a in involved):
             return self.perceptron_step(func, args, kwargs)
         tracked = [a for a in involved if id(a) in self.forms]
@@ -313,7 +343,8 @@ class _Interpreter(TorchDispatchMode):
                 self.transposed[id(out)] = args[0]
                 self.keep.append(out)
             # a y-independent value stretched over the probe's rows (`sigma.expand_as(y)`, `sigma.expand(B, d)`)
-            if func._schema.name == "aten::expand" and torch.is_tensor(out) and tuple(out.shape) == (self.rows, self.d):
+            if func._schema.name == "aten::expand" and torch.is_tensor(out) and tuple(out.shape) == (self.rows, self.d) \
+                    and id(args[0]) not in self.time:
                 src = args[0]
                 if src.dim() <= 2 and (src.dim() < 2 or src.shape[0] == 1):
                     return self.track(out, _Form(rate=ZERO, shift=self.coefficient(src if src.dim() < 2 else src[0])))
@@ -332,14 +363,14 @@ class _Interpreter(TorchDispatchMode):
                 return self.track(out, x)
             raise NotElementwise(f"{name} applied to the output of the drift network")
         if name in self._LIKE or name in ("full_like", "empty_like", "new_zeros", "new_ones", "new_full", "new_empty"):
-            if name in self._LIKE and tuple(out.shape) == (self.rows, self.d) and out.dtype == args[0].dtype:
+            if name in self._LIKE and self.state_shaped(out) and out.dtype == args[0].dtype:
                 return self.track(out, _Form(rate=ZERO, shift=self._LIKE[name] or None))
-            if name == "full_like" and tuple(out.shape) == (self.rows, self.d) and out.dtype == args[0].dtype \
+            if name == "full_like" and self.state_shaped(out) and out.dtype == args[0].dtype \
                     and isinstance(args[1], (int, float)):
                 return self.track(out, _Form(rate=ZERO, shift=args[1]))
             raise NotElementwise(f"{name} of the state")
         if name in self._SAME:
-            if x is None or not torch.is_tensor(out) or tuple(out.shape) != (self.rows, self.d) \
+            if x is None or not torch.is_tensor(out) or out.shape != args[0].shape \
                     or out.dtype != args[0].dtype or out.device != args[0].device:
                 raise NotElementwise(f"{name} changes the shape, dtype or device of a value derived from the state")
             return self.track(out, x)
@@ -409,7 +440,8 @@ class Recognised:
             if isinstance(form, _Perceptron):
                 return ("perceptron", form.act, tuple(form.w1.shape), form.b1 is None, form.b2 is None)
             return (form.phi, form.constant()) + tuple(
-                None if c is None else "number" if isinstance(c, (int, float)) else "tensor"
+                None if c is None else "number" if isinstance(c, (int, float))
+                else "table" if torch.is_tensor(c) and c.dim() == 3 else "tensor"
                 for c in (form.scale, form.rate, form.shift, form.offset))
         return shape(self.f), shape(self.g)
 
@@ -423,7 +455,22 @@ class Recognised:
             raise NotElementwise(f"a 0-d coefficient of dtype {c.dtype}")
         if c.dtype != self.dtype or c.device != self.device:      # a 0-d tensor takes part like a Python number
             c = c.to(device=self.device, dtype=self.dtype)
+        if c.dim() == 3:            # (K, 1, 1) or (K, 1, d): a function of t, one row per step
+            return c.detach().reshape(c.shape[0], -1).expand(c.shape[0], self.d).contiguous()
         return c.detach().reshape(-1).expand(self.d).contiguous()
+
+    @staticmethod
+    def _as_tables(vectors):
+        """If any coefficient is a (K, d) table, every one becomes one (the `_timed` kernels take all or none)."""
+        steps = [v.shape[0] for v in vectors if v.dim() == 2]
+        if not steps:
+            return vectors
+        return tuple(v if v.dim() == 2 else v.expand(steps[0], v.shape[0]).contiguous() for v in vectors)
+
+    @property
+    def timed(self):
+        forms = [self.g] if self.perceptron else [self.f, self.g]
+        return any(torch.is_tensor(c) and c.dim() == 3 for v in forms for c in (v.scale, v.rate, v.shift, v.offset))
 
     def _four(self, form):
         if form.constant():         # the value is `shift (+ offset)`: rate 0, identity
@@ -440,6 +487,8 @@ class Recognised:
         g = self.g
         if isinstance(g, _Perceptron):
             raise NotElementwise("a perceptron diffusion")
+        if self.timed:
+            raise NotElementwise("a time-dependent diffusion beside a perceptron drift")
         if g.constant():
             return _native.DIFF_AFFINE, 1.0, 0.0, _add(g.shift, g.offset)
         if g.phi == "identity" and g.scale is None and g.offset is None:
@@ -495,8 +544,8 @@ class Recognised:
         seen as an operand of their code, so a parameter or something autograd saw them compute -- of shape (d,) or one
         element: a coefficient folded inside the interpretation (`mu - 0.5 * sigma ** 2` assembled from two terms) has
         no graph behind it."""
-        if self.perceptron or not all(v.phi == "identity" and v.scale is None and v.offset is None and not v.constant()
-                                      for v in (self.f, self.g)):
+        if self.perceptron or self.timed or not all(
+                v.phi == "identity" and v.scale is None and v.offset is None and not v.constant() for v in (self.f, self.g)):
             return None
         out = []
         for c, neutral in ((self.f.rate, 1.0), (self.f.shift, 0.0), (self.g.rate, 1.0), (self.g.shift, 0.0)):
@@ -519,8 +568,8 @@ class Recognised:
         f4, g4 = self._four(self.f), self._four(self.g)
         plain = all(v.phi == "identity" and v.scale is None and v.offset is None for v in (self.f, self.g))
         if plain:
-            return ("affine_diagonal", f4[1], f4[2], g4[1], g4[2])
-        return ("elementwise_diagonal", _native.FN_CODES[self.f.phi], _native.FN_CODES[self.g.phi]) + f4 + g4
+            return ("affine_diagonal",) + self._as_tables((f4[1], f4[2], g4[1], g4[2]))
+        return ("elementwise_diagonal", _native.FN_CODES[self.f.phi], _native.FN_CODES[self.g.phi]) + self._as_tables(f4 + g4)
 
 
 _VECTORS = {}
@@ -536,15 +585,17 @@ def _constant_vector(value, d, dtype, device):
     return hit
 
 
-def recognise(sde, t, y0, differentiable=False):
+def recognise(sde, t, y0, differentiable=False, times=None):
     """Interpret ``sde.f_and_g`` (a ForwardSDE: whichever of f / g / f_and_g the user defined) on a probe of the state's
     width; returns `Recognised` or raises `NotElementwise`. Launches a handful of tiny kernels, never synchronises."""
     rows = 2 if y0.shape[0] != 2 else 3         # a per-ROW constant of the real batch cannot broadcast against the probe
     d = y0.shape[1]
     probe = y0.detach()[:1].expand(rows, d).clone() if y0.shape[0] > 0 else torch.zeros(rows, d, dtype=y0.dtype,
                                                                                        device=y0.device)
-    t_probe = t.detach().clone()
-    interp = _Interpreter(probe, t_probe, rows, d)
+    # `times`: the (K,) tensor of every step's start time -> t is handed to the user's code as a (K, 1, 1) tensor and
+    # coefficients that depend on t come back as one row per step (module docstring)
+    t_probe = t.detach().clone() if times is None else times.detach().reshape(-1, 1, 1).clone()
+    interp = _Interpreter(probe, t_probe, rows, d, steps=None if times is None else int(times.numel()))
     try:
         # `differentiable`: autograd watches what the user's code computes from its parameters on the way (`-self.theta`,
         # `self.sigma ** 2`), so that a coefficient which is such a tensor carries its graph (see `affine_leaves`)
@@ -552,7 +603,7 @@ def recognise(sde, t, y0, differentiable=False):
             f, g = sde.f_and_g(t_probe, probe)
     except NotElementwise:
         raise
-    except Exception as e:        # the user's code failed on the probe (a per-row buffer of the real batch, say)
+    except Exception as e:        # the user's code failed on the probe (or on the vector of step times) (a per-row buffer of the real batch, say)
         raise NotElementwise(f"{type(e).__name__}: {e}") from None
     forms = []
     for name, value in (("drift", f), ("diffusion", g)):

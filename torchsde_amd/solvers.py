@@ -423,8 +423,20 @@ class BaseSDESolver:
                 book["refused"][key] = reason
             return None
 
+        times = None
         try:
-            found = recognise.recognise(sde, ts[0], y0)
+            try:
+                found = recognise.recognise(sde, ts[0], y0)
+            except recognise.DependsOnTime:
+                # f, g use t in their arithmetic: Euler and Milstein evaluate them at the start of each step only, so all
+                # step times can be interpreted at once and the kernels read one coefficient row per step
+                if self._trajectory_code() not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO,
+                                                   _native.TRAJ_MILSTEIN_STRAT):
+                    raise
+                times = self._step_start_times(ts, y0.device)
+                if times is None:
+                    raise
+                found = recognise.recognise(sde, ts[0], y0, times=times)
             spec = found.spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
@@ -445,7 +457,7 @@ class BaseSDESolver:
         # reproduce the stepwise solve?
         before = graph.python_state(base)
         try:
-            again = recognise.recognise(sde, ts[0], y0).spec()
+            again = recognise.recognise(sde, ts[0], y0, times=times).spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if before is None or graph.python_state(base) != before:
@@ -520,6 +532,25 @@ class BaseSDESolver:
             book["trusted"].clear()
         book["trusted"][key] = True if bool(close.all()) else "the sensitivity kernel's values differ from the stepwise solve"
         return stepwise
+
+    _STEP_TIMES = {}
+
+    def _step_start_times(self, ts, device):
+        """The start time of every step of this solve, (K,) in ts.dtype on the device -- the `t` the stepwise loop hands
+        to f and g at step k (`_plan`: stage time 0) -- remembered by content."""
+        grid = timegrid.build(timegrid.ts_to_host(ts), self.dt)
+        if grid.n_steps == 0:
+            return None
+        key = (grid.t.tobytes(), str(grid.t.dtype), str(device))
+        hit = self._STEP_TIMES.get(key)
+        if hit is None:
+            if len(self._STEP_TIMES) >= 16:
+                self._STEP_TIMES.clear()
+            hit = torch.from_numpy(np.ascontiguousarray(grid.t[:-1])).to(device=device)
+            if hit.dtype != ts.dtype:
+                hit = hit.to(ts.dtype)
+            self._STEP_TIMES[key] = hit
+        return hit
 
     def _recognised_key(self, found, chain, y0):
         return (found.structure(), chain, type(self).__name__, self.sde.sde_type, y0.shape[1], y0.dtype)
