@@ -133,11 +133,6 @@ def test_every_solve_uses_the_live_values(monkeypatch):
     assert list(_book(sde)["trusted"].values()) == [True]          # one form all along: verified once
 
 
-class _TimeDependent(_Live):
-    def f(self, t, y):
-        return torch.cos(t) * self.theta * y
-
-
 class _Counting(_Live):
     calls = 0
 
@@ -152,7 +147,9 @@ class _PerRow(_Live):
 
 
 def test_code_that_does_not_fit_keeps_the_stepwise_path():
-    for sde in (_TimeDependent([0.2]).to(DEV), problems.make("mlpdiag_ito", d=D).to(DEV), _Counting([0.2]).to(DEV)):
+    # (an MLP that takes t as an input, a call counter that feeds the coefficients; time-dependent COEFFICIENTS fit since
+    #  the timed kernels exist: test_time_dependent_coefficients_take_the_timed_kernels)
+    for sde in (problems.make("mlpdiag_ito", d=D).to(DEV), _Counting([0.2]).to(DEV)):
         if isinstance(sde, _Counting):
             # (its coefficients change with every call: only the comparison of two interpretations can tell)
             for entropy in (1, 2, 3):
