@@ -344,11 +344,13 @@ int tsde_trajectory_affine_diag(void* ys, const void* y0, int64_t rows, int64_t 
                                 const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                                 const uint64_t* entropy_dev, int dtype, void* stream);
 
-/* The same solve for coefficients that depend on TIME, f(t, y) = rate(t) * y + shift(t): each of the four arrays holds one
- * row of d values per step, `coef_step_stride` elements apart (0 = the constant-coefficient kernel above); step k uses row
- * k, i.e. the coefficients at the step's start t_k, where torchsde's Euler and Milstein steps evaluate f and g
- * (methods/euler.py:31, milstein.py:54). Euler and Milstein (Ito / Stratonovich) only: the other schemes evaluate at
- * further stage times. Values only. */
+/* The same solve for coefficients that depend on TIME, f(t, y) = rate(t) * y + shift(t): each of the four arrays holds
+ * S rows of d values per step, `coef_step_stride` elements apart (0 = the constant-coefficient kernel above), one row per
+ * STAGE TIME of the scheme, in this order -- the times at which torchsde's step evaluates f and g:
+ *   Euler, Milstein  S = 1: t_k                                             (methods/euler.py:31, milstein.py:54)
+ *   midpoint         S = 2: t_k, t_k + dt/2                                 (midpoint.py:33,40)
+ *   SRK (SRID2)      S = 4: t_k, t_k + dt/4, t_k + dt/2, t_k + dt           (srk.py:66-72 with tableaus/srid2.py:21-22)
+ * Step k uses rows k*S ... k*S + S - 1. Values only. */
 int tsde_trajectory_affine_diag_timed(void* ys, const void* y0, int64_t rows, int64_t d, const void* drift_rate,
                                       const void* drift_shift, const void* diff_rate, const void* diff_shift,
                                       int64_t coef_step_stride, int method, const tsde_traj_t* traj, uint64_t entropy,
@@ -413,7 +415,7 @@ int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d,
                               int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                               const uint64_t* entropy_dev, int dtype, void* stream);
 
-/* ... and with time-dependent coefficients (see tsde_trajectory_affine_diag_timed): eight tables of one row per step. */
+/* ... and with time-dependent coefficients (see tsde_trajectory_affine_diag_timed): eight tables, S rows per step. */
 int tsde_trajectory_expr_diag_timed(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8],
                                     int64_t coef_step_stride, int f_kind, int g_kind, int method,
                                     const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,

@@ -454,17 +454,27 @@ def test_time_dependent_coefficients_take_the_timed_kernels(make, method, sde_ty
     torch.testing.assert_close(solve(3), solve(3, stepwise=True), rtol=2e-5, atol=2e-6)
 
 
-def test_schemes_with_further_stage_times_keep_time_dependent_sdes_stepwise():
+@pytest.mark.parametrize("make,method,levy,sde_type", [(_Scheduled, "srk", "space-time", "ito"),
+                                                       (_ScheduledAffine, "srk", "space-time", "ito"),
+                                                       (_Scheduled, "midpoint", "none", "stratonovich"),
+                                                       (_ScheduledAffine, None, "space-time", "ito")])
+def test_time_dependent_coefficients_under_the_default_schemes(make, method, levy, sde_type):
+    """SRK (the default for diagonal Ito noise) and the Stratonovich midpoint evaluate f, g at further stage times of a
+    step (t + dt/4, t + dt/2, t + dt): the interpretation covers every stage time and the kernels read 4 (2) coefficient
+    rows per step."""
     import torchsde_amd
-    for method, levy, sde_type in (("srk", "space-time", "ito"), ("midpoint", "none", "stratonovich")):
-        sde = _Scheduled(sde_type).to(DEV)
-        y0 = torch.full((B, D), 0.2, device=DEV)
-        ts = torch.tensor([0.0, 0.5], device=DEV)
-        for entropy in (1, 2):
-            bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, D), device=DEV, entropy=entropy,
-                                               levy_area_approximation=levy)
-            with torch.no_grad():
-                _, n = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.01,
-                                                             options={"hip_graph": False}))
-            assert n == 0
-        assert _book(sde)["refused"] and not _book(sde)["trusted"]
+    sde = make(sde_type).to(DEV)
+    y0 = torch.full((B, D), 0.2, device=DEV)
+    ts = torch.tensor([0.0, 0.13, 0.5], device=DEV)
+
+    def solve(entropy, stepwise=False):
+        bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, D), device=DEV, entropy=entropy,
+                                           levy_area_approximation=levy)
+        options = {"hip_graph": False, "trajectory_kernel": False} if stepwise else {"hip_graph": False}
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.01, options=options)
+    assert torch.equal(solve(1), solve(1, stepwise=True))
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast, n = _launches(lambda: solve(2))
+    assert n == 1
+    torch.testing.assert_close(fast, solve(2, stepwise=True), rtol=3e-5, atol=3e-6)

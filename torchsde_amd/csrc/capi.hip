@@ -459,8 +459,7 @@ static int trajectory_affine_diag(const char* where, void* ys, void* sens, const
                                   void* stream) {
   if (!ys || !y0 || !drift_rate || !drift_shift || !diff_rate || !diff_shift || !traj) return bad_arg(where, "null argument");
   if (coef_step_stride != 0 && coef_step_stride < d) return bad_arg(where, "coef_step_stride must be 0 or >= d");
-  if (coef_step_stride != 0 && (sens || method > TSDE_TRAJ_MILSTEIN_STRAT))
-    return bad_arg(where, "per-step coefficients: Euler and Milstein, values only");
+  if (coef_step_stride != 0 && sens) return bad_arg(where, "per-step coefficients: values only");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
   if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
@@ -546,8 +545,7 @@ int tsde_trajectory_expr_diag_timed(void* ys, const void* y0, int64_t rows, int6
                                     const uint64_t* entropy_dev, int dtype, void* stream) {
   const char* where = coef_step_stride ? "tsde_trajectory_expr_diag_timed" : "tsde_trajectory_expr_diag";
   if (!ys || !y0 || !coef || !traj) return bad_arg(where, "null argument");
-  if (coef_step_stride != 0 && (coef_step_stride < d || method > TSDE_TRAJ_MILSTEIN_STRAT))
-    return bad_arg(where, "per-step coefficients: stride >= d, Euler and Milstein only");
+  if (coef_step_stride != 0 && coef_step_stride < d) return bad_arg(where, "coef_step_stride must be 0 or >= d");
   for (int c = 0; c < 8; ++c)
     if (!coef[c]) return bad_arg(where, "null coefficient array");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");

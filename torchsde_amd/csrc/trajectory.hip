@@ -126,41 +126,48 @@ enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStr
 // One step of one element of a diagonal SDE whose drift and diffusion the kernel can evaluate itself. `w` = W, `u` = U
 // (SRK only). S is T (values only) or Dual<T>. `M` supplies f(x), g(x) and gdg(x, g, v) = (g * v) * g'(x), the
 // diffusion VJP with cotangent g * v that derivative-form Milstein takes through autograd (base_sde.py:147-152).
+// Stage-time slots. A scheme evaluates f and g at a few times of the step; a model whose coefficients depend on t holds
+// one coefficient set per slot (TIMED kernels) and `m.f<SLOT>(x)` picks it; models with constant coefficients ignore the slot.
+//   Euler, Milstein : slot 0 = t0                                         (euler.py:31, milstein.py:54)
+//   midpoint        : slot 0 = t0, 1 = t0 + dt/2                          (midpoint.py:33,40)
+//   SRK (SRID2)     : slot 0 = t0, 1 = t0 + dt/4, 2 = t0 + dt/2, 3 = t0 + dt;  f at C0 = (0, 1, 1/2) -> slots 0, 3, 2 and
+//                     g at C1 = (0, 1/4, 1, 1/4) -> slots 0, 1, 3, 1       (srk.py:66-72, tableaus/srid2.py:21-22)
+template <int METHOD>
+constexpr int stage_slots() { return METHOD == kSrk ? 4 : (METHOD == kMidpoint ? 2 : 1); }
+
 template <typename T, int METHOD, typename S, typename M>
 TSDE_D S scheme_step(const S y, const M& m, const T w, const T u, const T dt, const T half_dt, const T rdt,
                      const T sqrt_dt) {
-  auto F = [&](const S& x) { return m.f(x); };
-  auto G = [&](const S& x) { return m.g(x); };
   if constexpr (METHOD == kEuler) {
-    return drift_diffusion_update<T, S>(y, F(y), G(y), w, dt, (T)1);
+    return drift_diffusion_update<T, S>(y, m.template f<0>(y), m.template g<0>(y), w, dt, (T)1);
   } else if constexpr (METHOD == kMilIto || METHOD == kMilStrat) {
     const T v2 = milstein_v<T>(w, dt, (T)0.5, METHOD == kMilIto);
-    const S g = G(y);
-    const S gdg = m.gdg(y, g, v2);
-    return milstein_update<T, S>(y, F(y), g, gdg, w, dt);
+    const S g = m.template g<0>(y);
+    const S gdg = m.template gdg<0>(y, g, v2);
+    return milstein_update<T, S>(y, m.template f<0>(y), g, gdg, w, dt);
   } else if constexpr (METHOD == kMidpoint) {
-    const S yp = drift_diffusion_update<T, S>(y, F(y), G(y), w, half_dt, (T)0.5);
-    return drift_diffusion_update<T, S>(y, F(yp), G(yp), w, dt, (T)1);
+    const S yp = drift_diffusion_update<T, S>(y, m.template f<0>(y), m.template g<0>(y), w, half_dt, (T)0.5);
+    return drift_diffusion_update<T, S>(y, m.template f<1>(yp), m.template g<1>(yp), w, dt, (T)1);
   } else {
     const S zero = S((T)0);
     S f[3], g[4], h0, h1;
     S fz[3] = {zero, zero, zero};
-    f[0] = F(y);
-    g[0] = G(y);
+    f[0] = m.template f<0>(y);
+    g[0] = m.template g<0>(y);
     fz[0] = Srid2::need_f(1, 0) ? f[0] : zero;
     srid2_stage_states<T, 1, S>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
-    f[1] = F(h0);
-    g[1] = G(h1);
+    f[1] = m.template f<3>(h0);
+    g[1] = m.template g<1>(h1);
     fz[0] = Srid2::need_f(2, 0) ? f[0] : zero;
     fz[1] = Srid2::need_f(2, 1) ? f[1] : zero;
     srid2_stage_states<T, 2, S>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
-    f[2] = F(h0);
-    g[2] = G(h1);
+    f[2] = m.template f<2>(h0);
+    g[2] = m.template g<3>(h1);
     fz[0] = Srid2::need_f(3, 0) ? f[0] : zero;
     fz[1] = Srid2::need_f(3, 1) ? f[1] : zero;
     fz[2] = Srid2::need_f(3, 2) ? f[2] : zero;
     srid2_stage_states<T, 3, S>(y, fz, g, u, dt, rdt, sqrt_dt, h0, h1);
-    g[3] = G(h1);
+    g[3] = m.template g<1>(h1);
     return srid2_final<T, S>(y, f, g, w, u, dt, rdt, sqrt_dt);
   }
 }
@@ -172,9 +179,24 @@ struct AffineModel {
   B b;
   C c;
   E e;
+  template <int SLOT>
   TSDE_D S f(const S& x) const { return a * x + b; }
+  template <int SLOT>
   TSDE_D S g(const S& x) const { return c * x + e; }
+  template <int SLOT>
   TSDE_D S gdg(const S&, const S& gv, T v2) const { return (gv * v2) * c; }   // vjp of y -> c*y + e with cotangent g*v2
+};
+
+// ... with one coefficient set per stage-time slot (coefficients that depend on t; values only)
+template <typename T, int NS>
+struct AffineModelTimed {
+  T a[NS], b[NS], c[NS], e[NS];
+  template <int SLOT>
+  TSDE_D T f(const T& x) const { return a[SLOT] * x + b[SLOT]; }
+  template <int SLOT>
+  TSDE_D T g(const T& x) const { return c[SLOT] * x + e[SLOT]; }
+  template <int SLOT>
+  TSDE_D T gdg(const T&, const T& gv, T v2) const { return (gv * v2) * c[SLOT]; }
 };
 
 template <typename T, int METHOD, typename S, typename A, typename B, typename C, typename E>
@@ -220,12 +242,31 @@ template <typename T>
 struct ExprModel {
   T fa, fp, fq, fb, ga, gp, gq, gb;
   int fk, gk;
+  template <int SLOT>
   TSDE_D T f(const T& x) const { return fa * expr_phi<T>(fk, fp * x + fq) + fb; }
+  template <int SLOT>
   TSDE_D T g(const T& x) const { return ga * expr_phi<T>(gk, gp * x + gq) + gb; }
   // (g v) g'(x), the chain rule in the order autograd walks scale * phi(rate * x + shift) + offset backwards
+  template <int SLOT>
   TSDE_D T gdg(const T& x, const T& gv, T v2) const {
     const T u = gp * x + gq;
     return (((gv * v2) * ga) * expr_dphi<T>(gk, u, expr_phi<T>(gk, u))) * gp;
+  }
+};
+
+// ... with one set of the eight coefficients per stage-time slot (coefficients that depend on t)
+template <typename T, int NS>
+struct ExprModelTimed {
+  T k[NS][8];          // fa, fp, fq, fb, ga, gp, gq, gb
+  int fk, gk;
+  template <int SLOT>
+  TSDE_D T f(const T& x) const { return k[SLOT][0] * expr_phi<T>(fk, k[SLOT][1] * x + k[SLOT][2]) + k[SLOT][3]; }
+  template <int SLOT>
+  TSDE_D T g(const T& x) const { return k[SLOT][4] * expr_phi<T>(gk, k[SLOT][5] * x + k[SLOT][6]) + k[SLOT][7]; }
+  template <int SLOT>
+  TSDE_D T gdg(const T& x, const T& gv, T v2) const {
+    const T u = k[SLOT][5] * x + k[SLOT][6];
+    return (((gv * v2) * k[SLOT][4]) * expr_dphi<T>(gk, u, expr_phi<T>(gk, u))) * k[SLOT][5];
   }
 };
 
@@ -237,9 +278,9 @@ TSDE_D T primal(const Dual<T>& x) { return x.v; }
 // W = 4: a lane owns one 16-byte group (needs d % 4 == 0 so the group stays inside one row).
 // W = 1: a lane owns one element (any d; also used for small problems, where it exposes 4x the lanes).
 // SENS : carry the kSens path-wise sensitivities of every element and write them next to the outputs.
-// TIMED: the coefficients are functions of time given as one row per step (f(t, y) = a(t) * y + b(t), evaluated at the
-//        step's start like the stepwise Euler / Milstein loop does: euler.py:31, milstein.py:54): re-read, through the
-//        L2, at the top of every step. A separate instantiation, so the constant-coefficient kernels are untouched.
+// TIMED: the coefficients are functions of time, f(t, y) = a(t) * y + b(t), given as one row per STAGE TIME of every step
+//        (`stage_slots<METHOD>()` rows per step, in slot order): re-read, through the L2, at the top of every step. A
+//        separate instantiation, so the constant-coefficient kernels are untouched.
 template <typename T, int METHOD, int W, bool SENS, bool TIMED = false>
 __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p) {
   constexpr bool kNeedU = METHOD == kSrk;
@@ -252,7 +293,8 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
   const int64_t i = lane * W;
   if (i >= p.n) return;
   const int64_t col = i % p.d;
-  Pack<T, W> a = load<T, W>(p.a, col), b = load<T, W>(p.b, col), c = load<T, W>(p.c, col), e = load<T, W>(p.e, col);
+  const Pack<T, W> a = load<T, W>(p.a, col), b = load<T, W>(p.b, col), c = load<T, W>(p.c, col),
+                   e = load<T, W>(p.e, col);
   const Pack<T, W> y_init = load<T, W>(p.y0, i);
   S y[W];
 #pragma unroll
@@ -272,13 +314,16 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
     const uint32_t cell = p.cells[k];
+    constexpr int NS = stage_slots<METHOD>();
+    Pack<T, W> ta[NS], tb[NS], tc[NS], te[NS];      // TIMED: the coefficient rows of this step's stage times
     if constexpr (TIMED) {
-      if (k > 0) {
-        const int64_t at = (int64_t)k * p.cstride + col;
-        a = load<T, W>(p.a, at);
-        b = load<T, W>(p.b, at);
-        c = load<T, W>(p.c, at);
-        e = load<T, W>(p.e, at);
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        const int64_t at = ((int64_t)k * NS + sl) * p.cstride + col;
+        ta[sl] = load<T, W>(p.a, at);
+        tb[sl] = load<T, W>(p.b, at);
+        tc[sl] = load<T, W>(p.c, at);
+        te[sl] = load<T, W>(p.e, at);
       }
     }
     Pack<T, W> w, u;
@@ -299,8 +344,20 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
     S y1[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-      y1[q] = affine_step<T, METHOD, S, A, B, C, E>(y[q], A{a.v[q]}, B{b.v[q]}, C{c.v[q]}, E{e.v[q]}, w.v[q],
-                                                     kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+      if constexpr (TIMED) {
+        AffineModelTimed<T, NS> m;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          m.a[sl] = ta[sl].v[q];
+          m.b[sl] = tb[sl].v[q];
+          m.c[sl] = tc[sl].v[q];
+          m.e[sl] = te[sl].v[q];
+        }
+        y1[q] = scheme_step<T, METHOD, S>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+      } else {
+        y1[q] = affine_step<T, METHOD, S, A, B, C, E>(y[q], A{a.v[q]}, B{b.v[q]}, C{c.v[q]}, E{e.v[q]}, w.v[q],
+                                                       kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+      }
     }
     while (j < p.n_out && p.out_step[j] == k + 1) {
       const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
@@ -355,14 +412,9 @@ static hipError_t launch_traj_timed(const TrajArgs<T>& p, bool vec, hipStream_t 
 
 template <typename T, int METHOD>
 static hipError_t launch_traj_m(const TrajArgs<T>& p, bool vec, hipStream_t s) {
-  if (p.cstride != 0) {
-    // coefficient tables: the schemes that evaluate f, g at the step's start only, values only
-    if constexpr (METHOD == kEuler || METHOD == kMilIto || METHOD == kMilStrat) {
-      if (p.sens) return hipErrorNotSupported;
-      return launch_traj_timed<T, METHOD>(p, vec, s);
-    } else {
-      return hipErrorNotSupported;
-    }
+  if (p.cstride != 0) {            // coefficient tables (values only)
+    if (p.sens) return hipErrorNotSupported;
+    return launch_traj_timed<T, METHOD>(p, vec, s);
   }
   return p.sens ? launch_traj_ms<T, METHOD, true>(p, vec, s) : launch_traj_ms<T, METHOD, false>(p, vec, s);
 }
@@ -453,11 +505,14 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
     const uint32_t cell = p.cells[k];
+    constexpr int NS = stage_slots<METHOD>();
+    Pack<T, W> tcf[NS][8];                          // TIMED: the coefficient rows of this step's stage times
     if constexpr (TIMED) {
-      if (k > 0) {
-        const int64_t at = (int64_t)k * p.cstride + col;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) cf[c] = load<T, W>(p.coef[c], at);
+      for (int sl = 0; sl < NS; ++sl) {
+        const int64_t at = ((int64_t)k * NS + sl) * p.cstride + col;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tcf[sl][c] = load<T, W>(p.coef[c], at);
       }
     }
     Pack<T, W> w, u;
@@ -478,9 +533,21 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
     T y1[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-      const ExprModel<T> m{cf[0].v[q], cf[1].v[q], cf[2].v[q], cf[3].v[q], cf[4].v[q], cf[5].v[q],
-                           cf[6].v[q], cf[7].v[q], p.f_kind,  p.g_kind};
-      y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+      if constexpr (TIMED) {
+        ExprModelTimed<T, NS> m;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) m.k[sl][c] = tcf[sl][c].v[q];
+        }
+        m.fk = p.f_kind;
+        m.gk = p.g_kind;
+        y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+      } else {
+        const ExprModel<T> m{cf[0].v[q], cf[1].v[q], cf[2].v[q], cf[3].v[q], cf[4].v[q], cf[5].v[q],
+                             cf[6].v[q], cf[7].v[q], p.f_kind,  p.g_kind};
+        y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+      }
     }
     while (j < p.n_out && p.out_step[j] == k + 1) {
       const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
@@ -499,19 +566,16 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
 template <typename T, int METHOD>
 static hipError_t launch_expr_m(const ExprArgs<T>& p, bool vec, hipStream_t s) {
   if (p.cstride != 0) {
-    if constexpr (METHOD == kEuler || METHOD == kMilIto || METHOD == kMilStrat) {
-      if (vec) {
-        const int64_t lanes = p.n >> 2;
-        hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 4, true>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, p);
-      } else {
-        hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 1, true>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, p);
-      }
-      return hipGetLastError();
+    // (SRK holds 4 slots x 8 coefficients per element: one element per lane keeps that in registers)
+    if (vec && METHOD != kSrk) {
+      const int64_t lanes = p.n >> 2;
+      hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 4, true>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)),
+                         dim3(kBlock), 0, s, p);
     } else {
-      return hipErrorNotSupported;
+      hipLaunchKernelGGL((trajectory_expr_kernel<T, METHOD, 1, true>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
+                         dim3(kBlock), 0, s, p);
     }
+    return hipGetLastError();
   }
   if (vec) {
     const int64_t lanes = p.n >> 2;

@@ -618,18 +618,19 @@ class TrajectorySchedule:
                                          [(0.0, 1.0)] * n, self.device, self.dtype)
 
 
-def _coefficient_tables(coefs, d, schedule, dtype):
+def _coefficient_tables(coefs, d, schedule, dtype, method):
     """False: every coefficient is a contiguous (d,) tensor (the same at every step). True: every one is a contiguous
-    (n_steps, d) table -- one row per step, for drift / diffusion coefficients that depend on t (the `_timed` entry
-    points). Anything else is an error."""
+    (n_steps * S, d) table -- one row per stage time of every step, for drift / diffusion coefficients that depend on t
+    (the `_timed` entry points; S = 1 Euler / Milstein, 2 midpoint, 4 SRK). Anything else is an error."""
     shapes = {tuple(c.shape) for c in coefs}
     if any(c.dtype != dtype or not c.is_contiguous() for c in coefs):
         raise ValueError("coefficients must be contiguous tensors in the state dtype")
     if shapes == {(d,)}:
         return False
-    if shapes == {(schedule.n_steps, d)}:
+    slots = {0: 1, 1: 1, 2: 1, 3: 2, 4: 4}[int(method)]       # stage times per step (csrc/trajectory.hip stage_slots)
+    if shapes == {(schedule.n_steps * slots, d)}:
         return True
-    raise ValueError(f"coefficients must all be (d,) tensors or all (n_steps, d) tables, got {sorted(shapes)}")
+    raise ValueError(f"coefficients must all be (d,) tensors or all (n_steps * {slots}, d) tables, got {sorted(shapes)}")
 
 
 def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, method, schedule, bm, sens=None):
@@ -640,7 +641,7 @@ def trajectory_affine_diag(ys, y0, drift_rate, drift_shift, diff_rate, diff_shif
     _native.require_device(ys, y0, drift_rate, drift_shift, diff_rate, diff_shift, sens)
     rows, d = y0.shape
     coefs = (drift_rate, drift_shift, diff_rate, diff_shift)
-    timed = _coefficient_tables(coefs, d, schedule, y0.dtype)
+    timed = _coefficient_tables(coefs, d, schedule, y0.dtype, method)
     if timed and sens is not None:
         raise ValueError("per-step coefficient tables: values only")
     if schedule.dtype != y0.dtype or ys.dtype != y0.dtype:
@@ -672,7 +673,7 @@ def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
     rows, d = y0.shape
     if len(coefs) != 8:
         raise ValueError("eight coefficient tensors are needed")
-    timed = _coefficient_tables(coefs, d, schedule, y0.dtype)
+    timed = _coefficient_tables(coefs, d, schedule, y0.dtype, method)
     if schedule.dtype != y0.dtype or ys.dtype != y0.dtype:
         raise ValueError("schedule / output dtype must equal the state dtype")
     if not (ys.is_contiguous() and y0.is_contiguous()) or ys.shape != (schedule.n_out, rows, d):

@@ -428,12 +428,9 @@ class BaseSDESolver:
             try:
                 found = recognise.recognise(sde, ts[0], y0)
             except recognise.DependsOnTime:
-                # f, g use t in their arithmetic: Euler and Milstein evaluate them at the start of each step only, so all
-                # step times can be interpreted at once and the kernels read one coefficient row per step
-                if self._trajectory_code() not in (_native.TRAJ_EULER, _native.TRAJ_MILSTEIN_ITO,
-                                                   _native.TRAJ_MILSTEIN_STRAT):
-                    raise
-                times = self._step_start_times(ts, y0.device)
+                # f, g use t in their arithmetic: interpret once more with ALL the times at which this scheme evaluates them
+                # (its stage times of every step); the kernels then read one coefficient row per stage time
+                times = self._stage_times(ts, y0.device)
                 if times is None:
                     raise
                 found = recognise.recognise(sde, ts[0], y0, times=times)
@@ -533,23 +530,32 @@ class BaseSDESolver:
         book["trusted"][key] = True if bool(close.all()) else "the sensitivity kernel's values differ from the stepwise solve"
         return stepwise
 
-    _STEP_TIMES = {}
+    _STAGE_TIMES = {}
+    # stage-time slots of the trajectory kernels (csrc/trajectory.hip stage_slots): offsets from t0 as multiples of dt
+    _TIMED_SLOTS = {_native.TRAJ_EULER: (0,), _native.TRAJ_MILSTEIN_ITO: (0,), _native.TRAJ_MILSTEIN_STRAT: (0,),
+                    _native.TRAJ_MIDPOINT: (0, 0.5), _native.TRAJ_SRK: (0, 0.25, 0.5, 1)}
 
-    def _step_start_times(self, ts, device):
-        """The start time of every step of this solve, (K,) in ts.dtype on the device -- the `t` the stepwise loop hands
-        to f and g at step k (`_plan`: stage time 0) -- remembered by content."""
+    def _stage_times(self, ts, device):
+        """Every time at which this scheme evaluates f and g during the solve -- (K * S,) in ts.dtype on the device, the S
+        stage times of step 0, then of step 1, ... -- computed like `_plan` computes the times the stepwise loop hands to
+        the user's code (`t0 + frac * dt` in ts.dtype). Remembered by content."""
+        slots = self._TIMED_SLOTS.get(self._trajectory_code())
         grid = timegrid.build(timegrid.ts_to_host(ts), self.dt)
-        if grid.n_steps == 0:
+        if slots is None or grid.n_steps == 0:
             return None
-        key = (grid.t.tobytes(), str(grid.t.dtype), str(device))
-        hit = self._STEP_TIMES.get(key)
+        key = (grid.t.tobytes(), str(grid.t.dtype), slots, str(device))
+        hit = self._STAGE_TIMES.get(key)
         if hit is None:
-            if len(self._STEP_TIMES) >= 16:
-                self._STEP_TIMES.clear()
-            hit = torch.from_numpy(np.ascontiguousarray(grid.t[:-1])).to(device=device)
+            if len(self._STAGE_TIMES) >= 16:
+                self._STAGE_TIMES.clear()
+            np_dtype = grid.t.dtype.type
+            table = np.empty((grid.n_steps, len(slots)), dtype=grid.t.dtype)
+            for j, frac in enumerate(slots):
+                table[:, j] = grid.t[:-1] if frac == 0 else grid.t[:-1] + np_dtype(frac) * grid.dt
+            hit = torch.from_numpy(table.reshape(-1)).to(device=device)
             if hit.dtype != ts.dtype:
                 hit = hit.to(ts.dtype)
-            self._STEP_TIMES[key] = hit
+            self._STAGE_TIMES[key] = hit
         return hit
 
     def _recognised_key(self, found, chain, y0):
