@@ -36,6 +36,20 @@ WORKLOADS = {
         problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -16,
         bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
         kernel="tsde_trajectory_expr_diag<float, euler> (user module recognised: f = y, g = exp(-y) in the kernel)"),
+    # coefficients that depend on t (a schedule: ScheduledDiag): the `_timed` kernels read one coefficient row per stage
+    # time; stepwise counterpart below
+    "c2_euler_scheduled_default_route_b65536_d64_s1000": dict(
+        problem="scheduled_diag", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_affine_diag_timed<float, euler> (user module with time-dependent coefficients recognised)"),
+    "c2_srk_scheduled_default_route_b65536_d64_s1000": dict(
+        problem="scheduled_diag", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=64 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_affine_diag_timed<float, srk> (4 coefficient rows per step)"),
+    "c2_euler_scheduled_b65536_d64_s1000": dict(
+        problem="scheduled_diag", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
     # BASELINE.json configs[1], STEPWISE (options={"trajectory_kernel": False}): the user's f and g run as torch kernels
     # between the per-step kernels -- the route of every SDE that is not a per-channel expression
     "c2_euler_diag_b65536_d64_s1000": dict(
@@ -192,6 +206,8 @@ def make_problem(name, d, m, dev):
         return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
     if name == "latent_diag":      # latent-SDE-style diagonal SDE
         return problems.LatentDiag(d).to(dev)
+    if name == "scheduled_diag":
+        return problems.ScheduledDiag(d).to(dev)
     if name == "exp_diffusion":    # the reference's own benchmark SDE (benchmarks/brownian.py:131-139): f = y, g = exp(-y)
         return problems.ExpDiffusion().to(dev)
     if name == "exp_diffusion_closed_form":

@@ -205,6 +205,28 @@ class ExpDiffusion(nn.Module):
         return torch.exp(-y)
 
 
+class ScheduledDiag(nn.Module):
+    """Time enters through a schedule only: dy = -1/2 beta(t) y dt + sqrt(beta(t)) sigma dW, beta(t) = b0 + t (b1 - b0) --
+    the forward SDE of a variance-preserving diffusion model, per channel (cf. the reference's examples/cont_ddpm.py)."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, d, seed=3):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.b0 = nn.Parameter(torch.tensor(0.1))
+        self.b1 = nn.Parameter(torch.tensor(4.0))
+        self.sigma = nn.Parameter(_sigmoid_randn(gen, d))
+
+    def beta(self, t):
+        return self.b0 + t * (self.b1 - self.b0)
+
+    def f(self, t, y):
+        return -0.5 * self.beta(t) * y
+
+    def g(self, t, y):
+        return torch.sqrt(self.beta(t)) * self.sigma * torch.ones_like(y)
+
+
 class ReadmeSDE(nn.Module):
     """The README quick example: general Ito noise, linear drift, linear diffusion reshaped to (B, d, m)."""
     noise_type = "general"
