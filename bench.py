@@ -258,7 +258,9 @@ class Job:
             from torchsde_amd import solvers
             book = getattr(self.sde, solvers.BaseSDESolver._RECOGNISED_ATTR, None)
             if not book or list(book["trusted"].values()) != [True]:
-                raise RuntimeError(f"{self.name}: the user module was not routed to the trajectory kernel: {book}")
+                why = list((book or {}).get("refused", {}).values()) + [v for v in (book or {}).get("trusted", {}).values()
+                                                                         if v is not True]
+                raise RuntimeError(f"{self.name}: the user module was not routed to the trajectory kernel: {why}")
 
     def live_state(self, out):
         """A state tensor of this workload's shape with live values: the solve's final state where `out` is one."""

@@ -215,7 +215,7 @@ class ScheduledDiag(nn.Module):
         gen = torch.Generator().manual_seed(seed)
         self.b0 = nn.Parameter(torch.tensor(0.1))
         self.b1 = nn.Parameter(torch.tensor(4.0))
-        self.sigma = nn.Parameter(_sigmoid_randn(gen, d))
+        self.sigma = nn.Parameter(_sigmoid_randn(gen, d).to(torch.float32))
 
     def beta(self, t):
         return self.b0 + t * (self.b1 - self.b0)
