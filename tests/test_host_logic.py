@@ -681,3 +681,24 @@ def test_auto_key_refuses_an_object_whose_state_never_repeats_and_schedule_of_ch
     monkeypatch.setenv("TSDE_HIP_GRAPH", "sometimes")
     with pytest.raises(ValueError):
         graph.mode_of({})
+
+
+def test_modules_that_must_not_be_called_an_extra_time_are_not_interpreted():
+    """recognise.py calls f and g once per solve on a two-row probe: a normalisation layer in training mode would take
+    the probe into its running statistics, a compiled module would recompile under the dispatch mode."""
+    from torch import nn
+    from torchsde_amd.solvers import BaseSDESolver
+
+    class WithBatchNorm(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.norm = nn.BatchNorm1d(4)
+
+    sde = WithBatchNorm()
+    assert not BaseSDESolver._may_be_interpreted(sde)
+    sde.eval()
+    assert BaseSDESolver._may_be_interpreted(sde)
+    assert BaseSDESolver._may_be_interpreted(problems.make("gbm_ito", d=4))
+    assert not BaseSDESolver._may_be_interpreted(type("OptimizedModule", (), {})())

@@ -405,6 +405,8 @@ class BaseSDESolver:
                 or (self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         chain, base = graph._wrapper_chain(sde)
+        if not self._may_be_interpreted(base):
+            return None
         try:
             book = base.__dict__.setdefault(self._RECOGNISED_ATTR, {"refused": {}, "trusted": {}})
         except AttributeError:
@@ -479,6 +481,20 @@ class BaseSDESolver:
         book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
         return stepwise
 
+    @staticmethod
+    def _may_be_interpreted(base):
+        """The interpretation CALLS the user's f and g on a two-row probe. Modules for which one extra call is not
+        harmless are left alone: compiled modules (a dispatch mode under torch.compile recompiles or fails), and modules
+        with normalisation layers in training mode (a call would feed the probe into their running statistics)."""
+        if type(base).__name__ == "OptimizedModule":
+            return False
+        if isinstance(base, torch.nn.Module):
+            for m in base.modules():
+                if m.training and isinstance(m, torch.nn.modules.batchnorm._NormBase) \
+                        and getattr(m, "track_running_stats", False):
+                    return False
+        return True
+
     def _integrate_recognised_with_grad(self, y0, ts):
         """Autograd is recording the solve (`sdeint` with trainable parameters or y0). A recognised module whose drift and
         diffusion are plain `rate * y + shift` with the user's own tensors as coefficients takes the sensitivity kernel
@@ -494,6 +510,8 @@ class BaseSDESolver:
                 or (self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         chain, base = graph._wrapper_chain(sde)
+        if not self._may_be_interpreted(base):
+            return None
         try:
             book = base.__dict__.setdefault(self._RECOGNISED_ATTR, {"refused": {}, "trusted": {}})
         except AttributeError:
@@ -572,6 +590,8 @@ class BaseSDESolver:
                 or sde.noise_type != NOISE_TYPES.diagonal or y0.dim() != 2 or not y0.is_cuda):
             return None
         chain, base = graph._wrapper_chain(sde)
+        if not self._may_be_interpreted(base):
+            return None
         book = getattr(base, self._RECOGNISED_ATTR, None)
         if book is not None and book["refused"]:
             state = graph.python_state(base)
