@@ -478,3 +478,14 @@ def test_time_dependent_coefficients_under_the_default_schemes(make, method, lev
     fast, n = _launches(lambda: solve(2))
     assert n == 1
     torch.testing.assert_close(fast, solve(2, stepwise=True), rtol=3e-5, atol=3e-6)
+
+
+def test_describe_says_which_route_and_why():
+    from torchsde_amd import recognise
+    sde = problems.make("gbm_ito", d=D).to(DEV)
+    assert "nothing recorded" in recognise.describe(sde)[0]
+    _solve(sde, 1)
+    assert any("trajectory kernel" in line and "Euler" in line for line in recognise.describe(sde))
+    mlp = problems.make("mlpdiag_ito", d=D).to(DEV)
+    _solve(mlp, 1)
+    assert any("stays stepwise" in line and "depends on t" in line for line in recognise.describe(mlp))

@@ -615,3 +615,28 @@ def recognise(sde, t, y0, differentiable=False, times=None):
     found.users_tensors = interp.seen
     found._alive = interp.keep        # (the ids above stay meaningful for as long as this object lives)
     return found
+
+
+def describe(sde):
+    """What the recognised route has decided about `sde` so far, one line per form / refusal: the answer to "why is my
+    solve (not) one kernel launch?" (cf. `graph.describe_cache` for the stepwise route's launch graphs)."""
+    base = sde
+    while hasattr(base, "_base_sde"):
+        base = base._base_sde
+    book = getattr(base, "_tsde_recognised", None)
+    if not book:
+        return ["nothing recorded: no solve of this object has reached the recognised route (see the conditions in "
+                "solvers.BaseSDESolver._integrate_recognised: diagonal noise, fixed step, this package's BrownianInterval, "
+                "a CUDA state of at least 8 rows)"]
+    lines = []
+    for key, verdict in book["trusted"].items():
+        structure, _, solver, sde_type, d, dtype = key[:6]
+        kind = "perceptron drift" if structure[0][0] == "perceptron" else f"f: {structure[0][0]}, g: {structure[1][0]}"
+        timed = any("table" in part for part in structure if isinstance(part, tuple))
+        route = ("trajectory kernel" + (" with per-stage-time coefficient rows" if timed else "")
+                 + (" (sensitivity kernel: autograd)" if key[6:] == ("autograd",) else ""))
+        lines.append(f"[{solver}, {sde_type}, d = {d}, {dtype}] {kind}: "
+                     + (route if verdict is True else f"stays stepwise: {verdict}"))
+    for (_, _, solver), reason in book["refused"].items():
+        lines.append(f"[{solver}] stays stepwise: {reason}")
+    return lines
