@@ -435,7 +435,11 @@ class BaseSDESolver:
                 times = self._stage_times(ts, y0.device)
                 if times is None:
                     raise
-                found = recognise.recognise(sde, ts[0], y0, times=times)
+                try:
+                    found = recognise.recognise(sde, ts[0], y0, times=times)
+                except recognise.NotElementwise as e:
+                    raise recognise.NotElementwise("drift or diffusion depends on t, and not only through arithmetic that "
+                                                   f"broadcasts ({e})") from None
             spec = found.spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
