@@ -15,15 +15,17 @@ probe state of a few rows under a dispatch mode that follows every ATen operator
 and keeps, for each such value, the five per-channel coefficient tensors of the form above. Operators among tensors that
 do not depend on ``y`` (parameters, buffers, Python numbers) simply execute -- on (d,)-sized data -- so the coefficients
 are computed from the LIVE parameter values of this very solve: an optimiser step, a changed module global or closure
-are seen because the user's code has just run. Anything else -- a value derived from ``t``, an operator outside the
-small elementwise table, a reshape of the state, an in-place update of it, a per-row constant, `float(t)` -- ends the interpretation and the solve takes the stepwise path, as before.
+are seen because the user's code has just run. Anything else -- an operator outside the small elementwise table, a
+reshape of the state, an in-place update of it, a per-row constant, `float(t)` -- ends the interpretation and the solve
+takes the stepwise path, as before.
 
-Time. With t a 0-d tensor any arithmetic on t ends the interpretation (`DependsOnTime`). For the schemes that evaluate f
-and g at the start of a step only (Euler, Milstein) the caller then interprets once more with t = the (K, 1, 1) tensor of
-ALL step times: code that only ever broadcasts t (`beta(t) * y`, `torch.sqrt(self.b0 + t * self.b1)`) runs unchanged,
-values derived from the state become (K, rows, d), coefficients (K, 1, 1) or (K, 1, d) -- one row per step -- and the
-`_timed` trajectory kernels read row k at step k. Code that does anything else with t (`float(t)`, `if t > 0.5`, `cat`
-with the state, an index) fails on the (K, 1, 1) tensor by itself or leaves these shapes, and the solve stays stepwise.
+Time. With t a 0-d tensor any arithmetic on t ends the interpretation (`DependsOnTime`). The caller then interprets once
+more with t = the (K, 1, 1) tensor of ALL the times at which the scheme evaluates f and g (its stage times of every
+step): code that only ever broadcasts t (`beta(t) * y`, `torch.sqrt(self.b0 + t * self.b1)`) runs unchanged, values
+derived from the state become (K, rows, d), coefficients (K, 1, 1) or (K, 1, d) -- one row per stage time -- and the
+`_timed` trajectory kernels read those rows step by step. Code that does anything else with t (`float(t)`, `if t > 0.5`,
+`cat` with the state, a reshape, a reduction) fails on the (K, 1, 1) tensor by itself or leaves these shapes, and the
+solve stays stepwise.
 
 A second form is followed the same way: a drift that is a two-layer perceptron of the state shared by the batch,
 ``lin2(act(lin1(y)))`` with ``act`` tanh or softplus -- ``nn.Sequential(nn.Linear, nn.Softplus, nn.Linear)`` as in the
@@ -31,17 +33,19 @@ reference's latent-SDE examples (examples/latent_sde_lorenz.py:122-128) -- with 
 diffusion: the forms ``tsde_trajectory_mlp_diag`` (sampling) and ``tsde_adjoint_mlp_diag`` (``sdeint_adjoint``) integrate
 on the matrix cores. There the interpretation hands back the user's own parameter tensors, so that gradients reach them.
 
-Nothing here synchronises with the host (unless the user's code does, on its own constants). Whether a recognised form may be trusted is decided once per (Python-side state
-of the SDE object, form, scheme, shapes) by solving both ways and comparing (`solvers.BaseSDESolver._recognised`).
+Nothing here synchronises with the host (unless the user's code does, on its own constants). Whether a recognised form
+may be trusted is decided once per (form, scheme, state width, dtype) on each SDE object by solving both ways and
+comparing (`solvers.BaseSDESolver._integrate_recognised`); `describe(sde)` reports what was decided.
 """
+import os
+
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import _native
 
 # TSDE_RECOGNISE=0 switches the route off for the process (tests of the stepwise machinery also clear `ENABLED`)
-import os as _os
-ENABLED = _os.environ.get("TSDE_RECOGNISE", "1").strip().lower() not in ("0", "false", "off")
+ENABLED = os.environ.get("TSDE_RECOGNISE", "1").strip().lower() not in ("0", "false", "off")
 
 
 class NotElementwise(Exception):
