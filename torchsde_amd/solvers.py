@@ -428,8 +428,11 @@ class BaseSDESolver:
         times = None
         try:
             try:
+                if book.get("uses_t") == (chain, type(self).__name__):
+                    raise recognise.DependsOnTime("(remembered)")         # skip the pass that is known to end at t
                 found = recognise.recognise(sde, ts[0], y0)
             except recognise.DependsOnTime:
+                book["uses_t"] = (chain, type(self).__name__)
                 # f, g use t in their arithmetic: interpret once more with ALL the times at which this scheme evaluates them
                 # (its stage times of every step); the kernels then read one coefficient row per stage time
                 times = self._stage_times(ts, y0.device)
