@@ -213,7 +213,28 @@ inline int grid_for(int64_t work_items) {
 // 1 -> 13.4 us, 4 or 8 -> 13.3-13.7 us. Small problems keep QPT=1 so that every CU still gets >= 8 blocks.
 template <typename Op, int QPT, bool NT>
 __global__ void __launch_bounds__(kBlock) elementwise_kernel(const Op op, const int64_t n, const int vec) {
-  if (vec) {
+  if (vec == 2) {
+    // XCD-matched tiling (launch_elementwise; `TSDE_XCD_MATCH=0` switches it off). Workgroups go to the 8 XCDs round-robin, and so do the
+    // workgroups of the torch kernels that produced f and g just before this launch (and that will read y1 right
+    // after it): ATen's broadcasting elementwise kernel gives workgroup c the 512 consecutive elements c*512 ..
+    // (elementwise_kernel_manual_unroll<128, 4>), i.e. 128 16-byte groups, so chunk c was written through the L2 of XCD
+    // c % 8. This tiling hands block b the 128-group chunks c with c % 8 == b % 8 -- its own XCD's lines.
+    const int64_t nq = n >> 2;
+    const int64_t n_chunks = (nq + 127) >> 7;                         // 128-group chunks
+    const int64_t per_xcd = (n_chunks + 7) >> 3;                      // chunks whose index is = x (mod 8), upper bound
+    const int x = blockIdx.x & 7;
+    const int64_t lane_block = blockIdx.x >> 3, blocks_per_xcd = gridDim.x >> 3;
+    constexpr int kSub = (kBlock * QPT) / 128;                        // chunks per block iteration
+    for (int64_t j0 = lane_block * kSub; j0 < per_xcd; j0 += blocks_per_xcd * kSub) {
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        const int idx = u * kBlock + threadIdx.x;
+        const int64_t c = ((j0 + (idx >> 7)) << 3) + x;               // chunk index
+        const int64_t q = (c << 7) + (idx & 127);
+        if (q < nq) op.template run<4, NT>(q << 2);
+      }
+    }
+  } else if (vec) {
     const int64_t nq = n >> 2;
     constexpr int64_t kChunk = (int64_t)kBlock * QPT;
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < nq; base += (int64_t)gridDim.x * kChunk) {
@@ -242,6 +263,16 @@ inline bool use_streaming_variant(int64_t n, size_t elem_size) {
   return (uint64_t)n * elem_size >= (96ull << 20);
 }
 
+// The XCD-matched tiling of elementwise_kernel is the default; TSDE_XCD_MATCH=0 restores consecutive tiles (the on / off
+// measurement: profiles/r4_xcd_matched_tiling.txt -- stepwise GBM solves 8-20 % faster, nothing slower than 1 %).
+inline bool xcd_matched() {
+  static const bool on = [] {
+    const char* e = getenv("TSDE_XCD_MATCH");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 template <typename Op>
 inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStream_t stream, size_t elem_size = 4) {
   if (n <= 0) return hipSuccess;
@@ -252,10 +283,11 @@ inline hipError_t launch_elementwise(const Op& op, int64_t n, bool vec, hipStrea
     TSDE_LAUNCH((elementwise_kernel<Op, 1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, op, n, 1);
   } else if (vec && nq >= (int64_t)2 * kBlock * kMaxGrid) {
     TSDE_LAUNCH((elementwise_kernel<Op, 2, false>), dim3(grid_for((nq + 1) / 2)), dim3(kBlock), 0, stream, op,
-                       n, 1);
+                       n, xcd_matched() ? 2 : 1);
   } else {
-    TSDE_LAUNCH((elementwise_kernel<Op, 1, false>), dim3(grid_for(vec ? nq : n)), dim3(kBlock), 0, stream, op,
-                       n, vec ? 1 : 0);
+    const int grid = grid_for(vec ? nq : n);
+    TSDE_LAUNCH((elementwise_kernel<Op, 1, false>), dim3(grid), dim3(kBlock), 0, stream, op,
+                       n, vec ? ((xcd_matched() && grid >= 8 && grid % 8 == 0) ? 2 : 1) : 0);
   }
   return hipGetLastError();
 }
