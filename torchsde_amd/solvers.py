@@ -637,20 +637,28 @@ class BaseSDESolver:
         if cells is None:
             return None
         cells = np.asarray(cells, dtype=np.int64)
-        np_dtype = grid.t.dtype.type
-        dt = grid.dt
         h = bm._edges[cells + 1] - bm._edges[cells]
-        rows = np.zeros((grid.n_steps, 8), dtype=np.float64)
-        # each entry is rounded in ts.dtype like the stepwise path's scalars, then (below) cast to the state dtype
-        rows[:, 0] = dt
-        rows[:, 1] = np_dtype(0.5) * dt
-        rows[:, 2] = np_dtype(1) / dt
-        rows[:, 3] = np.sqrt(dt)
-        rows[:, 4] = np.sqrt(h)
-        rows[:, 5] = np.sqrt(h / 12.0)
-        rows[:, 6] = h
-        out_step = [kc for (_, kc, _, _) in grid.outputs]
-        out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
+        # (the step rows of a grid the process has just seen -- every iteration of a training loop: remembered on the
+        #  grid object, which timegrid.build hands back for equal (ts, dt); valid for these cell widths)
+        memo = getattr(grid, "_step_rows", None)
+        if memo is not None and memo[0].shape == h.shape and np.array_equal(memo[0], h):
+            rows, out_step, out_w = memo[1:]
+        else:
+            np_dtype = grid.t.dtype.type
+            dt = grid.dt
+            rows = np.zeros((grid.n_steps, 8), dtype=np.float64)
+            # each entry is rounded in ts.dtype like the stepwise path's scalars, then (below) cast to the state dtype
+            rows[:, 0] = dt
+            rows[:, 1] = np_dtype(0.5) * dt
+            rows[:, 2] = np_dtype(1) / dt
+            rows[:, 3] = np.sqrt(dt)
+            rows[:, 4] = np.sqrt(h)
+            rows[:, 5] = np.sqrt(h / 12.0)
+            rows[:, 6] = h
+            rows.setflags(write=False)
+            out_step = [kc for (_, kc, _, _) in grid.outputs]
+            out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
+            grid._step_rows = (h.copy(), rows, out_step, out_w)
         if coefficients[0] == "mlp_differentiable":
             if any(not (w0 == 0.0 and w1 == 1.0) for (w0, w1) in out_w):
                 return None
