@@ -489,3 +489,31 @@ def test_describe_says_which_route_and_why():
     mlp = problems.make("mlpdiag_ito", d=D).to(DEV)
     _solve(mlp, 1)
     assert any("stays stepwise" in line and "depends on t" in line for line in recognise.describe(mlp))
+
+
+@pytest.mark.parametrize("method,levy", [("euler", "none"), ("srk", "space-time")])
+def test_full_size_time_dependent_sde_on_the_timed_kernels_rows_vs_oracle(method, levy):
+    """65536 x 64 x 1000 steps of the scheduled SDE (coefficients depend on t) through tsde_trajectory_affine_diag_timed:
+    sampled rows against the oracle's restatement of the reference's loop on the same Brownian path, with the bound the
+    other full-size tests use (max |hip32 - ref64| <= 4 max |ref32 - ref64| + 1e-6 scale)."""
+    import torchsde_amd
+    from tests import helpers
+    from tests.test_gpu_full_size_oracle import _bm, _oracle_forward
+    Bf, d, n, dt = 65536, 64, 1000, 2.0 ** -10
+    sde = problems.ScheduledDiag(d).to(DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            torchsde_amd.sdeint(sde, y0[:256], ts, bm=_bm(256, d, n, dt, 5, levy=levy), method=method, dt=dt)   # earns trust
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=_bm(Bf, d, n, dt, 20240601, levy=levy),
+                                                                 method=method, dt=dt))
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True]
+        rows = helpers.sampled_rows(Bf, 48, seed=4, seams=(32, Bf - 32))
+        ref32, ref64 = _oracle_forward(sde, rows, d, d, 20240601, n, dt, method, 0.1, levy=levy != "none")
+        new = ys[-1][torch.from_numpy(rows).to(DEV)]
+        helpers.assert_within_reference_rounding(new, ref32[-1], ref64[-1], f"scheduled SDE, {method}, timed kernel")
+    finally:
+        torch.set_num_threads(before)
