@@ -517,3 +517,44 @@ def test_full_size_time_dependent_sde_on_the_timed_kernels_rows_vs_oracle(method
         helpers.assert_within_reference_rounding(new, ref32[-1], ref64[-1], f"scheduled SDE, {method}, timed kernel")
     finally:
         torch.set_num_threads(before)
+
+
+def test_other_ways_of_providing_drift_and_diffusion():
+    """The contract lets a module provide `f_and_g` instead of `f` and `g`, or other method names through `names=`
+    (sdeint.py:199-243, base_sde.py:51-73): the interpretation runs whatever `ForwardSDE` resolved."""
+    import torchsde_amd
+
+    class Both(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.mu = nn.Parameter(torch.linspace(-0.5, 0.5, D))
+
+        def f_and_g(self, t, y):
+            return self.mu * y, 0.3 * torch.tanh(y)
+
+    class Renamed(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.mu = nn.Parameter(torch.linspace(-0.5, 0.5, D))
+
+        def drift(self, t, y):
+            return self.mu * y
+
+        def vol(self, t, y):
+            return 0.3 * torch.tanh(y)
+
+    y0 = torch.full((B, D), 0.1, device=DEV)
+    ts = torch.tensor([0.0, STEPS * DT], device=DEV)
+    for sde, kw in ((Both().to(DEV), {}), (Renamed().to(DEV), {"names": {"drift": "drift", "diffusion": "vol"}})):
+        def solve(entropy, options):
+            bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, D), device=DEV, entropy=entropy)
+            with torch.no_grad():
+                return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=DT, options=options, **kw)
+        solve(1, {"hip_graph": False})
+        fast, n = _launches(lambda: solve(2, {"hip_graph": False}))
+        assert n == 1, type(sde).__name__
+        torch.testing.assert_close(fast, solve(2, {"hip_graph": False, "trajectory_kernel": False}), rtol=5e-6, atol=5e-7)
