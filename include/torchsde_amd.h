@@ -411,6 +411,9 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
 #define TSDE_FN_SOFTPLUS 4
 #define TSDE_FN_SIN 5
 #define TSDE_FN_COS 6
+/* kind 7: no phi -- the four coefficients are those of a cubic, f = ((coef[0] * y + coef[1]) * y + coef[2]) * y + coef[3]
+ * (likewise g from coef[4..7]): double-well and logistic drifts, quadratic diffusions. */
+#define TSDE_FN_POLY3 7
 int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8], int f_kind,
                               int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                               const uint64_t* entropy_dev, int dtype, void* stream);

@@ -558,3 +558,59 @@ def test_other_ways_of_providing_drift_and_diffusion():
         fast, n = _launches(lambda: solve(2, {"hip_graph": False}))
         assert n == 1, type(sde).__name__
         torch.testing.assert_close(fast, solve(2, {"hip_graph": False, "trajectory_kernel": False}), rtol=5e-6, atol=5e-7)
+
+
+class _DoubleWell(nn.Module):
+    """dy = (y - y^3) dt + sigma (1 + y^2 / 2) dW: the drift is a sum of two functions of the state, the diffusion a
+    quadratic -- polynomials, which the expression kernel evaluates as cubics (TSDE_FN_POLY3)."""
+    noise_type = "diagonal"
+
+    def __init__(self, sde_type="ito"):
+        super().__init__()
+        self.sde_type = sde_type
+        self.sigma = nn.Parameter(torch.linspace(0.1, 0.3, D))
+        self.rate = nn.Parameter(torch.tensor(1.0))
+
+    def f(self, t, y):
+        return self.rate * (y - y ** 3)
+
+    def g(self, t, y):
+        return self.sigma * (1.0 + 0.5 * y * y)
+
+
+class _Logistic(nn.Module):
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, sde_type="ito"):
+        super().__init__()
+        self.r = nn.Parameter(torch.linspace(0.5, 1.5, D))
+
+    def f(self, t, y):
+        return self.r * y * (1.0 - y / (1.5 + torch.cos(t)))           # the capacity moves with t
+
+    def g(self, t, y):
+        return 0.2 * y
+
+
+@pytest.mark.parametrize("make,method,levy,sde_type", [
+    (_DoubleWell, "euler", "none", "ito"), (_DoubleWell, "milstein", "none", "ito"),
+    (_DoubleWell, "milstein", "none", "stratonovich"), (_DoubleWell, "srk", "space-time", "ito"),
+    (_DoubleWell, "midpoint", "none", "stratonovich"), (_Logistic, "euler", "none", "ito"),
+    (_Logistic, "srk", "space-time", "ito")])
+def test_polynomial_drift_and_diffusion_take_the_expression_kernel(make, method, levy, sde_type):
+    import torchsde_amd
+    sde = make(sde_type).to(DEV)
+    y0 = (0.2 + 0.6 * torch.rand(B, D, generator=torch.Generator().manual_seed(1))).to(DEV)
+    ts = torch.tensor([0.0, 0.13, 0.5], device=DEV)
+
+    def solve(entropy, stepwise=False):
+        bm = torchsde_amd.BrownianInterval(0.0, 0.5, size=(B, D), device=DEV, entropy=entropy,
+                                           levy_area_approximation=levy)
+        options = {"hip_graph": False, "trajectory_kernel": False} if stepwise else {"hip_graph": False}
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.01, options=options)
+    assert torch.equal(solve(1), solve(1, stepwise=True))
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast, n = _launches(lambda: solve(2))
+    assert n == 1
+    torch.testing.assert_close(fast, solve(2, stepwise=True), rtol=5e-5, atol=5e-6)

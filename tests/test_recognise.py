@@ -17,6 +17,9 @@ PHI = {"identity": lambda u: u, "exp": torch.exp, "sigmoid": torch.sigmoid, "tan
 
 def _value(form, y):
     """scale * phi(rate * y + shift) + offset with None as the neutral element (what the kernels evaluate)."""
+    if form.phi == "poly3":
+        c3, c2, c1, c0 = (0.0 if c is None else c for c in (form.scale, form.rate, form.shift, form.offset))
+        return ((c3 * y + c2) * y + c1) * y + c0
     if form.constant():
         c = recognise._add(form.shift, form.offset)
         return torch.zeros_like(y) + (0.0 if c is None else c)
@@ -80,7 +83,6 @@ def test_followed_forms_evaluate_to_the_users_code(name):
 REFUSED = {
     "depends on t": (lambda s, t, y: torch.sin(t) * y, "depends on t"),
     "reads t on the host": (lambda s, t, y: float(t) * y, "reads t on the host"),
-    "quadratic": (lambda s, t, y: y * y, "product of two functions"),
     "matrix product": (lambda s, t, y: y @ torch.eye(D), "drift is not"),
     "nested functions": (lambda s, t, y: torch.tanh(torch.exp(y)), "nested"),
     "per-row constant": (lambda s, t, y: y * torch.ones(16, 1), "RuntimeError"),
@@ -271,3 +273,38 @@ def test_other_uses_of_t_end_the_interpretation(name, f):
             recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D))
         except recognise.DependsOnTime:
             recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D), times=times)
+
+
+POLYNOMIALS = {
+    "double well": (lambda s, t, y: y - y ** 3, lambda s, t, y: s.sigma * torch.ones_like(y)),
+    "logistic growth": (lambda s, t, y: s.sigma * y * (1.0 - y / 2.5), lambda s, t, y: 0.2 * y),
+    "quadratic diffusion": (lambda s, t, y: -y, lambda s, t, y: s.sigma * y * y + 0.1),
+    "square of an affine": (lambda s, t, y: (s.mu * y + s.b) ** 2, lambda s, t, y: torch.square(y) - y),
+    "cubic by products": (lambda s, t, y: (y - 1.0) * (y + s.b) * (0.5 * y - s.mu), lambda s, t, y: -(y * y) * s.w),
+    "sum of polynomials": (lambda s, t, y: (y ** 2 - s.b) + (y ** 3) * 0.1 - 2 * (y * y), lambda s, t, y: 1.0 - y ** 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(POLYNOMIALS))
+def test_polynomials_of_the_state_up_to_degree_three(name):
+    """Sums and products of affine functions of the state (double-well and logistic drifts, quadratic diffusions) come
+    back as cubics (TSDE_FN_POLY3: the expression kernel with ((c3 y + c2) y + c1) y + c0 in place of phi)."""
+    f, g = POLYNOMIALS[name]
+    sde = _M(f, g)
+    y, t = 0.7 * torch.randn(16, D), torch.tensor(0.3)
+    found = recognise.recognise(ForwardSDE(sde), t, y)
+    torch.testing.assert_close(_value(found.f, y), sde.f(t, y).detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(_value(found.g, y), sde.g(t, y).detach(), rtol=2e-5, atol=2e-5)
+    kind, fk, gk, *coefs = found.spec()
+    assert kind == "elementwise_diagonal" and 7 in (fk, gk) and not found.exact and found.affine_leaves() is None
+    for code, c4, fn in ((fk, coefs[:4], f), (gk, coefs[4:], g)):
+        if code == 7:
+            got = ((c4[0] * y + c4[1]) * y + c4[2]) * y + c4[3]
+            torch.testing.assert_close(got, fn(sde, t, y).detach(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("f", [lambda s, t, y: y ** 4, lambda s, t, y: (y * y) * (y * y), lambda s, t, y: torch.exp(y * y),
+                               lambda s, t, y: torch.tanh(y) * y, lambda s, t, y: (y ** 2) * torch.sin(y)])
+def test_higher_degrees_and_functions_of_polynomials_are_refused(f):
+    with pytest.raises(recognise.NotElementwise):
+        recognise.recognise(ForwardSDE(_M(f, lambda s, t, y: y)), torch.tensor(0.3), torch.randn(16, D))

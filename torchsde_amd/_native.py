@@ -19,7 +19,7 @@ TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
-FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6}
+FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6, "poly3": 7}
 
 # include/torchsde_amd.h: the device tables of adaptive stepping (TSDE_CTL_*, TSDE_SUB_*, TSDE_SCAL_*)
 ADAPTIVE_MAX_STAGES = 6

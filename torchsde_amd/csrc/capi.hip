@@ -550,7 +550,7 @@ int tsde_trajectory_expr_diag_timed(void* ys, const void* y0, int64_t rows, int6
     if (!coef[c]) return bad_arg(where, "null coefficient array");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
   if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
-  if (f_kind < TSDE_FN_IDENTITY || f_kind > TSDE_FN_COS || g_kind < TSDE_FN_IDENTITY || g_kind > TSDE_FN_COS)
+  if (f_kind < TSDE_FN_IDENTITY || f_kind > TSDE_FN_POLY3 || g_kind < TSDE_FN_IDENTITY || g_kind > TSDE_FN_POLY3)
     return bad_arg(where, "unknown function code");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");

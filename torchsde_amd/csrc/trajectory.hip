@@ -242,13 +242,22 @@ template <typename T>
 struct ExprModel {
   T fa, fp, fq, fb, ga, gp, gq, gb;
   int fk, gk;
+  // kind TSDE_FN_POLY3: the four coefficients are those of a cubic, ((c3 x + c2) x + c1) x + c0 (a drift such as y - y^3,
+  // logistic growth, a quadratic diffusion): sums and products of several affine functions of the state
   template <int SLOT>
-  TSDE_D T f(const T& x) const { return fa * expr_phi<T>(fk, fp * x + fq) + fb; }
+  TSDE_D T f(const T& x) const {
+    if (fk == TSDE_FN_POLY3) return ((fa * x + fp) * x + fq) * x + fb;
+    return fa * expr_phi<T>(fk, fp * x + fq) + fb;
+  }
   template <int SLOT>
-  TSDE_D T g(const T& x) const { return ga * expr_phi<T>(gk, gp * x + gq) + gb; }
+  TSDE_D T g(const T& x) const {
+    if (gk == TSDE_FN_POLY3) return ((ga * x + gp) * x + gq) * x + gb;
+    return ga * expr_phi<T>(gk, gp * x + gq) + gb;
+  }
   // (g v) g'(x), the chain rule in the order autograd walks scale * phi(rate * x + shift) + offset backwards
   template <int SLOT>
   TSDE_D T gdg(const T& x, const T& gv, T v2) const {
+    if (gk == TSDE_FN_POLY3) return (gv * v2) * ((((T)3 * ga) * x + (T)2 * gp) * x + gq);
     const T u = gp * x + gq;
     return (((gv * v2) * ga) * expr_dphi<T>(gk, u, expr_phi<T>(gk, u))) * gp;
   }
@@ -260,11 +269,18 @@ struct ExprModelTimed {
   T k[NS][8];          // fa, fp, fq, fb, ga, gp, gq, gb
   int fk, gk;
   template <int SLOT>
-  TSDE_D T f(const T& x) const { return k[SLOT][0] * expr_phi<T>(fk, k[SLOT][1] * x + k[SLOT][2]) + k[SLOT][3]; }
+  TSDE_D T f(const T& x) const {
+    if (fk == TSDE_FN_POLY3) return ((k[SLOT][0] * x + k[SLOT][1]) * x + k[SLOT][2]) * x + k[SLOT][3];
+    return k[SLOT][0] * expr_phi<T>(fk, k[SLOT][1] * x + k[SLOT][2]) + k[SLOT][3];
+  }
   template <int SLOT>
-  TSDE_D T g(const T& x) const { return k[SLOT][4] * expr_phi<T>(gk, k[SLOT][5] * x + k[SLOT][6]) + k[SLOT][7]; }
+  TSDE_D T g(const T& x) const {
+    if (gk == TSDE_FN_POLY3) return ((k[SLOT][4] * x + k[SLOT][5]) * x + k[SLOT][6]) * x + k[SLOT][7];
+    return k[SLOT][4] * expr_phi<T>(gk, k[SLOT][5] * x + k[SLOT][6]) + k[SLOT][7];
+  }
   template <int SLOT>
   TSDE_D T gdg(const T& x, const T& gv, T v2) const {
+    if (gk == TSDE_FN_POLY3) return (gv * v2) * ((((T)3 * k[SLOT][4]) * x + (T)2 * k[SLOT][5]) * x + k[SLOT][6]);
     const T u = k[SLOT][5] * x + k[SLOT][6];
     return (((gv * v2) * k[SLOT][4]) * expr_dphi<T>(gk, u, expr_phi<T>(gk, u))) * k[SLOT][5];
   }

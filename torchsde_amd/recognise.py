@@ -119,6 +119,45 @@ def _times(a, c):
     return None if a is None else a * c
 
 
+# ---- cubic polynomials of the state: sums and products of affine functions (y - y**3, r * y * (1 - y / K)) -----------
+# A polynomial is (c3, c2, c1, c0), each a per-channel coefficient or None (= 0). As a `_Form` it has phi "poly3" and
+# keeps its coefficients in the slots (scale, rate, shift, offset) -- the order TSDE_FN_POLY3 reads them in.
+def _padd(a, b):
+    return b if a is None else a if b is None else a + b
+
+
+def _pmul(a, b):
+    return None if a is None or b is None else a * b
+
+
+def _as_poly(form):
+    """(c3, c2, c1, c0) of a form that is a polynomial of the state (a plain `rate * y + shift`, or a cubic), else None."""
+    if form.constant():
+        return None
+    if form.phi == "poly3":
+        return (form.scale, form.rate, form.shift, form.offset)
+    if form.phi == "identity" and form.scale is None and form.offset is None:
+        return (None, None, 1.0 if form.rate is None else form.rate, form.shift)
+    return None
+
+
+def _poly_form(c):
+    return _Form("poly3", c[0], c[1], c[2], c[3], exact=False)
+
+
+def _poly_product(p, q):
+    """Product of two polynomials given as (c3, c2, c1, c0); NotElementwise beyond degree 3."""
+    out = [None] * 7                                      # coefficient of y^k at index k
+    for i, a in enumerate(reversed(p)):                   # i = power of a
+        for j, b in enumerate(reversed(q)):
+            term = _pmul(a, b)
+            if term is not None:
+                out[i + j] = _padd(out[i + j], term)
+    if any(c is not None for c in out[4:]):
+        raise NotElementwise("a polynomial of the state of degree above 3")
+    return (out[3], out[2], out[1], out[0])
+
+
 class _Interpreter(TorchDispatchMode):
     def __init__(self, y, t, rows, d, steps=None):
         super().__init__()
@@ -170,6 +209,8 @@ class _Interpreter(TorchDispatchMode):
     # ---- the algebra ---------------------------------------------------------------------------------------------
     def scaled(self, x, c, exact=True):
         """x * c for a per-channel c."""
+        if x.phi == "poly3":
+            return _poly_form(tuple(_pmul(k, c) for k in _as_poly(x)))
         if x.constant():
             return _Form(rate=ZERO, shift=_times(_add(x.shift, x.offset), c), exact=x.exact)
         if x.phi == "identity" and x.scale is None and x.offset is None:
@@ -181,6 +222,9 @@ class _Interpreter(TorchDispatchMode):
 
     def shifted(self, x, c):
         """x + c for a per-channel c."""
+        if x.phi == "poly3":
+            p = _as_poly(x)
+            return _poly_form((p[0], p[1], p[2], _padd(p[3], c)))
         if x.constant():
             return _Form(rate=ZERO, shift=_add(_add(x.shift, x.offset), c), exact=x.exact)
         if x.phi == "identity" and x.scale is None and x.offset is None:
@@ -188,6 +232,8 @@ class _Interpreter(TorchDispatchMode):
         return _Form(x.phi, x.scale, x.rate, x.shift, _add(x.offset, c), exact=x.exact and x.offset is None)
 
     def negated(self, x):
+        if x.phi == "poly3":
+            return _poly_form(tuple(_neg(k) for k in _as_poly(x)))
         if x.constant():
             return _Form(rate=ZERO, shift=_neg(_add(x.shift, x.offset)), exact=x.exact)
         if x.phi == "identity" and x.scale is None and x.offset is None:
@@ -203,6 +249,11 @@ class _Interpreter(TorchDispatchMode):
             c = _add(x.shift, x.offset)
             z = z if sign == 1.0 else self.negated(z)
             return self.shifted(z, c) if c is not None else z
+        p, q = _as_poly(x), _as_poly(z)
+        if p is not None and q is not None and "poly3" in (x.phi, z.phi):
+            if sign != 1.0:
+                q = tuple(_neg(k) for k in q)
+            return _poly_form(tuple(_padd(a, b) for a, b in zip(p, q)))
         if x.phi == "identity" and z.phi == "identity" and all(v.scale is None and v.offset is None for v in (x, z)):
             one = 1.0
             zr, zs = (one if z.rate is None else z.rate), z.shift
@@ -218,7 +269,10 @@ class _Interpreter(TorchDispatchMode):
         if x.constant():
             c = _add(x.shift, x.offset)
             return self.scaled(z, 0.0 if c is None else c)
-        raise NotElementwise("a product of two functions of the state")
+        p, q = _as_poly(x), _as_poly(z)
+        if p is not None and q is not None:
+            return _poly_form(_poly_product(p, q))
+        raise NotElementwise("a product of two functions of the state that are not both polynomials")
 
     def applied(self, name, x):
         if x.constant():
@@ -422,6 +476,15 @@ class _Interpreter(TorchDispatchMode):
             return self.track(out, form)
         if name == "pow" and x is not None and len(args) == 2 and isinstance(args[1], (int, float)) and args[1] == 1:
             return self.track(out, x)
+        if (name == "pow" and x is not None and len(args) == 2 and isinstance(args[1], (int, float))
+                and args[1] in (2, 3)) or (name == "square" and x is not None):
+            p = _as_poly(x)
+            if p is None:
+                raise NotElementwise(f"a power of {x.phi}")
+            q = p
+            for _ in range(1 if name == "square" else int(args[1]) - 1):
+                q = _poly_product(q, p)
+            return self.track(out, _poly_form(q))
         raise NotElementwise(f"operator {schema.name} on a value derived from the state")
 
 
@@ -477,6 +540,8 @@ class Recognised:
         return any(torch.is_tensor(c) and c.dim() == 3 for v in forms for c in (v.scale, v.rate, v.shift, v.offset))
 
     def _four(self, form):
+        if form.phi == "poly3":     # (c3, c2, c1, c0): every missing coefficient is 0
+            return tuple(self._vector(c, 0.0) for c in (form.scale, form.rate, form.shift, form.offset))
         if form.constant():         # the value is `shift (+ offset)`: rate 0, identity
             return (self._vector(None, 1.0), self._vector(None, 0.0), self._vector(_add(form.shift, form.offset), 0.0),
                     self._vector(None, 0.0))
