@@ -655,7 +655,6 @@ class BaseSDESolver:
             rows[:, 4] = np.sqrt(h)
             rows[:, 5] = np.sqrt(h / 12.0)
             rows[:, 6] = h
-            rows.setflags(write=False)
             out_step = [kc for (_, kc, _, _) in grid.outputs]
             out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
             grid._step_rows = (h.copy(), rows, out_step, out_w)
