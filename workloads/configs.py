@@ -50,6 +50,15 @@ WORKLOADS = {
         problem="scheduled_diag", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
         kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
+    # a polynomial SDE (double well, quadratic diffusion): TSDE_FN_POLY3 in the expression kernel; stepwise counterpart below
+    "c2_euler_doublewell_default_route_b65536_d64_s1000": dict(
+        problem="double_well", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_expr_diag<float, euler> (user module recognised: cubic drift, quadratic diffusion)"),
+    "c2_euler_doublewell_b65536_d64_s1000": dict(
+        problem="double_well", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
     # BASELINE.json configs[1], STEPWISE (options={"trajectory_kernel": False}): the user's f and g run as torch kernels
     # between the per-step kernels -- the route of every SDE that is not a per-channel expression
     "c2_euler_diag_b65536_d64_s1000": dict(
@@ -206,6 +215,8 @@ def make_problem(name, d, m, dev):
         return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
     if name == "latent_diag":      # latent-SDE-style diagonal SDE
         return problems.LatentDiag(d).to(dev)
+    if name == "double_well":
+        return problems.DoubleWell(d).to(dev)
     if name == "scheduled_diag":
         return problems.ScheduledDiag(d).to(dev)
     if name == "exp_diffusion":    # the reference's own benchmark SDE (benchmarks/brownian.py:131-139): f = y, g = exp(-y)

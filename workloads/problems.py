@@ -227,6 +227,23 @@ class ScheduledDiag(nn.Module):
         return torch.sqrt(self.beta(t)) * self.sigma * torch.ones_like(y)
 
 
+class DoubleWell(nn.Module):
+    """dy = (y - y^3) dt + sigma (1 + y^2 / 2) dW, per channel: a drift that is a SUM of functions of the state and a
+    quadratic diffusion -- polynomials (the textbook bistable system)."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, d, seed=5):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.sigma = nn.Parameter((0.3 * _sigmoid_randn(gen, d)).to(torch.float32))
+
+    def f(self, t, y):
+        return y - y ** 3
+
+    def g(self, t, y):
+        return self.sigma * (1.0 + 0.5 * y * y)
+
+
 class ReadmeSDE(nn.Module):
     """The README quick example: general Ito noise, linear drift, linear diffusion reshaped to (B, d, m)."""
     noise_type = "general"
