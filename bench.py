@@ -61,6 +61,9 @@ from workloads.configs import WORKLOADS, make_problem as _make_problem  # noqa: 
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-in/f32-accumulate matrix rate (same guide)
+# vector-issue capacity: 256 CUs x 4 SIMD-32 units, one wave64 VALU instruction occupying its SIMD for >= 2 cycles
+# (same guide); in units of 1e12 SIMD cycles per second at the nominal 2.4 GHz
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 1e12
 HEADLINE = "c2_euler_diag_default_route_b65536_d64_s1000"
 # the stepwise BASELINE configurations, then what the closed-form route makes of the same jobs
 ALSO = ("c2_milstein_diag", "c2_srk_diag",
@@ -400,25 +403,50 @@ class Job:
                             "guides/MI355X_MICROARCH.md",
                     "timing": "HIP events bracketing every launch of this kernel in 8 eagerly issued solves"}
         if self.trajectory and c.get("bytes_per_traj_step"):
-            # One launch is the whole solve: B x nsteps trajectory-steps. `achieved` prices it as the contract says --
-            # SURVEY 8d's bytes per trajectory-step x the units one launch processes / its duration -- and comes out ABOVE
-            # the HBM peak, because those bytes never reach HBM: the state lives in registers, the increments come from
-            # the counter RNG, f and g are evaluated in the kernel. `traffic` is what the launch really moves.
+            # One launch is the whole solve: B x nsteps trajectory-steps with the state in registers, the increments from
+            # the counter RNG and f, g evaluated in the kernel. It moves y0 in and the outputs out -- SURVEY 8d's bytes per
+            # trajectory-step never reach HBM -- so its roof is the rate at which a SIMD ISSUES vector instructions:
+            #   achieved = (issue cycles of the step loop's VALU instructions per wave-step: the loop's instruction histogram
+            #               from the compiled kernel x per-instruction issue cycles measured on the device,
+            #               tools/valu_model.py + tools/microbench_valu.hip) x wave-steps per launch / launch duration
+            #   peak     = 1024 SIMDs x 2.4e9 cycles/s (every SIMD issuing VALU work every cycle at the nominal clock)
+            # `hbm_equivalent` keeps the contract's byte-priced number (above the HBM peak by construction).
             per_launch = c["bytes_per_traj_step"] * B * nsteps
-            achieved = per_launch / raw_s / 1e9
             moved = 2 * B * d * 4
-            return {"bound": "hbm", "kernel": c["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS,
-                    "frac_is": "SURVEY 8d bytes per trajectory-step x trajectory-steps per launch / launch time / peak; above 1 "
-                               "because a one-launch solve keeps those bytes in registers (VALU-bound: Philox + Box-Muller)",
-                    "bytes_per_traj_step": c["bytes_per_traj_step"], "bytes_per_launch": per_launch,
-                    "solve_achieved": c["bytes_per_traj_step"] * value / self.world / 1e9,
-                    "solve_frac": c["bytes_per_traj_step"] * value / self.world / 1e9 / HBM_PEAK_GBPS,
-                    "traffic": moved, "traffic_is": "HBM bytes one launch really moves: y0 in, final state out",
-                    "traffic_over_algorithmic": moved / per_launch,
+            hbm = {"is": "SURVEY 8d bytes per trajectory-step x trajectory-steps per launch / launch time: what a "
+                         "one-kernel-per-step design would have to stream to keep up; NOT a fraction of anything this "
+                         "kernel is bound by",
+                   "achieved_GBps": per_launch / raw_s / 1e9, "over_hbm_peak": per_launch / raw_s / 1e9 / HBM_PEAK_GBPS,
+                   "bytes_per_traj_step": c["bytes_per_traj_step"], "bytes_per_launch": per_launch,
+                   "solve_achieved_GBps": c["bytes_per_traj_step"] * value / self.world / 1e9,
+                   "solve_over_hbm_peak": c["bytes_per_traj_step"] * value / self.world / 1e9 / HBM_PEAK_GBPS}
+            roof = {"bound": "valu", "kernel": c["kernel"], "traffic": moved,
+                    "traffic_is": "HBM bytes one launch really moves: y0 in, final state out",
+                    "traffic_over_hbm_equivalent": moved / per_launch, "hbm_equivalent": hbm,
                     "avg_launch_us": raw_s * 1e6, "launches_timed": k_launches, "launches_per_solve": 1,
                     "element_steps_per_s": B * d * nsteps / raw_s,
                     "timing": "HIP events bracketing the single launch of each of 8 eagerly issued solves"}
+            model = _valu_model(self.name)
+            if model is None:
+                roof.update(achieved=None, peak=VALU_ISSUE_PEAK, unit="T SIMD issue-cycles/s", frac=None,
+                            frac_is="no VALU model for this kernel instantiation (tools/valu_model.py)")
+                return roof
+            lanes = B * d // model["elements_per_lane_step"]
+            wave_steps = (lanes + 63) // 64 * nsteps
+            issue_cycles = model["issue_cycles_per_wave_step"] * wave_steps
+            achieved = issue_cycles / raw_s / 1e12
+            roof.update(achieved=achieved, peak=VALU_ISSUE_PEAK, unit="T SIMD issue-cycles/s", frac=achieved / VALU_ISSUE_PEAK,
+                        frac_is="VALU issue cycles of the step loop x wave-steps per launch / (1024 SIMDs x 2.4 GHz x launch "
+                                "time): the share of the chip's vector-issue capacity the launch used for the loop's own "
+                                "instructions at their measured issue cost",
+                        wave_steps_per_launch=wave_steps,
+                        issue_cycles_per_wave_step=model["issue_cycles_per_wave_step"],
+                        valu_instructions_per_wave_step=model["valu_instructions_per_wave_step"],
+                        frac_if_every_instruction_took_2_cycles=model["issue_cycles_per_wave_step_all_plain"] * wave_steps
+                        / raw_s / 1e12 / VALU_ISSUE_PEAK,
+                        model_source=model.get("source"), rates=model.get("rates"))
+            _attach_headline_pmc(roof, self.name)
+            return roof
         if self.trajectory:
             # One launch per solve: it reads y0 and writes the requested outputs, nothing else touches HBM. The kernel is
             # bound by the VALU work of the counter RNG (Philox-4x32-10 + Box-Muller per element-step) and of f, g.
@@ -469,6 +497,66 @@ class Job:
             roof["moved_is"] = ("bytes the implementation's kernels stream per trajectory-step (DESIGN.md: 23 streams for "
                                 "SRID2 with user code between the stages vs the 16 of SURVEY 8d)")
         return roof
+
+
+_VALU_MODELS = {}
+_TRAJ_METHOD_CODES = {("euler", "ito"): 0, ("milstein", "ito"): 1, ("milstein", "stratonovich"): 2,
+                      ("midpoint", "stratonovich"): 3, ("srk", "ito"): 4}        # include/torchsde_amd.h TSDE_TRAJ_*
+
+
+def _valu_model(name):
+    """The VALU-issue model of a workload's trajectory kernel (tools/valu_model.py) -- the constant-coefficient affine
+    kernels with one 16-byte group per lane, i.e. the GBM workloads at their benchmark sizes -- from
+    profiles/valu_model_latest.json when that file was made from the kernel sources this run uses, else computed now
+    (hipcc -S of trajectory.hip, ~25 s, no GPU involved); None for other kernels or when neither is possible."""
+    cfg = WORKLOADS[name]
+    if not cfg["problem"].startswith("gbm_") or cfg.get("train") or cfg["B"] * cfg["d"] // 4 < 256 * 8 * 64:
+        return None
+    sde_type = "stratonovich" if "strat" in cfg["problem"] else "ito"
+    code = _TRAJ_METHOD_CODES.get((cfg["method"], sde_type))
+    if code is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_model
+    symbol = valu_model.affine_symbol(code)
+    if symbol in _VALU_MODELS:
+        return _VALU_MODELS[symbol]
+    digest = csrc_digest()
+    rec = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_model_latest.json")) as fh:
+            on_file = json.load(fh)
+        if on_file.get("csrc_sha") == digest and symbol in on_file.get("kernels", {}):
+            rec = dict(on_file["kernels"][symbol], source=f"profiles/valu_model_latest.json @ csrc {digest}")
+    except (OSError, ValueError):
+        pass
+    if rec is None:
+        try:
+            rec = dict(valu_model.model(symbol), source=f"computed by this run @ csrc {digest}")
+        except Exception as e:        # no hipcc on this host, or the loop could not be cut out
+            print(f"[bench] no VALU model: {type(e).__name__}: {e}", file=sys.stderr)
+    _VALU_MODELS[symbol] = rec
+    return rec
+
+
+def _attach_headline_pmc(roofline, workload):
+    """SQ counters of the same kernel from a rocprofv3 --pmc run of this workload (tools/profile_trajectory.sh ->
+    profiles/headline_pmc_latest.json), attached only if they were collected on the kernel sources this run uses:
+    instructions per wave-step as the hardware counted them, and the share of the kernel's cycles in which the VALU was
+    busy -- the counter-side cross-check of the model's fraction."""
+    path = os.path.join(ROOT, "profiles", "headline_pmc_latest.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return
+    digest = csrc_digest()
+    if rec.get("csrc_sha") != digest or rec.get("workload") != workload:
+        roofline["pmc"] = (f"profiles/headline_pmc_latest.json is for {rec.get('workload')} @ csrc {rec.get('csrc_sha')}; this "
+                           f"run is {workload} @ {digest}: stale, not reported (re-run tools/profile_trajectory.sh)")
+        return
+    roofline["pmc"] = {k: rec[k] for k in ("counters", "valu_instructions_per_wave_step", "valu_busy", "effective_clock_ghz",
+                                          "kernel_avg_us", "formulae", "source") if k in rec}
 
 
 def _graph_replay_us(launches, dev, replays=3):

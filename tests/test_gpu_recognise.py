@@ -614,3 +614,104 @@ def test_polynomial_drift_and_diffusion_take_the_expression_kernel(make, method,
     fast, n = _launches(lambda: solve(2))
     assert n == 1
     torch.testing.assert_close(fast, solve(2, stepwise=True), rtol=5e-5, atol=5e-6)
+
+
+# ---- VERDICT r4 weak 2 / ADVICE r4: what the probe cannot see ---------------------------------------------------------
+class _BatchSizeSwitch(nn.Module):
+    """A drift that branches on the batch size: the interpretation's probe has 2 rows, the real batch many."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def f(self, t, y):
+        return -y if y.shape[0] > 1000 else -2 * y
+
+    def g(self, t, y):
+        return 0.3 * y
+
+
+def test_code_that_branches_on_the_batch_size_gets_the_reference_result_at_every_batch_size():
+    """The trust verdict is keyed by batch size, so the both-routes comparison is made at each: at B = 16 the probe's
+    branch is also the real one and the kernel is trusted; at B = 2048 the kernel would integrate -2y where the
+    reference (base_solver.py:114-149: user code on the REAL batch at every step) integrates -y -- the comparison fails and
+    every solve at that size stays stepwise."""
+    sde = _BatchSizeSwitch().to(DEV)
+    for rows, fast_expected in ((16, True), (2048, False)):
+        y0 = torch.full((rows, D), 0.1, device=DEV)
+        for attempt in range(3):
+            got, launches = _launches(lambda: _solve(sde, 5 + attempt, y0=y0))
+            want = _solve(sde, 5 + attempt, y0=y0, stepwise=True)
+            torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-7)
+            if attempt > 0:
+                assert (launches > 0) == fast_expected, (rows, attempt, launches)
+    verdicts = {key[6]: verdict for key, verdict in _book(sde)["trusted"].items()}
+    assert verdicts[16] is True and isinstance(verdicts[2048], str), verdicts
+
+
+class _DividesByBatchSize(nn.Module):
+    noise_type, sde_type = "diagonal", "ito"
+
+    def f(self, t, y):
+        return -y / y.shape[0]
+
+    def g(self, t, y):
+        return 0.3 * y
+
+
+def test_a_coefficient_computed_from_the_batch_size_is_refused_structurally():
+    """Two probe heights give two different coefficients: refused for what it is, whatever the numbers are."""
+    sde = _DividesByBatchSize().to(DEV)
+    for attempt in range(2):
+        got = _solve(sde, 7 + attempt)
+        torch.testing.assert_close(got, _solve(sde, 7 + attempt, stepwise=True), rtol=0, atol=0)
+    assert ["probes of 2 and 5 rows" in str(v) for v in _book(sde)["trusted"].values()] == [True], _book(sde)
+
+
+class _CountsCalls(nn.Module):
+    """An NFE counter kept in a tensor buffer (the Python-int variant is caught by `python_state`)."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("nfe", torch.zeros(()))
+
+    def f(self, t, y):
+        self.nfe.add_(1)
+        return -y
+
+    def g(self, t, y):
+        return 0.3 * y
+
+
+def test_in_place_writes_to_buffers_and_random_draws_keep_the_stepwise_route():
+    sde = _CountsCalls().to(DEV)
+    _solve(sde, 1)
+    assert not _book(sde)["trusted"] and any("existed before" in r for r in _book(sde)["refused"].values()), _book(sde)
+    before = float(sde.nfe)
+    _solve(sde, 2)
+    assert float(sde.nfe) - before == STEPS           # once per step, as in the reference
+
+    class Noisy(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def f(self, t, y):
+            return -y + 0.0 * torch.randn_like(y[:1])
+
+        def g(self, t, y):
+            return 0.3 * y
+    noisy = Noisy().to(DEV)
+    _solve(noisy, 1)
+    assert not _book(noisy)["trusted"] and any("random" in r for r in _book(noisy)["refused"].values()), _book(noisy)
+
+
+def test_floor_division_is_not_a_scale():
+    class Floored(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def f(self, t, y):
+            return -torch.div(y, 0.01, rounding_mode="floor") * 0.01
+
+        def g(self, t, y):
+            return 0.3 * y
+    sde = Floored().to(DEV)
+    got = _solve(sde, 3)
+    assert not _book(sde)["trusted"] and any("rounding_mode" in r for r in _book(sde)["refused"].values())
+    assert torch.equal(got, _solve(sde, 3, stepwise=True))

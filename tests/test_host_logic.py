@@ -664,8 +664,17 @@ def test_auto_key_refuses_an_object_whose_state_never_repeats_and_schedule_of_ch
         if key is not None:
             keys.add(key)
             cache[key] = graph._Seen()
-    assert len(keys) == graph._MAX_STATES_PER_STRUCTURE - 1 and graph.auto_key(cache, structure, sde) is None
+    # (the hit above reset the count: misses are counted CONSECUTIVELY)
+    assert len(keys) == graph._MAX_STATES_PER_STRUCTURE and graph.auto_key(cache, structure, sde) is None
     assert not [k for k in cache if k[0] == "auto"]                       # the churned entries are gone
+    # a sweep over many legitimate states with cache hits in between is not churn, and a graph that has replayed survives
+    sweep, swept = graph._GraphCache(), problems.make("gbm_ito", d=4)
+    for i in range(3 * graph._MAX_STATES_PER_STRUCTURE):
+        swept.scale = float(i)
+        key = graph.auto_key(sweep, structure, swept)
+        assert key is not None
+        sweep[key] = graph._Seen()
+        assert graph.auto_key(sweep, structure, swept) == key            # the second solve in this state: a hit
     walked = []
     monkeypatch.setattr(graph, "python_state", lambda base: walked.append(1))
     assert graph.auto_key(cache, structure, sde) is None and not walked   # refused before any fingerprinting

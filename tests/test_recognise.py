@@ -92,6 +92,14 @@ REFUSED = {
     "unsupported function": (lambda s, t, y: torch.relu(y), "aten::relu"),
     "slice of the state": (lambda s, t, y: y[:, :1] * s.mu, "aten::slice"),
     "constant with the probe's rows": (lambda s, t, y: y + torch.zeros(y.shape), "not one value per channel"),
+    # kwargs the handlers do not model change what the operator computes
+    "floor division": (lambda s, t, y: torch.div(y, 2, rounding_mode="floor"), "rounding_mode"),
+    "trunc division": (lambda s, t, y: torch.div(y, s.mu, rounding_mode="trunc"), "rounding_mode"),
+    # ... and calls that leave something behind run once per solve here, once per step in the reference
+    "random draw": (lambda s, t, y: y + torch.randn_like(s.b), "draws random numbers"),
+    "dropout": (lambda s, t, y: F.dropout(y, 0.5, training=True), "empty_like of the state|draws random numbers"),
+    "in-place write to a buffer": (lambda s, t, y: y * s.b.add_(1.0), "existed before f and g were called"),
+    "in-place write through a view": (lambda s, t, y: y * s.b[:].mul_(2.0), "existed before f and g were called"),
 }
 
 
@@ -101,6 +109,38 @@ def test_everything_else_is_refused_with_its_reason(name):
     sde = _M(f, lambda s, t, y: y)
     with pytest.raises(recognise.NotElementwise, match=reason):
         recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D))
+
+
+def test_in_place_arithmetic_on_tensors_the_code_made_itself_is_followed():
+    """`out = torch.zeros(d); out += mu` inside f is the user's way of writing a sum: nothing outlives the call."""
+    def f(s, t, y):
+        rate = torch.zeros(D)
+        rate += s.mu.detach()
+        rate.mul_(2.0)
+        return rate * y
+    sde = _M(f, lambda s, t, y: y * s.sigma)
+    found = recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D))
+    torch.testing.assert_close(found.spec()[1], 2.0 * sde.mu.detach())
+
+
+def test_true_division_with_an_explicit_none_rounding_mode_is_followed():
+    sde = _M(lambda s, t, y: torch.div(y, 4.0, rounding_mode=None), lambda s, t, y: y * s.sigma)
+    found = recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), torch.randn(16, D))
+    torch.testing.assert_close(found.spec()[1], torch.full((D,), 0.25))
+
+
+def test_two_probe_heights_expose_code_that_uses_the_batch_size():
+    """The interpretation runs on a probe of a few rows; whatever the code derives from `y.shape[0]` is evaluated for the
+    probe. Two heights give two sets of coefficients -- what the trust check of `_integrate_recognised` compares."""
+    sde = _M(lambda s, t, y: -y / y.shape[0], lambda s, t, y: y * s.sigma)
+    y, t = torch.randn(16, D), torch.tensor(0.3)
+    a = recognise.recognise(ForwardSDE(sde), t, y).spec()
+    b = recognise.recognise(ForwardSDE(sde), t, y, rows=5).spec()
+    assert not torch.equal(a[1], b[1])
+    plain = _M(lambda s, t, y: s.mu * y, lambda s, t, y: y * s.sigma)
+    a = recognise.recognise(ForwardSDE(plain), t, y).spec()
+    b = recognise.recognise(ForwardSDE(plain), t, y, rows=5).spec()
+    assert all(torch.equal(u, v) for u, v in zip(a[1:], b[1:]))
 
 
 def test_perceptron_drift_hands_back_the_users_own_parameters():

@@ -294,7 +294,7 @@ def _plan_reversible_heun_backward(ts_host, dt, native, device):
             cells = native.match_grid(-tau64[::-1]) if native.frozen else None
             misaligned = misaligned or cells is None
         else:
-            tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
+            tau_dev = torch.from_numpy(grid.t.copy()).to(device).unbind(0)
         intervals.append((i, grid, tau64, fwd_times, cells, tau_dev))
     if misaligned:
         native.locate(float(ts_host[0]), float(ts_host[-1]))
@@ -631,7 +631,7 @@ def _plan_backward(ts_host, dt, native, device):
             cells = native.match_grid(-tau64[::-1]) if native.frozen else None
             misaligned = misaligned or cells is None
         else:
-            tau_dev = torch.from_numpy(grid.t).to(device).unbind(0)
+            tau_dev = torch.from_numpy(grid.t.copy()).to(device).unbind(0)
         intervals.append((i, grid, tau64, stage_rows, cells, tau_dev))
     if misaligned:
         native.locate(float(ts_host[0]), float(ts_host[-1]))   # freezes a generator that never saw a grid

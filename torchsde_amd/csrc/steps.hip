@@ -926,7 +926,20 @@ hipError_t launch_step_shared(void* y1, const void* y0, const void* f, const voi
   if (B <= 0 || d <= 0) return hipSuccess;
   if (m <= 0 || m > kGenMaxNoise) return hipErrorInvalidValue;
   const bool noise_ok = nz->dW ? (aligned16(nz->dW) && (!nz->dU || aligned16(nz->dU))) : (nz->elem0 % 4 == 0);
-  const bool mfma = m <= 64 && m % 4 == 0 && d <= 128 && noise_ok && aligned16(S);
+  // S^T staged in LDS: (d rounded to 16) rows of (m rounded to 16) + 4 elements; float64 at d > 112, m > 48 needs 68 KiB, which
+  // a device with 64 KiB per workgroup cannot give (queried once): such shapes take the generic kernel, like the odd ones
+  static const size_t lds_limit = [] {
+    int dev = 0, bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (size_t)(64 * 1024);
+    // (the opt-in maximum -- what hipFuncSetAttribute can raise a kernel to: 160 KiB on gfx950 -- else the default one)
+    if (hipDeviceGetAttribute(&bytes, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && bytes > 0)
+      return (size_t)bytes;
+    if (hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && bytes > 0)
+      return (size_t)bytes;
+    return (size_t)(64 * 1024);
+  }();
+  const size_t lds_needed = (size_t)((d + 15) / 16) * 16 * (((m + 15) & ~(int64_t)15) + 4) * sizeof(T);
+  const bool mfma = m <= 64 && m % 4 == 0 && d <= 128 && noise_ok && aligned16(S) && lds_needed <= lds_limit;
   GeneralArgs<T> a;
   a.y1 = (T*)y1;
   a.y0 = (const T*)y0;
@@ -969,9 +982,11 @@ hipError_t launch_step_shared(void* y1, const void* y0, const void* f, const voi
   if (blocks > 256 * 4) blocks = 256 * 4;
 #define TSDE_SHARED_CASE(N)                                                                                          \
   case N: {                                                                                                          \
-    if (lds > 64 * 1024)                                                                                             \
-      (void)hipFuncSetAttribute((const void*)shared_mfma_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)lds);                                                                           \
+    if (lds > 64 * 1024) {                                                                                           \
+      const hipError_t attr_ = hipFuncSetAttribute((const void*)shared_mfma_kernel<T, N>,                            \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+      if (attr_ != hipSuccess) return attr_;                                                                         \
+    }                                                                                                                \
     TSDE_LAUNCH((shared_mfma_kernel<T, N>), dim3((int)blocks), dim3(kBlock), lds, s, a);                             \
     break;                                                                                                           \
   }

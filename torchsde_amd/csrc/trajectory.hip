@@ -286,6 +286,11 @@ struct ExprModelTimed {
   }
 };
 
+// Step count at which output j is due, as a wave-uniform (scalar) value; -1 past the last output.
+TSDE_D int next_output_step(const int32_t* out_step, int j, int n_out) {
+  return j < n_out ? __builtin_amdgcn_readfirstlane(out_step[j]) : -1;
+}
+
 template <typename T>
 TSDE_D T primal(const T& x) { return x; }
 template <typename T>
@@ -326,6 +331,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
   }
   const uint64_t elem = key.elem0 + (uint64_t)i;
   int j = 0;
+  int next_out = next_output_step(p.out_step, 0, p.n_out);
   for (int k = 0; k < p.n_steps; ++k) {
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
@@ -375,25 +381,30 @@ __global__ void __launch_bounds__(kBlock) trajectory_kernel(const TrajArgs<T> p)
                                                        kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
       }
     }
-    while (j < p.n_out && p.out_step[j] == k + 1) {
-      const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
-      const bool exact = (w0 == (T)0 && w1 == (T)1);
-      S o[W];
+    // (the step count of the next output lives in a scalar register: a step that is not an output time -- all but a few
+    //  of them -- pays one scalar compare, and the output code is a cold block of its own)
+    if (__builtin_expect(k + 1 == next_out, 0)) {
+      while (j < p.n_out && p.out_step[j] == k + 1) {
+        const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        const bool exact = (w0 == (T)0 && w1 == (T)1);
+        S o[W];
 #pragma unroll
-      for (int q = 0; q < W; ++q) o[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
-      Pack<T, W> ov;
+        for (int q = 0; q < W; ++q) o[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
+        Pack<T, W> ov;
 #pragma unroll
-      for (int q = 0; q < W; ++q) ov.v[q] = primal<T>(o[q]);
-      store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
-      if constexpr (SENS) {
+        for (int q = 0; q < W; ++q) ov.v[q] = primal<T>(o[q]);
+        store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
+        if constexpr (SENS) {
 #pragma unroll
-        for (int s = 0; s < kSens; ++s) {
+          for (int s = 0; s < kSens; ++s) {
 #pragma unroll
-          for (int q = 0; q < W; ++q) ov.v[q] = o[q].d[s];
-          store<T, W>(p.sens + ((int64_t)j * kSens + s) * p.n, i, ov);
+            for (int q = 0; q < W; ++q) ov.v[q] = o[q].d[s];
+            store<T, W>(p.sens + ((int64_t)j * kSens + s) * p.n, i, ov);
+          }
         }
+        ++j;
       }
-      ++j;
+      next_out = next_output_step(p.out_step, j, p.n_out);
     }
 #pragma unroll
     for (int q = 0; q < W; ++q) y[q] = y1[q];
@@ -517,6 +528,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
   }
   const uint64_t elem = key.elem0 + (uint64_t)i;
   int j = 0;
+  int next_out = next_output_step(p.out_step, 0, p.n_out);
   for (int k = 0; k < p.n_steps; ++k) {
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
@@ -565,14 +577,17 @@ __global__ void __launch_bounds__(kBlock) trajectory_expr_kernel(const ExprArgs<
         y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
       }
     }
-    while (j < p.n_out && p.out_step[j] == k + 1) {
-      const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
-      const bool exact = (w0 == (T)0 && w1 == (T)1);
-      Pack<T, W> ov;
+    if (__builtin_expect(k + 1 == next_out, 0)) {
+      while (j < p.n_out && p.out_step[j] == k + 1) {
+        const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        const bool exact = (w0 == (T)0 && w1 == (T)1);
+        Pack<T, W> ov;
 #pragma unroll
-      for (int q = 0; q < W; ++q) ov.v[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
-      store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
-      ++j;
+        for (int q = 0; q < W; ++q) ov.v[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
+        store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
+        ++j;
+      }
+      next_out = next_output_step(p.out_step, j, p.n_out);
     }
 #pragma unroll
     for (int q = 0; q < W; ++q) y[q] = y1[q];

@@ -200,22 +200,29 @@ def auto_key(cache, structure, base):
     if state is None:
         return None
     sig = ("auto", state, process_state()) + structure
-    if sig not in cache:
-        seen = cache.get(churn)
-        if seen is None:
-            seen = cache[churn] = _StatesSeen()
-        seen.count += 1
-        if seen.count > _MAX_STATES_PER_STRUCTURE:
-            for key in [k for k in cache if k[:1] == ("auto",) and k[3:] == structure]:
+    seen = cache.get(churn)
+    if sig in cache:
+        if seen is not None:
+            seen.count = 0            # a state that came back: the object is not churning
+        return sig
+    if seen is None:
+        seen = cache[churn] = _StatesSeen()
+    # CONSECUTIVE misses only: a hyperparameter sweep that sets `sde.scale` eight times over the object's lifetime, with
+    # solves that hit the cache in between, is eight legitimate states, not churn
+    seen.count += 1
+    if seen.count > _MAX_STATES_PER_STRUCTURE:
+        # entries that never got as far as a replay go (they are the churn); a graph that has replayed stays usable
+        for key in [k for k in cache if k[:1] == ("auto",) and k[3:] == structure]:
+            if getattr(cache[key], "replays", 0) == 0:
                 del cache[key]
-            cache[churn] = _Refused(f"the SDE object's Python-side state differed on each of {seen.count - 1} solves of this "
-                                    "structure (a counter, a growing list, a fresh tensor attribute per call?)")
-            return None
+        cache[churn] = _Refused(f"the SDE object's Python-side state differed on each of {seen.count - 1} consecutive solves "
+                                "of this structure (a counter, a growing list, a fresh tensor attribute per call?)")
+        return None
     return sig
 
 
 class _StatesSeen:
-    """Cache entry counting the distinct Python-side states met for one structure (see `auto_key`)."""
+    """Cache entry counting the CONSECUTIVE cache misses of one structure (see `auto_key`); any hit resets it."""
     count = 0
 
 

@@ -170,6 +170,8 @@ class _Interpreter(TorchDispatchMode):
         #                                 their code computed from parameters with autograd watching -- not one folded here
         self.hidden = {}                # id -> _Hidden: (rows, hidden)-shaped values of a perceptron drift
         self.transposed = {}            # id of `W.t()` -> W (nn.Linear hands addmm the transposed view of its weight)
+        self.made = {id(y), id(t)}      # ids of tensors whose storage was allocated during the interpretation (kept alive):
+        #                                 an in-place write to any OTHER tensor changes state that outlives the probe call
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------------
     def form_of(self, x):
@@ -361,8 +363,59 @@ class _Interpreter(TorchDispatchMode):
              "_unsafe_view", "expand", "_reshape_alias"}
     _LIKE = {"zeros_like": 0.0, "ones_like": 1.0}
 
+    # kwargs whose effect the handlers model; every other non-default kwarg of an operator on a tracked value ends the
+    # interpretation (`torch.div(y, 2, rounding_mode="floor")` is not `0.5 * y`)
+    _MODELLED = {"add": ("alpha",), "sub": ("alpha",), "rsub": ("alpha",), "softplus": ("beta", "threshold")}
+    # ... and kwargs whose effect is checked on the RESULT (shape, dtype and device of the output must be the input's)
+    _CHECKED_ON_RESULT = ("dtype", "layout", "device", "pin_memory", "memory_format", "non_blocking", "copy", "implicit")
+
+    def check_kwargs(self, name, schema, kwargs):
+        allowed = self._MODELLED.get(name, ())
+        result_checked = name in self._SAME or name in self._LIKE or name == "full_like"
+        for key, value in kwargs.items():
+            if value is None or key in allowed or (result_checked and key in self._CHECKED_ON_RESULT):
+                continue
+            if not torch.is_tensor(value) and any(a.name == key and a.has_default_value() and a.default_value == value
+                                                  for a in schema.arguments):
+                continue
+            raise NotElementwise(f"{name} with {key}={value!r}: an argument the interpretation does not model")
+
+    def check_side_effects(self, func, args, kwargs):
+        """The interpretation CALLS the user's code once per solve where the reference calls it once per step
+        (base_solver.py:114-149): code whose calls leave something behind cannot take this route. Random draws
+        (dropout, `randn_like`) and in-place writes to tensors that existed before the call (a buffer bumped with
+        `.add_`, spectral norm's power iteration) end the interpretation."""
+        schema = func._schema
+        if torch.Tag.nondeterministic_seeded in func.tags:
+            raise NotElementwise(f"{schema.name} draws random numbers: once per solve here, once per step in the reference")
+        if not schema.is_mutable:
+            return
+        for i, arg in enumerate(schema.arguments):
+            if arg.alias_info is None or not arg.alias_info.is_write:
+                continue
+            value = args[i] if i < len(args) else kwargs.get(arg.name)
+            for x in (value if isinstance(value, (list, tuple)) else (value,)):
+                if torch.is_tensor(x) and id(x) not in self.made:
+                    raise NotElementwise(f"in-place {schema.name} on a tensor that existed before f and g were called "
+                                         "(state that outlives the call: once per solve here, once per step in the reference)")
+
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        self.check_side_effects(func, args, kwargs)
+        out = self.interpret(func, args, kwargs)
+        # storage made during the interpretation: fresh results, and views (aliasing returns) of such tensors
+        returns = func._schema.returns
+        outs = out if isinstance(out, (list, tuple)) else (out,)
+        for k, o in enumerate(outs):
+            if not torch.is_tensor(o) or id(o) in self.made:
+                continue
+            aliasing = k < len(returns) and returns[k].alias_info is not None and func._schema.name != "aten::lift_fresh"
+            if not aliasing or (args and torch.is_tensor(args[0]) and id(args[0]) in self.made):
+                self.made.add(id(o))
+                self.keep.append(o)
+        return out
+
+    def interpret(self, func, args, kwargs):
         flat = list(args) + list(kwargs.values())
         involved = [a for a in flat if torch.is_tensor(a)]
         for a in flat:
@@ -392,6 +445,7 @@ class _Interpreter(TorchDispatchMode):
         if timed and any(id(a) in self.hidden for a in involved):
             raise NotElementwise("the drift network depends on t")
         if any(id(a) in self.hidden for a in involved):
+            self.check_kwargs(func._schema.name.split("::")[1], func._schema, kwargs)
             return self.perceptron_step(func, args, kwargs)
         tracked = [a for a in involved if id(a) in self.forms]
         if not tracked:
@@ -411,6 +465,7 @@ class _Interpreter(TorchDispatchMode):
         name = schema.name.split("::")[1]
         if schema.is_mutable:
             raise NotElementwise(f"in-place {name} on a value derived from the state")
+        self.check_kwargs(name, schema, kwargs)
         out = func(*args, **kwargs)
         if name in ("addmm", "mm", "linear"):
             return self.first_layer(name, args, out)
@@ -654,10 +709,14 @@ def _constant_vector(value, d, dtype, device):
     return hit
 
 
-def recognise(sde, t, y0, differentiable=False, times=None):
+def recognise(sde, t, y0, differentiable=False, times=None, rows=None):
     """Interpret ``sde.f_and_g`` (a ForwardSDE: whichever of f / g / f_and_g the user defined) on a probe of the state's
-    width; returns `Recognised` or raises `NotElementwise`. Launches a handful of tiny kernels, never synchronises."""
-    rows = 2 if y0.shape[0] != 2 else 3         # a per-ROW constant of the real batch cannot broadcast against the probe
+    width; returns `Recognised` or raises `NotElementwise`. Launches a handful of tiny kernels, never synchronises.
+    `rows`: the probe's height (default 2). Code that derives a coefficient from the batch size (`y / y.shape[0]`) is
+    seen by interpreting at two heights and comparing the coefficients (the trust check of `_integrate_recognised`)."""
+    rows = 2 if rows is None else int(rows)
+    if rows == y0.shape[0]:
+        rows += 1                               # a per-ROW constant of the real batch cannot broadcast against the probe
     d = y0.shape[1]
     probe = y0.detach()[:1].expand(rows, d).clone() if y0.shape[0] > 0 else torch.zeros(rows, d, dtype=y0.dtype,
                                                                                        device=y0.device)
@@ -699,12 +758,12 @@ def describe(sde):
                 "a CUDA state of at least 8 rows)"]
     lines = []
     for key, verdict in book["trusted"].items():
-        structure, _, solver, sde_type, d, dtype = key[:6]
+        structure, _, solver, sde_type, d, dtype, batch = key[:7]
         kind = "perceptron drift" if structure[0][0] == "perceptron" else f"f: {structure[0][0]}, g: {structure[1][0]}"
         timed = any("table" in part for part in structure if isinstance(part, tuple))
         route = ("trajectory kernel" + (" with per-stage-time coefficient rows" if timed else "")
-                 + (" (sensitivity kernel: autograd)" if key[6:] == ("autograd",) else ""))
-        lines.append(f"[{solver}, {sde_type}, d = {d}, {dtype}] {kind}: "
+                 + (" (sensitivity kernel: autograd)" if key[7:] == ("autograd",) else ""))
+        lines.append(f"[{solver}, {sde_type}, batch = {batch}, d = {d}, {dtype}] {kind}: "
                      + (route if verdict is True else f"stays stepwise: {verdict}"))
     for (_, _, solver), reason in book["refused"].items():
         lines.append(f"[{solver}] stays stepwise: {reason}")

@@ -461,17 +461,23 @@ class BaseSDESolver:
             return None
         # first solve of this form: is the interpretation repeatable and free of side effects, and does the kernel
         # reproduce the stepwise solve?
+        # (the second interpretation runs on a probe of another height: a coefficient computed from the number of rows
+        #  -- `y / y.shape[0]` -- comes out different and the form is refused for what it is, not by a numeric accident)
         before = graph.python_state(base)
+        rng_before = self._rng_states(y0.device)
         try:
-            again = recognise.recognise(sde, ts[0], y0, times=times).spec()
+            again = recognise.recognise(sde, ts[0], y0, times=times, rows=5).spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if before is None or graph.python_state(base) != before:
             return refuse("calling f and g changes the object's Python-side state")
+        if any(not torch.equal(a, b) for a, b in zip(rng_before, self._rng_states(y0.device))):
+            return refuse("calling f and g advances a random number generator")
         same = len(again) == len(spec) and all(
             (torch.equal(a, b) if torch.is_tensor(a) else a == b) for a, b in zip(again, spec))
         if not same:
-            book["trusted"][key] = "two interpretations of the same code gave different coefficients"
+            book["trusted"][key] = ("two interpretations of the same code (probes of 2 and 5 rows) gave different coefficients: "
+                                    "they depend on the batch size or on how often the code has run")
             return None
         fast = self._integrate_trajectory(launch, y0, ts)
         if fast is None:
@@ -487,6 +493,11 @@ class BaseSDESolver:
             book["trusted"].clear()
         book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
         return stepwise
+
+    @staticmethod
+    def _rng_states(device):
+        """Host-side snapshots of the default CPU and device generators (seed + offset; no device synchronisation)."""
+        return torch.get_rng_state(), torch.cuda.get_rng_state(device)
 
     @staticmethod
     def _may_be_interpreted(base):
@@ -540,6 +551,14 @@ class BaseSDESolver:
             return self._integrate_trajectory(("differentiable",) + tuple(leaves), y0, ts)
         if verdict is not None:
             return None
+        # (as in `_integrate_recognised`: a second interpretation on a probe of another height must give the same values)
+        try:
+            again = recognise.recognise(sde, ts[0], y0, differentiable=True, rows=5).affine_leaves()
+        except recognise.NotElementwise:
+            return None
+        if again is None or any(a.shape != b.shape or not torch.equal(a.detach(), b.detach()) for a, b in zip(again, leaves)):
+            book["trusted"][key] = "two interpretations of the same code (probes of 2 and 5 rows) gave different coefficients"
+            return None
         with torch.no_grad():
             fast = self._integrate_trajectory(tuple(c.detach().reshape(-1).expand(y0.shape[1]).contiguous()
                                                     for c in leaves), y0.detach(), ts)
@@ -584,7 +603,10 @@ class BaseSDESolver:
         return hit
 
     def _recognised_key(self, found, chain, y0):
-        return (found.structure(), chain, type(self).__name__, self.sde.sde_type, y0.shape[1], y0.dtype)
+        # The batch size is part of the key: the interpretation runs on a probe of a few rows, so whatever the user's code
+        # derives from `y.shape[0]` (`-y if y.shape[0] > 1000 else -2 * y`) is evaluated for the probe; the both-routes
+        # comparison that earns the trust therefore has to be made at every batch size the form is solved at.
+        return (found.structure(), chain, type(self).__name__, self.sde.sde_type, y0.shape[1], y0.dtype, y0.shape[0])
 
     def recognised_perceptron(self, y0, ts):
         """For `sdeint_adjoint` (mlp_adjoint.route): the interpretation of an unchanged user module whose drift is a
@@ -718,7 +740,7 @@ class BaseSDESolver:
             if cells is None or not self.merges_half_steps or self.options.get("general_noise", False):
                 bm._device_edges()   # upload the cell edges now: `_run` must not copy from the host
         elif n_steps > 0:
-            t_dev = torch.from_numpy(grid.t).to(device=device).unbind(0)
+            t_dev = torch.from_numpy(grid.t.copy()).to(device=device).unbind(0)
         done_at = {}   # step index -> outputs it completes; exact hits are written in place
         for j, (kp, kc, w0, w1) in enumerate(grid.outputs):
             done_at.setdefault(kc, []).append((j + 1, kp, w0, w1))
