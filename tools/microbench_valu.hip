@@ -51,6 +51,12 @@ __device__ __forceinline__ void body(float (&a)[kChains], float (&b)[kChains], u
 #define V_CNDMASK(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[i]) : "v"(w[i]), "s"(mask));
 #define V_BITOP3V(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(u[i]) : "v"(w[i]), "v"(w[(i + 1) & 7]));
 #define V_MOV(i) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(w[i]));
+#define V_MAD64V(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(q[i]) : "v"(u[i]), "v"(w[i]) : "vcc");
+#define V_XORS(i) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(u[i]) : "s"(s1));
+#define V_CNDVCC(i) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(w[i]));
+#define V_MULS(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(s1));
+#define V_PKMULS(i) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(q[i]) : "v"(r[i]));
+#define V_XOR2(i) asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %2, %0" : "+v"(u[i]) : "v"(w[i]), "s"(s1));
 #define V_CMP(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(u[i]), "v"(w[i]) : "vcc");
 #define V_CVT(i) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[i]) : "v"(u[i]));
 #define V_LOG(i) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
@@ -89,14 +95,21 @@ __device__ __forceinline__ void body(float (&a)[kChains], float (&b)[kChains], u
   if constexpr (OP == 24) { EIGHT(V_FMAMK) }
   if constexpr (OP == 25) { EIGHT(V_BITOP3V) }
   if constexpr (OP == 26) { EIGHT(V_MOV) }
+  if constexpr (OP == 27) { EIGHT(V_MAD64V) }
+  if constexpr (OP == 28) { EIGHT(V_XORS) }
+  if constexpr (OP == 29) { EIGHT(V_CNDVCC) }
+  if constexpr (OP == 30) { EIGHT(V_MULS) }
+  if constexpr (OP == 31) { EIGHT(V_PKMULS) }
+  if constexpr (OP == 32) { EIGHT(V_XOR2) }
 }
 
 static const char* kNames[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32",
                                "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_bitop3_b32", "v_xor_b32", "v_add_u32",
                                "v_not_b32", "v_cndmask_b32", "v_cmp_lt_u32", "v_cvt_f32_u32", "v_log_f32", "v_exp_f32",
                                "v_rcp_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_lshl_add_u64", "v_mov_b64",
-                               "v_fmamk_f32", "v_bitop3_b32(vgpr)", "v_mov_b32"};
-constexpr int kOps = 27;
+                               "v_fmamk_f32", "v_bitop3_b32(vgpr)", "v_mov_b32", "v_mad_u64_u32(vgpr)", "v_xor_b32(sgpr)",
+                               "v_cndmask_b32(vcc)", "v_mul_f32(sgpr)", "v_pk_mul_f32(op_sel)", "2x v_xor_b32(v,s)"};
+constexpr int kOps = 33;
 
 template <int OP>
 __global__ void __launch_bounds__(256) issue(uint64_t* ticks, float* sink, uint32_t s0, uint32_t s1) {

@@ -129,7 +129,7 @@ def model(symbol=HEADLINE_SYMBOL, rates_path=None, source="trajectory.hip", elem
     if os.path.exists(rates_path):
         with open(rates_path) as fh:
             rec = json.load(fh)
-        col = "shader" if rec.get("ticks_are_shader_cycles") else "wall_2p4ghz"
+        col = rec.get("column") or ("shader" if rec.get("ticks_are_shader_cycles") else "wall_2p4ghz")
         rates = {k: v[col] for k, v in rec["cycles"].items()}
         rates_meta = {"file": os.path.relpath(rates_path, ROOT), "column": col, "device": rec.get("device")}
     hot, where = step_loop(kernel_body(asm if asm is not None else device_asm(source), symbol))
