@@ -78,7 +78,8 @@ typedef struct tsde_seg {
 /* The step schedule of one whole solve, for the trajectory kernels (all DEVICE pointers).
  * Row k of `step_rows` holds, already rounded to `dtype` exactly as the per-step entry points round their
  * double arguments:  dt_k, dt_k/2, 1/dt_k, sqrt(dt_k), sqrt(h_k), sqrt(h_k/12), h_k, 0   (h_k = width of
- * Brownian cell `cells[k]`; step k must cover exactly that cell). Output j (the j-th requested time after
+ * Brownian cell `cells[k]`; step k must cover exactly that cell; the last slot may carry t_k, the step's start time,
+ * which only tsde_trajectory_mlp_general reads). Output j (the j-th requested time after
  * t0) is written once `out_step[j]` steps are complete, as w0*y_prev + w1*y_curr with the weights of row j
  * of `out_w` ((0,1) = the step lands on the output time). `out_step` is ascending. */
 typedef struct tsde_traj {
@@ -398,6 +399,53 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
                              const void* diff_shift, int diff_kind, double diff_amp, int activation, int method,
                              const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
                              int dtype, void* stream);
+
+/* ---- neural SDEs: drift AND diffusion two-layer perceptrons of (t, y) -------------------------------------------------
+ * One perceptron shared by the batch:  out = scale * final(W2 . act(W1 . y + w1t * t + b1) + b2)
+ *   w1   (in, hidden)   input-major (the transpose of torch.nn.Linear.weight restricted to the STATE columns)
+ *   w1t  (hidden)       the weight column of the time input, for modules that feed torch.cat([t.expand(B, 1), y], 1) to
+ *                       their first layer (every Neural* problem of the reference, tests/problems.py:153-159,183-189,
+ *                       215-217,246-252); NULL: the net does not see t
+ *   w2   (hidden, out)  input-major;  b1 (hidden), b2 (out)
+ *   final: TSDE_FINAL_NONE | TSDE_FINAL_SIGMOID (nn.Sigmoid() closing g_net);  scale: a number (the 0.1 of
+ *   NeuralDiagonal.g, tests/problems.py:159); the drift uses final = NONE, scale = 1. */
+#define TSDE_FINAL_NONE 0
+#define TSDE_FINAL_SIGMOID 1
+#define TSDE_NOISE_DIAGONAL 0
+#define TSDE_NOISE_SCALAR 1
+#define TSDE_NOISE_GENERAL 2
+typedef struct tsde_mlp {
+  const void* w1;
+  const void* w1t;
+  const void* b1;
+  const void* w2;
+  const void* b2;
+  int32_t hidden;
+  int32_t out;
+  int32_t activation; /* TSDE_ACT_* */
+  int32_t final;
+  double scale;
+} tsde_mlp_t;
+
+/* All fixed steps of the SDE  dy = drift(t, y) dt + g(t, y) dW  with both functions perceptrons as above, in ONE launch
+ * (replaces base_solver.py:114-134 driving methods/euler.py:29-37 -- whose f_and_g_prod is misc.batch_mvp,
+ * _core/misc.py:62-63: bmm(g, dW) -- or methods/midpoint.py:29-45). BASELINE configs[2] is this with noise = GENERAL:
+ *   noise = TSDE_NOISE_GENERAL   diffusion->out = d * m, read as (rows, d, m) row-major (`.view(B, d, m)`); m in {4, 8, 16, 32};
+ *                                increments: the (rows, m) field, element (row, j) = elem0 + row * m + j
+ *   noise = TSDE_NOISE_DIAGONAL  diffusion->out = d, m = d: g[., i] dW[., i]             (NeuralDiagonal)
+ *   noise = TSDE_NOISE_SCALAR    diffusion->out = d, m = 1: g[., i] dW[.]                (NeuralScalar)
+ * method: TSDE_TRAJ_EULER (Ito) or TSDE_TRAJ_MIDPOINT (Stratonovich; stage times t_k and t_k + dt/2).
+ * A wave keeps 16 rows in registers for the whole solve; every weight lives in LDS; all four layers run on
+ * v_mfma_f32_16x16x4_f32 (exact f32), the contraction with the increments included (csrc/mlp_general.hip).
+ * traj->step_rows[k][7] must hold t_k, the time at which step k starts (the other trajectory kernels ignore that slot).
+ * d a multiple of 4 up to 64, hidden sizes up to 64, and all weights must fit the 160 KiB of LDS:
+ * tsde_trajectory_mlp_general_lds returns the bytes a shape needs (0: no kernel for it). dtype must be TSDE_F32;
+ * elem0 a multiple of 4; ys, y0 16-byte aligned; rows * d < 2^30. Outputs and increments as tsde_trajectory_mlp_diag. */
+int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                                const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method, const tsde_traj_t* traj,
+                                uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
+int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden,
+                                        int64_t diffusion_out, int noise);
 
 /* tsde_trajectory_affine_diag for drift and diffusion given as elementwise expressions per state channel:
  *     f = coef[0] * phi_f(coef[1] * y + coef[2]) + coef[3]        g = coef[4] * phi_g(coef[5] * y + coef[6]) + coef[7]

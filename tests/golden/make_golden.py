@@ -13,6 +13,8 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   closed_form_mlp_<case>.npz   reference `sdeint` (+ autograd gradients) of the perceptron-drift module in float64, on
                       the counter-RNG path the trajectory kernels generate for themselves
   closed_form_affine_<case>.npz   the same for the affine diagonal module (all five schemes of its trajectory kernel)
+  recognised_poly3_<case>.npz   reference `sdeint` of plain user modules with polynomial drift / diffusion (double well,
+                                logistic growth), float64, counter-RNG path: pins TSDE_FN_POLY3 to the reference
   closed_form_expr_<case>.npz   reference `sdeint` of the elementwise-expression module (incl. the reference's own
                       benchmark SDE f = y, g = exp(-y)), float64, counter-RNG path
   closed_form_adjoint_<case>.npz   reference `sdeint_adjoint(adjoint_method="euler")` of the perceptron-drift module, float64,
@@ -792,9 +794,65 @@ def gen_closed_form_expr():
         print(f"closed_form_expr_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}")
 
 
+# Plain USER modules whose drift / diffusion are polynomials of the state (workloads.problems.DoubleWell, Logistic: nothing
+# of this package in them), solved by the REAL reference in float64 on the counter-RNG path: pins the cubic mode of
+# tsde_trajectory_expr_diag (TSDE_FN_POLY3) that recognise.py routes such modules to -- against the reference itself, not
+# against this package's stepwise route.
+POLY3_CASES = [
+    # name, problem class, sde_type, method, levy
+    ("doublewell_euler", "DoubleWell", "ito", "euler", "none"),
+    ("doublewell_milstein", "DoubleWell", "ito", "milstein", "none"),
+    ("doublewell_srk", "DoubleWell", "ito", "srk", "space-time"),
+    ("logistic_euler", "Logistic", "ito", "euler", "none"),
+    ("logistic_midpoint", "Logistic", "stratonovich", "midpoint", "none"),
+    ("logistic_milstein_strat", "Logistic", "stratonovich", "milstein", "none"),
+]
+
+
+def gen_poly3():
+    from oracle import counter
+    from workloads import problems
+    B, d, steps, entropy, dt = 40, 12, 16, 515151, 2.0 ** -5
+
+    for name, cls, sde_type, method, levy in POLY3_CASES:
+        edges = np.arange(steps + 1) * dt
+        ts = [0.0, 5 * dt, 7.5 * dt, steps * dt]
+
+        class CounterPath(torchsde.BaseBrownian):
+            def __call__(self, ta, tb=None, return_U=False, return_A=False):
+                W, U, _ = counter.query(B * d, entropy, edges, float(ta), float(tb), dtype=np.float64,
+                                        have_h=levy != "none")
+                W = torch.from_numpy(W).reshape(B, d)
+                return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+            def __repr__(self):
+                return "CounterPath"
+
+            dtype = property(lambda self: torch.float64)
+            device = property(lambda self: torch.device("cpu"))
+            shape = property(lambda self: (B, d))
+            levy_area_approximation = property(lambda self: levy)
+
+        sde = (problems.DoubleWell(d) if cls == "DoubleWell" else problems.Logistic(d, sde_type)).double()
+        sde.sde_type = sde_type
+        gen = torch.Generator().manual_seed(sum(map(ord, "poly3_" + name)))
+        # (double well: both wells and the barrier; logistic growth: positive populations around the carrying capacity)
+        y0 = (2.4 * torch.rand(B, d, generator=gen, dtype=torch.float64) - 1.2 if cls == "DoubleWell"
+              else 0.2 + 1.6 * torch.rand(B, d, generator=gen, dtype=torch.float64))
+        with torch.no_grad():
+            ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method, dt=dt)
+        out = {"problem": cls, "sde_type": sde_type, "method": method, "levy": levy, "entropy": np.int64(entropy),
+               "dt": np.float64(dt), "ts": np.asarray(ts), "shape": np.array([B, d, steps]), "y0": y0.numpy(), "ys": ys.numpy()}
+        for pname, p in sde.named_parameters():
+            out["param__" + pname] = p.detach().numpy()
+        np.savez_compressed(os.path.join(HERE, f"recognised_poly3_{name}.npz"), **out)
+        print(f"recognised_poly3_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
-                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr", "double_backward", "adjoint_adaptive"]
+                             "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr", "double_backward",
+                             "adjoint_adaptive", "poly3"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,180 @@
+"""Neural SDEs -- drift AND diffusion two-layer perceptrons of (t, y), the reference's Neural* problems
+(tests/problems.py:135-252) and BASELINE configs[2] -- on `tsde_trajectory_mlp_general` (``-m gpu``): an UNCHANGED user
+module, no options; the first solve of a form runs both routes and returns the stepwise result, later ones are one launch.
+
+Pinned three ways: against the stepwise route (which replays the reference's goldens), against the ORACLE's restatement of
+the reference's loop on the same Brownian path at the full configs[2] size (sampled rows, the bound of
+tests/test_gpu_full_size_oracle.py), and through the C ABI directly against a torch evaluation of the same networks."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from tests import helpers
+from workloads import configs, problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DT = 2.0 ** -7
+
+
+def _bm(B, m, t1, entropy, row_offset=0):
+    import torchsde_amd
+    return torchsde_amd.BrownianInterval(0.0, t1, size=(B, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=DT,
+                                         row_offset=row_offset)
+
+
+def _solve(sde, m, entropy, method, B=96, d=None, steps=24, stepwise=False, ts=None, row_offset=0):
+    import torchsde_amd
+    d = sde.d if d is None else d
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, 7.5 * DT, steps * DT] if ts is None else ts, device=DEV)
+    options = {"hip_graph": False}
+    if stepwise:
+        options["trajectory_kernel"] = False
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, m, float(ts[-1]), entropy, row_offset), method=method, dt=DT,
+                                   options=options)
+
+
+def _book(sde):
+    from torchsde_amd import solvers
+    return getattr(sde, solvers.BaseSDESolver._RECOGNISED_ATTR, {"trusted": {}, "refused": {}})
+
+
+def _launches(fn):
+    from torchsde_amd import kernels as K
+    K.prof_begin(8, 64)
+    out = fn()
+    torch.cuda.synchronize()
+    return out, K.prof_end()[1]
+
+
+GENERAL = [(8, 4, 8), (12, 4, 8), (8, 8, 8), (20, 8, 16), (32, 16, 64), (16, 16, 8), (8, 32, 24), (36, 8, 40)]
+
+
+@pytest.mark.parametrize("d,m,hidden", GENERAL)
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich")])
+def test_general_noise_networks_take_the_matrix_core_kernel(d, m, hidden, method, sde_type):
+    """NeuralGeneral (tests/problems.py:226-252): f_net, g_net of cat([t, y]), g reshaped to (B, d, m); an output time
+    inside a step (interpolated in the kernel); every tile shape of the contraction (m = 4, 8, 16, 32; d not a multiple of
+    16: padded tiles)."""
+    sde = problems.MLPGeneral(d, m, sde_type, hidden=hidden).to(DEV)
+    first = _solve(sde, m, 1, method)
+    assert torch.equal(first, _solve(sde, m, 1, method, stepwise=True))             # the verifying solve returns the stepwise one
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    for entropy in (2, 3):
+        fast, launches = _launches(lambda: _solve(sde, m, entropy, method))
+        assert launches == 1
+        slow = _solve(sde, m, entropy, method, stepwise=True)
+        torch.testing.assert_close(fast, slow, rtol=2e-5, atol=2e-6)
+        assert not torch.equal(fast[-1], fast[0])
+
+
+@pytest.mark.parametrize("name,m_of", [("netdiag", lambda d: d), ("netscalar", lambda d: 1)])
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich")])
+def test_diagonal_and_scalar_noise_networks(name, m_of, method, sde_type):
+    """NeuralDiagonal / NeuralScalar (tests/problems.py:135-192): 0.1 * sigmoid-closed g_net, (B, d) or (B, d, 1)."""
+    for d, hidden in ((8, 8), (20, 24), (64, 64)):
+        sde = problems.make(f"{name}_{'ito' if sde_type == 'ito' else 'strat'}", d=d, hidden=hidden).to(DEV)
+        m = m_of(d)
+        _solve(sde, m, 1, method, d=d)
+        assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        fast, launches = _launches(lambda: _solve(sde, m, 2, method, d=d))
+        assert launches == 1
+        torch.testing.assert_close(fast, _solve(sde, m, 2, method, d=d, stepwise=True), rtol=2e-5, atol=2e-6)
+
+
+def test_rows_are_global_and_a_partial_last_group_is_handled():
+    """The increments are those of GLOBAL rows (sharding-invariant), and a batch that is not a multiple of 16 works."""
+    sde = problems.MLPGeneral(8, 8, "ito", hidden=8).to(DEV)
+    whole = [_solve(sde, 8, 5, "euler", B=200) for _ in range(2)][1]                # (the second solve: the kernel)
+    for lo, hi in ((0, 104), (104, 200)):
+        part = [_solve(sde, 8, 5, "euler", B=hi - lo, row_offset=lo) for _ in range(2)][1]
+        assert torch.equal(part, whole[:, lo:hi])
+    odd = [_solve(sde, 8, 5, "euler", B=77) for _ in range(2)][1]
+    assert torch.equal(odd, whole[:, :77])
+
+
+def test_live_parameters_and_what_stays_stepwise():
+    sde = problems.MLPGeneral(8, 4, "ito", hidden=8).to(DEV)
+    _solve(sde, 4, 1, "euler")
+    a = _solve(sde, 4, 2, "euler")
+    with torch.no_grad():
+        sde.g_net[2].bias.add_(0.5)                                               # an optimiser step
+    b, launches = _launches(lambda: _solve(sde, 4, 2, "euler"))
+    assert launches == 1 and not torch.equal(a, b)
+    torch.testing.assert_close(b, _solve(sde, 4, 2, "euler", stepwise=True), rtol=2e-5, atol=2e-6)
+    # shapes without a tile form (m = 5, d = 3), and schemes the kernel does not have, keep the stepwise route
+    odd = problems.make("general_odd_ito").to(DEV)
+    for _ in range(2):
+        got, launches = _launches(lambda: _solve(odd, 5, 3, "euler", d=3))
+        assert launches == 0
+    strat = problems.MLPGeneral(8, 4, "stratonovich", hidden=8).to(DEV)
+    for _ in range(2):
+        got, launches = _launches(lambda: _solve(strat, 4, 3, "heun"))
+        assert launches == 0
+    assert torch.equal(got, _solve(strat, 4, 3, "heun", stepwise=True))
+
+
+def test_c_abi_against_a_torch_evaluation_of_the_same_networks():
+    """tsde_trajectory_mlp_general called directly (no module, no interpretation): tanh nets without a time input, an
+    identity-closed diffusion with a scale, Euler, materialised increments of the same generator."""
+    import torchsde_amd
+    from torchsde_amd import _native, kernels as K
+    torch.manual_seed(0)
+    B, d, m, hf, hg, steps = 80, 12, 8, 16, 24, 9
+    mk = lambda *shape: (0.4 * torch.randn(*shape, device=DEV)).contiguous()      # noqa: E731
+    fnet = K.NeuralNet(mk(d, hf), None, mk(hf), mk(hf, d), mk(d), _native.ACT_TANH)
+    gnet = K.NeuralNet(mk(d, hg), mk(hg), mk(hg), mk(hg, d * m), mk(d * m), _native.ACT_TANH, _native.FINAL_NONE, 0.3)
+    bm = _bm(B, m, steps * DT, 11)
+    grid = np.arange(steps + 1) * DT
+    bm.adopt_grid(grid)
+    cells = np.asarray(bm.match_grid(grid), dtype=np.int64)
+    rows = np.zeros((steps, 8))
+    rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3] = DT, DT / 2, 1 / DT, np.sqrt(DT)
+    rows[:, 4], rows[:, 5], rows[:, 6], rows[:, 7] = np.sqrt(DT), np.sqrt(DT / 12), DT, grid[:-1]
+    schedule = K.TrajectorySchedule(rows, cells, [steps], [(0.0, 1.0)], torch.device(DEV), torch.float32)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ys = torch.empty(1, B, d, device=DEV)
+    K.trajectory_mlp_general(ys, y0, fnet, gnet, _native.NOISE_GENERAL, m, _native.TRAJ_EULER, schedule, bm)
+    y = y0.double()
+    W = lambda t: t.double()                                                       # noqa: E731
+    for k in range(steps):
+        t = grid[k]
+        dW = bm(float(grid[k]), float(grid[k + 1])).double()
+        f = torch.tanh(y @ W(fnet.tensors[0]) + W(fnet.tensors[2])) @ W(fnet.tensors[3]) + W(fnet.tensors[4])
+        hid = torch.tanh(y @ W(gnet.tensors[0]) + W(gnet.tensors[2]) + W(gnet.tensors[1]) * t)
+        g = (0.3 * (hid @ W(gnet.tensors[3]) + W(gnet.tensors[4]))).reshape(B, d, m)
+        y = y + f * DT + torch.bmm(g, dW.unsqueeze(-1)).squeeze(-1)
+    torch.testing.assert_close(ys[0].double(), y, rtol=2e-5, atol=2e-6)
+
+
+def test_c3_full_size_default_route_rows_vs_oracle():
+    """BASELINE configs[2] (16384 x 32 x 16, 1000 steps, hidden 64) as a drop-in call: the untouched NeuralGeneral-style
+    module through `sdeint` with no options is ONE launch, and its sampled rows agree with the oracle's restatement of the
+    reference's loop (euler.py:29-37 with misc.batch_mvp) on the same Brownian path."""
+    import torchsde_amd
+    from tests.test_gpu_full_size_oracle import _oracle_forward
+    c = configs.WORKLOADS["c3_euler_general_b16384_d32_m16"]
+    B, d, m, n, dt = c["B"], c["d"], c["m"], c["nsteps"], c["dt"]
+    sde = configs.make_problem(c["problem"], d, m, DEV)
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def bm(entropy):
+        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(B, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            first = torchsde_amd.sdeint(sde, y0, ts, bm=bm(20240601), method="euler", dt=dt)     # both routes, compared
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm(20240601), method="euler", dt=dt))
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        torch.testing.assert_close(ys, first, rtol=1e-4, atol=1e-5)
+        rows = helpers.sampled_rows(B, 64, seed=3, seams=(16, 64, B - 16))
+        ref32, ref64 = _oracle_forward(sde, rows, d, m, 20240601, n, dt, "euler", 0.1)
+        helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1],
+                                                 "C3 Euler-general final state, neural-SDE kernel")
+    finally:
+        torch.set_num_threads(before)

@@ -488,7 +488,7 @@ def test_describe_says_which_route_and_why():
     assert any("trajectory kernel" in line and "Euler" in line for line in recognise.describe(sde))
     mlp = problems.make("mlpdiag_ito", d=D).to(DEV)
     _solve(mlp, 1)
-    assert any("stays stepwise" in line and "depends on t" in line for line in recognise.describe(mlp))
+    assert any("stays stepwise" in line and "takes t" in line for line in recognise.describe(mlp))
 
 
 @pytest.mark.parametrize("method,levy", [("euler", "none"), ("srk", "space-time")])
@@ -716,3 +716,96 @@ def test_floor_division_is_not_a_scale():
     got = _solve(sde, 3)
     assert not _book(sde)["trusted"] and any("rounding_mode" in r for r in _book(sde)["refused"].values())
     assert torch.equal(got, _solve(sde, 3, stepwise=True))
+
+
+# ---- the cubic mode pinned to the REFERENCE (and to the oracle at full size), not to the stepwise route
+def _poly3_cases():
+    import os
+    from tests import helpers
+    return sorted(f[len("recognised_poly3_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("recognised_poly3_"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("name", _poly3_cases())
+def test_polynomial_user_modules_on_the_expression_kernel_match_the_reference(name, dtype):
+    """tests/golden/recognised_poly3_*.npz: the REAL reference's `sdeint` of the plain double-well / logistic modules in
+    float64 on the counter path (make_golden.py gen_poly3). The recognised route (TSDE_FN_POLY3 in
+    tsde_trajectory_expr_diag) must reproduce it: the verifying first solve (stepwise result) and the kernel launches after."""
+    import torchsde_amd
+    from tests import helpers
+    from tests.test_oracle_solvers import poly3_module
+    z = helpers.load(f"recognised_poly3_{name}.npz")
+    Bz, d, steps = (int(v) for v in z["shape"])
+    dt, levy = float(z["dt"]), str(z["levy"])
+    sde = poly3_module(z, dtype).to(DEV)
+    y0 = torch.tensor(z["y0"], dtype=dtype, device=DEV)
+    ts = torch.tensor(z["ts"], dtype=dtype, device=DEV)
+    want = torch.tensor(z["ys"])
+    tol = dict(rtol=1e-9, atol=1e-11) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-5)
+
+    def solve():
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(Bz, d), dtype=dtype, device=DEV, entropy=int(z["entropy"]),
+                                           dt=dt, levy_area_approximation=levy)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=str(z["method"]), dt=dt)
+    torch.testing.assert_close(solve().double().cpu(), want, **tol)                 # both routes, the stepwise one returned
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    assert [key[0][0][0] for key in _book(sde)["trusted"]] == ["poly3"]             # the drift is a cubic
+    fast, launches = _launches(solve)
+    assert launches == 1
+    torch.testing.assert_close(fast.double().cpu(), want, **tol)
+
+
+def test_full_size_double_well_on_the_expression_kernel_rows_vs_oracle():
+    """65536 x 64 x 1000 Euler steps of the double-well module through TSDE_FN_POLY3: sampled rows against the oracle's
+    restatement of the reference's loop on the same Brownian path (the bound of tests/test_gpu_full_size_oracle.py)."""
+    import torchsde_amd
+    from tests import helpers
+    from tests.test_gpu_full_size_oracle import _bm, _oracle_forward
+    Bf, d, n, dt = 65536, 64, 1000, 2.0 ** -10
+    sde = problems.DoubleWell(d).to(DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            torchsde_amd.sdeint(sde, y0, ts, bm=_bm(Bf, d, n, dt, 5), method="euler", dt=dt)       # earns trust at this size
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=_bm(Bf, d, n, dt, 20240601),
+                                                                 method="euler", dt=dt))
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True]
+        rows = helpers.sampled_rows(Bf, 48, seed=6, seams=(32, Bf - 32))
+        ref32, ref64 = _oracle_forward(sde, rows, d, d, 20240601, n, dt, "euler", 0.1)
+        helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1],
+                                                 "double well, Euler, TSDE_FN_POLY3")
+    finally:
+        torch.set_num_threads(before)
+
+
+@pytest.mark.parametrize("method,adjoint_method,sde_type", [("euler", "euler", "ito"), ("milstein", "milstein", "ito"),
+                                                            ("midpoint", "milstein", "stratonovich")])
+def test_recognised_perceptron_adjoint_against_the_oracle(method, adjoint_method, sde_type):
+    """`sdeint_adjoint` of an unchanged latent-SDE module on the matrix-core adjoint (tsde_trajectory_mlp_diag forward,
+    tsde_adjoint_mlp_diag + tsde_gram_partials backward), pinned to the ORACLE's restatement of the reference's adjoint
+    (oracle/adjoint_ref.py: adjoint.py:64-127, adjoint_sde.py:177-230, 296-323, 332-377) on the same Brownian path -- states,
+    dL/dy0 and every parameter gradient within the reference's own float32 rounding (not only against
+    this package's stepwise route)."""
+    import numpy as np
+
+    import torchsde_amd
+    from tests import helpers
+    from tests.test_gpu_full_size_oracle import _loss_weights, _oracle_adjoint
+    Bn, d, hidden, n, dt, entropy = 64, 32, 32, 48, 2.0 ** -7, 777
+    sde = _Latent(d, hidden, sde_type, nn.Softplus, True).to(DEV)
+    wt = _loss_weights(Bn, d)
+    y0 = torch.full((Bn, d), 0.1, device=DEV, requires_grad=True)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+    bm = torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bn, d), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt)
+    ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method=method, adjoint_method=adjoint_method, dt=dt)
+    assert type(ys.grad_fn).__name__.startswith("_MlpAdjointFn"), type(ys.grad_fn).__name__
+    (ys[-1] * wt.to(DEV, torch.float32)).sum().backward()
+    (ys32, gy32, gp32), (ys64, gy64, gp64) = _oracle_adjoint(sde, np.arange(Bn), d, entropy, n, dt, method, adjoint_method, wt)
+    helpers.assert_within_reference_rounding(ys[-1], ys32[-1], ys64[-1], "final state")
+    helpers.assert_within_reference_rounding(y0.grad, gy32, gy64, "dL/dy0")
+    for (name, p), g32, g64 in zip(sde.named_parameters(), gp32, gp64):
+        helpers.assert_within_reference_rounding(p.grad, g32, g64, f"dL/d{name}")

@@ -146,3 +146,45 @@ def test_oracle_matches_reference_on_the_counter_path_expressions(name):
     with torch.no_grad():
         ys = solvers_ref.integrate(sde, bm, torch.tensor(z["y0"]), torch.tensor(z["ts"]), dt, str(z["method"]), None)
     torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
+
+
+def _poly3_cases():
+    import os
+    return sorted(f[len("recognised_poly3_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("recognised_poly3_"))
+
+
+def poly3_module(z, dtype=torch.float64):
+    """The plain user module of a recognised_poly3_* fixture (workloads.problems.DoubleWell / Logistic) with the fixture's
+    parameter values."""
+    from workloads import problems
+    d = int(z["shape"][1])
+    sde = problems.DoubleWell(d) if str(z["problem"]) == "DoubleWell" else problems.Logistic(d, str(z["sde_type"]))
+    sde = sde.to(dtype)
+    sde.sde_type = str(z["sde_type"])
+    with torch.no_grad():
+        for name, p in sde.named_parameters():
+            p.copy_(torch.tensor(z["param__" + name]).to(dtype))
+    return sde
+
+
+@pytest.mark.parametrize("name", _poly3_cases())
+def test_oracle_matches_reference_on_polynomial_user_modules(name):
+    """The oracle's loop on the double-well / logistic modules, counter path, against the REAL reference's output."""
+    import numpy as np
+
+    from oracle import counter
+    z = helpers.load(f"recognised_poly3_{name}.npz")
+    B, d, steps = (int(v) for v in z["shape"])
+    dt, levy = float(z["dt"]), str(z["levy"])
+    edges = np.arange(steps + 1) * dt
+
+    def bm(ta, tb, return_U=False):
+        W, U, _ = counter.query(B * d, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float64,
+                                have_h=levy != "none")
+        W = torch.from_numpy(W).reshape(B, d)
+        return (W, torch.from_numpy(U).reshape(B, d)) if return_U else W
+
+    with torch.no_grad():
+        ys = solvers_ref.integrate(poly3_module(z), bm, torch.tensor(z["y0"]), torch.tensor(z["ts"]), dt,
+                                   str(z["method"]), None)
+    torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)

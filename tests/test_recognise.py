@@ -166,9 +166,14 @@ def test_perceptron_drift_hands_back_the_users_own_parameters():
     deep.net = nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8))
     with pytest.raises(recognise.NotElementwise):
         recognise.recognise(ForwardSDE(deep), torch.tensor(0.0), y)
-    mlp_with_time = problems.make("mlpdiag_ito", d=8)          # the reference's NeuralDiagonal: t is an input of the net
-    with pytest.raises(recognise.NotElementwise, match="depends on t"):
-        recognise.recognise(ForwardSDE(mlp_with_time), torch.tensor(0.0), y)
+    # a drift net that takes t (`cat([t, y])`, like the reference's NeuralDiagonal) beside an ELEMENTWISE diffusion: followed,
+    # but neither kernel family evaluates it (the perceptron-drift kernels have no time input, the neural-SDE kernel wants
+    # a diffusion net)
+    mlp_with_time = problems.make("mlpdiag_ito", d=8)
+    found = recognise.recognise(ForwardSDE(mlp_with_time), torch.tensor(0.0), y)
+    assert found.perceptron and found.f.wt is not None
+    with pytest.raises(recognise.NotElementwise, match="takes t"):
+        found.spec()
 
 
 def test_affine_leaves_are_the_users_tensors_or_nothing():
@@ -348,3 +353,66 @@ def test_polynomials_of_the_state_up_to_degree_three(name):
 def test_higher_degrees_and_functions_of_polynomials_are_refused(f):
     with pytest.raises(recognise.NotElementwise):
         recognise.recognise(ForwardSDE(_M(f, lambda s, t, y: y)), torch.tensor(0.3), torch.randn(16, D))
+
+
+# ---- drift AND diffusion networks of (t, y): the reference's Neural* problems ------------------------------------------
+def _evaluate(net, t, y):
+    """What tsde_trajectory_mlp_general computes for one `kernels.NeuralNet` (include/torchsde_amd.h: tsde_mlp_t)."""
+    w1, w1t, b1, w2, b2 = net.tensors
+    pre = y @ w1 + b1 + (0.0 if w1t is None else w1t * t)
+    hid = F.softplus(pre) if net.activation == 1 else torch.tanh(pre)
+    z = hid @ w2 + b2
+    return net.scale * (torch.sigmoid(z) if net.final == 1 else z)
+
+
+@pytest.mark.parametrize("name,noise,d,m", [("general_ito", "general", 8, 4), ("general_strat", "general", 8, 16),
+                                            ("netdiag_ito", "diagonal", 8, 8), ("netscalar_ito", "scalar", 8, 1)])
+def test_drift_and_diffusion_networks_with_time_as_an_input(name, noise, d, m):
+    """`torch.cat([t.expand(B, 1), y], 1)` into `nn.Sequential(Linear, Softplus, Linear[, Sigmoid])`, a numeric factor, the
+    reshape to (B, d, m): followed, and the spec evaluates to what the module computes (tests/problems.py:135-252)."""
+    from torchsde_amd import _native
+    if not _native.is_built():
+        pytest.skip("needs the built library (shape limits come from the C ABI)")
+    sde = problems.make(name, d=d, m=m) if noise == "general" else problems.make(name, d=d)
+    y, t = 0.5 * torch.randn(16, d), torch.tensor(0.37)
+    found = recognise.recognise(ForwardSDE(sde), t, y)
+    assert found.neural and not found.perceptron and not found.timed and found.affine_leaves() is None
+    kind, fnet, gnet, code, m_found = found.neural_spec(noise)
+    assert kind == "neural" and m_found == m and code == {"diagonal": 0, "scalar": 1, "general": 2}[noise]
+    assert fnet.tensors[1] is not None and gnet.tensors[1] is not None            # both nets see t
+    with torch.no_grad():
+        torch.testing.assert_close(_evaluate(fnet, t, y), sde.f(t, y), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(_evaluate(gnet, t, y).reshape(sde.g(t, y).shape), sde.g(t, y), rtol=1e-5, atol=1e-6)
+    # two probe heights, same networks (the trust check's comparison)
+    again = recognise.recognise(ForwardSDE(sde), t, y, rows=5).neural_spec(noise)
+    assert again[1] == fnet and again[2] == gnet and again[3:] == (code, m)
+    with pytest.raises(recognise.NotElementwise):
+        found.spec()
+
+
+def test_networks_the_neural_kernel_does_not_take():
+    from torchsde_amd import _native
+    if not _native.is_built():
+        pytest.skip("needs the built library")
+    y, t = torch.randn(16, 8), torch.tensor(0.1)
+    odd = problems.make("general_odd_ito")                     # d = 3, m = 5: no tile shape for it
+    with pytest.raises(recognise.NotElementwise):
+        recognise.recognise(ForwardSDE(odd), t, torch.randn(16, 3)).neural_spec("general")
+
+    class TimeTwice(problems.MLPNetDiag):                      # arithmetic on t before the cat: not "the time" any more
+        def _ty(self, t, y):
+            return torch.cat([(2 * t).expand(y.size(0), 1), y], dim=1)
+    with pytest.raises(recognise.NotElementwise, match="cat of t"):
+        recognise.recognise(ForwardSDE(TimeTwice(8)), t, y)
+
+    class Wrong(problems.MLPNetDiag):                          # [y, t] instead of [t, y]
+        def _ty(self, t, y):
+            return torch.cat([y, t.expand(y.size(0), 1)], dim=1)
+    with pytest.raises(recognise.NotElementwise, match="cat of t"):
+        recognise.recognise(ForwardSDE(Wrong(8)), t, y)
+
+    class Squared(problems.MLPNetDiag):                        # something after the net that is not a factor or a reshape
+        def g(self, t, y):
+            return self.g_net(self._ty(t, y)) ** 2
+    with pytest.raises(recognise.NotElementwise, match="output of the drift network"):
+        recognise.recognise(ForwardSDE(Squared(8)), t, y)

@@ -115,6 +115,12 @@ def _base(mnemonic):
     return mnemonic
 
 
+# Scalar operands. In isolation a VALU instruction that reads an SGPR issues every ~4.1 cycles (microbench rows v_bitop3_b32,
+# v_xor_b32(sgpr), v_mul_f32(sgpr)); in the step loop -- where 37 of 99 instructions read one -- making the Philox round keys
+# VGPR-resident changed nothing (profiles/r5e_vgpr_round_keys_experiment.txt): the limit is on back-to-back scalar reads.
+# The loop is therefore priced with the ALL-VGPR issue cost of those instructions (the lower, defensible figure).
+_IN_LOOP = {"v_bitop3_b32": "v_bitop3_b32(vgpr)", "v_mad_u64_u32": "v_mad_u64_u32(vgpr)"}
+
 # instructions that were measured under another name of the same encoding class / rate
 _ALIASES = {"v_sub_f32": "v_add_f32", "v_subrev_f32": "v_add_f32", "v_mov_b32": "v_not_b32", "v_and_b32": "v_xor_b32",
             "v_or_b32": "v_xor_b32", "v_sub_u32": "v_add_u32", "v_cmp_le_u32": "v_cmp_lt_u32",
@@ -139,6 +145,7 @@ def model(symbol=HEADLINE_SYMBOL, rates_path=None, source="trajectory.hip", elem
     cycles, unmeasured, plain = 0.0, [], 0.0
     for k, n in valu.items():
         key = _ALIASES.get(k, k)
+        key = _IN_LOOP[key] if _IN_LOOP.get(key) in rates else key
         if key in rates:
             cycles += n * rates[key]
         else:

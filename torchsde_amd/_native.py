@@ -18,6 +18,8 @@ ERROR_NORM_WORKSPACE = 1024
 TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
+FINAL_NONE, FINAL_SIGMOID = 0, 1
+NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL = 0, 1, 2
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6, "poly3": 7}
 
@@ -60,6 +62,12 @@ class Traj(ctypes.Structure):
     """``tsde_traj_t``."""
     _fields_ = [("step_rows", _c_ptr), ("cells", _c_ptr), ("out_step", _c_ptr), ("out_w", _c_ptr),
                 ("n_steps", ctypes.c_int32), ("n_out", ctypes.c_int32)]
+
+
+class Mlp(ctypes.Structure):
+    """``tsde_mlp_t``."""
+    _fields_ = [("w1", _c_ptr), ("w1t", _c_ptr), ("b1", _c_ptr), ("w2", _c_ptr), ("b2", _c_ptr), ("hidden", _c_i32),
+                ("out", _c_i32), ("activation", _c_i32), ("final", _c_i32), ("scale", _c_dbl)]
 
 
 _PTR4 = _c_ptr * 4
@@ -132,6 +140,10 @@ SIGNATURES = {
     "tsde_trajectory_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_ptr, _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                           _c_ptr]),
+    "tsde_trajectory_mlp_general": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(Mlp),
+                                             ctypes.POINTER(Mlp), _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
+                                             _c_ptr]),
+    "tsde_trajectory_mlp_general_lds": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int]),
     "tsde_trajectory_mlp_diag_backward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i32, _c_ptr,
                                                    _c_ptr, _c_i32, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                    _c_int, _c_dbl, _c_int, _c_int, ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64,

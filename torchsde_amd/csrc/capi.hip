@@ -532,6 +532,55 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
               where);
 }
 
+int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden,
+                                        int64_t diffusion_out, int noise) {
+  if (d < 4 || d % 4 != 0 || drift_hidden < 1 || diffusion_hidden < 1 || diffusion_out < 1) return 0;
+  return (int64_t)tsde::neural_footprint(d, m, drift_hidden, diffusion_hidden, diffusion_out, noise);
+}
+
+int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                                const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method, const tsde_traj_t* traj,
+                                uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_trajectory_mlp_general";
+  if (!ys || !y0 || !drift || !diffusion || !traj) return bad_arg(where, "null argument");
+  for (const tsde_mlp_t* net : {drift, diffusion}) {
+    if (!net->w1 || !net->b1 || !net->w2 || !net->b2) return bad_arg(where, "a perceptron without weights or biases");
+    if (net->hidden < 1 || net->hidden > 64) return bad_arg(where, "hidden sizes must be in [1, 64]");
+    if (net->activation != TSDE_ACT_TANH && net->activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
+    if (net->final != TSDE_FINAL_NONE && net->final != TSDE_FINAL_SIGMOID) return bad_arg(where, "unknown output function");
+  }
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (rows < 0) return bad_arg(where, "need rows >= 0");
+  if (d < 4 || d > 64 || d % 4 != 0) return bad_arg(where, "need d a multiple of 4 in [4, 64]");
+  if (drift->out != d || drift->final != TSDE_FINAL_NONE || drift->scale != 1.0)
+    return bad_arg(where, "the drift maps to d channels, with no output function and scale 1");
+  if (noise == TSDE_NOISE_GENERAL) {
+    if (m != 4 && m != 8 && m != 16 && m != 32) return bad_arg(where, "general noise: m must be 4, 8, 16 or 32");
+    if (diffusion->out != d * m) return bad_arg(where, "general noise: the diffusion net maps to d * m outputs");
+  } else if (noise == TSDE_NOISE_DIAGONAL || noise == TSDE_NOISE_SCALAR) {
+    if (diffusion->out != d) return bad_arg(where, "diagonal / scalar noise: the diffusion net maps to d outputs");
+    if (m != (noise == TSDE_NOISE_DIAGONAL ? d : 1)) return bad_arg(where, "m must be d (diagonal) or 1 (scalar)");
+  } else {
+    return bad_arg(where, "unknown noise kind");
+  }
+  if (tsde::neural_footprint(d, m, drift->hidden, diffusion->hidden, diffusion->out, noise) == 0)
+    return bad_arg(where, "no kernel for this shape");
+  if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
+    return bad_arg(where, "ys and y0 must be 16-byte aligned");
+  if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
+  if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT) return bad_arg(where, "method must be Euler or midpoint");
+  if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
+  if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  const hipError_t e = tsde::launch_trajectory_mlp_general(ys, y0, rows, d, m, noise, drift, diffusion, method, traj,
+                                                           make_key(entropy, elem0), entropy_dev, s);
+  if (e == hipErrorInvalidValue) return bad_arg(where, "the weights of this shape do not fit the LDS of a CU");
+  return fail(e, where);
+}
+
 int tsde_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, int64_t d, const void* const coef[8], int f_kind,
                               int g_kind, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
                               const uint64_t* entropy_dev, int dtype, void* stream) {

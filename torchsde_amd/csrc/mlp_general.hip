@@ -1,0 +1,515 @@
+// Whole-trajectory kernel for neural SDEs whose drift AND diffusion are two-layer perceptrons of (t, y) shared by the
+// batch, on gfx950 -- the reference's `Neural*` problems (tests/problems.py:135-252) and BASELINE configs[2]:
+//
+//     f(t, y) = W2f . act(W1f . y + w1tf * t + b1f) + b2f                                       (rows, d)
+//     g(t, y) = scale * final(W2g . act(W1g . y + w1tg * t + b1g) + b2g)                         final: identity | sigmoid
+//         general noise : (rows, d * m) read as (rows, d, m)  -> the step adds  sum_j g[., i, j] dW[., j]
+//         diagonal noise: (rows, d)                            -> g[., i] dW[., i]
+//         scalar noise  : (rows, d), one Brownian channel/row  -> g[., i] dW[.]
+//
+// `w1t` is the first layer's weight column of the TIME input, torch.cat([t.expand(B, 1), y], 1) in the reference's
+// modules: per stage time it is one more bias, b1 + w1t * t, so t never becomes a matrix operand.
+//
+// Replaces, for such modules, the whole stepping loop torchsde/_core/base_solver.py:114-134 with
+//   methods/euler.py:29-37 (f_and_g_prod -> misc.batch_mvp, _core/misc.py:62-63: bmm(g, dW))     TSDE_TRAJ_EULER
+//   methods/midpoint.py:29-45 (two evaluations, the second at t + dt/2 and the predicted state)   TSDE_TRAJ_MIDPOINT
+// in ONE launch. Stepwise, this SDE costs a (rows, d, m) diffusion tensor through HBM and four library GEMMs per step
+// (the user's two nets are 93 % of the solve at the configs[2] shape); here nothing but y0 and the outputs touches HBM.
+//
+// A wave owns 16 batch rows; state, hidden activations and results live in the accumulator layout of
+// v_mfma_f32_16x16x4_f32 exactly as in mlp_trajectory.hip (lane (part, n): batch row n, channels 4 part + r of a tile),
+// all weights live in LDS for the whole solve (hidden-major, rows padded by 4 floats: conflict-free ds_read_b32).
+// The diffusion's second layer produces G^T tile by tile -- 16 consecutive outputs o = i * m + j of 16 batch rows -- and
+// each tile is consumed on the spot:
+//   * lane (part, n) holds G[n][o = 16 tile + 4 part + r], r = 0..3: four consecutive Brownian channels j of ONE state
+//     channel i (m % 4 == 0), i.e. the four normals of ONE Philox quad of the (rows, m) increment field every other
+//     kernel draws from -- generated in registers once per step and lane;
+//   * the lane's partial sum s = sum_r G[r] dW[r] still has to be added over the lanes that hold the other j of the same
+//     (n, i): that reduction is one more MFMA, D[i][n] += sum_k A[i][k] s_k[n] with a 0/1 selector as A operand, which
+//     lands the sum in register r', lane (part', n) with i = 4 part' + r' -- the layout of the state. No shuffle, no
+//     LDS round trip, no select: the contraction's result is born where the update needs it.
+#include <type_traits>
+
+#include "tsde_common.h"
+#include "tsde_launch.h"
+#include "tsde_mlp.h"
+#include "tsde_schemes.h"
+
+namespace tsde {
+
+struct NeuralNet {          // device view of tsde_mlp_t (pointers as given: input-major weights)
+  const float *w1, *w1t, *b1, *w2, *b2;
+  int32_t hidden, out, act, final;
+  float scale;
+};
+
+struct NeuralArgs {
+  float* ys;                // (n_out, B, d)
+  const float* y0;          // (B, d)
+  NeuralNet f, g;
+  const float* rows;        // (n_steps, 8): dt, dt/2, 1/dt, sqrt(dt), sqrt(h), sqrt(h/12), h, t_k
+  const uint32_t* cells;
+  const int32_t* out_step;
+  const float* out_w;
+  int64_t B;
+  int32_t d, m;
+  int32_t n_steps, n_out;
+  int32_t method;           // TSDE_TRAJ_EULER | TSDE_TRAJ_MIDPOINT
+  NoiseKey key;
+  const uint64_t* key_dev;
+};
+
+// MODE: 0 = diagonal noise, 1 = scalar noise, else general noise with m = MODE Brownian channels (4, 8, 16, 32).
+template <int MODE>
+struct NoiseShape {
+  static constexpr bool kGeneral = MODE >= 4;
+  static constexpr int M = kGeneral ? MODE : 1;
+  // tiles of G^T handled together (independent accumulator chains: a dependent f32 MFMA waits 40 cycles, issue is 32)
+  static constexpr int G = (M >= 32) ? M / 16 : 2;
+  static constexpr int kQuads = (M >= 16) ? M / 16 : 1;      // Philox quads of a row's increments one lane needs
+};
+
+// the diffusion net's output function (uniform over the launch: callers branch once, outside their loops)
+template <bool SIGMOID>
+TSDE_D float finalise(float z) {
+  if constexpr (SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+  return z;
+}
+
+// Schedule of a straight-line region of READS LDS operand reads, each feeding PER matrix instructions: the first few reads
+// go out ahead, then every group of PER MFMAs is followed by one more read -- left alone, hipcc emits read -> wait -> PER
+// MFMAs and the wave (there is ONE per SIMD at the configs[2] shape, nothing else to switch to) sits out the LDS latency
+// once per read: 18.7 ms per 1000-step solve at 16384 x 32 x 16 before, see DESIGN.md for after.
+template <int READS, int PER>
+TSDE_D void reads_ahead() {
+  constexpr int AHEAD = READS < 4 ? READS : 4;
+  __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+  for (int i = 0; i < READS; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+    if (i < READS - AHEAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// LDS footprint in floats (rows padded by 4: the four lane quarters of a wave read rows 4 apart, see mlp_trajectory.hip)
+template <int D, int H>
+struct NeuralLds {
+  static constexpr int S1 = H + 4, S2F = D + 4;
+  static constexpr int out_padded(int out, int group) { return (out + 16 * group - 1) / (16 * group) * (16 * group); }
+  static constexpr size_t floats(int outp) {
+    return (size_t)2 * D * S1 + (size_t)H * S2F + (size_t)H * (outp + 4) + 4 * H + D + outp;
+  }
+};
+
+template <int D, int H, int MODE>
+__global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
+  using NS = NoiseShape<MODE>;
+  using L = NeuralLds<D, H>;
+  constexpr int TD = D / 16, TH = H / 16, S1 = L::S1, S2F = L::S2F, M = NS::M, G = NS::G;
+  const int S2G = outp + 4;
+  extern __shared__ float lds[];
+  float* W1f = lds;                     // D rows of S1:  [input channel][hidden unit]
+  float* W1g = W1f + D * S1;
+  float* W2f = W1g + D * S1;            // H rows of S2F: [hidden unit][state channel]
+  float* W2g = W2f + H * S2F;           // H rows of S2G: [hidden unit][output o]
+  float* b1f = W2g + H * S2G;           // H each: b1f, wtf, b1g, wtg
+  float* wtf = b1f + H;
+  float* b1g = wtf + H;
+  float* wtg = b1g + H;
+  float* b2f = wtg + H;                 // D
+  float* b2g = b2f + D;                 // outp
+  const int dT = p.d, hf = p.f.hidden, hg = p.g.hidden, outT = p.g.out;
+  // weights into LDS, zero-padded to the tile sizes: padded hidden units see zero weights both ways, padded state channels
+  // and padded outputs are never read back (their selectors are 0 / their channels are skipped)
+  for (int i = threadIdx.x; i < D * H; i += 256) {
+    const int k = i / H, u = i % H;
+    W1f[k * S1 + u] = (k < dT && u < hf) ? p.f.w1[k * hf + u] : 0.0f;
+    W1g[k * S1 + u] = (k < dT && u < hg) ? p.g.w1[k * hg + u] : 0.0f;
+    const int u2 = i / D, c = i % D;
+    W2f[u2 * S2F + c] = (u2 < hf && c < dT) ? p.f.w2[u2 * dT + c] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < H * outp; i += 256) {
+    const int u = i / outp, o = i % outp;
+    W2g[u * S2G + o] = (u < hg && o < outT) ? p.g.w2[(int64_t)u * outT + o] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < H; i += 256) {
+    b1f[i] = i < hf ? p.f.b1[i] : 0.0f;
+    wtf[i] = (i < hf && p.f.w1t) ? p.f.w1t[i] : 0.0f;
+    b1g[i] = i < hg ? p.g.b1[i] : 0.0f;
+    wtg[i] = (i < hg && p.g.w1t) ? p.g.w1t[i] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < D; i += 256) b2f[i] = i < dT ? p.f.b2[i] : 0.0f;
+  for (int i = threadIdx.x; i < outp; i += 256) b2g[i] = i < outT ? p.g.b2[i] : 0.0f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane >> 4, n = lane & 15;
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+  const bool midpoint = p.method == TSDE_TRAJ_MIDPOINT;
+  const float g_scale = p.g.scale;
+  const bool sigmoid_out = p.g.final == TSDE_FINAL_SIGMOID;
+  const int64_t n_groups = (p.B + 15) / 16;
+  // a block stages the weights once and its four waves walk over groups of 16 rows (grid = resident blocks)
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = grp * 16;
+    // in the last partial group the surplus lanes shadow the last row (same reads, same noise, same writes)
+    const int64_t row = row0 + n < p.B ? row0 + n : p.B - 1;
+    const uint32_t off_d = (uint32_t)(row * dT);
+    auto real = [&](int ch) { return ch < dT; };
+
+    f32x4 y[TD];
+#pragma unroll
+    for (int t = 0; t < TD; ++t) {
+      const int ch = 16 * t + 4 * part;
+      y[t] = real(ch) ? *reinterpret_cast<const f32x4*>(p.y0 + off_d + ch) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+
+    // hid^T = act(W1^T x^T + (b1 + wt * t)): loop order (t, r) outer, th inner -> consecutive MFMAs hit different accumulators
+    auto hidden_layer = [&](const float* W1, const float* b1, const float* wt, int act, float time, const f32x4* x,
+                            f32x4* hid) {
+      int o1 = 0;
+      asm volatile("" : "+v"(o1));        // (the two stages of the midpoint scheme must not share their operand reads)
+#pragma unroll
+      for (int th = 0; th < TH; ++th) hid[th] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int th = 0; th < TH; ++th) {
+            const float a = W1[o1 + (16 * t + 4 * part + r) * S1 + 16 * th + n];
+            hid[th] = Tile<16>::mfma(a, x[t][r], hid[th]);
+          }
+        }
+      }
+      reads_ahead<TD * 4 * TH / 2, 2>();      // (operands of two neighbouring unit tiles arrive as one ds_read2_b32)
+      // (the activation kind is uniform over the launch: one scalar branch around two straight-line copies)
+      auto finish = [&](auto kind) {
+        constexpr int ACT = decltype(kind)::value;
+#pragma unroll
+        for (int th = 0; th < TH; ++th) {
+          const f32x4 bias = lds_quad(b1, 16 * th + 4 * part), slope = lds_quad(wt, 16 * th + 4 * part);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hid[th][r] = activate<ACT>(hid[th][r] + (bias[r] + slope[r] * time));
+        }
+      };
+      if (act == TSDE_ACT_TANH) finish(std::integral_constant<int, TSDE_ACT_TANH>{});
+      else finish(std::integral_constant<int, TSDE_ACT_SOFTPLUS>{});
+    };
+
+    // drift tiles f^T = W2f^T hid^T + b2f (TD independent chains)
+    auto drift = [&](const f32x4* hid, f32x4* f) {
+      int o2 = 0;
+      asm volatile("" : "+v"(o2));
+#pragma unroll
+      for (int t = 0; t < TD; ++t) f[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int th = 0; th < TH; ++th) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+            const float a = W2f[o2 + (16 * th + 4 * part + r) * S2F + 16 * t + n];
+            f[t] = Tile<16>::mfma(a, hid[th][r], f[t]);
+          }
+        }
+      }
+      if constexpr (TD == 1) reads_ahead<TH * 4, 1>();
+      else reads_ahead<TH * 4 * TD / 2, 2>();
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const f32x4 bias = lds_quad(b2f, 16 * t + 4 * part);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[t][r] += bias[r];
+      }
+    };
+
+    // (g dW)^T in the state's layout, from the diffusion net's hidden activations
+    auto diffusion_product = [&](const f32x4* hid, uint32_t cell, float sw, f32x4* gdw) {
+#pragma unroll
+      for (int t = 0; t < TD; ++t) gdw[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if constexpr (NS::kGeneral) {
+        // this lane's increments: kQuads Philox quads of row `row`, scaled by sqrt(h) and the net's output scale
+        const uint64_t quad_row = (key.elem0 + (uint64_t)row * (uint64_t)M) >> 2;
+        float dw[NS::kQuads][4];
+#pragma unroll
+        for (int q = 0; q < NS::kQuads; ++q) {
+          uint64_t quad = quad_row + (M >= 16 ? 4 * q + part : (M == 8 ? (part & 1) : 0));
+          asm volatile("" : "+v"(quad));
+          float z[4];
+          normal4<float>(key, quad, cell, 0, kStreamW, z);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dw[q][r] = (z[r] * sw) * g_scale;
+        }
+#pragma unroll
+        for (int ty = 0; ty < TD; ++ty) {
+          const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;        // real state channels of this tile (wave-uniform)
+          if (channels <= 0) continue;
+          const int tiles = channels * M / 16;                               // G^T tiles that feed them
+          for (int p0 = 0; p0 < tiles; p0 += G) {
+            f32x4 acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int col0 = 16 * (ty * M + p0) + n;                         // output column of tile p0 for this lane
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int th = 0; th < TH; ++th) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                  const float a = W2g[(16 * th + 4 * part + r) * S2G + col0 + 16 * g];
+                  acc[g] = Tile<16>::mfma(a, hid[th][r], acc[g]);
+                }
+              }
+            }
+            reads_ahead<TH * 4 * G / 2, 2>();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int tl = p0 + g;                                         // tile within this state tile
+              const f32x4 bias = lds_quad(b2g, 16 * (ty * M + tl) + 4 * part);
+              // which state channel (within the tile) this lane's four outputs belong to, and which of its quads they meet
+              int target, q;
+              if constexpr (M >= 16) {
+                target = tl / (M / 16);
+                q = (M == 16) ? 0 : g;                                       // (G = M / 16 tiles per channel for M >= 32)
+              } else if constexpr (M == 8) {
+                target = 2 * tl + (part >> 1);
+                q = 0;
+              } else {
+                target = 4 * tl + part;
+                q = 0;
+              }
+              float s = 0.0f;
+              if (sigmoid_out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(finalise<true>(acc[g][r] + bias[r]), dw[q][r], s);
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(acc[g][r] + bias[r], dw[q][r], s);
+              }
+              const float sel = (n == target && tl < tiles) ? 1.0f : 0.0f;
+              gdw[ty] = Tile<16>::mfma(sel, s, gdw[ty]);
+            }
+          }
+        }
+      } else {
+        // diagonal / scalar noise: the net's output IS one diffusion value per state channel
+        float w_row = 0.0f;
+        if constexpr (MODE == 1) w_row = normal1<float>(key, key.elem0 + (uint64_t)row, cell, 0, kStreamW) * sw;
+        int o2 = 0;
+        asm volatile("" : "+v"(o2));
+        f32x4 acc[TD];
+#pragma unroll
+        for (int t = 0; t < TD; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int th = 0; th < TH; ++th) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+              const float a = W2g[o2 + (16 * th + 4 * part + r) * S2G + 16 * t + n];
+              acc[t] = Tile<16>::mfma(a, hid[th][r], acc[t]);
+            }
+          }
+        }
+        if constexpr (TD == 1) reads_ahead<TH * 4, 1>();
+        else reads_ahead<TH * 4 * TD / 2, 2>();
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+          const int ch = 16 * t + 4 * part;
+          const f32x4 bias = lds_quad(b2g, ch);
+          float z[4] = {w_row, w_row, w_row, w_row};
+          if constexpr (MODE == 0) {
+            uint64_t quad = (key.elem0 + (uint64_t)off_d + (uint64_t)ch) >> 2;
+            asm volatile("" : "+v"(quad));
+            if (real(ch)) normal4<float>(key, quad, cell, 0, kStreamW, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] *= sw;
+          }
+          if (sigmoid_out) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gdw[t][r] = (g_scale * finalise<true>(acc[t][r] + bias[r])) * z[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gdw[t][r] = (g_scale * (acc[t][r] + bias[r])) * z[r];
+          }
+        }
+      }
+    };
+
+    int jout = 0;
+    for (int k = 0; k < p.n_steps; ++k) {
+      const float* srow = p.rows + (int64_t)k * 8;
+      const float dt = srow[0], half_dt = srow[1], sw = srow[4], t0 = srow[7];
+      const uint32_t cell = p.cells[k];
+      f32x4 hid[TH], f[TD], gdw[TD], yn[TD];
+      hidden_layer(W1f, b1f, wtf, p.f.act, t0, y, hid);
+      drift(hid, f);
+      hidden_layer(W1g, b1g, wtg, p.g.act, t0, y, hid);
+      diffusion_product(hid, cell, sw, gdw);
+      if (midpoint) {
+        // y' = (y + f dt/2) + (g dW)/2, then everything again at (t + dt/2, y')          (midpoint.py:31-43)
+        f32x4 yp[TD];
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yp[t][r] = (y[t][r] + f[t][r] * half_dt) + 0.5f * gdw[t][r];
+        }
+        const float tm = t0 + half_dt;
+        hidden_layer(W1f, b1f, wtf, p.f.act, tm, yp, hid);
+        drift(hid, f);
+        hidden_layer(W1g, b1g, wtg, p.g.act, tm, yp, hid);
+        diffusion_product(hid, cell, sw, gdw);
+      }
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yn[t][r] = (y[t][r] + f[t][r] * dt) + gdw[t][r];          // euler.py:36
+      }
+      // outputs due at the end of this step: w0 y_k + w1 y_{k+1} (base_solver.py:147, interp.py:15-18)
+      while (jout < p.n_out && p.out_step[jout] == k + 1) {
+        const float w0 = p.out_w[2 * jout], w1 = p.out_w[2 * jout + 1];
+        const bool exact = w0 == 0.0f && w1 == 1.0f;
+        float* dst = p.ys + (int64_t)jout * p.B * dT;
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+          const int ch = 16 * t + 4 * part;
+          Pack<float, 4> o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o.v[r] = exact ? yn[t][r] : (w0 * y[t][r] + w1 * yn[t][r]);
+          if (real(ch)) store<float, 4>(dst, off_d + ch, o);
+        }
+        ++jout;
+      }
+#pragma unroll
+      for (int t = 0; t < TD; ++t) y[t] = yn[t];
+    }
+  }
+}
+
+size_t neural_lds_bytes(int D, int H, int outp) {
+  return ((size_t)2 * D * (H + 4) + (size_t)H * (D + 4) + (size_t)H * (outp + 4) + 4 * H + D + outp) * sizeof(float);
+}
+
+static size_t neural_lds_limit() {
+  static const size_t limit = [] {
+    int dev = 0, bytes = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&bytes, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && bytes > 0)
+      return (size_t)bytes;
+    return (size_t)(64 * 1024);
+  }();
+  return limit;
+}
+
+template <int D, int H, int MODE>
+static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
+  const int outp = NeuralLds<D, H>::out_padded(p.g.out, NoiseShape<MODE>::kGeneral ? NoiseShape<MODE>::G : 1);
+  const size_t lds_bytes = neural_lds_bytes(D, H, outp);
+  if (lds_bytes > neural_lds_limit()) return hipErrorInvalidValue;
+  static bool configured = false;   // per instantiation
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&neural_trajectory_kernel<D, H, MODE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  const int64_t groups = (p.B + 15) / 16;
+  int64_t blocks = (groups + 3) / 4;
+  // resident blocks: the LDS of a CU holds floor(160 KiB / footprint) of them
+  const int64_t per_cu = (int64_t)((160 * 1024) / lds_bytes) < 1 ? 1 : (int64_t)((160 * 1024) / lds_bytes);
+  const int64_t resident = 256 * (per_cu > 8 ? 8 : per_cu);
+  if (blocks > resident) blocks = resident;
+  hipLaunchKernelGGL((neural_trajectory_kernel<D, H, MODE>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p, outp);
+  return hipGetLastError();
+}
+
+template <int D, int H>
+static hipError_t launch_neural_dh(const NeuralArgs& p, int noise, hipStream_t s) {
+  if (noise == TSDE_NOISE_DIAGONAL) return launch_neural_mode<D, H, 0>(p, s);
+  if (noise == TSDE_NOISE_SCALAR) return launch_neural_mode<D, H, 1>(p, s);
+  switch (p.m) {
+    case 4: return launch_neural_mode<D, H, 4>(p, s);
+    case 8: return launch_neural_mode<D, H, 8>(p, s);
+    case 16: return launch_neural_mode<D, H, 16>(p, s);
+    case 32: return launch_neural_mode<D, H, 32>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int D>
+static hipError_t launch_neural_d(const NeuralArgs& p, int noise, hipStream_t s) {
+  const int h = p.f.hidden > p.g.hidden ? p.f.hidden : p.g.hidden;
+  if (h <= 32) return launch_neural_dh<D, 32>(p, noise, s);
+  if (h <= 64) return launch_neural_dh<D, 64>(p, noise, s);
+  return hipErrorInvalidValue;
+}
+
+static NeuralNet device_view(const tsde_mlp_t* n) {
+  NeuralNet v;
+  v.w1 = (const float*)n->w1;
+  v.w1t = (const float*)n->w1t;
+  v.b1 = (const float*)n->b1;
+  v.w2 = (const float*)n->w2;
+  v.b2 = (const float*)n->b2;
+  v.hidden = n->hidden;
+  v.out = n->out;
+  v.act = n->activation;
+  v.final = n->final;
+  v.scale = (float)n->scale;
+  return v;
+}
+
+// The LDS footprint of a shape in bytes, or 0 if no instantiation covers it (the C ABI's tsde_trajectory_mlp_general_lds:
+// the host asks before it routes a module here).
+size_t neural_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t out, int noise) {
+  const int D = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 0;
+  const int64_t h = hf > hg ? hf : hg;
+  const int H = h <= 32 ? 32 : h <= 64 ? 64 : 0;
+  if (D == 0 || H == 0) return 0;
+  int group = 1;
+  if (noise == TSDE_NOISE_GENERAL) {
+    if (m != 4 && m != 8 && m != 16 && m != 32) return 0;
+    group = m >= 32 ? (int)m / 16 : 2;
+  }
+  const int outp = (int)((out + 16 * group - 1) / (16 * group) * (16 * group));
+  return neural_lds_bytes(D, H, outp);
+}
+
+hipError_t launch_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                                         const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method,
+                                         const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
+  NeuralArgs p;
+  p.ys = (float*)ys;
+  p.y0 = (const float*)y0;
+  p.f = device_view(drift);
+  p.g = device_view(diffusion);
+  p.rows = (const float*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const float*)tr->out_w;
+  p.B = rows;
+  p.d = (int32_t)d;
+  p.m = (int32_t)m;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.method = method;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (rows <= 0 || tr->n_steps <= 0) return hipSuccess;
+  if (d <= 16) return launch_neural_d<16>(p, noise, s);
+  if (d <= 32) return launch_neural_d<32>(p, noise, s);
+  if (d <= 64) return launch_neural_d<64>(p, noise, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace tsde

@@ -711,6 +711,60 @@ def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activatio
     return ys
 
 
+class NeuralNet:
+    """One perceptron of ``tsde_trajectory_mlp_general`` (``tsde_mlp_t``): out = scale * final(W2 . act(W1 . y + w1t * t + b1)
+    + b2) with `w1` (in, hidden) and `w2` (hidden, out) input-major, `w1t` (hidden) the weight column of the time input or
+    None. Holds contiguous float32 device tensors (and keeps them alive for the launch)."""
+
+    def __init__(self, w1, w1t, b1, w2, b2, activation, final=_native.FINAL_NONE, scale=1.0):
+        self.tensors = [None if t is None else _native.contiguous(t.detach()) for t in (w1, w1t, b1, w2, b2)]
+        self.activation, self.final, self.scale = int(activation), int(final), float(scale)
+        self.hidden, self.out = int(self.tensors[2].numel()), int(self.tensors[4].numel())
+
+    def struct(self):
+        w1, w1t, b1, w2, b2 = self.tensors
+        return _native.Mlp(w1.data_ptr(), 0 if w1t is None else w1t.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                           self.hidden, self.out, self.activation, self.final, self.scale)
+
+    def __eq__(self, other):
+        return isinstance(other, NeuralNet) and (self.activation, self.final, self.scale) == (
+            other.activation, other.final, other.scale) and all(
+            (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and torch.equal(a, b))
+            for a, b in zip(self.tensors, other.tensors))
+
+    __hash__ = None
+
+
+def mlp_general_lds(d, m, drift_hidden, diffusion_hidden, diffusion_out, noise):
+    """Bytes of LDS ``tsde_trajectory_mlp_general`` needs for a shape (0: no kernel covers it)."""
+    return int(_native.load().tsde_trajectory_mlp_general_lds(d, m, drift_hidden, diffusion_hidden, diffusion_out, noise))
+
+
+def trajectory_mlp_general(ys, y0, drift, diffusion, noise, m, method, schedule, bm):
+    """All steps of a neural SDE (drift and diffusion two-layer perceptrons of (t, y)) in one launch
+    (``tsde_trajectory_mlp_general``); slot 7 of the schedule's step rows must hold each step's start time
+    (`BaseSDESolver._integrate_trajectory` fills it)."""
+    _native.require_device(ys, y0, *[t for net in (drift, diffusion) for t in net.tensors])
+    rows, d = y0.shape
+    tensors = [ys, y0] + [t for net in (drift, diffusion) for t in net.tensors if t is not None]
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        raise ValueError("the neural-SDE kernel takes contiguous float32 tensors")
+    if ys.shape != (schedule.n_out, rows, d):
+        raise ValueError("shape mismatch: ys (n_out, rows, d)")
+    for net in (drift, diffusion):
+        w1, w1t, b1, w2, b2 = net.tensors
+        if w1.shape != (d, net.hidden) or w2.shape != (net.hidden, net.out) or (w1t is not None and w1t.numel() != net.hidden):
+            raise ValueError("shape mismatch: w1 (d, hidden), w1t (hidden), w2 (hidden, out)")
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    code = lib.tsde_trajectory_mlp_general(
+        ys.data_ptr(), y0.data_ptr(), rows, d, int(m), int(noise), ctypes.byref(drift.struct()),
+        ctypes.byref(diffusion.struct()), int(method), schedule.struct(), bm._key, bm._elem0,
+        None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    _native.check(code, "tsde_trajectory_mlp_general")
+    return ys
+
+
 class _TrajectoryFn(torch.autograd.Function):
     """Differentiable whole-trajectory solve of an affine diagonal SDE: the forward launch also produces the
     path-wise sensitivities of every output element (forward-mode tangents carried in registers), and the backward

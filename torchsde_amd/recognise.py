@@ -76,20 +76,38 @@ ZERO = object()         # the rate of a y-independent value
 
 
 class _Hidden:
-    """``act(y @ W1^T + b1)`` (act None: before the activation): a (rows, hidden) value of a perceptron drift."""
-    __slots__ = ("w1", "b1", "act")
+    """``act(x @ W1^T + b1)`` (act None: before the activation): a (rows, hidden) value of a perceptron. `x` is the state,
+    or ``cat([t.expand(rows, 1), y], 1)``: then `wt` is the weight column of the time input and `w1` the state columns."""
+    __slots__ = ("w1", "b1", "act", "wt")
 
-    def __init__(self, w1, b1, act=None):
-        self.w1, self.b1, self.act = w1, b1, act
+    def __init__(self, w1, b1, act=None, wt=None):
+        self.w1, self.b1, self.act, self.wt = w1, b1, act, wt
 
 
 class _Perceptron:
-    """``act(y @ W1^T + b1) @ W2^T + b2``: weights as the (out, in) tensors `nn.Linear` holds."""
-    __slots__ = ("w1", "b1", "act", "w2", "b2", "exact")
+    """``scale * final(act(x @ W1^T + b1) @ W2^T + b2)``: weights as the (out, in) tensors `nn.Linear` holds; `wt` as in
+    `_Hidden`; `final` None or "sigmoid" (``nn.Sigmoid()`` closing a diffusion net); `scale` a Python number; `shape` the
+    shape the user's code gave the result (``.view(B, d, m)``)."""
+    __slots__ = ("w1", "b1", "act", "w2", "b2", "exact", "wt", "final", "scale", "shape")
     phi = "perceptron"
 
-    def __init__(self, hidden, w2, b2):
-        self.w1, self.b1, self.act, self.w2, self.b2, self.exact = hidden.w1, hidden.b1, hidden.act, w2, b2, False
+    def __init__(self, hidden, w2, b2, shape):
+        self.w1, self.b1, self.act, self.wt = hidden.w1, hidden.b1, hidden.act, hidden.wt
+        self.w2, self.b2, self.exact, self.final, self.scale, self.shape = w2, b2, False, None, 1.0, tuple(shape)
+
+    @property
+    def out(self):
+        return self.w2.shape[0]
+
+    def but(self, **changes):
+        new = object.__new__(_Perceptron)
+        for slot in self.__slots__:
+            setattr(new, slot, changes.get(slot, getattr(self, slot)))
+        return new
+
+    def plain(self):
+        """The form the diagonal-noise perceptron kernels take: a network of the bare state, nothing after it."""
+        return self.wt is None and self.final is None and self.scale == 1.0
 
 
 def _mul(a, b):
@@ -170,6 +188,9 @@ class _Interpreter(TorchDispatchMode):
         #                                 their code computed from parameters with autograd watching -- not one folded here
         self.hidden = {}                # id -> _Hidden: (rows, hidden)-shaped values of a perceptron drift
         self.transposed = {}            # id of `W.t()` -> W (nn.Linear hands addmm the transposed view of its weight)
+        self.raw_time = {id(t)}         # t itself and value-preserving copies of it (`t.expand(B, 1)`, `.to(y.dtype)`)
+        self.time_state = set()         # ids of `cat([t.expand(rows, 1), y], 1)`: the input of the reference's Neural* nets
+        self.nets = {}                  # id -> _Perceptron for network outputs that are not state-shaped ((rows, d * m), ...)
         self.made = {id(y), id(t)}      # ids of tensors whose storage was allocated during the interpretation (kept alive):
         #                                 an in-place write to any OTHER tensor changes state that outlives the probe call
 
@@ -316,15 +337,89 @@ class _Interpreter(TorchDispatchMode):
 
     def first_layer(self, name, args, out):
         x, w, b = self.layer_operands(name, args)
-        form = self.form_of(x)
-        if form is None or form.constant() or form.phi != "identity" or any(
-                c is not None for c in (form.scale, form.rate, form.shift, form.offset)):
-            raise NotElementwise("a matrix product of something other than the state itself")
-        if tuple(w.shape)[1:] != (self.d,) or tuple(out.shape) != (self.rows, w.shape[0]):
-            raise NotElementwise("a matrix product that does not act on the state channels")
-        self.hidden[id(out)] = _Hidden(w, self.bias_of(b, w.shape[0]))
+        wt = None
+        if torch.is_tensor(x) and id(x) in self.time_state:
+            # the first layer of a net that is fed cat([t, y]): column 0 of its weight multiplies t
+            if tuple(w.shape)[1:] != (self.d + 1,) or tuple(out.shape) != (self.rows, w.shape[0]):
+                raise NotElementwise("a matrix product that does not act on [t, state channels]")
+            wt, w = w[:, 0], w[:, 1:]
+        else:
+            form = self.form_of(x)
+            if form is None or isinstance(form, _Perceptron) or form.constant() or form.phi != "identity" or any(
+                    c is not None for c in (form.scale, form.rate, form.shift, form.offset)):
+                raise NotElementwise("a matrix product of something other than the state itself")
+            if tuple(w.shape)[1:] != (self.d,) or tuple(out.shape) != (self.rows, w.shape[0]):
+                raise NotElementwise("a matrix product that does not act on the state channels")
+        self.hidden[id(out)] = _Hidden(w, self.bias_of(b, w.shape[0]), wt=wt)
         self.keep.append(out)
         return out
+
+    def time_state_cat(self, func, args, kwargs):
+        """``torch.cat([t.expand(rows, 1), y], dim=1)`` -- how every Neural* problem of the reference feeds t to its nets
+        (tests/problems.py:153-159, 183-189, 215-217, 246-252)."""
+        tensors = args[0] if args else ()
+        dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
+        if not isinstance(tensors, (list, tuple)) or len(tensors) != 2 or dim not in (1, -1):
+            raise NotElementwise("cat of t with the state other than [t, y] along the channels")
+        tc, yv = tensors
+        form = self.form_of(yv)
+        if (id(tc) not in self.raw_time or tuple(tc.shape) != (self.rows, 1) or form is None or isinstance(form, _Perceptron)
+                or form.constant() or form.phi != "identity"
+                or any(c is not None for c in (form.scale, form.rate, form.shift, form.offset))):
+            raise NotElementwise("cat of t with the state other than [t.expand(rows, 1), y]")
+        out = func(*args, **kwargs)
+        self.time_state.add(id(out))
+        self.keep.append(out)
+        return out
+
+    def register_net(self, out, net):
+        """Remember `out` as the value of perceptron `net`: among the tracked state-shaped values, or (other shapes) the nets."""
+        if not torch.is_tensor(out) or out.dim() < 2 or out.shape[0] != self.rows or out.numel() != self.rows * net.out:
+            raise NotElementwise(f"the output of a network was given shape {tuple(getattr(out, 'shape', ()))}")
+        net = net.but(shape=tuple(out.shape))
+        self.keep.append(out)
+        if self.state_shaped(out):
+            self.forms[id(out)] = net
+        else:
+            self.nets[id(out)] = net
+        return out
+
+    def net_of(self, x):
+        if not torch.is_tensor(x):
+            return None
+        form = self.forms.get(id(x))
+        return form if isinstance(form, _Perceptron) else self.nets.get(id(x))
+
+    _RESHAPES = ("view", "reshape", "_unsafe_view", "_reshape_alias", "unsqueeze", "squeeze")
+
+    def output_step(self, func, args, kwargs):
+        """An operator applied to the output of a network: the closing sigmoid, a numeric factor, the reshape to
+        (rows, d, m). Anything else ends the interpretation."""
+        schema = func._schema
+        name = schema.name.split("::")[1]
+        if schema.is_mutable:
+            raise NotElementwise(f"in-place {name} on the output of a network")
+        self.check_kwargs(name, schema, kwargs)
+        net = self.net_of(args[0]) if args else None
+        if name == "mul" and len(args) == 2:
+            other = args[1] if net is not None else args[0]
+            net = net if net is not None else self.net_of(args[1])
+            if self.net_of(other) is not None or self.form_of(other) is not None:
+                raise NotElementwise("a product of the output of a network with a function of the state")
+            if torch.is_tensor(other) and (other.dim() != 0 or other.device.type != "cpu"):
+                raise NotElementwise("the output of a network times something that is not a plain number")
+            out = func(*args, **kwargs)
+            return self.register_net(out, net.but(scale=net.scale * float(other)))
+        if net is None:
+            raise NotElementwise(f"{name} applied to the output of the drift network")
+        out = func(*args, **kwargs)
+        if name == "sigmoid" and len(args) == 1 and net.final is None and net.scale == 1.0:
+            return self.register_net(out, net.but(final="sigmoid"))
+        if name in self._SAME or name in self._RESHAPES:
+            if not torch.is_tensor(out) or out.dtype != args[0].dtype or out.device != args[0].device:
+                raise NotElementwise(f"{name} changes the dtype or device of the output of a network")
+            return self.register_net(out, net)
+        raise NotElementwise(f"{name} applied to the output of the drift network")
 
     def perceptron_step(self, func, args, kwargs):
         schema = func._schema
@@ -339,7 +434,7 @@ class _Interpreter(TorchDispatchMode):
                 threshold = args[2] if len(args) > 2 else kwargs.get("threshold", 20)
                 if beta != 1 or threshold != 20:
                     raise NotElementwise("softplus with a non-default beta or threshold")
-            self.hidden[id(out)] = _Hidden(h.w1, h.b1, name)
+            self.hidden[id(out)] = _Hidden(h.w1, h.b1, name, wt=h.wt)
             self.keep.append(out)
             return out
         if name in ("addmm", "mm", "linear"):
@@ -347,9 +442,9 @@ class _Interpreter(TorchDispatchMode):
             h = self.hidden.get(id(x))
             if h is None or h.act is None:
                 raise NotElementwise("a second layer without an activation before it")
-            if tuple(w.shape) != (self.d, h.w1.shape[0]) or tuple(out.shape) != (self.rows, self.d):
-                raise NotElementwise("the drift network does not map back to the state channels")
-            return self.track(out, _Perceptron(h, w, self.bias_of(b, self.d)))
+            if tuple(w.shape)[1:] != (h.w1.shape[0],) or tuple(out.shape) != (self.rows, w.shape[0]):
+                raise NotElementwise("a second layer that does not act on the hidden units")
+            return self.register_net(out, _Perceptron(h, w, self.bias_of(b, w.shape[0]), out.shape))
         if name in self._SAME and h is not None and torch.is_tensor(out) and out.shape == args[0].shape \
                 and out.dtype == args[0].dtype:
             self.hidden[id(out)] = h
@@ -362,6 +457,8 @@ class _Interpreter(TorchDispatchMode):
     _SAME = {"alias", "detach", "clone", "lift_fresh", "positive", "contiguous", "_to_copy", "view", "reshape",
              "_unsafe_view", "expand", "_reshape_alias"}
     _LIKE = {"zeros_like": 0.0, "ones_like": 1.0}
+    _TIME_COPIES = ("expand", "view", "reshape", "_unsafe_view", "_reshape_alias", "unsqueeze", "squeeze", "alias", "detach",
+                    "clone", "contiguous", "_to_copy", "lift_fresh")
 
     # kwargs whose effect the handlers model; every other non-default kwarg of an operator on a tracked value ends the
     # interpretation (`torch.div(y, 2, rounding_mode="floor")` is not `0.5 * y`)
@@ -426,7 +523,8 @@ class _Interpreter(TorchDispatchMode):
                 self.seen.add(id(a))
                 self.keep.append(a)
         timed = any(id(a) in self.time for a in involved)
-        if timed and not any(id(a) in self.forms or id(a) in self.hidden for a in involved):
+        if timed and not any(id(a) in self.forms or id(a) in self.hidden or id(a) in self.nets or id(a) in self.time_state
+                             for a in involved):
             # arithmetic among t and constants: executes; its results are functions of t
             name = func._schema.name
             if name in ("aten::_local_scalar_dense", "aten::item"):
@@ -439,14 +537,28 @@ class _Interpreter(TorchDispatchMode):
                                              "step and channel")
                     self.time.add(id(o))
                     self.keep.append(o)
+            # t itself, copied without arithmetic (`t.expand(B, 1)`, `.to(y.dtype)`): still "the time"
+            if (name.split("::")[1] in self._TIME_COPIES and torch.is_tensor(out) and args and torch.is_tensor(args[0])
+                    and id(args[0]) in self.raw_time and out.is_floating_point() and len(involved) == 1):
+                self.raw_time.add(id(out))
             return out
+        if timed and self.steps is None and func._schema.name == "aten::cat":
+            return self.time_state_cat(func, args, kwargs)
         if timed and self.steps is None:
             raise DependsOnTime("drift or diffusion depends on t")
-        if timed and any(id(a) in self.hidden for a in involved):
+        if timed and any(id(a) in self.hidden or id(a) in self.nets or id(a) in self.time_state for a in involved):
             raise NotElementwise("the drift network depends on t")
         if any(id(a) in self.hidden for a in involved):
             self.check_kwargs(func._schema.name.split("::")[1], func._schema, kwargs)
             return self.perceptron_step(func, args, kwargs)
+        if any(id(a) in self.time_state for a in involved):
+            name = func._schema.name.split("::")[1]
+            if name not in ("addmm", "mm", "linear") or func._schema.is_mutable:
+                raise NotElementwise(f"{name} applied to cat([t, y]): only a first layer may take it")
+            self.check_kwargs(name, func._schema, kwargs)
+            return self.first_layer(name, args, func(*args, **kwargs))
+        if any(self.net_of(a) is not None for a in involved):
+            return self.output_step(func, args, kwargs)
         tracked = [a for a in involved if id(a) in self.forms]
         if not tracked:
             out = func(*args, **kwargs)
@@ -470,11 +582,6 @@ class _Interpreter(TorchDispatchMode):
         if name in ("addmm", "mm", "linear"):
             return self.first_layer(name, args, out)
         x = self.form_of(args[0]) if args else None
-        if any(isinstance(self.form_of(v), _Perceptron) for v in args[:2]):
-            if name in self._SAME and isinstance(x, _Perceptron) and tuple(out.shape) == (self.rows, self.d) \
-                    and out.dtype == args[0].dtype:
-                return self.track(out, x)
-            raise NotElementwise(f"{name} applied to the output of the drift network")
         if name in self._LIKE or name in ("full_like", "empty_like", "new_zeros", "new_ones", "new_full", "new_empty"):
             if name in self._LIKE and self.state_shaped(out) and out.dtype == args[0].dtype:
                 return self.track(out, _Form(rate=ZERO, shift=self._LIKE[name] or None))
@@ -549,18 +656,25 @@ class Recognised:
     def __init__(self, f, g, d, dtype, device):
         self.f, self.g, self.d, self.dtype, self.device = f, g, d, dtype, device
         self.exact = f.exact and g.exact
-        if isinstance(g, _Perceptron):
-            raise NotElementwise("a perceptron diffusion")
+        if isinstance(g, _Perceptron) and not isinstance(f, _Perceptron):
+            raise NotElementwise("a network diffusion beside a drift that is not a network")
 
     @property
     def perceptron(self):
-        return isinstance(self.f, _Perceptron)
+        """Perceptron drift with an elementwise diagonal diffusion: `tsde_trajectory_mlp_diag` and its adjoint."""
+        return isinstance(self.f, _Perceptron) and not isinstance(self.g, _Perceptron)
+
+    @property
+    def neural(self):
+        """Drift AND diffusion are perceptrons (of y, or of [t, y]): `tsde_trajectory_mlp_general`."""
+        return isinstance(self.f, _Perceptron) and isinstance(self.g, _Perceptron)
 
     def structure(self):
         """The part of the result that does not change when parameter VALUES change: key of the trust verdict."""
         def shape(form):
             if isinstance(form, _Perceptron):
-                return ("perceptron", form.act, tuple(form.w1.shape), form.b1 is None, form.b2 is None)
+                return ("perceptron", form.act, tuple(form.w1.shape), form.b1 is None, form.b2 is None, form.out,
+                        form.wt is not None, form.final, form.scale, form.shape[1:])
             return (form.phi, form.constant()) + tuple(
                 None if c is None else "number" if isinstance(c, (int, float))
                 else "table" if torch.is_tensor(c) and c.dim() == 3 else "tensor"
@@ -591,6 +705,8 @@ class Recognised:
 
     @property
     def timed(self):
+        if self.neural:
+            return False
         forms = [self.g] if self.perceptron else [self.f, self.g]
         return any(torch.is_tensor(c) and c.dim() == 3 for v in forms for c in (v.scale, v.rate, v.shift, v.offset))
 
@@ -626,6 +742,8 @@ class Recognised:
         f = self.f
         hidden = f.w1.shape[0]
         tensors = [t for t in (f.w1, f.b1, f.w2, f.b2) if t is not None]
+        if not f.plain() or f.out != self.d:
+            return False            # (a net that takes t, or is followed by a factor: not what these kernels evaluate)
         return (self.dtype == torch.float32 and all(t.dtype == torch.float32 and t.device == self.device for t in tensors)
                 and self.d % 4 == 0 and self.d <= 128 and hidden <= (256 if self.d <= 64 else 128))
 
@@ -633,6 +751,10 @@ class Recognised:
         """("mlp_diagonal", W1 (d, hidden) input-major, b1, W2 (hidden, d), b2, rate (d,), shift (d,), activation code,
         (diffusion kind, amplitude)): what `kernels.trajectory_mlp_diag` takes (closed_form.py)."""
         f = self.f
+        if not f.plain() or f.out != self.d:
+            raise NotElementwise("a drift network that takes t (or is followed by a factor) beside an elementwise diffusion: "
+                                 "the perceptron-drift kernels have no time input, the neural-SDE kernel wants a diffusion "
+                                 "network")
         if not self.perceptron_supported():
             raise NotElementwise("a perceptron drift outside the kernels' shapes")
         kind, amplitude, rate, shift = self.perceptron_diffusion()
@@ -641,6 +763,54 @@ class Recognised:
         b2 = f.b2.detach().contiguous() if f.b2 is not None else _constant_vector(0.0, self.d, self.dtype, self.device)
         return ("mlp_diagonal", f.w1.detach().t().contiguous(), b1, f.w2.detach().t().contiguous(), b2,
                 self._vector(rate, 1.0), self._vector(shift, 0.0), self._ACTIVATIONS[f.act], (kind, amplitude))
+
+    _NOISE_CODES = {"diagonal": _native.NOISE_DIAGONAL, "scalar": _native.NOISE_SCALAR, "general": _native.NOISE_GENERAL}
+
+    def neural_spec(self, noise_type):
+        """("neural", drift NeuralNet, diffusion NeuralNet, noise code, m): what `kernels.trajectory_mlp_general` takes, for
+        a module whose drift and diffusion are both perceptrons (the reference's Neural* problems, tests/problems.py:135-252).
+        The diffusion's output must have the shape the noise type prescribes (sdeint.py:179-197): (rows, d) diagonal,
+        (rows, d, 1) scalar, (rows, d, m) general."""
+        from . import kernels as K
+        f, g, d = self.f, self.g, self.d
+        if self.dtype != torch.float32:
+            raise NotElementwise("the neural-SDE kernel is float32")
+        if f.out != d or f.final is not None or f.shape[1:] != (d,):
+            raise NotElementwise("a drift network that does not map to the state channels")
+        if noise_type == "diagonal":
+            want, m = (d,), d
+        elif noise_type == "scalar":
+            want, m = (d, 1), 1
+        elif noise_type == "general":
+            if len(g.shape) != 3 or g.shape[1] != d:
+                raise NotElementwise(f"a general-noise diffusion of shape {g.shape}")
+            want, m = (d, g.shape[2]), g.shape[2]
+        else:
+            raise NotElementwise(f"{noise_type} noise")
+        if g.shape[1:] != want or g.out != (d if noise_type != "general" else d * m):
+            raise NotElementwise(f"a diffusion network of shape {g.shape} for {noise_type} noise")
+        nets = []
+        for net in (f, g):
+            tensors = [t for t in (net.w1, net.b1, net.w2, net.b2, net.wt) if t is not None]
+            if any(t.dtype != torch.float32 or t.device != self.device for t in tensors):
+                raise NotElementwise("network weights of another dtype or device than the state")
+            hidden = net.w1.shape[0]
+            scale = float(net.scale)
+            w2, b2 = net.w2.detach().t(), (net.b2.detach() if net.b2 is not None else
+                                           _constant_vector(0.0, net.out, self.dtype, self.device))
+            fold = net.final is None and scale != 1.0          # a plain factor after a linear layer: into that layer
+            if fold:
+                w2, b2, scale = w2 * scale, b2 * scale, 1.0
+            b1 = net.b1.detach() if net.b1 is not None else _constant_vector(0.0, hidden, self.dtype, self.device)
+            nets.append(K.NeuralNet(net.w1.detach().t(), None if net.wt is None else net.wt.detach(), b1, w2, b2,
+                                    self._ACTIVATIONS[net.act],
+                                    _native.FINAL_SIGMOID if net.final == "sigmoid" else _native.FINAL_NONE, scale))
+        noise = self._NOISE_CODES[noise_type]
+        need = K.mlp_general_lds(d, m, nets[0].hidden, nets[1].hidden, nets[1].out, noise)
+        if d % 4 != 0 or need <= 0 or need > 160 * 1024:
+            raise NotElementwise(f"networks outside the neural-SDE kernel's shapes (d = {d}, m = {m}, hidden "
+                                 f"{nets[0].hidden} / {nets[1].hidden}: {need} bytes of LDS)")
+        return ("neural", nets[0], nets[1], noise, m)
 
     def perceptron_parameters(self):
         """(lin1.weight, lin1.bias, lin2.weight, lin2.bias, rate, shift) as the tensors the user's module holds -- what
@@ -687,8 +857,8 @@ class Recognised:
         are plain `rate * y + shift`, else the expression kernel; perceptron drift: `perceptron_spec`."""
         if self.perceptron:
             return self.perceptron_spec()
-        if isinstance(self.g, _Perceptron):
-            raise NotElementwise("a perceptron diffusion")
+        if self.neural:
+            raise NotElementwise("drift and diffusion networks: `neural_spec(noise_type)`")
         f4, g4 = self._four(self.f), self._four(self.g)
         plain = all(v.phi == "identity" and v.scale is None and v.offset is None for v in (self.f, self.g))
         if plain:
@@ -736,6 +906,8 @@ def recognise(sde, t, y0, differentiable=False, times=None, rows=None):
     forms = []
     for name, value in (("drift", f), ("diffusion", g)):
         form = interp.form_of(value)
+        if form is None:
+            form = interp.net_of(value)
         if form is None:
             raise NotElementwise(f"the {name} is not a tracked function of the state")
         forms.append(form)

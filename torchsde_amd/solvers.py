@@ -315,6 +315,11 @@ class BaseSDESolver:
         """TSDE_TRAJ_* code of this scheme's in-register form, or None if it has none."""
         return None
 
+    def _neural_code(self):
+        """TSDE_TRAJ_* code of this scheme in the neural-SDE kernel (`tsde_trajectory_mlp_general`: any noise type but
+        additive), or None."""
+        return None
+
     def _closed_form_coefficients(self, y0):
         """What `_integrate_trajectory` needs if the whole solve can run as ONE launch of a trajectory kernel, else
         None: a closed-form SDE handed to `sdeint` as is (closed_form.py) and this package's BrownianInterval
@@ -392,17 +397,24 @@ class BaseSDESolver:
         from . import graph, recognise
         from .sde import ForwardSDE
         sde = self.sde
+        # diagonal noise: every scheme with an in-register form; drift AND diffusion networks (recognise.Recognised.neural:
+        # the reference's Neural* problems, any of diagonal / scalar / general noise): Euler and midpoint
+        elementwise = sde.noise_type == NOISE_TYPES.diagonal and self._trajectory_code() is not None
+        networks = (sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar, NOISE_TYPES.general)
+                    and self._neural_code() is not None)
         if (not recognise.ENABLED or not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful
-                or type(sde) is not ForwardSDE or sde.user_product or sde.noise_type != NOISE_TYPES.diagonal
-                or self._trajectory_code() is None):
+                or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks)):
             return None
         if self._tracks_grad(y0):
-            return self._integrate_recognised_with_grad(y0, ts)
+            return self._integrate_recognised_with_grad(y0, ts) if elementwise else None
         bm = self._native_bm()
-        if (bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or not y0.is_cuda or y0.shape[0] < 8
+        if (bm is None or y0.dim() != 2 or len(bm.shape) != 2 or bm.shape[0] != y0.shape[0] or not y0.is_cuda
+                or y0.shape[0] < 8
                 or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
                 or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
-                or (self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
+                or (elementwise and self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
+            return None
+        if sde.noise_type == NOISE_TYPES.diagonal and tuple(bm.shape) != tuple(y0.shape):
             return None
         chain, base = graph._wrapper_chain(sde)
         if not self._may_be_interpreted(base):
@@ -443,7 +455,16 @@ class BaseSDESolver:
                 except recognise.NotElementwise as e:
                     raise recognise.NotElementwise("drift or diffusion depends on t, and not only through arithmetic that "
                                                    f"broadcasts ({e})") from None
-            spec = found.spec()
+            if found.neural:
+                if not networks or times is not None:
+                    raise recognise.NotElementwise("drift and diffusion networks, but no neural-SDE kernel for this scheme")
+                spec = found.neural_spec(sde.noise_type)
+                if tuple(bm.shape) != (y0.shape[0], spec[4]) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
+                    return None
+            elif not elementwise:
+                raise recognise.NotElementwise(f"{sde.noise_type} noise whose drift and diffusion are not both networks")
+            else:
+                spec = found.spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if spec[0] == "mlp_diagonal":
@@ -466,7 +487,8 @@ class BaseSDESolver:
         before = graph.python_state(base)
         rng_before = self._rng_states(y0.device)
         try:
-            again = recognise.recognise(sde, ts[0], y0, times=times, rows=5).spec()
+            again = recognise.recognise(sde, ts[0], y0, times=times, rows=5)
+            again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if before is None or graph.python_state(base) != before:
@@ -485,7 +507,7 @@ class BaseSDESolver:
         self._extra = ()
         stepwise = self._run(self._plan(y0, ts), y0)
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
-        if spec[0] == "mlp_diagonal":       # the matrix cores sum the layers' products in another order than the library
+        if spec[0] in ("mlp_diagonal", "neural"):      # the matrix cores sum the layers' products in another order than the library
             rtol, atol = 1e-3, 1e-4
         both_nan = fast.isnan() & stepwise.isnan()
         close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
@@ -677,6 +699,7 @@ class BaseSDESolver:
             rows[:, 4] = np.sqrt(h)
             rows[:, 5] = np.sqrt(h / 12.0)
             rows[:, 6] = h
+            rows[:, 7] = grid.t[:-1]         # t_k, the time a step starts at (read by tsde_trajectory_mlp_general only)
             out_step = [kc for (_, kc, _, _) in grid.outputs]
             out_w = [(w0, w1) for (_, _, w0, w1) in grid.outputs]
             grid._step_rows = (h.copy(), rows, out_step, out_w)
@@ -689,6 +712,13 @@ class BaseSDESolver:
             return K.trajectory_mlp_diag_differentiable(y0, coefficients[3:], coefficients[1], coefficients[2],
                                                         self._trajectory_code(), schedule_all, out_step, bm)
         schedule = K.TrajectorySchedule.cached(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        if coefficients[0] == "neural":
+            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            K.trajectory_mlp_general(ys[1:], y0c, coefficients[1], coefficients[2], coefficients[3], coefficients[4],
+                                     self._neural_code(), schedule, bm)
+            return ys
         if coefficients[0] == "mlp_diagonal":
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
@@ -829,6 +859,9 @@ class Euler(BaseSDESolver):
     def _trajectory_code(self):
         return _native.TRAJ_EULER if self._diag() else None
 
+    def _neural_code(self):
+        return _native.TRAJ_EULER
+
     def _advance(self, y0, st, out):
         return self._drift_diffusion_update(st.times[0], y0, st.dt, 1.0, st.noise, out)
 
@@ -847,6 +880,9 @@ class Midpoint(BaseSDESolver):
 
     def _trajectory_code(self):
         return _native.TRAJ_MIDPOINT if self._diag() else None
+
+    def _neural_code(self):
+        return _native.TRAJ_MIDPOINT
 
     def _advance(self, y0, st, out):
         dt, half_dt = st.dt, st.half_dt

@@ -81,6 +81,22 @@ WORKLOADS = {
         problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=1, kernel_match=["general_rows_kernel<float"],
         kernel="tsde_step_general<float> (general_rows_kernel)"),
+    # BASELINE configs[2] as a drop-in user gets it: the untouched NeuralGeneral-style module (f_net, g_net of cat([t, y]),
+    # g reshaped to (B, d, m); tests/problems.py:226-252 at hidden 64) through sdeint with no options. recognise.py follows
+    # both nets and the whole solve is ONE launch of tsde_trajectory_mlp_general: four layers and the contraction with the
+    # increments on the f32 matrix cores, weights in LDS. MFMA-bound: 2 * (d*h + h*d + d*h + h*d*m) flop per trajectory-step.
+    "c3_euler_general_default_route_b16384_d32_m16": dict(
+        problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, recognised=True, stepwise="c3_euler_general_b16384_d32_m16",
+        mfma_flops_per_traj_step=2 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
+        kernel="tsde_trajectory_mlp_general<32, 64, general m = 16, euler> (neural_trajectory_kernel, v_mfma_f32_16x16x4_f32; "
+               "user module recognised)"),
+    # ... and the Stratonovich default for general noise, midpoint (sdeint.py:155): two evaluations of both nets per step
+    "c3_midpoint_general_default_route_b16384_d32_m16": dict(
+        problem="general_big_strat", method="midpoint", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, recognised=True,
+        mfma_flops_per_traj_step=4 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
+        kernel="tsde_trajectory_mlp_general<32, 64, general m = 16, midpoint> (user module recognised)"),
     # The batch-broadcast diffusion of north_star's "MFMA ... for the dense g.dW batched matmul": additive noise returned
     # as sigma.expand(B, d, m) at the configs[2] shape and at a larger one. One launch of the matrix-core kernel per
     # step: reads y0, f, writes y1 (12*d bytes per trajectory-step), increments generated in registers, S in LDS.
@@ -213,6 +229,8 @@ def make_problem(name, d, m, dev):
     from . import problems
     if name == "general_big":      # NeuralGeneral-style: hidden 64
         return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
+    if name == "general_big_strat":
+        return problems.MLPGeneral(d, m, "stratonovich", hidden=64).to(dev)
     if name == "latent_diag":      # latent-SDE-style diagonal SDE
         return problems.LatentDiag(d).to(dev)
     if name == "double_well":

@@ -144,6 +144,37 @@ class MLPGeneral(nn.Module):
         return -y
 
 
+class MLPNetDiag(nn.Module):
+    """Diagonal noise with drift AND diffusion nets of (t, y), the shape of the reference's NeuralDiagonal
+    (tests/problems.py:135-162): g = 0.1 * sigmoid-closed net. (Such a g mixes channels, so it is "diagonal" only in
+    the sense of the contract -- (B, d) times dW (B, d) -- exactly like the reference's problem.)"""
+    noise_type = "diagonal"
+
+    def __init__(self, d, sde_type="ito", seed=5, hidden=8, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.sde_type = sde_type
+        self.f_net = _mlp(gen, (d + 1, hidden, d), dtype)
+        self.g_net = _mlp(gen, (d + 1, hidden, d), dtype, final=nn.Sigmoid())
+
+    def _ty(self, t, y):
+        return torch.cat([t.expand(y.size(0), 1).to(y.dtype), y], dim=1)
+
+    def f(self, t, y):
+        return self.f_net(self._ty(t, y))
+
+    def g(self, t, y):
+        return 0.1 * self.g_net(self._ty(t, y))
+
+
+class MLPNetScalar(MLPNetDiag):
+    """... and the reference's NeuralScalar (tests/problems.py:165-192): one Brownian channel, g of shape (B, d, 1)."""
+    noise_type = "scalar"
+
+    def g(self, t, y):
+        return 0.1 * self.g_net(self._ty(t, y)).unsqueeze(-1)
+
+
 class MLPDiag(nn.Module):
     """Diagonal noise with an elementwise diffusion g_i(y_i) (a valid diagonal SDE for Milstein/adjoint)."""
     noise_type = "diagonal"
@@ -244,6 +275,26 @@ class DoubleWell(nn.Module):
         return self.sigma * (1.0 + 0.5 * y * y)
 
 
+class Logistic(nn.Module):
+    """dy = r y (1 - y / K) dt + sigma y dW per channel: a drift that is a PRODUCT of two affine functions of the state
+    (stochastic logistic growth); Ito or Stratonovich."""
+    noise_type = "diagonal"
+
+    def __init__(self, d, sde_type="ito", seed=6):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.sde_type = sde_type
+        self.r = nn.Parameter((0.5 + _sigmoid_randn(gen, d)).to(torch.float32))
+        self.K = nn.Parameter((1.0 + _sigmoid_randn(gen, d)).to(torch.float32))
+        self.sigma = nn.Parameter((0.4 * _sigmoid_randn(gen, d)).to(torch.float32))
+
+    def f(self, t, y):
+        return self.r * y * (1.0 - y / self.K)
+
+    def g(self, t, y):
+        return self.sigma * y
+
+
 class ReadmeSDE(nn.Module):
     """The README quick example: general Ito noise, linear drift, linear diffusion reshaped to (B, d, m)."""
     noise_type = "general"
@@ -291,6 +342,10 @@ def make(name, dtype=torch.float32, **kw):
         "general_ito": lambda: MLPGeneral(kw.get("d", 4), kw.get("m", 4), "ito", dtype=dtype),
         "general_strat": lambda: MLPGeneral(kw.get("d", 4), kw.get("m", 4), "stratonovich", dtype=dtype),
         "general_odd_ito": lambda: MLPGeneral(kw.get("d", 3), kw.get("m", 5), "ito", dtype=dtype),
+        "netdiag_ito": lambda: MLPNetDiag(kw.get("d", 4), "ito", hidden=kw.get("hidden", 8), dtype=dtype),
+        "netdiag_strat": lambda: MLPNetDiag(kw.get("d", 4), "stratonovich", hidden=kw.get("hidden", 8), dtype=dtype),
+        "netscalar_ito": lambda: MLPNetScalar(kw.get("d", 4), "ito", hidden=kw.get("hidden", 8), dtype=dtype),
+        "netscalar_strat": lambda: MLPNetScalar(kw.get("d", 4), "stratonovich", hidden=kw.get("hidden", 8), dtype=dtype),
         "mlpdiag_ito": lambda: MLPDiag(kw.get("d", 4), "ito", dtype=dtype),
         "mlpdiag_strat": lambda: MLPDiag(kw.get("d", 4), "stratonovich", dtype=dtype),
         "readme": lambda: ReadmeSDE(dtype=dtype),
