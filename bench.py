@@ -77,6 +77,8 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_euler_scheduled_b65536_d64_s1000", "c2_euler_scheduled_default_route_b65536_d64_s1000",
         "c2_srk_scheduled_default_route_b65536_d64_s1000",
         "c2_euler_doublewell_b65536_d64_s1000", "c2_euler_doublewell_default_route_b65536_d64_s1000",
+        "c2_srk_exscalar_b65536_d64_s1000", "c2_srk_exscalar_default_route_b65536_d64_s1000",
+        "c2_euler_exscalar_default_route_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
         "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500",
         "c5_adjoint_latent_default_route_b32768_d128_s500", "c5_adjoint_latent_defaults_default_route_b32768_d128_s500")

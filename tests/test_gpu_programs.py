@@ -1,0 +1,161 @@
+"""Elementwise user code that no single-function form holds -- several functions of the state summed or multiplied, powers,
+quotients, and SCALAR noise -- on `tsde_trajectory_prog_diag` (``-m gpu``): drift and diffusion travel as small postfix programs
+(recognise.RecognisedProgram) and the whole solve is one launch, for every scheme with an in-register form.
+
+Pinned against the ORACLE's restatement of the reference's loops on the same Brownian path (the reference's own ExScalar,
+tests/problems.py:75-103) and against this package's stepwise route."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from tests import helpers
+from workloads import problems
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, D, STEPS, DT = 256, 8, 32, 2.0 ** -7
+
+
+def _solve(sde, entropy, method, levy="none", stepwise=False, dtype=torch.float32, rows=B, d=D, m=None, row_offset=0):
+    import torchsde_amd
+    m = (1 if sde.noise_type == "scalar" else d) if m is None else m
+    y0 = torch.full((rows, d), 0.3, device=DEV, dtype=dtype)
+    ts = torch.tensor([0.0, 11.5 * DT, STEPS * DT], device=DEV, dtype=dtype)
+    bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(rows, m), device=DEV, dtype=dtype, entropy=entropy, dt=DT,
+                                       levy_area_approximation=levy, row_offset=row_offset)
+    options = {"hip_graph": False}
+    if stepwise:
+        options["trajectory_kernel"] = False
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=DT, options=options)
+
+
+def _book(sde):
+    from torchsde_amd import solvers
+    return getattr(sde, solvers.BaseSDESolver._RECOGNISED_ATTR, {"trusted": {}, "refused": {}})
+
+
+def _launches(fn):
+    from torchsde_amd import kernels as K
+    K.prof_begin(8, 64)
+    out = fn()
+    torch.cuda.synchronize()
+    return out, K.prof_end()[1]
+
+
+SCHEMES = [("euler", "ito", "none"), ("milstein", "ito", "none"), ("srk", "ito", "space-time"),
+           ("midpoint", "stratonovich", "none"), ("milstein", "stratonovich", "none")]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
+def test_the_references_scalar_noise_problem_is_one_launch(method, sde_type, levy, dtype):
+    """ExScalar verbatim (workloads.problems.ScalarTrig: f = -p^2 sin(y) cos(y)^3 -- zeros for Stratonovich --, g = p cos(y)^2 of
+    shape (B, d, 1), one Brownian channel per row)."""
+    sde = problems.ScalarTrig(D, sde_type, dtype=dtype).to(DEV)
+    first = _solve(sde, 1, method, levy, dtype=dtype)
+    assert torch.equal(first, _solve(sde, 1, method, levy, stepwise=True, dtype=dtype))
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    tol = dict(rtol=2e-5, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-11, atol=1e-12)
+    for entropy in (2, 3):
+        fast, launches = _launches(lambda: _solve(sde, entropy, method, levy, dtype=dtype))
+        assert launches == 1
+        torch.testing.assert_close(fast, _solve(sde, entropy, method, levy, stepwise=True, dtype=dtype), **tol)
+        assert not torch.equal(fast[-1], fast[0])
+
+
+class _Mixed(nn.Module):
+    """Diagonal noise, drift and diffusion mixing several functions of the state."""
+    noise_type = "diagonal"
+
+    def __init__(self, sde_type, which):
+        super().__init__()
+        self.sde_type, self.which = sde_type, which
+        gen = torch.Generator().manual_seed(7)
+        self.mu = nn.Parameter(0.5 + torch.rand(D, generator=gen))
+        self.sigma = nn.Parameter(0.1 + 0.3 * torch.rand(D, generator=gen))
+
+    def f(self, t, y):
+        if self.which == "sum":
+            return torch.tanh(y) * self.mu - y
+        if self.which == "rational":
+            return -y / (1.0 + y ** 2) * self.mu
+        return y - y ** 4 * self.mu - F.softplus(y) * 0.1
+
+    def g(self, t, y):
+        if self.which == "sum":
+            return self.sigma * torch.sigmoid(y) + 0.05 * torch.cos(y)
+        if self.which == "rational":
+            return self.sigma / (2.0 + torch.cos(y))
+        return self.sigma * torch.sqrt(1.0 + y * y)
+
+
+@pytest.mark.parametrize("which", ["sum", "rational", "quartic"])
+@pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
+def test_mixed_elementwise_code_takes_the_program_kernel(which, method, sde_type, levy):
+    sde = _Mixed(sde_type, which).to(DEV)
+    _solve(sde, 1, method, levy)
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    assert [key[0][0][0] for key in _book(sde)["trusted"]] == ["program"]
+    fast, launches = _launches(lambda: _solve(sde, 2, method, levy))
+    assert launches == 1
+    torch.testing.assert_close(fast, _solve(sde, 2, method, levy, stepwise=True), rtol=2e-5, atol=2e-6)
+    # odd widths take the one-element-per-lane form; rows are global
+    odd = _Mixed(sde_type, which).to(DEV)
+    odd.mu, odd.sigma = nn.Parameter(odd.mu[:5].detach()), nn.Parameter(odd.sigma[:5].detach())
+    whole = [_solve(odd, 4, method, levy, rows=64, d=5) for _ in range(2)][1]
+    part = [_solve(odd, 4, method, levy, rows=40, d=5, row_offset=24) for _ in range(2)][1]
+    assert torch.equal(part, whole[:, 24:])
+    torch.testing.assert_close(whole, _solve(odd, 4, method, levy, rows=64, d=5, stepwise=True), rtol=2e-5, atol=2e-6)
+
+
+def test_live_parameters_and_refusals():
+    sde = _Mixed("ito", "sum").to(DEV)
+    _solve(sde, 1, "euler")
+    a = _solve(sde, 2, "euler")
+    with torch.no_grad():
+        sde.sigma.mul_(1.5)
+    b, launches = _launches(lambda: _solve(sde, 2, "euler"))
+    assert launches == 1 and not torch.equal(a, b)
+    torch.testing.assert_close(b, _solve(sde, 2, "euler", stepwise=True), rtol=2e-5, atol=2e-6)
+
+    class UsesTime(_Mixed):
+        def f(self, t, y):
+            return torch.tanh(y) * torch.cos(t) - y ** 3 * torch.sin(y)
+    timed = UsesTime("ito", "sum").to(DEV)
+    for entropy in (1, 2):
+        got, launches = _launches(lambda: _solve(timed, entropy, "euler"))
+        assert launches == 0
+    assert any("depends on t" in r for r in _book(timed)["refused"].values()), _book(timed)
+
+
+@pytest.mark.parametrize("method,levy", [("euler", "none"), ("milstein", "none"), ("srk", "space-time")])
+def test_scalar_noise_program_rows_vs_oracle(method, levy):
+    """16384 x 32, 500 steps of the reference's scalar-noise problem: sampled rows against the oracle's restatement of the
+    reference's loop (euler.py:29-37, milstein.py:52-74, srk.py:57-88 on g of shape (B, d, 1)) on the same Brownian path, with
+    the bound of tests/test_gpu_full_size_oracle.py."""
+    import torchsde_amd
+    from tests.test_gpu_full_size_oracle import _oracle_forward
+    Bf, d, n, dt = 16384, 32, 500, 2.0 ** -9
+    sde = problems.ScalarTrig(d, "ito").to(DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def bm(entropy):
+        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bf, 1), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt,
+                                             levy_area_approximation=levy)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            torchsde_amd.sdeint(sde, y0, ts, bm=bm(5), method=method, dt=dt)
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm(20240601), method=method, dt=dt))
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        rows = helpers.sampled_rows(Bf, 48, seed=8, seams=(2, 8, Bf - 2))
+        ref32, ref64 = _oracle_forward(sde, rows, d, 1, 20240601, n, dt, method, 0.1, levy=levy != "none")
+        helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1],
+                                                 f"scalar noise, {method}, program kernel")
+    finally:
+        torch.set_num_threads(before)

@@ -416,3 +416,86 @@ def test_networks_the_neural_kernel_does_not_take():
             return self.g_net(self._ty(t, y)) ** 2
     with pytest.raises(recognise.NotElementwise, match="output of the drift network"):
         recognise.recognise(ForwardSDE(Squared(8)), t, y)
+
+
+# ---- expression programs: any elementwise code --------------------------------------------------------------------------
+def _run_program(words, consts, y):
+    """The stack machine of csrc/trajectory.hip (ProgModel::run) in torch: what the kernel evaluates per element."""
+    stack = []
+    unary = {16: torch.neg, 17: torch.exp, 18: torch.log, 19: torch.sin, 20: torch.cos, 21: torch.tanh, 22: torch.sigmoid,
+             23: F.softplus, 24: torch.sqrt, 25: torch.abs, 26: torch.relu, 27: torch.reciprocal, 28: lambda v: v * v,
+             29: lambda v: (v * v) * v}
+    for w in words:
+        op, src, k = w & 0xFF, (w >> 8) & 0xFF, w >> 16
+        if op < 16:
+            if src == 0:
+                b, a = stack.pop(), stack.pop()
+            else:
+                b = consts[k].expand_as(y) if src == 1 else y
+                a = stack.pop() if op != 0 else None
+            if op == 0:
+                stack.append(b)
+            else:
+                stack.append({1: a + b, 2: a - b, 3: b - a, 4: a * b, 5: a / b, 6: b / a}[op])
+        elif op == 30:
+            stack.append(stack[-1])
+        else:
+            stack.append(unary[op](stack.pop()))
+        assert len(stack) <= 4
+    assert len(stack) == 1
+    return stack[0]
+
+
+PROGRAMS = {
+    # the reference's ExScalar verbatim (tests/problems.py:75-103)
+    "ex_scalar": ("scalar", lambda s, t, y: -s.mu ** 2. * torch.sin(y) * torch.cos(y) ** 3.,
+                  lambda s, t, y: (s.sigma * torch.cos(y) ** 2).unsqueeze(dim=-1)),
+    "two functions summed": ("diagonal", lambda s, t, y: torch.tanh(y) + y, lambda s, t, y: 0.3 * torch.sigmoid(y) + s.sigma),
+    "quartic well": ("diagonal", lambda s, t, y: y - y ** 4 * s.mu, lambda s, t, y: s.sigma * torch.sqrt(1.0 + y * y)),
+    "rational": ("diagonal", lambda s, t, y: -y / (1.0 + y ** 2), lambda s, t, y: s.sigma / (2.0 + torch.cos(y))),
+    "deep tree": ("diagonal", lambda s, t, y: (torch.sin(y) * s.mu + torch.cos(y)) * (torch.exp(-y * y) + s.b * y),
+                  lambda s, t, y: (y * s.sigma + 0.1) * (torch.tanh(y) - 2.0)),
+    "softplus and abs": ("diagonal", lambda s, t, y: F.softplus(y) - torch.abs(y) * s.mu, lambda s, t, y: torch.relu(y) + 0.2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PROGRAMS))
+def test_expression_programs_evaluate_to_the_users_code(name):
+    """Code the single-function forms refuse comes back as postfix programs over a four-deep stack; running them (and the
+    derivative program Milstein uses) reproduces f, g and dg/dy."""
+    noise, f, g = PROGRAMS[name]
+    sde = _M(f, g)
+    sde.noise_type = noise
+    y, t = 0.8 * torch.randn(16, D), torch.tensor(0.3)
+    with pytest.raises(recognise.NotElementwise):
+        recognise.recognise(ForwardSDE(sde), t, y).spec()
+    found = recognise.recognise_program(ForwardSDE(sde), t, y, noise)
+    kind, fw, gw, dgw, table, scalar = found.spec(milstein=name != "softplus and abs")
+    assert kind == "program_diagonal" and scalar == (noise == "scalar") and table.shape[1] == D
+    with torch.no_grad():
+        torch.testing.assert_close(_run_program(fw, table, y), sde.f(t, y), rtol=1e-5, atol=1e-6)
+        want_g = sde.g(t, y)
+        torch.testing.assert_close(_run_program(gw, table, y), want_g.reshape(16, D), rtol=1e-5, atol=1e-6)
+    if dgw:
+        yy = y.clone().requires_grad_(True)
+        dg, = torch.autograd.grad(sde.g(t, yy).sum(), yy)            # elementwise g: the gradient of the sum is g'
+        torch.testing.assert_close(_run_program(dgw, table, y), dg, rtol=1e-4, atol=1e-5)
+    again = recognise.recognise_program(ForwardSDE(sde), t, y, noise, rows=5)
+    assert again.structure() == found.structure()
+
+
+def test_programs_refuse_what_is_not_elementwise_arithmetic():
+    y, t = torch.randn(16, D), torch.tensor(0.3)
+    for f, reason in ((lambda s, t, y: y @ torch.eye(D), "aten::mm"), (lambda s, t, y: y * t, "depends on t"),
+                      (lambda s, t, y: y - y.mean(0), "aten::mean"), (lambda s, t, y: y ** 2.5, "power"),
+                      (lambda s, t, y: y + torch.randn(D), "random"), (lambda s, t, y: y * s.b.add_(1.0), "existed before")):
+        with pytest.raises(recognise.NotElementwise, match=reason):
+            recognise.recognise_program(ForwardSDE(_M(f, lambda s, t, y: y)), t, y, "diagonal")
+    # five values alive at once: beyond the four-deep stack
+    wide = lambda s, t, y: ((torch.sin(y) * torch.cos(y)) + (torch.exp(y) * torch.tanh(y))) * \
+        ((torch.sin(2 * y) * torch.cos(3 * y)) + (torch.exp(-y) * torch.tanh(2 * y)))          # noqa: E731
+    found = recognise.recognise_program(ForwardSDE(_M(wide, lambda s, t, y: y)), t, y, "diagonal")      # depth 4: fits
+    assert found.programs[0]
+    wider = lambda s, t, y: wide(s, t, y) * (wide(s, t, 2 * y) + wide(s, t, 3 * y) * wide(s, t, 4 * y))       # noqa: E731
+    with pytest.raises(recognise.NotElementwise, match="more than four"):
+        recognise.recognise_program(ForwardSDE(_M(wider, lambda s, t, y: y)), t, y, "diagonal")

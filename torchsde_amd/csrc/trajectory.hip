@@ -658,6 +658,246 @@ hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, i
   }
 }
 
+// ---- expression PROGRAMS ------------------------------------------------------------------------------------------------
+// Drift, diffusion (and the diffusion's derivative, for Milstein) as small postfix programs over a four-deep value stack:
+// whatever elementwise code a user's f and g consist of -- several functions of the state summed or multiplied
+// (`-p**2 * sin(y) * cos(y)**3`, tests/problems.py:84-86; `tanh(y) + y`; y**4) -- which the single-function forms above
+// cannot express. recognise.py builds the expression tree of the user's code while it runs on the probe, orders it so that
+// four stack slots suffice, and hands over: `code` (32-bit words: opcode | source << 8 | constant row << 16) and a table of
+// per-channel constants (n_const, d). One instruction = one torch operator of the user's code, evaluated in the same order
+// and (for + - * /) with the same rounding; functions as in `expr_phi`. The instruction stream is wave-uniform: decoding it
+// is scalar work, the vector unit sees one operation per instruction and element.
+//   source: 0 = the value below the top of the stack (binary operators pop it), 1 = constant row k of this channel, 2 = the state
+//   a binary operator computes  A op B  with A = top of stack, B = source  (R variants: B op A); source 0: A = the value
+//   below the top, B = the top (R variants swapped), and the result replaces both
+enum : uint32_t { kSrcStack = 0, kSrcConst = 1, kSrcState = 2 };
+enum : uint32_t {
+  kOpLoad = 0, kOpAdd, kOpSub, kOpRsub, kOpMul, kOpDiv, kOpRdiv,                       // take a source
+  kOpNeg = 16, kOpExp, kOpLog, kOpSin, kOpCos, kOpTanh, kOpSigmoid, kOpSoftplus, kOpSqrt, kOpAbs, kOpRelu, kOpRecip,
+  kOpSquare, kOpCube, kOpDup
+};
+
+template <typename T>
+struct ProgModel {
+  const uint32_t* code;            // f program, then g, then g' (wave-uniform)
+  int f_len, g_len, dg_len;
+  const T* consts;                 // (n_const, d)
+  int64_t d, col;                  // this element's channel
+
+  TSDE_D T run(const uint32_t* prog, int len, const T x) const {
+    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+    for (int pc = 0; pc < len; ++pc) {
+      const uint32_t ins = __builtin_amdgcn_readfirstlane(prog[pc]);
+      const uint32_t op = ins & 0xFFu, src = (ins >> 8) & 0xFFu, k = ins >> 16;
+      if (op < kOpNeg) {
+        T a = s0, b;
+        if (src == kSrcStack) {        // pop: the operands are the two top values
+          b = s0;
+          a = s1;
+          s1 = s2;
+          s2 = s3;
+        } else if (src == kSrcConst) {
+          b = consts[(int64_t)k * d + col];
+        } else {
+          b = x;
+        }
+        switch (op) {
+          case kOpLoad:                // push the source (never the stack)
+            s3 = s2;
+            s2 = s1;
+            s1 = s0;
+            s0 = b;
+            break;
+          case kOpAdd: s0 = a + b; break;
+          case kOpSub: s0 = a - b; break;
+          case kOpRsub: s0 = b - a; break;
+          case kOpMul: s0 = a * b; break;
+          case kOpDiv: s0 = a / b; break;
+          default: s0 = b / a; break;  // kOpRdiv
+        }
+      } else {
+        switch (op) {
+          case kOpNeg: s0 = -s0; break;
+          case kOpExp: s0 = exp(s0); break;
+          case kOpLog: s0 = log(s0); break;
+          case kOpSin: s0 = sin(s0); break;
+          case kOpCos: s0 = cos(s0); break;
+          case kOpTanh: s0 = tanh(s0); break;
+          case kOpSigmoid: s0 = (T)1 / ((T)1 + exp(-s0)); break;
+          case kOpSoftplus: s0 = s0 > (T)20 ? s0 : log1p(exp(s0)); break;
+          case kOpSqrt: s0 = sqrt(s0); break;
+          case kOpAbs: s0 = fabs(s0); break;
+          case kOpRelu: s0 = s0 > (T)0 ? s0 : (T)0; break;
+          case kOpRecip: s0 = (T)1 / s0; break;
+          case kOpSquare: s0 = s0 * s0; break;
+          case kOpCube: s0 = (s0 * s0) * s0; break;
+          default:                     // kOpDup
+            s3 = s2;
+            s2 = s1;
+            s1 = s0;
+            break;
+        }
+      }
+    }
+    return s0;
+  }
+  template <int SLOT>
+  TSDE_D T f(const T& x) const { return run(code, f_len, x); }
+  template <int SLOT>
+  TSDE_D T g(const T& x) const { return run(code + f_len, g_len, x); }
+  template <int SLOT>
+  TSDE_D T gdg(const T& x, const T& gv, T v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x); }
+};
+
+template <typename T>
+struct ProgArgs {
+  T* ys;
+  const T* y0;
+  const uint32_t* code;
+  const T* consts;
+  int32_t f_len, g_len, dg_len;
+  int32_t scalar_noise;     // 1: one Brownian channel per ROW (noise type "scalar"): element (row, c) meets increment `row`
+  const T* rows;
+  const uint32_t* cells;
+  const int32_t* out_step;
+  const T* out_w;
+  int64_t n, d;
+  int32_t n_steps, n_out;
+  NoiseKey key;
+  const uint64_t* key_dev;
+};
+
+// The expression kernels' loop with the program model. W = 4 needs d % 4 == 0 (a lane's elements share their row).
+template <typename T, int METHOD, int W>
+__global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<T> p) {
+  constexpr bool kNeedU = METHOD == kSrk;
+  const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = lane * W;
+  if (i >= p.n) return;
+  const int64_t col = i % p.d;
+  const Pack<T, W> y_init = load<T, W>(p.y0, i);
+  T y[W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) y[q] = y_init.v[q];
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+  const bool scalar_noise = p.scalar_noise != 0;
+  const uint64_t elem = key.elem0 + (uint64_t)(scalar_noise ? i / p.d : i);
+  int j = 0;
+  int next_out = next_output_step(p.out_step, 0, p.n_out);
+  for (int k = 0; k < p.n_steps; ++k) {
+    const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
+    const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
+    const uint32_t cell = p.cells[k];
+    Pack<T, W> w, u;
+    if (scalar_noise) {
+      const T w_row = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
+      T u_row = (T)0;
+      if constexpr (kNeedU) u_row = th * ((T)0.5 * w_row + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        w.v[q] = w_row;
+        u.v[q] = u_row;
+      }
+    } else if constexpr (W == 4) {
+      T z[4];
+      normal4<T>(key, elem >> 2, cell, 0, kStreamW, z);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w.v[q] = z[q] * sw;
+      if constexpr (kNeedU) {
+        normal4<T>(key, elem >> 2, cell, 0, kStreamH, z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u.v[q] = th * ((T)0.5 * w.v[q] + z[q] * sh);
+      }
+    } else {
+      w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
+      if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+    }
+    T y1[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const ProgModel<T> m{p.code, p.f_len, p.g_len, p.dg_len, p.consts, p.d, col + q};
+      y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
+    }
+    if (__builtin_expect(k + 1 == next_out, 0)) {
+      while (j < p.n_out && p.out_step[j] == k + 1) {
+        const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        const bool exact = (w0 == (T)0 && w1 == (T)1);
+        Pack<T, W> ov;
+#pragma unroll
+        for (int q = 0; q < W; ++q) ov.v[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
+        store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
+        ++j;
+      }
+      next_out = next_output_step(p.out_step, j, p.n_out);
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) y[q] = y1[q];
+  }
+}
+
+template <typename T, int METHOD>
+static hipError_t launch_prog_m(const ProgArgs<T>& p, bool vec, hipStream_t s) {
+  if (vec) {
+    const int64_t lanes = p.n >> 2;
+    hipLaunchKernelGGL((trajectory_prog_kernel<T, METHOD, 4>), dim3((unsigned)((lanes + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, s, p);
+  } else {
+    hipLaunchKernelGGL((trajectory_prog_kernel<T, METHOD, 1>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, s, p);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, int64_t d, const uint32_t* code, int f_len,
+                                       int g_len, int dg_len, const void* consts, int scalar_noise, int method,
+                                       const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
+  ProgArgs<T> p;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  p.code = code;
+  p.consts = (const T*)consts;
+  p.f_len = f_len;
+  p.g_len = g_len;
+  p.dg_len = dg_len;
+  p.scalar_noise = scalar_noise;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
+  // (scalar noise addresses the field by row: no alignment condition on elem0)
+  const bool can_vec = (d % 4 == 0) && (scalar_noise || key.elem0 % 4 == 0) && aligned16(ys) && aligned16(y0) &&
+                       ((p.n * sizeof(T)) % 16 == 0);
+  const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
+  switch (method) {
+    case kEuler: return launch_prog_m<T, kEuler>(p, vec, s);
+    case kMilIto: return launch_prog_m<T, kMilIto>(p, vec, s);
+    case kMilStrat: return launch_prog_m<T, kMilStrat>(p, vec, s);
+    case kMidpoint: return launch_prog_m<T, kMidpoint>(p, vec, s);
+    case kSrk: return launch_prog_m<T, kSrk>(p, vec, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t launch_trajectory_prog_diag<float>(void*, const void*, int64_t, int64_t, const uint32_t*, int, int, int,
+                                                       const void*, int, int, const tsde_traj_t*, NoiseKey,
+                                                       const uint64_t*, hipStream_t);
+template hipError_t launch_trajectory_prog_diag<double>(void*, const void*, int64_t, int64_t, const uint32_t*, int, int, int,
+                                                        const void*, int, int, const tsde_traj_t*, NoiseKey,
+                                                        const uint64_t*, hipStream_t);
+
 template hipError_t launch_trajectory_expr_diag<float>(void*, const void*, int64_t, int64_t, const void* const[8],
                                                        int64_t, int, int, int, const tsde_traj_t*, NoiseKey,
                                                        const uint64_t*, hipStream_t);

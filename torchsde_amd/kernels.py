@@ -688,6 +688,42 @@ def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
     return ys
 
 
+_PROGRAMS = collections.OrderedDict()       # (code words, device) -> device tensor of the instruction stream
+
+
+def _program_tensor(words, device):
+    key = (words, str(device))
+    hit = _PROGRAMS.get(key)
+    if hit is None:
+        hit = _PROGRAMS[key] = torch.from_numpy(np.asarray(words, dtype=np.uint32).view(np.int32).copy()).to(device)
+        while len(_PROGRAMS) > 64:
+            _PROGRAMS.popitem(last=False)
+    else:
+        _PROGRAMS.move_to_end(key)
+    return hit
+
+
+def trajectory_prog_diag(ys, y0, f_code, g_code, dg_code, consts, scalar_noise, method, schedule, bm):
+    """All steps of a diagonal- or scalar-noise SDE whose drift and diffusion are expression programs (tuples of
+    instruction words, recognise.RecognisedProgram) in one launch (``tsde_trajectory_prog_diag``)."""
+    _native.require_device(ys, y0, consts)
+    rows, d = y0.shape
+    if schedule.dtype != y0.dtype or ys.dtype != y0.dtype or consts.dtype != y0.dtype:
+        raise ValueError("schedule / output / constant dtype must equal the state dtype")
+    if not (ys.is_contiguous() and y0.is_contiguous() and consts.is_contiguous()) or ys.shape != (schedule.n_out, rows, d) \
+            or consts.dim() != 2 or consts.shape[1] != d:
+        raise ValueError("ys must be a contiguous (n_out, rows, d) tensor, y0 contiguous, consts (n_const, d)")
+    code = _program_tensor(tuple(f_code) + tuple(g_code) + tuple(dg_code), y0.device)
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    rc = lib.tsde_trajectory_prog_diag(ys.data_ptr(), y0.data_ptr(), rows, d, code.data_ptr(), len(f_code), len(g_code),
+                                       len(dg_code), consts.data_ptr(), consts.shape[0], int(bool(scalar_noise)), int(method),
+                                       schedule.struct(), bm._key, bm._elem0,
+                                       None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    _native.check(rc, "tsde_trajectory_prog_diag")
+    return ys
+
+
 def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, diffusion, method, schedule, bm):
     """All steps of a diagonal SDE with a two-layer perceptron drift in one launch (``tsde_trajectory_mlp_diag``);
     writes ys[j] for the schedule's outputs (an output time inside a step is interpolated in the kernel with the

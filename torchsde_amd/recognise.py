@@ -571,8 +571,16 @@ class _Interpreter(TorchDispatchMode):
                     and id(args[0]) not in self.time:
                 src = args[0]
                 if src.dim() <= 2 and (src.dim() < 2 or src.shape[0] == 1):
-                    return self.track(out, _Form(rate=ZERO, shift=self.coefficient(src if src.dim() < 2 else src[0])))
+                    return self.track(out, self.constant_value(self.coefficient(src if src.dim() < 2 else src[0])))
             return out
+        return self.tracked_op(func, args, kwargs)
+
+    def constant_value(self, c):
+        """The tracked value of something that does not depend on the state (`sigma.expand_as(y)`, `torch.ones_like(y)`)."""
+        return _Form(rate=ZERO, shift=c)
+
+    def tracked_op(self, func, args, kwargs):
+        """An operator with at least one operand derived from the state: the single-function algebra (`_Form`)."""
         schema = func._schema
         name = schema.name.split("::")[1]
         if schema.is_mutable:
@@ -648,6 +656,330 @@ class _Interpreter(TorchDispatchMode):
                 q = _poly_product(q, p)
             return self.track(out, _poly_form(q))
         raise NotElementwise(f"operator {schema.name} on a value derived from the state")
+
+
+# ---- expression programs: any elementwise code ---------------------------------------------------------------------------
+class _Expr:
+    """A node of the expression tree of a value derived from the state: op "y" (the state), "const" (`value`: a number or a
+    per-channel tensor), a unary function or a binary operator (`args`). Duck-typed like `_Form` where the interpreter asks."""
+    __slots__ = ("op", "args", "value", "trailing")
+    phi, exact = "program", False
+
+    def __init__(self, op, args=(), value=None, trailing=False):
+        self.op, self.args, self.value, self.trailing = op, tuple(args), value, trailing
+
+    def constant(self):
+        return False
+
+    def leaf(self):
+        return self.op in ("y", "const")
+
+
+_OPCODES = {"load": 0, "add": 1, "sub": 2, "rsub": 3, "mul": 4, "div": 5, "rdiv": 6, "neg": 16, "exp": 17, "log": 18, "sin": 19,
+            "cos": 20, "tanh": 21, "sigmoid": 22, "softplus": 23, "sqrt": 24, "abs": 25, "relu": 26, "reciprocal": 27,
+            "square": 28, "cube": 29, "dup": 30}          # include/torchsde_amd.h: tsde_trajectory_prog_diag
+_SRC_STACK, _SRC_CONST, _SRC_STATE = 0, 1, 2
+_REVERSED = {"add": "add", "mul": "mul", "sub": "rsub", "div": "rdiv"}
+_STACK_DEPTH = 4
+
+
+class _Program:
+    """Postfix code for one expression tree: `words` (ints as the C ABI wants them) referring to rows of `consts`."""
+
+    def __init__(self, consts):
+        self.words, self.consts = [], consts
+
+    def const_row(self, value):
+        for k, have in enumerate(self.consts):
+            if have is value or (not torch.is_tensor(value) and not torch.is_tensor(have) and have == value):
+                return k
+        if len(self.consts) >= 64:
+            raise NotElementwise("more than 64 constants in drift and diffusion")
+        self.consts.append(value)
+        return len(self.consts) - 1
+
+    def emit(self, op, src=_SRC_STACK, k=0):
+        self.words.append(_OPCODES[op] | (src << 8) | (k << 16))
+
+    @staticmethod
+    def need(node):
+        """Stack slots the evaluation of `node` occupies at its peak (Sethi-Ullman numbering; leaves are operands)."""
+        if node.leaf():
+            return 1
+        if len(node.args) == 1:
+            return _Program.need(node.args[0])
+        a, b = node.args
+        if b.leaf():
+            return _Program.need(a)
+        if a.leaf():
+            return _Program.need(b)
+        na, nb = _Program.need(a), _Program.need(b)
+        return max(na, nb) + 1 if na == nb else max(na, nb)
+
+    def source(self, leaf):
+        return (_SRC_STATE, 0) if leaf.op == "y" else (_SRC_CONST, self.const_row(leaf.value))
+
+    def compile(self, node):
+        """Append the code that leaves the value of `node` on top of the stack."""
+        if node.leaf():
+            self.emit("load", *self.source(node))
+        elif len(node.args) == 1:
+            self.compile(node.args[0])
+            self.emit(node.op)
+        else:
+            a, b = node.args
+            if b.leaf():
+                self.compile(a)
+                self.emit(node.op, *self.source(b))
+            elif a.leaf():
+                self.compile(b)
+                self.emit(_REVERSED[node.op], *self.source(a))
+            elif self.need(a) >= self.need(b):
+                self.compile(a)
+                self.compile(b)
+                self.emit(node.op)                      # (below the top) op (top)
+            else:
+                self.compile(b)
+                self.compile(a)
+                self.emit(_REVERSED[node.op])           # (top) op (below the top)
+
+
+def _is_number(node, value):
+    return node.op == "const" and not torch.is_tensor(node.value) and node.value == value
+
+
+def _expr(op, *args):
+    """A node with the obvious simplifications (the derivative trees are full of 0 and 1)."""
+    if op == "mul":
+        a, b = args
+        if _is_number(a, 0) or _is_number(b, 0):
+            return _Expr("const", value=0.0)
+        if _is_number(a, 1):
+            return b
+        if _is_number(b, 1):
+            return a
+    if op == "add":
+        a, b = args
+        if _is_number(a, 0):
+            return b
+        if _is_number(b, 0):
+            return a
+    if op == "sub" and _is_number(args[1], 0):
+        return args[0]
+    if op == "neg" and args[0].op == "const" and not torch.is_tensor(args[0].value):
+        return _Expr("const", value=-args[0].value)
+    return _Expr(op, args)
+
+
+def _number(v):
+    return _Expr("const", value=float(v))
+
+
+def _derivative(node):
+    """d node / d y as a tree (what autograd computes for `g` in derivative-form Milstein, base_sde.py:147-152)."""
+    op = node.op
+    if op == "y":
+        return _number(1)
+    if op == "const":
+        return _number(0)
+    if len(node.args) == 1:
+        u = node.args[0]
+        du = _derivative(u)
+        if op == "neg":
+            return _expr("neg", du)
+        outer = {
+            "exp": lambda: node,
+            "log": lambda: _expr("reciprocal", u),
+            "sin": lambda: _expr("cos", u),
+            "cos": lambda: _expr("neg", _expr("sin", u)),
+            "tanh": lambda: _expr("sub", _number(1), _expr("square", node)),
+            "sigmoid": lambda: _expr("mul", node, _expr("sub", _number(1), node)),
+            "softplus": lambda: _expr("sigmoid", u),
+            "sqrt": lambda: _expr("div", _number(0.5), node),
+            "reciprocal": lambda: _expr("neg", _expr("square", node)),
+            "square": lambda: _expr("mul", _number(2), u),
+            "cube": lambda: _expr("mul", _number(3), _expr("square", u)),
+        }.get(op)
+        if outer is None:
+            raise NotElementwise(f"no derivative rule for {op} (Milstein needs the diffusion's derivative)")
+        return _expr("mul", outer(), du)
+    a, b = node.args
+    da, db = _derivative(a), _derivative(b)
+    if op == "add":
+        return _expr("add", da, db)
+    if op == "sub":
+        return _expr("sub", da, db) if not _is_number(da, 0) else _expr("neg", db)
+    if op == "mul":
+        return _expr("add", _expr("mul", da, b), _expr("mul", a, db))
+    if op == "div":
+        if _is_number(db, 0):
+            return _expr("div", da, b)
+        return _expr("div", _expr("sub", _expr("mul", da, b), _expr("mul", a, db)), _expr("square", b))
+    raise NotElementwise(f"no derivative rule for {op}")
+
+
+class _TreeInterpreter(_Interpreter):
+    """The same walk over the user's code, keeping the whole expression TREE of every value derived from the state instead
+    of folding it into one function: anything built from + - * /, integer powers and the unary functions below."""
+    _FUNCTIONS = {"exp": "exp", "log": "log", "sin": "sin", "cos": "cos", "tanh": "tanh", "sigmoid": "sigmoid", "sqrt": "sqrt",
+                  "abs": "abs", "relu": "relu", "reciprocal": "reciprocal", "neg": "neg", "square": "square"}
+
+    def __init__(self, y, t, rows, d):
+        super().__init__(y, t, rows, d)
+        self.forms[id(y)] = _Expr("y")
+
+    def constant_value(self, c):
+        return _Expr("const", value=c)
+
+    def state_shaped(self, tensor):
+        shape = tuple(tensor.shape)
+        return shape == (self.rows, self.d) or shape == (self.rows, self.d, 1)      # (rows, d, 1): scalar noise's g
+
+    def operand(self, x):
+        node = self.form_of(x)
+        return node if node is not None else _Expr("const", value=self.coefficient(x))
+
+    def tracked_op(self, func, args, kwargs):
+        schema = func._schema
+        name = schema.name.split("::")[1]
+        if schema.is_mutable:
+            raise NotElementwise(f"in-place {name} on a value derived from the state")
+        self.check_kwargs(name, schema, kwargs)
+        out = func(*args, **kwargs)
+        x = self.form_of(args[0]) if args else None
+        if name in self._LIKE and out.dtype == args[0].dtype:
+            return self.track(out, _Expr("const", value=self._LIKE[name]))
+        if name == "full_like" and out.dtype == args[0].dtype and isinstance(args[1], (int, float)):
+            return self.track(out, _Expr("const", value=float(args[1])))
+        if name in self._SAME and x is not None:
+            if not torch.is_tensor(out) or out.shape != args[0].shape or out.dtype != args[0].dtype \
+                    or out.device != args[0].device:
+                raise NotElementwise(f"{name} changes the shape, dtype or device of a value derived from the state")
+            return self.track(out, x)
+        if name == "unsqueeze" and x is not None and tuple(out.shape) == (self.rows, self.d, 1) and not x.trailing:
+            return self.track(out, _Expr(x.op, x.args, x.value, trailing=True))          # scalar noise: g of shape (B, d, 1)
+        if x is not None and x.trailing:
+            raise NotElementwise(f"{name} after the (rows, d, 1) reshape of the diffusion")
+        if name in self._FUNCTIONS and x is not None and len(args) == 1:
+            return self.track(out, _Expr(self._FUNCTIONS[name], (x,)))
+        if name == "softplus" and x is not None:
+            beta = args[1] if len(args) > 1 else kwargs.get("beta", 1)
+            threshold = args[2] if len(args) > 2 else kwargs.get("threshold", 20)
+            if beta != 1 or threshold != 20:
+                raise NotElementwise("softplus with a non-default beta or threshold")
+            return self.track(out, _Expr("softplus", (x,)))
+        if name == "pow" and x is not None and len(args) == 2 and isinstance(args[1], (int, float)):
+            n = args[1]
+            if n == 1:
+                return self.track(out, x)
+            if n == 2:
+                return self.track(out, _Expr("square", (x,)))
+            if n == 3:
+                return self.track(out, _Expr("cube", (x,)))           # (torch evaluates x**3 as (x * x) * x)
+            if n == 0.5:
+                return self.track(out, _Expr("sqrt", (x,)))
+            if n == -1:
+                return self.track(out, _Expr("reciprocal", (x,)))
+            if n == 4:
+                return self.track(out, _Expr("square", (_Expr("square", (x,)),)))
+            raise NotElementwise(f"the power {n} of a function of the state")
+        if name in ("mul", "add", "sub", "rsub", "div") and len(args) >= 2:
+            a, b = self.operand(args[0]), self.operand(args[1])
+            alpha = kwargs.get("alpha", 1)
+            if name == "rsub":
+                a, b, name = b, a, "sub"
+            if alpha != 1:
+                if not isinstance(alpha, (int, float)):
+                    raise NotElementwise("a tensor-valued alpha")
+                b = _Expr("mul", (b, _number(alpha)))
+            return self.track(out, _Expr(name, (a, b)))
+        raise NotElementwise(f"operator {schema.name} on a value derived from the state")
+
+
+class RecognisedProgram:
+    """Drift and diffusion of a diagonal- or scalar-noise SDE as expression programs (`tsde_trajectory_prog_diag`)."""
+    perceptron = neural = timed = False
+    exact = False
+
+    def __init__(self, f, g, d, dtype, device, noise_type):
+        self.d, self.dtype, self.device, self.noise_type = d, dtype, device, noise_type
+        if f.trailing or g.trailing != (noise_type == "scalar"):
+            raise NotElementwise(f"drift / diffusion of the wrong shape for {noise_type} noise")
+        consts = []
+        self.programs = []
+        for tree in (f, g, None):
+            if tree is None:
+                try:
+                    tree = _derivative(g)
+                except NotElementwise:
+                    self.programs.append(None)           # (no derivative rule: every scheme but Milstein)
+                    continue
+            if _Program.need(tree) > _STACK_DEPTH:
+                if len(self.programs) == 2:
+                    self.programs.append(None)
+                    continue
+                raise NotElementwise("an expression that needs more than four intermediate values at once")
+            prog = _Program(consts)
+            prog.compile(tree)
+            self.programs.append(tuple(prog.words))
+        if sum(len(w) for w in self.programs if w) > 256:
+            raise NotElementwise("drift and diffusion of more than 256 operations")
+        self.consts = consts
+
+    def structure(self):
+        """Key of the trust verdict: the programs themselves (constants by position only: values are live)."""
+        return (("program", self.noise_type) + tuple(self.programs), ("consts", len(self.consts)))
+
+    def affine_leaves(self):
+        return None
+
+    def const_table(self):
+        if not self.consts:
+            return torch.zeros(1, self.d, dtype=self.dtype, device=self.device)
+        rows = []
+        for c in self.consts:
+            if torch.is_tensor(c):
+                if c.dtype != self.dtype and c.dim() > 0:
+                    raise NotElementwise(f"a constant of dtype {c.dtype} with a state of dtype {self.dtype}")
+                rows.append(c.detach().to(device=self.device, dtype=self.dtype).reshape(-1).expand(self.d))
+            else:
+                rows.append(_constant_vector(float(c), self.d, self.dtype, self.device))
+        return torch.stack(rows).contiguous()
+
+    def spec(self, milstein=False):
+        f, g, dg = self.programs
+        if milstein and dg is None:
+            raise NotElementwise("Milstein: the diffusion's derivative has no program")
+        return ("program_diagonal", f, g, dg if (milstein and dg) else (), self.const_table(), self.noise_type == "scalar")
+
+
+def recognise_program(sde, t, y0, noise_type, rows=None):
+    """`recognise` for code the single-function forms cannot hold: the expression trees of `sde.f_and_g` on the probe ->
+    `RecognisedProgram`, or NotElementwise (anything that is not elementwise arithmetic of the state and constants; any
+    use of t)."""
+    rows = 2 if rows is None else int(rows)
+    if rows == y0.shape[0]:
+        rows += 1
+    d = y0.shape[1]
+    probe = y0.detach()[:1].expand(rows, d).clone() if y0.shape[0] > 0 else torch.zeros(rows, d, dtype=y0.dtype, device=y0.device)
+    t_probe = t.detach().clone()
+    interp = _TreeInterpreter(probe, t_probe, rows, d)
+    try:
+        with torch.no_grad(), interp:
+            f, g = sde.f_and_g(t_probe, probe)
+    except NotElementwise:
+        raise
+    except Exception as e:
+        raise NotElementwise(f"{type(e).__name__}: {e}") from None
+    trees = []
+    for name, value in (("drift", f), ("diffusion", g)):
+        tree = interp.form_of(value)
+        if not isinstance(tree, _Expr):
+            raise NotElementwise(f"the {name} is not a tracked function of the state")
+        trees.append(tree)
+    found = RecognisedProgram(trees[0], trees[1], d, y0.dtype, y0.device, noise_type)
+    found._alive = interp.keep
+    return found
 
 
 class Recognised:

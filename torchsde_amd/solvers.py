@@ -320,6 +320,11 @@ class BaseSDESolver:
         additive), or None."""
         return None
 
+    def _program_code(self):
+        """TSDE_TRAJ_* code of this scheme in the expression-program kernel (`tsde_trajectory_prog_diag`: diagonal or scalar
+        noise), or None."""
+        return None
+
     def _closed_form_coefficients(self, y0):
         """What `_integrate_trajectory` needs if the whole solve can run as ONE launch of a trajectory kernel, else
         None: a closed-form SDE handed to `sdeint` as is (closed_form.py) and this package's BrownianInterval
@@ -402,8 +407,11 @@ class BaseSDESolver:
         elementwise = sde.noise_type == NOISE_TYPES.diagonal and self._trajectory_code() is not None
         networks = (sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar, NOISE_TYPES.general)
                     and self._neural_code() is not None)
+        # ... and any other elementwise code (several functions of the state summed / multiplied, scalar noise): expression
+        # programs (recognise.RecognisedProgram), every scheme with an in-register form
+        programs = sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar) and self._program_code() is not None
         if (not recognise.ENABLED or not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful
-                or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks)):
+                or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks or programs)):
             return None
         if self._tracks_grad(y0):
             return self._integrate_recognised_with_grad(y0, ts) if elementwise else None
@@ -412,9 +420,11 @@ class BaseSDESolver:
                 or y0.shape[0] < 8
                 or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
                 or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
-                or (elementwise and self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
+                or ((elementwise or programs) and self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         if sde.noise_type == NOISE_TYPES.diagonal and tuple(bm.shape) != tuple(y0.shape):
+            return None
+        if sde.noise_type == NOISE_TYPES.scalar and tuple(bm.shape) != (y0.shape[0], 1):
             return None
         chain, base = graph._wrapper_chain(sde)
         if not self._may_be_interpreted(base):
@@ -438,8 +448,24 @@ class BaseSDESolver:
             return None
 
         times = None
+        milstein = self._program_code() in (_native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT)
+
+        def as_program(first_reason):
+            """The second chance of code the single-function forms cannot hold: its expression trees as programs."""
+            if not programs:
+                raise recognise.NotElementwise(first_reason)
+            try:
+                found = recognise.recognise_program(sde, ts[0], y0, sde.noise_type)
+                spec = found.spec(milstein)
+            except recognise.NotElementwise as e:
+                raise recognise.NotElementwise(f"{first_reason}; as an expression program: {e}") from None
+            book["program"] = (chain, type(self).__name__)
+            return found, spec
+
         try:
             try:
+                if book.get("program") == (chain, type(self).__name__):
+                    raise recognise.NotElementwise("(remembered: an expression program)")
                 if book.get("uses_t") == (chain, type(self).__name__):
                     raise recognise.DependsOnTime("(remembered)")         # skip the pass that is known to end at t
                 found = recognise.recognise(sde, ts[0], y0)
@@ -455,7 +481,11 @@ class BaseSDESolver:
                 except recognise.NotElementwise as e:
                     raise recognise.NotElementwise("drift or diffusion depends on t, and not only through arithmetic that "
                                                    f"broadcasts ({e})") from None
-            if found.neural:
+            except recognise.NotElementwise as e:
+                found, spec = as_program(str(e))
+            if isinstance(found, recognise.RecognisedProgram):
+                pass
+            elif found.neural:
                 if not networks or times is not None:
                     raise recognise.NotElementwise("drift and diffusion networks, but no neural-SDE kernel for this scheme")
                 spec = found.neural_spec(sde.noise_type)
@@ -464,7 +494,10 @@ class BaseSDESolver:
             elif not elementwise:
                 raise recognise.NotElementwise(f"{sde.noise_type} noise whose drift and diffusion are not both networks")
             else:
-                spec = found.spec()
+                try:
+                    spec = found.spec()
+                except recognise.NotElementwise as e:
+                    found, spec = as_program(str(e))
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if spec[0] == "mlp_diagonal":
@@ -487,8 +520,11 @@ class BaseSDESolver:
         before = graph.python_state(base)
         rng_before = self._rng_states(y0.device)
         try:
-            again = recognise.recognise(sde, ts[0], y0, times=times, rows=5)
-            again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
+            if spec[0] == "program_diagonal":
+                again = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, rows=5).spec(milstein)
+            else:
+                again = recognise.recognise(sde, ts[0], y0, times=times, rows=5)
+                again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if before is None or graph.python_state(base) != before:
@@ -712,6 +748,13 @@ class BaseSDESolver:
             return K.trajectory_mlp_diag_differentiable(y0, coefficients[3:], coefficients[1], coefficients[2],
                                                         self._trajectory_code(), schedule_all, out_step, bm)
         schedule = K.TrajectorySchedule.cached(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        if coefficients[0] == "program_diagonal":
+            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            K.trajectory_prog_diag(ys[1:], y0c, coefficients[1], coefficients[2], coefficients[3], coefficients[4],
+                                   coefficients[5], self._program_code(), schedule, bm)
+            return ys
         if coefficients[0] == "neural":
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
@@ -862,6 +905,9 @@ class Euler(BaseSDESolver):
     def _neural_code(self):
         return _native.TRAJ_EULER
 
+    def _program_code(self):
+        return _native.TRAJ_EULER
+
     def _advance(self, y0, st, out):
         return self._drift_diffusion_update(st.times[0], y0, st.dt, 1.0, st.noise, out)
 
@@ -882,6 +928,9 @@ class Midpoint(BaseSDESolver):
         return _native.TRAJ_MIDPOINT if self._diag() else None
 
     def _neural_code(self):
+        return _native.TRAJ_MIDPOINT
+
+    def _program_code(self):
         return _native.TRAJ_MIDPOINT
 
     def _advance(self, y0, st, out):
@@ -960,6 +1009,11 @@ class _Milstein(BaseSDESolver):
 
     def _trajectory_code(self):
         if not self._diag() or self.options[METHOD_OPTIONS.grad_free]:
+            return None
+        return _native.TRAJ_MILSTEIN_ITO if self.ito else _native.TRAJ_MILSTEIN_STRAT
+
+    def _program_code(self):
+        if self.options[METHOD_OPTIONS.grad_free]:
             return None
         return _native.TRAJ_MILSTEIN_ITO if self.ito else _native.TRAJ_MILSTEIN_STRAT
 
@@ -1074,6 +1128,9 @@ class SRK(BaseSDESolver):
 
     def _trajectory_code(self):
         return _native.TRAJ_SRK if self._diag() else None
+
+    def _program_code(self):
+        return _native.TRAJ_SRK
 
     def _advance(self, y0, st, out):
         if self.sde.noise_type == NOISE_TYPES.additive:

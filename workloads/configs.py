@@ -59,6 +59,22 @@ WORKLOADS = {
         problem="double_well", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
         kernel="tsde_step_diag<float> (elementwise_kernel<StepDiagOp<float>>)"),
+    # The reference's scalar-noise problem (ExScalar, tests/problems.py:75-103: f = -p^2 sin(y) cos(y)^3, g = p cos(y)^2 of shape
+    # (B, d, 1), one Brownian channel per row) with the method `sdeint` picks for it by default (SRK): drift and diffusion are
+    # products of several functions of the state, so they travel as expression programs (recognise.RecognisedProgram) and the
+    # solve is ONE launch of tsde_trajectory_prog_diag; stepwise counterpart below
+    "c2_srk_exscalar_default_route_b65536_d64_s1000": dict(
+        problem="scalar_ito", method="srk", levy="space-time", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=64 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_prog_diag<float, srk, scalar noise> (user module recognised as expression programs)"),
+    "c2_euler_exscalar_default_route_b65536_d64_s1000": dict(
+        problem="scalar_ito", method="euler", levy="none", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_prog_diag<float, euler, scalar noise> (user module recognised as expression programs)"),
+    "c2_srk_exscalar_b65536_d64_s1000": dict(
+        problem="scalar_ito", method="srk", levy="space-time", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
+        kernel="tsde_srk_diag_stage<float> (4 stage kernels; user f, g: ~12 torch kernels per evaluation)"),
     # BASELINE.json configs[1], STEPWISE (options={"trajectory_kernel": False}): the user's f and g run as torch kernels
     # between the per-step kernels -- the route of every SDE that is not a per-channel expression
     "c2_euler_diag_b65536_d64_s1000": dict(
