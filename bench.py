@@ -78,7 +78,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_srk_scheduled_default_route_b65536_d64_s1000",
         "c2_euler_doublewell_b65536_d64_s1000", "c2_euler_doublewell_default_route_b65536_d64_s1000",
         "c2_srk_exscalar_b65536_d64_s1000", "c2_srk_exscalar_default_route_b65536_d64_s1000",
-        "c2_euler_exscalar_default_route_b65536_d64_s1000",
+        "c2_euler_exscalar_default_route_b65536_d64_s1000", "c2_euler_exscalar_training_default_route_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
         "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500",
         "c5_adjoint_latent_default_route_b32768_d128_s500", "c5_adjoint_latent_defaults_default_route_b32768_d128_s500")
@@ -310,6 +310,9 @@ class Job:
         with torch.no_grad():
             f, g = (None, None) if kid == 5 else (sde.f(t0, y).contiguous(), sde.g(t0, y))
             g = g if kid in (5, 12) else g.contiguous()
+            if kid in (1, 3, 4) and g.dim() == 3 and g.shape[-1] == 1:      # scalar noise: g (B, d, 1), one increment per row
+                g = g.squeeze(-1).contiguous()
+                spec = [NoiseSpec((B, d), torch.float32, dev, entropy=7, elem0=0, cell=i, h=dt) for i in range(n)]
 
         def copies(*tensors):
             """Enough distinct copies of an operand set that the rotation's working set is >= 128 MiB (4x the L2s)."""

@@ -403,14 +403,16 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
 /* tsde_trajectory_affine_diag for drift and diffusion given as expression PROGRAMS: any elementwise code -- sums and
  * products of several functions of the state, powers, quotients (the reference's ExScalar, tests/problems.py:75-103:
  * f = -p^2 sin(y) cos(y)^3, g = p cos(y)^2) -- as postfix instruction streams over a four-deep value stack.
- *   code  device array of 32-bit words: the f program (f_len words), then g (g_len), then g' (dg_len; Milstein only, may be 0
- *         words for the other methods). One word = opcode | source << 8 | constant row << 16.
+ *   code  HOST array of 32-bit words (at most 96; they travel in the kernel arguments, so decoding is scalar work): the f
+ *         program (f_len words), then g (g_len), then g' (dg_len; Milstein only, may be 0 words for the other methods).
+ *         One word = opcode | source << 8 | constant row << 16.
  *         opcodes with a source: 0 LOAD (push), 1 ADD, 2 SUB, 3 RSUB, 4 MUL, 5 DIV, 6 RDIV; without: 16 NEG, 17 EXP, 18 LOG,
  *         19 SIN, 20 COS, 21 TANH, 22 SIGMOID, 23 SOFTPLUS (threshold 20), 24 SQRT, 25 ABS, 26 RELU, 27 RECIP, 28 SQUARE,
  *         29 CUBE, 30 DUP.  source: 0 the value below the top of the stack (popped), 1 constant row k (this channel's entry),
  *         2 the state y.  A binary operator computes  A op B,  A = top of stack, B = source (RSUB, RDIV: B op A); with
  *         source 0: A = the value below the top, B = the top, and the result replaces both. A program leaves its value on top.
- *   consts (n_const, d) in `dtype`: every number or per-channel parameter the programs use, one row each
+ *   consts (n_const <= 64, d) in `dtype`, device: every number or per-channel parameter the programs use, one row each (the
+ *         first 8 rows are kept in registers for the whole solve; later rows are read through the cache at each use)
  *   scalar_noise 1: noise type "scalar" -- ONE Brownian channel per row: element (row, c) takes increment elem0 + row of the
  *         (rows, 1) field; 0: diagonal noise as in tsde_trajectory_affine_diag
  * Same schedule, methods (all five), outputs and Brownian path as the affine kernel; values only. The host must make sure a
@@ -419,6 +421,16 @@ int tsde_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, int64_t d,
                               int32_t g_len, int32_t dg_len, const void* consts, int32_t n_const, int scalar_noise, int method,
                               const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
                               int dtype, void* stream);
+
+/* ... and with the path-wise sensitivities of every output (training through `sdeint`, _core/sdeint.py:27-112, for SDEs stated
+ * as programs): forward-mode tangents carried through the same programs.
+ *   sens (n_out, TSDE_TRAJ_SENS, rows, d): plane 0 = d out / d y0; plane s in 1 .. TSDE_TRAJ_SENS - 1 = d out / d (the
+ *        constant row k with param_slot[k] == s), element-wise (a constant's entry for channel c only reaches channel c).
+ *   param_slot HOST array of n_const entries: the plane of each constant row, or -1 for rows that need no gradient. */
+int tsde_trajectory_prog_diag_sens(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const uint32_t* code,
+                                   int32_t f_len, int32_t g_len, int32_t dg_len, const void* consts, int32_t n_const,
+                                   const int8_t* param_slot, int scalar_noise, int method, const tsde_traj_t* traj,
+                                   uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
 
 /* ---- neural SDEs: drift AND diffusion two-layer perceptrons of (t, y) -------------------------------------------------
  * One perceptron shared by the batch:  out = scale * final(W2 . act(W1 . y + w1t * t + b1) + b2)

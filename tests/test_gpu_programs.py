@@ -159,3 +159,69 @@ def test_scalar_noise_program_rows_vs_oracle(method, levy):
                                                  f"scalar noise, {method}, program kernel")
     finally:
         torch.set_num_threads(before)
+
+
+# ---- training THROUGH sdeint (autograd on): the programs on dual numbers --------------------------------------------------
+def _train(sde, entropy, method, levy, stepwise, dtype, d=D):
+    import torchsde_amd
+    m = 1 if sde.noise_type == "scalar" else d
+    y0 = torch.full((B, d), 0.3, device=DEV, dtype=dtype, requires_grad=True)
+    ts = torch.tensor([0.0, 11.5 * DT, STEPS * DT], device=DEV, dtype=dtype)
+    bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, m), device=DEV, dtype=dtype, entropy=entropy, dt=DT,
+                                       levy_area_approximation=levy)
+    options = {"hip_graph": False}
+    if stepwise:
+        options["trajectory_kernel"] = False
+    sde.zero_grad()
+    ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=DT, options=options)
+    weights = torch.cos(torch.arange(ys.numel(), device=DEV, dtype=dtype)).reshape(ys.shape)
+    (ys * weights).sum().backward()
+    return ys, y0.grad.clone(), {n: p.grad.clone() for n, p in sde.named_parameters()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
+@pytest.mark.parametrize("which", ["scalar", "sum", "logistic"])
+def test_gradients_through_sdeint_take_the_program_sensitivity_kernel(which, method, sde_type, levy, dtype):
+    """`sdeint` with autograd recording, on modules whose code is not affine: values, dL/dy0 and the gradients of the module's
+    own parameters (through whatever the user's code derives from them: `-p ** 2`) from tsde_trajectory_prog_diag_sens agree
+    with back-propagation through the stepwise solver (the reference's behaviour, _core/sdeint.py:27-112)."""
+    if which == "scalar":
+        sde = problems.ScalarTrig(D, sde_type, dtype=dtype).to(DEV)
+    elif which == "sum":
+        sde = _Mixed(sde_type, "sum").to(DEV).to(dtype)
+    else:
+        sde = problems.Logistic(D, sde_type).to(DEV).to(dtype)
+    first = _train(sde, 1, method, levy, False, dtype)                       # earns trust: the stepwise result, with its graph
+    assert type(first[0].grad_fn).__name__ != "_ProgTrajectoryFnBackward"
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast = _train(sde, 2, method, levy, False, dtype)
+    assert type(fast[0].grad_fn).__name__ == "_ProgTrajectoryFnBackward", type(fast[0].grad_fn).__name__
+    slow = _train(sde, 2, method, levy, True, dtype)
+    tol = dict(rtol=2e-3, atol=2e-4) if dtype == torch.float32 else dict(rtol=1e-8, atol=1e-10)
+    torch.testing.assert_close(fast[0], slow[0], **(dict(rtol=2e-5, atol=2e-6) if dtype == torch.float32 else tol))
+    torch.testing.assert_close(fast[1], slow[1], **tol)
+    assert set(fast[2]) == set(slow[2]) and fast[2]
+    for name in fast[2]:
+        scale = slow[2][name].abs().max().item() + 1e-12
+        err = (fast[2][name] - slow[2][name]).abs().max().item()
+        assert err <= (2e-3 if dtype == torch.float32 else 1e-8) * scale, (name, err, scale)
+
+
+def test_more_than_four_trainable_constants_stay_stepwise():
+    class Many(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.c = nn.ParameterList([nn.Parameter(0.1 * torch.ones(D) * (k + 1)) for k in range(5)])
+
+        def f(self, t, y):
+            return torch.tanh(y) * self.c[0] - y * self.c[1] + self.c[2]
+
+        def g(self, t, y):
+            return self.c[3] * torch.sigmoid(y) + self.c[4]
+    sde = Many().to(DEV)
+    for entropy in (1, 2):
+        ys, _, grads = _train(sde, entropy, "euler", "none", False, torch.float32)
+        assert type(ys.grad_fn).__name__ != "_ProgTrajectoryFnBackward" and len(grads) == 5

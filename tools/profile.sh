@@ -1,5 +1,6 @@
 #!/bin/bash
-# Profiling recipe used for profiles/ (run on the GPU box through gpurun). Usage: tools/profile.sh <tag>
+# Kernel-trace recipe used for profiles/ (run on the GPU box through gpurun). Usage: tools/profile.sh <tag>
+# (HBM traffic counters: tools/profile_traffic.sh, the one recipe for them; SQ counters of the headline: tools/profile_trajectory.sh)
 # (every pass under its own `timeout`: a counter pass of round 4 did not come back and ate the rest of the GPU budget)
 set -u
 TAG=${1:-r1}
@@ -8,9 +9,6 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also > $OUT/bench_under_trace.json 2> $OUT/trace.log
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-stepwise > /dev/null 2> $OUT/pmc_fetch.log
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-stepwise > /dev/null 2> $OUT/pmc_write.log
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 python $R/tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
-find $OUT -name "*counter_collection.csv" -size +4M -delete

@@ -9,9 +9,8 @@ mkdir -p $OUT
 cd $R
 # 1. the default bench line (what the driver runs), on its own
 python bench.py > $OUT/bench_c2_default.json 2> $OUT/bench_c2_default.err
-# 2. default bench under rocprofv3: kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes -> traffic.json (with the csrc digest)
+# 2. default bench under rocprofv3: kernel trace + stats
 tools/profile.sh $TAG > $OUT/bench_c2_rocprofv3_summary.txt 2>&1
-cp gpurun_out/prof_$TAG/traffic.json $OUT/traffic.json 2>/dev/null
 cp gpurun_out/prof_$TAG/bench_under_trace.json $OUT/bench_c2_under_trace.json 2>/dev/null
 f=$(find gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 $f | cut -c1-400 > $OUT/bench_c2_kernel_stats.csv
 # 3. kernel statistics of the other BASELINE configurations (stepwise) and of the closed-form routes

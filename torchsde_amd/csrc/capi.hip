@@ -532,14 +532,14 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
               where);
 }
 
-int tsde_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, int64_t d, const uint32_t* code, int32_t f_len,
-                              int32_t g_len, int32_t dg_len, const void* consts, int32_t n_const, int scalar_noise, int method,
-                              const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
-                              int dtype, void* stream) {
-  const char* where = "tsde_trajectory_prog_diag";
+static int prog_diag(const char* where, void* ys, void* sens, const int8_t* param_slot, const void* y0, int64_t rows,
+                     int64_t d, const uint32_t* code, int32_t f_len, int32_t g_len, int32_t dg_len, const void* consts,
+                     int32_t n_const, int scalar_noise, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                     const uint64_t* entropy_dev, int dtype, void* stream) {
   if (!ys || !y0 || !code || !traj) return bad_arg(where, "null argument");
-  if (f_len < 1 || g_len < 1 || dg_len < 0 || f_len + g_len + dg_len > 256) return bad_arg(where, "program lengths out of range");
-  if (n_const < 0 || (n_const > 0 && !consts)) return bad_arg(where, "constant table missing");
+  if (f_len < 1 || g_len < 1 || dg_len < 0 || f_len + g_len + dg_len > 96)
+    return bad_arg(where, "program lengths out of range (at most 96 words together)");
+  if (n_const < 0 || n_const > 64 || (n_const > 0 && !consts)) return bad_arg(where, "constant table missing or above 64 rows");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
   if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
   if ((method == TSDE_TRAJ_MILSTEIN_ITO || method == TSDE_TRAJ_MILSTEIN_STRAT) && dg_len < 1)
@@ -547,14 +547,35 @@ int tsde_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, int64_t d,
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
   if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  if (sens && param_slot)
+    for (int k = 0; k < n_const; ++k)
+      if (param_slot[k] == 0 || param_slot[k] >= TSDE_TRAJ_SENS || param_slot[k] < -1)
+        return bad_arg(where, "param_slot entries must be -1 or in 1 .. TSDE_TRAJ_SENS - 1");
   const hipStream_t s = (hipStream_t)stream;
   const tsde::NoiseKey key = make_key(entropy, elem0);
   ProfScope p(TSDE_KID_TRAJECTORY, s);
   TSDE_DISPATCH(dtype, where,
-                tsde::launch_trajectory_prog_diag<float>(ys, y0, rows, d, code, f_len, g_len, dg_len, consts, scalar_noise != 0,
-                                                         method, traj, key, entropy_dev, s),
-                tsde::launch_trajectory_prog_diag<double>(ys, y0, rows, d, code, f_len, g_len, dg_len, consts,
-                                                          scalar_noise != 0, method, traj, key, entropy_dev, s));
+                tsde::launch_trajectory_prog_diag<float>(ys, sens, param_slot, y0, rows, d, code, f_len, g_len, dg_len, consts,
+                                                         n_const, scalar_noise != 0, method, traj, key, entropy_dev, s),
+                tsde::launch_trajectory_prog_diag<double>(ys, sens, param_slot, y0, rows, d, code, f_len, g_len, dg_len, consts,
+                                                          n_const, scalar_noise != 0, method, traj, key, entropy_dev, s));
+}
+
+int tsde_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, int64_t d, const uint32_t* code, int32_t f_len,
+                              int32_t g_len, int32_t dg_len, const void* consts, int32_t n_const, int scalar_noise, int method,
+                              const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev,
+                              int dtype, void* stream) {
+  return prog_diag("tsde_trajectory_prog_diag", ys, nullptr, nullptr, y0, rows, d, code, f_len, g_len, dg_len, consts, n_const,
+                   scalar_noise, method, traj, entropy, elem0, entropy_dev, dtype, stream);
+}
+
+int tsde_trajectory_prog_diag_sens(void* ys, void* sens, const void* y0, int64_t rows, int64_t d, const uint32_t* code,
+                                   int32_t f_len, int32_t g_len, int32_t dg_len, const void* consts, int32_t n_const,
+                                   const int8_t* param_slot, int scalar_noise, int method, const tsde_traj_t* traj,
+                                   uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+  if (!sens || !param_slot) return bad_arg("tsde_trajectory_prog_diag_sens", "sens and param_slot are required");
+  return prog_diag("tsde_trajectory_prog_diag_sens", ys, sens, param_slot, y0, rows, d, code, f_len, g_len, dg_len, consts,
+                   n_const, scalar_noise, method, traj, entropy, elem0, entropy_dev, dtype, stream);
 }
 
 int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden,

@@ -140,7 +140,14 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
     wtg[i] = (i < hg && p.g.w1t) ? p.g.w1t[i] : 0.0f;
   }
   for (int i = threadIdx.x; i < D; i += 256) b2f[i] = i < dT ? p.f.b2[i] : 0.0f;
-  for (int i = threadIdx.x; i < outp; i += 256) b2g[i] = i < outT ? p.g.b2[i] : 0.0f;
+  // (general noise with a closing sigmoid: the bias is staged as -log2(e) * b2, so that the epilogue's sigmoid argument is one
+  //  fma of the accumulator, 1 / (1 + 2^(-log2(e) acc - log2(e) b2)))
+  constexpr float kNegLog2e = -1.4426950408889634f;
+  const bool prescaled = NS::kGeneral && p.g.final == TSDE_FINAL_SIGMOID;
+  for (int i = threadIdx.x; i < outp; i += 256) {
+    const float b = i < outT ? p.g.b2[i] : 0.0f;
+    b2g[i] = prescaled ? b * kNegLog2e : b;
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,6 +266,11 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             const int col0 = 16 * (ty * M + p0) + n;                         // output column of tile p0 for this lane
+            // the tiles' output biases are requested BEFORE the matrix products (they used to be read, and waited for, in
+            // the epilogue: two exposed LDS round trips per group of tiles)
+            f32x4 bias[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) bias[g] = lds_quad(b2g, 16 * (ty * M + p0 + g) + 4 * part);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int th = 0; th < TH; ++th) {
@@ -275,7 +287,6 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
 #pragma unroll
             for (int g = 0; g < G; ++g) {
               const int tl = p0 + g;                                         // tile within this state tile
-              const f32x4 bias = lds_quad(b2g, 16 * (ty * M + tl) + 4 * part);
               // which state channel (within the tile) this lane's four outputs belong to, and which of its quads they meet
               int target, q;
               if constexpr (M >= 16) {
@@ -291,10 +302,13 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
               float s = 0.0f;
               if (sigmoid_out) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(finalise<true>(acc[g][r] + bias[r]), dw[q][r], s);
+                for (int r = 0; r < 4; ++r) {
+                  const float e = __builtin_amdgcn_exp2f(fmaf(acc[g][r], kNegLog2e, bias[g][r]));      // exp(-(acc + b2))
+                  s = fmaf(__builtin_amdgcn_rcpf(1.0f + e), dw[q][r], s);
+                }
               } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(acc[g][r] + bias[r], dw[q][r], s);
+                for (int r = 0; r < 4; ++r) s = fmaf(acc[g][r] + bias[g][r], dw[q][r], s);
               }
               const float sel = (n == target && tl < tiles) ? 1.0f : 0.0f;
               gdw[ty] = Tile<16>::mfma(sel, s, gdw[ty]);

@@ -135,13 +135,13 @@ enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStr
 template <int METHOD>
 constexpr int stage_slots() { return METHOD == kSrk ? 4 : (METHOD == kMidpoint ? 2 : 1); }
 
-template <typename T, int METHOD, typename S, typename M>
-TSDE_D S scheme_step(const S y, const M& m, const T w, const T u, const T dt, const T half_dt, const T rdt,
+template <typename T, int METHOD, typename S, typename M, typename N = T>
+TSDE_D S scheme_step(const S y, const M& m, const N w, const N u, const T dt, const T half_dt, const T rdt,
                      const T sqrt_dt) {
   if constexpr (METHOD == kEuler) {
     return drift_diffusion_update<T, S>(y, m.template f<0>(y), m.template g<0>(y), w, dt, (T)1);
   } else if constexpr (METHOD == kMilIto || METHOD == kMilStrat) {
-    const T v2 = milstein_v<T>(w, dt, (T)0.5, METHOD == kMilIto);
+    const N v2 = milstein_v<T>(w, dt, (T)0.5, METHOD == kMilIto);
     const S g = m.template g<0>(y);
     const S gdg = m.template gdg<0>(y, g, v2);
     return milstein_update<T, S>(y, m.template f<0>(y), g, gdg, w, dt);
@@ -677,27 +677,98 @@ enum : uint32_t {
   kOpSquare, kOpCube, kOpDup
 };
 
-template <typename T>
+// W elements processed together: one decoded instruction serves all of them.
+template <typename T, int W>
+struct Vec {
+  T v[W];
+  Vec() = default;
+  TSDE_D explicit Vec(T s) {
+#pragma unroll
+    for (int q = 0; q < W; ++q) v[q] = s;
+  }
+};
+#define TSDE_VEC_BINARY(OP)                                                                  \
+  template <typename T, int W>                                                               \
+  TSDE_D Vec<T, W> operator OP(const Vec<T, W>& a, const Vec<T, W>& b) {                     \
+    Vec<T, W> r;                                                                             \
+    _Pragma("unroll") for (int q = 0; q < W; ++q) r.v[q] = a.v[q] OP b.v[q];                 \
+    return r;                                                                                \
+  }                                                                                          \
+  template <typename T, int W>                                                               \
+  TSDE_D Vec<T, W> operator OP(const Vec<T, W>& a, T b) {                                    \
+    Vec<T, W> r;                                                                             \
+    _Pragma("unroll") for (int q = 0; q < W; ++q) r.v[q] = a.v[q] OP b;                      \
+    return r;                                                                                \
+  }                                                                                          \
+  template <typename T, int W>                                                               \
+  TSDE_D Vec<T, W> operator OP(T a, const Vec<T, W>& b) {                                    \
+    Vec<T, W> r;                                                                             \
+    _Pragma("unroll") for (int q = 0; q < W; ++q) r.v[q] = a OP b.v[q];                      \
+    return r;                                                                                \
+  }
+TSDE_VEC_BINARY(+)
+TSDE_VEC_BINARY(-)
+TSDE_VEC_BINARY(*)
+TSDE_VEC_BINARY(/)
+#undef TSDE_VEC_BINARY
+
+template <typename T, int W, typename F>
+TSDE_D Vec<T, W> vmap(const Vec<T, W>& a, F fn) {
+  Vec<T, W> r;
+#pragma unroll
+  for (int q = 0; q < W; ++q) r.v[q] = fn(a.v[q]);
+  return r;
+}
+
+constexpr int kProgWords = 96;     // instruction words of f, g and g' together (they travel in the kernel arguments)
+constexpr int kProgRegs = 8;       // constant rows kept in registers; rows beyond are read through the cache at each use
+
+template <typename T, int W>
 struct ProgModel {
-  const uint32_t* code;            // f program, then g, then g' (wave-uniform)
+  using V = Vec<T, W>;
+  const uint32_t* code;            // f program, then g, then g': kernel arguments -> scalar loads, wave-uniform
   int f_len, g_len, dg_len;
   const T* consts;                 // (n_const, d)
-  int64_t d, col;                  // this element's channel
+  int64_t d, col;                  // channel of this lane's first element
+  V creg[kProgRegs];               // this lane's entries of the first constant rows
 
-  TSDE_D T run(const uint32_t* prog, int len, const T x) const {
-    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+  TSDE_D V constant(uint32_t k) const {
+    switch (k) {                   // (uniform: a scalar branch; a register array indexed by k would go through scratch)
+      case 0: return creg[0];
+      case 1: return creg[1];
+      case 2: return creg[2];
+      case 3: return creg[3];
+      case 4: return creg[4];
+      case 5: return creg[5];
+      case 6: return creg[6];
+      case 7: return creg[7];
+      default: {
+        V r;
+        const Pack<T, W> pk = load<T, W>(consts, (int64_t)k * d + col);
+#pragma unroll
+        for (int q = 0; q < W; ++q) r.v[q] = pk.v[q];
+        return r;
+      }
+    }
+  }
+
+  TSDE_D V run(const uint32_t* prog, int len, const V& x) const {
+    V s0((T)0), s1((T)0), s2((T)0), s3((T)0);
+    uint32_t fetched = prog[0];
     for (int pc = 0; pc < len; ++pc) {
-      const uint32_t ins = __builtin_amdgcn_readfirstlane(prog[pc]);
+      // (the next word is requested before this one executes: the scalar load's latency hides behind the vector work)
+      const uint32_t ins = fetched;
+      fetched = prog[pc + 1 < len ? pc + 1 : pc];
       const uint32_t op = ins & 0xFFu, src = (ins >> 8) & 0xFFu, k = ins >> 16;
       if (op < kOpNeg) {
-        T a = s0, b;
+        V a = s0, b;
         if (src == kSrcStack) {        // pop: the operands are the two top values
           b = s0;
           a = s1;
           s1 = s2;
           s2 = s3;
         } else if (src == kSrcConst) {
-          b = consts[(int64_t)k * d + col];
+          b = constant(k);
         } else {
           b = x;
         }
@@ -717,18 +788,18 @@ struct ProgModel {
         }
       } else {
         switch (op) {
-          case kOpNeg: s0 = -s0; break;
-          case kOpExp: s0 = exp(s0); break;
-          case kOpLog: s0 = log(s0); break;
-          case kOpSin: s0 = sin(s0); break;
-          case kOpCos: s0 = cos(s0); break;
-          case kOpTanh: s0 = tanh(s0); break;
-          case kOpSigmoid: s0 = (T)1 / ((T)1 + exp(-s0)); break;
-          case kOpSoftplus: s0 = s0 > (T)20 ? s0 : log1p(exp(s0)); break;
-          case kOpSqrt: s0 = sqrt(s0); break;
-          case kOpAbs: s0 = fabs(s0); break;
-          case kOpRelu: s0 = s0 > (T)0 ? s0 : (T)0; break;
-          case kOpRecip: s0 = (T)1 / s0; break;
+          case kOpNeg: s0 = vmap(s0, [](T v) { return -v; }); break;
+          case kOpExp: s0 = vmap(s0, [](T v) { return exp(v); }); break;
+          case kOpLog: s0 = vmap(s0, [](T v) { return log(v); }); break;
+          case kOpSin: s0 = vmap(s0, [](T v) { return sin(v); }); break;
+          case kOpCos: s0 = vmap(s0, [](T v) { return cos(v); }); break;
+          case kOpTanh: s0 = vmap(s0, [](T v) { return tanh(v); }); break;
+          case kOpSigmoid: s0 = vmap(s0, [](T v) { return (T)1 / ((T)1 + exp(-v)); }); break;
+          case kOpSoftplus: s0 = vmap(s0, [](T v) { return v > (T)20 ? v : log1p(exp(v)); }); break;
+          case kOpSqrt: s0 = vmap(s0, [](T v) { return sqrt(v); }); break;
+          case kOpAbs: s0 = vmap(s0, [](T v) { return fabs(v); }); break;
+          case kOpRelu: s0 = vmap(s0, [](T v) { return v > (T)0 ? v : (T)0; }); break;
+          case kOpRecip: s0 = vmap(s0, [](T v) { return (T)1 / v; }); break;
           case kOpSquare: s0 = s0 * s0; break;
           case kOpCube: s0 = (s0 * s0) * s0; break;
           default:                     // kOpDup
@@ -742,20 +813,19 @@ struct ProgModel {
     return s0;
   }
   template <int SLOT>
-  TSDE_D T f(const T& x) const { return run(code, f_len, x); }
+  TSDE_D V f(const V& x) const { return run(code, f_len, x); }
   template <int SLOT>
-  TSDE_D T g(const T& x) const { return run(code + f_len, g_len, x); }
+  TSDE_D V g(const V& x) const { return run(code + f_len, g_len, x); }
   template <int SLOT>
-  TSDE_D T gdg(const T& x, const T& gv, T v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x); }
+  TSDE_D V gdg(const V& x, const V& gv, const V& v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x); }
 };
 
 template <typename T>
 struct ProgArgs {
   T* ys;
   const T* y0;
-  const uint32_t* code;
   const T* consts;
-  int32_t f_len, g_len, dg_len;
+  int32_t f_len, g_len, dg_len, n_const;
   int32_t scalar_noise;     // 1: one Brownian channel per ROW (noise type "scalar"): element (row, c) meets increment `row`
   const T* rows;
   const uint32_t* cells;
@@ -765,20 +835,40 @@ struct ProgArgs {
   int32_t n_steps, n_out;
   NoiseKey key;
   const uint64_t* key_dev;
+  uint32_t code[kProgWords];
 };
 
-// The expression kernels' loop with the program model. W = 4 needs d % 4 == 0 (a lane's elements share their row).
+// The expression kernels' loop with the program model; a lane's W elements run through each program together.
+// W = 4 needs d % 4 == 0 (a lane's elements share their row).
 template <typename T, int METHOD, int W>
 __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<T> p) {
   constexpr bool kNeedU = METHOD == kSrk;
+  using V = Vec<T, W>;
   const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t i = lane * W;
   if (i >= p.n) return;
   const int64_t col = i % p.d;
   const Pack<T, W> y_init = load<T, W>(p.y0, i);
-  T y[W];
+  V y;
 #pragma unroll
-  for (int q = 0; q < W; ++q) y[q] = y_init.v[q];
+  for (int q = 0; q < W; ++q) y.v[q] = y_init.v[q];
+  ProgModel<T, W> m;
+  m.code = p.code;
+  m.f_len = p.f_len;
+  m.g_len = p.g_len;
+  m.dg_len = p.dg_len;
+  m.consts = p.consts;
+  m.d = p.d;
+  m.col = col;
+#pragma unroll
+  for (int k = 0; k < kProgRegs; ++k) {
+    m.creg[k] = V((T)0);
+    if (k < p.n_const) {
+      const Pack<T, W> pk = load<T, W>(p.consts, (int64_t)k * p.d + col);
+#pragma unroll
+      for (int q = 0; q < W; ++q) m.creg[k].v[q] = pk.v[q];
+    }
+  }
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
     const uint64_t ent = *p.key_dev;
@@ -793,16 +883,11 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<
     const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
     const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
     const uint32_t cell = p.cells[k];
-    Pack<T, W> w, u;
+    V w((T)0), u((T)0);
     if (scalar_noise) {
       const T w_row = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
-      T u_row = (T)0;
-      if constexpr (kNeedU) u_row = th * ((T)0.5 * w_row + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
-#pragma unroll
-      for (int q = 0; q < W; ++q) {
-        w.v[q] = w_row;
-        u.v[q] = u_row;
-      }
+      w = V(w_row);
+      if constexpr (kNeedU) u = V(th * ((T)0.5 * w_row + normal1<T>(key, elem, cell, 0, kStreamH) * sh));
     } else if constexpr (W == 4) {
       T z[4];
       normal4<T>(key, elem >> 2, cell, 0, kStreamW, z);
@@ -817,26 +902,208 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<
       w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
       if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
     }
-    T y1[W];
-#pragma unroll
-    for (int q = 0; q < W; ++q) {
-      const ProgModel<T> m{p.code, p.f_len, p.g_len, p.dg_len, p.consts, p.d, col + q};
-      y1[q] = scheme_step<T, METHOD, T>(y[q], m, w.v[q], kNeedU ? u.v[q] : (T)0, dt, half_dt, rdt, sqrt_dt);
-    }
+    const V y1 = scheme_step<T, METHOD, V, ProgModel<T, W>, V>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
     if (__builtin_expect(k + 1 == next_out, 0)) {
       while (j < p.n_out && p.out_step[j] == k + 1) {
         const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
         const bool exact = (w0 == (T)0 && w1 == (T)1);
         Pack<T, W> ov;
 #pragma unroll
-        for (int q = 0; q < W; ++q) ov.v[q] = exact ? y1[q] : (w0 * y[q] + w1 * y1[q]);
+        for (int q = 0; q < W; ++q) ov.v[q] = exact ? y1.v[q] : (w0 * y.v[q] + w1 * y1.v[q]);
         store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
         ++j;
       }
       next_out = next_output_step(p.out_step, j, p.n_out);
     }
+    y = y1;
+  }
+}
+
+// ---- ... and their path-wise sensitivities ------------------------------------------------------------------------------
+// Training THROUGH the solver (ordinary autograd through torchsde.sdeint, _core/sdeint.py:27-112) for an SDE stated as
+// expression programs: the same programs run on forward-mode dual numbers. Tangent slot 0 is d/dy0; slots 1..4 belong to up
+// to four constant rows (`param_slot[k]` = slot of row k, or -1): the per-channel parameters of the user's module. Every
+// recursion is elementwise, so each tangent is one more scalar recursion in registers -- what `trajectory_kernel<.., SENS>`
+// does for the affine form, for arbitrary elementwise code.
+template <typename T>
+TSDE_D Dual<T> operator-(const Dual<T>& x, const Dual<T>& y) {
+  Dual<T> r;
+  r.v = x.v - y.v;
 #pragma unroll
-    for (int q = 0; q < W; ++q) y[q] = y1[q];
+  for (int i = 0; i < kSens; ++i) r.d[i] = x.d[i] - y.d[i];
+  return r;
+}
+template <typename T>
+TSDE_D Dual<T> operator*(const Dual<T>& x, const Dual<T>& y) {
+  Dual<T> r;
+  r.v = x.v * y.v;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = x.d[i] * y.v + x.v * y.d[i];
+  return r;
+}
+template <typename T>
+TSDE_D Dual<T> operator/(const Dual<T>& x, const Dual<T>& y) {
+  Dual<T> r;
+  const T inv = (T)1 / y.v;
+  r.v = x.v / y.v;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = (x.d[i] - r.v * y.d[i]) * inv;
+  return r;
+}
+// phi(x) with derivative `slope` at x.v
+template <typename T>
+TSDE_D Dual<T> chain(const Dual<T>& x, T value, T slope) {
+  Dual<T> r;
+  r.v = value;
+#pragma unroll
+  for (int i = 0; i < kSens; ++i) r.d[i] = slope * x.d[i];
+  return r;
+}
+
+template <typename T>
+struct ProgSensModel {
+  using S = Dual<T>;
+  const uint32_t* code;
+  int f_len, g_len, dg_len;
+  const T* consts;
+  const int8_t* param_slot;        // per constant row: tangent slot 1..4, or -1 (kernel arguments, uniform)
+  int64_t d, col;
+
+  TSDE_D S constant(uint32_t k) const {
+    S c(consts[(int64_t)k * d + col]);
+    const int slot = param_slot[k];
+    if (slot > 0) c.d[slot] = (T)1;
+    return c;
+  }
+
+  TSDE_D S run(const uint32_t* prog, int len, const S& x) const {
+    S s0((T)0), s1((T)0), s2((T)0), s3((T)0);
+    uint32_t fetched = prog[0];
+    for (int pc = 0; pc < len; ++pc) {
+      const uint32_t ins = fetched;
+      fetched = prog[pc + 1 < len ? pc + 1 : pc];
+      const uint32_t op = ins & 0xFFu, src = (ins >> 8) & 0xFFu, k = ins >> 16;
+      if (op < kOpNeg) {
+        S a = s0, b;
+        if (src == kSrcStack) {
+          b = s0;
+          a = s1;
+          s1 = s2;
+          s2 = s3;
+        } else if (src == kSrcConst) {
+          b = constant(k);
+        } else {
+          b = x;
+        }
+        switch (op) {
+          case kOpLoad:
+            s3 = s2;
+            s2 = s1;
+            s1 = s0;
+            s0 = b;
+            break;
+          case kOpAdd: s0 = a + b; break;
+          case kOpSub: s0 = a - b; break;
+          case kOpRsub: s0 = b - a; break;
+          case kOpMul: s0 = a * b; break;
+          case kOpDiv: s0 = a / b; break;
+          default: s0 = b / a; break;
+        }
+      } else {
+        const T v = s0.v;
+        switch (op) {
+          case kOpNeg: s0 = chain(s0, -v, (T)-1); break;
+          case kOpExp: { const T e = exp(v); s0 = chain(s0, e, e); break; }
+          case kOpLog: s0 = chain(s0, log(v), (T)1 / v); break;
+          case kOpSin: s0 = chain(s0, sin(v), cos(v)); break;
+          case kOpCos: s0 = chain(s0, cos(v), -sin(v)); break;
+          case kOpTanh: { const T t = tanh(v); s0 = chain(s0, t, (T)1 - t * t); break; }
+          case kOpSigmoid: { const T g = (T)1 / ((T)1 + exp(-v)); s0 = chain(s0, g, g * ((T)1 - g)); break; }
+          case kOpSoftplus:
+            s0 = chain(s0, v > (T)20 ? v : log1p(exp(v)), v > (T)20 ? (T)1 : (T)1 / ((T)1 + exp(-v)));
+            break;
+          case kOpSqrt: { const T r = sqrt(v); s0 = chain(s0, r, (T)0.5 / r); break; }
+          case kOpAbs: s0 = chain(s0, fabs(v), v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : (T)0)); break;
+          case kOpRelu: s0 = chain(s0, v > (T)0 ? v : (T)0, v > (T)0 ? (T)1 : (T)0); break;
+          case kOpRecip: { const T r = (T)1 / v; s0 = chain(s0, r, -(r * r)); break; }
+          case kOpSquare: s0 = chain(s0, v * v, (T)2 * v); break;
+          case kOpCube: s0 = chain(s0, (v * v) * v, (T)3 * (v * v)); break;
+          default:
+            s3 = s2;
+            s2 = s1;
+            s1 = s0;
+            break;
+        }
+      }
+    }
+    return s0;
+  }
+  template <int SLOT>
+  TSDE_D S f(const S& x) const { return run(code, f_len, x); }
+  template <int SLOT>
+  TSDE_D S g(const S& x) const { return run(code + f_len, g_len, x); }
+  template <int SLOT>
+  TSDE_D S gdg(const S& x, const S& gv, T v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x); }
+};
+
+constexpr int kProgParamRows = 64;
+
+template <typename T>
+struct ProgSensArgs {
+  ProgArgs<T> base;
+  T* sens;                          // (n_out, kSens, n)
+  int8_t param_slot[kProgParamRows];
+};
+
+// One element per lane (the duals are six values wide); values AND sensitivities of every requested output.
+template <typename T, int METHOD>
+__global__ void __launch_bounds__(kBlock) trajectory_prog_sens_kernel(const ProgSensArgs<T> q) {
+  constexpr bool kNeedU = METHOD == kSrk;
+  const ProgArgs<T>& p = q.base;
+  using S = Dual<T>;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= p.n) return;
+  ProgSensModel<T> m;
+  m.code = p.code;
+  m.f_len = p.f_len;
+  m.g_len = p.g_len;
+  m.dg_len = p.dg_len;
+  m.consts = p.consts;
+  m.param_slot = q.param_slot;
+  m.d = p.d;
+  m.col = i % p.d;
+  S y(p.y0[i]);
+  y.d[0] = (T)1;
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+  const uint64_t elem = key.elem0 + (uint64_t)(p.scalar_noise ? i / p.d : i);
+  int j = 0;
+  int next_out = next_output_step(p.out_step, 0, p.n_out);
+  for (int k = 0; k < p.n_steps; ++k) {
+    const T* row = p.rows + (int64_t)k * 8;
+    const T dt = row[0], half_dt = row[1], rdt = row[2], sqrt_dt = row[3], sw = row[4], sh = row[5], th = row[6];
+    const uint32_t cell = p.cells[k];
+    const T w = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
+    T u = (T)0;
+    if constexpr (kNeedU) u = th * ((T)0.5 * w + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+    const S y1 = scheme_step<T, METHOD, S>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
+    if (__builtin_expect(k + 1 == next_out, 0)) {
+      while (j < p.n_out && p.out_step[j] == k + 1) {
+        const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        const bool exact = (w0 == (T)0 && w1 == (T)1);
+        const S o = exact ? y1 : (w0 * y + w1 * y1);
+        p.ys[(int64_t)j * p.n + i] = o.v;
+#pragma unroll
+        for (int s = 0; s < kSens; ++s) q.sens[((int64_t)j * kSens + s) * p.n + i] = o.d[s];
+        ++j;
+      }
+      next_out = next_output_step(p.out_step, j, p.n_out);
+    }
+    y = y1;
   }
 }
 
@@ -854,17 +1121,20 @@ static hipError_t launch_prog_m(const ProgArgs<T>& p, bool vec, hipStream_t s) {
 }
 
 template <typename T>
-hipError_t launch_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, int64_t d, const uint32_t* code, int f_len,
-                                       int g_len, int dg_len, const void* consts, int scalar_noise, int method,
-                                       const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
+hipError_t launch_trajectory_prog_diag(void* ys, void* sens, const int8_t* param_slot, const void* y0, int64_t rows, int64_t d,
+                                       const uint32_t* code, int f_len, int g_len, int dg_len, const void* consts, int n_const,
+                                       int scalar_noise, int method, const tsde_traj_t* tr, NoiseKey key,
+                                       const uint64_t* key_dev, hipStream_t s) {
   ProgArgs<T> p;
   p.ys = (T*)ys;
   p.y0 = (const T*)y0;
-  p.code = code;
+  if (f_len + g_len + dg_len > kProgWords) return hipErrorInvalidValue;
+  for (int w = 0; w < kProgWords; ++w) p.code[w] = w < f_len + g_len + dg_len ? code[w] : 0u;
   p.consts = (const T*)consts;
   p.f_len = f_len;
   p.g_len = g_len;
   p.dg_len = dg_len;
+  p.n_const = n_const;
   p.scalar_noise = scalar_noise;
   p.rows = (const T*)tr->step_rows;
   p.cells = tr->cells;
@@ -877,6 +1147,22 @@ hipError_t launch_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, i
   p.key = key;
   p.key_dev = key_dev;
   if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
+  if (sens != nullptr) {
+    ProgSensArgs<T> q;
+    q.base = p;
+    q.sens = (T*)sens;
+    for (int k = 0; k < kProgParamRows; ++k) q.param_slot[k] = (param_slot && k < n_const) ? param_slot[k] : (int8_t)-1;
+    const dim3 grid((unsigned)((p.n + kBlock - 1) / kBlock));
+    switch (method) {
+      case kEuler: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kEuler>), grid, dim3(kBlock), 0, s, q); break;
+      case kMilIto: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kMilIto>), grid, dim3(kBlock), 0, s, q); break;
+      case kMilStrat: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kMilStrat>), grid, dim3(kBlock), 0, s, q); break;
+      case kMidpoint: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kMidpoint>), grid, dim3(kBlock), 0, s, q); break;
+      case kSrk: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kSrk>), grid, dim3(kBlock), 0, s, q); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   // (scalar noise addresses the field by row: no alignment condition on elem0)
   const bool can_vec = (d % 4 == 0) && (scalar_noise || key.elem0 % 4 == 0) && aligned16(ys) && aligned16(y0) &&
                        ((p.n * sizeof(T)) % 16 == 0);
@@ -891,12 +1177,12 @@ hipError_t launch_trajectory_prog_diag(void* ys, const void* y0, int64_t rows, i
   }
 }
 
-template hipError_t launch_trajectory_prog_diag<float>(void*, const void*, int64_t, int64_t, const uint32_t*, int, int, int,
-                                                       const void*, int, int, const tsde_traj_t*, NoiseKey,
-                                                       const uint64_t*, hipStream_t);
-template hipError_t launch_trajectory_prog_diag<double>(void*, const void*, int64_t, int64_t, const uint32_t*, int, int, int,
-                                                        const void*, int, int, const tsde_traj_t*, NoiseKey,
-                                                        const uint64_t*, hipStream_t);
+template hipError_t launch_trajectory_prog_diag<float>(void*, void*, const int8_t*, const void*, int64_t, int64_t,
+                                                       const uint32_t*, int, int, int, const void*, int, int, int,
+                                                       const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
+template hipError_t launch_trajectory_prog_diag<double>(void*, void*, const int8_t*, const void*, int64_t, int64_t,
+                                                        const uint32_t*, int, int, int, const void*, int, int, int,
+                                                        const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
 
 template hipError_t launch_trajectory_expr_diag<float>(void*, const void*, int64_t, int64_t, const void* const[8],
                                                        int64_t, int, int, int, const tsde_traj_t*, NoiseKey,

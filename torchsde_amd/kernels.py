@@ -688,21 +688,6 @@ def trajectory_expr_diag(ys, y0, f_kind, g_kind, coefs, method, schedule, bm):
     return ys
 
 
-_PROGRAMS = collections.OrderedDict()       # (code words, device) -> device tensor of the instruction stream
-
-
-def _program_tensor(words, device):
-    key = (words, str(device))
-    hit = _PROGRAMS.get(key)
-    if hit is None:
-        hit = _PROGRAMS[key] = torch.from_numpy(np.asarray(words, dtype=np.uint32).view(np.int32).copy()).to(device)
-        while len(_PROGRAMS) > 64:
-            _PROGRAMS.popitem(last=False)
-    else:
-        _PROGRAMS.move_to_end(key)
-    return hit
-
-
 def trajectory_prog_diag(ys, y0, f_code, g_code, dg_code, consts, scalar_noise, method, schedule, bm):
     """All steps of a diagonal- or scalar-noise SDE whose drift and diffusion are expression programs (tuples of
     instruction words, recognise.RecognisedProgram) in one launch (``tsde_trajectory_prog_diag``)."""
@@ -713,15 +698,80 @@ def trajectory_prog_diag(ys, y0, f_code, g_code, dg_code, consts, scalar_noise, 
     if not (ys.is_contiguous() and y0.is_contiguous() and consts.is_contiguous()) or ys.shape != (schedule.n_out, rows, d) \
             or consts.dim() != 2 or consts.shape[1] != d:
         raise ValueError("ys must be a contiguous (n_out, rows, d) tensor, y0 contiguous, consts (n_const, d)")
-    code = _program_tensor(tuple(f_code) + tuple(g_code) + tuple(dg_code), y0.device)
+    words = tuple(f_code) + tuple(g_code) + tuple(dg_code)
+    code = (ctypes.c_uint32 * len(words))(*words)            # a host array: the words travel in the kernel arguments
     lib, dt_code, stream = _launch_env(y0)
     entropy_dev = bm._entropy_dev
-    rc = lib.tsde_trajectory_prog_diag(ys.data_ptr(), y0.data_ptr(), rows, d, code.data_ptr(), len(f_code), len(g_code),
+    rc = lib.tsde_trajectory_prog_diag(ys.data_ptr(), y0.data_ptr(), rows, d, code, len(f_code), len(g_code),
                                        len(dg_code), consts.data_ptr(), consts.shape[0], int(bool(scalar_noise)), int(method),
                                        schedule.struct(), bm._key, bm._elem0,
                                        None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
     _native.check(rc, "tsde_trajectory_prog_diag")
     return ys
+
+
+class _ProgTrajectoryFn(torch.autograd.Function):
+    """Differentiable whole-trajectory solve of an SDE stated as expression programs: the forward launch also produces the
+    path-wise sensitivities of every output element with respect to y0 and to up to four constant rows (the per-channel
+    parameters of the user's module), and the backward pass is a handful of torch reductions of cotangent x sensitivity --
+    the gradient back-propagation through the stepwise solver gives, without storing or revisiting a step."""
+
+    @staticmethod
+    def forward(ctx, programs, scalar_noise, method, schedule, bm, const_values, param_rows, y0, *params):
+        rows, d = y0.shape
+        f_code, g_code, dg_code = programs
+        y0c = _native.contiguous(y0.detach())
+        table = []
+        for k, c in enumerate(const_values):
+            c = params[param_rows.index(k)] if k in param_rows else c
+            if torch.is_tensor(c):
+                table.append(c.detach().to(device=y0.device, dtype=y0.dtype).reshape(-1).expand(d))
+            else:
+                table.append(torch.full((d,), float(c), dtype=y0.dtype, device=y0.device))
+        consts = torch.stack(table).contiguous() if table else torch.zeros(1, d, dtype=y0.dtype, device=y0.device)
+        slots = (ctypes.c_int8 * max(len(const_values), 1))(*[(param_rows.index(k) + 1 if k in param_rows else -1)
+                                                              for k in range(len(const_values))])
+        ys = torch.empty((schedule.n_out + 1, rows, d), dtype=y0.dtype, device=y0.device)
+        sens = torch.empty((schedule.n_out, _native.TRAJ_SENS, rows, d), dtype=y0.dtype, device=y0.device)
+        ys[0].copy_(y0c)
+        words = tuple(f_code) + tuple(g_code) + tuple(dg_code)
+        code = (ctypes.c_uint32 * len(words))(*words)
+        lib, dt_code, stream = _launch_env(y0c)
+        entropy_dev = bm._entropy_dev
+        rc = lib.tsde_trajectory_prog_diag_sens(
+            ys[1:].data_ptr(), sens.data_ptr(), y0c.data_ptr(), rows, d, code, len(f_code), len(g_code), len(dg_code),
+            consts.data_ptr(), len(const_values), slots, int(bool(scalar_noise)), int(method), schedule.struct(), bm._key,
+            bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+        _native.check(rc, "tsde_trajectory_prog_diag_sens")
+        ctx.save_for_backward(sens)
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return ys
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gys):
+        sens, = ctx.saved_tensors
+        weighted = (gys[1:].unsqueeze(1) * sens).sum(dim=0)           # (TRAJ_SENS, rows, d)
+        grad_y0 = gys[0] + weighted[0] if ctx.needs_input_grad[7] else None
+        grads = []
+        for k, shape in enumerate(ctx.param_shapes):
+            if not ctx.needs_input_grad[8 + k]:
+                grads.append(None)
+                continue
+            per_channel = weighted[1 + k].sum(dim=0)                  # (d,): the batch shares the constants
+            numel = 1
+            for n in shape:
+                numel *= n
+            grads.append(per_channel.reshape(shape) if numel == per_channel.numel() else per_channel.sum().reshape(shape))
+        return (None,) * 7 + (grad_y0,) + tuple(grads)
+
+
+def trajectory_prog_diag_differentiable(y0, programs, const_values, param_rows, scalar_noise, method, schedule, bm):
+    """ys (n_out + 1, rows, d) with a grad_fn towards y0 and the constants `const_values[k]`, k in `param_rows` (at most
+    four tensors of one element or d elements each), through ``tsde_trajectory_prog_diag_sens``."""
+    params = [const_values[k] for k in param_rows]
+    return _ProgTrajectoryFn.apply(tuple(programs), bool(scalar_noise), int(method), schedule, bm, tuple(const_values),
+                                   tuple(param_rows), y0, *params)
 
 
 def trajectory_mlp_diag(ys, y0, w1, b1, w2, b2, diff_rate, diff_shift, activation, diffusion, method, schedule, bm):

@@ -922,8 +922,10 @@ class RecognisedProgram:
             prog = _Program(consts)
             prog.compile(tree)
             self.programs.append(tuple(prog.words))
-        if sum(len(w) for w in self.programs if w) > 256:
-            raise NotElementwise("drift and diffusion of more than 256 operations")
+        if sum(len(w) for w in self.programs[:2]) > 96:
+            raise NotElementwise("drift and diffusion of more than 96 operations")
+        if self.programs[2] is not None and sum(len(w) for w in self.programs) > 96:
+            self.programs[2] = None                      # (the derivative does not fit: every scheme but Milstein)
         self.consts = consts
 
     def structure(self):
@@ -946,6 +948,18 @@ class RecognisedProgram:
                 rows.append(_constant_vector(float(c), self.d, self.dtype, self.device))
         return torch.stack(rows).contiguous()
 
+    def trainable_rows(self, users_tensors=None):
+        """Rows of the constant table that need a gradient: tensors with requires_grad that the user's code handed to an
+        operator as they stand (parameters, or values autograd watched them derive) with one element or d elements. None
+        when such a constant has another shape or there are more than four of them (the kernel carries four tangents)."""
+        rows = []
+        for k, c in enumerate(self.consts):
+            if torch.is_tensor(c) and c.requires_grad:
+                if c.numel() not in (1, self.d) or c.dtype != self.dtype or c.device != self.device:
+                    return None
+                rows.append(k)
+        return rows if len(rows) <= _native.TRAJ_SENS - 1 else None
+
     def spec(self, milstein=False):
         f, g, dg = self.programs
         if milstein and dg is None:
@@ -953,7 +967,7 @@ class RecognisedProgram:
         return ("program_diagonal", f, g, dg if (milstein and dg) else (), self.const_table(), self.noise_type == "scalar")
 
 
-def recognise_program(sde, t, y0, noise_type, rows=None):
+def recognise_program(sde, t, y0, noise_type, rows=None, differentiable=False):
     """`recognise` for code the single-function forms cannot hold: the expression trees of `sde.f_and_g` on the probe ->
     `RecognisedProgram`, or NotElementwise (anything that is not elementwise arithmetic of the state and constants; any
     use of t)."""
@@ -965,7 +979,9 @@ def recognise_program(sde, t, y0, noise_type, rows=None):
     t_probe = t.detach().clone()
     interp = _TreeInterpreter(probe, t_probe, rows, d)
     try:
-        with torch.no_grad(), interp:
+        # `differentiable`: autograd watches the user's own constant arithmetic (`-self.p ** 2`), so that a constant which is
+        # such a tensor carries its graph back to the parameters (cf. `recognise`)
+        with (torch.enable_grad() if differentiable else torch.no_grad()), interp:
             f, g = sde.f_and_g(t_probe, probe)
     except NotElementwise:
         raise

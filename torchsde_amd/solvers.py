@@ -414,7 +414,7 @@ class BaseSDESolver:
                 or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks or programs)):
             return None
         if self._tracks_grad(y0):
-            return self._integrate_recognised_with_grad(y0, ts) if elementwise else None
+            return self._integrate_recognised_with_grad(y0, ts) if (elementwise or programs) else None
         bm = self._native_bm()
         if (bm is None or y0.dim() != 2 or len(bm.shape) != 2 or bm.shape[0] != y0.shape[0] or not y0.is_cuda
                 or y0.shape[0] < 8
@@ -580,10 +580,12 @@ class BaseSDESolver:
         that is returned (with its graph). None: the stepwise path."""
         from . import graph, recognise
         sde, bm = self.sde, self._native_bm()
-        if (bm is None or y0.dim() != 2 or tuple(bm.shape) != tuple(y0.shape) or not y0.is_cuda or y0.shape[0] < 8
+        scalar = sde.noise_type == NOISE_TYPES.scalar
+        if (bm is None or y0.dim() != 2 or not y0.is_cuda or y0.shape[0] < 8
+                or tuple(bm.shape) != ((y0.shape[0], 1) if scalar else tuple(y0.shape))
                 or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
                 or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
-                or (self._trajectory_code() == _native.TRAJ_SRK and not bm._have_H)):
+                or (self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         chain, base = graph._wrapper_chain(sde)
         if not self._may_be_interpreted(base):
@@ -596,13 +598,16 @@ class BaseSDESolver:
             state = graph.python_state(base)
             if state is None or (state, chain, type(self).__name__) in book["refused"]:
                 return None
-        try:
-            found = recognise.recognise(sde, ts[0], y0, differentiable=True)
-        except recognise.NotElementwise:
-            return None         # (the forward route records refusals; a training loop reaches it under no_grad or not at all)
-        leaves = found.affine_leaves()
+        leaves = None
+        if not scalar and self._trajectory_code() is not None:
+            try:
+                found = recognise.recognise(sde, ts[0], y0, differentiable=True)
+                leaves = found.affine_leaves()
+            except recognise.NotElementwise:
+                pass    # (the forward route records refusals; a training loop reaches it under no_grad or not at all)
         if leaves is None:
-            return None
+            # anything else that is elementwise: expression programs on dual numbers (tsde_trajectory_prog_diag_sens)
+            return self._integrate_program_with_grad(y0, ts, book, chain)
         key = self._recognised_key(found, chain, y0) + ("autograd",)
         verdict = book["trusted"].get(key)
         if verdict is True:
@@ -630,6 +635,70 @@ class BaseSDESolver:
         if len(book["trusted"]) >= 32:
             book["trusted"].clear()
         book["trusted"][key] = True if bool(close.all()) else "the sensitivity kernel's values differ from the stepwise solve"
+        return stepwise
+
+    def _integrate_program_with_grad(self, y0, ts, book, chain):
+        """`_integrate_recognised_with_grad` for code the affine form does not hold: drift and diffusion as expression
+        programs, gradients to y0 and to up to four per-channel constants of the user's module (the tensors their code hands
+        to its operators: parameters, or what autograd saw it derive from them) through the sensitivity kernel."""
+        from . import recognise
+        sde = self.sde
+        code = self._program_code()
+        if code is None or sde.noise_type not in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar):
+            return None
+        milstein = code in (_native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT)
+        try:
+            found = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, differentiable=True)
+            spec = found.spec(milstein)
+        except recognise.NotElementwise:
+            return None
+        rows = found.trainable_rows(None)
+        if rows is None:
+            return None
+        # every trainable parameter of the module must be reached through those constants, or its gradient would be lost
+        reached = set()
+        for k in rows:
+            stack, seen = [found.consts[k].grad_fn], set()
+            if found.consts[k].is_leaf:
+                reached.add(id(found.consts[k]))
+            while stack:
+                fn = stack.pop()
+                if fn is None or id(fn) in seen:
+                    continue
+                seen.add(id(fn))
+                if hasattr(fn, "variable"):
+                    reached.add(id(fn.variable))
+                stack.extend(nxt for nxt, _ in fn.next_functions)
+        if any(p.requires_grad and id(p) not in reached for p in self._params()):
+            return None
+        key = self._recognised_key(found, chain, y0) + ("autograd",)
+        verdict = book["trusted"].get(key)
+        launch = ("program_differentiable", spec[1], spec[2], spec[3], tuple(found.consts), tuple(rows), spec[5])
+        if verdict is True:
+            return self._integrate_trajectory(launch, y0, ts)
+        if verdict is not None:
+            return None
+        try:
+            again = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, rows=5, differentiable=True)
+            again_spec = again.spec(milstein)
+        except recognise.NotElementwise:
+            return None
+        if (again.structure() != found.structure()
+                or not torch.equal(again_spec[4], spec[4]) or again.trainable_rows(None) != rows):
+            book["trusted"][key] = "two interpretations of the same code (probes of 2 and 5 rows) gave different programs"
+            return None
+        with torch.no_grad():
+            fast = self._integrate_trajectory(spec, y0.detach(), ts)
+        if fast is None:
+            return None
+        self._extra = ()
+        stepwise = self._run(self._plan(y0, ts), y0)           # recorded by autograd: this is the result
+        rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
+        ref = stepwise.detach()
+        close = ((fast - ref).abs() <= atol + rtol * ref.abs()) | (fast.isnan() & ref.isnan()) | (fast == ref)
+        if len(book["trusted"]) >= 32:
+            book["trusted"].clear()
+        book["trusted"][key] = True if bool(close.all()) else "the program kernel's values differ from the stepwise solve"
         return stepwise
 
     _STAGE_TIMES = {}
@@ -748,6 +817,10 @@ class BaseSDESolver:
             return K.trajectory_mlp_diag_differentiable(y0, coefficients[3:], coefficients[1], coefficients[2],
                                                         self._trajectory_code(), schedule_all, out_step, bm)
         schedule = K.TrajectorySchedule.cached(rows, cells, out_step, out_w, y0.device, y0.dtype)
+        if coefficients[0] == "program_differentiable":
+            _, f_code, g_code, dg_code, const_values, rows_with_grad, scalar_noise = coefficients
+            return K.trajectory_prog_diag_differentiable(y0, (f_code, g_code, dg_code), const_values, rows_with_grad,
+                                                         scalar_noise, self._program_code(), schedule, bm)
         if coefficients[0] == "program_diagonal":
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)

@@ -71,6 +71,13 @@ WORKLOADS = {
         problem="scalar_ito", method="euler", levy="none", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
         kernel="tsde_trajectory_prog_diag<float, euler, scalar noise> (user module recognised as expression programs)"),
+    # ... and TRAINING through sdeint on the same module (autograd on, loss.backward()): the programs on dual numbers
+    # (tsde_trajectory_prog_diag_sens), gradients to p through the user's own `-p ** 2`, `p * cos(y) ** 2`. (Stepwise, autograd
+    # would have to keep ~12 (B, d) tensors for each of the 1000 steps: ~200 GB at this size.)
+    "c2_euler_exscalar_training_default_route_b65536_d64_s1000": dict(
+        problem="scalar_ito", method="euler", levy="none", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True, train=True,
+        kernel="tsde_trajectory_prog_diag_sens<float, euler, scalar noise> (user module recognised; sdeint + loss.backward())"),
     "c2_srk_exscalar_b65536_d64_s1000": dict(
         problem="scalar_ito", method="srk", levy="space-time", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
