@@ -419,9 +419,8 @@ class Job:
             # `hbm_equivalent` keeps the contract's byte-priced number (above the HBM peak by construction).
             per_launch = c["bytes_per_traj_step"] * B * nsteps
             moved = 2 * B * d * 4
-            hbm = {"is": "SURVEY 8d bytes per trajectory-step x trajectory-steps per launch / launch time: what a "
-                         "one-kernel-per-step design would have to stream to keep up; NOT a fraction of anything this "
-                         "kernel is bound by",
+            hbm = {"is": "SURVEY 8d bytes per trajectory-step x trajectory-steps / time: what a one-kernel-per-step design "
+                         "would stream; not a bound of this kernel",
                    "achieved_GBps": per_launch / raw_s / 1e9, "over_hbm_peak": per_launch / raw_s / 1e9 / HBM_PEAK_GBPS,
                    "bytes_per_traj_step": c["bytes_per_traj_step"], "bytes_per_launch": per_launch,
                    "solve_achieved_GBps": c["bytes_per_traj_step"] * value / self.world / 1e9,
@@ -442,9 +441,8 @@ class Job:
             issue_cycles = model["issue_cycles_per_wave_step"] * wave_steps
             achieved = issue_cycles / raw_s / 1e12
             roof.update(achieved=achieved, peak=VALU_ISSUE_PEAK, unit="T SIMD issue-cycles/s", frac=achieved / VALU_ISSUE_PEAK,
-                        frac_is="VALU issue cycles of the step loop x wave-steps per launch / (1024 SIMDs x 2.4 GHz x launch "
-                                "time): the share of the chip's vector-issue capacity the launch used for the loop's own "
-                                "instructions at their measured issue cost",
+                        frac_is="measured issue cycles of the step loop's VALU instructions x wave-steps per launch / "
+                                "(1024 SIMDs x 2.4 GHz x launch time)",
                         wave_steps_per_launch=wave_steps,
                         issue_cycles_per_wave_step=model["issue_cycles_per_wave_step"],
                         valu_instructions_per_wave_step=model["valu_instructions_per_wave_step"],
@@ -561,8 +559,11 @@ def _attach_headline_pmc(roofline, workload):
         roofline["pmc"] = (f"profiles/headline_pmc_latest.json is for {rec.get('workload')} @ csrc {rec.get('csrc_sha')}; this "
                            f"run is {workload} @ {digest}: stale, not reported (re-run tools/profile_trajectory.sh)")
         return
-    roofline["pmc"] = {k: rec[k] for k in ("counters", "valu_instructions_per_wave_step", "valu_busy", "effective_clock_ghz",
-                                          "kernel_avg_us", "formulae", "source") if k in rec}
+    # (the counters themselves and the formulae are in the file; the line carries what follows from them)
+    roofline["pmc"] = {k: (round(rec[k], 4) if isinstance(rec[k], float) else rec[k])
+                       for k in ("valu_instructions_per_wave_step", "valu_busy", "effective_clock_ghz", "kernel_avg_us",
+                                 "cycles_per_wave_step_per_simd") if k in rec}
+    roofline["pmc"]["source"] = f"profiles/headline_pmc_latest.json @ csrc {digest} (rocprofv3 --pmc, tools/profile_trajectory.sh)"
 
 
 def _graph_replay_us(launches, dev, replays=3):

@@ -409,7 +409,8 @@ int tsde_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, 
  *         opcodes with a source: 0 LOAD (push), 1 ADD, 2 SUB, 3 RSUB, 4 MUL, 5 DIV, 6 RDIV; without: 16 NEG, 17 EXP, 18 LOG,
  *         19 SIN, 20 COS, 21 TANH, 22 SIGMOID, 23 SOFTPLUS (threshold 20), 24 SQRT, 25 ABS, 26 RELU, 27 RECIP, 28 SQUARE,
  *         29 CUBE, 30 DUP.  source: 0 the value below the top of the stack (popped), 1 constant row k (this channel's entry),
- *         2 the state y.  A binary operator computes  A op B,  A = top of stack, B = source (RSUB, RDIV: B op A); with
+ *         2 the state y, 3 the time t at which the scheme evaluates the function (its stage time; traj->step_rows[k][7] must
+ *         hold t_k, as for tsde_trajectory_mlp_general).  A binary operator computes  A op B,  A = top of stack, B = source (RSUB, RDIV: B op A); with
  *         source 0: A = the value below the top, B = the top, and the result replaces both. A program leaves its value on top.
  *   consts (n_const <= 64, d) in `dtype`, device: every number or per-channel parameter the programs use, one row each (the
  *         first 8 rows are kept in registers for the whole solve; later rows are read through the cache at each use)

@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ["monte_carlo_closed_form.py"],
     ["sample_neural_sde.py"],
     ["train_neural_sde.py", "--iters", "12"],
+    ["neural_general_sde.py"],
+    ["scalar_noise_training.py"],
 ])
 def test_example_runs(argv):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "examples", argv[0])] + argv[1:], capture_output=True,

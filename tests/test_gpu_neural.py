@@ -178,3 +178,35 @@ def test_c3_full_size_default_route_rows_vs_oracle():
                                                  "C3 Euler-general final state, neural-SDE kernel")
     finally:
         torch.set_num_threads(before)
+
+
+@pytest.mark.parametrize("name,noise,method,d,m", [("netdiag_ito", "diagonal", "euler", 32, 32),
+                                                   ("netscalar_ito", "scalar", "euler", 32, 1),
+                                                   ("general_strat", "general", "midpoint", 16, 8)])
+def test_neural_kernel_rows_vs_oracle(name, noise, method, d, m):
+    """The other modes of the neural-SDE kernel -- diagonal and scalar noise (the reference's NeuralDiagonal, NeuralScalar),
+    and the midpoint scheme on general noise -- against the ORACLE's restatement of the reference's loops (euler.py:29-37,
+    midpoint.py:29-45) on the same Brownian path: 4096 rows, 256 steps, sampled rows, the bound of
+    tests/test_gpu_full_size_oracle.py."""
+    import torchsde_amd
+    from tests.test_gpu_full_size_oracle import _oracle_forward
+    Bf, n, dt = 4096, 256, 2.0 ** -8
+    sde = (problems.make(name, d=d, m=m) if noise == "general" else problems.make(name, d=d, hidden=16)).to(DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def bm(entropy):
+        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bf, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            torchsde_amd.sdeint(sde, y0, ts, bm=bm(5), method=method, dt=dt)
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm(20240601), method=method, dt=dt))
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        rows = helpers.sampled_rows(Bf, 48, seed=11, seams=(16, Bf - 16))
+        ref32, ref64 = _oracle_forward(sde, rows, d, m, 20240601, n, dt, method, 0.1)
+        helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1],
+                                                 f"{name}, {method}, neural-SDE kernel")
+    finally:
+        torch.set_num_threads(before)

@@ -121,14 +121,48 @@ def test_live_parameters_and_refusals():
     assert launches == 1 and not torch.equal(a, b)
     torch.testing.assert_close(b, _solve(sde, 2, "euler", stepwise=True), rtol=2e-5, atol=2e-6)
 
-    class UsesTime(_Mixed):
+    class ReadsTimeOnTheHost(_Mixed):
         def f(self, t, y):
-            return torch.tanh(y) * torch.cos(t) - y ** 3 * torch.sin(y)
-    timed = UsesTime("ito", "sum").to(DEV)
+            return torch.tanh(y) * float(t) - y ** 3 * torch.sin(y)
+    timed = ReadsTimeOnTheHost("ito", "sum").to(DEV)
     for entropy in (1, 2):
         got, launches = _launches(lambda: _solve(timed, entropy, "euler"))
         assert launches == 0
-    assert any("depends on t" in r for r in _book(timed)["refused"].values()), _book(timed)
+    assert any("expression program" in r for r in _book(timed)["refused"].values()), _book(timed)
+
+
+class _TimeInTheArithmetic(nn.Module):
+    """t takes part in arithmetic that is not affine in the state (the reference's ExAdditive drift, tests/problems.py:
+    119-121, plus a nonlinear term; a diffusion that decays with t and depends on the state)."""
+    noise_type = "diagonal"
+
+    def __init__(self, sde_type):
+        super().__init__()
+        self.sde_type = sde_type
+        gen = torch.Generator().manual_seed(9)
+        self.a = nn.Parameter(0.2 + 0.3 * torch.rand(D, generator=gen))
+        self.b = nn.Parameter(0.2 + 0.3 * torch.rand(D, generator=gen))
+
+    def f(self, t, y):
+        return self.b / torch.sqrt(1. + t) - y / (2. + 2. * t) + torch.tanh(y) * torch.cos(3.0 * t)
+
+    def g(self, t, y):
+        return (self.a * self.b / torch.sqrt(1. + t)).expand_as(y) * (1.0 + torch.sigmoid(y))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
+def test_time_as_an_operand_of_the_programs(method, sde_type, levy, dtype):
+    """Every scheme evaluates f and g at its own stage times (t_k; t_k + dt/2; t_k + dt/4, t_k + dt/2, t_k + dt): the programs
+    read the time of the evaluation they are part of, and the solve agrees with the stepwise route, which hands the user's
+    code those times one call at a time (base_solver.py:114-149, srk.py:66-72)."""
+    sde = _TimeInTheArithmetic(sde_type).to(DEV).to(dtype)
+    _solve(sde, 1, method, levy, dtype=dtype)
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast, launches = _launches(lambda: _solve(sde, 2, method, levy, dtype=dtype))
+    assert launches == 1
+    tol = dict(rtol=2e-5, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-11, atol=1e-12)
+    torch.testing.assert_close(fast, _solve(sde, 2, method, levy, stepwise=True, dtype=dtype), **tol)
 
 
 @pytest.mark.parametrize("method,levy", [("euler", "none"), ("milstein", "none"), ("srk", "space-time")])

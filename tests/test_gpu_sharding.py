@@ -125,8 +125,16 @@ def test_bench_multi_rank_logic_on_one_gpu(workload, launcher):
     roof = rec["roofline"]
     assert roof["frac"] > 0 and rec["cpu_baseline"] is None and "also" not in rec
     # the solve-level fraction is the SURVEY 8d definition: bytes per trajectory-step x value / (n_gpus x peak)
-    want = roof["bytes_per_traj_step"] * rec["value"] / 2 / (roof["peak"] * 1e9)
-    assert abs(roof["solve_frac"] - want) <= 1e-9 + 1e-6 * want
+    if roof["bound"] == "valu":
+        # the headline's trajectory kernel: a fraction of the chip's vector-issue capacity (at most 1); the byte-priced
+        # figure of SURVEY 8d lives on under `hbm_equivalent`, per GPU
+        assert 0 < roof["frac"] <= 1.0 and roof["unit"].endswith("issue-cycles/s")
+        hbm = roof["hbm_equivalent"]
+        want = hbm["bytes_per_traj_step"] * rec["value"] / 2 / 8e12
+        assert abs(hbm["solve_over_hbm_peak"] - want) <= 1e-9 + 1e-6 * want
+    else:
+        want = roof["bytes_per_traj_step"] * rec["value"] / 2 / (roof["peak"] * 1e9)
+        assert abs(roof["solve_frac"] - want) <= 1e-9 + 1e-6 * want
 
 
 def _run_bench(cmd, env, root):

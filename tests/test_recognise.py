@@ -419,7 +419,7 @@ def test_networks_the_neural_kernel_does_not_take():
 
 
 # ---- expression programs: any elementwise code --------------------------------------------------------------------------
-def _run_program(words, consts, y):
+def _run_program(words, consts, y, t=None):
     """The stack machine of csrc/trajectory.hip (ProgModel::run) in torch: what the kernel evaluates per element."""
     stack = []
     unary = {16: torch.neg, 17: torch.exp, 18: torch.log, 19: torch.sin, 20: torch.cos, 21: torch.tanh, 22: torch.sigmoid,
@@ -431,7 +431,7 @@ def _run_program(words, consts, y):
             if src == 0:
                 b, a = stack.pop(), stack.pop()
             else:
-                b = consts[k].expand_as(y) if src == 1 else y
+                b = consts[k].expand_as(y) if src == 1 else (y if src == 2 else t.expand_as(y))
                 a = stack.pop() if op != 0 else None
             if op == 0:
                 stack.append(b)
@@ -456,6 +456,9 @@ PROGRAMS = {
     "deep tree": ("diagonal", lambda s, t, y: (torch.sin(y) * s.mu + torch.cos(y)) * (torch.exp(-y * y) + s.b * y),
                   lambda s, t, y: (y * s.sigma + 0.1) * (torch.tanh(y) - 2.0)),
     "softplus and abs": ("diagonal", lambda s, t, y: F.softplus(y) - torch.abs(y) * s.mu, lambda s, t, y: torch.relu(y) + 0.2),
+    # t as one more leaf (the reference's ExAdditive drift, tests/problems.py:119-121, beside a state-dependent diffusion)
+    "time in the arithmetic": ("diagonal", lambda s, t, y: s.b / torch.sqrt(1. + t) - y / (2. + 2. * t) + torch.tanh(y) * torch.cos(t),
+                               lambda s, t, y: (s.sigma / torch.sqrt(1. + t)).expand_as(y) * torch.sigmoid(y)),
 }
 
 
@@ -473,20 +476,20 @@ def test_expression_programs_evaluate_to_the_users_code(name):
     kind, fw, gw, dgw, table, scalar = found.spec(milstein=name != "softplus and abs")
     assert kind == "program_diagonal" and scalar == (noise == "scalar") and table.shape[1] == D
     with torch.no_grad():
-        torch.testing.assert_close(_run_program(fw, table, y), sde.f(t, y), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(_run_program(fw, table, y, t), sde.f(t, y), rtol=1e-5, atol=1e-6)
         want_g = sde.g(t, y)
-        torch.testing.assert_close(_run_program(gw, table, y), want_g.reshape(16, D), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(_run_program(gw, table, y, t), want_g.reshape(16, D), rtol=1e-5, atol=1e-6)
     if dgw:
         yy = y.clone().requires_grad_(True)
         dg, = torch.autograd.grad(sde.g(t, yy).sum(), yy)            # elementwise g: the gradient of the sum is g'
-        torch.testing.assert_close(_run_program(dgw, table, y), dg, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(_run_program(dgw, table, y, t), dg, rtol=1e-4, atol=1e-5)
     again = recognise.recognise_program(ForwardSDE(sde), t, y, noise, rows=5)
     assert again.structure() == found.structure()
 
 
 def test_programs_refuse_what_is_not_elementwise_arithmetic():
     y, t = torch.randn(16, D), torch.tensor(0.3)
-    for f, reason in ((lambda s, t, y: y @ torch.eye(D), "aten::mm"), (lambda s, t, y: y * t, "depends on t"),
+    for f, reason in ((lambda s, t, y: y @ torch.eye(D), "aten::mm"), (lambda s, t, y: y * float(t), "aten::_local_scalar_dense"),
                       (lambda s, t, y: y - y.mean(0), "aten::mean"), (lambda s, t, y: y ** 2.5, "power"),
                       (lambda s, t, y: y + torch.randn(D), "random"), (lambda s, t, y: y * s.b.add_(1.0), "existed before")):
         with pytest.raises(recognise.NotElementwise, match=reason):

@@ -667,10 +667,11 @@ hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, i
 // per-channel constants (n_const, d). One instruction = one torch operator of the user's code, evaluated in the same order
 // and (for + - * /) with the same rounding; functions as in `expr_phi`. The instruction stream is wave-uniform: decoding it
 // is scalar work, the vector unit sees one operation per instruction and element.
-//   source: 0 = the value below the top of the stack (binary operators pop it), 1 = constant row k of this channel, 2 = the state
+//   source: 0 = the value below the top of the stack (binary operators pop it), 1 = constant row k of this channel, 2 = the state,
+//           3 = the time t at which the scheme evaluates the function (its stage time: t_k, t_k + dt/4, t_k + dt/2 or t_k + dt)
 //   a binary operator computes  A op B  with A = top of stack, B = source  (R variants: B op A); source 0: A = the value
 //   below the top, B = the top (R variants swapped), and the result replaces both
-enum : uint32_t { kSrcStack = 0, kSrcConst = 1, kSrcState = 2 };
+enum : uint32_t { kSrcStack = 0, kSrcConst = 1, kSrcState = 2, kSrcTime = 3 };
 enum : uint32_t {
   kOpLoad = 0, kOpAdd, kOpSub, kOpRsub, kOpMul, kOpDiv, kOpRdiv,                       // take a source
   kOpNeg = 16, kOpExp, kOpLog, kOpSin, kOpCos, kOpTanh, kOpSigmoid, kOpSoftplus, kOpSqrt, kOpAbs, kOpRelu, kOpRecip,
@@ -731,6 +732,7 @@ struct ProgModel {
   const T* consts;                 // (n_const, d)
   int64_t d, col;                  // channel of this lane's first element
   V creg[kProgRegs];               // this lane's entries of the first constant rows
+  T tslot[4];                      // the scheme's stage times of the current step (slot order of `stage_slots`)
 
   TSDE_D V constant(uint32_t k) const {
     switch (k) {                   // (uniform: a scalar branch; a register array indexed by k would go through scratch)
@@ -752,7 +754,7 @@ struct ProgModel {
     }
   }
 
-  TSDE_D V run(const uint32_t* prog, int len, const V& x) const {
+  TSDE_D V run(const uint32_t* prog, int len, const V& x, const T time) const {
     V s0((T)0), s1((T)0), s2((T)0), s3((T)0);
     uint32_t fetched = prog[0];
     for (int pc = 0; pc < len; ++pc) {
@@ -769,6 +771,8 @@ struct ProgModel {
           s2 = s3;
         } else if (src == kSrcConst) {
           b = constant(k);
+        } else if (src == kSrcTime) {
+          b = V(time);
         } else {
           b = x;
         }
@@ -813,12 +817,24 @@ struct ProgModel {
     return s0;
   }
   template <int SLOT>
-  TSDE_D V f(const V& x) const { return run(code, f_len, x); }
+  TSDE_D V f(const V& x) const { return run(code, f_len, x, tslot[SLOT]); }
   template <int SLOT>
-  TSDE_D V g(const V& x) const { return run(code + f_len, g_len, x); }
+  TSDE_D V g(const V& x) const { return run(code + f_len, g_len, x, tslot[SLOT]); }
   template <int SLOT>
-  TSDE_D V gdg(const V& x, const V& gv, const V& v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x); }
+  TSDE_D V gdg(const V& x, const V& gv, const V& v2) const {
+    return (gv * v2) * run(code + f_len + g_len, dg_len, x, tslot[SLOT]);
+  }
 };
+
+// The times at which a scheme evaluates f and g within the step that starts at t0 (slot order of `stage_slots`; computed like
+// the stepwise path's host code: t0 + frac * dt in the state dtype).
+template <typename T, int METHOD>
+TSDE_D void stage_times(T t0, T dt, T (&out)[4]) {
+  out[0] = t0;
+  out[1] = METHOD == kSrk ? t0 + (T)0.25 * dt : t0 + (T)0.5 * dt;
+  out[2] = t0 + (T)0.5 * dt;
+  out[3] = t0 + dt;
+}
 
 template <typename T>
 struct ProgArgs {
@@ -902,6 +918,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<
       w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
       if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
     }
+    stage_times<T, METHOD>(row[7], dt, m.tslot);
     const V y1 = scheme_step<T, METHOD, V, ProgModel<T, W>, V>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
     if (__builtin_expect(k + 1 == next_out, 0)) {
       while (j < p.n_out && p.out_step[j] == k + 1) {
@@ -968,6 +985,7 @@ struct ProgSensModel {
   const T* consts;
   const int8_t* param_slot;        // per constant row: tangent slot 1..4, or -1 (kernel arguments, uniform)
   int64_t d, col;
+  T tslot[4];
 
   TSDE_D S constant(uint32_t k) const {
     S c(consts[(int64_t)k * d + col]);
@@ -976,7 +994,7 @@ struct ProgSensModel {
     return c;
   }
 
-  TSDE_D S run(const uint32_t* prog, int len, const S& x) const {
+  TSDE_D S run(const uint32_t* prog, int len, const S& x, const T time) const {
     S s0((T)0), s1((T)0), s2((T)0), s3((T)0);
     uint32_t fetched = prog[0];
     for (int pc = 0; pc < len; ++pc) {
@@ -992,6 +1010,8 @@ struct ProgSensModel {
           s2 = s3;
         } else if (src == kSrcConst) {
           b = constant(k);
+        } else if (src == kSrcTime) {
+          b = S(time);
         } else {
           b = x;
         }
@@ -1039,11 +1059,11 @@ struct ProgSensModel {
     return s0;
   }
   template <int SLOT>
-  TSDE_D S f(const S& x) const { return run(code, f_len, x); }
+  TSDE_D S f(const S& x) const { return run(code, f_len, x, tslot[SLOT]); }
   template <int SLOT>
-  TSDE_D S g(const S& x) const { return run(code + f_len, g_len, x); }
+  TSDE_D S g(const S& x) const { return run(code + f_len, g_len, x, tslot[SLOT]); }
   template <int SLOT>
-  TSDE_D S gdg(const S& x, const S& gv, T v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x); }
+  TSDE_D S gdg(const S& x, const S& gv, T v2) const { return (gv * v2) * run(code + f_len + g_len, dg_len, x, tslot[SLOT]); }
 };
 
 constexpr int kProgParamRows = 64;
@@ -1090,6 +1110,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_sens_kernel(const Prog
     const T w = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
     T u = (T)0;
     if constexpr (kNeedU) u = th * ((T)0.5 * w + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+    stage_times<T, METHOD>(row[7], dt, m.tslot);
     const S y1 = scheme_step<T, METHOD, S>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
     if (__builtin_expect(k + 1 == next_out, 0)) {
       while (j < p.n_out && p.out_step[j] == k + 1) {

@@ -672,13 +672,13 @@ class _Expr:
         return False
 
     def leaf(self):
-        return self.op in ("y", "const")
+        return self.op in ("y", "t", "const")
 
 
 _OPCODES = {"load": 0, "add": 1, "sub": 2, "rsub": 3, "mul": 4, "div": 5, "rdiv": 6, "neg": 16, "exp": 17, "log": 18, "sin": 19,
             "cos": 20, "tanh": 21, "sigmoid": 22, "softplus": 23, "sqrt": 24, "abs": 25, "relu": 26, "reciprocal": 27,
             "square": 28, "cube": 29, "dup": 30}          # include/torchsde_amd.h: tsde_trajectory_prog_diag
-_SRC_STACK, _SRC_CONST, _SRC_STATE = 0, 1, 2
+_SRC_STACK, _SRC_CONST, _SRC_STATE, _SRC_TIME = 0, 1, 2, 3
 _REVERSED = {"add": "add", "mul": "mul", "sub": "rsub", "div": "rdiv"}
 _STACK_DEPTH = 4
 
@@ -717,7 +717,11 @@ class _Program:
         return max(na, nb) + 1 if na == nb else max(na, nb)
 
     def source(self, leaf):
-        return (_SRC_STATE, 0) if leaf.op == "y" else (_SRC_CONST, self.const_row(leaf.value))
+        if leaf.op == "y":
+            return (_SRC_STATE, 0)
+        if leaf.op == "t":
+            return (_SRC_TIME, 0)
+        return (_SRC_CONST, self.const_row(leaf.value))
 
     def compile(self, node):
         """Append the code that leaves the value of `node` on top of the stack."""
@@ -780,7 +784,7 @@ def _derivative(node):
     op = node.op
     if op == "y":
         return _number(1)
-    if op == "const":
+    if op in ("const", "t"):
         return _number(0)
     if len(node.args) == 1:
         u = node.args[0]
@@ -827,13 +831,18 @@ class _TreeInterpreter(_Interpreter):
     def __init__(self, y, t, rows, d):
         super().__init__(y, t, rows, d)
         self.forms[id(y)] = _Expr("y")
+        # t is one more leaf: the kernel hands the programs the scheme's stage time, so arithmetic on t (`torch.cos(t) * y`,
+        # `y / (2 + 2 * t)`) is followed like arithmetic on the state; what is NOT elementwise (`float(t)`, `cat` with the
+        # state, comparisons) fails on its own operator
+        self.forms[id(t)] = _Expr("t")
+        self.time = set()
 
     def constant_value(self, c):
         return _Expr("const", value=c)
 
     def state_shaped(self, tensor):
-        shape = tuple(tensor.shape)
-        return shape == (self.rows, self.d) or shape == (self.rows, self.d, 1)      # (rows, d, 1): scalar noise's g
+        # state-shaped, the (rows, d, 1) of scalar noise's g, or -- functions of t alone -- anything per-channel
+        return tuple(tensor.shape) in ((self.rows, self.d), (self.rows, self.d, 1), (), (1,), (self.d,), (1, self.d), (1, 1))
 
     def operand(self, x):
         node = self.form_of(x)
@@ -851,6 +860,9 @@ class _TreeInterpreter(_Interpreter):
             return self.track(out, _Expr("const", value=self._LIKE[name]))
         if name == "full_like" and out.dtype == args[0].dtype and isinstance(args[1], (int, float)):
             return self.track(out, _Expr("const", value=float(args[1])))
+        if name in ("expand", "view", "reshape", "_unsafe_view", "unsqueeze", "squeeze") and x is not None \
+                and torch.is_tensor(out) and out.shape != args[0].shape and out.dim() <= 2 and args[0].dim() <= 2 and out.numel() in (args[0].numel(), args[0].numel() * self.rows):
+            return self.track(out, x)            # a per-channel value (a function of t) reshaped or stretched over the rows
         if name in self._SAME and x is not None:
             if not torch.is_tensor(out) or out.shape != args[0].shape or out.dtype != args[0].dtype \
                     or out.device != args[0].device:
@@ -905,6 +917,7 @@ class RecognisedProgram:
         self.d, self.dtype, self.device, self.noise_type = d, dtype, device, noise_type
         if f.trailing or g.trailing != (noise_type == "scalar"):
             raise NotElementwise(f"drift / diffusion of the wrong shape for {noise_type} noise")
+        self.uses_time = any(self._mentions_time(tree) for tree in (f, g))
         consts = []
         self.programs = []
         for tree in (f, g, None):
@@ -927,6 +940,10 @@ class RecognisedProgram:
         if self.programs[2] is not None and sum(len(w) for w in self.programs) > 96:
             self.programs[2] = None                      # (the derivative does not fit: every scheme but Milstein)
         self.consts = consts
+
+    @staticmethod
+    def _mentions_time(node):
+        return node.op == "t" or any(RecognisedProgram._mentions_time(a) for a in node.args)
 
     def structure(self):
         """Key of the trust verdict: the programs themselves (constants by position only: values are live)."""

@@ -473,14 +473,16 @@ class BaseSDESolver:
                 book["uses_t"] = (chain, type(self).__name__)
                 # f, g use t in their arithmetic: interpret once more with ALL the times at which this scheme evaluates them
                 # (its stage times of every step); the kernels then read one coefficient row per stage time
-                times = self._stage_times(ts, y0.device)
-                if times is None:
-                    raise
+                times = self._stage_times(ts, y0.device) if elementwise else None
                 try:
+                    if times is None:
+                        raise recognise.NotElementwise("no coefficient tables for this scheme")
                     found = recognise.recognise(sde, ts[0], y0, times=times)
                 except recognise.NotElementwise as e:
-                    raise recognise.NotElementwise("drift or diffusion depends on t, and not only through arithmetic that "
-                                                   f"broadcasts ({e})") from None
+                    # ... or t takes part in arithmetic that is not affine in the state: t as an operand of a program
+                    times = None
+                    found, spec = as_program("drift or diffusion depends on t, and not only through arithmetic that "
+                                             f"broadcasts ({e})")
             except recognise.NotElementwise as e:
                 found, spec = as_program(str(e))
             if isinstance(found, recognise.RecognisedProgram):
