@@ -72,12 +72,14 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c3_euler_additive_shared_b262144_d64_m32", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c3_euler_general_default_route_b16384_d32_m16", "c3_midpoint_general_default_route_b16384_d32_m16",
+        "c2_srk_netdiag_b65536_d64_s1000", "c2_srk_netdiag_default_route_b65536_d64_s1000",
         "c2_milstein_diag_default_route", "c2_srk_diag_default_route", "c4_midpoint_diag_default_route_b32768_d64",
         "c2_euler_expdiff_default_route_b65536_d64_s1000", "c2_euler_training_default_route_b65536_d64_s1000",
         "c2_euler_scheduled_b65536_d64_s1000", "c2_euler_scheduled_default_route_b65536_d64_s1000",
         "c2_srk_scheduled_default_route_b65536_d64_s1000",
         "c2_euler_doublewell_b65536_d64_s1000", "c2_euler_doublewell_default_route_b65536_d64_s1000",
-        "c2_srk_exscalar_b65536_d64_s1000", "c2_srk_exscalar_default_route_b65536_d64_s1000",
+        "c2_euler_exscalar_b65536_d64_s1000", "c2_srk_exscalar_b65536_d64_s1000",
+        "c2_srk_exscalar_default_route_b65536_d64_s1000",
         "c2_euler_exscalar_default_route_b65536_d64_s1000", "c2_euler_exscalar_training_default_route_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
         "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500",

@@ -467,7 +467,10 @@ typedef struct tsde_mlp {
  *                                increments: the (rows, m) field, element (row, j) = elem0 + row * m + j
  *   noise = TSDE_NOISE_DIAGONAL  diffusion->out = d, m = d: g[., i] dW[., i]             (NeuralDiagonal)
  *   noise = TSDE_NOISE_SCALAR    diffusion->out = d, m = 1: g[., i] dW[.]                (NeuralScalar)
- * method: TSDE_TRAJ_EULER (Ito) or TSDE_TRAJ_MIDPOINT (Stratonovich; stage times t_k and t_k + dt/2).
+ * method: TSDE_TRAJ_EULER (Ito), TSDE_TRAJ_MIDPOINT (Stratonovich; stage times t_k and t_k + dt/2), or -- diagonal and scalar
+ * noise only, like the reference's (srk.py:34-35) -- TSDE_TRAJ_SRK (SRID2, srk.py:57-88: three drift and four diffusion
+ * evaluations per step, every one a pass of its net; needs the increments' second stream, i.e. a Brownian motion with a
+ * space-time Levy area).
  * A wave keeps 16 rows in registers for the whole solve; every weight lives in LDS; all four layers run on
  * v_mfma_f32_16x16x4_f32 (exact f32), the contraction with the increments included (csrc/mlp_general.hip).
  * traj->step_rows[k][7] must hold t_k, the time at which step k starts (the other trajectory kernels ignore that slot).

@@ -18,10 +18,10 @@ DEV = "cuda"
 DT = 2.0 ** -7
 
 
-def _bm(B, m, t1, entropy, row_offset=0):
+def _bm(B, m, t1, entropy, row_offset=0, levy="none"):
     import torchsde_amd
     return torchsde_amd.BrownianInterval(0.0, t1, size=(B, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=DT,
-                                         row_offset=row_offset)
+                                         row_offset=row_offset, levy_area_approximation=levy)
 
 
 def _solve(sde, m, entropy, method, B=96, d=None, steps=24, stepwise=False, ts=None, row_offset=0):
@@ -33,7 +33,8 @@ def _solve(sde, m, entropy, method, B=96, d=None, steps=24, stepwise=False, ts=N
     if stepwise:
         options["trajectory_kernel"] = False
     with torch.no_grad():
-        return torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, m, float(ts[-1]), entropy, row_offset), method=method, dt=DT,
+        levy = "space-time" if method in ("srk", None) else "none"
+        return torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, m, float(ts[-1]), entropy, row_offset, levy), method=method, dt=DT,
                                    options=options)
 
 
@@ -72,9 +73,11 @@ def test_general_noise_networks_take_the_matrix_core_kernel(d, m, hidden, method
 
 
 @pytest.mark.parametrize("name,m_of", [("netdiag", lambda d: d), ("netscalar", lambda d: 1)])
-@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich")])
+@pytest.mark.parametrize("method,sde_type", [("euler", "ito"), ("midpoint", "stratonovich"), ("srk", "ito"), (None, "ito")])
 def test_diagonal_and_scalar_noise_networks(name, m_of, method, sde_type):
-    """NeuralDiagonal / NeuralScalar (tests/problems.py:135-192): 0.1 * sigmoid-closed g_net, (B, d) or (B, d, 1)."""
+    """NeuralDiagonal / NeuralScalar (tests/problems.py:135-192): 0.1 * sigmoid-closed g_net, (B, d) or (B, d, 1); Euler,
+    midpoint, SRK (SRID2: three drift and four diffusion evaluations per step, srk.py:57-88) and the call with EVERY default
+    (method None: `sdeint` picks SRK for diagonal and scalar Ito noise, sdeint.py:246-253)."""
     for d, hidden in ((8, 8), (20, 24), (64, 64)):
         sde = problems.make(f"{name}_{'ito' if sde_type == 'ito' else 'strat'}", d=d, hidden=hidden).to(DEV)
         m = m_of(d)
@@ -182,6 +185,8 @@ def test_c3_full_size_default_route_rows_vs_oracle():
 
 @pytest.mark.parametrize("name,noise,method,d,m", [("netdiag_ito", "diagonal", "euler", 32, 32),
                                                    ("netscalar_ito", "scalar", "euler", 32, 1),
+                                                   ("netdiag_ito", "diagonal", "srk", 32, 32),
+                                                   ("netscalar_ito", "scalar", "srk", 16, 1),
                                                    ("general_strat", "general", "midpoint", 16, 8)])
 def test_neural_kernel_rows_vs_oracle(name, noise, method, d, m):
     """The other modes of the neural-SDE kernel -- diagonal and scalar noise (the reference's NeuralDiagonal, NeuralScalar),
@@ -195,8 +200,11 @@ def test_neural_kernel_rows_vs_oracle(name, noise, method, d, m):
     y0 = torch.full((Bf, d), 0.1, device=DEV)
     ts = torch.tensor([0.0, n * dt], device=DEV)
 
+    levy = "space-time" if method == "srk" else "none"
+
     def bm(entropy):
-        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bf, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt)
+        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bf, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt,
+                                             levy_area_approximation=levy)
     before = torch.get_num_threads()
     torch.set_num_threads(min(8, before))
     try:
@@ -205,7 +213,7 @@ def test_neural_kernel_rows_vs_oracle(name, noise, method, d, m):
             ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm(20240601), method=method, dt=dt))
         assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
         rows = helpers.sampled_rows(Bf, 48, seed=11, seams=(16, Bf - 16))
-        ref32, ref64 = _oracle_forward(sde, rows, d, m, 20240601, n, dt, method, 0.1)
+        ref32, ref64 = _oracle_forward(sde, rows, d, m, 20240601, n, dt, method, 0.1, levy=levy != "none")
         helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1],
                                                  f"{name}, {method}, neural-SDE kernel")
     finally:

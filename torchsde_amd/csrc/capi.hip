@@ -614,7 +614,10 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
   if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
     return bad_arg(where, "ys and y0 must be 16-byte aligned");
   if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
-  if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT) return bad_arg(where, "method must be Euler or midpoint");
+  if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT && method != TSDE_TRAJ_SRK)
+    return bad_arg(where, "method must be Euler, midpoint or SRK");
+  if (method == TSDE_TRAJ_SRK && noise == TSDE_NOISE_GENERAL)
+    return bad_arg(where, "SRK (SRID2) takes diagonal or scalar noise, like the reference's (srk.py:34-35)");
   if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");

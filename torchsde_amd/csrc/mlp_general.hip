@@ -13,6 +13,7 @@
 // Replaces, for such modules, the whole stepping loop torchsde/_core/base_solver.py:114-134 with
 //   methods/euler.py:29-37 (f_and_g_prod -> misc.batch_mvp, _core/misc.py:62-63: bmm(g, dW))     TSDE_TRAJ_EULER
 //   methods/midpoint.py:29-45 (two evaluations, the second at t + dt/2 and the predicted state)   TSDE_TRAJ_MIDPOINT
+//   methods/srk.py:57-88 (SRID2, diagonal / scalar noise: 3 drift + 4 diffusion evaluations)       TSDE_TRAJ_SRK
 // in ONE launch. Stepwise, this SDE costs a (rows, d, m) diffusion tensor through HBM and four library GEMMs per step
 // (the user's two nets are 93 % of the solve at the configs[2] shape); here nothing but y0 and the outputs touches HBM.
 //
@@ -54,7 +55,7 @@ struct NeuralArgs {
   int64_t B;
   int32_t d, m;
   int32_t n_steps, n_out;
-  int32_t method;           // TSDE_TRAJ_EULER | TSDE_TRAJ_MIDPOINT
+  int32_t method;           // TSDE_TRAJ_EULER | TSDE_TRAJ_MIDPOINT | TSDE_TRAJ_SRK (diagonal / scalar noise)
   NoiseKey key;
   const uint64_t* key_dev;
 };
@@ -360,12 +361,158 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
       }
     };
 
+    // diagonal / scalar noise: the diffusion VALUES g (one per state channel) of a net evaluation, and the step's increments
+    // W (and U = h (W/2 + H), SRK) in the state's layout -- what the stochastic Runge-Kutta scheme combines stage by stage
+    auto diffusion_values = [&](const f32x4* hid, f32x4* g) {
+      int o2 = 0;
+      asm volatile("" : "+v"(o2));
+#pragma unroll
+      for (int t = 0; t < TD; ++t) g[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int th = 0; th < TH; ++th) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+            const float a = W2g[o2 + (16 * th + 4 * part + r) * S2G + 16 * t + n];
+            g[t] = Tile<16>::mfma(a, hid[th][r], g[t]);
+          }
+        }
+      }
+      if constexpr (TD == 1) reads_ahead<TH * 4, 1>();
+      else reads_ahead<TH * 4 * TD / 2, 2>();
+#pragma unroll
+      for (int t = 0; t < TD; ++t) {
+        const f32x4 bias = lds_quad(b2g, 16 * t + 4 * part);
+        if (sigmoid_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g[t][r] = g_scale * finalise<true>(g[t][r] + bias[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g[t][r] = g_scale * (g[t][r] + bias[r]);
+        }
+      }
+    };
+    auto increments = [&](uint32_t cell, float sw, float sh, float th_, f32x4* w, f32x4* u) {
+      if constexpr (MODE == 1) {
+        const uint64_t e = key.elem0 + (uint64_t)row;
+        const float wr = normal1<float>(key, e, cell, 0, kStreamW) * sw;
+        const float ur = th_ * (0.5f * wr + normal1<float>(key, e, cell, 0, kStreamH) * sh);
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+          w[t] = f32x4{wr, wr, wr, wr};
+          u[t] = f32x4{ur, ur, ur, ur};
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+          const int ch = 16 * t + 4 * part;
+          uint64_t quad = (key.elem0 + (uint64_t)off_d + (uint64_t)ch) >> 2;
+          asm volatile("" : "+v"(quad));
+          float zw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (real(ch)) {
+            normal4<float>(key, quad, cell, 0, kStreamW, zw);
+            normal4<float>(key, quad, cell, 0, kStreamH, zh);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            w[t][r] = zw[r] * sw;
+            u[t][r] = th_ * (0.5f * w[t][r] + zh[r] * sh);
+          }
+        }
+      }
+    };
+
     int jout = 0;
     for (int k = 0; k < p.n_steps; ++k) {
       const float* srow = p.rows + (int64_t)k * 8;
       const float dt = srow[0], half_dt = srow[1], sw = srow[4], t0 = srow[7];
       const uint32_t cell = p.cells[k];
       f32x4 hid[TH], f[TD], gdw[TD], yn[TD];
+      bool stepped = false;
+      if constexpr (!NS::kGeneral) {
+        if (p.method == TSDE_TRAJ_SRK) {
+          // SRID2 (srk.py:57-88, tableaus/srid2.py) for diagonal / scalar noise with BOTH functions networks: three drift
+          // evaluations f(t, y), f(t + dt, H0_1), f(t + dt/2, H0_2) (the tableau's alpha_3 = 0) and four diffusion
+          // evaluations g(t, y), g(t + dt/4, H1_1), g(t + dt, H1_2), g(t + dt/4, H1_3), every one a pass of its net on the
+          // matrix cores; the running sums hold everything a later stage needs (operation order of tsde_schemes.h).
+          const float rdt = srow[2], sqrt_dt = srow[3], sh = srow[5], th_ = srow[6];
+          f32x4 w[TD], u[TD], g0[TD], g1[TD], g2[TD], f0[TD], f1[TD], acc[TD], hs[TD];
+          increments(cell, sw, sh, th_, w, u);
+          auto weight = [&](int st, float wv, float uv) {
+            const float Ikk = (wv * wv - dt) * 0.5f;
+            const float Ikkk = ((wv * wv) * wv - (3.0f * dt) * wv) * (float)(1.0 / 6);
+            return ((((float)Srid2::beta1(st) * wv) + ((float)Srid2::beta2(st) * Ikk) / sqrt_dt) +
+                    ((float)Srid2::beta3(st) * uv) * rdt) + ((float)Srid2::beta4(st) * Ikkk) * rdt;
+          };
+          hidden_layer(W1f, b1f, wtf, p.f.act, t0, y, hid);
+          drift(hid, f0);
+          hidden_layer(W1g, b1g, wtg, p.g.act, t0, y, hid);
+          diffusion_values(hid, g0);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[t][r] = (y[t][r] + ((float)Srid2::alpha(0) * f0[t][r]) * dt) + g0[t][r] * weight(0, w[t][r], u[t][r]);
+              hs[t][r] = (y[t][r] + ((float)Srid2::A1(1, 0) * f0[t][r]) * dt) + ((float)Srid2::B1(1, 0) * g0[t][r]) * sqrt_dt;
+            }
+          }
+          hidden_layer(W1g, b1g, wtg, p.g.act, t0 + 0.25f * dt, hs, hid);          // g1 = g(t + dt/4, H1_1)
+          diffusion_values(hid, g1);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[t][r] = acc[t][r] + g1[t][r] * weight(1, w[t][r], u[t][r]);
+              hs[t][r] = (y[t][r] + ((float)Srid2::A1(2, 0) * f0[t][r]) * dt) + ((float)Srid2::B1(2, 0) * g0[t][r]) * sqrt_dt;
+            }
+          }
+          hidden_layer(W1g, b1g, wtg, p.g.act, t0 + dt, hs, hid);                  // g2 = g(t + dt, H1_2)
+          diffusion_values(hid, g2);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[t][r] = acc[t][r] + g2[t][r] * weight(2, w[t][r], u[t][r]);
+              hs[t][r] = y[t][r] + ((float)Srid2::A0(1, 0) * f0[t][r]) * dt;      // H0_1
+            }
+          }
+          hidden_layer(W1f, b1f, wtf, p.f.act, t0 + dt, hs, hid);                  // f1 = f(t + dt, H0_1)
+          drift(hid, f1);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[t][r] = acc[t][r] + ((float)Srid2::alpha(1) * f1[t][r]) * dt;
+              hs[t][r] = (((y[t][r] + ((float)Srid2::A0(2, 0) * f0[t][r]) * dt) +
+                           (((float)Srid2::B0(2, 0) * g0[t][r]) * u[t][r]) * rdt) +
+                          ((float)Srid2::A0(2, 1) * f1[t][r]) * dt) + (((float)Srid2::B0(2, 1) * g1[t][r]) * u[t][r]) * rdt;
+            }
+          }
+          hidden_layer(W1f, b1f, wtf, p.f.act, t0 + 0.5f * dt, hs, hid);           // f2 = f(t + dt/2, H0_2)
+          drift(hid, f);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[t][r] = acc[t][r] + ((float)Srid2::alpha(2) * f[t][r]) * dt;
+              hs[t][r] = (((y[t][r] + ((float)Srid2::B1(3, 0) * g0[t][r]) * sqrt_dt) +
+                           ((float)Srid2::B1(3, 1) * g1[t][r]) * sqrt_dt) + ((float)Srid2::A1(3, 2) * f[t][r]) * dt) +
+                         ((float)Srid2::B1(3, 2) * g2[t][r]) * sqrt_dt;             // H1_3
+            }
+          }
+          hidden_layer(W1g, b1g, wtg, p.g.act, t0 + 0.25f * dt, hs, hid);          // g3 = g(t + dt/4, H1_3)
+          diffusion_values(hid, g0);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yn[t][r] = acc[t][r] + g0[t][r] * weight(3, w[t][r], u[t][r]);
+          }
+          stepped = true;
+        }
+      }
+      if (!stepped) {
       hidden_layer(W1f, b1f, wtf, p.f.act, t0, y, hid);
       drift(hid, f);
       hidden_layer(W1g, b1g, wtg, p.g.act, t0, y, hid);
@@ -388,6 +535,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
       for (int t = 0; t < TD; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) yn[t][r] = (y[t][r] + f[t][r] * dt) + gdw[t][r];          // euler.py:36
+      }
       }
       // outputs due at the end of this step: w0 y_k + w1 y_{k+1} (base_solver.py:147, interp.py:15-18)
       while (jout < p.n_out && p.out_step[jout] == k + 1) {

@@ -420,7 +420,7 @@ class BaseSDESolver:
                 or y0.shape[0] < 8
                 or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
                 or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
-                or ((elementwise or programs) and self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
+                or (self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         if sde.noise_type == NOISE_TYPES.diagonal and tuple(bm.shape) != tuple(y0.shape):
             return None
@@ -1206,6 +1206,10 @@ class SRK(BaseSDESolver):
 
     def _program_code(self):
         return _native.TRAJ_SRK
+
+    def _neural_code(self):
+        # (diagonal and scalar noise; additive noise takes SRA1, which the neural-SDE kernel does not have)
+        return _native.TRAJ_SRK if self.sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar) else None
 
     def _advance(self, y0, st, out):
         if self.sde.noise_type == NOISE_TYPES.additive:

@@ -78,6 +78,10 @@ WORKLOADS = {
         problem="scalar_ito", method="euler", levy="none", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True, train=True,
         kernel="tsde_trajectory_prog_diag_sens<float, euler, scalar noise> (user module recognised; sdeint + loss.backward())"),
+    "c2_euler_exscalar_b65536_d64_s1000": dict(
+        problem="scalar_ito", method="euler", levy="none", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=16 * 64, kid=1, launches_per_step=1,
+        kernel="tsde_step_diag<float> (user f, g: ~11 torch kernels per step)"),
     "c2_srk_exscalar_b65536_d64_s1000": dict(
         problem="scalar_ito", method="srk", levy="space-time", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
@@ -120,6 +124,17 @@ WORKLOADS = {
         kid=8, trajectory=True, recognised=True,
         mfma_flops_per_traj_step=4 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
         kernel="tsde_trajectory_mlp_general<32, 64, general m = 16, midpoint> (user module recognised)"),
+    # The reference's NeuralDiagonal (tests/problems.py:135-162: f_net, g_net of cat([t, y]), g = 0.1 * sigmoid-closed net) at
+    # d = hidden = 64 with EVERY default of sdeint -- SRK (SRID2) for diagonal Ito noise: seven net evaluations per step, all on
+    # the matrix cores in one launch; stepwise counterpart below
+    "c2_srk_netdiag_default_route_b65536_d64_s1000": dict(
+        problem="netdiag_big", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, recognised=True, mfma_flops_per_traj_step=7 * 2 * (64 * 64 + 64 * 64),
+        kernel="tsde_trajectory_mlp_general<64, 64, diagonal, srk> (neural_trajectory_kernel; user module recognised)"),
+    "c2_srk_netdiag_b65536_d64_s1000": dict(
+        problem="netdiag_big", method="srk", levy="space-time", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4, bench_steps=200,
+        kernel="tsde_srk_diag_stage<float> (4 stage kernels; user f_net, g_net: 7 evaluations per step)"),
     # The batch-broadcast diffusion of north_star's "MFMA ... for the dense g.dW batched matmul": additive noise returned
     # as sigma.expand(B, d, m) at the configs[2] shape and at a larger one. One launch of the matrix-core kernel per
     # step: reads y0, f, writes y1 (12*d bytes per trajectory-step), increments generated in registers, S in LDS.
@@ -252,6 +267,8 @@ def make_problem(name, d, m, dev):
     from . import problems
     if name == "general_big":      # NeuralGeneral-style: hidden 64
         return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
+    if name == "netdiag_big":
+        return problems.MLPNetDiag(d, "ito", hidden=64).to(dev)
     if name == "general_big_strat":
         return problems.MLPGeneral(d, m, "stratonovich", hidden=64).to(dev)
     if name == "latent_diag":      # latent-SDE-style diagonal SDE
