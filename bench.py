@@ -72,6 +72,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c3_euler_additive_shared_b262144_d64_m32", "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500",
         "c2_euler_expdiff_b65536_d64_s1000",
         "c3_euler_general_default_route_b16384_d32_m16", "c3_midpoint_general_default_route_b16384_d32_m16",
+        "c3_euler_general_bf16x3_default_route_b16384_d32_m16",
         "c2_srk_netdiag_b65536_d64_s1000", "c2_srk_netdiag_default_route_b65536_d64_s1000",
         "c2_milstein_diag_default_route", "c2_srk_diag_default_route", "c4_midpoint_diag_default_route_b32768_d64",
         "c2_euler_expdiff_default_route_b65536_d64_s1000", "c2_euler_training_default_route_b65536_d64_s1000",
@@ -233,7 +234,8 @@ class Job:
         with torch.no_grad():
             # (a recognised workload is the drop-in call: no options at all)
             ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
-                              options=None if c.get("recognised") else dict(extra_options, hip_graph=bool(graph)))
+                              options=(dict(extra_options) or None) if c.get("recognised")
+                              else dict(extra_options, hip_graph=bool(graph)))
             if self.dist is not None:
                 # The one collective of a solve, issued asynchronously: it waits for this solve's kernels on RCCL's own
                 # stream and overlaps the NEXT solve's compute; at most two are in flight (double buffer), the one before

@@ -444,6 +444,8 @@ int tsde_trajectory_prog_diag_sens(void* ys, void* sens, const void* y0, int64_t
  *   NeuralDiagonal.g, tests/problems.py:159); the drift uses final = NONE, scale = 1. */
 #define TSDE_FINAL_NONE 0
 #define TSDE_FINAL_SIGMOID 1
+#define TSDE_PRECISION_F32 0
+#define TSDE_PRECISION_BF16X3 1
 #define TSDE_NOISE_DIAGONAL 0
 #define TSDE_NOISE_SCALAR 1
 #define TSDE_NOISE_GENERAL 2
@@ -458,6 +460,11 @@ typedef struct tsde_mlp {
   int32_t activation; /* TSDE_ACT_* */
   int32_t final;
   double scale;
+  int32_t precision;  /* TSDE_PRECISION_F32 (exact f32 products: the reference's arithmetic, the default) or, diffusion net under
+                         general noise with up to 64 hidden units only, TSDE_PRECISION_BF16X3: its second layer on split-bf16
+                         products a_hi b_hi + a_hi b_lo + a_lo b_hi with f32 accumulation (~2^-16 relative per product; an
+                         opt-in experiment, never benchmarked as the headline) */
+  int32_t reserved;
 } tsde_mlp_t;
 
 /* All fixed steps of the SDE  dy = drift(t, y) dt + g(t, y) dW  with both functions perceptrons as above, in ONE launch

@@ -218,3 +218,44 @@ def test_neural_kernel_rows_vs_oracle(name, noise, method, d, m):
                                                  f"{name}, {method}, neural-SDE kernel")
     finally:
         torch.set_num_threads(before)
+
+
+def test_opt_in_split_bf16_products_error_against_float64():
+    """`options={"matrix_precision": "bf16x3"}` (an opt-in experiment, never the default): the diffusion
+    net's second layer on v_mfma_f32_16x16x32_bf16 with heads and tails of both operands. Its error against a float64
+    evaluation of the same recursion on the same increments is reported next to the exact-f32 mode's and bounded (measured
+    on MI355X: 6.9e-7 exact, 1.7e-6 split, relative to max |y|; the dropped lo*lo term is ~2^-16 of a product)."""
+    import torchsde_amd
+    Bf, d, m, hidden, n, dt = 2048, 32, 16, 64, 256, 2.0 ** -8
+    sde = problems.MLPGeneral(d, m, "ito", hidden=hidden).to(DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def bm():
+        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bf, m), dtype=torch.float32, device=DEV, entropy=77, dt=dt)
+
+    def solve(options):
+        with torch.no_grad():
+            for _ in range(2):                       # (the first solve of a mode earns its trust and returns the stepwise result)
+                out, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm(), method="euler", dt=dt, options=options))
+        assert launches == 1
+        return out[-1]
+    exact, split = solve(None), solve({"matrix_precision": "bf16x3"})
+    assert sorted(str(k[-1]) for k in _book(sde)["trusted"]) == [str(Bf), "bf16x3"] and all(
+        v is True for v in _book(sde)["trusted"].values()), _book(sde)
+    # float64 reference: the same Euler recursion, the same increments (materialised from the same generator)
+    sde64 = problems.MLPGeneral(d, m, "ito", hidden=hidden).to(DEV).double()
+    sde64.load_state_dict({k: v.double() for k, v in sde.state_dict().items()})
+    path, y = bm(), y0.double()
+    with torch.no_grad():
+        for k in range(n):
+            t = torch.tensor(k * dt, device=DEV, dtype=torch.float64)
+            dW = path(k * dt, (k + 1) * dt).double()
+            y = y + sde64.f(t, y) * dt + torch.bmm(sde64.g(t, y), dW.unsqueeze(-1)).squeeze(-1)
+    scale = y.abs().max().item()
+    err_exact = (exact.double() - y).abs().max().item() / scale
+    err_split = (split.double() - y).abs().max().item() / scale
+    print(f"max |y - y64| / max |y64|: exact f32 {err_exact:.2e}, split bf16 x3 {err_split:.2e}")
+    assert err_exact < 5e-6 and err_split < 2e-5 and not torch.equal(exact, split)      # measured: 6.9e-7 and 1.7e-6
+    with pytest.raises(ValueError, match="matrix_precision"):
+        torchsde_amd.sdeint(sde, y0, ts, bm=bm(), method="euler", dt=dt, options={"matrix_precision": "fp8"})

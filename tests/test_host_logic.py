@@ -711,3 +711,15 @@ def test_modules_that_must_not_be_called_an_extra_time_are_not_interpreted():
     assert BaseSDESolver._may_be_interpreted(sde)
     assert BaseSDESolver._may_be_interpreted(problems.make("gbm_ito", d=4))
     assert not BaseSDESolver._may_be_interpreted(type("OptimizedModule", (), {})())
+
+
+def test_matrix_precision_option_is_validated_before_any_route():
+    """`options["matrix_precision"]` (opt-in split-bf16 products of the neural general-noise kernel): anything but "f32" /
+    "bf16x3" raises on every route, CPU tensors included (before the no-CPU-fallback error)."""
+    import torch
+    import torchsde_amd
+    from workloads import problems
+    sde = problems.MLPGeneral(4, 2, "ito")
+    with pytest.raises(ValueError, match="matrix_precision"):
+        torchsde_amd.sdeint(sde, torch.zeros(8, 4), torch.tensor([0.0, 1.0]), dt=0.1, method="euler",
+                            options={"matrix_precision": "fp8"})

@@ -19,6 +19,7 @@ TRAJ_SENS = 5
 ACT_TANH, ACT_SOFTPLUS = 0, 1
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 FINAL_NONE, FINAL_SIGMOID = 0, 1
+PRECISION_F32, PRECISION_BF16X3 = 0, 1
 NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL = 0, 1, 2
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6, "poly3": 7}
@@ -67,7 +68,8 @@ class Traj(ctypes.Structure):
 class Mlp(ctypes.Structure):
     """``tsde_mlp_t``."""
     _fields_ = [("w1", _c_ptr), ("w1t", _c_ptr), ("b1", _c_ptr), ("w2", _c_ptr), ("b2", _c_ptr), ("hidden", _c_i32),
-                ("out", _c_i32), ("activation", _c_i32), ("final", _c_i32), ("scale", _c_dbl)]
+                ("out", _c_i32), ("activation", _c_i32), ("final", _c_i32), ("scale", _c_dbl), ("precision", _c_i32),
+                ("reserved", _c_i32)]
 
 
 _PTR4 = _c_ptr * 4

@@ -594,7 +594,10 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
     if (net->hidden < 1 || net->hidden > 64) return bad_arg(where, "hidden sizes must be in [1, 64]");
     if (net->activation != TSDE_ACT_TANH && net->activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
     if (net->final != TSDE_FINAL_NONE && net->final != TSDE_FINAL_SIGMOID) return bad_arg(where, "unknown output function");
+    if (net->precision != TSDE_PRECISION_F32 && net->precision != TSDE_PRECISION_BF16X3) return bad_arg(where, "unknown precision");
   }
+  if (drift->precision != TSDE_PRECISION_F32 || (diffusion->precision != TSDE_PRECISION_F32 && noise != TSDE_NOISE_GENERAL))
+    return bad_arg(where, "split-bf16 products are for the diffusion net under general noise only");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
   if (d < 4 || d > 64 || d % 4 != 0) return bad_arg(where, "need d a multiple of 4 in [4, 64]");

@@ -44,7 +44,10 @@ struct NeuralNet {          // device view of tsde_mlp_t (pointers as given: inp
   float scale;
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 struct NeuralArgs {
+  int32_t split;            // 1: the diffusion net's second layer on split-bf16 products (opt-in; see the kernel)
   float* ys;                // (n_out, B, d)
   const float* y0;          // (B, d)
   NeuralNet f, g;
@@ -103,9 +106,19 @@ struct NeuralLds {
   }
 };
 
-template <int D, int H, int MODE>
+// SPLIT (opt-in, `options={"matrix_precision": "bf16x3"}`; general noise, H = 64): the diffusion net's SECOND layer -- 512 of
+// the 640 f32 MFMAs of a configs[2] step -- runs on v_mfma_f32_16x16x32_bf16 with both operands split into a bf16 head and
+// a bf16 tail, a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi (f32 accumulation; the dropped a_lo b_lo and the tails' own rounding
+// are ~2^-16 relative per product): three instructions of ~17 cycles per 32 hidden units instead of eight of 32. NOT the
+// reference's arithmetic: the default and every benchmarked configuration stay exact f32; the mode's error against float64 is
+// reported beside its speed (tests/test_gpu_neural.py, bench_also.json). The weights are split once per launch into two bf16
+// arrays in LDS, K-contiguous per output (a lane's eight k of a 32-block: the four channels 4 part + r of the block's two
+// 16-unit tiles -- the order its own activations have in the accumulator layout), 16-byte chunks XOR-swizzled by the output
+// row so that the ds_read_b128 of a 16-lane group hits 16 different bank quads.
+template <int D, int H, int MODE, bool SPLIT = false>
 __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
   using NS = NoiseShape<MODE>;
+  static_assert(!SPLIT || (NS::kGeneral && H == 64), "split mode: general noise, 64 hidden units");
   using L = NeuralLds<D, H>;
   constexpr int TD = D / 16, TH = H / 16, S1 = L::S1, S2F = L::S2F, M = NS::M, G = NS::G;
   const int S2G = outp + 4;
@@ -130,9 +143,21 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
     const int u2 = i / D, c = i % D;
     W2f[u2 * S2F + c] = (u2 < hf && c < dT) ? p.f.w2[u2 * dT + c] : 0.0f;
   }
+  __bf16* W2hi = reinterpret_cast<__bf16*>(W2g);         // SPLIT: [outp][H] heads, then [outp][H] tails (same bytes as f32)
+  __bf16* W2lo = W2hi + (size_t)outp * H;
   for (int i = threadIdx.x; i < H * outp; i += 256) {
     const int u = i / outp, o = i % outp;
-    W2g[u * S2G + o] = (u < hg && o < outT) ? p.g.w2[(int64_t)u * outT + o] : 0.0f;
+    const float w = (u < hg && o < outT) ? p.g.w2[(int64_t)u * outT + o] : 0.0f;
+    if constexpr (SPLIT) {
+      // unit u = 32 b + 16 tt + 4 part + r  ->  chunk 4 b + part (swizzled by the row), position 4 tt + r
+      const int b = u >> 5, tt = (u >> 4) & 1, pq = (u >> 2) & 3, r = u & 3;
+      const int chunk = (4 * b + pq) ^ ((o >> 1) & 7);
+      const __bf16 hi = (__bf16)w;
+      W2hi[(size_t)o * H + 8 * chunk + 4 * tt + r] = hi;
+      W2lo[(size_t)o * H + 8 * chunk + 4 * tt + r] = (__bf16)(w - (float)hi);
+    } else {
+      W2g[u * S2G + o] = w;
+    }
   }
   for (int i = threadIdx.x; i < H; i += 256) {
     b1f[i] = i < hf ? p.f.b1[i] : 0.0f;
@@ -257,6 +282,20 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
 #pragma unroll
           for (int r = 0; r < 4; ++r) dw[q][r] = (z[r] * sw) * g_scale;
         }
+        // SPLIT: the activations of this evaluation as bf16 heads and tails, in B-operand order (see the kernel's comment)
+        bf16x8 hid_hi[SPLIT ? H / 32 : 1], hid_lo[SPLIT ? H / 32 : 1];
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int b = 0; b < H / 32; ++b) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float v = hid[2 * b + (j >> 2)][j & 3];
+              const __bf16 hi = (__bf16)v;
+              hid_hi[b][j] = hi;
+              hid_lo[b][j] = (__bf16)(v - (float)hi);
+            }
+          }
+        }
 #pragma unroll
         for (int ty = 0; ty < TD; ++ty) {
           const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;        // real state channels of this tile (wave-uniform)
@@ -273,18 +312,34 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
 #pragma unroll
             for (int g = 0; g < G; ++g) bias[g] = lds_quad(b2g, 16 * (ty * M + p0 + g) + 4 * part);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int th = 0; th < TH; ++th) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
+              for (int b = 0; b < H / 32; ++b) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                  const float a = W2g[(16 * th + 4 * part + r) * S2G + col0 + 16 * g];
-                  acc[g] = Tile<16>::mfma(a, hid[th][r], acc[g]);
+                  const int o = 16 * (ty * M + p0 + g) + n;
+                  const int chunk = (4 * b + part) ^ ((o >> 1) & 7);
+                  const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(W2hi + (size_t)o * H + 8 * chunk);
+                  const bf16x8 alo = *reinterpret_cast<const bf16x8*>(W2lo + (size_t)o * H + 8 * chunk);
+                  acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, hid_hi[b], acc[g], 0, 0, 0);
+                  acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, hid_lo[b], acc[g], 0, 0, 0);
+                  acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, hid_hi[b], acc[g], 0, 0, 0);
                 }
               }
+            } else {
+#pragma unroll
+              for (int th = 0; th < TH; ++th) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                  for (int g = 0; g < G; ++g) {
+                    const float a = W2g[(16 * th + 4 * part + r) * S2G + col0 + 16 * g];
+                    acc[g] = Tile<16>::mfma(a, hid[th][r], acc[g]);
+                  }
+                }
+              }
+              reads_ahead<TH * 4 * G / 2, 2>();
             }
-            reads_ahead<TH * 4 * G / 2, 2>();
 #pragma unroll
             for (int g = 0; g < G; ++g) {
               const int tl = p0 + g;                                         // tile within this state tile
@@ -573,14 +628,17 @@ static size_t neural_lds_limit() {
   return limit;
 }
 
-template <int D, int H, int MODE>
+template <int D, int H, int MODE, bool SPLIT = false>
 static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
+  if constexpr (!SPLIT && NoiseShape<MODE>::kGeneral && H == 64) {
+    if (p.split) return launch_neural_mode<D, H, MODE, true>(p, s);
+  }
   const int outp = NeuralLds<D, H>::out_padded(p.g.out, NoiseShape<MODE>::kGeneral ? NoiseShape<MODE>::G : 1);
   const size_t lds_bytes = neural_lds_bytes(D, H, outp);
   if (lds_bytes > neural_lds_limit()) return hipErrorInvalidValue;
   static bool configured = false;   // per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&neural_trajectory_kernel<D, H, MODE>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&neural_trajectory_kernel<D, H, MODE, SPLIT>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) return e;
     configured = true;
@@ -591,7 +649,7 @@ static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
   const int64_t per_cu = (int64_t)((160 * 1024) / lds_bytes) < 1 ? 1 : (int64_t)((160 * 1024) / lds_bytes);
   const int64_t resident = 256 * (per_cu > 8 ? 8 : per_cu);
   if (blocks > resident) blocks = resident;
-  hipLaunchKernelGGL((neural_trajectory_kernel<D, H, MODE>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p, outp);
+  hipLaunchKernelGGL((neural_trajectory_kernel<D, H, MODE, SPLIT>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p, outp);
   return hipGetLastError();
 }
 
@@ -651,6 +709,7 @@ hipError_t launch_trajectory_mlp_general(void* ys, const void* y0, int64_t rows,
                                          const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method,
                                          const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
   NeuralArgs p;
+  p.split = diffusion->precision == TSDE_PRECISION_BF16X3 ? 1 : 0;
   p.ys = (float*)ys;
   p.y0 = (const float*)y0;
   p.f = device_view(drift);

@@ -802,19 +802,19 @@ class NeuralNet:
     + b2) with `w1` (in, hidden) and `w2` (hidden, out) input-major, `w1t` (hidden) the weight column of the time input or
     None. Holds contiguous float32 device tensors (and keeps them alive for the launch)."""
 
-    def __init__(self, w1, w1t, b1, w2, b2, activation, final=_native.FINAL_NONE, scale=1.0):
+    def __init__(self, w1, w1t, b1, w2, b2, activation, final=_native.FINAL_NONE, scale=1.0, precision=_native.PRECISION_F32):
         self.tensors = [None if t is None else _native.contiguous(t.detach()) for t in (w1, w1t, b1, w2, b2)]
-        self.activation, self.final, self.scale = int(activation), int(final), float(scale)
+        self.activation, self.final, self.scale, self.precision = int(activation), int(final), float(scale), int(precision)
         self.hidden, self.out = int(self.tensors[2].numel()), int(self.tensors[4].numel())
 
     def struct(self):
         w1, w1t, b1, w2, b2 = self.tensors
         return _native.Mlp(w1.data_ptr(), 0 if w1t is None else w1t.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                           self.hidden, self.out, self.activation, self.final, self.scale)
+                           self.hidden, self.out, self.activation, self.final, self.scale, self.precision, 0)
 
     def __eq__(self, other):
-        return isinstance(other, NeuralNet) and (self.activation, self.final, self.scale) == (
-            other.activation, other.final, other.scale) and all(
+        return isinstance(other, NeuralNet) and (self.activation, self.final, self.scale, self.precision) == (
+            other.activation, other.final, other.scale, other.precision) and all(
             (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and torch.equal(a, b))
             for a, b in zip(self.tensors, other.tensors))
 

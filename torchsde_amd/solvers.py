@@ -410,6 +410,9 @@ class BaseSDESolver:
         # ... and any other elementwise code (several functions of the state summed / multiplied, scalar noise): expression
         # programs (recognise.RecognisedProgram), every scheme with an in-register form
         programs = sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar) and self._program_code() is not None
+        precision = self.options.get("matrix_precision", "f32")
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError(f"Expected options['matrix_precision'] in ('f32', 'bf16x3'), got {precision!r}.")
         if (not recognise.ENABLED or not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful
                 or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks or programs)):
             return None
@@ -493,6 +496,10 @@ class BaseSDESolver:
                 spec = found.neural_spec(sde.noise_type)
                 if tuple(bm.shape) != (y0.shape[0], spec[4]) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
                     return None
+                if precision == "bf16x3" and sde.noise_type == NOISE_TYPES.general:
+                    # opt-in: the diffusion net's second layer on split-bf16 products (csrc/mlp_general.hip SPLIT); NOT the
+                    # reference's arithmetic -- the default, and everything benchmarked as such, stays exact f32
+                    spec[2].precision = _native.PRECISION_BF16X3
             elif not elementwise:
                 raise recognise.NotElementwise(f"{sde.noise_type} noise whose drift and diffusion are not both networks")
             else:
@@ -509,6 +516,8 @@ class BaseSDESolver:
                              _native.TRAJ_MIDPOINT, _native.TRAJ_SRK) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30):
                 return None
         key = self._recognised_key(found, chain, y0)
+        if spec[0] == "neural" and spec[2].precision != _native.PRECISION_F32:
+            key = key + ("bf16x3",)
         verdict = book["trusted"].get(key)
         launch = spec[1:] if spec[0] == "affine_diagonal" else spec       # (what `_integrate_trajectory` takes)
         if verdict is True:
@@ -527,6 +536,8 @@ class BaseSDESolver:
             else:
                 again = recognise.recognise(sde, ts[0], y0, times=times, rows=5)
                 again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
+                if spec[0] == "neural":
+                    again[2].precision = spec[2].precision
         except recognise.NotElementwise as e:
             return refuse(str(e))
         if before is None or graph.python_state(base) != before:

@@ -118,6 +118,14 @@ WORKLOADS = {
         mfma_flops_per_traj_step=2 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
         kernel="tsde_trajectory_mlp_general<32, 64, general m = 16, euler> (neural_trajectory_kernel, v_mfma_f32_16x16x4_f32; "
                "user module recognised)"),
+    # ... with the OPT-IN split-bf16 products for the diffusion net's second layer (options={"matrix_precision": "bf16x3"};
+    # an experiment: NOT the reference's arithmetic, never the headline; its error against float64 is in
+    # tests/test_gpu_neural.py). `tflops_f32` below is the exact-f32 flop count per second, for comparison only.
+    "c3_euler_general_bf16x3_default_route_b16384_d32_m16": dict(
+        problem="general_big", method="euler", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, recognised=True, options={"matrix_precision": "bf16x3"},
+        mfma_flops_per_traj_step=2 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
+        kernel="tsde_trajectory_mlp_general<32, 64, general m = 16, euler, split bf16 x3> (opt-in experiment)"),
     # ... and the Stratonovich default for general noise, midpoint (sdeint.py:155): two evaluations of both nets per step
     "c3_midpoint_general_default_route_b16384_d32_m16": dict(
         problem="general_big_strat", method="midpoint", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
