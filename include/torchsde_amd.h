@@ -433,6 +433,23 @@ int tsde_trajectory_prog_diag_sens(void* ys, void* sens, const void* y0, int64_t
                                    const int8_t* param_slot, int scalar_noise, int method, const tsde_traj_t* traj,
                                    uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
 
+/* Noise type "additive" (base_sde.py:101-102: g depends on t only; the reference's ExAdditive, tests/problems.py:106-132; the
+ * step functions euler.py:29-37, midpoint.py:29-45 and SRK's additive_step, srk.py:90-111 with tableaus/sra1.py): the drift as
+ * a program (as above, f only), the diffusion as a TABLE of the (d, m) matrix at the scheme's stage times.
+ *   m        Brownian channels per row, 1 .. 16; the increments are those of the (rows, m) field: element elem0 + row * m + j
+ *   g_table  `dtype`, device, 16-byte aligned. g_time_dependent == 0: (m, d), the transpose of the one matrix g.
+ *            != 0: (n_steps, slots, m, d), entry [k][s][j][c] = g(t_k + frac_s * dt_k)[c, j] with
+ *            frac = (0) for Euler, (0, 1/2) for midpoint, (1, 0) for SRK (sra1.py C1) -- computed by the host like the
+ *            stage times of the stepwise loop (t0 + frac * dt in `dtype`).
+ *   method   TSDE_TRAJ_EULER (also Milstein: with additive noise its correction is zero, base_sde.py:157-158),
+ *            TSDE_TRAJ_MIDPOINT, TSDE_TRAJ_SRK (SRA1; needs the space-time Levy area, step_rows as for the affine kernel)
+ * The drift program reads t from step_rows[k][7] (+ 1/2 dt for midpoint's second evaluation, + 3/4 dt for SRA1's, C0).
+ * Values only. Same schedule, outputs and Brownian path as the other trajectory kernels. */
+int tsde_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const uint32_t* code,
+                                  int32_t f_len, const void* consts, int32_t n_const, const void* g_table,
+                                  int g_time_dependent, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                  const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* ---- neural SDEs: drift AND diffusion two-layer perceptrons of (t, y) -------------------------------------------------
  * One perceptron shared by the batch:  out = scale * final(W2 . act(W1 . y + w1t * t + b1) + b2)
  *   w1   (in, hidden)   input-major (the transpose of torch.nn.Linear.weight restricted to the STATE columns)

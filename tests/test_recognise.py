@@ -502,3 +502,75 @@ def test_programs_refuse_what_is_not_elementwise_arithmetic():
     wider = lambda s, t, y: wide(s, t, y) * (wide(s, t, 2 * y) + wide(s, t, 3 * y) * wide(s, t, 4 * y))       # noqa: E731
     with pytest.raises(recognise.NotElementwise, match="more than four"):
         recognise.recognise_program(ForwardSDE(_M(wider, lambda s, t, y: y)), t, y, "diagonal")
+
+
+# ---- additive noise: the drift a program, the diffusion a table over the stage times ---------------------------------------
+class _NetOfTimeDiffusion(nn.Module):
+    """g of the reference's NeuralAdditive (tests/problems.py:208-220)."""
+    noise_type, sde_type = "additive", "ito"
+
+    def __init__(self, d, m):
+        super().__init__()
+        self.d, self.m = d, m
+        self.g_net = nn.Sequential(nn.Linear(1, 8), nn.Softplus(), nn.Linear(8, d * m), nn.Sigmoid())
+
+    def f(self, t, y):
+        return -torch.sin(y) * t
+
+    def g(self, t, y):
+        return self.g_net(t.expand(y.size(0), 1)).view(y.size(0), self.d, self.m)
+
+
+@pytest.mark.parametrize("make,m,timed", [(lambda: problems.AdditiveDecay(D, 3), 3, True),
+                                          (lambda: problems.AdditiveShared(D, 4), 4, False),
+                                          (lambda: _NetOfTimeDiffusion(D, 5), 5, True)])
+def test_additive_noise_drift_program_and_diffusion_table(make, m, timed):
+    """The reference's ExAdditive, a constant matrix `sigma.expand(B, d, m)`, a network of t: the table holds g(t)^T for every
+    stage time -- one batched call of the user's g -- and equals g called time by time; the drift program evaluates to f."""
+    sde = ForwardSDE(make())
+    y, t = 0.8 * torch.randn(16, D), torch.tensor(0.3)
+    times = torch.linspace(0.0, 1.0, 13)
+    found = recognise.recognise_additive(sde, t, y, times, check_rows=True)
+    kind, fw, consts, table, m_found = found.spec()
+    assert kind == "program_additive" and m_found == m and found.time_dependent == timed
+    with torch.no_grad():
+        if timed:
+            want = torch.stack([sde.g(tt, y[:1])[0].t() for tt in times])
+            assert table.shape == (13, m, D)
+        else:
+            want = sde.g(t, y[:1])[0].t()
+            assert table.shape == (m, D)
+        torch.testing.assert_close(table, want, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(_run_program(fw, consts, y, t), sde.f(t, y), rtol=1e-5, atol=1e-6)
+    again = recognise.recognise_additive(sde, t, y, times, rows=5, check_rows=True)
+    assert again.structure() == found.structure()
+    torch.testing.assert_close(again.table, table, rtol=1e-6, atol=1e-7)
+
+
+def test_additive_noise_refusals():
+    y, t, times = torch.randn(16, D), torch.tensor(0.3), torch.linspace(0.0, 1.0, 5)
+
+    class FromState(problems.AdditiveShared):
+        def g(self, t, y):
+            return (self.sigma * y.mean()).expand(y.size(0), -1, -1)
+
+    class HostTime(problems.AdditiveShared):
+        def g(self, t, y):
+            return self.sigma.expand(y.size(0), -1, -1) * (1.0 if t > 0.5 else 2.0)
+
+    class PerRow(problems.AdditiveShared):
+        def g(self, t, y):
+            return self.sigma.expand(y.size(0), -1, -1) * torch.arange(y.size(0), dtype=y.dtype).reshape(-1, 1, 1)
+
+    class Random(problems.AdditiveShared):
+        def g(self, t, y):
+            return self.sigma.expand(y.size(0), -1, -1) + torch.randn(D, 4)
+
+    class MatrixDrift(problems.AdditiveShared):
+        def f(self, t, y):
+            return y @ torch.eye(D)
+
+    for cls, m, reason in ((FromState, 4, "aten::mean"), (HostTime, 4, "reads t on the host"), (PerRow, 4, "differs between batch rows"),
+                           (Random, 4, "random"), (MatrixDrift, 4, "aten::mm"), (problems.AdditiveShared, 32, "up to 16")):
+        with pytest.raises(recognise.NotElementwise, match=reason):
+            recognise.recognise_additive(ForwardSDE(cls(D, m)), t, y, times, check_rows=True)

@@ -147,6 +147,8 @@ SIGNATURES = {
     "tsde_trajectory_prog_diag_sens": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i32, _c_i32, _c_i32, _c_ptr, _c_i32,
                                                 _c_ptr, _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                                 _c_ptr]),
+    "tsde_trajectory_prog_additive": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i32, _c_ptr, _c_i32, _c_ptr,
+                                               _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_trajectory_mlp_general": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(Mlp),
                                              ctypes.POINTER(Mlp), _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                              _c_ptr]),

@@ -578,6 +578,31 @@ int tsde_trajectory_prog_diag_sens(void* ys, void* sens, const void* y0, int64_t
                    n_const, scalar_noise, method, traj, entropy, elem0, entropy_dev, dtype, stream);
 }
 
+int tsde_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const uint32_t* code,
+                                  int32_t f_len, const void* consts, int32_t n_const, const void* g_table,
+                                  int g_time_dependent, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,
+                                  const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_trajectory_prog_additive";
+  if (!ys || !y0 || !code || !traj || !g_table) return bad_arg(where, "null argument");
+  if (f_len < 1 || f_len > 96) return bad_arg(where, "the drift program has 1 to 96 words");
+  if (n_const < 0 || n_const > 64 || (n_const > 0 && !consts)) return bad_arg(where, "constant table missing or above 64 rows");
+  if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
+  if (m < 1 || m > 16) return bad_arg(where, "need 1 <= m <= 16 Brownian channels");
+  if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT && method != TSDE_TRAJ_SRK)
+    return bad_arg(where, "method must be Euler, midpoint or SRK (SRA1)");
+  if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  const hipStream_t s = (hipStream_t)stream;
+  const tsde::NoiseKey key = make_key(entropy, elem0);
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  TSDE_DISPATCH(dtype, where,
+                tsde::launch_trajectory_prog_additive<float>(ys, y0, rows, d, m, code, f_len, consts, n_const, g_table,
+                                                             g_time_dependent != 0, method, traj, key, entropy_dev, s),
+                tsde::launch_trajectory_prog_additive<double>(ys, y0, rows, d, m, code, f_len, consts, n_const, g_table,
+                                                              g_time_dependent != 0, method, traj, key, entropy_dev, s));
+}
+
 int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden,
                                         int64_t diffusion_out, int noise) {
   if (d < 4 || d % 4 != 0 || drift_hidden < 1 || diffusion_hidden < 1 || diffusion_out < 1) return 0;

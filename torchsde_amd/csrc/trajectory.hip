@@ -1128,6 +1128,217 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_sens_kernel(const Prog
   }
 }
 
+// ---- additive noise: the drift as a program, the diffusion as a table ---------------------------------------------------
+// Noise type "additive" (base_sde.py:101-102; the reference's ExAdditive, tests/problems.py:106-132): g depends on t only
+// and every batch row meets the same (d, m) matrix. The host evaluates the user's g at every stage time of the solve
+// (recognise.RecognisedAdditive: one batched call) and hands the kernel `gtab[step][slot][j][c]` = g(t)[c, j]; a matrix that
+// does not depend on t is one slot with stride 0. A lane holds W channels of its row, draws the row's m increments itself
+// (the field is (rows, m): element row * m + j -- a lane of the same row draws the same numbers) and contracts them with its
+// W rows of G in ascending j. Schemes: Euler (euler.py:29-37; Milstein with additive noise is the same step, milstein.py:
+// base_sde.py:157-158 gdg = 0), midpoint (midpoint.py:29-45), SRK = SRA1 (srk.py:90-111, tableaus/sra1.py) with the
+// operation order of the stepwise route's `tsde_step_general_w` calls (solvers.SRK._advance_additive).
+template <typename T>
+struct ProgAdditiveArgs {
+  ProgArgs<T> base;         // g_len = dg_len = 0
+  const T* gtab;
+  int64_t step_stride;      // elements between the tables of consecutive steps (0: the matrix does not depend on t)
+  int64_t slot_stride;      // elements between the stage-time slots of one step (m * d)
+  int32_t m;                // Brownian channels per row, <= MP of the instantiation
+  int32_t quads;            // != 0: m % 4 == 0 and elem0 % 4 == 0, a row's channels are whole Philox quads
+};
+
+template <typename T, int METHOD, int W, int MP>
+__global__ void __launch_bounds__(kBlock) trajectory_prog_additive_kernel(const ProgAdditiveArgs<T> q) {
+  constexpr bool kNeedU = METHOD == kSrk;
+  using V = Vec<T, W>;
+  const ProgArgs<T>& p = q.base;
+  const int64_t lane = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = lane * W;
+  if (i >= p.n) return;
+  const int64_t col = i % p.d;
+  const Pack<T, W> y_init = load<T, W>(p.y0, i);
+  V y;
+#pragma unroll
+  for (int e = 0; e < W; ++e) y.v[e] = y_init.v[e];
+  ProgModel<T, W> m;
+  m.code = p.code;
+  m.f_len = p.f_len;
+  m.g_len = 0;
+  m.dg_len = 0;
+  m.consts = p.consts;
+  m.d = p.d;
+  m.col = col;
+#pragma unroll
+  for (int k = 0; k < kProgRegs; ++k) {
+    m.creg[k] = V((T)0);
+    if (k < p.n_const) {
+      const Pack<T, W> pk = load<T, W>(p.consts, (int64_t)k * p.d + col);
+#pragma unroll
+      for (int e = 0; e < W; ++e) m.creg[k].v[e] = pk.v[e];
+    }
+  }
+  NoiseKey key = p.key;
+  if (p.key_dev != nullptr) {
+    const uint64_t ent = *p.key_dev;
+    key.k0 = (uint32_t)ent;
+    key.k1 = (uint32_t)(ent >> 32);
+  }
+  const int nm = q.m;
+  const uint64_t elem = key.elem0 + (uint64_t)(i / p.d) * (uint64_t)nm;      // the row's first Brownian channel
+  int j = 0;
+  int next_out = next_output_step(p.out_step, 0, p.n_out);
+  for (int k = 0; k < p.n_steps; ++k) {
+    const T* row = p.rows + (int64_t)k * 8;   // wave-uniform
+    const T dt = row[0], half_dt = row[1], rdt = row[2], sw = row[4], sh = row[5], th = row[6], t0 = row[7];
+    const uint32_t cell = p.cells[k];
+    T wv[MP], uv[MP];
+#pragma unroll
+    for (int c = 0; c < MP; ++c) wv[c] = uv[c] = (T)0;
+    if (q.quads) {
+#pragma unroll
+      for (int c = 0; c < MP / 4; ++c) {
+        if (4 * c < nm) {
+          T z[4];
+          normal4<T>(key, (elem >> 2) + (uint64_t)c, cell, 0, kStreamW, z);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wv[4 * c + e] = z[e] * sw;
+          if constexpr (kNeedU) {
+            normal4<T>(key, (elem >> 2) + (uint64_t)c, cell, 0, kStreamH, z);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) uv[4 * c + e] = th * ((T)0.5 * wv[4 * c + e] + z[e] * sh);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < MP; ++c) {
+        if (c < nm) {
+          wv[c] = normal1<T>(key, elem + (uint64_t)c, cell, 0, kStreamW) * sw;
+          if constexpr (kNeedU) uv[c] = th * ((T)0.5 * wv[c] + normal1<T>(key, elem + (uint64_t)c, cell, 0, kStreamH) * sh);
+        }
+      }
+    }
+    const T* gk = q.gtab + (int64_t)k * q.step_stride + col;
+    // sum_j G[c, j] * weight(j) for this lane's channels, ascending j
+    auto contract = [&](const T* G, auto weight) {
+      V acc((T)0);
+#pragma unroll
+      for (int c = 0; c < MP; ++c) {
+        if (c < nm) {
+          const Pack<T, W> gp = load<T, W>(G, (int64_t)c * p.d);
+          const T wc = weight(c);
+#pragma unroll
+          for (int e = 0; e < W; ++e) acc.v[e] = c == 0 ? gp.v[e] * wc : acc.v[e] + gp.v[e] * wc;
+        }
+      }
+      return acc;
+    };
+    m.tslot[0] = t0;
+    V y1;
+    if constexpr (METHOD == kEuler) {
+      y1 = (y + m.template f<0>(y) * dt) + contract(gk, [&](int c) { return wv[c]; });
+    } else if constexpr (METHOD == kMidpoint) {
+      m.tslot[1] = t0 + (T)0.5 * dt;
+      const V yp = (y + m.template f<0>(y) * half_dt) + (T)0.5 * contract(gk, [&](int c) { return wv[c]; });
+      y1 = (y + m.template f<1>(yp) * dt) + contract(gk + q.slot_stride, [&](int c) { return wv[c]; });
+    } else {
+      // slot 0: g(t0 + C1[0] dt) = g(t0 + dt); slot 1: g(t0 + C1[1] dt) = g(t0)
+      m.tslot[1] = t0 + (T)0.75 * dt;
+      const V f0 = m.template f<0>(y);
+      const V h = (y + ((T)0.75 * f0) * dt) + contract(gk, [&](int c) { return ((T)1.5 * uv[c]) * rdt; });
+      const V acc = (y + ((T)(1.0 / 3) * f0) * dt) + contract(gk, [&](int c) { return ((T)1 * wv[c]) + ((T)-1 * uv[c]) * rdt; });
+      const V f1 = m.template f<1>(h);
+      y1 = (acc + ((T)(2.0 / 3) * f1) * dt) +
+           contract(gk + q.slot_stride, [&](int c) { return ((T)0 * wv[c]) + ((T)1 * uv[c]) * rdt; });
+    }
+    if (__builtin_expect(k + 1 == next_out, 0)) {
+      while (j < p.n_out && p.out_step[j] == k + 1) {
+        const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
+        const bool exact = (w0 == (T)0 && w1 == (T)1);
+        Pack<T, W> ov;
+#pragma unroll
+        for (int e = 0; e < W; ++e) ov.v[e] = exact ? y1.v[e] : (w0 * y.v[e] + w1 * y1.v[e]);
+        store<T, W>(p.ys + (int64_t)j * p.n, i, ov);
+        ++j;
+      }
+      next_out = next_output_step(p.out_step, j, p.n_out);
+    }
+    y = y1;
+  }
+}
+
+template <typename T, int METHOD, int MP>
+static hipError_t launch_additive_mp(const ProgAdditiveArgs<T>& q, bool vec, hipStream_t s) {
+  const int64_t n = q.base.n;
+  if (vec) {
+    hipLaunchKernelGGL((trajectory_prog_additive_kernel<T, METHOD, 4, MP>), dim3((unsigned)(((n >> 2) + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, q);
+  } else {
+    hipLaunchKernelGGL((trajectory_prog_additive_kernel<T, METHOD, 1, MP>), dim3((unsigned)((n + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, q);
+  }
+  return hipGetLastError();
+}
+
+template <typename T, int METHOD>
+static hipError_t launch_additive_m(const ProgAdditiveArgs<T>& q, bool vec, hipStream_t s) {
+  if (q.m <= 4) return launch_additive_mp<T, METHOD, 4>(q, vec, s);
+  if (q.m <= 8) return launch_additive_mp<T, METHOD, 8>(q, vec, s);
+  if (q.m <= 16) return launch_additive_mp<T, METHOD, 16>(q, vec, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T>
+hipError_t launch_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const uint32_t* code,
+                                           int f_len, const void* consts, int n_const, const void* gtab, int time_dependent,
+                                           int method, const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev,
+                                           hipStream_t s) {
+  ProgAdditiveArgs<T> q;
+  ProgArgs<T>& p = q.base;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  if (f_len > kProgWords) return hipErrorInvalidValue;
+  for (int w = 0; w < kProgWords; ++w) p.code[w] = w < f_len ? code[w] : 0u;
+  p.consts = (const T*)consts;
+  p.f_len = f_len;
+  p.g_len = 0;
+  p.dg_len = 0;
+  p.n_const = n_const;
+  p.scalar_noise = 0;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key = key;
+  p.key_dev = key_dev;
+  if (p.n <= 0 || p.n_steps <= 0) return hipSuccess;
+  const int slots = method == kEuler ? 1 : 2;
+  q.gtab = (const T*)gtab;
+  q.slot_stride = time_dependent ? m * d : 0;
+  q.step_stride = time_dependent ? (int64_t)slots * m * d : 0;
+  q.m = (int32_t)m;
+  q.quads = (m % 4 == 0 && key.elem0 % 4 == 0) ? 1 : 0;
+  const bool can_vec = (d % 4 == 0) && aligned16(ys) && aligned16(y0) && aligned16(gtab) && ((p.n * sizeof(T)) % 16 == 0);
+  const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
+  switch (method) {
+    case kEuler: return launch_additive_m<T, kEuler>(q, vec, s);
+    case kMidpoint: return launch_additive_m<T, kMidpoint>(q, vec, s);
+    case kSrk: return launch_additive_m<T, kSrk>(q, vec, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template hipError_t launch_trajectory_prog_additive<float>(void*, const void*, int64_t, int64_t, int64_t, const uint32_t*, int,
+                                                           const void*, int, const void*, int, int, const tsde_traj_t*,
+                                                           NoiseKey, const uint64_t*, hipStream_t);
+template hipError_t launch_trajectory_prog_additive<double>(void*, const void*, int64_t, int64_t, int64_t, const uint32_t*, int,
+                                                            const void*, int, const void*, int, int, const tsde_traj_t*,
+                                                            NoiseKey, const uint64_t*, hipStream_t);
+
 template <typename T, int METHOD>
 static hipError_t launch_prog_m(const ProgArgs<T>& p, bool vec, hipStream_t s) {
   if (vec) {

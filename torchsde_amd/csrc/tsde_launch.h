@@ -127,6 +127,11 @@ hipError_t launch_trajectory_prog_diag(void* ys, void* sens, const int8_t* param
                                        const uint32_t* code, int f_len, int g_len, int dg_len, const void* consts, int n_const,
                                        int scalar_noise, int method, const tsde_traj_t* tr, NoiseKey key,
                                        const uint64_t* key_dev, hipStream_t s);
+template <typename T>
+hipError_t launch_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const uint32_t* code,
+                                           int f_len, const void* consts, int n_const, const void* gtab, int time_dependent,
+                                           int method, const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev,
+                                           hipStream_t s);
 // mlp_trajectory.hip
 hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, int64_t d, int64_t h, const void* W1,
                                       const void* b1, const void* W2, const void* b2, const void* c, const void* e,

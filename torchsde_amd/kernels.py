@@ -710,6 +710,32 @@ def trajectory_prog_diag(ys, y0, f_code, g_code, dg_code, consts, scalar_noise, 
     return ys
 
 
+def trajectory_prog_additive(ys, y0, f_code, consts, g_table, m, method, schedule, bm):
+    """All steps of an additive-noise SDE in one launch (``tsde_trajectory_prog_additive``): the drift an expression program,
+    the diffusion the table `g_table` -- (m, d), the transpose of the one matrix g, or (n_steps, slots, m, d) with the matrices
+    at the scheme's stage times (recognise.RecognisedAdditive)."""
+    _native.require_device(ys, y0, consts, g_table)
+    rows, d = y0.shape
+    if any(t.dtype != y0.dtype for t in (ys, consts, g_table)) or schedule.dtype != y0.dtype:
+        raise ValueError("schedule / output / constant / table dtype must equal the state dtype")
+    if not (ys.is_contiguous() and y0.is_contiguous() and consts.is_contiguous() and g_table.is_contiguous()) \
+            or ys.shape != (schedule.n_out, rows, d) or consts.dim() != 2 or consts.shape[1] != d:
+        raise ValueError("ys must be a contiguous (n_out, rows, d) tensor, y0 contiguous, consts (n_const, d)")
+    slots = 1 if int(method) == _native.TRAJ_EULER else 2
+    timed = g_table.dim() == 4
+    if tuple(g_table.shape) != ((schedule.n_steps, slots, m, d) if timed else (m, d)):
+        raise ValueError(f"g_table must be (m, d) or (n_steps, {slots}, m, d), got {tuple(g_table.shape)}")
+    code = (ctypes.c_uint32 * len(f_code))(*f_code)
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    rc = lib.tsde_trajectory_prog_additive(ys.data_ptr(), y0.data_ptr(), rows, d, int(m), code, len(f_code), consts.data_ptr(),
+                                           consts.shape[0], g_table.data_ptr(), int(timed), int(method), schedule.struct(),
+                                           bm._key, bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
+                                           dt_code, stream)
+    _native.check(rc, "tsde_trajectory_prog_additive")
+    return ys
+
+
 class _ProgTrajectoryFn(torch.autograd.Function):
     """Differentiable whole-trajectory solve of an SDE stated as expression programs: the forward launch also produces the
     path-wise sensitivities of every output element with respect to y0 and to up to four constant rows (the per-channel

@@ -1015,6 +1015,100 @@ def recognise_program(sde, t, y0, noise_type, rows=None, differentiable=False):
     return found
 
 
+class RecognisedAdditive:
+    """An additive-noise SDE (base_sde.py:101-102: g depends on t only) for `tsde_trajectory_prog_additive`: the drift as an
+    expression program, the diffusion as the table of its (d, m) matrix at the scheme's stage times."""
+    perceptron = neural = timed = False
+    exact = False
+    noise_type = "additive"
+
+    def __init__(self, f, table, m, time_dependent, d, dtype, device):
+        self.d, self.m, self.dtype, self.device, self.time_dependent = d, m, dtype, device, bool(time_dependent)
+        if f.trailing:
+            raise NotElementwise("a drift of the wrong shape")
+        if _Program.need(f) > _STACK_DEPTH:
+            raise NotElementwise("an expression that needs more than four intermediate values at once")
+        self.consts = []
+        prog = _Program(self.consts)
+        prog.compile(f)
+        if len(prog.words) > 96:
+            raise NotElementwise("a drift of more than 96 operations")
+        self.program = tuple(prog.words)
+        self.table = table          # (m, d), or (K, m, d): one matrix (transposed) per stage time, in the order of `times`
+
+    def structure(self):
+        return (("program", "additive", self.program), ("consts", len(self.consts)), ("g", self.m, self.time_dependent))
+
+    def affine_leaves(self):
+        return None
+
+    const_table = RecognisedProgram.const_table
+
+    def spec(self):
+        return ("program_additive", self.program, self.const_table(), self.table, self.m)
+
+
+def recognise_additive(sde, t, y0, times, rows=None, check_rows=False):
+    """Additive noise (the reference's ExAdditive, tests/problems.py:106-132): the drift's expression tree as for
+    `recognise_program`; the diffusion must not touch the state (it may use its SHAPE: `.repeat(y.size(0), 1, m)`) and is
+    tabulated: the user's `g` evaluated for every entry of `times` (the (K,) stage times of the solve) in ONE batched call
+    (`torch.vmap` over t), or once if it does not use t. `check_rows`: also confirm that every probe row got the same
+    matrix (one device synchronisation; the verifying solve asks for it)."""
+    rows = 2 if rows is None else int(rows)
+    if rows == y0.shape[0]:
+        rows += 1
+    d = y0.shape[1]
+    probe = y0.detach()[:1].expand(rows, d).clone() if y0.shape[0] > 0 else torch.zeros(rows, d, dtype=y0.dtype, device=y0.device)
+    t_probe = t.detach().clone()
+    drift = _TreeInterpreter(probe, t_probe, rows, d)
+    diffusion = _Interpreter(probe, t_probe, rows, d)
+    try:
+        with torch.no_grad():
+            with drift:
+                f = sde.f(t_probe, probe)
+            with diffusion:
+                g = sde.g(t_probe, probe)
+    except NotElementwise:
+        raise
+    except Exception as e:
+        raise NotElementwise(f"{type(e).__name__}: {e}") from None
+    tree = drift.form_of(f)
+    if not isinstance(tree, _Expr):
+        raise NotElementwise("the drift is not a tracked function of the state")
+    if not torch.is_tensor(g) or g.dim() != 3 or tuple(g.shape[:2]) != (rows, d) or g.dtype != y0.dtype or g.device != y0.device:
+        raise NotElementwise(f"the diffusion of an additive-noise SDE must have shape (rows, d, m), got "
+                             f"{tuple(getattr(g, 'shape', ()))}")
+    if any(id(g) in book for book in (diffusion.forms, diffusion.hidden, diffusion.nets, diffusion.time_state)):
+        raise NotElementwise("the diffusion of an additive-noise SDE is computed from the state")
+    m = int(g.shape[2])
+    if not 1 <= m <= 16:
+        raise NotElementwise(f"{m} Brownian channels (the additive-noise kernel takes up to 16)")
+    time_dependent = id(g) in diffusion.time
+    if time_dependent:
+        if times is None:
+            raise NotElementwise("no stage times for this scheme")
+        try:
+            with torch.no_grad():
+                g = torch.vmap(lambda tt: sde.g(tt, probe))(times.detach().to(t_probe.dtype))
+        except Exception as e:
+            raise NotElementwise(f"the diffusion cannot be evaluated for all stage times at once ({type(e).__name__}: {e})") \
+                from None
+        if tuple(g.shape) != (times.numel(), rows, d, m) or g.dtype != y0.dtype:
+            raise NotElementwise(f"the diffusion evaluated for all stage times has shape {tuple(g.shape)}")
+        # (to rounding: a network of t goes through a batched matrix product whose rows need not agree in the last bit)
+        tight = dict(rtol=1e-5, atol=1e-7) if g.dtype == torch.float32 else dict(rtol=1e-12, atol=1e-14)
+        if check_rows and not torch.allclose(g[:, 0], g[:, -1], **tight):
+            raise NotElementwise("the diffusion differs between batch rows")
+        table = g[:, 0].transpose(1, 2).contiguous()                 # (K, m, d)
+    else:
+        if check_rows and not torch.equal(g[0], g[-1]):
+            raise NotElementwise("the diffusion differs between batch rows")
+        table = g[0].t().contiguous()                                # (m, d)
+    found = RecognisedAdditive(tree, table, m, time_dependent, d, y0.dtype, y0.device)
+    found._alive = drift.keep + diffusion.keep
+    return found
+
+
 class Recognised:
     """What the interpretation found: the function codes and, per function, the four coefficients (None = neutral)."""
 
@@ -1296,7 +1390,9 @@ def describe(sde):
     lines = []
     for key, verdict in book["trusted"].items():
         structure, _, solver, sde_type, d, dtype, batch = key[:7]
-        kind = "perceptron drift" if structure[0][0] == "perceptron" else f"f: {structure[0][0]}, g: {structure[1][0]}"
+        kind = ("perceptron drift" if structure[0][0] == "perceptron"
+                else f"expression program, {structure[0][1]} noise" if structure[0][0] == "program"
+                else f"f: {structure[0][0]}, g: {structure[1][0]}")
         timed = any("table" in part for part in structure if isinstance(part, tuple))
         route = ("trajectory kernel" + (" with per-stage-time coefficient rows" if timed else "")
                  + (" (sensitivity kernel: autograd)" if key[7:] == ("autograd",) else ""))

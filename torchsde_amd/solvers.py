@@ -86,6 +86,10 @@ def _update_step_size(error_estimate, prev_step_size, prev_error_ratio, safety=0
     return prev_step_size * factor, prev_error_ratio
 
 
+class _Found(Exception):
+    """Control flow of `_integrate_recognised`: the additive route found its form, skip the other interpreters."""
+
+
 class BaseSDESolver:
     strong_order = None
     weak_order = None
@@ -325,6 +329,14 @@ class BaseSDESolver:
         noise), or None."""
         return None
 
+    def _additive_code(self):
+        """TSDE_TRAJ_* code of this scheme in the additive-noise kernel (`tsde_trajectory_prog_additive`: Euler, midpoint,
+        SRK = SRA1), or None."""
+        return None
+
+    # stage times at which a scheme evaluates an additive diffusion, as multiples of dt from t0 (sra1.py: C1 = (1, 0))
+    _ADDITIVE_SLOTS = {_native.TRAJ_EULER: (0,), _native.TRAJ_MIDPOINT: (0, 0.5), _native.TRAJ_SRK: (1, 0)}
+
     def _closed_form_coefficients(self, y0):
         """What `_integrate_trajectory` needs if the whole solve can run as ONE launch of a trajectory kernel, else
         None: a closed-form SDE handed to `sdeint` as is (closed_form.py) and this package's BrownianInterval
@@ -410,11 +422,14 @@ class BaseSDESolver:
         # ... and any other elementwise code (several functions of the state summed / multiplied, scalar noise): expression
         # programs (recognise.RecognisedProgram), every scheme with an in-register form
         programs = sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar) and self._program_code() is not None
+        # ... and additive noise: the drift a program, the diffusion tabulated at the scheme's stage times
+        additive = (sde.noise_type == NOISE_TYPES.additive and self._additive_code() is not None
+                    and not getattr(sde, "user_g_prod", False))
         precision = self.options.get("matrix_precision", "f32")
         if precision not in ("f32", "bf16x3"):
             raise ValueError(f"Expected options['matrix_precision'] in ('f32', 'bf16x3'), got {precision!r}.")
         if (not recognise.ENABLED or not self.options.get("trajectory_kernel", True) or self.adaptive or self.stateful
-                or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks or programs)):
+                or type(sde) is not ForwardSDE or sde.user_product or not (elementwise or networks or programs or additive)):
             return None
         if self._tracks_grad(y0):
             return self._integrate_recognised_with_grad(y0, ts) if (elementwise or programs) else None
@@ -424,6 +439,8 @@ class BaseSDESolver:
                 or y0.dtype not in (torch.float32, torch.float64) or ts.dtype != y0.dtype or bm.dtype != y0.dtype
                 or bm._rootW is not None or bm._rootH is not None or torch.cuda.is_current_stream_capturing()
                 or (self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
+            return None
+        if additive and (not hasattr(sde._base_sde, "f") or not hasattr(sde._base_sde, "g")):
             return None
         if sde.noise_type == NOISE_TYPES.diagonal and tuple(bm.shape) != tuple(y0.shape):
             return None
@@ -467,6 +484,13 @@ class BaseSDESolver:
 
         try:
             try:
+                if additive:
+                    times = self._stage_times(ts, y0.device, slots=self._ADDITIVE_SLOTS[self._additive_code()])
+                    found = recognise.recognise_additive(sde, ts[0], y0, times)
+                    spec = found.spec()
+                    if tuple(bm.shape) != (y0.shape[0], found.m):
+                        return None
+                    raise _Found()
                 if book.get("program") == (chain, type(self).__name__):
                     raise recognise.NotElementwise("(remembered: an expression program)")
                 if book.get("uses_t") == (chain, type(self).__name__):
@@ -486,9 +510,13 @@ class BaseSDESolver:
                     times = None
                     found, spec = as_program("drift or diffusion depends on t, and not only through arithmetic that "
                                              f"broadcasts ({e})")
+            except _Found:
+                pass
             except recognise.NotElementwise as e:
+                if additive:
+                    raise
                 found, spec = as_program(str(e))
-            if isinstance(found, recognise.RecognisedProgram):
+            if isinstance(found, (recognise.RecognisedProgram, recognise.RecognisedAdditive)):
                 pass
             elif found.neural:
                 if not networks or times is not None:
@@ -533,6 +561,13 @@ class BaseSDESolver:
         try:
             if spec[0] == "program_diagonal":
                 again = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, rows=5).spec(milstein)
+            elif spec[0] == "program_additive":
+                again = recognise.recognise_additive(sde, ts[0], y0, times, rows=5, check_rows=True).spec()
+                # (a diffusion that is a network of t comes out of another matrix-product kernel on the taller probe: its
+                #  table is compared to rounding; everything else bit for bit, below)
+                tight = dict(rtol=1e-5, atol=1e-7) if y0.dtype == torch.float32 else dict(rtol=1e-12, atol=1e-14)
+                if again[3].shape == spec[3].shape and torch.allclose(again[3], spec[3], **tight):
+                    again = again[:3] + (spec[3],) + again[4:]
             else:
                 again = recognise.recognise(sde, ts[0], y0, times=times, rows=5)
                 again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
@@ -719,11 +754,11 @@ class BaseSDESolver:
     _TIMED_SLOTS = {_native.TRAJ_EULER: (0,), _native.TRAJ_MILSTEIN_ITO: (0,), _native.TRAJ_MILSTEIN_STRAT: (0,),
                     _native.TRAJ_MIDPOINT: (0, 0.5), _native.TRAJ_SRK: (0, 0.25, 0.5, 1)}
 
-    def _stage_times(self, ts, device):
+    def _stage_times(self, ts, device, slots=None):
         """Every time at which this scheme evaluates f and g during the solve -- (K * S,) in ts.dtype on the device, the S
         stage times of step 0, then of step 1, ... -- computed like `_plan` computes the times the stepwise loop hands to
         the user's code (`t0 + frac * dt` in ts.dtype). Remembered by content."""
-        slots = self._TIMED_SLOTS.get(self._trajectory_code())
+        slots = self._TIMED_SLOTS.get(self._trajectory_code()) if slots is None else slots
         grid = timegrid.build(timegrid.ts_to_host(ts), self.dt)
         if slots is None or grid.n_steps == 0:
             return None
@@ -840,6 +875,19 @@ class BaseSDESolver:
             ys[0].copy_(y0c)
             K.trajectory_prog_diag(ys[1:], y0c, coefficients[1], coefficients[2], coefficients[3], coefficients[4],
                                    coefficients[5], self._program_code(), schedule, bm)
+            return ys
+        if coefficients[0] == "program_additive":
+            _, f_code, const_table, table, m = coefficients
+            code = self._additive_code()
+            if table.dim() == 3:
+                slots = len(self._ADDITIVE_SLOTS[code])
+                if table.shape[0] != grid.n_steps * slots:
+                    return None
+                table = table.view(grid.n_steps, slots, m, y0.shape[1])
+            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            K.trajectory_prog_additive(ys[1:], y0c, f_code, const_table, table, m, code, schedule, bm)
             return ys
         if coefficients[0] == "neural":
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
@@ -994,6 +1042,9 @@ class Euler(BaseSDESolver):
     def _program_code(self):
         return _native.TRAJ_EULER
 
+    def _additive_code(self):
+        return _native.TRAJ_EULER
+
     def _advance(self, y0, st, out):
         return self._drift_diffusion_update(st.times[0], y0, st.dt, 1.0, st.noise, out)
 
@@ -1017,6 +1068,9 @@ class Midpoint(BaseSDESolver):
         return _native.TRAJ_MIDPOINT
 
     def _program_code(self):
+        return _native.TRAJ_MIDPOINT
+
+    def _additive_code(self):
         return _native.TRAJ_MIDPOINT
 
     def _advance(self, y0, st, out):
@@ -1102,6 +1156,10 @@ class _Milstein(BaseSDESolver):
         if self.options[METHOD_OPTIONS.grad_free]:
             return None
         return _native.TRAJ_MILSTEIN_ITO if self.ito else _native.TRAJ_MILSTEIN_STRAT
+
+    def _additive_code(self):
+        # additive noise: the correction is zero (base_sde.py:157-158) and the step is Euler's (`_advance`)
+        return _native.TRAJ_EULER
 
     def _row_noise(self, noise, d):
         """Scalar noise: one increment per batch row, broadcast over the d state channels."""
@@ -1216,6 +1274,9 @@ class SRK(BaseSDESolver):
         return _native.TRAJ_SRK if self._diag() else None
 
     def _program_code(self):
+        return _native.TRAJ_SRK
+
+    def _additive_code(self):
         return _native.TRAJ_SRK
 
     def _neural_code(self):

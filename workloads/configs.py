@@ -86,6 +86,26 @@ WORKLOADS = {
         problem="scalar_ito", method="srk", levy="space-time", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
         kernel="tsde_srk_diag_stage<float> (4 stage kernels; user f, g: ~12 torch kernels per evaluation)"),
+    # The reference's additive-noise problem (ExAdditive, tests/problems.py:106-132: f and g use t; g repeated over m columns)
+    # with sdeint's default method for additive noise, SRK = SRA1 (sdeint.py:151, srk.py:90-111), as a drop-in call: the
+    # drift travels as an expression program, the diffusion as a table over the stage times (one batched call of g), the
+    # solve is ONE launch of tsde_trajectory_prog_additive; stepwise counterpart below (3 contractions + 2 f + 2 g per step)
+    "exadditive_srk_default_route_b65536_d64_m8": dict(
+        problem="additive_ito", method="srk", levy="space-time", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=3 * 4 * (64 * 8 + 3 * 64), kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_prog_additive<float, srk (SRA1), m = 8> (user module recognised: drift program + g(t) table)"),
+    "exadditive_euler_default_route_b65536_d64_m8": dict(
+        problem="additive_ito", method="euler", levy="none", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (64 * 8 + 3 * 64), kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_prog_additive<float, euler, m = 8> (user module recognised: drift program + g(t) table)"),
+    "exadditive_srk_b65536_d64_m8": dict(
+        problem="additive_ito", method="srk", levy="space-time", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=3 * 4 * (64 * 8 + 3 * 64), kid=2, launches_per_step=3, bench_steps=200,
+        kernel="tsde_step_general_w<float> (3 weighted contractions per step; user f x2, g x2: ~20 torch kernels per step)"),
+    "exadditive_euler_b65536_d64_m8": dict(
+        problem="additive_ito", method="euler", levy="none", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=4 * (64 * 8 + 3 * 64), kid=2, launches_per_step=1, bench_steps=200,
+        kernel="tsde_step_general<float> (user f, g: ~12 torch kernels per step)"),
     # BASELINE.json configs[1], STEPWISE (options={"trajectory_kernel": False}): the user's f and g run as torch kernels
     # between the per-step kernels -- the route of every SDE that is not a per-channel expression
     "c2_euler_diag_b65536_d64_s1000": dict(
