@@ -81,6 +81,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_euler_doublewell_b65536_d64_s1000", "c2_euler_doublewell_default_route_b65536_d64_s1000",
         "exadditive_srk_default_route_b65536_d64_m8", "exadditive_euler_default_route_b65536_d64_m8",
         "exadditive_srk_b65536_d64_m8", "exadditive_euler_b65536_d64_m8",
+        "neuraladditive_srk_default_route_b65536_d64_m8", "neuraladditive_srk_b65536_d64_m8",
         "c2_euler_exscalar_b65536_d64_s1000", "c2_srk_exscalar_b65536_d64_s1000",
         "c2_srk_exscalar_default_route_b65536_d64_s1000",
         "c2_euler_exscalar_default_route_b65536_d64_s1000", "c2_euler_exscalar_training_default_route_b65536_d64_s1000",

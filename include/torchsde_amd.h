@@ -466,6 +466,7 @@ int tsde_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_
 #define TSDE_NOISE_DIAGONAL 0
 #define TSDE_NOISE_SCALAR 1
 #define TSDE_NOISE_GENERAL 2
+#define TSDE_NOISE_ADDITIVE 3   /* tsde_trajectory_mlp_additive only */
 typedef struct tsde_mlp {
   const void* w1;
   const void* w1t;
@@ -506,6 +507,17 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
                                 uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
 int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden,
                                         int64_t diffusion_out, int noise);
+
+/* The same kernel for ADDITIVE noise (base_sde.py:101-102; the reference's NeuralAdditive, tests/problems.py:195-224: the
+ * drift a perceptron of cat([t, y]), the diffusion a function of t only): no diffusion net -- the (d, m) matrix arrives as
+ * the table of tsde_trajectory_prog_additive (same layout, same stage times: g_time_dependent == 0: (m, d);
+ * else (n_steps, slots, m, d) with slots = 1 Euler, 2 midpoint (t_k, t_k + dt/2), 2 SRK (t_k + dt, t_k)) and is contracted
+ * with the row's increments on the matrix cores. method: TSDE_TRAJ_EULER (also Milstein with additive noise),
+ * TSDE_TRAJ_MIDPOINT, TSDE_TRAJ_SRK (SRA1, srk.py:90-111: two drift evaluations per step, at t_k and t_k + 3/4 dt).
+ * 1 <= m <= 16, any elem0; d a multiple of 4 up to 64, hidden up to 64; dtype TSDE_F32. */
+int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const tsde_mlp_t* drift,
+                                 const void* g_table, int g_time_dependent, int method, const tsde_traj_t* traj,
+                                 uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
 
 /* tsde_trajectory_affine_diag for drift and diffusion given as elementwise expressions per state channel:
  *     f = coef[0] * phi_f(coef[1] * y + coef[2]) + coef[3]        g = coef[4] * phi_g(coef[5] * y + coef[6]) + coef[7]

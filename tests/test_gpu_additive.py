@@ -85,6 +85,48 @@ def test_a_diffusion_that_is_a_network_of_t(method, sde_type, levy):
     _check(sde, method, levy, 8, 4)
 
 
+@pytest.mark.parametrize("d,m,hidden", [(8, 3, 8), (16, 4, 32), (12, 5, 8), (32, 8, 64), (64, 16, 40), (20, 2, 8)])
+@pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
+def test_the_references_neural_additive_problem_is_one_launch(method, sde_type, levy, d, m, hidden):
+    """NeuralAdditive (tests/problems.py:195-224): f_net of cat([t, y]) on the matrix cores (`tsde_trajectory_mlp_additive`),
+    g_net of t alone tabulated over the stage times and contracted with the increments by one more MFMA per four channels."""
+    sde = problems.MLPNetAdditive(d, m, sde_type, hidden=hidden).to(DEV)
+    _solve(sde, 1, method, levy, d, m)
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    fast, launches = _launches(lambda: _solve(sde, 2, method, levy, d, m))
+    assert launches == 1
+    torch.testing.assert_close(fast, _solve(sde, 2, method, levy, d, m, stepwise=True), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("method,levy", [("euler", "none"), ("srk", "space-time")])
+def test_neural_additive_rows_vs_oracle(method, levy):
+    """16384 x 32 x 8, hidden 64, 500 steps: sampled rows against the oracle's restatement of the reference's loop on the same
+    Brownian path (the bound of tests/test_gpu_full_size_oracle.py)."""
+    import torchsde_amd
+    from tests.test_gpu_full_size_oracle import _oracle_forward
+    Bf, d, m, n, dt = 16384, 32, 8, 500, 2.0 ** -9
+    sde = problems.MLPNetAdditive(d, m, "ito", hidden=64).to(DEV)
+    y0 = torch.full((Bf, d), 0.1, device=DEV)
+    ts = torch.tensor([0.0, n * dt], device=DEV)
+
+    def bm(entropy):
+        return torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bf, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt,
+                                             levy_area_approximation=levy)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(8, before))
+    try:
+        with torch.no_grad():
+            torchsde_amd.sdeint(sde, y0, ts, bm=bm(5), method=method, dt=dt)
+            ys, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=bm(20240601), method=method, dt=dt))
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        rows = helpers.sampled_rows(Bf, 48, seed=8, seams=(2, 16, Bf - 2))
+        ref32, ref64 = _oracle_forward(sde, rows, d, m, 20240601, n, dt, method, 0.1, levy=levy != "none")
+        helpers.assert_within_reference_rounding(ys[-1][torch.from_numpy(rows).to(DEV)], ref32[-1], ref64[-1],
+                                                 f"neural additive, {method}, matrix-core kernel")
+    finally:
+        torch.set_num_threads(before)
+
+
 def test_parameters_are_read_at_every_solve_and_row_offsets_shard():
     """The table and the constants are this solve's live values (an optimiser step between solves is seen); two shards with
     row offsets reproduce the unsharded solve bit for bit (the increments are addressed by global row)."""

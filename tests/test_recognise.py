@@ -574,3 +574,20 @@ def test_additive_noise_refusals():
                            (Random, 4, "random"), (MatrixDrift, 4, "aten::mm"), (problems.AdditiveShared, 32, "up to 16")):
         with pytest.raises(recognise.NotElementwise, match=reason):
             recognise.recognise_additive(ForwardSDE(cls(D, m)), t, y, times, check_rows=True)
+
+
+def test_additive_noise_with_a_network_drift():
+    """The reference's NeuralAdditive (tests/problems.py:195-224): the drift is followed as a perceptron of cat([t, y]) (time
+    column split off), the diffusion tabulated."""
+    sde = ForwardSDE(problems.MLPNetAdditive(8, 3, hidden=16))
+    y, t, times = torch.randn(16, 8), torch.tensor(0.3), torch.linspace(0.0, 1.0, 7)
+    found = recognise.recognise_additive(sde, t, y, times, check_rows=True)
+    kind, net, _, table, m = found.spec()
+    assert kind == "neural_additive" and m == 3 and table.shape == (7, 3, 8) and found.structure()[0][0] == "perceptron"
+    w1, w1t, b1, w2, b2 = net.tensors
+    assert w1.shape == (8, 16) and w1t.shape == (16,) and w2.shape == (16, 8)
+    with torch.no_grad():
+        hidden = torch.nn.functional.softplus(y @ w1 + w1t * t + b1)
+        torch.testing.assert_close(hidden @ w2 + b2, sde.f(t, y), rtol=1e-5, atol=1e-6)
+    again = recognise.recognise_additive(sde, t, y, times, rows=5, check_rows=True)
+    assert again.structure() == found.structure() and again.spec()[1] == net

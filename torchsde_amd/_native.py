@@ -20,7 +20,7 @@ ACT_TANH, ACT_SOFTPLUS = 0, 1
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 FINAL_NONE, FINAL_SIGMOID = 0, 1
 PRECISION_F32, PRECISION_BF16X3 = 0, 1
-NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL = 0, 1, 2
+NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL, NOISE_ADDITIVE = 0, 1, 2, 3
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
 FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6, "poly3": 7}
 
@@ -149,6 +149,8 @@ SIGNATURES = {
                                                 _c_ptr]),
     "tsde_trajectory_prog_additive": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i32, _c_ptr, _c_i32, _c_ptr,
                                                _c_int, _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_trajectory_mlp_additive": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, ctypes.POINTER(Mlp), _c_ptr, _c_int, _c_int,
+                                              ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_trajectory_mlp_general": (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(Mlp),
                                              ctypes.POINTER(Mlp), _c_int, ctypes.POINTER(Traj), _c_u64, _c_u64, _c_ptr, _c_int,
                                              _c_ptr]),

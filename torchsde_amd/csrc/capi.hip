@@ -578,6 +578,37 @@ int tsde_trajectory_prog_diag_sens(void* ys, void* sens, const void* y0, int64_t
                    n_const, scalar_noise, method, traj, entropy, elem0, entropy_dev, dtype, stream);
 }
 
+int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const tsde_mlp_t* drift,
+                                 const void* g_table, int g_time_dependent, int method, const tsde_traj_t* traj,
+                                 uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_trajectory_mlp_additive";
+  if (!ys || !y0 || !drift || !g_table || !traj) return bad_arg(where, "null argument");
+  if (!drift->w1 || !drift->b1 || !drift->w2 || !drift->b2) return bad_arg(where, "a perceptron without weights or biases");
+  if (drift->hidden < 1 || drift->hidden > 64) return bad_arg(where, "hidden sizes must be in [1, 64]");
+  if (drift->activation != TSDE_ACT_TANH && drift->activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
+  if (drift->precision != TSDE_PRECISION_F32) return bad_arg(where, "the drift runs in exact f32");
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (rows < 0) return bad_arg(where, "need rows >= 0");
+  if (d < 4 || d > 64 || d % 4 != 0) return bad_arg(where, "need d a multiple of 4 in [4, 64]");
+  if (m < 1 || m > 16) return bad_arg(where, "need 1 <= m <= 16 Brownian channels");
+  if (drift->out != d || drift->final != TSDE_FINAL_NONE || drift->scale != 1.0)
+    return bad_arg(where, "the drift maps to d channels, with no output function and scale 1");
+  if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
+    return bad_arg(where, "ys and y0 must be 16-byte aligned");
+  if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
+  if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT && method != TSDE_TRAJ_SRK)
+    return bad_arg(where, "method must be Euler, midpoint or SRK (SRA1)");
+  if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_TRAJECTORY, s);
+  const hipError_t e = tsde::launch_trajectory_mlp_additive(ys, y0, rows, d, m, drift, g_table, g_time_dependent != 0, method,
+                                                            traj, make_key(entropy, elem0), entropy_dev, s);
+  if (e == hipErrorInvalidValue) return bad_arg(where, "no kernel for this shape");
+  return fail(e, where);
+}
+
 int tsde_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const uint32_t* code,
                                   int32_t f_len, const void* consts, int32_t n_const, const void* g_table,
                                   int g_time_dependent, int method, const tsde_traj_t* traj, uint64_t entropy, uint64_t elem0,

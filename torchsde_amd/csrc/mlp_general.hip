@@ -6,6 +6,9 @@
 //         general noise : (rows, d * m) read as (rows, d, m)  -> the step adds  sum_j g[., i, j] dW[., j]
 //         diagonal noise: (rows, d)                            -> g[., i] dW[., i]
 //         scalar noise  : (rows, d), one Brownian channel/row  -> g[., i] dW[.]
+//         additive noise: no diffusion net -- g depends on t only and arrives as a TABLE of its (d, m) matrix at the
+//                         scheme's stage times (the reference's NeuralAdditive, tests/problems.py:195-224, whose g is a
+//                         network of t alone: the host evaluates it for all stage times in one batched call)
 //
 // `w1t` is the first layer's weight column of the TIME input, torch.cat([t.expand(B, 1), y], 1) in the reference's
 // modules: per stage time it is one more bias, b1 + w1t * t, so t never becomes a matrix operand.
@@ -61,12 +64,16 @@ struct NeuralArgs {
   int32_t method;           // TSDE_TRAJ_EULER | TSDE_TRAJ_MIDPOINT | TSDE_TRAJ_SRK (diagonal / scalar noise)
   NoiseKey key;
   const uint64_t* key_dev;
+  const float* gtab;        // additive noise: (m, d) or (n_steps, slots, m, d), the diffusion matrix transposed
+  int64_t g_step_stride, g_slot_stride;     // floats; 0 for a matrix that does not depend on t
 };
 
-// MODE: 0 = diagonal noise, 1 = scalar noise, else general noise with m = MODE Brownian channels (4, 8, 16, 32).
+// MODE: 0 = diagonal noise, 1 = scalar noise, 2 = additive noise (table), else general noise with m = MODE Brownian
+// channels (4, 8, 16, 32).
 template <int MODE>
 struct NoiseShape {
   static constexpr bool kGeneral = MODE >= 4;
+  static constexpr bool kTable = MODE == 2;
   static constexpr int M = kGeneral ? MODE : 1;
   // tiles of G^T handled together (independent accumulator chains: a dependent f32 MFMA waits 40 cycles, issue is 32)
   static constexpr int G = (M >= 32) ? M / 16 : 2;
@@ -479,6 +486,40 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
       }
     };
 
+    // additive noise: (G w)^T in the state's layout, D[i][n] = sum_j G[i][j] w[n][j] on the matrix cores -- lane (part, n)
+    // supplies A[i = n][k = part] = G[16 t + n][4 kk + part] (read from the table: a few KB, cache-resident) and
+    // B[k = part][n] = the weight of ITS batch row for Brownian channel j = 4 kk + part, drawn by the lane itself
+    // (element row * m + j of the (rows, m) field; every channel count and alignment). m <= 16: four k-blocks.
+    auto table_increments = [&](uint32_t cell, float sw, float sh, float th_, bool need_u, float* wj, float* uj) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        wj[kk] = 0.0f;
+        uj[kk] = 0.0f;
+        const int j = 4 * kk + part;
+        if (4 * kk < p.m && j < p.m) {
+          const uint64_t e = key.elem0 + (uint64_t)row * (uint64_t)p.m + (uint64_t)j;
+          wj[kk] = normal1<float>(key, e, cell, 0, kStreamW) * sw;
+          if (need_u) uj[kk] = th_ * (0.5f * wj[kk] + normal1<float>(key, e, cell, 0, kStreamH) * sh);
+        }
+      }
+    };
+    auto table_product = [&](const float* Gt, const float* wsel, f32x4* gdw) {
+#pragma unroll
+      for (int t = 0; t < TD; ++t) gdw[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (4 * kk < p.m) {
+          const int j = 4 * kk + part;
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+            const int ch = 16 * t + n;
+            const float a = (j < p.m && ch < dT) ? Gt[j * dT + ch] : 0.0f;
+            gdw[t] = Tile<16>::mfma(a, wsel[kk], gdw[t]);
+          }
+        }
+      }
+    };
+
     int jout = 0;
     for (int k = 0; k < p.n_steps; ++k) {
       const float* srow = p.rows + (int64_t)k * 8;
@@ -486,7 +527,65 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
       const uint32_t cell = p.cells[k];
       f32x4 hid[TH], f[TD], gdw[TD], yn[TD];
       bool stepped = false;
-      if constexpr (!NS::kGeneral) {
+      if constexpr (NS::kTable) {
+        // additive noise (base_sde.py:101-102): Euler (euler.py:29-37), midpoint (midpoint.py:29-45), SRK = SRA1
+        // (srk.py:90-111, tableaus/sra1.py: C0 = (0, 3/4), C1 = (1, 0)) in the stepwise route's operation order
+        const float rdt = srow[2], sh = srow[5], th_ = srow[6];
+        const float* gk = p.gtab + (int64_t)k * p.g_step_stride;
+        float wj[4], uj[4], ws[4];
+        table_increments(cell, sw, sh, th_, p.method == TSDE_TRAJ_SRK, wj, uj);
+        hidden_layer(W1f, b1f, wtf, p.f.act, t0, y, hid);
+        drift(hid, f);
+        if (p.method == TSDE_TRAJ_SRK) {
+          f32x4 h[TD], acc[TD];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) ws[kk] = (1.5f * uj[kk]) * rdt;
+          table_product(gk, ws, gdw);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[t][r] = (y[t][r] + (0.75f * f[t][r]) * dt) + gdw[t][r];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) ws[kk] = (1.0f * wj[kk]) + (-1.0f * uj[kk]) * rdt;
+          table_product(gk, ws, gdw);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = (y[t][r] + ((float)(1.0 / 3) * f[t][r]) * dt) + gdw[t][r];
+          }
+          hidden_layer(W1f, b1f, wtf, p.f.act, t0 + 0.75f * dt, h, hid);
+          drift(hid, f);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) ws[kk] = (0.0f * wj[kk]) + (1.0f * uj[kk]) * rdt;
+          table_product(gk + p.g_slot_stride, ws, gdw);
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yn[t][r] = (acc[t][r] + ((float)(2.0 / 3) * f[t][r]) * dt) + gdw[t][r];
+          }
+        } else {
+          table_product(gk, wj, gdw);
+          if (midpoint) {
+            f32x4 yp[TD];
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) yp[t][r] = (y[t][r] + f[t][r] * half_dt) + 0.5f * gdw[t][r];
+            }
+            hidden_layer(W1f, b1f, wtf, p.f.act, t0 + half_dt, yp, hid);
+            drift(hid, f);
+            table_product(gk + p.g_slot_stride, wj, gdw);
+          }
+#pragma unroll
+          for (int t = 0; t < TD; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yn[t][r] = (y[t][r] + f[t][r] * dt) + gdw[t][r];
+          }
+        }
+        stepped = true;
+      }
+      if constexpr (MODE <= 1) {
         if (p.method == TSDE_TRAJ_SRK) {
           // SRID2 (srk.py:57-88, tableaus/srid2.py) for diagonal / scalar noise with BOTH functions networks: three drift
           // evaluations f(t, y), f(t + dt, H0_1), f(t + dt/2, H0_2) (the tableau's alpha_3 = 0) and four diffusion
@@ -567,6 +666,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           stepped = true;
         }
       }
+      if constexpr (!NS::kTable) {
       if (!stepped) {
       hidden_layer(W1f, b1f, wtf, p.f.act, t0, y, hid);
       drift(hid, f);
@@ -590,6 +690,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
       for (int t = 0; t < TD; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) yn[t][r] = (y[t][r] + f[t][r] * dt) + gdw[t][r];          // euler.py:36
+      }
       }
       }
       // outputs due at the end of this step: w0 y_k + w1 y_{k+1} (base_solver.py:147, interp.py:15-18)
@@ -657,6 +758,7 @@ template <int D, int H>
 static hipError_t launch_neural_dh(const NeuralArgs& p, int noise, hipStream_t s) {
   if (noise == TSDE_NOISE_DIAGONAL) return launch_neural_mode<D, H, 0>(p, s);
   if (noise == TSDE_NOISE_SCALAR) return launch_neural_mode<D, H, 1>(p, s);
+  if (noise == TSDE_NOISE_ADDITIVE) return launch_neural_mode<D, H, 2>(p, s);
   switch (p.m) {
     case 4: return launch_neural_mode<D, H, 4>(p, s);
     case 8: return launch_neural_mode<D, H, 8>(p, s);
@@ -726,10 +828,45 @@ hipError_t launch_trajectory_mlp_general(void* ys, const void* y0, int64_t rows,
   p.method = method;
   p.key = key;
   p.key_dev = key_dev;
+  p.gtab = nullptr;
+  p.g_step_stride = p.g_slot_stride = 0;
   if (rows <= 0 || tr->n_steps <= 0) return hipSuccess;
   if (d <= 16) return launch_neural_d<16>(p, noise, s);
   if (d <= 32) return launch_neural_d<32>(p, noise, s);
   if (d <= 64) return launch_neural_d<64>(p, noise, s);
+  return hipErrorInvalidValue;
+}
+
+// Additive noise: the drift a perceptron of (t, y), the diffusion a table (see the kernel's MODE 2).
+hipError_t launch_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const tsde_mlp_t* drift,
+                                          const void* gtab, int time_dependent, int method, const tsde_traj_t* tr,
+                                          NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
+  NeuralArgs p;
+  p.split = 0;
+  p.ys = (float*)ys;
+  p.y0 = (const float*)y0;
+  p.f = device_view(drift);
+  p.g = NeuralNet{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, TSDE_ACT_TANH, TSDE_FINAL_NONE, 1.0f};
+  p.rows = (const float*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const float*)tr->out_w;
+  p.B = rows;
+  p.d = (int32_t)d;
+  p.m = (int32_t)m;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.method = method;
+  p.key = key;
+  p.key_dev = key_dev;
+  const int slots = method == TSDE_TRAJ_EULER ? 1 : 2;
+  p.gtab = (const float*)gtab;
+  p.g_slot_stride = time_dependent ? m * d : 0;
+  p.g_step_stride = time_dependent ? (int64_t)slots * m * d : 0;
+  if (rows <= 0 || tr->n_steps <= 0) return hipSuccess;
+  if (d <= 16) return launch_neural_d<16>(p, TSDE_NOISE_ADDITIVE, s);
+  if (d <= 32) return launch_neural_d<32>(p, TSDE_NOISE_ADDITIVE, s);
+  if (d <= 64) return launch_neural_d<64>(p, TSDE_NOISE_ADDITIVE, s);
   return hipErrorInvalidValue;
 }
 

@@ -141,6 +141,9 @@ hipError_t launch_trajectory_mlp_diag(void* ys, const void* y0, int64_t rows, in
 hipError_t launch_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
                                          const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method,
                                          const tsde_traj_t* tr, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
+hipError_t launch_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const tsde_mlp_t* drift,
+                                          const void* gtab, int time_dependent, int method, const tsde_traj_t* tr,
+                                          NoiseKey key, const uint64_t* key_dev, hipStream_t s);
 size_t neural_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t out, int noise);
 // mlp_backward.hip
 hipError_t launch_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hid, void* stash_delta,

@@ -877,6 +877,30 @@ def trajectory_mlp_general(ys, y0, drift, diffusion, noise, m, method, schedule,
     return ys
 
 
+def trajectory_mlp_additive(ys, y0, drift, g_table, m, method, schedule, bm):
+    """All steps of an additive-noise SDE whose drift is a two-layer perceptron of (t, y) in one launch
+    (``tsde_trajectory_mlp_additive``); `g_table` as for `trajectory_prog_additive`."""
+    tensors = [ys, y0, g_table] + [t for t in drift.tensors if t is not None]
+    _native.require_device(*tensors)
+    rows, d = y0.shape
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        raise ValueError("the neural-SDE kernel takes contiguous float32 tensors")
+    if ys.shape != (schedule.n_out, rows, d):
+        raise ValueError("shape mismatch: ys (n_out, rows, d)")
+    slots = 1 if int(method) == _native.TRAJ_EULER else 2
+    timed = g_table.dim() == 4
+    if tuple(g_table.shape) != ((schedule.n_steps, slots, m, d) if timed else (m, d)):
+        raise ValueError(f"g_table must be (m, d) or (n_steps, {slots}, m, d), got {tuple(g_table.shape)}")
+    lib, dt_code, stream = _launch_env(y0)
+    entropy_dev = bm._entropy_dev
+    code = lib.tsde_trajectory_mlp_additive(
+        ys.data_ptr(), y0.data_ptr(), rows, d, int(m), ctypes.byref(drift.struct()), g_table.data_ptr(), int(timed),
+        int(method), schedule.struct(), bm._key, bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
+        dt_code, stream)
+    _native.check(code, "tsde_trajectory_mlp_additive")
+    return ys
+
+
 class _TrajectoryFn(torch.autograd.Function):
     """Differentiable whole-trajectory solve of an affine diagonal SDE: the forward launch also produces the
     path-wise sensitivities of every output element (forward-mode tangents carried in registers), and the backward

@@ -1024,6 +1024,19 @@ class RecognisedAdditive:
 
     def __init__(self, f, table, m, time_dependent, d, dtype, device):
         self.d, self.m, self.dtype, self.device, self.time_dependent = d, m, dtype, device, bool(time_dependent)
+        self.table = table          # (m, d), or (K, m, d): one matrix (transposed) per stage time, in the order of `times`
+        self.net, self.program, self.consts = None, None, []
+        if isinstance(f, _Perceptron):
+            # the drift of the reference's NeuralAdditive (tests/problems.py:203-217): a perceptron of cat([t, y])
+            if dtype != torch.float32 or d % 4 != 0 or d > 64:
+                raise NotElementwise("a drift network outside the neural-SDE kernel's shapes (float32, d a multiple of 4 up "
+                                     "to 64)")
+            if f.out != d or f.final is not None or f.scale != 1.0 or f.shape[1:] != (d,) or f.w1.shape[0] > 64:
+                raise NotElementwise("a drift network that does not map to the state channels (or is wider than 64)")
+            if any(t is not None and (t.dtype != torch.float32 or t.device != device) for t in (f.w1, f.b1, f.w2, f.b2, f.wt)):
+                raise NotElementwise("network weights of another dtype or device than the state")
+            self.net = f
+            return
         if f.trailing:
             raise NotElementwise("a drift of the wrong shape")
         if _Program.need(f) > _STACK_DEPTH:
@@ -1034,9 +1047,12 @@ class RecognisedAdditive:
         if len(prog.words) > 96:
             raise NotElementwise("a drift of more than 96 operations")
         self.program = tuple(prog.words)
-        self.table = table          # (m, d), or (K, m, d): one matrix (transposed) per stage time, in the order of `times`
 
     def structure(self):
+        if self.net is not None:
+            f = self.net
+            return (("perceptron", "additive", f.act, tuple(f.w1.shape), f.wt is not None, f.b1 is not None, f.b2 is not None),
+                    ("consts", 0), ("g", self.m, self.time_dependent))
         return (("program", "additive", self.program), ("consts", len(self.consts)), ("g", self.m, self.time_dependent))
 
     def affine_leaves(self):
@@ -1045,6 +1061,15 @@ class RecognisedAdditive:
     const_table = RecognisedProgram.const_table
 
     def spec(self):
+        if self.net is not None:
+            from . import kernels as K
+            f = self.net
+            hidden = f.w1.shape[0]
+            b1 = f.b1.detach() if f.b1 is not None else _constant_vector(0.0, hidden, self.dtype, self.device)
+            b2 = f.b2.detach() if f.b2 is not None else _constant_vector(0.0, f.out, self.dtype, self.device)
+            net = K.NeuralNet(f.w1.detach().t(), None if f.wt is None else f.wt.detach(), b1, f.w2.detach().t(), b2,
+                              Recognised._ACTIVATIONS[f.act])
+            return ("neural_additive", net, None, self.table, self.m)
         return ("program_additive", self.program, self.const_table(), self.table, self.m)
 
 
@@ -1062,19 +1087,32 @@ def recognise_additive(sde, t, y0, times, rows=None, check_rows=False):
     t_probe = t.detach().clone()
     drift = _TreeInterpreter(probe, t_probe, rows, d)
     diffusion = _Interpreter(probe, t_probe, rows, d)
+    tree = None
     try:
         with torch.no_grad():
-            with drift:
-                f = sde.f(t_probe, probe)
+            try:
+                with drift:
+                    f = sde.f(t_probe, probe)
+                tree = drift.form_of(f)
+                if not isinstance(tree, _Expr):
+                    raise NotElementwise("the drift is not a tracked function of the state")
+            except NotElementwise as first:
+                # not elementwise code: a perceptron of (t, y)? (the single-function interpreter follows networks)
+                drift = _Interpreter(probe, t_probe, rows, d)
+                try:
+                    with drift:
+                        f = sde.f(t_probe, probe)
+                except NotElementwise as second:
+                    raise NotElementwise(f"{first}; as a network: {second}") from None
+                tree = drift.net_of(f)
+                if tree is None:
+                    raise NotElementwise(f"{first}; and the drift is not a two-layer network either") from None
             with diffusion:
                 g = sde.g(t_probe, probe)
     except NotElementwise:
         raise
     except Exception as e:
         raise NotElementwise(f"{type(e).__name__}: {e}") from None
-    tree = drift.form_of(f)
-    if not isinstance(tree, _Expr):
-        raise NotElementwise("the drift is not a tracked function of the state")
     if not torch.is_tensor(g) or g.dim() != 3 or tuple(g.shape[:2]) != (rows, d) or g.dtype != y0.dtype or g.device != y0.device:
         raise NotElementwise(f"the diffusion of an additive-noise SDE must have shape (rows, d, m), got "
                              f"{tuple(getattr(g, 'shape', ()))}")

@@ -561,7 +561,7 @@ class BaseSDESolver:
         try:
             if spec[0] == "program_diagonal":
                 again = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, rows=5).spec(milstein)
-            elif spec[0] == "program_additive":
+            elif spec[0] in ("program_additive", "neural_additive"):
                 again = recognise.recognise_additive(sde, ts[0], y0, times, rows=5, check_rows=True).spec()
                 # (a diffusion that is a network of t comes out of another matrix-product kernel on the taller probe: its
                 #  table is compared to rounding; everything else bit for bit, below)
@@ -591,7 +591,7 @@ class BaseSDESolver:
         self._extra = ()
         stepwise = self._run(self._plan(y0, ts), y0)
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
-        if spec[0] in ("mlp_diagonal", "neural"):      # the matrix cores sum the layers' products in another order than the library
+        if spec[0] in ("mlp_diagonal", "neural", "neural_additive"):      # the matrix cores sum the layers' products in another order than the library
             rtol, atol = 1e-3, 1e-4
         both_nan = fast.isnan() & stepwise.isnan()
         close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
@@ -876,8 +876,8 @@ class BaseSDESolver:
             K.trajectory_prog_diag(ys[1:], y0c, coefficients[1], coefficients[2], coefficients[3], coefficients[4],
                                    coefficients[5], self._program_code(), schedule, bm)
             return ys
-        if coefficients[0] == "program_additive":
-            _, f_code, const_table, table, m = coefficients
+        if coefficients[0] in ("program_additive", "neural_additive"):
+            kind, f_code, const_table, table, m = coefficients
             code = self._additive_code()
             if table.dim() == 3:
                 slots = len(self._ADDITIVE_SLOTS[code])
@@ -887,7 +887,10 @@ class BaseSDESolver:
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
             ys[0].copy_(y0c)
-            K.trajectory_prog_additive(ys[1:], y0c, f_code, const_table, table, m, code, schedule, bm)
+            if kind == "neural_additive":
+                K.trajectory_mlp_additive(ys[1:], y0c, f_code, table, m, code, schedule, bm)       # (f_code: the drift net)
+            else:
+                K.trajectory_prog_additive(ys[1:], y0c, f_code, const_table, table, m, code, schedule, bm)
             return ys
         if coefficients[0] == "neural":
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()

@@ -98,6 +98,16 @@ WORKLOADS = {
         problem="additive_ito", method="euler", levy="none", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=4 * (64 * 8 + 3 * 64), kid=8, trajectory=True, recognised=True,
         kernel="tsde_trajectory_prog_additive<float, euler, m = 8> (user module recognised: drift program + g(t) table)"),
+    # ... and the reference's NeuralAdditive (tests/problems.py:195-224; hidden 64): f_net of cat([t, y]) on the matrix cores,
+    # g_net of t alone tabulated, the default method (SRK = SRA1)
+    "neuraladditive_srk_default_route_b65536_d64_m8": dict(
+        problem="netadditive_big", method="srk", levy="space-time", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
+        kid=8, trajectory=True, recognised=True, mfma_flops_per_traj_step=2 * 2 * (64 * 64 + 64 * 64) + 3 * 2 * 64 * 8,
+        kernel="tsde_trajectory_mlp_additive<64, 64, srk (SRA1), m = 8> (neural_trajectory_kernel; user module recognised)"),
+    "neuraladditive_srk_b65536_d64_m8": dict(
+        problem="netadditive_big", method="srk", levy="space-time", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=3 * 4 * (64 * 8 + 3 * 64), kid=2, launches_per_step=3, bench_steps=200,
+        kernel="tsde_step_general_w<float> (3 weighted contractions per step; user f_net x2, g_net x2)"),
     "exadditive_srk_b65536_d64_m8": dict(
         problem="additive_ito", method="srk", levy="space-time", B=65536, d=64, m=8, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=3 * 4 * (64 * 8 + 3 * 64), kid=2, launches_per_step=3, bench_steps=200,
@@ -295,6 +305,8 @@ def make_problem(name, d, m, dev):
     from . import problems
     if name == "general_big":      # NeuralGeneral-style: hidden 64
         return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
+    if name == "netadditive_big":
+        return problems.MLPNetAdditive(d, m, "ito", hidden=64).to(dev)
     if name == "netdiag_big":
         return problems.MLPNetDiag(d, "ito", hidden=64).to(dev)
     if name == "general_big_strat":

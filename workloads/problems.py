@@ -175,6 +175,25 @@ class MLPNetScalar(MLPNetDiag):
         return 0.1 * self.g_net(self._ty(t, y)).unsqueeze(-1)
 
 
+class MLPNetAdditive(nn.Module):
+    """... and the reference's NeuralAdditive (tests/problems.py:195-224): the drift a net of (t, y), the diffusion a net of
+    t alone reshaped to (B, d, m)."""
+    noise_type = "additive"
+
+    def __init__(self, d, m, sde_type="ito", seed=6, hidden=8, dtype=torch.float32):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.d, self.m, self.sde_type = d, m, sde_type
+        self.f_net = _mlp(gen, (d + 1, hidden, d), dtype)
+        self.g_net = _mlp(gen, (1, hidden, d * m), dtype, final=nn.Sigmoid())
+
+    def f(self, t, y):
+        return self.f_net(torch.cat([t.expand(y.size(0), 1).to(y.dtype), y], dim=1))
+
+    def g(self, t, y):
+        return self.g_net(t.expand(y.size(0), 1).to(y.dtype)).view(y.size(0), self.d, self.m)
+
+
 class MLPDiag(nn.Module):
     """Diagonal noise with an elementwise diffusion g_i(y_i) (a valid diagonal SDE for Milstein/adjoint)."""
     noise_type = "diagonal"
@@ -346,6 +365,9 @@ def make(name, dtype=torch.float32, **kw):
         "netdiag_strat": lambda: MLPNetDiag(kw.get("d", 4), "stratonovich", hidden=kw.get("hidden", 8), dtype=dtype),
         "netscalar_ito": lambda: MLPNetScalar(kw.get("d", 4), "ito", hidden=kw.get("hidden", 8), dtype=dtype),
         "netscalar_strat": lambda: MLPNetScalar(kw.get("d", 4), "stratonovich", hidden=kw.get("hidden", 8), dtype=dtype),
+        "netadditive_ito": lambda: MLPNetAdditive(kw.get("d", 4), kw.get("m", 3), "ito", hidden=kw.get("hidden", 8), dtype=dtype),
+        "netadditive_strat": lambda: MLPNetAdditive(kw.get("d", 4), kw.get("m", 3), "stratonovich", hidden=kw.get("hidden", 8),
+                                                    dtype=dtype),
         "mlpdiag_ito": lambda: MLPDiag(kw.get("d", 4), "ito", dtype=dtype),
         "mlpdiag_strat": lambda: MLPDiag(kw.get("d", 4), "stratonovich", dtype=dtype),
         "readme": lambda: ReadmeSDE(dtype=dtype),
