@@ -291,7 +291,11 @@ int tsde_error_norm(double* out, double* workspace, const void* y_full, const vo
 #define TSDE_CTL_BOUNDS_A 12 /* (a, b) of the first half step */
 #define TSDE_CTL_BOUNDS_B 14 /* (a, b) of the second half step */
 #define TSDE_CTL_WIDTHS 16   /* (ha, hb) */
-#define TSDE_CTL_SIZE 18
+#define TSDE_CTL_OUT_IDX 18    /* output times already reached (tsde_adaptive_begin_outputs) */
+#define TSDE_CTL_N_OUT 19
+#define TSDE_CTL_EMIT_FIRST 20 /* the output rows the last attempt's step reached: [first, first + count) */
+#define TSDE_CTL_EMIT_COUNT 21
+#define TSDE_CTL_SIZE 22
 #define TSDE_SUB_DT 0
 #define TSDE_SUB_HALF_DT 1
 #define TSDE_SUB_SQRT_DT 2
@@ -313,6 +317,19 @@ int tsde_adaptive_begin(double* ctl, void* scal, double out_t, const double* sta
  * ctl[ACTIVE] == 0. */
 int tsde_adaptive_control(double* ctl, void* scal, const double* error, const double* stage_fracs, int n_fracs,
                           int dtype, void* stream);
+/* The same two with the whole list of output times on the device (base_solver.py:117-145, both loops): `out_times` n_out
+ * DEVICE doubles, ascending. The controller walks the list -- the attempt whose step carries curr_t to or past one or more
+ * output times marks them (ctl[EMIT_FIRST], ctl[EMIT_COUNT]) and aims at the next -- and tsde_adaptive_emit, launched after
+ * the commit of every attempt (and once after begin, for output times the start state already meets), writes the marked
+ * rows  ys[j] = w0 prev_y + w1 curr_y  (interp.py:15-18; n elements per row) to the address stored in the device word
+ * `ys_slot`. ctl[OUT_IDX] == ctl[N_OUT] means the solve is complete; later attempts are inert. One host
+ * synchronisation per solve (to read that) instead of one per output time. */
+int tsde_adaptive_begin_outputs(double* ctl, void* scal, const double* out_times, int32_t n_out, const double* stage_fracs,
+                                int n_fracs, int dtype, void* stream);
+int tsde_adaptive_control_outputs(double* ctl, void* scal, const double* error, const double* out_times,
+                                  const double* stage_fracs, int n_fracs, int dtype, void* stream);
+int tsde_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
+                       const double* out_times, int dtype, void* stream);
 /* prev_y <- curr_y, curr_y <- y_next if the controller accepted the attempt; moves nothing otherwise. */
 int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal, int dtype,
                          void* stream);

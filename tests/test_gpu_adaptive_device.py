@@ -161,3 +161,46 @@ def test_attempt_replayed_as_a_cached_graph_is_bit_identical(method, levy):
     from torchsde_amd import graph as graph_module
     cached = [key for key in graph_module._cache_of(sde) if key[0] == "adaptive-attempt"]
     assert len(cached) == 1                                     # three solves, one capture
+
+
+def _solve_on(sde, ts_list, entropy, device_control, shape=(48, 4, 4), method="milstein", dt=0.05, rtol=1e-3, atol=1e-4):
+    import torchsde_amd
+    from torchsde_amd import adaptive
+    B, d, m = shape
+    y0 = torch.full((B, d), 0.1, device=DEV)
+    bm = torchsde_amd.BrownianInterval(ts_list[0], ts_list[-1], size=(B, m), dtype=torch.float32, device=DEV, entropy=entropy)
+    adaptive.last_stats = None
+    with torch.no_grad():
+        ys = torchsde_amd.sdeint(sde, y0, torch.tensor(ts_list, device=DEV), bm=bm, method=method, dt=dt, adaptive=True,
+                                 rtol=rtol, atol=atol, options={"device_adaptive": device_control, "hip_graph": False})
+    return ys, (dict(adaptive.last_stats) if adaptive.last_stats else None)
+
+
+def test_output_times_on_the_device_one_or_two_synchronisations_per_solve():
+    """The controller walks the list of output times and the emit kernel writes their rows (base_solver.py:117-145, both
+    loops, on the device): a solve synchronises to learn that it is complete, not once per output time. First solve of an
+    SDE object: the budget is the upper bound the initial step size gives (rejections may cost a second round); later
+    solves: the attempts the previous one used."""
+    ts_list = [0.0, 0.1, 0.25, 0.3, 0.5, 0.75, 0.8, 1.0]
+    sde = problems.make("gbm_ito", d=4).to(DEV)
+    first, stats1 = _solve_on(sde, ts_list, 11, True)
+    again, stats2 = _solve_on(sde, ts_list, 11, True)
+    other, stats3 = _solve_on(sde, ts_list, 12, True)
+    host, _ = _solve_on(sde, ts_list, 11, False)
+    host_other, _ = _solve_on(sde, ts_list, 12, False)
+    assert stats1["output_times"] == 7 and stats1["host_syncs"] <= 3, stats1
+    assert stats2["host_syncs"] == 1 and stats2["attempts_enqueued"] == stats2["attempts_used"] + 1, stats2
+    assert stats3["host_syncs"] <= 2, stats3
+    assert torch.equal(first, again)
+    torch.testing.assert_close(first, host, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(other, host_other, rtol=2e-5, atol=2e-6)
+
+
+def test_many_output_times_inside_single_steps():
+    """Forty output times over a handful of steps (several rows written by one emit launch): the rows are the host loop's."""
+    sde = problems.make("gbm_ito", d=4).to(DEV)
+    dense = [0.0] + [round(0.025 * k, 6) for k in range(1, 40)] + [1.0]
+    a, stats = _solve_on(sde, dense, 5, True, dt=0.2, rtol=1e-2, atol=1e-2)
+    b, _ = _solve_on(sde, dense, 5, False, dt=0.2, rtol=1e-2, atol=1e-2)
+    assert stats["output_times"] == len(dense) - 1 and stats["host_syncs"] <= 3 and stats["accepted"] < 30, stats
+    torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)

@@ -28,7 +28,8 @@ FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "si
 ADAPTIVE_MAX_STAGES = 6
 CTL_CURR_T, CTL_PREV_T, CTL_STEP_SIZE, CTL_PREV_ERROR_RATIO, CTL_OUT_T, CTL_T_END, CTL_DT_MIN = range(7)
 CTL_ATTEMPTS, CTL_ACCEPTED, CTL_DT_MIN_HITS, CTL_NAN_SEEN, CTL_ACTIVE = 7, 8, 9, 10, 11
-CTL_BOUNDS_A, CTL_BOUNDS_B, CTL_WIDTHS, CTL_SIZE = 12, 14, 16, 18
+CTL_BOUNDS_A, CTL_BOUNDS_B, CTL_WIDTHS = 12, 14, 16
+CTL_OUT_IDX, CTL_N_OUT, CTL_EMIT_FIRST, CTL_EMIT_COUNT, CTL_SIZE = 18, 19, 20, 21, 22
 SUB_DT, SUB_HALF_DT, SUB_SQRT_DT, SUB_RDT, SUB_TIMES = 0, 1, 2, 3, 4
 SUB_STRIDE = SUB_TIMES + ADAPTIVE_MAX_STAGES
 SCAL_W0, SCAL_W1, SCAL_ACCEPT, SCAL_SIZE = 3 * SUB_STRIDE, 3 * SUB_STRIDE + 1, 3 * SUB_STRIDE + 2, 3 * SUB_STRIDE + 3
@@ -167,6 +168,9 @@ SIGNATURES = {
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_adaptive_begin": (_c_int, [_c_ptr, _c_ptr, _c_dbl, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
     "tsde_adaptive_control": (_c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
+    "tsde_adaptive_begin_outputs": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i32, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
+    "tsde_adaptive_control_outputs": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
+    "tsde_adaptive_emit": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr]),
     "tsde_adaptive_commit": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),
     "tsde_merge_halves": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_dbl, _c_dbl, _c_int,
                                    _c_ptr]),

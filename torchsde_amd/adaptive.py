@@ -7,9 +7,13 @@ times from that decision. Here the decision is taken by a one-thread controller 
 time, and writes the scalars the NEXT attempt needs into a small device table. Every kernel of an attempt reads its
 scalars from that table (step size, dt/2, sqrt(dt), 1/dt through `TSDE_DEV_SCALAR` coefficients; the user's ``f`` and
 ``g`` get the stage times as 0-d views of it; the Brownian query kernel reads the half-step bounds from it), so an
-attempt is the SAME sequence of launches with the SAME arguments every time. The host enqueues a budget of attempts
-without synchronising and reads the controller's state back once per output time; attempts left over after the output
-time has been reached are inert (the controller leaves the state alone, the commit kernel copies nothing).
+attempt is the SAME sequence of launches with the SAME arguments every time. The OUTPUT TIMES live on the device too: the
+controller walks their list, and the last launch of every attempt (`tsde_adaptive_emit`) interpolates and writes the rows of
+`ys` whose time the step has just reached (interp.py:15-18). The host therefore takes no decision during a solve: it enqueues
+a budget of attempts without synchronising and reads the controller's state back to learn whether the last output time has
+been reached -- once per solve when the budget was right (later solves of an SDE object size it from the attempts the
+previous one used), once per round otherwise. Attempts left over are inert (the controller leaves the state alone, the commit
+kernel copies nothing, the emit kernel writes nothing).
 
 Used by ``BaseSDESolver._integrate_adaptive`` whenever this package's ``BrownianInterval`` generates the path, autograd is
 off and the solver keeps no state between steps; everything else takes the host-driven loop (one sync per attempt).
@@ -34,10 +38,16 @@ class DeviceController:
     def __init__(self, device, dtype, stage_fracs):
         self.ctl = torch.zeros(_native.CTL_SIZE, dtype=torch.float64, device=device)
         self.scal = torch.zeros(_native.SCAL_SIZE, dtype=dtype, device=device)
+        # the output times of the solve (at most OUT_CAPACITY at a time) and the address of the first output row of ys: static
+        # buffers, so that a recorded attempt serves every later solve
+        self.out_times = torch.zeros(self.OUT_CAPACITY, dtype=torch.float64, device=device)
+        self.ys_slot = torch.zeros(1, dtype=torch.int64, device=device)
         self.dtype, self.device = dtype, device
         self.n_fracs = len(stage_fracs)
         self._fracs = (ctypes.c_double * max(self.n_fracs, 1))(*[float(f) for f in stage_fracs])
         self._lib, self._dt_code, _ = K._launch_env(self.scal)
+
+    OUT_CAPACITY = 1024
 
     def load(self, t0, t_end, step_size, dt_min):
         """The state a solve starts from: the one host->device copy of the solve."""
@@ -52,15 +62,26 @@ class DeviceController:
     def _stream(self):
         return K._launch_env(self.scal)[2]
 
-    def begin(self, out_t):
-        code = self._lib.tsde_adaptive_begin(self.ctl.data_ptr(), self.scal.data_ptr(), float(out_t), self._fracs,
-                                             self.n_fracs, self._dt_code, self._stream())
-        _native.check(code, "tsde_adaptive_begin")
+    def begin(self, out_times, ys_rows):
+        """Aim at `out_times` (host float64 array, ascending, at most OUT_CAPACITY) whose rows are `ys_rows` (n_out, ...)."""
+        n_out = len(out_times)
+        self.out_times[:n_out].copy_(torch.from_numpy(np.array(out_times, dtype=np.float64)))      # (a writable copy)
+        self.ys_slot.copy_(torch.tensor([ys_rows.data_ptr()], dtype=torch.int64))
+        code = self._lib.tsde_adaptive_begin_outputs(self.ctl.data_ptr(), self.scal.data_ptr(), self.out_times.data_ptr(),
+                                                     n_out, self._fracs, self.n_fracs, self._dt_code, self._stream())
+        _native.check(code, "tsde_adaptive_begin_outputs")
 
     def control(self, error):
-        code = self._lib.tsde_adaptive_control(self.ctl.data_ptr(), self.scal.data_ptr(), error.data_ptr(), self._fracs,
-                                               self.n_fracs, self._dt_code, self._stream())
-        _native.check(code, "tsde_adaptive_control")
+        code = self._lib.tsde_adaptive_control_outputs(self.ctl.data_ptr(), self.scal.data_ptr(), error.data_ptr(),
+                                                       self.out_times.data_ptr(), self._fracs, self.n_fracs, self._dt_code,
+                                                       self._stream())
+        _native.check(code, "tsde_adaptive_control_outputs")
+
+    def emit(self, prev_y, curr_y):
+        """Write the output rows the controller has marked (none: the kernel returns at once)."""
+        code = self._lib.tsde_adaptive_emit(self.ys_slot.data_ptr(), prev_y.data_ptr(), curr_y.data_ptr(), curr_y.numel(),
+                                            self.ctl.data_ptr(), self.out_times.data_ptr(), self._dt_code, self._stream())
+        _native.check(code, "tsde_adaptive_emit")
 
     def commit(self, prev_y, curr_y, y_next):
         code = self._lib.tsde_adaptive_commit(prev_y.data_ptr(), curr_y.data_ptr(), y_next.data_ptr(), curr_y.numel(),
@@ -200,6 +221,7 @@ class _Attempt:
         advance(self.y_mid, self.steps[2], self.y_next)
         ctrl.control(K.error_norm(self.y_full, self.y_next, self.rtol, self.atol, scratch=self.norm_scratch))
         ctrl.commit(self.prev_y, self.curr_y, self.y_next)
+        ctrl.emit(self.prev_y, self.curr_y)
 
     def run(self, solver, bm, n):
         for _ in range(n):
@@ -225,8 +247,9 @@ class _GraphedAttempt(_Attempt):
         bm._entropy_dev = self.seed_dev
         try:
             # any consistent state will do for the warm-up and the capture: the launches read it from the tables
+            self.scratch_ys = torch.empty((1,) + tuple(y0.shape), dtype=y0.dtype, device=device)
             self.load(y0, float(bm._t0), float(bm._t1), float(bm._t1 - bm._t0), 0.0, bm)
-            self.ctrl.begin(float(bm._t1))
+            self.ctrl.begin([float(bm._t1)], self.scratch_ys)
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):           # warm-up outside capture (lazy inits, allocator)
@@ -241,11 +264,12 @@ class _GraphedAttempt(_Attempt):
                 # attempt gives (state, controller tables) and keeps giving it with eager work in between
                 # (graph.replays_are_stable: the second line of defence behind the memset-node rewrite)
                 def fresh():
+                    self.scratch_ys.zero_()
                     self.load(y0, float(bm._t0), float(bm._t1), float(bm._t1 - bm._t0), 0.0, bm)
-                    self.ctrl.begin(float(bm._t1))
+                    self.ctrl.begin([float(bm._t1)], self.scratch_ys)
 
                 def outputs():
-                    return [self.curr_y, self.prev_y, self.y_next, self.ctrl.ctl, self.ctrl.scal]
+                    return [self.curr_y, self.prev_y, self.y_next, self.ctrl.ctl, self.ctrl.scal, self.scratch_ys]
 
                 def replay():
                     fresh()
@@ -329,6 +353,25 @@ def _attempt_for(solver, y0, ts_host, step_cls):
     return attempt
 
 
+# States up to this many elements: an attempt is a chain of launch-bound kernels, so an inert attempt costs little and a host
+# synchronisation costs as much as several attempts -- aim the first round at the end of the solve.
+_LATENCY_BOUND_ELEMENTS = 1 << 18
+
+
+def _hints_of(solver, y0, ts_host):
+    """({key: attempts the last such solve used}, key of this solve) kept on the user's SDE object, or (None, None)."""
+    from . import graph as graph_module
+    _, base = graph_module._wrapper_chain(solver.sde)
+    try:
+        hints = base.__dict__.setdefault("_tsde_adaptive_hints", {})
+    except AttributeError:
+        return None, None
+    dt = solver.dt if not torch.is_tensor(solver.dt) else float(solver.dt)
+    key = (type(solver).__name__, tuple(y0.shape), y0.dtype, float(solver.rtol), float(solver.atol), float(dt),
+           float(solver.dt_min), ts_host.tobytes())
+    return hints, key
+
+
 def integrate(solver, y0, ts, extra0, step_cls):
     """The adaptive solve of `solver` (see the module docstring). Returns (ys, extra solver state)."""
     bm = solver._native_bm()
@@ -345,20 +388,36 @@ def integrate(solver, y0, ts, extra0, step_cls):
     ys[0].copy_(y0)
 
     curr_t, dt_min_hits, syncs, attempts, state = float(ts_host[0]), 0.0, 0, 0, None
+    t_end = float(ts_host[-1])
+    # How many attempts the previous solve of this structure on this SDE object used: the budget of this solve's first round.
+    # (Paths differ, so it is a guess; a shortfall costs one more round, a surplus a few inert attempts.)
+    hints, hint_key = _hints_of(solver, y0, ts_host)
+    hint = hints.get(hint_key) if hints is not None else None
+    small = y0.numel() <= _LATENCY_BOUND_ELEMENTS
     with torch.no_grad():
         attempt = _attempt_for(solver, y0, ts_host, step_cls)
-        attempt.load(y0.detach(), float(ts_host[0]), float(ts_host[-1]), float(step_size), float(solver.dt_min), bm)
+        attempt.load(y0.detach(), float(ts_host[0]), t_end, float(step_size), float(solver.dt_min), bm)
         ctrl = attempt.ctrl
-        for i in range(1, T):
-            out_t = ts_host[i]
-            ctrl.begin(float(out_t))
-            while curr_t < float(out_t):
-                # The attempts the current step size needs to get there, less one when that is more than two: accepted
-                # steps only ever grow (adaptive_stepping.py:35-37), so the estimate is an upper bound unless attempts
-                # are rejected; an attempt enqueued after the output time is reached is inert but still costs its
-                # kernels, while a shortfall costs one more (cheap) round.
-                need = int(math.ceil((float(out_t) - curr_t) / max(step_size, solver.dt_min)))
-                budget = min(max(1, need - 1 if need > 2 else need), 256)
+        for lo in range(1, T, ctrl.OUT_CAPACITY):          # (more output times than the device list holds: in chunks)
+            outs = np.asarray(ts_host[lo:lo + ctrl.OUT_CAPACITY], dtype=np.float64)
+            ctrl.begin(outs, ys[lo:lo + len(outs)])
+            ctrl.emit(attempt.prev_y, attempt.curr_y)       # output times the state already meets (ts[k] == ts[0], ...)
+            reached, first_round = 0, True
+            while True:
+                # The attempts the current step size needs, less one when that is more than two: accepted steps only ever
+                # grow (adaptive_stepping.py:35-37), so the estimate is an upper bound unless attempts are rejected. An
+                # attempt enqueued after the last output time is reached is inert but still costs its kernels, a shortfall
+                # costs one more round -- one more synchronisation:
+                #   * with a hint, the first round is the hint;
+                #   * a small state (latency-bound attempts) aims at the LAST output time at once;
+                #   * a large one (attempts of hundreds of microseconds) at the next output time only, like a host loop.
+                target = float(outs[-1]) if (small or hint is not None) else float(outs[min(reached, len(outs) - 1)])
+                need = int(math.ceil(max(target - curr_t, 0.0) / max(step_size, solver.dt_min)))
+                budget = need - 1 if need > 2 else need
+                if hint is not None and first_round and lo == 1:
+                    budget = hint + 1
+                budget = min(max(0 if need == 0 else 1, budget), 256)      # (0: every output time is already met)
+                first_round = False
                 screen = getattr(attempt, "screen", None)
                 if screen is not None:      # (hip_graph="auto", first solve of this structure)
                     from . import graph as graph_module
@@ -377,9 +436,15 @@ def integrate(solver, y0, ts, extra0, step_cls):
                     dt_min_hits = state[_native.CTL_DT_MIN_HITS]
                     warnings.warn("Hitting minimum allowed step size in adaptive time-stepping.")
                 curr_t, step_size = float(state[_native.CTL_CURR_T]), float(state[_native.CTL_STEP_SIZE])
-            K.linear_interp(attempt.prev_y, attempt.curr_y, attempt.w0, attempt.w1, out=ys[i])
+                reached = int(state[_native.CTL_OUT_IDX])
+                if reached >= len(outs):
+                    break
     global last_stats
     final = ctrl.read() if state is None else state
+    if hints is not None:
+        if len(hints) >= 16:
+            hints.clear()
+        hints[hint_key] = int(final[_native.CTL_ATTEMPTS])
     last_stats = {"control": "device", "host_syncs": syncs, "output_times": T - 1, "attempts_enqueued": attempts,
                   "attempts_used": int(final[_native.CTL_ATTEMPTS]), "accepted": int(final[_native.CTL_ACCEPTED]),
                   "dtype": np_dtype.__name__, "launch": "graph replay" if hasattr(attempt, "graph") else "eager"}

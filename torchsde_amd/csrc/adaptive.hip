@@ -13,9 +13,12 @@
 //   * `ctl` (double): controller state and the (a, b) bounds of the two half-step Brownian queries, which the query
 //     kernel reads from here (brownian.hip: QueryArgs::ab_dev).
 //
-// The host enqueues a budget of attempts without looking at any of this and reads `ctl` back once per output time.
-// Attempts issued after the output time has been reached are inert: the controller leaves the state alone and the
-// commit kernel copies nothing.
+// The host enqueues a budget of attempts without looking at any of this. With the OUTPUT TIMES on the device too
+// (tsde_adaptive_begin_outputs / _control_outputs / _emit) the controller also walks the list of output times: the step that
+// carries curr_t past one or more of them marks them for the emit kernel that follows the commit, which interpolates and
+// writes those rows of ys (interp.py:15-18) -- so a whole solve needs no host decision and synchronises once, to learn that
+// it is complete. Attempts issued after the last output time has been reached are inert: the controller leaves the state
+// alone, the commit kernel copies nothing, the emit kernel writes nothing.
 //
 // Arithmetic: times are advanced in T exactly as the host loop does with numpy scalars of ts.dtype (t + T(step),
 // min with t_end, T(0.5) * (t0 + t1)); the step size, the error ratio and the controller's powers are doubles, as
@@ -33,7 +36,8 @@ enum : int {
   kPrevErrRatio = TSDE_CTL_PREV_ERROR_RATIO, kOutT = TSDE_CTL_OUT_T, kTEnd = TSDE_CTL_T_END, kDtMin = TSDE_CTL_DT_MIN,
   kAttempts = TSDE_CTL_ATTEMPTS, kAccepted = TSDE_CTL_ACCEPTED, kDtMinHits = TSDE_CTL_DT_MIN_HITS,
   kNanSeen = TSDE_CTL_NAN_SEEN, kActive = TSDE_CTL_ACTIVE, kBoundsA = TSDE_CTL_BOUNDS_A, kBoundsB = TSDE_CTL_BOUNDS_B,
-  kHa = TSDE_CTL_WIDTHS, kHb = TSDE_CTL_WIDTHS + 1
+  kHa = TSDE_CTL_WIDTHS, kHb = TSDE_CTL_WIDTHS + 1, kOutIdx = TSDE_CTL_OUT_IDX, kNOut = TSDE_CTL_N_OUT,
+  kEmitFirst = TSDE_CTL_EMIT_FIRST, kEmitCount = TSDE_CTL_EMIT_COUNT
 };
 constexpr int kMaxStages = TSDE_ADAPTIVE_MAX_STAGES;      // stage times per sub-step, the step end included
 constexpr int kSubDt = TSDE_SUB_DT, kSubHalfDt = TSDE_SUB_HALF_DT, kSubSqrtDt = TSDE_SUB_SQRT_DT, kSubRdt = TSDE_SUB_RDT,
@@ -107,19 +111,44 @@ TSDE_D double next_step_size(double error_estimate, double prev_step_size, doubl
   return prev_step_size * factor;
 }
 
+// The output times curr_t has reached (base_solver.py:117-145: the inner loop of an output time ends when curr_t >= out_t, and
+// an output time the state is already past needs no step at all): mark them for the emit kernel and aim at the next one.
 template <typename T>
-__global__ void adaptive_begin_kernel(double* ctl, T* scal, double out_t, StageFracs sf) {
+TSDE_D void advance_outputs(double* ctl, const double* __restrict__ out_times) {
+  const int n_out = (int)ctl[kNOut];
+  int idx = (int)ctl[kOutIdx];
+  const int first = idx;
+  const T curr = (T)ctl[kCurrT];
+  while (idx < n_out && !(curr < (T)out_times[idx])) ++idx;
+  ctl[kEmitFirst] = (double)first;
+  ctl[kEmitCount] = (double)(idx - first);
+  ctl[kOutIdx] = (double)idx;
+  if (n_out > 0) ctl[kOutT] = out_times[idx < n_out ? idx : n_out - 1];
+}
+
+// `out_times` null: one output time, handed over by the host (tsde_adaptive_begin); else the device list of n_out of them.
+template <typename T>
+__global__ void adaptive_begin_kernel(double* ctl, T* scal, double out_t, const double* __restrict__ out_times, int n_out,
+                                      StageFracs sf) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  ctl[kOutT] = out_t;
   scal[kAccept] = (T)0;
+  if (out_times == nullptr) {
+    ctl[kOutT] = out_t;
+  } else {
+    ctl[kNOut] = (double)n_out;
+    ctl[kOutIdx] = 0.0;
+    advance_outputs<T>(ctl, out_times);
+  }
   refresh<T>(ctl, scal, sf);
 }
 
 // After an attempt: base_solver.py:125-142.
 template <typename T>
-__global__ void adaptive_control_kernel(double* ctl, T* scal, const double* __restrict__ error, StageFracs sf) {
+__global__ void adaptive_control_kernel(double* ctl, T* scal, const double* __restrict__ error,
+                                        const double* __restrict__ out_times, StageFracs sf) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   scal[kAccept] = (T)0;
+  if (out_times != nullptr) ctl[kEmitCount] = 0.0;
   if (ctl[kActive] == 0.0) return;                       // the output time was reached: this attempt is inert
   const double err = *error;
   if (err != err) ctl[kNanSeen] = 1.0;                   // the host raises the reference's AssertionError at its next read
@@ -142,6 +171,7 @@ __global__ void adaptive_control_kernel(double* ctl, T* scal, const double* __re
   }
   ctl[kStepSize] = step;
   ctl[kPrevErrRatio] = per;
+  if (out_times != nullptr) advance_outputs<T>(ctl, out_times);
   refresh<T>(ctl, scal, sf);
 }
 
@@ -156,6 +186,40 @@ struct CommitOp {
     if (*accept == (T)0) return;
     store<T, W, NT>(prev_y, i, load<T, W, NT>(curr_y, i));
     store<T, W, NT>(curr_y, i, load<T, W, NT>(y_next, i));
+  }
+};
+
+// ys[j] = w0 prev_y + w1 curr_y for the output times the controller has just marked (interp.py:15-18 with the host's
+// rounding: w0 = (t1 - t) / (t1 - t0), w1 = (t - t0) / (t1 - t0) in T; a state that has not moved yet gives curr_y itself).
+// `ys_slot`: device word holding the address of the first output row (a recorded attempt serves solves whose ys live
+// elsewhere).
+template <typename T>
+struct EmitOp {
+  T* const* ys_slot;
+  const T *prev_y, *curr_y;
+  const double* ctl;
+  const double* out_times;
+  int64_t n;
+  template <int W, bool NT = false>
+  TSDE_D void run(int64_t i) const {
+    const int count = (int)ctl[kEmitCount];
+    if (count == 0) return;
+    const int first = (int)ctl[kEmitFirst];
+    T* ys = *ys_slot;
+    const T prev = (T)ctl[kPrevT], curr = (T)ctl[kCurrT];
+    const Pack<T, W> a = load<T, W, NT>(prev_y, i), b = load<T, W, NT>(curr_y, i);
+    for (int j = first; j < first + count; ++j) {
+      const T out_t = (T)out_times[j];
+      T w0 = (T)0, w1 = (T)1;
+      if (curr > prev) {
+        w0 = (curr - out_t) / (curr - prev);
+        w1 = (out_t - prev) / (curr - prev);
+      }
+      Pack<T, W> o;
+#pragma unroll
+      for (int e = 0; e < W; ++e) o.v[e] = w0 * a.v[e] + w1 * b.v[e];
+      store<T, W, NT>(ys + (int64_t)j * n, i, o);
+    }
   }
 };
 
@@ -191,23 +255,32 @@ struct MergeHalvesOp {
 };
 
 template <typename T>
-hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const double* fracs, int n_fracs,
-                                 hipStream_t s) {
+hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const double* out_times, int n_out,
+                                 const double* fracs, int n_fracs, hipStream_t s) {
   StageFracs sf;
   sf.n = n_fracs;
   for (int j = 0; j < kMaxStages - 1; ++j) sf.frac[j] = j < n_fracs ? fracs[j] : 0.0;
-  hipLaunchKernelGGL(adaptive_begin_kernel<T>, dim3(1), dim3(64), 0, s, ctl, (T*)scal, out_t, sf);
+  hipLaunchKernelGGL(adaptive_begin_kernel<T>, dim3(1), dim3(64), 0, s, ctl, (T*)scal, out_t, out_times, n_out, sf);
   return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* fracs, int n_fracs,
-                                   hipStream_t s) {
+hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* out_times,
+                                   const double* fracs, int n_fracs, hipStream_t s) {
   StageFracs sf;
   sf.n = n_fracs;
   for (int j = 0; j < kMaxStages - 1; ++j) sf.frac[j] = j < n_fracs ? fracs[j] : 0.0;
-  hipLaunchKernelGGL(adaptive_control_kernel<T>, dim3(1), dim3(64), 0, s, ctl, (T*)scal, error, sf);
+  hipLaunchKernelGGL(adaptive_control_kernel<T>, dim3(1), dim3(64), 0, s, ctl, (T*)scal, error, out_times, sf);
   return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
+                                const double* out_times, hipStream_t s) {
+  EmitOp<T> op{(T* const*)ys_slot, (const T*)prev_y, (const T*)curr_y, ctl, out_times, n};
+  // (the rows of ys are n elements apart: 16-byte groups need n % 4 == 0; the host allocates ys 16-byte aligned)
+  const bool vec = (n % 4 == 0) && aligned16(prev_y) && aligned16(curr_y);
+  return launch_elementwise(op, n, vec, s, sizeof(T));
 }
 
 template <typename T>
@@ -229,8 +302,12 @@ hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha,
 }
 
 #define TSDE_ADAPTIVE_INSTANTIATE(T)                                                                              \
-  template hipError_t launch_adaptive_begin<T>(double*, void*, double, const double*, int, hipStream_t);          \
-  template hipError_t launch_adaptive_control<T>(double*, void*, const double*, const double*, int, hipStream_t); \
+  template hipError_t launch_adaptive_begin<T>(double*, void*, double, const double*, int, const double*, int,    \
+                                               hipStream_t);                                                      \
+  template hipError_t launch_adaptive_control<T>(double*, void*, const double*, const double*, const double*, int, \
+                                                 hipStream_t);                                                    \
+  template hipError_t launch_adaptive_emit<T>(const void*, const void*, const void*, int64_t, const double*,      \
+                                              const double*, hipStream_t);                                        \
   template hipError_t launch_adaptive_commit<T>(void*, void*, const void*, int64_t, const void*, hipStream_t);    \
   template hipError_t launch_merge_halves<T>(void*, void*, const void*, const void*, const void*, const void*,    \
                                              int64_t, const double*, double, double, hipStream_t);

@@ -420,8 +420,41 @@ int tsde_adaptive_begin(double* ctl, void* scal, double out_t, const double* sta
   if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg("tsde_adaptive_begin", "bad number of stages");
   const hipStream_t s = (hipStream_t)stream;
   TSDE_DISPATCH(dtype, "tsde_adaptive_begin",
-                tsde::launch_adaptive_begin<float>(ctl, scal, out_t, stage_fracs, n_fracs, s),
-                tsde::launch_adaptive_begin<double>(ctl, scal, out_t, stage_fracs, n_fracs, s));
+                tsde::launch_adaptive_begin<float>(ctl, scal, out_t, nullptr, 0, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_begin<double>(ctl, scal, out_t, nullptr, 0, stage_fracs, n_fracs, s));
+}
+
+int tsde_adaptive_begin_outputs(double* ctl, void* scal, const double* out_times, int32_t n_out, const double* stage_fracs,
+                                int n_fracs, int dtype, void* stream) {
+  const char* where = "tsde_adaptive_begin_outputs";
+  if (!ctl || !scal || !out_times || !stage_fracs) return bad_arg(where, "null argument");
+  if (n_out < 1) return bad_arg(where, "need at least one output time");
+  if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg(where, "bad number of stages");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, where,
+                tsde::launch_adaptive_begin<float>(ctl, scal, 0.0, out_times, n_out, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_begin<double>(ctl, scal, 0.0, out_times, n_out, stage_fracs, n_fracs, s));
+}
+
+int tsde_adaptive_control_outputs(double* ctl, void* scal, const double* error, const double* out_times,
+                                  const double* stage_fracs, int n_fracs, int dtype, void* stream) {
+  const char* where = "tsde_adaptive_control_outputs";
+  if (!ctl || !scal || !error || !out_times || !stage_fracs) return bad_arg(where, "null argument");
+  if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg(where, "bad number of stages");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, where,
+                tsde::launch_adaptive_control<float>(ctl, scal, error, out_times, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_control<double>(ctl, scal, error, out_times, stage_fracs, n_fracs, s));
+}
+
+int tsde_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
+                       const double* out_times, int dtype, void* stream) {
+  const char* where = "tsde_adaptive_emit";
+  if (!ys_slot || !prev_y || !curr_y || !ctl || !out_times) return bad_arg(where, "null argument");
+  if (n <= 0) return bad_arg(where, "n must be positive");
+  const hipStream_t s = (hipStream_t)stream;
+  TSDE_DISPATCH(dtype, where, tsde::launch_adaptive_emit<float>(ys_slot, prev_y, curr_y, n, ctl, out_times, s),
+                tsde::launch_adaptive_emit<double>(ys_slot, prev_y, curr_y, n, ctl, out_times, s));
 }
 
 int tsde_adaptive_control(double* ctl, void* scal, const double* error, const double* stage_fracs, int n_fracs,
@@ -430,8 +463,8 @@ int tsde_adaptive_control(double* ctl, void* scal, const double* error, const do
   if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg("tsde_adaptive_control", "bad number of stages");
   const hipStream_t s = (hipStream_t)stream;
   TSDE_DISPATCH(dtype, "tsde_adaptive_control",
-                tsde::launch_adaptive_control<float>(ctl, scal, error, stage_fracs, n_fracs, s),
-                tsde::launch_adaptive_control<double>(ctl, scal, error, stage_fracs, n_fracs, s));
+                tsde::launch_adaptive_control<float>(ctl, scal, error, nullptr, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_control<double>(ctl, scal, error, nullptr, stage_fracs, n_fracs, s));
 }
 
 int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal, int dtype,

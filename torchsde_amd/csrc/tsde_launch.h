@@ -102,11 +102,14 @@ hipError_t launch_error_norm(double* out, double* workspace, const void* yf, con
                              double atol, double eps, hipStream_t s);
 // adaptive.hip
 template <typename T>
-hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const double* fracs, int n_fracs,
-                                 hipStream_t s);
+hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const double* out_times, int n_out,
+                                 const double* fracs, int n_fracs, hipStream_t s);
 template <typename T>
-hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* fracs, int n_fracs,
-                                   hipStream_t s);
+hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* out_times,
+                                   const double* fracs, int n_fracs, hipStream_t s);
+template <typename T>
+hipError_t launch_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
+                                const double* out_times, hipStream_t s);
 template <typename T>
 hipError_t launch_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal,
                                   hipStream_t s);
