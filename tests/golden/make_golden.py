@@ -15,6 +15,8 @@ The GPU box has no /root/reference; tests read the committed .npz files. Fixture
   closed_form_affine_<case>.npz   the same for the affine diagonal module (all five schemes of its trajectory kernel)
   recognised_poly3_<case>.npz   reference `sdeint` of plain user modules with polynomial drift / diffusion (double well,
                                 logistic growth), float64, counter-RNG path: pins TSDE_FN_POLY3 to the reference
+  recognised_additive_<case>.npz   reference `sdeint` of plain additive-noise modules (the shapes of ExAdditive, a constant
+                                matrix, NeuralAdditive), float64, counter-RNG path: pins the additive trajectory kernels
   closed_form_expr_<case>.npz   reference `sdeint` of the elementwise-expression module (incl. the reference's own
                       benchmark SDE f = y, g = exp(-y)), float64, counter-RNG path
   closed_form_adjoint_<case>.npz   reference `sdeint_adjoint(adjoint_method="euler")` of the perceptron-drift module, float64,
@@ -849,10 +851,71 @@ def gen_poly3():
         print(f"recognised_poly3_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}")
 
 
+ADDITIVE_CASES = [
+    # name, problem class, sde_type, method, levy, m
+    ("exadditive_euler", "AdditiveDecay", "ito", "euler", "none", 3),
+    ("exadditive_milstein", "AdditiveDecay", "ito", "milstein", "none", 4),
+    ("exadditive_srk", "AdditiveDecay", "ito", "srk", "space-time", 3),
+    ("exadditive_midpoint", "AdditiveDecay", "stratonovich", "midpoint", "none", 8),
+    ("shared_srk", "AdditiveShared", "ito", "srk", "space-time", 4),
+    ("netadditive_euler", "MLPNetAdditive", "ito", "euler", "none", 3),
+    ("netadditive_srk", "MLPNetAdditive", "ito", "srk", "space-time", 4),
+    ("netadditive_midpoint", "MLPNetAdditive", "stratonovich", "midpoint", "none", 5),
+]
+
+
+def additive_module(cls, d, m, sde_type):
+    from workloads import problems
+    return {"AdditiveDecay": lambda: problems.AdditiveDecay(d, m, sde_type),
+            "AdditiveShared": lambda: problems.AdditiveShared(d, m, sde_type),
+            "MLPNetAdditive": lambda: problems.MLPNetAdditive(d, m, sde_type, hidden=8)}[cls]()
+
+
+def gen_additive():
+    """The REAL reference on unchanged additive-noise modules (the shapes of its ExAdditive / NeuralAdditive,
+    tests/problems.py:106-132,195-224), float64, increments of the counter generator: what the additive trajectory kernels
+    (tsde_trajectory_prog_additive / _mlp_additive) and the oracle must reproduce."""
+    from oracle import counter
+    B, d, steps, entropy, dt = 40, 12, 16, 626262, 2.0 ** -5
+
+    for name, cls, sde_type, method, levy, m in ADDITIVE_CASES:
+        edges = np.arange(steps + 1) * dt
+        ts = [0.0, 5 * dt, 7.5 * dt, steps * dt]
+
+        class CounterPath(torchsde.BaseBrownian):
+            def __call__(self, ta, tb=None, return_U=False, return_A=False):
+                W, U, _ = counter.query(B * m, entropy, edges, float(ta), float(tb), dtype=np.float64,
+                                        have_h=levy != "none")
+                W = torch.from_numpy(W).reshape(B, m)
+                return (W, torch.from_numpy(U).reshape(B, m)) if return_U else W
+
+            def __repr__(self):
+                return "CounterPath"
+
+            dtype = property(lambda self: torch.float64)
+            device = property(lambda self: torch.device("cpu"))
+            shape = property(lambda self: (B, m))
+            levy_area_approximation = property(lambda self: levy)
+
+        sde = additive_module(cls, d, m, sde_type).double()
+        sde.sde_type = sde_type
+        gen = torch.Generator().manual_seed(sum(map(ord, "additive_" + name)))
+        y0 = 2.0 * torch.rand(B, d, generator=gen, dtype=torch.float64) - 1.0
+        with torch.no_grad():
+            ys = torchsde.sdeint(sde, y0, torch.tensor(ts, dtype=torch.float64), bm=CounterPath(), method=method, dt=dt)
+        out = {"problem": cls, "sde_type": sde_type, "method": method, "levy": levy, "entropy": np.int64(entropy),
+               "dt": np.float64(dt), "ts": np.asarray(ts), "shape": np.array([B, d, steps, m]), "y0": y0.numpy(),
+               "ys": ys.numpy()}
+        for pname, p in sde.named_parameters():
+            out["param__" + pname] = p.detach().numpy()
+        np.savez_compressed(os.path.join(HERE, f"recognised_additive_{name}.npz"), **out)
+        print(f"recognised_additive_{name}.npz  |ys|={np.abs(out['ys']).mean():.4f}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["timegrid", "solver", "adaptive", "adjoint", "bridge", "brownian_seq", "closed_form",
                              "closed_form_affine", "logqp", "closed_form_adjoint", "closed_form_expr", "double_backward",
-                             "adjoint_adaptive", "poly3"]
+                             "adjoint_adaptive", "poly3", "additive"]
     torch.manual_seed(0)
     for w in which:
         globals()["gen_" + w]()

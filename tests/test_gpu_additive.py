@@ -196,3 +196,42 @@ def test_additive_rows_vs_oracle(method, levy):
                                                  f"additive noise, {method}, program + table kernel")
     finally:
         torch.set_num_threads(before)
+
+
+def _golden_cases():
+    import os
+    return sorted(f[len("recognised_additive_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("recognised_additive_"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("name", _golden_cases())
+def test_additive_user_modules_on_the_trajectory_kernels_match_the_reference(name, dtype):
+    """tests/golden/recognised_additive_*.npz: the REAL reference's `sdeint` of plain additive-noise modules (the shapes of
+    its ExAdditive, a constant matrix, its NeuralAdditive) in float64 on the counter path (make_golden.py gen_additive). The
+    verifying first solve (the stepwise result) and the kernel launches after it must both reproduce it. (The network kernel is
+    float32 only: in float64 a network drift stays stepwise, which is checked too.)"""
+    import torchsde_amd
+    from tests.test_oracle_solvers import additive_module
+    z = helpers.load(f"recognised_additive_{name}.npz")
+    Bz, d, steps, m = (int(v) for v in z["shape"])
+    dt, levy = float(z["dt"]), str(z["levy"])
+    sde = additive_module(z, dtype).to(DEV)
+    y0 = torch.tensor(z["y0"], dtype=dtype, device=DEV)
+    ts = torch.tensor(z["ts"], dtype=dtype, device=DEV)
+    want = torch.tensor(z["ys"])
+    network = str(z["problem"]) == "MLPNetAdditive"
+    tol = dict(rtol=1e-9, atol=1e-11) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-5)
+
+    def solve():
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(Bz, m), dtype=dtype, device=DEV, entropy=int(z["entropy"]),
+                                           dt=dt, levy_area_approximation=levy)
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=str(z["method"]), dt=dt, options={"hip_graph": False})
+    torch.testing.assert_close(solve().double().cpu(), want, **tol)                 # both routes, the stepwise one returned
+    fast, launches = _launches(solve)
+    torch.testing.assert_close(fast.double().cpu(), want, **tol)
+    if network and dtype == torch.float64:
+        assert launches == 0 and not _book(sde)["trusted"], _book(sde)
+    else:
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        assert [key[0][0][:2] for key in _book(sde)["trusted"]] == [("perceptron" if network else "program", "additive")]

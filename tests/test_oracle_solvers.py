@@ -188,3 +188,48 @@ def test_oracle_matches_reference_on_polynomial_user_modules(name):
         ys = solvers_ref.integrate(poly3_module(z), bm, torch.tensor(z["y0"]), torch.tensor(z["ts"]), dt,
                                    str(z["method"]), None)
     torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
+
+
+def _additive_cases():
+    import os
+    return sorted(f[len("recognised_additive_"):-4] for f in os.listdir(helpers.GOLDEN) if f.startswith("recognised_additive_"))
+
+
+def additive_module(z, dtype=torch.float64):
+    """The plain user module of a recognised_additive_* fixture (workloads.problems.AdditiveDecay / AdditiveShared /
+    MLPNetAdditive: the shapes of the reference's ExAdditive and NeuralAdditive) with the fixture's parameter values."""
+    from workloads import problems
+    _, d, _, m = (int(v) for v in z["shape"])
+    sde_type = str(z["sde_type"])
+    sde = {"AdditiveDecay": lambda: problems.AdditiveDecay(d, m, sde_type),
+           "AdditiveShared": lambda: problems.AdditiveShared(d, m, sde_type),
+           "MLPNetAdditive": lambda: problems.MLPNetAdditive(d, m, sde_type, hidden=8)}[str(z["problem"])]().to(dtype)
+    sde.sde_type = sde_type
+    with torch.no_grad():
+        for name, p in sde.named_parameters():
+            p.copy_(torch.tensor(z["param__" + name]).to(dtype))
+    return sde
+
+
+@pytest.mark.parametrize("name", _additive_cases())
+def test_oracle_matches_reference_on_additive_user_modules(name):
+    """The oracle's loop (Euler, Milstein, midpoint, SRK's additive step srk.py:90-111) on the additive-noise modules, counter
+    path, against the REAL reference's output (make_golden.py gen_additive)."""
+    import numpy as np
+
+    from oracle import counter
+    z = helpers.load(f"recognised_additive_{name}.npz")
+    B, d, steps, m = (int(v) for v in z["shape"])
+    dt, levy = float(z["dt"]), str(z["levy"])
+    edges = np.arange(steps + 1) * dt
+
+    def bm(ta, tb, return_U=False):
+        W, U, _ = counter.query(B * m, int(z["entropy"]), edges, float(ta), float(tb), dtype=np.float64,
+                                have_h=levy != "none")
+        W = torch.from_numpy(W).reshape(B, m)
+        return (W, torch.from_numpy(U).reshape(B, m)) if return_U else W
+
+    with torch.no_grad():
+        ys = solvers_ref.integrate(additive_module(z), bm, torch.tensor(z["y0"]), torch.tensor(z["ts"]), dt,
+                                   str(z["method"]), None)
+    torch.testing.assert_close(ys, torch.tensor(z["ys"]), rtol=1e-12, atol=1e-13)
