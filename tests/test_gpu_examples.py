@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ["train_neural_sde.py", "--iters", "12"],
     ["neural_general_sde.py"],
     ["scalar_noise_training.py"],
+    ["additive_noise_sde.py"],
 ])
 def test_example_runs(argv):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "examples", argv[0])] + argv[1:], capture_output=True,
