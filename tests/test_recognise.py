@@ -591,3 +591,64 @@ def test_additive_noise_with_a_network_drift():
         torch.testing.assert_close(hidden @ w2 + b2, sde.f(t, y), rtol=1e-5, atol=1e-6)
     again = recognise.recognise_additive(sde, t, y, times, rows=5, check_rows=True)
     assert again.structure() == found.structure() and again.spec()[1] == net
+
+
+# ---- random expression trees through the program compiler -------------------------------------------------------------
+def _random_tree(rng, depth):
+    """(python source of an expression of y, t, s.mu, s.sigma, s.b and numbers): smooth on y in [-1, 1], denominators and
+    arguments of log / sqrt kept positive."""
+    leaves = ["y", "y", "y", "s.mu", "s.sigma", "s.b", "t", "torch.tensor(0.5)", "torch.tensor(2.0)", "torch.tensor(-1.5)"]
+    if depth == 0 or rng.random() < 0.15:
+        return rng.choice(leaves)
+    kind = rng.random()
+    if kind < 0.35:
+        fn = rng.choice(["torch.sin", "torch.cos", "torch.tanh", "torch.sigmoid", "torch.exp", "F.softplus", "torch.square",
+                         "torch.neg"])
+        inner = _random_tree(rng, depth - 1)
+        if fn == "torch.exp":
+            inner = f"torch.tanh({inner})"                # (bounded argument)
+        return f"{fn}({inner})"
+    if kind < 0.45:
+        inner = _random_tree(rng, depth - 1)
+        return rng.choice([f"torch.sqrt(1.5 + torch.tanh({inner}))", f"torch.log(2.5 + torch.sin({inner}))",
+                           f"({inner}) ** 2", f"({inner}) ** 3", f"torch.reciprocal(2.0 + torch.cos({inner}))"])
+    a, b = _random_tree(rng, depth - 1), _random_tree(rng, depth - 1)
+    op = rng.choice(["+", "-", "*", "/"])
+    if op == "/":
+        b = f"(2.5 + torch.sin({b}))"
+    return f"({a} {op} {b})"
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_expression_trees_compile_to_programs_that_evaluate_to_the_code(seed):
+    """120 seeded random expression trees (depth <= 5; unary functions, powers, the four operations with operands in either
+    order, constants, parameters, t) as drift and diffusion of a user module: whatever the interpreter accepts must come back
+    as programs whose evaluation on the four-deep stack (the kernel's machine, restated in `_run_program`) equals the user's
+    code, and whose derivative program equals autograd's dg/dy. Trees that need more than four live values or 96 words are
+    refused with that reason -- never evaluated wrongly."""
+    import random
+    rng = random.Random(seed)
+    src_f, src_g = _random_tree(rng, 5 if seed % 3 == 0 else 4), _random_tree(rng, 4 if seed % 3 == 0 else 3)
+    if "y" not in src_f:
+        src_f = f"({src_f}) * y"
+    if "y" not in src_g:
+        src_g = f"({src_g}) + torch.sin(y)"
+    env = {"torch": torch, "F": F}
+    f = eval(f"lambda s, t, y: {src_f}", env)
+    g = eval(f"lambda s, t, y: {src_g}", env)
+    sde = _M(f, g)
+    y, t = 2.0 * torch.rand(16, D) - 1.0, torch.tensor(0.3)
+    try:
+        found = recognise.recognise_program(ForwardSDE(sde), t, y, "diagonal")
+    except recognise.NotElementwise as e:
+        assert any(reason in str(e) for reason in ("more than four", "more than 96", "more than 64")), (src_f, src_g, str(e))
+        return
+    fw, gw, dgw = found.programs
+    table = found.const_table()
+    with torch.no_grad():
+        torch.testing.assert_close(_run_program(fw, table, y, t), sde.f(t, y).expand_as(y), rtol=2e-5, atol=2e-6, msg=src_f)
+        torch.testing.assert_close(_run_program(gw, table, y, t), sde.g(t, y).expand_as(y), rtol=2e-5, atol=2e-6, msg=src_g)
+    if dgw:
+        yy = y.clone().requires_grad_(True)
+        dg, = torch.autograd.grad(sde.g(t, yy).expand_as(yy).sum(), yy)
+        torch.testing.assert_close(_run_program(dgw, table, y, t), dg, rtol=2e-4, atol=2e-5, msg=src_g)
