@@ -259,3 +259,40 @@ def test_more_than_four_trainable_constants_stay_stepwise():
     for entropy in (1, 2):
         ys, _, grads = _train(sde, entropy, "euler", "none", False, torch.float32)
         assert type(ys.grad_fn).__name__ != "_ProgTrajectoryFnBackward" and len(grads) == 5
+
+
+@pytest.mark.parametrize("method,levy", [("euler", "none"), ("milstein", "none"), ("srk", "space-time")])
+@pytest.mark.parametrize("seed", range(0, 120, 5))
+def test_random_expression_trees_on_the_program_kernel(seed, method, levy):
+    """The seeded random trees of tests/test_recognise.py (drift depth <= 5: unary functions, powers, the four operations,
+    constants, parameters, t) as user modules through the real kernel: the stack machine of csrc/trajectory.hip -- operand
+    order of the reversed operators, constants beyond the eight register rows, the derivative program -- against the stepwise
+    route, which runs the user's own torch code."""
+    import random
+
+    import torch.nn.functional as F
+
+    from tests.test_recognise import _M, _random_tree
+    rng = random.Random(seed)
+    src_f, src_g = _random_tree(rng, 5 if seed % 3 == 0 else 4), _random_tree(rng, 4 if seed % 3 == 0 else 3)
+    if "y" not in src_f:
+        src_f = f"({src_f}) * y"
+    if "y" not in src_g:
+        src_g = f"({src_g}) + torch.sin(y)"
+    env = {"torch": torch, "F": F}
+    # (bounded dynamics: the random drift and diffusion are squashed, so that 32 steps stay finite whatever the tree)
+    f = eval(f"lambda s, t, y: torch.tanh({src_f}) - y", env)
+    g = eval(f"lambda s, t, y: 0.3 * torch.tanh({src_g})", env)
+    sde = _M(f, g).to(DEV)
+    sde.b = sde.b.to(DEV)
+    d = sde.mu.numel()
+    _solve(sde, 1, method, levy, d=d)
+    book = _book(sde)
+    if book["refused"]:
+        assert any("more than" in r or "derivative" in r for r in book["refused"].values()), (src_f, src_g, book)
+        return
+    assert list(book["trusted"].values()) == [True], (src_f, src_g, book)
+    fast, launches = _launches(lambda: _solve(sde, 2, method, levy, d=d))
+    assert launches == 1
+    torch.testing.assert_close(fast, _solve(sde, 2, method, levy, stepwise=True, d=d), rtol=5e-5, atol=5e-6,
+                               msg=f"f: {src_f}\ng: {src_g}")
