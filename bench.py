@@ -79,6 +79,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_euler_scheduled_b65536_d64_s1000", "c2_euler_scheduled_default_route_b65536_d64_s1000",
         "c2_srk_scheduled_default_route_b65536_d64_s1000",
         "c2_euler_doublewell_b65536_d64_s1000", "c2_euler_doublewell_default_route_b65536_d64_s1000",
+        "c2_heun_diag_default_route_b65536_d64_s1000", "c2_heun_diag_b65536_d64_s1000",
         "exadditive_srk_default_route_b65536_d64_m8", "exadditive_euler_default_route_b65536_d64_m8",
         "exadditive_srk_b65536_d64_m8", "exadditive_euler_b65536_d64_m8",
         "neuraladditive_srk_default_route_b65536_d64_m8", "neuraladditive_srk_b65536_d64_m8",
@@ -512,7 +513,8 @@ class Job:
 
 _VALU_MODELS = {}
 _TRAJ_METHOD_CODES = {("euler", "ito"): 0, ("milstein", "ito"): 1, ("milstein", "stratonovich"): 2,
-                      ("midpoint", "stratonovich"): 3, ("srk", "ito"): 4}        # include/torchsde_amd.h TSDE_TRAJ_*
+                      ("midpoint", "stratonovich"): 3, ("srk", "ito"): 4, ("heun", "stratonovich"): 5,
+                      ("euler_heun", "stratonovich"): 6}                         # include/torchsde_amd.h TSDE_TRAJ_*
 
 
 def _valu_model(name):

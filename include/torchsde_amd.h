@@ -349,6 +349,8 @@ int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entro
 #define TSDE_TRAJ_MILSTEIN_STRAT 2
 #define TSDE_TRAJ_MIDPOINT 3
 #define TSDE_TRAJ_SRK 4
+#define TSDE_TRAJ_HEUN 5       /* heun.py:35-48; the affine / expression / program kernels (values and sensitivities) */
+#define TSDE_TRAJ_EULER_HEUN 6 /* euler_heun.py:29-42; the same kernels */
 
 /* All `traj->n_steps` fixed steps of a diagonal-noise SDE with per-channel affine drift and diffusion
  *   f(t, y) = drift_rate * y + drift_shift,   g(t, y) = diff_rate * y + diff_shift      (each of length d)

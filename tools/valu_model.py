@@ -174,7 +174,7 @@ def all_affine(rates_path=None):
     import bench
     asm = device_asm()
     kernels = {}
-    for method in range(5):
+    for method in range(7):        # TSDE_TRAJ_EULER .. TSDE_TRAJ_EULER_HEUN
         symbol = affine_symbol(method)
         kernels[symbol] = model(symbol, rates_path, asm=asm)
     return {"csrc_sha": bench.csrc_digest(), "kernels": kernels}

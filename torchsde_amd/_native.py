@@ -21,7 +21,7 @@ DIFF_AFFINE, DIFF_SIGMOID = 0, 1
 FINAL_NONE, FINAL_SIGMOID = 0, 1
 PRECISION_F32, PRECISION_BF16X3 = 0, 1
 NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL, NOISE_ADDITIVE = 0, 1, 2, 3
-TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK = 0, 1, 2, 3, 4
+TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK, TRAJ_HEUN, TRAJ_EULER_HEUN = 0, 1, 2, 3, 4, 5, 6
 FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6, "poly3": 7}
 
 # include/torchsde_amd.h: the device tables of adaptive stepping (TSDE_CTL_*, TSDE_SUB_*, TSDE_SCAL_*)

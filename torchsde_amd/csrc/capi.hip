@@ -494,7 +494,7 @@ static int trajectory_affine_diag(const char* where, void* ys, void* sens, const
   if (coef_step_stride != 0 && coef_step_stride < d) return bad_arg(where, "coef_step_stride must be 0 or >= d");
   if (coef_step_stride != 0 && sens) return bad_arg(where, "per-step coefficients: values only");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
-  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
+  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_EULER_HEUN) return bad_arg(where, "unknown method");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
   if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");
@@ -574,7 +574,7 @@ static int prog_diag(const char* where, void* ys, void* sens, const int8_t* para
     return bad_arg(where, "program lengths out of range (at most 96 words together)");
   if (n_const < 0 || n_const > 64 || (n_const > 0 && !consts)) return bad_arg(where, "constant table missing or above 64 rows");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
-  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
+  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_EULER_HEUN) return bad_arg(where, "unknown method");
   if ((method == TSDE_TRAJ_MILSTEIN_ITO || method == TSDE_TRAJ_MILSTEIN_STRAT) && dg_len < 1)
     return bad_arg(where, "Milstein needs the program of the diffusion's derivative");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
@@ -739,7 +739,7 @@ int tsde_trajectory_expr_diag_timed(void* ys, const void* y0, int64_t rows, int6
   for (int c = 0; c < 8; ++c)
     if (!coef[c]) return bad_arg(where, "null coefficient array");
   if (rows < 0 || d <= 0) return bad_arg(where, "need rows >= 0 and d > 0");
-  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_SRK) return bad_arg(where, "unknown method");
+  if (method < TSDE_TRAJ_EULER || method > TSDE_TRAJ_EULER_HEUN) return bad_arg(where, "unknown method");
   if (f_kind < TSDE_FN_IDENTITY || f_kind > TSDE_FN_POLY3 || g_kind < TSDE_FN_IDENTITY || g_kind > TSDE_FN_POLY3)
     return bad_arg(where, "unknown function code");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");

@@ -121,7 +121,7 @@ struct TrajArgs {
 };
 
 enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStrat = TSDE_TRAJ_MILSTEIN_STRAT,
-             kMidpoint = TSDE_TRAJ_MIDPOINT, kSrk = TSDE_TRAJ_SRK };
+             kMidpoint = TSDE_TRAJ_MIDPOINT, kSrk = TSDE_TRAJ_SRK, kHeun = TSDE_TRAJ_HEUN, kEulerHeun = TSDE_TRAJ_EULER_HEUN };
 
 // One step of one element of a diagonal SDE whose drift and diffusion the kernel can evaluate itself. `w` = W, `u` = U
 // (SRK only). S is T (values only) or Dual<T>. `M` supplies f(x), g(x) and gdg(x, g, v) = (g * v) * g'(x), the
@@ -132,8 +132,11 @@ enum : int { kEuler = TSDE_TRAJ_EULER, kMilIto = TSDE_TRAJ_MILSTEIN_ITO, kMilStr
 //   midpoint        : slot 0 = t0, 1 = t0 + dt/2                          (midpoint.py:33,40)
 //   SRK (SRID2)     : slot 0 = t0, 1 = t0 + dt/4, 2 = t0 + dt/2, 3 = t0 + dt;  f at C0 = (0, 1, 1/2) -> slots 0, 3, 2 and
 //                     g at C1 = (0, 1/4, 1, 1/4) -> slots 0, 1, 3, 1       (srk.py:66-72, tableaus/srid2.py:21-22)
+//   Heun, Euler-Heun: slot 0 = t0, 1 = t0 + dt = t1                       (heun.py:39,43, euler_heun.py:33,37)
 template <int METHOD>
-constexpr int stage_slots() { return METHOD == kSrk ? 4 : (METHOD == kMidpoint ? 2 : 1); }
+constexpr int stage_slots() {
+  return METHOD == kSrk ? 4 : ((METHOD == kMidpoint || METHOD == kHeun || METHOD == kEulerHeun) ? 2 : 1);
+}
 
 template <typename T, int METHOD, typename S, typename M, typename N = T>
 TSDE_D S scheme_step(const S y, const M& m, const N w, const N u, const T dt, const T half_dt, const T rdt,
@@ -148,6 +151,20 @@ TSDE_D S scheme_step(const S y, const M& m, const N w, const N u, const T dt, co
   } else if constexpr (METHOD == kMidpoint) {
     const S yp = drift_diffusion_update<T, S>(y, m.template f<0>(y), m.template g<0>(y), w, half_dt, (T)0.5);
     return drift_diffusion_update<T, S>(y, m.template f<1>(yp), m.template g<1>(yp), w, dt, (T)1);
+  } else if constexpr (METHOD == kHeun || METHOD == kEulerHeun) {
+    // Stratonovich predictor-corrector (heun.py:35-48, euler_heun.py:29-42) in the operation order of the stepwise route
+    // (tsde_step_diag as predictor, tsde_heun_final): Heun predicts with the full Euler step, Euler-Heun with the noise alone
+    constexpr bool heun = METHOD == kHeun;
+    const S f0 = m.template f<0>(y), g0 = m.template g<0>(y);
+    const S yp = drift_diffusion_update<T, S>(y, f0, g0, w, heun ? dt : (T)0, (T)1);
+    const S g1 = m.template g<1>(yp);
+    const S p0 = g0 * w, p1 = g1 * w;
+    if constexpr (heun) {
+      const S f1 = m.template f<1>(yp);
+      return y + (((dt * (f0 + f1)) + p0) + p1) * (T)0.5;
+    } else {
+      return (y + dt * f0) + ((p0 + p1) * (T)0.5);
+    }
   } else {
     const S zero = S((T)0);
     S f[3], g[4], h0, h1;
@@ -484,6 +501,8 @@ hipError_t launch_trajectory_affine_diag(void* ys, void* sens, const void* y0, i
     case kMilStrat: return launch_traj_m<T, kMilStrat>(p, vec, s);
     case kMidpoint: return launch_traj_m<T, kMidpoint>(p, vec, s);
     case kSrk: return launch_traj_m<T, kSrk>(p, vec, s);
+    case kHeun: return launch_traj_m<T, kHeun>(p, vec, s);
+    case kEulerHeun: return launch_traj_m<T, kEulerHeun>(p, vec, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -654,6 +673,8 @@ hipError_t launch_trajectory_expr_diag(void* ys, const void* y0, int64_t rows, i
     case kMilStrat: return launch_expr_m<T, kMilStrat>(p, vec, s);
     case kMidpoint: return launch_expr_m<T, kMidpoint>(p, vec, s);
     case kSrk: return launch_expr_m<T, kSrk>(p, vec, s);
+    case kHeun: return launch_expr_m<T, kHeun>(p, vec, s);
+    case kEulerHeun: return launch_expr_m<T, kEulerHeun>(p, vec, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -831,7 +852,7 @@ struct ProgModel {
 template <typename T, int METHOD>
 TSDE_D void stage_times(T t0, T dt, T (&out)[4]) {
   out[0] = t0;
-  out[1] = METHOD == kSrk ? t0 + (T)0.25 * dt : t0 + (T)0.5 * dt;
+  out[1] = METHOD == kSrk ? t0 + (T)0.25 * dt : ((METHOD == kHeun || METHOD == kEulerHeun) ? t0 + dt : t0 + (T)0.5 * dt);
   out[2] = t0 + (T)0.5 * dt;
   out[3] = t0 + dt;
 }
@@ -1391,6 +1412,8 @@ hipError_t launch_trajectory_prog_diag(void* ys, void* sens, const int8_t* param
       case kMilStrat: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kMilStrat>), grid, dim3(kBlock), 0, s, q); break;
       case kMidpoint: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kMidpoint>), grid, dim3(kBlock), 0, s, q); break;
       case kSrk: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kSrk>), grid, dim3(kBlock), 0, s, q); break;
+      case kHeun: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kHeun>), grid, dim3(kBlock), 0, s, q); break;
+      case kEulerHeun: hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, kEulerHeun>), grid, dim3(kBlock), 0, s, q); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1405,6 +1428,8 @@ hipError_t launch_trajectory_prog_diag(void* ys, void* sens, const int8_t* param
     case kMilStrat: return launch_prog_m<T, kMilStrat>(p, vec, s);
     case kMidpoint: return launch_prog_m<T, kMidpoint>(p, vec, s);
     case kSrk: return launch_prog_m<T, kSrk>(p, vec, s);
+    case kHeun: return launch_prog_m<T, kHeun>(p, vec, s);
+    case kEulerHeun: return launch_prog_m<T, kEulerHeun>(p, vec, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -627,7 +627,7 @@ def _coefficient_tables(coefs, d, schedule, dtype, method):
         raise ValueError("coefficients must be contiguous tensors in the state dtype")
     if shapes == {(d,)}:
         return False
-    slots = {0: 1, 1: 1, 2: 1, 3: 2, 4: 4}[int(method)]       # stage times per step (csrc/trajectory.hip stage_slots)
+    slots = {0: 1, 1: 1, 2: 1, 3: 2, 4: 4, 5: 2, 6: 2}[int(method)]       # stage times per step (csrc/trajectory.hip stage_slots)
     if shapes == {(schedule.n_steps * slots, d)}:
         return True
     raise ValueError(f"coefficients must all be (d,) tensors or all (n_steps * {slots}, d) tables, got {sorted(shapes)}")

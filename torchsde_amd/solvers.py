@@ -752,7 +752,8 @@ class BaseSDESolver:
     _STAGE_TIMES = {}
     # stage-time slots of the trajectory kernels (csrc/trajectory.hip stage_slots): offsets from t0 as multiples of dt
     _TIMED_SLOTS = {_native.TRAJ_EULER: (0,), _native.TRAJ_MILSTEIN_ITO: (0,), _native.TRAJ_MILSTEIN_STRAT: (0,),
-                    _native.TRAJ_MIDPOINT: (0, 0.5), _native.TRAJ_SRK: (0, 0.25, 0.5, 1)}
+                    _native.TRAJ_MIDPOINT: (0, 0.5), _native.TRAJ_SRK: (0, 0.25, 0.5, 1),
+                    _native.TRAJ_HEUN: (0, 1), _native.TRAJ_EULER_HEUN: (0, 1)}
 
     def _stage_times(self, ts, device, slots=None):
         """Every time at which this scheme evaluates f and g during the solve -- (K * S,) in ts.dtype on the device, the S
@@ -1339,6 +1340,12 @@ class _TwoStageStratonovich(BaseSDESolver):
     def __init__(self, sde, **kwargs):
         self.strong_order = 0.5 if sde.noise_type == NOISE_TYPES.general else 1.0
         super().__init__(sde=sde, **kwargs)
+
+    def _trajectory_code(self):
+        return self._program_code() if self._diag() else None
+
+    def _program_code(self):
+        return _native.TRAJ_HEUN if self.mode == 0 else _native.TRAJ_EULER_HEUN
 
     def _advance(self, y0, st, out):
         sde, dt, noise = self.sde, st.dt, st.noise

@@ -86,6 +86,16 @@ WORKLOADS = {
         problem="scalar_ito", method="srk", levy="space-time", B=65536, d=64, m=1, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=64 * 64, bytes_moved_per_traj_step=92 * 64, kid=4, launches_per_step=4,
         kernel="tsde_srk_diag_stage<float> (4 stage kernels; user f, g: ~12 torch kernels per evaluation)"),
+    # Heun (heun.py:35-48), the Stratonovich predictor-corrector, on the untouched GBM module: one launch of the affine
+    # kernel (two evaluations of f and g per step); stepwise counterpart below (tsde_step_diag + tsde_heun_final)
+    "c2_heun_diag_default_route_b65536_d64_s1000": dict(
+        problem="gbm_strat", method="heun", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=(16 + 28) * 64, kid=8, trajectory=True, recognised=True,
+        kernel="tsde_trajectory_affine_diag<float, heun> (user module recognised)"),
+    "c2_heun_diag_b65536_d64_s1000": dict(
+        problem="gbm_strat", method="heun", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=(16 + 28) * 64, kid=1, launches_per_step=2, bench_steps=200,
+        kernel="tsde_step_diag<float> + tsde_heun_final<float> (user f, g evaluated twice per step)"),
     # The reference's additive-noise problem (ExAdditive, tests/problems.py:106-132: f and g use t; g repeated over m columns)
     # with sdeint's default method for additive noise, SRK = SRA1 (sdeint.py:151, srk.py:90-111), as a drop-in call: the
     # drift travels as an expression program, the diffusion as a table over the stage times (one batched call of g), the
