@@ -323,11 +323,15 @@ int tsde_adaptive_control(double* ctl, void* scal, const double* error, const do
  * the commit of every attempt (and once after begin, for output times the start state already meets), writes the marked
  * rows  ys[j] = w0 prev_y + w1 curr_y  (interp.py:15-18; n elements per row) to the address stored in the device word
  * `ys_slot`. ctl[OUT_IDX] == ctl[N_OUT] means the solve is complete; later attempts are inert. One host
- * synchronisation per solve (to read that) instead of one per output time. */
+ * synchronisation per solve (to read that) instead of one per output time.
+ * `accept_log` (DEVICE, 2 * log_capacity doubles, or NULL): accepted step number k (k < log_capacity) leaves its
+ * (t0, t1) at [2k], [2k + 1] -- what a caller needs to run the accepted steps again, e.g. with autograd recording
+ * (base_solver.py:117-142 records every attempt; only the accepted half-steps reach the result). */
 int tsde_adaptive_begin_outputs(double* ctl, void* scal, const double* out_times, int32_t n_out, const double* stage_fracs,
                                 int n_fracs, int dtype, void* stream);
 int tsde_adaptive_control_outputs(double* ctl, void* scal, const double* error, const double* out_times,
-                                  const double* stage_fracs, int n_fracs, int dtype, void* stream);
+                                  double* accept_log, int32_t log_capacity, const double* stage_fracs, int n_fracs, int dtype,
+                                  void* stream);
 int tsde_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
                        const double* out_times, int dtype, void* stream);
 /* prev_y <- curr_y, curr_y <- y_next if the controller accepted the attempt; moves nothing otherwise. */

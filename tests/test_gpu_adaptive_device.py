@@ -204,3 +204,62 @@ def test_many_output_times_inside_single_steps():
     b, _ = _solve_on(sde, dense, 5, False, dt=0.2, rtol=1e-2, atol=1e-2)
     assert stats["output_times"] == len(dense) - 1 and stats["host_syncs"] <= 3 and stats["accepted"] < 30, stats
     torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.filterwarnings("ignore:Numerical solution is not guaranteed")
+@pytest.mark.parametrize("prob,method,levy,shape", [("gbm_ito", "milstein", "none", (48, 4, 4)),
+                                                    ("gbm_ito", "srk", "space-time", (48, 4, 4)),
+                                                    ("mlpdiag_ito", "euler", "none", (48, 4, 4)),
+                                                    ("additive_ito", "srk", "space-time", (48, 4, 3)),
+                                                    ("general_ito", "euler", "none", (48, 4, 4))])
+def test_adaptive_solve_with_gradients_replays_the_accepted_steps(prob, method, levy, shape):
+    """Autograd recording: the device-controlled loop finds the accepted steps under no_grad, then those alone are run again
+    with autograd on (adaptive.integrate_with_grad) -- values and gradients (y0 and every parameter) equal the host-driven
+    loop's, which records every attempt like the reference (base_solver.py:117-142); one synchronisation per round instead of
+    one per attempt."""
+    import torchsde_amd
+    from torchsde_amd import adaptive
+    B, d, m = shape
+    sde = problems.make(prob, d=d, m=m).to(DEV)
+    ts = torch.tensor([0.0, 0.3, 0.35, 1.0], device=DEV)
+    weights = None
+
+    def run(device_control):
+        nonlocal weights
+        y0 = torch.full((B, d), 0.1, device=DEV, requires_grad=True)
+        bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), dtype=torch.float32, device=DEV, entropy=21,
+                                           levy_area_approximation=levy)
+        sde.zero_grad()
+        adaptive.last_stats = None
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.1, adaptive=True, rtol=1e-3, atol=1e-3,
+                                 options={"device_adaptive": device_control, "hip_graph": False})
+        if weights is None:
+            weights = torch.cos(torch.arange(ys.numel(), device=DEV, dtype=torch.float32)).reshape(ys.shape)
+        (ys * weights).sum().backward()
+        return ys.detach(), y0.grad.clone(), {n: p.grad.clone() for n, p in sde.named_parameters()}, adaptive.last_stats
+
+    ys_d, gy_d, gp_d, stats = run(True)
+    ys_h, gy_h, gp_h, none = run(False)
+    assert none is None and stats is not None and "replayed" in stats["control"], stats
+    assert stats["replayed_steps"] == stats["accepted"] >= 3 and stats["host_syncs"] <= 3, stats
+    # the replayed steps ARE the device-controlled solve: same kernels, same increments
+    with torch.no_grad():
+        y0 = torch.full((B, d), 0.1, device=DEV)
+        bm = torchsde_amd.BrownianInterval(0.0, 1.0, size=(B, m), dtype=torch.float32, device=DEV, entropy=21,
+                                           levy_area_approximation=levy)
+        plain = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.1, adaptive=True, rtol=1e-3, atol=1e-3,
+                                    options={"hip_graph": False})
+    torch.testing.assert_close(ys_d, plain, rtol=2e-6, atol=2e-6)
+    assert gp_h and set(gp_d) == set(gp_h)
+    same_grid = torch.allclose(ys_d, ys_h, rtol=2e-5, atol=2e-6)
+    # The host loop's step sizes agree with the controller kernel's to an ulp of a double; where that rounds to another
+    # float32 time the two runs continue on different -- equally valid -- grids (profiles/r5_adaptive_one_sync.txt) and
+    # values and gradients agree to the accuracy of the solve instead of to rounding.
+    tol_y = dict(rtol=2e-5, atol=2e-6) if same_grid else dict(rtol=5e-3, atol=5e-4)
+    torch.testing.assert_close(ys_d, ys_h, **tol_y)
+    scale = max(gy_h.abs().max().item(), 1e-6)
+    torch.testing.assert_close(gy_d, gy_h, rtol=2e-4 if same_grid else 2e-2, atol=(2e-5 if same_grid else 2e-2) * scale)
+    for key in gp_h:
+        scale = max(gp_h[key].abs().max().item(), 1e-6)
+        torch.testing.assert_close(gp_d[key], gp_h[key], rtol=5e-4 if same_grid else 2e-2,
+                                   atol=(5e-5 if same_grid else 2e-2) * scale)

@@ -169,7 +169,8 @@ SIGNATURES = {
     "tsde_adaptive_begin": (_c_int, [_c_ptr, _c_ptr, _c_dbl, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
     "tsde_adaptive_control": (_c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
     "tsde_adaptive_begin_outputs": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i32, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
-    "tsde_adaptive_control_outputs": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
+    "tsde_adaptive_control_outputs": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i32, ctypes.POINTER(_c_dbl), _c_int,
+                                               _c_int, _c_ptr]),
     "tsde_adaptive_emit": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr]),
     "tsde_adaptive_commit": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr]),
     "tsde_merge_halves": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_dbl, _c_dbl, _c_int,

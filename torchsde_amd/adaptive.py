@@ -42,12 +42,15 @@ class DeviceController:
         # buffers, so that a recorded attempt serves every later solve
         self.out_times = torch.zeros(self.OUT_CAPACITY, dtype=torch.float64, device=device)
         self.ys_slot = torch.zeros(1, dtype=torch.int64, device=device)
+        # (t0, t1) of every accepted step, in order: what `integrate_with_grad` replays with autograd recording
+        self.accept_log = torch.zeros(2 * self.LOG_CAPACITY, dtype=torch.float64, device=device)
         self.dtype, self.device = dtype, device
         self.n_fracs = len(stage_fracs)
         self._fracs = (ctypes.c_double * max(self.n_fracs, 1))(*[float(f) for f in stage_fracs])
         self._lib, self._dt_code, _ = K._launch_env(self.scal)
 
     OUT_CAPACITY = 1024
+    LOG_CAPACITY = 8192
 
     def load(self, t0, t_end, step_size, dt_min):
         """The state a solve starts from: the one host->device copy of the solve."""
@@ -73,7 +76,8 @@ class DeviceController:
 
     def control(self, error):
         code = self._lib.tsde_adaptive_control_outputs(self.ctl.data_ptr(), self.scal.data_ptr(), error.data_ptr(),
-                                                       self.out_times.data_ptr(), self._fracs, self.n_fracs, self._dt_code,
+                                                       self.out_times.data_ptr(), self.accept_log.data_ptr(),
+                                                       self.LOG_CAPACITY, self._fracs, self.n_fracs, self._dt_code,
                                                        self._stream())
         _native.check(code, "tsde_adaptive_control_outputs")
 
@@ -110,6 +114,7 @@ class DeviceController:
 
 
 last_stats = None     # of the most recent device-controlled solve (tests, tools/bench_adaptive.py)
+_last_controller = None   # ... and its DeviceController (the accepted-step log `integrate_with_grad` reads)
 
 
 def query_dev(bm, bounds_ptr, out_W, out_U, out_H):
@@ -161,15 +166,20 @@ def _probe_no_gradient(solver, y0, ts):
     return not any(torch.is_tensor(p) and p.requires_grad for p in probes)
 
 
-def usable(solver, y0, ts):
-    """Can this solve run with device-side control? (Otherwise: the host-driven loop, one sync per attempt.)"""
+def controllable(solver, y0, ts):
+    """Everything device-side control needs, gradients aside."""
     bm = solver._native_bm()
     return (bm is not None and solver.options.get("device_adaptive", True)
             and bm._snap == 0 and bm._tol == 0. and bm._rootW is None and bm._rootH is None
             and not solver.stateful and solver.merges_half_steps and not solver.options.get("general_noise", False)
             and y0.dtype == ts.dtype == bm.dtype and y0.dtype in (torch.float32, torch.float64)
-            and len(solver.stage_fracs) <= _native.ADAPTIVE_MAX_STAGES - 1 and y0.numel() > 0
-            and _no_gradient_can_flow(solver, y0, ts))
+            and len(solver.stage_fracs) <= _native.ADAPTIVE_MAX_STAGES - 1 and y0.numel() > 0)
+
+
+def usable(solver, y0, ts):
+    """Can this solve run with device-side control and nothing else? (With gradients: `integrate_with_grad`; otherwise the
+    host-driven loop, one sync per attempt.)"""
+    return controllable(solver, y0, ts) and _no_gradient_can_flow(solver, y0, ts)
 
 
 class _Attempt:
@@ -372,6 +382,50 @@ def _hints_of(solver, y0, ts_host):
     return hints, key
 
 
+def integrate_with_grad(solver, y0, ts, extra0, step_cls):
+    """The adaptive solve when autograd is recording. The reference (base_solver.py:117-142) records EVERY attempt -- the
+    full step, both half steps, rejected ones included -- and synchronises after each; only the half steps of the accepted
+    attempts reach the result. Here the device-controlled loop runs first, under no_grad, and logs the accepted steps; then
+    exactly those are run again with autograd recording (two half steps each, the same kernels on the same increments, so the
+    same values), and the output rows are interpolated from them. Same gradients, no synchronisation per attempt, a third of
+    the autograd graph. None when the log overflowed (the caller takes the host-driven loop)."""
+    global last_stats
+    with torch.no_grad():
+        values, _ = integrate(solver, y0.detach(), ts, extra0, step_cls)
+    stats = dict(last_stats)
+    accepted = stats["accepted"]
+    ctrl = _last_controller
+    if accepted > ctrl.LOG_CAPACITY:
+        return None
+    log = ctrl.accept_log[:2 * accepted].cpu().numpy().reshape(-1, 2)
+    ts_host = timegrid.ts_to_host(ts)
+    np_dtype = ts_host.dtype.type
+    prev_t = curr_t = ts_host[0]
+    prev_y = curr_y = y0
+    extra = tuple(extra0) if extra0 is not None else ()
+    ys, i_out, T = [y0], 1, len(ts_host)
+    for t0, t1 in log:
+        t0, t1 = np_dtype(t0), np_dtype(t1)
+        mid = np_dtype(0.5) * (t0 + t1)
+        _, n_a, n_b = solver._step_doubling_noise(float(t0), float(mid), float(t1))
+        host = solver._stage_times_host(t0, mid) + solver._stage_times_host(mid, t1)
+        dev_times = torch.tensor(np.asarray(host, dtype=ts_host.dtype), device=y0.device).to(ts.dtype).unbind(0)
+        k = len(host) // 2
+        y_mid, mid_extra = solver.step(t0, mid, curr_y, extra, noise=n_a, times=dev_times[:k])
+        y_next, extra = solver.step(mid, t1, y_mid, mid_extra, noise=n_b, times=dev_times[k:])
+        prev_t, prev_y, curr_t, curr_y = t0, curr_y, t1, y_next
+        while i_out < T and not curr_t < ts_host[i_out]:
+            out_t = ts_host[i_out]
+            w0 = (curr_t - out_t) / (curr_t - prev_t)
+            w1 = (out_t - prev_t) / (curr_t - prev_t)
+            ys.append(K.linear_interp(prev_y, curr_y, float(w0), float(w1)))
+            i_out += 1
+    if i_out != T:
+        return None                     # (cannot happen: the device loop reached every output time with these steps)
+    last_stats = dict(stats, control="device, accepted steps replayed with autograd", replayed_steps=int(accepted))
+    return torch.stack(ys, dim=0), extra
+
+
 def integrate(solver, y0, ts, extra0, step_cls):
     """The adaptive solve of `solver` (see the module docstring). Returns (ys, extra solver state)."""
     bm = solver._native_bm()
@@ -448,4 +502,6 @@ def integrate(solver, y0, ts, extra0, step_cls):
     last_stats = {"control": "device", "host_syncs": syncs, "output_times": T - 1, "attempts_enqueued": attempts,
                   "attempts_used": int(final[_native.CTL_ATTEMPTS]), "accepted": int(final[_native.CTL_ACCEPTED]),
                   "dtype": np_dtype.__name__, "launch": "graph replay" if hasattr(attempt, "graph") else "eager"}
+    global _last_controller
+    _last_controller = ctrl
     return ys, solver._extra

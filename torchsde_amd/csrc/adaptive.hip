@@ -145,7 +145,8 @@ __global__ void adaptive_begin_kernel(double* ctl, T* scal, double out_t, const 
 // After an attempt: base_solver.py:125-142.
 template <typename T>
 __global__ void adaptive_control_kernel(double* ctl, T* scal, const double* __restrict__ error,
-                                        const double* __restrict__ out_times, StageFracs sf) {
+                                        const double* __restrict__ out_times, double* __restrict__ accept_log,
+                                        int log_capacity, StageFracs sf) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   scal[kAccept] = (T)0;
   if (out_times != nullptr) ctl[kEmitCount] = 0.0;
@@ -166,6 +167,12 @@ __global__ void adaptive_control_kernel(double* ctl, T* scal, const double* __re
     const T t_end = (T)ctl[kTEnd];
     ctl[kPrevT] = (double)curr;
     ctl[kCurrT] = (double)(nxt <= t_end ? nxt : t_end);
+    // the accepted steps in order, for a caller that replays them (gradients: adaptive.integrate_with_grad)
+    const int n_acc = (int)ctl[kAccepted];
+    if (accept_log != nullptr && n_acc < log_capacity) {
+      accept_log[2 * n_acc] = ctl[kPrevT];
+      accept_log[2 * n_acc + 1] = ctl[kCurrT];
+    }
     ctl[kAccepted] += 1.0;
     scal[kAccept] = (T)1;
   }
@@ -266,11 +273,12 @@ hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const do
 
 template <typename T>
 hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* out_times,
-                                   const double* fracs, int n_fracs, hipStream_t s) {
+                                   double* accept_log, int log_capacity, const double* fracs, int n_fracs, hipStream_t s) {
   StageFracs sf;
   sf.n = n_fracs;
   for (int j = 0; j < kMaxStages - 1; ++j) sf.frac[j] = j < n_fracs ? fracs[j] : 0.0;
-  hipLaunchKernelGGL(adaptive_control_kernel<T>, dim3(1), dim3(64), 0, s, ctl, (T*)scal, error, out_times, sf);
+  hipLaunchKernelGGL(adaptive_control_kernel<T>, dim3(1), dim3(64), 0, s, ctl, (T*)scal, error, out_times, accept_log,
+                     log_capacity, sf);
   return hipGetLastError();
 }
 
@@ -304,8 +312,8 @@ hipError_t launch_merge_halves(void* W, void* U, const void* Wa, const void* Ha,
 #define TSDE_ADAPTIVE_INSTANTIATE(T)                                                                              \
   template hipError_t launch_adaptive_begin<T>(double*, void*, double, const double*, int, const double*, int,    \
                                                hipStream_t);                                                      \
-  template hipError_t launch_adaptive_control<T>(double*, void*, const double*, const double*, const double*, int, \
-                                                 hipStream_t);                                                    \
+  template hipError_t launch_adaptive_control<T>(double*, void*, const double*, const double*, double*, int,      \
+                                                 const double*, int, hipStream_t);                                \
   template hipError_t launch_adaptive_emit<T>(const void*, const void*, const void*, int64_t, const double*,      \
                                               const double*, hipStream_t);                                        \
   template hipError_t launch_adaptive_commit<T>(void*, void*, const void*, int64_t, const void*, hipStream_t);    \

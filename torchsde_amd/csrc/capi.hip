@@ -437,14 +437,17 @@ int tsde_adaptive_begin_outputs(double* ctl, void* scal, const double* out_times
 }
 
 int tsde_adaptive_control_outputs(double* ctl, void* scal, const double* error, const double* out_times,
-                                  const double* stage_fracs, int n_fracs, int dtype, void* stream) {
+                                  double* accept_log, int32_t log_capacity, const double* stage_fracs, int n_fracs, int dtype,
+                                  void* stream) {
   const char* where = "tsde_adaptive_control_outputs";
   if (!ctl || !scal || !error || !out_times || !stage_fracs) return bad_arg(where, "null argument");
   if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg(where, "bad number of stages");
   const hipStream_t s = (hipStream_t)stream;
   TSDE_DISPATCH(dtype, where,
-                tsde::launch_adaptive_control<float>(ctl, scal, error, out_times, stage_fracs, n_fracs, s),
-                tsde::launch_adaptive_control<double>(ctl, scal, error, out_times, stage_fracs, n_fracs, s));
+                tsde::launch_adaptive_control<float>(ctl, scal, error, out_times, accept_log, log_capacity, stage_fracs,
+                                                     n_fracs, s),
+                tsde::launch_adaptive_control<double>(ctl, scal, error, out_times, accept_log, log_capacity, stage_fracs,
+                                                      n_fracs, s));
 }
 
 int tsde_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
@@ -463,8 +466,8 @@ int tsde_adaptive_control(double* ctl, void* scal, const double* error, const do
   if (n_fracs < 1 || n_fracs > TSDE_ADAPTIVE_MAX_STAGES - 1) return bad_arg("tsde_adaptive_control", "bad number of stages");
   const hipStream_t s = (hipStream_t)stream;
   TSDE_DISPATCH(dtype, "tsde_adaptive_control",
-                tsde::launch_adaptive_control<float>(ctl, scal, error, nullptr, stage_fracs, n_fracs, s),
-                tsde::launch_adaptive_control<double>(ctl, scal, error, nullptr, stage_fracs, n_fracs, s));
+                tsde::launch_adaptive_control<float>(ctl, scal, error, nullptr, nullptr, 0, stage_fracs, n_fracs, s),
+                tsde::launch_adaptive_control<double>(ctl, scal, error, nullptr, nullptr, 0, stage_fracs, n_fracs, s));
 }
 
 int tsde_adaptive_commit(void* prev_y, void* curr_y, const void* y_next, int64_t n, const void* scal, int dtype,

@@ -106,7 +106,7 @@ hipError_t launch_adaptive_begin(double* ctl, void* scal, double out_t, const do
                                  const double* fracs, int n_fracs, hipStream_t s);
 template <typename T>
 hipError_t launch_adaptive_control(double* ctl, void* scal, const double* error, const double* out_times,
-                                   const double* fracs, int n_fracs, hipStream_t s);
+                                   double* accept_log, int log_capacity, const double* fracs, int n_fracs, hipStream_t s);
 template <typename T>
 hipError_t launch_adaptive_emit(const void* ys_slot, const void* prev_y, const void* curr_y, int64_t n, const double* ctl,
                                 const double* out_times, hipStream_t s);

@@ -243,6 +243,11 @@ class BaseSDESolver:
         if adaptive.usable(self, y0, ts):
             # the same loop with accept / reject decided ON THE DEVICE: no sync per attempt (adaptive.py)
             return adaptive.integrate(self, y0, ts, extra0, _Step)
+        if adaptive.controllable(self, y0, ts) and torch.is_grad_enabled():
+            # gradients flow: the device-controlled loop finds the accepted steps, autograd records only those
+            done = adaptive.integrate_with_grad(self, y0, ts, extra0, _Step)
+            if done is not None:
+                return done
         np_dtype = timegrid._NP[ts.dtype]
         ts_host = timegrid.ts_to_host(ts)
         t_end = ts_host[-1]
