@@ -207,3 +207,39 @@ def test_bridge_law_of_path_and_tree(kind):
     two_d = torchsde_amd.BrownianPath(t0=0.0, w0=torch.zeros(64, 5, device=DEV))
     with pytest.warns(UserWarning):
         assert two_d(0.4).shape == (64, 5)
+
+
+@pytest.mark.parametrize("kind", ["path", "tree"])
+def test_legacy_brownian_objects_reach_the_one_launch_route(kind):
+    """`sdeint(..., bm=BrownianPath(...))` / `BrownianTree(...)` (derived.py:52-191): interval queries of these objects ARE
+    their BrownianInterval's increments, so the solver talks to that interval; with a BrownianPath an unchanged user module
+    takes the trajectory kernel exactly as with a BrownianInterval -- same path, same values as the stepwise route."""
+    import torchsde_amd
+    from tests.test_gpu_programs import _book, _launches
+    from workloads import problems
+    B, d, dt = 256, 8, 2.0 ** -6
+    sde = problems.make("gbm_ito", d=d).to(DEV)
+    y0 = torch.full((B, d), 0.3, device=DEV)
+    ts = torch.tensor([0.0, 0.25, 0.5], device=DEV)
+    w0 = torch.zeros(B, d, device=DEV)
+    bm = torchsde_amd.BrownianPath(t0=0.0, w0=w0) if kind == "path" else \
+        torchsde_amd.BrownianTree(t0=0.0, w0=w0, t1=1.0, entropy=5, tol=1e-6)
+
+    def solve(options=None):
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, ts, bm=bm, method="euler", dt=dt, options=options)
+    first = solve({"hip_graph": False})                                 # both routes, compared; the stepwise result
+    fast, launches = _launches(lambda: solve({"hip_graph": False}))
+    stepwise = solve({"hip_graph": False, "trajectory_kernel": False})
+    assert torch.equal(first, stepwise)
+    if kind == "path":
+        assert launches == 1 and list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    else:
+        # a BrownianTree's path is its dyadic tree resolved to `tol`: its cells are not the solver's steps, the kernels'
+        # per-step generator cannot reproduce it, and the solve stays stepwise (on the same increments)
+        assert launches == 0 and not _book(sde)["trusted"], _book(sde)
+    torch.testing.assert_close(fast, stepwise, rtol=2e-5, atol=2e-6)
+    # ... and the increments the solver consumed are the object's own
+    direct = torch.stack([bm(k * dt, (k + 1) * dt) for k in range(4)])
+    again = torch.stack([bm._interval(k * dt, (k + 1) * dt) for k in range(4)])
+    assert torch.equal(direct, again)

@@ -117,7 +117,10 @@ class BaseSDESolver:
         if sde.noise_type == NOISE_TYPES.scalar and torch.Size(bm.shape[1:]).numel() != 1:
             raise ValueError("The Brownian motion for scalar SDEs must of dimension 1.")
         self.sde = sde
-        self.bm = bm
+        # BrownianPath / BrownianTree (derived.py:52-191) answer interval queries with their BrownianInterval's increments
+        # (w0 only shifts point values): the solver talks to that interval, so these objects reach every route it does
+        from .brownian import _IntervalWrapper
+        self.bm = bm._interval if isinstance(bm, _IntervalWrapper) else bm
         self.dt = dt
         self.adaptive = adaptive
         self.rtol = rtol
