@@ -522,7 +522,7 @@ typedef struct tsde_mlp {
  * A wave keeps 16 rows in registers for the whole solve; every weight lives in LDS; all four layers run on
  * v_mfma_f32_16x16x4_f32 (exact f32), the contraction with the increments included (csrc/mlp_general.hip).
  * traj->step_rows[k][7] must hold t_k, the time at which step k starts (the other trajectory kernels ignore that slot).
- * d a multiple of 4 up to 64, hidden sizes up to 64, and all weights must fit the 160 KiB of LDS:
+ * d a multiple of 4 up to 64, hidden sizes up to 128 (general noise: 64), and all weights must fit the 160 KiB of LDS:
  * tsde_trajectory_mlp_general_lds returns the bytes a shape needs (0: no kernel for it). dtype must be TSDE_F32;
  * elem0 a multiple of 4; ys, y0 16-byte aligned; rows * d < 2^30. Outputs and increments as tsde_trajectory_mlp_diag. */
 int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
@@ -537,7 +537,7 @@ int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidd
  * else (n_steps, slots, m, d) with slots = 1 Euler, 2 midpoint (t_k, t_k + dt/2), 2 SRK (t_k + dt, t_k)) and is contracted
  * with the row's increments on the matrix cores. method: TSDE_TRAJ_EULER (also Milstein with additive noise),
  * TSDE_TRAJ_MIDPOINT, TSDE_TRAJ_SRK (SRA1, srk.py:90-111: two drift evaluations per step, at t_k and t_k + 3/4 dt).
- * 1 <= m <= 16, any elem0; d a multiple of 4 up to 64, hidden up to 64; dtype TSDE_F32. */
+ * 1 <= m <= 16, any elem0; d a multiple of 4 up to 64, hidden up to 128; dtype TSDE_F32. */
 int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const tsde_mlp_t* drift,
                                  const void* g_table, int g_time_dependent, int method, const tsde_traj_t* traj,
                                  uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);

@@ -78,7 +78,7 @@ def test_diagonal_and_scalar_noise_networks(name, m_of, method, sde_type):
     """NeuralDiagonal / NeuralScalar (tests/problems.py:135-192): 0.1 * sigmoid-closed g_net, (B, d) or (B, d, 1); Euler,
     midpoint, SRK (SRID2: three drift and four diffusion evaluations per step, srk.py:57-88) and the call with EVERY default
     (method None: `sdeint` picks SRK for diagonal and scalar Ito noise, sdeint.py:246-253)."""
-    for d, hidden in ((8, 8), (20, 24), (64, 64)):
+    for d, hidden in ((8, 8), (20, 24), (64, 64), (16, 128), (64, 100)):       # (hidden above 64: the 128-unit instantiations)
         sde = problems.make(f"{name}_{'ito' if sde_type == 'ito' else 'strat'}", d=d, hidden=hidden).to(DEV)
         m = m_of(d)
         _solve(sde, m, 1, method, d=d)

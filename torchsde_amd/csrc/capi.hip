@@ -620,7 +620,7 @@ int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t
   const char* where = "tsde_trajectory_mlp_additive";
   if (!ys || !y0 || !drift || !g_table || !traj) return bad_arg(where, "null argument");
   if (!drift->w1 || !drift->b1 || !drift->w2 || !drift->b2) return bad_arg(where, "a perceptron without weights or biases");
-  if (drift->hidden < 1 || drift->hidden > 64) return bad_arg(where, "hidden sizes must be in [1, 64]");
+  if (drift->hidden < 1 || drift->hidden > 128) return bad_arg(where, "hidden sizes must be in [1, 128]");
   if (drift->activation != TSDE_ACT_TANH && drift->activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
   if (drift->precision != TSDE_PRECISION_F32) return bad_arg(where, "the drift runs in exact f32");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
@@ -683,7 +683,8 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
   if (!ys || !y0 || !drift || !diffusion || !traj) return bad_arg(where, "null argument");
   for (const tsde_mlp_t* net : {drift, diffusion}) {
     if (!net->w1 || !net->b1 || !net->w2 || !net->b2) return bad_arg(where, "a perceptron without weights or biases");
-    if (net->hidden < 1 || net->hidden > 64) return bad_arg(where, "hidden sizes must be in [1, 64]");
+    if (net->hidden < 1 || net->hidden > (noise == TSDE_NOISE_GENERAL ? 64 : 128))
+      return bad_arg(where, "hidden sizes must be in [1, 64] (general noise) or [1, 128]");
     if (net->activation != TSDE_ACT_TANH && net->activation != TSDE_ACT_SOFTPLUS) return bad_arg(where, "unknown activation");
     if (net->final != TSDE_FINAL_NONE && net->final != TSDE_FINAL_SIGMOID) return bad_arg(where, "unknown output function");
     if (net->precision != TSDE_PRECISION_F32 && net->precision != TSDE_PRECISION_BF16X3) return bad_arg(where, "unknown precision");

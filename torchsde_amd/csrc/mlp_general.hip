@@ -759,13 +759,16 @@ static hipError_t launch_neural_dh(const NeuralArgs& p, int noise, hipStream_t s
   if (noise == TSDE_NOISE_DIAGONAL) return launch_neural_mode<D, H, 0>(p, s);
   if (noise == TSDE_NOISE_SCALAR) return launch_neural_mode<D, H, 1>(p, s);
   if (noise == TSDE_NOISE_ADDITIVE) return launch_neural_mode<D, H, 2>(p, s);
-  switch (p.m) {
-    case 4: return launch_neural_mode<D, H, 4>(p, s);
-    case 8: return launch_neural_mode<D, H, 8>(p, s);
-    case 16: return launch_neural_mode<D, H, 16>(p, s);
-    case 32: return launch_neural_mode<D, H, 32>(p, s);
-    default: return hipErrorInvalidValue;
+  if constexpr (H <= 64) {      // (general noise: H x d*m weights of the diffusion's second layer; 128 units do not fit the LDS)
+    switch (p.m) {
+      case 4: return launch_neural_mode<D, H, 4>(p, s);
+      case 8: return launch_neural_mode<D, H, 8>(p, s);
+      case 16: return launch_neural_mode<D, H, 16>(p, s);
+      case 32: return launch_neural_mode<D, H, 32>(p, s);
+      default: return hipErrorInvalidValue;
+    }
   }
+  return hipErrorInvalidValue;
 }
 
 template <int D>
@@ -773,6 +776,7 @@ static hipError_t launch_neural_d(const NeuralArgs& p, int noise, hipStream_t s)
   const int h = p.f.hidden > p.g.hidden ? p.f.hidden : p.g.hidden;
   if (h <= 32) return launch_neural_dh<D, 32>(p, noise, s);
   if (h <= 64) return launch_neural_dh<D, 64>(p, noise, s);
+  if (h <= 128 && noise != TSDE_NOISE_GENERAL) return launch_neural_dh<D, 128>(p, noise, s);
   return hipErrorInvalidValue;
 }
 
@@ -796,7 +800,7 @@ static NeuralNet device_view(const tsde_mlp_t* n) {
 size_t neural_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t out, int noise) {
   const int D = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 0;
   const int64_t h = hf > hg ? hf : hg;
-  const int H = h <= 32 ? 32 : h <= 64 ? 64 : 0;
+  const int H = h <= 32 ? 32 : h <= 64 ? 64 : (h <= 128 && noise != TSDE_NOISE_GENERAL) ? 128 : 0;
   if (D == 0 || H == 0) return 0;
   int group = 1;
   if (noise == TSDE_NOISE_GENERAL) {

@@ -1031,8 +1031,8 @@ class RecognisedAdditive:
             if dtype != torch.float32 or d % 4 != 0 or d > 64:
                 raise NotElementwise("a drift network outside the neural-SDE kernel's shapes (float32, d a multiple of 4 up "
                                      "to 64)")
-            if f.out != d or f.final is not None or f.scale != 1.0 or f.shape[1:] != (d,) or f.w1.shape[0] > 64:
-                raise NotElementwise("a drift network that does not map to the state channels (or is wider than 64)")
+            if f.out != d or f.final is not None or f.scale != 1.0 or f.shape[1:] != (d,) or f.w1.shape[0] > 128:
+                raise NotElementwise("a drift network that does not map to the state channels (or is wider than 128)")
             if any(t is not None and (t.dtype != torch.float32 or t.device != device) for t in (f.w1, f.b1, f.w2, f.b2, f.wt)):
                 raise NotElementwise("network weights of another dtype or device than the state")
             self.net = f
