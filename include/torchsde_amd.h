@@ -511,7 +511,8 @@ typedef struct tsde_mlp {
 /* All fixed steps of the SDE  dy = drift(t, y) dt + g(t, y) dW  with both functions perceptrons as above, in ONE launch
  * (replaces base_solver.py:114-134 driving methods/euler.py:29-37 -- whose f_and_g_prod is misc.batch_mvp,
  * _core/misc.py:62-63: bmm(g, dW) -- or methods/midpoint.py:29-45). BASELINE configs[2] is this with noise = GENERAL:
- *   noise = TSDE_NOISE_GENERAL   diffusion->out = d * m, read as (rows, d, m) row-major (`.view(B, d, m)`); m in {4, 8, 16, 32};
+ *   noise = TSDE_NOISE_GENERAL   diffusion->out = d * m, read as (rows, d, m) row-major (`.view(B, d, m)`); 1 <= m <= 32 (run in
+ *                                the next tile width 4 / 8 / 16 / 32: the padding is zero weights and zero increments);
  *                                increments: the (rows, m) field, element (row, j) = elem0 + row * m + j
  *   noise = TSDE_NOISE_DIAGONAL  diffusion->out = d, m = d: g[., i] dW[., i]             (NeuralDiagonal)
  *   noise = TSDE_NOISE_SCALAR    diffusion->out = d, m = 1: g[., i] dW[.]                (NeuralScalar)
@@ -522,9 +523,10 @@ typedef struct tsde_mlp {
  * A wave keeps 16 rows in registers for the whole solve; every weight lives in LDS; all four layers run on
  * v_mfma_f32_16x16x4_f32 (exact f32), the contraction with the increments included (csrc/mlp_general.hip).
  * traj->step_rows[k][7] must hold t_k, the time at which step k starts (the other trajectory kernels ignore that slot).
- * d a multiple of 4 up to 64, hidden sizes up to 128 (general noise: 64), and all weights must fit the 160 KiB of LDS:
+ * 1 <= d <= 64 (a multiple of 4 with an aligned field takes the 16-byte / whole-quad paths), hidden sizes up to 128 (general
+ * noise: 64), and all weights must fit the 160 KiB of LDS:
  * tsde_trajectory_mlp_general_lds returns the bytes a shape needs (0: no kernel for it). dtype must be TSDE_F32;
- * elem0 a multiple of 4; ys, y0 16-byte aligned; rows * d < 2^30. Outputs and increments as tsde_trajectory_mlp_diag. */
+ * any elem0; ys, y0 16-byte aligned; rows * d < 2^30. Outputs and increments as tsde_trajectory_mlp_diag. */
 int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
                                 const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method, const tsde_traj_t* traj,
                                 uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);
@@ -537,7 +539,7 @@ int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidd
  * else (n_steps, slots, m, d) with slots = 1 Euler, 2 midpoint (t_k, t_k + dt/2), 2 SRK (t_k + dt, t_k)) and is contracted
  * with the row's increments on the matrix cores. method: TSDE_TRAJ_EULER (also Milstein with additive noise),
  * TSDE_TRAJ_MIDPOINT, TSDE_TRAJ_SRK (SRA1, srk.py:90-111: two drift evaluations per step, at t_k and t_k + 3/4 dt).
- * 1 <= m <= 16, any elem0; d a multiple of 4 up to 64, hidden up to 128; dtype TSDE_F32. */
+ * 1 <= m <= 16, any elem0; 1 <= d <= 64, hidden up to 128; dtype TSDE_F32. */
 int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const tsde_mlp_t* drift,
                                  const void* g_table, int g_time_dependent, int method, const tsde_traj_t* traj,
                                  uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);

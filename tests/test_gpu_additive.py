@@ -86,7 +86,7 @@ def test_a_diffusion_that_is_a_network_of_t(method, sde_type, levy):
 
 
 @pytest.mark.parametrize("d,m,hidden", [(8, 3, 8), (16, 4, 32), (12, 5, 8), (32, 8, 64), (64, 16, 40), (20, 2, 8), (64, 8, 128),
-                                        (24, 4, 96)])
+                                        (24, 4, 96), (3, 2, 8), (10, 3, 16), (37, 5, 24)])
 @pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
 def test_the_references_neural_additive_problem_is_one_launch(method, sde_type, levy, d, m, hidden):
     """NeuralAdditive (tests/problems.py:195-224): f_net of cat([t, y]) on the matrix cores (`tsde_trajectory_mlp_additive`),

@@ -51,7 +51,9 @@ def _launches(fn):
     return out, K.prof_end()[1]
 
 
-GENERAL = [(8, 4, 8), (12, 4, 8), (8, 8, 8), (20, 8, 16), (32, 16, 64), (16, 16, 8), (8, 32, 24), (36, 8, 40)]
+GENERAL = [(8, 4, 8), (12, 4, 8), (8, 8, 8), (20, 8, 16), (32, 16, 64), (16, 16, 8), (8, 32, 24), (36, 8, 40),
+           # any d <= 64 and any m <= 32: rows that are not 16-byte groups, channel counts between the tile widths
+           (3, 5, 8), (10, 3, 16), (6, 2, 8), (17, 12, 24), (5, 20, 8), (1, 1, 8), (63, 7, 32)]
 
 
 @pytest.mark.parametrize("d,m,hidden", GENERAL)
@@ -78,7 +80,8 @@ def test_diagonal_and_scalar_noise_networks(name, m_of, method, sde_type):
     """NeuralDiagonal / NeuralScalar (tests/problems.py:135-192): 0.1 * sigmoid-closed g_net, (B, d) or (B, d, 1); Euler,
     midpoint, SRK (SRID2: three drift and four diffusion evaluations per step, srk.py:57-88) and the call with EVERY default
     (method None: `sdeint` picks SRK for diagonal and scalar Ito noise, sdeint.py:246-253)."""
-    for d, hidden in ((8, 8), (20, 24), (64, 64), (16, 128), (64, 100)):       # (hidden above 64: the 128-unit instantiations)
+    # (hidden above 64: the 128-unit instantiations; d = 3, 10, 37: rows that are not 16-byte groups)
+    for d, hidden in ((8, 8), (20, 24), (64, 64), (16, 128), (64, 100), (3, 8), (10, 16), (37, 24)):
         sde = problems.make(f"{name}_{'ito' if sde_type == 'ito' else 'strat'}", d=d, hidden=hidden).to(DEV)
         m = m_of(d)
         _solve(sde, m, 1, method, d=d)
@@ -108,10 +111,10 @@ def test_live_parameters_and_what_stays_stepwise():
     b, launches = _launches(lambda: _solve(sde, 4, 2, "euler"))
     assert launches == 1 and not torch.equal(a, b)
     torch.testing.assert_close(b, _solve(sde, 4, 2, "euler", stepwise=True), rtol=2e-5, atol=2e-6)
-    # shapes without a tile form (m = 5, d = 3), and schemes the kernel does not have, keep the stepwise route
-    odd = problems.make("general_odd_ito").to(DEV)
+    # schemes the kernel does not have, and states wider than 64 channels, keep the stepwise route
+    wide = problems.MLPGeneral(68, 4, "ito", hidden=8).to(DEV)
     for _ in range(2):
-        got, launches = _launches(lambda: _solve(odd, 5, 3, "euler", d=3))
+        got, launches = _launches(lambda: _solve(wide, 4, 3, "euler", d=68))
         assert launches == 0
     strat = problems.MLPGeneral(8, 4, "stratonovich", hidden=8).to(DEV)
     for _ in range(2):

@@ -395,9 +395,14 @@ def test_networks_the_neural_kernel_does_not_take():
     if not _native.is_built():
         pytest.skip("needs the built library")
     y, t = torch.randn(16, 8), torch.tensor(0.1)
-    odd = problems.make("general_odd_ito")                     # d = 3, m = 5: no tile shape for it
-    with pytest.raises(recognise.NotElementwise):
-        recognise.recognise(ForwardSDE(odd), t, torch.randn(16, 3)).neural_spec("general")
+    odd = problems.make("general_odd_ito")                     # d = 3, m = 5: runs in the m = 8 tile width, element-wise rows
+    assert recognise.recognise(ForwardSDE(odd), t, torch.randn(16, 3)).neural_spec("general")[3:] == (_native.NOISE_GENERAL, 5)
+    wide = problems.MLPGeneral(68, 4, "ito", hidden=8)         # more than 64 state channels / 33 Brownian channels: no kernel
+    with pytest.raises(recognise.NotElementwise, match="outside the neural-SDE kernel's shapes"):
+        recognise.recognise(ForwardSDE(wide), t, torch.randn(16, 68)).neural_spec("general")
+    many = problems.MLPGeneral(8, 33, "ito", hidden=8)
+    with pytest.raises(recognise.NotElementwise, match="outside the neural-SDE kernel's shapes"):
+        recognise.recognise(ForwardSDE(many), t, y).neural_spec("general")
 
     class TimeTwice(problems.MLPNetDiag):                      # arithmetic on t before the cat: not "the time" any more
         def _ty(self, t, y):

@@ -625,7 +625,7 @@ int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t
   if (drift->precision != TSDE_PRECISION_F32) return bad_arg(where, "the drift runs in exact f32");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
-  if (d < 4 || d > 64 || d % 4 != 0) return bad_arg(where, "need d a multiple of 4 in [4, 64]");
+  if (d < 1 || d > 64) return bad_arg(where, "need d in [1, 64]");
   if (m < 1 || m > 16) return bad_arg(where, "need 1 <= m <= 16 Brownian channels");
   if (drift->out != d || drift->final != TSDE_FINAL_NONE || drift->scale != 1.0)
     return bad_arg(where, "the drift maps to d channels, with no output function and scale 1");
@@ -672,7 +672,7 @@ int tsde_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_
 
 int64_t tsde_trajectory_mlp_general_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden,
                                         int64_t diffusion_out, int noise) {
-  if (d < 4 || d % 4 != 0 || drift_hidden < 1 || diffusion_hidden < 1 || diffusion_out < 1) return 0;
+  if (d < 1 || drift_hidden < 1 || diffusion_hidden < 1 || diffusion_out < 1) return 0;
   return (int64_t)tsde::neural_footprint(d, m, drift_hidden, diffusion_hidden, diffusion_out, noise);
 }
 
@@ -693,11 +693,11 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
     return bad_arg(where, "split-bf16 products are for the diffusion net under general noise only");
   if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
   if (rows < 0) return bad_arg(where, "need rows >= 0");
-  if (d < 4 || d > 64 || d % 4 != 0) return bad_arg(where, "need d a multiple of 4 in [4, 64]");
+  if (d < 1 || d > 64) return bad_arg(where, "need d in [1, 64]");
   if (drift->out != d || drift->final != TSDE_FINAL_NONE || drift->scale != 1.0)
     return bad_arg(where, "the drift maps to d channels, with no output function and scale 1");
   if (noise == TSDE_NOISE_GENERAL) {
-    if (m != 4 && m != 8 && m != 16 && m != 32) return bad_arg(where, "general noise: m must be 4, 8, 16 or 32");
+    if (m < 1 || m > 32) return bad_arg(where, "general noise: m must be in [1, 32]");
     if (diffusion->out != d * m) return bad_arg(where, "general noise: the diffusion net maps to d * m outputs");
   } else if (noise == TSDE_NOISE_DIAGONAL || noise == TSDE_NOISE_SCALAR) {
     if (diffusion->out != d) return bad_arg(where, "diagonal / scalar noise: the diffusion net maps to d outputs");
@@ -714,7 +714,6 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
     return bad_arg(where, "method must be Euler, midpoint or SRK");
   if (method == TSDE_TRAJ_SRK && noise == TSDE_NOISE_GENERAL)
     return bad_arg(where, "SRK (SRID2) takes diagonal or scalar noise, like the reference's (srk.py:34-35)");
-  if (elem0 % 4 != 0) return bad_arg(where, "elem0 must be a multiple of 4");
   if (traj->n_steps < 0 || traj->n_out < 0) return bad_arg(where, "negative schedule length");
   if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return bad_arg(where, "schedule without step rows");
   if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return bad_arg(where, "schedule without output map");

@@ -80,6 +80,12 @@ struct NoiseShape {
   static constexpr int kQuads = (M >= 16) ? M / 16 : 1;      // Philox quads of a row's increments one lane needs
 };
 
+// One normal of the field, out of line: the element-by-element paths (d % 4 != 0, m not a tile width, an unaligned field) are
+// rare and must not cost the common path registers.
+__device__ __noinline__ float draw_one(NoiseKey key, uint64_t elem, uint32_t cell, uint32_t stream) {
+  return normal1<float>(key, elem, cell, 0, stream);
+}
+
 // the diffusion net's output function (uniform over the launch: callers branch once, outside their loops)
 template <bool SIGMOID>
 TSDE_D float finalise(float z) {
@@ -154,7 +160,16 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
   __bf16* W2lo = W2hi + (size_t)outp * H;
   for (int i = threadIdx.x; i < H * outp; i += 256) {
     const int u = i / outp, o = i % outp;
-    const float w = (u < hg && o < outT) ? p.g.w2[(int64_t)u * outT + o] : 0.0f;
+    // general noise: the net's outputs are (i, j) row-major with m REAL Brownian channels; the tiles want i * M + j with M the
+    // channel count padded to 4 / 8 / 16 / 32 (padded channels: zero weights, zero bias, zero increments)
+    int src = o;
+    bool have = o < outT;
+    if constexpr (NS::kGeneral) {
+      const int ci = o / M, cj = o % M;
+      have = ci < dT && cj < p.m;
+      src = ci * p.m + cj;
+    }
+    const float w = (u < hg && have) ? p.g.w2[(int64_t)u * outT + src] : 0.0f;
     if constexpr (SPLIT) {
       // unit u = 32 b + 16 tt + 4 part + r  ->  chunk 4 b + part (swizzled by the row), position 4 tt + r
       const int b = u >> 5, tt = (u >> 4) & 1, pq = (u >> 2) & 3, r = u & 3;
@@ -178,7 +193,14 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
   constexpr float kNegLog2e = -1.4426950408889634f;
   const bool prescaled = NS::kGeneral && p.g.final == TSDE_FINAL_SIGMOID;
   for (int i = threadIdx.x; i < outp; i += 256) {
-    const float b = i < outT ? p.g.b2[i] : 0.0f;
+    int src = i;
+    bool have = i < outT;
+    if constexpr (NS::kGeneral) {
+      const int ci = i / M, cj = i % M;
+      have = ci < dT && cj < p.m;
+      src = ci * p.m + cj;
+    }
+    const float b = have ? p.g.b2[src] : 0.0f;
     b2g[i] = prescaled ? b * kNegLog2e : b;
   }
   __syncthreads();
@@ -202,12 +224,24 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
     const int64_t row = row0 + n < p.B ? row0 + n : p.B - 1;
     const uint32_t off_d = (uint32_t)(row * dT);
     auto real = [&](int ch) { return ch < dT; };
+    // d a multiple of 4 (and the field aligned): rows are 16-byte groups and a lane's four channels one Philox quad; any other d:
+    // element by element (the start, the outputs and the diagonal-noise draws only -- everything else lives in padded tiles)
+    const bool row_quads = (dT & 3) == 0;
+    const bool noise_quads = row_quads && (key.elem0 & 3) == 0;
 
     f32x4 y[TD];
 #pragma unroll
     for (int t = 0; t < TD; ++t) {
       const int ch = 16 * t + 4 * part;
-      y[t] = real(ch) ? *reinterpret_cast<const f32x4*>(p.y0 + off_d + ch) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      y[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (row_quads) {
+        if (real(ch)) y[t] = *reinterpret_cast<const f32x4*>(p.y0 + off_d + ch);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (ch + r < dT) y[t][r] = p.y0[off_d + ch + r];
+        }
+      }
     }
 
     // hid^T = act(W1^T x^T + (b1 + wt * t)): loop order (t, r) outer, th inner -> consecutive MFMAs hit different accumulators
@@ -282,10 +316,19 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
         float dw[NS::kQuads][4];
 #pragma unroll
         for (int q = 0; q < NS::kQuads; ++q) {
-          uint64_t quad = quad_row + (M >= 16 ? 4 * q + part : (M == 8 ? (part & 1) : 0));
+          const int quad_of_row = M >= 16 ? 4 * q + part : (M == 8 ? (part & 1) : 0);
+          uint64_t quad = quad_row + quad_of_row;
           asm volatile("" : "+v"(quad));
-          float z[4];
-          normal4<float>(key, quad, cell, 0, kStreamW, z);
+          float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (p.m == M && (key.elem0 & 3) == 0) {
+            normal4<float>(key, quad, cell, 0, kStreamW, z);
+          } else {          // m not one of the tile widths (or an unaligned field): the row's REAL channels one by one
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int cj = 4 * quad_of_row + r;
+              if (cj < p.m) z[r] = draw_one(key, key.elem0 + (uint64_t)row * (uint64_t)p.m + (uint64_t)cj, cell, kStreamW);
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) dw[q][r] = (z[r] * sw) * g_scale;
         }
@@ -307,7 +350,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
         for (int ty = 0; ty < TD; ++ty) {
           const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;        // real state channels of this tile (wave-uniform)
           if (channels <= 0) continue;
-          const int tiles = channels * M / 16;                               // G^T tiles that feed them
+          const int tiles = (channels * M + 15) / 16;                        // G^T tiles that feed them
           for (int p0 = 0; p0 < tiles; p0 += G) {
             f32x4 acc[G];
 #pragma unroll
@@ -408,7 +451,14 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           if constexpr (MODE == 0) {
             uint64_t quad = (key.elem0 + (uint64_t)off_d + (uint64_t)ch) >> 2;
             asm volatile("" : "+v"(quad));
-            if (real(ch)) normal4<float>(key, quad, cell, 0, kStreamW, z);
+            if (noise_quads) {
+              if (real(ch)) normal4<float>(key, quad, cell, 0, kStreamW, z);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                z[r] = ch + r < dT ? draw_one(key, key.elem0 + (uint64_t)off_d + (uint64_t)(ch + r), cell, kStreamW) : 0.0f;
+              }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] *= sw;
           }
@@ -473,9 +523,20 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           uint64_t quad = (key.elem0 + (uint64_t)off_d + (uint64_t)ch) >> 2;
           asm volatile("" : "+v"(quad));
           float zw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (real(ch)) {
-            normal4<float>(key, quad, cell, 0, kStreamW, zw);
-            normal4<float>(key, quad, cell, 0, kStreamH, zh);
+          if (noise_quads) {
+            if (real(ch)) {
+              normal4<float>(key, quad, cell, 0, kStreamW, zw);
+              normal4<float>(key, quad, cell, 0, kStreamH, zh);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (ch + r < dT) {
+                const uint64_t e = key.elem0 + (uint64_t)off_d + (uint64_t)(ch + r);
+                zw[r] = draw_one(key, e, cell, kStreamW);
+                zh[r] = draw_one(key, e, cell, kStreamH);
+              }
+            }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -704,7 +765,14 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           Pack<float, 4> o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o.v[r] = exact ? yn[t][r] : (w0 * y[t][r] + w1 * yn[t][r]);
-          if (real(ch)) store<float, 4>(dst, off_d + ch, o);
+          if (row_quads) {
+            if (real(ch)) store<float, 4>(dst, off_d + ch, o);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (ch + r < dT) dst[off_d + ch + r] = o.v[r];
+            }
+          }
         }
         ++jout;
       }
@@ -734,7 +802,8 @@ static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
   if constexpr (!SPLIT && NoiseShape<MODE>::kGeneral && H == 64) {
     if (p.split) return launch_neural_mode<D, H, MODE, true>(p, s);
   }
-  const int outp = NeuralLds<D, H>::out_padded(p.g.out, NoiseShape<MODE>::kGeneral ? NoiseShape<MODE>::G : 1);
+  const int outp = NoiseShape<MODE>::kGeneral ? NeuralLds<D, H>::out_padded(p.d * MODE, NoiseShape<MODE>::G)
+                                               : NeuralLds<D, H>::out_padded(p.g.out, 1);
   const size_t lds_bytes = neural_lds_bytes(D, H, outp);
   if (lds_bytes > neural_lds_limit()) return hipErrorInvalidValue;
   static bool configured = false;   // per instantiation
@@ -760,13 +829,12 @@ static hipError_t launch_neural_dh(const NeuralArgs& p, int noise, hipStream_t s
   if (noise == TSDE_NOISE_SCALAR) return launch_neural_mode<D, H, 1>(p, s);
   if (noise == TSDE_NOISE_ADDITIVE) return launch_neural_mode<D, H, 2>(p, s);
   if constexpr (H <= 64) {      // (general noise: H x d*m weights of the diffusion's second layer; 128 units do not fit the LDS)
-    switch (p.m) {
-      case 4: return launch_neural_mode<D, H, 4>(p, s);
-      case 8: return launch_neural_mode<D, H, 8>(p, s);
-      case 16: return launch_neural_mode<D, H, 16>(p, s);
-      case 32: return launch_neural_mode<D, H, 32>(p, s);
-      default: return hipErrorInvalidValue;
-    }
+    // (m real Brownian channels run in the next tile width up; the padding is zero weights and zero increments)
+    if (p.m < 1 || p.m > 32) return hipErrorInvalidValue;
+    if (p.m <= 4) return launch_neural_mode<D, H, 4>(p, s);
+    if (p.m <= 8) return launch_neural_mode<D, H, 8>(p, s);
+    if (p.m <= 16) return launch_neural_mode<D, H, 16>(p, s);
+    return launch_neural_mode<D, H, 32>(p, s);
   }
   return hipErrorInvalidValue;
 }
@@ -804,8 +872,10 @@ size_t neural_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t ou
   if (D == 0 || H == 0) return 0;
   int group = 1;
   if (noise == TSDE_NOISE_GENERAL) {
-    if (m != 4 && m != 8 && m != 16 && m != 32) return 0;
-    group = m >= 32 ? (int)m / 16 : 2;
+    if (m < 1 || m > 32) return 0;
+    const int64_t M = m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : 32;
+    group = M >= 32 ? (int)M / 16 : 2;
+    out = d * M;
   }
   const int outp = (int)((out + 16 * group - 1) / (16 * group) * (16 * group));
   return neural_lds_bytes(D, H, outp);

@@ -1028,9 +1028,8 @@ class RecognisedAdditive:
         self.net, self.program, self.consts = None, None, []
         if isinstance(f, _Perceptron):
             # the drift of the reference's NeuralAdditive (tests/problems.py:203-217): a perceptron of cat([t, y])
-            if dtype != torch.float32 or d % 4 != 0 or d > 64:
-                raise NotElementwise("a drift network outside the neural-SDE kernel's shapes (float32, d a multiple of 4 up "
-                                     "to 64)")
+            if dtype != torch.float32 or d > 64:
+                raise NotElementwise("a drift network outside the neural-SDE kernel's shapes (float32, d up to 64)")
             if f.out != d or f.final is not None or f.scale != 1.0 or f.shape[1:] != (d,) or f.w1.shape[0] > 128:
                 raise NotElementwise("a drift network that does not map to the state channels (or is wider than 128)")
             if any(t is not None and (t.dtype != torch.float32 or t.device != device) for t in (f.w1, f.b1, f.w2, f.b2, f.wt)):
@@ -1304,7 +1303,7 @@ class Recognised:
                                     _native.FINAL_SIGMOID if net.final == "sigmoid" else _native.FINAL_NONE, scale))
         noise = self._NOISE_CODES[noise_type]
         need = K.mlp_general_lds(d, m, nets[0].hidden, nets[1].hidden, nets[1].out, noise)
-        if d % 4 != 0 or need <= 0 or need > 160 * 1024:
+        if need <= 0 or need > 160 * 1024:
             raise NotElementwise(f"networks outside the neural-SDE kernel's shapes (d = {d}, m = {m}, hidden "
                                  f"{nets[0].hidden} / {nets[1].hidden}: {need} bytes of LDS)")
         return ("neural", nets[0], nets[1], noise, m)

@@ -530,7 +530,7 @@ class BaseSDESolver:
                 if not networks or times is not None:
                     raise recognise.NotElementwise("drift and diffusion networks, but no neural-SDE kernel for this scheme")
                 spec = found.neural_spec(sde.noise_type)
-                if tuple(bm.shape) != (y0.shape[0], spec[4]) or bm._elem0 % 4 != 0 or y0.numel() >= 2 ** 30:
+                if tuple(bm.shape) != (y0.shape[0], spec[4]) or y0.numel() >= 2 ** 30:
                     return None
                 if precision == "bf16x3" and sde.noise_type == NOISE_TYPES.general:
                     # opt-in: the diffusion net's second layer on split-bf16 products (csrc/mlp_general.hip SPLIT); NOT the
