@@ -461,6 +461,9 @@ PROGRAMS = {
     "deep tree": ("diagonal", lambda s, t, y: (torch.sin(y) * s.mu + torch.cos(y)) * (torch.exp(-y * y) + s.b * y),
                   lambda s, t, y: (y * s.sigma + 0.1) * (torch.tanh(y) - 2.0)),
     "softplus and abs": ("diagonal", lambda s, t, y: F.softplus(y) - torch.abs(y) * s.mu, lambda s, t, y: torch.relu(y) + 0.2),
+    # single ATen operators that are compositions of the machine's functions
+    "silu, mish, rsqrt, clamp": ("diagonal", lambda s, t, y: F.silu(y) - F.mish(y * s.mu) + torch.clamp(y, min=0),
+                                 lambda s, t, y: s.sigma * torch.rsqrt(1.0 + y * y) + (2.0 + y * y) ** -2 + (1.5 + torch.sin(y)) ** -0.5),
     # t as one more leaf (the reference's ExAdditive drift, tests/problems.py:119-121, beside a state-dependent diffusion)
     "time in the arithmetic": ("diagonal", lambda s, t, y: s.b / torch.sqrt(1. + t) - y / (2. + 2. * t) + torch.tanh(y) * torch.cos(t),
                                lambda s, t, y: (s.sigma / torch.sqrt(1. + t)).expand_as(y) * torch.sigmoid(y)),
@@ -478,7 +481,7 @@ def test_expression_programs_evaluate_to_the_users_code(name):
     with pytest.raises(recognise.NotElementwise):
         recognise.recognise(ForwardSDE(sde), t, y).spec()
     found = recognise.recognise_program(ForwardSDE(sde), t, y, noise)
-    kind, fw, gw, dgw, table, scalar = found.spec(milstein=name != "softplus and abs")
+    kind, fw, gw, dgw, table, scalar = found.spec(milstein=name not in ("softplus and abs",))
     assert kind == "program_diagonal" and scalar == (noise == "scalar") and table.shape[1] == D
     with torch.no_grad():
         torch.testing.assert_close(_run_program(fw, table, y, t), sde.f(t, y), rtol=1e-5, atol=1e-6)

@@ -462,7 +462,8 @@ class _Interpreter(TorchDispatchMode):
 
     # kwargs whose effect the handlers model; every other non-default kwarg of an operator on a tracked value ends the
     # interpretation (`torch.div(y, 2, rounding_mode="floor")` is not `0.5 * y`)
-    _MODELLED = {"add": ("alpha",), "sub": ("alpha",), "rsub": ("alpha",), "softplus": ("beta", "threshold")}
+    _MODELLED = {"add": ("alpha",), "sub": ("alpha",), "rsub": ("alpha",), "softplus": ("beta", "threshold"),
+                 "clamp": ("min", "max")}
     # ... and kwargs whose effect is checked on the RESULT (shape, dtype and device of the output must be the input's)
     _CHECKED_ON_RESULT = ("dtype", "layout", "device", "pin_memory", "memory_format", "non_blocking", "copy", "implicit")
 
@@ -880,6 +881,22 @@ class _TreeInterpreter(_Interpreter):
             if beta != 1 or threshold != 20:
                 raise NotElementwise("softplus with a non-default beta or threshold")
             return self.track(out, _Expr("softplus", (x,)))
+        # single ATen operators that are compositions of the machine's functions (to rounding: torch evaluates silu as
+        # x / (1 + exp(-x)), mish with its own softplus threshold -- the both-routes check of the first solve covers that)
+        if name == "silu" and x is not None and len(args) == 1:
+            return self.track(out, _Expr("mul", (x, _Expr("sigmoid", (x,)))))
+        if name == "mish" and x is not None and len(args) == 1:
+            return self.track(out, _Expr("mul", (x, _Expr("tanh", (_Expr("softplus", (x,)),)))))
+        if name == "rsqrt" and x is not None and len(args) == 1:
+            return self.track(out, _Expr("reciprocal", (_Expr("sqrt", (x,)),)))
+        if name == "clamp_min" and x is not None and len(args) == 2 and isinstance(args[1], (int, float)) and args[1] == 0:
+            return self.track(out, _Expr("relu", (x,)))
+        if name == "clamp" and x is not None:
+            low = args[1] if len(args) > 1 else kwargs.get("min")
+            high = args[2] if len(args) > 2 else kwargs.get("max")
+            if isinstance(low, (int, float)) and not isinstance(low, bool) and low == 0 and high is None:
+                return self.track(out, _Expr("relu", (x,)))
+            raise NotElementwise("clamp other than clamp(min=0)")
         if name == "pow" and x is not None and len(args) == 2 and isinstance(args[1], (int, float)):
             n = args[1]
             if n == 1:
@@ -894,6 +911,10 @@ class _TreeInterpreter(_Interpreter):
                 return self.track(out, _Expr("reciprocal", (x,)))
             if n == 4:
                 return self.track(out, _Expr("square", (_Expr("square", (x,)),)))
+            if n == -2:
+                return self.track(out, _Expr("reciprocal", (_Expr("square", (x,)),)))
+            if n == -0.5:
+                return self.track(out, _Expr("reciprocal", (_Expr("sqrt", (x,)),)))
             raise NotElementwise(f"the power {n} of a function of the state")
         if name in ("mul", "add", "sub", "rsub", "div") and len(args) >= 2:
             a, b = self.operand(args[0]), self.operand(args[1])
