@@ -82,9 +82,13 @@ class _Mixed(nn.Module):
             return torch.tanh(y) * self.mu - y
         if self.which == "rational":
             return -y / (1.0 + y ** 2) * self.mu
+        if self.which == "compositions":          # single ATen operators that run as compositions of the machine's functions
+            return F.silu(y) * self.mu - F.mish(y) - torch.clamp(y, min=0)
         return y - y ** 4 * self.mu - F.softplus(y) * 0.1
 
     def g(self, t, y):
+        if self.which == "compositions":
+            return self.sigma * torch.rsqrt(1.0 + y * y) + 0.05 * (2.0 + y * y) ** -2
         if self.which == "sum":
             return self.sigma * torch.sigmoid(y) + 0.05 * torch.cos(y)
         if self.which == "rational":
@@ -92,7 +96,7 @@ class _Mixed(nn.Module):
         return self.sigma * torch.sqrt(1.0 + y * y)
 
 
-@pytest.mark.parametrize("which", ["sum", "rational", "quartic"])
+@pytest.mark.parametrize("which", ["sum", "rational", "quartic", "compositions"])
 @pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
 def test_mixed_elementwise_code_takes_the_program_kernel(which, method, sde_type, levy):
     sde = _Mixed(sde_type, which).to(DEV)
