@@ -128,7 +128,10 @@ struct NeuralLds {
 // arrays in LDS, K-contiguous per output (a lane's eight k of a 32-block: the four channels 4 part + r of the block's two
 // 16-unit tiles -- the order its own activations have in the accumulator layout), 16-byte chunks XOR-swizzled by the output
 // row so that the ds_read_b128 of a 16-lane group hits 16 different bank quads.
-template <int D, int H, int MODE, bool SPLIT = false>
+// GENERIC (diagonal noise only): the state width is not a multiple of 4 or the field is unaligned, so the increments are
+// drawn element by element; a separate instantiation, so that the common one carries no call and no second path (the SRK
+// body keeps ~300 registers live across the draws).
+template <int D, int H, int MODE, bool SPLIT = false, bool GENERIC = false>
 __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
   using NS = NoiseShape<MODE>;
   static_assert(!SPLIT || (NS::kGeneral && H == 64), "split mode: general noise, 64 hidden units");
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
     // d a multiple of 4 (and the field aligned): rows are 16-byte groups and a lane's four channels one Philox quad; any other d:
     // element by element (the start, the outputs and the diagonal-noise draws only -- everything else lives in padded tiles)
     const bool row_quads = (dT & 3) == 0;
-    const bool noise_quads = row_quads && (key.elem0 & 3) == 0;
+    constexpr bool noise_quads = !GENERIC;      // (the launcher picks GENERIC unless d % 4 == 0 and elem0 % 4 == 0)
 
     f32x4 y[TD];
 #pragma unroll
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           if constexpr (MODE == 0) {
             uint64_t quad = (key.elem0 + (uint64_t)off_d + (uint64_t)ch) >> 2;
             asm volatile("" : "+v"(quad));
-            if (noise_quads) {
+            if constexpr (noise_quads) {
               if (real(ch)) normal4<float>(key, quad, cell, 0, kStreamW, z);
             } else {
 #pragma unroll
@@ -523,7 +526,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           uint64_t quad = (key.elem0 + (uint64_t)off_d + (uint64_t)ch) >> 2;
           asm volatile("" : "+v"(quad));
           float zw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (noise_quads) {
+          if constexpr (noise_quads) {
             if (real(ch)) {
               normal4<float>(key, quad, cell, 0, kStreamW, zw);
               normal4<float>(key, quad, cell, 0, kStreamH, zh);
@@ -797,7 +800,7 @@ static size_t neural_lds_limit() {
   return limit;
 }
 
-template <int D, int H, int MODE, bool SPLIT = false>
+template <int D, int H, int MODE, bool SPLIT = false, bool GENERIC = false>
 static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
   if constexpr (!SPLIT && NoiseShape<MODE>::kGeneral && H == 64) {
     if (p.split) return launch_neural_mode<D, H, MODE, true>(p, s);
@@ -808,7 +811,7 @@ static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
   if (lds_bytes > neural_lds_limit()) return hipErrorInvalidValue;
   static bool configured = false;   // per instantiation
   if (!configured) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&neural_trajectory_kernel<D, H, MODE, SPLIT>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&neural_trajectory_kernel<D, H, MODE, SPLIT, GENERIC>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) return e;
     configured = true;
@@ -819,13 +822,17 @@ static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
   const int64_t per_cu = (int64_t)((160 * 1024) / lds_bytes) < 1 ? 1 : (int64_t)((160 * 1024) / lds_bytes);
   const int64_t resident = 256 * (per_cu > 8 ? 8 : per_cu);
   if (blocks > resident) blocks = resident;
-  hipLaunchKernelGGL((neural_trajectory_kernel<D, H, MODE, SPLIT>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p, outp);
+  hipLaunchKernelGGL((neural_trajectory_kernel<D, H, MODE, SPLIT, GENERIC>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p,
+                     outp);
   return hipGetLastError();
 }
 
 template <int D, int H>
 static hipError_t launch_neural_dh(const NeuralArgs& p, int noise, hipStream_t s) {
-  if (noise == TSDE_NOISE_DIAGONAL) return launch_neural_mode<D, H, 0>(p, s);
+  if (noise == TSDE_NOISE_DIAGONAL) {
+    const bool quads = (p.d % 4 == 0) && (p.key.elem0 % 4 == 0);
+    return quads ? launch_neural_mode<D, H, 0, false, false>(p, s) : launch_neural_mode<D, H, 0, false, true>(p, s);
+  }
   if (noise == TSDE_NOISE_SCALAR) return launch_neural_mode<D, H, 1>(p, s);
   if (noise == TSDE_NOISE_ADDITIVE) return launch_neural_mode<D, H, 2>(p, s);
   if constexpr (H <= 64) {      // (general noise: H x d*m weights of the diffusion's second layer; 128 units do not fit the LDS)
