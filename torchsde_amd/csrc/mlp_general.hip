@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
     auto real = [&](int ch) { return ch < dT; };
     // d a multiple of 4 (and the field aligned): rows are 16-byte groups and a lane's four channels one Philox quad; any other d:
     // element by element (the start, the outputs and the diagonal-noise draws only -- everything else lives in padded tiles)
-    const bool row_quads = (dT & 3) == 0;
+    const bool row_quads = MODE == 0 ? !GENERIC : (dT & 3) == 0;      // (diagonal noise: decided with the instantiation)
     constexpr bool noise_quads = !GENERIC;      // (the launcher picks GENERIC unless d % 4 == 0 and elem0 % 4 == 0)
 
     f32x4 y[TD];
