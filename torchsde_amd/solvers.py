@@ -328,8 +328,8 @@ class BaseSDESolver:
         return None
 
     def _neural_code(self):
-        """TSDE_TRAJ_* code of this scheme in the neural-SDE kernel (`tsde_trajectory_mlp_general`: any noise type but
-        additive), or None."""
+        """TSDE_TRAJ_* code of this scheme in the neural-SDE kernel (`tsde_trajectory_mlp_general`: diagonal, scalar or general
+        noise; additive noise: `_additive_code`), or None."""
         return None
 
     def _program_code(self):
@@ -1292,7 +1292,7 @@ class SRK(BaseSDESolver):
         return _native.TRAJ_SRK
 
     def _neural_code(self):
-        # (diagonal and scalar noise; additive noise takes SRA1, which the neural-SDE kernel does not have)
+        # (SRID2: diagonal and scalar noise; additive noise takes SRA1 through `_additive_code`)
         return _native.TRAJ_SRK if self.sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar) else None
 
     def _advance(self, y0, st, out):
