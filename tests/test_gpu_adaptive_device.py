@@ -213,8 +213,8 @@ def test_many_output_times_inside_single_steps():
                                                     ("additive_ito", "srk", "space-time", (48, 4, 3)),
                                                     ("general_ito", "euler", "none", (48, 4, 4))])
 def test_adaptive_solve_with_gradients_replays_the_accepted_steps(prob, method, levy, shape):
-    """Autograd recording: the device-controlled loop finds the accepted steps under no_grad, then those alone are run again
-    with autograd on (adaptive.integrate_with_grad) -- values and gradients (y0 and every parameter) equal the host-driven
+    """Autograd recording, `options={"adaptive_replay": True}`: the device-controlled loop finds the accepted steps under
+    no_grad, then those alone are run again with autograd on (adaptive.integrate_with_grad) -- values and gradients (y0 and every parameter) equal the host-driven
     loop's, which records every attempt like the reference (base_solver.py:117-142); one synchronisation per round instead of
     one per attempt."""
     import torchsde_amd
@@ -232,7 +232,7 @@ def test_adaptive_solve_with_gradients_replays_the_accepted_steps(prob, method, 
         sde.zero_grad()
         adaptive.last_stats = None
         ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=0.1, adaptive=True, rtol=1e-3, atol=1e-3,
-                                 options={"device_adaptive": device_control, "hip_graph": False})
+                                 options={"device_adaptive": device_control, "hip_graph": False, "adaptive_replay": True})
         if weights is None:
             weights = torch.cos(torch.arange(ys.numel(), device=DEV, dtype=torch.float32)).reshape(ys.shape)
         (ys * weights).sum().backward()

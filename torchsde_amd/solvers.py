@@ -246,8 +246,10 @@ class BaseSDESolver:
         if adaptive.usable(self, y0, ts):
             # the same loop with accept / reject decided ON THE DEVICE: no sync per attempt (adaptive.py)
             return adaptive.integrate(self, y0, ts, extra0, _Step)
-        if adaptive.controllable(self, y0, ts) and torch.is_grad_enabled():
-            # gradients flow: the device-controlled loop finds the accepted steps, autograd records only those
+        if self.options.get("adaptive_replay", False) and adaptive.controllable(self, y0, ts) and torch.is_grad_enabled():
+            # gradients flow, opt-in: the device-controlled loop finds the accepted steps, autograd records only those -- a
+            # third of the autograd graph and one synchronisation, but the steps are computed twice: measured SLOWER than the
+            # loop below unless the first pass replays a recorded attempt on a small state (profiles/r5_adaptive_one_sync.txt)
             done = adaptive.integrate_with_grad(self, y0, ts, extra0, _Step)
             if done is not None:
                 return done
