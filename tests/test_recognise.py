@@ -660,3 +660,14 @@ def test_random_expression_trees_compile_to_programs_that_evaluate_to_the_code(s
         yy = y.clone().requires_grad_(True)
         dg, = torch.autograd.grad(sde.g(t, yy).expand_as(yy).sum(), yy)
         torch.testing.assert_close(_run_program(dgw, table, y, t), dg, rtol=2e-4, atol=2e-5, msg=src_g)
+
+
+def test_additive_noise_table_size_is_bounded():
+    """A time-dependent diffusion is tabulated over EVERY stage time of the solve: a solve of millions of steps keeps the
+    stepwise route instead of allocating gigabytes."""
+    sde = ForwardSDE(problems.AdditiveDecay(64, 16))
+    with pytest.raises(recognise.NotElementwise, match="MiB"):
+        recognise.recognise_additive(sde, torch.tensor(0.0), torch.randn(16, 64), torch.linspace(0.0, 1.0, 2 ** 17))
+    found = recognise.recognise_additive(ForwardSDE(problems.AdditiveShared(64, 16)), torch.tensor(0.0), torch.randn(16, 64),
+                                         torch.linspace(0.0, 1.0, 2 ** 17))
+    assert found.table.shape == (16, 64)                    # (a constant matrix needs no table over time)

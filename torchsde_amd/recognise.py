@@ -1145,6 +1145,9 @@ def recognise_additive(sde, t, y0, times, rows=None, check_rows=False):
     if time_dependent:
         if times is None:
             raise NotElementwise("no stage times for this scheme")
+        if times.numel() * rows * d * m > 2 ** 27:
+            raise NotElementwise(f"the diffusion's table over {times.numel()} stage times would take "
+                                 f"{times.numel() * d * m * y0.element_size() >> 20} MiB")
         try:
             with torch.no_grad():
                 g = torch.vmap(lambda tt: sde.g(tt, probe))(times.detach().to(t_probe.dtype))
