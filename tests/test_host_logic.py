@@ -723,3 +723,14 @@ def test_matrix_precision_option_is_validated_before_any_route():
     with pytest.raises(ValueError, match="matrix_precision"):
         torchsde_amd.sdeint(sde, torch.zeros(8, 4), torch.tensor([0.0, 1.0]), dt=0.1, method="euler",
                             options={"matrix_precision": "fp8"})
+
+
+def test_adaptive_round_budget():
+    """The number of attempts the host enqueues before it synchronises (adaptive.round_budget): an upper bound from the
+    current step size, the previous solve's count when there is one, nothing when every output time is met, capped."""
+    from torchsde_amd.adaptive import round_budget
+    assert round_budget(1.0, 0.1) == 9                  # ceil(10) - 1: steps only grow
+    assert round_budget(0.15, 0.1) == 2 and round_budget(0.05, 0.1) == 1
+    assert round_budget(0.0, 0.1) == 0 and round_budget(-1e-9, 0.1) == 0
+    assert round_budget(1.0, 0.1, hint=25) == 26 and round_budget(0.0, 0.1, hint=25) == 0
+    assert round_budget(100.0, 0.001) == 256 and round_budget(1.0, 0.1, hint=1000) == 256

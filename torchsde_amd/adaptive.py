@@ -368,6 +368,18 @@ def _attempt_for(solver, y0, ts_host, step_cls):
 _LATENCY_BOUND_ELEMENTS = 1 << 18
 
 
+def round_budget(span, step_size, hint=None, cap=256):
+    """Attempts to enqueue before the next look at the controller: `hint` + 1 when a previous solve of this structure said how
+    many it used; else what the current step size needs to cover `span`, less one when that is more than two (accepted steps
+    only ever grow, adaptive_stepping.py:35-37: an upper bound unless attempts are rejected); 0 when nothing is left to cover;
+    never more than `cap`."""
+    need = int(math.ceil(max(span, 0.0) / step_size))
+    if need == 0:
+        return 0
+    budget = hint + 1 if hint is not None else (need - 1 if need > 2 else need)
+    return min(max(1, budget), cap)
+
+
 def _hints_of(solver, y0, ts_host):
     """({key: attempts the last such solve used}, key of this solve) kept on the user's SDE object, or (None, None)."""
     from . import graph as graph_module
@@ -466,11 +478,8 @@ def integrate(solver, y0, ts, extra0, step_cls):
                 #   * a small state (latency-bound attempts) aims at the LAST output time at once;
                 #   * a large one (attempts of hundreds of microseconds) at the next output time only, like a host loop.
                 target = float(outs[-1]) if (small or hint is not None) else float(outs[min(reached, len(outs) - 1)])
-                need = int(math.ceil(max(target - curr_t, 0.0) / max(step_size, solver.dt_min)))
-                budget = need - 1 if need > 2 else need
-                if hint is not None and first_round and lo == 1:
-                    budget = hint + 1
-                budget = min(max(0 if need == 0 else 1, budget), 256)      # (0: every output time is already met)
+                budget = round_budget(target - curr_t, max(step_size, solver.dt_min),
+                                      hint if (first_round and lo == 1) else None)
                 first_round = False
                 screen = getattr(attempt, "screen", None)
                 if screen is not None:      # (hip_graph="auto", first solve of this structure)
