@@ -671,3 +671,44 @@ def test_additive_noise_table_size_is_bounded():
     found = recognise.recognise_additive(ForwardSDE(problems.AdditiveShared(64, 16)), torch.tensor(0.0), torch.randn(16, 64),
                                          torch.linspace(0.0, 1.0, 2 ** 17))
     assert found.table.shape == (16, 64)                    # (a constant matrix needs no table over time)
+
+
+# ---- random single-function forms through the coefficient algebra -----------------------------------------------------
+def _random_affine(rng, inner):
+    for _ in range(rng.randint(0, 3)):
+        c = rng.choice(["s.mu", "s.sigma", "s.b", "2.0", "-0.5", "s.w"])
+        inner = rng.choice([f"({inner} * {c})", f"({c} * {inner})", f"({inner} + {c})", f"({c} - {inner})", f"({inner} - {c})",
+                            f"(-{inner})", f"({inner} / (1.5 + s.sigma))", f"torch.add({c}, {inner}, alpha=2)"])
+    return inner
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_single_function_forms_fold_to_the_right_coefficients(seed):
+    """Sixty seeded compositions of per-channel affine operations around at most one function of the state (or products of
+    affine values up to a cubic): the five coefficients `recognise` folds them into evaluate to what the code computes.
+    Whatever leaves the form is refused, never folded wrongly."""
+    import random
+    rng = random.Random(1000 + seed)
+    def one():
+        kind = rng.random()
+        inner = _random_affine(rng, "y")
+        if kind < 0.5:
+            fn = rng.choice(["torch.exp", "torch.sigmoid", "torch.tanh", "F.softplus", "torch.sin", "torch.cos"])
+            return _random_affine(rng, f"{fn}({inner})")
+        if kind < 0.8:
+            return rng.choice([f"({inner}) * ({_random_affine(rng, 'y')})", f"({inner}) ** 2", f"({inner}) ** 3",
+                               f"({inner}) * ({_random_affine(rng, 'y')}) + ({_random_affine(rng, 'y')})"])
+        return inner
+    src_f, src_g = one(), one()
+    env = {"torch": torch, "F": F}
+    sde = _M(eval(f"lambda s, t, y: {src_f}", env), eval(f"lambda s, t, y: {src_g}", env))
+    y, t = 0.6 * torch.randn(16, D), torch.tensor(0.3)
+    try:
+        found = recognise.recognise(ForwardSDE(sde), t, y)
+    except recognise.NotElementwise:
+        return
+    with torch.no_grad():
+        for got, want, src in ((_value(found.f, y), sde.f(t, y).expand_as(y), src_f),
+                               (_value(found.g, y), sde.g(t, y).expand_as(y), src_g)):
+            # (an expanded cubic cancels near its roots: the error scales with the size of its terms, not of its value)
+            torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6 * max(1.0, want.abs().max().item()), msg=src)
