@@ -809,3 +809,75 @@ def test_recognised_perceptron_adjoint_against_the_oracle(method, adjoint_method
     helpers.assert_within_reference_rounding(y0.grad, gy32, gy64, "dL/dy0")
     for (name, p), g32, g64 in zip(sde.named_parameters(), gp32, gp64):
         helpers.assert_within_reference_rounding(p.grad, g32, g64, f"dL/d{name}")
+
+
+# ---- pure call counters: the `self._nfe += 1` of the reference's Ex* test problems --------------------------------------
+class _CountsItsCalls:
+    """Mixin: count the calls of f and g in a Python attribute, exactly as the reference's ExDiagonal / ExScalar / ExAdditive do
+    (tests/problems.py:60-66, 92-98, 118-124)."""
+
+    def f(self, t, y):
+        self._nfe += 1
+        return super().f(t, y)
+
+    def g(self, t, y):
+        self._nfe += 1
+        return super().g(t, y)
+
+    @property
+    def nfe(self):
+        return self._nfe
+
+
+@pytest.mark.parametrize("kind,method,levy", [("gbm", "euler", "none"), ("gbm", "srk", "space-time"), ("scalar", "srk", "space-time"),
+                                              ("scalar", "milstein", "none"), ("additive", "srk", "space-time"),
+                                              ("additive", "euler", "none")])
+def test_call_counters_neither_refuse_the_route_nor_lose_their_meaning(kind, method, levy):
+    """A module that counts its calls like the reference's Ex* problems takes the one-launch route, and `sde.nfe` reads after
+    every solve what the stepwise loop would have left: the verifying solve measures the advance per step, a kernel solve
+    applies it. A counter that gates the dynamics is state, and is refused."""
+    import torchsde_amd
+    from workloads import problems
+    base_cls = {"gbm": problems.GBMDiag, "scalar": problems.ScalarTrig, "additive": problems.AdditiveDecay}[kind]
+    Bc, d, m, n, dt = 64, 8, {"gbm": 8, "scalar": 1, "additive": 4}[kind], 24, 2.0 ** -7
+
+    class Counted(_CountsItsCalls, base_cls):
+        pass
+
+    def make():
+        sde = (Counted(d, m, "ito") if kind == "additive" else Counted(d, "ito")).to(DEV)
+        sde._nfe = 0
+        return sde
+
+    def solve(sde, entropy, stepwise=False):
+        y0 = torch.full((Bc, d), 0.3, device=DEV)
+        bm = torchsde_amd.BrownianInterval(0.0, n * dt, size=(Bc, m), dtype=torch.float32, device=DEV, entropy=entropy, dt=dt,
+                                           levy_area_approximation=levy)
+        options = {"hip_graph": False}
+        if stepwise:
+            options["trajectory_kernel"] = False
+        with torch.no_grad():
+            return torchsde_amd.sdeint(sde, y0, torch.tensor([0.0, n * dt], device=DEV), bm=bm, method=method, dt=dt,
+                                       options=options)
+    reference = make()
+    want1 = solve(reference, 1, stepwise=True)
+    per_solve = reference.nfe
+    want2 = solve(reference, 2, stepwise=True)
+    assert per_solve > 0 and reference.nfe == 2 * per_solve
+    sde = make()
+    got1 = solve(sde, 1)                                             # both routes, compared; the stepwise result
+    assert torch.equal(got1, want1) and sde.nfe == per_solve, (sde.nfe, per_solve)
+    assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+    got2, launches = _launches(lambda: solve(sde, 2))
+    assert launches == 1 and sde.nfe == 2 * per_solve, (launches, sde.nfe, per_solve)
+    torch.testing.assert_close(got2, want2, rtol=2e-5, atol=2e-6)
+
+    class Gate(Counted):
+        def f(self, t, y):
+            self._nfe += 1
+            return base_cls.f(self, t, y) * (1.0 if self._nfe > 10 ** 6 else 1.0)
+    gate = (Gate(d, m, "ito") if kind == "additive" else Gate(d, "ito")).to(DEV)
+    gate._nfe = 0
+    solve(gate, 1)
+    solve(gate, 2)
+    assert not _book(gate)["trusted"] and any("Python-side state" in r for r in _book(gate)["refused"].values()), _book(gate)

@@ -734,3 +734,71 @@ def test_adaptive_round_budget():
     assert round_budget(0.0, 0.1) == 0 and round_budget(-1e-9, 0.1) == 0
     assert round_budget(1.0, 0.1, hint=25) == 26 and round_budget(0.0, 0.1, hint=25) == 0
     assert round_budget(100.0, 0.001) == 256 and round_budget(1.0, 0.1, hint=1000) == 256
+
+
+def test_pure_call_counters_are_told_from_state_that_reaches_the_dynamics():
+    """graph.call_counters: `self._nfe += 1` in f / g / h with a getter nothing else calls (the reference's Ex* test problems,
+    tests/problems.py:60-66, 92-98, 118-124) is a pure counter; a counter that is read anywhere else -- in f itself, through its
+    getter, in a lambda, in a module-level helper -- or that two classes of the MRO both advance, is state."""
+    import torch
+    from torch import nn
+    from torchsde_amd import graph
+
+    class Counted(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._nfe, self.width = 0, 3
+            self.p = nn.Parameter(torch.ones(4))
+
+        def f(self, t, y):
+            self._nfe += 1
+            return -self.p * y
+
+        def g(self, t, y):
+            self._nfe += 1
+            return 0.1 * y
+
+        def h(self, t, y):
+            self._nfe += 1
+            return torch.zeros_like(y)
+
+        @property
+        def nfe(self):
+            return self._nfe
+
+    class Gate(Counted):
+        def f(self, t, y):
+            self._nfe += 1
+            return -y if self._nfe > 100 else -2 * y
+
+    class ThroughGetter(Counted):
+        def g(self, t, y):
+            self._nfe += 1
+            return 0.1 * y * self.nfe
+
+    class InLambda(Counted):
+        def f(self, t, y):
+            self._nfe += 1
+            return (lambda: -y * self._nfe)()
+
+    class ViaHelper(Counted):
+        def f(self, t, y):
+            self._nfe += 1
+            return -y * _helper_that_reads_the_counter(self)
+
+    class TwiceInTheMro(Counted):
+        def g(self, t, y):
+            self._nfe += 2
+            return 0.1 * y
+
+    assert graph.call_counters(Counted()) == {"_nfe": {"f": 1, "g": 1, "h": 1}}
+    for cls in (Gate, ThroughGetter, InLambda, ViaHelper, TwiceInTheMro):
+        assert graph.call_counters(cls()) == {}, cls.__name__
+    sde = Counted()
+    before = graph.python_state(sde, ignore=("_nfe",))
+    sde.f(torch.tensor(0.0), torch.zeros(2, 4))
+    assert graph.python_state(sde, ignore=("_nfe",)) == before and graph.python_state(sde) != before
+
+
+def _helper_that_reads_the_counter(sde):
+    return 1.0 if sde._nfe < 10 else 2.0

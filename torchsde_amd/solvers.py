@@ -210,9 +210,14 @@ class BaseSDESolver:
             if ys is not None:
                 return ys, self._extra
         else:
+            self._counter_start = None
             ys = self._integrate_recognised(y0, ts)
             if ys is not None:
                 return ys, self._extra
+            if self._counter_start is not None:       # (the probe calls of the interpretation are not steps of the solve)
+                owner, start = self._counter_start
+                for name, value in start.items():
+                    setattr(owner, name, value)
         from . import graph
         mode = graph.mode_of(self.options)
         if mode is True:
@@ -463,14 +468,24 @@ class BaseSDESolver:
             book = base.__dict__.setdefault(self._RECOGNISED_ATTR, {"refused": {}, "trusted": {}})
         except AttributeError:
             return None
+        # Pure call counters (`self._nfe += 1` in the reference's Ex* test problems): not state of the dynamics (graph.
+        # call_counters decides that on the bytecode), so they neither refuse the form nor lose their meaning -- the verifying
+        # solve learns by how much the stepwise loop advances them per step, and a kernel solve leaves them at that value.
+        counters = graph.call_counters(base)
+        ignore = frozenset(counters)
+        counter_start = {name: getattr(base, name) for name in counters}
+        self._counter_start = (base, counter_start) if counters else None
+
+        def state_of():
+            return graph.python_state(base, ignore=ignore)
         state = None
         if book["refused"]:
-            state = graph.python_state(base)
+            state = state_of()
             if state is None or (state, chain, type(self).__name__) in book["refused"]:
                 return None
 
         def refuse(reason):
-            key = (state if state is not None else graph.python_state(base), chain, type(self).__name__)
+            key = (state if state is not None else state_of(), chain, type(self).__name__)
             if key[0] is not None:
                 if len(book["refused"]) >= 16:
                     book["refused"].clear()
@@ -559,14 +574,22 @@ class BaseSDESolver:
         verdict = book["trusted"].get(key)
         launch = spec[1:] if spec[0] == "affine_diagonal" else spec       # (what `_integrate_trajectory` takes)
         if verdict is True:
-            return self._integrate_trajectory(launch, y0, ts)
+            rate = book.get("counter_rate", {}).get(key) if counters else {}
+            if rate is None or set(rate) != set(counters):
+                return None
+            ys = self._integrate_trajectory(launch, y0, ts)
+            if ys is not None and counters:
+                n_steps = timegrid.build(timegrid.ts_to_host(ts), self.dt).n_steps
+                for name in counters:
+                    setattr(base, name, counter_start[name] + rate[name] * n_steps)
+            return ys
         if verdict is not None:
             return None
         # first solve of this form: is the interpretation repeatable and free of side effects, and does the kernel
         # reproduce the stepwise solve?
         # (the second interpretation runs on a probe of another height: a coefficient computed from the number of rows
         #  -- `y / y.shape[0]` -- comes out different and the form is refused for what it is, not by a numeric accident)
-        before = graph.python_state(base)
+        before = state_of()
         rng_before = self._rng_states(y0.device)
         try:
             if spec[0] == "program_diagonal":
@@ -585,7 +608,7 @@ class BaseSDESolver:
                     again[2].precision = spec[2].precision
         except recognise.NotElementwise as e:
             return refuse(str(e))
-        if before is None or graph.python_state(base) != before:
+        if before is None or state_of() != before:
             return refuse("calling f and g changes the object's Python-side state")
         if any(not torch.equal(a, b) for a, b in zip(rng_before, self._rng_states(y0.device))):
             return refuse("calling f and g advances a random number generator")
@@ -599,7 +622,16 @@ class BaseSDESolver:
         if fast is None:
             return None                  # (grid and Brownian cells do not line up: nothing learnt about the form)
         self._extra = ()
+        for name, value in counter_start.items():       # (the interpretations' calls are not steps: count the real loop only)
+            setattr(base, name, value)
         stepwise = self._run(self._plan(y0, ts), y0)
+        if counters:
+            n_steps = timegrid.build(timegrid.ts_to_host(ts), self.dt).n_steps
+            advanced = {name: getattr(base, name) - counter_start[name] for name in counters}
+            if any(v % n_steps for v in advanced.values()):
+                book["trusted"][key] = "a call counter does not advance by a fixed amount per step"
+                return stepwise
+            book.setdefault("counter_rate", {})[key] = {name: v // n_steps for name, v in advanced.items()}
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
         if spec[0] in ("mlp_diagonal", "neural", "neural_additive"):      # the matrix cores sum the layers' products in another order than the library
             rtol, atol = 1e-3, 1e-4
