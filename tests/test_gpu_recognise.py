@@ -881,3 +881,29 @@ def test_call_counters_neither_refuse_the_route_nor_lose_their_meaning(kind, met
     solve(gate, 1)
     solve(gate, 2)
     assert not _book(gate)["trusted"] and any("Python-side state" in r for r in _book(gate)["refused"].values()), _book(gate)
+
+
+def test_call_counters_with_autograd_stay_on_the_stepwise_route():
+    """Training through `sdeint` on a module that counts its calls: only the forward route settles the counter, so with autograd
+    recording such a module keeps the stepwise route and `sde.nfe` is what the stepwise loop leaves, by construction."""
+    import torchsde_amd
+    from workloads import problems
+
+    class Counted(_CountsItsCalls, problems.GBMDiag):
+        pass
+
+    def train(options):
+        sde = Counted(D, "ito").to(DEV)
+        sde._nfe = 0
+        kinds = []
+        for entropy in (1, 2):
+            y0 = torch.full((B, D), 0.1, device=DEV, requires_grad=True)
+            bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, D), device=DEV, entropy=entropy, dt=DT)
+            ys = torchsde_amd.sdeint(sde, y0, torch.tensor([0.0, STEPS * DT], device=DEV), bm=bm, method="euler", dt=DT,
+                                     options=options)
+            ys[-1].sum().backward()
+            kinds.append(type(ys.grad_fn).__name__)
+        return sde.nfe, kinds
+    default, kinds = train({"hip_graph": False})
+    stepwise, _ = train({"hip_graph": False, "trajectory_kernel": False})
+    assert default == stepwise > 0 and not any(k.startswith("_TrajectoryFn") for k in kinds), (default, stepwise, kinds)

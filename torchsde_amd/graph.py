@@ -273,6 +273,21 @@ def call_counters(obj):
     names = [k for k, v in vars(obj).items() if type(v) is int and isinstance(k, str) and not k.startswith("_tsde")]
     if not names:
         return {}
+    memo = (type(obj), tuple(names))                  # (the answer is a property of the classes' code and of these names)
+    if memo in _CALL_COUNTERS:
+        return _CALL_COUNTERS[memo]
+    if len(_CALL_COUNTERS) >= 64:
+        _CALL_COUNTERS.clear()
+    found = _CALL_COUNTERS[memo] = _call_counters_of(obj, names)
+    return found
+
+
+_CALL_COUNTERS = {}
+
+
+def _call_counters_of(obj, names):
+    import dis
+    import types
     functions = []                                   # (name in the class, code)
     for klass in type(obj).__mro__:
         if klass is object or _is_library(klass):

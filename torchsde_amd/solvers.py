@@ -678,7 +678,9 @@ class BaseSDESolver:
                 or (self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         chain, base = graph._wrapper_chain(sde)
-        if not self._may_be_interpreted(base):
+        if not self._may_be_interpreted(base) or graph.call_counters(base):
+            # (call counters: only the forward route above keeps them at the stepwise loop's value; with autograd recording such
+            #  modules stay stepwise, where the counters are right by construction)
             return None
         try:
             book = base.__dict__.setdefault(self._RECOGNISED_ATTR, {"refused": {}, "trusted": {}})
@@ -837,7 +839,7 @@ class BaseSDESolver:
                 or sde.noise_type != NOISE_TYPES.diagonal or y0.dim() != 2 or not y0.is_cuda):
             return None
         chain, base = graph._wrapper_chain(sde)
-        if not self._may_be_interpreted(base):
+        if not self._may_be_interpreted(base) or graph.call_counters(base):
             return None
         book = getattr(base, self._RECOGNISED_ATTR, None)
         if book is not None and book["refused"]:
