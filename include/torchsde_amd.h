@@ -526,7 +526,7 @@ typedef struct tsde_mlp {
  * 1 <= d <= 64 (a multiple of 4 with an aligned field takes the 16-byte / whole-quad paths), hidden sizes up to 128 (general
  * noise: 64), and all weights must fit the 160 KiB of LDS:
  * tsde_trajectory_mlp_general_lds returns the bytes a shape needs (0: no kernel for it). dtype must be TSDE_F32;
- * any elem0; ys, y0 16-byte aligned; rows * d < 2^30. Outputs and increments as tsde_trajectory_mlp_diag. */
+ * any elem0; ys, y0 16-byte aligned (4-byte when d is not a multiple of 4: such rows go element by element); rows * d < 2^30. Outputs and increments as tsde_trajectory_mlp_diag. */
 int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
                                 const tsde_mlp_t* drift, const tsde_mlp_t* diffusion, int method, const tsde_traj_t* traj,
                                 uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype, void* stream);

@@ -102,6 +102,43 @@ def test_rows_are_global_and_a_partial_last_group_is_handled():
     assert torch.equal(odd, whole[:, :77])
 
 
+@pytest.mark.parametrize("B,d", [(9, 3), (11, 10), (13, 5), (9, 63)])
+def test_rows_times_width_not_a_multiple_of_four_and_offset_views_of_the_start(B, d):
+    """`ys[1:]` starts rows * d * 4 bytes into its allocation, so a batch with rows * d % 4 != 0 handed the
+    C entry points an output pointer that is not 16-byte aligned and a plain `sdeint` of a Neural* module raised. Such rows go
+    element by element (the entry points ask for 16-byte alignment only when d % 4 == 0); a y0 that is an offset view of a
+    larger tensor is copied to an aligned buffer."""
+    import torchsde_amd
+    for name, m in (("netdiag_ito", d), ("netscalar_ito", 1)):
+        sde = problems.make(name, d=d, hidden=8).to(DEV)
+        _solve(sde, m, 1, "euler", B=B, d=d)
+        assert list(_book(sde)["trusted"].values()) == [True], _book(sde)
+        fast, launches = _launches(lambda: _solve(sde, m, 2, "euler", B=B, d=d))
+        assert launches == 1
+        torch.testing.assert_close(fast, _solve(sde, m, 2, "euler", B=B, d=d, stepwise=True), rtol=2e-5, atol=2e-6)
+    gen = problems.MLPGeneral(d, 3, "ito", hidden=8).to(DEV)
+    add = problems.make("netadditive_ito", d=d, m=3, hidden=8).to(DEV) if d <= 16 else None
+    for sde in (gen, add):
+        if sde is None:
+            continue
+        _solve(sde, 3, 1, "euler", B=B, d=d)
+        fast, launches = _launches(lambda: _solve(sde, 3, 2, "euler", B=B, d=d))
+        assert launches == 1, _book(sde)
+        torch.testing.assert_close(fast, _solve(sde, 3, 2, "euler", B=B, d=d, stepwise=True), rtol=2e-5, atol=2e-6)
+    # an offset view as the start (d a multiple of 4, the view 4 bytes off a 16-byte boundary)
+    sde = problems.make("netdiag_ito", d=8, hidden=8).to(DEV)
+    big = torch.full((1 + 16 * 8,), 0.1, device=DEV)
+    y0 = big[1:].view(16, 8)
+    assert y0.data_ptr() % 16 != 0
+    ts = torch.tensor([0.0, 24 * DT], device=DEV)
+    outs = []
+    for entropy in (1, 2, 2):
+        with torch.no_grad():
+            outs.append(torchsde_amd.sdeint(sde, y0, ts, bm=_bm(16, 8, 24 * DT, entropy), method="euler", dt=DT,
+                                            options={"hip_graph": False, "trajectory_kernel": len(outs) < 2}))
+    torch.testing.assert_close(outs[1], outs[2], rtol=2e-5, atol=2e-6)
+
+
 def test_live_parameters_and_what_stays_stepwise():
     sde = problems.MLPGeneral(8, 4, "ito", hidden=8).to(DEV)
     _solve(sde, 4, 1, "euler")

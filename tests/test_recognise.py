@@ -712,3 +712,81 @@ def test_random_single_function_forms_fold_to_the_right_coefficients(seed):
                                (_value(found.g, y), sde.g(t, y).expand_as(y), src_g)):
             # (an expanded cubic cancels near its roots: the error scales with the size of its terms, not of its value)
             torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6 * max(1.0, want.abs().max().item()), msg=src)
+
+
+# ---- stop-gradients ---------------------------------------------------------------------------------------
+class _StopGrad(nn.Module):
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+        self.mu = nn.Parameter(torch.full((4,), 0.3))
+        self.sigma = nn.Parameter(torch.full((4,), 0.2))
+
+    def f(self, t, y):
+        if self.kind == "detach":
+            return y.detach() * self.mu
+        if self.kind == "no_grad":
+            with torch.no_grad():
+                z = y * 2
+            return z * self.mu
+        if self.kind == "mixed":
+            return y.detach() * self.mu + y * self.sigma
+        if self.kind == "function_detached":
+            return torch.tanh(y).detach() * self.mu + y
+        if self.kind == "parameter_detached":
+            return y * self.mu.detach()
+        if self.kind == "clamp":
+            return torch.clamp(y, min=0) * self.mu
+        return y * self.mu
+
+    def g(self, t, y):
+        if self.kind == "data":
+            return self.sigma * y.data
+        return self.sigma * y
+
+
+@pytest.mark.parametrize("kind", ["detach", "no_grad", "data", "mixed", "function_detached"])
+def test_a_stop_gradient_on_the_state_ends_the_differentiable_interpretation(kind):
+    """The reference differentiates the user's code as written (autograd through base_solver.py:143-149): `y.detach()`,
+    `y.data` and state arithmetic under `torch.no_grad()` cut the gradient there. The kernels' sensitivities would run straight
+    through, so with `differentiable=True` both interpreters refuse; without gradients a stop-gradient is the identity."""
+    from torchsde_amd import recognise
+    from torchsde_amd.sde import ForwardSDE
+    sde = ForwardSDE(_StopGrad(kind))
+    y0, t = torch.full((16, 4), 0.1), torch.tensor(0.0)
+    for interpret in (recognise.recognise, lambda *a, **k: recognise.recognise_program(*a, "diagonal", **k)):
+        with pytest.raises(recognise.NotElementwise, match="stop-gradient"):
+            interpret(sde, t, y0, differentiable=True)
+    assert recognise.recognise_program(sde, t, y0, "diagonal") is not None          # values only: followed
+
+
+def test_what_is_not_a_stop_gradient_on_the_state_is_still_followed():
+    from torchsde_amd import recognise
+    from torchsde_amd.sde import ForwardSDE
+    y0, t = torch.full((16, 4), 0.1), torch.tensor(0.0)
+    for kind in ("plain", "parameter_detached"):
+        sde = ForwardSDE(_StopGrad(kind))
+        found = recognise.recognise(sde, t, y0, differentiable=True)
+        leaves = found.affine_leaves()
+        assert leaves is not None
+        # the detached parameter is a coefficient without a graph: no gradient reaches `mu`, as in the reference
+        assert leaves[0].requires_grad == (kind == "plain")
+        assert recognise.recognise_program(sde, t, y0, "diagonal", differentiable=True) is not None
+    # constants made from the state's shape carry no gradient and need none
+    class Ones(_StopGrad):
+        def g(self, t, y):
+            return torch.ones_like(y) * self.sigma
+    assert recognise.recognise(ForwardSDE(Ones("plain")), t, y0, differentiable=True) is not None
+
+
+def test_clamp_is_refused_when_gradients_flow():
+    """torch's clamp passes the gradient at the boundary (x >= min), the machine's relu does not."""
+    from torchsde_amd import recognise
+    from torchsde_amd.sde import ForwardSDE
+    sde = ForwardSDE(_StopGrad("clamp"))
+    y0, t = torch.zeros(16, 4), torch.tensor(0.0)
+    assert recognise.recognise_program(sde, t, y0, "diagonal") is not None
+    with pytest.raises(recognise.NotElementwise, match="clamp"):
+        recognise.recognise_program(sde, t, y0, "diagonal", differentiable=True)

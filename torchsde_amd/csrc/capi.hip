@@ -629,8 +629,10 @@ int tsde_trajectory_mlp_additive(void* ys, const void* y0, int64_t rows, int64_t
   if (m < 1 || m > 16) return bad_arg(where, "need 1 <= m <= 16 Brownian channels");
   if (drift->out != d || drift->final != TSDE_FINAL_NONE || drift->scale != 1.0)
     return bad_arg(where, "the drift maps to d channels, with no output function and scale 1");
-  if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
-    return bad_arg(where, "ys and y0 must be 16-byte aligned");
+  // (rows are read and written as 16-byte groups only when d is a multiple of 4 -- then every row of every output is aligned
+  //  with the bases; any other width goes element by element, mlp_general.hip `row_quads`)
+  if (((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & (d % 4 == 0 ? 15u : 3u)) != 0)
+    return bad_arg(where, "ys and y0 must be 16-byte aligned (4-byte when d is not a multiple of 4)");
   if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
   if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT && method != TSDE_TRAJ_SRK)
     return bad_arg(where, "method must be Euler, midpoint or SRK (SRA1)");
@@ -707,8 +709,10 @@ int tsde_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t 
   }
   if (tsde::neural_footprint(d, m, drift->hidden, diffusion->hidden, diffusion->out, noise) == 0)
     return bad_arg(where, "no kernel for this shape");
-  if ((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & 15u)
-    return bad_arg(where, "ys and y0 must be 16-byte aligned");
+  // (rows are read and written as 16-byte groups only when d is a multiple of 4 -- then every row of every output is aligned
+  //  with the bases; any other width goes element by element, mlp_general.hip `row_quads`)
+  if (((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys)) & (d % 4 == 0 ? 15u : 3u)) != 0)
+    return bad_arg(where, "ys and y0 must be 16-byte aligned (4-byte when d is not a multiple of 4)");
   if (rows * d >= (int64_t(1) << 30)) return bad_arg(where, "need rows * d < 2^30 (32-bit lane offsets)");
   if (method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT && method != TSDE_TRAJ_SRK)
     return bad_arg(where, "method must be Euler, midpoint or SRK");

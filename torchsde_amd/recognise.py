@@ -193,6 +193,35 @@ class _Interpreter(TorchDispatchMode):
         self.nets = {}                  # id -> _Perceptron for network outputs that are not state-shaped ((rows, d * m), ...)
         self.made = {id(y), id(t)}      # ids of tensors whose storage was allocated during the interpretation (kept alive):
         #                                 an in-place write to any OTHER tensor changes state that outlives the probe call
+        self.differentiable = False     # True: the kernel's GRADIENTS will stand for autograd through this code, so the probe
+        #                                 requires grad and a value derived from the state that does not is a stop-gradient
+
+    # ---- stop-gradients --------------------------------------------------------------------------------------------
+    def depends_on_state(self, x):
+        """Is the tracked tensor `x` a non-constant function of the state?"""
+        if id(x) in self.hidden or id(x) in self.nets or id(x) in self.time_state:
+            return True
+        form = self.forms.get(id(x))
+        if form is None:
+            return False
+        if isinstance(form, _Form):
+            return not form.constant()
+        if isinstance(form, _Expr):
+            return form.mentions_state()
+        return True
+
+    def check_stop_gradient(self, tensors, where="an operand"):
+        """With autograd recording the solve, the reference differentiates the user's code as it stands (ordinary autograd
+        through base_solver.py:143-149; adjoint_sde.py:111-128 for `sdeint_adjoint`): `y.detach() * mu`, `sigma * y.data` or
+        state arithmetic inside `torch.no_grad()` are stop-gradients there, while the sensitivity / adjoint kernels would
+        differentiate the recognised expression straight through them. The probe requires grad (`differentiable=True`), so a
+        floating-point value derived from the state that does NOT is the trace of such a construct: the interpretation ends."""
+        if not self.differentiable:
+            return
+        for a in tensors:
+            if torch.is_tensor(a) and a.is_floating_point() and not a.requires_grad and self.depends_on_state(a):
+                raise NotElementwise(f"{where} derived from the state carries no gradient (detach, .data or torch.no_grad() "
+                                     "in the user's code): a stop-gradient the kernels' derivatives would ignore")
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------------
     def form_of(self, x):
@@ -523,6 +552,7 @@ class _Interpreter(TorchDispatchMode):
             if id(a) not in self.seen:
                 self.seen.add(id(a))
                 self.keep.append(a)
+        self.check_stop_gradient(involved)
         timed = any(id(a) in self.time for a in involved)
         if timed and not any(id(a) in self.forms or id(a) in self.hidden or id(a) in self.nets or id(a) in self.time_state
                              for a in involved):
@@ -674,6 +704,9 @@ class _Expr:
 
     def leaf(self):
         return self.op in ("y", "t", "const")
+
+    def mentions_state(self):
+        return self.op == "y" or any(a.mentions_state() for a in self.args)
 
 
 _OPCODES = {"load": 0, "add": 1, "sub": 2, "rsub": 3, "mul": 4, "div": 5, "rdiv": 6, "neg": 16, "exp": 17, "log": 18, "sin": 19,
@@ -889,6 +922,10 @@ class _TreeInterpreter(_Interpreter):
             return self.track(out, _Expr("mul", (x, _Expr("tanh", (_Expr("softplus", (x,)),)))))
         if name == "rsqrt" and x is not None and len(args) == 1:
             return self.track(out, _Expr("reciprocal", (_Expr("sqrt", (x,)),)))
+        if name in ("clamp_min", "clamp") and x is not None and self.differentiable:
+            # (torch's clamp passes the gradient AT the boundary, mask x >= min; the machine's relu has slope 0 there, like
+            #  torch's relu: with a state that sits exactly on 0 the sensitivity kernel would differ from autograd)
+            raise NotElementwise("clamp with autograd recording: its backward passes the gradient at the boundary, relu's does not")
         if name == "clamp_min" and x is not None and len(args) == 2 and isinstance(args[1], (int, float)) and args[1] == 0:
             return self.track(out, _Expr("relu", (x,)))
         if name == "clamp" and x is not None:
@@ -1015,7 +1052,10 @@ def recognise_program(sde, t, y0, noise_type, rows=None, differentiable=False):
     d = y0.shape[1]
     probe = y0.detach()[:1].expand(rows, d).clone() if y0.shape[0] > 0 else torch.zeros(rows, d, dtype=y0.dtype, device=y0.device)
     t_probe = t.detach().clone()
+    if differentiable:
+        probe.requires_grad_(True)               # (so that a stop-gradient in the user's code shows: `check_stop_gradient`)
     interp = _TreeInterpreter(probe, t_probe, rows, d)
+    interp.differentiable = bool(differentiable)
     try:
         # `differentiable`: autograd watches the user's own constant arithmetic (`-self.p ** 2`), so that a constant which is
         # such a tensor carries its graph back to the parameters (cf. `recognise`)
@@ -1030,6 +1070,7 @@ def recognise_program(sde, t, y0, noise_type, rows=None, differentiable=False):
         tree = interp.form_of(value)
         if not isinstance(tree, _Expr):
             raise NotElementwise(f"the {name} is not a tracked function of the state")
+        interp.check_stop_gradient((value,), where=f"the {name}")
         trees.append(tree)
     found = RecognisedProgram(trees[0], trees[1], d, y0.dtype, y0.device, noise_type)
     found._alive = interp.keep
@@ -1413,7 +1454,10 @@ def recognise(sde, t, y0, differentiable=False, times=None, rows=None):
     # `times`: the (K,) tensor of every step's start time -> t is handed to the user's code as a (K, 1, 1) tensor and
     # coefficients that depend on t come back as one row per step (module docstring)
     t_probe = t.detach().clone() if times is None else times.detach().reshape(-1, 1, 1).clone()
+    if differentiable:
+        probe.requires_grad_(True)               # (so that a stop-gradient in the user's code shows: `check_stop_gradient`)
     interp = _Interpreter(probe, t_probe, rows, d, steps=None if times is None else int(times.numel()))
+    interp.differentiable = bool(differentiable)
     try:
         # `differentiable`: autograd watches what the user's code computes from its parameters on the way (`-self.theta`,
         # `self.sigma ** 2`), so that a coefficient which is such a tensor carries its graph (see `affine_leaves`)
@@ -1430,6 +1474,7 @@ def recognise(sde, t, y0, differentiable=False, times=None, rows=None):
             form = interp.net_of(value)
         if form is None:
             raise NotElementwise(f"the {name} is not a tracked function of the state")
+        interp.check_stop_gradient((value,), where=f"the {name}")
         forms.append(form)
     found = Recognised(forms[0], forms[1], d, y0.dtype, y0.device)
     found.users_tensors = interp.seen

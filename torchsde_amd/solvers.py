@@ -13,6 +13,8 @@ increment of the step's grid cell in registers and writes the new state straight
 (the next ``ys[i]`` slot when the step lands on an output time). No host sync, no per-step allocation of
 increments, no ``torch.stack`` copy.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -23,6 +25,14 @@ from . import timegrid
 from .brownian import BrownianInterval
 from .kernels import NoiseSpec
 from .settings import LEVY_AREA_APPROXIMATIONS, METHOD_OPTIONS, METHODS, NOISE_TYPES, SDE_TYPES
+
+
+# TSDE_VERIFY_EVERY=N: every N-th solve of a form that has earned trust on a kernel route runs both routes again and compares
+# values (and gradients where autograd records); a mismatch raises. 0 = only the first solve verifies.
+try:
+    VERIFY_EVERY = max(0, int(os.environ.get("TSDE_VERIFY_EVERY", "0").strip() or 0))
+except ValueError:
+    VERIFY_EVERY = 0
 
 
 class _Step:
@@ -120,7 +130,8 @@ class BaseSDESolver:
         # BrownianPath / BrownianTree (derived.py:52-191) answer interval queries with their BrownianInterval's increments
         # (w0 only shifts point values): the solver talks to that interval, so these objects reach every route it does
         from .brownian import _IntervalWrapper
-        self.bm = bm._interval if isinstance(bm, _IntervalWrapper) else bm
+        stock = isinstance(bm, _IntervalWrapper) and type(bm).__call__ is _IntervalWrapper.__call__
+        self.bm = bm._interval if stock else bm            # (a subclass with its own __call__ is a foreign Brownian motion)
         self.dt = dt
         self.adaptive = adaptive
         self.rtol = rtol
@@ -471,13 +482,18 @@ class BaseSDESolver:
         # Pure call counters (`self._nfe += 1` in the reference's Ex* test problems): not state of the dynamics (graph.
         # call_counters decides that on the bytecode), so they neither refuse the form nor lose their meaning -- the verifying
         # solve learns by how much the stepwise loop advances them per step, and a kernel solve leaves them at that value.
-        counters = graph.call_counters(base)
+        # `options={"assume_pure": True}` (or the attribute `tsde_assume_pure = True` on the SDE object): the USER vouches that
+        # whatever Python-side state their f and g touch (counters, logs, caches) does not reach the dynamics -- the documented
+        # switch for modules the checks below would keep stepwise. Nothing is fingerprinted then, counters run once per solve
+        # instead of once per step; the both-routes comparison of the first solve (and TSDE_VERIFY_EVERY) still applies.
+        assume_pure = self._assume_pure(base)
+        counters = {} if assume_pure else graph.call_counters(base)
         ignore = frozenset(counters)
         counter_start = {name: getattr(base, name) for name in counters}
         self._counter_start = (base, counter_start) if counters else None
 
         def state_of():
-            return graph.python_state(base, ignore=ignore)
+            return ("assumed pure",) if assume_pure else graph.python_state(base, ignore=ignore)
         state = None
         if book["refused"]:
             state = state_of()
@@ -573,6 +589,9 @@ class BaseSDESolver:
             key = key + ("bf16x3",)
         verdict = book["trusted"].get(key)
         launch = spec[1:] if spec[0] == "affine_diagonal" else spec       # (what `_integrate_trajectory` takes)
+        reverify = verdict is True and self._due_for_reverification(book, key)
+        if reverify:
+            verdict = None
         if verdict is True:
             rate = book.get("counter_rate", {}).get(key) if counters else {}
             if rate is None or set(rate) != set(counters):
@@ -615,8 +634,8 @@ class BaseSDESolver:
         same = len(again) == len(spec) and all(
             (torch.equal(a, b) if torch.is_tensor(a) else a == b) for a, b in zip(again, spec))
         if not same:
-            book["trusted"][key] = ("two interpretations of the same code (probes of 2 and 5 rows) gave different coefficients: "
-                                    "they depend on the batch size or on how often the code has run")
+            self._record_verdict(book, key, "two interpretations of the same code (probes of 2 and 5 rows) gave different "
+                                 "coefficients: they depend on the batch size or on how often the code has run", reverify)
             return None
         fast = self._integrate_trajectory(launch, y0, ts)
         if fast is None:
@@ -629,18 +648,22 @@ class BaseSDESolver:
             n_steps = timegrid.build(timegrid.ts_to_host(ts), self.dt).n_steps
             advanced = {name: getattr(base, name) - counter_start[name] for name in counters}
             if any(v % n_steps for v in advanced.values()):
-                book["trusted"][key] = "a call counter does not advance by a fixed amount per step"
+                self._record_verdict(book, key, "a call counter does not advance by a fixed amount per step", reverify)
                 return stepwise
-            book.setdefault("counter_rate", {})[key] = {name: v // n_steps for name, v in advanced.items()}
+            counter_rate = {name: v // n_steps for name, v in advanced.items()}
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
         if spec[0] in ("mlp_diagonal", "neural", "neural_additive"):      # the matrix cores sum the layers' products in another order than the library
             rtol, atol = 1e-3, 1e-4
         both_nan = fast.isnan() & stepwise.isnan()
         close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
-        if len(book["trusted"]) >= 32:
-            book["trusted"].clear()
-        book["trusted"][key] = True if bool(close.all()) else "the trajectory kernel did not reproduce the stepwise solve"
+        self._record_verdict(book, key, True if bool(close.all()) else
+                             "the trajectory kernel did not reproduce the stepwise solve", reverify)
+        if counters:                        # (after the verdict: recording it prunes the book, rates included, when it is full)
+            book.setdefault("counter_rate", {})[key] = counter_rate
         return stepwise
+
+    def _assume_pure(self, base):
+        return bool(self.options.get("assume_pure", False) or getattr(base, "tsde_assume_pure", False))
 
     @staticmethod
     def _rng_states(device):
@@ -678,7 +701,8 @@ class BaseSDESolver:
                 or (self._program_code() == _native.TRAJ_SRK and not bm._have_H)):
             return None
         chain, base = graph._wrapper_chain(sde)
-        if not self._may_be_interpreted(base) or graph.call_counters(base):
+        assume_pure = self._assume_pure(base)
+        if not self._may_be_interpreted(base) or (not assume_pure and graph.call_counters(base)):
             # (call counters: only the forward route above keeps them at the stepwise loop's value; with autograd recording such
             #  modules stay stepwise, where the counters are right by construction)
             return None
@@ -687,7 +711,7 @@ class BaseSDESolver:
         except AttributeError:
             return None
         if book["refused"]:
-            state = graph.python_state(base)
+            state = ("assumed pure",) if assume_pure else graph.python_state(base)
             if state is None or (state, chain, type(self).__name__) in book["refused"]:
                 return None
         leaves = None
@@ -702,9 +726,10 @@ class BaseSDESolver:
             return self._integrate_program_with_grad(y0, ts, book, chain)
         key = self._recognised_key(found, chain, y0) + ("autograd",)
         verdict = book["trusted"].get(key)
-        if verdict is True:
+        reverify = verdict is True and self._due_for_reverification(book, key)
+        if verdict is True and not reverify:
             return self._integrate_trajectory(("differentiable",) + tuple(leaves), y0, ts)
-        if verdict is not None:
+        if verdict is not None and not reverify:
             return None
         # (as in `_integrate_recognised`: a second interpretation on a probe of another height must give the same values)
         try:
@@ -712,21 +737,16 @@ class BaseSDESolver:
         except recognise.NotElementwise:
             return None
         if again is None or any(a.shape != b.shape or not torch.equal(a.detach(), b.detach()) for a, b in zip(again, leaves)):
-            book["trusted"][key] = "two interpretations of the same code (probes of 2 and 5 rows) gave different coefficients"
+            self._record_verdict(book, key, "two interpretations of the same code (probes of 2 and 5 rows) gave different "
+                                 "coefficients", reverify)
             return None
-        with torch.no_grad():
-            fast = self._integrate_trajectory(tuple(c.detach().reshape(-1).expand(y0.shape[1]).contiguous()
-                                                    for c in leaves), y0.detach(), ts)
+        fast = self._integrate_trajectory(("differentiable",) + tuple(leaves), y0, ts)     # values AND a grad_fn
         if fast is None:
             return None
         self._extra = ()
         stepwise = self._run(self._plan(y0, ts), y0)           # recorded by autograd: this is the result
-        rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
-        ref = stepwise.detach()
-        close = ((fast - ref).abs() <= atol + rtol * ref.abs()) | (fast.isnan() & ref.isnan()) | (fast == ref)
-        if len(book["trusted"]) >= 32:
-            book["trusted"].clear()
-        book["trusted"][key] = True if bool(close.all()) else "the sensitivity kernel's values differ from the stepwise solve"
+        verdict = self._both_routes_agree(fast, stepwise, y0, "the sensitivity kernel")
+        self._record_verdict(book, key, verdict, reverify)
         return stepwise
 
     def _integrate_program_with_grad(self, y0, ts, book, chain):
@@ -766,9 +786,10 @@ class BaseSDESolver:
         key = self._recognised_key(found, chain, y0) + ("autograd",)
         verdict = book["trusted"].get(key)
         launch = ("program_differentiable", spec[1], spec[2], spec[3], tuple(found.consts), tuple(rows), spec[5])
-        if verdict is True:
+        reverify = verdict is True and self._due_for_reverification(book, key)
+        if verdict is True and not reverify:
             return self._integrate_trajectory(launch, y0, ts)
-        if verdict is not None:
+        if verdict is not None and not reverify:
             return None
         try:
             again = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, rows=5, differentiable=True)
@@ -777,21 +798,77 @@ class BaseSDESolver:
             return None
         if (again.structure() != found.structure()
                 or not torch.equal(again_spec[4], spec[4]) or again.trainable_rows(None) != rows):
-            book["trusted"][key] = "two interpretations of the same code (probes of 2 and 5 rows) gave different programs"
+            self._record_verdict(book, key, "two interpretations of the same code (probes of 2 and 5 rows) gave different "
+                                 "programs", reverify)
             return None
-        with torch.no_grad():
-            fast = self._integrate_trajectory(spec, y0.detach(), ts)
+        fast = self._integrate_trajectory(launch, y0, ts)       # values AND a grad_fn (the program sensitivity kernel)
         if fast is None:
             return None
         self._extra = ()
         stepwise = self._run(self._plan(y0, ts), y0)           # recorded by autograd: this is the result
-        rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
-        ref = stepwise.detach()
-        close = ((fast - ref).abs() <= atol + rtol * ref.abs()) | (fast.isnan() & ref.isnan()) | (fast == ref)
+        verdict = self._both_routes_agree(fast, stepwise, y0, "the program sensitivity kernel")
+        self._record_verdict(book, key, verdict, reverify)
+        return stepwise
+
+
+    # ---- the verifying solve: values AND gradients -----------------------------------------------------------------
+    def _both_routes_agree(self, fast, stepwise, y0, what):
+        """True, or the reason the kernel route is not to be trusted. `fast` and `stepwise` are the two routes' results of
+        the SAME solve, both with their autograd graphs. Values: elementwise, at the tolerances of the forward route. Gradients:
+        d<ys, r>/d(y0, every trainable parameter) for one fixed random cotangent r, the kernel's sensitivities against
+        ordinary autograd through the stepwise loop -- what the reference computes (base_solver.py:143-149 under autograd,
+        sdeint.py:27-112) -- relative to the largest entry of each gradient. (One extra backward pass through the stepwise
+        graph, which is retained for the caller; once per form, scheme, batch size and SDE object.)"""
+        f32 = y0.dtype == torch.float32
+        rtol, atol = (1e-4, 1e-5) if f32 else (1e-9, 1e-11)
+        ref, got = stepwise.detach(), fast.detach()
+        close = ((got - ref).abs() <= atol + rtol * ref.abs()) | (got.isnan() & ref.isnan()) | (got == ref)
+        if not bool(close.all()):
+            return f"{what}'s values differ from the stepwise solve"
+        inputs = ([y0] if y0.requires_grad else []) + [p for p in self._params() if p.requires_grad]
+        if not inputs or fast.grad_fn is None or stepwise.grad_fn is None:
+            return True if fast.grad_fn is None and stepwise.grad_fn is None else \
+                f"{what}: one route carries a gradient and the other does not"
+        gen = torch.Generator(device=y0.device)
+        gen.manual_seed(0x5DE)
+        r = torch.randn(ref.shape, generator=gen, device=y0.device, dtype=y0.dtype)
+        want = torch.autograd.grad((stepwise * r).sum(), inputs, retain_graph=True, allow_unused=True)
+        have = torch.autograd.grad((fast * r).sum(), inputs, allow_unused=True)
+        g_rtol, g_atol = (2e-3, 1e-6) if f32 else (1e-8, 1e-12)
+        for i, (w, h) in enumerate(zip(want, have)):
+            w = torch.zeros_like(inputs[i]) if w is None else w
+            h = torch.zeros_like(inputs[i]) if h is None else h
+            scale = w.abs().max()
+            bad = ((h - w).abs().max() > g_rtol * scale + g_atol) | ~torch.isfinite(h).all()
+            if bool(bad) and bool(torch.isfinite(w).all()):
+                name = "y0" if (i == 0 and y0.requires_grad) else f"parameter {i - (1 if y0.requires_grad else 0)}"
+                return (f"{what}'s gradient with respect to {name} differs from autograd through the stepwise solve "
+                        f"(max error {float((h - w).abs().max()):.3e} at scale {float(scale):.3e})")
+        return True
+
+    @staticmethod
+    def _record_verdict(book, key, verdict, reverify=False):
         if len(book["trusted"]) >= 32:
             book["trusted"].clear()
-        book["trusted"][key] = True if bool(close.all()) else "the program kernel's values differ from the stepwise solve"
-        return stepwise
+            book.get("counter_rate", {}).clear()
+            book.get("solves", {}).clear()
+        book["trusted"][key] = verdict
+        if reverify and verdict is not True:
+            # TSDE_VERIFY_EVERY: a form that had earned trust and no longer reproduces the stepwise solve is a loud failure
+            raise RuntimeError(f"torchsde_amd: periodic re-verification (TSDE_VERIFY_EVERY) of a trusted kernel route failed: "
+                               f"{verdict}. Results of earlier solves of this object on that route are suspect; "
+                               "options={'trajectory_kernel': False} keeps the stepwise path.")
+
+    @staticmethod
+    def _due_for_reverification(book, key):
+        """TSDE_VERIFY_EVERY=N (or `solvers.VERIFY_EVERY`): every N-th solve of a trusted form runs both routes again and
+        compares (values, and gradients where autograd records) -- a mis-recognition fails loudly in CI instead of quietly
+        in training. 0 (the default): only the first solve verifies."""
+        if VERIFY_EVERY <= 0:
+            return False
+        count = book.setdefault("solves", {})
+        count[key] = count.get(key, 0) + 1
+        return count[key] % VERIFY_EVERY == 0
 
     _STAGE_TIMES = {}
     # stage-time slots of the trajectory kernels (csrc/trajectory.hip stage_slots): offsets from t0 as multiples of dt
@@ -839,16 +916,18 @@ class BaseSDESolver:
                 or sde.noise_type != NOISE_TYPES.diagonal or y0.dim() != 2 or not y0.is_cuda):
             return None
         chain, base = graph._wrapper_chain(sde)
-        if not self._may_be_interpreted(base) or graph.call_counters(base):
+        assume_pure = self._assume_pure(base)
+        if not self._may_be_interpreted(base) or (not assume_pure and graph.call_counters(base)):
             return None
         book = getattr(base, self._RECOGNISED_ATTR, None)
         if book is not None and book["refused"]:
-            state = graph.python_state(base)
+            state = ("assumed pure",) if assume_pure else graph.python_state(base)
             if state is None or (state, chain, type(self).__name__) in book["refused"]:
                 return None
         try:
-            with torch.no_grad():
-                found = recognise.recognise(sde, ts[0], y0.detach())
+            # (differentiable=True: the adjoint kernels differentiate the recognised network -- a stop-gradient in the user's
+            #  code, which adjoint_sde.py:111-128 would honour, ends the interpretation: recognise.check_stop_gradient)
+            found = recognise.recognise(sde, ts[0], y0.detach(), differentiable=True)
             if not found.perceptron:
                 return None
             found.perceptron_spec()
@@ -929,7 +1008,9 @@ class BaseSDESolver:
                 if table.shape[0] != grid.n_steps * slots:
                     return None
                 table = table.view(grid.n_steps, slots, m, y0.shape[1])
-            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            if kind == "neural_additive" and y0.numel() >= 2 ** 30:
+                return None
+            y0c = self._aligned_start(y0)
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
             ys[0].copy_(y0c)
             if kind == "neural_additive":
@@ -938,14 +1019,14 @@ class BaseSDESolver:
                 K.trajectory_prog_additive(ys[1:], y0c, f_code, const_table, table, m, code, schedule, bm)
             return ys
         if coefficients[0] == "neural":
-            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            y0c = self._aligned_start(y0)
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
             ys[0].copy_(y0c)
             K.trajectory_mlp_general(ys[1:], y0c, coefficients[1], coefficients[2], coefficients[3], coefficients[4],
                                      self._neural_code(), schedule, bm)
             return ys
         if coefficients[0] == "mlp_diagonal":
-            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            y0c = self._aligned_start(y0)
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
             ys[0].copy_(y0c)
             K.trajectory_mlp_diag(ys[1:], y0c, *coefficients[1:], self._trajectory_code(), schedule, bm)
@@ -964,6 +1045,13 @@ class BaseSDESolver:
         ys[0].copy_(y0c)
         K.trajectory_affine_diag(ys[1:], y0c, *coefficients, self._trajectory_code(), schedule, bm)
         return ys
+
+    @staticmethod
+    def _aligned_start(y0):
+        """y0 as the network kernels read it: detached, contiguous, and -- an offset view of a larger tensor need not be --
+        on a 16-byte boundary (their C entry points refuse anything else when rows are read as 16-byte groups)."""
+        y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+        return y0c.clone() if y0c.data_ptr() % 16 else y0c
 
     def _plan(self, y0, ts):
         """Host-side preparation of a solve: time grid, stage times (one upload), Brownian cell map, output map.
