@@ -88,7 +88,10 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c2_euler_exscalar_default_route_b65536_d64_s1000", "c2_euler_exscalar_training_default_route_b65536_d64_s1000",
         "c5_sampling_mlp_b32768_d128_s500", "c5_sampling_mlp_srk_b32768_d128_s500", "c5_training_mlp_b32768_d128_s500", "c5_adjoint_mlp_b32768_d128_s500",
         "c5_adjoint_mlp_milstein_b32768_d128_s500", "c5_adjoint_mlp_defaults_b32768_d128_s500",
-        "c5_adjoint_latent_default_route_b32768_d128_s500", "c5_adjoint_latent_defaults_default_route_b32768_d128_s500")
+        "c5_adjoint_latent_default_route_b32768_d128_s500", "c5_adjoint_latent_defaults_default_route_b32768_d128_s500",
+        # SURVEY 8(f) rows, measured on the routes they have
+        "c5_rheun_adjoint_latent_b32768_d128_s500", "c5_logqp_adjoint_latent_b32768_d128_s500",
+        "c3_log_ode_general_b16384_d32_m16")
 
 
 def csrc_digest():
@@ -222,7 +225,11 @@ class Job:
                     ys = self._sdeint_adjoint(self.sde, self.y0, self.ts, bm=bm, method=c["method"],
                                               adjoint_method=c["adjoint_method"], dt=c["dt"],
                                               options=None if plain else dict(gopt),
-                                              adjoint_options=None if plain else dict(gopt))
+                                              adjoint_options=None if plain else dict(gopt), logqp=bool(c.get("logqp")))
+                    if c.get("logqp"):
+                        # (ys, log-ratio (T - 1, B)): a latent-SDE user's loss has a term of the path and the KL term
+                        states, log_ratio = ys
+                        ys = torch.cat([states[-1], log_ratio.sum(0).unsqueeze(-1)], dim=1).unsqueeze(0)
                     if plain and not type(ys.grad_fn).__name__.startswith("_MlpAdjointFn"):
                         raise RuntimeError(f"{self.name}: sdeint_adjoint did not take the matrix-core route")
                 else:
@@ -336,7 +343,37 @@ class Job:
                 (ya, fa, ga), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
                 cf, cg = coefs[i % len(coefs)]
                 K._raw_step_diag(ya, fa, ga, cf, cg, spec[i], yb)
-            return {"tsde_step_diag": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+            out = {"tsde_step_diag": _graph_replay_us([(lambda i=i: launch(i)) for i in range(n)], dev)}
+            if "tsde_heun_final" in (c.get("step_kernels") or {}):
+                hsets = copies(y, f, f, g, g)
+
+                def final(i):
+                    (ya, fa, fb, ga, gb), yb = hsets[i % len(hsets)], hsets[(i + 1) % len(hsets)][0]
+                    K.heun_final(ya, fa, fb, ga, gb, dt, 0, spec[i], out=yb)
+                out["tsde_heun_final"] = _graph_replay_us([(lambda i=i: final(i)) for i in range(n)], dev)
+            return out
+        if kid == 7:
+            # reversible Heun, diagonal noise: the four elementwise kernels of a forward + backward step
+            sets = copies(y, y.clone(), f, g, f.clone(), g.clone())
+
+            def z_launch(i):
+                (ya, za, fa, ga, _, _), zb = sets[i % len(sets)], sets[(i + 1) % len(sets)][1]
+                K.rheun_z(ya, za, fa, ga, dt, 1.0, spec[i], out=zb)
+
+            def y_launch(i):
+                (ya, _, fa, ga, fb, gb), yb = sets[i % len(sets)], sets[(i + 1) % len(sets)][0]
+                K.rheun_y(ya, fa, fb, ga, gb, 0.5 * dt, 1.0, spec[i], out=yb)
+
+            def a_launch(i):
+                ya, _, fa, ga, _, _ = sets[i % len(sets)]
+                K.rheun_adj_a(ya, fa, ga, 0.5 * dt, spec[i])
+
+            def b_launch(i):
+                ya, za, fa, _, _, _ = sets[i % len(sets)]
+                K.rheun_adj_b(ya, za, fa, dt, 0.5 * dt, spec[i])
+            return {label: _graph_replay_us([(lambda i=i, fn=fn: fn(i)) for i in range(n)], dev)
+                    for label, fn in (("tsde_rheun_z", z_launch), ("tsde_rheun_y", y_launch), ("tsde_rheun_adj_a", a_launch),
+                                      ("tsde_rheun_adj_b", b_launch))}
         if kid == 2:
             sets = copies(y, f, g)
 
@@ -485,7 +522,15 @@ class Job:
         moved = c.get("bytes_moved_per_traj_step", contract)
         if b2b is None:
             return None
-        step_us = sum(b2b.values()) if c["kid"] == 4 else next(iter(b2b.values())) * per_step
+        # a step made of several different kernels prices each at its own launch time (`step_kernels`: launches per step)
+        counts = c.get("step_kernels")
+        if counts is not None:
+            if set(counts) - set(b2b):
+                return None
+            step_us = sum(b2b[k] * n for k, n in counts.items())
+            per_step = sum(counts.values())
+        else:
+            step_us = sum(b2b.values()) if c["kid"] == 4 else next(iter(b2b.values())) * per_step
         achieved = contract * B / (step_us * 1e-6) / 1e9
         solve_achieved = contract * value / self.world / 1e9
         roof = {"bound": "hbm", "kernel": c["kernel"],
@@ -738,6 +783,58 @@ def _stepwise_beside(dev, name, args):
             "roofline": {k: roof[k] for k in keep if k in roof}}
 
 
+CONFIG3 = "c4_midpoint_diag_default_route_b32768_d64"
+
+
+def _config3_beside(dev, rank, world, dist, args):
+    """BASELINE configs[3] -- Stratonovich midpoint, 262144 x 64 rows sharded 32768 per GPU over 8 GPUs, one RCCL gather of
+    final states per solve -- measured by EVERY multi-GPU run of the default bench line, beside the headline (VERDICT r5 next 8:
+    the driver's scale run passes no --workload). Same timing contract as the headline (barrier + synchronize on both sides,
+    max over ranks). Also checks, once, that the rows rank 0 GATHERED from another rank's shard are bit-identical to a
+    single-rank solve of those global rows on rank 0 (the increments are addressed by global row: sharding.py)."""
+    job = Job(CONFIG3, dev, rank=rank, world=world, dist=dist, graph=not args.eager)
+    c = job.cfg
+    job.prepare()
+
+    def barrier():
+        job.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        job.solve(i)
+    barrier()
+    start = time.perf_counter()
+    for i in range(args.steps):
+        out = job.solve(1000 + i)
+    barrier()
+    elapsed = torch.tensor([time.perf_counter() - start], device=dev, dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    # bit-equality of one foreign shard: the last rank's rows, solved again here as a single-rank job with its row offset
+    other = world - 1
+    gathered = job.solve(77)
+    barrier()
+    shard = gathered[other * c["B"]:(other + 1) * c["B"]].clone()
+    alone = Job(CONFIG3, dev, rank=other, world=world, dist=None, graph=not args.eager)
+    alone.sde = job.sde
+    for i in range(2):
+        alone.solve(9000 + i)                   # (the module's route is already trusted; warm the plan)
+    same = bool(torch.equal(alone.solve(77), shard))
+    flag = torch.tensor([1 if same else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ranks = _what_the_ranks_saw(job, dev, dist, os.environ.get("TSDE_BENCH_SHARE_GPU") == "1")
+    value = world * c["B"] * c["nsteps"] * args.steps / elapsed
+    return {"workload": CONFIG3, "is": "BASELINE configs[3]: Stratonovich midpoint, diagonal noise, batch sharded "
+            f"{c['B']} rows per GPU", "value": value, "unit": "trajectory-steps/s", "n_gpus": world,
+            "global_batch": world * c["B"], "state": c["d"], "solver_steps": c["nsteps"],
+            "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak",
+            "gathered_shard_equals_single_rank_solve": bool(flag.item()), "shard_checked": f"rank {other}'s rows on every rank",
+            "ranks_seen": ranks["ranks_seen"], "all_gather_ms_per_solve": ranks["all_gather_ms_per_solve"],
+            "all_gather_bytes_per_rank": ranks.get("all_gather_bytes_per_rank"),
+            "collective_backend": ranks["collective_backend"]}
+
+
 def _side_measurements(dev):
     """Short measurements reported under `also`: outside the headline's timed region and NOT part of `value`. A
     failure here is reported in place and never takes the headline down with it."""
@@ -949,6 +1046,12 @@ def main():
         roofline = job.roofline_stepwise(value, job.back_to_back_us(job.live_state(out)))
         _attach_offline_traffic(roofline, args.workload)
 
+    config3 = None
+    if world > 1 and args.workload == HEADLINE and use_dist:
+        try:
+            config3 = _config3_beside(dev, rank, world, dist, args)
+        except Exception as e:           # (never takes the headline down with it -- but every rank must fail alike)
+            config3 = {"workload": CONFIG3, "error": f"{type(e).__name__}: {e}"}
     stepwise = None
     if world == 1 and cfg.get("stepwise") and not args.no_stepwise:
         stepwise = _stepwise_beside(dev, cfg["stepwise"], args)
@@ -990,6 +1093,8 @@ def main():
         }
         if stepwise is not None:
             line["stepwise"] = stepwise
+        if config3 is not None:
+            line["configs3"] = config3
         line.update(ranks)
         if also is not None:
             line["also_file"] = _emit_also(also)

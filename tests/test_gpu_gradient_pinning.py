@@ -277,3 +277,47 @@ def test_assume_pure_is_the_one_switch_for_python_side_state(how):
         ys, launches = solve(sde, entropy, options)
         assert launches == 1
         assert torch.equal(ys, solve(plain, entropy, {})[0])
+
+
+class _LatentStopGradient(nn.Module):
+    """The latent-SDE shape of tests/test_gpu_recognise.py::_Latent with a stop-gradient in front of the drift network."""
+    noise_type, sde_type = "diagonal", "ito"
+
+    def __init__(self, d, hidden, stop):
+        super().__init__()
+        self.stop = stop
+        self.net = nn.Sequential(nn.Linear(d, hidden), nn.Softplus(), nn.Linear(hidden, d))
+        self.w = nn.Parameter(torch.full((d,), 0.5))
+        self.b = nn.Parameter(torch.zeros(d))
+
+    def f(self, t, y):
+        return self.net(y.detach() if self.stop else y)
+
+    def g(self, t, y):
+        return 0.1 * torch.sigmoid(self.w * y + self.b)
+
+
+@pytest.mark.parametrize("stop", [False, True])
+def test_sdeint_adjoint_honours_a_stop_gradient_in_front_of_the_drift_network(stop):
+    """adjoint_sde.py:111-128 asks autograd for a^T df/dy of the user's code: with `net(y.detach())` that is zero. The matrix-core
+    adjoint differentiates the recognised network, so such a module must stay on the stepwise adjoint (and the honest one must
+    still take the kernels)."""
+    import torchsde_amd
+    d, hidden, Bn, steps, dt = 32, 32, 96, 16, 2.0 ** -6
+    sde = _LatentStopGradient(d, hidden, stop).to(DEV)
+    ts = torch.tensor([0.0, steps * dt], device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    weights = torch.randn(2, Bn, d, device=DEV, generator=gen)
+    results = []
+    for stepwise in (False, False, True):
+        y0 = torch.full((Bn, d), 0.1, device=DEV, requires_grad=True)
+        sde.zero_grad()
+        bm = torchsde_amd.BrownianInterval(0.0, steps * dt, size=(Bn, d), device=DEV, entropy=9)
+        opts = {"trajectory_kernel": False} if stepwise else None
+        ys = torchsde_amd.sdeint_adjoint(sde, y0, ts, bm=bm, method="euler", adjoint_method="euler", dt=dt, options=opts,
+                                         adjoint_options=opts)
+        took_kernel = type(ys.grad_fn).__name__.startswith("_MlpAdjointFn")
+        assert took_kernel == (not stop and not stepwise), (stop, stepwise, type(ys.grad_fn).__name__)
+        (ys * weights).sum().backward()
+        results.append((ys.detach(), y0.grad.clone(), {n: p.grad.clone() for n, p in sde.named_parameters()}, ""))
+    _same_gradients(results[1], results[2], 2e-3 if not stop else 1e-6)

@@ -120,6 +120,19 @@ def test_bench_multi_rank_logic_on_one_gpu(workload, launcher):
     if workload is not None:
         assert rec["config"]["workload"] == workload and rec["config"]["batch_per_gpu"] == 32768
         assert rec["config"]["method"] == "midpoint"
+        assert "configs3" not in rec
+    else:
+        # the default multi-GPU line (what the driver's scale run launches) carries BASELINE configs[3] beside the headline:
+        # sharded Stratonovich midpoint, 32768 rows per rank, gathered -- and rank 0's copy of a foreign shard is bit-identical
+        # to a single-rank solve of those global rows
+        c3 = rec["configs3"]
+        assert "error" not in c3, c3
+        assert c3["workload"] == "c4_midpoint_diag_default_route_b32768_d64" and c3["n_gpus"] == 2
+        assert c3["global_batch"] == 2 * 32768 and c3["solver_steps"] == 1000 and c3["ranks_seen"] == 2
+        assert c3["gathered_shard_equals_single_rank_solve"] is True
+        assert c3["all_gather_ms_per_solve"] > 0
+        want = c3["global_batch"] * c3["solver_steps"] / (c3["ms_per_step"] * 1e-3)
+        assert abs(c3["value"] - want) <= 1e-6 * want
     expected = rec["config"]["global_batch"] * rec["config"]["solver_steps"] / (rec["ms_per_step"] * 1e-3)
     assert abs(rec["value"] - expected) <= 1e-6 * expected
     roof = rec["roofline"]

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-WORKLOADS="c2_euler_diag_default_route_b65536_d64_s1000 c2_euler_diag_b65536_d64_s1000 c2_milstein_diag c2_srk_diag c3_euler_general_b16384_d32_m16 c3_milstein_general_gradfree_b16384_d32_m16 c3_euler_additive_shared_b16384_d32_m16 c3_euler_additive_shared_b262144_d64_m32 c4_midpoint_diag_b32768_d64 c5_adjoint_latent_b32768_d128_s500"
+WORKLOADS="c2_euler_diag_default_route_b65536_d64_s1000 c2_euler_diag_b65536_d64_s1000 c2_milstein_diag c2_srk_diag c3_euler_general_b16384_d32_m16 c3_milstein_general_gradfree_b16384_d32_m16 c3_euler_additive_shared_b16384_d32_m16 c3_euler_additive_shared_b262144_d64_m32 c4_midpoint_diag_b32768_d64 c5_adjoint_latent_b32768_d128_s500 c5_rheun_adjoint_latent_b32768_d128_s500 c3_log_ode_general_b16384_d32_m16"
 for W in $WORKLOADS; do
   ARGS="--workload $W --steps 1 --warmup 1 --profile-steps 100"
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o b -- python $R/bench.py $ARGS > $OUT/$W.trace.json 2> $OUT/$W.trace.log

@@ -938,7 +938,43 @@ class BaseSDESolver:
             with torch.no_grad():                                  # the verifying solve (both routes, compared)
                 self._integrate_recognised(y0.detach(), ts)
             book = getattr(base, self._RECOGNISED_ATTR, None)
+            # ... and the DERIVATIVES the adjoint kernels will stand for: vector-Jacobian products of the user's f and g
+            # (what adjoint_sde.py:111-128, 218-230 asks autograd for at every backward step) against those of the recognised
+            # network built from the same parameter tensors, on real rows of this solve
+            if book is not None and book["trusted"].get(key) is True:
+                reason = self._perceptron_derivatives_agree(found, y0, ts)
+                if reason is not True:
+                    book["trusted"][key] = reason
         return found if book is not None and book["trusted"].get(key) is True else None
+
+    def _perceptron_derivatives_agree(self, found, y0, ts):
+        own = found.perceptron_parameters()
+        if own is None:
+            return True                     # (mlp_adjoint.route refuses such a module on its own)
+        kind, amplitude, _, _ = found.perceptron_diffusion()
+        w1, b1, w2, b2, rate, shift = own
+        probe = y0.detach()[:32].clone().requires_grad_(True)
+        gen = torch.Generator(device=y0.device)
+        gen.manual_seed(0x5DE)
+        r_f = torch.randn(probe.shape, generator=gen, device=y0.device, dtype=y0.dtype)
+        r_g = torch.randn(probe.shape, generator=gen, device=y0.device, dtype=y0.dtype)
+        with torch.enable_grad():
+            f_user, g_user = self.sde.f_and_g(ts[0], probe)
+            hidden = torch.addmm(b1, probe, w1.t())
+            hidden = torch.tanh(hidden) if found.f.act == "tanh" else torch.nn.functional.softplus(hidden)
+            f_kernel = torch.addmm(b2, hidden, w2.t())
+            z = rate * probe + shift
+            g_kernel = z if kind == _native.DIFF_AFFINE else amplitude * torch.sigmoid(z)
+            inputs = [probe] + [p for p in own if p.requires_grad]
+            want = torch.autograd.grad((f_user * r_f).sum() + (g_user * r_g).sum(), inputs, allow_unused=True)
+            have = torch.autograd.grad((f_kernel * r_f).sum() + (g_kernel * r_g).sum(), inputs, allow_unused=True)
+        for i, (w, h) in enumerate(zip(want, have)):
+            w = torch.zeros_like(inputs[i]) if w is None else w
+            h = torch.zeros_like(inputs[i]) if h is None else h
+            if bool((h - w).abs().max() > 1e-4 * w.abs().max() + 1e-6):
+                return ("the derivatives of the recognised network differ from autograd through the user's f and g "
+                        f"(input {i} of [state, lin1.weight, lin1.bias, lin2.weight, lin2.bias, rate, shift])")
+        return True
 
     def recognised_route(self):
         """{form key: True | reason} and {state: reason} of the SDE object this solver integrates (diagnostics)."""

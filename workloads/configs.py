@@ -95,6 +95,7 @@ WORKLOADS = {
     "c2_heun_diag_b65536_d64_s1000": dict(
         problem="gbm_strat", method="heun", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=(16 + 28) * 64, kid=1, launches_per_step=2, bench_steps=200,
+        step_kernels={"tsde_step_diag": 1, "tsde_heun_final": 1},
         kernel="tsde_step_diag<float> + tsde_heun_final<float> (user f, g evaluated twice per step)"),
     # The reference's additive-noise problem (ExAdditive, tests/problems.py:106-132: f and g use t; g repeated over m columns)
     # with sdeint's default method for additive noise, SRK = SRA1 (sdeint.py:151, srk.py:90-111), as a drop-in call: the
@@ -308,11 +309,45 @@ WORKLOADS = {
         nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 128, kid=5, launches_per_step=1, adjoint=True,
         kernel_match=["aug_multi_kernel<float>"],
         kernel="tsde_aug_update<float> (aug_multi_kernel, backward sweep)"),
+    # ---- SURVEY 8(f) rows on the routes they have today (stepwise): measured so that they are rows with numbers -------------
+    # 8f rank 1: the reference's recommended training pair (DOCUMENTATION.md:97,118; reversible_heun.py:48-144) at the
+    # configs[4] shape. Forward per step: tsde_rheun_z (y, z, f, g -> z': 5 streams) + tsde_rheun_y (y, f, f', g, g' -> y': 6
+    # streams); backward per step: tsde_rheun_adj_a (3 in, 2 out) + _z (5) + _y (6) + tsde_rheun_adj_b (3 in, 4 out):
+    # (11 + 23) * 4 * d bytes per trajectory-step forward + backward.
+    "c5_rheun_adjoint_latent_b32768_d128_s500": dict(
+        problem="latent_diag_strat", method="reversible_heun", adjoint_method="adjoint_reversible_heun", levy="none",
+        B=32768, d=128, m=128, nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=(11 + 23) * 4 * 128, kid=7, adjoint=True,
+        launches_per_step=6,
+        step_kernels={"tsde_rheun_z": 2, "tsde_rheun_y": 2, "tsde_rheun_adj_a": 1, "tsde_rheun_adj_b": 1},
+        kernel_match=["RheunZOp<float>", "RheunYOp<float>", "RheunAdjAOp<float>", "RheunAdjBOp<float>"],
+        kernel="tsde_rheun_z / _y / _adj_a / _adj_b <float> (6 launches per forward + backward step; user f, g and their "
+               "vector-Jacobian products between them)"),
+    # 8f rank 4: `sdeint_adjoint(..., logqp=True)` (base_sde.py:240-306) at the configs[4] shape: the state carries one more
+    # column, u = (f - h) / g, through the same stepwise kernels as c5_adjoint_latent (d + 1 = 129 channels: rows are no longer
+    # 16-byte groups)
+    "c5_logqp_adjoint_latent_b32768_d128_s500": dict(
+        problem="latent_diag_logqp", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=129,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=(16 + 32) * 129, kid=5, launches_per_step=1, adjoint=True, logqp=True,
+        kernel_match=["aug_multi_kernel<float>"],
+        kernel="tsde_step_diag + tsde_aug_update <float> on the (B, d + 1) logqp state (user f, g, h and their VJPs between "
+               "them)"),
+    # 8f rank 3: log-ODE (log_ode.py:39-56) with Foster's Levy area (brownian_interval.py:78-99) at the configs[2] shape:
+    # per step tsde_levy_area (W, H -> A (B, m, m)), two general contractions, and the user's m-column JVP
+    "c3_log_ode_general_b16384_d32_m16": dict(
+        problem="general_big_strat", method="log_ode", levy="foster", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=2 * 4 * (32 * 16 + 3 * 32) + 4 * (16 * 16 + 2 * 16), kid=2, launches_per_step=2, eager=True,
+        bench_steps=50, kernel_match=["general_rows_kernel<float", "levy_area"],
+        step_kernels={"tsde_step_general": 2},
+        kernel="tsde_step_general x2 + tsde_levy_area <float> (+ the user's g and its Jacobian-vector products per step)"),
 }
 
 
 def make_problem(name, d, m, dev):
     from . import problems
+    if name == "latent_diag_strat":
+        return problems.LatentDiagStrat(d).to(dev)
+    if name == "latent_diag_logqp":
+        return problems.LatentDiagLogqp(d).to(dev)
     if name == "general_big":      # NeuralGeneral-style: hidden 64
         return problems.MLPGeneral(d, m, "ito", hidden=64).to(dev)
     if name == "netadditive_big":

@@ -243,6 +243,24 @@ class LatentDiag(nn.Module):
         return 0.1 * torch.sigmoid(self.w * y + self.b)
 
 
+class LatentDiagStrat(LatentDiag):
+    """The same dynamics read as a Stratonovich SDE: what `method="reversible_heun"` (reversible_heun.py:48-73, Stratonovich
+    only) integrates -- the reference's recommended training pair at the configs[4] shape."""
+    sde_type = "stratonovich"
+
+
+class LatentDiagLogqp(LatentDiag):
+    """... with a prior drift `h` (an Ornstein-Uhlenbeck pull, cf. examples/latent_sde.py:119-121), so that
+    `sdeint(..., logqp=True)` (base_sde.py:240-306) can integrate the KL column u = (f - h) / g beside the state."""
+
+    def __init__(self, d, seed=0):
+        super().__init__(d, seed)
+        self.theta = nn.Parameter(torch.full((d,), 0.5))
+
+    def h(self, t, y):
+        return -self.theta * y
+
+
 class ExpDiffusion(nn.Module):
     """The SDE the reference's own benchmark integrates (benchmarks/brownian.py:131-139): f = y, g = exp(-y),
     diagonal Ito noise, no parameters."""
