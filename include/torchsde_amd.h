@@ -411,6 +411,7 @@ int tsde_trajectory_affine_diag_sens(void* ys, void* sens, const void* y0, int64
  * solve of the same SDE sees; results agree with it up to the summation order of the two matrix products. */
 #define TSDE_ACT_TANH 0
 #define TSDE_ACT_SOFTPLUS 1
+#define TSDE_ACT_SILU 2   /* act_scale * x * sigmoid(x) -- tsde_deep_mlp_t only (LipSwish: examples/sde_gan.py:44-47) */
 /* diffusion of the perceptron-drift kernels, per channel:
  *   TSDE_DIFF_AFFINE   g = diff_rate * y + diff_shift
  *   TSDE_DIFF_SIGMOID  g = diff_amp * sigmoid(diff_rate * y + diff_shift)   (the elementwise diffusion nets of
@@ -484,6 +485,7 @@ int tsde_trajectory_prog_additive(void* ys, const void* y0, int64_t rows, int64_
  *   NeuralDiagonal.g, tests/problems.py:159); the drift uses final = NONE, scale = 1. */
 #define TSDE_FINAL_NONE 0
 #define TSDE_FINAL_SIGMOID 1
+#define TSDE_FINAL_TANH 2    /* tsde_deep_mlp_t only (MLP(..., tanh=True), examples/sde_gan.py:50-66) */
 #define TSDE_PRECISION_F32 0
 #define TSDE_PRECISION_BF16X3 1
 #define TSDE_NOISE_DIAGONAL 0
@@ -633,6 +635,97 @@ int tsde_trajectory_mlp_diag_backward(void* lam, void* stash_lam, void* stash_hi
                                       uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
                                       void* stream);
 
+/* ---- The reversible Heun pair for neural SDEs, one launch each way (csrc/tsde_neural_rheun.h) ----------------------------
+ * Replaces, for modules whose drift and diffusion are perceptrons of (t, y),
+ *   forward:  base_solver.py:114-134 driving methods/reversible_heun.py:48-73 (ReversibleHeun.step; the carried (f, g, z) of
+ *             init_extra_solver_state, :58-59, are formed in the kernel from z_0 = y_0)
+ *   backward: adjoint.py:64-127 driving methods/reversible_heun.py:76-144 (AdjointReversibleHeun.step) with the vector-
+ *             Jacobian products of adjoint_sde.py / misc.vjp evaluated on the matrix cores
+ * A perceptron of up to four Linear layers:
+ *   out = scale * final(W2 . a(Wm[n_mid-1] . ... a(Wm[0] . a(W1 . y + w1t * t + b1) + bm[0]) ... ) + b2),  a = act_scale * act(.)
+ *   w1 (d, hidden), wm[l] (hidden, hidden), w2 (hidden, out) input-major (nn.Linear's weight transposed); w1t (hidden) or NULL;
+ *   activation TSDE_ACT_TANH | _SOFTPLUS | _SILU; final TSDE_FINAL_NONE | _SIGMOID | _TANH; 0 <= n_mid <= 2. */
+typedef struct tsde_deep_mlp {
+  const void* w1;
+  const void* w1t;
+  const void* b1;
+  const void* wm[2];
+  const void* bm[2];
+  const void* w2;
+  const void* b2;
+  int32_t hidden;
+  int32_t out;
+  int32_t activation;
+  int32_t final;
+  int32_t n_mid;
+  int32_t reserved;
+  double scale;
+  double act_scale;
+} tsde_deep_mlp_t;
+
+/* ys (n_out, rows, d): the state at the outputs of traj (out_step / out_w as for the trajectory kernels); z_out (rows, d) or
+ * NULL: the scheme's second state after the last step (what the backward call starts from; reversible_heun.py:73). times
+ * (n_steps + 1): the step boundaries t_0 ... t_K in the state dtype -- the nets are evaluated at exactly these. noise as for
+ * tsde_trajectory_mlp_general (general: 1 <= m <= 16; increments of the (rows, m) field). 1 <= d <= 64, hidden sizes <= 64,
+ * weights must fit the LDS (tsde_rheun_mlp_lds: bytes, 0 = no kernel). dtype TSDE_F32; ys, z_out, y0 16-byte aligned when d is a
+ * multiple of 4. */
+int tsde_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                           const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj,
+                           const void* times, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                           void* stream);
+int64_t tsde_rheun_mlp_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden, int64_t diffusion_out,
+                           int noise, int drift_mid, int diffusion_mid);
+
+/* The carried state of the backward sweep, (rows, d) each, read and written by every call:
+ *   y    before the first call: the last output; between calls: the state's running reconstruction
+ *   z    before the first call: z_out of the forward launch
+ *   a_y  before the first call: the last output's cotangent; after the call that reaches evaluation 0: dL/dy0
+ *   a_z, a_f, p   zero before the first call (p: the vector of the rank-one a_g = p (x) dW, reversible_heun.py:137) */
+typedef struct tsde_rheun_state {
+  void* y;
+  void* z;
+  void* a_y;
+  void* a_z;
+  void* a_f;
+  void* p;
+} tsde_rheun_state_t;
+
+/* What the parameter gradients are formed from: per evaluation e = j_hi - j of the call and row, (n_eval, rows, stride)
+ * arrays (any may be NULL; strides are multiples of 4 floats >= the width):
+ *   z (stride_d)            the point of evaluation            cf (stride_d)  cotangent of the drift net's output BEFORE `final`
+ *   hf[l], df[l] (stride_hf) layer l's activations and the cotangent of its pre-activations, drift net (l = 0 .. n_mid)
+ *   hg[l], dg[l] (stride_hg) the same for the diffusion net
+ *   general noise: p, q (stride_d), wa, wb (stride_m): the cotangent of the diffusion net's final output is
+ *                  p (x) wa + q (x) wb  (wa, wb: the two increments, scaled by the net's `scale`)
+ *   diagonal / scalar noise: p (stride_d) holds the cotangent of the diffusion net's output BEFORE `final`; q, wa, wb unused
+ * => dL/dW2 = sum h_top^T c, dL/dWm[l] = sum h[l]^T d[l+1], dL/dW1 = sum z^T d[0], dL/dw1t = sum t_j d[0], biases: column sums. */
+typedef struct tsde_rheun_stash {
+  void* z;
+  void* cf;
+  void* p;
+  void* q;
+  void* wa;
+  void* wb;
+  void* hf[3];
+  void* df[3];
+  void* hg[3];
+  void* dg[3];
+  int32_t stride_d;
+  int32_t stride_m;
+  int32_t stride_hf;
+  int32_t stride_hg;
+} tsde_rheun_stash_t;
+
+/* Evaluations j_hi, j_hi - 1, ..., j_lo of the backward sweep (0 <= j_lo <= j_hi <= n_steps; call on consecutive ranges, the
+ * first with j_hi = n_steps). ys_all (n_out + 1, rows, d): y0 followed by the forward outputs -- every output must sit ON a
+ * step boundary (out_w = (0, 1)); grad_ys the same shape: their cotangents. At an output boundary the state is reset to the
+ * stored one and its cotangent joins a_y (adjoint.py:114-116). */
+int tsde_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde_rheun_stash_t* stash, const void* ys_all,
+                            const void* grad_ys, int64_t rows, int64_t d, int64_t m, int noise,
+                            const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj,
+                            const void* times, int32_t j_hi, int32_t j_lo, uint64_t entropy, uint64_t elem0,
+                            const uint64_t* entropy_dev, int dtype, void* stream);
+
 /* partials[i] = sum over the i-th contiguous range of the k rows of a[row, :m]^T b[row, :n]   (a, b row-major with
  * row strides lda >= m, ldb >= n floats -- column blocks of wider matrices are served in place --, m, n <= 128;
  * partials (blocks, m, n)) and, if colsum_partials (blocks, m) is not NULL, the column sums of a over the same range: the weight- and bias-gradient sums of the call above -- a product with a 128 x 128 result
@@ -654,6 +747,7 @@ int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int
 #define TSDE_KID_MLP_ADJOINT 10
 #define TSDE_KID_MILSTEIN_GF_GENERAL 11
 #define TSDE_KID_STEP_SHARED 12
+#define TSDE_KID_RHEUN_MLP 13
 /* Start timing every launch of kernel family `kid` (at most `capacity` launches). Families 1-6 and 11 are timed PER
  * DISPATCH: the launch is issued with hipExtLaunchKernel and the two events are bound to that dispatch, so their elapsed
  * time is the kernel's own start-to-end interval (what a rocprofv3 kernel trace reports) with no marker packets on the

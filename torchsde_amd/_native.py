@@ -14,11 +14,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtorchsde_amd.so")
 F32, F64 = 0, 1
 KID_STEP_DIAG, KID_STEP_GENERAL, KID_MILSTEIN_DIAG, KID_SRK_STAGE, KID_AUG_UPDATE, KID_BROWNIAN_QUERY = 1, 2, 3, 4, 5, 6
 KID_RHEUN, KID_TRAJECTORY, KID_MLP_BACKWARD, KID_MLP_ADJOINT = 7, 8, 9, 10
+KID_RHEUN_MLP = 13
 ERROR_NORM_WORKSPACE = 1024
 TRAJ_SENS = 5
-ACT_TANH, ACT_SOFTPLUS = 0, 1
+ACT_TANH, ACT_SOFTPLUS, ACT_SILU = 0, 1, 2
 DIFF_AFFINE, DIFF_SIGMOID = 0, 1
-FINAL_NONE, FINAL_SIGMOID = 0, 1
+FINAL_NONE, FINAL_SIGMOID, FINAL_TANH = 0, 1, 2
 PRECISION_F32, PRECISION_BF16X3 = 0, 1
 NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL, NOISE_ADDITIVE = 0, 1, 2, 3
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK, TRAJ_HEUN, TRAJ_EULER_HEUN = 0, 1, 2, 3, 4, 5, 6
@@ -71,6 +72,25 @@ class Mlp(ctypes.Structure):
     _fields_ = [("w1", _c_ptr), ("w1t", _c_ptr), ("b1", _c_ptr), ("w2", _c_ptr), ("b2", _c_ptr), ("hidden", _c_i32),
                 ("out", _c_i32), ("activation", _c_i32), ("final", _c_i32), ("scale", _c_dbl), ("precision", _c_i32),
                 ("reserved", _c_i32)]
+
+
+class DeepMlp(ctypes.Structure):
+    """``tsde_deep_mlp_t``."""
+    _fields_ = [("w1", _c_ptr), ("w1t", _c_ptr), ("b1", _c_ptr), ("wm", _c_ptr * 2), ("bm", _c_ptr * 2), ("w2", _c_ptr),
+                ("b2", _c_ptr), ("hidden", _c_i32), ("out", _c_i32), ("activation", _c_i32), ("final", _c_i32),
+                ("n_mid", _c_i32), ("reserved", _c_i32), ("scale", _c_dbl), ("act_scale", _c_dbl)]
+
+
+class RheunState(ctypes.Structure):
+    """``tsde_rheun_state_t``."""
+    _fields_ = [("y", _c_ptr), ("z", _c_ptr), ("a_y", _c_ptr), ("a_z", _c_ptr), ("a_f", _c_ptr), ("p", _c_ptr)]
+
+
+class RheunStash(ctypes.Structure):
+    """``tsde_rheun_stash_t``."""
+    _fields_ = [("z", _c_ptr), ("cf", _c_ptr), ("p", _c_ptr), ("q", _c_ptr), ("wa", _c_ptr), ("wb", _c_ptr),
+                ("hf", _c_ptr * 3), ("df", _c_ptr * 3), ("hg", _c_ptr * 3), ("dg", _c_ptr * 3),
+                ("stride_d", _c_i32), ("stride_m", _c_i32), ("stride_hf", _c_i32), ("stride_hg", _c_i32)]
 
 
 _PTR4 = _c_ptr * 4
@@ -165,6 +185,13 @@ SIGNATURES = {
     "tsde_adjoint_mlp_diag": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,
                                        _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_dbl, _c_int, _c_int,
                                        ctypes.POINTER(Traj), _c_i32, _c_i32, _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_rheun_mlp_forward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(DeepMlp),
+                                        ctypes.POINTER(DeepMlp), ctypes.POINTER(Traj), _c_ptr, _c_u64, _c_u64, _c_ptr, _c_int,
+                                        _c_ptr]),
+    "tsde_rheun_mlp_lds": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int]),
+    "tsde_rheun_mlp_backward": (_c_int, [ctypes.POINTER(RheunState), ctypes.POINTER(RheunStash), _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                         _c_i64, _c_int, ctypes.POINTER(DeepMlp), ctypes.POINTER(DeepMlp),
+                                         ctypes.POINTER(Traj), _c_ptr, _c_i32, _c_i32, _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_adaptive_begin": (_c_int, [_c_ptr, _c_ptr, _c_dbl, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
     "tsde_adaptive_control": (_c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),

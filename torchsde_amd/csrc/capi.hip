@@ -847,6 +847,102 @@ int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int
               where);
 }
 
+static const char* deep_mlp_problem(const tsde_deep_mlp_t* n, int64_t d, int64_t out, const char* which) {
+  static thread_local char msg[160];
+  const char* what = nullptr;
+  if (!n) what = "null";
+  else if (!n->w1 || !n->b1 || !n->w2 || !n->b2) what = "a perceptron without weights or biases";
+  else if (n->hidden < 1 || n->hidden > 64) what = "hidden sizes must be in [1, 64]";
+  else if (n->n_mid < 0 || n->n_mid > 2) what = "0 to 2 hidden-to-hidden layers";
+  else if ((n->n_mid > 0 && (!n->wm[0] || !n->bm[0])) || (n->n_mid > 1 && (!n->wm[1] || !n->bm[1])))
+    what = "a hidden-to-hidden layer without weights or biases";
+  else if (n->activation != TSDE_ACT_TANH && n->activation != TSDE_ACT_SOFTPLUS && n->activation != TSDE_ACT_SILU)
+    what = "unknown activation";
+  else if (n->final != TSDE_FINAL_NONE && n->final != TSDE_FINAL_SIGMOID && n->final != TSDE_FINAL_TANH)
+    what = "unknown output function";
+  else if (n->out != out) what = "wrong number of outputs";
+  if (!what) return nullptr;
+  snprintf(msg, sizeof(msg), "%s net: %s", which, what);
+  (void)d;
+  return msg;
+}
+
+static const char* rheun_mlp_problem(int64_t rows, int64_t d, int64_t m, int noise, const tsde_deep_mlp_t* drift,
+                                     const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj, const void* times, int dtype) {
+  if (!drift || !diffusion || !traj || !times) return "null argument";
+  if (dtype != TSDE_F32) return "dtype must be TSDE_F32";
+  if (rows < 0) return "need rows >= 0";
+  if (d < 1 || d > 64) return "need d in [1, 64]";
+  int64_t out = d;
+  if (noise == TSDE_NOISE_GENERAL) {
+    if (m < 1 || m > 16) return "general noise: m must be in [1, 16]";
+    out = d * m;
+  } else if (noise == TSDE_NOISE_DIAGONAL || noise == TSDE_NOISE_SCALAR) {
+    if (m != (noise == TSDE_NOISE_DIAGONAL ? d : 1)) return "m must be d (diagonal) or 1 (scalar)";
+  } else {
+    return "unknown noise kind";
+  }
+  if (const char* bad = deep_mlp_problem(drift, d, d, "drift")) return bad;
+  if (const char* bad = deep_mlp_problem(diffusion, d, out, "diffusion")) return bad;
+  if (tsde::rheun_footprint(d, m, drift->hidden, diffusion->hidden, diffusion->out, noise, drift->n_mid, diffusion->n_mid) == 0)
+    return "no kernel for this shape";
+  if (rows * d >= (int64_t(1) << 30)) return "need rows * d < 2^30 (32-bit lane offsets)";
+  if (traj->n_steps < 0 || traj->n_out < 0) return "negative schedule length";
+  if (traj->n_steps > 0 && (!traj->step_rows || !traj->cells)) return "schedule without step rows";
+  if (traj->n_out > 0 && (!traj->out_step || !traj->out_w)) return "schedule without output map";
+  return nullptr;
+}
+
+int tsde_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                           const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj,
+                           const void* times, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                           void* stream) {
+  const char* where = "tsde_rheun_mlp_forward";
+  if (!ys || !y0) return bad_arg(where, "null argument");
+  if (const char* bad = rheun_mlp_problem(rows, d, m, noise, drift, diffusion, traj, times, dtype)) return bad_arg(where, bad);
+  const uintptr_t mask = d % 4 == 0 ? 15u : 3u;
+  if (((reinterpret_cast<uintptr_t>(y0) | reinterpret_cast<uintptr_t>(ys) | reinterpret_cast<uintptr_t>(z_out)) & mask) != 0)
+    return bad_arg(where, "ys, z_out and y0 must be 16-byte aligned (4-byte when d is not a multiple of 4)");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_RHEUN_MLP, s, true);
+  const hipError_t e = tsde::launch_rheun_mlp_forward(ys, z_out, y0, rows, d, m, noise, drift, diffusion, traj, times,
+                                                      make_key(entropy, elem0), entropy_dev, s);
+  if (e == hipErrorInvalidValue) return bad_arg(where, "the weights of this shape do not fit the LDS of a CU");
+  return fail(e, where);
+}
+
+int64_t tsde_rheun_mlp_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden, int64_t diffusion_out,
+                           int noise, int drift_mid, int diffusion_mid) {
+  return (int64_t)tsde::rheun_footprint(d, m, drift_hidden, diffusion_hidden, diffusion_out, noise, drift_mid, diffusion_mid);
+}
+
+int tsde_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde_rheun_stash_t* stash, const void* ys_all,
+                            const void* grad_ys, int64_t rows, int64_t d, int64_t m, int noise,
+                            const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj,
+                            const void* times, int32_t j_hi, int32_t j_lo, uint64_t entropy, uint64_t elem0,
+                            const uint64_t* entropy_dev, int dtype, void* stream) {
+  const char* where = "tsde_rheun_mlp_backward";
+  if (!state || !stash || !ys_all || !grad_ys) return bad_arg(where, "null argument");
+  if (!state->y || !state->z || !state->a_y || !state->a_z || !state->a_f || !state->p) return bad_arg(where, "null state buffer");
+  if (const char* bad = rheun_mlp_problem(rows, d, m, noise, drift, diffusion, traj, times, dtype)) return bad_arg(where, bad);
+  if (j_lo < 0 || j_hi < j_lo || j_hi > traj->n_steps) return bad_arg(where, "need 0 <= j_lo <= j_hi <= n_steps");
+  for (int i = 0; i < traj->n_out; ++i) {
+    (void)i;      // (the output map lives on the device: that every output sits on a step boundary is the caller's contract)
+  }
+  if ((stash->stride_d | stash->stride_m | stash->stride_hf | stash->stride_hg) & 3) return bad_arg(where, "stash strides must be multiples of 4");
+  const void* aligned[] = {state->y, state->z, state->a_y, state->a_z, state->a_f, state->p, ys_all, grad_ys, stash->z, stash->cf,
+                           stash->p, stash->q, stash->wa, stash->wb};
+  const uintptr_t mask = d % 4 == 0 ? 15u : 3u;
+  for (const void* q : aligned)
+    if (reinterpret_cast<uintptr_t>(q) & mask) return bad_arg(where, "state-shaped buffers must be 16-byte aligned");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope p(TSDE_KID_RHEUN_MLP, s, true);
+  const hipError_t e = tsde::launch_rheun_mlp_backward(state, stash, ys_all, grad_ys, rows, d, m, noise, drift, diffusion, traj,
+                                                       times, j_hi, j_lo, make_key(entropy, elem0), entropy_dev, s);
+  if (e == hipErrorInvalidValue) return bad_arg(where, "the weights of this shape do not fit the LDS of a CU");
+  return fail(e, where);
+}
+
 int tsde_prof_begin(int kid, int capacity) {
   if (capacity <= 0) return bad_arg("tsde_prof_begin", "capacity must be positive");
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);

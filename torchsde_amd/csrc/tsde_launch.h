@@ -167,4 +167,14 @@ hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, in
                                 int64_t K, int64_t M, int64_t N, int32_t blocks, hipStream_t s);
 // graph_nodes.hip: memset nodes of a captured, not yet instantiated graph -> fill-kernel nodes with the same edges
 hipError_t memset_nodes_to_kernels(hipGraph_t graph, int* n_memset, int* n_replaced);
+// neural_rheun.hip
+hipError_t launch_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                                    const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* tr,
+                                    const void* times, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
+hipError_t launch_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde_rheun_stash_t* stash, const void* ys_all,
+                                     const void* grad_ys, int64_t rows, int64_t d, int64_t m, int noise,
+                                     const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* tr,
+                                     const void* times, int j_hi, int j_lo, NoiseKey key, const uint64_t* key_dev,
+                                     hipStream_t s);
+size_t rheun_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t out, int noise, int nmf, int nmg);
 }  // namespace tsde
