@@ -164,8 +164,12 @@ def test_perceptron_drift_hands_back_the_users_own_parameters():
         recognise.recognise(ForwardSDE(Residual(8)), torch.tensor(0.0), y)
     deep = problems.LatentDiag(8)
     deep.net = nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8))
+    # a three-layer drift is FOLLOWED (its middle layer kept: the reversible-Heun kernels take such nets, recognise.deep_spec) --
+    # but the two-layer perceptron-drift kernels do not evaluate it
+    found = recognise.recognise(ForwardSDE(deep), torch.tensor(0.0), y)
+    assert found.perceptron and len(found.f.mids) == 1 and found.f.mids[0][0] is deep.net[2].weight and not found.f.classic()
     with pytest.raises(recognise.NotElementwise):
-        recognise.recognise(ForwardSDE(deep), torch.tensor(0.0), y)
+        found.spec()
     # a drift net that takes t (`cat([t, y])`, like the reference's NeuralDiagonal) beside an ELEMENTWISE diffusion: followed,
     # but neither kernel family evaluates it (the perceptron-drift kernels have no time input, the neural-SDE kernel wants
     # a diffusion net)
@@ -790,3 +794,80 @@ def test_clamp_is_refused_when_gradients_flow():
     assert recognise.recognise_program(sde, t, y0, "diagonal") is not None
     with pytest.raises(recognise.NotElementwise, match="clamp"):
         recognise.recognise_program(sde, t, y0, "diagonal", differentiable=True)
+
+
+# ---- deeper networks, LipSwish, closing tanh: the generator of the reference's examples/sde_gan.py -----------------------------
+class _LipSwish(nn.Module):
+    def forward(self, x):
+        return 0.909 * F.silu(x)
+
+
+def _sde_gan_mlp(in_size, out_size, mlp_size, num_layers, tanh):
+    """examples/sde_gan.py:50-66 (restated: the layer list of its MLP)."""
+    model = [nn.Linear(in_size, mlp_size), _LipSwish()]
+    for _ in range(num_layers - 1):
+        model += [nn.Linear(mlp_size, mlp_size), _LipSwish()]
+    model.append(nn.Linear(mlp_size, out_size))
+    if tanh:
+        model.append(nn.Tanh())
+    return nn.Sequential(*model)
+
+
+class _GeneratorFunc(nn.Module):
+    """examples/sde_gan.py:77-101: Stratonovich, general noise, drift and diffusion MLPs of cat([t, x])."""
+    sde_type, noise_type = "stratonovich", "general"
+
+    def __init__(self, noise_size, hidden_size, mlp_size, num_layers):
+        super().__init__()
+        self._noise_size, self._hidden_size = noise_size, hidden_size
+        self._drift = _sde_gan_mlp(1 + hidden_size, hidden_size, mlp_size, num_layers, tanh=True)
+        self._diffusion = _sde_gan_mlp(1 + hidden_size, hidden_size * noise_size, mlp_size, num_layers, tanh=True)
+
+    def f_and_g(self, t, x):
+        t = t.expand(x.size(0), 1)
+        tx = torch.cat([t, x], dim=1)
+        return self._drift(tx), self._diffusion(tx).view(x.size(0), self._hidden_size, self._noise_size)
+
+
+@pytest.mark.parametrize("num_layers", [1, 2, 3])
+def test_the_sde_gan_generator_is_followed_at_every_depth(num_layers):
+    sde = _GeneratorFunc(3, 16, 16, num_layers)
+    y = torch.randn(12, 16)
+    found = recognise.recognise(ForwardSDE(sde), torch.tensor(0.3), y, differentiable=True)
+    assert found.neural
+    for net, module in ((found.f, sde._drift), (found.g, sde._diffusion)):
+        linears = [m for m in module if isinstance(m, nn.Linear)]
+        assert net.act == "silu" and net.act_scale == 0.909 and net.final == "tanh" and net.wt is not None
+        assert net.w_full is linears[0].weight and net.b1 is linears[0].bias
+        assert [w for w, _ in net.mids] == [m.weight for m in linears[1:-1]] or all(
+            a is b.weight for (a, _), b in zip(net.mids, linears[1:-1]))
+        assert net.w2 is linears[-1].weight and net.b2 is linears[-1].bias
+        assert not net.classic()
+    assert found.g.shape == (2, 16, 3)
+    with pytest.raises(recognise.NotElementwise, match="deeper than two layers"):
+        found.neural_spec("general")             # (the Euler / midpoint kernel does not take it)
+
+
+def test_hidden_layers_must_share_activation_width_and_factor():
+    class Mixed(nn.Module):
+        sde_type, noise_type = "stratonovich", "diagonal"
+
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+            self.g_net = nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8))
+
+        def f(self, t, y):
+            return self.net(y)
+
+        def g(self, t, y):
+            return self.g_net(y)
+    y = torch.randn(12, 8)
+    for net in (nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8), nn.Softplus(), nn.Linear(8, 8)),
+                nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 12), nn.Tanh(), nn.Linear(12, 8)),
+                nn.Sequential(nn.Linear(8, 8), _LipSwish(), nn.Linear(8, 8), nn.SiLU(), nn.Linear(8, 8))):
+        with pytest.raises(recognise.NotElementwise):
+            recognise.recognise(ForwardSDE(Mixed(net)), torch.tensor(0.0), y)
+    ok = nn.Sequential(nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8), nn.Tanh(), nn.Linear(8, 8))
+    found = recognise.recognise(ForwardSDE(Mixed(ok)), torch.tensor(0.0), y)
+    assert len(found.f.mids) == 2 and found.f.final is None

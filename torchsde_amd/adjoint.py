@@ -825,6 +825,19 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
                                adjoint_options, adjoint_params, extra_solver_state, solver=solver)
         if ys is not None:
             return contract.parse_return(y0, ys, (), extra, logqp)
+    # the reversible pair on networks of (t, y): forward one launch, backward the exact-gradient sweep on the matrix cores
+    # (neural_rheun.py). The first solve of a form runs both routes and compares values AND gradients (below).
+    kernels_route = None
+    if (method == METHODS.reversible_heun and adjoint_method == METHODS.adjoint_reversible_heun and torch.is_grad_enabled()
+            and (y0.requires_grad or adjoint_params) and not extra and not logqp and extra_solver_state is None
+            and not adaptive and not adjoint_adaptive and adjoint_options.get("trajectory_kernel", True)
+            and y0.numel() > 0):
+        from . import neural_rheun_route
+        kernels_route = neural_rheun_route.plan_adjoint(solver, sde, y0, ts, bm, dt, adjoint_params)
+        if kernels_route is not None and kernels_route.trusted:
+            return contract.parse_return(y0, kernels_route.solve(y0), (), extra, logqp)
+    if hasattr(solver, "wants_extra"):
+        solver.wants_extra = True        # (the autograd function below carries the solver's final (f, g, z) to its backward)
     if extra_solver_state is None:
         extra_solver_state = solver.init_extra_solver_state(ts[0], y0)
     if y0.numel() == 0:      # an empty batch: nothing to launch, and no trajectory for a gradient to come from
@@ -834,6 +847,10 @@ def _sdeint_adjoint(sde, y0, ts, bm, method, adjoint_method, dt, adaptive, adjoi
     ys, *extra_solver_state = _SdeintAdjointMethod.apply(
         sde, ts, dt, bm, solver, method, adjoint_method, adjoint_adaptive, adjoint_rtol, adjoint_atol, dt_min,
         adjoint_options, len(extra_solver_state), y0, *extra_solver_state, *adjoint_params)
+    if kernels_route is not None:
+        # the verifying solve: the stepwise pair's result is what is returned; the kernels must reproduce its values and, for
+        # one random cotangent, its gradients with respect to y0 and every adjoint parameter
+        kernels_route.record(kernels_route.solve(y0), ys, y0, extra_inputs=adjoint_params)
     from . import graph
     graph_mode = graph.mode_of(adjoint_options)
     # (the parameter gradients of a sweep are sums over the batch; above ~1000 rows torch computes them with multi-block

@@ -31,6 +31,8 @@ def _sdeint(sde, y0, ts, bm, method, dt, adaptive, rtol, atol, dt_min, options, 
     solver_cls = solvers.select(method=method, sde_type=sde.sde_type)
     solver = solver_cls(sde=sde, bm=bm, dt=dt, adaptive=adaptive, rtol=rtol, atol=atol, dt_min=dt_min,
                         options=options)
+    if hasattr(solver, "wants_extra"):
+        solver.wants_extra = bool(extra)
     if extra_solver_state is None:
         extra_solver_state = solver.init_extra_solver_state(ts[0], y0)
     if y0.numel() == 0:      # an empty batch: nothing to launch (the reference's loop runs on empty tensors)

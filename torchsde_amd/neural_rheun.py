@@ -244,7 +244,7 @@ class ReversibleHeunFn(torch.autograd.Function):
     exact-gradient sweep of the reversible pair on the matrix cores, nothing of the trajectory stored."""
 
     @staticmethod
-    def forward(ctx, drift, diffusion, noise, m, schedule, times, times_host, bm, y0, *tensors):
+    def forward(ctx, drift, diffusion, noise, m, schedule, times, z_holder, bm, y0, *tensors):
         rows, d = y0.shape
         nf = len(drift.parameters())
         f_net, g_net = drift.rebuilt(tensors[:nf]), diffusion.rebuilt(tensors[nf:])
@@ -256,8 +256,9 @@ class ReversibleHeunFn(torch.autograd.Function):
         z_last = torch.empty_like(y0c)
         forward(ys[1:], z_last, y0c, f_net, g_net, noise, m, schedule, times, bm)
         ctx.save_for_backward(ys, z_last, *tensors)
-        ctx.nets, ctx.noise, ctx.m, ctx.schedule, ctx.times, ctx.times_host, ctx.bm = (drift, diffusion), noise, m, schedule, \
-            times, times_host, bm
+        ctx.nets, ctx.noise, ctx.m, ctx.schedule, ctx.times, ctx.bm = (drift, diffusion), noise, m, schedule, times, bm
+        if z_holder is not None:
+            z_holder.append(z_last)        # (the scheme's second state after the last step: `extra=True` callers)
         return ys
 
     @staticmethod
@@ -329,9 +330,25 @@ def _net_gradients_but_last(net, acc, z, t_eval, hid, delta, d):
             k += 1
 
 
-def solve(y0, drift, diffusion, noise, m, schedule, times_host, bm):
+_times_on_device = {}
+
+
+def _device_times(times_host, device):
+    """The step boundaries on the device, remembered by content (every iteration of a training loop has the same grid)."""
+    host = np.ascontiguousarray(times_host, dtype=np.float32)
+    key = (host.tobytes(), str(device))
+    hit = _times_on_device.get(key)
+    if hit is None:
+        if len(_times_on_device) >= 16:
+            _times_on_device.clear()
+        hit = _times_on_device[key] = torch.from_numpy(host.copy()).to(device)
+    return hit
+
+
+def solve(y0, drift, diffusion, noise, m, schedule, times_host, bm, z_holder=None):
     """ys (n_out + 1, rows, d) of reversible Heun through the kernels, differentiable with respect to y0 and the nets' tensors.
-    `times_host`: the n_steps + 1 step boundaries (numpy, in the state dtype)."""
-    times = torch.from_numpy(np.ascontiguousarray(times_host, dtype=np.float32)).to(y0.device)
+    `times_host`: the n_steps + 1 step boundaries (numpy, in the state dtype). `z_holder`: a list that receives the scheme's
+    second state after the last step."""
+    times = _device_times(times_host, y0.device)
     tensors = drift.parameters() + diffusion.parameters()
-    return ReversibleHeunFn.apply(drift, diffusion, int(noise), int(m), schedule, times, times_host, bm, y0, *tensors)
+    return ReversibleHeunFn.apply(drift, diffusion, int(noise), int(m), schedule, times, z_holder, bm, y0, *tensors)

@@ -77,22 +77,35 @@ ZERO = object()         # the rate of a y-independent value
 
 class _Hidden:
     """``act(x @ W1^T + b1)`` (act None: before the activation): a (rows, hidden) value of a perceptron. `x` is the state,
-    or ``cat([t.expand(rows, 1), y], 1)``: then `wt` is the weight column of the time input and `w1` the state columns."""
-    __slots__ = ("w1", "b1", "act", "wt")
+    or ``cat([t.expand(rows, 1), y], 1)``: then `wt` is the weight column of the time input and `w1` the state columns.
+    `mids`: the (weight, bias) of hidden-to-hidden layers already passed (deeper nets: examples/sde_gan.py:50-66,
+    examples/latent_sde_lorenz.py:122-135); `act_scale`: a numeric factor after the activation (LipSwish = 0.909 * silu,
+    examples/sde_gan.py:44-47); `w_full`: the first layer's weight as the user's module holds it (time column included)."""
+    __slots__ = ("w1", "b1", "act", "wt", "mids", "act_scale", "w_full")
 
-    def __init__(self, w1, b1, act=None, wt=None):
+    def __init__(self, w1, b1, act=None, wt=None, mids=(), act_scale=1.0, w_full=None):
         self.w1, self.b1, self.act, self.wt = w1, b1, act, wt
+        self.mids, self.act_scale, self.w_full = tuple(mids), float(act_scale), (w1 if w_full is None else w_full)
+
+    def but(self, **changes):
+        new = object.__new__(_Hidden)
+        for slot in self.__slots__:
+            setattr(new, slot, changes.get(slot, getattr(self, slot)))
+        return new
 
 
 class _Perceptron:
-    """``scale * final(act(x @ W1^T + b1) @ W2^T + b2)``: weights as the (out, in) tensors `nn.Linear` holds; `wt` as in
-    `_Hidden`; `final` None or "sigmoid" (``nn.Sigmoid()`` closing a diffusion net); `scale` a Python number; `shape` the
-    shape the user's code gave the result (``.view(B, d, m)``)."""
-    __slots__ = ("w1", "b1", "act", "w2", "b2", "exact", "wt", "final", "scale", "shape")
+    """``scale * final(act(... act(x @ W1^T + b1) ...) @ W2^T + b2)``: weights as the (out, in) tensors `nn.Linear` holds; `wt`
+    as in `_Hidden`; `final` None, or the function applied to the last layer's output ("sigmoid": ``nn.Sigmoid()`` closing a
+    diffusion net; "tanh": ``MLP(..., tanh=True)``, examples/sde_gan.py:63-64 -- or an activation whose Linear is yet to come);
+    `scale` a Python number; `shape` the shape the user's code gave the result (``.view(B, d, m)``); `mids`, `act_scale`,
+    `w_full` as in `_Hidden`."""
+    __slots__ = ("w1", "b1", "act", "w2", "b2", "exact", "wt", "final", "scale", "shape", "mids", "act_scale", "w_full")
     phi = "perceptron"
 
     def __init__(self, hidden, w2, b2, shape):
         self.w1, self.b1, self.act, self.wt = hidden.w1, hidden.b1, hidden.act, hidden.wt
+        self.mids, self.act_scale, self.w_full = hidden.mids, hidden.act_scale, hidden.w_full
         self.w2, self.b2, self.exact, self.final, self.scale, self.shape = w2, b2, False, None, 1.0, tuple(shape)
 
     @property
@@ -105,9 +118,19 @@ class _Perceptron:
             setattr(new, slot, changes.get(slot, getattr(self, slot)))
         return new
 
+    def classic(self):
+        """What the two-layer kernels (mlp_trajectory.hip, mlp_general.hip, mlp_adjoint.hip) evaluate: one hidden layer, tanh or
+        softplus, at most a closing sigmoid. Anything deeper or with other functions: the reversible-Heun kernels only."""
+        return (not self.mids and self.act in ("tanh", "softplus") and self.act_scale == 1.0
+                and self.final in (None, "sigmoid"))
+
     def plain(self):
         """The form the diagonal-noise perceptron kernels take: a network of the bare state, nothing after it."""
-        return self.wt is None and self.final is None and self.scale == 1.0
+        return self.wt is None and self.final is None and self.scale == 1.0 and self.classic()
+
+    def as_hidden(self):
+        """This net's output read as one more hidden layer (its pending `final` the activation): what a further Linear acts on."""
+        return _Hidden(self.w1, self.b1, self.act, self.wt, self.mids + ((self.w2, self.b2),), self.act_scale, self.w_full)
 
 
 def _mul(a, b):
@@ -367,6 +390,7 @@ class _Interpreter(TorchDispatchMode):
     def first_layer(self, name, args, out):
         x, w, b = self.layer_operands(name, args)
         wt = None
+        w_full = w
         if torch.is_tensor(x) and id(x) in self.time_state:
             # the first layer of a net that is fed cat([t, y]): column 0 of its weight multiplies t
             if tuple(w.shape)[1:] != (self.d + 1,) or tuple(out.shape) != (self.rows, w.shape[0]):
@@ -379,7 +403,7 @@ class _Interpreter(TorchDispatchMode):
                 raise NotElementwise("a matrix product of something other than the state itself")
             if tuple(w.shape)[1:] != (self.d,) or tuple(out.shape) != (self.rows, w.shape[0]):
                 raise NotElementwise("a matrix product that does not act on the state channels")
-        self.hidden[id(out)] = _Hidden(w, self.bias_of(b, w.shape[0]), wt=wt)
+        self.hidden[id(out)] = _Hidden(w, self.bias_of(b, w.shape[0]), wt=wt, w_full=w_full)
         self.keep.append(out)
         return out
 
@@ -439,11 +463,32 @@ class _Interpreter(TorchDispatchMode):
                 raise NotElementwise("the output of a network times something that is not a plain number")
             out = func(*args, **kwargs)
             return self.register_net(out, net.but(scale=net.scale * float(other)))
+        if name in ("addmm", "mm", "linear"):
+            # one more Linear on what so far looked like a net's output: that output was a hidden layer (depth > 2)
+            x, w, b = self.layer_operands(name, args)
+            net = self.net_of(x)
+            if net is None or self.net_of(w) is not None or (b is not None and self.net_of(b) is not None):
+                raise NotElementwise("a matrix product whose input is not the output of the layer before")
+            if net.final not in ("tanh", "softplus", "silu") or net.final != net.act or net.scale != net.act_scale \
+                    or tuple(net.shape) != (self.rows, net.out) or net.out != net.w1.shape[0]:
+                raise NotElementwise("a further layer after a net's output: hidden layers must share one width, one activation "
+                                     "and one factor")
+            out = func(*args, **kwargs)
+            hidden = net.as_hidden()
+            if tuple(w.shape)[1:] != (net.out,) or tuple(out.shape) != (self.rows, w.shape[0]):
+                raise NotElementwise("a layer that does not act on the hidden units")
+            return self.register_net(out, _Perceptron(hidden, w, self.bias_of(b, w.shape[0]), out.shape))
         if net is None:
             raise NotElementwise(f"{name} applied to the output of the drift network")
         out = func(*args, **kwargs)
-        if name == "sigmoid" and len(args) == 1 and net.final is None and net.scale == 1.0:
-            return self.register_net(out, net.but(final="sigmoid"))
+        if name in ("sigmoid", "tanh", "softplus", "silu") and net.final is None and net.scale == 1.0 \
+                and (len(args) == 1 or name == "softplus"):
+            if name == "softplus":
+                beta = args[1] if len(args) > 1 else kwargs.get("beta", 1)
+                threshold = args[2] if len(args) > 2 else kwargs.get("threshold", 20)
+                if beta != 1 or threshold != 20:
+                    raise NotElementwise("softplus with a non-default beta or threshold")
+            return self.register_net(out, net.but(final=name))
         if name in self._SAME or name in self._RESHAPES:
             if not torch.is_tensor(out) or out.dtype != args[0].dtype or out.device != args[0].device:
                 raise NotElementwise(f"{name} changes the dtype or device of the output of a network")
@@ -457,13 +502,24 @@ class _Interpreter(TorchDispatchMode):
             raise NotElementwise(f"in-place {name} inside the drift network")
         out = func(*args, **kwargs)
         h = self.hidden.get(id(args[0])) if args and torch.is_tensor(args[0]) else None
-        if name in ("tanh", "softplus") and h is not None and h.act is None:
+        if name in ("tanh", "softplus", "silu") and h is not None and h.act is None and len(args) >= 1 \
+                and (name == "softplus" or len(args) == 1):
             if name == "softplus":
                 beta = args[1] if len(args) > 1 else kwargs.get("beta", 1)
                 threshold = args[2] if len(args) > 2 else kwargs.get("threshold", 20)
                 if beta != 1 or threshold != 20:
                     raise NotElementwise("softplus with a non-default beta or threshold")
-            self.hidden[id(out)] = _Hidden(h.w1, h.b1, name, wt=h.wt)
+            self.hidden[id(out)] = h.but(act=name)
+            self.keep.append(out)
+            return out
+        if name == "mul" and len(args) == 2 and (h is not None or self.hidden.get(id(args[1])) is not None):
+            # a numeric factor after a hidden activation (LipSwish: 0.909 * silu(x), examples/sde_gan.py:44-47)
+            hv, other = (h, args[1]) if h is not None else (self.hidden.get(id(args[1])), args[0])
+            if hv.act is None or hv.act_scale != 1.0:
+                raise NotElementwise("a factor inside a network before its activation (or a second one after it)")
+            if torch.is_tensor(other) and (other.dim() != 0 or other.device.type != "cpu" or id(other) in self.time):
+                raise NotElementwise("a hidden layer times something that is not a plain number")
+            self.hidden[id(out)] = hv.but(act_scale=float(other))
             self.keep.append(out)
             return out
         if name in ("addmm", "mm", "linear"):
@@ -1090,8 +1146,8 @@ class RecognisedAdditive:
         self.net, self.program, self.consts = None, None, []
         if isinstance(f, _Perceptron):
             # the drift of the reference's NeuralAdditive (tests/problems.py:203-217): a perceptron of cat([t, y])
-            if dtype != torch.float32 or d > 64:
-                raise NotElementwise("a drift network outside the neural-SDE kernel's shapes (float32, d up to 64)")
+            if dtype != torch.float32 or d > 64 or not f.classic():
+                raise NotElementwise("a drift network outside the neural-SDE kernel's shapes (float32, d up to 64, two layers)")
             if f.out != d or f.final is not None or f.scale != 1.0 or f.shape[1:] != (d,) or f.w1.shape[0] > 128:
                 raise NotElementwise("a drift network that does not map to the state channels (or is wider than 128)")
             if any(t is not None and (t.dtype != torch.float32 or t.device != device) for t in (f.w1, f.b1, f.w2, f.b2, f.wt)):
@@ -1235,7 +1291,8 @@ class Recognised:
         def shape(form):
             if isinstance(form, _Perceptron):
                 return ("perceptron", form.act, tuple(form.w1.shape), form.b1 is None, form.b2 is None, form.out,
-                        form.wt is not None, form.final, form.scale, form.shape[1:])
+                        form.wt is not None, form.final, form.scale, form.shape[1:], len(form.mids), form.act_scale,
+                        tuple(b is None for _, b in form.mids))
             return (form.phi, form.constant()) + tuple(
                 None if c is None else "number" if isinstance(c, (int, float))
                 else "table" if torch.is_tensor(c) and c.dim() == 3 else "tensor"
@@ -1336,6 +1393,9 @@ class Recognised:
         f, g, d = self.f, self.g, self.d
         if self.dtype != torch.float32:
             raise NotElementwise("the neural-SDE kernel is float32")
+        if not (f.classic() and g.classic()):
+            raise NotElementwise("networks deeper than two layers, or with functions other than tanh / softplus (+ closing "
+                                 "sigmoid): the reversible-Heun kernels take those, the Euler / midpoint / SRK kernel does not")
         if f.out != d or f.final is not None or f.shape[1:] != (d,):
             raise NotElementwise("a drift network that does not map to the state channels")
         if noise_type == "diagonal":
@@ -1372,6 +1432,56 @@ class Recognised:
             raise NotElementwise(f"networks outside the neural-SDE kernel's shapes (d = {d}, m = {m}, hidden "
                                  f"{nets[0].hidden} / {nets[1].hidden}: {need} bytes of LDS)")
         return ("neural", nets[0], nets[1], noise, m)
+
+    _DEEP_ACTS = {"tanh": _native.ACT_TANH, "softplus": _native.ACT_SOFTPLUS, "silu": _native.ACT_SILU}
+    _DEEP_FINALS = {None: _native.FINAL_NONE, "sigmoid": _native.FINAL_SIGMOID, "tanh": _native.FINAL_TANH}
+
+    def deep_spec(self, noise_type):
+        """("neural_rheun", drift DeepNet, diffusion DeepNet, noise code, m): what the reversible-Heun kernels take
+        (neural_rheun.py) -- perceptrons of two to four Linear layers, tanh / softplus / (a factor times) silu between them, an
+        optional closing sigmoid or tanh and a numeric factor: the reference's Neural* problems AND the generator of
+        examples/sde_gan.py:50-66,77-101. The DeepNets hold the USER's own tensors (`nn.Linear.weight` as it stands, time column
+        included), so that the backward kernels' gradients land on them."""
+        from . import neural_rheun
+        f, g, d = self.f, self.g, self.d
+        if not self.neural:
+            raise NotElementwise("drift and diffusion are not both networks")
+        if self.dtype != torch.float32:
+            raise NotElementwise("the reversible-Heun kernels are float32")
+        if f.out != d or f.shape[1:] != (d,):
+            raise NotElementwise("a drift network that does not map to the state channels")
+        if noise_type == "diagonal":
+            want, m = (d,), d
+        elif noise_type == "scalar":
+            want, m = (d, 1), 1
+        elif noise_type == "general":
+            if len(g.shape) != 3 or g.shape[1] != d:
+                raise NotElementwise(f"a general-noise diffusion of shape {g.shape}")
+            want, m = (d, g.shape[2]), g.shape[2]
+        else:
+            raise NotElementwise(f"{noise_type} noise")
+        if g.shape[1:] != want or g.out != (d if noise_type != "general" else d * m):
+            raise NotElementwise(f"a diffusion network of shape {g.shape} for {noise_type} noise")
+        nets = []
+        for net in (f, g):
+            if net.final not in self._DEEP_FINALS:
+                raise NotElementwise(f"a network closed by {net.final}")
+            if len(net.mids) > neural_rheun.MAX_MID:
+                raise NotElementwise(f"a network of more than {neural_rheun.MAX_MID + 2} Linear layers")
+            linears = [(net.w_full, net.b1)] + list(net.mids) + [(net.w2, net.b2)]
+            if any(t is not None and (t.dtype != torch.float32 or t.device != self.device) for pair in linears for t in pair):
+                raise NotElementwise("network weights of another dtype or device than the state")
+            if any(tuple(w.shape) != (net.w1.shape[0], net.w1.shape[0]) for w, _ in net.mids):
+                raise NotElementwise("hidden layers of different widths")
+            nets.append(neural_rheun.DeepNet(linears, self._DEEP_ACTS[net.act], net.act_scale, self._DEEP_FINALS[net.final],
+                                             float(net.scale), time_input=net.wt is not None))
+        noise = self._NOISE_CODES[noise_type]
+        need = neural_rheun.lds_bytes(d, m, nets[0], nets[1], noise)
+        if need <= 0 or need > 160 * 1024:
+            raise NotElementwise(f"networks outside the reversible-Heun kernels' shapes (d = {d}, m = {m}, hidden "
+                                 f"{nets[0].hidden} / {nets[1].hidden}, {nets[0].n_mid + 2} / {nets[1].n_mid + 2} layers: "
+                                 f"{need} bytes of LDS)")
+        return ("neural_rheun", nets[0], nets[1], noise, m)
 
     def perceptron_parameters(self):
         """(lin1.weight, lin1.bias, lin2.weight, lin2.bias, rate, shift) as the tensors the user's module holds -- what
