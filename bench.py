@@ -91,7 +91,11 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "c5_adjoint_latent_default_route_b32768_d128_s500", "c5_adjoint_latent_defaults_default_route_b32768_d128_s500",
         # SURVEY 8(f) rows, measured on the routes they have
         "c5_rheun_adjoint_latent_b32768_d128_s500", "c5_logqp_adjoint_latent_b32768_d128_s500",
-        "c3_log_ode_general_b16384_d32_m16")
+        "c3_log_ode_general_b16384_d32_m16",
+        # the reversible pair on the matrix cores, beside its stepwise twins
+        "sdegan_rheun_adjoint_default_route_b1024_d16_m3_s63", "sdegan_rheun_adjoint_b1024_d16_m3_s63",
+        "c3_rheun_general_default_route_b16384_d32_m16", "c3_rheun_general_b16384_d32_m16",
+        "c3_rheun_adjoint_general_default_route_b16384_d32_m16", "c3_rheun_adjoint_general_b16384_d32_m16")
 
 
 def csrc_digest():
@@ -201,9 +205,12 @@ class Job:
         self.sde = _make_problem(c["problem"], c["d"], c["m"], dev)
         self.y0 = torch.full((c["B"], c["d"]), 0.1, device=dev, requires_grad=self.adjoint or self.train)
         self.ts = torch.tensor([0.0, c["nsteps"] * c["dt"]], device=dev)
+        if c.get("output_every_step"):      # (examples/sde_gan.py: an output at every step of the grid)
+            self.ts = torch.arange(c["nsteps"] + 1, device=dev, dtype=torch.float32) * c["dt"]
         # two gather buffers: the all-gather of solve i runs (on RCCL's stream) while solve i + 1 computes
         self.gathered = [torch.empty((world * c["B"], c["d"]), device=dev) for _ in range(2)] if dist is not None else None
         self._gathers, self._pending = 0, []
+        self._prepared = not c.get("method") == "reversible_heun"       # (the pair's first solve is the verifying one: stepwise)
         self._sdeint, self._sdeint_adjoint = torchsde_amd.sdeint, torchsde_amd.sdeint_adjoint
         self._BM = torchsde_amd.BrownianInterval
 
@@ -230,14 +237,15 @@ class Job:
                         # (ys, log-ratio (T - 1, B)): a latent-SDE user's loss has a term of the path and the KL term
                         states, log_ratio = ys
                         ys = torch.cat([states[-1], log_ratio.sum(0).unsqueeze(-1)], dim=1).unsqueeze(0)
-                    if plain and not type(ys.grad_fn).__name__.startswith("_MlpAdjointFn"):
+                    if plain and not type(ys.grad_fn).__name__.startswith(("_MlpAdjointFn", "ReversibleHeunFn")) \
+                            and self._prepared:
                         raise RuntimeError(f"{self.name}: sdeint_adjoint did not take the matrix-core route")
                 else:
                     ys = self._sdeint(self.sde, self.y0, self.ts, bm=bm, method=c["method"], dt=c["dt"],
                                       options=dict(extra_options) or None)
                 self.y0.grad = None
                 self.sde.zero_grad()
-                ys[-1].sum().backward()
+                (ys.sum() if c.get("output_every_step") else ys[-1].sum()).backward()
             if self.dist is not None:
                 from torchsde_amd import sharding
                 sharding.all_reduce_gradients(list(self.sde.parameters()))
@@ -274,6 +282,7 @@ class Job:
         if self.use_graph or self.cfg.get("recognised"):
             for i in range(4):
                 self.solve(9000 + i)
+                self._prepared = True
             torch.cuda.synchronize()
         if self.cfg.get("recognised"):
             # the first solve ran both ways and compared (solvers._integrate_recognised); the timed ones must be launches
@@ -318,6 +327,8 @@ class Job:
         from torchsde_amd.kernels import NoiseSpec
         c, dev, sde = self.cfg, self.dev, self.sde
         B, d, m, dt, kid = c["B"], c["d"], c["m"], float(c["dt"]), c["kid"]
+        if kid not in (1, 2, 3, 4, 5, 7, 11, 12):
+            return None              # (a workload without a dominant kernel of its own to time back to back)
         n = 200
         y = live_state[:B].detach().clone().contiguous()
         t0 = self.ts[0]

@@ -797,36 +797,15 @@ def test_clamp_is_refused_when_gradients_flow():
 
 
 # ---- deeper networks, LipSwish, closing tanh: the generator of the reference's examples/sde_gan.py -----------------------------
-class _LipSwish(nn.Module):
-    def forward(self, x):
-        return 0.909 * F.silu(x)
+_LipSwish = problems.LipSwish
+_sde_gan_mlp = problems.sde_gan_mlp
 
 
-def _sde_gan_mlp(in_size, out_size, mlp_size, num_layers, tanh):
-    """examples/sde_gan.py:50-66 (restated: the layer list of its MLP)."""
-    model = [nn.Linear(in_size, mlp_size), _LipSwish()]
-    for _ in range(num_layers - 1):
-        model += [nn.Linear(mlp_size, mlp_size), _LipSwish()]
-    model.append(nn.Linear(mlp_size, out_size))
-    if tanh:
-        model.append(nn.Tanh())
-    return nn.Sequential(*model)
-
-
-class _GeneratorFunc(nn.Module):
-    """examples/sde_gan.py:77-101: Stratonovich, general noise, drift and diffusion MLPs of cat([t, x])."""
-    sde_type, noise_type = "stratonovich", "general"
+class _GeneratorFunc(problems.SdeGanGenerator):
+    """examples/sde_gan.py:77-101 (workloads.problems.SdeGanGenerator) with the example's argument order."""
 
     def __init__(self, noise_size, hidden_size, mlp_size, num_layers):
-        super().__init__()
-        self._noise_size, self._hidden_size = noise_size, hidden_size
-        self._drift = _sde_gan_mlp(1 + hidden_size, hidden_size, mlp_size, num_layers, tanh=True)
-        self._diffusion = _sde_gan_mlp(1 + hidden_size, hidden_size * noise_size, mlp_size, num_layers, tanh=True)
-
-    def f_and_g(self, t, x):
-        t = t.expand(x.size(0), 1)
-        tx = torch.cat([t, x], dim=1)
-        return self._drift(tx), self._diffusion(tx).view(x.size(0), self._hidden_size, self._noise_size)
+        super().__init__(noise_size, hidden_size, mlp_size, num_layers, seed=int(torch.randint(0, 2 ** 31, (1,))))
 
 
 @pytest.mark.parametrize("num_layers", [1, 2, 3])

@@ -146,9 +146,24 @@ def plan(solver, y0, ts, differentiable, need_boundaries=False, tag=()):
     return route
 
 
+_GRID_MATCHES = {}
+
+
 def backward_grid_matches(bm, ts_host, dt, schedule_cells, out_steps):
     """The backward solver builds its own grid on every [-ts[i], -ts[i-1]] (adjoint.py:97-112): its steps must be the forward
-    cells walked backwards (cf. mlp_adjoint.route)."""
+    cells walked backwards (cf. mlp_adjoint.route). Remembered by content: a training loop asks the same question every
+    iteration, and an example with 64 output times (examples/sde_gan.py) builds 63 grids to answer it."""
+    key = (ts_host.tobytes(), str(ts_host.dtype), float(dt), np.asarray(schedule_cells).tobytes(), tuple(out_steps),
+           bm._edges.tobytes())
+    hit = _GRID_MATCHES.get(key)
+    if hit is None:
+        if len(_GRID_MATCHES) >= 32:
+            _GRID_MATCHES.clear()
+        hit = _GRID_MATCHES[key] = _backward_grid_matches(bm, ts_host, dt, schedule_cells, out_steps)
+    return hit
+
+
+def _backward_grid_matches(bm, ts_host, dt, schedule_cells, out_steps):
     boundaries = [0] + list(out_steps)
     for i in range(len(ts_host) - 1, 0, -1):
         back = timegrid.build(np.array([-ts_host[i], -ts_host[i - 1]], dtype=ts_host.dtype), dt)

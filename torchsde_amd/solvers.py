@@ -824,6 +824,10 @@ class BaseSDESolver:
         if network:                          # (the matrix cores sum the layers' products in another order than the library)
             rtol, atol = 1e-3, 1e-4
         ref, got = stepwise.detach(), fast.detach()
+        # (the absolute part scales with the solution: an element that crosses zero in a solve of magnitude 100 carries the
+        #  rounding of its neighbours, not of its own size)
+        finite = torch.where(torch.isfinite(ref), ref.abs(), torch.zeros_like(ref))
+        atol = atol * torch.clamp(finite.max(), min=1.0)
         close = ((got - ref).abs() <= atol + rtol * ref.abs()) | (got.isnan() & ref.isnan()) | (got == ref)
         if not bool(close.all()):
             return f"{what}'s values differ from the stepwise solve"

@@ -339,11 +339,47 @@ WORKLOADS = {
         bench_steps=50, kernel_match=["general_rows_kernel<float", "levy_area"],
         step_kernels={"tsde_step_general": 2},
         kernel="tsde_step_general x2 + tsde_levy_area <float> (+ the user's g and its Jacobian-vector products per step)"),
+    # ---- the reversible pair on the matrix cores (csrc/tsde_neural_rheun.h): the reference's recommended training method ------
+    # The generator of the reference's examples/sde_gan.py at the example's own sizes (hidden 16, noise 3, mlp 16, batch 1024,
+    # 64 output times a unit step apart), `sdeint_adjoint(method="reversible_heun", adjoint_method="adjoint_reversible_heun")`
+    # as :129-130 calls it: forward ONE launch, backward ONE launch + the weight-gradient products; stepwise twin below
+    "sdegan_rheun_adjoint_default_route_b1024_d16_m3_s63": dict(
+        problem="sdegan_generator", method="reversible_heun", adjoint_method="adjoint_reversible_heun", levy="none", B=1024,
+        d=16, m=3, nsteps=63, dt=1.0, output_every_step=True, kid=13, trajectory=True, recognised=True, adjoint=True,
+        mfma_flops_per_traj_step=3 * 2 * (16 * 32 + 32 * 16 + 16 * 32 + 32 * 16 * 4),
+        kernel="tsde_rheun_mlp_forward + _backward<16, 32, general m <= 4> (neural_rheun_kernel; user module recognised; "
+               "flops of the padded tiles)"),
+    "sdegan_rheun_adjoint_b1024_d16_m3_s63": dict(
+        problem="sdegan_generator", method="reversible_heun", adjoint_method="adjoint_reversible_heun", levy="none", B=1024,
+        d=16, m=3, nsteps=63, dt=1.0, output_every_step=True, kid=0, launches_per_step=2, adjoint=True,
+        bytes_per_traj_step=0, kernel="stepwise pair: tsde_step_general_w + torch ops + autograd VJPs of the user's nets"),
+    # ... and at the BASELINE configs[2] shape (NeuralGeneral-style nets, hidden 64): sampling, then forward + backward
+    "c3_rheun_general_default_route_b16384_d32_m16": dict(
+        problem="general_big_strat", method="reversible_heun", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        kid=13, trajectory=True, recognised=True, mfma_flops_per_traj_step=2 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
+        kernel="tsde_rheun_mlp_forward<32, 64, general m = 16> (neural_rheun_kernel: one pass of both nets per step, two "
+               "contractions)"),
+    "c3_rheun_general_b16384_d32_m16": dict(
+        problem="general_big_strat", method="reversible_heun", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=2 * 4 * (32 * 16 + 3 * 32), kid=2, launches_per_step=2, bench_steps=200,
+        kernel="tsde_step_general_w<float> x2 per step (+ tsde_lincomb2 x3; user f_net, g_net once)"),
+    "c3_rheun_adjoint_general_default_route_b16384_d32_m16": dict(
+        problem="general_big_strat", method="reversible_heun", adjoint_method="adjoint_reversible_heun", levy="none", B=16384,
+        d=32, m=16, nsteps=1000, dt=2.0 ** -10, kid=13, trajectory=True, recognised=True, adjoint=True,
+        mfma_flops_per_traj_step=3 * 2 * (32 * 64 + 64 * 32 + 32 * 64 + 64 * 32 * 16),
+        kernel="tsde_rheun_mlp_forward + _backward<32, 64, general m = 16> (forward pass + reconstruction pass with the "
+               "transposed products: 3 passes' worth of flops per trajectory-step)"),
+    "c3_rheun_adjoint_general_b16384_d32_m16": dict(
+        problem="general_big_strat", method="reversible_heun", adjoint_method="adjoint_reversible_heun", levy="none", B=16384,
+        d=32, m=16, nsteps=1000, dt=2.0 ** -10, bytes_per_traj_step=0, kid=2, launches_per_step=2, adjoint=True, bench_steps=50,
+        eager=True, kernel="stepwise pair: tsde_step_general_w + torch outer products + autograd VJPs of the user's nets"),
 }
 
 
 def make_problem(name, d, m, dev):
     from . import problems
+    if name == "sdegan_generator":
+        return problems.SdeGanGenerator(noise_size=m, hidden_size=d).to(dev)
     if name == "latent_diag_strat":
         return problems.LatentDiagStrat(d).to(dev)
     if name == "latent_diag_logqp":

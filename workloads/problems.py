@@ -261,6 +261,46 @@ class LatentDiagLogqp(LatentDiag):
         return -self.theta * y
 
 
+class LipSwish(nn.Module):
+    """examples/sde_gan.py:44-47."""
+
+    def forward(self, x):
+        return 0.909 * torch.nn.functional.silu(x)
+
+
+def sde_gan_mlp(in_size, out_size, mlp_size, num_layers, tanh):
+    """The layer list of the MLP of examples/sde_gan.py:50-66 (restated)."""
+    model = [nn.Linear(in_size, mlp_size), LipSwish()]
+    for _ in range(num_layers - 1):
+        model += [nn.Linear(mlp_size, mlp_size), LipSwish()]
+    model.append(nn.Linear(mlp_size, out_size))
+    if tanh:
+        model.append(nn.Tanh())
+    return nn.Sequential(*model)
+
+
+class SdeGanGenerator(nn.Module):
+    """The generator SDE of the reference's examples/sde_gan.py:77-101 (restated): Stratonovich, general noise, drift and
+    diffusion LipSwish MLPs of cat([t, x]) closed by tanh. The example's sizes: hidden 16, noise 3, mlp 16, one hidden layer
+    (examples/sde_gan.py:336-340), batch 1024, 64 output times a unit step apart, `reversible_heun` + `adjoint_reversible_heun`
+    (:129-130)."""
+    sde_type, noise_type = "stratonovich", "general"
+
+    def __init__(self, noise_size=3, hidden_size=16, mlp_size=16, num_layers=1, seed=0):
+        super().__init__()
+        self._noise_size, self._hidden_size = noise_size, hidden_size
+        state = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self._drift = sde_gan_mlp(1 + hidden_size, hidden_size, mlp_size, num_layers, tanh=True)
+        self._diffusion = sde_gan_mlp(1 + hidden_size, hidden_size * noise_size, mlp_size, num_layers, tanh=True)
+        torch.random.set_rng_state(state)
+
+    def f_and_g(self, t, x):
+        t = t.expand(x.size(0), 1)
+        tx = torch.cat([t, x], dim=1)
+        return self._drift(tx), self._diffusion(tx).view(x.size(0), self._hidden_size, self._noise_size)
+
+
 class ExpDiffusion(nn.Module):
     """The SDE the reference's own benchmark integrates (benchmarks/brownian.py:131-139): f = y, g = exp(-y),
     diagonal Ito noise, no parameters."""
