@@ -726,6 +726,15 @@ int tsde_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde_rheun_st
                             const void* times, int32_t j_hi, int32_t j_lo, uint64_t entropy, uint64_t elem0,
                             const uint64_t* entropy_dev, int dtype, void* stream);
 
+/* The LAST layer of a general-noise diffusion net in that sweep (csrc/rheun_grad.hip): from the stash rows of
+ * tsde_rheun_mlp_backward -- hid = hg[n_mid] (N, stride_h), p, q (N, stride_d), wa, wb (N, stride_m), N = evaluations x rows --
+ * partial sums of  dL/dW2 = sum hid^T cot  and  dL/db2 = sum cot,  cot[., i m + j] = (p_i wa_j + q_i wb_j) final'(hid W2 + b2):
+ *   gw (row_blocks, hidden, out), gb (row_blocks, out): one slice per row block (add them up in a fixed order: deterministic).
+ * diffusion: w2 (hidden, out) input-major, b2, hidden <= 64, out = d * m, final as in tsde_deep_mlp_t; dtype TSDE_F32. */
+int tsde_rheun_last_layer_grad(void* gw, void* gb, const void* hid, const void* p, const void* q, const void* wa, const void* wb,
+                               int64_t n_rows, int64_t d, int64_t m, const tsde_deep_mlp_t* diffusion, int32_t stride_h,
+                               int32_t stride_d, int32_t stride_m, int32_t row_blocks, int dtype, void* stream);
+
 /* partials[i] = sum over the i-th contiguous range of the k rows of a[row, :m]^T b[row, :n]   (a, b row-major with
  * row strides lda >= m, ldb >= n floats -- column blocks of wider matrices are served in place --, m, n <= 128;
  * partials (blocks, m, n)) and, if colsum_partials (blocks, m) is not NULL, the column sums of a over the same range: the weight- and bias-gradient sums of the call above -- a product with a 128 x 128 result

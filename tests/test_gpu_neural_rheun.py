@@ -134,3 +134,25 @@ def test_chunked_backward_sweep_equals_the_single_launch(monkeypatch):
     assert torch.equal(results[0][0], results[1][0])
     for a, b in zip(results[0][1:], results[1][1:]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("d,m,hidden,final,N", [(16, 3, 16, "tanh", 1000), (32, 16, 64, "sigmoid", 4099), (8, 5, 24, None, 77),
+                                                 (3, 2, 8, "tanh", 16), (64, 16, 40, "sigmoid", 300)])
+def test_last_layer_gradient_kernel_against_a_torch_statement(d, m, hidden, final, N):
+    """``tsde_rheun_last_layer_grad``: dL/dW2, dL/db2 of a general diffusion net's last layer from stash rows (hid, p, q, wa, wb),
+    against the (N, d m) cotangent formed in torch -- every tile path (outputs not a multiple of 16 or of the 256-output slice,
+    rows not a multiple of 16, hidden between the tile widths, strides wider than the widths)."""
+    from torchsde_amd import _native, neural_rheun
+    f, g = _nets(d, m, hidden, 2, "tanh", None, final, "general", seed=N)
+    gen = torch.Generator(device=DEV).manual_seed(N)
+    pad = lambda n: (n + 3) // 4 * 4                                                      # noqa: E731
+    mk = lambda w: torch.randn(N, pad(w), device=DEV, generator=gen)                      # noqa: E731
+    hid, p, q, wa, wb = mk(hidden), mk(d), mk(d), mk(m), mk(m)
+    acc_w = torch.zeros(d * m, hidden, device=DEV)
+    acc_b = torch.zeros(d * m, device=DEV)
+    neural_rheun._general_last_layer(g, acc_w, acc_b, hid, p, q, wa, wb, d, m)
+    want_w, want_b = neural_rheun.general_last_layer_reference(
+        g.rebuilt([t.double() for t in g.parameters()]), hid.double(), p.double(), q.double(), wa.double(), wb.double(), d, m)
+    for got, want in ((acc_w, want_w), (acc_b, want_b)):
+        scale = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() <= 2e-5 * scale + 1e-6, (got.shape, scale)

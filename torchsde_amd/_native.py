@@ -192,6 +192,8 @@ SIGNATURES = {
     "tsde_rheun_mlp_backward": (_c_int, [ctypes.POINTER(RheunState), ctypes.POINTER(RheunStash), _c_ptr, _c_ptr, _c_i64, _c_i64,
                                          _c_i64, _c_int, ctypes.POINTER(DeepMlp), ctypes.POINTER(DeepMlp),
                                          ctypes.POINTER(Traj), _c_ptr, _c_i32, _c_i32, _c_u64, _c_u64, _c_ptr, _c_int, _c_ptr]),
+    "tsde_rheun_last_layer_grad": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                            ctypes.POINTER(DeepMlp), _c_i32, _c_i32, _c_i32, _c_i32, _c_int, _c_ptr]),
     "tsde_gram_partials": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _c_int, _c_ptr]),
     "tsde_adaptive_begin": (_c_int, [_c_ptr, _c_ptr, _c_dbl, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),
     "tsde_adaptive_control": (_c_int, [_c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_dbl), _c_int, _c_int, _c_ptr]),

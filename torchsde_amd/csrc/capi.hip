@@ -943,6 +943,27 @@ int tsde_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde_rheun_st
   return fail(e, where);
 }
 
+int tsde_rheun_last_layer_grad(void* gw, void* gb, const void* hid, const void* p, const void* q, const void* wa, const void* wb,
+                               int64_t n_rows, int64_t d, int64_t m, const tsde_deep_mlp_t* diffusion, int32_t stride_h,
+                               int32_t stride_d, int32_t stride_m, int32_t row_blocks, int dtype, void* stream) {
+  const char* where = "tsde_rheun_last_layer_grad";
+  if (!gw || !gb || !hid || !p || !q || !wa || !wb || !diffusion) return bad_arg(where, "null argument");
+  if (dtype != TSDE_F32) return bad_arg(where, "dtype must be TSDE_F32");
+  if (!diffusion->w2 || !diffusion->b2) return bad_arg(where, "a net without its last layer");
+  if (n_rows < 0 || d < 1 || m < 1 || m > 255 || row_blocks < 1) return bad_arg(where, "need n_rows >= 0, d >= 1, 1 <= m <= 255, row_blocks >= 1");
+  if (diffusion->hidden < 1 || diffusion->hidden > 64) return bad_arg(where, "hidden sizes must be in [1, 64]");
+  if (diffusion->out != d * m) return bad_arg(where, "the net maps to d * m outputs");
+  if (diffusion->final != TSDE_FINAL_NONE && diffusion->final != TSDE_FINAL_SIGMOID && diffusion->final != TSDE_FINAL_TANH)
+    return bad_arg(where, "unknown output function");
+  if (((stride_h | stride_d | stride_m) & 3) || stride_h < 4 || stride_d < d || stride_m < m)
+    return bad_arg(where, "strides must be multiples of 4 that cover the widths");
+  if ((reinterpret_cast<uintptr_t>(hid) & 15u) != 0) return bad_arg(where, "hid must be 16-byte aligned");
+  const hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(TSDE_KID_RHEUN_MLP, s, true);
+  return fail(tsde::launch_rheun_last_layer_grad(gw, gb, hid, p, q, wa, wb, n_rows, d, m, diffusion, stride_h, stride_d, stride_m,
+                                                 row_blocks, s), where);
+}
+
 int tsde_prof_begin(int kid, int capacity) {
   if (capacity <= 0) return bad_arg("tsde_prof_begin", "capacity must be positive");
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);

@@ -176,5 +176,8 @@ hipError_t launch_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde
                                      const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* tr,
                                      const void* times, int j_hi, int j_lo, NoiseKey key, const uint64_t* key_dev,
                                      hipStream_t s);
+hipError_t launch_rheun_last_layer_grad(void* gw, void* gb, const void* hid, const void* p, const void* q, const void* wa,
+                                        const void* wb, int64_t N, int64_t d, int64_t m, const tsde_deep_mlp_t* net,
+                                        int32_t stride_h, int32_t stride_d, int32_t stride_m, int32_t row_blocks, hipStream_t s);
 size_t rheun_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t out, int noise, int nmf, int nmg);
 }  // namespace tsde

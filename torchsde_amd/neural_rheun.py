@@ -22,7 +22,6 @@ from . import kernels as K
 
 MAX_MID = 2
 STASH_BYTES = 2 << 30            # per chunk of the backward sweep
-LAST_LAYER_ROWS = 1 << 18        # rows per block of the (rows, d * m) cotangent of a general diffusion's last layer
 
 
 class DeepNet:
@@ -193,23 +192,30 @@ def backward_chunk(state, stash, ys_all, grad_ys, drift, diffusion, noise, m, sc
     _native.check(code, "tsde_rheun_mlp_backward")
 
 
-def _net_gradients(net, acc, z, t_eval, hid, delta, last_cot, d):
-    """Adds one chunk's weight gradients of `net` to `acc` (a list in `net.parameters()` order). `z` (N, >= d) the points of
-    evaluation, `t_eval` (n,) their times, `hid[l]` / `delta[l]` (N, >= hidden) the layers' activations / pre-activation
-    cotangents, `last_cot` (N, out) the cotangent of the last layer's output before `final`. n evaluations of N / n rows."""
+def _tall_product(a, b, m, n):
+    """(a^T b)[:m, :n] and the column sums of a[:, :m] for tall (N, stride) stash views: tsde_gram_partials -- a product with a
+    result of at most 64 x 64 and N in the millions, the shape the BLAS library serves worst (measured here: 120 of the 220 ms of
+    a configs[2]-sized forward + backward went to its kernels before this call replaced them)."""
+    w, sums = K.gram(a, b, column_sums=True)
+    return w[:m, :n], sums[:m]
+
+
+def _net_gradients(net, acc, z, t_eval, hid, delta, last_cot, d, last=True):
+    """Adds one chunk's weight gradients of `net` to `acc` (a list in `net.parameters()` order). `z` (N, stride) the points of
+    evaluation, `t_eval` (n,) their times, `hid[l]` / `delta[l]` (N, stride) the layers' activations / pre-activation
+    cotangents, `last_cot` (N, stride) the cotangent of the last layer's output before `final` (`last=False`: that layer is
+    somebody else's, `_general_last_layer`). n evaluations of N / n rows."""
     h = net.hidden
     n = t_eval.numel()
-    grads = []
-    d0 = delta[0][:, :h]
-    g_w1 = d0.t() @ z[:, :d]                                           # (hidden, d)
+    g_w1, g_b1 = _tall_product(delta[0], z, h, d)                       # (hidden, d)
     if net.time_input:
-        g_t = (d0.reshape(n, -1, h).sum(dim=1) * t_eval.unsqueeze(1)).sum(dim=0)
+        g_t = (delta[0].reshape(n, -1, delta[0].shape[1]).sum(dim=1)[:, :h] * t_eval.unsqueeze(1)).sum(dim=0)
         g_w1 = torch.cat([g_t.unsqueeze(1), g_w1], dim=1)
-    grads.append((g_w1, d0.sum(dim=0)))
+    grads = [(g_w1, g_b1)]
     for l in range(net.n_mid):
-        dl = delta[l + 1][:, :h]
-        grads.append((dl.t() @ hid[l][:, :h], dl.sum(dim=0)))
-    grads.append((last_cot.t() @ hid[net.n_mid][:, :h], last_cot.sum(dim=0)))
+        grads.append(_tall_product(delta[l + 1], hid[l], h, h))
+    if last:
+        grads.append(_tall_product(last_cot, hid[net.n_mid], net.out, h))
     k = 0
     for (w, b), (gw, gb) in zip(net.linears, grads):
         acc[k] += gw
@@ -221,22 +227,35 @@ def _net_gradients(net, acc, z, t_eval, hid, delta, last_cot, d):
 
 def _general_last_layer(net, acc_w, acc_b, hid, p, q, wa, wb, d, m):
     """The last layer of a general-noise diffusion net: the cotangent of its (rows, d, m) output is p (x) wa + q (x) wb (the
-    increments already carry the net's `scale`), times final'(.) of the recomputed pre-activations. Blocks of rows."""
+    increments already carry the net's `scale`), times final'(.) of the recomputed pre-activations -- formed, contracted with
+    the hidden activations and summed over the stash rows by ``tsde_rheun_last_layer_grad`` (csrc/rheun_grad.hip) without ever
+    materialising the (rows, d * m) cotangent. `hid`, `p`, `q`, `wa`, `wb`: (N, stride) views of the stash."""
+    N = hid.shape[0]
+    row_blocks = int(max(1, min(512, (N + 15) // 16)))
+    gw = torch.empty((row_blocks, net.hidden, net.out), dtype=torch.float32, device=hid.device)
+    gb = torch.empty((row_blocks, net.out), dtype=torch.float32, device=hid.device)
+    lib, dt_code, stream = K._launch_env(hid)
+    ns = net.struct()
+    code = lib.tsde_rheun_last_layer_grad(gw.data_ptr(), gb.data_ptr(), hid.data_ptr(), p.data_ptr(), q.data_ptr(), wa.data_ptr(),
+                                          wb.data_ptr(), N, int(d), int(m), ctypes.byref(ns), hid.shape[1], p.shape[1],
+                                          wa.shape[1], row_blocks, dt_code, stream)
+    _native.check(code, "tsde_rheun_last_layer_grad")
+    acc_w += gw.sum(dim=0).t()
+    if acc_b is not None:
+        acc_b += gb.sum(dim=0)
+
+
+def general_last_layer_reference(net, hid, p, q, wa, wb, d, m):
+    """A torch statement of what `_general_last_layer` adds (tests): (dL/dW2 (out, hidden), dL/db2 (out,))."""
     h = net.hidden
     w2, b2 = net.linears[-1]
-    w2, b2 = w2.detach(), (None if b2 is None else b2.detach())
-    N = hid.shape[0]
-    for lo in range(0, N, LAST_LAYER_ROWS):
-        sl = slice(lo, min(N, lo + LAST_LAYER_ROWS))
-        top = hid[sl, :h]
-        cot = (p[sl, :d].unsqueeze(2) * wa[sl, :m].unsqueeze(1) + q[sl, :d].unsqueeze(2) * wb[sl, :m].unsqueeze(1))
-        cot = cot.reshape(top.shape[0], d * m)
-        if net.final != _native.FINAL_NONE:
-            v = net.final_act(torch.nn.functional.linear(top, w2, b2))
-            cot = cot * ((1.0 - v * v) if net.final == _native.FINAL_TANH else v * (1.0 - v))
-        acc_w += cot.t() @ top
-        if acc_b is not None:
-            acc_b += cot.sum(dim=0)
+    top = hid[:, :h]
+    cot = (p[:, :d].unsqueeze(2) * wa[:, :m].unsqueeze(1) + q[:, :d].unsqueeze(2) * wb[:, :m].unsqueeze(1))
+    cot = cot.reshape(top.shape[0], d * m)
+    if net.final != _native.FINAL_NONE:
+        v = net.final_act(torch.nn.functional.linear(top, w2.detach(), None if b2 is None else b2.detach()))
+        cot = cot * ((1.0 - v * v) if net.final == _native.FINAL_TANH else v * (1.0 - v))
+    return cot.t() @ top, cot.sum(dim=0)
 
 
 class ReversibleHeunFn(torch.autograd.Function):
@@ -289,45 +308,22 @@ class ReversibleHeunFn(torch.autograd.Function):
             t_eval = t_all[j_lo:j_hi + 1].flip(0)                           # evaluation e of the chunk is j = j_hi - e
             flat = lambda x: x[:n].reshape(n * rows, x.shape[2])           # noqa: E731
             z = flat(stash.z)
-            _net_gradients(f_net, acc_f, z, t_eval, [flat(x) for x in stash.hf], [flat(x) for x in stash.df],
-                           flat(stash.cf)[:, :d], d)
+            _net_gradients(f_net, acc_f, z, t_eval, [flat(x) for x in stash.hf], [flat(x) for x in stash.df], flat(stash.cf), d)
             if general:
                 # every layer but the last from the stash; the last one from (p, q) and the two increments
                 k_last = len(acc_g) - (2 if g_net.linears[-1][1] is not None else 1)
-                _net_gradients_but_last(g_net, acc_g, z, t_eval, [flat(x) for x in stash.hg], [flat(x) for x in stash.dg], d)
+                _net_gradients(g_net, acc_g, z, t_eval, [flat(x) for x in stash.hg], [flat(x) for x in stash.dg], None, d,
+                               last=False)
                 _general_last_layer(g_net, acc_g[k_last], acc_g[k_last + 1] if g_net.linears[-1][1] is not None else None,
                                     flat(stash.hg[g_net.n_mid]), flat(stash.p), flat(stash.q), flat(stash.wa), flat(stash.wb),
                                     d, m)
             else:
-                _net_gradients(g_net, acc_g, z, t_eval, [flat(x) for x in stash.hg], [flat(x) for x in stash.dg],
-                               flat(stash.p)[:, :g_net.out], d)
+                _net_gradients(g_net, acc_g, z, t_eval, [flat(x) for x in stash.hg], [flat(x) for x in stash.dg], flat(stash.p), d)
             j_hi = j_lo - 1
         grad_y0 = state[2] if ctx.needs_input_grad[8] else None
         grads = [g.to(t.dtype) for g, t in zip(acc_f + acc_g, tensors)]
         grads = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[9:])]
         return (None,) * 8 + (grad_y0, *grads)
-
-
-def _net_gradients_but_last(net, acc, z, t_eval, hid, delta, d):
-    """`_net_gradients` without the last layer (a general diffusion's: `_general_last_layer`)."""
-    h = net.hidden
-    n = t_eval.numel()
-    d0 = delta[0][:, :h]
-    g_w1 = d0.t() @ z[:, :d]
-    if net.time_input:
-        g_t = (d0.reshape(n, -1, h).sum(dim=1) * t_eval.unsqueeze(1)).sum(dim=0)
-        g_w1 = torch.cat([g_t.unsqueeze(1), g_w1], dim=1)
-    grads = [(g_w1, d0.sum(dim=0))]
-    for l in range(net.n_mid):
-        dl = delta[l + 1][:, :h]
-        grads.append((dl.t() @ hid[l][:, :h], dl.sum(dim=0)))
-    k = 0
-    for (w, b), (gw, gb) in zip(net.linears[:-1], grads):
-        acc[k] += gw
-        k += 1
-        if b is not None:
-            acc[k] += gb
-            k += 1
 
 
 _times_on_device = {}
