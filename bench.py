@@ -57,6 +57,9 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+# (program kernels compiled at run time, torchsde_amd/specialise.py: compile in the calling thread, so that the timed solves of
+#  a program workload are the compiled kernel's -- a training loop reaches that state after its first few iterations)
+os.environ.setdefault("TSDE_SPECIALISE", "sync")
 from workloads.configs import WORKLOADS, make_problem as _make_problem  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)

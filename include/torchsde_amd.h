@@ -762,6 +762,11 @@ int tsde_gram_partials(void* partials, void* colsum_partials, const void* a, int
  * time is the kernel's own start-to-end interval (what a rocprofv3 kernel trace reports) with no marker packets on the
  * stream. The other families (one long kernel per call) are bracketed by hipEventRecord calls around the launch. */
 int tsde_prof_begin(int kid, int capacity);
+/* A launch made OUTSIDE this library that belongs to family `kid` (a program kernel compiled at run time,
+ * torchsde_amd/specialise.py): `open` records the start event of the next free slot on `stream` and returns the slot (-1: family
+ * not being timed, or capacity used up), `close` records its end event. */
+int tsde_prof_bracket_open(int kid, void* stream);
+int tsde_prof_bracket_close(int slot, void* stream);
 /* The per-launch times (ms) recorded so far, in launch order (`*used` of them, at most `capacity`); synchronises on
  * them. Call before tsde_prof_end. */
 int tsde_prof_read(double* ms, int capacity, int* used);

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# Program kernels compiled at run time (torchsde_amd/specialise.py) are exercised by tests/test_gpu_specialise.py, which
+# switches them on; everywhere else the suite pins the interpreter (hundreds of different programs pass through it here, and
+# each would start a 4 s compilation).
+os.environ.setdefault("TSDE_SPECIALISE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -207,6 +207,8 @@ SIGNATURES = {
     "tsde_brownian_query_dev": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_u64, _c_u64, _c_ptr, _c_i64, _c_ptr, _c_int,
                                          _c_int, _c_ptr, _c_int, _c_ptr]),
     "tsde_prof_begin": (_c_int, [_c_int, _c_int]),
+    "tsde_prof_bracket_open": (_c_int, [_c_int, _c_ptr]),
+    "tsde_prof_bracket_close": (_c_int, [_c_int, _c_ptr]),
     "tsde_delay_us": (_c_int, [_c_dbl, _c_ptr]),
     "tsde_graph_memset_nodes_to_kernels": (_c_int, [_c_ptr, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     "tsde_prof_bracket_overhead": (_c_int, [_c_int, _c_dbl, ctypes.POINTER(_c_dbl), _c_ptr]),

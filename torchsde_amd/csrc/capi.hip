@@ -1045,6 +1045,18 @@ int tsde_prof_bracket_overhead(int n, double spin_us, double* overhead_ms, void*
   return fail(r, "tsde_prof_bracket_overhead");
 }
 
+int tsde_prof_bracket_open(int kid, void* stream) {
+  if (g_prof.kid != kid || g_prof.used >= g_prof.cap) return -1;
+  const int slot = g_prof.used++;
+  (void)hipEventRecord(g_prof.ev[2 * slot], (hipStream_t)stream);
+  return slot;
+}
+
+int tsde_prof_bracket_close(int slot, void* stream) {
+  if (slot < 0 || slot >= g_prof.used) return bad_arg("tsde_prof_bracket_close", "no such bracket");
+  return fail(hipEventRecord(g_prof.ev[2 * slot + 1], (hipStream_t)stream), "tsde_prof_bracket_close");
+}
+
 int tsde_prof_read(double* ms, int capacity, int* used) {
   hipError_t r = hipSuccess;
   if (used) *used = g_prof.used < capacity ? g_prof.used : capacity;

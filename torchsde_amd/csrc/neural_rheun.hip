@@ -14,7 +14,8 @@ static size_t rheun_lds_limit() {
   return limit;
 }
 
-static int rheun_outp(int d, int out, int mode) { return mode >= 4 ? (d * mode + 15) / 16 * 16 : (out + 15) / 16 * 16; }
+// (general noise: a multiple of 32 -- the kernel takes the diffusion's output tiles two at a time)
+static int rheun_outp(int d, int out, int mode) { return mode >= 4 ? (d * mode + 31) / 32 * 32 : (out + 15) / 16 * 16; }
 
 template <int D, int H, int MODE, bool BACKWARD>
 static hipError_t launch_rheun_mode(const RheunArgs& p, hipStream_t s) {

@@ -745,9 +745,13 @@ TSDE_D Vec<T, W> vmap(const Vec<T, W>& a, F fn) {
 constexpr int kProgWords = 96;     // instruction words of f, g and g' together (they travel in the kernel arguments)
 constexpr int kProgRegs = 8;       // constant rows kept in registers; rows beyond are read through the cache at each use
 
+template <typename T>
+struct ProgArgs;
+
 template <typename T, int W>
 struct ProgModel {
   using V = Vec<T, W>;
+  TSDE_D void setup(const ProgArgs<T>& p, int64_t column);
   const uint32_t* code;            // f program, then g, then g': kernel arguments -> scalar loads, wave-uniform
   int f_len, g_len, dg_len;
   const T* consts;                 // (n_const, d)
@@ -875,9 +879,32 @@ struct ProgArgs {
   uint32_t code[kProgWords];
 };
 
+template <typename T, int W>
+TSDE_D void ProgModel<T, W>::setup(const ProgArgs<T>& p, int64_t column) {
+  code = p.code;
+  f_len = p.f_len;
+  g_len = p.g_len;
+  dg_len = p.dg_len;
+  consts = p.consts;
+  d = p.d;
+  col = column;
+#pragma unroll
+  for (int k = 0; k < kProgRegs; ++k) {
+    creg[k] = V((T)0);
+    if (k < p.n_const) {
+      const Pack<T, W> pk = load<T, W>(p.consts, (int64_t)k * p.d + col);
+#pragma unroll
+      for (int q = 0; q < W; ++q) creg[k].v[q] = pk.v[q];
+    }
+  }
+}
+
 // The expression kernels' loop with the program model; a lane's W elements run through each program together.
 // W = 4 needs d % 4 == 0 (a lane's elements share their row).
-template <typename T, int METHOD, int W>
+// `M`: the model of drift and diffusion -- `ProgModel` (the interpreter), or a struct GENERATED from the same programs and
+// compiled at run time (torchsde_amd/specialise.py: the instruction stream becomes straight-line code, ~8x fewer cycles per
+// wave-step; same operations in the same order, hence the same bits).
+template <typename T, int METHOD, int W, typename M = ProgModel<T, W>>
 __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<T> p) {
   constexpr bool kNeedU = METHOD == kSrk;
   using V = Vec<T, W>;
@@ -889,23 +916,8 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<
   V y;
 #pragma unroll
   for (int q = 0; q < W; ++q) y.v[q] = y_init.v[q];
-  ProgModel<T, W> m;
-  m.code = p.code;
-  m.f_len = p.f_len;
-  m.g_len = p.g_len;
-  m.dg_len = p.dg_len;
-  m.consts = p.consts;
-  m.d = p.d;
-  m.col = col;
-#pragma unroll
-  for (int k = 0; k < kProgRegs; ++k) {
-    m.creg[k] = V((T)0);
-    if (k < p.n_const) {
-      const Pack<T, W> pk = load<T, W>(p.consts, (int64_t)k * p.d + col);
-#pragma unroll
-      for (int q = 0; q < W; ++q) m.creg[k].v[q] = pk.v[q];
-    }
-  }
+  M m;
+  m.setup(p, col);
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
     const uint64_t ent = *p.key_dev;
@@ -940,7 +952,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<
       if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
     }
     stage_times<T, METHOD>(row[7], dt, m.tslot);
-    const V y1 = scheme_step<T, METHOD, V, ProgModel<T, W>, V>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
+    const V y1 = scheme_step<T, METHOD, V, M, V>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
     if (__builtin_expect(k + 1 == next_out, 0)) {
       while (j < p.n_out && p.out_step[j] == k + 1) {
         const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];
@@ -1353,12 +1365,14 @@ hipError_t launch_trajectory_prog_additive(void* ys, const void* y0, int64_t row
   }
 }
 
+#ifndef TSDE_SPECIALISE_TU
 template hipError_t launch_trajectory_prog_additive<float>(void*, const void*, int64_t, int64_t, int64_t, const uint32_t*, int,
                                                            const void*, int, const void*, int, int, const tsde_traj_t*,
                                                            NoiseKey, const uint64_t*, hipStream_t);
 template hipError_t launch_trajectory_prog_additive<double>(void*, const void*, int64_t, int64_t, int64_t, const uint32_t*, int,
                                                             const void*, int, const void*, int, int, const tsde_traj_t*,
                                                             NoiseKey, const uint64_t*, hipStream_t);
+#endif
 
 template <typename T, int METHOD>
 static hipError_t launch_prog_m(const ProgArgs<T>& p, bool vec, hipStream_t s) {
@@ -1434,25 +1448,31 @@ hipError_t launch_trajectory_prog_diag(void* ys, void* sens, const int8_t* param
   }
 }
 
+#ifndef TSDE_SPECIALISE_TU
 template hipError_t launch_trajectory_prog_diag<float>(void*, void*, const int8_t*, const void*, int64_t, int64_t,
                                                        const uint32_t*, int, int, int, const void*, int, int, int,
                                                        const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
 template hipError_t launch_trajectory_prog_diag<double>(void*, void*, const int8_t*, const void*, int64_t, int64_t,
                                                         const uint32_t*, int, int, int, const void*, int, int, int,
                                                         const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
+#endif
 
+#ifndef TSDE_SPECIALISE_TU
 template hipError_t launch_trajectory_expr_diag<float>(void*, const void*, int64_t, int64_t, const void* const[8],
                                                        int64_t, int, int, int, const tsde_traj_t*, NoiseKey,
                                                        const uint64_t*, hipStream_t);
 template hipError_t launch_trajectory_expr_diag<double>(void*, const void*, int64_t, int64_t, const void* const[8],
                                                         int64_t, int, int, int, const tsde_traj_t*, NoiseKey,
                                                         const uint64_t*, hipStream_t);
+#endif
 
+#ifndef TSDE_SPECIALISE_TU
 template hipError_t launch_trajectory_affine_diag<float>(void*, void*, const void*, int64_t, int64_t, const void*,
                                                          const void*, const void*, const void*, int64_t, int,
                                                          const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
 template hipError_t launch_trajectory_affine_diag<double>(void*, void*, const void*, int64_t, int64_t, const void*,
                                                           const void*, const void*, const void*, int64_t, int,
                                                           const tsde_traj_t*, NoiseKey, const uint64_t*, hipStream_t);
+#endif
 
 }  // namespace tsde

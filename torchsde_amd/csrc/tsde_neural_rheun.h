@@ -75,6 +75,21 @@ __device__ __noinline__ float rheun_draw_one(NoiseKey key, uint64_t elem, uint32
   return normal1<float>(key, elem, cell, 0, kStreamW);
 }
 
+// Schedule of a straight-line region of READS LDS operand reads, each feeding PER matrix instructions: the first few reads go out
+// ahead, then every group of PER MFMAs is followed by one more read (cf. mlp_general.hip: left alone, hipcc emits read -> wait ->
+// MFMAs, and with one wave per SIMD nothing else hides the LDS latency).
+template <int READS, int PER>
+TSDE_D void rheun_reads_ahead() {
+  constexpr int AHEAD = READS < 4 ? READS : 4;
+  __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+  for (int i = 0; i < READS; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+    if (i < READS - AHEAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // value and slope of a hidden activation / of a net's closing function
 template <int ACT>
 TSDE_D void hidden_act(float x, float c, float& value, float& slope) {
@@ -463,74 +478,91 @@ __global__ void __launch_bounds__(256) neural_rheun_kernel(const RheunArgs p, co
           const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;
           if (channels <= 0) continue;
           const int tiles = (channels * M + 15) / 16;
-          for (int tl = 0; tl < tiles; ++tl) {
-            const int tile = ty * M + tl;                    // 16 consecutive outputs o = 16 tile + 4 part + r
-            const f32x4 bias = lds_quad(b2g, 16 * tile + 4 * part);
-            f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          // two tiles per turn: two independent accumulator chains (a dependent f32 MFMA waits 40 cycles, issue is 32) and
+          // operand pairs 16 floats apart (one ds_read2_b32); a turn's second tile may lie past the real outputs -- `outp` is
+          // a multiple of 32, its weights and bias are zero, and it is masked out of the selector and the cotangent
+          for (int tl = 0; tl < tiles; tl += 2) {
+            const int tile = ty * M + tl;                    // 16 consecutive outputs o = 16 tile + 4 part + r (and tile + 1)
+            const bool two = tl + 1 < tiles;
+            f32x4 bias[2], acc[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              bias[g] = lds_quad(b2g, 16 * (tile + g) + 4 * part);
+              acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int th = 0; th < TH; ++th) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float a = W2g[(16 * th + 4 * part + r) * S2G + 16 * tile + n];
-                acc = Tile<16>::mfma(a, top[th][r], acc);
-              }
-            }
-            // the state channel (within tile ty) this lane's four outputs belong to, and which of its quads they meet
-            int target, q;
-            if constexpr (M >= 16) {
-              target = tl;
-              q = 0;
-            } else {                                         // M == 4: four channels per tile, one per lane quarter
-              target = 4 * tl + part;
-              q = 0;
-            }
-            f32x4 cot = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            f32x4 pl = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ql = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // p, q of this lane's four outputs
-            if constexpr (BACKWARD) {
-              const f32x4 pt = pv[ty], qt = qv[ty];
-              if constexpr (M >= 16) {
-                // one channel per tile: p, q of (row n, channel target) sit in lane (target / 4, n), register target % 4
-                const int src = (((target >> 2) << 4) + n) << 2;
-                const int reg = target & 3;
-                const float psel = reg == 0 ? pt[0] : reg == 1 ? pt[1] : reg == 2 ? pt[2] : pt[3];
-                const float qsel = reg == 0 ? qt[0] : reg == 1 ? qt[1] : reg == 2 ? qt[2] : qt[3];
-                const float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, psel)));
-                const float qb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, qsel)));
-                pl = f32x4{pb, pb, pb, pb};
-                ql = f32x4{qb, qb, qb, qb};
-              } else {
-                // four channels per tile, one per lane quarter: the asking lanes want DIFFERENT registers of the holder, and a
-                // chain of ds_bpermutes with a per-lane pick afterwards is folded by hipcc into ONE bpermute of a value picked
-                // in the SOURCE lane (seen in the ISA; wrong gradients). The matrix cores do the broadcast instead:
-                // D[o][row] = sum_c Sel[o][c] p[c][row], Sel[o][c] = 1 iff output o of the tile belongs to channel c -- and the
-                // result is born in the layout of the tile's outputs.
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float a = (part == tl && r == (n >> 2)) ? 1.0f : 0.0f;     // A[o = n][c = 4 part + r]
-                  pl = Tile<16>::mfma(a, pt[r], pl);
-                  ql = Tile<16>::mfma(a, qt[r], ql);
+                for (int g = 0; g < 2; ++g) {
+                  const float a = W2g[(16 * th + 4 * part + r) * S2G + 16 * (tile + g) + n];
+                  acc[g] = Tile<16>::mfma(a, top[th][r], acc[g]);
                 }
               }
             }
-            float s_a = 0.0f, s_b = 0.0f;
+            rheun_reads_ahead<TH * 4, 2>();          // (the two tiles' operands arrive as one ds_read2_b32)
+            f32x4 cot[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v, s;
-              final_value(p.g.final, acc[r] + bias[r], v, s);
-              s_a = fmaf(v, dwa[q][r], s_a);
-              s_b = fmaf(v, dwb[q][r], s_b);
-              if constexpr (BACKWARD) cot[r] = (pl[r] * dwa[q][r] + ql[r] * dwb[q][r]) * s;
-            }
-            const float sel = (n == target) ? 1.0f : 0.0f;
-            sa[ty] = Tile<16>::mfma(sel, s_a, sa[ty]);
-            sb[ty] = Tile<16>::mfma(sel, s_b, sb[ty]);
-            if constexpr (BACKWARD) {
+            for (int g = 0; g < 2; ++g) {
+              const bool live = g == 0 || two;
+              // the state channel (within tile ty) this lane's four outputs belong to (their Brownian channels: quad 0 of
+              // the lane's draws -- 4 part + r for 16 channels per state channel, r for 4)
+              const int target = M >= 16 ? tl + g : 4 * (tl + g) + part;
+              cot[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+              f32x4 pl = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ql = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // p, q of this lane's four outputs
+              if constexpr (BACKWARD) {
+                const f32x4 pt = pv[ty], qt = qv[ty];
+                if constexpr (M >= 16) {
+                  // one channel per tile: p, q of (row n, channel target) sit in lane (target / 4, n), register target % 4
+                  const int src = ((((target >> 2) & 3) << 4) + n) << 2;
+                  const int reg = target & 3;
+                  const float psel = reg == 0 ? pt[0] : reg == 1 ? pt[1] : reg == 2 ? pt[2] : pt[3];
+                  const float qsel = reg == 0 ? qt[0] : reg == 1 ? qt[1] : reg == 2 ? qt[2] : qt[3];
+                  const float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, psel)));
+                  const float qb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, qsel)));
+                  pl = f32x4{pb, pb, pb, pb};
+                  ql = f32x4{qb, qb, qb, qb};
+                } else {
+                  // four channels per tile, one per lane quarter: the asking lanes want DIFFERENT registers of the holder, and a
+                  // chain of ds_bpermutes with a per-lane pick afterwards is folded by hipcc into ONE bpermute of a value picked
+                  // in the SOURCE lane (seen in the ISA; wrong gradients). The matrix cores do the broadcast instead:
+                  // D[o][row] = sum_c Sel[o][c] p[c][row], Sel[o][c] = 1 iff output o of the tile belongs to channel c -- and the
+                  // result is born in the layout of the tile's outputs.
 #pragma unroll
-              for (int th = 0; th < TH; ++th) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(W2g + (16 * th + n) * S2G + 16 * tile + 4 * part);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) back[th] = Tile<16>::mfma(a[r], cot[r], back[th]);
+                  for (int r = 0; r < 4; ++r) {
+                    const float a = (part == ((tl + g) & 3) && r == (n >> 2) && tl + g < 4) ? 1.0f : 0.0f;   // A[o = n][c = 4 part + r]
+                    pl = Tile<16>::mfma(a, pt[r], pl);
+                    ql = Tile<16>::mfma(a, qt[r], ql);
+                  }
+                }
               }
+              float s_a = 0.0f, s_b = 0.0f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float v, s;
+                final_value(p.g.final, acc[g][r] + bias[g][r], v, s);
+                s_a = fmaf(v, dwa[0][r], s_a);
+                s_b = fmaf(v, dwb[0][r], s_b);
+                if constexpr (BACKWARD) cot[g][r] = live ? (pl[r] * dwa[0][r] + ql[r] * dwb[0][r]) * s : 0.0f;
+              }
+              const float sel = (live && n == target) ? 1.0f : 0.0f;
+              sa[ty] = Tile<16>::mfma(sel, s_a, sa[ty]);
+              sb[ty] = Tile<16>::mfma(sel, s_b, sb[ty]);
+            }
+            if constexpr (BACKWARD) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int th = 0; th < TH; ++th) {      // (th inner: consecutive MFMAs hit different accumulators)
+                  const f32x4 a = *reinterpret_cast<const f32x4*>(W2g + (16 * th + n) * S2G + 16 * (tile + g) + 4 * part);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) back[th] = Tile<16>::mfma(a[r], cot[g][r], back[th]);
+                }
+              }
+              rheun_reads_ahead<TH * 2, 4>();          // (one 16-byte read feeds four MFMAs)
             }
           }
         }
