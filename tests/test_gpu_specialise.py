@@ -125,3 +125,33 @@ def test_a_compiled_kernel_that_disagrees_is_never_used(monkeypatch):
         got = _solve(sde, e, "euler", "none", 1)
     assert any(specialise.verified(k) is False for k in specialise.status())
     assert torch.equal(got, _interpreted(lambda: _solve(sde, 3, "euler", "none", 1)))
+
+
+@pytest.mark.parametrize("method,levy", [("euler", "none"), ("milstein", "none"), ("srk", "space-time")])
+def test_training_through_sdeint_compiled_sensitivities_equal_interpreted(method, levy):
+    """`sdeint` with autograd recording on the reference's ExScalar: the programs on dual numbers
+    (`tsde_trajectory_prog_diag_sens`) as generated code -- values, dL/dy0 and the parameter gradient bit for bit the
+    interpreter's."""
+    import torchsde_amd
+    sde = problems.ScalarTrig(D, "ito").to(DEV)
+    ts = torch.tensor([0.0, 7 * DT, STEPS * DT], device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    weights = torch.randn(3, B, D, device=DEV, generator=gen)
+
+    def train(entropy):
+        y0 = torch.full((B, D), 0.1, device=DEV, requires_grad=True)
+        sde.zero_grad()
+        bm = torchsde_amd.BrownianInterval(0.0, STEPS * DT, size=(B, 1), device=DEV, entropy=entropy, levy_area_approximation=levy)
+        ys = torchsde_amd.sdeint(sde, y0, ts, bm=bm, method=method, dt=DT, options={"hip_graph": False})
+        (ys * weights).sum().backward()
+        return ys.detach(), y0.grad.clone(), sde.p.grad.clone(), type(ys.grad_fn).__name__
+    train(1)                  # the verifying solve of the route (stepwise)
+    train(2)                  # compiles; interpreter + compiled compared
+    train(3)
+    fast = train(4)
+    assert fast[3].startswith("_ProgTrajectoryFn")
+    slow = _interpreted(lambda: train(4))
+    for a, b in zip(fast[:3], slow[:3]):
+        assert torch.equal(a, b)
+    from torchsde_amd import specialise
+    assert any(specialise.verified(k) for k in specialise.status())

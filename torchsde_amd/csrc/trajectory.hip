@@ -1011,8 +1011,12 @@ TSDE_D Dual<T> chain(const Dual<T>& x, T value, T slope) {
 }
 
 template <typename T>
+struct ProgSensArgs;
+
+template <typename T>
 struct ProgSensModel {
   using S = Dual<T>;
+  TSDE_D void setup(const ProgSensArgs<T>& q, int64_t column);
   const uint32_t* code;
   int f_len, g_len, dg_len;
   const T* consts;
@@ -1108,23 +1112,29 @@ struct ProgSensArgs {
   int8_t param_slot[kProgParamRows];
 };
 
+template <typename T>
+TSDE_D void ProgSensModel<T>::setup(const ProgSensArgs<T>& q, int64_t column) {
+  code = q.base.code;
+  f_len = q.base.f_len;
+  g_len = q.base.g_len;
+  dg_len = q.base.dg_len;
+  consts = q.base.consts;
+  param_slot = q.param_slot;
+  d = q.base.d;
+  col = column;
+}
+
 // One element per lane (the duals are six values wide); values AND sensitivities of every requested output.
-template <typename T, int METHOD>
+// (`M`: the interpreter, or the same programs as generated straight-line code on dual numbers -- specialise.py.)
+template <typename T, int METHOD, typename M = ProgSensModel<T>>
 __global__ void __launch_bounds__(kBlock) trajectory_prog_sens_kernel(const ProgSensArgs<T> q) {
   constexpr bool kNeedU = METHOD == kSrk;
   const ProgArgs<T>& p = q.base;
   using S = Dual<T>;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= p.n) return;
-  ProgSensModel<T> m;
-  m.code = p.code;
-  m.f_len = p.f_len;
-  m.g_len = p.g_len;
-  m.dg_len = p.dg_len;
-  m.consts = p.consts;
-  m.param_slot = q.param_slot;
-  m.d = p.d;
-  m.col = i % p.d;
+  M m;
+  m.setup(q, i % p.d);
   S y(p.y0[i]);
   y.d[0] = (T)1;
   NoiseKey key = p.key;
@@ -1144,7 +1154,7 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_sens_kernel(const Prog
     T u = (T)0;
     if constexpr (kNeedU) u = th * ((T)0.5 * w + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
     stage_times<T, METHOD>(row[7], dt, m.tslot);
-    const S y1 = scheme_step<T, METHOD, S>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
+    const S y1 = scheme_step<T, METHOD, S, M>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);
     if (__builtin_expect(k + 1 == next_out, 0)) {
       while (j < p.n_out && p.out_step[j] == k + 1) {
         const T w0 = p.out_w[2 * j], w1 = p.out_w[2 * j + 1];

@@ -773,14 +773,27 @@ class _ProgTrajectoryFn(torch.autograd.Function):
         sens = torch.empty((schedule.n_out, _native.TRAJ_SENS, rows, d), dtype=y0.dtype, device=y0.device)
         ys[0].copy_(y0c)
         words = tuple(f_code) + tuple(g_code) + tuple(dg_code)
-        code = (ctypes.c_uint32 * len(words))(*words)
         lib, dt_code, stream = _launch_env(y0c)
         entropy_dev = bm._entropy_dev
-        rc = lib.tsde_trajectory_prog_diag_sens(
-            ys[1:].data_ptr(), sens.data_ptr(), y0c.data_ptr(), rows, d, code, len(f_code), len(g_code), len(dg_code),
-            consts.data_ptr(), len(const_values), slots, int(bool(scalar_noise)), int(method), schedule.struct(), bm._key,
-            bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
-        _native.check(rc, "tsde_trajectory_prog_diag_sens")
+        # the same programs on dual numbers as straight-line code, compiled at run time and verified bit for bit on first use
+        from . import specialise
+        key, compiled = specialise.lookup(f_code, g_code, dg_code, len(const_values), y0.dtype, method, y0.device, kind="sens")
+        if compiled is not None and specialise.verified(key):
+            specialise.launch_sens(compiled, ys[1:], sens, slots, y0c, consts, len(const_values), scalar_noise, schedule, bm, stream)
+        else:
+            code = (ctypes.c_uint32 * len(words))(*words)
+            rc = lib.tsde_trajectory_prog_diag_sens(
+                ys[1:].data_ptr(), sens.data_ptr(), y0c.data_ptr(), rows, d, code, len(f_code), len(g_code), len(dg_code),
+                consts.data_ptr(), len(const_values), slots, int(bool(scalar_noise)), int(method), schedule.struct(), bm._key,
+                bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+            _native.check(rc, "tsde_trajectory_prog_diag_sens")
+            if compiled is not None and specialise.verified(key) is None:
+                ys2, sens2 = torch.empty_like(ys[1:]), torch.empty_like(sens)
+                specialise.launch_sens(compiled, ys2, sens2, slots, y0c, consts, len(const_values), scalar_noise, schedule, bm,
+                                       stream)
+                same = (((ys2 == ys[1:]) | (ys2.isnan() & ys[1:].isnan())).all()
+                        & ((sens2 == sens) | (sens2.isnan() & sens.isnan())).all())
+                specialise.set_verified(key, bool(same))
         ctx.save_for_backward(sens)
         ctx.param_shapes = [tuple(p.shape) for p in params]
         return ys

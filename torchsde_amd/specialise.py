@@ -48,17 +48,50 @@ _BINARY = {"add": "({a} + {b})", "sub": "({a} - {b})", "rsub": "({b} - {a})", "m
            "rdiv": "({b} / {a})"}
 
 
-def _body(words, name):
-    """Straight-line code for one program: the interpreter's stack machine (csrc/trajectory.hip ProgModel::run) run at
-    generation time, every instruction one `const V` statement. Returns (lines, result expression, constants used)."""
+# the same functions on forward-mode dual numbers: value and slope exactly as ProgSensModel::run forms them
+_DUAL_HELPERS = '''
+template <typename T> TSDE_D Dual<T> d_neg(const Dual<T>& s) { return chain(s, -s.v, (T)-1); }
+template <typename T> TSDE_D Dual<T> d_exp(const Dual<T>& s) { const T e = exp(s.v); return chain(s, e, e); }
+template <typename T> TSDE_D Dual<T> d_log(const Dual<T>& s) { return chain(s, log(s.v), (T)1 / s.v); }
+template <typename T> TSDE_D Dual<T> d_sin(const Dual<T>& s) { return chain(s, sin(s.v), cos(s.v)); }
+template <typename T> TSDE_D Dual<T> d_cos(const Dual<T>& s) { return chain(s, cos(s.v), -sin(s.v)); }
+template <typename T> TSDE_D Dual<T> d_tanh(const Dual<T>& s) { const T t = tanh(s.v); return chain(s, t, (T)1 - t * t); }
+template <typename T> TSDE_D Dual<T> d_sigmoid(const Dual<T>& s) {
+  const T g = (T)1 / ((T)1 + exp(-s.v));
+  return chain(s, g, g * ((T)1 - g));
+}
+template <typename T> TSDE_D Dual<T> d_softplus(const Dual<T>& s) {
+  const T v = s.v;
+  return chain(s, v > (T)20 ? v : log1p(exp(v)), v > (T)20 ? (T)1 : (T)1 / ((T)1 + exp(-v)));
+}
+template <typename T> TSDE_D Dual<T> d_sqrt(const Dual<T>& s) { const T r = sqrt(s.v); return chain(s, r, (T)0.5 / r); }
+template <typename T> TSDE_D Dual<T> d_abs(const Dual<T>& s) {
+  const T v = s.v;
+  return chain(s, fabs(v), v > (T)0 ? (T)1 : (v < (T)0 ? (T)-1 : (T)0));
+}
+template <typename T> TSDE_D Dual<T> d_relu(const Dual<T>& s) {
+  const T v = s.v;
+  return chain(s, v > (T)0 ? v : (T)0, v > (T)0 ? (T)1 : (T)0);
+}
+template <typename T> TSDE_D Dual<T> d_reciprocal(const Dual<T>& s) { const T r = (T)1 / s.v; return chain(s, r, -(r * r)); }
+template <typename T> TSDE_D Dual<T> d_square(const Dual<T>& s) { const T v = s.v; return chain(s, v * v, (T)2 * v); }
+template <typename T> TSDE_D Dual<T> d_cube(const Dual<T>& s) { const T v = s.v; return chain(s, (v * v) * v, (T)3 * (v * v)); }
+'''
+
+
+def _body(words, name, dual=False):
+    """Straight-line code for one program: the interpreter's stack machine (csrc/trajectory.hip ProgModel::run; `dual`:
+    ProgSensModel::run) run at generation time, every instruction one `const V` statement. Returns (lines, result expression,
+    constants used)."""
     lines, stack, used = [], [], set()
     count = 0
+    vtype = "S" if dual else "V"
 
     def fresh(expr):
         nonlocal count
         var = f"{name}{count}"
         count += 1
-        lines.append(f"    const V {var} = {expr};")
+        lines.append(f"    const {vtype} {var} = {expr};")
         return var
     for ins in words:
         op, src, k = _OPS[ins & 0xFF], (ins >> 8) & 0xFF, ins >> 16
@@ -72,7 +105,7 @@ def _body(words, name):
                 used.add(k)
                 operand = f"c{k}"
             elif src == _SRC_TIME:
-                operand = "V(time)"
+                operand = f"{vtype}(time)"
             else:
                 operand = "x"
             if op == "load":
@@ -82,15 +115,20 @@ def _body(words, name):
                 stack.append(fresh(_BINARY[op].format(a=a, b=operand)))
         elif op == "dup":
             stack.append(stack[-1])
+        elif dual:
+            stack.append(fresh(f"d_{op}({stack.pop()})"))
         else:
             stack.append(fresh(_UNARY[op].format(stack.pop())))
     if not stack:
-        return lines, "V((T)0)", used
+        return lines, f"{vtype}((T)0)", used
     return lines, stack[-1], used
 
 
-def source(f_code, g_code, dg_code, n_const, dtype, method):
-    """The translation unit for these programs, this state dtype and this scheme."""
+def source(f_code, g_code, dg_code, n_const, dtype, method, kind="values"):
+    """The translation unit for these programs, this state dtype and this scheme. `kind`: "values"
+    (`trajectory_prog_kernel`), or "sens" (`trajectory_prog_sens_kernel`: the programs on dual numbers)."""
+    if kind == "sens":
+        return _source_sens(f_code, g_code, dg_code, n_const, dtype, method)
     ctype = "float" if dtype == torch.float32 else "double"
     parts, used = {}, set()
     for name, words in (("f", f_code), ("g", g_code), ("h", dg_code)):
@@ -179,6 +217,89 @@ extern "C" int tsde_specialised_launch(void* ys, const void* y0, int64_t rows, i
 '''
 
 
+def _source_sens(f_code, g_code, dg_code, n_const, dtype, method):
+    ctype = "float" if dtype == torch.float32 else "double"
+    parts, used = {}, set()
+    for name, words in (("f", f_code), ("g", g_code), ("h", dg_code)):
+        lines, result, consts = _body(tuple(words), name, dual=True)
+        parts[name] = (lines, result)
+        used |= consts
+    used = sorted(used)
+    members = "".join(f"  S c{k};\n" for k in used)
+    setup = "".join(
+        f"    c{k} = S(q.base.consts[(int64_t){k} * q.base.d + column]);\n"
+        f"    if (q.param_slot[{k}] > 0) c{k}.d[q.param_slot[{k}]] = (T)1;\n" for k in used)
+
+    def fn(name):
+        lines, result = parts[name]
+        return "\n".join(lines) + ("\n" if lines else "") + f"    return {result};"
+    return f'''// generated by torchsde_amd/specialise.py -- do not edit
+#define TSDE_SPECIALISE_TU 1
+#include "{os.path.join(_CSRC, "trajectory.hip")}"
+namespace tsde {{
+{_DUAL_HELPERS}
+template <typename T>
+struct SpecSensModel {{
+  using S = Dual<T>;
+{members}  T tslot[4];
+  TSDE_D void setup(const ProgSensArgs<T>& q, int64_t column) {{
+{setup}  }}
+  TSDE_D S eval_f(const S& x, const T time) const {{
+{fn("f")}
+  }}
+  TSDE_D S eval_g(const S& x, const T time) const {{
+{fn("g")}
+  }}
+  TSDE_D S eval_h(const S& x, const T time) const {{
+{fn("h")}
+  }}
+  template <int SLOT>
+  TSDE_D S f(const S& x) const {{ return eval_f(x, tslot[SLOT]); }}
+  template <int SLOT>
+  TSDE_D S g(const S& x) const {{ return eval_g(x, tslot[SLOT]); }}
+  template <int SLOT>
+  TSDE_D S gdg(const S& x, const S& gv, T v2) const {{ return (gv * v2) * eval_h(x, tslot[SLOT]); }}
+}};
+}}  // namespace tsde
+
+extern "C" int tsde_specialised_sens_launch(void* ys, void* sens, const int8_t* param_slot, const void* y0, int64_t rows,
+                                            int64_t d, const void* consts, int n_const, int scalar_noise, const tsde_traj_t* tr,
+                                            uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, void* stream) {{
+  using namespace tsde;
+  using T = {ctype};
+  constexpr int METHOD = {int(method)};
+  if (n_const < {(used[-1] + 1) if used else 0} || n_const > kProgParamRows) return (int)hipErrorInvalidValue;
+  ProgSensArgs<T> q;
+  ProgArgs<T>& p = q.base;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  p.consts = (const T*)consts;
+  p.f_len = p.g_len = p.dg_len = 0;
+  p.n_const = n_const;
+  p.scalar_noise = scalar_noise;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key.k0 = (uint32_t)entropy;
+  p.key.k1 = (uint32_t)(entropy >> 32);
+  p.key.elem0 = elem0;
+  p.key_dev = entropy_dev;
+  for (int w = 0; w < kProgWords; ++w) p.code[w] = 0u;
+  q.sens = (T*)sens;
+  for (int k = 0; k < kProgParamRows; ++k) q.param_slot[k] = (param_slot && k < n_const) ? param_slot[k] : (int8_t)-1;
+  if (p.n <= 0 || p.n_steps <= 0) return 0;
+  hipLaunchKernelGGL((trajectory_prog_sens_kernel<T, METHOD, SpecSensModel<T>>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, (hipStream_t)stream, q);
+  return (int)hipGetLastError();
+}}
+'''
+
+
 # ---- compiling, caching, loading -------------------------------------------------------------------------------------------
 _lock = threading.Lock()
 _state = {}            # key -> "pending" | "failed: ..." | _Library
@@ -189,11 +310,15 @@ class _Library:
     def __init__(self, path):
         self.path = path
         self.lib = ctypes.CDLL(path)
-        fn = self.lib.tsde_specialised_launch
+        tail = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_native.Traj),
+                ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        if hasattr(self.lib, "tsde_specialised_sens_launch"):
+            fn = self.lib.tsde_specialised_sens_launch
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + tail
+        else:
+            fn = self.lib.tsde_specialised_launch
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + tail
         fn.restype = ctypes.c_int
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
-                       ctypes.c_int, ctypes.POINTER(_native.Traj), ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
-                       ctypes.c_void_p]
         self.launch = fn
 
 
@@ -235,13 +360,13 @@ def _compile(key, text, arch):
         _state[key] = result
 
 
-def lookup(f_code, g_code, dg_code, n_const, dtype, method, device, wait=None):
+def lookup(f_code, g_code, dg_code, n_const, dtype, method, device, wait=None, kind="values"):
     """(key, the loaded library of these programs or None). The first call starts the compilation (in the background unless
     TSDE_SPECIALISE=sync or `wait`)."""
     if MODE in ("0", "false", "off") or compiler() is None:
         return None, None
     arch = _arch(device)
-    text = source(f_code, g_code, dg_code, n_const, dtype, method)
+    text = source(f_code, g_code, dg_code, n_const, dtype, method, kind)
     key = hashlib.sha256((text + arch + _sources_digest()).encode()).hexdigest()[:24]
     with _lock:
         have = _state.get(key)
@@ -324,3 +449,17 @@ def verified(key):
 
 def set_verified(key, ok):
     _verified[key] = bool(ok)
+
+
+def launch_sens(library, ys, sens, slots, y0, consts, n_const, scalar_noise, schedule, bm, stream):
+    rows, d = y0.shape
+    entropy_dev = bm._entropy_dev
+    lib = _native.load()
+    slot = lib.tsde_prof_bracket_open(_native.KID_TRAJECTORY, stream)
+    rc = library.launch(ys.data_ptr(), sens.data_ptr(), ctypes.cast(slots, ctypes.c_void_p), y0.data_ptr(), rows, d,
+                        consts.data_ptr(), int(n_const), int(bool(scalar_noise)), schedule.struct(), bm._key, bm._elem0,
+                        None if entropy_dev is None else entropy_dev.data_ptr(), stream)
+    if slot >= 0:
+        lib.tsde_prof_bracket_close(slot, stream)
+    if rc != 0:
+        raise _native.NativeLibraryError(f"torchsde_amd: a specialised program kernel failed with hipError {rc}")
