@@ -155,3 +155,19 @@ def test_training_through_sdeint_compiled_sensitivities_equal_interpreted(method
         assert torch.equal(a, b)
     from torchsde_amd import specialise
     assert any(specialise.verified(k) for k in specialise.status())
+
+
+@pytest.mark.parametrize("method,levy,sde_type,m", [("euler", "none", "ito", 3), ("srk", "space-time", "ito", 8),
+                                                    ("midpoint", "none", "stratonovich", 16), ("milstein", "none", "ito", 4)])
+def test_additive_noise_drift_program_compiled_equals_interpreted(method, levy, sde_type, m):
+    """The reference's ExAdditive (tests/problems.py:106-132: drift and diffusion use t) on `tsde_trajectory_prog_additive` with
+    the drift program compiled: every channel-count class, Euler / midpoint / SRK (SRA1)."""
+    sde = problems.make("additive_ito" if sde_type == "ito" else "additive_strat", d=D, m=m).to(DEV)
+    _solve(sde, 1, method, levy, m)
+    _solve(sde, 2, method, levy, m)
+    fast = _solve(sde, 3, method, levy, m)
+    slow = _interpreted(lambda: _solve(sde, 3, method, levy, m))
+    assert torch.equal(fast, slow)
+    torch.testing.assert_close(fast, _solve(sde, 3, method, levy, m, stepwise=True), rtol=2e-5, atol=2e-6)
+    from torchsde_amd import specialise
+    assert any(specialise.verified(k) for k, v in specialise.status().items())

@@ -1190,7 +1190,7 @@ struct ProgAdditiveArgs {
   int32_t quads;            // != 0: m % 4 == 0 and elem0 % 4 == 0, a row's channels are whole Philox quads
 };
 
-template <typename T, int METHOD, int W, int MP>
+template <typename T, int METHOD, int W, int MP, typename M = ProgModel<T, W>>
 __global__ void __launch_bounds__(kBlock) trajectory_prog_additive_kernel(const ProgAdditiveArgs<T> q) {
   constexpr bool kNeedU = METHOD == kSrk;
   using V = Vec<T, W>;
@@ -1203,23 +1203,8 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_additive_kernel(const 
   V y;
 #pragma unroll
   for (int e = 0; e < W; ++e) y.v[e] = y_init.v[e];
-  ProgModel<T, W> m;
-  m.code = p.code;
-  m.f_len = p.f_len;
-  m.g_len = 0;
-  m.dg_len = 0;
-  m.consts = p.consts;
-  m.d = p.d;
-  m.col = col;
-#pragma unroll
-  for (int k = 0; k < kProgRegs; ++k) {
-    m.creg[k] = V((T)0);
-    if (k < p.n_const) {
-      const Pack<T, W> pk = load<T, W>(p.consts, (int64_t)k * p.d + col);
-#pragma unroll
-      for (int e = 0; e < W; ++e) m.creg[k].v[e] = pk.v[e];
-    }
-  }
+  M m;                      // (the interpreter, or the drift program as generated code: specialise.py)
+  m.setup(p, col);
   NoiseKey key = p.key;
   if (p.key_dev != nullptr) {
     const uint64_t ent = *p.key_dev;

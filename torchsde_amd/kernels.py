@@ -737,14 +737,25 @@ def trajectory_prog_additive(ys, y0, f_code, consts, g_table, m, method, schedul
     timed = g_table.dim() == 4
     if tuple(g_table.shape) != ((schedule.n_steps, slots, m, d) if timed else (m, d)):
         raise ValueError(f"g_table must be (m, d) or (n_steps, {slots}, m, d), got {tuple(g_table.shape)}")
-    code = (ctypes.c_uint32 * len(f_code))(*f_code)
     lib, dt_code, stream = _launch_env(y0)
+    # the drift program as straight-line code, compiled at run time and verified bit for bit on first use (specialise.py)
+    from . import specialise
+    kind = "additive4" if m <= 4 else "additive8" if m <= 8 else "additive16"
+    key, compiled = specialise.lookup(f_code, (), (), consts.shape[0], y0.dtype, method, y0.device, kind=kind)
+    if compiled is not None and specialise.verified(key):
+        specialise.launch_additive(compiled, ys, y0, consts, g_table, m, timed, schedule, bm, stream)
+        return ys
+    code = (ctypes.c_uint32 * len(f_code))(*f_code)
     entropy_dev = bm._entropy_dev
     rc = lib.tsde_trajectory_prog_additive(ys.data_ptr(), y0.data_ptr(), rows, d, int(m), code, len(f_code), consts.data_ptr(),
                                            consts.shape[0], g_table.data_ptr(), int(timed), int(method), schedule.struct(),
                                            bm._key, bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(),
                                            dt_code, stream)
     _native.check(rc, "tsde_trajectory_prog_additive")
+    if compiled is not None and specialise.verified(key) is None and not torch.cuda.is_current_stream_capturing():
+        other = torch.empty_like(ys)
+        specialise.launch_additive(compiled, other, y0, consts, g_table, m, timed, schedule, bm, stream)
+        specialise.set_verified(key, bool(((other == ys) | (other.isnan() & ys.isnan())).all()))
     return ys
 
 

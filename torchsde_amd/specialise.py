@@ -129,6 +129,7 @@ def source(f_code, g_code, dg_code, n_const, dtype, method, kind="values"):
     (`trajectory_prog_kernel`), or "sens" (`trajectory_prog_sens_kernel`: the programs on dual numbers)."""
     if kind == "sens":
         return _source_sens(f_code, g_code, dg_code, n_const, dtype, method)
+    additive = kind.startswith("additive")
     ctype = "float" if dtype == torch.float32 else "double"
     parts, used = {}, set()
     for name, words in (("f", f_code), ("g", g_code), ("h", dg_code)):
@@ -172,10 +173,12 @@ struct SpecModel {{
 }};
 }}  // namespace tsde
 
+{_additive_launcher(ctype, method, kind, used) if additive else ""}
 extern "C" int tsde_specialised_launch(void* ys, const void* y0, int64_t rows, int64_t d, const void* consts, int n_const,
                                        int scalar_noise, const tsde_traj_t* tr, uint64_t entropy, uint64_t elem0,
                                        const uint64_t* entropy_dev, void* stream) {{
   using namespace tsde;
+  if ({1 if additive else 0}) return (int)hipErrorInvalidValue;        // (an additive-noise unit: tsde_specialised_additive_launch)
   using T = {ctype};
   constexpr int METHOD = {int(method)};
   if (n_const < {(used[-1] + 1) if used else 0}) return (int)hipErrorInvalidValue;
@@ -211,6 +214,62 @@ extern "C" int tsde_specialised_launch(void* ys, const void* y0, int64_t rows, i
   }} else {{
     hipLaunchKernelGGL((trajectory_prog_kernel<T, METHOD, 1, SpecModel<T, 1>>), dim3((unsigned)((p.n + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, p);
+  }}
+  return (int)hipGetLastError();
+}}
+'''
+
+
+def _additive_launcher(ctype, method, kind, used):
+    """The launcher of an additive-noise unit (kind "additive<MP>"): csrc/trajectory.hip launch_trajectory_prog_additive for ONE
+    scheme and ONE channel-count class, with the generated drift model."""
+    mp = int(kind[len("additive"):])
+    return f'''
+extern "C" int tsde_specialised_additive_launch(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, const void* consts,
+                                                int n_const, const void* gtab, int time_dependent, const tsde_traj_t* tr,
+                                                uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, void* stream) {{
+  using namespace tsde;
+  using T = {ctype};
+  constexpr int METHOD = {int(method)};
+  constexpr int MP = {mp};
+  if (n_const < {(used[-1] + 1) if used else 0} || m < 1 || m > MP) return (int)hipErrorInvalidValue;
+  ProgAdditiveArgs<T> q;
+  ProgArgs<T>& p = q.base;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  for (int w = 0; w < kProgWords; ++w) p.code[w] = 0u;
+  p.consts = (const T*)consts;
+  p.f_len = p.g_len = p.dg_len = 0;
+  p.n_const = n_const;
+  p.scalar_noise = 0;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key.k0 = (uint32_t)entropy;
+  p.key.k1 = (uint32_t)(entropy >> 32);
+  p.key.elem0 = elem0;
+  p.key_dev = entropy_dev;
+  if (p.n <= 0 || p.n_steps <= 0) return 0;
+  const int slots = METHOD == kEuler ? 1 : 2;
+  q.gtab = (const T*)gtab;
+  q.slot_stride = time_dependent ? m * d : 0;
+  q.step_stride = time_dependent ? (int64_t)slots * m * d : 0;
+  q.m = (int32_t)m;
+  q.quads = (m % 4 == 0 && elem0 % 4 == 0) ? 1 : 0;
+  const bool can_vec = (d % 4 == 0) && aligned16(ys) && aligned16(y0) && aligned16(gtab) && ((p.n * sizeof(T)) % 16 == 0);
+  const bool vec = can_vec && (p.n >> 2) >= kTrajVecMinGroups;
+  const hipStream_t s = (hipStream_t)stream;
+  if (vec) {{
+    hipLaunchKernelGGL((trajectory_prog_additive_kernel<T, METHOD, 4, MP, SpecModel<T, 4>>),
+                       dim3((unsigned)(((p.n >> 2) + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, q);
+  }} else {{
+    hipLaunchKernelGGL((trajectory_prog_additive_kernel<T, METHOD, 1, MP, SpecModel<T, 1>>),
+                       dim3((unsigned)((p.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, q);
   }}
   return (int)hipGetLastError();
 }}
@@ -312,7 +371,12 @@ class _Library:
         self.lib = ctypes.CDLL(path)
         tail = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_native.Traj),
                 ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
-        if hasattr(self.lib, "tsde_specialised_sens_launch"):
+        if hasattr(self.lib, "tsde_specialised_additive_launch"):
+            fn = self.lib.tsde_specialised_additive_launch
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(_native.Traj), ctypes.c_uint64,
+                           ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        elif hasattr(self.lib, "tsde_specialised_sens_launch"):
             fn = self.lib.tsde_specialised_sens_launch
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + tail
         else:
@@ -458,6 +522,20 @@ def launch_sens(library, ys, sens, slots, y0, consts, n_const, scalar_noise, sch
     slot = lib.tsde_prof_bracket_open(_native.KID_TRAJECTORY, stream)
     rc = library.launch(ys.data_ptr(), sens.data_ptr(), ctypes.cast(slots, ctypes.c_void_p), y0.data_ptr(), rows, d,
                         consts.data_ptr(), int(n_const), int(bool(scalar_noise)), schedule.struct(), bm._key, bm._elem0,
+                        None if entropy_dev is None else entropy_dev.data_ptr(), stream)
+    if slot >= 0:
+        lib.tsde_prof_bracket_close(slot, stream)
+    if rc != 0:
+        raise _native.NativeLibraryError(f"torchsde_amd: a specialised program kernel failed with hipError {rc}")
+
+
+def launch_additive(library, ys, y0, consts, g_table, m, timed, schedule, bm, stream):
+    rows, d = y0.shape
+    entropy_dev = bm._entropy_dev
+    lib = _native.load()
+    slot = lib.tsde_prof_bracket_open(_native.KID_TRAJECTORY, stream)
+    rc = library.launch(ys.data_ptr(), y0.data_ptr(), rows, d, int(m), consts.data_ptr(), consts.shape[0], g_table.data_ptr(),
+                        int(bool(timed)), schedule.struct(), bm._key, bm._elem0,
                         None if entropy_dev is None else entropy_dev.data_ptr(), stream)
     if slot >= 0:
         lib.tsde_prof_bracket_close(slot, stream)
