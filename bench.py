@@ -95,6 +95,9 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         # SURVEY 8(f) rows, measured on the routes they have
         "c5_rheun_adjoint_latent_b32768_d128_s500", "c5_logqp_adjoint_latent_b32768_d128_s500",
         "c3_log_ode_general_b16384_d32_m16",
+        # a row-coupled system (the reference's StochasticLorenz): generated model, one lane per row
+        "lorenz_euler_default_route_b262144_d3_s1000", "lorenz_euler_b262144_d3_s1000",
+        "lorenz_srk_default_route_b1024_d3_s1000", "lorenz_srk_b1024_d3_s1000",
         # the reversible pair on the matrix cores, beside its stepwise twins
         "sdegan_rheun_adjoint_default_route_b1024_d16_m3_s63", "sdegan_rheun_adjoint_b1024_d16_m3_s63",
         "c3_rheun_general_default_route_b16384_d32_m16", "c3_rheun_general_b16384_d32_m16",

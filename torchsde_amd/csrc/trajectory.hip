@@ -948,8 +948,13 @@ __global__ void __launch_bounds__(kBlock) trajectory_prog_kernel(const ProgArgs<
         for (int q = 0; q < 4; ++q) u.v[q] = th * ((T)0.5 * w.v[q] + z[q] * sh);
       }
     } else {
-      w.v[0] = normal1<T>(key, elem, cell, 0, kStreamW) * sw;
-      if constexpr (kNeedU) u.v[0] = th * ((T)0.5 * w.v[0] + normal1<T>(key, elem, cell, 0, kStreamH) * sh);
+      // one element per lane -- or (W = d, a generated row model: specialise.py) a lane that owns a whole ROW of a small
+      // coupled system and draws its d increments one by one
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        w.v[q] = normal1<T>(key, elem + (uint64_t)q, cell, 0, kStreamW) * sw;
+        if constexpr (kNeedU) u.v[q] = th * ((T)0.5 * w.v[q] + normal1<T>(key, elem + (uint64_t)q, cell, 0, kStreamH) * sh);
+      }
     }
     stage_times<T, METHOD>(row[7], dt, m.tslot);
     const V y1 = scheme_step<T, METHOD, V, M, V>(y, m, w, u, dt, half_dt, rdt, sqrt_dt);

@@ -722,6 +722,25 @@ def trajectory_prog_diag(ys, y0, f_code, g_code, dg_code, consts, scalar_noise, 
     return ys
 
 
+def trajectory_rows(ys, y0, structure, consts, method, schedule, bm):
+    """All steps of a small ROW-COUPLED diagonal-noise system (recognise_rows.RecognisedRows) in one launch: the program
+    kernel with one lane per row and the system's generated model (specialise.source_rows). Returns `ys`, or None while the
+    generated unit is not compiled yet (there is no interpreter for such systems: the caller stays stepwise)."""
+    from . import specialise
+    _native.require_device(ys, y0, consts)
+    rows, d = y0.shape
+    if ys.dtype != y0.dtype or consts.dtype != y0.dtype or schedule.dtype != y0.dtype:
+        raise ValueError("schedule / output / constant dtype must equal the state dtype")
+    if not (ys.is_contiguous() and y0.is_contiguous() and consts.is_contiguous()) or ys.shape != (schedule.n_out, rows, d):
+        raise ValueError("ys must be a contiguous (n_out, rows, d) tensor, y0 and consts contiguous")
+    key, compiled = specialise.lookup_rows(structure, structure[1][1], y0.dtype, method, y0.device)
+    if compiled is None:
+        return None
+    _, _, stream = _launch_env(y0)
+    specialise.launch_rows(compiled, ys, y0, consts, schedule, bm, stream)
+    return ys
+
+
 def trajectory_prog_additive(ys, y0, f_code, consts, g_table, m, method, schedule, bm):
     """All steps of an additive-noise SDE in one launch (``tsde_trajectory_prog_additive``): the drift an expression program,
     the diffusion the table `g_table` -- (m, d), the transpose of the one matrix g, or (n_steps, slots, m, d) with the matrices

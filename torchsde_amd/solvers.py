@@ -512,14 +512,25 @@ class BaseSDESolver:
         milstein = self._program_code() in (_native.TRAJ_MILSTEIN_ITO, _native.TRAJ_MILSTEIN_STRAT)
 
         def as_program(first_reason):
-            """The second chance of code the single-function forms cannot hold: its expression trees as programs."""
+            """The second chance of code the single-function forms cannot hold: its expression trees as programs -- and the
+            third: channels that read each other (`split` / `cat` of the state's columns), a small ROW-COUPLED system
+            (recognise_rows.py: one lane per row, the model generated and compiled at run time)."""
             if not programs:
                 raise recognise.NotElementwise(first_reason)
             try:
                 found = recognise.recognise_program(sde, ts[0], y0, sde.noise_type)
                 spec = found.spec(milstein)
             except recognise.NotElementwise as e:
-                raise recognise.NotElementwise(f"{first_reason}; as an expression program: {e}") from None
+                from . import recognise_rows
+                reason = f"{first_reason}; as an expression program: {e}"
+                if (sde.noise_type != NOISE_TYPES.diagonal or milstein or y0.shape[1] > recognise_rows.MAX_D
+                        or self._program_code() is None):
+                    raise recognise.NotElementwise(reason) from None
+                try:
+                    found = recognise_rows.recognise_rows(sde, ts[0], y0)
+                    return found, found.spec()
+                except recognise.NotElementwise as e2:
+                    raise recognise.NotElementwise(f"{reason}; as a row-coupled system: {e2}") from None
             book["program"] = (chain, type(self).__name__)
             return found, spec
 
@@ -557,7 +568,7 @@ class BaseSDESolver:
                 if additive:
                     raise
                 found, spec = as_program(str(e))
-            if isinstance(found, (recognise.RecognisedProgram, recognise.RecognisedAdditive)):
+            if isinstance(found, (recognise.RecognisedProgram, recognise.RecognisedAdditive)) or spec[0] == "program_rows":
                 pass
             elif found.neural:
                 if not networks or times is not None:
@@ -611,7 +622,10 @@ class BaseSDESolver:
         before = state_of()
         rng_before = self._rng_states(y0.device)
         try:
-            if spec[0] == "program_diagonal":
+            if spec[0] == "program_rows":
+                from . import recognise_rows
+                again = recognise_rows.recognise_rows(sde, ts[0], y0, rows=5).spec()
+            elif spec[0] == "program_diagonal":
                 again = recognise.recognise_program(sde, ts[0], y0, sde.noise_type, rows=5).spec(milstein)
             elif spec[0] in ("program_additive", "neural_additive"):
                 again = recognise.recognise_additive(sde, ts[0], y0, times, rows=5, check_rows=True).spec()
@@ -1036,6 +1050,12 @@ class BaseSDESolver:
             _, f_code, g_code, dg_code, const_values, rows_with_grad, scalar_noise = coefficients
             return K.trajectory_prog_diag_differentiable(y0, (f_code, g_code, dg_code), const_values, rows_with_grad,
                                                          scalar_noise, self._program_code(), schedule, bm)
+        if coefficients[0] == "program_rows":
+            y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            done = K.trajectory_rows(ys[1:], y0c, coefficients[1], coefficients[2], self._program_code(), schedule, bm)
+            return None if done is None else ys          # (None: the generated unit is still compiling -- stepwise for now)
         if coefficients[0] == "program_diagonal":
             y0c = y0.detach() if y0.is_contiguous() else y0.detach().contiguous()
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)

@@ -371,7 +371,11 @@ class _Library:
         self.lib = ctypes.CDLL(path)
         tail = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_native.Traj),
                 ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
-        if hasattr(self.lib, "tsde_specialised_additive_launch"):
+        if hasattr(self.lib, "tsde_specialised_rows_launch"):
+            fn = self.lib.tsde_specialised_rows_launch
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                           ctypes.POINTER(_native.Traj), ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        elif hasattr(self.lib, "tsde_specialised_additive_launch"):
             fn = self.lib.tsde_specialised_additive_launch
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                            ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(_native.Traj), ctypes.c_uint64,
@@ -541,3 +545,134 @@ def launch_additive(library, ys, y0, consts, g_table, m, timed, schedule, bm, st
         lib.tsde_prof_bracket_close(slot, stream)
     if rc != 0:
         raise _native.NativeLibraryError(f"torchsde_amd: a specialised program kernel failed with hipError {rc}")
+
+
+# ---- row-coupled systems: a lane owns a whole row (recognise_rows.py) --------------------------------------------------------
+_ROW_OPS = {
+    "add": "({0} + {1})", "sub": "({0} - {1})", "mul": "({0} * {1})", "div": "({0} / {1})", "neg": "(-{0})",
+    "exp": "exp({0})", "log": "log({0})", "sin": "sin({0})", "cos": "cos({0})", "tanh": "tanh({0})",
+    "sigmoid": "((T)1 / ((T)1 + exp(-{0})))", "softplus": "({0} > (T)20 ? {0} : log1p(exp({0})))", "sqrt": "sqrt({0})",
+    "abs": "fabs({0})", "relu": "({0} > (T)0 ? {0} : (T)0)", "reciprocal": "((T)1 / {0})", "square": "({0} * {0})",
+    "cube": "(({0} * {0}) * {0})",
+}
+
+
+def source_rows(structure, n_const, dtype, method):
+    """The translation unit of a row-coupled system: `structure` = RecognisedRows.structure()."""
+    (_, d, statements, outputs), _ = structure
+    ctype = "float" if dtype == torch.float32 else "double"
+    names = [f"n{k}" for k in range(len(statements))]
+    needs = {}
+    for name, (op, operands) in zip(names, statements):
+        needs[name] = set(o for o in operands if o in needs or o.startswith("n"))
+
+    def body(outs):
+        wanted, stack = set(), [o for o in outs if o.startswith("n")]
+        while stack:
+            x = stack.pop()
+            if x in wanted:
+                continue
+            wanted.add(x)
+            stack.extend(o for o in needs.get(x, ()) if o.startswith("n"))
+        lines = [f"    const T {name} = {_ROW_OPS[op].format(*operands)};" for name, (op, operands) in zip(names, statements)
+                 if name in wanted]
+        lines.append("    V r;")
+        lines += [f"    r.v[{c}] = {o};" for c, o in enumerate(outs)]
+        lines.append("    return r;")
+        return "\n".join(lines)
+    nc = max(1, n_const)
+    return f'''// generated by torchsde_amd/specialise.py (a row-coupled system) -- do not edit
+#define TSDE_SPECIALISE_TU 1
+#include "{os.path.join(_CSRC, "trajectory.hip")}"
+namespace tsde {{
+template <typename T>
+struct RowModel {{
+  using V = Vec<T, {d}>;
+  T c[{nc}];
+  T tslot[4];
+  TSDE_D void setup(const ProgArgs<T>& p, int64_t) {{
+    _Pragma("unroll") for (int k = 0; k < {nc}; ++k) c[k] = k < p.n_const ? p.consts[k] : (T)0;
+  }}
+  TSDE_D V eval_f(const V& x, const T time) const {{
+{body(list(outputs[:d]))}
+  }}
+  TSDE_D V eval_g(const V& x, const T time) const {{
+{body(list(outputs[d:]))}
+  }}
+  template <int SLOT>
+  TSDE_D V f(const V& x) const {{ return eval_f(x, tslot[SLOT]); }}
+  template <int SLOT>
+  TSDE_D V g(const V& x) const {{ return eval_g(x, tslot[SLOT]); }}
+  template <int SLOT>
+  TSDE_D V gdg(const V& x, const V& gv, const V& v2) const {{ return V((T)0); }}        // (no derivative schemes on this route)
+}};
+}}  // namespace tsde
+
+extern "C" int tsde_specialised_rows_launch(void* ys, const void* y0, int64_t rows, int64_t d, const void* consts, int n_const,
+                                            const tsde_traj_t* tr, uint64_t entropy, uint64_t elem0,
+                                            const uint64_t* entropy_dev, void* stream) {{
+  using namespace tsde;
+  using T = {ctype};
+  constexpr int METHOD = {int(method)};
+  if (d != {d} || n_const > {nc}) return (int)hipErrorInvalidValue;
+  ProgArgs<T> p;
+  p.ys = (T*)ys;
+  p.y0 = (const T*)y0;
+  p.consts = (const T*)consts;
+  p.f_len = p.g_len = p.dg_len = 0;
+  p.n_const = n_const;
+  p.scalar_noise = 0;
+  p.rows = (const T*)tr->step_rows;
+  p.cells = tr->cells;
+  p.out_step = tr->out_step;
+  p.out_w = (const T*)tr->out_w;
+  p.n = rows * d;
+  p.d = d;
+  p.n_steps = tr->n_steps;
+  p.n_out = tr->n_out;
+  p.key.k0 = (uint32_t)entropy;
+  p.key.k1 = (uint32_t)(entropy >> 32);
+  p.key.elem0 = elem0;
+  p.key_dev = entropy_dev;
+  for (int w = 0; w < kProgWords; ++w) p.code[w] = 0u;
+  if (p.n <= 0 || p.n_steps <= 0) return 0;
+  hipLaunchKernelGGL((trajectory_prog_kernel<T, METHOD, {d}, RowModel<T>>), dim3((unsigned)((rows + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}}
+'''
+
+
+def lookup_rows(structure, n_const, dtype, method, device, wait=None):
+    """(key, library or None) of a row-coupled system; starts the compilation on first sight (cf. `lookup`)."""
+    if MODE in ("0", "false", "off") or compiler() is None:
+        return None, None
+    arch = _arch(device)
+    text = source_rows(structure, n_const, dtype, method)
+    key = hashlib.sha256((text + arch + _sources_digest()).encode()).hexdigest()[:24]
+    with _lock:
+        have = _state.get(key)
+        if have is None:
+            _state[key] = "pending"
+    if have is None:
+        if MODE == "sync" or wait:
+            _compile(key, text, arch)
+        elif not _enqueue(key, text, arch):
+            with _lock:
+                _state.pop(key, None)
+        with _lock:
+            have = _state.get(key)
+    return key, (have if isinstance(have, _Library) else None)
+
+
+def launch_rows(library, ys, y0, consts, schedule, bm, stream):
+    rows, d = y0.shape
+    entropy_dev = bm._entropy_dev
+    lib = _native.load()
+    slot = lib.tsde_prof_bracket_open(_native.KID_TRAJECTORY, stream)
+    rc = library.launch(ys.data_ptr(), y0.data_ptr(), rows, d, consts.data_ptr(), consts.numel(), schedule.struct(), bm._key,
+                        bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), stream)
+    if slot >= 0:
+        lib.tsde_prof_bracket_close(slot, stream)
+    if rc != 0:
+        raise _native.NativeLibraryError(f"torchsde_amd: a specialised row kernel failed with hipError {rc}")

@@ -339,6 +339,25 @@ WORKLOADS = {
         bench_steps=50, kernel_match=["general_rows_kernel<float", "levy_area"],
         step_kernels={"tsde_step_general": 2},
         kernel="tsde_step_general x2 + tsde_levy_area <float> (+ the user's g and its Jacobian-vector products per step)"),
+    # The reference's StochasticLorenz (examples/latent_sde_lorenz.py:56-86), unchanged: channels that read each other. One
+    # lane owns a row (recognise_rows.py), the model is generated from the user's code and compiled at run time; stepwise twin
+    # below (split / cat and ~20 small torch kernels per step). The example's own sizes: 1024 rows; here also 262144.
+    "lorenz_euler_default_route_b262144_d3_s1000": dict(
+        problem="stochastic_lorenz", method="euler", levy="none", B=262144, d=3, m=3, nsteps=1000, dt=2.0 ** -12,
+        bytes_per_traj_step=16 * 3, kid=8, trajectory=True, recognised=True,
+        kernel="trajectory_prog_kernel<float, euler, 3, RowModel> (one lane per row; model generated by specialise.source_rows)"),
+    "lorenz_euler_b262144_d3_s1000": dict(
+        problem="stochastic_lorenz", method="euler", levy="none", B=262144, d=3, m=3, nsteps=1000, dt=2.0 ** -12,
+        bytes_per_traj_step=16 * 3, kid=1, launches_per_step=1, bench_steps=200,
+        kernel="tsde_step_diag<float> (user f, g: split, cat and ~20 torch kernels per step)"),
+    "lorenz_srk_default_route_b1024_d3_s1000": dict(
+        problem="stochastic_lorenz", method="srk", levy="space-time", B=1024, d=3, m=3, nsteps=1000, dt=2.0 ** -12,
+        bytes_per_traj_step=64 * 3, kid=8, trajectory=True, recognised=True,
+        kernel="trajectory_prog_kernel<float, srk, 3, RowModel> (the example's batch of 1024, sdeint's default method)"),
+    "lorenz_srk_b1024_d3_s1000": dict(
+        problem="stochastic_lorenz", method="srk", levy="space-time", B=1024, d=3, m=3, nsteps=1000, dt=2.0 ** -12,
+        bytes_per_traj_step=64 * 3, kid=0, launches_per_step=4, bench_steps=200,
+        kernel="tsde_srk_diag_stage<float> (4 stage kernels; user f, g: 7 evaluations per step)"),
     # ---- the reversible pair on the matrix cores (csrc/tsde_neural_rheun.h): the reference's recommended training method ------
     # The generator of the reference's examples/sde_gan.py at the example's own sizes (hidden 16, noise 3, mlp 16, batch 1024,
     # 64 output times a unit step apart), `sdeint_adjoint(method="reversible_heun", adjoint_method="adjoint_reversible_heun")`
@@ -378,6 +397,8 @@ WORKLOADS = {
 
 def make_problem(name, d, m, dev):
     from . import problems
+    if name == "stochastic_lorenz":
+        return problems.StochasticLorenz()
     if name == "sdegan_generator":
         return problems.SdeGanGenerator(noise_size=m, hidden_size=d).to(dev)
     if name == "latent_diag_strat":

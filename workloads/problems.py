@@ -261,6 +261,42 @@ class LatentDiagLogqp(LatentDiag):
         return -self.theta * y
 
 
+class StochasticLorenz(object):
+    """The reference's examples/latent_sde_lorenz.py:56-86 (restated verbatim): a row-coupled diagonal-noise system -- the
+    columns of the state read each other through `split` / `cat`."""
+    noise_type = "diagonal"
+    sde_type = "ito"
+
+    def __init__(self, a=(10., 28., 8 / 3), b=(.1, .28, .3)):
+        super(StochasticLorenz, self).__init__()
+        self.a = a
+        self.b = b
+
+    def f(self, t, y):
+        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
+        a1, a2, a3 = self.a
+
+        f1 = a1 * (x2 - x1)
+        f2 = a2 * x1 - x2 - x1 * x3
+        f3 = x1 * x2 - a3 * x3
+        return torch.cat([f1, f2, f3], dim=1)
+
+    def g(self, t, y):
+        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
+        b1, b2, b3 = self.b
+
+        g1 = x1 * b1
+        g2 = x2 * b2
+        g3 = x3 * b3
+        return torch.cat([g1, g2, g3], dim=1)
+
+    def to(self, device):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+
 class LipSwish(nn.Module):
     """examples/sde_gan.py:44-47."""
 
