@@ -355,6 +355,7 @@ int tsde_brownian_query_dev(void* W, void* U, void* H, int64_t n, uint64_t entro
 #define TSDE_TRAJ_SRK 4
 #define TSDE_TRAJ_HEUN 5       /* heun.py:35-48; the affine / expression / program kernels (values and sensitivities) */
 #define TSDE_TRAJ_EULER_HEUN 6 /* euler_heun.py:29-42; the same kernels */
+#define TSDE_TRAJ_REVERSIBLE_HEUN 7 /* reversible_heun.py:48-73; tsde_rheun_mlp_forward only */
 
 /* All `traj->n_steps` fixed steps of a diagonal-noise SDE with per-channel affine drift and diffusion
  *   f(t, y) = drift_rate * y + drift_shift,   g(t, y) = diff_rate * y + diff_shift      (each of length d)
@@ -673,6 +674,15 @@ int tsde_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, 
                            const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj,
                            const void* times, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
                            void* stream);
+/* The same launch for the schemes that carry no state -- method = TSDE_TRAJ_EULER (euler.py:29-37), TSDE_TRAJ_MIDPOINT
+ * (midpoint.py:29-45; second evaluation at t_k + dt/2), TSDE_TRAJ_HEUN (heun.py:35-48), TSDE_TRAJ_EULER_HEUN (euler_heun.py:
+ * 29-42; second evaluation at t_{k+1}), or TSDE_TRAJ_REVERSIBLE_HEUN (= tsde_rheun_mlp_forward): networks deeper than the two
+ * layers of tsde_trajectory_mlp_general, LipSwish, a closing tanh, under every fixed-step method the reference offers for general
+ * noise. z_out (may be NULL) receives the final state for these schemes. */
+int tsde_deep_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                          const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, int method, const tsde_traj_t* traj,
+                          const void* times, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                          void* stream);
 int64_t tsde_rheun_mlp_lds(int64_t d, int64_t m, int64_t drift_hidden, int64_t diffusion_hidden, int64_t diffusion_out,
                            int noise, int drift_mid, int diffusion_mid);
 

@@ -153,11 +153,12 @@ def test_live_parameters_and_what_stays_stepwise():
     for _ in range(2):
         got, launches = _launches(lambda: _solve(wide, 4, 3, "euler", d=68))
         assert launches == 0
+    # (Heun and Euler-Heun: not this kernel's -- since round 6 the deep-network kernel's, tests/test_gpu_neural_rheun_route.py)
     strat = problems.MLPGeneral(8, 4, "stratonovich", hidden=8).to(DEV)
     for _ in range(2):
         got, launches = _launches(lambda: _solve(strat, 4, 3, "heun"))
         assert launches == 0
-    assert torch.equal(got, _solve(strat, 4, 3, "heun", stepwise=True))
+    torch.testing.assert_close(got, _solve(strat, 4, 3, "heun", stepwise=True), rtol=2e-5, atol=2e-6)
 
 
 def test_c_abi_against_a_torch_evaluation_of_the_same_networks():

@@ -254,3 +254,54 @@ def test_configs2_shape_rows_vs_oracle():
                                                                   torch.tensor([0.0, n * dt], dtype=dtype), dt)
     new = ys[-1][torch.from_numpy(rows).to(DEV)]
     helpers.assert_within_reference_rounding(new, out[torch.float32][-1], out[torch.float64][-1], "configs[2] reversible Heun")
+
+
+def _sdeint_method(sde, d, m, entropy, method, B=48, steps=16, stepwise=False, ts=None):
+    import torchsde_amd
+    y0 = torch.full((B, d), 0.2, device=DEV)
+    ts = torch.tensor([0.0, 5.5 * DT, steps * DT] if ts is None else ts, device=DEV)
+    options = {"hip_graph": False}
+    if stepwise:
+        options["trajectory_kernel"] = False
+    with torch.no_grad():
+        return torchsde_amd.sdeint(sde, y0, ts, bm=_bm(B, m, float(ts[-1]), entropy), method=method, dt=DT, options=options)
+
+
+@pytest.mark.parametrize("method", ["midpoint", "heun", "euler_heun"])
+@pytest.mark.parametrize("name", ["sde_gan_1", "sde_gan_3", "neural_general", "neural_diagonal", "neural_scalar"])
+def test_the_stateless_stratonovich_schemes_on_deep_networks(name, method):
+    """`tsde_deep_mlp_forward`: midpoint (the Stratonovich default of `sdeint`, sdeint.py:155), Heun, Euler-Heun for the same
+    nets -- the sde_gan generator at depth 1 and 3, and the reference's Neural* problems under the two schemes the two-layer
+    kernel does not have. One launch, against the stepwise route."""
+    make, d, m = MODULES[name]
+    sde = make()
+    if method == "euler_heun" and name.startswith("sde_gan"):
+        # Euler-Heun calls `g` alone (euler_heun.py:38); a module that only defines `f_and_g` raises in the reference as here
+        with pytest.raises(RuntimeError, match="Method `g` has not been provided"):
+            _sdeint_method(sde, d, m, 1, method)
+        return
+    first = _sdeint_method(sde, d, m, 1, method)
+    assert torch.equal(first, _sdeint_method(sde, d, m, 1, method, stepwise=True))
+    assert [v for v in _book(sde)["trusted"].values()] == [True], _book(sde)
+    fast, launches = _launches(lambda: _sdeint_method(sde, d, m, 2, method))
+    # (midpoint on a two-layer tanh / softplus net is the older kernel's: kernel family 8, not counted here)
+    assert launches == (0 if (method == "midpoint" and name.startswith("neural")) else 1)
+    torch.testing.assert_close(fast, _sdeint_method(sde, d, m, 2, method, stepwise=True), rtol=5e-5, atol=5e-6)
+
+
+def test_euler_on_an_ito_deep_network():
+    class ItoGenerator(type(MODULES["sde_gan_2"][0]())):
+        sde_type = "ito"
+    torch.manual_seed(0)
+    sde = ItoGenerator(3, 16, 16, 2).to(DEV)
+    _sdeint_method(sde, 16, 3, 1, "euler")
+    fast, launches = _launches(lambda: _sdeint_method(sde, 16, 3, 2, "euler"))
+    assert launches == 1
+    torch.testing.assert_close(fast, _sdeint_method(sde, 16, 3, 2, "euler", stepwise=True), rtol=5e-5, atol=5e-6)
+    # the default method of sdeint for general Ito noise IS Euler (sdeint.py:147-156): the drop-in call
+    import torchsde_amd
+    y0 = torch.full((48, 16), 0.2, device=DEV)
+    ts = torch.tensor([0.0, 16 * DT], device=DEV)
+    with torch.no_grad():
+        out, launches = _launches(lambda: torchsde_amd.sdeint(sde, y0, ts, bm=_bm(48, 3, 16 * DT, 2), dt=DT))
+    assert launches == 1

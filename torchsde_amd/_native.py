@@ -23,6 +23,7 @@ FINAL_NONE, FINAL_SIGMOID, FINAL_TANH = 0, 1, 2
 PRECISION_F32, PRECISION_BF16X3 = 0, 1
 NOISE_DIAGONAL, NOISE_SCALAR, NOISE_GENERAL, NOISE_ADDITIVE = 0, 1, 2, 3
 TRAJ_EULER, TRAJ_MILSTEIN_ITO, TRAJ_MILSTEIN_STRAT, TRAJ_MIDPOINT, TRAJ_SRK, TRAJ_HEUN, TRAJ_EULER_HEUN = 0, 1, 2, 3, 4, 5, 6
+TRAJ_REVERSIBLE_HEUN = 7
 FN_CODES = {"identity": 0, "exp": 1, "sigmoid": 2, "tanh": 3, "softplus": 4, "sin": 5, "cos": 6, "poly3": 7}
 
 # include/torchsde_amd.h: the device tables of adaptive stepping (TSDE_CTL_*, TSDE_SUB_*, TSDE_SCAL_*)
@@ -188,6 +189,9 @@ SIGNATURES = {
     "tsde_rheun_mlp_forward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(DeepMlp),
                                         ctypes.POINTER(DeepMlp), ctypes.POINTER(Traj), _c_ptr, _c_u64, _c_u64, _c_ptr, _c_int,
                                         _c_ptr]),
+    "tsde_deep_mlp_forward": (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, ctypes.POINTER(DeepMlp),
+                                       ctypes.POINTER(DeepMlp), _c_int, ctypes.POINTER(Traj), _c_ptr, _c_u64, _c_u64, _c_ptr, _c_int,
+                                       _c_ptr]),
     "tsde_rheun_mlp_lds": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int]),
     "tsde_rheun_mlp_backward": (_c_int, [ctypes.POINTER(RheunState), ctypes.POINTER(RheunStash), _c_ptr, _c_ptr, _c_i64, _c_i64,
                                          _c_i64, _c_int, ctypes.POINTER(DeepMlp), ctypes.POINTER(DeepMlp),

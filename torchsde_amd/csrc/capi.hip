@@ -897,7 +897,18 @@ int tsde_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, 
                            const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* traj,
                            const void* times, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
                            void* stream) {
-  const char* where = "tsde_rheun_mlp_forward";
+  return tsde_deep_mlp_forward(ys, z_out, y0, rows, d, m, noise, drift, diffusion, TSDE_TRAJ_REVERSIBLE_HEUN, traj, times, entropy,
+                               elem0, entropy_dev, dtype, stream);
+}
+
+int tsde_deep_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
+                          const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, int method, const tsde_traj_t* traj,
+                          const void* times, uint64_t entropy, uint64_t elem0, const uint64_t* entropy_dev, int dtype,
+                          void* stream) {
+  const char* where = method == TSDE_TRAJ_REVERSIBLE_HEUN ? "tsde_rheun_mlp_forward" : "tsde_deep_mlp_forward";
+  if (method != TSDE_TRAJ_REVERSIBLE_HEUN && method != TSDE_TRAJ_EULER && method != TSDE_TRAJ_MIDPOINT &&
+      method != TSDE_TRAJ_HEUN && method != TSDE_TRAJ_EULER_HEUN)
+    return bad_arg(where, "method must be Euler, midpoint, Heun, Euler-Heun or reversible Heun");
   if (!ys || !y0) return bad_arg(where, "null argument");
   if (const char* bad = rheun_mlp_problem(rows, d, m, noise, drift, diffusion, traj, times, dtype)) return bad_arg(where, bad);
   const uintptr_t mask = d % 4 == 0 ? 15u : 3u;
@@ -905,7 +916,7 @@ int tsde_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, 
     return bad_arg(where, "ys, z_out and y0 must be 16-byte aligned (4-byte when d is not a multiple of 4)");
   const hipStream_t s = (hipStream_t)stream;
   ProfScope p(TSDE_KID_RHEUN_MLP, s, true);
-  const hipError_t e = tsde::launch_rheun_mlp_forward(ys, z_out, y0, rows, d, m, noise, drift, diffusion, traj, times,
+  const hipError_t e = tsde::launch_rheun_mlp_forward(ys, z_out, y0, rows, d, m, noise, drift, diffusion, method, traj, times,
                                                       make_key(entropy, elem0), entropy_dev, s);
   if (e == hipErrorInvalidValue) return bad_arg(where, "the weights of this shape do not fit the LDS of a CU");
   return fail(e, where);

@@ -124,10 +124,12 @@ static void fill_common(RheunArgs& p, int64_t rows, int64_t d, int64_t m, const 
 }
 
 hipError_t launch_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
-                                    const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* tr,
-                                    const void* times, NoiseKey key, const uint64_t* key_dev, hipStream_t s) {
+                                    const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, int method,
+                                    const tsde_traj_t* tr, const void* times, NoiseKey key, const uint64_t* key_dev,
+                                    hipStream_t s) {
   RheunArgs p;
   fill_common(p, rows, d, m, drift, diffusion, tr, times, key, key_dev);
+  p.method = method;
   p.ys = (float*)ys;
   p.z_out = (float*)z_out;
   p.y0 = (const float*)y0;

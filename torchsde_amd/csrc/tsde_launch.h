@@ -169,8 +169,9 @@ hipError_t launch_gram_partials(void* partials, void* colsums, const void* A, in
 hipError_t memset_nodes_to_kernels(hipGraph_t graph, int* n_memset, int* n_replaced);
 // neural_rheun.hip
 hipError_t launch_rheun_mlp_forward(void* ys, void* z_out, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
-                                    const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* tr,
-                                    const void* times, NoiseKey key, const uint64_t* key_dev, hipStream_t s);
+                                    const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, int method,
+                                    const tsde_traj_t* tr, const void* times, NoiseKey key, const uint64_t* key_dev,
+                                    hipStream_t s);
 hipError_t launch_rheun_mlp_backward(const tsde_rheun_state_t* state, const tsde_rheun_stash_t* stash, const void* ys_all,
                                      const void* grad_ys, int64_t rows, int64_t d, int64_t m, int noise,
                                      const tsde_deep_mlp_t* drift, const tsde_deep_mlp_t* diffusion, const tsde_traj_t* tr,

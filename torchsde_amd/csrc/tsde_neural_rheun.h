@@ -66,6 +66,7 @@ struct RheunArgs {
   int64_t B;
   int32_t d, m, n_steps, n_out;
   int32_t j_hi, j_lo;           // backward: this launch runs the evaluations j_hi, j_hi - 1, ..., j_lo
+  int32_t method;               // forward: TSDE_TRAJ_REVERSIBLE_HEUN, or one of the stateless schemes for the same nets
   NoiseKey key;
   const uint64_t* key_dev;
   RheunStash st;
@@ -609,13 +610,69 @@ __global__ void __launch_bounds__(256) neural_rheun_kernel(const RheunArgs p, co
 
     f32x4 dwa[NW], dwb[NW], f[TD], sa[TD], sb[TD];
     if constexpr (!BACKWARD) {
-      // ---- forward: reversible_heun.py:61-73 ---------------------------------------------------------------------------------
       f32x4 y[TD], z[TD], yp[TD], yprev[TD];
       load_state(p.y0, y);
 #pragma unroll
       for (int t = 0; t < TD; ++t) z[t] = yp[t] = yprev[t] = y[t];
       zero_w(dwa);
       int jout = 0;
+      if (p.method != TSDE_TRAJ_REVERSIBLE_HEUN) {
+        // ---- the schemes that carry no state, for the same (deep) nets: Euler (euler.py:29-37), midpoint (midpoint.py:29-45),
+        //      Heun (heun.py:35-48), Euler-Heun (euler_heun.py:29-42) in the stepwise route's operation order ------------------
+        f32x4 f2[TD], sa2[TD], x2[TD], y1[TD];
+        zero_w(dwb);
+        for (int k = 0; k < K; ++k) {
+          const float dt = p.rows[(int64_t)k * 8], hdt = p.rows[(int64_t)k * 8 + 1];
+          draw(p.cells[k], p.rows[(int64_t)k * 8 + 4], dwa);
+          evaluate(p.times[k], y, dwa, dwb, f, sa, sb, nullptr, nullptr, nullptr, nullptr, 0);
+          if (p.method == TSDE_TRAJ_EULER) {
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) y1[t][r] = (y[t][r] + f[t][r] * dt) + sa[t][r];
+            }
+          } else {
+            float t2 = p.times[k + 1];
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                x2[t][r] = p.method == TSDE_TRAJ_MIDPOINT ? (y[t][r] + f[t][r] * hdt) + 0.5f * sa[t][r]
+                           : p.method == TSDE_TRAJ_HEUN   ? (y[t][r] + dt * f[t][r]) + sa[t][r]
+                                                          : y[t][r] + sa[t][r];
+              }
+            }
+            if (p.method == TSDE_TRAJ_MIDPOINT) t2 = p.times[k] + 0.5f * dt;
+            evaluate(t2, x2, dwa, dwb, f2, sa2, sb, nullptr, nullptr, nullptr, nullptr, 0);
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                y1[t][r] = p.method == TSDE_TRAJ_MIDPOINT ? (y[t][r] + f2[t][r] * dt) + sa2[t][r]
+                           : p.method == TSDE_TRAJ_HEUN   ? y[t][r] + (((dt * (f[t][r] + f2[t][r])) + sa[t][r]) + sa2[t][r]) * 0.5f
+                                                          : (y[t][r] + dt * f[t][r]) + ((sa[t][r] + sa2[t][r]) * 0.5f);
+              }
+            }
+          }
+          while (jout < p.n_out && p.out_step[jout] == k + 1) {
+            const float w0 = p.out_w[2 * jout], w1 = p.out_w[2 * jout + 1];
+            const bool exact = w0 == 0.0f && w1 == 1.0f;
+            f32x4 o[TD];
+#pragma unroll
+            for (int t = 0; t < TD; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[t][r] = exact ? y1[t][r] : (w0 * y[t][r] + w1 * y1[t][r]);
+            }
+            store_state(p.ys + (int64_t)jout * p.B * dT, o);
+            ++jout;
+          }
+#pragma unroll
+          for (int t = 0; t < TD; ++t) y[t] = y1[t];
+        }
+        if (p.z_out != nullptr) store_state(p.z_out, y);
+        continue;
+      }
+      // ---- forward: reversible_heun.py:61-73 ---------------------------------------------------------------------------------
       for (int j = 0; j <= K; ++j) {
         const bool later = j < K, earlier = j > 0;
 #pragma unroll

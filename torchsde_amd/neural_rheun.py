@@ -119,9 +119,10 @@ def lds_bytes(d, m, drift, diffusion, noise):
                                                  diffusion.n_mid))
 
 
-def forward(ys, z_out, y0, drift, diffusion, noise, m, schedule, times, bm):
+def forward(ys, z_out, y0, drift, diffusion, noise, m, schedule, times, bm, method=_native.TRAJ_REVERSIBLE_HEUN):
     """All steps of reversible Heun in one launch (``tsde_rheun_mlp_forward``): `ys` (n_out, rows, d) the outputs of
-    `schedule`, `z_out` (rows, d) the scheme's second state after the last step; `times` (n_steps + 1) on the device."""
+    `schedule`, `z_out` (rows, d) the scheme's second state after the last step; `times` (n_steps + 1) on the device.
+    `method`: also Euler, midpoint, Heun, Euler-Heun for the same nets (``tsde_deep_mlp_forward``; `z_out`: the final state)."""
     rows, d = y0.shape
     _native.require_device(ys, y0, z_out, times)
     if ys.shape != (schedule.n_out, rows, d) or times.numel() != schedule.n_steps + 1:
@@ -131,10 +132,10 @@ def forward(ys, z_out, y0, drift, diffusion, noise, m, schedule, times, bm):
     lib, dt_code, stream = K._launch_env(y0)
     entropy_dev = bm._entropy_dev
     fs, gs = drift.struct(), diffusion.struct()
-    code = lib.tsde_rheun_mlp_forward(ys.data_ptr(), z_out.data_ptr(), y0.data_ptr(), rows, d, int(m), int(noise),
-                                      ctypes.byref(fs), ctypes.byref(gs), schedule.struct(), times.data_ptr(), bm._key,
-                                      bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
-    _native.check(code, "tsde_rheun_mlp_forward")
+    code = lib.tsde_deep_mlp_forward(ys.data_ptr(), z_out.data_ptr(), y0.data_ptr(), rows, d, int(m), int(noise),
+                                     ctypes.byref(fs), ctypes.byref(gs), int(method), schedule.struct(), times.data_ptr(),
+                                     bm._key, bm._elem0, None if entropy_dev is None else entropy_dev.data_ptr(), dt_code, stream)
+    _native.check(code, "tsde_deep_mlp_forward")
     return ys
 
 

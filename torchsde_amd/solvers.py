@@ -350,6 +350,11 @@ class BaseSDESolver:
         noise; additive noise: `_additive_code`), or None."""
         return None
 
+    def _deep_code(self):
+        """TSDE_TRAJ_* code of this scheme in the deep-network kernel (`tsde_deep_mlp_forward`: nets of up to four Linear
+        layers, LipSwish, a closing tanh; Euler, midpoint, Heun, Euler-Heun -- reversible Heun has its own route), or None."""
+        return None
+
     def _program_code(self):
         """TSDE_TRAJ_* code of this scheme in the expression-program kernel (`tsde_trajectory_prog_diag`: diagonal or scalar
         noise), or None."""
@@ -444,7 +449,7 @@ class BaseSDESolver:
         # the reference's Neural* problems, any of diagonal / scalar / general noise): Euler and midpoint
         elementwise = sde.noise_type == NOISE_TYPES.diagonal and self._trajectory_code() is not None
         networks = (sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar, NOISE_TYPES.general)
-                    and self._neural_code() is not None)
+                    and (self._neural_code() is not None or self._deep_code() is not None))
         # ... and any other elementwise code (several functions of the state summed / multiplied, scalar noise): expression
         # programs (recognise.RecognisedProgram), every scheme with an in-register form
         programs = sde.noise_type in (NOISE_TYPES.diagonal, NOISE_TYPES.scalar) and self._program_code() is not None
@@ -568,15 +573,27 @@ class BaseSDESolver:
                 if additive:
                     raise
                 found, spec = as_program(str(e))
-            if isinstance(found, (recognise.RecognisedProgram, recognise.RecognisedAdditive)) or spec[0] == "program_rows":
+            if isinstance(found, (recognise.RecognisedProgram, recognise.RecognisedAdditive)) \
+                    or getattr(found, "statements", None) is not None:       # (programs, additive tables, row-coupled systems)
                 pass
             elif found.neural:
                 if not networks or times is not None:
                     raise recognise.NotElementwise("drift and diffusion networks, but no neural-SDE kernel for this scheme")
-                spec = found.neural_spec(sde.noise_type)
+                try:
+                    if self._neural_code() is None:
+                        raise recognise.NotElementwise("no two-layer neural-SDE kernel for this scheme")
+                    spec = found.neural_spec(sde.noise_type)
+                except recognise.NotElementwise as e:
+                    # deeper nets, LipSwish, a closing tanh -- or a scheme only the deep kernel has (Heun, Euler-Heun)
+                    if self._deep_code() is None or y0.dtype != torch.float32:
+                        raise
+                    try:
+                        spec = found.deep_spec(sde.noise_type)
+                    except recognise.NotElementwise as e2:
+                        raise recognise.NotElementwise(f"{e}; as deeper networks: {e2}") from None
                 if tuple(bm.shape) != (y0.shape[0], spec[4]) or y0.numel() >= 2 ** 30:
                     return None
-                if precision == "bf16x3" and sde.noise_type == NOISE_TYPES.general:
+                if precision == "bf16x3" and sde.noise_type == NOISE_TYPES.general and spec[0] == "neural":
                     # opt-in: the diffusion net's second layer on split-bf16 products (csrc/mlp_general.hip SPLIT); NOT the
                     # reference's arithmetic -- the default, and everything benchmarked as such, stays exact f32
                     spec[2].precision = _native.PRECISION_BF16X3
@@ -636,7 +653,13 @@ class BaseSDESolver:
                     again = again[:3] + (spec[3],) + again[4:]
             else:
                 again = recognise.recognise(sde, ts[0], y0, times=times, rows=5)
-                again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
+                if spec[0] == "neural_rheun":
+                    again = again.deep_spec(sde.noise_type)
+                    same_nets = all(a.structure() == b.structure() and all(x is y for x, y in zip(a.parameters(), b.parameters()))
+                                    for a, b in zip(again[1:3], spec[1:3]))
+                    again = spec if (same_nets and again[3:] == spec[3:]) else again
+                else:
+                    again = again.neural_spec(sde.noise_type) if spec[0] == "neural" else again.spec()
                 if spec[0] == "neural":
                     again[2].precision = spec[2].precision
         except recognise.NotElementwise as e:
@@ -666,7 +689,7 @@ class BaseSDESolver:
                 return stepwise
             counter_rate = {name: v // n_steps for name, v in advanced.items()}
         rtol, atol = (1e-4, 1e-5) if y0.dtype == torch.float32 else (1e-9, 1e-11)
-        if spec[0] in ("mlp_diagonal", "neural", "neural_additive"):      # the matrix cores sum the layers' products in another order than the library
+        if spec[0] in ("mlp_diagonal", "neural", "neural_additive", "neural_rheun"):      # the matrix cores sum the layers' products in another order than the library
             rtol, atol = 1e-3, 1e-4
         both_nan = fast.isnan() & stepwise.isnan()
         close = ((fast - stepwise).abs() <= atol + rtol * stepwise.abs()) | both_nan | (fast == stepwise)
@@ -1081,6 +1104,16 @@ class BaseSDESolver:
             else:
                 K.trajectory_prog_additive(ys[1:], y0c, f_code, const_table, table, m, code, schedule, bm)
             return ys
+        if coefficients[0] == "neural_rheun":
+            # (a stateless scheme on the deep-network kernel, csrc/tsde_neural_rheun.h)
+            from . import neural_rheun
+            y0c = self._aligned_start(y0)
+            ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
+            ys[0].copy_(y0c)
+            times = neural_rheun._device_times(np.ascontiguousarray(grid.t, dtype=np.float32), y0.device)
+            neural_rheun.forward(ys[1:], torch.empty_like(y0c), y0c, coefficients[1], coefficients[2], coefficients[3],
+                                 coefficients[4], schedule, times, bm, method=self._deep_code())
+            return ys
         if coefficients[0] == "neural":
             y0c = self._aligned_start(y0)
             ys = torch.empty((len(grid.outputs) + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device)
@@ -1238,6 +1271,9 @@ class Euler(BaseSDESolver):
     def _neural_code(self):
         return _native.TRAJ_EULER
 
+    def _deep_code(self):
+        return _native.TRAJ_EULER
+
     def _program_code(self):
         return _native.TRAJ_EULER
 
@@ -1264,6 +1300,9 @@ class Midpoint(BaseSDESolver):
         return _native.TRAJ_MIDPOINT if self._diag() else None
 
     def _neural_code(self):
+        return _native.TRAJ_MIDPOINT
+
+    def _deep_code(self):
         return _native.TRAJ_MIDPOINT
 
     def _program_code(self):
@@ -1573,6 +1612,9 @@ class _TwoStageStratonovich(BaseSDESolver):
 
     def _program_code(self):
         return _native.TRAJ_HEUN if self.mode == 0 else _native.TRAJ_EULER_HEUN
+
+    def _deep_code(self):
+        return self._program_code()
 
     def _advance(self, y0, st, out):
         sde, dt, noise = self.sde, st.dt, st.noise
