@@ -100,6 +100,7 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "lorenz_srk_default_route_b1024_d3_s1000", "lorenz_srk_b1024_d3_s1000",
         # the reversible pair on the matrix cores, beside its stepwise twins
         "sdegan_rheun_adjoint_default_route_b1024_d16_m3_s63", "sdegan_rheun_adjoint_b1024_d16_m3_s63",
+        "sdegan_midpoint_default_route_b16384_d16_m3_s1000", "sdegan_midpoint_b16384_d16_m3_s1000",
         "c3_rheun_general_default_route_b16384_d32_m16", "c3_rheun_general_b16384_d32_m16",
         "c3_rheun_adjoint_general_default_route_b16384_d32_m16", "c3_rheun_adjoint_general_b16384_d32_m16")
 

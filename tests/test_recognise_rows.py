@@ -121,3 +121,27 @@ def test_more_than_eight_channels_is_refused():
             return 0.1 * y
     with pytest.raises(NotElementwise, match="more than 8"):
         recognise_rows.recognise_rows(ForwardSDE(Wide()), torch.tensor(0.0), torch.randn(6, 9))
+
+
+def test_side_effects_end_the_column_interpretation_too():
+    class Counts(nn.Module):
+        noise_type, sde_type = "diagonal", "ito"
+
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("nfe", torch.zeros(()))
+
+        def f(self, t, y):
+            self.nfe.add_(1)
+            return torch.cat([y[:, 1:], y[:, :1]], dim=1)
+
+        def g(self, t, y):
+            return 0.3 * y
+
+    class Noisy(Counts):
+        def f(self, t, y):
+            return torch.cat([y[:, 1:], y[:, :1]], dim=1) + 0.0 * torch.randn(y.shape[1])
+    with pytest.raises(NotElementwise, match="existed before"):
+        recognise_rows.recognise_rows(ForwardSDE(Counts()), torch.tensor(0.0), torch.randn(6, 3))
+    with pytest.raises(NotElementwise, match="random"):
+        recognise_rows.recognise_rows(ForwardSDE(Noisy()), torch.tensor(0.0), torch.randn(6, 3))

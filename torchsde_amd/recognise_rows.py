@@ -43,6 +43,7 @@ class _Columns(TorchDispatchMode):
         self.t_id = id(t)
         self.flat = set()           # ids of tracked values of shape (rows,) (a column without its unit axis)
         self.scalar_like = set()    # ids of 0-d functions of t (they broadcast against either kind)
+        self.made = {id(y), id(t)}  # ids of tensors whose storage was allocated during the interpretation
         self.differentiable = False
 
     def track(self, tensor, cols, flat=False):
@@ -79,6 +80,37 @@ class _Columns(TorchDispatchMode):
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        self.check_side_effects(func, args, kwargs)
+        out = self.follow(func, args, kwargs)
+        returns = func._schema.returns
+        outs = out if isinstance(out, (list, tuple)) else (out,)
+        for k, o in enumerate(outs):
+            if torch.is_tensor(o) and id(o) not in self.made:
+                aliasing = k < len(returns) and returns[k].alias_info is not None
+                if not aliasing or (args and torch.is_tensor(args[0]) and id(args[0]) in self.made):
+                    self.made.add(id(o))
+                    self.keep.append(o)
+        return out
+
+    def check_side_effects(self, func, args, kwargs):
+        """As recognise._Interpreter.check_side_effects: the code runs once per solve here, once per step in the reference
+        (base_solver.py:114-149) -- random draws and in-place writes to tensors that existed before the call end the
+        interpretation."""
+        schema = func._schema
+        if torch.Tag.nondeterministic_seeded in func.tags:
+            raise NotElementwise(f"{schema.name} draws random numbers: once per solve here, once per step in the reference")
+        if not schema.is_mutable:
+            return
+        for i, arg in enumerate(schema.arguments):
+            if arg.alias_info is None or not arg.alias_info.is_write:
+                continue
+            value = args[i] if i < len(args) else kwargs.get(arg.name)
+            for x in (value if isinstance(value, (list, tuple)) else (value,)):
+                if torch.is_tensor(x) and id(x) not in self.made:
+                    raise NotElementwise(f"in-place {schema.name} on a tensor that existed before f and g were called "
+                                         "(state that outlives the call: once per solve here, once per step in the reference)")
+
+    def follow(self, func, args, kwargs):
         schema = func._schema
         name = schema.name.split("::")[1]
         flat_args = list(args) + list(kwargs.values())

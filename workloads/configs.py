@@ -372,6 +372,16 @@ WORKLOADS = {
         problem="sdegan_generator", method="reversible_heun", adjoint_method="adjoint_reversible_heun", levy="none", B=1024,
         d=16, m=3, nsteps=63, dt=1.0, output_every_step=True, kid=0, launches_per_step=2, adjoint=True,
         bytes_per_traj_step=0, kernel="stepwise pair: tsde_step_general_w + torch ops + autograd VJPs of the user's nets"),
+    # ... sampling from the same generator with the Stratonovich default of `sdeint`, midpoint (sdeint.py:155), 16384 paths:
+    # tsde_deep_mlp_forward (the reversible-Heun kernel's evaluation under a stateless scheme); stepwise twin below
+    "sdegan_midpoint_default_route_b16384_d16_m3_s1000": dict(
+        problem="sdegan_generator", method="midpoint", levy="none", B=16384, d=16, m=3, nsteps=1000, dt=2.0 ** -10,
+        kid=13, trajectory=True, recognised=True, mfma_flops_per_traj_step=2 * 2 * (16 * 32 + 32 * 16 + 16 * 32 + 32 * 16 * 4),
+        kernel="tsde_deep_mlp_forward<16, 32, general m <= 4, midpoint> (LipSwish nets closed by tanh; flops of the padded tiles)"),
+    "sdegan_midpoint_b16384_d16_m3_s1000": dict(
+        problem="sdegan_generator", method="midpoint", levy="none", B=16384, d=16, m=3, nsteps=1000, dt=2.0 ** -10,
+        bytes_per_traj_step=2 * 4 * (16 * 3 + 3 * 16), kid=0, launches_per_step=2, bench_steps=200,
+        kernel="tsde_step_general<float> x2 per step (user nets: ~30 torch kernels per step)"),
     # ... and at the BASELINE configs[2] shape (NeuralGeneral-style nets, hidden 64): sampling, then forward + backward
     "c3_rheun_general_default_route_b16384_d32_m16": dict(
         problem="general_big_strat", method="reversible_heun", levy="none", B=16384, d=32, m=16, nsteps=1000, dt=2.0 ** -10,
