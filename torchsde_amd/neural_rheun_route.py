@@ -70,15 +70,19 @@ def plan(solver, y0, ts, differentiable, need_boundaries=False, tag=()):
 
     def state_of():
         return ("assumed pure",) if assume_pure else graph.python_state(base)
-    state = state_of()
     who = (chain, type(solver).__name__ + (":kernels, with gradients" if differentiable else ":kernels"))
-    if state is None or (state,) + who in book["refused"]:
-        return None
+    state = None                 # (the fingerprint costs ~0.8 ms: taken only when there is a refusal to look up or to file)
+    if book["refused"]:
+        state = state_of()
+        if state is None or (state,) + who in book["refused"]:
+            return None
 
     def refuse(reason):
-        if len(book["refused"]) >= 16:
-            book["refused"].clear()
-        book["refused"][(state,) + who] = reason
+        key_state = state if state is not None else state_of()
+        if key_state is not None:
+            if len(book["refused"]) >= 16:
+                book["refused"].clear()
+            book["refused"][(key_state,) + who] = reason
         return None
     try:
         found = recognise.recognise(sde, ts[0], y0, differentiable=differentiable)
@@ -125,6 +129,10 @@ def plan(solver, y0, ts, differentiable, need_boundaries=False, tag=()):
     if not trusted:
         # the verifying solve: a second interpretation on a probe of another height must find the same nets over the same
         # tensors, and the calls must leave the object's Python-side state and the random generators alone
+        if state is None:
+            state = state_of()
+            if state is None:
+                return None
         rng_before = solver._rng_states(y0.device)
         try:
             again = recognise.recognise(sde, ts[0], y0, differentiable=differentiable, rows=5).deep_spec(sde.noise_type)
