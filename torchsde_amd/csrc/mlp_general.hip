@@ -48,6 +48,7 @@ struct NeuralNet {          // device view of tsde_mlp_t (pointers as given: inp
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct NeuralArgs {
   int32_t split;            // 1: the diffusion net's second layer on split-bf16 products (opt-in; see the kernel)
@@ -114,9 +115,19 @@ template <int D, int H>
 struct NeuralLds {
   static constexpr int S1 = H + 4, S2F = D + 4;
   static constexpr int out_padded(int out, int group) { return (out + 16 * group - 1) / (16 * group) * (16 * group); }
-  static constexpr size_t floats(int outp) {
-    return (size_t)2 * D * S1 + (size_t)H * S2F + (size_t)H * (outp + 4) + 4 * H + D + outp;
-  }
+};
+
+// General noise, exact f32: the diffusion net's second layer sits in LDS with the two tiles of a PAIR interleaved -- element
+// (unit u, output o = 16 tile + c) at u * stride + 32 (tile / 2) + 2 c + (tile & 1) -- so that a lane's two A operands of a
+// unit are ONE ds_read_b64, and with a row stride of 8 (mod 16) floats: a b64 read is served in two halves of 32 lanes, the two
+// lane quarters of a half read units 4 apart, 4 * stride = 32 (mod 64) banks puts them on the two halves of the banks.
+// For D <= 32 the stride is D * M + 8 whatever the real width: every row offset of the products is then an immediate of the
+// read (the address arithmetic between the matrix instructions cost more than the reads: profiles/r6_microbench_mfma_fillers.txt).
+template <int D, int MODE, bool SPLIT>
+struct PairLayout {
+  static constexpr bool kOn = MODE >= 4 && !SPLIT;
+  static constexpr bool kFixed = kOn && D <= 32;
+  static constexpr int kPad = kOn ? 8 : 4;
 };
 
 // SPLIT (opt-in, `options={"matrix_precision": "bf16x3"}`; general noise, H = 64): the diffusion net's SECOND layer -- 512 of
@@ -132,12 +143,16 @@ struct NeuralLds {
 // drawn element by element; a separate instantiation, so that the common one carries no call and no second path (the SRK
 // body keeps ~300 registers live across the draws).
 template <int D, int H, int MODE, bool SPLIT = false, bool GENERIC = false>
-__global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
+__global__ void __launch_bounds__(256, MODE >= 4 ? 2 : 1) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
+  // (general noise asks the compiler for at most 256 registers: it then keeps the accumulators in ordinary registers; with the
+  //  512 of one wave per SIMD it parks them in the accumulation file and every tile pays eight copies out and back)
   using NS = NoiseShape<MODE>;
   static_assert(!SPLIT || (NS::kGeneral && H == 64), "split mode: general noise, 64 hidden units");
   using L = NeuralLds<D, H>;
+  using PL = PairLayout<D, MODE, SPLIT>;
+  static_assert(!PL::kOn || NS::G == 2, "pairs of tiles");
   constexpr int TD = D / 16, TH = H / 16, S1 = L::S1, S2F = L::S2F, M = NS::M, G = NS::G;
-  const int S2G = outp + 4;
+  const int S2G = PL::kFixed ? D * M + PL::kPad : outp + PL::kPad;
   extern __shared__ float lds[];
   float* W1f = lds;                     // D rows of S1:  [input channel][hidden unit]
   float* W1g = W1f + D * S1;
@@ -180,6 +195,8 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
       const __bf16 hi = (__bf16)w;
       W2hi[(size_t)o * H + 8 * chunk + 4 * tt + r] = hi;
       W2lo[(size_t)o * H + 8 * chunk + 4 * tt + r] = (__bf16)(w - (float)hi);
+    } else if constexpr (PL::kOn) {
+      W2g[u * S2G + 32 * (o >> 5) + 2 * (o & 15) + ((o >> 4) & 1)] = w;
     } else {
       W2g[u * S2G + o] = w;
     }
@@ -310,7 +327,9 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
     };
 
     // (g dW)^T in the state's layout, from the diffusion net's hidden activations
-    auto diffusion_product = [&](const f32x4* hid, uint32_t cell, float sw, f32x4* gdw) {
+    // (the closing function is uniform over the launch: `closing` carries it as a type, one scalar branch per evaluation)
+    auto diffusion_product_as = [&](const f32x4* hid, uint32_t cell, float sw, f32x4* gdw, auto closing) {
+      constexpr bool sigmoid_out = decltype(closing)::value;
 #pragma unroll
       for (int t = 0; t < TD; ++t) gdw[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if constexpr (NS::kGeneral) {
@@ -349,23 +368,48 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
             }
           }
         }
+        // what one lane does with a finished tile: its four outputs are four Brownian channels of ONE state channel of its row
+        auto close_tile = [&](const f32x4 acc, const f32x4 bias, int tl, int g, int tiles, float& s, float& sel) {
+          int target, q;
+          if constexpr (M >= 16) {
+            target = tl / (M / 16);
+            q = (M == 16) ? 0 : g;                                           // (G = M / 16 tiles per channel for M >= 32)
+          } else if constexpr (M == 8) {
+            target = 2 * tl + (part >> 1);
+            q = 0;
+          } else {
+            target = 4 * tl + part;
+            q = 0;
+          }
+          s = 0.0f;
+          if constexpr (sigmoid_out) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = __builtin_amdgcn_exp2f(fmaf(acc[r], kNegLog2e, bias[r]));      // exp(-(acc + b2))
+              s = fmaf(__builtin_amdgcn_rcpf(1.0f + e), dw[q][r], s);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(acc[r] + bias[r], dw[q][r], s);
+          }
+          sel = (n == target && tl < tiles) ? 1.0f : 0.0f;
+        };
 #pragma unroll
         for (int ty = 0; ty < TD; ++ty) {
           const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;        // real state channels of this tile (wave-uniform)
           if (channels <= 0) continue;
           const int tiles = (channels * M + 15) / 16;                        // G^T tiles that feed them
-          for (int p0 = 0; p0 < tiles; p0 += G) {
-            f32x4 acc[G];
+          if constexpr (SPLIT) {
+            for (int p0 = 0; p0 < tiles; p0 += G) {
+              f32x4 acc[G];
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const int col0 = 16 * (ty * M + p0) + n;                         // output column of tile p0 for this lane
-            // the tiles' output biases are requested BEFORE the matrix products (they used to be read, and waited for, in
-            // the epilogue: two exposed LDS round trips per group of tiles)
-            f32x4 bias[G];
+              for (int g = 0; g < G; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+              // the tiles' output biases are requested BEFORE the matrix products (they used to be read, and waited for, in
+              // the epilogue: two exposed LDS round trips per group of tiles)
+              f32x4 bias[G];
 #pragma unroll
-            for (int g = 0; g < G; ++g) bias[g] = lds_quad(b2g, 16 * (ty * M + p0 + g) + 4 * part);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (SPLIT) {
+              for (int g = 0; g < G; ++g) bias[g] = lds_quad(b2g, 16 * (ty * M + p0 + g) + 4 * part);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int b = 0; b < H / 32; ++b) {
 #pragma unroll
@@ -379,49 +423,87 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
                   acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, hid_hi[b], acc[g], 0, 0, 0);
                 }
               }
-            } else {
 #pragma unroll
-              for (int th = 0; th < TH; ++th) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                  for (int g = 0; g < G; ++g) {
-                    const float a = W2g[(16 * th + 4 * part + r) * S2G + col0 + 16 * g];
-                    acc[g] = Tile<16>::mfma(a, hid[th][r], acc[g]);
-                  }
-                }
+              for (int g = 0; g < G; ++g) {
+                float s, sel;
+                close_tile(acc[g], bias[g], p0 + g, g, tiles, s, sel);
+                gdw[ty] = Tile<16>::mfma(sel, s, gdw[ty]);
               }
-              reads_ahead<TH * 4 * G / 2, 2>();
+            }
+          } else {
+            // Exact f32, pair by pair, one stage of software pipelining (one wave per SIMD: nothing else hides a wait, and a
+            // vector instruction between two matrix instructions costs three times its own issue --
+            // profiles/r6_microbench_mfma_fillers.txt). Per pair: [the PREVIOUS pair's two selector products + 2 NR products,
+            // the operand reads (ds_read_b64, immediate row offsets) running kAhead ahead] [the NEXT pair's first kAhead operands
+            // and its output biases requested] [this pair's closing arithmetic, unbroken].
+            constexpr int NR = TH * 4, kAhead = 4;
+            // (the operands' LDS addresses as two opaque 32-bit bases -- units 0..31 and 32..63 of this lane's pair -- so that
+            //  every row offset is an immediate of its read: left to itself hipcc folds the array's own offset into the
+            //  immediates, overflows their 16 bits and repairs that with additions between the matrix instructions)
+            typedef const __attribute__((address_space(3))) f32x2* lds_pair_t;
+            typedef const __attribute__((address_space(3))) float* lds_float_t;
+            uint32_t lo = (uint32_t)(uintptr_t)(lds_float_t)(W2g + (4 * part) * S2G + 32 * ((ty * M) >> 1) + 2 * n);
+            uint32_t up = lo + (uint32_t)(32 * S2G * sizeof(float));
+            asm volatile("" : "+v"(lo), "+v"(up));
+            const float* bq = b2g + 16 * (ty * M) + 4 * part;
+            auto operand = [&](int i) {
+              const int th = i >> 2, r = i & 3;
+              const uint32_t at = th < 2 ? lo + (uint32_t)((16 * th + r) * S2G * sizeof(float))
+                                         : up + (uint32_t)((16 * (th - 2) + r) * S2G * sizeof(float));
+              return *(lds_pair_t)(uintptr_t)at;
+            };
+            f32x2 ahead[kAhead];
+            f32x4 bias_next[G];
+#pragma unroll
+            for (int i = 0; i < kAhead; ++i) ahead[i] = operand(i);
+#pragma unroll
+            for (int g = 0; g < G; ++g) bias_next[g] = *reinterpret_cast<const f32x4*>(bq + 16 * g);
+            float s_prev[G], sel_prev[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) s_prev[g] = sel_prev[g] = 0.0f;
+            for (int p0 = 0; p0 < tiles; p0 += G) {
+              f32x4 acc[G], bias[G];
+              f32x2 a[NR];
+#pragma unroll
+              for (int g = 0; g < G; ++g) {
+                acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                bias[g] = bias_next[g];
+              }
+#pragma unroll
+              for (int i = 0; i < kAhead; ++i) a[i] = ahead[i];
+              __builtin_amdgcn_sched_barrier(0);
+              gdw[ty] = Tile<16>::mfma(sel_prev[0], s_prev[0], gdw[ty]);
+#pragma unroll
+              for (int i = kAhead; i < NR; ++i) a[i] = operand(i);
+#pragma unroll
+              for (int i = 0; i < NR; ++i) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = Tile<16>::mfma(a[i][g], hid[i >> 2][i & 3], acc[g]);
+              }
+              gdw[ty] = Tile<16>::mfma(sel_prev[1], s_prev[1], gdw[ty]);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+              for (int i = kAhead; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, kAhead * G + 1, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              lo += 32 * sizeof(float);
+              up += 32 * sizeof(float);
+              bq += 32;
+              asm volatile("" : "+v"(lo), "+v"(up));
+#pragma unroll
+              for (int i = 0; i < kAhead; ++i) ahead[i] = operand(i);
+#pragma unroll
+              for (int g = 0; g < G; ++g) bias_next[g] = *reinterpret_cast<const f32x4*>(bq + 16 * g);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int g = 0; g < G; ++g) close_tile(acc[g], bias[g], p0 + g, g, tiles, s_prev[g], sel_prev[g]);
+              __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-              const int tl = p0 + g;                                         // tile within this state tile
-              // which state channel (within the tile) this lane's four outputs belong to, and which of its quads they meet
-              int target, q;
-              if constexpr (M >= 16) {
-                target = tl / (M / 16);
-                q = (M == 16) ? 0 : g;                                       // (G = M / 16 tiles per channel for M >= 32)
-              } else if constexpr (M == 8) {
-                target = 2 * tl + (part >> 1);
-                q = 0;
-              } else {
-                target = 4 * tl + part;
-                q = 0;
-              }
-              float s = 0.0f;
-              if (sigmoid_out) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float e = __builtin_amdgcn_exp2f(fmaf(acc[g][r], kNegLog2e, bias[g][r]));      // exp(-(acc + b2))
-                  s = fmaf(__builtin_amdgcn_rcpf(1.0f + e), dw[q][r], s);
-                }
-              } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(acc[g][r] + bias[g][r], dw[q][r], s);
-              }
-              const float sel = (n == target && tl < tiles) ? 1.0f : 0.0f;
-              gdw[ty] = Tile<16>::mfma(sel, s, gdw[ty]);
-            }
+            for (int g = 0; g < G; ++g) gdw[ty] = Tile<16>::mfma(sel_prev[g], s_prev[g], gdw[ty]);
           }
         }
       } else {
@@ -474,6 +556,11 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
           }
         }
       }
+    };
+
+    auto diffusion_product = [&](const f32x4* hid, uint32_t cell, float sw, f32x4* gdw) {
+      if (sigmoid_out) diffusion_product_as(hid, cell, sw, gdw, std::true_type{});
+      else diffusion_product_as(hid, cell, sw, gdw, std::false_type{});
     };
 
     // diagonal / scalar noise: the diffusion VALUES g (one per state channel) of a net evaluation, and the step's increments
@@ -785,8 +872,9 @@ __global__ void __launch_bounds__(256) neural_trajectory_kernel(const NeuralArgs
   }
 }
 
-size_t neural_lds_bytes(int D, int H, int outp) {
-  return ((size_t)2 * D * (H + 4) + (size_t)H * (D + 4) + (size_t)H * (outp + 4) + 4 * H + D + outp) * sizeof(float);
+size_t neural_lds_bytes(int D, int H, int outp, int pad) {
+  // (+ 32: the general-noise pipeline requests the output biases of the pair after the last one)
+  return ((size_t)2 * D * (H + 4) + (size_t)H * (D + 4) + (size_t)H * (outp + pad) + 4 * H + D + outp + 32) * sizeof(float);
 }
 
 static size_t neural_lds_limit() {
@@ -805,9 +893,11 @@ static hipError_t launch_neural_mode(const NeuralArgs& p, hipStream_t s) {
   if constexpr (!SPLIT && NoiseShape<MODE>::kGeneral && H == 64) {
     if (p.split) return launch_neural_mode<D, H, MODE, true>(p, s);
   }
-  const int outp = NoiseShape<MODE>::kGeneral ? NeuralLds<D, H>::out_padded(p.d * MODE, NoiseShape<MODE>::G)
-                                               : NeuralLds<D, H>::out_padded(p.g.out, 1);
-  const size_t lds_bytes = neural_lds_bytes(D, H, outp);
+  using PL = PairLayout<D, MODE, SPLIT>;
+  const int outp = PL::kFixed ? D * MODE
+                   : NoiseShape<MODE>::kGeneral ? NeuralLds<D, H>::out_padded(p.d * MODE, NoiseShape<MODE>::G)
+                                                : NeuralLds<D, H>::out_padded(p.g.out, 1);
+  const size_t lds_bytes = neural_lds_bytes(D, H, outp, PL::kPad);
   if (lds_bytes > neural_lds_limit()) return hipErrorInvalidValue;
   static bool configured = false;   // per instantiation
   if (!configured) {
@@ -877,15 +967,16 @@ size_t neural_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t ou
   const int64_t h = hf > hg ? hf : hg;
   const int H = h <= 32 ? 32 : h <= 64 ? 64 : (h <= 128 && noise != TSDE_NOISE_GENERAL) ? 128 : 0;
   if (D == 0 || H == 0) return 0;
-  int group = 1;
+  int group = 1, pad = 4;
   if (noise == TSDE_NOISE_GENERAL) {
     if (m < 1 || m > 32) return 0;
     const int64_t M = m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : 32;
     group = M >= 32 ? (int)M / 16 : 2;
-    out = d * M;
+    out = (D <= 32 ? D : d) * M;          // (PairLayout: a fixed stride up to 32 state channels; the split mode is no larger)
+    pad = 8;
   }
   const int outp = (int)((out + 16 * group - 1) / (16 * group) * (16 * group));
-  return neural_lds_bytes(D, H, outp);
+  return neural_lds_bytes(D, H, outp, pad);
 }
 
 hipError_t launch_trajectory_mlp_general(void* ys, const void* y0, int64_t rows, int64_t d, int64_t m, int noise,
