@@ -15,11 +15,14 @@ static size_t rheun_lds_limit() {
 }
 
 // (general noise: a multiple of 32 -- the kernel takes the diffusion's output tiles two at a time)
-static int rheun_outp(int d, int out, int mode) { return mode >= 4 ? (d * mode + 31) / 32 * 32 : (out + 15) / 16 * 16; }
+// (up to 32 state channels the padded width D * mode: the kernels' row stride is then a compile-time constant)
+static int rheun_outp(int D, int d, int out, int mode) {
+  return mode >= 4 ? ((D <= 32 ? D : d) * mode + 31) / 32 * 32 : (out + 15) / 16 * 16;
+}
 
 template <int D, int H, int MODE, bool BACKWARD>
 static hipError_t launch_rheun_mode(const RheunArgs& p, hipStream_t s) {
-  const int outp = rheun_outp(p.d, p.g.out, MODE);
+  const int outp = rheun_outp(D, p.d, p.g.out, MODE);
   const size_t lds_bytes = rheun_lds_floats(D, H, outp, p.f.n_mid, p.g.n_mid) * sizeof(float);
   if (lds_bytes > rheun_lds_limit()) return hipErrorInvalidValue;
   static bool configured = false;   // per instantiation
@@ -79,7 +82,7 @@ size_t rheun_footprint(int64_t d, int64_t m, int64_t hf, int64_t hg, int64_t out
     mode = m <= 4 ? 4 : 16;
   }
   if (mode < 0) return 0;
-  return rheun_lds_floats(D, H, rheun_outp((int)d, (int)out, mode), nmf, nmg) * sizeof(float);
+  return rheun_lds_floats(D, H, rheun_outp(D, (int)d, (int)out, mode), nmf, nmg) * sizeof(float);
 }
 
 static DeepNet deep_view(const tsde_deep_mlp_t* n) {

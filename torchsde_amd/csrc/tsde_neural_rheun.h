@@ -121,21 +121,32 @@ TSDE_D void final_act(float x, float& value, float& slope) {
 }
 
 // LDS floats of a shape: both first layers, the hidden-to-hidden layers, both last layers, every bias
+// (the diffusion's last layer: rows padded by 8 and 32 floats of slack behind the output biases -- what the forward kernel's
+//  paired layout and its one-pair-ahead requests need, see `kPaired`; the backward kernel pads by 4 and leaves the rest unused)
 inline size_t rheun_lds_floats(int D, int H, int outp, int nmf, int nmg) {
   const size_t S1 = H + 4;
-  return (size_t)2 * D * S1 + (size_t)(nmf + nmg) * H * S1 + (size_t)H * (D + 4) + (size_t)H * (outp + 4) + (size_t)4 * H +
-         (size_t)(nmf + nmg) * H + D + outp;
+  return (size_t)2 * D * S1 + (size_t)(nmf + nmg) * H * S1 + (size_t)H * (D + 4) + (size_t)H * (outp + 8) + (size_t)4 * H +
+         (size_t)(nmf + nmg) * H + D + outp + 32;
 }
 
 // MODE: 0 = diagonal noise, 1 = scalar noise, else general noise with the Brownian channels padded to MODE (4 or 16).
 template <int D, int H, int MODE, bool BACKWARD>
-__global__ void __launch_bounds__(256) neural_rheun_kernel(const RheunArgs p, const int outp) {
+__global__ void __launch_bounds__(256, (!BACKWARD && D <= 32) ? 2 : 1) neural_rheun_kernel(const RheunArgs p, const int outp) {
+  // (forward, up to 32 state channels: at most 256 registers asked of the compiler, which then keeps the accumulators in
+  //  ordinary registers instead of copying every tile out of the accumulation file -- cf. mlp_general.hip)
   constexpr bool kGeneral = MODE >= 4;
   static_assert(MODE == 0 || MODE == 1 || MODE == 4 || MODE == 16, "diagonal, scalar, or general noise in tiles of 4 / 16 channels");
   constexpr int M = kGeneral ? MODE : 1;
   constexpr int kQuads = M >= 16 ? M / 16 : 1;
   constexpr int TD = D / 16, TH = H / 16, S1 = H + 4, S2F = D + 4;
-  const int S2G = outp + 4;
+  // general noise, forward: the two tiles of a PAIR interleaved in the diffusion's last layer -- element (unit u, output
+  // o = 16 tile + c) at u * S2G + 32 (tile / 2) + 2 c + (tile & 1), rows padded by 8 -- one ds_read_b64 per unit and pair,
+  // conflict-free (mlp_general.hip, PairLayout); the backward kernel reads the same weights transposed, four consecutive
+  // outputs at a time, and keeps them in output order. Up to 32 state channels the stride is a compile-time constant
+  // (the launcher passes outp = D * M), so every row offset is an immediate of its read.
+  constexpr bool kPaired = kGeneral && !BACKWARD;
+  constexpr int kPad = kPaired ? 8 : 4;
+  const int S2G = (kGeneral && D <= 32) ? D * M + kPad : outp + kPad;
   const int nmf = p.f.n_mid, nmg = p.g.n_mid;
   extern __shared__ float lds[];
   float* cur = lds;
@@ -196,7 +207,8 @@ __global__ void __launch_bounds__(256) neural_rheun_kernel(const RheunArgs p, co
       have = ci < dT && cj < p.m;
       src = ci * p.m + cj;
     }
-    W2g[u * S2G + o] = (u < hg && have) ? p.g.w2[(int64_t)u * outT + src] : 0.0f;
+    const int at = kPaired ? 32 * (o >> 5) + 2 * (o & 15) + ((o >> 4) & 1) : o;
+    W2g[u * S2G + at] = (u < hg && have) ? p.g.w2[(int64_t)u * outT + src] : 0.0f;
   }
   for (int i = threadIdx.x; i < H; i += 256) {
     b1f[i] = i < hf ? p.f.b1[i] : 0.0f;
@@ -474,8 +486,111 @@ __global__ void __launch_bounds__(256) neural_rheun_kernel(const RheunArgs p, co
           stash(p.st.wa, p.st.sm, e, dwa, kQuads);          // (tile q of the stash row = channels 16 q + 4 part + r)
           stash(p.st.wb, p.st.sm, e, dwb, kQuads);
         }
+        if constexpr (!BACKWARD) {
+          // Forward: pair by pair with one stage of software pipelining, as in mlp_general.hip -- per pair [the PREVIOUS pair's
+          // four selector products and 2 NR products, the operand reads kAhead ahead] [the NEXT pair's first operands and output
+          // biases requested] [this pair's closing arithmetic, unbroken]; the closing function is a type here (one scalar
+          // branch per evaluation instead of one per output).
+          auto pairs = [&](auto kind) {
+            constexpr int FINAL = decltype(kind)::value;
+            constexpr int NR = TH * 4, kAhead = 4;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(3))) f32x2* lds_pair_t;
+            typedef const __attribute__((address_space(3))) float* lds_float_t;
 #pragma unroll
-        for (int ty = 0; ty < TD; ++ty) {
+            for (int ty = 0; ty < TD; ++ty) {
+              const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;
+              if (channels <= 0) continue;
+              const int tiles = (channels * M + 15) / 16;
+              uint32_t lo = (uint32_t)(uintptr_t)(lds_float_t)(W2g + (4 * part) * S2G + 32 * ((ty * M) >> 1) + 2 * n);
+              uint32_t up = lo + (uint32_t)(32 * S2G * sizeof(float));
+              asm volatile("" : "+v"(lo), "+v"(up));
+              const float* bq = b2g + 16 * (ty * M) + 4 * part;
+              auto operand = [&](int i) {
+                const int th = i >> 2, r = i & 3;
+                const uint32_t at = th < 2 ? lo + (uint32_t)((16 * th + r) * S2G * sizeof(float))
+                                           : up + (uint32_t)((16 * (th - 2) + r) * S2G * sizeof(float));
+                return *(lds_pair_t)(uintptr_t)at;
+              };
+              f32x2 ahead[kAhead];
+              f32x4 bias_next[2];
+#pragma unroll
+              for (int i = 0; i < kAhead; ++i) ahead[i] = operand(i);
+#pragma unroll
+              for (int g = 0; g < 2; ++g) bias_next[g] = *reinterpret_cast<const f32x4*>(bq + 16 * g);
+              float a_prev[2], b_prev[2], sel_prev[2];
+#pragma unroll
+              for (int g = 0; g < 2; ++g) a_prev[g] = b_prev[g] = sel_prev[g] = 0.0f;
+              for (int tl = 0; tl < tiles; tl += 2) {
+                f32x4 acc[2], bias[2];
+                f32x2 a[NR];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                  bias[g] = bias_next[g];
+                }
+#pragma unroll
+                for (int i = 0; i < kAhead; ++i) a[i] = ahead[i];
+                __builtin_amdgcn_sched_barrier(0);
+                sa[ty] = Tile<16>::mfma(sel_prev[0], a_prev[0], sa[ty]);
+                sb[ty] = Tile<16>::mfma(sel_prev[0], b_prev[0], sb[ty]);
+#pragma unroll
+                for (int i = kAhead; i < NR; ++i) a[i] = operand(i);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+#pragma unroll
+                  for (int g = 0; g < 2; ++g) acc[g] = Tile<16>::mfma(a[i][g], top[i >> 2][i & 3], acc[g]);
+                }
+                sa[ty] = Tile<16>::mfma(sel_prev[1], a_prev[1], sa[ty]);
+                sb[ty] = Tile<16>::mfma(sel_prev[1], b_prev[1], sb[ty]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                for (int i = kAhead; i < NR; ++i) {
+                  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, kAhead * 2 + 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                lo += 32 * sizeof(float);
+                up += 32 * sizeof(float);
+                bq += 32;
+                asm volatile("" : "+v"(lo), "+v"(up));
+#pragma unroll
+                for (int i = 0; i < kAhead; ++i) ahead[i] = operand(i);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) bias_next[g] = *reinterpret_cast<const f32x4*>(bq + 16 * g);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  const bool live = g == 0 || tl + 1 < tiles;
+                  const int target = M >= 16 ? tl + g : 4 * (tl + g) + part;
+                  float s_a = 0.0f, s_b = 0.0f;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    float v, s;
+                    final_act<FINAL>(acc[g][r] + bias[g][r], v, s);
+                    s_a = fmaf(v, dwa[0][r], s_a);
+                    s_b = fmaf(v, dwb[0][r], s_b);
+                  }
+                  a_prev[g] = s_a;
+                  b_prev[g] = s_b;
+                  sel_prev[g] = (live && n == target) ? 1.0f : 0.0f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                sa[ty] = Tile<16>::mfma(sel_prev[g], a_prev[g], sa[ty]);
+                sb[ty] = Tile<16>::mfma(sel_prev[g], b_prev[g], sb[ty]);
+              }
+            }
+          };
+          if (p.g.final == TSDE_FINAL_SIGMOID) pairs(std::integral_constant<int, TSDE_FINAL_SIGMOID>{});
+          else if (p.g.final == TSDE_FINAL_TANH) pairs(std::integral_constant<int, TSDE_FINAL_TANH>{});
+          else pairs(std::integral_constant<int, TSDE_FINAL_NONE>{});
+        }
+#pragma unroll
+        for (int ty = 0; ty < (BACKWARD ? TD : 0); ++ty) {
           const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;
           if (channels <= 0) continue;
           const int tiles = (channels * M + 15) / 16;
