@@ -10,10 +10,14 @@
 // the 309 ms of a configs[2]-sized forward + backward before this kernel existed). Deterministic: every row block writes its own
 // partial sums, the host adds them in a fixed order.
 //
-// A block = 4 waves works on 16 stash rows at a time (hid, p, q, wa, wb of those rows staged in LDS once) and on 16 consecutive
-// output tiles of 16 outputs (its slice of W2 staged in LDS once per block); wave w owns tiles 4 w .. 4 w + 3 of the slice.
-// Per tile: 16 MFMAs recompute pre^T (outputs x rows), the cotangent tile goes through a 16 x 16 LDS transpose (rows become the
-// K index), 16 MFMAs add hid^T cot to the wave's accumulators.
+// A block = 4 waves works on 16 stash rows at a time and on 16 consecutive output tiles of 16 outputs (its slice of W2 staged in
+// LDS once per block); wave w owns tiles 4 w .. 4 w + 3 of the slice. Per tile 16 MFMAs recompute pre (ROWS x outputs: a lane
+// then holds one output and four rows 4 part + r), the closing arithmetic runs on those four, and 16 MFMAs add hid^T cot with the
+// rows as the K index in the order the lanes hold them (MFMA r: k = part stands for row 4 part + r) -- the cotangent tile is
+// consumed from the registers it was born in. p, q, wa, wb sit transposed in LDS ([channel][row], rows padded to 20: a lane's
+// four rows are one conflict-free 16-byte read). The next group's rows are fetched into registers while this group computes.
+#include <type_traits>
+
 #include "tsde_common.h"
 #include "tsde_launch.h"
 #include "tsde_mlp.h"
@@ -47,123 +51,145 @@ TSDE_D float final_slope(float x) {
 constexpr int kOT = 4;                  // output tiles per wave
 constexpr int kSlice = 4 * kOT * 16;    // outputs per block
 
+constexpr int kST = 20;                 // row stride of the transposed p / q / wa / wb tiles
+
 template <int H>
-__global__ void __launch_bounds__(256) rheun_last_layer_kernel(const LastLayerArgs p) {
-  constexpr int TH = H / 16, SH = H + 4, SW = kSlice + 4, SC = 20;
+__global__ void __launch_bounds__(256, 2) rheun_last_layer_kernel(const LastLayerArgs p) {
+  constexpr int TH = H / 16, SH = H + 4, SW = kSlice + 4;
   extern __shared__ float lds[];
   float* W2L = lds;                       // [H][SW]: this block's slice of W2
   float* hidL = W2L + H * SW;             // [16][SH]
-  float* pL = hidL + 16 * SH;             // [16][sd], [16][sd], [16][sm], [16][sm]
-  float* qL = pL + 16 * p.sd;
-  float* waL = qL + 16 * p.sd;
-  float* wbL = waL + 16 * p.sm;
-  float* cotL = wbL + 16 * p.sm;          // [4 waves][16][SC]
+  float* pT = hidL + 16 * SH;             // [sd][kST], [sd][kST], [sm][kST], [sm][kST]
+  float* qT = pT + p.sd * kST;
+  float* waT = qT + p.sd * kST;
+  float* wbT = waT + p.sm * kST;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane >> 4, n = lane & 15;
   const int o_base = blockIdx.y * kSlice;
   for (int i = threadIdx.x; i < H * kSlice; i += 256) {
     const int u = i / kSlice, c = i % kSlice, o = o_base + c;
     W2L[u * SW + c] = (u < p.hidden && o < p.out) ? p.w2[(int64_t)u * p.out + o] : 0.0f;
   }
-  float* cotW = cotL + wave * 16 * SC;
-  // per tile and register: the output's bias, its state channel i and Brownian channel j (packed), whether it exists
-  f32x4 bias[kOT];
-  int ij[kOT][4];
+  // per tile: this lane's output o = (i, j), its bias, where its four rows of p / q and of wa / wb sit
+  float bias[kOT], live[kOT];
+  int pofs[kOT], wofs[kOT];
 #pragma unroll
   for (int tl = 0; tl < kOT; ++tl) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = o_base + 16 * (kOT * wave + tl) + 4 * part + r;
-      const bool have = o < p.out;
-      const int i = have ? o / p.m : 0;
-      ij[tl][r] = have ? (i << 8) | (o - i * p.m) : -1;
-      bias[tl][r] = have ? p.b2[o] : 0.0f;
-    }
+    const int o = o_base + 16 * (kOT * wave + tl) + n;
+    const bool have = o < p.out;
+    const int i = have ? o / p.m : 0, j = have ? o - i * p.m : 0;
+    bias[tl] = have ? p.b2[o] : 0.0f;
+    live[tl] = have ? 1.0f : 0.0f;
+    pofs[tl] = i * kST + 4 * part;
+    wofs[tl] = j * kST + 4 * part;
   }
-  f32x4 acc[kOT][TH], gbacc[kOT];
+  f32x4 acc[kOT][TH];
+  float gbacc[kOT];
 #pragma unroll
   for (int tl = 0; tl < kOT; ++tl) {
-    gbacc[tl] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    gbacc[tl] = 0.0f;
 #pragma unroll
     for (int th = 0; th < TH; ++th) acc[tl][th] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  const int64_t groups = (p.N + 15) / 16;
-  for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    const int64_t row0 = grp * 16;
-    __syncthreads();                      // (the previous group's tiles are no longer read; W2L is complete on the first pass)
-    for (int i = threadIdx.x; i < 16 * (H / 4); i += 256) {
-      const int rr = i / (H / 4), c4 = 4 * (i % (H / 4));
-      f32x4 v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (row0 + rr < p.N && c4 < p.sh) v = *reinterpret_cast<const f32x4*>(p.hid + (row0 + rr) * p.sh + c4);
+  // a group's rows on their way to LDS: 16 x H of hid (one 16-byte piece per thread for H = 64), 16 x sd of p and q (sd <= 64:
+  // up to four elements per thread), 16 x sm of wa and wb (sm <= 16: one)
+  constexpr int kPQ = 4;
+  f32x4 r_hid;
+  float r_p[kPQ], r_q[kPQ], r_wa, r_wb;
+  const int hid_row = threadIdx.x / (H / 4), hid_col = 4 * (threadIdx.x % (H / 4));
+  auto fetch = [&](int64_t row0) {
+    r_hid = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (hid_row < 16 && row0 + hid_row < p.N && hid_col < p.sh)
+      r_hid = *reinterpret_cast<const f32x4*>(p.hid + (row0 + hid_row) * p.sh + hid_col);
+#pragma unroll
+    for (int e = 0; e < kPQ; ++e) {
+      const int i = threadIdx.x + 256 * e, rr = i / p.sd, c = i - rr * p.sd;
+      const bool have = i < 16 * p.sd && row0 + rr < p.N;
+      r_p[e] = have ? p.p[(row0 + rr) * p.sd + c] : 0.0f;
+      r_q[e] = have ? p.q[(row0 + rr) * p.sd + c] : 0.0f;
+    }
+    {
+      const int i = threadIdx.x, rr = i / p.sm, c = i - rr * p.sm;
+      const bool have = i < 16 * p.sm && row0 + rr < p.N;
+      r_wa = have ? p.wa[(row0 + rr) * p.sm + c] : 0.0f;
+      r_wb = have ? p.wb[(row0 + rr) * p.sm + c] : 0.0f;
+    }
+  };
+  auto deposit = [&]() {
+    if (hid_row < 16) {
+      f32x4 v = r_hid;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (c4 + r >= p.hidden) v[r] = 0.0f;          // (padded units of the stash hold act(0), not 0)
+        if (hid_col + r >= p.hidden) v[r] = 0.0f;          // (padded units of the stash hold act(0), not 0)
       }
-      *reinterpret_cast<f32x4*>(hidL + rr * SH + c4) = v;
+      *reinterpret_cast<f32x4*>(hidL + hid_row * SH + hid_col) = v;
     }
-    for (int i = threadIdx.x; i < 16 * p.sd; i += 256) {
-      const int rr = i / p.sd, c = i % p.sd;
-      const bool have = row0 + rr < p.N;
-      pL[i] = have ? p.p[(row0 + rr) * p.sd + c] : 0.0f;
-      qL[i] = have ? p.q[(row0 + rr) * p.sd + c] : 0.0f;
-    }
-    for (int i = threadIdx.x; i < 16 * p.sm; i += 256) {
-      const int rr = i / p.sm, c = i % p.sm;
-      const bool have = row0 + rr < p.N;
-      waL[i] = have ? p.wa[(row0 + rr) * p.sm + c] : 0.0f;
-      wbL[i] = have ? p.wb[(row0 + rr) * p.sm + c] : 0.0f;
-    }
-    __syncthreads();
-    // hid as the B operand of pre^T (lane (part, n): row n, units 16 th + 4 part + r) and as the A operand of hid^T cot
-    // (lane (part, n): unit 16 th + n of row 4 kb + part)
-    f32x4 hb[TH];
-    float ha[4][TH];
 #pragma unroll
-    for (int th = 0; th < TH; ++th) {
-      hb[th] = *reinterpret_cast<const f32x4*>(hidL + n * SH + 16 * th + 4 * part);
+    for (int e = 0; e < kPQ; ++e) {
+      const int i = threadIdx.x + 256 * e, rr = i / p.sd, c = i - rr * p.sd;
+      if (i < 16 * p.sd) {
+        pT[c * kST + rr] = r_p[e];
+        qT[c * kST + rr] = r_q[e];
+      }
+    }
+    {
+      const int i = threadIdx.x, rr = i / p.sm, c = i - rr * p.sm;
+      if (i < 16 * p.sm) {
+        waT[c * kST + rr] = r_wa;
+        wbT[c * kST + rr] = r_wb;
+      }
+    }
+  };
+  auto compute = [&](auto kind) {
+    constexpr int FINAL = decltype(kind)::value;
+    // hid as the A operand of pre (lane (part, n): row n, unit 4 kk + part) and of hid^T cot (unit 16 th + n of row 4 part + r)
+    float hA[H / 4], hT[4][TH];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) ha[kb][th] = hidL[(4 * kb + part) * SH + 16 * th + n];
+    for (int kk = 0; kk < H / 4; ++kk) hA[kk] = hidL[n * SH + 4 * kk + part];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int th = 0; th < TH; ++th) hT[r][th] = hidL[(4 * part + r) * SH + 16 * th + n];
     }
 #pragma unroll
     for (int tl = 0; tl < kOT; ++tl) {
       const int col = 16 * (kOT * wave + tl);
-      if (o_base + col >= p.out) continue;               // (wave-uniform: a tile past the net's outputs)
+      const f32x4 p4 = *reinterpret_cast<const f32x4*>(pT + pofs[tl]), q4 = *reinterpret_cast<const f32x4*>(qT + pofs[tl]);
+      const f32x4 wa4 = *reinterpret_cast<const f32x4*>(waT + wofs[tl]), wb4 = *reinterpret_cast<const f32x4*>(wbT + wofs[tl]);
       f32x4 pre = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int th = 0; th < TH; ++th) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = W2L[(16 * th + 4 * part + r) * SW + col + n];
-          pre = Tile<16>::mfma(a, hb[th][r], pre);
-        }
+      for (int kk = 0; kk < H / 4; ++kk) {
+        const float b = W2L[(4 * kk + part) * SW + col + n];
+        pre = Tile<16>::mfma(hA[kk], b, pre);
       }
       f32x4 cot;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int code = ij[tl][r];
-        float c = 0.0f;
-        if (code >= 0) {
-          const int i = code >> 8, j = code & 255;
-          const float x = pre[r] + bias[tl][r];
-          const float s = p.final == TSDE_FINAL_SIGMOID ? final_slope<TSDE_FINAL_SIGMOID>(x)
-                          : p.final == TSDE_FINAL_TANH ? final_slope<TSDE_FINAL_TANH>(x) : 1.0f;
-          c = (pL[n * p.sd + i] * waL[n * p.sm + j] + qL[n * p.sd + i] * wbL[n * p.sm + j]) * s;
-        }
-        cot[r] = c;
-        gbacc[tl][r] += c;
+        const float s = final_slope<FINAL>(pre[r] + bias[tl]);
+        cot[r] = ((p4[r] * wa4[r] + q4[r] * wb4[r]) * s) * live[tl];
+        gbacc[tl] += cot[r];
       }
-      // rows become the K index: through a 16 x 16 transpose in this wave's own LDS tile
-      *reinterpret_cast<f32x4*>(cotW + n * SC + 4 * part) = cot;
-      __builtin_amdgcn_s_waitcnt(0xc07f);                // (lgkmcnt(0): the wave's own writes have landed)
-      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const float b = cotW[(4 * kb + part) * SC + n];
+      for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int th = 0; th < TH; ++th) acc[tl][th] = Tile<16>::mfma(ha[kb][th], b, acc[tl][th]);
+        for (int th = 0; th < TH; ++th) acc[tl][th] = Tile<16>::mfma(hT[r][th], cot[r], acc[tl][th]);
       }
-      __builtin_amdgcn_wave_barrier();
     }
-  }
+  };
+  const int64_t groups = (p.N + 15) / 16;
+  const bool wave_has_outputs = o_base + 16 * kOT * wave < p.out;      // (a small net: the other waves only stage and wait)
+  auto sweep = [&](auto kind) {           // (the closing function is uniform over the launch: one branch around the whole sweep)
+    if ((int64_t)blockIdx.x < groups) fetch((int64_t)blockIdx.x * 16);
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+      __syncthreads();                    // (the previous group's tiles are no longer read; W2L is complete on the first pass)
+      deposit();
+      __syncthreads();
+      if (grp + gridDim.x < groups) fetch((grp + gridDim.x) * 16);
+      if (wave_has_outputs) compute(kind);
+    }
+  };
+  if (p.final == TSDE_FINAL_SIGMOID) sweep(std::integral_constant<int, TSDE_FINAL_SIGMOID>{});
+  else if (p.final == TSDE_FINAL_TANH) sweep(std::integral_constant<int, TSDE_FINAL_TANH>{});
+  else sweep(std::integral_constant<int, TSDE_FINAL_NONE>{});
   // partial sums of this row block
 #pragma unroll
   for (int tl = 0; tl < kOT; ++tl) {
@@ -176,17 +202,11 @@ __global__ void __launch_bounds__(256) rheun_last_layer_kernel(const LastLayerAr
         if (u < p.hidden && o < p.out) p.gw[((int64_t)blockIdx.x * p.hidden + u) * p.out + o] = acc[tl][th][r];
       }
     }
-    // column sums: over the 16 rows a lane quarter holds (lanes n = 0 .. 15)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = gbacc[tl][r];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      s += __shfl_xor(s, 8);
-      const int ob = o_base + 16 * (kOT * wave + tl) + 4 * part + r;
-      if (n == 0 && ob < p.out) p.gb[(int64_t)blockIdx.x * p.out + ob] = s;
-    }
+    // column sums: a lane holds its output's sum over the rows 4 part + r of every group; the four lane quarters add up
+    float s = gbacc[tl];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (part == 0 && o < p.out) p.gb[(int64_t)blockIdx.x * p.out + o] = s;
   }
 }
 
@@ -214,7 +234,8 @@ hipError_t launch_rheun_last_layer_grad(void* gw, void* gb, const void* hid, con
   a.sm = stride_m;
   if (N <= 0) return hipSuccess;
   const int H = net->hidden <= 32 ? 32 : 64;
-  const size_t lds = ((size_t)H * (kSlice + 4) + 16 * (H + 4) + 32 * (size_t)stride_d + 32 * (size_t)stride_m + 4 * 16 * 20) *
+  if (stride_d > 64 || stride_m > 16 || stride_h > H) return hipErrorInvalidValue;      // (what a thread's fetch registers hold)
+  const size_t lds = ((size_t)H * (kSlice + 4) + 16 * (H + 4) + 2 * kST * (size_t)stride_d + 2 * kST * (size_t)stride_m) *
                      sizeof(float);
   const dim3 grid((unsigned)row_blocks, (unsigned)((net->out + kSlice - 1) / kSlice));
   if (H == 32) {
