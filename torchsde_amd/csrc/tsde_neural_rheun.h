@@ -589,98 +589,126 @@ __global__ void __launch_bounds__(256, (!BACKWARD && D <= 32) ? 2 : 1) neural_rh
           else if (p.g.final == TSDE_FINAL_TANH) pairs(std::integral_constant<int, TSDE_FINAL_TANH>{});
           else pairs(std::integral_constant<int, TSDE_FINAL_NONE>{});
         }
+        if constexpr (BACKWARD) {
+          // Backward: two tiles per turn -- two independent accumulator chains (a dependent f32 MFMA waits 40 cycles, issue is
+          // 32); a turn's second tile may lie past the real outputs -- `outp` is a multiple of 32, its weights and bias are zero,
+          // and it is masked out of the selector and the cotangent. The weights' LDS addresses are four opaque 32-bit bases
+          // (forward reads / transposed reads, units 0..31 / 32..63) advanced by one pair per turn, so that with a
+          // compile-time stride every row offset is an immediate of its read; the closing function is a type.
+          auto pairs_back = [&](auto kind) {
+            constexpr int FINAL = decltype(kind)::value;
+            typedef const __attribute__((address_space(3))) float* lds_float_t;
+            typedef const __attribute__((address_space(3))) f32x4* lds_quad_t;
 #pragma unroll
-        for (int ty = 0; ty < (BACKWARD ? TD : 0); ++ty) {
-          const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;
-          if (channels <= 0) continue;
-          const int tiles = (channels * M + 15) / 16;
-          // two tiles per turn: two independent accumulator chains (a dependent f32 MFMA waits 40 cycles, issue is 32) and
-          // operand pairs 16 floats apart (one ds_read2_b32); a turn's second tile may lie past the real outputs -- `outp` is
-          // a multiple of 32, its weights and bias are zero, and it is masked out of the selector and the cotangent
-          for (int tl = 0; tl < tiles; tl += 2) {
-            const int tile = ty * M + tl;                    // 16 consecutive outputs o = 16 tile + 4 part + r (and tile + 1)
-            const bool two = tl + 1 < tiles;
-            f32x4 bias[2], acc[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              bias[g] = lds_quad(b2g, 16 * (tile + g) + 4 * part);
-              acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int th = 0; th < TH; ++th) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
+            for (int ty = 0; ty < TD; ++ty) {
+              const int channels = dT - 16 * ty < 16 ? dT - 16 * ty : 16;
+              if (channels <= 0) continue;
+              const int tiles = (channels * M + 15) / 16;
+              uint32_t f_lo = (uint32_t)(uintptr_t)(lds_float_t)(W2g + (4 * part) * S2G + 16 * (ty * M) + n);
+              uint32_t t_lo = (uint32_t)(uintptr_t)(lds_float_t)(W2g + n * S2G + 16 * (ty * M) + 4 * part);
+              uint32_t f_up = f_lo + (uint32_t)(32 * S2G * sizeof(float)), t_up = t_lo + (uint32_t)(32 * S2G * sizeof(float));
+              asm volatile("" : "+v"(f_lo), "+v"(f_up), "+v"(t_lo), "+v"(t_up));
+              const float* bq = b2g + 16 * (ty * M) + 4 * part;
+              for (int tl = 0; tl < tiles; tl += 2) {
+                const bool two = tl + 1 < tiles;
+                f32x4 bias[2], acc[2];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                  const float a = W2g[(16 * th + 4 * part + r) * S2G + 16 * (tile + g) + n];
-                  acc[g] = Tile<16>::mfma(a, top[th][r], acc[g]);
+                  bias[g] = *reinterpret_cast<const f32x4*>(bq + 16 * g);
+                  acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 }
-              }
-            }
-            rheun_reads_ahead<TH * 4, 2>();          // (the two tiles' operands arrive as one ds_read2_b32)
-            f32x4 cot[2];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              const bool live = g == 0 || two;
-              // the state channel (within tile ty) this lane's four outputs belong to (their Brownian channels: quad 0 of
-              // the lane's draws -- 4 part + r for 16 channels per state channel, r for 4)
-              const int target = M >= 16 ? tl + g : 4 * (tl + g) + part;
-              cot[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-              f32x4 pl = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ql = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // p, q of this lane's four outputs
-              if constexpr (BACKWARD) {
-                const f32x4 pt = pv[ty], qt = qv[ty];
-                if constexpr (M >= 16) {
-                  // one channel per tile: p, q of (row n, channel target) sit in lane (target / 4, n), register target % 4
-                  const int src = ((((target >> 2) & 3) << 4) + n) << 2;
-                  const int reg = target & 3;
-                  const float psel = reg == 0 ? pt[0] : reg == 1 ? pt[1] : reg == 2 ? pt[2] : pt[3];
-                  const float qsel = reg == 0 ? qt[0] : reg == 1 ? qt[1] : reg == 2 ? qt[2] : qt[3];
-                  const float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, psel)));
-                  const float qb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, qsel)));
-                  pl = f32x4{pb, pb, pb, pb};
-                  ql = f32x4{qb, qb, qb, qb};
-                } else {
-                  // four channels per tile, one per lane quarter: the asking lanes want DIFFERENT registers of the holder, and a
-                  // chain of ds_bpermutes with a per-lane pick afterwards is folded by hipcc into ONE bpermute of a value picked
-                  // in the SOURCE lane (seen in the ISA; wrong gradients). The matrix cores do the broadcast instead:
-                  // D[o][row] = sum_c Sel[o][c] p[c][row], Sel[o][c] = 1 iff output o of the tile belongs to channel c -- and the
-                  // result is born in the layout of the tile's outputs.
+                for (int th = 0; th < TH; ++th) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
-                    const float a = (part == ((tl + g) & 3) && r == (n >> 2) && tl + g < 4) ? 1.0f : 0.0f;   // A[o = n][c = 4 part + r]
-                    pl = Tile<16>::mfma(a, pt[r], pl);
-                    ql = Tile<16>::mfma(a, qt[r], ql);
+                    const uint32_t at = (th < 2 ? f_lo : f_up) + (uint32_t)((16 * (th & 1) + r) * S2G * sizeof(float));
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                      const float a = *(lds_float_t)(uintptr_t)(at + 64 * g);
+                      acc[g] = Tile<16>::mfma(a, top[th][r], acc[g]);
+                    }
                   }
                 }
-              }
-              float s_a = 0.0f, s_b = 0.0f;
+                {   // (eight operand reads ahead, then one more per matrix instruction)
+                  constexpr int kReads = TH * 8, kAhead = 8;
+                  __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float v, s;
-                final_value(p.g.final, acc[g][r] + bias[g][r], v, s);
-                s_a = fmaf(v, dwa[0][r], s_a);
-                s_b = fmaf(v, dwb[0][r], s_b);
-                if constexpr (BACKWARD) cot[g][r] = live ? (pl[r] * dwa[0][r] + ql[r] * dwb[0][r]) * s : 0.0f;
-              }
-              const float sel = (live && n == target) ? 1.0f : 0.0f;
-              sa[ty] = Tile<16>::mfma(sel, s_a, sa[ty]);
-              sb[ty] = Tile<16>::mfma(sel, s_b, sb[ty]);
-            }
-            if constexpr (BACKWARD) {
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int g = 0; g < 2; ++g) {
-#pragma unroll
-                for (int th = 0; th < TH; ++th) {      // (th inner: consecutive MFMAs hit different accumulators)
-                  const f32x4 a = *reinterpret_cast<const f32x4*>(W2g + (16 * th + n) * S2G + 16 * (tile + g) + 4 * part);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) back[th] = Tile<16>::mfma(a[r], cot[g][r], back[th]);
+                  for (int i = 0; i < kReads; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < kReads - kAhead) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
                 }
+                f32x4 cot[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  const bool live = g == 0 || two;
+                  // the state channel (within tile ty) this lane's four outputs belong to (their Brownian channels: quad 0 of
+                  // the lane's draws -- 4 part + r for 16 channels per state channel, r for 4)
+                  const int target = M >= 16 ? tl + g : 4 * (tl + g) + part;
+                  f32x4 pl = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ql = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // p, q of this lane's four outputs
+                  const f32x4 pt = pv[ty], qt = qv[ty];
+                  if constexpr (M >= 16) {
+                    // one channel per tile: p, q of (row n, channel target) sit in lane (target / 4, n), register target % 4
+                    const int src = ((((target >> 2) & 3) << 4) + n) << 2;
+                    const int reg = target & 3;
+                    const float psel = reg == 0 ? pt[0] : reg == 1 ? pt[1] : reg == 2 ? pt[2] : pt[3];
+                    const float qsel = reg == 0 ? qt[0] : reg == 1 ? qt[1] : reg == 2 ? qt[2] : qt[3];
+                    const float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, psel)));
+                    const float qb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, qsel)));
+                    pl = f32x4{pb, pb, pb, pb};
+                    ql = f32x4{qb, qb, qb, qb};
+                  } else {
+                    // four channels per tile, one per lane quarter: the asking lanes want DIFFERENT registers of the holder, and a
+                    // chain of ds_bpermutes with a per-lane pick afterwards is folded by hipcc into ONE bpermute of a value picked
+                    // in the SOURCE lane (seen in the ISA; wrong gradients). The matrix cores do the broadcast instead:
+                    // D[o][row] = sum_c Sel[o][c] p[c][row], Sel[o][c] = 1 iff output o of the tile belongs to channel c -- and the
+                    // result is born in the layout of the tile's outputs.
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                      const float a = (part == ((tl + g) & 3) && r == (n >> 2) && tl + g < 4) ? 1.0f : 0.0f;   // A[o = n][c = 4 part + r]
+                      pl = Tile<16>::mfma(a, pt[r], pl);
+                      ql = Tile<16>::mfma(a, qt[r], ql);
+                    }
+                  }
+                  float s_a = 0.0f, s_b = 0.0f;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    float v, s;
+                    final_act<FINAL>(acc[g][r] + bias[g][r], v, s);
+                    s_a = fmaf(v, dwa[0][r], s_a);
+                    s_b = fmaf(v, dwb[0][r], s_b);
+                    cot[g][r] = live ? (pl[r] * dwa[0][r] + ql[r] * dwb[0][r]) * s : 0.0f;
+                  }
+                  const float sel = (live && n == target) ? 1.0f : 0.0f;
+                  sa[ty] = Tile<16>::mfma(sel, s_a, sa[ty]);
+                  sb[ty] = Tile<16>::mfma(sel, s_b, sb[ty]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                  for (int th = 0; th < TH; ++th) {      // (th inner: consecutive MFMAs hit different accumulators)
+                    const uint32_t at = (th < 2 ? t_lo : t_up) + (uint32_t)((16 * (th & 1)) * S2G * sizeof(float)) + 64 * g;
+                    const f32x4 a = *(lds_quad_t)(uintptr_t)at;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) back[th] = Tile<16>::mfma(a[r], cot[g][r], back[th]);
+                  }
+                }
+                rheun_reads_ahead<TH * 2, 4>();          // (one 16-byte read feeds four MFMAs)
+                f_lo += 128;
+                f_up += 128;
+                t_lo += 128;
+                t_up += 128;
+                bq += 32;
+                asm volatile("" : "+v"(f_lo), "+v"(f_up), "+v"(t_lo), "+v"(t_up));
               }
-              rheun_reads_ahead<TH * 2, 4>();          // (one 16-byte read feeds four MFMAs)
             }
-          }
+          };
+          if (p.g.final == TSDE_FINAL_SIGMOID) pairs_back(std::integral_constant<int, TSDE_FINAL_SIGMOID>{});
+          else if (p.g.final == TSDE_FINAL_TANH) pairs_back(std::integral_constant<int, TSDE_FINAL_TANH>{});
+          else pairs_back(std::integral_constant<int, TSDE_FINAL_NONE>{});
         }
       } else {
         // diagonal / scalar noise: one diffusion value per state channel
