@@ -143,7 +143,7 @@ struct PairLayout {
 // drawn element by element; a separate instantiation, so that the common one carries no call and no second path (the SRK
 // body keeps ~300 registers live across the draws).
 template <int D, int H, int MODE, bool SPLIT = false, bool GENERIC = false>
-__global__ void __launch_bounds__(256, MODE >= 4 ? 2 : 1) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
+__global__ void __launch_bounds__(256, (MODE >= 4 || (D <= 32 && H <= 64)) ? 2 : 1) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
   // (general noise asks the compiler for at most 256 registers: it then keeps the accumulators in ordinary registers; with the
   //  512 of one wave per SIMD it parks them in the accumulation file and every tile pays eight copies out and back)
   using NS = NoiseShape<MODE>;
