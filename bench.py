@@ -41,7 +41,7 @@ line per workload, and written whole to bench_also.json:
 * side measurements (single-GPU default run; `also` lines + bench_also.json): every other BASELINE configuration at its
   single-GPU size on the stepwise path (configs[2] Euler-general and the Milstein-general extension, the configs[3]
   shard, configs[4] sdeint_adjoint), each with ms per solve (median of 5) and the same kernel-level measurement, bytes,
-  fractions and counter traffic; then the default-route and closed-form variants. Not part of `value`; `--no-also` skips them.
+  fractions and counter traffic; then the default-route and closed-form variants. Not part of `value`; `--no-also` skips them, `--also-budget S` (default 150 s; 0 = no limit) bounds their total time.
 """
 import argparse
 import hashlib
@@ -103,6 +103,23 @@ ALSO = ("c2_milstein_diag", "c2_srk_diag",
         "sdegan_midpoint_default_route_b16384_d16_m3_s1000", "sdegan_midpoint_b16384_d16_m3_s1000",
         "c3_rheun_general_default_route_b16384_d32_m16", "c3_rheun_general_b16384_d32_m16",
         "c3_rheun_adjoint_general_default_route_b16384_d32_m16", "c3_rheun_adjoint_general_b16384_d32_m16")
+
+
+# The default run gives the side measurements a time budget (`--also-budget`, seconds; 0 = no limit): these go first, what
+# the budget does not reach is recorded as skipped (`python bench.py --workload W` measures any of them on its own;
+# profiles/r6_bench_also.json holds a run without the limit).
+ALSO_FIRST = ("c3_euler_general_default_route_b16384_d32_m16", "c3_midpoint_general_default_route_b16384_d32_m16",
+              "c4_midpoint_diag_default_route_b32768_d64", "c2_milstein_diag_default_route", "c2_srk_diag_default_route",
+              "c5_adjoint_latent_default_route_b32768_d128_s500",
+              "c3_rheun_general_default_route_b16384_d32_m16", "c3_rheun_adjoint_general_default_route_b16384_d32_m16",
+              "sdegan_rheun_adjoint_default_route_b1024_d16_m3_s63", "lorenz_euler_default_route_b262144_d3_s1000",
+              "c2_euler_exscalar_default_route_b65536_d64_s1000", "c2_srk_exscalar_default_route_b65536_d64_s1000",
+              "c2_euler_exscalar_training_default_route_b65536_d64_s1000", "exadditive_srk_default_route_b65536_d64_m8",
+              "neuraladditive_srk_default_route_b65536_d64_m8", "c2_srk_netdiag_default_route_b65536_d64_s1000",
+              "c2_heun_diag_default_route_b65536_d64_s1000", "c5_rheun_adjoint_latent_b32768_d128_s500",
+              "c5_logqp_adjoint_latent_b32768_d128_s500", "c2_milstein_diag", "c2_srk_diag", "c3_euler_general_b16384_d32_m16",
+              "c4_midpoint_diag_b32768_d64", "c5_adjoint_latent_b32768_d128_s500")
+ALSO = ALSO_FIRST + tuple(w for w in ALSO if w not in ALSO_FIRST)
 
 
 def csrc_digest():
@@ -853,12 +870,17 @@ def _config3_beside(dev, rank, world, dist, args):
             "collective_backend": ranks["collective_backend"]}
 
 
-def _side_measurements(dev):
+def _side_measurements(dev, budget=0.0):
     """Short measurements reported under `also`: outside the headline's timed region and NOT part of `value`. A
     failure here is reported in place and never takes the headline down with it."""
     also = {}
+    began = time.time()
     for name in ALSO:
         if name not in WORKLOADS:
+            continue
+        if budget > 0 and time.time() - began > budget:
+            also[name] = {"skipped": f"the side measurements' time budget ({budget:.0f} s, --also-budget) was used up; "
+                                     f"python bench.py --workload {name}"}
             continue
         try:
             also[name] = _side_measurement(dev, name)
@@ -974,6 +996,8 @@ def main():
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short side measurements reported under `also`")
+    ap.add_argument("--also-budget", type=float, default=150.0,
+                    help="seconds the side measurements may take in all (0 = no limit); the rest is recorded as skipped")
     ap.add_argument("--no-stepwise", action="store_true",
                     help="skip the stepwise solve of the same workload reported beside a recognised headline")
     ap.add_argument("--eager", action="store_true", help="issue every solve eagerly instead of replaying a HIP graph")
@@ -1077,7 +1101,7 @@ def main():
     if world == 1 and not args.no_also and args.workload == HEADLINE:
         del job
         torch.cuda.empty_cache()
-        also = _side_measurements(dev)
+        also = _side_measurements(dev, args.also_budget)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # What profiles/r6_* holds, in a few GPU calls (each through gpurun, then copy gpurun_out/round_r6/* into profiles/ with the
-# r6_ prefix). Usage: tools/profile_round6.sh <tag> <stage ...>, stages: bench trace headline kernels workloads traffic.
+# r6_ prefix). Usage: tools/profile_round6.sh <tag> <stage ...>, stages: bench also trace headline kernels workloads traffic.
 # Every rocprofv3 pass runs under its own timeout; counter passes carry no trace domain but --kernel-trace; raw traces are
 # deleted before the call returns (gpurun copies back at most 64 MiB, and nothing at all beyond that).
 # (One call with every stage took more than 50 minutes and came back empty: run the stages in separate calls.)
@@ -18,7 +18,10 @@ for STAGE in "$@"; do
       T0=$SECONDS
       python bench.py > $OUT/bench_c2_default.json 2> $OUT/bench_c2_default.err
       echo "bench.py wall seconds: $((SECONDS - T0))" | tee -a $OUT/bench_c2_default.err
-      cp bench_also.json $OUT/bench_also.json 2>/dev/null || cp gpurun_out/bench_also.json $OUT/bench_also.json 2>/dev/null ;;
+      cp bench_also.json $OUT/bench_also_default_budget.json 2>/dev/null ;;
+    also)       # every side measurement, without the default run's time budget
+      python bench.py --also-budget 0 --no-cpu-baseline > $OUT/bench_c2_all_side_measurements.json 2> $OUT/bench_also.err
+      cp bench_also.json $OUT/bench_also.json 2>/dev/null ;;
     trace)      # the default bench under rocprofv3 (kernel trace + stats), at the shipped sources
       tools/profile.sh $TAG > $OUT/bench_c2_rocprofv3_summary.txt 2>&1
       rm -rf gpurun_out/prof_$TAG/trace ;;
