@@ -327,10 +327,10 @@ WORKLOADS = {
     # 16-byte groups)
     "c5_logqp_adjoint_latent_b32768_d128_s500": dict(
         problem="latent_diag_logqp", method="euler", adjoint_method="euler", levy="none", B=32768, d=128, m=129,
-        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=(16 + 32) * 129, kid=5, launches_per_step=1, adjoint=True, logqp=True,
+        nsteps=500, dt=2.0 ** -9, bytes_per_traj_step=32 * 129, kid=5, launches_per_step=1, adjoint=True, logqp=True,
         kernel_match=["aug_multi_kernel<float>"],
-        kernel="tsde_step_diag + tsde_aug_update <float> on the (B, d + 1) logqp state (user f, g, h and their VJPs between "
-               "them)"),
+        kernel="tsde_aug_update<float> on the (B, d + 1) logqp state (aug_multi_kernel, backward sweep; user f, g, h and "
+               "their VJPs between the launches)"),
     # 8f rank 3: log-ODE (log_ode.py:39-56) with Foster's Levy area (brownian_interval.py:78-99) at the configs[2] shape:
     # per step tsde_levy_area (W, H -> A (B, m, m)), two general contractions, and the user's m-column JVP
     "c3_log_ode_general_b16384_d32_m16": dict(
