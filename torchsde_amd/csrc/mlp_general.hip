@@ -143,9 +143,12 @@ struct PairLayout {
 // drawn element by element; a separate instantiation, so that the common one carries no call and no second path (the SRK
 // body keeps ~300 registers live across the draws).
 template <int D, int H, int MODE, bool SPLIT = false, bool GENERIC = false>
-__global__ void __launch_bounds__(256, (MODE >= 4 || (D <= 32 && H <= 64)) ? 2 : 1) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
-  // (general noise asks the compiler for at most 256 registers: it then keeps the accumulators in ordinary registers; with the
-  //  512 of one wave per SIMD it parks them in the accumulation file and every tile pays eight copies out and back)
+__global__ void __launch_bounds__(256, (MODE >= 4 || (H <= 64 && !GENERIC)) ? 2 : 1) neural_trajectory_kernel(const NeuralArgs p, const int outp) {
+  // (up to 64 hidden units the compiler is asked for at most 256 registers: it then keeps the accumulators in ordinary
+  //  registers -- with the 512 of one wave per SIMD it parks them in the accumulation file and every tile pays eight copies
+  //  out and back -- and the 64-channel shapes, whose LDS footprint admits two blocks per CU, get their second wave per SIMD
+  //  (they asked for ~300 registers before: one wave per SIMD whatever the LDS allowed). Not the element-by-element
+  //  instantiation, which would spill ~100 registers.)
   using NS = NoiseShape<MODE>;
   static_assert(!SPLIT || (NS::kGeneral && H == 64), "split mode: general noise, 64 hidden units");
   using L = NeuralLds<D, H>;
