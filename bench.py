@@ -135,6 +135,26 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def csrc_file_digests():
+    """sha256 of every kernel source on its own: a counter file stays a measurement of a kernel as long as the files that kernel
+    is made of have not changed, whatever happened to the others."""
+    csrc = os.path.join(ROOT, "torchsde_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "torchsde_amd.h"))
+    out = {}
+    for path in files:
+        with open(path, "rb") as fh:
+            out[os.path.basename(path)] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out
+
+
+# the files the stepwise kernels (and the affine / expression / program trajectory kernels) are made of: what
+# tools/profile_traffic.sh measures
+_COMMON_SOURCES = ("tsde_common.h", "tsde_rng.h", "tsde_bridge.h", "tsde_launch.h", "tsde_schemes.h", "torchsde_amd.h")
+_STEPWISE_SOURCES = _COMMON_SOURCES + ("steps.hip", "rheun.hip", "brownian.hip", "milstein_general.hip", "capi.hip")
+_TRAJECTORY_SOURCES = _COMMON_SOURCES + ("trajectory.hip", "capi.hip")
+
+
 def _reference_package():
     """The REAL reference (google-research/torchsde) if this host has it: /root/reference (or $TORCHSDE_REFERENCE) with
     the `trampoline` stand-in of tests/golden/_ref_shim ahead of it on the path. None elsewhere -- the
@@ -648,6 +668,11 @@ def _attach_headline_pmc(roofline, workload):
     except (OSError, ValueError):
         return
     digest = csrc_digest()
+    if rec.get("csrc_sha") != digest and rec.get("workload") == workload and rec.get("files"):
+        # other kernels changed since: the counters stand if the files the trajectory kernel is made of did not
+        now = csrc_file_digests()
+        if all(now.get(f) == rec["files"].get(f) for f in _TRAJECTORY_SOURCES):
+            digest = rec["csrc_sha"]
     if rec.get("csrc_sha") != digest or rec.get("workload") != workload:
         roofline["pmc"] = (f"profiles/headline_pmc_latest.json is for {rec.get('workload')} @ csrc {rec.get('csrc_sha')}; this "
                            f"run is {workload} @ {digest}: stale, not reported (re-run tools/profile_trajectory.sh)")
@@ -700,9 +725,16 @@ def _attach_offline_traffic(roofline, workload):
             rec = json.load(fh)
         digest = csrc_digest()
         if rec.get("csrc_sha") != digest:
-            roofline["traffic_source"] = (f"profiles/traffic_latest.json is for kernel sources {rec.get('csrc_sha')}, "
-                                          f"this run uses {digest}: stale, not reported (re-run tools/profile_traffic.sh)")
-            return
+            # other kernels changed since: the counters still stand if the files THESE kernels are made of did not
+            now, then = csrc_file_digests(), rec.get("files") or {}
+            needed = _TRAJECTORY_SOURCES if cfg.get("trajectory") else _STEPWISE_SOURCES
+            changed = [f for f in needed if now.get(f) != then.get(f)]
+            if changed:
+                roofline["traffic_source"] = (f"profiles/traffic_latest.json is for kernel sources {rec.get('csrc_sha')}, this "
+                                              f"run uses {digest} and {', '.join(changed)} changed since: stale, not reported "
+                                              "(re-run tools/profile_traffic.sh)")
+                return
+            digest = f"{rec.get('csrc_sha')} (this run: {digest}; the files of the measured kernels are unchanged)"
         kernels = rec.get("workloads", {}).get(workload, {}).get("kernels")
         if kernels is None and workload == HEADLINE:
             kernels = rec.get("kernels")          # (the one-workload layout of rounds 1-2)

@@ -33,7 +33,7 @@ def counter_means(path, name):
     return {k: (n, tot / max(n, 1)) for k, (n, tot) in agg.items()}
 
 
-result = {"csrc_sha": bench.csrc_digest(),
+result = {"csrc_sha": bench.csrc_digest(), "files": bench.csrc_file_digests(),
           "collected": "tools/profile_traffic.sh: per workload, rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes "
                        "(separate) and a --kernel-trace --stats pass of `bench.py --workload W --profile-steps 100`; "
                        "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",

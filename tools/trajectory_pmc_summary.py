@@ -43,7 +43,8 @@ need = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE")
 if all(k in counters for k in need) and kernel_ns:
     wave_steps = counters["SQ_WAVES"] * cfg["nsteps"]
     cycles = counters["GRBM_GUI_ACTIVE"] / 8.0                  # the counter sums the 8 XCDs
-    rec = {"workload": workload, "csrc_sha": digest, "kernel_avg_us": kernel_ns / 1e3, "counters": counters,
+    rec = {"workload": workload, "csrc_sha": digest, "files": bench.csrc_file_digests(), "kernel_avg_us": kernel_ns / 1e3,
+           "counters": counters,
            "valu_instructions_per_wave_step": counters["SQ_INSTS_VALU"] / wave_steps,
            "valu_busy": counters["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cycles,
            "effective_clock_ghz": cycles / kernel_ns,
