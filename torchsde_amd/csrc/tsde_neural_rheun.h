@@ -612,6 +612,40 @@ __global__ void __launch_bounds__(256, (!BACKWARD && D <= 32) ? 2 : 1) neural_rh
               for (int tl = 0; tl < tiles; tl += 2) {
                 const bool two = tl + 1 < tiles;
                 f32x4 bias[2], acc[2];
+                // p, q of this lane's four outputs, asked for BEFORE the products (their LDS round trip -- a ds_bpermute each --
+                // used to sit exposed in the closing arithmetic)
+                f32x4 pl[2], ql[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  // the state channel (within tile ty) this lane's four outputs belong to (their Brownian channels: quad 0 of
+                  // the lane's draws -- 4 part + r for 16 channels per state channel, r for 4)
+                  const int target = M >= 16 ? tl + g : 4 * (tl + g) + part;
+                  pl[g] = ql[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                  const f32x4 pt = pv[ty], qt = qv[ty];
+                  if constexpr (M >= 16) {
+                    // one channel per tile: p, q of (row n, channel target) sit in lane (target / 4, n), register target % 4
+                    const int src = ((((target >> 2) & 3) << 4) + n) << 2;
+                    const int reg = target & 3;
+                    const float psel = reg == 0 ? pt[0] : reg == 1 ? pt[1] : reg == 2 ? pt[2] : pt[3];
+                    const float qsel = reg == 0 ? qt[0] : reg == 1 ? qt[1] : reg == 2 ? qt[2] : qt[3];
+                    const float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, psel)));
+                    const float qb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, qsel)));
+                    pl[g] = f32x4{pb, pb, pb, pb};
+                    ql[g] = f32x4{qb, qb, qb, qb};
+                  } else {
+                    // four channels per tile, one per lane quarter: the asking lanes want DIFFERENT registers of the holder, and a
+                    // chain of ds_bpermutes with a per-lane pick afterwards is folded by hipcc into ONE bpermute of a value picked
+                    // in the SOURCE lane (seen in the ISA; wrong gradients). The matrix cores do the broadcast instead:
+                    // D[o][row] = sum_c Sel[o][c] p[c][row], Sel[o][c] = 1 iff output o of the tile belongs to channel c -- and the
+                    // result is born in the layout of the tile's outputs.
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                      const float a = (part == ((tl + g) & 3) && r == (n >> 2) && tl + g < 4) ? 1.0f : 0.0f;   // A[o = n][c = 4 part + r]
+                      pl[g] = Tile<16>::mfma(a, pt[r], pl[g]);
+                      ql[g] = Tile<16>::mfma(a, qt[r], ql[g]);
+                    }
+                  }
+                }
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                   bias[g] = *reinterpret_cast<const f32x4*>(bq + 16 * g);
@@ -641,51 +675,29 @@ __global__ void __launch_bounds__(256, (!BACKWARD && D <= 32) ? 2 : 1) neural_rh
                   __builtin_amdgcn_sched_barrier(0);
                 }
                 f32x4 cot[2];
+                float s_a[2], s_b[2], sel[2];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                   const bool live = g == 0 || two;
-                  // the state channel (within tile ty) this lane's four outputs belong to (their Brownian channels: quad 0 of
-                  // the lane's draws -- 4 part + r for 16 channels per state channel, r for 4)
                   const int target = M >= 16 ? tl + g : 4 * (tl + g) + part;
-                  f32x4 pl = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ql = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // p, q of this lane's four outputs
-                  const f32x4 pt = pv[ty], qt = qv[ty];
-                  if constexpr (M >= 16) {
-                    // one channel per tile: p, q of (row n, channel target) sit in lane (target / 4, n), register target % 4
-                    const int src = ((((target >> 2) & 3) << 4) + n) << 2;
-                    const int reg = target & 3;
-                    const float psel = reg == 0 ? pt[0] : reg == 1 ? pt[1] : reg == 2 ? pt[2] : pt[3];
-                    const float qsel = reg == 0 ? qt[0] : reg == 1 ? qt[1] : reg == 2 ? qt[2] : qt[3];
-                    const float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, psel)));
-                    const float qb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, qsel)));
-                    pl = f32x4{pb, pb, pb, pb};
-                    ql = f32x4{qb, qb, qb, qb};
-                  } else {
-                    // four channels per tile, one per lane quarter: the asking lanes want DIFFERENT registers of the holder, and a
-                    // chain of ds_bpermutes with a per-lane pick afterwards is folded by hipcc into ONE bpermute of a value picked
-                    // in the SOURCE lane (seen in the ISA; wrong gradients). The matrix cores do the broadcast instead:
-                    // D[o][row] = sum_c Sel[o][c] p[c][row], Sel[o][c] = 1 iff output o of the tile belongs to channel c -- and the
-                    // result is born in the layout of the tile's outputs.
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                      const float a = (part == ((tl + g) & 3) && r == (n >> 2) && tl + g < 4) ? 1.0f : 0.0f;   // A[o = n][c = 4 part + r]
-                      pl = Tile<16>::mfma(a, pt[r], pl);
-                      ql = Tile<16>::mfma(a, qt[r], ql);
-                    }
-                  }
-                  float s_a = 0.0f, s_b = 0.0f;
+                  s_a[g] = s_b[g] = 0.0f;
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
                     float v, s;
                     final_act<FINAL>(acc[g][r] + bias[g][r], v, s);
-                    s_a = fmaf(v, dwa[0][r], s_a);
-                    s_b = fmaf(v, dwb[0][r], s_b);
-                    cot[g][r] = live ? (pl[r] * dwa[0][r] + ql[r] * dwb[0][r]) * s : 0.0f;
+                    s_a[g] = fmaf(v, dwa[0][r], s_a[g]);
+                    s_b[g] = fmaf(v, dwb[0][r], s_b[g]);
+                    cot[g][r] = live ? (pl[g][r] * dwa[0][r] + ql[g][r] * dwb[0][r]) * s : 0.0f;
                   }
-                  const float sel = (live && n == target) ? 1.0f : 0.0f;
-                  sa[ty] = Tile<16>::mfma(sel, s_a, sa[ty]);
-                  sb[ty] = Tile<16>::mfma(sel, s_b, sb[ty]);
+                  sel[g] = (live && n == target) ? 1.0f : 0.0f;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // (the four selector products open the block of transposed products: no vector instruction between them)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                  sa[ty] = Tile<16>::mfma(sel[g], s_a[g], sa[ty]);
+                  sb[ty] = Tile<16>::mfma(sel[g], s_b[g], sb[ty]);
+                }
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -696,6 +708,7 @@ __global__ void __launch_bounds__(256, (!BACKWARD && D <= 32) ? 2 : 1) neural_rh
                     for (int r = 0; r < 4; ++r) back[th] = Tile<16>::mfma(a[r], cot[g][r], back[th]);
                   }
                 }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 rheun_reads_ahead<TH * 2, 4>();          // (one 16-byte read feeds four MFMAs)
                 f_lo += 128;
                 f_up += 128;
