@@ -588,6 +588,45 @@ def test_bench_headline_is_the_last_line_and_fits_the_drivers_window(capsys, tmp
     assert sum(len(t) + 1 for t in out[-3:]) < 9000      # even a window of ~9 KB holds the headline whole
 
 
+def test_bench_offline_counters_follow_the_sources_of_the_kernels_they_measured(tmp_path, monkeypatch):
+    """profiles/traffic_latest.json is a measurement of the stepwise kernels: editing ANOTHER kernel's source (the digest over
+    all sources changes) must not drop it from the bench line, editing steps.hip must; the side measurements are a list
+    without repeats of known workloads, and their time budget leaves the rest marked as skipped."""
+    import importlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    assert len(set(bench.ALSO)) == len(bench.ALSO) and all(w in bench.WORKLOADS for w in bench.ALSO)
+    with open(os.path.join(root, "profiles", "traffic_latest.json")) as fh:
+        rec = json.load(fh)
+    files = dict(bench.csrc_file_digests())
+    rec["files"], rec["csrc_sha"] = dict(files), "f" * 16        # collected at other sources, same per-file hashes
+    (tmp_path / "profiles").mkdir()
+    with open(tmp_path / "profiles" / "traffic_latest.json", "w") as fh:
+        json.dump(rec, fh)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "0" * 16)
+    monkeypatch.setattr(bench, "csrc_file_digests", lambda: dict(files, **{"mlp_general.hip": "changed"}))
+    roof = {}
+    bench._attach_offline_traffic(roof, "c2_srk_diag")
+    assert roof.get("traffic_over_algorithmic", 0) > 1.0 and "unchanged" in roof["traffic_source"]
+    monkeypatch.setattr(bench, "csrc_file_digests", lambda: dict(files, **{"steps.hip": "changed"}))
+    roof = {}
+    bench._attach_offline_traffic(roof, "c2_srk_diag")
+    assert "traffic" not in roof and "steps.hip changed" in roof["traffic_source"]
+    # the time budget of the side measurements
+    ran = []
+    monkeypatch.setattr(bench, "_side_measurement", lambda dev, name: ran.append(name) or {"ms_per_solve": 1.0})
+    monkeypatch.setattr(bench.torch.cuda, "empty_cache", lambda: None)
+    ticks = iter(range(0, 10 ** 6, 40))
+    monkeypatch.setattr(bench.time, "time", lambda: next(ticks))
+    also = bench._side_measurements(None, budget=150.0)
+    assert ran == list(bench.ALSO[:3]) and set(also) == set(bench.ALSO)
+    assert all("skipped" in also[w] for w in bench.ALSO[3:])
+
+
 _FINGERPRINT_GLOBAL_SCALE = 1.5
 
 
