@@ -41,7 +41,7 @@ line per workload, and written whole to bench_also.json:
 * side measurements (single-GPU default run; `also` lines + bench_also.json): every other BASELINE configuration at its
   single-GPU size on the stepwise path (configs[2] Euler-general and the Milstein-general extension, the configs[3]
   shard, configs[4] sdeint_adjoint), each with ms per solve (median of 5) and the same kernel-level measurement, bytes,
-  fractions and counter traffic; then the default-route and closed-form variants. Not part of `value`; `--no-also` skips them, `--also-budget S` (default 150 s; 0 = no limit) bounds their total time.
+  fractions and counter traffic; then the default-route and closed-form variants. Not part of `value`; `--no-also` skips them, `--also-budget S` (default 100 s; 0 = no limit) bounds their total time.
 """
 import argparse
 import hashlib
@@ -1032,7 +1032,7 @@ def main():
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short side measurements reported under `also`")
-    ap.add_argument("--also-budget", type=float, default=150.0,
+    ap.add_argument("--also-budget", type=float, default=100.0,
                     help="seconds the side measurements may take in all (0 = no limit); the rest is recorded as skipped")
     ap.add_argument("--no-stepwise", action="store_true",
                     help="skip the stepwise solve of the same workload reported beside a recognised headline")
