@@ -87,6 +87,10 @@ CASES = [
     (12, 12, 20, 3, "softplus", "tanh", None, "diagonal", 19),
     (6, 1, 8, 2, "tanh", None, "sigmoid", "scalar", 21),               # NeuralScalar
     (3, 2, 8, 2, "tanh", None, None, "general", 9),                    # rows that are not 16-byte groups
+    # more than 32 state channels: the 64-channel instantiations (run-time row stride of the diffusion's last layer)
+    (40, 4, 16, 2, "tanh", None, "sigmoid", "general", 20),
+    (36, 12, 16, 3, "softplus", None, "tanh", "general", 18),
+    (48, 48, 32, 2, "softplus", None, None, "diagonal", 18),
 ]
 
 
