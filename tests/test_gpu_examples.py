@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ["neural_general_sde.py"],
     ["scalar_noise_training.py"],
     ["additive_noise_sde.py"],
+    ["train_reversible_heun.py", "--iters", "6"],
 ])
 def test_example_runs(argv):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "examples", argv[0])] + argv[1:], capture_output=True,

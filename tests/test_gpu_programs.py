@@ -52,7 +52,7 @@ SCHEMES = [("euler", "ito", "none"), ("milstein", "ito", "none"), ("srk", "ito",
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("method,sde_type,levy", SCHEMES)
 def test_the_references_scalar_noise_problem_is_one_launch(method, sde_type, levy, dtype):
-    """ExScalar verbatim (workloads.problems.ScalarTrig: f = -p^2 sin(y) cos(y)^3 -- zeros for Stratonovich --, g = p cos(y)^2 of
+    """The SDE of the reference's ExScalar test problem (workloads.problems.ScalarTrig: f = -p^2 sin(y) cos(y)^3 -- zeros for Stratonovich --, g = p cos(y)^2 of
     shape (B, d, 1), one Brownian channel per row)."""
     sde = problems.ScalarTrig(D, sde_type, dtype=dtype).to(DEV)
     first = _solve(sde, 1, method, levy, dtype=dtype)

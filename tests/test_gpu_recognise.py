@@ -41,7 +41,7 @@ def _launches(fn):
 
 
 class _Benchmark(nn.Module):
-    """The SDE of the reference's own benchmark (benchmarks/brownian.py:131-139), verbatim."""
+    """The SDE the reference's own benchmark solves (benchmarks/brownian.py:131-139): f = y, g = exp(-y)."""
     noise_type, sde_type = "diagonal", "ito"
 
     def f(self, t, y):

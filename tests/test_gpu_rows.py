@@ -1,11 +1,13 @@
 """Small row-coupled systems -- channels that read each other -- take ONE launch (torchsde_amd/recognise_rows.py +
-specialise.source_rows; ``-m gpu``): the reference's own `StochasticLorenz` (examples/latent_sde_lorenz.py:56-86, restated
-verbatim below) and modules written with `y[:, c]` / `torch.stack`, parameters and t in the arithmetic. The kernel is the
+specialise.source_rows; ``-m gpu``): the stochastic Lorenz system of the reference's examples/latent_sde_lorenz.py:56-86,
+written with `torch.split` / `torch.cat` the way that example writes it (workloads/problems.py), and modules written with `y[:, c]` / `torch.stack`, parameters and t in the arithmetic. The kernel is the
 program kernel with one lane per ROW and a model generated from the user's code; pinned against the stepwise route, which runs
 the user's own torch code (and replays the reference's goldens)."""
 import pytest
 import torch
 from torch import nn
+
+from workloads.problems import StochasticLorenz
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -18,33 +20,6 @@ def _compile_in_the_calling_thread(monkeypatch, tmp_path_factory):
     monkeypatch.setattr(specialise, "MODE", "sync")
     monkeypatch.setenv("TSDE_SPECIALISE_CACHE", str(tmp_path_factory.getbasetemp() / "specialised"))
     yield
-
-
-class StochasticLorenz(object):
-    """examples/latent_sde_lorenz.py:56-86."""
-    noise_type = "diagonal"
-    sde_type = "ito"
-
-    def __init__(self, a=(10., 28., 8 / 3), b=(.1, .28, .3)):
-        super(StochasticLorenz, self).__init__()
-        self.a = a
-        self.b = b
-
-    def f(self, t, y):
-        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
-        a1, a2, a3 = self.a
-        f1 = a1 * (x2 - x1)
-        f2 = a2 * x1 - x2 - x1 * x3
-        f3 = x1 * x2 - a3 * x3
-        return torch.cat([f1, f2, f3], dim=1)
-
-    def g(self, t, y):
-        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
-        b1, b2, b3 = self.b
-        g1 = x1 * b1
-        g2 = x2 * b2
-        g3 = x3 * b3
-        return torch.cat([g1, g2, g3], dim=1)
 
 
 class ForcedVanDerPol(nn.Module):

@@ -456,7 +456,7 @@ def _run_program(words, consts, y, t=None):
 
 
 PROGRAMS = {
-    # the reference's ExScalar verbatim (tests/problems.py:75-103)
+    # the SDE of the reference's ExScalar test problem (tests/problems.py:75-103): the same formulas as user code
     "ex_scalar": ("scalar", lambda s, t, y: -s.mu ** 2. * torch.sin(y) * torch.cos(y) ** 3.,
                   lambda s, t, y: (s.sigma * torch.cos(y) ** 2).unsqueeze(dim=-1)),
     "two functions summed": ("diagonal", lambda s, t, y: torch.tanh(y) + y, lambda s, t, y: 0.3 * torch.sigmoid(y) + s.sigma),

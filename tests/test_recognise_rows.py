@@ -6,22 +6,7 @@ from torch import nn
 from torchsde_amd import recognise_rows, specialise
 from torchsde_amd.recognise import NotElementwise
 from torchsde_amd.sde import ForwardSDE
-
-
-class _Lorenz(object):
-    """examples/latent_sde_lorenz.py:56-86 (restated)."""
-    noise_type, sde_type = "diagonal", "ito"
-    a, b = (10., 28., 8 / 3), (.1, .28, .3)
-
-    def f(self, t, y):
-        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
-        a1, a2, a3 = self.a
-        return torch.cat([a1 * (x2 - x1), a2 * x1 - x2 - x1 * x3, x1 * x2 - a3 * x3], dim=1)
-
-    def g(self, t, y):
-        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
-        b1, b2, b3 = self.b
-        return torch.cat([x1 * b1, x2 * b2, x3 * b3], dim=1)
+from workloads.problems import StochasticLorenz as _Lorenz
 
 
 def _evaluate(found, y, t):

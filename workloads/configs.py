@@ -31,7 +31,7 @@ WORKLOADS = {
         problem="gbm_ito", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -10,
         bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True, train=True,
         kernel="tsde_trajectory_affine_diag_sens<float, euler> (user module recognised; sdeint + loss.backward())"),
-    # the reference's own benchmark SDE, verbatim (benchmarks/brownian.py:131-139: f = y, g = exp(-y)), no options
+    # the SDE the reference's own benchmark solves (benchmarks/brownian.py:131-139: f = y, g = exp(-y)), no options
     "c2_euler_expdiff_default_route_b65536_d64_s1000": dict(
         problem="exp_diffusion", method="euler", levy="none", B=65536, d=64, m=64, nsteps=1000, dt=2.0 ** -16,
         bytes_per_traj_step=16 * 64, kid=8, trajectory=True, recognised=True,
@@ -339,7 +339,8 @@ WORKLOADS = {
         bench_steps=50, kernel_match=["general_rows_kernel<float", "levy_area"],
         step_kernels={"tsde_step_general": 2},
         kernel="tsde_step_general x2 + tsde_levy_area <float> (+ the user's g and its Jacobian-vector products per step)"),
-    # The reference's StochasticLorenz (examples/latent_sde_lorenz.py:56-86), unchanged: channels that read each other. One
+    # The stochastic Lorenz system of the reference's examples/latent_sde_lorenz.py:56-86, written as that example writes it
+    # (split / cat; workloads/problems.py): channels that read each other. One
     # lane owns a row (recognise_rows.py), the model is generated from the user's code and compiled at run time; stepwise twin
     # below (split / cat and ~20 small torch kernels per step). The example's own sizes: 1024 rows; here also 262144.
     "lorenz_euler_default_route_b262144_d3_s1000": dict(

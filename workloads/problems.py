@@ -261,34 +261,32 @@ class LatentDiagLogqp(LatentDiag):
         return -self.theta * y
 
 
-class StochasticLorenz(object):
-    """The reference's examples/latent_sde_lorenz.py:56-86 (restated verbatim): a row-coupled diagonal-noise system -- the
-    columns of the state read each other through `split` / `cat`."""
+class StochasticLorenz:
+    """The stochastic Lorenz system of the reference's examples/latent_sde_lorenz.py:56-86 with that example's constants,
+    written the way that example writes it -- the state's columns taken apart with `torch.split` and put back together with
+    `torch.cat` -- because that is the kind of user code the column interpreter (recognise_rows.py) has to follow: a
+    row-coupled system with diagonal noise, no parameters, not an nn.Module."""
     noise_type = "diagonal"
     sde_type = "ito"
 
-    def __init__(self, a=(10., 28., 8 / 3), b=(.1, .28, .3)):
-        super(StochasticLorenz, self).__init__()
-        self.a = a
-        self.b = b
+    def __init__(self, drift_constants=(10.0, 28.0, 8.0 / 3.0), noise_constants=(0.1, 0.28, 0.3)):
+        self.sigma, self.rho, self.beta = drift_constants
+        self.noise_constants = noise_constants
+
+    @staticmethod
+    def _columns(y):
+        return torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
 
     def f(self, t, y):
-        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
-        a1, a2, a3 = self.a
-
-        f1 = a1 * (x2 - x1)
-        f2 = a2 * x1 - x2 - x1 * x3
-        f3 = x1 * x2 - a3 * x3
-        return torch.cat([f1, f2, f3], dim=1)
+        x, yy, z = self._columns(y)
+        dx = self.sigma * (yy - x)
+        dy = self.rho * x - yy - x * z
+        dz = x * yy - self.beta * z
+        return torch.cat([dx, dy, dz], dim=1)
 
     def g(self, t, y):
-        x1, x2, x3 = torch.split(y, split_size_or_sections=(1, 1, 1), dim=1)
-        b1, b2, b3 = self.b
-
-        g1 = x1 * b1
-        g2 = x2 * b2
-        g3 = x3 * b3
-        return torch.cat([g1, g2, g3], dim=1)
+        scaled = [column * c for column, c in zip(self._columns(y), self.noise_constants)]
+        return torch.cat(scaled, dim=1)
 
     def to(self, device):
         return self
