@@ -142,7 +142,7 @@ def test_background_compilation_keeps_the_solve_stepwise_until_the_unit_is_there
 
     from torchsde_amd import specialise
     monkeypatch.setattr(specialise, "MODE", "1")
-    sde = StochasticLorenz(a=(9., 27., 2.5))                  # (other constants: another unit than the tests above)
+    sde = StochasticLorenz(drift_constants=(9., 27., 2.5))     # (other constants: another unit than the tests above)
     first, launches = _launches(lambda: _solve(sde, 3, 1, "euler"))
     assert launches == 0
     deadline = time.time() + 120
