@@ -958,7 +958,8 @@ def _wrapper_chain(sde):
     drift / diffusion code, so they must not share a captured graph."""
     chain = []
     while hasattr(sde, "_base_sde"):
-        renamed = tuple(sorted((k, getattr(v, "__name__", repr(v))) for k, v in vars(sde).items()
+        # (`getattr(v, "__name__", repr(v))` would evaluate the repr -- of a bound method: the whole module's -- at every solve)
+        renamed = tuple(sorted((k, v.__name__ if hasattr(v, "__name__") else repr(v)) for k, v in vars(sde).items()
                                if k in ("f", "g", "h", "g_prod", "f_and_g", "f_and_g_prod") and callable(v)))
         chain.append((type(sde).__name__, renamed))
         sde = sde._base_sde
