@@ -588,6 +588,30 @@ def test_bench_headline_is_the_last_line_and_fits_the_drivers_window(capsys, tmp
     assert sum(len(t) + 1 for t in out[-3:]) < 9000      # even a window of ~9 KB holds the headline whole
 
 
+def test_lds_footprints_of_the_network_kernels():
+    """What the host asks before it routes a module to a network kernel (host arithmetic of the C ABI: no GPU involved).
+    General noise up to 32 state channels: the diffusion's last layer is laid out for the padded width (a compile-time row
+    stride, csrc/mlp_general.hip PairLayout), so the footprint does not depend on d within a tile size; the BASELINE configs[2]
+    shape fits the 160 KiB of a CU in both kernels (with 0.75 KiB to spare); above 32 channels it follows d."""
+    from torchsde_amd import _native
+    lib = _native.load()
+    general, diagonal = 2, 0
+    limit = 160 * 1024
+
+    def euler(d, m, h, out):
+        return lib.tsde_trajectory_mlp_general_lds(d, m, h, h, out, general)
+
+    def rheun(d, m, h, out, mids=0):
+        return lib.tsde_rheun_mlp_lds(d, m, h, h, out, general, mids, mids)
+    assert 0 < euler(32, 16, 64, 512) <= limit and 0 < rheun(32, 16, 64, 512) <= limit
+    assert euler(32, 16, 64, 512) == 4 * (2 * 32 * 68 + 64 * 36 + 64 * (512 + 8) + 4 * 64 + 32 + 512 + 32)
+    assert euler(20, 16, 64, 320) == euler(32, 16, 64, 512) and rheun(17, 12, 40, 17 * 12) == rheun(32, 16, 64, 512)
+    assert euler(36, 8, 40, 36 * 8) < euler(63, 7, 40, 63 * 7)                  # 64-channel tile: the real width counts
+    assert rheun(32, 16, 64, 512, mids=1) > limit                              # (a hidden-to-hidden layer per net no longer fits)
+    assert euler(65, 4, 16, 260) == 0 and rheun(16, 17, 16, 16 * 17) == 0      # no kernel for these shapes
+    assert lib.tsde_trajectory_mlp_general_lds(64, 64, 128, 128, 64, diagonal) > 0
+
+
 def test_bench_offline_counters_follow_the_sources_of_the_kernels_they_measured(tmp_path, monkeypatch):
     """profiles/traffic_latest.json is a measurement of the stepwise kernels: editing ANOTHER kernel's source (the digest over
     all sources changes) must not drop it from the bench line, editing steps.hip must; the side measurements are a list
