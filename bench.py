@@ -177,8 +177,8 @@ def _cpu_baseline(cfg, budget_s=20.0):
     """The reference's CPU path on this host's cores, on a bounded number of solver steps of the same workload: the real
     package when the host has it (`kind: "reference"`: torchsde.sdeint under no_grad, BrownianInterval built for the full
     horizon with the dt hint, ts shortened to the sample), else the oracle's restatement of it (`kind:
-    "port"`: tree-based BrownianInterval + solver loop, same torch CPU ops; the two run at the same speed and give the
-    same bits at equal thread counts, profiles/r2_cpu_port_vs_reference.txt)."""
+    "port"`: tree-based BrownianInterval + solver loop, same torch CPU ops; same bits as the reference at equal thread
+    counts and 1.2-1.4x slower than it at 4-8 threads, where both could be run: profiles/r6_cpu_port_vs_reference.txt)."""
     ncpu = os.cpu_count() or 1
     base = {"value": None, "unit": "trajectory-steps/s", "cores": None, "host_cpus": ncpu, "kind": "port"}
     if cfg.get("adjoint") or cfg.get("train"):
@@ -204,7 +204,8 @@ def _cpu_baseline(cfg, budget_s=20.0):
             from oracle import brownian_ref, solvers_ref
         except Exception as e:  # oracle piece missing: report, don't fake
             return dict(base, sample=f"unavailable: {e}")
-        kind, what = "port", "oracle port of the reference CPU algorithm (A/B vs the reference: profiles/r2_cpu_port_vs_reference.txt)"
+        kind, what = "port", ("oracle port of the reference CPU algorithm (A/B vs the reference where it exists: bit-identical, 1.2-1.4x "
+                      "slower, profiles/r6_cpu_port_vs_reference.txt)")
         step = solvers_ref.STEPS[cfg["method"]]
 
         def run(threads, n):
