@@ -1,4 +1,6 @@
 """The column interpreter of torchsde_amd/recognise_rows.py and the code it generates (CPU: no kernel is launched)."""
+import os
+
 import pytest
 import torch
 from torch import nn
@@ -130,3 +132,18 @@ def test_side_effects_end_the_column_interpretation_too():
         recognise_rows.recognise_rows(ForwardSDE(Counts()), torch.tensor(0.0), torch.randn(6, 3))
     with pytest.raises(NotElementwise, match="random"):
         recognise_rows.recognise_rows(ForwardSDE(Noisy()), torch.tensor(0.0), torch.randn(6, 3))
+
+
+def test_compiled_programs_find_a_writable_directory(monkeypatch, tmp_path):
+    """``~/.cache`` may not be writable (a container's read-only user): the units then go under the temporary directory, and a
+    compilation that cannot happen at all is a recorded failure -- the interpreter / stepwise route stays -- not an exception out
+    of a solve."""
+    import tempfile
+    monkeypatch.setenv("TSDE_SPECIALISE_CACHE", "/proc/no_such_place/specialised")
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    where = specialise.cache_dir()
+    assert where.startswith(str(tmp_path)) and os.access(where, os.W_OK)
+    monkeypatch.setattr(specialise, "cache_dir", lambda: (_ for _ in ()).throw(OSError("nowhere to write")))
+    specialise._compile("0" * 24, "// nothing", "gfx950")
+    assert str(specialise._state["0" * 24]).startswith("failed: OSError")
+    specialise._state.pop("0" * 24, None)

@@ -391,9 +391,18 @@ class _Library:
 
 
 def cache_dir():
-    root = os.environ.get("TSDE_SPECIALISE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "torchsde_amd", "specialised")
-    os.makedirs(root, exist_ok=True)
-    return root
+    """Where the compiled units live: ``TSDE_SPECIALISE_CACHE``, else under ``~/.cache``; a home that cannot be written to
+    (a container's read-only user) falls back to the system's temporary directory."""
+    import tempfile
+    wanted = os.environ.get("TSDE_SPECIALISE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "torchsde_amd", "specialised")
+    for root in (wanted, os.path.join(tempfile.gettempdir(), f"torchsde_amd_specialised_{os.getuid()}")):
+        try:
+            os.makedirs(root, exist_ok=True)
+            if os.access(root, os.W_OK):
+                return root
+        except OSError:
+            continue
+    raise OSError(f"no writable directory for compiled programs (tried {wanted} and the temporary directory)")
 
 
 def compiler():
@@ -409,8 +418,8 @@ def _arch(device):
 
 
 def _compile(key, text, arch):
-    path = os.path.join(cache_dir(), f"{key}.so")
     try:
+        path = os.path.join(cache_dir(), f"{key}.so")
         if not os.path.exists(path):
             src = os.path.join(cache_dir(), f"{key}.hip")
             with open(src, "w") as fh:
