@@ -33,6 +33,9 @@ for STAGE in "$@"; do
       tools/profile_kernel_pmc.sh $TAG c3_euler_general_default_route_b16384_d32_m16 neural_trajectory_kernel > $OUT/pmc_c3_neural_kernel.txt 2>&1
       tools/profile_kernel_pmc.sh $TAG c3_rheun_general_default_route_b16384_d32_m16 "neural_rheun_kernel<32, 64, 16, false>" > $OUT/pmc_c3_rheun_forward_kernel.txt 2>&1
       tools/profile_kernel_pmc.sh $TAG c3_rheun_adjoint_general_default_route_b16384_d32_m16 "neural_rheun_kernel<32, 64, 16, true>" > $OUT/pmc_c3_rheun_backward_kernel.txt 2>&1
+      tools/profile_kernel_pmc.sh $TAG c3_rheun_adjoint_general_default_route_b16384_d32_m16 "rheun_last_layer_kernel" > $OUT/pmc_c3_rheun_last_layer_kernel.txt 2>&1
+      tools/profile_kernel_pmc.sh $TAG neuraladditive_srk_default_route_b65536_d64_m8 "neural_trajectory_kernel<64, 64, 2" > $OUT/pmc_neuraladditive_srk_kernel.txt 2>&1
+      tools/profile_kernel_pmc.sh $TAG c2_srk_netdiag_default_route_b65536_d64_s1000 "neural_trajectory_kernel<64, 64, 0" > $OUT/pmc_netdiag_srk_kernel.txt 2>&1
       rm -rf gpurun_out/pmc_${TAG}_*/trace gpurun_out/pmc_${TAG}_*/pmc1 gpurun_out/pmc_${TAG}_*/pmc2 ;;
     workloads)  # kernel statistics of the new routes' workloads
       : > $OUT/rheun_and_rows_rocprofv3.txt
